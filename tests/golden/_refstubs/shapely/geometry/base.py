@@ -1,0 +1,224 @@
+"""Geometry containers + exact-rational predicates for convex rings."""
+import math
+from fractions import Fraction
+
+import numpy as np
+
+
+def _F(v):
+    return Fraction(float(v))
+
+
+class _Coords(list):
+    @property
+    def xy(self):
+        return ([c[0] for c in self], [c[1] for c in self])
+
+
+class BaseGeometry:
+    is_valid = True
+    is_empty = False
+
+    def buffer(self, *a, **k):
+        return self
+
+    def simplify(self, *a, **k):
+        return self
+
+    def __ne__(self, other):
+        return not self.__eq__(other)
+
+
+class LineString(BaseGeometry):
+    def __init__(self, coords=()):
+        if isinstance(coords, LineString):
+            coords = coords.coords
+        self.coords = _Coords(
+            tuple(float(v) for v in np.asarray(c).ravel()[:2]) for c in coords
+        )
+
+    @property
+    def xy(self):
+        return self.coords.xy
+
+    @property
+    def length(self):
+        c = np.array(self.coords)
+        return float(np.linalg.norm(np.diff(c, axis=0), axis=1).sum()) if len(c) > 1 else 0.0
+
+    def project(self, pt):
+        """Arclength of the nearest point of the polyline (analytic, fp64)."""
+        p = np.array([pt.x, pt.y])
+        c = np.array(self.coords)
+        best, best_s, acc = None, 0.0, 0.0
+        for a, b in zip(c[:-1], c[1:]):
+            d = b - a
+            L2 = float(d @ d)
+            u = 0.0 if L2 == 0 else min(1.0, max(0.0, float((p - a) @ d) / L2))
+            q = a + u * d
+            dist = float(np.hypot(*(p - q)))
+            if best is None or dist < best:
+                best, best_s = dist, acc + u * math.sqrt(L2)
+            acc += math.sqrt(L2)
+        return best_s
+
+    def __eq__(self, o):
+        return type(o) is type(self) and list(o.coords) == list(self.coords)
+
+    def __hash__(self):
+        return hash(tuple(self.coords))
+
+
+class LinearRing(LineString):
+    pass
+
+
+class Point(BaseGeometry):
+    def __init__(self, *xy):
+        if len(xy) == 1:
+            xy = tuple(np.asarray(xy[0]).ravel())
+        self.x, self.y = float(xy[0]), float(xy[1])
+
+    @property
+    def xy(self):
+        return ([self.x], [self.y])
+
+    @property
+    def coords(self):
+        return _Coords([(self.x, self.y)])
+
+    def buffer(self, r, quad_segs=16, **k):
+        """64-gon inscribed in the circle, vertices at k*pi/32 (GEOS default)."""
+        n = 4 * quad_segs
+        ang = [2.0 * math.pi * i / n for i in range(n)]
+        return Polygon([(self.x + r * math.cos(a), self.y - r * math.sin(a)) for a in ang])
+
+    def __eq__(self, o):
+        return type(o) is type(self) and (o.x, o.y) == (self.x, self.y)
+
+    def __hash__(self):
+        return hash((self.x, self.y))
+
+
+class Polygon(BaseGeometry):
+    def __init__(self, shell=None, holes=None):
+        if isinstance(shell, Polygon):
+            holes = shell.interiors if holes is None else holes
+            shell = shell.exterior.coords
+        if isinstance(shell, LineString):
+            shell = shell.coords
+        pts = [] if shell is None else [
+            tuple(float(v) for v in np.asarray(c).ravel()[:2]) for c in shell
+        ]
+        if pts and pts[0] != pts[-1]:
+            pts.append(pts[0])
+        self.exterior = LinearRing(pts)
+        self.interiors = [LinearRing(h) for h in (holes or [])]
+
+    # -- helpers -----------------------------------------------------------
+    def _ring(self):
+        return list(self.exterior.coords[:-1])
+
+    @property
+    def area(self):
+        c = self._ring()
+        if len(c) < 3:
+            return 0.0
+        s = 0.0
+        for (x0, y0), (x1, y1) in zip(c, c[1:] + c[:1]):
+            s += x0 * y1 - x1 * y0
+        return abs(s) / 2.0
+
+    @property
+    def bounds(self):
+        xs, ys = self.exterior.coords.xy
+        return (min(xs), min(ys), max(xs), max(ys))
+
+    @property
+    def centroid(self):
+        c = self._ring()
+        a = cx = cy = 0.0
+        for (x0, y0), (x1, y1) in zip(c, c[1:] + c[:1]):
+            w = x0 * y1 - x1 * y0
+            a += w
+            cx += (x0 + x1) * w
+            cy += (y0 + y1) * w
+        if a == 0:
+            return Point(np.mean([p[0] for p in c]), np.mean([p[1] for p in c]))
+        return Point(cx / (3 * a), cy / (3 * a))
+
+    def contains(self, other):
+        if isinstance(other, Point):
+            return bool(_contains_xy(self, [other.x], [other.y])[0])
+        raise NotImplementedError
+
+    def intersects(self, other):
+        return convex_intersects_exact(self._ring(), other._ring())
+
+    def __eq__(self, o):
+        return (
+            type(o) is type(self)
+            and list(o.exterior.coords) == list(self.exterior.coords)
+            and len(o.interiors) == len(self.interiors)
+        )
+
+    def __hash__(self):
+        return hash(tuple(self.exterior.coords))
+
+
+class MultiPolygon(BaseGeometry):
+    def __init__(self, polygons=None):
+        self.geoms = list(polygons) if polygons is not None else []
+
+    @property
+    def area(self):
+        return float(sum(g.area for g in self.geoms))
+
+    def contains(self, other):
+        return any(g.contains(other) for g in self.geoms)
+
+    def __eq__(self, o):
+        return type(o) is type(self) and o.geoms == self.geoms
+
+    def __hash__(self):
+        return hash(tuple(self.geoms))
+
+
+def _orient(ring):
+    s = Fraction(0)
+    for (x0, y0), (x1, y1) in zip(ring, ring[1:] + ring[:1]):
+        s += _F(x0) * _F(y1) - _F(x1) * _F(y0)
+    return 1 if s > 0 else (-1 if s < 0 else 0)
+
+
+def convex_intersects_exact(A, B):
+    """Closed-set intersection of two convex rings, exact rational SAT."""
+    for P, Q in ((A, B), (B, A)):
+        o = _orient(P)
+        if o == 0:
+            continue
+        Pf = [(_F(x), _F(y)) for x, y in P]
+        Qf = [(_F(x), _F(y)) for x, y in Q]
+        for (ax, ay), (bx, by) in zip(Pf, Pf[1:] + Pf[:1]):
+            ex, ey = bx - ax, by - ay
+            # Q strictly outside this edge's half-plane => separated
+            if all(o * (ex * (qy - ay) - ey * (qx - ax)) < 0 for qx, qy in Qf):
+                return False
+    return True
+
+
+def _contains_xy(poly, xs, ys):
+    """Strict interior test of points in a convex ring (exact rational)."""
+    ring = poly._ring()
+    o = _orient(ring)
+    Rf = [(_F(x), _F(y)) for x, y in ring]
+    out = []
+    for x, y in zip(xs, ys):
+        px, py = _F(x), _F(y)
+        inside = o != 0
+        for (ax, ay), (bx, by) in zip(Rf, Rf[1:] + Rf[:1]):
+            if o * ((bx - ax) * (py - ay) - (by - ay) * (px - ax)) <= 0:
+                inside = False
+                break
+        out.append(inside)
+    return np.array(out, dtype=bool)
