@@ -1,0 +1,209 @@
+"""ctypes front-end of the CPU oracle (TEST INFRASTRUCTURE, NOT PRODUCT CODE).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module.
+It takes plain numpy arrays (the numeric content of a scenario) and returns the oracle's
+restatement of what the reference's ScenarioGym.rollout() would produce.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "_build", "libsgym_oracle.so")
+
+KIND_NONE, KIND_REPLAY, KIND_AGENT_REPLAY, KIND_AGENT_PID, KIND_AGENT_VEHICLE = range(5)
+TERM_MAX_LENGTH, TERM_COLLISION, TERM_EGO_COLLISION = 1, 2, 4
+NCTRL = 12
+# controller.py:64-70, 157-161 defaults: max_steer, max_accel, max_speed(None), allow_reverse,
+# steer_Kp, steer_Kd, accel_Kp, accel_Kd, accel_Ki
+DEFAULT_CTRL = np.array(
+    [0.7, 5.0, np.nan, 0.0, 0.03054, 1.5709, 0.3753, 1.8970, 0.0204, 0, 0, 0], np.float64
+)
+
+
+def build(force=False):
+    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < os.path.getmtime(
+        os.path.join(HERE, "sgym_oracle.c")
+    ):
+        subprocess.check_call(["make", "-C", HERE, "-s"])
+    return LIB_PATH
+
+
+class _Scenario(C.Structure):
+    _fields_ = [
+        ("n_entities", C.c_int32),
+        ("ego", C.c_int32),
+        ("kind", C.c_void_p),
+        ("etype", C.c_void_p),
+        ("bbox", C.c_void_p),
+        ("knot_off", C.c_void_p),
+        ("knots", C.c_void_p),
+        ("ctrl", C.c_void_p),
+        ("t0", C.c_double),
+        ("length", C.c_double),
+    ]
+
+
+class _Config(C.Structure):
+    _fields_ = [("dt", C.c_double), ("persist", C.c_int32), ("terminal_mask", C.c_int32)]
+
+
+class _Event(C.Structure):
+    _fields_ = [("t", C.c_double), ("other", C.c_int32), ("type", C.c_int32)]
+
+
+class _Record(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("t", "poses", "vels", "dists", "coll", "extra")]
+
+
+class _Result(C.Structure):
+    _fields_ = [
+        ("final_t", C.c_double),
+        ("ego_avg_speed", C.c_double),
+        ("ego_max_speed", C.c_double),
+        ("ego_distance", C.c_double),
+        ("n_steps", C.c_int32),
+        ("done", C.c_int32),
+        ("n_events", C.c_int32),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(LIB_PATH)
+        _lib.sgo_rollout.restype = C.c_int
+        _lib.sgo_rollout.argtypes = [
+            C.POINTER(_Scenario), C.POINTER(_Config), C.c_int, C.c_int, C.c_void_p,
+            C.POINTER(_Record), C.POINTER(_Event), C.c_int, C.POINTER(_Result),
+        ]
+        _lib.sgo_position_at_t.restype = C.c_int
+        _lib.sgo_position_at_t.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        _lib.sgo_velocity_at_t.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_void_p]
+        _lib.sgo_corners.argtypes = [C.c_void_p] * 3
+        _lib.sgo_quads_intersect.restype = C.c_int
+        _lib.sgo_quads_intersect.argtypes = [C.c_void_p] * 2
+        _lib.sgo_sincos.argtypes = [C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        _lib.sgo_batch_eval.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def default_kinds(n, ego=0):
+    """agent.py:151-169 default: the ego replays through an agent, everyone else is batched."""
+    k = np.full(n, KIND_REPLAY, np.int32)
+    k[ego] = KIND_AGENT_REPLAY
+    return k
+
+
+def rollout(knot_off, knots, bbox, etype, kind, ego, t0, length, dt, persist=False,
+            terminal_mask=TERM_MAX_LENGTH, ctrl=None, actions=None, max_steps=None,
+            force_steps=False, record=True, event_cap=256):
+    """One scenario through the oracle.  Returns a dict shaped like make_golden.record_rollout."""
+    L = lib()
+    E = int(len(kind))
+    W = (E + 63) // 64
+    knot_off = np.ascontiguousarray(knot_off, np.int64)
+    knots = np.ascontiguousarray(knots, np.float64)
+    bbox = np.ascontiguousarray(bbox, np.float64)
+    etype = np.ascontiguousarray(etype, np.int32)
+    kind = np.ascontiguousarray(kind, np.int32)
+    ctrl = np.ascontiguousarray(np.tile(DEFAULT_CTRL, (E, 1)) if ctrl is None else ctrl, np.float64)
+    if max_steps is None:
+        max_steps = int(np.ceil((length - t0) / dt)) + 16
+    max_steps = max(int(max_steps), 1)
+    sc = _Scenario(E, int(ego), _p(kind), _p(etype), _p(bbox), _p(knot_off), _p(knots), _p(ctrl),
+                   float(t0), float(length))
+    cfg = _Config(float(dt), int(bool(persist)), int(terminal_mask))
+    S = max_steps + 1
+    out = {}
+    rec = None
+    if record:
+        out = dict(
+            t=np.full(S, np.nan), poses=np.full((S, E, 6), np.nan), vels=np.full((S, E, 6), np.nan),
+            dists=np.zeros((S, E)), coll=np.zeros((S, E, W), np.uint64), extra=np.zeros((S, E, 4)),
+        )
+        rec = _Record(*[_p(out[k]) for k in ("t", "poses", "vels", "dists", "coll", "extra")])
+    ev = (_Event * event_cap)()
+    res = _Result()
+    acts = None
+    if actions is not None:
+        acts = np.ascontiguousarray(actions, np.float64)
+        assert acts.shape[0] >= max_steps and acts.shape[1] == 2
+    rc = L.sgo_rollout(C.byref(sc), C.byref(cfg), max_steps, int(force_steps),
+                       _p(acts) if acts is not None else None,
+                       C.byref(rec) if rec is not None else None, ev, event_cap, C.byref(res))
+    if rc != 0:
+        raise RuntimeError(f"sgo_rollout failed: {rc}")
+    n = res.n_steps
+    for k in list(out):
+        out[k] = out[k][: n + 1]
+    out.update(
+        n_steps=n, is_done=bool(res.done), final_t=res.final_t,
+        metric_ego_avg_speed=res.ego_avg_speed, metric_ego_max_speed=res.ego_max_speed,
+        metric_ego_distance_travelled=res.ego_distance, n_events=res.n_events,
+        ev_t=np.array([ev[i].t for i in range(min(res.n_events, event_cap))]),
+        ev_other=np.array([ev[i].other for i in range(min(res.n_events, event_cap))], np.int64),
+        ev_type=np.array([ev[i].type for i in range(min(res.n_events, event_cap))], np.int64),
+    )
+    return out
+
+
+def coll_to_dense(coll, E):
+    """[S][E][W] u64 rows -> [S][E][E] uint8 adjacency."""
+    bits = np.unpackbits(coll.view(np.uint8), axis=-1, bitorder="little")
+    return bits.reshape(coll.shape[0], E, -1)[:, :, :E]
+
+
+def position_at_t(knots, t, ext_bck, ext_fwd, none_outside=False):
+    knots = np.ascontiguousarray(knots, np.float64)
+    out = np.empty(6)
+    ok = lib().sgo_position_at_t(_p(knots), len(knots), float(t), int(ext_bck), int(ext_fwd), int(none_outside), _p(out))
+    return out if ok else None
+
+
+def velocity_at_t(knots, t):
+    knots = np.ascontiguousarray(knots, np.float64)
+    out = np.empty(6)
+    lib().sgo_velocity_at_t(_p(knots), len(knots), float(t), _p(out))
+    return out
+
+
+def corners(pose, bbox):
+    pose = np.ascontiguousarray(pose, np.float64)
+    bbox = np.ascontiguousarray(bbox, np.float64)
+    out = np.empty((4, 2))
+    lib().sgo_corners(_p(pose), _p(bbox), _p(out))
+    return out
+
+
+def quads_intersect(a, b):
+    a = np.ascontiguousarray(a, np.float64)
+    b = np.ascontiguousarray(b, np.float64)
+    return bool(lib().sgo_quads_intersect(_p(a), _p(b)))
+
+
+def sincos(x):
+    s, c = C.c_double(), C.c_double()
+    lib().sgo_sincos(float(x), C.byref(s), C.byref(c))
+    return s.value, c.value
+
+
+def batch_eval(knot_off, knots, ts, persist=False):
+    knot_off = np.ascontiguousarray(knot_off, np.int64)
+    knots = np.ascontiguousarray(knots, np.float64)
+    ts = np.ascontiguousarray(ts, np.float64)
+    E = len(knot_off) - 1
+    out = np.empty((len(ts), E, 6))
+    pres = np.empty((len(ts), E), np.uint8)
+    lib().sgo_batch_eval(_p(knot_off), _p(knots), E, int(persist), _p(ts), len(ts), _p(out), _p(pres))
+    return out, pres.astype(bool)

@@ -1,0 +1,619 @@
+/*
+ * sgym_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE (see sgym_oracle.h).
+ *
+ * Plain scalar C restatement of the reference's per-step path.  Every function cites the
+ * reference file:line (relative to /root/reference) it follows.  Compiled with
+ * -ffp-contract=off: every fused multiply-add below is an explicit fma() that mirrors a place
+ * where the reference's numpy/OpenBLAS stack fuses (np.linalg.norm of a short vector).
+ */
+#include "sgym_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define MAXE 1024
+
+/* ------------------------------------------------------------------------------------------
+ * sin/cos.  numpy's np.cos/np.sin (entity/base.py:113, controller.py:126-127) are platform
+ * SIMD routines accurate to <1 ulp but not bit-reproducible across libms.  The oracle and the
+ * HIP kernels therefore both use this fixed plain-fp64 algorithm (two-step Cody-Waite
+ * reduction by pi/2 and the classic Sun fdlibm minimax kernels, restated), which is within
+ * 1 ulp of the reference and identical bit-for-bit wherever IEEE fp64 add/mul is.
+ * ---------------------------------------------------------------------------------------- */
+static const double INV_PIO2 = 6.36619772367581382433e-01;
+static const double PIO2_1 = 1.57079632673412561417e+00; /* first 33 bits of pi/2 */
+static const double PIO2_2 = 6.07710050630396597660e-11; /* next 33 bits */
+static const double PIO2_2T = 2.02226624879595063154e-21;
+static const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
+                    S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
+                    S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+static const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
+                    C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
+                    C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+
+void sgo_sincos(double x, double *s, double *c)
+{
+    if (!(fabs(x) < 1.0e5)) { /* huge / inf / nan headings: defer to libm */
+        *s = sin(x);
+        *c = cos(x);
+        return;
+    }
+    double fn = rint(x * INV_PIO2);
+    int n = (int)fn;
+    double t = x - fn * PIO2_1;
+    double w = fn * PIO2_2;
+    double r = t - w;
+    w = fn * PIO2_2T - ((t - r) - w);
+    double y0 = r - w;
+    double y1 = (r - y0) - w;
+
+    double z = y0 * y0;
+    double v = z * y0;
+    double rs = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
+    double ks = y0 - ((z * (0.5 * y1 - v * rs) - y1) - v * S1);
+
+    double rc = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
+    double ay = fabs(y0);
+    double kc;
+    if (ay < 0.3) {
+        kc = 1.0 - (0.5 * z - (z * rc - y0 * y1));
+    } else {
+        double qx;
+        if (ay > 0.78125) {
+            qx = 0.28125;
+        } else {
+            uint64_t b;
+            memcpy(&b, &ay, 8);
+            b = (b - ((uint64_t)0x00200000 << 32)) & 0xFFFFFFFF00000000ULL;
+            memcpy(&qx, &b, 8);
+        }
+        double hz = 0.5 * z - qx;
+        double a = 1.0 - qx;
+        kc = a - (hz - (z * rc - y0 * y1));
+    }
+    switch (n & 3) {
+    case 0: *s = ks; *c = kc; break;
+    case 1: *s = kc; *c = -ks; break;
+    case 2: *s = -ks; *c = -kc; break;
+    default: *s = -kc; *c = ks; break;
+    }
+}
+
+/* np.linalg.norm of a 2-/3-vector = sqrt(x.dot(x)); the OpenBLAS ddot tail loop on x86-64 is an
+ * FMA chain (probed against numpy 2.2.6 / OpenBLAS 0.3.29: 20000/20000 bitwise matches). */
+static double norm2(double a, double b) { return sqrt(fma(b, b, a * a)); }
+static double norm3(double a, double b, double c) { return sqrt(fma(c, c, fma(b, b, a * a))); }
+
+/* ------------------------------------------------------------------------------------------
+ * scipy.interpolate.interp1d(kind="linear")._call_linear
+ * (scipy/interpolate/_interpolate.py:457-481): idx = clip(searchsorted_left(x, xn), 1, n-1),
+ * slope = (y_hi - y_lo)/(x_hi - x_lo), y = slope*(xn - x_lo) + y_lo.
+ * y is [n][stride] row-major; m channels are evaluated.
+ * ---------------------------------------------------------------------------------------- */
+static int searchsorted_left(const double *x, int n, double v)
+{
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        if (x[mid] < v) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+static void call_linear(const double *x, const double *y, int n, int stride, int m, double xn,
+                        double *out)
+{
+    int idx = searchsorted_left(x, n, xn);
+    if (idx < 1) idx = 1;
+    if (idx > n - 1) idx = n - 1;
+    double x_lo = x[idx - 1], x_hi = x[idx];
+    const double *y_lo = y + (size_t)(idx - 1) * stride, *y_hi = y + (size_t)idx * stride;
+    for (int c = 0; c < m; ++c) {
+        double slope = (y_hi[c] - y_lo[c]) / (x_hi - x_lo);
+        out[c] = slope * (xn - x_lo) + y_lo[c];
+    }
+}
+
+/* Trajectory.position_at_t, scenario_gym/trajectory.py:142-205 (scalar-t branch :188-196).
+ * knots: [n][7].  none_outside <=> extrapolate=False.  Returns 0 for None. */
+int sgo_position_at_t(const double *knots, int n, double t, int ext_bck, int ext_fwd,
+                      int none_outside, double *out)
+{
+    double min_t = knots[0], max_t = knots[(size_t)(n - 1) * 7];
+    if (none_outside && (t < min_t || t > max_t)) return 0;
+    if (t < min_t && !ext_bck) { memcpy(out, knots + 1, 48); return 1; }
+    if (t > max_t && !ext_fwd) { memcpy(out, knots + (size_t)(n - 1) * 7 + 1, 48); return 1; }
+    if (n == 1) { /* trajectory.py:175-177: duplicate the knot at t + 1e-3 */
+        double x[2] = {knots[0], knots[0] + 1e-3};
+        double y[12];
+        memcpy(y, knots + 1, 48);
+        memcpy(y + 6, knots + 1, 48);
+        call_linear(x, y, 2, 6, 6, t, out);
+        return 1;
+    }
+    /* x = column 0 (stride 7): gather times */
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        if (knots[(size_t)mid * 7] < t) lo = mid + 1; else hi = mid;
+    }
+    int idx = lo < 1 ? 1 : (lo > n - 1 ? n - 1 : lo);
+    const double *a = knots + (size_t)(idx - 1) * 7, *b = knots + (size_t)idx * 7;
+    for (int c = 0; c < 6; ++c) {
+        double slope = (b[1 + c] - a[1 + c]) / (b[0] - a[0]);
+        out[c] = slope * (t - a[0]) + a[1 + c];
+    }
+    return 1;
+}
+
+/* Trajectory.velocity_at_t, scenario_gym/trajectory.py:243-273 (eps = 1e-4) */
+void sgo_velocity_at_t(const double *knots, int n, double t, double *out)
+{
+    const double eps = 1e-4;
+    double min_t = knots[0], max_t = knots[(size_t)(n - 1) * 7];
+    double a[6], b[6];
+    sgo_position_at_t(knots, n, t + eps / 2, 1, 1, 0, a);
+    sgo_position_at_t(knots, n, t - eps / 2, 1, 1, 0, b);
+    int inside = (min_t <= t) && (t <= max_t);
+    for (int c = 0; c < 6; ++c) out[c] = inside ? (a[c] - b[c]) / eps : 0.0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * BatchReplayEntity.add_entities, scenario_gym/entity/batch.py:55-128: union knot grid `ts`,
+ * stage-1 resample of every trajectory onto it (fill = first/last knot), stage-2 interp1d on ts.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    int n_ent;  /* batched entities */
+    int n_grid; /* len(ts) */
+    double *ts; /* [N] */
+    double *X;  /* [N][n_ent*6] */
+} batch_t;
+
+static int cmp_double(const void *a, const void *b)
+{
+    double x = *(const double *)a, y = *(const double *)b;
+    return (x > y) - (x < y);
+}
+
+static void batch_build(batch_t *B, const int64_t *knot_off, const double *knots, const int *ids,
+                        int n_ent)
+{
+    B->n_ent = n_ent;
+    B->n_grid = 0;
+    B->ts = NULL;
+    B->X = NULL;
+    if (n_ent == 0) return;
+    size_t cap = 0;
+    for (int i = 0; i < n_ent; ++i) {
+        int n = (int)(knot_off[ids[i] + 1] - knot_off[ids[i]]);
+        cap += n == 1 ? 2 : n;
+    }
+    double *all = (double *)malloc(cap * sizeof(double));
+    size_t k = 0;
+    for (int i = 0; i < n_ent; ++i) {
+        const double *d = knots + knot_off[ids[i]] * 7;
+        int n = (int)(knot_off[ids[i] + 1] - knot_off[ids[i]]);
+        for (int j = 0; j < n; ++j) all[k++] = d[(size_t)j * 7];
+        if (n == 1) all[k++] = d[0] + 1e-1; /* batch.py:85-88 */
+    }
+    qsort(all, k, sizeof(double), cmp_double);
+    size_t N = 0;
+    for (size_t i = 0; i < k; ++i)
+        if (i == 0 || all[i] != all[N - 1]) all[N++] = all[i];
+    B->n_grid = (int)N;
+    B->ts = all;
+    B->X = (double *)malloc(N * n_ent * 6 * sizeof(double));
+    for (int i = 0; i < n_ent; ++i) {
+        const double *d = knots + knot_off[ids[i]] * 7;
+        int n = (int)(knot_off[ids[i] + 1] - knot_off[ids[i]]);
+        double two[14];
+        if (n == 1) {
+            memcpy(two, d, 56);
+            memcpy(two + 7, d, 56);
+            two[7] += 1e-1;
+            d = two;
+            n = 2;
+        }
+        /* x = d[:,0], y = d[:,1:] -> copy to contiguous arrays for call_linear */
+        double *x = (double *)malloc(n * sizeof(double));
+        for (int j = 0; j < n; ++j) x[j] = d[(size_t)j * 7];
+        for (size_t g = 0; g < N; ++g) {
+            double *o = B->X + (g * n_ent + i) * 6;
+            double tq = all[g];
+            if (tq < x[0]) memcpy(o, d + 1, 48);                       /* fill below: d[0,1:] */
+            else if (tq > x[n - 1]) memcpy(o, d + (size_t)(n - 1) * 7 + 1, 48); /* above */
+            else call_linear(x, d + 1, n, 7, 6, tq, o);
+        }
+        free(x);
+    }
+}
+
+static void batch_free(batch_t *B)
+{
+    free(B->ts);
+    free(B->X);
+}
+
+/* self.fn(t), batch.py:122-128: interp1d(ts, X.T, fill=(X[0], X[-1])) */
+static void batch_eval(const batch_t *B, double t, double *out /*[n_ent][6]*/)
+{
+    int m = B->n_ent * 6;
+    if (t < B->ts[0]) memcpy(out, B->X, m * sizeof(double));
+    else if (t > B->ts[B->n_grid - 1])
+        memcpy(out, B->X + (size_t)(B->n_grid - 1) * m, m * sizeof(double));
+    else call_linear(B->ts, B->X, B->n_grid, m, m, t, out);
+}
+
+void sgo_batch_eval(const int64_t *knot_off, const double *knots, int n_ent, int persist,
+                    const double *ts, int n_t, double *out, uint8_t *present)
+{
+    int *ids = (int *)malloc(n_ent * sizeof(int));
+    for (int i = 0; i < n_ent; ++i) ids[i] = i;
+    batch_t B;
+    batch_build(&B, knot_off, knots, ids, n_ent);
+    for (int q = 0; q < n_t; ++q) {
+        batch_eval(&B, ts[q], out + (size_t)q * n_ent * 6);
+        for (int i = 0; i < n_ent; ++i) { /* BatchReplayEntity.step, batch.py:34-53 */
+            const double *d = knots + knot_off[i] * 7;
+            int n = (int)(knot_off[i + 1] - knot_off[i]);
+            present[(size_t)q * n_ent + i] =
+                persist || n == 1 || (ts[q] >= d[0] && ts[q] <= d[(size_t)(n - 1) * 7]);
+        }
+    }
+    batch_free(&B);
+    free(ids);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Entity.get_bounding_box_points, scenario_gym/entity/base.py:100-138: corners RR, FR, FL, RL.
+ * out[i] = xy + points[i] @ [[c, s], [-s, c]]
+ * ---------------------------------------------------------------------------------------- */
+void sgo_corners(const double *pose, const double *bbox, double *out)
+{
+    double W = bbox[0], L = bbox[1], cx = bbox[2], cy = bbox[3];
+    double s, c;
+    sgo_sincos(pose[3], &s, &c);
+    double px[4] = {cx - 0.5 * L, cx + 0.5 * L, cx + 0.5 * L, cx - 0.5 * L};
+    double py[4] = {cy + 0.5 * W, cy + 0.5 * W, cy - 0.5 * W, cy - 0.5 * W};
+    for (int i = 0; i < 4; ++i) {
+        out[2 * i] = pose[0] + (px[i] * c + py[i] * (-s));
+        out[2 * i + 1] = pose[1] + (px[i] * s + py[i] * c);
+    }
+}
+
+/* Closed-set intersection of two convex quads = shapely `intersects` predicate used by
+ * detect_geom_collisions (scenario_gym/utils.py:52-59).  Separating-axis test over the 8 edge
+ * lines: separated iff some edge has every vertex of the other quad strictly outside.
+ * Orientation-agnostic (sign of the quad's own doubled area picks the outer side). */
+static double cross2(double ex, double ey, double dx, double dy) { return ex * dy - ey * dx; }
+
+int sgo_quads_intersect(const double *A, const double *B)
+{
+    for (int pass = 0; pass < 2; ++pass) {
+        const double *P = pass ? B : A, *Q = pass ? A : B;
+        /* orientation from the diagonal cross product (doubled area) */
+        double o = cross2(P[4] - P[0], P[5] - P[1], P[6] - P[2], P[7] - P[3]);
+        for (int i = 0; i < 4; ++i) {
+            int j = (i + 1) & 3;
+            double ax = P[2 * i], ay = P[2 * i + 1];
+            double ex = P[2 * j] - ax, ey = P[2 * j + 1] - ay;
+            int all_out = 1;
+            for (int k = 0; k < 4 && all_out; ++k) {
+                double cr = cross2(ex, ey, Q[2 * k] - ax, Q[2 * k + 1] - ay);
+                /* outside = opposite side to the interior; interior has sign(o) */
+                if (o > 0 ? !(cr < 0) : !(cr > 0)) all_out = 0;
+            }
+            if (all_out) return 0;
+        }
+    }
+    return 1;
+}
+
+static int corners_equal(const double *a, const double *b)
+{
+    for (int i = 0; i < 8; ++i)
+        if (a[i] != b[i]) return 0;
+    return 1;
+}
+
+/* State.collisions -> detect_collisions -> detect_geom_collisions
+ * (scenario_gym/state/state.py:306-310, state/utils.py:10-49, utils.py:28-62).
+ * rows[i] bit j set <=> entity j is listed for entity i.  Geometry-equality quirks:
+ * equal geometries never list each other (utils.py:59) and a geometry maps back to the LAST
+ * entity that owns it (state/utils.py:32-40).  mult[i*E+j] = how often j is listed for i. */
+static void detect_collisions(int E, int W, const uint8_t *present, const double *poses,
+                              const double *bbox, uint64_t *rows, uint8_t *mult, double *scratch)
+{
+    double *cor = scratch;                 /* [E][8] */
+    double *aabb = scratch + (size_t)E * 8; /* [E][4] */
+    int *last = (int *)(scratch + (size_t)E * 12); /* [E] */
+    memset(rows, 0, (size_t)E * W * sizeof(uint64_t));
+    if (mult) memset(mult, 0, (size_t)E * E);
+    for (int i = 0; i < E; ++i) {
+        if (!present[i]) continue;
+        sgo_corners(poses + (size_t)i * 6, bbox + (size_t)i * 4, cor + (size_t)i * 8);
+        double *c = cor + (size_t)i * 8, *b = aabb + (size_t)i * 4;
+        b[0] = b[2] = c[0];
+        b[1] = b[3] = c[1];
+        for (int k = 1; k < 4; ++k) {
+            if (c[2 * k] < b[0]) b[0] = c[2 * k];
+            if (c[2 * k] > b[2]) b[2] = c[2 * k];
+            if (c[2 * k + 1] < b[1]) b[1] = c[2 * k + 1];
+            if (c[2 * k + 1] > b[3]) b[3] = c[2 * k + 1];
+        }
+    }
+    for (int i = 0; i < E; ++i) {
+        if (!present[i]) continue;
+        last[i] = i;
+        for (int j = i + 1; j < E; ++j)
+            if (present[j] && corners_equal(cor + (size_t)i * 8, cor + (size_t)j * 8)) last[i] = j;
+    }
+    for (int i = 0; i < E; ++i) {
+        if (!present[i]) continue;
+        for (int j = 0; j < E; ++j) {
+            if (j == i || !present[j]) continue;
+            const double *a = aabb + (size_t)i * 4, *b = aabb + (size_t)j * 4;
+            if (a[2] < b[0] || b[2] < a[0] || a[3] < b[1] || b[3] < a[1]) continue; /* STRtree envelope */
+            if (corners_equal(cor + (size_t)i * 8, cor + (size_t)j * 8)) continue;  /* g != g_prime */
+            if (!sgo_quads_intersect(cor + (size_t)i * 8, cor + (size_t)j * 8)) continue;
+            int o = last[j];
+            rows[(size_t)i * W + (o >> 6)] |= (uint64_t)1 << (o & 63);
+            if (mult) mult[(size_t)i * E + o]++;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * The rollout: ScenarioGym.reset_scenario/step/rollout (scenario_gym/scenario_gym.py:217-267),
+ * State.reset/step/update_poses/update_statistics (scenario_gym/state/state.py:106-239).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct { double speed, e_lon_prev, e_lat_prev, e_lon_int; } ctrl_state;
+
+/* VehicleController._step, scenario_gym/controller.py:105-140 */
+static void vehicle_step(ctrl_state *cs, const double *ctrl, double l, double dt, double accel,
+                         double steer, double *pose)
+{
+    double max_accel = ctrl[SGO_C_MAX_ACCEL], max_steer = ctrl[SGO_C_MAX_STEER];
+    accel = fmin(fmax(accel, -max_accel), max_accel); /* np.clip */
+    steer = fmin(fmax(steer, -max_steer), max_steer);
+    double h = pose[3], s, c, ss, sc;
+    sgo_sincos(h, &s, &c);
+    sgo_sincos(steer, &ss, &sc);
+    double dx = cs->speed * c;
+    double dy = cs->speed * s;
+    double dh = cs->speed * (ss / sc) / l;
+    pose[0] += dx * dt;
+    pose[1] += dy * dt;
+    pose[3] += dh * dt;
+    double speed = cs->speed + accel * dt;
+    if (ctrl[SGO_C_ALLOW_REVERSE] == 0.0) speed = fmax(0.0, speed);
+    if (!isnan(ctrl[SGO_C_MAX_SPEED])) speed = fmin(ctrl[SGO_C_MAX_SPEED], speed);
+    cs->speed = speed;
+}
+
+/* PIDController._step, scenario_gym/controller.py:205-258 */
+static void pid_step(ctrl_state *cs, const double *ctrl, double l, double state_dt, double dt,
+                     const double *target, double *pose)
+{
+    double h = pose[3], s, c;
+    sgo_sincos(h, &s, &c);
+    double e0 = target[0] - pose[0], e1 = target[1] - pose[1];
+    double e_lon = c * e0 + s * e1;
+    double e_lat = -s * e0 + c * e1;
+    double speed = cs->speed, gain;
+    if (speed > 5.0 && speed <= 15) gain = 1.0 - 0.9 * (speed - 5.0) / 10.0;
+    else if (speed > 15) gain = 0.1;
+    else gain = 1.0;
+    double e_lat_D = (e_lat - cs->e_lat_prev) / state_dt;
+    double kp = ctrl[SGO_C_STEER_KP] * gain, kd = ctrl[SGO_C_STEER_KD] * gain;
+    double steer = kp * e_lat + kd * e_lat_D;
+    double e_lon_D = (e_lon - cs->e_lon_prev) / state_dt;
+    double e_lon_I = cs->e_lon_int + e_lon * state_dt;
+    double accel = 0.0;
+    if (fabs(e_lon) > 0.1)
+        accel = ctrl[SGO_C_ACCEL_KP] * e_lon + ctrl[SGO_C_ACCEL_KD] * e_lon_D +
+                ctrl[SGO_C_ACCEL_KI] * e_lon_I;
+    cs->e_lat_prev = e_lat;
+    cs->e_lon_prev = e_lon;
+    cs->e_lon_int = e_lon_I;
+    vehicle_step(cs, ctrl, l, dt, accel, steer, pose);
+}
+
+int sgo_rollout(const sgo_scenario *sc, const sgo_config *cfg, int max_steps, int force_steps,
+                const double *actions, sgo_record *rec, sgo_event *events, int event_cap,
+                sgo_result *res)
+{
+    const int E = sc->n_entities, W = (E + 63) / 64;
+    if (E > MAXE) return -1;
+    const double NaN = nan("");
+    double *poses = (double *)calloc((size_t)E * 6, 8), *newp = (double *)calloc((size_t)E * 6, 8);
+    double *vels = (double *)calloc((size_t)E * 6, 8), *dists = (double *)calloc(E, 8);
+    uint8_t *present = (uint8_t *)calloc(E, 1), *newpres = (uint8_t *)calloc(E, 1);
+    uint8_t *velvalid = (uint8_t *)calloc(E, 1);
+    uint64_t *rows = (uint64_t *)calloc((size_t)E * W, 8);
+    uint8_t *mult = (uint8_t *)calloc((size_t)E * E, 1);
+    uint64_t *last_row = (uint64_t *)calloc(W, 8);
+    ctrl_state *cs = (ctrl_state *)calloc(E, sizeof(ctrl_state));
+    int *ids = (int *)malloc(E * sizeof(int)), *slot = (int *)malloc(E * sizeof(int));
+    double *bpos = (double *)malloc((size_t)E * 6 * 8);
+    double *scratch = (double *)malloc((size_t)E * 13 * 8);
+    int nb = 0;
+    for (int i = 0; i < E; ++i)
+        if (sc->kind[i] == SGO_KIND_REPLAY) { slot[i] = nb; ids[nb++] = i; }
+    batch_t B;
+    batch_build(&B, sc->knot_off, sc->knots, ids, nb); /* ScenarioGym.create_agents :188-211 */
+
+#define KN(i) (sc->knots + sc->knot_off[i] * 7)
+#define NK(i) ((int)(sc->knot_off[(i) + 1] - sc->knot_off[i]))
+
+    /* ---- State.reset(t0), state.py:106-143 ---- */
+    double t = sc->t0, prev_t, next_t;
+    for (int i = 0; i < E; ++i) {
+        present[i] = 0;
+        velvalid[i] = 0;
+        if (sc->kind[i] == SGO_KIND_NONE) continue;
+        int n = NK(i), is_static = n == 1, ok;
+        if (is_static) ok = sgo_position_at_t(KN(i), n, t, 1, 1, 0, poses + (size_t)i * 6);
+        else if (cfg->persist) ok = sgo_position_at_t(KN(i), n, t, 0, 0, 0, poses + (size_t)i * 6);
+        else ok = sgo_position_at_t(KN(i), n, t, 0, 0, 1, poses + (size_t)i * 6);
+        if (ok) {
+            present[i] = 1;
+            velvalid[i] = 1;
+            sgo_velocity_at_t(KN(i), n, t, vels + (size_t)i * 6);
+        }
+    }
+    prev_t = t - 0.1; /* state.py:135 */
+    for (int i = 0; i < E; ++i) { /* Controller.reset: controller.py:100-103, :198-203 */
+        cs[i].speed = present[i] ? norm2(vels[(size_t)i * 6], vels[(size_t)i * 6 + 1]) : 0.0;
+        cs[i].e_lon_prev = cs[i].e_lat_prev = cs[i].e_lon_int = 0.0;
+    }
+    /* Metric resets: metrics/trajectory.py:13-17,36-39; metrics/collision.py:64-68 */
+    const int ego = sc->ego;
+    double avg = NaN, vmax = NaN, m_t = 0.0, ego_dist = NaN;
+    if (present[ego]) {
+        const double *v = vels + (size_t)ego * 6;
+        avg = vmax = norm3(v[0], v[1], v[2]);
+    }
+    int n_events = 0, n_steps = 0, done = 0;
+    memset(last_row, 0, (size_t)W * 8);
+    detect_collisions(E, W, present, poses, sc->bbox, rows, mult, scratch);
+
+#define RECORD(row)                                                                             \
+    do {                                                                                        \
+        if (rec) {                                                                              \
+            size_t s_ = (size_t)(row);                                                          \
+            if (rec->t) rec->t[s_] = t;                                                         \
+            for (int i_ = 0; i_ < E; ++i_) {                                                    \
+                for (int c_ = 0; c_ < 6; ++c_) {                                                \
+                    if (rec->poses)                                                             \
+                        rec->poses[(s_ * E + i_) * 6 + c_] = present[i_] ? poses[(size_t)i_ * 6 + c_] : NaN; \
+                    if (rec->vels)                                                              \
+                        rec->vels[(s_ * E + i_) * 6 + c_] = velvalid[i_] ? vels[(size_t)i_ * 6 + c_] : NaN; \
+                }                                                                               \
+                if (rec->dists) rec->dists[s_ * E + i_] = dists[i_];                            \
+                if (rec->extra) memcpy(rec->extra + (s_ * E + i_) * 4, &cs[i_], 32);            \
+            }                                                                                   \
+            if (rec->coll) memcpy(rec->coll + s_ * E * W, rows, (size_t)E * W * 8);             \
+        }                                                                                       \
+    } while (0)
+
+    RECORD(0);
+
+    /* ---- rollout loop, scenario_gym.py:262-263 ---- */
+    while ((force_steps || !done) && n_steps < max_steps) {
+        next_t = t + cfg->dt; /* scenario_gym.py:229 */
+        double state_dt = t - prev_t;
+        if (nb) batch_eval(&B, next_t, bpos);
+        for (int i = 0; i < E; ++i) {
+            double *np_ = newp + (size_t)i * 6;
+            newpres[i] = 0;
+            int n = NK(i);
+            switch (sc->kind[i]) {
+            case SGO_KIND_REPLAY: /* BatchReplayEntity.step, batch.py:34-53 */
+                if (cfg->persist || n == 1 ||
+                    (next_t >= KN(i)[0] && next_t <= KN(i)[(size_t)(n - 1) * 7])) {
+                    memcpy(np_, bpos + (size_t)slot[i] * 6, 48);
+                    newpres[i] = 1;
+                }
+                break;
+            case SGO_KIND_AGENT_REPLAY:
+            case SGO_KIND_AGENT_PID:
+            case SGO_KIND_AGENT_VEHICLE:
+                if (present[i]) { /* scenario_gym.py:234-239 */
+                    if (sc->kind[i] == SGO_KIND_AGENT_REPLAY) {
+                        sgo_position_at_t(KN(i), n, next_t, 0, 0, 0, np_); /* agent.py:125-128 */
+                    } else {
+                        memcpy(np_, poses + (size_t)i * 6, 48);
+                        const double *ct = sc->ctrl + (size_t)i * SGO_NCTRL;
+                        double l = sc->bbox[(size_t)i * 4 + 1];
+                        if (sc->kind[i] == SGO_KIND_AGENT_PID) {
+                            double tgt[6];
+                            sgo_position_at_t(KN(i), n, next_t, 0, 0, 0, tgt); /* agent.py:145-148 */
+                            pid_step(&cs[i], ct, l, state_dt, next_t - t, tgt, np_);
+                        } else {
+                            const double *a = actions + (size_t)n_steps * 2;
+                            vehicle_step(&cs[i], ct, l, next_t - t, a[0], a[1], np_);
+                        }
+                    }
+                    newpres[i] = 1;
+                } else if (KN(i)[0] >= t) { /* scenario_gym.py:240-244: spawn */
+                    sgo_position_at_t(KN(i), n, next_t, 0, 0, 0, np_);
+                    newpres[i] = 1;
+                }
+                break;
+            default: break;
+            }
+        }
+        /* ---- State.step -> update_poses, state.py:165-228 ---- */
+        prev_t = t;
+        t = next_t;
+        double dt = t - prev_t;
+        for (int i = 0; i < E; ++i) {
+            velvalid[i] = 0;
+            if (!newpres[i]) continue;
+            double prev[6];
+            if (present[i]) memcpy(prev, poses + (size_t)i * 6, 48);
+            else sgo_position_at_t(KN(i), NK(i), prev_t, 1, 1, 0, prev); /* state.py:219-222 */
+            double d[6];
+            for (int c = 0; c < 6; ++c) { /* update_statistics, state.py:230-239 */
+                d[c] = newp[(size_t)i * 6 + c] - prev[c];
+                vels[(size_t)i * 6 + c] = d[c] / dt;
+            }
+            dists[i] += norm3(d[0], d[1], d[2]);
+            velvalid[i] = 1;
+        }
+        memcpy(poses, newp, (size_t)E * 48);
+        memcpy(present, newpres, E);
+        ++n_steps;
+        /* collisions are evaluated lazily in the reference; results are per-step pure */
+        detect_collisions(E, W, present, poses, sc->bbox, rows, mult, scratch);
+        /* check_terminal, state.py:268-270, 397-408 */
+        done = 0;
+        if ((cfg->terminal_mask & SGO_TERM_MAX_LENGTH) && (t + dt > sc->length)) done = 1;
+        if (cfg->terminal_mask & SGO_TERM_COLLISION)
+            for (int k = 0; k < E * W; ++k) if (rows[k]) done = 1;
+        if ((cfg->terminal_mask & SGO_TERM_EGO_COLLISION) && present[0])
+            for (int k = 0; k < W; ++k) if (rows[k]) done = 1;
+        /* metrics, scenario_gym.py:251-252 */
+        if (present[ego]) {
+            const double *v = vels + (size_t)ego * 6;
+            double speed = norm3(v[0], v[1], v[2]);
+            double w = m_t / t; /* EgoAvgSpeed._step, metrics/trajectory.py:19-24 */
+            avg += (1.0 - w) * (speed - avg);
+            m_t = t;
+            vmax = fmax(speed, vmax); /* np.maximum */
+            ego_dist = dists[ego];
+            /* CollisionMetric._step, metrics/collision.py:70-75 */
+            for (int j = 0; j < E; ++j) {
+                int hit = (rows[(size_t)ego * W + (j >> 6)] >> (j & 63)) & 1;
+                int was = (last_row[j >> 6] >> (j & 63)) & 1;
+                if (hit && !was)
+                    for (int r = 0; r < mult[(size_t)ego * E + j]; ++r) {
+                        if (events && n_events < event_cap) {
+                            events[n_events].t = t;
+                            events[n_events].other = j;
+                            events[n_events].type = sc->etype[j] == 0 ? -1 : 5;
+                        }
+                        ++n_events;
+                    }
+            }
+            memcpy(last_row, rows + (size_t)ego * W, (size_t)W * 8);
+        }
+        RECORD(n_steps);
+    }
+    if (res) {
+        res->final_t = t;
+        res->ego_avg_speed = avg;
+        res->ego_max_speed = vmax;
+        res->ego_distance = ego_dist;
+        res->n_steps = n_steps;
+        res->done = done;
+        res->n_events = n_events;
+    }
+    batch_free(&B);
+    free(poses); free(newp); free(vels); free(dists); free(present); free(newpres);
+    free(velvalid); free(rows); free(mult); free(last_row); free(cs); free(ids); free(slot);
+    free(bpos); free(scratch);
+    return 0;
+}

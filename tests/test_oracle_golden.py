@@ -1,0 +1,226 @@
+"""The CPU oracle against golden vectors captured from the real reference (CPU-only tests).
+
+Tolerances: replay poses / t / step counts / velocities / distances / metrics
+bit-identical; controller-integrated poses <= 1e-5 abs (measured: < 1e-10); collisions exact.
+"""
+import numpy as np
+import pytest
+
+from conftest import bits_equal, load_golden, scenario_arrays
+
+CTRL_TOL = 1e-9  # measured worst 7.5e-11; the contract is 1e-5
+
+
+# ---------------------------------------------------------------- T1/T2 trajectories
+def test_position_at_t_modes(oracle):
+    g = load_golden("trajectory")
+    for i in range(int(g["pos/n"])):
+        data, q = g[f"pos/{i}/data"], g[f"pos/{i}/q"]
+        for name, (eb, ef) in dict(true=(1, 1), ff=(0, 0), ft=(0, 1), tf=(1, 0)).items():
+            got = np.array([oracle.position_at_t(data, t, eb, ef) for t in q])
+            assert bits_equal(got, g[f"pos/{i}/{name}"]), (i, name)
+        none = g[f"pos/{i}/false_is_none"]
+        for t, m, ref in zip(q, none, g[f"pos/{i}/false"]):
+            got = oracle.position_at_t(data, t, 0, 0, none_outside=True)
+            assert (got is None) == bool(m)
+            if got is not None:
+                assert bits_equal(got, ref)
+        vel = np.array([oracle.velocity_at_t(data, t) for t in q])
+        assert bits_equal(vel, g[f"pos/{i}/vel"]), i
+
+
+def test_reference_known_answers_trajectory(oracle):
+    """Inputs/expected values of the reference's own tests/test_trajectory.py:166-269, 112-128."""
+    k = np.array([[0, 0, 0, 0, 0, 0, 0], [1, 1, 1, 0, 0, 0, 0], [2, 2, 2, 0, 0, 0, 0]], np.float64)
+    P = oracle.position_at_t
+    assert np.allclose(P(k, 0.5, 1, 1)[:2], [0.5, 0.5])
+    assert np.allclose(P(k, 1.5, 1, 1)[:2], [1.5, 1.5])
+    assert np.allclose(P(k, 2.5, 1, 1)[:2], [2.5, 2.5])
+    assert np.allclose(P(k, -1.0, 1, 1)[:2], [-1.0, -1.0])
+    assert P(k, -1.0, 0, 0, none_outside=True) is None
+    assert P(k, 3.0, 0, 0, none_outside=True) is None
+    assert np.allclose(P(k, -1.0, 0, 1)[:2], [0.0, 0.0])
+    assert np.allclose(P(k, 3.0, 1, 0)[:2], [2.0, 2.0])
+    assert np.allclose(P(k, 3.0, 1, 1)[:2], [3.0, 3.0])
+    one = np.array([[0.0, 1.0, 1.0, 0, 0, 0, 0]])
+    assert np.allclose(P(one, 10.0, 0, 0)[:2], [1.0, 1.0])  # test_single_cp
+    kv = np.array([[0, 0, 0, 0, 0, 0, 0], [1, 0, 1, 0, 0, 0, 0], [2, 0, 2, 0, 0, 0, 0]], np.float64)
+    V = oracle.velocity_at_t
+    assert np.allclose(V(kv, 0.5)[:2], [0, 1])
+    assert np.allclose(V(kv, 2.5)[:2], [0, 0])
+    assert np.allclose(V(kv, 0.0)[:2], [0, 1])
+    assert np.allclose(V(kv, 2.0)[:2], [0, 1])
+
+
+# ---------------------------------------------------------------- B1/B2 batch replay
+@pytest.mark.parametrize("key,persist", [("kat", False), ("rand0", False), ("rand1", True)])
+def test_batch_replay(oracle, key, persist):
+    g = load_golden("batch")
+    poses, present = oracle.batch_eval(g[key + "/knot_off"], g[key + "/knots"], g[key + "/q"], persist)
+    ref = g[key + "/poses"]
+    assert np.array_equal(present, ~np.isnan(ref[:, :, 0]))
+    poses[~present] = np.nan
+    assert bits_equal(poses, ref)
+
+
+def test_batch_known_answer(oracle):
+    """tests/test_entity.py:40-77: static at origin, mover at (1.5, 0) at t=1, absent at t=5."""
+    off = np.array([0, 1, 3])
+    knots = np.array([[0.0, 0, 0, 0, 0, 0, 0], [0.0, 1, 0, 0, 0, 0, 0], [2.0, 2, 0, 0, 0, 0, 0]])
+    poses, present = oracle.batch_eval(off, knots, [1.0, 5.0])
+    assert np.allclose(poses[0, 0, :2], 0) and np.allclose(poses[0, 1, :2], [1.5, 0.0])
+    assert present[1, 0] and not present[1, 1]
+
+
+# ---------------------------------------------------------------- full rollouts
+def _check_run(oracle, g, sc, p, exact, **kw):
+    E = len(sc["etype"])
+    o = oracle.rollout(**sc, **kw)
+    assert o["n_steps"] == int(g[p + "/n_steps"]), p
+    assert o["is_done"] == bool(g[p + "/is_done"])
+    assert bits_equal(o["t"], g[p + "/t"]), p
+    for k in ("poses", "vels", "dists"):
+        if exact:
+            assert bits_equal(o[k], g[p + "/" + k]), (p, k)
+        else:
+            assert np.array_equal(np.isnan(o[k]), np.isnan(g[p + "/" + k])), (p, k)
+            assert np.nanmax(np.abs(o[k] - g[p + "/" + k])) < CTRL_TOL, (p, k)
+    assert np.array_equal(oracle.coll_to_dense(o["coll"], E), g[p + "/coll"]), p
+    for k in ("metric_ego_avg_speed", "metric_ego_max_speed", "metric_ego_distance_travelled"):
+        if exact:
+            assert o[k] == float(g[p + "/" + k]), (p, k)
+        else:
+            assert abs(o[k] - float(g[p + "/" + k])) < CTRL_TOL, (p, k)
+    if p + "/ev_t" in g:
+        assert np.array_equal(o["ev_t"], g[p + "/ev_t"]), p
+        assert np.array_equal(o["ev_other"], g[p + "/ev_other"]), p
+        assert all((t == 5) == (n == "non_vehicle") for t, n in zip(o["ev_type"], g[p + "/ev_type"]))
+    return o
+
+
+def test_xosc_scenarios_replay_bit_identical(oracle):
+    g = load_golden("scenarios")
+    for name in g["names"]:
+        sc = scenario_arrays(g, f"{name}/scenario")
+        kind = oracle.default_kinds(len(sc["etype"]), sc["ego"])
+        for run, dt in (("dt30", 1 / 30), ("dt10", 0.1)):
+            _check_run(oracle, g, sc, f"{name}/{run}", True, kind=kind, dt=dt)
+
+
+def test_known_values_from_survey(oracle):
+    """a5e43fe4: t0 = 5.087952, 377 steps, final t = 17.65461866666671;
+    3fee6507 metrics inside the ranges asserted by tests/test_metrics.py:27-30."""
+    g = load_golden("scenarios")
+    sc = scenario_arrays(g, "a5e43fe4/scenario")
+    o = oracle.rollout(**sc, kind=oracle.default_kinds(len(sc["etype"]), sc["ego"]), dt=1 / 30)
+    assert sc["t0"] == 5.087952 and o["n_steps"] == 377 and o["final_t"] == 17.65461866666671
+    sc = scenario_arrays(g, "3fee6507/scenario")
+    o = oracle.rollout(**sc, kind=oracle.default_kinds(len(sc["etype"]), sc["ego"]), dt=1 / 30)
+    assert 4 <= o["metric_ego_avg_speed"] <= 5
+    assert 10 <= o["metric_ego_max_speed"] <= 12
+    assert 90 <= o["metric_ego_distance_travelled"] <= 110
+    assert o["n_events"] == 0
+
+
+def test_vanishing_and_persist(oracle):
+    """tests/test_scenario_gym.py:17-25, 68-97."""
+    g = load_golden("scenarios")
+    sc = scenario_arrays(g, "vanish/scenario")
+    kind = oracle.default_kinds(len(sc["etype"]), sc["ego"])
+    o = _check_run(oracle, g, sc, "vanish/nopersist", True, kind=kind, dt=0.1)
+    assert np.isnan(o["poses"][-1, 1, 0])  # entity 1 absent at the end
+    o = _check_run(oracle, g, sc, "vanish/persist", True, kind=kind, dt=0.1, persist=True)
+    assert not np.isnan(o["poses"]).any()  # everyone present at every step
+
+
+@pytest.mark.parametrize("i", range(4))
+def test_synthetic_scenes(oracle, i):
+    g = load_golden("synth")
+    sc = scenario_arrays(g, f"{i}/scenario")
+    E = len(sc["etype"])
+    for dtn, dt in (("dt30", 1 / 30), ("dt10", 0.1)):
+        kind = oracle.default_kinds(E, sc["ego"])
+        _check_run(oracle, g, sc, f"{i}/replay_{dtn}_nopersist", True, kind=kind, dt=dt)
+        _check_run(oracle, g, sc, f"{i}/replay_{dtn}_persist", True, kind=kind, dt=dt, persist=True)
+        _check_run(oracle, g, sc, f"{i}/term_collision_{dtn}", True, kind=kind, dt=dt,
+                   terminal_mask=oracle.TERM_MAX_LENGTH | oracle.TERM_COLLISION)
+        _check_run(oracle, g, sc, f"{i}/term_ego_collision_{dtn}", True, kind=kind, dt=dt,
+                   terminal_mask=oracle.TERM_MAX_LENGTH | oracle.TERM_EGO_COLLISION)
+        kind = kind.copy()
+        kind[sc["ego"]] = oracle.KIND_AGENT_PID
+        o = _check_run(oracle, g, sc, f"{i}/pid_{dtn}", False, kind=kind, dt=dt)
+        assert np.abs(o["extra"][:, sc["ego"]] - g[f"{i}/pid_{dtn}/extra"]).max() < CTRL_TOL
+        kind[sc["ego"]] = oracle.KIND_AGENT_VEHICLE
+        p = f"{i}/ext_{dtn}"
+        o = _check_run(oracle, g, sc, p, False, kind=kind, dt=dt, actions=g[p + "/actions"],
+                       max_steps=int(g[p + "/n_steps"]) + 3)
+        assert np.abs(o["extra"][:, sc["ego"], 0] - g[p + "/extra"][:, 0]).max() < CTRL_TOL
+
+
+def test_pid_agent_on_xosc(oracle):
+    """tests/test_controller.py:7-25 configuration; 225 steps, final ego from SURVEY 8c G-F."""
+    g = load_golden("pid_xosc")
+    sc = scenario_arrays(g, "scenario")
+    E = len(sc["etype"])
+    kind = oracle.default_kinds(E, sc["ego"])
+    kind[sc["ego"]] = oracle.KIND_AGENT_PID
+    ctrl = np.tile(oracle.DEFAULT_CTRL, (E, 1))
+    ctrl[:, 6], ctrl[:, 1], ctrl[:, 0] = g["params"]
+    o = _check_run(oracle, g, sc, "run", False, kind=kind, dt=0.1, ctrl=ctrl)
+    assert o["n_steps"] == 225
+    assert np.allclose(o["poses"][-1, sc["ego"], [0, 1, 3]], [310.19444195, 368.25547349, 1.69257669], atol=1e-7)
+
+
+# ---------------------------------------------------------------- G1/G2 geometry
+def test_head_on_collision_event(oracle):
+    """tests/test_utils.py:12-61 scene: no collision at start, collision at the end; at dt=0.1 the
+    first (only) ego event is at t = 8.799999999999985 with entity_1, non_vehicle."""
+    g = load_golden("collision")
+    sc = scenario_arrays(g, "headon/scenario")
+    o = _check_run(oracle, g, sc, "headon/run", True, kind=oracle.default_kinds(2, 0), dt=0.1)
+    dense = oracle.coll_to_dense(o["coll"], 2)
+    assert not dense[0].any() and dense[-1, 0, 1] and dense[-1, 1, 0]
+    assert o["ev_t"].tolist() == [8.799999999999985] and o["ev_other"].tolist() == [1]
+    assert o["ev_type"].tolist() == [5]
+
+
+def test_corners_match_reference(oracle):
+    g = load_golden("collision")
+    got = np.array([oracle.corners(p, b) for p, b in zip(g["corners/poses"], g["corners/boxes"])])
+    # np.cos/np.sin differ from the oracle's sincos in the last ulp -> 1e-12 abs at |xy| <= 200
+    assert np.abs(got - g["corners/points"]).max() < 1e-12
+
+
+def test_sincos_accuracy(oracle):
+    """< 1 ulp against 60-digit mpmath, including arguments next to multiples of pi/2."""
+    import mpmath as mp
+
+    mp.mp.dps = 60
+    rng = np.random.default_rng(1)
+    xs = np.concatenate([
+        rng.uniform(-8, 8, 400), rng.uniform(-3e4, 3e4, 400), rng.normal(0, 1e-3, 50),
+        np.arange(-40, 41) * (np.pi / 2), np.nextafter(np.arange(1, 30) * (np.pi / 2), 0), [0.0, 0.3, 0.78125],
+    ])
+    worst = 0.0
+    for x in xs:
+        s, c = oracle.sincos(x)
+        for got, ref in ((s, mp.sin(mp.mpf(float(x)))), (c, mp.cos(mp.mpf(float(x))))):
+            ulp = np.spacing(abs(float(ref))) if float(ref) != 0 else 5e-324
+            worst = max(worst, abs(float((mp.mpf(got) - ref) / ulp)))
+    assert worst < 1.0, worst
+    assert oracle.sincos(0.0) == (0.0, 1.0)
+
+
+def test_pair_intersections_exact(oracle):
+    """10^4 OBB pairs: (a) the fp64 SAT on the REFERENCE's corners equals the exact-rational label
+    for every pair; (b) so does the SAT on the oracle's own corners (sincos differs by <= 1 ulp)."""
+    g = load_golden("collision")
+    lab = g["pairs/intersects"].astype(bool)
+    got = np.array([oracle.quads_intersect(a, b) for a, b in zip(g["pairs/corners_a"], g["pairs/corners_b"])])
+    assert np.array_equal(got, lab)
+    own = np.array([
+        oracle.quads_intersect(oracle.corners(pa, ba), oracle.corners(pb, bb))
+        for pa, ba, pb, bb in zip(g["pairs/pose_a"], g["pairs/box_a"], g["pairs/pose_b"], g["pairs/box_b"])
+    ])
+    assert np.array_equal(own, lab)
+    assert 0.2 < lab.mean() < 0.5
