@@ -1,0 +1,178 @@
+/*
+ * sgym.h -- C ABI of libsgym_hip.so: the MI355X (gfx950) batched scenario-rollout engine.
+ *
+ * The reference (driskai/scenario_gym v0.3.1) is pure Python and has no FFI; its extension surface
+ * for the per-step hot path is Python subclassing.  This header is the device boundary the build
+ * introduces at the ScenarioGym <-> (agents + State + metrics) seam; every entry point names the
+ * reference interface it stands in for (paths relative to the reference checkout).
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; every function returns 0 (SG_OK) or a negative sg_status.
+ *   - the caller owns every host buffer it passes; the library owns all device memory and one HIP
+ *     stream per handle.  Device pointers returned by sg_state_view stay valid until sg_upload /
+ *     sg_destroy on that handle.
+ *   - a handle is bound to one device and is not thread-safe; different handles may be driven
+ *     from different host threads.  Calls are synchronous on return unless documented otherwise.
+ *   - R = scenarios (replicas) on this handle, E = entity slots per scenario (ragged scenarios
+ *     pad with SG_KIND_NONE), poses are fp64 [x, y, z, h, p, r] exactly as in the reference.
+ */
+#ifndef SGYM_H
+#define SGYM_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SG_ABI_VERSION 1
+
+typedef enum {
+    SG_OK = 0,
+    SG_ERR_INVALID = -1,   /* bad argument */
+    SG_ERR_HIP = -2,       /* HIP runtime error, see sg_last_error */
+    SG_ERR_STATE = -3,     /* call order (e.g. step before upload) */
+    SG_ERR_NO_DEVICE = -4, /* no gfx950 device visible */
+    SG_ERR_CAPACITY = -5,  /* record / event capacity exceeded */
+} sg_status;
+
+/* how an entity slot gets its next pose (ScenarioGym.create_agents, scenario_gym/scenario_gym.py:188-211) */
+typedef enum {
+    SG_KIND_NONE = 0,          /* padding, never present */
+    SG_KIND_REPLAY = 1,        /* non-agent: BatchReplayEntity, scenario_gym/entity/batch.py:34-128 */
+    SG_KIND_AGENT_REPLAY = 2,  /* ReplayTrajectoryAgent + ReplayTrajectoryController, agent.py:118-128, controller.py:45-54 */
+    SG_KIND_AGENT_PID = 3,     /* PIDAgent + PIDController, agent.py:131-148, controller.py:143-258 */
+    SG_KIND_AGENT_VEHICLE = 4, /* external (accel, steer) -> VehicleController, controller.py:57-140; integrations/openaigym.py:197-204 */
+} sg_kind;
+
+/* TERMINAL_CONDITIONS, scenario_gym/state/state.py:397-408 */
+#define SG_TERM_MAX_LENGTH 1u
+#define SG_TERM_COLLISION 2u
+#define SG_TERM_EGO_COLLISION 4u
+
+/* controller parameter slots (VehicleController.__init__ controller.py:64-98, PIDController.__init__ :154-196) */
+enum {
+    SG_C_MAX_STEER = 0,
+    SG_C_MAX_ACCEL = 1,
+    SG_C_MAX_SPEED = 2, /* NaN = None */
+    SG_C_ALLOW_REVERSE = 3,
+    SG_C_STEER_KP = 4,
+    SG_C_STEER_KD = 5,
+    SG_C_ACCEL_KP = 6,
+    SG_C_ACCEL_KD = 7,
+    SG_C_ACCEL_KI = 8,
+    SG_NCTRL = 12
+};
+
+/* ScenarioGym.__init__(timestep, persist, terminal_conditions), scenario_gym/scenario_gym.py:29-95 */
+typedef struct {
+    int32_t device;          /* HIP device ordinal */
+    int32_t n_scenarios;     /* R */
+    int32_t n_entities;      /* E, entity slots per scenario (<= 64 in this ABI version) */
+    int32_t persist;         /* ScenarioGym(persist=...) */
+    uint32_t terminal_mask;  /* SG_TERM_* */
+    int32_t record_capacity; /* rows of State._recorded_poses kept on device (0 = off), state.py:227-228 */
+    int32_t event_capacity;  /* CollisionMetric events kept per scenario (metrics/collision.py:70-75) */
+    int32_t reserved;
+    double timestep;         /* ScenarioGym(timestep=...) */
+} sg_config;
+
+/* Numeric content of R scenarios: what State/Entity/Trajectory objects hold after load.
+ * All pointers are HOST pointers, entity index i = scenario*E + slot. */
+typedef struct {
+    const int32_t *kind;     /* [R*E] sg_kind */
+    const int32_t *etype;    /* [R*E] catalog type: 0 Vehicle, 1 Pedestrian, 2 other (metrics/collision.py:85) */
+    const double *bbox;      /* [R*E][4] BoundingBox width, length, center_x, center_y (catalog_entry.py:83-91) */
+    const int64_t *knot_off; /* [R*E+1] row offsets into knots (empty range for SG_KIND_NONE) */
+    const double *knots;     /* [rows][7] Trajectory.data rows t,x,y,z,h,p,r (trajectory.py:91) */
+    const double *ctrl;      /* [R*E][SG_NCTRL] or NULL for the reference defaults */
+    const int32_t *ego;      /* [R] slot of Scenario.ego (scenario/scenario.py:53-65) */
+    const double *t0;        /* [R] ScenarioGym.get_start_time (scenario_gym.py:213-215) */
+    const double *length;    /* [R] Scenario.length (scenario/scenario.py:88-91) */
+} sg_scenarios;
+
+/* Device-resident state after the latest step: the arrays behind State.poses / velocities /
+ * distances / collisions() (state.py:90-96, 306-310).  Entity-major SoA, index r*EP + slot with
+ * EP = entity_stride.  Raw device pointers (wrap with torch/dlpack for zero-copy views). */
+typedef struct {
+    int32_t n_scenarios, n_entities, entity_stride, row_words;
+    double *pose[6];    /* [R*EP] each */
+    double *vel[6];     /* [R*EP] each */
+    double *dist;       /* [R*EP] State.distances */
+    uint64_t *coll;     /* [R*EP][row_words] adjacency rows of State.collisions() */
+    uint8_t *present;   /* [R*EP] entity in State.poses */
+    double *ctrl_state; /* [4][R*EP] speed, e_lon_prev, e_lat_prev, e_lon_int */
+    double *t;          /* [R] State.t */
+    double *prev_t;     /* [R] State.prev_t */
+    int32_t *done;      /* [R] State.is_done */
+    int32_t *n_steps;   /* [R] steps taken since reset */
+} sg_state_view;
+
+/* per-scenario metric row: EgoAvgSpeed/EgoMaxSpeed/EgoDistanceTravelled (metrics/trajectory.py:8-66),
+ * CollisionMetric count (metrics/collision.py:46-79), plus bookkeeping */
+typedef struct {
+    double ego_avg_speed, ego_max_speed, ego_distance_travelled;
+    double final_t;
+    int32_t n_steps, done, n_collisions, reserved;
+} sg_metrics;
+
+/* one CollisionMetric entry (t, other entity, type): metrics/collision.py:81-86 */
+typedef struct {
+    double t;
+    int32_t scenario, other;
+    int32_t type; /* 5 = CollisionTypes.non_vehicle; -1 = Vehicle hazard, classification not done on device */
+    int32_t reserved;
+} sg_event;
+
+typedef struct sg_handle sg_handle;
+
+int sg_version(void);
+const char *sg_last_error(const sg_handle *h); /* valid until the next call on h; h may be NULL for create errors */
+
+/* ScenarioGym(...) */
+int sg_create(const sg_config *cfg, sg_handle **out);
+int sg_destroy(sg_handle *h);
+
+/* ScenarioGym.set_scenario -> State(...) + create_agents (scenario_gym.py:157-211): copies the
+ * scenarios to HBM, builds the BatchReplayEntity union knot grids + stage-1 resample on device
+ * (entity/batch.py:83-109), then resets (sg_reset). */
+int sg_upload(sg_handle *h, const sg_scenarios *sc);
+
+/* ScenarioGym.reset_scenario -> State.reset(t0), Controller.reset, Metric.reset (scenario_gym.py:217-225) */
+int sg_reset(sg_handle *h);
+
+/* gym.timestep = x between steps (tests/test_scenario_gym.py:37-39) */
+int sg_set_timestep(sg_handle *h, double timestep);
+
+/* n x ScenarioGym.step() on every scenario, done or not (scenario_gym.py:227-254).
+ * actions: HOST [n_steps][R][2] (accel, steer) for SG_KIND_AGENT_VEHICLE slots or NULL;
+ * actions_device != 0 means `actions` is a DEVICE pointer of the same shape. */
+int sg_step(sg_handle *h, int32_t n_steps, const double *actions, int32_t actions_device);
+
+/* ScenarioGym.rollout(): reset, then step each scenario while it is not done, at most max_steps
+ * (scenario_gym.py:256-267).  One kernel launch for the whole batch. */
+int sg_rollout(sg_handle *h, int32_t max_steps);
+/* Same without the reset and without waiting: enqueue on the handle's stream (bench timing) */
+int sg_rollout_async(sg_handle *h, int32_t max_steps, int32_t do_reset);
+int sg_synchronize(sg_handle *h);
+void *sg_stream(sg_handle *h); /* hipStream_t */
+
+int sg_state_view_get(sg_handle *h, sg_state_view *out);
+
+/* ScenarioGym.get_metrics (scenario_gym.py:308-319): out [R]; events [cap] (may be NULL) */
+int sg_read_metrics(sg_handle *h, sg_metrics *out, sg_event *events, int32_t cap, int32_t *n_events);
+
+/* State.recorded_poses (state.py:272-290): rows [0, n_rows) of the device record:
+ * t_out [n_rows][R], pose_out [n_rows][R*E][6] with NaN for absent entities. HOST buffers. */
+int sg_read_record(sg_handle *h, int32_t n_rows, double *t_out, double *pose_out);
+
+/* plain device->host copy of `bytes` from a pointer obtained through sg_state_view_get (after
+ * synchronising the handle's stream); lets a ctypes caller read state without any GPU array library */
+int sg_copy_to_host(sg_handle *h, const void *device_ptr, void *host_ptr, uint64_t bytes);
+
+/* time of the last sg_rollout / sg_step kernel in milliseconds (HIP events on the handle's stream) */
+int sg_last_kernel_ms(sg_handle *h, float *ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,103 @@
+"""ctypes binding of libsgym_hip.so (the C ABI of include/sgym.h).
+
+There is no CPU fallback: if the HIP library is missing or cannot be loaded this module raises.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libsgym_hip.so")
+
+SG_OK = 0
+ABI_VERSION = 1
+KIND_NONE, KIND_REPLAY, KIND_AGENT_REPLAY, KIND_AGENT_PID, KIND_AGENT_VEHICLE = range(5)
+TERM_MAX_LENGTH, TERM_COLLISION, TERM_EGO_COLLISION = 1, 2, 4
+NCTRL = 12
+(C_MAX_STEER, C_MAX_ACCEL, C_MAX_SPEED, C_ALLOW_REVERSE, C_STEER_KP, C_STEER_KD, C_ACCEL_KP,
+ C_ACCEL_KD, C_ACCEL_KI) = range(9)
+
+# every symbol include/sgym.h declares
+SYMBOLS = (
+    "sg_version", "sg_last_error", "sg_create", "sg_destroy", "sg_upload", "sg_reset",
+    "sg_set_timestep", "sg_step", "sg_rollout", "sg_rollout_async", "sg_synchronize", "sg_stream",
+    "sg_state_view_get", "sg_read_metrics", "sg_read_record", "sg_copy_to_host", "sg_last_kernel_ms",
+)
+
+
+class SgConfig(C.Structure):
+    _fields_ = [
+        ("device", C.c_int32), ("n_scenarios", C.c_int32), ("n_entities", C.c_int32),
+        ("persist", C.c_int32), ("terminal_mask", C.c_uint32), ("record_capacity", C.c_int32),
+        ("event_capacity", C.c_int32), ("reserved", C.c_int32), ("timestep", C.c_double),
+    ]
+
+
+class SgScenarios(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in
+                ("kind", "etype", "bbox", "knot_off", "knots", "ctrl", "ego", "t0", "length")]
+
+
+class SgStateView(C.Structure):
+    _fields_ = [
+        ("n_scenarios", C.c_int32), ("n_entities", C.c_int32), ("entity_stride", C.c_int32),
+        ("row_words", C.c_int32), ("pose", C.c_void_p * 6), ("vel", C.c_void_p * 6),
+        ("dist", C.c_void_p), ("coll", C.c_void_p), ("present", C.c_void_p),
+        ("ctrl_state", C.c_void_p), ("t", C.c_void_p), ("prev_t", C.c_void_p),
+        ("done", C.c_void_p), ("n_steps", C.c_void_p),
+    ]
+
+
+class SgMetrics(C.Structure):
+    _fields_ = [
+        ("ego_avg_speed", C.c_double), ("ego_max_speed", C.c_double),
+        ("ego_distance_travelled", C.c_double), ("final_t", C.c_double),
+        ("n_steps", C.c_int32), ("done", C.c_int32), ("n_collisions", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+class SgEvent(C.Structure):
+    _fields_ = [("t", C.c_double), ("scenario", C.c_int32), ("other", C.c_int32),
+                ("type", C.c_int32), ("reserved", C.c_int32)]
+
+
+_lib = None
+
+
+def load():
+    """Load libsgym_hip.so and declare its prototypes.  Raises if it is not there."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `make -C scenario_gym_amd/csrc` "
+            "(or __graft_entry__.build()).  scenario_gym_amd has no CPU fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+    H = C.c_void_p
+    lib.sg_version.restype = C.c_int
+    lib.sg_last_error.restype = C.c_char_p
+    lib.sg_last_error.argtypes = [H]
+    lib.sg_create.argtypes = [C.POINTER(SgConfig), C.POINTER(H)]
+    lib.sg_destroy.argtypes = [H]
+    lib.sg_upload.argtypes = [H, C.POINTER(SgScenarios)]
+    lib.sg_reset.argtypes = [H]
+    lib.sg_set_timestep.argtypes = [H, C.c_double]
+    lib.sg_step.argtypes = [H, C.c_int32, C.c_void_p, C.c_int32]
+    lib.sg_rollout.argtypes = [H, C.c_int32]
+    lib.sg_rollout_async.argtypes = [H, C.c_int32, C.c_int32]
+    lib.sg_synchronize.argtypes = [H]
+    lib.sg_stream.restype = C.c_void_p
+    lib.sg_stream.argtypes = [H]
+    lib.sg_state_view_get.argtypes = [H, C.POINTER(SgStateView)]
+    lib.sg_read_metrics.argtypes = [H, C.POINTER(SgMetrics), C.POINTER(SgEvent), C.c_int32, C.POINTER(C.c_int32)]
+    lib.sg_read_record.argtypes = [H, C.c_int32, C.c_void_p, C.c_void_p]
+    lib.sg_copy_to_host.argtypes = [H, C.c_void_p, C.c_void_p, C.c_uint64]
+    lib.sg_last_kernel_ms.argtypes = [H, C.POINTER(C.c_float)]
+    for name in SYMBOLS:
+        if name not in ("sg_last_error", "sg_stream", "sg_version"):
+            getattr(lib, name).restype = C.c_int
+    if lib.sg_version() != ABI_VERSION:
+        raise RuntimeError(f"libsgym_hip.so ABI {lib.sg_version()} != binding {ABI_VERSION}")
+    _lib = lib
+    return lib

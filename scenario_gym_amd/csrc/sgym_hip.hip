@@ -1,0 +1,484 @@
+// sgym_hip.hip -- host side of libsgym_hip.so: the C ABI declared in include/sgym.h.
+// Owns the device buffers and one HIP stream per handle; builds the BatchReplayEntity union knot
+// grids on the host (sort/unique per scenario, threaded) and everything else on the device.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "sgym_device.hpp"
+
+using sg::Params;
+
+struct sg_handle {
+    sg_config cfg{};
+    int R = 0, E = 0, EP = 0, G = 0;
+    size_t NE = 0; // padded entity count
+    bool uploaded = false;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    Params p{};
+    std::vector<void *> static_allocs, state_allocs;
+    int32_t *d_row_scen = nullptr;
+    int64_t total_rows = 0;
+    double *d_actions = nullptr;
+    size_t actions_cap = 0;
+    std::string err;
+};
+
+static thread_local std::string g_create_err;
+
+static int fail(sg_handle *h, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf; else g_create_err = buf;
+    return code;
+}
+
+#define HIP_TRY(h, expr)                                                                          \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return fail(h, SG_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),    \
+                        __FILE__, __LINE__);                                                      \
+    } while (0)
+
+template <typename T>
+static int dev_alloc(sg_handle *h, std::vector<void *> &pool, T **out, size_t n, bool zero = true)
+{
+    void *ptr = nullptr;
+    size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
+    HIP_TRY(h, hipMalloc(&ptr, bytes));
+    pool.push_back(ptr);
+    if (zero) HIP_TRY(h, hipMemsetAsync(ptr, 0, bytes, h->stream));
+    *out = (T *)ptr;
+    return SG_OK;
+}
+
+template <typename T>
+static int dev_upload(sg_handle *h, std::vector<void *> &pool, const T **out, const std::vector<T> &v)
+{
+    T *d = nullptr;
+    int rc = dev_alloc(h, pool, &d, v.size(), false);
+    if (rc) return rc;
+    if (!v.empty()) HIP_TRY(h, hipMemcpyAsync(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, h->stream));
+    *out = d;
+    return SG_OK;
+}
+
+static void free_pool(std::vector<void *> &pool)
+{
+    for (void *ptr : pool) (void)hipFree(ptr);
+    pool.clear();
+}
+
+extern "C" int sg_version(void) { return SG_ABI_VERSION; }
+
+extern "C" const char *sg_last_error(const sg_handle *h) { return h ? h->err.c_str() : g_create_err.c_str(); }
+
+extern "C" int sg_create(const sg_config *cfg, sg_handle **out)
+{
+    if (!cfg || !out) return fail(nullptr, SG_ERR_INVALID, "sg_create: null argument");
+    *out = nullptr;
+    if (cfg->n_scenarios <= 0 || cfg->n_entities <= 0)
+        return fail(nullptr, SG_ERR_INVALID, "sg_create: n_scenarios and n_entities must be positive");
+    if (cfg->n_entities > 64)
+        return fail(nullptr, SG_ERR_INVALID, "sg_create: n_entities=%d > 64 is not supported by ABI version %d",
+                    cfg->n_entities, SG_ABI_VERSION);
+    if (!(cfg->timestep > 0.0)) return fail(nullptr, SG_ERR_INVALID, "sg_create: timestep must be > 0");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, SG_ERR_NO_DEVICE, "sg_create: no HIP device visible");
+    if (cfg->device < 0 || cfg->device >= ndev)
+        return fail(nullptr, SG_ERR_INVALID, "sg_create: device %d out of range (%d devices)", cfg->device, ndev);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess)
+        return fail(nullptr, SG_ERR_HIP, "sg_create: hipGetDeviceProperties failed");
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, SG_ERR_NO_DEVICE, "sg_create: device %d is %s; this library is built for gfx950 only",
+                    cfg->device, prop.gcnArchName);
+    sg_handle *h = new sg_handle();
+    h->cfg = *cfg;
+    h->R = cfg->n_scenarios;
+    h->E = cfg->n_entities;
+    int G = 4;
+    while (G < h->E) G <<= 1;
+    h->G = G;
+    h->EP = G;
+    h->NE = (((size_t)h->R * h->EP + 63) / 64) * 64;
+    if (hipSetDevice(cfg->device) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess ||
+        hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {
+        delete h;
+        return fail(nullptr, SG_ERR_HIP, "sg_create: stream/event creation failed");
+    }
+    *out = h;
+    return SG_OK;
+}
+
+extern "C" int sg_destroy(sg_handle *h)
+{
+    if (!h) return SG_OK;
+    (void)hipSetDevice(h->cfg.device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    free_pool(h->static_allocs);
+    free_pool(h->state_allocs);
+    if (h->d_actions) (void)hipFree(h->d_actions);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return SG_OK;
+}
+
+// reference defaults: VehicleController.__init__ controller.py:64-70, PIDController.__init__ :154-161
+static const double kDefaultCtrl[SG_NCTRL] = {0.7, 5.0, NAN, 0.0, 0.03054, 1.5709, 0.3753, 1.8970, 0.0204, 0, 0, 0};
+
+static int launch_rollout(sg_handle *h, int n_steps, int do_reset, int force, const double *d_actions)
+{
+    dim3 block(64), grid((unsigned)(h->NE / 64));
+    HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
+    switch (h->G) {
+    case 4: sg::rollout_kernel<4><<<grid, block, 0, h->stream>>>(h->p, h->cfg.timestep, n_steps, do_reset, force, d_actions); break;
+    case 8: sg::rollout_kernel<8><<<grid, block, 0, h->stream>>>(h->p, h->cfg.timestep, n_steps, do_reset, force, d_actions); break;
+    case 16: sg::rollout_kernel<16><<<grid, block, 0, h->stream>>>(h->p, h->cfg.timestep, n_steps, do_reset, force, d_actions); break;
+    case 32: sg::rollout_kernel<32><<<grid, block, 0, h->stream>>>(h->p, h->cfg.timestep, n_steps, do_reset, force, d_actions); break;
+    default: sg::rollout_kernel<64><<<grid, block, 0, h->stream>>>(h->p, h->cfg.timestep, n_steps, do_reset, force, d_actions); break;
+    }
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
+    h->timed = true;
+    return SG_OK;
+}
+
+extern "C" int sg_upload(sg_handle *h, const sg_scenarios *sc)
+{
+    if (!h || !sc) return SG_ERR_INVALID;
+    if (!sc->kind || !sc->etype || !sc->bbox || !sc->knot_off || !sc->knots || !sc->ego || !sc->t0 || !sc->length)
+        return fail(h, SG_ERR_INVALID, "sg_upload: null array in sg_scenarios");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    free_pool(h->static_allocs);
+    free_pool(h->state_allocs);
+    h->uploaded = false;
+    const int R = h->R, E = h->E, EP = h->EP;
+    const size_t NE = h->NE;
+
+    // ---- validate + SoA re-layout (host) ----
+    std::vector<int32_t> kind(NE, SG_KIND_NONE), etype(NE, 2), knot_n(NE, 0), ego(R);
+    std::vector<int64_t> knot_off(NE, 0);
+    std::vector<double> bbox[4], ctrl[9], min_t(NE, 0.0), max_t(NE, 0.0), t0(R), length(R);
+    for (auto &v : bbox) v.assign(NE, 1.0);
+    for (int k = 0; k < 9; ++k) ctrl[k].assign(NE, kDefaultCtrl[k]);
+    const int64_t rows_total = sc->knot_off[(size_t)R * E];
+    for (int r = 0; r < R; ++r) {
+        if (sc->ego[r] < 0 || sc->ego[r] >= E) return fail(h, SG_ERR_INVALID, "sg_upload: ego[%d]=%d out of range", r, sc->ego[r]);
+        ego[r] = sc->ego[r];
+        t0[r] = sc->t0[r];
+        length[r] = sc->length[r];
+        for (int e = 0; e < E; ++e) {
+            size_t i = (size_t)r * E + e, o = (size_t)r * EP + e;
+            int k = sc->kind[i];
+            if (k < SG_KIND_NONE || k > SG_KIND_AGENT_VEHICLE) return fail(h, SG_ERR_INVALID, "sg_upload: kind[%zu]=%d unknown", i, k);
+            int64_t a = sc->knot_off[i], b = sc->knot_off[i + 1];
+            if (a < 0 || b < a || b > rows_total) return fail(h, SG_ERR_INVALID, "sg_upload: knot_off not monotone at %zu", i);
+            if (k != SG_KIND_NONE && b == a) return fail(h, SG_ERR_INVALID, "sg_upload: entity %zu has no knots", i);
+            kind[o] = k;
+            etype[o] = sc->etype[i];
+            knot_off[o] = a;
+            knot_n[o] = (int32_t)(b - a);
+            for (int q = 0; q < 4; ++q) bbox[q][o] = sc->bbox[i * 4 + q];
+            if (sc->ctrl) for (int q = 0; q < 9; ++q) ctrl[q][o] = sc->ctrl[i * SG_NCTRL + q];
+            if (b > a) {
+                min_t[o] = sc->knots[(size_t)a * 7];
+                max_t[o] = sc->knots[(size_t)(b - 1) * 7];
+                for (int64_t j = a + 1; j < b; ++j)
+                    if (!(sc->knots[(size_t)j * 7] > sc->knots[(size_t)(j - 1) * 7]))
+                        return fail(h, SG_ERR_INVALID, "sg_upload: knot times of entity %zu are not strictly increasing", i);
+            }
+        }
+    }
+
+    // ---- BatchReplayEntity union knot grid per scenario (entity/batch.py:83-95), threaded ----
+    std::vector<std::vector<double>> grids(R);
+    {
+        unsigned nthr = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+        std::vector<std::thread> pool;
+        for (unsigned w = 0; w < nthr; ++w)
+            pool.emplace_back([&, w]() {
+                for (int r = w; r < R; r += nthr) {
+                    std::vector<double> &g = grids[r];
+                    for (int e = 0; e < E; ++e) {
+                        size_t i = (size_t)r * E + e;
+                        if (sc->kind[i] != SG_KIND_REPLAY) continue;
+                        int64_t a = sc->knot_off[i], b = sc->knot_off[i + 1];
+                        for (int64_t j = a; j < b; ++j) {
+                            double v = sc->knots[(size_t)j * 7];
+                            g.push_back(v == v ? v : 0.0); // np.nan_to_num
+                        }
+                        if (b - a == 1) g.push_back(sc->knots[(size_t)a * 7] + 1e-1); // batch.py:85-88
+                    }
+                    std::sort(g.begin(), g.end());
+                    g.erase(std::unique(g.begin(), g.end()), g.end());
+                }
+            });
+        for (auto &th : pool) th.join();
+    }
+    std::vector<int64_t> grid_off(R + 1, 0);
+    std::vector<int32_t> grid_n(R);
+    for (int r = 0; r < R; ++r) {
+        grid_n[r] = (int32_t)grids[r].size();
+        grid_off[r + 1] = grid_off[r] + grid_n[r];
+    }
+    const int64_t total_rows = grid_off[R];
+    std::vector<double> grid_t((size_t)total_rows);
+    std::vector<int32_t> row_scen((size_t)total_rows);
+    for (int r = 0; r < R; ++r) {
+        std::copy(grids[r].begin(), grids[r].end(), grid_t.begin() + grid_off[r]);
+        std::fill(row_scen.begin() + grid_off[r], row_scen.begin() + grid_off[r + 1], r);
+    }
+    grid_off.pop_back();
+
+    // ---- device copies ----
+    Params &p = h->p;
+    p = Params{};
+    p.R = R; p.E = E; p.EP = EP; p.W = 1;
+    p.persist = h->cfg.persist;
+    p.term_mask = h->cfg.terminal_mask;
+    p.rec_cap = h->cfg.record_capacity > 0 ? h->cfg.record_capacity : 0;
+    p.ev_cap = h->cfg.event_capacity > 0 ? h->cfg.event_capacity : 0;
+    auto &S = h->static_allocs;
+    int rc = 0;
+#define UP(field, vec) if ((rc = dev_upload(h, S, &p.field, vec))) return rc
+    UP(kind, kind); UP(etype, etype);
+    for (int q = 0; q < 4; ++q) UP(bbox[q], bbox[q]);
+    UP(min_t, min_t); UP(max_t, max_t); UP(knot_off, knot_off); UP(knot_n, knot_n);
+    for (int q = 0; q < 9; ++q) UP(ctrl[q], ctrl[q]);
+    UP(ego, ego); UP(t0, t0); UP(length, length);
+    UP(grid_off, grid_off); UP(grid_n, grid_n); UP(grid_t, grid_t);
+#undef UP
+    {
+        double *d = nullptr;
+        if ((rc = dev_alloc(h, S, &d, (size_t)std::max<int64_t>(rows_total, 1) * 7, false))) return rc;
+        if (rows_total > 0)
+            HIP_TRY(h, hipMemcpyAsync(d, sc->knots, (size_t)rows_total * 7 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        p.knots = d;
+        const int32_t *drs = nullptr;
+        if ((rc = dev_upload(h, S, &drs, row_scen))) return rc;
+        h->d_row_scen = const_cast<int32_t *>(drs);
+        h->total_rows = total_rows;
+        if ((rc = dev_alloc(h, S, &p.grid_y, (size_t)total_rows * 6 * EP, false))) return rc;
+    }
+    auto &M = h->state_allocs;
+#define AL(field, n) if ((rc = dev_alloc(h, M, &p.field, (n)))) return rc
+    for (int c = 0; c < 6; ++c) { AL(pose[c], NE); AL(vel[c], NE); }
+    AL(dist, NE); AL(coll, NE); AL(present, NE);
+    AL(cs[0], 4 * NE); // one block [4][NE]: speed, e_lon_prev, e_lat_prev, e_lon_int
+    for (int c = 1; c < 4; ++c) p.cs[c] = p.cs[0] + (size_t)c * NE;
+    AL(t, R); AL(prev_t, R); AL(done, R); AL(n_steps, R);
+    AL(m_avg, R); AL(m_max, R); AL(m_t, R); AL(m_dist, R); AL(last_row, R); AL(n_events, R);
+    AL(events, (size_t)R * std::max(p.ev_cap, 1));
+    AL(rec_t, (size_t)std::max(p.rec_cap, 1) * R);
+    AL(rec_pose, (size_t)std::max(p.rec_cap, 0) * 6 * R * EP + 1);
+    AL(rec_rows, R);
+#undef AL
+
+    // stage-1 resample on device
+    if (total_rows > 0) {
+        int64_t threads = total_rows * EP;
+        dim3 block(256), grid((unsigned)((threads + 255) / 256));
+        sg::build_grid_kernel<<<grid, block, 0, h->stream>>>(p, h->d_row_scen, total_rows);
+        HIP_TRY(h, hipGetLastError());
+    }
+    HIP_TRY(h, hipStreamSynchronize(h->stream)); // host vectors go out of scope
+    h->uploaded = true;
+    return sg_reset(h);
+}
+
+extern "C" int sg_reset(sg_handle *h)
+{
+    if (!h) return SG_ERR_INVALID;
+    if (!h->uploaded) return fail(h, SG_ERR_STATE, "sg_reset: no scenarios uploaded");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    int rc = launch_rollout(h, 0, 1, 0, nullptr);
+    if (rc) return rc;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return SG_OK;
+}
+
+extern "C" int sg_set_timestep(sg_handle *h, double timestep)
+{
+    if (!h || !(timestep > 0.0)) return h ? fail(h, SG_ERR_INVALID, "sg_set_timestep: timestep must be > 0") : SG_ERR_INVALID;
+    h->cfg.timestep = timestep;
+    return SG_OK;
+}
+
+extern "C" int sg_step(sg_handle *h, int32_t n_steps, const double *actions, int32_t actions_device)
+{
+    if (!h) return SG_ERR_INVALID;
+    if (!h->uploaded) return fail(h, SG_ERR_STATE, "sg_step: no scenarios uploaded");
+    if (n_steps < 0) return fail(h, SG_ERR_INVALID, "sg_step: n_steps < 0");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    const double *d_act = nullptr;
+    if (actions && actions_device) {
+        d_act = actions;
+    } else if (actions) {
+        size_t n = (size_t)n_steps * h->R * 2;
+        if (n > h->actions_cap) {
+            if (h->d_actions) HIP_TRY(h, hipFree(h->d_actions));
+            h->d_actions = nullptr;
+            HIP_TRY(h, hipMalloc((void **)&h->d_actions, std::max<size_t>(n, 2) * sizeof(double)));
+            h->actions_cap = n;
+        }
+        if (n) HIP_TRY(h, hipMemcpyAsync(h->d_actions, actions, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        d_act = h->d_actions;
+    } else {
+        // no actions: SG_KIND_AGENT_VEHICLE slots get (0, 0)
+        size_t n = (size_t)n_steps * h->R * 2;
+        if (n > h->actions_cap) {
+            if (h->d_actions) HIP_TRY(h, hipFree(h->d_actions));
+            h->d_actions = nullptr;
+            HIP_TRY(h, hipMalloc((void **)&h->d_actions, std::max<size_t>(n, 2) * sizeof(double)));
+            h->actions_cap = n;
+        }
+        if (n) HIP_TRY(h, hipMemsetAsync(h->d_actions, 0, n * sizeof(double), h->stream));
+        d_act = h->d_actions;
+    }
+    int rc = launch_rollout(h, n_steps, 0, 1, d_act);
+    if (rc) return rc;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return SG_OK;
+}
+
+extern "C" int sg_rollout_async(sg_handle *h, int32_t max_steps, int32_t do_reset)
+{
+    if (!h) return SG_ERR_INVALID;
+    if (!h->uploaded) return fail(h, SG_ERR_STATE, "sg_rollout: no scenarios uploaded");
+    if (max_steps < 0) return fail(h, SG_ERR_INVALID, "sg_rollout: max_steps < 0");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    // external-action slots are fed (0, 0) here; drive them with sg_step(actions)
+    return launch_rollout(h, max_steps, do_reset ? 1 : 0, 0, nullptr);
+}
+
+extern "C" int sg_rollout(sg_handle *h, int32_t max_steps)
+{
+    int rc = sg_rollout_async(h, max_steps, 1);
+    if (rc) return rc;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return SG_OK;
+}
+
+extern "C" int sg_synchronize(sg_handle *h)
+{
+    if (!h) return SG_ERR_INVALID;
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return SG_OK;
+}
+
+extern "C" void *sg_stream(sg_handle *h) { return h ? (void *)h->stream : nullptr; }
+
+extern "C" int sg_state_view_get(sg_handle *h, sg_state_view *out)
+{
+    if (!h || !out) return SG_ERR_INVALID;
+    if (!h->uploaded) return fail(h, SG_ERR_STATE, "sg_state_view_get: no scenarios uploaded");
+    const Params &p = h->p;
+    out->n_scenarios = h->R; out->n_entities = h->E; out->entity_stride = h->EP; out->row_words = 1;
+    for (int c = 0; c < 6; ++c) { out->pose[c] = p.pose[c]; out->vel[c] = p.vel[c]; }
+    out->dist = p.dist; out->coll = p.coll; out->present = p.present;
+    out->ctrl_state = p.cs[0];
+    out->t = p.t; out->prev_t = p.prev_t; out->done = p.done; out->n_steps = p.n_steps;
+    return SG_OK;
+}
+
+extern "C" int sg_read_metrics(sg_handle *h, sg_metrics *out, sg_event *events, int32_t cap, int32_t *n_events)
+{
+    if (!h || !out) return SG_ERR_INVALID;
+    if (!h->uploaded) return fail(h, SG_ERR_STATE, "sg_read_metrics: no scenarios uploaded");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    const int R = h->R;
+    const Params &p = h->p;
+    std::vector<double> avg(R), mx(R), md(R), t(R);
+    std::vector<int32_t> ns(R), dn(R), ne(R);
+    HIP_TRY(h, hipMemcpy(avg.data(), p.m_avg, R * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(mx.data(), p.m_max, R * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(md.data(), p.m_dist, R * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(t.data(), p.t, R * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(ns.data(), p.n_steps, R * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(dn.data(), p.done, R * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(ne.data(), p.n_events, R * 4, hipMemcpyDeviceToHost));
+    int64_t total = 0;
+    bool overflow = false;
+    for (int r = 0; r < R; ++r) {
+        out[r].ego_avg_speed = avg[r]; out[r].ego_max_speed = mx[r]; out[r].ego_distance_travelled = md[r];
+        out[r].final_t = t[r]; out[r].n_steps = ns[r]; out[r].done = dn[r]; out[r].n_collisions = ne[r];
+        out[r].reserved = 0;
+        if (ne[r] > p.ev_cap) overflow = true;
+        total += std::min(ne[r], p.ev_cap);
+    }
+    if (n_events) *n_events = (int32_t)total;
+    if (events && cap > 0 && p.ev_cap > 0) {
+        std::vector<sg_event> all((size_t)R * p.ev_cap);
+        HIP_TRY(h, hipMemcpy(all.data(), p.events, all.size() * sizeof(sg_event), hipMemcpyDeviceToHost));
+        int64_t k = 0;
+        for (int r = 0; r < R; ++r)
+            for (int i = 0; i < std::min(ne[r], p.ev_cap); ++i) {
+                if (k >= cap) return fail(h, SG_ERR_CAPACITY, "sg_read_metrics: %lld events do not fit cap=%d", (long long)total, cap);
+                events[k++] = all[(size_t)r * p.ev_cap + i];
+            }
+    }
+    if (overflow) return fail(h, SG_ERR_CAPACITY, "sg_read_metrics: a scenario recorded more than event_capacity=%d collisions", p.ev_cap);
+    return SG_OK;
+}
+
+extern "C" int sg_read_record(sg_handle *h, int32_t n_rows, double *t_out, double *pose_out)
+{
+    if (!h || n_rows < 0) return SG_ERR_INVALID;
+    if (!h->uploaded) return fail(h, SG_ERR_STATE, "sg_read_record: no scenarios uploaded");
+    const Params &p = h->p;
+    if (n_rows > p.rec_cap) return fail(h, SG_ERR_CAPACITY, "sg_read_record: n_rows=%d > record_capacity=%d", n_rows, p.rec_cap);
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    const int R = h->R, E = h->E, EP = h->EP;
+    if (t_out && n_rows) HIP_TRY(h, hipMemcpy(t_out, p.rec_t, (size_t)n_rows * R * 8, hipMemcpyDeviceToHost));
+    if (pose_out && n_rows) {
+        std::vector<double> raw((size_t)n_rows * 6 * R * EP);
+        HIP_TRY(h, hipMemcpy(raw.data(), p.rec_pose, raw.size() * 8, hipMemcpyDeviceToHost));
+        for (int s = 0; s < n_rows; ++s)
+            for (int r = 0; r < R; ++r)
+                for (int e = 0; e < E; ++e)
+                    for (int c = 0; c < 6; ++c)
+                        pose_out[(((size_t)s * R + r) * E + e) * 6 + c] = raw[((size_t)s * 6 + c) * R * EP + (size_t)r * EP + e];
+    }
+    return SG_OK;
+}
+
+extern "C" int sg_copy_to_host(sg_handle *h, const void *device_ptr, void *host_ptr, uint64_t bytes)
+{
+    if (!h || !device_ptr || !host_ptr) return SG_ERR_INVALID;
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipMemcpy(host_ptr, device_ptr, bytes, hipMemcpyDeviceToHost));
+    return SG_OK;
+}
+
+extern "C" int sg_last_kernel_ms(sg_handle *h, float *ms)
+{
+    if (!h || !ms) return SG_ERR_INVALID;
+    if (!h->timed) return fail(h, SG_ERR_STATE, "sg_last_kernel_ms: nothing launched yet");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, hipEventSynchronize(h->ev1));
+    HIP_TRY(h, hipEventElapsedTime(ms, h->ev0, h->ev1));
+    return SG_OK;
+}

@@ -1,0 +1,211 @@
+"""RolloutEngine: thin object wrapper over one sg_handle (one GPU, R scenarios x E entity slots)."""
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Optional
+
+import numpy as np
+
+from . import _lib as L
+
+TERMINAL_BITS = {"max_length": L.TERM_MAX_LENGTH, "collision": L.TERM_COLLISION,
+                 "ego_collision": L.TERM_EGO_COLLISION}
+
+# VehicleController / PIDController constructor defaults (reference controller.py:64-70, 157-161)
+DEFAULT_CTRL = np.array([0.7, 5.0, np.nan, 0.0, 0.03054, 1.5709, 0.3753, 1.8970, 0.0204, 0, 0, 0])
+
+
+@dataclass
+class PackedScenarios:
+    """Numeric content of R scenarios x E entity slots in the sg_scenarios layout."""
+
+    n_scenarios: int
+    n_entities: int
+    kind: np.ndarray      # [R*E] int32
+    etype: np.ndarray     # [R*E] int32
+    bbox: np.ndarray      # [R*E, 4]
+    knot_off: np.ndarray  # [R*E+1] int64
+    knots: np.ndarray     # [rows, 7]
+    ego: np.ndarray       # [R] int32
+    t0: np.ndarray        # [R]
+    length: np.ndarray    # [R]
+    ctrl: Optional[np.ndarray] = None  # [R*E, 12]
+    refs: list = field(default_factory=list)
+
+    def validate(self):
+        R, E = self.n_scenarios, self.n_entities
+        assert self.kind.shape == (R * E,) and self.etype.shape == (R * E,)
+        assert self.bbox.shape == (R * E, 4) and self.knot_off.shape == (R * E + 1,)
+        assert self.knots.ndim == 2 and self.knots.shape[1] == 7
+        assert self.ego.shape == (R,) and self.t0.shape == (R,) and self.length.shape == (R,)
+        assert self.ctrl is None or self.ctrl.shape == (R * E, L.NCTRL)
+        return self
+
+    def shard(self, lo, hi):
+        """Scenarios [lo, hi) as an independent batch (replica sharding across GPUs)."""
+        E = self.n_entities
+        a, b = int(self.knot_off[lo * E]), int(self.knot_off[hi * E])
+        return PackedScenarios(
+            hi - lo, E, self.kind[lo * E:hi * E], self.etype[lo * E:hi * E], self.bbox[lo * E:hi * E],
+            self.knot_off[lo * E:hi * E + 1] - a, self.knots[a:b], self.ego[lo:hi], self.t0[lo:hi],
+            self.length[lo:hi], None if self.ctrl is None else self.ctrl[lo * E:hi * E],
+            self.refs[lo:hi] if self.refs else [],
+        )
+
+
+def terminal_mask(conditions):
+    if conditions is None:
+        return L.TERM_MAX_LENGTH
+    mask = 0
+    for c in conditions:
+        if c not in TERMINAL_BITS:
+            raise ValueError(f"terminal condition {c!r} is not available on the device path "
+                             f"(supported: {sorted(TERMINAL_BITS)})")
+        mask |= TERMINAL_BITS[c]
+    return mask
+
+
+class RolloutEngine:
+    """ScenarioGym's step loop for a whole batch, resident on one MI355X."""
+
+    def __init__(self, n_scenarios, n_entities, timestep=1.0 / 30.0, persist=False,
+                 terminal_conditions=None, record_capacity=0, event_capacity=16, device=0):
+        self.lib = L.load()
+        self.R, self.E = int(n_scenarios), int(n_entities)
+        self.cfg = L.SgConfig(int(device), self.R, self.E, int(bool(persist)),
+                              terminal_mask(terminal_conditions), int(record_capacity),
+                              int(event_capacity), 0, float(timestep))
+        self.h = C.c_void_p()
+        rc = self.lib.sg_create(C.byref(self.cfg), C.byref(self.h))
+        if rc != L.SG_OK:
+            msg = self.lib.sg_last_error(None).decode()
+            self.h = None
+            raise RuntimeError(f"sg_create failed ({rc}): {msg}")
+        self._view = None
+        self._keep = None
+
+    # ------------------------------------------------------------------ plumbing
+    def _check(self, rc, what):
+        if rc != L.SG_OK:
+            raise RuntimeError(f"{what} failed ({rc}): {self.lib.sg_last_error(self.h).decode()}")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.sg_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ ABI calls
+    def upload(self, packed: PackedScenarios):
+        packed.validate()
+        if (packed.n_scenarios, packed.n_entities) != (self.R, self.E):
+            raise ValueError("packed batch does not match the engine's (n_scenarios, n_entities)")
+        arrs = dict(
+            kind=np.ascontiguousarray(packed.kind, np.int32), etype=np.ascontiguousarray(packed.etype, np.int32),
+            bbox=np.ascontiguousarray(packed.bbox, np.float64), knot_off=np.ascontiguousarray(packed.knot_off, np.int64),
+            knots=np.ascontiguousarray(packed.knots, np.float64),
+            ctrl=None if packed.ctrl is None else np.ascontiguousarray(packed.ctrl, np.float64),
+            ego=np.ascontiguousarray(packed.ego, np.int32), t0=np.ascontiguousarray(packed.t0, np.float64),
+            length=np.ascontiguousarray(packed.length, np.float64),
+        )
+        sc = L.SgScenarios(*[None if arrs[n] is None else arrs[n].ctypes.data for n, _ in L.SgScenarios._fields_])
+        self._check(self.lib.sg_upload(self.h, C.byref(sc)), "sg_upload")
+        self._view = L.SgStateView()
+        self._check(self.lib.sg_state_view_get(self.h, C.byref(self._view)), "sg_state_view_get")
+        return self
+
+    def reset(self):
+        self._check(self.lib.sg_reset(self.h), "sg_reset")
+
+    def set_timestep(self, dt):
+        self._check(self.lib.sg_set_timestep(self.h, float(dt)), "sg_set_timestep")
+
+    def step(self, n_steps=1, actions=None):
+        """n x ScenarioGym.step(); actions [n, R, 2] (accel, steer) for external-action slots."""
+        ptr = None
+        if actions is not None:
+            actions = np.ascontiguousarray(actions, np.float64).reshape(n_steps, self.R, 2)
+            ptr = actions.ctypes.data
+        self._check(self.lib.sg_step(self.h, int(n_steps), ptr, 0), "sg_step")
+
+    def rollout(self, max_steps):
+        self._check(self.lib.sg_rollout(self.h, int(max_steps)), "sg_rollout")
+
+    def rollout_async(self, max_steps, do_reset=True):
+        self._check(self.lib.sg_rollout_async(self.h, int(max_steps), int(do_reset)), "sg_rollout_async")
+
+    def synchronize(self):
+        self._check(self.lib.sg_synchronize(self.h), "sg_synchronize")
+
+    def last_kernel_ms(self):
+        ms = C.c_float()
+        self._check(self.lib.sg_last_kernel_ms(self.h, C.byref(ms)), "sg_last_kernel_ms")
+        return ms.value
+
+    # ------------------------------------------------------------------ reads
+    def _d2h(self, ptr, shape, dtype):
+        out = np.empty(shape, dtype)
+        self._check(self.lib.sg_copy_to_host(self.h, ptr, out.ctypes.data, out.nbytes), "sg_copy_to_host")
+        return out
+
+    def state(self):
+        """Host copy of the step-materialised state: dict of [R, E, ...] arrays (NaN = absent)."""
+        v, R, E, EP = self._view, self.R, self.E, self._view.entity_stride
+        n = R * EP
+        pose = np.stack([self._d2h(v.pose[c], n, np.float64) for c in range(6)], -1).reshape(R, EP, 6)[:, :E]
+        vel = np.stack([self._d2h(v.vel[c], n, np.float64) for c in range(6)], -1).reshape(R, EP, 6)[:, :E]
+        present = self._d2h(v.present, n, np.uint8).reshape(R, EP)[:, :E].astype(bool)
+        pose = np.where(present[..., None], pose, np.nan)
+        vel = np.where(present[..., None], vel, np.nan)
+        NEp = ((n + 63) // 64) * 64
+        cs = self._d2h(v.ctrl_state, 4 * NEp, np.float64).reshape(4, NEp)[:, :n].reshape(4, R, EP)[:, :, :E]
+        return dict(
+            poses=pose, vels=vel, present=present,
+            dists=self._d2h(v.dist, n, np.float64).reshape(R, EP)[:, :E],
+            coll=self._d2h(v.coll, n, np.uint64).reshape(R, EP)[:, :E],
+            ctrl_state=np.moveaxis(cs, 0, -1),
+            t=self._d2h(v.t, R, np.float64), prev_t=self._d2h(v.prev_t, R, np.float64),
+            done=self._d2h(v.done, R, np.int32).astype(bool), n_steps=self._d2h(v.n_steps, R, np.int32),
+        )
+
+    def metrics(self, event_cap=None):
+        m = (L.SgMetrics * self.R)()
+        cap = self.R * max(self.cfg.event_capacity, 1) if event_cap is None else int(event_cap)
+        ev = (L.SgEvent * cap)()
+        n_ev = C.c_int32()
+        self._check(self.lib.sg_read_metrics(self.h, m, ev, cap, C.byref(n_ev)), "sg_read_metrics")
+        rows = np.frombuffer(m, dtype=np.dtype([
+            ("ego_avg_speed", "f8"), ("ego_max_speed", "f8"), ("ego_distance_travelled", "f8"),
+            ("final_t", "f8"), ("n_steps", "i4"), ("done", "i4"), ("n_collisions", "i4"), ("reserved", "i4")])).copy()
+        events = np.frombuffer(ev, dtype=np.dtype([
+            ("t", "f8"), ("scenario", "i4"), ("other", "i4"), ("type", "i4"), ("reserved", "i4")]))[: n_ev.value].copy()
+        return rows, events
+
+    def record(self, n_rows):
+        """State.recorded_poses for the whole batch: t [n, R], poses [n, R, E, 6]."""
+        t = np.empty((n_rows, self.R))
+        poses = np.empty((n_rows, self.R, self.E, 6))
+        self._check(self.lib.sg_read_record(self.h, int(n_rows), t.ctypes.data, poses.ctypes.data), "sg_read_record")
+        return t, poses
+
+    def torch_state(self):
+        """Zero-copy torch views ([R*EP] fp64) over the device state (torch is only the container)."""
+        import torch
+
+        v = self._view
+        n = self.R * v.entity_stride
+
+        class _Arr:
+            def __init__(self, ptr, shape, typestr):
+                self.__cuda_array_interface__ = dict(shape=shape, typestr=typestr, data=(int(ptr), False), version=2)
+
+        dev = f"cuda:{self.cfg.device}"
+        out = {f"pose{c}": torch.as_tensor(_Arr(v.pose[c], (n,), "<f8"), device=dev) for c in range(6)}
+        out.update({f"vel{c}": torch.as_tensor(_Arr(v.vel[c], (n,), "<f8"), device=dev) for c in range(6)})
+        out["dist"] = torch.as_tensor(_Arr(v.dist, (n,), "<f8"), device=dev)
+        out["t"] = torch.as_tensor(_Arr(v.t, (self.R,), "<f8"), device=dev)
+        return out

@@ -1,0 +1,68 @@
+"""Pack scenarios into the sg_scenarios layout (host side, numpy only)."""
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import _lib as L
+from .engine import DEFAULT_CTRL, PackedScenarios
+
+
+def default_kinds(n_entities: int, ego: int) -> np.ndarray:
+    """The reference's default create_agent (agent.py:151-169): only the entity with ref "ego"
+    gets a ReplayTrajectoryAgent, every other entity goes to the BatchReplayEntity."""
+    k = np.full(n_entities, L.KIND_REPLAY, np.int32)
+    k[ego] = L.KIND_AGENT_REPLAY
+    return k
+
+
+def pack_arrays(scenarios: Sequence[dict], kinds: Optional[Sequence[np.ndarray]] = None,
+                ctrls: Optional[Sequence[Optional[np.ndarray]]] = None,
+                n_entities: Optional[int] = None) -> PackedScenarios:
+    """Batch scenarios given as plain arrays.
+
+    Each scenario dict holds knot_off [E_r+1], knots [rows,7], bbox [E_r,4], etype [E_r], ego,
+    t0, length.  Scenarios with fewer entities than the batch width are padded with SG_KIND_NONE.
+    """
+    R = len(scenarios)
+    E = int(n_entities or max(len(s["etype"]) for s in scenarios))
+    kind = np.zeros(R * E, np.int32)
+    etype = np.full(R * E, 2, np.int32)
+    bbox = np.ones((R * E, 4))
+    ctrl = np.tile(DEFAULT_CTRL, (R * E, 1))
+    knot_off = np.zeros(R * E + 1, np.int64)
+    chunks: List[np.ndarray] = []
+    rows = 0
+    ego, t0, length = np.zeros(R, np.int32), np.zeros(R), np.zeros(R)
+    for r, s in enumerate(scenarios):
+        Er = len(s["etype"])
+        if Er > E:
+            raise ValueError(f"scenario {r} has {Er} entities > batch width {E}")
+        off = np.asarray(s["knot_off"], np.int64)
+        k = default_kinds(Er, int(s["ego"])) if kinds is None else np.asarray(kinds[r], np.int32)
+        kind[r * E:r * E + Er] = k
+        etype[r * E:r * E + Er] = s["etype"]
+        bbox[r * E:r * E + Er] = s["bbox"]
+        if ctrls is not None and ctrls[r] is not None:
+            ctrl[r * E:r * E + Er] = ctrls[r]
+        knot_off[r * E:r * E + Er + 1] = rows + off
+        knot_off[r * E + Er + 1:(r + 1) * E + 1] = rows + off[-1]
+        chunks.append(np.asarray(s["knots"], np.float64)[: off[-1]])
+        rows += int(off[-1])
+        ego[r], t0[r], length[r] = s["ego"], s["t0"], s["length"]
+    knots = np.concatenate(chunks, axis=0) if chunks else np.zeros((0, 7))
+    return PackedScenarios(R, E, kind, etype, bbox, knot_off, knots, ego, t0, length, ctrl).validate()
+
+
+def unpack_scenario(packed: PackedScenarios, r: int) -> dict:
+    """Scenario r of a batch as plain arrays (inverse of pack_arrays, padding removed)."""
+    E = packed.n_entities
+    kind = packed.kind[r * E:(r + 1) * E]
+    n = int((kind != L.KIND_NONE).sum()) if (kind != L.KIND_NONE).any() else 0
+    n = max(n, int(np.max(np.nonzero(kind != L.KIND_NONE)[0])) + 1 if n else 0)
+    off = packed.knot_off[r * E:r * E + n + 1]
+    return dict(
+        knot_off=off - off[0], knots=packed.knots[off[0]:off[-1]], bbox=packed.bbox[r * E:r * E + n],
+        etype=packed.etype[r * E:r * E + n], kind=kind[:n], ego=int(packed.ego[r]), t0=float(packed.t0[r]),
+        length=float(packed.length[r]),
+        ctrl=None if packed.ctrl is None else packed.ctrl[r * E:r * E + n],
+    )

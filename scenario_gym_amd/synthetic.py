@@ -1,0 +1,98 @@
+"""Seeded synthetic scenario batches: the bench / parity workload.
+
+Per scenario: a shared grid of K knot times uniform on [0, L]; every entity drives a constant-speed
+arc (start ~ U[-100,100]^2, heading ~ U[-pi,pi], speed ~ U[2,12] m/s, curvature ~ N(0, 0.02) rad/m)
+sampled at the grid; bounding box = the reference's car1 catalog entry (2.0 x 4.2 m, centre
+(1.37, 0)); `static_frac` of the non-ego entities are static (one knot) and `vanish_frac` only exist
+on a strict sub-interval of [0, L].  Scenario r depends only on (seed, r // CHUNK), so any rank can
+generate exactly its own shard.
+"""
+import numpy as np
+
+from . import _lib as L
+from .engine import DEFAULT_CTRL, PackedScenarios
+
+SEED = 20240807
+CHUNK = 64
+CAR1_BBOX = (2.0, 4.2, 1.37, 0.0)  # width, length, center_x, center_y
+
+
+def _chunk(seed, chunk_id, n, E, K, length, ego_kind, static_frac, vanish_frac, extent):
+    rng = np.random.default_rng([seed, chunk_id])
+    grid = np.linspace(0.0, length, K)
+    x0 = rng.uniform(-extent, extent, (n, E))
+    y0 = rng.uniform(-extent, extent, (n, E))
+    h0 = rng.uniform(-np.pi, np.pi, (n, E))
+    v = rng.uniform(2.0, 12.0, (n, E))
+    kappa = rng.normal(0.0, 0.02, (n, E))
+    kappa = np.where(np.abs(kappa) < 1e-6, 1e-6, kappa)
+    u = rng.random((n, E))
+    u[:, 0] = 1.0  # the ego always spans the whole scenario
+    static = u < static_frac
+    vanish = (~static) & (u < static_frac + vanish_frac)
+    # knot index range [a, b] per entity
+    a = np.zeros((n, E), np.int64)
+    b = np.full((n, E), K - 1, np.int64)
+    va = rng.integers(1, K // 2, (n, E))
+    vb = rng.integers(K // 2 + 1, K - 1, (n, E))
+    a = np.where(vanish, va, a)
+    b = np.where(vanish, vb, b)
+    ks = rng.integers(0, K, (n, E))
+    a = np.where(static, ks, a)
+    b = np.where(static, ks, b)
+    cnt = (b - a + 1).ravel()
+    off = np.concatenate([[0], np.cumsum(cnt)])
+    # flat (entity, knot) index lists
+    ent = np.repeat(np.arange(n * E), cnt)
+    kidx = np.arange(off[-1]) - np.repeat(off[:-1], cnt) + np.repeat(a.ravel(), cnt)
+    t = grid[kidx]
+    h = h0.ravel()[ent] + kappa.ravel()[ent] * v.ravel()[ent] * t
+    x = x0.ravel()[ent] + (np.sin(h) - np.sin(h0.ravel()[ent])) / kappa.ravel()[ent]
+    y = y0.ravel()[ent] - (np.cos(h) - np.cos(h0.ravel()[ent])) / kappa.ravel()[ent]
+    knots = np.zeros((off[-1], 7))
+    knots[:, 0], knots[:, 1], knots[:, 2], knots[:, 4] = t, x, y, h
+    kind = np.full((n, E), L.KIND_REPLAY, np.int32)
+    kind[:, 0] = ego_kind
+    return kind.ravel(), off, knots
+
+
+def make_batch(n_scenarios, n_entities, n_steps=10000, timestep=1.0 / 30.0, n_knots=128,
+               ego_kind=L.KIND_AGENT_REPLAY, static_frac=0.1, vanish_frac=0.1, extent=100.0,
+               seed=SEED, first_scenario=0) -> PackedScenarios:
+    """Scenarios [first_scenario, first_scenario + n_scenarios) of the seeded synthetic family."""
+    R, E = int(n_scenarios), int(n_entities)
+    length = n_steps * timestep
+    assert first_scenario % CHUNK == 0, "shards start on a chunk boundary"
+    kinds, offs, knotss = [], [], []
+    rows = 0
+    for c0 in range(0, R, CHUNK):
+        n = min(CHUNK, R - c0)
+        kind, off, knots = _chunk(seed, (first_scenario + c0) // CHUNK, CHUNK, E, n_knots, length,
+                                  ego_kind, static_frac, vanish_frac, extent)
+        m = n * E
+        kinds.append(kind[:m])
+        offs.append(off[:m] + rows)
+        knotss.append(knots[: off[m]])
+        rows += int(off[m])
+    knot_off = np.concatenate(offs + [[rows]]).astype(np.int64)
+    knots = np.concatenate(knotss, axis=0)
+    bbox = np.tile(np.array(CAR1_BBOX), (R * E, 1))
+    ego_rows = knot_off[np.arange(R) * E]
+    t0 = np.maximum(0.0, knots[ego_rows, 0])  # ScenarioGym.get_start_time
+    # Scenario.length = max over entities of the last knot time
+    last = knots[knot_off[1:] - 1, 0].reshape(R, E)
+    return PackedScenarios(
+        R, E, np.concatenate(kinds), np.zeros(R * E, np.int32), bbox, knot_off, knots,
+        np.zeros(R, np.int32), t0, last.max(axis=1), np.tile(DEFAULT_CTRL, (R * E, 1)),
+    ).validate()
+
+
+def make_actions(n_steps, n_scenarios, seed=SEED, first_scenario=0):
+    """Seeded external (accel, steer) sequences: accel ~ U[-5,5], steer ~ U[-0.7,0.7]; [n, R, 2]."""
+    out = np.empty((n_steps, n_scenarios, 2))
+    for c0 in range(0, n_scenarios, CHUNK):
+        n = min(CHUNK, n_scenarios - c0)
+        rng = np.random.default_rng([seed, 7, (first_scenario + c0) // CHUNK])
+        a = np.stack([rng.uniform(-5, 5, (n_steps, CHUNK)), rng.uniform(-0.7, 0.7, (n_steps, CHUNK))], -1)
+        out[:, c0:c0 + n] = a[:, :n]
+    return out
