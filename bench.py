@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""Batched-rollout benchmark: entity-steps/s on BASELINE.json's 4096 scenarios x 64 entities x 10k steps.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One bench "step" = one full pass of the hot path over the batch: sg_rollout of R x E x T
+(reset + T simulated steps, every scenario running to its end) with the scenarios resident in HBM.
+Every rank owns its own R scenarios (weak scaling: replicas are independent); RCCL is
+used only to dispatch the run configuration and to collect the per-replica metric rows.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+B_ALG = 114.0        # algorithmic bytes per entity-step: pose 48 + vel 48 + dist 8 + row 8 + knots 2
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def cpu_baseline(workload, seconds_budget=20.0):
+    """The CPU oracle (a port of the reference's algorithm, NOT the thing measured) on a bounded
+    sample of the same workload: one scenario per host thread, the same E, shortened T."""
+    import concurrent.futures as cf
+
+    import numpy as np
+
+    import scenario_gym_amd._lib as L
+    from oracle import oracle as O
+    from scenario_gym_amd import synthetic
+    from scenario_gym_amd.packing import unpack_scenario
+
+    O.build()
+    O.lib()
+    cores = os.cpu_count() or 1
+    E, T = workload["E"], workload["T"]
+    t_sample = T
+    n_scen = max(cores, 1) * 4
+    packed = synthetic.make_batch(n_scen, E, n_steps=t_sample, ego_kind=workload["ego_kind"])
+    scen = [unpack_scenario(packed, r) for r in range(n_scen)]
+
+    def one(s):
+        o = O.rollout(s["knot_off"], s["knots"], s["bbox"], s["etype"], s["kind"], s["ego"], s["t0"],
+                      s["length"], workload["dt"], ctrl=s["ctrl"], max_steps=t_sample, record=False)
+        return o["n_steps"]
+
+    one(scen[0])  # warm
+    t0 = time.perf_counter()
+    with cf.ThreadPoolExecutor(cores) as ex:  # ctypes releases the GIL: real parallelism
+        steps = list(ex.map(one, scen))
+    dt = time.perf_counter() - t0
+    return {
+        "value": float(sum(steps)) * E / dt, "unit": "entity-steps/s", "cores": cores, "kind": "port",
+        "sample": f"{n_scen} scenarios x {E} entities x {t_sample} steps of the same seeded family, "
+                  f"{cores} threads, C oracle (oracle/sgym_oracle.c), {dt:.1f}s",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--scenarios", type=int, default=4096, help="scenarios per GPU")
+    ap.add_argument("--entities", type=int, default=64)
+    ap.add_argument("--sim-steps", type=int, default=10000)
+    ap.add_argument("--ego", default="pid", choices=["pid", "replay"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    import scenario_gym_amd as sga
+    import scenario_gym_amd._lib as L
+    from scenario_gym_amd import synthetic
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if args.gpus != world and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
+    dev = torch.device("cuda", local_rank)
+
+    R, E, T = args.scenarios, args.entities, args.sim_steps
+    dt = 1.0 / 30.0
+    ego_kind = L.KIND_AGENT_PID if args.ego == "pid" else L.KIND_AGENT_REPLAY
+    # dispatch: rank 0 broadcasts the run configuration (RCCL), each rank generates its own shard
+    cfg = torch.tensor([R, E, T, ego_kind, synthetic.SEED], dtype=torch.int64, device=dev)
+    if dist is not None:
+        dist.broadcast(cfg, src=0)
+    R, E, T, ego_kind, seed = (int(x) for x in cfg.tolist())
+
+    packed = synthetic.make_batch(R, E, n_steps=T, timestep=dt, ego_kind=ego_kind, seed=seed,
+                                  first_scenario=rank * R)
+    eng = sga.RolloutEngine(R, E, timestep=dt, terminal_conditions=["max_length"], event_capacity=64,
+                            device=local_rank)
+    eng.upload(packed)
+    del packed
+
+    def one_pass():
+        eng.rollout_async(T, do_reset=True)
+        eng.synchronize()
+        rows, _ = eng.metrics()
+        m = torch.from_numpy(np.stack([rows["ego_avg_speed"], rows["ego_max_speed"],
+                                       rows["ego_distance_travelled"], rows["n_collisions"].astype(np.float64),
+                                       rows["n_steps"].astype(np.float64)], axis=1)).to(dev)
+        if dist is not None:  # collection: every rank's metric rows to rank 0
+            out = [torch.empty_like(m) for _ in range(world)] if rank == 0 else None
+            dist.gather(m, out, dst=0)
+        return rows, eng.last_kernel_ms()
+
+    for _ in range(args.warmup):
+        one_pass()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    kernel_ms = []
+    ent_steps = 0
+    for _ in range(args.steps):
+        rows, ms = one_pass()
+        kernel_ms.append(ms)
+        ent_steps += int(rows["n_steps"].sum()) * E
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+
+    stats = torch.tensor([elapsed, float(ent_steps)], dtype=torch.float64, device=dev)
+    if dist is not None:
+        tmax = stats.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+        elapsed, total = float(tmax[0]), float(stats[1])
+    else:
+        total = float(ent_steps)
+
+    if rank == 0:
+        per_launch = ent_steps / args.steps
+        avg_ms = sum(kernel_ms) / len(kernel_ms)
+        achieved = per_launch * B_ALG / (avg_ms * 1e-3) / 1e9
+        line = {
+            "metric": "entity-steps/sec (batched rollout)",
+            "value": total / elapsed,
+            "unit": "entity-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{R} scenarios x {E} entities x {T} steps per GPU, "
+                            f"{'PIDAgent' if ego_kind == L.KIND_AGENT_PID else 'ReplayTrajectoryAgent'} ego + batch replay "
+                            "others, all-pairs OBB collisions, CollisionMetric + EgoAvgSpeed/MaxSpeed/DistanceTravelled, "
+                            "terminal max_length (BASELINE.json configs[2])",
+                "scenarios_per_gpu": R, "entities": E, "sim_steps": T, "timestep": dt,
+                "sharding": f"replicas x{world}, no data-path collective",
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "kernel": "sg::rollout_kernel<64>", "kernel_ms": avg_ms,
+                "bytes_per_entity_step": B_ALG, "entity_steps_per_launch": per_launch,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(dict(E=E, T=T, dt=dt, ego_kind=ego_kind))
+        print(json.dumps(line))
+    eng.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
