@@ -91,20 +91,42 @@ typedef struct {
 } sg_scenarios;
 
 /* Device-resident state after the latest step: the arrays behind State.poses / velocities /
- * distances / collisions() (state.py:90-96, 306-310).  Entity-major SoA, index r*EP + slot with
- * EP = entity_stride.  Raw device pointers (wrap with torch/dlpack for zero-copy views). */
+ * distances / collisions() (state.py:90-96, 306-310).
+ *
+ * Layout: entity slot i = scenario * entity_stride + slot.  Entities are grouped in blocks of 64
+ * consecutive slots (the 64 lanes of one gfx950 wavefront); inside a block every field is one row of
+ * 64 eight-byte values, so a wavefront loads/stores whole 512-byte rows:
+ *     value(field f, entity i) = blocks[(i / 64) * SG_F_COUNT * 64 + f * 64 + (i % 64)]
+ * Raw device pointers (wrap with torch/dlpack for zero-copy strided views). */
+enum {
+    SG_F_POSE = 0,      /* 6 rows: x, y, z, h, p, r  (State.poses) */
+    SG_F_VEL = 6,       /* 6 rows (State.velocities) */
+    SG_F_DIST = 12,     /* State.distances */
+    SG_F_COLL = 13,     /* uint64 adjacency row of State.collisions(): bit j = slot j of the same scenario */
+    SG_F_PRESENT = 14,  /* uint64 0/1: entity in State.poses */
+    SG_F_CTRL = 15,     /* 4 rows: controller speed, e_lon_prev, e_lat_prev, e_lon_int (controller.py:100-103,198-203) */
+    SG_F_COUNT = 19
+};
+
+/* per-scenario clock, terminal flag and metric accumulators */
 typedef struct {
-    int32_t n_scenarios, n_entities, entity_stride, row_words;
-    double *pose[6];    /* [R*EP] each */
-    double *vel[6];     /* [R*EP] each */
-    double *dist;       /* [R*EP] State.distances */
-    uint64_t *coll;     /* [R*EP][row_words] adjacency rows of State.collisions() */
-    uint8_t *present;   /* [R*EP] entity in State.poses */
-    double *ctrl_state; /* [4][R*EP] speed, e_lon_prev, e_lat_prev, e_lon_int */
-    double *t;          /* [R] State.t */
-    double *prev_t;     /* [R] State.prev_t */
-    int32_t *done;      /* [R] State.is_done */
-    int32_t *n_steps;   /* [R] steps taken since reset */
+    double t, prev_t;              /* State.t, State.prev_t */
+    double ego_avg_speed;          /* EgoAvgSpeed (metrics/trajectory.py:8-28) */
+    double ego_max_speed;          /* EgoMaxSpeed (:31-48) */
+    double avg_t;                  /* EgoAvgSpeed.t */
+    double ego_distance_travelled; /* EgoDistanceTravelled (:51-66) */
+    uint64_t last_row;             /* CollisionMetric.last_timestep (metrics/collision.py:75) */
+    int32_t done;                  /* State.is_done */
+    int32_t n_steps;               /* steps since reset */
+    int32_t n_events;              /* len(CollisionMetric.collisions) */
+    int32_t rec_rows;              /* rows written to the pose record */
+    int64_t reserved;
+} sg_scenario_state;               /* 80 bytes */
+
+typedef struct {
+    int32_t n_scenarios, n_entities, entity_stride, n_blocks;
+    double *blocks;          /* [n_blocks][SG_F_COUNT][64] */
+    sg_scenario_state *scen; /* [n_scenarios] */
 } sg_state_view;
 
 /* per-scenario metric row: EgoAvgSpeed/EgoMaxSpeed/EgoDistanceTravelled (metrics/trajectory.py:8-66),

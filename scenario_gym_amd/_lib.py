@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libsgym_hip.so")
+LIB_PATH = os.environ.get("SGYM_LIB") or os.path.join(HERE, "lib", "libsgym_hip.so")  # SGYM_LIB: A/B builds
 
 SG_OK = 0
 ABI_VERSION = 1
@@ -15,6 +15,9 @@ TERM_MAX_LENGTH, TERM_COLLISION, TERM_EGO_COLLISION = 1, 2, 4
 NCTRL = 12
 (C_MAX_STEER, C_MAX_ACCEL, C_MAX_SPEED, C_ALLOW_REVERSE, C_STEER_KP, C_STEER_KD, C_ACCEL_KP,
  C_ACCEL_KD, C_ACCEL_KI) = range(9)
+
+# SG_F_* rows of a state block (include/sgym.h)
+F_POSE, F_VEL, F_DIST, F_COLL, F_PRESENT, F_CTRL, F_COUNT = 0, 6, 12, 13, 14, 15, 19
 
 # every symbol include/sgym.h declares
 SYMBOLS = (
@@ -40,10 +43,7 @@ class SgScenarios(C.Structure):
 class SgStateView(C.Structure):
     _fields_ = [
         ("n_scenarios", C.c_int32), ("n_entities", C.c_int32), ("entity_stride", C.c_int32),
-        ("row_words", C.c_int32), ("pose", C.c_void_p * 6), ("vel", C.c_void_p * 6),
-        ("dist", C.c_void_p), ("coll", C.c_void_p), ("present", C.c_void_p),
-        ("ctrl_state", C.c_void_p), ("t", C.c_void_p), ("prev_t", C.c_void_p),
-        ("done", C.c_void_p), ("n_steps", C.c_void_p),
+        ("n_blocks", C.c_int32), ("blocks", C.c_void_p), ("scen", C.c_void_p),
     ]
 
 

@@ -26,40 +26,46 @@
 
 namespace sg {
 
+// static per-entity rows (same 64-slot block layout as the dynamic state, see sgym.h)
+enum {
+    ST_BW = 0, ST_BL, ST_BCX, ST_BCY,   // BoundingBox width, length, center_x, center_y
+    ST_MIN_T, ST_MAX_T,                 // Trajectory.min_t / max_t
+    ST_KNOT_OFF,                        // int64 first row of the entity's own knots
+    ST_META,                            // int64: kind | etype << 8 | knot_n << 32
+    ST_CTRL,                            // 9 rows of controller parameters (SG_C_*)
+    ST_COUNT = ST_CTRL + 9
+};
+constexpr uint32_t ROW = 512; // bytes of one field row of a block (64 lanes x 8 B)
+
+struct ScenStatic { // per scenario, read-only
+    double t0, length;
+    int64_t grid_off;
+    int32_t grid_n, ego;
+};
+
 struct Params {
-    // geometry of the batch
-    int R, E, EP, W;
+    int R, E, EP;
     int persist;
     unsigned term_mask;
     int rec_cap, ev_cap;
-    // static scenario data (device pointers)
-    const int32_t *kind, *etype;
-    const double *bbox[4];
-    const double *min_t, *max_t;
-    const int64_t *knot_off;
-    const int32_t *knot_n;
-    const double *knots;
-    const double *ctrl[9];
-    const int32_t *ego;
-    const double *t0, *length;
-    const int64_t *grid_off;
-    const int32_t *grid_n;
-    const double *grid_t;
-    double *grid_y;
-    // mutable state
-    double *pose[6], *vel[6], *dist;
-    uint64_t *coll;
-    uint8_t *present;
-    double *cs[4];
-    double *t, *prev_t;
-    int32_t *done, *n_steps;
-    double *m_avg, *m_max, *m_t, *m_dist;
-    uint64_t *last_row;
-    int32_t *n_events;
-    sg_event *events;
+    const double *stat;      // [n_blocks][ST_COUNT][64]
+    const ScenStatic *sstat; // [R]
+    const double *knots;     // [rows][7] own knots of every entity
+    const double *grid_t;    // union knot grids, all scenarios
+    double *grid_y;          // [grid rows][6][EP] stage-1 resample
+    double *dyn;             // [n_blocks][SG_F_COUNT][64]
+    sg_scenario_state *sdyn; // [R]
+    sg_event *events;        // [R][ev_cap]
     double *rec_t, *rec_pose;
-    int32_t *rec_rows;
 };
+
+// field f of the calling lane's entity: base is the (wave-uniform) block pointer, voff = lane * 8.
+// Compiles to global_load/store with SGPR base + VGPR offset + immediate f * 512.
+template <typename T = double>
+__device__ __forceinline__ T &fld(const double *blk, uint32_t voff, int f)
+{
+    return *reinterpret_cast<T *>(reinterpret_cast<char *>(const_cast<double *>(blk)) + voff + (uint32_t)f * ROW);
+}
 
 // ------------------------------------------------------------------------------------------------
 // math
@@ -219,9 +225,9 @@ __device__ __forceinline__ void seg_advance(const Table &T, Segment &S, double t
 __device__ __forceinline__ void own_position_extrap(const double *kn, int n, double t, double (&out)[6])
 {
     if (n == 1) { // trajectory.py:175-177: knot duplicated at t + 1e-3
-        double x_lo = kn[0], x_hi = kn[0] + 1e-3;
+        double x_lo = kn[0];
         for (int c = 0; c < 6; ++c) {
-            double slope = (kn[1 + c] - kn[1 + c]) / (x_hi - x_lo);
+            double slope = kn[1 + c] - kn[1 + c]; // (y - y)/(x_hi - x_lo): +0, or NaN for a non-finite knot
             out[c] = slope * (t - x_lo) + kn[1 + c];
         }
         return;
@@ -288,12 +294,12 @@ struct CtrlState { double speed, e_lon_prev, e_lat_prev, e_lon_int; };
 
 // VehicleController._step (controller.py:105-140); sin_h/cos_h of the current heading come from
 // the previous step's corner computation.
-__device__ __forceinline__ void vehicle_step(CtrlState &cs, const Params &p, size_t idx, double l,
+__device__ __forceinline__ void vehicle_step(CtrlState &cs, const double *st, uint32_t voff, double l,
                                              double dt, double accel, double steer, double sin_h,
                                              double cos_h, double *pose)
 {
-    double max_steer = p.ctrl[SG_C_MAX_STEER][idx], max_accel = p.ctrl[SG_C_MAX_ACCEL][idx];
-    double max_speed = p.ctrl[SG_C_MAX_SPEED][idx], allow_rev = p.ctrl[SG_C_ALLOW_REVERSE][idx];
+    double max_steer = fld(st, voff, ST_CTRL + SG_C_MAX_STEER), max_accel = fld(st, voff, ST_CTRL + SG_C_MAX_ACCEL);
+    double max_speed = fld(st, voff, ST_CTRL + SG_C_MAX_SPEED), allow_rev = fld(st, voff, ST_CTRL + SG_C_ALLOW_REVERSE);
     accel = __builtin_fmin(__builtin_fmax(accel, -max_accel), max_accel);
     steer = __builtin_fmin(__builtin_fmax(steer, -max_steer), max_steer);
     double ss, sc;
@@ -311,7 +317,7 @@ __device__ __forceinline__ void vehicle_step(CtrlState &cs, const Params &p, siz
 }
 
 // PIDController._step (controller.py:205-258)
-__device__ __forceinline__ void pid_step(CtrlState &cs, const Params &p, size_t idx, double l,
+__device__ __forceinline__ void pid_step(CtrlState &cs, const double *st, uint32_t voff, double l,
                                          double state_dt, double dt, double tx, double ty,
                                          double sin_h, double cos_h, double *pose)
 {
@@ -323,62 +329,148 @@ __device__ __forceinline__ void pid_step(CtrlState &cs, const Params &p, size_t 
     else if (speed > 15) gain = 0.1;
     else gain = 1.0;
     double e_lat_D = (e_lat - cs.e_lat_prev) / state_dt;
-    double kp = p.ctrl[SG_C_STEER_KP][idx] * gain, kd = p.ctrl[SG_C_STEER_KD][idx] * gain;
+    double kp = fld(st, voff, ST_CTRL + SG_C_STEER_KP) * gain, kd = fld(st, voff, ST_CTRL + SG_C_STEER_KD) * gain;
     double steer = kp * e_lat + kd * e_lat_D;
     double e_lon_D = (e_lon - cs.e_lon_prev) / state_dt;
     double e_lon_I = cs.e_lon_int + e_lon * state_dt;
     double accel = 0.0;
     if (__builtin_fabs(e_lon) > 0.1)
-        accel = p.ctrl[SG_C_ACCEL_KP][idx] * e_lon + p.ctrl[SG_C_ACCEL_KD][idx] * e_lon_D +
-                p.ctrl[SG_C_ACCEL_KI][idx] * e_lon_I;
+        accel = fld(st, voff, ST_CTRL + SG_C_ACCEL_KP) * e_lon + fld(st, voff, ST_CTRL + SG_C_ACCEL_KD) * e_lon_D +
+                fld(st, voff, ST_CTRL + SG_C_ACCEL_KI) * e_lon_I;
     cs.e_lat_prev = e_lat;
     cs.e_lon_prev = e_lon;
     cs.e_lon_int = e_lon_I;
-    vehicle_step(cs, p, idx, l, dt, accel, steer, sin_h, cos_h, pose);
+    vehicle_step(cs, st, voff, l, dt, accel, steer, sin_h, cos_h, pose);
 }
 
 // ------------------------------------------------------------------------------------------------
 // State.collisions() for one tile (state.py:306-310 -> state/utils.py:10-49 -> utils.py:28-62).
-// Returns this lane's adjacency row (bit j = tile slot j).  lds: 9*64 doubles per wave.
+// Returns this lane's adjacency row (bit j = tile slot j).
+//
+//   broad phase  fp32 bounding circles about the box centres, all pairs inside the tile: every
+//                lane walks the tile's centres through wave-uniform LDS reads (broadcast) and the
+//                v_cmp result IS the ballot of column j; columns without a hit cost 5 VALU ops.
+//   filter       fp32 rectangle-rectangle separating-axis test (4 axes) on the candidate pairs
+//                with a conservative error margin: certain-overlap / certain-separation decide.
+//   exact        pairs inside the margin (touching, or bit-identical boxes) take the fp64
+//                8-edge test on the corners -- the same operation sequence as the CPU oracle.
+// The fp32 stages are strictly conservative, so the result equals the fp64 test on every pair.
 // ------------------------------------------------------------------------------------------------
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+struct CollLds {
+    float cx[64], cy[64]; // box centres (NaN when absent), SoA for packed-fp32 pair math
+    float2 sc[64];    // sin, cos of the heading
+    float2 half[64];  // half length, half width (static)
+    double cor[8][64]; // fp64 corners, only filled on the exact path
+    int last[64];
+};
+
 template <int G>
 __device__ __forceinline__ uint64_t tile_collisions(bool present, double x, double y, double s, double c,
-                                                    double bw, double bl, double bcx, double bcy, int lane,
-                                                    double *lds, uint64_t *mult_rows /* pre-alias row, for event multiplicity */)
+                                                    double bw, double bl, double bcx, double bcy, float rad_thr,
+                                                    int lane, CollLds &L, uint64_t *mult_rows)
 {
     const int base = lane & ~(G - 1), slot = lane & (G - 1);
-    // bounding circle about the box centre
-    double ccx = x + (bcx * c - bcy * s), ccy = y + (bcx * s + bcy * c);
-    double rad = 0.5 * __builtin_sqrt(bl * bl + bw * bw);
-    uint64_t pmask = __ballot(present);
-    uint64_t cand = 0;
-#pragma unroll 4
-    for (int j = 0; j < G; ++j) {
-        double ox = shfl_d(ccx, base + j), oy = shfl_d(ccy, base + j), orad = shfl_d(rad, base + j);
-        double dx = ox - ccx, dy = oy - ccy, rr = (orad + rad) * (1.0 + 1e-9) + 1e-9;
-        bool hit = (dx * dx + dy * dy <= rr * rr) && ((pmask >> (base + j)) & 1) && (j != slot);
-        cand |= (uint64_t)hit << j;
+    // box centre; bounding circle radius + margins live in rad_thr (static per lane)
+    const double ccx = x + (bcx * c - bcy * s), ccy = y + (bcx * s + bcy * c);
+    const float nanf_ = __builtin_nanf("");
+    const float fx = present ? (float)ccx : nanf_, fy = present ? (float)ccy : nanf_;
+    const float fs = (float)s, fc = (float)c;
+    // fp32 conversion error of the centre grows with |coordinate|: 2^-19 * (|x| + |y|) covers both lanes
+    const float mag = __builtin_fabsf(fx) + __builtin_fabsf(fy);
+    const float reach = rad_thr + 1.9073486e-6f * mag;
+    const float thr = reach * reach;
+    __syncthreads();
+    L.cx[lane] = fx;
+    L.cy[lane] = fy;
+    L.sc[lane] = make_float2(fs, fc);
+    __syncthreads();
+    // All pairs of the tile: lane i tests itself against slots j..j+3 per iteration (wave-uniform
+    // LDS broadcast reads, one ds_read_b128 per coordinate), squared distances in packed fp32
+    // (2 columns per v_pk_* op), and shifts the compare results into its candidate row through the
+    // carry chain: row = 2*row + hit is ONE v_addc_co_u32 per column (columns walked high -> low).
+    // 4 VALU ops per column, no branches, no mask constants.
+    const v2f fx2 = {fx, fx}, fy2 = {fy, fy};
+    uint32_t cand_w[2] = {0u, 0u};
+    v4f xs = *reinterpret_cast<const v4f *>(&L.cx[base + G - 4]);
+    v4f ys = *reinterpret_cast<const v4f *>(&L.cy[base + G - 4]);
+#pragma unroll
+    for (int jb = G - 4; jb >= 0; jb -= 4) {
+        v4f nxs = xs, nys = ys; // prefetch the next four slots while these are being tested
+        if (jb >= 4) {
+            nxs = *reinterpret_cast<const v4f *>(&L.cx[base + jb - 4]);
+            nys = *reinterpret_cast<const v4f *>(&L.cy[base + jb - 4]);
+        }
+        v2f dxa = v2f{xs.x, xs.y} - fx2, dya = v2f{ys.x, ys.y} - fy2;
+        v2f dxb = v2f{xs.z, xs.w} - fx2, dyb = v2f{ys.z, ys.w} - fy2;
+        v2f d2a = __builtin_elementwise_fma(dya, dya, dxa * dxa);
+        v2f d2b = __builtin_elementwise_fma(dyb, dyb, dxb * dxb);
+        uint64_t m0, m1, m2, m3;
+        // NaN (absent) compares false.  The four compares go first so that each SGPR mask is
+        // >= 3 instructions old when the add-with-carry consumes it (VALU-SGPR-write hazard).
+        asm("v_cmp_le_f32 %1, %5, %9\n\t"
+            "v_cmp_le_f32 %2, %6, %9\n\t"
+            "v_cmp_le_f32 %3, %7, %9\n\t"
+            "v_cmp_le_f32 %4, %8, %9\n\t"
+            "v_addc_co_u32 %0, vcc, %0, %0, %1\n\t"
+            "v_addc_co_u32 %0, vcc, %0, %0, %2\n\t"
+            "v_addc_co_u32 %0, vcc, %0, %0, %3\n\t"
+            "v_addc_co_u32 %0, vcc, %0, %0, %4"
+            : "+v"(cand_w[jb >> 5]), "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3)
+            : "v"(d2b.y), "v"(d2b.x), "v"(d2a.y), "v"(d2a.x), "v"(thr)
+            : "vcc");
+        xs = nxs;
+        ys = nys;
     }
+    uint64_t cand = ((uint64_t)cand_w[1] << 32) | cand_w[0];
+    cand &= ~(1ull << slot); // not with itself
     cand = present ? cand : 0;
     *mult_rows = 0;
     if (!__any(cand != 0)) return 0; // wave-uniform
+
+    const float hl = (float)(0.5 * bl), hw = (float)(0.5 * bw);
+    uint64_t rows = 0, fuzzy = 0;
+    while (__any(cand != 0)) {
+        if (cand) {
+            int j = __builtin_ctzll(cand);
+            cand &= cand - 1;
+            float2 oc = make_float2(L.cx[base + j], L.cy[base + j]), os = L.sc[base + j], oh = L.half[base + j];
+            float dx = oc.x - fx, dy = oc.y - fy;
+            float cd = __builtin_fabsf(fc * os.y + fs * os.x);  // |cos(delta heading)|
+            float sd = __builtin_fabsf(fs * os.y - fc * os.x);  // |sin(delta heading)|
+            float g0 = __builtin_fabsf(dx * fc + dy * fs) - (hl + oh.x * cd + oh.y * sd);
+            float g1 = __builtin_fabsf(dy * fc - dx * fs) - (hw + oh.x * sd + oh.y * cd);
+            float g2 = __builtin_fabsf(dx * os.y + dy * os.x) - (oh.x + hl * cd + hw * sd);
+            float g3 = __builtin_fabsf(dy * os.y - dx * os.x) - (oh.y + hl * sd + hw * cd);
+            float gap = __builtin_fmaxf(__builtin_fmaxf(g0, g1), __builtin_fmaxf(g2, g3));
+            float eps = 1e-3f + 1.9073486e-6f * (mag + __builtin_fabsf(oc.x) + __builtin_fabsf(oc.y));
+            bool unsure = !(gap > eps) && !(gap < -eps);
+            unsure = unsure || (dx == 0.0f && dy == 0.0f); // possibly bit-identical boxes
+            if (unsure) fuzzy |= 1ull << j;
+            else if (gap < -eps) rows |= 1ull << j;
+        }
+    }
+    *mult_rows = rows;
+    if (!__any(fuzzy != 0)) return rows; // wave-uniform; the rest is the rare exact path
 
     double A[8];
     sg_corners(x, y, s, c, bw, bl, bcx, bcy, A);
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < 8; ++k) lds[k * 64 + lane] = A[k];
+    for (int k = 0; k < 8; ++k) L.cor[k][lane] = A[k];
     __syncthreads();
-    uint64_t rows = 0, eq = 0;
-    while (__any(cand != 0)) {
-        if (cand) {
-            int j = __builtin_ctzll(cand);
-            cand &= cand - 1;
+    uint64_t eq = 0;
+    while (__any(fuzzy != 0)) {
+        if (fuzzy) {
+            int j = __builtin_ctzll(fuzzy);
+            fuzzy &= fuzzy - 1;
             double B[8];
             bool same = true;
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                B[k] = lds[k * 64 + base + j];
+                B[k] = L.cor[k][base + j];
                 same = same && (B[k] == A[k]);
             }
             if (same) eq |= 1ull << j;                      // g == g_prime: never listed (utils.py:59)
@@ -388,15 +480,14 @@ __device__ __forceinline__ uint64_t tile_collisions(bool present, double x, doub
     *mult_rows = rows;
     if (__any(eq != 0)) { // geometry -> LAST entity owning it (state/utils.py:32-40)
         int last = 63 - __builtin_clzll(eq | (1ull << slot));
-        int *li = (int *)(lds + 8 * 64);
         __syncthreads();
-        li[lane] = last;
+        L.last[lane] = last;
         __syncthreads();
         uint64_t nr = 0, tmp = rows;
         while (tmp) {
             int j = __builtin_ctzll(tmp);
             tmp &= tmp - 1;
-            nr |= 1ull << li[base + j];
+            nr |= 1ull << L.last[base + j];
         }
         rows = nr;
     }
@@ -414,12 +505,15 @@ __global__ void build_grid_kernel(Params p, const int32_t *row_scen /*[totalN]*/
     int e = (int)(gid - row * p.EP);
     if (row >= total_rows) return;
     int r = row_scen[row];
-    size_t idx = (size_t)r * p.EP + e;
+    uint32_t idx = (uint32_t)r * p.EP + e;
+    const double *st = p.stat + (size_t)(idx >> 6) * ST_COUNT * 64;
+    uint32_t voff = (idx & 63) * 8u;
+    int64_t meta = fld<int64_t>(st, voff, ST_META);
     double out[6] = {0, 0, 0, 0, 0, 0};
-    if (e < p.E && p.kind[idx] == SG_KIND_REPLAY) {
+    if (e < p.E && (meta & 0xff) == SG_KIND_REPLAY) {
         double tq = p.grid_t[row];
-        const double *kn = p.knots + p.knot_off[idx] * 7;
-        int n = p.knot_n[idx];
+        const double *kn = p.knots + fld<int64_t>(st, voff, ST_KNOT_OFF) * 7;
+        int n = (int)(meta >> 32);
         if (n == 1) { // batch.py:85-88: second knot at t + 0.1
             double x_lo = kn[0], x_hi = kn[0] + 1e-1;
             for (int c = 0; c < 6; ++c) {
@@ -453,63 +547,121 @@ __global__ void build_grid_kernel(Params p, const int32_t *row_scen /*[totalN]*/
 }
 
 // ------------------------------------------------------------------------------------------------
+// x / d for many numerators and one denominator.  `a / b` on gfx950 expands to
+//   v_div_scale x2, v_rcp_f64, 2 Newton steps on the reciprocal, q = a*r, e = a - b*q,
+//   v_div_fmas(e, r, q), v_div_fixup
+// which is correctly rounded.  When neither operand needs v_div_scale's rescaling (both well inside
+// the normal range) that sequence is exactly: r = refined reciprocal of b (depends on b only),
+// q0 = a*r, e = fma(-b, q0, a), q = fma(e, r, q0).  RecipDiv hoists the b-only part; callers
+// fall back to `/` when an operand is outside the safe range.
+// ------------------------------------------------------------------------------------------------
+struct RecipDiv {
+    double b, r;
+    bool ok;
+    __device__ __forceinline__ explicit RecipDiv(double den) : b(den)
+    {
+        double ab = __builtin_fabs(den);
+        ok = ab > 0x1p-500 && ab < 0x1p500;
+        double r0 = __builtin_amdgcn_rcp(den);
+        double e0 = __builtin_fma(-den, r0, 1.0);
+        double r1 = __builtin_fma(r0, e0, r0);
+        double e1 = __builtin_fma(-den, r1, 1.0);
+        r = __builtin_fma(r1, e1, r1);
+    }
+    __device__ __forceinline__ bool safe(double a) const
+    {
+        double aa = __builtin_fabs(a);
+        return ok && (aa == 0.0 || (aa > 0x1p-500 && aa < 0x1p500));
+    }
+    __device__ __forceinline__ double div(double a) const
+    {
+        double q0 = a * r;
+        double e = __builtin_fma(-b, q0, a);
+        return __builtin_fma(e, r, q0);
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
 // The rollout kernel: ScenarioGym.reset_scenario / step / rollout (scenario_gym.py:217-267) for
 // 64/G scenarios per wavefront.  do_reset: State.reset first.  force: step done scenarios too
 // (gym.step()); otherwise each scenario stops at is_done (gym.rollout()).
+//
+// Register-resident per lane across the time loop: pose, distance, the knot segment (x_lo, x_hi,
+// y_lo[6], slope[6]), the clock.  Controller state, metric accumulators and event cursors are only
+// touched by the one or two lanes that own them and live in HBM/L2.
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ Table lane_table(const Params &p, int kind, const ScenStatic &ss, int slot,
+                                            const double *st, uint32_t voff)
+{
+    Table T;
+    if (kind == SG_KIND_REPLAY) {
+        size_t go = (size_t)ss.grid_off;
+        T.x = p.grid_t + go; T.xs = 1;
+        T.y = p.grid_y + go * 6 * p.EP + slot; T.ys = 6 * p.EP; T.cs = p.EP;
+        T.n = ss.grid_n;
+    } else if (kind >= SG_KIND_AGENT_REPLAY) {
+        const double *kn = p.knots + fld<int64_t>(st, voff, ST_KNOT_OFF) * 7;
+        T.x = kn; T.xs = 7; T.y = kn + 1; T.ys = 7; T.cs = 1;
+        T.n = (int)(fld<int64_t>(st, voff, ST_META) >> 32);
+    } else {
+        T.x = nullptr; T.y = nullptr; T.n = 0; T.xs = T.ys = T.cs = 0;
+    }
+    return T;
+}
+
 template <int G>
 __global__ __launch_bounds__(64, SG_WAVES_PER_SIMD) void rollout_kernel(Params p, double timestep, int n_steps, int do_reset,
                                                      int force, const double *actions /*[n][R][2]*/)
 {
-    __shared__ double lds[9 * 64];
+    __shared__ CollLds lds;
     const int lane = threadIdx.x;
+    const uint32_t voff = lane * 8u;
+    // one wavefront = one 64-slot block of the state arrays: wave-uniform block pointers
+    const double *st = p.stat + (size_t)blockIdx.x * (ST_COUNT * 64);
+    double *dy = p.dyn + (size_t)blockIdx.x * (SG_F_COUNT * 64);
     const int gl = blockIdx.x * 64 + lane;
     const int r_raw = gl / G, slot = gl & (G - 1), base = lane & ~(G - 1);
     const bool in_range = r_raw < p.R;
-    const int r = in_range ? r_raw : p.R - 1;
-    const size_t idx = (size_t)r * p.EP + slot;
-    const int kind = (in_range && slot < p.E) ? p.kind[idx] : SG_KIND_NONE;
-    const int ego = p.ego[r];
-    const bool is_ego = in_range && slot == ego;
-    const double bw = p.bbox[0][idx], bl = p.bbox[1][idx], bcx = p.bbox[2][idx], bcy = p.bbox[3][idx];
-    const double min_t = p.min_t[idx], max_t = p.max_t[idx];
-    const int nk = p.knot_n[idx];
-    const double *kn = p.knots + p.knot_off[idx] * 7;
-    const bool is_static = nk == 1;
-    const double length = p.length[r];
+    const uint32_t r = in_range ? r_raw : p.R - 1;
+    const ScenStatic &ss = p.sstat[r];
+    sg_scenario_state &sd = p.sdyn[r];
+    const int64_t meta = fld<int64_t>(st, voff, ST_META);
+    const int kind = (in_range && slot < p.E) ? (int)(meta & 0xff) : SG_KIND_NONE;
+    const bool is_ego = in_range && slot == ss.ego;
+    const double bcx = fld(st, voff, ST_BCX), bcy = fld(st, voff, ST_BCY);
+    const double min_t = fld(st, voff, ST_MIN_T), max_t = fld(st, voff, ST_MAX_T);
+    const bool is_static = (int)(meta >> 32) == 1;
     const bool is_agent = kind >= SG_KIND_AGENT_REPLAY;
-
-    Table T;
-    if (kind == SG_KIND_REPLAY) {
-        size_t go = (size_t)p.grid_off[r];
-        T.x = p.grid_t + go; T.xs = 1;
-        T.y = p.grid_y + go * 6 * p.EP + slot; T.ys = 6 * p.EP; T.cs = p.EP;
-        T.n = p.grid_n[r];
-    } else if (is_agent) {
-        T.x = kn; T.xs = 7; T.y = kn + 1; T.ys = 7; T.cs = 1; T.n = nk;
-    } else {
-        T.x = nullptr; T.y = nullptr; T.n = 0; T.xs = T.ys = T.cs = 0;
+    // broad-phase reach of this lane: own bounding-circle radius + the largest radius in the tile + slack
+    float rad_thr;
+    {
+        const double bw = fld(st, voff, ST_BW), bl = fld(st, voff, ST_BL);
+        float rad = (float)(0.5 * __builtin_sqrt(bl * bl + bw * bw)) * 1.000001f;
+        float rmax = rad;
+#pragma unroll
+        for (int o = 1; o < G; o <<= 1) rmax = __builtin_fmaxf(rmax, __shfl_xor(rmax, o, 64));
+        rad_thr = rad + rmax + 2e-3f;
+        lds.half[lane] = make_float2((float)(0.5 * bl), (float)(0.5 * bw));
     }
 
-    double pose[6], vel[6], dist, t, prev_t;
-    CtrlState cs;
+    double pose[6], dist, t, prev_t;
     bool present;
     int done, steps;
-    double m_avg, m_max, m_t, m_dist;
-    uint64_t last_row, row = 0;
-    int n_ev;
+    uint64_t row = 0, mult_rows = 0;
     double sin_h, cos_h;
 
     if (do_reset) {
         // ---- State.reset(t0), state.py:106-143 ----
-        t = p.t0[r];
+        const double *kn = p.knots + fld<int64_t>(st, voff, ST_KNOT_OFF) * 7;
+        const int nk = (int)(meta >> 32);
+        double vel[6];
+        t = ss.t0;
         present = false;
 #pragma unroll
         for (int c = 0; c < 6; ++c) { pose[c] = 0.0; vel[c] = 0.0; }
         if (kind != SG_KIND_NONE) {
             bool inside = (t >= min_t) && (t <= max_t);
-            if (is_static) { own_position_extrap(kn, nk, t, pose); present = true; }
-            else if (inside) { own_position_extrap(kn, nk, t, pose); present = true; }
+            if (is_static || inside) { own_position_extrap(kn, nk, t, pose); present = true; }
             else if (p.persist) { // extrapolate=(False, False): clamp
                 const double *rowp = t < min_t ? kn : kn + (size_t)(nk - 1) * 7;
                 for (int c = 0; c < 6; ++c) pose[c] = rowp[1 + c];
@@ -525,59 +677,56 @@ __global__ __launch_bounds__(64, SG_WAVES_PER_SIMD) void rollout_kernel(Params p
         }
         prev_t = t - 0.1; // state.py:135
         dist = 0.0;
-        cs.speed = present ? sg_norm2(vel[0], vel[1]) : 0.0; // controller.py:100-103
-        cs.e_lon_prev = cs.e_lat_prev = cs.e_lon_int = 0.0;   // controller.py:198-203
         done = 0;
         steps = 0;
-        double v0 = sg_norm3(vel[0], vel[1], vel[2]); // metrics/trajectory.py:13-17, 36-39
-        m_avg = m_max = present ? v0 : __builtin_nan("");
-        m_t = 0.0;
-        m_dist = __builtin_nan("");
-        last_row = 0;
-        n_ev = 0;
-    } else {
-        t = p.t[r];
-        prev_t = p.prev_t[r];
-        present = p.present[idx] != 0;
+        sg_sincos(pose[3], sin_h, cos_h);
+        row = tile_collisions<G>(present, pose[0], pose[1], sin_h, cos_h, fld(st, voff, ST_BW), fld(st, voff, ST_BL),
+                                 bcx, bcy, rad_thr, lane, lds, &mult_rows);
+        if (in_range) {
 #pragma unroll
-        for (int c = 0; c < 6; ++c) { pose[c] = p.pose[c][idx]; vel[c] = p.vel[c][idx]; }
-        dist = p.dist[idx];
-        cs.speed = p.cs[0][idx]; cs.e_lon_prev = p.cs[1][idx];
-        cs.e_lat_prev = p.cs[2][idx]; cs.e_lon_int = p.cs[3][idx];
-        done = p.done[r];
-        steps = p.n_steps[r];
-        m_avg = p.m_avg[r]; m_max = p.m_max[r]; m_t = p.m_t[r]; m_dist = p.m_dist[r];
-        last_row = p.last_row[r];
-        n_ev = p.n_events[r];
-    }
-    sg_sincos(pose[3], sin_h, cos_h);
-
-    Segment S;
-    S.cur = seg_locate(T, t);
-    seg_load(T, S);
-
-    uint64_t mult_rows = 0;
-    if (do_reset) {
-        row = tile_collisions<G>(present, pose[0], pose[1], sin_h, cos_h, bw, bl, bcx, bcy, lane, lds, &mult_rows);
-        if (in_range && slot < p.EP) {
-#pragma unroll
-            for (int c = 0; c < 6; ++c) { p.pose[c][idx] = pose[c]; p.vel[c][idx] = vel[c]; }
-            p.dist[idx] = dist;
-            p.coll[idx] = row;
-            p.present[idx] = present;
-            p.cs[0][idx] = cs.speed; p.cs[1][idx] = 0.0; p.cs[2][idx] = 0.0; p.cs[3][idx] = 0.0;
+            for (int c = 0; c < 6; ++c) { fld(dy, voff, SG_F_POSE + c) = pose[c]; fld(dy, voff, SG_F_VEL + c) = vel[c]; }
+            fld(dy, voff, SG_F_DIST) = dist;
+            fld<uint64_t>(dy, voff, SG_F_COLL) = row;
+            fld<uint64_t>(dy, voff, SG_F_PRESENT) = present;
+            fld(dy, voff, SG_F_CTRL + 0) = present ? sg_norm2(vel[0], vel[1]) : 0.0; // controller.py:100-103
+            fld(dy, voff, SG_F_CTRL + 1) = 0.0; // controller.py:198-203
+            fld(dy, voff, SG_F_CTRL + 2) = 0.0;
+            fld(dy, voff, SG_F_CTRL + 3) = 0.0;
             if (p.rec_cap > 0) {
 #pragma unroll
                 for (int c = 0; c < 6; ++c)
-                    p.rec_pose[((size_t)0 * 6 + c) * p.R * p.EP + idx] = present ? pose[c] : __builtin_nan("");
+                    p.rec_pose[(size_t)c * p.R * p.EP + (size_t)r * p.EP + slot] = present ? pose[c] : __builtin_nan("");
             }
             if (slot == 0) {
-                p.t[r] = t; p.prev_t[r] = prev_t; p.done[r] = 0; p.n_steps[r] = 0;
-                p.n_events[r] = 0; p.last_row[r] = 0;
-                if (p.rec_cap > 0) { p.rec_t[r] = t; p.rec_rows[r] = 1; }
+                sd.t = t; sd.prev_t = prev_t; sd.done = 0; sd.n_steps = 0;
+                sd.rec_rows = p.rec_cap > 0 ? 1 : 0;
+                if (p.rec_cap > 0) p.rec_t[r] = t;
             }
-            if (is_ego) { p.m_avg[r] = m_avg; p.m_max[r] = m_max; p.m_t[r] = 0.0; p.m_dist[r] = m_dist; }
+            if (is_ego) { // metrics/trajectory.py:13-17, 36-39; metrics/collision.py:64-68
+                double v0 = present ? sg_norm3(vel[0], vel[1], vel[2]) : __builtin_nan("");
+                sd.ego_avg_speed = v0; sd.ego_max_speed = v0; sd.avg_t = 0.0;
+                sd.ego_distance_travelled = __builtin_nan("");
+                sd.last_row = 0; sd.n_events = 0;
+            }
         }
+    } else {
+        t = sd.t;
+        prev_t = sd.prev_t;
+        present = fld<uint64_t>(dy, voff, SG_F_PRESENT) != 0;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) pose[c] = fld(dy, voff, SG_F_POSE + c);
+        dist = fld(dy, voff, SG_F_DIST);
+        done = sd.done;
+        steps = sd.n_steps;
+        row = fld<uint64_t>(dy, voff, SG_F_COLL);
+        sg_sincos(pose[3], sin_h, cos_h);
+    }
+
+    Segment S;
+    {
+        Table T = lane_table(p, kind, ss, slot, st, voff);
+        S.cur = seg_locate(T, t);
+        seg_load(T, S);
     }
 
     for (int k = 0; k < n_steps; ++k) {
@@ -586,36 +735,42 @@ __global__ __launch_bounds__(64, SG_WAVES_PER_SIMD) void rollout_kernel(Params p
 
         const double next_t = t + timestep; // scenario_gym.py:229
         const double state_dt = t - prev_t; // State.dt, state.py:198-201
-        const double dt = next_t - t;       // = new State.dt after the step
-        seg_advance(T, S, next_t);
-        double tgt[6];
+        const double dt = next_t - t;       // = State.dt after this step
+        if (next_t > S.x_hi) {
+            Table T = lane_table(p, kind, ss, slot, st, voff);
+            seg_advance(T, S, next_t);
+        }
+        double np_[6];
         {
             double dq = next_t - S.x_lo;
 #pragma unroll
-            for (int c = 0; c < 6; ++c) tgt[c] = S.sl[c] * dq + S.ylo[c];
+            for (int c = 0; c < 6; ++c) np_[c] = S.sl[c] * dq + S.ylo[c];
         }
 
         // ---- new poses: scenario_gym.py:233-245 ----
-        double np_[6];
         bool npres = false;
-#pragma unroll
-        for (int c = 0; c < 6; ++c) np_[c] = tgt[c];
-        CtrlState ncs = cs;
         if (kind == SG_KIND_REPLAY) { // BatchReplayEntity.step, batch.py:34-53
             npres = p.persist || is_static || (next_t >= min_t && next_t <= max_t);
         } else if (is_agent) {
             if (present) {
                 npres = true;
-                if (kind != SG_KIND_AGENT_REPLAY) {
+                if (kind != SG_KIND_AGENT_REPLAY && run) {
+                    const double tx = np_[0], ty = np_[1];
 #pragma unroll
                     for (int c = 0; c < 6; ++c) np_[c] = pose[c];
+                    CtrlState cs;
+                    cs.speed = fld(dy, voff, SG_F_CTRL + 0); cs.e_lon_prev = fld(dy, voff, SG_F_CTRL + 1);
+                    cs.e_lat_prev = fld(dy, voff, SG_F_CTRL + 2); cs.e_lon_int = fld(dy, voff, SG_F_CTRL + 3);
+                    const double bl = fld(st, voff, ST_BL);
                     if (kind == SG_KIND_AGENT_PID) {
-                        pid_step(ncs, p, idx, bl, state_dt, dt, tgt[0], tgt[1], sin_h, cos_h, np_);
+                        pid_step(cs, st, voff, bl, state_dt, dt, tx, ty, sin_h, cos_h, np_);
                     } else {
                         const double *a = actions + ((size_t)k * p.R + r) * 2;
                         double accel = actions ? a[0] : 0.0, steer = actions ? a[1] : 0.0;
-                        vehicle_step(ncs, p, idx, bl, dt, accel, steer, sin_h, cos_h, np_);
+                        vehicle_step(cs, st, voff, bl, dt, accel, steer, sin_h, cos_h, np_);
                     }
+                    fld(dy, voff, SG_F_CTRL + 0) = cs.speed; fld(dy, voff, SG_F_CTRL + 1) = cs.e_lon_prev;
+                    fld(dy, voff, SG_F_CTRL + 2) = cs.e_lat_prev; fld(dy, voff, SG_F_CTRL + 3) = cs.e_lon_int;
                 }
             } else if (min_t >= t) { // scenario_gym.py:240-244: spawn at trajectory start
                 npres = true;
@@ -623,26 +778,39 @@ __global__ __launch_bounds__(64, SG_WAVES_PER_SIMD) void rollout_kernel(Params p
         }
 
         // ---- State.update_poses / update_statistics, state.py:203-239 ----
-        double prev[6];
+        double d[6];
+        if (npres && !present) { // newcomer: previous pose from the extrapolated trajectory, state.py:219-222
+            double prev[6];
+            own_position_extrap(p.knots + fld<int64_t>(st, voff, ST_KNOT_OFF) * 7,
+                                (int)(fld<int64_t>(st, voff, ST_META) >> 32), t, prev);
 #pragma unroll
-        for (int c = 0; c < 6; ++c) prev[c] = pose[c];
-        if (npres && !present) own_position_extrap(kn, nk, t, prev); // newcomer, state.py:219-222
-        double d[6], nvel[6];
+            for (int c = 0; c < 6; ++c) d[c] = np_[c] - prev[c];
+        } else {
 #pragma unroll
-        for (int c = 0; c < 6; ++c) {
-            d[c] = np_[c] - prev[c];
-            nvel[c] = d[c] / dt;
+            for (int c = 0; c < 6; ++c) d[c] = np_[c] - pose[c];
         }
-        double ndist = dist + sg_norm3(d[0], d[1], d[2]);
+        double vel[6];
+        {
+            RecipDiv rd(dt);
+            bool safe = true;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) safe = safe && rd.safe(d[c]);
+            if (__all(safe)) {
+#pragma unroll
+                for (int c = 0; c < 6; ++c) vel[c] = rd.div(d[c]);
+            } else {
+#pragma unroll
+                for (int c = 0; c < 6; ++c) vel[c] = d[c] / dt;
+            }
+        }
 
         // commit (lanes of scenarios that are already done keep their state)
         if (run) {
             present = npres;
-            cs = ncs;
             if (npres) {
 #pragma unroll
-                for (int c = 0; c < 6; ++c) { pose[c] = np_[c]; vel[c] = nvel[c]; }
-                dist = ndist;
+                for (int c = 0; c < 6; ++c) pose[c] = np_[c];
+                dist += sg_norm3(d[0], d[1], d[2]);
             }
             prev_t = t;
             t = next_t;
@@ -651,78 +819,86 @@ __global__ __launch_bounds__(64, SG_WAVES_PER_SIMD) void rollout_kernel(Params p
         sg_sincos(pose[3], sin_h, cos_h);
 
         // ---- State.collisions ----
-        uint64_t nrow = tile_collisions<G>(present, pose[0], pose[1], sin_h, cos_h, bw, bl, bcx, bcy, lane, lds, &mult_rows);
+        uint64_t nrow = tile_collisions<G>(present, pose[0], pose[1], sin_h, cos_h, fld(st, voff, ST_BW),
+                                           fld(st, voff, ST_BL), bcx, bcy, rad_thr, lane, lds, &mult_rows);
         if (run) row = nrow;
 
         // ---- check_terminal, state.py:268-270, 397-408 ----
         int ndone = 0;
-        if ((p.term_mask & SG_TERM_MAX_LENGTH) && (t + dt > length)) ndone = 1;
-        uint64_t any_row = __ballot(row != 0) >> base;
-        if (G < 64) any_row &= (1ull << (G & 63)) - 1;
-        if ((p.term_mask & SG_TERM_COLLISION) && any_row) ndone = 1;
-        uint64_t row0 = __shfl(row, base, 64);
-        bool pres0 = (__ballot(present) >> base) & 1;
-        if ((p.term_mask & SG_TERM_EGO_COLLISION) && pres0 && row0) ndone = 1;
+        if ((p.term_mask & SG_TERM_MAX_LENGTH) && (t + dt > ss.length)) ndone = 1;
+        if (p.term_mask & (SG_TERM_COLLISION | SG_TERM_EGO_COLLISION)) {
+            uint64_t any_row = __ballot(row != 0) >> base;
+            if (G < 64) any_row &= (1ull << (G & 63)) - 1;
+            if ((p.term_mask & SG_TERM_COLLISION) && any_row) ndone = 1;
+            uint64_t row0 = __shfl(row, base, 64);
+            bool pres0 = (__ballot(present) >> base) & 1;
+            if ((p.term_mask & SG_TERM_EGO_COLLISION) && pres0 && row0) ndone = 1;
+        }
         if (run) done = ndone;
 
-        // ---- metrics, scenario_gym.py:251-252 (ego lane only) ----
+        // ---- metrics, scenario_gym.py:251-252 (ego lane only; accumulators live in memory) ----
         if (run && is_ego && present) {
             double speed = sg_norm3(vel[0], vel[1], vel[2]);
+            double m_t = sd.avg_t, m_avg = sd.ego_avg_speed;
             double w = m_t / t; // EgoAvgSpeed._step, metrics/trajectory.py:19-24
             m_avg += (1.0 - w) * (speed - m_avg);
-            m_t = t;
-            m_max = __builtin_fmax(speed, m_max); // EgoMaxSpeed, :41-44
-            m_dist = dist;                         // EgoDistanceTravelled, :60-62
-            uint64_t fresh = row & ~last_row;      // CollisionMetric._step, metrics/collision.py:70-75
-            while (fresh) {
-                int j = __builtin_ctzll(fresh);
-                fresh &= fresh - 1;
-                int mult = 1;
-                if (mult_rows != row) { // aliased geometries are listed once per owner
-                    mult = 0;
-                    const int *li = (const int *)(lds + 8 * 64);
-                    uint64_t tmp = mult_rows;
-                    while (tmp) { int q = __builtin_ctzll(tmp); tmp &= tmp - 1; mult += li[base + q] == j; }
-                }
-                for (int q = 0; q < mult; ++q) {
-                    if (n_ev < p.ev_cap) {
-                        sg_event ev;
-                        ev.t = t; ev.scenario = r; ev.other = j;
-                        ev.type = p.etype[(size_t)r * p.EP + j] == 0 ? -1 : 5;
-                        ev.reserved = 0;
-                        p.events[(size_t)r * p.ev_cap + n_ev] = ev;
+            sd.ego_avg_speed = m_avg;
+            sd.avg_t = t;
+            sd.ego_max_speed = __builtin_fmax(speed, sd.ego_max_speed); // EgoMaxSpeed, :41-44
+            sd.ego_distance_travelled = dist;                            // EgoDistanceTravelled, :60-62
+            uint64_t last_row = sd.last_row;
+            uint64_t fresh = row & ~last_row;                  // CollisionMetric._step, metrics/collision.py:70-75
+            if (fresh) {
+                int n_ev = sd.n_events;
+                while (fresh) {
+                    int j = __builtin_ctzll(fresh);
+                    fresh &= fresh - 1;
+                    int mult = 1;
+                    if (mult_rows != row) { // aliased geometries are listed once per owner
+                        mult = 0;
+                        uint64_t tmp = mult_rows;
+                        while (tmp) { int q = __builtin_ctzll(tmp); tmp &= tmp - 1; mult += lds.last[base + q] == j; }
                     }
-                    ++n_ev;
+                    // catalog type of the other entity (same block: lanes base + j)
+                    int64_t ometa = fld<int64_t>(st, (uint32_t)(base + j) * 8u, ST_META);
+                    for (int q = 0; q < mult; ++q) {
+                        if (n_ev < p.ev_cap) {
+                            sg_event ev;
+                            ev.t = t; ev.scenario = r; ev.other = j;
+                            ev.type = ((ometa >> 8) & 0xff) == 0 ? -1 : 5;
+                            ev.reserved = 0;
+                            p.events[(size_t)r * p.ev_cap + n_ev] = ev;
+                        }
+                        ++n_ev;
+                    }
                 }
+                sd.n_events = n_ev;
             }
-            last_row = row;
+            if (row != last_row) sd.last_row = row;
         }
 
         // ---- step-materialised state ----
         if (run) {
 #pragma unroll
-            for (int c = 0; c < 6; ++c) { p.pose[c][idx] = pose[c]; p.vel[c][idx] = vel[c]; }
-            p.dist[idx] = dist;
-            p.coll[idx] = row;
-            p.present[idx] = present;
+            for (int c = 0; c < 6; ++c) fld(dy, voff, SG_F_POSE + c) = pose[c];
+            if (present) {
+#pragma unroll
+                for (int c = 0; c < 6; ++c) fld(dy, voff, SG_F_VEL + c) = vel[c];
+            }
+            fld(dy, voff, SG_F_DIST) = dist;
+            fld<uint64_t>(dy, voff, SG_F_COLL) = row;
+            fld<uint64_t>(dy, voff, SG_F_PRESENT) = present;
             if (p.rec_cap > 0 && steps < p.rec_cap) {
 #pragma unroll
                 for (int c = 0; c < 6; ++c)
-                    p.rec_pose[((size_t)steps * 6 + c) * p.R * p.EP + idx] = present ? pose[c] : __builtin_nan("");
-                if (slot == 0) { p.rec_t[(size_t)steps * p.R + r] = t; p.rec_rows[r] = steps + 1; }
+                    p.rec_pose[((size_t)steps * 6 + c) * p.R * p.EP + (size_t)r * p.EP + slot] =
+                        present ? pose[c] : __builtin_nan("");
+                if (slot == 0) { p.rec_t[(size_t)steps * p.R + r] = t; sd.rec_rows = steps + 1; }
             }
         }
     }
 
-    if (in_range) {
-        p.cs[0][idx] = cs.speed; p.cs[1][idx] = cs.e_lon_prev;
-        p.cs[2][idx] = cs.e_lat_prev; p.cs[3][idx] = cs.e_lon_int;
-        if (slot == 0) { p.t[r] = t; p.prev_t[r] = prev_t; p.done[r] = done; p.n_steps[r] = steps; }
-        if (is_ego) {
-            p.m_avg[r] = m_avg; p.m_max[r] = m_max; p.m_t[r] = m_t; p.m_dist[r] = m_dist;
-            p.last_row[r] = last_row; p.n_events[r] = n_ev;
-        }
-    }
+    if (in_range && slot == 0) { sd.t = t; sd.prev_t = prev_t; sd.done = done; sd.n_steps = steps; }
 }
 
 } // namespace sg

@@ -174,18 +174,23 @@ extern "C" int sg_upload(sg_handle *h, const sg_scenarios *sc)
     const int R = h->R, E = h->E, EP = h->EP;
     const size_t NE = h->NE;
 
-    // ---- validate + SoA re-layout (host) ----
-    std::vector<int32_t> kind(NE, SG_KIND_NONE), etype(NE, 2), knot_n(NE, 0), ego(R);
-    std::vector<int64_t> knot_off(NE, 0);
-    std::vector<double> bbox[4], ctrl[9], min_t(NE, 0.0), max_t(NE, 0.0), t0(R), length(R);
-    for (auto &v : bbox) v.assign(NE, 1.0);
-    for (int k = 0; k < 9; ++k) ctrl[k].assign(NE, kDefaultCtrl[k]);
+    // ---- validate + block re-layout (host): [n_blocks][ST_COUNT][64] ----
+    const size_t nblk = NE / 64;
+    std::vector<double> stat(nblk * sg::ST_COUNT * 64, 0.0);
+    auto S = [&](size_t ent, int f) -> double & { return stat[(ent >> 6) * sg::ST_COUNT * 64 + (size_t)f * 64 + (ent & 63)]; };
+    auto SI = [&](size_t ent, int f) -> int64_t & { return *reinterpret_cast<int64_t *>(&S(ent, f)); };
+    for (size_t o = 0; o < NE; ++o) {
+        for (int q = 0; q < 4; ++q) S(o, sg::ST_BW + q) = 1.0;
+        for (int q = 0; q < 9; ++q) S(o, sg::ST_CTRL + q) = kDefaultCtrl[q];
+        SI(o, sg::ST_META) = SG_KIND_NONE | (2 << 8);
+    }
+    std::vector<sg::ScenStatic> sstat(R);
     const int64_t rows_total = sc->knot_off[(size_t)R * E];
     for (int r = 0; r < R; ++r) {
         if (sc->ego[r] < 0 || sc->ego[r] >= E) return fail(h, SG_ERR_INVALID, "sg_upload: ego[%d]=%d out of range", r, sc->ego[r]);
-        ego[r] = sc->ego[r];
-        t0[r] = sc->t0[r];
-        length[r] = sc->length[r];
+        sstat[r].ego = sc->ego[r];
+        sstat[r].t0 = sc->t0[r];
+        sstat[r].length = sc->length[r];
         for (int e = 0; e < E; ++e) {
             size_t i = (size_t)r * E + e, o = (size_t)r * EP + e;
             int k = sc->kind[i];
@@ -193,15 +198,13 @@ extern "C" int sg_upload(sg_handle *h, const sg_scenarios *sc)
             int64_t a = sc->knot_off[i], b = sc->knot_off[i + 1];
             if (a < 0 || b < a || b > rows_total) return fail(h, SG_ERR_INVALID, "sg_upload: knot_off not monotone at %zu", i);
             if (k != SG_KIND_NONE && b == a) return fail(h, SG_ERR_INVALID, "sg_upload: entity %zu has no knots", i);
-            kind[o] = k;
-            etype[o] = sc->etype[i];
-            knot_off[o] = a;
-            knot_n[o] = (int32_t)(b - a);
-            for (int q = 0; q < 4; ++q) bbox[q][o] = sc->bbox[i * 4 + q];
-            if (sc->ctrl) for (int q = 0; q < 9; ++q) ctrl[q][o] = sc->ctrl[i * SG_NCTRL + q];
+            SI(o, sg::ST_META) = (int64_t)k | ((int64_t)(sc->etype[i] & 0xff) << 8) | ((int64_t)(b - a) << 32);
+            SI(o, sg::ST_KNOT_OFF) = a;
+            for (int q = 0; q < 4; ++q) S(o, sg::ST_BW + q) = sc->bbox[i * 4 + q];
+            if (sc->ctrl) for (int q = 0; q < 9; ++q) S(o, sg::ST_CTRL + q) = sc->ctrl[i * SG_NCTRL + q];
             if (b > a) {
-                min_t[o] = sc->knots[(size_t)a * 7];
-                max_t[o] = sc->knots[(size_t)(b - 1) * 7];
+                S(o, sg::ST_MIN_T) = sc->knots[(size_t)a * 7];
+                S(o, sg::ST_MAX_T) = sc->knots[(size_t)(b - 1) * 7];
                 for (int64_t j = a + 1; j < b; ++j)
                     if (!(sc->knots[(size_t)j * 7] > sc->knots[(size_t)(j - 1) * 7]))
                         return fail(h, SG_ERR_INVALID, "sg_upload: knot times of entity %zu are not strictly increasing", i);
@@ -235,10 +238,10 @@ extern "C" int sg_upload(sg_handle *h, const sg_scenarios *sc)
         for (auto &th : pool) th.join();
     }
     std::vector<int64_t> grid_off(R + 1, 0);
-    std::vector<int32_t> grid_n(R);
     for (int r = 0; r < R; ++r) {
-        grid_n[r] = (int32_t)grids[r].size();
-        grid_off[r + 1] = grid_off[r] + grid_n[r];
+        sstat[r].grid_n = (int32_t)grids[r].size();
+        sstat[r].grid_off = grid_off[r];
+        grid_off[r + 1] = grid_off[r] + sstat[r].grid_n;
     }
     const int64_t total_rows = grid_off[R];
     std::vector<double> grid_t((size_t)total_rows);
@@ -247,51 +250,38 @@ extern "C" int sg_upload(sg_handle *h, const sg_scenarios *sc)
         std::copy(grids[r].begin(), grids[r].end(), grid_t.begin() + grid_off[r]);
         std::fill(row_scen.begin() + grid_off[r], row_scen.begin() + grid_off[r + 1], r);
     }
-    grid_off.pop_back();
 
     // ---- device copies ----
     Params &p = h->p;
     p = Params{};
-    p.R = R; p.E = E; p.EP = EP; p.W = 1;
+    p.R = R; p.E = E; p.EP = EP;
     p.persist = h->cfg.persist;
     p.term_mask = h->cfg.terminal_mask;
     p.rec_cap = h->cfg.record_capacity > 0 ? h->cfg.record_capacity : 0;
     p.ev_cap = h->cfg.event_capacity > 0 ? h->cfg.event_capacity : 0;
-    auto &S = h->static_allocs;
+    auto &SA = h->static_allocs;
     int rc = 0;
-#define UP(field, vec) if ((rc = dev_upload(h, S, &p.field, vec))) return rc
-    UP(kind, kind); UP(etype, etype);
-    for (int q = 0; q < 4; ++q) UP(bbox[q], bbox[q]);
-    UP(min_t, min_t); UP(max_t, max_t); UP(knot_off, knot_off); UP(knot_n, knot_n);
-    for (int q = 0; q < 9; ++q) UP(ctrl[q], ctrl[q]);
-    UP(ego, ego); UP(t0, t0); UP(length, length);
-    UP(grid_off, grid_off); UP(grid_n, grid_n); UP(grid_t, grid_t);
-#undef UP
+    if ((rc = dev_upload(h, SA, &p.stat, stat))) return rc;
+    if ((rc = dev_upload(h, SA, &p.sstat, sstat))) return rc;
+    if ((rc = dev_upload(h, SA, &p.grid_t, grid_t))) return rc;
     {
         double *d = nullptr;
-        if ((rc = dev_alloc(h, S, &d, (size_t)std::max<int64_t>(rows_total, 1) * 7, false))) return rc;
+        if ((rc = dev_alloc(h, SA, &d, (size_t)std::max<int64_t>(rows_total, 1) * 7, false))) return rc;
         if (rows_total > 0)
             HIP_TRY(h, hipMemcpyAsync(d, sc->knots, (size_t)rows_total * 7 * sizeof(double), hipMemcpyHostToDevice, h->stream));
         p.knots = d;
         const int32_t *drs = nullptr;
-        if ((rc = dev_upload(h, S, &drs, row_scen))) return rc;
+        if ((rc = dev_upload(h, SA, &drs, row_scen))) return rc;
         h->d_row_scen = const_cast<int32_t *>(drs);
         h->total_rows = total_rows;
-        if ((rc = dev_alloc(h, S, &p.grid_y, (size_t)total_rows * 6 * EP, false))) return rc;
+        if ((rc = dev_alloc(h, SA, &p.grid_y, (size_t)total_rows * 6 * EP, false))) return rc;
     }
     auto &M = h->state_allocs;
-#define AL(field, n) if ((rc = dev_alloc(h, M, &p.field, (n)))) return rc
-    for (int c = 0; c < 6; ++c) { AL(pose[c], NE); AL(vel[c], NE); }
-    AL(dist, NE); AL(coll, NE); AL(present, NE);
-    AL(cs[0], 4 * NE); // one block [4][NE]: speed, e_lon_prev, e_lat_prev, e_lon_int
-    for (int c = 1; c < 4; ++c) p.cs[c] = p.cs[0] + (size_t)c * NE;
-    AL(t, R); AL(prev_t, R); AL(done, R); AL(n_steps, R);
-    AL(m_avg, R); AL(m_max, R); AL(m_t, R); AL(m_dist, R); AL(last_row, R); AL(n_events, R);
-    AL(events, (size_t)R * std::max(p.ev_cap, 1));
-    AL(rec_t, (size_t)std::max(p.rec_cap, 1) * R);
-    AL(rec_pose, (size_t)std::max(p.rec_cap, 0) * 6 * R * EP + 1);
-    AL(rec_rows, R);
-#undef AL
+    if ((rc = dev_alloc(h, M, &p.dyn, nblk * SG_F_COUNT * 64))) return rc;
+    if ((rc = dev_alloc(h, M, &p.sdyn, (size_t)R))) return rc;
+    if ((rc = dev_alloc(h, M, &p.events, (size_t)R * std::max(p.ev_cap, 1)))) return rc;
+    if ((rc = dev_alloc(h, M, &p.rec_t, (size_t)std::max(p.rec_cap, 1) * R))) return rc;
+    if ((rc = dev_alloc(h, M, &p.rec_pose, (size_t)std::max(p.rec_cap, 0) * 6 * R * EP + 1))) return rc;
 
     // stage-1 resample on device
     if (total_rows > 0) {
@@ -392,12 +382,10 @@ extern "C" int sg_state_view_get(sg_handle *h, sg_state_view *out)
 {
     if (!h || !out) return SG_ERR_INVALID;
     if (!h->uploaded) return fail(h, SG_ERR_STATE, "sg_state_view_get: no scenarios uploaded");
-    const Params &p = h->p;
-    out->n_scenarios = h->R; out->n_entities = h->E; out->entity_stride = h->EP; out->row_words = 1;
-    for (int c = 0; c < 6; ++c) { out->pose[c] = p.pose[c]; out->vel[c] = p.vel[c]; }
-    out->dist = p.dist; out->coll = p.coll; out->present = p.present;
-    out->ctrl_state = p.cs[0];
-    out->t = p.t; out->prev_t = p.prev_t; out->done = p.done; out->n_steps = p.n_steps;
+    out->n_scenarios = h->R; out->n_entities = h->E; out->entity_stride = h->EP;
+    out->n_blocks = (int32_t)(h->NE / 64);
+    out->blocks = h->p.dyn;
+    out->scen = h->p.sdyn;
     return SG_OK;
 }
 
@@ -409,31 +397,26 @@ extern "C" int sg_read_metrics(sg_handle *h, sg_metrics *out, sg_event *events, 
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     const int R = h->R;
     const Params &p = h->p;
-    std::vector<double> avg(R), mx(R), md(R), t(R);
-    std::vector<int32_t> ns(R), dn(R), ne(R);
-    HIP_TRY(h, hipMemcpy(avg.data(), p.m_avg, R * 8, hipMemcpyDeviceToHost));
-    HIP_TRY(h, hipMemcpy(mx.data(), p.m_max, R * 8, hipMemcpyDeviceToHost));
-    HIP_TRY(h, hipMemcpy(md.data(), p.m_dist, R * 8, hipMemcpyDeviceToHost));
-    HIP_TRY(h, hipMemcpy(t.data(), p.t, R * 8, hipMemcpyDeviceToHost));
-    HIP_TRY(h, hipMemcpy(ns.data(), p.n_steps, R * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(h, hipMemcpy(dn.data(), p.done, R * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(h, hipMemcpy(ne.data(), p.n_events, R * 4, hipMemcpyDeviceToHost));
+    std::vector<sg_scenario_state> sd(R);
+    HIP_TRY(h, hipMemcpy(sd.data(), p.sdyn, (size_t)R * sizeof(sg_scenario_state), hipMemcpyDeviceToHost));
     int64_t total = 0;
     bool overflow = false;
     for (int r = 0; r < R; ++r) {
-        out[r].ego_avg_speed = avg[r]; out[r].ego_max_speed = mx[r]; out[r].ego_distance_travelled = md[r];
-        out[r].final_t = t[r]; out[r].n_steps = ns[r]; out[r].done = dn[r]; out[r].n_collisions = ne[r];
+        out[r].ego_avg_speed = sd[r].ego_avg_speed; out[r].ego_max_speed = sd[r].ego_max_speed;
+        out[r].ego_distance_travelled = sd[r].ego_distance_travelled;
+        out[r].final_t = sd[r].t; out[r].n_steps = sd[r].n_steps; out[r].done = sd[r].done;
+        out[r].n_collisions = sd[r].n_events;
         out[r].reserved = 0;
-        if (ne[r] > p.ev_cap) overflow = true;
-        total += std::min(ne[r], p.ev_cap);
+        if (sd[r].n_events > p.ev_cap) overflow = true;
+        total += std::min(sd[r].n_events, p.ev_cap);
     }
     if (n_events) *n_events = (int32_t)total;
-    if (events && cap > 0 && p.ev_cap > 0) {
+    if (events && cap > 0 && p.ev_cap > 0 && total > 0) {
         std::vector<sg_event> all((size_t)R * p.ev_cap);
         HIP_TRY(h, hipMemcpy(all.data(), p.events, all.size() * sizeof(sg_event), hipMemcpyDeviceToHost));
         int64_t k = 0;
         for (int r = 0; r < R; ++r)
-            for (int i = 0; i < std::min(ne[r], p.ev_cap); ++i) {
+            for (int i = 0; i < std::min(sd[r].n_events, p.ev_cap); ++i) {
                 if (k >= cap) return fail(h, SG_ERR_CAPACITY, "sg_read_metrics: %lld events do not fit cap=%d", (long long)total, cap);
                 events[k++] = all[(size_t)r * p.ev_cap + i];
             }

@@ -11,6 +11,11 @@ TERMINAL_BITS = {"max_length": L.TERM_MAX_LENGTH, "collision": L.TERM_COLLISION,
                  "ego_collision": L.TERM_EGO_COLLISION}
 
 # VehicleController / PIDController constructor defaults (reference controller.py:64-70, 157-161)
+SCEN_DTYPE = np.dtype([  # sg_scenario_state
+    ("t", "f8"), ("prev_t", "f8"), ("ego_avg_speed", "f8"), ("ego_max_speed", "f8"), ("avg_t", "f8"),
+    ("ego_distance_travelled", "f8"), ("last_row", "u8"), ("done", "i4"), ("n_steps", "i4"),
+    ("n_events", "i4"), ("rec_rows", "i4"), ("reserved", "i8")])
+
 DEFAULT_CTRL = np.array([0.7, 5.0, np.nan, 0.0, 0.03054, 1.5709, 0.3753, 1.8970, 0.0204, 0, 0, 0])
 
 
@@ -156,20 +161,20 @@ class RolloutEngine:
         """Host copy of the step-materialised state: dict of [R, E, ...] arrays (NaN = absent)."""
         v, R, E, EP = self._view, self.R, self.E, self._view.entity_stride
         n = R * EP
-        pose = np.stack([self._d2h(v.pose[c], n, np.float64) for c in range(6)], -1).reshape(R, EP, 6)[:, :E]
-        vel = np.stack([self._d2h(v.vel[c], n, np.float64) for c in range(6)], -1).reshape(R, EP, 6)[:, :E]
-        present = self._d2h(v.present, n, np.uint8).reshape(R, EP)[:, :E].astype(bool)
-        pose = np.where(present[..., None], pose, np.nan)
-        vel = np.where(present[..., None], vel, np.nan)
-        NEp = ((n + 63) // 64) * 64
-        cs = self._d2h(v.ctrl_state, 4 * NEp, np.float64).reshape(4, NEp)[:, :n].reshape(4, R, EP)[:, :, :E]
+        blocks = self._d2h(v.blocks, (v.n_blocks, L.F_COUNT, 64), np.float64)
+
+        def rows(f, k=1, dtype=np.float64):
+            a = blocks[:, f:f + k, :].view(dtype)                      # [nblk, k, 64]
+            return np.moveaxis(a, 1, -1).reshape(-1, k)[:n].reshape(R, EP, k)[:, :E]
+
+        present = rows(L.F_PRESENT, 1, np.uint64)[..., 0] != 0
+        scen = self._d2h(v.scen, R, SCEN_DTYPE)
         return dict(
-            poses=pose, vels=vel, present=present,
-            dists=self._d2h(v.dist, n, np.float64).reshape(R, EP)[:, :E],
-            coll=self._d2h(v.coll, n, np.uint64).reshape(R, EP)[:, :E],
-            ctrl_state=np.moveaxis(cs, 0, -1),
-            t=self._d2h(v.t, R, np.float64), prev_t=self._d2h(v.prev_t, R, np.float64),
-            done=self._d2h(v.done, R, np.int32).astype(bool), n_steps=self._d2h(v.n_steps, R, np.int32),
+            poses=np.where(present[..., None], rows(L.F_POSE, 6), np.nan),
+            vels=np.where(present[..., None], rows(L.F_VEL, 6), np.nan),
+            present=present, dists=rows(L.F_DIST)[..., 0], coll=rows(L.F_COLL, 1, np.uint64)[..., 0],
+            ctrl_state=rows(L.F_CTRL, 4), t=scen["t"].copy(), prev_t=scen["prev_t"].copy(),
+            done=scen["done"].astype(bool), n_steps=scen["n_steps"].copy(),
         )
 
     def metrics(self, event_cap=None):
@@ -193,19 +198,14 @@ class RolloutEngine:
         return t, poses
 
     def torch_state(self):
-        """Zero-copy torch views ([R*EP] fp64) over the device state (torch is only the container)."""
+        """Zero-copy torch view [n_blocks, SG_F_COUNT, 64] (fp64) over the device state blocks;
+        field f of entity i is view[i // 64, f, i % 64].  torch is only the container."""
         import torch
 
         v = self._view
-        n = self.R * v.entity_stride
 
         class _Arr:
             def __init__(self, ptr, shape, typestr):
                 self.__cuda_array_interface__ = dict(shape=shape, typestr=typestr, data=(int(ptr), False), version=2)
 
-        dev = f"cuda:{self.cfg.device}"
-        out = {f"pose{c}": torch.as_tensor(_Arr(v.pose[c], (n,), "<f8"), device=dev) for c in range(6)}
-        out.update({f"vel{c}": torch.as_tensor(_Arr(v.vel[c], (n,), "<f8"), device=dev) for c in range(6)})
-        out["dist"] = torch.as_tensor(_Arr(v.dist, (n,), "<f8"), device=dev)
-        out["t"] = torch.as_tensor(_Arr(v.t, (self.R,), "<f8"), device=dev)
-        return out
+        return torch.as_tensor(_Arr(v.blocks, (v.n_blocks, L.F_COUNT, 64), "<f8"), device=f"cuda:{self.cfg.device}")
