@@ -59,12 +59,25 @@ struct Params {
     double *rec_t, *rec_pose;
 };
 
-// field f of the calling lane's entity: base is the (wave-uniform) block pointer, voff = lane * 8.
-// Compiles to global_load/store with SGPR base + VGPR offset + immediate f * 512.
+// Lane pointers into one 64-slot block.  Global loads/stores carry an immediate offset (the compiler
+// only uses 0..4095 of it), so a lane keeps three 64-bit addresses per block -- rows 0-7, 8-15 and
+// 16-23 -- and every field access is `address + immediate`: no per-field address registers.  The
+// upper two are made opaque to the optimiser, otherwise it re-derives one full 64-bit address per
+// field, hoists them all out of the time loop and spills them.
+struct LanePtr {
+    char *a[3];
+    __device__ __forceinline__ LanePtr(const double *blk, uint32_t voff)
+    {
+        a[0] = reinterpret_cast<char *>(const_cast<double *>(blk)) + voff;
+        a[1] = a[0] + 8 * ROW;
+        a[2] = a[0] + 16 * ROW;
+        asm("" : "+v"(a[1]), "+v"(a[2]));
+    }
+};
 template <typename T = double>
-__device__ __forceinline__ T &fld(const double *blk, uint32_t voff, int f)
+__device__ __forceinline__ T &fld(const LanePtr &lp, int f)
 {
-    return *reinterpret_cast<T *>(reinterpret_cast<char *>(const_cast<double *>(blk)) + voff + (uint32_t)f * ROW);
+    return *reinterpret_cast<T *>(lp.a[f >> 3] + (f & 7) * (int)ROW);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -89,7 +102,21 @@ __device__ __noinline__ double2 sg_sincos_slow(double x)
     return make_double2(sin(x), cos(x));
 }
 
-__device__ __forceinline__ void sg_sincos(double x, double &s, double &c)
+// The 16 fp64 coefficients live in constant memory and are fetched with scalar loads at the point of
+// use (the table pointer is made opaque once per time step), so they occupy SGPRs for a few dozen
+// instructions instead of 32 VGPRs for the whole kernel.
+__constant__ double SG_TRIG[16] = {
+    6.36619772367581382433e-01,  // 0 2/pi
+    1.57079632673412561417e+00,  // 1 pi/2 head (33 bits)
+    6.07710050630396597660e-11,  // 2 pi/2 next 33 bits
+    2.02226624879595063154e-21,  // 3 pi/2 tail
+    -1.66666666666666324348e-01, 8.33333333332248946124e-03, -1.98412698298579493134e-04,  // 4-6 S1..S3
+    2.75573137070700676789e-06, -2.50507602534068634195e-08, 1.58969099521155010221e-10,   // 7-9 S4..S6
+    4.16666666666666019037e-02, -1.38888888888741095749e-03, 2.48015872894767294178e-05,   // 10-12 C1..C3
+    -2.75573143513906633035e-07, 2.08757232129817482790e-09, -1.13596475577881948265e-11,  // 13-15 C4..C6
+};
+
+__device__ __forceinline__ void sg_sincos(double x, double &s, double &c, const double *K = SG_TRIG)
 {
     if (!(__builtin_fabs(x) < 1.0e5)) {
         double2 sc = sg_sincos_slow(x);
@@ -97,27 +124,19 @@ __device__ __forceinline__ void sg_sincos(double x, double &s, double &c)
         c = sc.y;
         return;
     }
-    const double INV_PIO2 = 6.36619772367581382433e-01, PIO2_1 = 1.57079632673412561417e+00,
-                 PIO2_2 = 6.07710050630396597660e-11, PIO2_2T = 2.02226624879595063154e-21;
-    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
-                 S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
-                 S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
-    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
-                 C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
-                 C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
-    double fn = __builtin_rint(x * INV_PIO2);
+    double fn = __builtin_rint(x * K[0]);
     int n = (int)fn;
-    double t = x - fn * PIO2_1;
-    double w = fn * PIO2_2;
+    double t = x - fn * K[1];
+    double w = fn * K[2];
     double r = t - w;
-    w = fn * PIO2_2T - ((t - r) - w);
+    w = fn * K[3] - ((t - r) - w);
     double y0 = r - w;
     double y1 = (r - y0) - w;
     double z = y0 * y0;
     double v = z * y0;
-    double rs = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
-    double ks = y0 - ((z * (0.5 * y1 - v * rs) - y1) - v * S1);
-    double rc = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
+    double rs = K[5] + z * (K[6] + z * (K[7] + z * (K[8] + z * K[9])));
+    double ks = y0 - ((z * (0.5 * y1 - v * rs) - y1) - v * K[4]);
+    double rc = z * (K[10] + z * (K[11] + z * (K[12] + z * (K[13] + z * (K[14] + z * K[15])))));
     double ay = __builtin_fabs(y0);
     uint64_t qb = ((uint64_t)__double_as_longlong(ay) - ((uint64_t)0x00200000 << 32)) & 0xFFFFFFFF00000000ULL;
     double qx = ay > 0.78125 ? 0.28125 : __longlong_as_double((long long)qb);
@@ -287,6 +306,19 @@ __device__ __forceinline__ bool sg_quads_intersect(const double *A, const double
     return !(sg_sat_pass(A, B) || sg_sat_pass(B, A));
 }
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+struct CollLds {
+    float cx[64], cy[64]; // box centres (NaN when absent), SoA for packed-fp32 pair math
+    float2 sc[64];    // sin, cos of the heading
+    float2 half[64];  // half length, half width (static)
+    double cor[8][64]; // fp64 corners, only filled on the exact path
+    int last[64];
+    double ctrl[9][64]; // controller parameters (SG_C_*) of every lane, copied once per launch
+    double boxwl[2][64]; // bounding box width, length (exact path and controllers only)
+};
+
 // ------------------------------------------------------------------------------------------------
 // controllers
 // ------------------------------------------------------------------------------------------------
@@ -294,16 +326,16 @@ struct CtrlState { double speed, e_lon_prev, e_lat_prev, e_lon_int; };
 
 // VehicleController._step (controller.py:105-140); sin_h/cos_h of the current heading come from
 // the previous step's corner computation.
-__device__ __forceinline__ void vehicle_step(CtrlState &cs, const double *st, uint32_t voff, double l,
+__device__ __forceinline__ void vehicle_step(CtrlState &cs, const CollLds &st, int lane, double l,
                                              double dt, double accel, double steer, double sin_h,
-                                             double cos_h, double *pose)
+                                             double cos_h, double *pose, const double *K)
 {
-    double max_steer = fld(st, voff, ST_CTRL + SG_C_MAX_STEER), max_accel = fld(st, voff, ST_CTRL + SG_C_MAX_ACCEL);
-    double max_speed = fld(st, voff, ST_CTRL + SG_C_MAX_SPEED), allow_rev = fld(st, voff, ST_CTRL + SG_C_ALLOW_REVERSE);
+    double max_steer = st.ctrl[SG_C_MAX_STEER][lane], max_accel = st.ctrl[SG_C_MAX_ACCEL][lane];
+    double max_speed = st.ctrl[SG_C_MAX_SPEED][lane], allow_rev = st.ctrl[SG_C_ALLOW_REVERSE][lane];
     accel = __builtin_fmin(__builtin_fmax(accel, -max_accel), max_accel);
     steer = __builtin_fmin(__builtin_fmax(steer, -max_steer), max_steer);
     double ss, sc;
-    sg_sincos(steer, ss, sc);
+    sg_sincos(steer, ss, sc, K);
     double dx = cs.speed * cos_h;
     double dy = cs.speed * sin_h;
     double dh = cs.speed * (ss / sc) / l;
@@ -317,9 +349,9 @@ __device__ __forceinline__ void vehicle_step(CtrlState &cs, const double *st, ui
 }
 
 // PIDController._step (controller.py:205-258)
-__device__ __forceinline__ void pid_step(CtrlState &cs, const double *st, uint32_t voff, double l,
+__device__ __forceinline__ void pid_step(CtrlState &cs, const CollLds &st, int lane, double l,
                                          double state_dt, double dt, double tx, double ty,
-                                         double sin_h, double cos_h, double *pose)
+                                         double sin_h, double cos_h, double *pose, const double *K)
 {
     double e0 = tx - pose[0], e1 = ty - pose[1];
     double e_lon = cos_h * e0 + sin_h * e1;
@@ -329,18 +361,18 @@ __device__ __forceinline__ void pid_step(CtrlState &cs, const double *st, uint32
     else if (speed > 15) gain = 0.1;
     else gain = 1.0;
     double e_lat_D = (e_lat - cs.e_lat_prev) / state_dt;
-    double kp = fld(st, voff, ST_CTRL + SG_C_STEER_KP) * gain, kd = fld(st, voff, ST_CTRL + SG_C_STEER_KD) * gain;
+    double kp = st.ctrl[SG_C_STEER_KP][lane] * gain, kd = st.ctrl[SG_C_STEER_KD][lane] * gain;
     double steer = kp * e_lat + kd * e_lat_D;
     double e_lon_D = (e_lon - cs.e_lon_prev) / state_dt;
     double e_lon_I = cs.e_lon_int + e_lon * state_dt;
     double accel = 0.0;
     if (__builtin_fabs(e_lon) > 0.1)
-        accel = fld(st, voff, ST_CTRL + SG_C_ACCEL_KP) * e_lon + fld(st, voff, ST_CTRL + SG_C_ACCEL_KD) * e_lon_D +
-                fld(st, voff, ST_CTRL + SG_C_ACCEL_KI) * e_lon_I;
+        accel = st.ctrl[SG_C_ACCEL_KP][lane] * e_lon + st.ctrl[SG_C_ACCEL_KD][lane] * e_lon_D +
+                st.ctrl[SG_C_ACCEL_KI][lane] * e_lon_I;
     cs.e_lat_prev = e_lat;
     cs.e_lon_prev = e_lon;
     cs.e_lon_int = e_lon_I;
-    vehicle_step(cs, st, voff, l, dt, accel, steer, sin_h, cos_h, pose);
+    vehicle_step(cs, st, lane, l, dt, accel, steer, sin_h, cos_h, pose, K);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -356,20 +388,9 @@ __device__ __forceinline__ void pid_step(CtrlState &cs, const double *st, uint32
 //                8-edge test on the corners -- the same operation sequence as the CPU oracle.
 // The fp32 stages are strictly conservative, so the result equals the fp64 test on every pair.
 // ------------------------------------------------------------------------------------------------
-typedef float v2f __attribute__((ext_vector_type(2)));
-typedef float v4f __attribute__((ext_vector_type(4)));
-
-struct CollLds {
-    float cx[64], cy[64]; // box centres (NaN when absent), SoA for packed-fp32 pair math
-    float2 sc[64];    // sin, cos of the heading
-    float2 half[64];  // half length, half width (static)
-    double cor[8][64]; // fp64 corners, only filled on the exact path
-    int last[64];
-};
-
 template <int G>
 __device__ __forceinline__ uint64_t tile_collisions(bool present, double x, double y, double s, double c,
-                                                    double bw, double bl, double bcx, double bcy, float rad_thr,
+                                                    double bcx, double bcy, float rad_thr,
                                                     int lane, CollLds &L, uint64_t *mult_rows)
 {
     const int base = lane & ~(G - 1), slot = lane & (G - 1);
@@ -424,13 +445,18 @@ __device__ __forceinline__ uint64_t tile_collisions(bool present, double x, doub
         xs = nxs;
         ys = nys;
     }
+#ifdef SG_ABL_NO_NARROW
+    *mult_rows = 0;
+    return ((uint64_t)cand_w[1] << 32) | cand_w[0];
+#endif
     uint64_t cand = ((uint64_t)cand_w[1] << 32) | cand_w[0];
     cand &= ~(1ull << slot); // not with itself
     cand = present ? cand : 0;
     *mult_rows = 0;
     if (!__any(cand != 0)) return 0; // wave-uniform
 
-    const float hl = (float)(0.5 * bl), hw = (float)(0.5 * bw);
+    const float2 myh = L.half[lane];
+    const float hl = myh.x, hw = myh.y;
     uint64_t rows = 0, fuzzy = 0;
     while (__any(cand != 0)) {
         if (cand) {
@@ -456,7 +482,7 @@ __device__ __forceinline__ uint64_t tile_collisions(bool present, double x, doub
     if (!__any(fuzzy != 0)) return rows; // wave-uniform; the rest is the rare exact path
 
     double A[8];
-    sg_corners(x, y, s, c, bw, bl, bcx, bcy, A);
+    sg_corners(x, y, s, c, L.boxwl[0][lane], L.boxwl[1][lane], bcx, bcy, A);
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < 8; ++k) L.cor[k][lane] = A[k];
@@ -506,13 +532,12 @@ __global__ void build_grid_kernel(Params p, const int32_t *row_scen /*[totalN]*/
     if (row >= total_rows) return;
     int r = row_scen[row];
     uint32_t idx = (uint32_t)r * p.EP + e;
-    const double *st = p.stat + (size_t)(idx >> 6) * ST_COUNT * 64;
-    uint32_t voff = (idx & 63) * 8u;
-    int64_t meta = fld<int64_t>(st, voff, ST_META);
+    const LanePtr st(p.stat + (size_t)(idx >> 6) * ST_COUNT * 64, (idx & 63) * 8u);
+    int64_t meta = fld<int64_t>(st, ST_META);
     double out[6] = {0, 0, 0, 0, 0, 0};
     if (e < p.E && (meta & 0xff) == SG_KIND_REPLAY) {
         double tq = p.grid_t[row];
-        const double *kn = p.knots + fld<int64_t>(st, voff, ST_KNOT_OFF) * 7;
+        const double *kn = p.knots + fld<int64_t>(st, ST_KNOT_OFF) * 7;
         int n = (int)(meta >> 32);
         if (n == 1) { // batch.py:85-88: second knot at t + 0.1
             double x_lo = kn[0], x_hi = kn[0] + 1e-1;
@@ -591,7 +616,7 @@ struct RecipDiv {
 // touched by the one or two lanes that own them and live in HBM/L2.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ Table lane_table(const Params &p, int kind, const ScenStatic &ss, int slot,
-                                            const double *st, uint32_t voff)
+                                            const LanePtr &st)
 {
     Table T;
     if (kind == SG_KIND_REPLAY) {
@@ -600,9 +625,9 @@ __device__ __forceinline__ Table lane_table(const Params &p, int kind, const Sce
         T.y = p.grid_y + go * 6 * p.EP + slot; T.ys = 6 * p.EP; T.cs = p.EP;
         T.n = ss.grid_n;
     } else if (kind >= SG_KIND_AGENT_REPLAY) {
-        const double *kn = p.knots + fld<int64_t>(st, voff, ST_KNOT_OFF) * 7;
+        const double *kn = p.knots + fld<int64_t>(st, ST_KNOT_OFF) * 7;
         T.x = kn; T.xs = 7; T.y = kn + 1; T.ys = 7; T.cs = 1;
-        T.n = (int)(fld<int64_t>(st, voff, ST_META) >> 32);
+        T.n = (int)(fld<int64_t>(st, ST_META) >> 32);
     } else {
         T.x = nullptr; T.y = nullptr; T.n = 0; T.xs = T.ys = T.cs = 0;
     }
@@ -617,34 +642,46 @@ __global__ __launch_bounds__(64, SG_WAVES_PER_SIMD) void rollout_kernel(Params p
     const int lane = threadIdx.x;
     const uint32_t voff = lane * 8u;
     // one wavefront = one 64-slot block of the state arrays: wave-uniform block pointers
-    const double *st = p.stat + (size_t)blockIdx.x * (ST_COUNT * 64);
-    double *dy = p.dyn + (size_t)blockIdx.x * (SG_F_COUNT * 64);
+    const double *st_blk = p.stat + (size_t)blockIdx.x * (ST_COUNT * 64);
+    const LanePtr st(st_blk, voff);
+    const LanePtr dy(p.dyn + (size_t)blockIdx.x * (SG_F_COUNT * 64), voff);
     const int gl = blockIdx.x * 64 + lane;
     const int r_raw = gl / G, slot = gl & (G - 1), base = lane & ~(G - 1);
     const bool in_range = r_raw < p.R;
     const uint32_t r = in_range ? r_raw : p.R - 1;
     const ScenStatic &ss = p.sstat[r];
     sg_scenario_state &sd = p.sdyn[r];
-    const int64_t meta = fld<int64_t>(st, voff, ST_META);
+    const int64_t meta = fld<int64_t>(st, ST_META);
     const int kind = (in_range && slot < p.E) ? (int)(meta & 0xff) : SG_KIND_NONE;
     const bool is_ego = in_range && slot == ss.ego;
-    const double bcx = fld(st, voff, ST_BCX), bcy = fld(st, voff, ST_BCY);
-    const double min_t = fld(st, voff, ST_MIN_T), max_t = fld(st, voff, ST_MAX_T);
+    const double bcx = fld(st, ST_BCX), bcy = fld(st, ST_BCY);
+    const double min_t = fld(st, ST_MIN_T), max_t = fld(st, ST_MAX_T);
+    const double length = ss.length;
     const bool is_static = (int)(meta >> 32) == 1;
     const bool is_agent = kind >= SG_KIND_AGENT_REPLAY;
-    // broad-phase reach of this lane: own bounding-circle radius + the largest radius in the tile + slack
+    // per-launch LDS tables: box extents, controller parameters; broad-phase reach of this lane =
+    // own bounding-circle radius + the largest radius in the tile + slack
     float rad_thr;
     {
-        const double bw = fld(st, voff, ST_BW), bl = fld(st, voff, ST_BL);
+        const double bw = fld(st, ST_BW), bl = fld(st, ST_BL);
         float rad = (float)(0.5 * __builtin_sqrt(bl * bl + bw * bw)) * 1.000001f;
         float rmax = rad;
 #pragma unroll
         for (int o = 1; o < G; o <<= 1) rmax = __builtin_fmaxf(rmax, __shfl_xor(rmax, o, 64));
         rad_thr = rad + rmax + 2e-3f;
         lds.half[lane] = make_float2((float)(0.5 * bl), (float)(0.5 * bw));
+        lds.boxwl[0][lane] = bw;
+        lds.boxwl[1][lane] = bl;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) lds.ctrl[q][lane] = fld(st, ST_CTRL + q);
     }
 
+    // register-resident across the time loop
     double pose[6], dist, t, prev_t;
+    CtrlState cs;                 // controller state (agent lanes)
+    double m_avg, m_max, m_t;     // ego metric accumulators (ego lane)
+    uint64_t last_row;            // CollisionMetric.last_timestep (ego lane)
+    int n_ev;
     bool present;
     int done, steps;
     uint64_t row = 0, mult_rows = 0;
@@ -652,7 +689,7 @@ __global__ __launch_bounds__(64, SG_WAVES_PER_SIMD) void rollout_kernel(Params p
 
     if (do_reset) {
         // ---- State.reset(t0), state.py:106-143 ----
-        const double *kn = p.knots + fld<int64_t>(st, voff, ST_KNOT_OFF) * 7;
+        const double *kn = p.knots + fld<int64_t>(st, ST_KNOT_OFF) * 7;
         const int nk = (int)(meta >> 32);
         double vel[6];
         t = ss.t0;
@@ -679,52 +716,52 @@ __global__ __launch_bounds__(64, SG_WAVES_PER_SIMD) void rollout_kernel(Params p
         dist = 0.0;
         done = 0;
         steps = 0;
+        cs.speed = present ? sg_norm2(vel[0], vel[1]) : 0.0; // controller.py:100-103
+        cs.e_lon_prev = cs.e_lat_prev = cs.e_lon_int = 0.0;   // controller.py:198-203
+        m_avg = m_max = present ? sg_norm3(vel[0], vel[1], vel[2]) : __builtin_nan(""); // metrics/trajectory.py:13-17,36-39
+        m_t = 0.0;
+        last_row = 0; // metrics/collision.py:64-68
+        n_ev = 0;
         sg_sincos(pose[3], sin_h, cos_h);
-        row = tile_collisions<G>(present, pose[0], pose[1], sin_h, cos_h, fld(st, voff, ST_BW), fld(st, voff, ST_BL),
-                                 bcx, bcy, rad_thr, lane, lds, &mult_rows);
+        row = tile_collisions<G>(present, pose[0], pose[1], sin_h, cos_h, bcx, bcy, rad_thr, lane, lds, &mult_rows);
         if (in_range) {
 #pragma unroll
-            for (int c = 0; c < 6; ++c) { fld(dy, voff, SG_F_POSE + c) = pose[c]; fld(dy, voff, SG_F_VEL + c) = vel[c]; }
-            fld(dy, voff, SG_F_DIST) = dist;
-            fld<uint64_t>(dy, voff, SG_F_COLL) = row;
-            fld<uint64_t>(dy, voff, SG_F_PRESENT) = present;
-            fld(dy, voff, SG_F_CTRL + 0) = present ? sg_norm2(vel[0], vel[1]) : 0.0; // controller.py:100-103
-            fld(dy, voff, SG_F_CTRL + 1) = 0.0; // controller.py:198-203
-            fld(dy, voff, SG_F_CTRL + 2) = 0.0;
-            fld(dy, voff, SG_F_CTRL + 3) = 0.0;
+            for (int c = 0; c < 6; ++c) { fld(dy, SG_F_POSE + c) = pose[c]; fld(dy, SG_F_VEL + c) = vel[c]; }
+            fld(dy, SG_F_DIST) = dist;
+            fld<uint64_t>(dy, SG_F_COLL) = row;
+            fld<uint64_t>(dy, SG_F_PRESENT) = present;
             if (p.rec_cap > 0) {
 #pragma unroll
                 for (int c = 0; c < 6; ++c)
                     p.rec_pose[(size_t)c * p.R * p.EP + (size_t)r * p.EP + slot] = present ? pose[c] : __builtin_nan("");
             }
             if (slot == 0) {
-                sd.t = t; sd.prev_t = prev_t; sd.done = 0; sd.n_steps = 0;
                 sd.rec_rows = p.rec_cap > 0 ? 1 : 0;
                 if (p.rec_cap > 0) p.rec_t[r] = t;
             }
-            if (is_ego) { // metrics/trajectory.py:13-17, 36-39; metrics/collision.py:64-68
-                double v0 = present ? sg_norm3(vel[0], vel[1], vel[2]) : __builtin_nan("");
-                sd.ego_avg_speed = v0; sd.ego_max_speed = v0; sd.avg_t = 0.0;
-                sd.ego_distance_travelled = __builtin_nan("");
-                sd.last_row = 0; sd.n_events = 0;
-            }
+            if (is_ego) sd.ego_distance_travelled = __builtin_nan("");
         }
     } else {
         t = sd.t;
         prev_t = sd.prev_t;
-        present = fld<uint64_t>(dy, voff, SG_F_PRESENT) != 0;
+        present = fld<uint64_t>(dy, SG_F_PRESENT) != 0;
 #pragma unroll
-        for (int c = 0; c < 6; ++c) pose[c] = fld(dy, voff, SG_F_POSE + c);
-        dist = fld(dy, voff, SG_F_DIST);
+        for (int c = 0; c < 6; ++c) pose[c] = fld(dy, SG_F_POSE + c);
+        dist = fld(dy, SG_F_DIST);
+        cs.speed = fld(dy, SG_F_CTRL + 0); cs.e_lon_prev = fld(dy, SG_F_CTRL + 1);
+        cs.e_lat_prev = fld(dy, SG_F_CTRL + 2); cs.e_lon_int = fld(dy, SG_F_CTRL + 3);
+        m_avg = sd.ego_avg_speed; m_max = sd.ego_max_speed; m_t = sd.avg_t;
+        last_row = sd.last_row;
+        n_ev = sd.n_events;
         done = sd.done;
         steps = sd.n_steps;
-        row = fld<uint64_t>(dy, voff, SG_F_COLL);
+        row = fld<uint64_t>(dy, SG_F_COLL);
         sg_sincos(pose[3], sin_h, cos_h);
     }
 
     Segment S;
     {
-        Table T = lane_table(p, kind, ss, slot, st, voff);
+        Table T = lane_table(p, kind, ss, slot, st);
         S.cur = seg_locate(T, t);
         seg_load(T, S);
     }
@@ -732,12 +769,26 @@ __global__ __launch_bounds__(64, SG_WAVES_PER_SIMD) void rollout_kernel(Params p
     for (int k = 0; k < n_steps; ++k) {
         const bool run = in_range && (force || !done);
         if (!__any(run)) break;
+        const double *K = SG_TRIG; // opaque per step: keeps the coefficient loads (SGPRs) inside the loop
+        asm volatile("" : "+s"(K));
 
         const double next_t = t + timestep; // scenario_gym.py:229
         const double state_dt = t - prev_t; // State.dt, state.py:198-201
         const double dt = next_t - t;       // = State.dt after this step
-        if (next_t > S.x_hi) {
-            Table T = lane_table(p, kind, ss, slot, st, voff);
+        // external actions are the only global loads of a steady-state step: issue them first
+        double act_a = 0.0, act_s = 0.0;
+        if (kind == SG_KIND_AGENT_VEHICLE && actions) {
+            const double *a = actions + ((size_t)k * p.R + r) * 2;
+            act_a = a[0];
+            act_s = a[1];
+        }
+        if (next_t > S.x_hi) { // rare: next knot segment
+            // opaque copies keep the table address arithmetic inside this branch (otherwise ~15 invariant
+            // 64-bit row addresses are hoisted out of the time loop and held in VGPRs / spilled)
+            int kind_o = kind, slot_o = slot;
+            LanePtr st_o = st;
+            asm volatile("" : "+v"(kind_o), "+v"(slot_o), "+v"(st_o.a[0]));
+            Table T = lane_table(p, kind_o, ss, slot_o, st_o);
             seg_advance(T, S, next_t);
         }
         double np_[6];
@@ -758,19 +809,11 @@ __global__ __launch_bounds__(64, SG_WAVES_PER_SIMD) void rollout_kernel(Params p
                     const double tx = np_[0], ty = np_[1];
 #pragma unroll
                     for (int c = 0; c < 6; ++c) np_[c] = pose[c];
-                    CtrlState cs;
-                    cs.speed = fld(dy, voff, SG_F_CTRL + 0); cs.e_lon_prev = fld(dy, voff, SG_F_CTRL + 1);
-                    cs.e_lat_prev = fld(dy, voff, SG_F_CTRL + 2); cs.e_lon_int = fld(dy, voff, SG_F_CTRL + 3);
-                    const double bl = fld(st, voff, ST_BL);
-                    if (kind == SG_KIND_AGENT_PID) {
-                        pid_step(cs, st, voff, bl, state_dt, dt, tx, ty, sin_h, cos_h, np_);
-                    } else {
-                        const double *a = actions + ((size_t)k * p.R + r) * 2;
-                        double accel = actions ? a[0] : 0.0, steer = actions ? a[1] : 0.0;
-                        vehicle_step(cs, st, voff, bl, dt, accel, steer, sin_h, cos_h, np_);
-                    }
-                    fld(dy, voff, SG_F_CTRL + 0) = cs.speed; fld(dy, voff, SG_F_CTRL + 1) = cs.e_lon_prev;
-                    fld(dy, voff, SG_F_CTRL + 2) = cs.e_lat_prev; fld(dy, voff, SG_F_CTRL + 3) = cs.e_lon_int;
+                    const double bl = lds.boxwl[1][lane];
+                    if (kind == SG_KIND_AGENT_PID)
+                        pid_step(cs, lds, lane, bl, state_dt, dt, tx, ty, sin_h, cos_h, np_, K);
+                    else
+                        vehicle_step(cs, lds, lane, bl, dt, act_a, act_s, sin_h, cos_h, np_, K);
                 }
             } else if (min_t >= t) { // scenario_gym.py:240-244: spawn at trajectory start
                 npres = true;
@@ -781,8 +824,10 @@ __global__ __launch_bounds__(64, SG_WAVES_PER_SIMD) void rollout_kernel(Params p
         double d[6];
         if (npres && !present) { // newcomer: previous pose from the extrapolated trajectory, state.py:219-222
             double prev[6];
-            own_position_extrap(p.knots + fld<int64_t>(st, voff, ST_KNOT_OFF) * 7,
-                                (int)(fld<int64_t>(st, voff, ST_META) >> 32), t, prev);
+            LanePtr st_o = st;
+            asm volatile("" : "+v"(st_o.a[0]));
+            own_position_extrap(p.knots + fld<int64_t>(st_o, ST_KNOT_OFF) * 7,
+                                (int)(fld<int64_t>(st_o, ST_META) >> 32), t, prev);
 #pragma unroll
             for (int c = 0; c < 6; ++c) d[c] = np_[c] - prev[c];
         } else {
@@ -815,17 +860,43 @@ __global__ __launch_bounds__(64, SG_WAVES_PER_SIMD) void rollout_kernel(Params p
             prev_t = t;
             t = next_t;
             ++steps;
+            // ---- step-materialised state (everything except the collision row, see below) ----
+#pragma unroll
+            for (int c = 0; c < 6; ++c) fld(dy, SG_F_POSE + c) = pose[c];
+            if (present) {
+#pragma unroll
+                for (int c = 0; c < 6; ++c) fld(dy, SG_F_VEL + c) = vel[c];
+            }
+            fld(dy, SG_F_DIST) = dist;
+            fld<uint64_t>(dy, SG_F_PRESENT) = present;
+            if (p.rec_cap > 0 && steps < p.rec_cap) {
+#pragma unroll
+                for (int c = 0; c < 6; ++c)
+                    p.rec_pose[((size_t)steps * 6 + c) * p.R * p.EP + (size_t)r * p.EP + slot] =
+                        present ? pose[c] : __builtin_nan("");
+                if (slot == 0) { p.rec_t[(size_t)steps * p.R + r] = t; sd.rec_rows = steps + 1; }
+            }
+            // ---- ego metrics, scenario_gym.py:251-252 ----
+            if (is_ego && present) {
+                double speed = sg_norm3(vel[0], vel[1], vel[2]);
+                double w = m_t / t; // EgoAvgSpeed._step, metrics/trajectory.py:19-24
+                m_avg += (1.0 - w) * (speed - m_avg);
+                m_t = t;
+                m_max = __builtin_fmax(speed, m_max); // EgoMaxSpeed, :41-44
+            }
         }
-        sg_sincos(pose[3], sin_h, cos_h);
+        sg_sincos(pose[3], sin_h, cos_h, K);
 
         // ---- State.collisions ----
-        uint64_t nrow = tile_collisions<G>(present, pose[0], pose[1], sin_h, cos_h, fld(st, voff, ST_BW),
-                                           fld(st, voff, ST_BL), bcx, bcy, rad_thr, lane, lds, &mult_rows);
-        if (run) row = nrow;
+        uint64_t nrow = tile_collisions<G>(present, pose[0], pose[1], sin_h, cos_h, bcx, bcy, rad_thr, lane, lds, &mult_rows);
+        if (run) {
+            row = nrow;
+            fld<uint64_t>(dy, SG_F_COLL) = row;
+        }
 
         // ---- check_terminal, state.py:268-270, 397-408 ----
         int ndone = 0;
-        if ((p.term_mask & SG_TERM_MAX_LENGTH) && (t + dt > ss.length)) ndone = 1;
+        if ((p.term_mask & SG_TERM_MAX_LENGTH) && (t + dt > length)) ndone = 1;
         if (p.term_mask & (SG_TERM_COLLISION | SG_TERM_EGO_COLLISION)) {
             uint64_t any_row = __ballot(row != 0) >> base;
             if (G < 64) any_row &= (1ull << (G & 63)) - 1;
@@ -836,69 +907,46 @@ __global__ __launch_bounds__(64, SG_WAVES_PER_SIMD) void rollout_kernel(Params p
         }
         if (run) done = ndone;
 
-        // ---- metrics, scenario_gym.py:251-252 (ego lane only; accumulators live in memory) ----
+        // ---- CollisionMetric._step, metrics/collision.py:70-75 (ego lane only) ----
         if (run && is_ego && present) {
-            double speed = sg_norm3(vel[0], vel[1], vel[2]);
-            double m_t = sd.avg_t, m_avg = sd.ego_avg_speed;
-            double w = m_t / t; // EgoAvgSpeed._step, metrics/trajectory.py:19-24
-            m_avg += (1.0 - w) * (speed - m_avg);
-            sd.ego_avg_speed = m_avg;
-            sd.avg_t = t;
-            sd.ego_max_speed = __builtin_fmax(speed, sd.ego_max_speed); // EgoMaxSpeed, :41-44
-            sd.ego_distance_travelled = dist;                            // EgoDistanceTravelled, :60-62
-            uint64_t last_row = sd.last_row;
-            uint64_t fresh = row & ~last_row;                  // CollisionMetric._step, metrics/collision.py:70-75
-            if (fresh) {
-                int n_ev = sd.n_events;
-                while (fresh) {
-                    int j = __builtin_ctzll(fresh);
-                    fresh &= fresh - 1;
-                    int mult = 1;
-                    if (mult_rows != row) { // aliased geometries are listed once per owner
-                        mult = 0;
-                        uint64_t tmp = mult_rows;
-                        while (tmp) { int q = __builtin_ctzll(tmp); tmp &= tmp - 1; mult += lds.last[base + q] == j; }
-                    }
-                    // catalog type of the other entity (same block: lanes base + j)
-                    int64_t ometa = fld<int64_t>(st, (uint32_t)(base + j) * 8u, ST_META);
-                    for (int q = 0; q < mult; ++q) {
-                        if (n_ev < p.ev_cap) {
-                            sg_event ev;
-                            ev.t = t; ev.scenario = r; ev.other = j;
-                            ev.type = ((ometa >> 8) & 0xff) == 0 ? -1 : 5;
-                            ev.reserved = 0;
-                            p.events[(size_t)r * p.ev_cap + n_ev] = ev;
-                        }
-                        ++n_ev;
-                    }
+            uint64_t fresh = row & ~last_row;
+            while (fresh) {
+                int j = __builtin_ctzll(fresh);
+                fresh &= fresh - 1;
+                int mult = 1;
+                if (mult_rows != row) { // aliased geometries are listed once per owner
+                    mult = 0;
+                    uint64_t tmp = mult_rows;
+                    while (tmp) { int q = __builtin_ctzll(tmp); tmp &= tmp - 1; mult += lds.last[base + q] == j; }
                 }
-                sd.n_events = n_ev;
+                // catalog type of the other entity (same block: lanes base + j)
+                int64_t ometa = reinterpret_cast<const int64_t *>(st_blk)[ST_META * 64 + base + j];
+                for (int q = 0; q < mult; ++q) {
+                    if (n_ev < p.ev_cap) {
+                        sg_event ev;
+                        ev.t = t; ev.scenario = r; ev.other = j;
+                        ev.type = ((ometa >> 8) & 0xff) == 0 ? -1 : 5;
+                        ev.reserved = 0;
+                        p.events[(size_t)r * p.ev_cap + n_ev] = ev;
+                    }
+                    ++n_ev;
+                }
             }
-            if (row != last_row) sd.last_row = row;
-        }
-
-        // ---- step-materialised state ----
-        if (run) {
-#pragma unroll
-            for (int c = 0; c < 6; ++c) fld(dy, voff, SG_F_POSE + c) = pose[c];
-            if (present) {
-#pragma unroll
-                for (int c = 0; c < 6; ++c) fld(dy, voff, SG_F_VEL + c) = vel[c];
-            }
-            fld(dy, voff, SG_F_DIST) = dist;
-            fld<uint64_t>(dy, voff, SG_F_COLL) = row;
-            fld<uint64_t>(dy, voff, SG_F_PRESENT) = present;
-            if (p.rec_cap > 0 && steps < p.rec_cap) {
-#pragma unroll
-                for (int c = 0; c < 6; ++c)
-                    p.rec_pose[((size_t)steps * 6 + c) * p.R * p.EP + (size_t)r * p.EP + slot] =
-                        present ? pose[c] : __builtin_nan("");
-                if (slot == 0) { p.rec_t[(size_t)steps * p.R + r] = t; sd.rec_rows = steps + 1; }
-            }
+            last_row = row;
         }
     }
 
-    if (in_range && slot == 0) { sd.t = t; sd.prev_t = prev_t; sd.done = done; sd.n_steps = steps; }
+    // ---- write back what lives in registers during the loop ----
+    if (in_range) {
+        fld(dy, SG_F_CTRL + 0) = cs.speed; fld(dy, SG_F_CTRL + 1) = cs.e_lon_prev;
+        fld(dy, SG_F_CTRL + 2) = cs.e_lat_prev; fld(dy, SG_F_CTRL + 3) = cs.e_lon_int;
+        if (slot == 0) { sd.t = t; sd.prev_t = prev_t; sd.done = done; sd.n_steps = steps; }
+        if (is_ego) {
+            sd.ego_avg_speed = m_avg; sd.ego_max_speed = m_max; sd.avg_t = m_t;
+            if (steps > 0 && present) sd.ego_distance_travelled = dist; // EgoDistanceTravelled, :60-62
+            sd.last_row = last_row; sd.n_events = n_ev;
+        }
+    }
 }
 
 } // namespace sg
