@@ -1,4 +1,18 @@
 """scenario_gym_amd: MI355X-native batched rollout engine behind scenario_gym's Python API."""
+from .agent import (  # noqa: F401
+    Agent,
+    ExternalVehicleAgent,
+    PIDAgent,
+    ReplayTrajectoryAgent,
+    TeleportAction,
+    VehicleAction,
+)
 from .engine import PackedScenarios, RolloutEngine  # noqa: F401
+from .entity import BoundingBox, CatalogEntry, Entity, MiscObject, Pedestrian, Vehicle  # noqa: F401
+from .gym import BatchedScenarioGym, ScenarioGym  # noqa: F401
+from .metrics import CollisionMetric, EgoAvgSpeed, EgoDistanceTravelled, EgoMaxSpeed, Metric  # noqa: F401
+from .scenario import Scenario  # noqa: F401
+from .state import State  # noqa: F401
+from .trajectory import Trajectory  # noqa: F401
 
 __version__ = "0.1.0"

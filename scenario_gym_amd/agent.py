@@ -1,0 +1,162 @@
+"""Agents, controllers, actions: the reference's plugin classes as *descriptors*.
+
+In the reference these objects compute one pose per step in Python (agent.py:52-57,
+controller.py:30-42).  Here the built-in kinds are recognised by type when a scenario is packed
+and lowered to device lanes (SG_KIND_*); the objects only carry their parameters.  Class names,
+constructor signatures and defaults follow the reference (agent.py:18-169, controller.py:12-258,
+action.py:12-83, sensor/common.py:39-50).
+"""
+from typing import Optional
+
+import numpy as np
+
+from . import _lib as L
+from .entity import Entity
+from .scenario import Scenario
+
+
+class Action:
+    pass
+
+
+class TeleportAction(Action):
+    """action.py:12-63 (note the x, y, z, h, r, p field order of the reference)."""
+
+    def __init__(self, x=0.0, y=0.0, z=0.0, h=0.0, r=0.0, p=0.0, pose: Optional[np.ndarray] = None):
+        self.x = pose[0] if pose is not None else x
+        self.y = pose[1] if pose is not None else y
+        self.z = pose[2] if pose is not None else z
+        self.h = pose[3] if pose is not None else h
+        self.r = pose[4] if pose is not None else r
+        self.p = pose[5] if pose is not None else p
+
+    @property
+    def pose(self):
+        return np.array([self.x, self.y, self.z, self.h, self.r, self.p])
+
+
+class VehicleAction(Action):
+    """action.py:66-83."""
+
+    def __init__(self, accel: float, steer: float):
+        self.acceleration = accel
+        self.steering = steer
+
+
+class Sensor:
+    def __init__(self, entity: Entity):
+        self.entity = entity
+
+
+class EgoLocalizationSensor(Sensor):
+    """sensor/common.py:39-50: the observation is State.get_entity_data(entity)."""
+
+
+class Controller:
+    device_kind = None
+
+    def __init__(self, entity: Entity):
+        self.entity = entity
+
+    def ctrl_row(self) -> np.ndarray:
+        from .engine import DEFAULT_CTRL
+
+        return DEFAULT_CTRL.copy()
+
+
+class ReplayTrajectoryController(Controller):
+    """controller.py:45-54: pose = action.pose."""
+
+    device_kind = L.KIND_AGENT_REPLAY
+
+
+class VehicleController(Controller):
+    """controller.py:57-140; driven by external (accel, steer) actions."""
+
+    device_kind = L.KIND_AGENT_VEHICLE
+
+    def __init__(self, entity, max_steer: float = 0.7, max_accel: float = 5.0, max_speed: Optional[float] = None,
+                 allow_reverse: bool = False):
+        super().__init__(entity)
+        self.max_steer, self.max_accel = max_steer, max_accel
+        self.max_speed, self.allow_reverse = max_speed, allow_reverse
+
+    def ctrl_row(self):
+        row = super().ctrl_row()
+        row[L.C_MAX_STEER], row[L.C_MAX_ACCEL] = self.max_steer, self.max_accel
+        row[L.C_MAX_SPEED] = np.nan if self.max_speed is None else self.max_speed
+        row[L.C_ALLOW_REVERSE] = float(bool(self.allow_reverse))
+        return row
+
+
+class PIDController(VehicleController):
+    """controller.py:143-258."""
+
+    device_kind = L.KIND_AGENT_PID
+
+    def __init__(self, entity, steer_Kp: float = 0.03054, steer_Kd: float = 1.5709, accel_Kp: float = 0.3753,
+                 accel_Kd: float = 1.8970, accel_Ki: float = 0.0204, **kwargs):
+        super().__init__(entity, **kwargs)
+        self.steer_Kp, self.steer_Kd = steer_Kp, steer_Kd
+        self.accel_Kp, self.accel_Kd, self.accel_Ki = accel_Kp, accel_Kd, accel_Ki
+
+    def ctrl_row(self):
+        row = super().ctrl_row()
+        row[L.C_STEER_KP], row[L.C_STEER_KD] = self.steer_Kp, self.steer_Kd
+        row[L.C_ACCEL_KP], row[L.C_ACCEL_KD], row[L.C_ACCEL_KI] = self.accel_Kp, self.accel_Kd, self.accel_Ki
+        return row
+
+
+class Agent:
+    """agent.py:18-116.  Subclasses with a custom Python `_step` cannot run on the device path."""
+
+    def __init__(self, entity: Entity, controller: Controller, sensor: Sensor):
+        self.entity, self.controller, self.sensor = entity, controller, sensor
+        self.last_action = None
+        self.last_reward = None
+
+    def device_kind(self) -> int:
+        raise NotImplementedError(
+            f"{type(self).__name__} has a Python _step: only ReplayTrajectoryAgent, PIDAgent and "
+            "ExternalVehicleAgent are lowered to device lanes in this version")
+
+    def finish(self, state) -> None:
+        pass
+
+
+class ReplayTrajectoryAgent(Agent):
+    """agent.py:118-128."""
+
+    def __init__(self, entity, controller=None, sensor=None):
+        super().__init__(entity, controller or ReplayTrajectoryController(entity), sensor or EgoLocalizationSensor(entity))
+
+    def device_kind(self):
+        return L.KIND_AGENT_REPLAY
+
+
+class PIDAgent(Agent):
+    """agent.py:131-148."""
+
+    def __init__(self, entity, **controller_kwargs):
+        super().__init__(entity, PIDController(entity, **controller_kwargs), EgoLocalizationSensor(entity))
+
+    def device_kind(self):
+        return L.KIND_AGENT_PID
+
+
+class ExternalVehicleAgent(Agent):
+    """VehicleController driven by caller-supplied (accel, steer) actions: the external-action loop of
+    integrations/openaigym.py:171-226 (`ScenarioGym.step(actions)` / `BatchedScenarioGym.step(actions)`)."""
+
+    def __init__(self, entity, **controller_kwargs):
+        super().__init__(entity, VehicleController(entity, **controller_kwargs), EgoLocalizationSensor(entity))
+
+    def device_kind(self):
+        return L.KIND_AGENT_VEHICLE
+
+
+def _create_agent(scenario: Scenario, entity: Entity) -> Optional[Agent]:
+    """Default create_agent (agent.py:151-169): only the entity with ref "ego" gets an agent."""
+    if entity.ref == "ego":
+        return ReplayTrajectoryAgent(entity)
+    return None

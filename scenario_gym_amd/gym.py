@@ -1,0 +1,258 @@
+"""ScenarioGym / BatchedScenarioGym: the reference's orchestrator API over the device engine.
+
+`ScenarioGym` keeps the reference's constructor and methods (scenario_gym/scenario_gym.py:13-319) for ONE
+scenario; `BatchedScenarioGym` is the batched front door (a list of scenarios = one device batch) that
+replaces the reference's `for scenario in scenarios: gym.rollout()` loops (scenario_gym.py:16-27,
+manager.py:272-282).  With only built-in agents / metrics / terminal conditions a rollout is ONE
+kernel launch; user-defined Python metrics, state callbacks or callable terminal conditions switch to
+one launch per step with the State view refreshed in between.
+"""
+import math
+from typing import Any, Callable, Dict, List, Optional, Sequence, Union
+
+import numpy as np
+
+from .agent import _create_agent
+from .engine import TERMINAL_BITS, RolloutEngine
+from .metrics import Metric, _DeviceMetric
+from .packing import pack_scenarios
+from .scenario import Scenario
+from .state import State
+
+
+class BatchedScenarioGym:
+    def __init__(self, timestep: float = 1.0 / 30.0, persist: bool = False,
+                 terminal_conditions: Optional[List[Union[str, Callable]]] = None,
+                 state_callbacks: Optional[List[Callable]] = None,
+                 metrics: Optional[Callable[[], List[Metric]]] = None,
+                 record: bool = False, event_capacity: int = 16, device: int = 0):
+        """`metrics` is a factory returning a fresh list of Metric objects (one list per scenario)."""
+        self._timestep = float(timestep)
+        self.persist = persist
+        self.terminal_conditions = ["max_length"] if terminal_conditions is None else list(terminal_conditions)
+        self.state_callbacks = state_callbacks or []
+        self.metric_factory = metrics or (lambda: [])
+        self.record = record
+        self.event_capacity = event_capacity
+        self.device = device
+        self.engine: Optional[RolloutEngine] = None
+        self.scenarios: List[Scenario] = []
+        self.states: List[State] = []
+        self.metrics: List[List[Metric]] = []
+        self._cache = None
+        self._prev_state = None
+        self._rec = None
+
+    # ------------------------------------------------------------------ properties
+    @property
+    def timestep(self) -> float:
+        return self._timestep
+
+    @timestep.setter
+    def timestep(self, dt: float) -> None:
+        self._timestep = float(dt)
+        if self.engine is not None:
+            self.engine.set_timestep(dt)
+
+    def _host_terminals(self):
+        return [c for c in self.terminal_conditions if callable(c)]
+
+    def _per_step_host_path(self) -> bool:
+        custom_metric = any(not isinstance(m, _DeviceMetric) for ms in self.metrics for m in ms)
+        return bool(custom_metric or self.state_callbacks or self._host_terminals())
+
+    # ------------------------------------------------------------------ set up
+    def set_scenarios(self, scenarios: Sequence[Scenario], create_agent=_create_agent, max_steps: Optional[int] = None):
+        self.close()
+        self.scenarios = list(scenarios)
+        packed, agents = pack_scenarios(self.scenarios, create_agent)
+        self._packed = packed
+        horizon = float(np.max(packed.length - packed.t0))
+        self.max_steps = int(max_steps or (math.ceil(max(horizon, 0.0) / self._timestep) + 8))
+        dev_terms = [c for c in self.terminal_conditions if not callable(c)]
+        for c in dev_terms:
+            if c not in TERMINAL_BITS:
+                raise ValueError(f"terminal condition {c!r} is not supported (needs the road network)")
+        self.engine = RolloutEngine(
+            packed.n_scenarios, packed.n_entities, timestep=self._timestep, persist=self.persist,
+            terminal_conditions=dev_terms, record_capacity=(self.max_steps + 1) if self.record else 0,
+            event_capacity=self.event_capacity, device=self.device)
+        self.engine.upload(packed)
+        self.states = [State(self, i, sc, agents[i], self.persist) for i, sc in enumerate(self.scenarios)]
+        self.metrics = [list(self.metric_factory()) for _ in self.scenarios]
+        self._invalidate()
+        self._prev_state = None
+        self._reset_host_side()
+
+    def _invalidate(self):
+        self._cache = None
+        self._rec = None
+
+    def _fetch_state(self):
+        if self._cache is None:
+            self._cache = self.engine.state()
+        return self._cache
+
+    def _fetch_record(self):
+        if not self.record:
+            raise RuntimeError("recorded_poses needs BatchedScenarioGym(record=True)")
+        if self._rec is None:
+            n = int(self._fetch_state()["n_steps"].max()) + 1
+            self._rec = self.engine.record(min(n, self.max_steps + 1))
+        return self._rec
+
+    def _reset_host_side(self):
+        for st, ms in zip(self.states, self.metrics):
+            for m in ms:
+                m.reset(st)
+            for cb in self.state_callbacks:
+                if hasattr(cb, "reset"):
+                    cb.reset(st)
+                cb(st)
+
+    def reset_scenarios(self):
+        self.engine.reset()
+        self._invalidate()
+        self._prev_state = None
+        self._reset_host_side()
+
+    # ------------------------------------------------------------------ stepping
+    def _after_host_step(self):
+        done_host = np.zeros(len(self.states), bool)
+        for i, (st, ms) in enumerate(zip(self.states, self.metrics)):
+            for cb in self.state_callbacks:
+                cb(st)
+            done_host[i] = any(c(st) for c in self._host_terminals())
+            for m in ms:
+                if not isinstance(m, _DeviceMetric):
+                    m.step(st)
+        return done_host
+
+    def step(self, actions=None, n: int = 1):
+        """n x ScenarioGym.step() for every scenario; actions [n, R, 2] for ExternalVehicleAgent egos."""
+        if n == 1 or not self._per_step_host_path():
+            self._prev_state = self._fetch_state() if self._per_step_host_path() or n == 1 else None
+            self.engine.step(n, actions)
+            self._invalidate()
+            if self._per_step_host_path():
+                self._after_host_step()
+            return
+        actions = None if actions is None else np.asarray(actions, np.float64).reshape(n, len(self.states), 2)
+        for k in range(n):
+            self.step(None if actions is None else actions[k:k + 1], 1)
+
+    def rollout(self, max_steps: Optional[int] = None):
+        """ScenarioGym.rollout() for the whole batch (scenario_gym.py:256-267)."""
+        max_steps = int(max_steps or self.max_steps)
+        if not self._per_step_host_path():
+            self.engine.rollout(max_steps)
+            self._invalidate()
+        else:
+            self.reset_scenarios()
+            done = np.zeros(len(self.states), bool)
+            for _ in range(max_steps):
+                # a scenario that finished keeps stepping on the device but is frozen for the caller
+                self._prev_state = self._fetch_state()
+                self.engine.step(1)
+                self._invalidate()
+                done |= self._after_host_step() | self._fetch_state()["done"]
+                if done.all():
+                    break
+        for st in self.states:
+            for agent in st.agents.values():
+                agent.finish(st)
+
+    # ------------------------------------------------------------------ results
+    def get_metrics(self) -> List[Dict[str, Any]]:
+        """ScenarioGym.get_metrics (scenario_gym.py:308-319) per scenario."""
+        rows, events = self.engine.metrics()
+        out = []
+        for i, ms in enumerate(self.metrics):
+            ev = events[events["scenario"] == i]
+            values = {}
+            for m in ms:
+                if isinstance(m, _DeviceMetric):
+                    m._load(rows[i], ev, self._packed.refs[i])
+                v = m.get_state()
+                if isinstance(v, dict):
+                    values.update({f"{m.name}_{k}": x for k, x in v.items() if isinstance(k, str)})
+                elif v is not None:
+                    values[m.name] = v
+            out.append(values)
+        return out
+
+    def metric_rows(self):
+        """Raw per-scenario sg_metrics rows + the ego collision event table (numpy structured arrays)."""
+        return self.engine.metrics()
+
+    def close(self):
+        if self.engine is not None:
+            self.engine.close()
+            self.engine = None
+
+
+class ScenarioGym:
+    """The reference's ScenarioGym for one scenario at a time (scenario_gym/scenario_gym.py:13-319)."""
+
+    @classmethod
+    def run_scenarios(cls, paths: List[str], render: bool = False, **kwargs) -> None:
+        gym = cls(**kwargs)
+        for path in paths:
+            gym.load_scenario(path)
+            gym.rollout(render=render)
+
+    def __init__(self, timestep: float = 1.0 / 30.0, persist: bool = False, viewer_class=None,
+                 terminal_conditions=None, state_callbacks=None, metrics: Optional[List[Metric]] = None,
+                 device: int = 0, **viewer_parameters):
+        if viewer_class is not None:
+            raise NotImplementedError("rendering is outside the device rollout path")
+        self._metrics: List[Metric] = list(metrics or [])
+        self._b = BatchedScenarioGym(timestep=timestep, persist=persist, terminal_conditions=terminal_conditions,
+                                     state_callbacks=state_callbacks, metrics=lambda: self._metrics,
+                                     record=True, event_capacity=256, device=device)
+        self.state: Optional[State] = None
+
+    timestep = property(lambda self: self._b.timestep, lambda self, dt: setattr(self._b, "timestep", dt))
+    persist = property(lambda self: self._b.persist)
+    metrics = property(lambda self: self._metrics)
+    terminal_conditions = property(lambda self: self._b.terminal_conditions)
+
+    def add_metrics(self, metrics: List[Metric]) -> None:
+        self._metrics.extend(metrics)
+
+    def reset_gym(self) -> None:
+        self._b.close()
+        self.state = None
+        self._metrics.clear()
+
+    def load_scenario(self, scenario_path: str, create_agent=_create_agent, relabel: bool = False, **kwargs) -> None:
+        from .xosc import import_scenario
+
+        self.set_scenario(import_scenario(scenario_path, relabel=relabel, **kwargs), scenario_path, create_agent)
+
+    def set_scenario(self, scenario: Scenario, scenario_path: Optional[str] = None, create_agent=_create_agent) -> None:
+        self._b.set_scenarios([scenario], create_agent=create_agent)
+        self.state = self._b.states[0]
+        self.state.scenario_path = scenario_path
+
+    def get_start_time(self, scenario: Scenario) -> float:
+        return max((0.0, scenario.ego.trajectory.min_t))
+
+    def reset_scenario(self) -> None:
+        if self.state is not None and self.state.t != self.get_start_time(self.state.scenario):
+            self._b.reset_scenarios()
+
+    def step(self, action=None) -> None:
+        """One tick; `action` = (accel, steer) when the ego is an ExternalVehicleAgent."""
+        self._b.step(None if action is None else np.asarray(action, np.float64).reshape(1, 1, 2))
+
+    def rollout(self, render: bool = False, video_path: Optional[str] = None) -> None:
+        if render:
+            raise NotImplementedError("rendering is outside the device rollout path")
+        self._b.rollout()
+
+    def get_metrics(self) -> Dict[str, Any]:
+        return self._b.get_metrics()[0]
+
+    def close(self) -> None:
+        pass

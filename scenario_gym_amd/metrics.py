@@ -1,0 +1,109 @@
+"""Metric API (reference metrics/base.py:8-73) with the built-in metrics as views over device results.
+
+Built-ins (EgoAvgSpeed, EgoMaxSpeed, EgoDistanceTravelled, CollisionMetric) are accumulated inside the
+rollout kernel; their `get_state()` reads the per-scenario row the gym fetched.  Any other Metric
+subclass is stepped on the host after every device step (ScenarioGym falls back to one launch per step).
+"""
+from abc import ABC, abstractmethod
+from typing import Any, List, Optional, Tuple
+
+
+class Metric(ABC):
+    name: Optional[str] = None
+    required_callbacks: List[type] = []
+    device_field: Optional[str] = None  # set on built-ins: column of sg_metrics
+
+    def __init__(self, name: Optional[str] = None):
+        if name is not None:
+            self.name = name
+        elif self.name is None:
+            self.name = self.__class__.__name__
+        self.callbacks = []
+
+    def reset(self, state) -> None:
+        self._reset(state)
+
+    def step(self, state) -> None:
+        self._step(state)
+
+    @abstractmethod
+    def _reset(self, state) -> None:
+        raise NotImplementedError
+
+    @abstractmethod
+    def _step(self, state) -> None:
+        raise NotImplementedError
+
+    @abstractmethod
+    def get_state(self) -> Any:
+        raise NotImplementedError
+
+
+class _DeviceMetric(Metric):
+    """A metric whose accumulator lives in sg_scenario_state."""
+
+    def __init__(self, name: Optional[str] = None):
+        super().__init__(name=name)
+        self._value = None
+
+    def _reset(self, state) -> None:
+        self._value = None
+
+    def _step(self, state) -> None:  # accumulated on the device
+        pass
+
+    def _load(self, row, events, refs) -> None:
+        self._value = float(row[self.device_field])
+
+    def get_state(self):
+        return self._value
+
+
+class EgoAvgSpeed(_DeviceMetric):
+    """metrics/trajectory.py:8-28."""
+
+    name = "ego_avg_speed"
+    device_field = "ego_avg_speed"
+
+
+class EgoMaxSpeed(_DeviceMetric):
+    """metrics/trajectory.py:31-48."""
+
+    name = "ego_max_speed"
+    device_field = "ego_max_speed"
+
+
+class EgoDistanceTravelled(_DeviceMetric):
+    """metrics/trajectory.py:51-66."""
+
+    name = "ego_distance_travelled"
+    device_field = "ego_distance_travelled"
+
+
+COLLISION_TYPE_NAMES = {5: "non_vehicle", -1: "vehicle"}
+
+
+class CollisionMetric(_DeviceMetric):
+    """metrics/collision.py:46-79: list of (t, other ref, type) for every NEW collision with the ego.
+
+    `type` is "non_vehicle" exactly as in the reference; for Vehicle hazards the reference's
+    classification code raises (it reads Entity.pose, which does not exist: metrics/collision.py:94)
+    and the device reports "vehicle" (unclassified)."""
+
+    name = "collisions"
+    device_field = "n_collisions"
+
+    def __init__(self, c_tol: float = 0.4, name: Optional[str] = None):
+        super().__init__(name=name)
+        self.c_tol = c_tol
+        self.collisions: List[Tuple[float, str, str]] = []
+
+    def _reset(self, state) -> None:
+        self.collisions = []
+
+    def _load(self, row, events, refs) -> None:
+        self.collisions = [(float(e["t"]), refs[int(e["other"])], COLLISION_TYPE_NAMES.get(int(e["type"]), "other"))
+                           for e in events]
+
+    def get_state(self):
+        return list(self.collisions)

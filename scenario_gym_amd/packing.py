@@ -66,3 +66,41 @@ def unpack_scenario(packed: PackedScenarios, r: int) -> dict:
         length=float(packed.length[r]),
         ctrl=None if packed.ctrl is None else packed.ctrl[r * E:r * E + n],
     )
+
+
+def pack_scenarios(scenarios, create_agent=None):
+    """Scenario objects -> PackedScenarios, mirroring ScenarioGym.set_scenario + create_agents
+    (reference scenario_gym.py:157-215): entities whose create_agent() returns None replay through the
+    batch path, the others become agent lanes of their device kind."""
+    from .agent import _create_agent
+    from .entity import catalog_type_code
+
+    create_agent = create_agent or _create_agent
+    arrays, kinds, ctrls, agents = [], [], [], []
+    for sc in scenarios:
+        ents = sc.entities
+        off = np.concatenate([[0], np.cumsum([len(e.trajectory) for e in ents])]).astype(np.int64)
+        ego = ents.index(sc.ego)
+        kind = np.full(len(ents), L.KIND_REPLAY, np.int32)
+        ctrl = np.tile(DEFAULT_CTRL, (len(ents), 1))
+        sc_agents = {}
+        for i, e in enumerate(ents):
+            agent = create_agent(sc, e)
+            if agent is not None:
+                kind[i] = agent.device_kind()
+                ctrl[i] = agent.controller.ctrl_row()
+                sc_agents[e] = agent
+        arrays.append(dict(
+            knot_off=off, knots=np.concatenate([e.trajectory.data for e in ents], axis=0),
+            bbox=np.array([[e.bounding_box.width, e.bounding_box.length, e.bounding_box.center_x,
+                            e.bounding_box.center_y] for e in ents], np.float64),
+            etype=np.array([catalog_type_code(e) for e in ents], np.int32), ego=ego,
+            t0=max(0.0, float(sc.ego.trajectory.min_t)),  # ScenarioGym.get_start_time
+            length=float(sc.length),
+        ))
+        kinds.append(kind)
+        ctrls.append(ctrl)
+        agents.append(sc_agents)
+    packed = pack_arrays(arrays, kinds=kinds, ctrls=ctrls)
+    packed.refs = [[e.ref for e in sc.entities] for sc in scenarios]
+    return packed, agents

@@ -1,0 +1,123 @@
+"""State: read-only view of one scenario of a device batch with the reference's State read API
+(scenario_gym/state/state.py:20-395).  Values are fetched from HBM on demand and cached per step."""
+from typing import Dict, List, Optional
+
+import numpy as np
+
+from .entity import Entity
+from .scenario import Scenario
+
+
+class State:
+    def __init__(self, gym, index: int, scenario: Scenario, agents: dict, persist: bool):
+        self._gym, self._i = gym, index
+        self._scenario = scenario
+        self.agents = agents
+        self.persist = persist
+        self.scenario_path: Optional[str] = None
+        self.last_keystroke = None
+        self.state_callbacks = []
+        self._prev_poses_arr = None
+
+    # ------------------------------------------------------------------ plumbing
+    def _s(self):
+        return self._gym._fetch_state()
+
+    @property
+    def scenario(self) -> Scenario:
+        return self._scenario
+
+    @property
+    def all_entities(self) -> List[Entity]:
+        return list(self._scenario.entities)
+
+    def _dict(self, arr) -> Dict[Entity, np.ndarray]:
+        s = self._s()
+        pres = s["present"][self._i]
+        return {e: arr[self._i, k].copy() for k, e in enumerate(self._scenario.entities) if pres[k]}
+
+    # ------------------------------------------------------------------ reference read API
+    @property
+    def t(self) -> float:
+        return float(self._s()["t"][self._i])
+
+    @property
+    def prev_t(self) -> float:
+        return float(self._s()["prev_t"][self._i])
+
+    @property
+    def dt(self) -> float:
+        return self.t - self.prev_t
+
+    @property
+    def next_t(self) -> float:
+        return self.t + self._gym.timestep
+
+    @property
+    def is_done(self) -> bool:
+        return bool(self._s()["done"][self._i])
+
+    @property
+    def poses(self) -> Dict[Entity, np.ndarray]:
+        return self._dict(self._s()["poses"])
+
+    @property
+    def velocities(self) -> Dict[Entity, np.ndarray]:
+        return self._dict(self._s()["vels"])
+
+    @property
+    def prev_poses(self) -> Dict[Entity, np.ndarray]:
+        """poses - velocities * dt is NOT used: the previous step's poses are kept by the gym."""
+        prev = self._gym._prev_state
+        if prev is None:
+            return {}
+        now = self._s()["present"][self._i]
+        return {e: prev["poses"][self._i, k].copy() for k, e in enumerate(self._scenario.entities)
+                if now[k] and prev["present"][self._i, k]}
+
+    @property
+    def distances(self) -> Dict[Entity, float]:
+        d = self._s()["dists"][self._i]
+        return {e: float(d[k]) for k, e in enumerate(self._scenario.entities)}
+
+    def collisions(self) -> Dict[Entity, List[Entity]]:
+        """State.collisions() (state.py:306-310): adjacency rows computed on the device."""
+        s = self._s()
+        ents = self._scenario.entities
+        rows, pres = s["coll"][self._i], s["present"][self._i]
+        return {e: [ents[j] for j in range(len(ents)) if (int(rows[k]) >> j) & 1]
+                for k, e in enumerate(ents) if pres[k]}
+
+    def recorded_poses(self, entity: Optional[Entity] = None):
+        """state.py:272-290: (n, 7) rows [t, x, y, z, h, p, r] of the steps the entity was present."""
+        t, poses = self._gym._fetch_record()
+        ents = self._scenario.entities
+
+        def one(k):
+            p = poses[:, self._i, k]
+            ok = ~np.isnan(p[:, 0])
+            return np.concatenate([t[ok, self._i, None], p[ok]], axis=1) if ok.any() else np.empty((0, 7))
+
+        if entity is not None:
+            return one(ents.index(entity))
+        return {e: one(k) for k, e in enumerate(ents)}
+
+    def get_entity_data(self, entity: Entity):
+        """state.py:292-304."""
+        return (self.t, self.next_t, self.poses.get(entity), self.velocities.get(entity),
+                self.distances.get(entity), self.recorded_poses(entity=entity), None)
+
+    def get_entity_box_points(self, e: Entity) -> np.ndarray:
+        return e.get_bounding_box_points(self.poses[e])
+
+    def get_entities_in_radius(self, x: float, y: float, r: float) -> List[Entity]:
+        """state.py:356-372.  The reference tests the centre against the 64-gon Point(x, y).buffer(r)."""
+        ang = 2.0 * np.pi * np.arange(64) / 64
+        vx, vy = x + r * np.cos(ang), y - r * np.sin(ang)
+        out = []
+        for e, pose in self.poses.items():
+            ex, ey = np.roll(vx, -1) - vx, np.roll(vy, -1) - vy
+            cr = ex * (pose[1] - vy) - ey * (pose[0] - vx)
+            if (cr < 0).all():  # clockwise ring: strictly inside
+                out.append(e)
+        return out

@@ -1,0 +1,156 @@
+"""Trajectory: knot container with the reference's normalisation and query semantics.
+
+Host-side mirror of scenario_gym/trajectory.py (reference v0.3.1).  Construction (`__init__`,
+trajectory.py:34-96) runs once per entity at load time and stays on the host; the per-step
+queries are executed on the device by the rollout engine -- `position_at_t` / `velocity_at_t`
+here exist for API parity, setup code and tests, and follow the same arithmetic
+(scipy interp1d(kind="linear")._call_linear restated in numpy).
+"""
+from typing import Optional, Tuple, Union
+
+import numpy as np
+
+_FIELDS = ("t", "x", "y", "z", "h", "p", "r")
+
+
+def _lerp_rows(x, y, xq):
+    """interp1d(x, y, axis=0, fill_value="extrapolate") at xq: clip(searchsorted_left, 1, n-1) bracket."""
+    idx = np.clip(np.searchsorted(x, xq), 1, len(x) - 1)
+    lo, hi = idx - 1, idx
+    slope = (y[hi] - y[lo]) / (x[hi] - x[lo])[:, None]
+    return slope * (xq - x[lo])[:, None] + y[lo]
+
+
+def _resolve_heading(h):
+    """trajectory.py:465-469: unwrap so that consecutive headings differ by less than pi."""
+    deltas = np.diff(h) % (2 * np.pi)
+    deltas = np.where(deltas > np.pi, deltas - 2 * np.pi, deltas)
+    return np.hstack([h[0], deltas]).cumsum()
+
+
+def is_stationary(data) -> bool:
+    """trajectory.py:472-490."""
+    return len(np.unique(np.where(np.isnan(data[:, 1:]), 0.0, data[:, 1:]), axis=0)) <= 1
+
+
+class Trajectory:
+    """(N, 7) fp64 knots [t, x, y, z, h, p, r], unique-sorted by t, read-only."""
+
+    _fields = _FIELDS
+
+    def __init__(self, data, fields: Tuple[str, ...] = _FIELDS):
+        data = np.asarray(data)
+        fields = tuple(fields)
+        if not all(f in fields for f in ("t", "x", "y")):
+            raise ValueError("Trajectory cannot be created with t, x and y values.")
+        if data.ndim != 2 or data.shape[1] != len(fields):
+            raise ValueError(f"Invalid shape: {data.shape}. Expected: (N, {len(fields)}).")
+        perm = [fields.index(f) for f in _FIELDS if f in fields]
+        data = data[:, perm]
+        data = data[np.unique(data[:, 0], return_index=True)[1]]  # trajectory.py:60
+        n = data.shape[0]
+        cols = []
+        for f in _FIELDS:
+            d = data[:, perm.index(fields.index(f))] if f in fields else np.zeros(n)
+            if f not in fields or np.isfinite(d).sum() != n:
+                if f == "h" and n == 1:
+                    d = np.zeros(1)
+                elif f == "h":  # heading from the finite difference of xy, trajectory.py:69-78
+                    t = cols[0]
+                    xy = np.array(cols[1:3]).T
+                    g = _lerp_rows(t, xy, t + 1e-2) - _lerp_rows(t, xy, t - 1e-2)
+                    d = _resolve_heading(np.arctan2(g[:, 1], g[:, 0]))
+                elif f in ("z", "p", "r"):
+                    d = np.zeros(n)
+                else:
+                    raise ValueError(f"Invalid values found for {f}. Values required for xyt.")
+            elif f == "h":
+                d = _resolve_heading(d)
+            cols.append(np.asarray(d, np.float64))
+        self._data = np.array(cols).T.copy()
+        self._data.flags.writeable = False
+
+    # ------------------------------------------------------------------ container API
+    @property
+    def data(self):
+        return self._data
+
+    def __len__(self):
+        return len(self._data)
+
+    def __getitem__(self, i):
+        return self._data[i]
+
+    t = property(lambda self: self._data[:, 0])
+    x = property(lambda self: self._data[:, 1])
+    y = property(lambda self: self._data[:, 2])
+    z = property(lambda self: self._data[:, 3])
+    h = property(lambda self: self._data[:, 4])
+    p = property(lambda self: self._data[:, 5])
+    r = property(lambda self: self._data[:, 6])
+
+    @property
+    def min_t(self):
+        return self._data[0, 0]
+
+    @property
+    def max_t(self):
+        return self._data[-1, 0]
+
+    @property
+    def s(self):
+        ds = np.linalg.norm(np.diff(self._data[:, [1, 2]], axis=0), axis=1).cumsum()
+        return np.hstack([[0.0], ds])
+
+    @property
+    def arclength(self):
+        return self.s[-1]
+
+    def is_stationary(self):
+        return is_stationary(self._data)
+
+    def copy(self):
+        return self.__class__(self._data.copy())
+
+    __copy__ = copy
+
+    def to_json(self):
+        return self._data.tolist()
+
+    # ------------------------------------------------------------------ queries (trajectory.py:142-273)
+    def _interp(self, t):
+        data = self._data
+        if data.shape[0] == 1:  # trajectory.py:175-177
+            data = np.repeat(data, 2, axis=0)
+            data[-1, 0] += 1e-3
+        return _lerp_rows(data[:, 0], data[:, 1:], np.atleast_1d(t))
+
+    def position_at_t(self, t, extrapolate: Union[bool, Tuple[bool, bool]] = (False, False)) -> Optional[np.ndarray]:
+        t = np.array(t, dtype=np.float64)
+        if isinstance(extrapolate, tuple):
+            ext_bck, ext_fwd = extrapolate
+            extrapolate = True
+        else:
+            ext_bck = ext_fwd = extrapolate
+        if t.ndim == 0:
+            if not extrapolate and (t < self.min_t or t > self.max_t):
+                return None
+            if t < self.min_t and not ext_bck:
+                return self._data[0, 1:]
+            if t > self.max_t and not ext_fwd:
+                return self._data[-1, 1:]
+            return self._interp(t)[0]
+        poses = self._interp(t)
+        if not ext_bck:
+            poses = np.where(t[:, None] < self.min_t, self._data[0, None, 1:], poses)
+        if not ext_fwd:
+            poses = np.where(t[:, None] > self.max_t, self._data[-1, None, 1:], poses)
+        return poses
+
+    def velocity_at_t(self, t, eps: float = 1e-4):
+        t = np.array(t, dtype=np.float64)
+        inside = np.logical_and(self.min_t <= t, t <= self.max_t)
+        v_in = (self.position_at_t(t + eps / 2, extrapolate=True) - self.position_at_t(t - eps / 2, extrapolate=True)) / eps
+        if t.ndim >= 1:
+            inside = inside.reshape(-1, 1)
+        return np.where(inside, v_in, np.zeros(t.shape + (6,)))

@@ -1,0 +1,220 @@
+"""GPU tests of the scenario_gym-shaped API (ScenarioGym / BatchedScenarioGym / State / Metric views):
+they read like the reference's own tests (tests/test_metrics.py, test_state.py, test_scenario_gym.py,
+test_controller.py, test_utils.py) and are checked against the same golden vectors."""
+import numpy as np
+import pytest
+
+from conftest import bits_equal, load_golden, scenario_arrays
+from test_host_api import scenario_from_arrays
+
+pytestmark = pytest.mark.gpu
+
+
+def _scenario(g, prefix):
+    return scenario_from_arrays(scenario_arrays(g, prefix), g[prefix + "/refs"])
+
+
+def test_metrics_on_xosc_scenario():
+    """tests/test_metrics.py:13-34 on scenario 3fee6507 with the default gym."""
+    import scenario_gym_amd as sga
+
+    g = load_golden("scenarios")
+    gym = sga.ScenarioGym(metrics=[sga.EgoAvgSpeed(), sga.EgoMaxSpeed(), sga.EgoDistanceTravelled(), sga.CollisionMetric()])
+    gym.set_scenario(_scenario(g, "3fee6507/scenario"))
+    gym.rollout()
+    m = gym.get_metrics()
+    assert 4 <= m["ego_avg_speed"] <= 5 and 10 <= m["ego_max_speed"] <= 12
+    assert 90 <= m["ego_distance_travelled"] <= 110 and m["collisions"] == []
+    for k in ("ego_avg_speed", "ego_max_speed", "ego_distance_travelled"):
+        assert m[k] == float(g[f"3fee6507/dt30/metric_{k}"])  # bit-identical to the reference
+    assert gym.state.is_done and gym.state.t == g["3fee6507/dt30/t"][-1]
+
+
+def test_state_view_matches_reference_bookkeeping():
+    """tests/test_state.py:32-73, 103-163: velocities == delta pose / dt, recorded poses, vanishing."""
+    import scenario_gym_amd as sga
+
+    g = load_golden("scenarios")
+    sc = _scenario(g, "vanish/scenario")
+    gym = sga.ScenarioGym(timestep=0.1)
+    gym.set_scenario(sc)
+    ref = "vanish/nopersist"
+    ents = sc.entities
+    assert gym.state.t == g[ref + "/t"][0]
+    for e in ents:  # tests/test_scenario_gym.py:57-65
+        if e.trajectory.min_t <= gym.state.t <= e.trajectory.max_t or e.is_static():
+            assert e in gym.state.poses
+    for k in range(1, 30):
+        gym.step()
+        st = gym.state
+        assert st.t == g[ref + "/t"][k] and np.isclose(st.dt, 0.1)
+        poses, prev, vels = st.poses, st.prev_poses, st.velocities
+        for i, e in enumerate(ents):
+            gp = g[ref + "/poses"][k, i]
+            assert (e in poses) == (not np.isnan(gp[0]))
+            if e in poses:
+                assert bits_equal(poses[e], gp) and bits_equal(vels[e], g[ref + "/vels"][k, i])
+                if e in prev:
+                    assert np.array_equal(vels[e], (poses[e] - prev[e]) / st.dt)
+            assert st.distances[e] == g[ref + "/dists"][k, i]
+    gym.rollout()
+    assert ents[1] not in gym.state.poses  # tests/test_scenario_gym.py:68-73
+    rec = gym.state.recorded_poses(ents[0])
+    n = int(g[ref + "/n_steps"])
+    assert rec.shape == (n + 1, 7) and bits_equal(rec[:, 0], g[ref + "/t"]) and bits_equal(rec[:, 1:], g[ref + "/poses"][:, 0])
+    all_rec = gym.state.recorded_poses()
+    assert len(all_rec[ents[1]]) == int((~np.isnan(g[ref + "/poses"][:, 1, 0])).sum())
+
+
+def test_persist_keeps_every_entity():
+    """tests/test_scenario_gym.py:76-97."""
+    import scenario_gym_amd as sga
+
+    g = load_golden("scenarios")
+    sc = _scenario(g, "vanish/scenario")
+    gym = sga.ScenarioGym(timestep=0.1, persist=True)
+    gym.set_scenario(sc)
+    assert len(gym.state.poses) == len(sc.entities)
+    while not gym.state.is_done:
+        gym.step()
+        assert len(gym.state.poses) == len(sc.entities)
+    assert gym.state.t == g["vanish/persist/t"][-1]
+
+
+def test_pid_agent_rollout():
+    """tests/test_controller.py:7-25."""
+    import scenario_gym_amd as sga
+
+    g = load_golden("pid_xosc")
+    sc = _scenario(g, "scenario")
+
+    def create_agent(s, e):
+        if e.ref == "ego":
+            return sga.PIDAgent(e, accel_Kp=2.0, max_accel=5.0, max_steer=np.pi / 90)
+
+    gym = sga.ScenarioGym(timestep=0.1)
+    gym.set_scenario(sc, create_agent=create_agent)
+    gym.rollout()
+    assert np.abs(gym.state.poses[sc.ego] - g["run/poses"][-1, 0]).max() < 1e-9
+    assert np.abs(gym.state.recorded_poses(sc.ego)[:, 1:] - g["run/poses"][:, 0]).max() < 1e-9
+
+
+def test_collision_scene_and_terminal_condition():
+    """tests/test_utils.py:12-61 + tests/test_scenario_gym.py:28-31 (terminal_conditions)."""
+    import scenario_gym_amd as sga
+
+    g = load_golden("collision")
+    sc = _scenario(g, "headon/scenario")
+    ego, haz = sc.entities
+    gym = sga.ScenarioGym(timestep=0.1, metrics=[sga.CollisionMetric()])
+    gym.set_scenario(sc)
+    assert not gym.state.collisions()[ego]
+    gym.rollout()
+    assert gym.state.collisions()[ego] == [haz] and gym.state.collisions()[haz] == [ego]
+    assert gym.get_metrics()["collisions"] == [(8.799999999999985, "entity_1", "non_vehicle")]
+    gym2 = sga.ScenarioGym(timestep=0.1, terminal_conditions=["max_length", "collision"])
+    gym2.set_scenario(sc)
+    gym2.rollout()
+    assert gym2.state.t == 8.799999999999985  # stops at the first contact
+
+
+def test_timestep_can_change_between_steps():
+    """tests/test_scenario_gym.py:28-44."""
+    import scenario_gym_amd as sga
+
+    g = load_golden("scenarios")
+    gym = sga.ScenarioGym(timestep=0.5)
+    gym.set_scenario(_scenario(g, "a5e43fe4/scenario"))
+    gym.rollout()
+    gym.reset_scenario()
+    gym.step()
+    assert np.allclose(gym.state.dt, 0.5)
+    gym.timestep = 0.2
+    gym.step()
+    assert np.allclose(gym.state.t, gym.state.prev_t + 0.2)
+
+
+def test_user_defined_python_metric_and_callback():
+    """The Metric / StateCallback extension API (metrics/base.py:8-73, callback.py:9-41): a Python
+    metric forces one launch per step and sees the same State the reference would show it."""
+    import scenario_gym_amd as sga
+
+    class MaxOthersSpeed(sga.Metric):
+        name = "max_other_speed"
+
+        def _reset(self, state):
+            self.v, self.steps = 0.0, 0
+
+        def _step(self, state):
+            self.steps += 1
+            for e, vel in state.velocities.items():
+                if e is not state.scenario.ego:
+                    self.v = max(self.v, float(np.linalg.norm(vel[:3])))
+
+        def get_state(self):
+            return {"value": self.v, "steps": self.steps}
+
+    seen = []
+    g = load_golden("scenarios")
+    p = "3fee6507/dt10"
+    gym = sga.ScenarioGym(timestep=0.1, state_callbacks=[lambda s: seen.append(s.t)],
+                          metrics=[MaxOthersSpeed(), sga.EgoMaxSpeed()])
+    gym.set_scenario(_scenario(g, "3fee6507/scenario"))
+    gym.rollout()
+    m = gym.get_metrics()
+    v = g[p + "/vels"][1:, 1:, :3]
+    assert m["max_other_speed_steps"] == int(g[p + "/n_steps"])
+    assert m["max_other_speed_value"] == np.nanmax(np.linalg.norm(v, axis=-1))
+    assert m["ego_max_speed"] == float(g[p + "/metric_ego_max_speed"])
+    assert seen[0] == g[p + "/t"][0] and seen[-1] == g[p + "/t"][-1]
+
+
+def test_batched_gym_with_external_actions_and_mixed_agents():
+    """BatchedScenarioGym: four scenes in one batch, ExternalVehicleAgent egos fed [n, R, 2] actions
+    (the loop of integrations/openaigym.py:171-226), per-scenario metric dicts."""
+    import scenario_gym_amd as sga
+
+    g = load_golden("synth")
+    n = int(g["n"])
+    scs = [_scenario(g, f"{i}/scenario") for i in range(n)]
+
+    def create_agent(s, e):
+        if e.ref == "ego":
+            return sga.ExternalVehicleAgent(e)
+
+    gym = sga.BatchedScenarioGym(timestep=0.1, metrics=lambda: [sga.EgoDistanceTravelled(), sga.CollisionMetric()],
+                                 event_capacity=64)
+    gym.set_scenarios(scs, create_agent=create_agent)
+    steps = int(g["0/ext_dt10/n_steps"])
+    acts = np.stack([g[f"{i}/ext_dt10/actions"][:steps] for i in range(n)], axis=1)
+    gym.step(acts, n=steps)
+    ms = gym.get_metrics()
+    for i in range(n):
+        p = f"{i}/ext_dt10"
+        assert abs(ms[i]["ego_distance_travelled"] - float(g[p + "/metric_ego_distance_travelled"])) < 1e-9
+        refs = list(g[f"{i}/scenario/refs"])
+        assert [(t, refs.index(r)) for t, r, _ in ms[i]["collisions"]] == list(zip(g[p + "/ev_t"], g[p + "/ev_other"]))
+        E = len(scs[i].entities)
+        st = gym.states[i]
+        got = np.array([st.poses.get(e, np.full(6, np.nan)) for e in scs[i].entities])
+        assert np.nanmax(np.abs(got - g[p + "/poses"][-1, :E])) < 1e-9
+        assert st.is_done
+    gym.close()
+
+
+def test_torch_zero_copy_view():
+    """The device state is exposed as raw pointers; torch only wraps them."""
+    import scenario_gym_amd as sga
+    import scenario_gym_amd._lib as L
+    from scenario_gym_amd import synthetic
+
+    packed = synthetic.make_batch(64, 16, n_steps=50)
+    eng = sga.RolloutEngine(64, 16)
+    eng.upload(packed)
+    eng.rollout(50)
+    view = eng.torch_state()
+    st = eng.state()
+    x = view[:, L.F_POSE, :].reshape(-1)[: 64 * 16].reshape(64, 16).cpu().numpy()
+    assert np.array_equal(np.where(st["present"], x, np.nan), st["poses"][..., 0], equal_nan=True)
+    assert view.is_cuda and view.dtype.is_floating_point and view.shape[1] == L.F_COUNT
+    eng.close()

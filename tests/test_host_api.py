@@ -1,0 +1,267 @@
+"""CPU tests of the host side: the scenario_gym-shaped Python API, packing, the OpenSCENARIO
+reader, the ABI surface of libsgym_hip.so and the no-fallback rule."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, bits_equal, load_golden, scenario_arrays
+
+
+# ---------------------------------------------------------------- Trajectory (T1-T3)
+def test_trajectory_normalisation_matches_reference():
+    from scenario_gym_amd import Trajectory
+
+    g = load_golden("trajectory")
+    for i in range(int(g["norm/n"])):
+        tr = Trajectory(g[f"norm/{i}/raw"], fields=tuple(g[f"norm/{i}/fields"]))
+        assert np.array_equal(tr.data, g[f"norm/{i}/data"]), i
+        assert not tr.data.flags.writeable
+
+
+def test_trajectory_queries_match_reference():
+    from scenario_gym_amd import Trajectory
+
+    g = load_golden("trajectory")
+    for i in range(int(g["pos/n"])):
+        tr, q = Trajectory(g[f"pos/{i}/data"]), g[f"pos/{i}/q"]
+        for name, ext in (("true", True), ("ff", (False, False)), ("ft", (False, True)), ("tf", (True, False))):
+            assert bits_equal(np.array([tr.position_at_t(float(x), extrapolate=ext) for x in q]), g[f"pos/{i}/{name}"])
+            assert bits_equal(tr.position_at_t(q, extrapolate=ext), g[f"pos/{i}/{name}"])
+        none = np.array([tr.position_at_t(float(x), extrapolate=False) is None for x in q])
+        assert np.array_equal(none, g[f"pos/{i}/false_is_none"])
+        assert bits_equal(tr.velocity_at_t(q), g[f"pos/{i}/vel"])
+
+
+def test_trajectory_known_answers():
+    """The reference's own assertions: tests/test_trajectory.py:7-15, 49-128, 166-228, 255-269."""
+    from scenario_gym_amd import Trajectory
+
+    data = np.repeat(np.arange(10, dtype=np.float32)[:, None], 4, axis=1)
+    traj = Trajectory(data, fields=["t", "x", "y", "h"])
+    assert traj.max_t == 9 and np.allclose(traj.arclength, 9 * np.sqrt(2))
+    with pytest.raises(ValueError):
+        Trajectory(np.empty((3, 2)), fields=["x", "y"])
+    with pytest.raises(ValueError):
+        Trajectory(np.array([[0, np.nan, 0]]), fields=["t", "x", "y"])
+    with pytest.raises(ValueError):
+        traj.data[-1][0] = 11
+    dup = Trajectory(np.array([[0, 0, 0], [1, 1, 1], [1, 5, 5], [2, 2, 2]]), fields=["t", "x", "y"])
+    assert len(dup) == 3  # duplicate t rows are dropped
+    one = Trajectory(np.array([[0.0, 1.0, 1.0]]), fields=["t", "x", "y"])
+    assert np.allclose(one.h, 0) and np.allclose(one.position_at_t(10.0)[:2], 1) and one.max_t == 0.0
+    t3 = Trajectory(np.array([[0, 0, 0], [1, 1, 1], [2, 2, 2]]), fields=["t", "x", "y"])
+    assert np.allclose(t3.z, 0) and np.allclose(t3.position_at_t(0.5, extrapolate=True)[:2], 0.5)
+    assert t3.position_at_t(-1.0, extrapolate=False) is None and t3.position_at_t(3.0, extrapolate=False) is None
+    assert np.allclose(t3.position_at_t(-1.0, extrapolate=(False, True))[:2], 0.0)
+    assert np.allclose(t3.position_at_t(3.0, extrapolate=(True, False))[:2], 2.0)
+    x = np.array([-1.0, 3.0])
+    assert np.allclose(t3.position_at_t(x, extrapolate=False)[:, :2], [[0, 0], [2, 2]])
+    assert np.allclose(t3.position_at_t(x, extrapolate=(True, True))[:, :2], [[-1, -1], [3, 3]])
+    tv = Trajectory(np.array([[0, 0, 0], [1, 0, 1], [2, 0, 2]]), fields=["t", "x", "y"])
+    assert np.allclose(tv.velocity_at_t(0.5)[:2], [0, 1]) and np.allclose(tv.velocity_at_t(2.0)[:2], [0, 1])
+    assert np.allclose(tv.velocity_at_t([0.5, 2.5])[:, :2], [[0, 1], [0, 0]])
+
+
+# ---------------------------------------------------------------- entities / packing
+def scenario_from_arrays(sc, refs):
+    from scenario_gym_amd import BoundingBox, CatalogEntry, Entity, Scenario, Trajectory
+
+    ents = []
+    types = {0: "Vehicle", 1: "Pedestrian", 2: "MiscObject"}
+    for i, ref in enumerate(refs):
+        a, b = sc["knot_off"][i], sc["knot_off"][i + 1]
+        ce = CatalogEntry(None, "x", None, types[int(sc["etype"][i])], BoundingBox(*sc["bbox"][i]))
+        ents.append(Entity(ce, Trajectory(sc["knots"][a:b]), ref=str(ref)))
+    return Scenario(ents)
+
+
+def test_corners_match_reference():
+    from scenario_gym_amd import BoundingBox, CatalogEntry, Entity
+
+    g = load_golden("collision")
+    for pose, box, ref in zip(g["corners/poses"][:200], g["corners/boxes"][:200], g["corners/points"][:200]):
+        e = Entity(CatalogEntry(None, "x", None, "Vehicle", BoundingBox(*box)))
+        assert np.abs(e.get_bounding_box_points(pose) - ref).max() < 1e-12
+
+
+def test_pack_scenarios_matches_reference_export():
+    """Scenario/Entity/Trajectory objects -> the sg_scenarios arrays, incl. the default agents split."""
+    import scenario_gym_amd._lib as L
+    from scenario_gym_amd.packing import pack_scenarios
+
+    g = load_golden("scenarios")
+    scs, raws = [], []
+    for n in g["names"]:
+        raw = scenario_arrays(g, f"{n}/scenario")
+        raws.append(raw)
+        scs.append(scenario_from_arrays(raw, g[f"{n}/scenario/refs"]))
+    packed, agents = pack_scenarios(scs)
+    E = packed.n_entities
+    assert E == max(len(r["etype"]) for r in raws)
+    for r, raw in enumerate(raws):
+        n = len(raw["etype"])
+        a, b = packed.knot_off[r * E], packed.knot_off[r * E + n]
+        assert np.array_equal(packed.knots[a:b], raw["knots"])
+        assert np.array_equal(packed.bbox[r * E:r * E + n], raw["bbox"])
+        assert packed.t0[r] == raw["t0"] and packed.length[r] == raw["length"] and packed.ego[r] == raw["ego"]
+        kind = packed.kind[r * E:(r + 1) * E]
+        assert kind[raw["ego"]] == L.KIND_AGENT_REPLAY and (kind[n:] == L.KIND_NONE).all()
+        assert (np.delete(kind[:n], raw["ego"]) == L.KIND_REPLAY).all()
+        assert len(agents[r]) == 1
+    sh = packed.shard(1, 3)
+    assert sh.n_scenarios == 2 and sh.knot_off[0] == 0 and sh.t0[0] == raws[1]["t0"]
+
+
+def test_agent_descriptors_lower_to_device_kinds():
+    import scenario_gym_amd as sga
+    import scenario_gym_amd._lib as L
+    from scenario_gym_amd.packing import pack_scenarios
+
+    g = load_golden("pid_xosc")
+    sc = scenario_from_arrays(scenario_arrays(g, "scenario"), g["scenario/refs"])
+
+    def create_agent(s, e):  # tests/test_controller.py:11-19
+        if e.ref == "ego":
+            return sga.PIDAgent(e, accel_Kp=2.0, max_accel=5.0, max_steer=np.pi / 90)
+
+    packed, _ = pack_scenarios([sc], create_agent)
+    ego = packed.ego[0]
+    assert packed.kind[ego] == L.KIND_AGENT_PID
+    row = packed.ctrl[ego]
+    assert row[L.C_ACCEL_KP] == 2.0 and row[L.C_MAX_ACCEL] == 5.0 and row[L.C_MAX_STEER] == np.pi / 90
+    assert row[L.C_STEER_KP] == 0.03054 and np.isnan(row[L.C_MAX_SPEED])
+
+    class MyAgent(sga.Agent):
+        pass
+
+    with pytest.raises(NotImplementedError):
+        pack_scenarios([sc], lambda s, e: MyAgent(e, None, None) if e.ref == "ego" else None)
+    a = sga.TeleportAction(pose=np.arange(6.0))
+    assert np.array_equal(a.pose, np.arange(6.0))
+
+
+def test_synthetic_generator_is_shardable_and_seeded():
+    from scenario_gym_amd import synthetic
+
+    a = synthetic.make_batch(192, 8, n_steps=100)
+    b = synthetic.make_batch(64, 8, n_steps=100, first_scenario=64)
+    sh = a.shard(64, 128)
+    for k in ("kind", "bbox", "knot_off", "knots", "t0", "length"):
+        assert np.array_equal(getattr(sh, k), getattr(b, k)), k
+    n = np.diff(a.knot_off)
+    assert (n == 1).any() and (n == 128).any() and ((n > 1) & (n < 128)).any()  # static / full / vanishing
+    assert np.array_equal(synthetic.make_actions(5, 64, first_scenario=64), synthetic.make_actions(5, 128)[:, 64:])
+
+
+# ---------------------------------------------------------------- OpenSCENARIO ingest
+XOSC = """<?xml version="1.0"?>
+<OpenSCENARIO>
+  <CatalogLocations><VehicleCatalog><Directory path="cats"/></VehicleCatalog></CatalogLocations>
+  <Entities>
+    <ScenarioObject name="hero"><CatalogReference catalogName="C" entryName="car"/></ScenarioObject>
+    <ScenarioObject name="walker"><CatalogReference catalogName="C" entryName="ped"/></ScenarioObject>
+  </Entities>
+  <Storyboard>
+    <Init><Actions><Private entityRef="walker"><PrivateAction><TeleportAction><Position>
+      <WorldPosition x="3" y="4" h="0.5"/></Position></TeleportAction></PrivateAction></Private></Actions></Init>
+    <Story><Act><ManeuverGroup><Actors><EntityRef entityRef="hero"/></Actors><Maneuver><Event><Action>
+      <PrivateAction><RoutingAction><FollowTrajectoryAction><Trajectory><Shape><Polyline>
+        <Vertex time="0"><Position><WorldPosition x="0" y="0"/></Position></Vertex>
+        <Vertex time="2"><Position><WorldPosition x="10" y="0"/></Position></Vertex>
+        <Vertex time="1"><Position><WorldPosition x="5" y="1"/></Position></Vertex>
+      </Polyline></Shape></Trajectory></FollowTrajectoryAction></RoutingAction></PrivateAction>
+    </Action></Event></Maneuver></ManeuverGroup></Act></Story>
+  </Storyboard>
+</OpenSCENARIO>"""
+CATALOG = """<?xml version="1.0"?>
+<OpenSCENARIO><Catalog name="C">
+  <Vehicle name="car" vehicleCategory="car"><BoundingBox><Center x="1.37" y="0" z="0.6"/>
+    <Dimensions width="2.0" length="4.2" height="1.3"/></BoundingBox></Vehicle>
+  <Pedestrian name="ped" pedestrianCategory="pedestrian"><BoundingBox><Center x="0" y="0" z="0.9"/>
+    <Dimensions width="0.69" length="0.7" height="1.8"/></BoundingBox></Pedestrian>
+</Catalog></OpenSCENARIO>"""
+
+
+def test_xosc_reader(tmp_path):
+    from scenario_gym_amd import Pedestrian, Vehicle
+    from scenario_gym_amd.xosc import import_scenario
+
+    (tmp_path / "cats").mkdir()
+    (tmp_path / "cats" / "c.xosc").write_text(CATALOG)
+    (tmp_path / "s.xosc").write_text(XOSC)
+    s = import_scenario(str(tmp_path / "s.xosc"))
+    assert [e.ref for e in s.entities] == ["ego", "pedestrian_0"] and s.ego is s.entities[0]
+    ego, ped = s.entities
+    assert isinstance(ego, Vehicle) and isinstance(ped, Pedestrian)
+    assert (ego.bounding_box.width, ego.bounding_box.length, ego.bounding_box.center_x) == (2.0, 4.2, 1.37)
+    assert np.array_equal(ego.trajectory.t, [0, 1, 2]) and ego.trajectory.data[1, 1] == 5  # sorted by time
+    assert np.allclose(ego.trajectory.h[0], np.arctan2(1, 5), atol=1e-6)                    # heading filled from xy
+    assert ped.is_static() and np.array_equal(ped.trajectory.data[0, :3], [0, 3, 4]) and ped.trajectory.h[0] == 0.5
+    assert s.length == 2.0
+    assert [e.ref for e in import_scenario(str(tmp_path / "s.xosc"), relabel=False).entities] == ["hero", "walker"]
+    with pytest.raises(FileNotFoundError):
+        import_scenario(str(tmp_path / "nope.xosc"))
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/tests/input_files"), reason="build container only")
+def test_xosc_reader_on_reference_inputs():
+    """Same knots / boxes / refs as the reference's own import_scenario (exported in the goldens)."""
+    import glob
+
+    from scenario_gym_amd.xosc import import_scenario
+
+    g = load_golden("scenarios")
+    for n in g["names"]:
+        s = import_scenario(glob.glob(f"/root/reference/tests/input_files/Scenarios/{n}*.xosc")[0])
+        assert np.array_equal(np.concatenate([e.trajectory.data for e in s.entities]), g[f"{n}/scenario/knots"])
+        assert [e.ref for e in s.entities] == list(g[f"{n}/scenario/refs"])
+
+
+# ---------------------------------------------------------------- the C ABI
+def test_library_exports_every_declared_symbol():
+    import ctypes
+
+    import scenario_gym_amd._lib as L
+
+    header = open(os.path.join(ROOT, "include", "sgym.h")).read()
+    declared = set(re.findall(r"^\s*(?:int|void \*|const char \*)\s*(sg_[a-z_]+)\(", header, re.M))
+    assert declared == set(L.SYMBOLS), declared ^ set(L.SYMBOLS)
+    lib = L.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.sg_version() == L.ABI_VERSION
+    assert ctypes.sizeof(L.SgConfig) == 40 and ctypes.sizeof(L.SgMetrics) == 48 and ctypes.sizeof(L.SgEvent) == 24
+    from scenario_gym_amd.engine import SCEN_DTYPE
+
+    assert SCEN_DTYPE.itemsize == 80  # sg_scenario_state
+
+
+def test_no_cpu_fallback(monkeypatch):
+    """Without a GPU the product fails loudly; it never routes through the oracle or numpy."""
+    import torch
+
+    import scenario_gym_amd as sga
+    import scenario_gym_amd._lib as L
+
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="sg_create failed"):
+            sga.RolloutEngine(4, 4)
+    pkg = os.path.join(ROOT, "scenario_gym_amd")
+    for f in os.listdir(pkg):
+        if f.endswith(".py"):
+            src = open(os.path.join(pkg, f)).read()
+            assert "import oracle" not in src and "from oracle" not in src and "sgym_oracle" not in src, f
+    monkeypatch.setattr(L, "LIB_PATH", "/nonexistent/libsgym_hip.so")
+    monkeypatch.setattr(L, "_lib", None)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        L.load()
+
+
+def test_terminal_condition_names():
+    from scenario_gym_amd.engine import terminal_mask
+
+    assert terminal_mask(None) == 1 and terminal_mask(["max_length", "collision", "ego_collision"]) == 7
+    with pytest.raises(ValueError):
+        terminal_mask(["ego_off_road"])
