@@ -198,6 +198,12 @@ def sincos(x):
     return s.value, c.value
 
 
+def tan(x):
+    f = lib().sgo_tan
+    f.restype, f.argtypes = C.c_double, [C.c_double]
+    return f(float(x))
+
+
 def batch_eval(knot_off, knots, ts, persist=False):
     knot_off = np.ascontiguousarray(knot_off, np.int64)
     knots = np.ascontiguousarray(knots, np.float64)

@@ -80,6 +80,33 @@ void sgo_sincos(double x, double *s, double *c)
     }
 }
 
+/* tan(steer) of VehicleController._step (controller.py:128, np.tan).  |x| < 0.67434: the classic odd
+ * minimax polynomial on the primary interval (fdlibm kernel, restated; < 1 ulp); otherwise sin/cos. */
+static const double TN[13] = {
+    3.33333333333334091986e-01, 1.33333333333201242699e-01, 5.39682539762260521377e-02,
+    2.18694882948595424599e-02, 8.86323982359930005737e-03, 3.59207910759131235356e-03,
+    1.45620945432529025516e-03, 5.88041240820264096874e-04, 2.46463134818469906812e-04,
+    7.81794442939557092300e-05, 7.14072491382608190305e-05, -1.85586374855275456654e-05,
+    2.59073051863633712884e-05,
+};
+
+double sgo_tan(double x)
+{
+    if (!(fabs(x) < 0.67434)) {
+        double s, c;
+        sgo_sincos(x, &s, &c);
+        return s / c;
+    }
+    double z = x * x;
+    double w = z * z;
+    double r = TN[1] + w * (TN[3] + w * (TN[5] + w * (TN[7] + w * (TN[9] + w * TN[11]))));
+    double v = z * (TN[2] + w * (TN[4] + w * (TN[6] + w * (TN[8] + w * (TN[10] + w * TN[12])))));
+    double s = z * x;
+    r = z * (s * (r + v));
+    r = r + TN[0] * s;
+    return x + r;
+}
+
 /* np.linalg.norm of a 2-/3-vector = sqrt(x.dot(x)); the OpenBLAS ddot tail loop on x86-64 is an
  * FMA chain (probed against numpy 2.2.6 / OpenBLAS 0.3.29: 20000/20000 bitwise matches). */
 static double norm2(double a, double b) { return sqrt(fma(b, b, a * a)); }
@@ -377,12 +404,11 @@ static void vehicle_step(ctrl_state *cs, const double *ctrl, double l, double dt
     double max_accel = ctrl[SGO_C_MAX_ACCEL], max_steer = ctrl[SGO_C_MAX_STEER];
     accel = fmin(fmax(accel, -max_accel), max_accel); /* np.clip */
     steer = fmin(fmax(steer, -max_steer), max_steer);
-    double h = pose[3], s, c, ss, sc;
+    double h = pose[3], s, c;
     sgo_sincos(h, &s, &c);
-    sgo_sincos(steer, &ss, &sc);
     double dx = cs->speed * c;
     double dy = cs->speed * s;
-    double dh = cs->speed * (ss / sc) / l;
+    double dh = cs->speed * sgo_tan(steer) / l;
     pose[0] += dx * dt;
     pose[1] += dy * dt;
     pose[3] += dh * dt;

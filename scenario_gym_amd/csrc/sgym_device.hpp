@@ -64,20 +64,26 @@ struct Params {
 // 16-23 -- and every field access is `address + immediate`: no per-field address registers.  The
 // upper two are made opaque to the optimiser, otherwise it re-derives one full 64-bit address per
 // field, hoists them all out of the time loop and spills them.
+#define SG_GLOBAL __attribute__((address_space(1)))
 struct LanePtr {
-    char *a[3];
+    SG_GLOBAL char *a[3]; // global address space: global_load/global_store (vmcnt only), never flat_*
     __device__ __forceinline__ LanePtr(const double *blk, uint32_t voff)
     {
-        a[0] = reinterpret_cast<char *>(const_cast<double *>(blk)) + voff;
+        a[0] = (SG_GLOBAL char *)(reinterpret_cast<char *>(const_cast<double *>(blk)) + voff);
         a[1] = a[0] + 8 * ROW;
         a[2] = a[0] + 16 * ROW;
         asm("" : "+v"(a[1]), "+v"(a[2]));
     }
 };
 template <typename T = double>
-__device__ __forceinline__ T &fld(const LanePtr &lp, int f)
+__device__ __forceinline__ T fld(const LanePtr &lp, int f)
 {
-    return *reinterpret_cast<T *>(lp.a[f >> 3] + (f & 7) * (int)ROW);
+    return *reinterpret_cast<SG_GLOBAL const T *>(lp.a[f >> 3] + (f & 7) * (int)ROW);
+}
+template <typename T>
+__device__ __forceinline__ void stf(const LanePtr &lp, int f, T v)
+{
+    *reinterpret_cast<SG_GLOBAL T *>(lp.a[f >> 3] + (f & 7) * (int)ROW) = v;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -105,7 +111,7 @@ __device__ __noinline__ double2 sg_sincos_slow(double x)
 // The 16 fp64 coefficients live in constant memory and are fetched with scalar loads at the point of
 // use (the table pointer is made opaque once per time step), so they occupy SGPRs for a few dozen
 // instructions instead of 32 VGPRs for the whole kernel.
-__constant__ double SG_TRIG[16] = {
+__constant__ double SG_TRIG[32] = {
     6.36619772367581382433e-01,  // 0 2/pi
     1.57079632673412561417e+00,  // 1 pi/2 head (33 bits)
     6.07710050630396597660e-11,  // 2 pi/2 next 33 bits
@@ -114,9 +120,17 @@ __constant__ double SG_TRIG[16] = {
     2.75573137070700676789e-06, -2.50507602534068634195e-08, 1.58969099521155010221e-10,   // 7-9 S4..S6
     4.16666666666666019037e-02, -1.38888888888741095749e-03, 2.48015872894767294178e-05,   // 10-12 C1..C3
     -2.75573143513906633035e-07, 2.08757232129817482790e-09, -1.13596475577881948265e-11,  // 13-15 C4..C6
+    // 16-28: tan polynomial T0..T12 (|x| < 0.67434)
+    3.33333333333334091986e-01, 1.33333333333201242699e-01, 5.39682539762260521377e-02,
+    2.18694882948595424599e-02, 8.86323982359930005737e-03, 3.59207910759131235356e-03,
+    1.45620945432529025516e-03, 5.88041240820264096874e-04, 2.46463134818469906812e-04,
+    7.81794442939557092300e-05, 7.14072491382608190305e-05, -1.85586374855275456654e-05,
+    2.59073051863633712884e-05, 0.0, 0.0, 0.0,
 };
 
-__device__ __forceinline__ void sg_sincos(double x, double &s, double &c, const double *K = SG_TRIG)
+typedef const __attribute__((address_space(4))) double *ConstTbl; // constant address space: scalar loads
+
+__device__ __forceinline__ void sg_sincos(double x, double &s, double &c, ConstTbl K = (ConstTbl)SG_TRIG)
 {
     if (!(__builtin_fabs(x) < 1.0e5)) {
         double2 sc = sg_sincos_slow(x);
@@ -150,6 +164,25 @@ __device__ __forceinline__ void sg_sincos(double x, double &s, double &c, const 
     c = ((n + 1) & 2) ? -cc : cc;
 }
 
+// tan(steer) of VehicleController._step (controller.py:128): same split as the oracle's sgo_tan
+__device__ __forceinline__ double sg_tan(double x, ConstTbl K)
+{
+    if (!(__builtin_fabs(x) < 0.67434)) {
+        double s, c;
+        sg_sincos(x, s, c, K);
+        return s / c;
+    }
+    ConstTbl T = K + 16;
+    double z = x * x;
+    double w = z * z;
+    double r = T[1] + w * (T[3] + w * (T[5] + w * (T[7] + w * (T[9] + w * T[11]))));
+    double v = z * (T[2] + w * (T[4] + w * (T[6] + w * (T[8] + w * (T[10] + w * T[12])))));
+    double s = z * x;
+    r = z * (s * (r + v));
+    r = r + T[0] * s;
+    return x + r;
+}
+
 __device__ __forceinline__ double sg_pred(double x) // nextafter(x, -inf) for finite x
 {
     long long b = __double_as_longlong(x);
@@ -159,6 +192,41 @@ __device__ __forceinline__ double sg_pred(double x) // nextafter(x, -inf) for fi
 }
 
 __device__ __forceinline__ double shfl_d(double v, int src) { return __shfl(v, src, 64); }
+
+// ------------------------------------------------------------------------------------------------
+// x / d for many numerators and one denominator.  `a / b` on gfx950 expands to
+//   v_div_scale x2, v_rcp_f64, 2 Newton steps on the reciprocal, q = a*r, e = a - b*q,
+//   v_div_fmas(e, r, q), v_div_fixup
+// which is correctly rounded.  When neither operand needs v_div_scale's rescaling (both well inside
+// the normal range) that sequence is exactly: r = refined reciprocal of b (depends on b only),
+// q0 = a*r, e = fma(-b, q0, a), q = fma(e, r, q0).  RecipDiv hoists the b-only part; callers
+// fall back to `/` when an operand is outside the safe range.
+// ------------------------------------------------------------------------------------------------
+struct RecipDiv {
+    double b, r;
+    bool ok;
+    __device__ __forceinline__ explicit RecipDiv(double den) : b(den)
+    {
+        double ab = __builtin_fabs(den);
+        ok = ab > 0x1p-500 && ab < 0x1p500;
+        double r0 = __builtin_amdgcn_rcp(den);
+        double e0 = __builtin_fma(-den, r0, 1.0);
+        double r1 = __builtin_fma(r0, e0, r0);
+        double e1 = __builtin_fma(-den, r1, 1.0);
+        r = __builtin_fma(r1, e1, r1);
+    }
+    __device__ __forceinline__ bool safe(double a) const
+    {
+        double aa = __builtin_fabs(a);
+        return ok && (aa == 0.0 || (aa > 0x1p-500 && aa < 0x1p500));
+    }
+    __device__ __forceinline__ double div(double a) const
+    {
+        double q0 = a * r;
+        double e = __builtin_fma(-b, q0, a);
+        return __builtin_fma(e, r, q0);
+    }
+};
 
 // ------------------------------------------------------------------------------------------------
 // knot tables.  A lane interpolates either the scenario's union grid (SG_KIND_REPLAY:
@@ -328,17 +396,15 @@ struct CtrlState { double speed, e_lon_prev, e_lat_prev, e_lon_int; };
 // the previous step's corner computation.
 __device__ __forceinline__ void vehicle_step(CtrlState &cs, const CollLds &st, int lane, double l,
                                              double dt, double accel, double steer, double sin_h,
-                                             double cos_h, double *pose, const double *K)
+                                             double cos_h, double *pose, ConstTbl K)
 {
     double max_steer = st.ctrl[SG_C_MAX_STEER][lane], max_accel = st.ctrl[SG_C_MAX_ACCEL][lane];
     double max_speed = st.ctrl[SG_C_MAX_SPEED][lane], allow_rev = st.ctrl[SG_C_ALLOW_REVERSE][lane];
     accel = __builtin_fmin(__builtin_fmax(accel, -max_accel), max_accel);
     steer = __builtin_fmin(__builtin_fmax(steer, -max_steer), max_steer);
-    double ss, sc;
-    sg_sincos(steer, ss, sc, K);
     double dx = cs.speed * cos_h;
     double dy = cs.speed * sin_h;
-    double dh = cs.speed * (ss / sc) / l;
+    double dh = cs.speed * sg_tan(steer, K) / l;
     pose[0] += dx * dt;
     pose[1] += dy * dt;
     pose[3] += dh * dt;
@@ -351,7 +417,7 @@ __device__ __forceinline__ void vehicle_step(CtrlState &cs, const CollLds &st, i
 // PIDController._step (controller.py:205-258)
 __device__ __forceinline__ void pid_step(CtrlState &cs, const CollLds &st, int lane, double l,
                                          double state_dt, double dt, double tx, double ty,
-                                         double sin_h, double cos_h, double *pose, const double *K)
+                                         double sin_h, double cos_h, double *pose, ConstTbl K)
 {
     double e0 = tx - pose[0], e1 = ty - pose[1];
     double e_lon = cos_h * e0 + sin_h * e1;
@@ -360,10 +426,12 @@ __device__ __forceinline__ void pid_step(CtrlState &cs, const CollLds &st, int l
     if (speed > 5.0 && speed <= 15) gain = 1.0 - 0.9 * (speed - 5.0) / 10.0;
     else if (speed > 15) gain = 0.1;
     else gain = 1.0;
-    double e_lat_D = (e_lat - cs.e_lat_prev) / state_dt;
+    const RecipDiv rd(state_dt); // both derivative terms divide by State.dt
+    const bool fast = rd.safe(e_lat - cs.e_lat_prev) && rd.safe(e_lon - cs.e_lon_prev);
+    double e_lat_D = fast ? rd.div(e_lat - cs.e_lat_prev) : (e_lat - cs.e_lat_prev) / state_dt;
     double kp = st.ctrl[SG_C_STEER_KP][lane] * gain, kd = st.ctrl[SG_C_STEER_KD][lane] * gain;
     double steer = kp * e_lat + kd * e_lat_D;
-    double e_lon_D = (e_lon - cs.e_lon_prev) / state_dt;
+    double e_lon_D = fast ? rd.div(e_lon - cs.e_lon_prev) : (e_lon - cs.e_lon_prev) / state_dt;
     double e_lon_I = cs.e_lon_int + e_lon * state_dt;
     double accel = 0.0;
     if (__builtin_fabs(e_lon) > 0.1)
@@ -409,42 +477,44 @@ __device__ __forceinline__ uint64_t tile_collisions(bool present, double x, doub
     L.sc[lane] = make_float2(fs, fc);
     __syncthreads();
     // All pairs of the tile: lane i tests itself against slots j..j+3 per iteration (wave-uniform
-    // LDS broadcast reads, one ds_read_b128 per coordinate), squared distances in packed fp32
-    // (2 columns per v_pk_* op), and shifts the compare results into its candidate row through the
-    // carry chain: row = 2*row + hit is ONE v_addc_co_u32 per column (columns walked high -> low).
-    // 4 VALU ops per column, no branches, no mask constants.
-    const v2f fx2 = {fx, fx}, fy2 = {fy, fy};
-    uint32_t cand_w[2] = {0u, 0u};
+    // LDS broadcast reads, one ds_read_b128 per coordinate, two iterations prefetched), everything in
+    // packed fp32 (2 columns per v_pk_* op): d2 = dx*dx + dy*dy, then thr - d2 whose SIGN bit says
+    // "outside"; the sign bits are shifted into the lane's row with one v_alignbit_b32 per column
+    // (columns walked high -> low).  3.5 VALU ops per column, no branches, no compares.
+    const v2f fx2 = {fx, fx}, fy2 = {fy, fy}, thr2 = {thr, thr};
+    uint32_t out_w[2] = {0u, 0u}; // bit j = 1: slot j is OUTSIDE this lane's reach
     v4f xs = *reinterpret_cast<const v4f *>(&L.cx[base + G - 4]);
     v4f ys = *reinterpret_cast<const v4f *>(&L.cy[base + G - 4]);
+    v4f xs1 = xs, ys1 = ys;
+    if (G >= 8) {
+        xs1 = *reinterpret_cast<const v4f *>(&L.cx[base + G - 8]);
+        ys1 = *reinterpret_cast<const v4f *>(&L.cy[base + G - 8]);
+    }
 #pragma unroll
     for (int jb = G - 4; jb >= 0; jb -= 4) {
-        v4f nxs = xs, nys = ys; // prefetch the next four slots while these are being tested
-        if (jb >= 4) {
-            nxs = *reinterpret_cast<const v4f *>(&L.cx[base + jb - 4]);
-            nys = *reinterpret_cast<const v4f *>(&L.cy[base + jb - 4]);
+        v4f xs2 = xs1, ys2 = ys1; // two groups of four slots stay in flight
+        if (jb >= 8) {
+            xs2 = *reinterpret_cast<const v4f *>(&L.cx[base + jb - 8]);
+            ys2 = *reinterpret_cast<const v4f *>(&L.cy[base + jb - 8]);
         }
         v2f dxa = v2f{xs.x, xs.y} - fx2, dya = v2f{ys.x, ys.y} - fy2;
         v2f dxb = v2f{xs.z, xs.w} - fx2, dyb = v2f{ys.z, ys.w} - fy2;
-        v2f d2a = __builtin_elementwise_fma(dya, dya, dxa * dxa);
-        v2f d2b = __builtin_elementwise_fma(dyb, dyb, dxb * dxb);
-        uint64_t m0, m1, m2, m3;
-        // NaN (absent) compares false.  The four compares go first so that each SGPR mask is
-        // >= 3 instructions old when the add-with-carry consumes it (VALU-SGPR-write hazard).
-        asm("v_cmp_le_f32 %1, %5, %9\n\t"
-            "v_cmp_le_f32 %2, %6, %9\n\t"
-            "v_cmp_le_f32 %3, %7, %9\n\t"
-            "v_cmp_le_f32 %4, %8, %9\n\t"
-            "v_addc_co_u32 %0, vcc, %0, %0, %1\n\t"
-            "v_addc_co_u32 %0, vcc, %0, %0, %2\n\t"
-            "v_addc_co_u32 %0, vcc, %0, %0, %3\n\t"
-            "v_addc_co_u32 %0, vcc, %0, %0, %4"
-            : "+v"(cand_w[jb >> 5]), "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3)
-            : "v"(d2b.y), "v"(d2b.x), "v"(d2a.y), "v"(d2a.x), "v"(thr)
-            : "vcc");
-        xs = nxs;
-        ys = nys;
+        v2f ma = thr2 - __builtin_elementwise_fma(dya, dya, dxa * dxa);
+        v2f mb = thr2 - __builtin_elementwise_fma(dyb, dyb, dxb * dxb);
+        uint32_t w = out_w[jb >> 5];
+        w = __builtin_amdgcn_alignbit(w, __float_as_uint(mb.y), 31); // w = (w << 1) | sign
+        w = __builtin_amdgcn_alignbit(w, __float_as_uint(mb.x), 31);
+        w = __builtin_amdgcn_alignbit(w, __float_as_uint(ma.y), 31);
+        w = __builtin_amdgcn_alignbit(w, __float_as_uint(ma.x), 31);
+        out_w[jb >> 5] = w;
+        xs = xs1; ys = ys1;
+        xs1 = xs2; ys1 = ys2;
     }
+    // absent slots hold NaN centres (sign bit clear): mask them with the tile's presence bits
+    uint64_t pres_tile = __ballot(present) >> base;
+    uint64_t inside = ~(((uint64_t)out_w[1] << 32) | out_w[0]);
+    if (G < 64) inside &= (1ull << (G & 63)) - 1;
+    const uint32_t cand_w[2] = {(uint32_t)(inside & pres_tile), (uint32_t)((inside & pres_tile) >> 32)};
 #ifdef SG_ABL_NO_NARROW
     *mult_rows = 0;
     return ((uint64_t)cand_w[1] << 32) | cand_w[0];
@@ -572,41 +642,6 @@ __global__ void build_grid_kernel(Params p, const int32_t *row_scen /*[totalN]*/
 }
 
 // ------------------------------------------------------------------------------------------------
-// x / d for many numerators and one denominator.  `a / b` on gfx950 expands to
-//   v_div_scale x2, v_rcp_f64, 2 Newton steps on the reciprocal, q = a*r, e = a - b*q,
-//   v_div_fmas(e, r, q), v_div_fixup
-// which is correctly rounded.  When neither operand needs v_div_scale's rescaling (both well inside
-// the normal range) that sequence is exactly: r = refined reciprocal of b (depends on b only),
-// q0 = a*r, e = fma(-b, q0, a), q = fma(e, r, q0).  RecipDiv hoists the b-only part; callers
-// fall back to `/` when an operand is outside the safe range.
-// ------------------------------------------------------------------------------------------------
-struct RecipDiv {
-    double b, r;
-    bool ok;
-    __device__ __forceinline__ explicit RecipDiv(double den) : b(den)
-    {
-        double ab = __builtin_fabs(den);
-        ok = ab > 0x1p-500 && ab < 0x1p500;
-        double r0 = __builtin_amdgcn_rcp(den);
-        double e0 = __builtin_fma(-den, r0, 1.0);
-        double r1 = __builtin_fma(r0, e0, r0);
-        double e1 = __builtin_fma(-den, r1, 1.0);
-        r = __builtin_fma(r1, e1, r1);
-    }
-    __device__ __forceinline__ bool safe(double a) const
-    {
-        double aa = __builtin_fabs(a);
-        return ok && (aa == 0.0 || (aa > 0x1p-500 && aa < 0x1p500));
-    }
-    __device__ __forceinline__ double div(double a) const
-    {
-        double q0 = a * r;
-        double e = __builtin_fma(-b, q0, a);
-        return __builtin_fma(e, r, q0);
-    }
-};
-
-// ------------------------------------------------------------------------------------------------
 // The rollout kernel: ScenarioGym.reset_scenario / step / rollout (scenario_gym.py:217-267) for
 // 64/G scenarios per wavefront.  do_reset: State.reset first.  force: step done scenarios too
 // (gym.step()); otherwise each scenario stops at is_done (gym.rollout()).
@@ -726,10 +761,10 @@ __global__ __launch_bounds__(64, SG_WAVES_PER_SIMD) void rollout_kernel(Params p
         row = tile_collisions<G>(present, pose[0], pose[1], sin_h, cos_h, bcx, bcy, rad_thr, lane, lds, &mult_rows);
         if (in_range) {
 #pragma unroll
-            for (int c = 0; c < 6; ++c) { fld(dy, SG_F_POSE + c) = pose[c]; fld(dy, SG_F_VEL + c) = vel[c]; }
-            fld(dy, SG_F_DIST) = dist;
-            fld<uint64_t>(dy, SG_F_COLL) = row;
-            fld<uint64_t>(dy, SG_F_PRESENT) = present;
+            for (int c = 0; c < 6; ++c) { stf(dy, SG_F_POSE + c, (pose[c])); stf(dy, SG_F_VEL + c, (vel[c])); }
+            stf(dy, SG_F_DIST, (dist));
+            stf(dy, SG_F_COLL, (uint64_t)(row));
+            stf(dy, SG_F_PRESENT, (uint64_t)(present));
             if (p.rec_cap > 0) {
 #pragma unroll
                 for (int c = 0; c < 6; ++c)
@@ -769,8 +804,11 @@ __global__ __launch_bounds__(64, SG_WAVES_PER_SIMD) void rollout_kernel(Params p
     for (int k = 0; k < n_steps; ++k) {
         const bool run = in_range && (force || !done);
         if (!__any(run)) break;
-        const double *K = SG_TRIG; // opaque per step: keeps the coefficient loads (SGPRs) inside the loop
-        asm volatile("" : "+s"(K));
+        // coefficient table: opaque per step so the scalar loads stay inside the loop (SGPRs for a few
+        // dozen instructions instead of VGPRs for the whole kernel); constant address space => s_load
+        const double *Kp = SG_TRIG;
+        asm volatile("" : "+s"(Kp));
+        ConstTbl K = (ConstTbl)Kp;
 
         const double next_t = t + timestep; // scenario_gym.py:229
         const double state_dt = t - prev_t; // State.dt, state.py:198-201
@@ -862,13 +900,13 @@ __global__ __launch_bounds__(64, SG_WAVES_PER_SIMD) void rollout_kernel(Params p
             ++steps;
             // ---- step-materialised state (everything except the collision row, see below) ----
 #pragma unroll
-            for (int c = 0; c < 6; ++c) fld(dy, SG_F_POSE + c) = pose[c];
+            for (int c = 0; c < 6; ++c) stf(dy, SG_F_POSE + c, (pose[c]));
             if (present) {
 #pragma unroll
-                for (int c = 0; c < 6; ++c) fld(dy, SG_F_VEL + c) = vel[c];
+                for (int c = 0; c < 6; ++c) stf(dy, SG_F_VEL + c, (vel[c]));
             }
-            fld(dy, SG_F_DIST) = dist;
-            fld<uint64_t>(dy, SG_F_PRESENT) = present;
+            stf(dy, SG_F_DIST, (dist));
+            stf(dy, SG_F_PRESENT, (uint64_t)(present));
             if (p.rec_cap > 0 && steps < p.rec_cap) {
 #pragma unroll
                 for (int c = 0; c < 6; ++c)
@@ -891,7 +929,7 @@ __global__ __launch_bounds__(64, SG_WAVES_PER_SIMD) void rollout_kernel(Params p
         uint64_t nrow = tile_collisions<G>(present, pose[0], pose[1], sin_h, cos_h, bcx, bcy, rad_thr, lane, lds, &mult_rows);
         if (run) {
             row = nrow;
-            fld<uint64_t>(dy, SG_F_COLL) = row;
+            stf(dy, SG_F_COLL, (uint64_t)(row));
         }
 
         // ---- check_terminal, state.py:268-270, 397-408 ----
@@ -938,8 +976,8 @@ __global__ __launch_bounds__(64, SG_WAVES_PER_SIMD) void rollout_kernel(Params p
 
     // ---- write back what lives in registers during the loop ----
     if (in_range) {
-        fld(dy, SG_F_CTRL + 0) = cs.speed; fld(dy, SG_F_CTRL + 1) = cs.e_lon_prev;
-        fld(dy, SG_F_CTRL + 2) = cs.e_lat_prev; fld(dy, SG_F_CTRL + 3) = cs.e_lon_int;
+        stf(dy, SG_F_CTRL + 0, (cs.speed)); stf(dy, SG_F_CTRL + 1, (cs.e_lon_prev));
+        stf(dy, SG_F_CTRL + 2, (cs.e_lat_prev)); stf(dy, SG_F_CTRL + 3, (cs.e_lon_int));
         if (slot == 0) { sd.t = t; sd.prev_t = prev_t; sd.done = done; sd.n_steps = steps; }
         if (is_ego) {
             sd.ego_avg_speed = m_avg; sd.ego_max_speed = m_max; sd.avg_t = m_t;
