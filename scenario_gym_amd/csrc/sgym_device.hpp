@@ -215,10 +215,12 @@ struct RecipDiv {
         double e1 = __builtin_fma(-den, r1, 1.0);
         r = __builtin_fma(r1, e1, r1);
     }
+    // numerator range in which the unscaled sequence is exactly the IEEE quotient: zero, or a biased
+    // exponent in [64, 1983] (|a| in [2^-959, 2^961)); denormals, huge values, inf and nan fall back
     __device__ __forceinline__ bool safe(double a) const
     {
-        double aa = __builtin_fabs(a);
-        return ok && (aa == 0.0 || (aa > 0x1p-500 && aa < 0x1p500));
+        uint32_t e = ((uint32_t)__double2hiint(a) >> 20) & 0x7ffu;
+        return ok && ((e - 64u) < 1920u || a == 0.0);
     }
     __device__ __forceinline__ double div(double a) const
     {
@@ -497,6 +499,9 @@ __device__ __forceinline__ uint64_t tile_collisions(bool present, double x, doub
             xs2 = *reinterpret_cast<const v4f *>(&L.cx[base + jb - 8]);
             ys2 = *reinterpret_cast<const v4f *>(&L.cy[base + jb - 8]);
         }
+#ifndef SG_NO_SCHED_BARRIER
+        __builtin_amdgcn_sched_barrier(0); // keep the prefetch above the arithmetic it overlaps with
+#endif
         v2f dxa = v2f{xs.x, xs.y} - fx2, dya = v2f{ys.x, ys.y} - fy2;
         v2f dxb = v2f{xs.z, xs.w} - fx2, dyb = v2f{ys.z, ys.w} - fy2;
         v2f ma = thr2 - __builtin_elementwise_fma(dya, dya, dxa * dxa);
@@ -807,7 +812,9 @@ __global__ __launch_bounds__(64, SG_WAVES_PER_SIMD) void rollout_kernel(Params p
         // coefficient table: opaque per step so the scalar loads stay inside the loop (SGPRs for a few
         // dozen instructions instead of VGPRs for the whole kernel); constant address space => s_load
         const double *Kp = SG_TRIG;
+#ifndef SG_HOIST_TRIG
         asm volatile("" : "+s"(Kp));
+#endif
         ConstTbl K = (ConstTbl)Kp;
 
         const double next_t = t + timestep; // scenario_gym.py:229
