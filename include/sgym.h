@@ -42,6 +42,7 @@ typedef enum {
     SG_KIND_AGENT_REPLAY = 2,  /* ReplayTrajectoryAgent + ReplayTrajectoryController, agent.py:118-128, controller.py:45-54 */
     SG_KIND_AGENT_PID = 3,     /* PIDAgent + PIDController, agent.py:131-148, controller.py:143-258 */
     SG_KIND_AGENT_VEHICLE = 4, /* external (accel, steer) -> VehicleController, controller.py:57-140; integrations/openaigym.py:197-204 */
+    SG_KIND_AGENT_PEDESTRIAN = 5, /* PedestrianAgent + SocialForce + PedestrianController, pedestrian/{agent,social_force,controller}.py */
 } sg_kind;
 
 /* TERMINAL_CONDITIONS, scenario_gym/state/state.py:397-408 */
@@ -60,14 +61,19 @@ enum {
     SG_C_ACCEL_KP = 6,
     SG_C_ACCEL_KD = 7,
     SG_C_ACCEL_KI = 8,
-    SG_NCTRL = 12
+    /* PedestrianAgent / PedestrianSensor / PedestrianController (pedestrian/agent.py:18-37, controller.py:12-19) */
+    SG_C_PED_SPEED_DESIRED = 9,
+    SG_C_PED_MAX_SPEED = 10,
+    SG_C_PED_HEAD_ROT = 11,
+    SG_C_PED_RADIUS = 12, /* PedestrianSensor.distance_threshold */
+    SG_NCTRL = 16
 };
 
 /* ScenarioGym.__init__(timestep, persist, terminal_conditions), scenario_gym/scenario_gym.py:29-95 */
 typedef struct {
     int32_t device;          /* HIP device ordinal */
     int32_t n_scenarios;     /* R */
-    int32_t n_entities;      /* E, entity slots per scenario (<= 64 in this ABI version) */
+    int32_t n_entities;      /* E, entity slots per scenario (<= 256 in this ABI version) */
     int32_t persist;         /* ScenarioGym(persist=...) */
     uint32_t terminal_mask;  /* SG_TERM_* */
     int32_t record_capacity; /* rows of State._recorded_poses kept on device (0 = off), state.py:227-228 */
@@ -88,7 +94,20 @@ typedef struct {
     const int32_t *ego;      /* [R] slot of Scenario.ego (scenario/scenario.py:53-65) */
     const double *t0;        /* [R] ScenarioGym.get_start_time (scenario_gym.py:213-215) */
     const double *length;    /* [R] Scenario.length (scenario/scenario.py:88-91) */
+    const int64_t *route_off; /* [R*E+1] row offsets into routes, or NULL when there are no pedestrian agents */
+    const double *routes;     /* [rows][2] PedestrianAgent.route waypoints (pedestrian/agent.py:43) */
 } sg_scenarios;
+
+/* SocialForceParameters (pedestrian/social_force.py:16-30; behaviour.py max_speed_factor; random_walk.py bias):
+ * one set per handle.  The Gaussian noise of the reference (np.random.normal on the global numpy RNG,
+ * social_force.py:107-108) is not reproduced: std_lon = std_lat = 0. */
+typedef struct {
+    double relaxation_time, ped_repulse_V, ped_repulse_sigma, ped_attract_C;
+    double sight_weight, sight_weight_use;
+    double cos_sight;        /* cos(sight_angle / 2 * pi / 180), computed by the caller */
+    double max_speed_factor, bias_lon, bias_lat;
+    double reserved[2];
+} sg_social_force;
 
 /* Device-resident state after the latest step: the arrays behind State.poses / velocities /
  * distances / collisions() (state.py:90-96, 306-310).
@@ -96,16 +115,18 @@ typedef struct {
  * Layout: entity slot i = scenario * entity_stride + slot.  Entities are grouped in blocks of 64
  * consecutive slots (the 64 lanes of one gfx950 wavefront); inside a block every field is one row of
  * 64 eight-byte values, so a wavefront loads/stores whole 512-byte rows:
- *     value(field f, entity i) = blocks[(i / 64) * SG_F_COUNT * 64 + f * 64 + (i % 64)]
+ *     value(field f, entity i) = blocks[(i / 64) * block_rows * 64 + f * 64 + (i % 64)]
+ * block_rows = SG_F_COLL + row_words, row_words = ceil(entity_stride / 64) (1 for up to 64 entities).
  * Raw device pointers (wrap with torch/dlpack for zero-copy strided views). */
 enum {
     SG_F_POSE = 0,      /* 6 rows: x, y, z, h, p, r  (State.poses) */
     SG_F_VEL = 6,       /* 6 rows (State.velocities) */
     SG_F_DIST = 12,     /* State.distances */
-    SG_F_COLL = 13,     /* uint64 adjacency row of State.collisions(): bit j = slot j of the same scenario */
-    SG_F_PRESENT = 14,  /* uint64 0/1: entity in State.poses */
-    SG_F_CTRL = 15,     /* 4 rows: controller speed, e_lon_prev, e_lat_prev, e_lon_int (controller.py:100-103,198-203) */
-    SG_F_COUNT = 19
+    SG_F_PRESENT = 13,  /* uint64 0/1: entity in State.poses */
+    SG_F_CTRL = 14,     /* 4 rows: controller speed, e_lon_prev, e_lat_prev, e_lon_int (controller.py:100-103,198-203);
+                           pedestrians: controller speed, goal_idx (pedestrian/controller.py:21-23, agent.py:38) */
+    SG_F_FORCE = 18,    /* 2 rows: PedestrianAgent.force (pedestrian/agent.py:41, social_force.py:114) */
+    SG_F_COLL = 20      /* row_words rows of uint64: adjacency row of State.collisions(), bit j = slot j of the scenario */
 };
 
 /* per-scenario clock, terminal flag and metric accumulators */
@@ -115,17 +136,18 @@ typedef struct {
     double ego_max_speed;          /* EgoMaxSpeed (:31-48) */
     double avg_t;                  /* EgoAvgSpeed.t */
     double ego_distance_travelled; /* EgoDistanceTravelled (:51-66) */
-    uint64_t last_row;             /* CollisionMetric.last_timestep (metrics/collision.py:75) */
+    uint64_t last_row[4];          /* CollisionMetric.last_timestep (metrics/collision.py:75) */
     int32_t done;                  /* State.is_done */
     int32_t n_steps;               /* steps since reset */
     int32_t n_events;              /* len(CollisionMetric.collisions) */
     int32_t rec_rows;              /* rows written to the pose record */
     int64_t reserved;
-} sg_scenario_state;               /* 80 bytes */
+} sg_scenario_state;               /* 104 bytes */
 
 typedef struct {
     int32_t n_scenarios, n_entities, entity_stride, n_blocks;
-    double *blocks;          /* [n_blocks][SG_F_COUNT][64] */
+    int32_t row_words, block_rows;
+    double *blocks;          /* [n_blocks][block_rows][64] */
     sg_scenario_state *scen; /* [n_scenarios] */
 } sg_state_view;
 
@@ -158,6 +180,9 @@ int sg_destroy(sg_handle *h);
  * scenarios to HBM, builds the BatchReplayEntity union knot grids + stage-1 resample on device
  * (entity/batch.py:83-109), then resets (sg_reset). */
 int sg_upload(sg_handle *h, const sg_scenarios *sc);
+
+/* SocialForce(params) shared by every pedestrian agent of the handle; call before sg_upload (defaults otherwise) */
+int sg_set_social_force(sg_handle *h, const sg_social_force *params);
 
 /* ScenarioGym.reset_scenario -> State.reset(t0), Controller.reset, Metric.reset (scenario_gym.py:217-225) */
 int sg_reset(sg_handle *h);

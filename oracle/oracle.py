@@ -13,14 +13,25 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "_build", "libsgym_oracle.so")
 
-KIND_NONE, KIND_REPLAY, KIND_AGENT_REPLAY, KIND_AGENT_PID, KIND_AGENT_VEHICLE = range(5)
+KIND_NONE, KIND_REPLAY, KIND_AGENT_REPLAY, KIND_AGENT_PID, KIND_AGENT_VEHICLE, KIND_AGENT_PEDESTRIAN = range(6)
 TERM_MAX_LENGTH, TERM_COLLISION, TERM_EGO_COLLISION = 1, 2, 4
-NCTRL = 12
+NCTRL = 16
+NSF = 12
 # controller.py:64-70, 157-161 defaults: max_steer, max_accel, max_speed(None), allow_reverse,
-# steer_Kp, steer_Kd, accel_Kp, accel_Kd, accel_Ki
+# steer_Kp, steer_Kd, accel_Kp, accel_Kd, accel_Ki; pedestrian/agent.py:18-27: speed_desired (none),
+# max_speed 5.0, head_rot_angle 0.0, distance_threshold 1.0
 DEFAULT_CTRL = np.array(
-    [0.7, 5.0, np.nan, 0.0, 0.03054, 1.5709, 0.3753, 1.8970, 0.0204, 0, 0, 0], np.float64
+    [0.7, 5.0, np.nan, 0.0, 0.03054, 1.5709, 0.3753, 1.8970, 0.0204, 0.0, 5.0, 0.0, 1.0, 0, 0, 0], np.float64
 )
+
+
+def social_force_params(relaxation_time=1.5, ped_repulse_V=1.0, ped_repulse_sigma=1.0, ped_attract_C=0.0,
+                        sight_weight=0.5, sight_weight_use=True, sight_angle=200, max_speed_factor=1.3,
+                        bias_lon=0.0, bias_lat=0.0):
+    """SocialForceParameters defaults (pedestrian/social_force.py:16-30) in the sf[] layout."""
+    return np.array([relaxation_time, ped_repulse_V, ped_repulse_sigma, ped_attract_C, sight_weight,
+                     float(sight_weight_use), np.cos(sight_angle / 2 * np.pi / 180), max_speed_factor,
+                     bias_lon, bias_lat, 0.0, 0.0], np.float64)
 
 
 def build(force=False):
@@ -43,11 +54,13 @@ class _Scenario(C.Structure):
         ("ctrl", C.c_void_p),
         ("t0", C.c_double),
         ("length", C.c_double),
+        ("route_off", C.c_void_p),
+        ("routes", C.c_void_p),
     ]
 
 
 class _Config(C.Structure):
-    _fields_ = [("dt", C.c_double), ("persist", C.c_int32), ("terminal_mask", C.c_int32)]
+    _fields_ = [("dt", C.c_double), ("persist", C.c_int32), ("terminal_mask", C.c_int32), ("sf", C.c_double * NSF)]
 
 
 class _Event(C.Structure):
@@ -107,7 +120,7 @@ def default_kinds(n, ego=0):
 
 def rollout(knot_off, knots, bbox, etype, kind, ego, t0, length, dt, persist=False,
             terminal_mask=TERM_MAX_LENGTH, ctrl=None, actions=None, max_steps=None,
-            force_steps=False, record=True, event_cap=256):
+            force_steps=False, record=True, event_cap=256, route_off=None, routes=None, sf=None):
     """One scenario through the oracle.  Returns a dict shaped like make_golden.record_rollout."""
     L = lib()
     E = int(len(kind))
@@ -121,9 +134,14 @@ def rollout(knot_off, knots, bbox, etype, kind, ego, t0, length, dt, persist=Fal
     if max_steps is None:
         max_steps = int(np.ceil((length - t0) / dt)) + 16
     max_steps = max(int(max_steps), 1)
+    if route_off is not None:
+        route_off = np.ascontiguousarray(route_off, np.int64)
+        routes = np.ascontiguousarray(routes, np.float64).reshape(-1, 2)
     sc = _Scenario(E, int(ego), _p(kind), _p(etype), _p(bbox), _p(knot_off), _p(knots), _p(ctrl),
-                   float(t0), float(length))
-    cfg = _Config(float(dt), int(bool(persist)), int(terminal_mask))
+                   float(t0), float(length), None if route_off is None else _p(route_off),
+                   None if route_off is None else _p(routes))
+    sf = social_force_params() if sf is None else np.ascontiguousarray(sf, np.float64)
+    cfg = _Config(float(dt), int(bool(persist)), int(terminal_mask), (C.c_double * NSF)(*sf))
     S = max_steps + 1
     out = {}
     rec = None
@@ -196,6 +214,24 @@ def sincos(x):
     s, c = C.c_double(), C.c_double()
     lib().sgo_sincos(float(x), C.byref(s), C.byref(c))
     return s.value, c.value
+
+
+def exp(x):
+    f = lib().sgo_exp
+    f.restype, f.argtypes = C.c_double, [C.c_double]
+    return f(float(x))
+
+
+def atan2(y, x):
+    f = lib().sgo_atan2
+    f.restype, f.argtypes = C.c_double, [C.c_double, C.c_double]
+    return f(float(y), float(x))
+
+
+def in_radius(cx, cy, r, px, py):
+    f = lib().sgo_in_radius
+    f.restype, f.argtypes = C.c_int, [C.c_double] * 5
+    return bool(f(cx, cy, r, px, py))
 
 
 def tan(x):

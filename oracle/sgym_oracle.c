@@ -107,6 +107,68 @@ double sgo_tan(double x)
     return x + r;
 }
 
+/* exp / atan2 used by the social force model (np.exp pedestrian/social_force.py:172, np.arctan2 :113).
+ * Fixed plain-fp64 algorithms (classic fdlibm reductions and minimax polynomials, restated) shared with
+ * the HIP kernels so that CPU and GPU agree bit-for-bit; < 1 ulp from numpy's. */
+double sgo_exp(double x)
+{
+    static const double LN2HI = 6.93147180369123816490e-01, LN2LO = 1.90821492927058770002e-10,
+                        INVLN2 = 1.44269504088896338700e+00;
+    static const double P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03,
+                        P3 = 6.61375632143793436117e-05, P4 = -1.65339022054652515390e-06,
+                        P5 = 4.13813679705723846039e-08;
+    if (x != x) return x;
+    if (x > 709.782712893383973096) return INFINITY;
+    if (x < -745.13321910194110842) return 0.0;
+    double k = rint(x * INVLN2);
+    double hi = x - k * LN2HI;
+    double lo = k * LN2LO;
+    double r = hi - lo;
+    double t = r * r;
+    double c = r - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))));
+    double y = 1.0 - ((lo - (r * c) / (2.0 - c)) - hi);
+    return ldexp(y, (int)k);
+}
+
+static double atan_pos(double ax) /* atan of a non-negative finite or infinite argument */
+{
+    static const double HI[4] = {4.63647609000806093515e-01, 7.85398163397448278999e-01,
+                                 9.82793723247329054082e-01, 1.57079632679489655800e+00};
+    static const double LO[4] = {2.26987774529616870924e-17, 3.06161699786838301793e-17,
+                                 1.39033110312309984516e-17, 6.12323399573676603587e-17};
+    static const double A[11] = {3.33333333333329318027e-01,  -1.99999999998764832476e-01,
+                                 1.42857142725034663711e-01,  -1.11111104054623557880e-01,
+                                 9.09088713343650656196e-02,  -7.69187620504482999495e-02,
+                                 6.66107313738753120669e-02,  -5.83357013379057348645e-02,
+                                 4.97687799461593236017e-02,  -3.65315727442169155270e-02,
+                                 1.62858201153657823623e-02};
+    if (ax >= 7.378697629483821e19) return HI[3] + LO[3]; /* 2^66 */
+    int id;
+    double x;
+    if (ax < 0.4375) { id = -1; x = ax; }
+    else if (ax < 0.6875) { id = 0; x = (2.0 * ax - 1.0) / (2.0 + ax); }
+    else if (ax < 1.1875) { id = 1; x = (ax - 1.0) / (ax + 1.0); }
+    else if (ax < 2.4375) { id = 2; x = (ax - 1.5) / (1.0 + 1.5 * ax); }
+    else { id = 3; x = -1.0 / ax; }
+    double z = x * x, w = z * z;
+    double s1 = z * (A[0] + w * (A[2] + w * (A[4] + w * (A[6] + w * (A[8] + w * A[10])))));
+    double s2 = w * (A[1] + w * (A[3] + w * (A[5] + w * (A[7] + w * A[9]))));
+    if (id < 0) return x - x * (s1 + s2);
+    return HI[id] - ((x * (s1 + s2) - LO[id]) - x);
+}
+
+double sgo_atan2(double y, double x)
+{
+    static const double PI = 3.1415926535897931160E+00, PI_LO = 1.2246467991473531772E-16;
+    if (x != x || y != y) return x + y;
+    if (y == 0.0) return (x < 0.0 || (x == 0.0 && signbit(x))) ? copysign(PI, y) : y;
+    if (x == 0.0) return copysign(0.5 * PI, y);
+    double z = atan_pos(fabs(y / x));
+    if (x > 0.0) return y > 0.0 ? z : -z;
+    z = PI - (z - PI_LO);
+    return y > 0.0 ? z : -z;
+}
+
 /* np.linalg.norm of a 2-/3-vector = sqrt(x.dot(x)); the OpenBLAS ddot tail loop on x86-64 is an
  * FMA chain (probed against numpy 2.2.6 / OpenBLAS 0.3.29: 20000/20000 bitwise matches). */
 static double norm2(double a, double b) { return sqrt(fma(b, b, a * a)); }
@@ -446,6 +508,159 @@ static void pid_step(ctrl_state *cs, const double *ctrl, double l, double state_
     vehicle_step(cs, ctrl, l, dt, accel, steer, pose);
 }
 
+/* ------------------------------------------------------------------------------------------
+ * Pedestrians: PedestrianSensor (pedestrian/sensor.py:42-64), PedestrianAgent._step
+ * (pedestrian/agent.py:49-69), SocialForce._step (pedestrian/social_force.py:44-222, boundary terms
+ * off: empty road network), PedestrianController._step (pedestrian/controller.py:25-46).
+ * ---------------------------------------------------------------------------------------- */
+static double GON_C[64], GON_S[64];
+static int gon_ready = 0;
+static void gon_init(void)
+{
+    if (gon_ready) return;
+    for (int i = 0; i < 64; ++i) { /* Point(x, y).buffer(r): 64-gon, vertices at 2*pi*i/64 */
+        double a = 2.0 * 3.141592653589793 * i / 64;
+        GON_C[i] = cos(a);
+        GON_S[i] = sin(a);
+    }
+    gon_ready = 1;
+}
+
+/* State.get_entities_in_radius (state/state.py:356-372): centre strictly inside the 64-gon */
+int sgo_in_radius(double cx, double cy, double r, double px, double py)
+{
+    gon_init();
+    double dx = px - cx, dy = py - cy, d2 = dx * dx + dy * dy, r2 = r * r;
+    if (d2 > r2 * (1.0 + 1e-9)) return 0;
+    if (d2 < r2 * 0.9975) return 1; /* inside the inscribed circle: cos^2(pi/64) = 0.99759 */
+    /* exact rule on the ring: vertices (cx + r*C_i, cy - r*S_i), clockwise */
+    double o = 0.0;
+    for (int i = 0; i < 64; ++i) {
+        int j = (i + 1) & 63;
+        double ax = cx + r * GON_C[i], ay = cy - r * GON_S[i], bx = cx + r * GON_C[j], by = cy - r * GON_S[j];
+        o += ax * by - bx * ay;
+    }
+    for (int i = 0; i < 64; ++i) {
+        int j = (i + 1) & 63;
+        double ax = cx + r * GON_C[i], ay = cy - r * GON_S[i], bx = cx + r * GON_C[j], by = cy - r * GON_S[j];
+        double cr = (bx - ax) * (py - ay) - (by - ay) * (px - ax);
+        if (o > 0 ? !(cr > 0) : !(cr < 0)) return 0;
+    }
+    return 1;
+}
+
+/* LineString(route).project(Point): arclength of the nearest point of the polyline (first minimum) */
+static double route_project(const double *wp, int n, double px, double py)
+{
+    double best = INFINITY, best_s = 0.0, acc = 0.0;
+    for (int i = 0; i + 1 < n; ++i) {
+        double ax = wp[2 * i], ay = wp[2 * i + 1], dx = wp[2 * i + 2] - ax, dy = wp[2 * i + 3] - ay;
+        double L2 = dx * dx + dy * dy;
+        double u = L2 == 0.0 ? 0.0 : fmin(1.0, fmax(0.0, ((px - ax) * dx + (py - ay) * dy) / L2));
+        double qx = ax + u * dx, qy = ay + u * dy;
+        double ex = px - qx, ey = py - qy;
+        double dist = sqrt(ex * ex + ey * ey);
+        double L = sqrt(L2);
+        if (dist < best) { best = dist; best_s = acc + u * L; }
+        acc += L;
+    }
+    return best_s;
+}
+
+typedef struct { double speed; int goal_idx; double fx, fy; } ped_state;
+
+/* one PedestrianAgent.step: returns the new pose in np_ */
+static void ped_step(const sgo_scenario *sc, const sgo_config *cfg, int i, const double *poses, const double *vels,
+                     const uint8_t *present, double t, double next_t, double state_dt, ped_state *ps, double *np_)
+{
+    const int E = sc->n_entities;
+    const double *sf = cfg->sf, *ct = sc->ctrl + (size_t)i * SGO_NCTRL;
+    const double *pose = poses + (size_t)i * 6, *vel = vels + (size_t)i * 6;
+    const double *wp = sc->routes + sc->route_off[i] * 2;
+    const int nwp = (int)(sc->route_off[i + 1] - sc->route_off[i]);
+    double speed = 0.0, heading = 0.0;
+    /* goal update, pedestrian/agent.py:59-62 */
+    if (ps->goal_idx <= nwp - 1) {
+        double s = route_project(wp, nwp, pose[0], pose[1]);
+        double arc = 0.0;
+        int last = 0;
+        for (int k = 0; k < nwp; ++k) {
+            if (k > 0) {
+                double dx = wp[2 * k] - wp[2 * k - 2], dy = wp[2 * k + 1] - wp[2 * k - 1];
+                arc += sqrt(dx * dx + dy * dy);
+            }
+            if (arc <= s) last = k;
+        }
+        ps->goal_idx = last + 1;
+    }
+    if (ps->goal_idx <= nwp - 1) {
+        /* _force_to_goal, social_force.py:119-138 */
+        double gx = wp[2 * ps->goal_idx] - pose[0], gy = wp[2 * ps->goal_idx + 1] - pose[1];
+        double gn = norm2(gx, gy);
+        if (gn == 0) gn += 0.000000001;
+        double vdes = ct[SGO_C_PED_SPEED_DESIRED];
+        double inv_tau = 1 / sf[SGO_SF_RELAX_TIME];
+        double fx = inv_tau * (vdes * (gx / gn) - vel[0]);
+        double fy = inv_tau * (vdes * (gy / gn) - vel[1]);
+        double hs, hc;
+        sgo_sincos(ct[SGO_C_PED_HEAD_ROT], &hs, &hc); /* rotate_coords: math.cos/math.sin(theta) */
+        for (int j = 0; j < E; ++j) { /* PedestrianSensor.get_nearby_pedestrians, sensor.py:55-64 */
+            if (j == i || !present[j] || sc->etype[j] != 1) continue;
+            const double *op = poses + (size_t)j * 6, *ov = vels + (size_t)j * 6;
+            if (!sgo_in_radius(pose[0], pose[1], ct[SGO_C_PED_RADIUS], op[0], op[1])) continue;
+            /* view direction of the NEIGHBOUR's rotated velocity, social_force.py:59-62; X.dot(R.T) */
+            double vx = fma(ov[0], hc, ov[1] * (-hs)), vy = fma(ov[0], hs, ov[1] * hc);
+            double vn = norm2(vx, vy) + 0.0000000001;
+            double ux = vx / vn, uy = vy / vn;
+            /* _force_pedestrian_repulsion, :140-176 */
+            double rx = pose[0] - op[0], ry = pose[1] - op[1];
+            double rn = norm2(rx, ry);
+            double vmag = norm2(ov[0], ov[1]) + 0.0000000001;
+            double odx = ov[0] / vmag, ody = ov[1] / vmag;
+            double step = vmag * (next_t - t);
+            double qx = rx - step * odx, qy = ry - step * ody;
+            double qn = norm2(qx, qy) + 0.0000000001;
+            double sum = rn + qn;
+            double b = (1.0 / 2) * sqrt(sum * sum - step * step);
+            double k1 = (1.0 / 4) * (1 / b) * sum;
+            double dbx = k1 * (rx / rn + qx / qn), dby = k1 * (ry / rn + qy / qn);
+            double k2 = sf[SGO_SF_REPULSE_V] / sf[SGO_SF_REPULSE_SIGMA] * sgo_exp(-b / sf[SGO_SF_REPULSE_SIGMA]);
+            double repx = k2 * dbx, repy = k2 * dby;
+            /* _force_pedestrian_attraction, :178-188 */
+            double k3 = 2 * sf[SGO_SF_ATTRACT_C];
+            double attx = k3 * rx, atty = k3 * ry;
+            if (sf[SGO_SF_SIGHT_USE] != 0.0) { /* _sight_weight, :213-222; np.dot = fma chain */
+                double w1 = fma(uy, repy, ux * repx) / (norm2(repx, repy) + 0.0000000001) >= sf[SGO_SF_COS_SIGHT]
+                                ? 1.0 : sf[SGO_SF_SIGHT_WEIGHT];
+                fx += w1 * repx; fy += w1 * repy;
+                double w2 = fma(uy, atty, ux * attx) / (norm2(attx, atty) + 0.0000000001) >= sf[SGO_SF_COS_SIGHT]
+                                ? 1.0 : sf[SGO_SF_SIGHT_WEIGHT];
+                fx += w2 * attx; fy += w2 * atty;
+            } else {
+                fx += attx; fy += atty;
+                fx += repx; fy += repy;
+            }
+        }
+        /* noise is off: np.random.normal(bias, 0) == bias */
+        speed = fmin(norm2(fx, fy) + sf[SGO_SF_BIAS_LON], vdes * sf[SGO_SF_MAX_SPEED_FACTOR]);
+        heading = sgo_atan2(fy, fx) + sf[SGO_SF_BIAS_LAT];
+        ps->fx = fx;
+        ps->fy = fy;
+    } else { /* reached the goal, agent.py:65-68 */
+        ps->fx = ps->fy = 0.0;
+    }
+    /* PedestrianController._step, pedestrian/controller.py:25-46 */
+    memcpy(np_, pose, 48);
+    double maxs = ct[SGO_C_PED_MAX_SPEED];
+    ps->speed = fmin(fmax(speed, -maxs), maxs);
+    double hs2, hc2;
+    sgo_sincos(heading, &hs2, &hc2);
+    double sd = ps->speed * state_dt;
+    np_[0] += sd * hc2;
+    np_[1] += sd * hs2;
+    np_[3] = heading;
+}
+
 int sgo_rollout(const sgo_scenario *sc, const sgo_config *cfg, int max_steps, int force_steps,
                 const double *actions, sgo_record *rec, sgo_event *events, int event_cap,
                 sgo_result *res)
@@ -461,6 +676,7 @@ int sgo_rollout(const sgo_scenario *sc, const sgo_config *cfg, int max_steps, in
     uint8_t *mult = (uint8_t *)calloc((size_t)E * E, 1);
     uint64_t *last_row = (uint64_t *)calloc(W, 8);
     ctrl_state *cs = (ctrl_state *)calloc(E, sizeof(ctrl_state));
+    ped_state *ps = (ped_state *)calloc(E, sizeof(ped_state));
     int *ids = (int *)malloc(E * sizeof(int)), *slot = (int *)malloc(E * sizeof(int));
     double *bpos = (double *)malloc((size_t)E * 6 * 8);
     double *scratch = (double *)malloc((size_t)E * 13 * 8);
@@ -518,7 +734,12 @@ int sgo_rollout(const sgo_scenario *sc, const sgo_config *cfg, int max_steps, in
                         rec->vels[(s_ * E + i_) * 6 + c_] = velvalid[i_] ? vels[(size_t)i_ * 6 + c_] : NaN; \
                 }                                                                               \
                 if (rec->dists) rec->dists[s_ * E + i_] = dists[i_];                            \
-                if (rec->extra) memcpy(rec->extra + (s_ * E + i_) * 4, &cs[i_], 32);            \
+                if (rec->extra) {                                                               \
+                    if (sc->kind[i_] == SGO_KIND_AGENT_PEDESTRIAN) {                            \
+                        double e4_[4] = {ps[i_].speed, (double)ps[i_].goal_idx, ps[i_].fx, ps[i_].fy}; \
+                        memcpy(rec->extra + (s_ * E + i_) * 4, e4_, 32);                        \
+                    } else memcpy(rec->extra + (s_ * E + i_) * 4, &cs[i_], 32);                 \
+                }                                                                               \
             }                                                                                   \
             if (rec->coll) memcpy(rec->coll + s_ * E * W, rows, (size_t)E * W * 8);             \
         }                                                                                       \
@@ -546,8 +767,11 @@ int sgo_rollout(const sgo_scenario *sc, const sgo_config *cfg, int max_steps, in
             case SGO_KIND_AGENT_REPLAY:
             case SGO_KIND_AGENT_PID:
             case SGO_KIND_AGENT_VEHICLE:
+            case SGO_KIND_AGENT_PEDESTRIAN:
                 if (present[i]) { /* scenario_gym.py:234-239 */
-                    if (sc->kind[i] == SGO_KIND_AGENT_REPLAY) {
+                    if (sc->kind[i] == SGO_KIND_AGENT_PEDESTRIAN) {
+                        ped_step(sc, cfg, i, poses, vels, present, t, next_t, state_dt, &ps[i], np_);
+                    } else if (sc->kind[i] == SGO_KIND_AGENT_REPLAY) {
                         sgo_position_at_t(KN(i), n, next_t, 0, 0, 0, np_); /* agent.py:125-128 */
                     } else {
                         memcpy(np_, poses + (size_t)i * 6, 48);
@@ -640,6 +864,6 @@ int sgo_rollout(const sgo_scenario *sc, const sgo_config *cfg, int max_steps, in
     batch_free(&B);
     free(poses); free(newp); free(vels); free(dists); free(present); free(newpres);
     free(velvalid); free(rows); free(mult); free(last_row); free(cs); free(ids); free(slot);
-    free(bpos); free(scratch);
+    free(bpos); free(scratch); free(ps);
     return 0;
 }

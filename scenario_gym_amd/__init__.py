@@ -2,8 +2,11 @@
 from .agent import (  # noqa: F401
     Agent,
     ExternalVehicleAgent,
+    PedestrianAgent,
     PIDAgent,
     ReplayTrajectoryAgent,
+    SocialForce,
+    SocialForceParameters,
     TeleportAction,
     VehicleAction,
 )

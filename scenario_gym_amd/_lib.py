@@ -10,18 +10,18 @@ LIB_PATH = os.environ.get("SGYM_LIB") or os.path.join(HERE, "lib", "libsgym_hip.
 
 SG_OK = 0
 ABI_VERSION = 1
-KIND_NONE, KIND_REPLAY, KIND_AGENT_REPLAY, KIND_AGENT_PID, KIND_AGENT_VEHICLE = range(5)
+KIND_NONE, KIND_REPLAY, KIND_AGENT_REPLAY, KIND_AGENT_PID, KIND_AGENT_VEHICLE, KIND_AGENT_PEDESTRIAN = range(6)
 TERM_MAX_LENGTH, TERM_COLLISION, TERM_EGO_COLLISION = 1, 2, 4
-NCTRL = 12
+NCTRL = 16
 (C_MAX_STEER, C_MAX_ACCEL, C_MAX_SPEED, C_ALLOW_REVERSE, C_STEER_KP, C_STEER_KD, C_ACCEL_KP,
- C_ACCEL_KD, C_ACCEL_KI) = range(9)
+ C_ACCEL_KD, C_ACCEL_KI, C_PED_SPEED_DESIRED, C_PED_MAX_SPEED, C_PED_HEAD_ROT, C_PED_RADIUS) = range(13)
 
 # SG_F_* rows of a state block (include/sgym.h)
-F_POSE, F_VEL, F_DIST, F_COLL, F_PRESENT, F_CTRL, F_COUNT = 0, 6, 12, 13, 14, 15, 19
+F_POSE, F_VEL, F_DIST, F_PRESENT, F_CTRL, F_FORCE, F_COLL = 0, 6, 12, 13, 14, 18, 20  # block_rows = F_COLL + row_words
 
 # every symbol include/sgym.h declares
 SYMBOLS = (
-    "sg_version", "sg_last_error", "sg_create", "sg_destroy", "sg_upload", "sg_reset",
+    "sg_version", "sg_last_error", "sg_create", "sg_destroy", "sg_upload", "sg_set_social_force", "sg_reset",
     "sg_set_timestep", "sg_step", "sg_rollout", "sg_rollout_async", "sg_synchronize", "sg_stream",
     "sg_state_view_get", "sg_read_metrics", "sg_read_record", "sg_copy_to_host", "sg_last_kernel_ms",
 )
@@ -37,13 +37,20 @@ class SgConfig(C.Structure):
 
 class SgScenarios(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in
-                ("kind", "etype", "bbox", "knot_off", "knots", "ctrl", "ego", "t0", "length")]
+                ("kind", "etype", "bbox", "knot_off", "knots", "ctrl", "ego", "t0", "length", "route_off", "routes")]
+
+
+class SgSocialForce(C.Structure):
+    _fields_ = [(n, C.c_double) for n in
+                ("relaxation_time", "ped_repulse_V", "ped_repulse_sigma", "ped_attract_C", "sight_weight",
+                 "sight_weight_use", "cos_sight", "max_speed_factor", "bias_lon", "bias_lat", "reserved0", "reserved1")]
 
 
 class SgStateView(C.Structure):
     _fields_ = [
         ("n_scenarios", C.c_int32), ("n_entities", C.c_int32), ("entity_stride", C.c_int32),
-        ("n_blocks", C.c_int32), ("blocks", C.c_void_p), ("scen", C.c_void_p),
+        ("n_blocks", C.c_int32), ("row_words", C.c_int32), ("block_rows", C.c_int32),
+        ("blocks", C.c_void_p), ("scen", C.c_void_p),
     ]
 
 
@@ -81,6 +88,7 @@ def load():
     lib.sg_create.argtypes = [C.POINTER(SgConfig), C.POINTER(H)]
     lib.sg_destroy.argtypes = [H]
     lib.sg_upload.argtypes = [H, C.POINTER(SgScenarios)]
+    lib.sg_set_social_force.argtypes = [H, C.POINTER(SgSocialForce)]
     lib.sg_reset.argtypes = [H]
     lib.sg_set_timestep.argtypes = [H, C.c_double]
     lib.sg_step.argtypes = [H, C.c_int32, C.c_void_p, C.c_int32]

@@ -160,3 +160,100 @@ def _create_agent(scenario: Scenario, entity: Entity) -> Optional[Agent]:
     if entity.ref == "ego":
         return ReplayTrajectoryAgent(entity)
     return None
+
+
+# --------------------------------------------------------------------------------------- pedestrians
+class BehaviourParameters:
+    """pedestrian/behaviour.py:8-15."""
+
+    max_speed_factor = 1.3
+
+    def __init__(self, **kwargs):
+        for k, v in kwargs.items():
+            setattr(self, k, v)
+
+
+class SocialForceParameters(BehaviourParameters):
+    """pedestrian/social_force.py:16-30 + random_walk.py:13-19.  The Gaussian noise terms
+    (std_lon / std_lat, drawn from the global numpy RNG in the reference) are not reproduced on the
+    device: construct with std_lon=0, std_lat=0 (the device path refuses anything else)."""
+
+    bias_lon = 0.0
+    bias_lat = 0.0
+    std_lon = 0.000002
+    std_lat = 0.0000001
+    distance_threshold = 3
+    sight_weight = 0.5
+    sight_weight_use = True
+    sight_angle = 200
+    relaxation_time = 1.5
+    ped_repulse_V = 1.0
+    ped_repulse_sigma = 1.0
+    ped_attract_C = 0.0
+    boundary_repulse_U = 10.0
+    boundary_repulse_R = 0.2
+    imp_boundary_repulse_U = 2.0
+    imp_boundary_repulse_R = 0.1
+
+
+class SocialForce:
+    """pedestrian/social_force.py:33-42: the behaviour object only carries its parameters here."""
+
+    def __init__(self, params: SocialForceParameters):
+        self.params = params
+        self.max_speed_factor = params.max_speed_factor
+
+    def device_params(self) -> dict:
+        p = self.params
+        if p.std_lon != 0 or p.std_lat != 0:
+            raise NotImplementedError("the device social force is deterministic: use std_lon=0, std_lat=0")
+        return dict(relaxation_time=p.relaxation_time, ped_repulse_V=p.ped_repulse_V,
+                    ped_repulse_sigma=p.ped_repulse_sigma, ped_attract_C=p.ped_attract_C,
+                    sight_weight=p.sight_weight, sight_weight_use=p.sight_weight_use, sight_angle=p.sight_angle,
+                    max_speed_factor=p.max_speed_factor, bias_lon=p.bias_lon, bias_lat=p.bias_lat)
+
+
+class PedestrianSensor(Sensor):
+    """pedestrian/sensor.py:12-40."""
+
+    def __init__(self, entity, head_rot_angle: float = 0.0, distance_threshold: float = 1.0):
+        super().__init__(entity)
+        self.head_rot_angle = head_rot_angle
+        self.distance_threshold = distance_threshold
+
+
+class PedestrianController(Controller):
+    """pedestrian/controller.py:9-46."""
+
+    device_kind = L.KIND_AGENT_PEDESTRIAN
+
+    def __init__(self, entity, max_speed: float = 5.0):
+        super().__init__(entity)
+        self.max_speed = max_speed
+
+
+class PedestrianAgent(Agent):
+    """pedestrian/agent.py:15-69: follows `route` with the social force model."""
+
+    def __init__(self, entity, route, speed_desired: float, behaviour: SocialForce, max_speed: float = 5.0,
+                 head_rot_angle: float = 0.0, distance_threshold: float = 1.0):
+        super().__init__(entity, PedestrianController(entity, max_speed=max_speed),
+                         PedestrianSensor(entity, head_rot_angle=head_rot_angle, distance_threshold=distance_threshold))
+        if not isinstance(behaviour, SocialForce):
+            raise NotImplementedError("only the SocialForce behaviour is lowered to the device")
+        self.goal_idx = 0
+        self.speed_desired = speed_desired
+        self.behaviour = behaviour
+        self.force = np.array([0.0, 0.0])
+        self.route = np.asarray(route, np.float64).reshape(-1, 2)
+
+    def device_kind(self):
+        return L.KIND_AGENT_PEDESTRIAN
+
+    def ctrl_row(self):
+        row = self.controller.ctrl_row()
+        row[L.C_PED_SPEED_DESIRED] = self.speed_desired
+        row[L.C_PED_MAX_SPEED] = self.controller.max_speed
+        row[L.C_PED_HEAD_ROT] = self.sensor.head_rot_angle
+        row[L.C_PED_RADIUS] = self.sensor.distance_threshold
+        return row

@@ -32,8 +32,10 @@ enum {
     ST_MIN_T, ST_MAX_T,                 // Trajectory.min_t / max_t
     ST_KNOT_OFF,                        // int64 first row of the entity's own knots
     ST_META,                            // int64: kind | etype << 8 | knot_n << 32
-    ST_CTRL,                            // 9 rows of controller parameters (SG_C_*)
-    ST_COUNT = ST_CTRL + 9
+    ST_ROUTE,                           // int64: first route waypoint | n_waypoints << 48 (pedestrian agents)
+    ST_CTRL,                            // NCTRL_ROWS rows of controller parameters (SG_C_*)
+    NCTRL_ROWS = 13,
+    ST_COUNT = ST_CTRL + NCTRL_ROWS     // 22 rows
 };
 constexpr uint32_t ROW = 512; // bytes of one field row of a block (64 lanes x 8 B)
 
@@ -53,10 +55,14 @@ struct Params {
     const double *knots;     // [rows][7] own knots of every entity
     const double *grid_t;    // union knot grids, all scenarios
     double *grid_y;          // [grid rows][6][EP] stage-1 resample
-    double *dyn;             // [n_blocks][SG_F_COUNT][64]
+    double *dyn;             // [n_blocks][FROWS][64]
     sg_scenario_state *sdyn; // [R]
     sg_event *events;        // [R][ev_cap]
     double *rec_t, *rec_pose;
+    const double *routes;    // [rows][2] pedestrian route waypoints
+    const double *gon;       // [64][2] cos, sin of 2*pi*i/64 (host libm): Point.buffer(r) vertices
+    int WV, FROWS;           // waves per scenario (1, 2, 4); rows per state block = SG_F_COLL + WV
+    sg_social_force sf;
 };
 
 // Lane pointers into one 64-slot block.  Global loads/stores carry an immediate offset (the compiler
@@ -379,14 +385,21 @@ __device__ __forceinline__ bool sg_quads_intersect(const double *A, const double
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-struct CollLds {
-    float cx[64], cy[64]; // box centres (NaN when absent), SoA for packed-fp32 pair math
-    float2 sc[64];    // sin, cos of the heading
-    float2 half[64];  // half length, half width (static)
-    double cor[8][64]; // fp64 corners, only filled on the exact path
-    int last[64];
-    double ctrl[9][64]; // controller parameters (SG_C_*) of every lane, copied once per launch
-    double boxwl[2][64]; // bounding box width, length (exact path and controllers only)
+// Workgroup-shared tile data.  NS = slots of the tile set a workgroup owns: 64 when one wavefront
+// carries 64/G scenarios (WV = 1), 64*WV when WV wavefronts carry one scenario of up to 64*WV entities.
+template <int NS, bool PED>
+struct TileLds {
+    float cx[NS], cy[NS];   // box centres (NaN when absent), SoA for packed-fp32 pair math
+    float2 sc[NS];          // sin, cos of the heading
+    float2 half[NS];        // half length, half width (static)
+    double cor[8][NS];      // fp64 corners, only filled on the exact path
+    int last[NS];
+    double ctrl[NCTRL_ROWS][NS]; // controller parameters (SG_C_*) of every slot, copied once per launch
+    double boxwl[2][NS];    // bounding box width, length (exact path and controllers only)
+    // social force inputs of the CURRENT state (pedestrian/sensor.py:55-64): reference point, velocity
+    double px[PED ? NS : 1], py[PED ? NS : 1], vx[PED ? NS : 1], vy[PED ? NS : 1];
+    unsigned char isped[PED ? NS : 1]; // entity.type == "Pedestrian" and present
+    int flag[4];
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -395,13 +408,14 @@ struct CollLds {
 struct CtrlState { double speed, e_lon_prev, e_lat_prev, e_lon_int; };
 
 // VehicleController._step (controller.py:105-140); sin_h/cos_h of the current heading come from
-// the previous step's corner computation.
-__device__ __forceinline__ void vehicle_step(CtrlState &cs, const CollLds &st, int lane, double l,
+// the previous step's corner computation.  cp = this slot's column of the LDS parameter table.
+template <typename LDS>
+__device__ __forceinline__ void vehicle_step(CtrlState &cs, const LDS &st, int sl, double l,
                                              double dt, double accel, double steer, double sin_h,
                                              double cos_h, double *pose, ConstTbl K)
 {
-    double max_steer = st.ctrl[SG_C_MAX_STEER][lane], max_accel = st.ctrl[SG_C_MAX_ACCEL][lane];
-    double max_speed = st.ctrl[SG_C_MAX_SPEED][lane], allow_rev = st.ctrl[SG_C_ALLOW_REVERSE][lane];
+    double max_steer = st.ctrl[SG_C_MAX_STEER][sl], max_accel = st.ctrl[SG_C_MAX_ACCEL][sl];
+    double max_speed = st.ctrl[SG_C_MAX_SPEED][sl], allow_rev = st.ctrl[SG_C_ALLOW_REVERSE][sl];
     accel = __builtin_fmin(__builtin_fmax(accel, -max_accel), max_accel);
     steer = __builtin_fmin(__builtin_fmax(steer, -max_steer), max_steer);
     double dx = cs.speed * cos_h;
@@ -417,7 +431,8 @@ __device__ __forceinline__ void vehicle_step(CtrlState &cs, const CollLds &st, i
 }
 
 // PIDController._step (controller.py:205-258)
-__device__ __forceinline__ void pid_step(CtrlState &cs, const CollLds &st, int lane, double l,
+template <typename LDS>
+__device__ __forceinline__ void pid_step(CtrlState &cs, const LDS &st, int sl, double l,
                                          double state_dt, double dt, double tx, double ty,
                                          double sin_h, double cos_h, double *pose, ConstTbl K)
 {
@@ -431,39 +446,244 @@ __device__ __forceinline__ void pid_step(CtrlState &cs, const CollLds &st, int l
     const RecipDiv rd(state_dt); // both derivative terms divide by State.dt
     const bool fast = rd.safe(e_lat - cs.e_lat_prev) && rd.safe(e_lon - cs.e_lon_prev);
     double e_lat_D = fast ? rd.div(e_lat - cs.e_lat_prev) : (e_lat - cs.e_lat_prev) / state_dt;
-    double kp = st.ctrl[SG_C_STEER_KP][lane] * gain, kd = st.ctrl[SG_C_STEER_KD][lane] * gain;
+    double kp = st.ctrl[SG_C_STEER_KP][sl] * gain, kd = st.ctrl[SG_C_STEER_KD][sl] * gain;
     double steer = kp * e_lat + kd * e_lat_D;
     double e_lon_D = fast ? rd.div(e_lon - cs.e_lon_prev) : (e_lon - cs.e_lon_prev) / state_dt;
     double e_lon_I = cs.e_lon_int + e_lon * state_dt;
     double accel = 0.0;
     if (__builtin_fabs(e_lon) > 0.1)
-        accel = st.ctrl[SG_C_ACCEL_KP][lane] * e_lon + st.ctrl[SG_C_ACCEL_KD][lane] * e_lon_D +
-                st.ctrl[SG_C_ACCEL_KI][lane] * e_lon_I;
+        accel = st.ctrl[SG_C_ACCEL_KP][sl] * e_lon + st.ctrl[SG_C_ACCEL_KD][sl] * e_lon_D +
+                st.ctrl[SG_C_ACCEL_KI][sl] * e_lon_I;
     cs.e_lat_prev = e_lat;
     cs.e_lon_prev = e_lon;
     cs.e_lon_int = e_lon_I;
-    vehicle_step(cs, st, lane, l, dt, accel, steer, sin_h, cos_h, pose, K);
+    vehicle_step(cs, st, sl, l, dt, accel, steer, sin_h, cos_h, pose, K);
+}
+
+// ------------------------------------------------------------------------------------------------
+// pedestrians: exp / atan2 shared (by restatement) with the oracle's sgo_exp / sgo_atan2
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double sg_exp(double x)
+{
+    const double LN2HI = 6.93147180369123816490e-01, LN2LO = 1.90821492927058770002e-10,
+                 INVLN2 = 1.44269504088896338700e+00;
+    const double P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03,
+                 P3 = 6.61375632143793436117e-05, P4 = -1.65339022054652515390e-06,
+                 P5 = 4.13813679705723846039e-08;
+    if (x != x) return x;
+    if (x > 709.782712893383973096) return __builtin_inf();
+    if (x < -745.13321910194110842) return 0.0;
+    double k = __builtin_rint(x * INVLN2);
+    double hi = x - k * LN2HI;
+    double lo = k * LN2LO;
+    double r = hi - lo;
+    double t = r * r;
+    double c = r - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))));
+    double y = 1.0 - ((lo - (r * c) / (2.0 - c)) - hi);
+    return ldexp(y, (int)k);
+}
+
+__device__ __forceinline__ double sg_atan_pos(double ax)
+{
+    const double A0 = 3.33333333333329318027e-01, A1 = -1.99999999998764832476e-01,
+                 A2 = 1.42857142725034663711e-01, A3 = -1.11111104054623557880e-01,
+                 A4 = 9.09088713343650656196e-02, A5 = -7.69187620504482999495e-02,
+                 A6 = 6.66107313738753120669e-02, A7 = -5.83357013379057348645e-02,
+                 A8 = 4.97687799461593236017e-02, A9 = -3.65315727442169155270e-02,
+                 A10 = 1.62858201153657823623e-02;
+    if (ax >= 7.378697629483821e19) return 1.57079632679489655800e+00 + 6.12323399573676603587e-17;
+    int id;
+    double x, hi, lo;
+    if (ax < 0.4375) { id = -1; x = ax; hi = 0.0; lo = 0.0; }
+    else if (ax < 0.6875) { id = 0; x = (2.0 * ax - 1.0) / (2.0 + ax); hi = 4.63647609000806093515e-01; lo = 2.26987774529616870924e-17; }
+    else if (ax < 1.1875) { id = 1; x = (ax - 1.0) / (ax + 1.0); hi = 7.85398163397448278999e-01; lo = 3.06161699786838301793e-17; }
+    else if (ax < 2.4375) { id = 2; x = (ax - 1.5) / (1.0 + 1.5 * ax); hi = 9.82793723247329054082e-01; lo = 1.39033110312309984516e-17; }
+    else { id = 3; x = -1.0 / ax; hi = 1.57079632679489655800e+00; lo = 6.12323399573676603587e-17; }
+    double z = x * x, w = z * z;
+    double s1 = z * (A0 + w * (A2 + w * (A4 + w * (A6 + w * (A8 + w * A10)))));
+    double s2 = w * (A1 + w * (A3 + w * (A5 + w * (A7 + w * A9))));
+    if (id < 0) return x - x * (s1 + s2);
+    return hi - ((x * (s1 + s2) - lo) - x);
+}
+
+__device__ __forceinline__ double sg_atan2(double y, double x)
+{
+    const double PI = 3.1415926535897931160E+00, PI_LO = 1.2246467991473531772E-16;
+    if (x != x || y != y) return x + y;
+    if (y == 0.0) return (x < 0.0 || (x == 0.0 && __builtin_signbit(x))) ? __builtin_copysign(PI, y) : y;
+    if (x == 0.0) return __builtin_copysign(0.5 * PI, y);
+    double z = sg_atan_pos(__builtin_fabs(y / x));
+    if (x > 0.0) return y > 0.0 ? z : -z;
+    z = PI - (z - PI_LO);
+    return y > 0.0 ? z : -z;
+}
+
+// State.get_entities_in_radius (state/state.py:356-372): centre strictly inside the 64-gon
+// Point(cx, cy).buffer(r); gon = cos/sin table of the polygon's vertex angles.
+__device__ __forceinline__ bool sg_in_radius(double cx, double cy, double r, double px, double py, const double *gon)
+{
+    double dx = px - cx, dy = py - cy, d2 = dx * dx + dy * dy, r2 = r * r;
+    if (d2 > r2 * (1.0 + 1e-9)) return false;
+    if (d2 < r2 * 0.9975) return true;
+    double o = 0.0;
+    for (int i = 0; i < 64; ++i) {
+        int j = (i + 1) & 63;
+        double ax = cx + r * gon[2 * i], ay = cy - r * gon[2 * i + 1];
+        double bx = cx + r * gon[2 * j], by = cy - r * gon[2 * j + 1];
+        o += ax * by - bx * ay;
+    }
+    for (int i = 0; i < 64; ++i) {
+        int j = (i + 1) & 63;
+        double ax = cx + r * gon[2 * i], ay = cy - r * gon[2 * i + 1];
+        double bx = cx + r * gon[2 * j], by = cy - r * gon[2 * j + 1];
+        double cr = (bx - ax) * (py - ay) - (by - ay) * (px - ax);
+        if (o > 0 ? !(cr > 0) : !(cr < 0)) return false;
+    }
+    return true;
+}
+
+// LineString(route).project(Point) + the goal update of PedestrianAgent._step (pedestrian/agent.py:59-62)
+__device__ __forceinline__ int ped_goal_update(const double *wp, int nwp, double px, double py)
+{
+    double best = __builtin_inf(), best_s = 0.0, acc = 0.0;
+    for (int i = 0; i + 1 < nwp; ++i) {
+        double ax = wp[2 * i], ay = wp[2 * i + 1], dx = wp[2 * i + 2] - ax, dy = wp[2 * i + 3] - ay;
+        double L2 = dx * dx + dy * dy;
+        double u = L2 == 0.0 ? 0.0 : __builtin_fmin(1.0, __builtin_fmax(0.0, ((px - ax) * dx + (py - ay) * dy) / L2));
+        double qx = ax + u * dx, qy = ay + u * dy;
+        double ex = px - qx, ey = py - qy;
+        double dist = __builtin_sqrt(ex * ex + ey * ey);
+        double L = __builtin_sqrt(L2);
+        if (dist < best) { best = dist; best_s = acc + u * L; }
+        acc += L;
+    }
+    double arc = 0.0;
+    int last = 0;
+    for (int k = 0; k < nwp; ++k) {
+        if (k > 0) {
+            double dx = wp[2 * k] - wp[2 * k - 2], dy = wp[2 * k + 1] - wp[2 * k - 1];
+            arc += __builtin_sqrt(dx * dx + dy * dy);
+        }
+        if (arc <= best_s) last = k;
+    }
+    return last + 1;
+}
+
+// PedestrianAgent.step for one lane: SocialForce._step (pedestrian/social_force.py:44-222, boundary
+// terms off) over the neighbour candidates `nbr` of the tile + PedestrianController._step
+// (pedestrian/controller.py:25-46).  All inputs are the CURRENT state (LDS px/py/vx/vy).
+template <int WV, typename LDS>
+__device__ __forceinline__ void ped_step(const Params &p, const LDS &L, int sl, int tile0, const uint64_t (&nbr)[WV],
+                                         const double *pose, double velx, double vely, double t, double next_t,
+                                         double state_dt, const double *wp, int nwp, int &goal_idx,
+                                         double &cspeed, double &fxo, double &fyo, double *np_, ConstTbl K)
+{
+    const sg_social_force &sf = p.sf;
+    double speed = 0.0, heading = 0.0;
+    if (goal_idx <= nwp - 1) goal_idx = ped_goal_update(wp, nwp, pose[0], pose[1]);
+    if (goal_idx <= nwp - 1) {
+        double gx = wp[2 * goal_idx] - pose[0], gy = wp[2 * goal_idx + 1] - pose[1]; // _force_to_goal, :119-138
+        double gn = sg_norm2(gx, gy);
+        if (gn == 0) gn += 0.000000001;
+        const double vdes = L.ctrl[SG_C_PED_SPEED_DESIRED][sl];
+        const double inv_tau = 1 / sf.relaxation_time;
+        double fx = inv_tau * (vdes * (gx / gn) - velx);
+        double fy = inv_tau * (vdes * (gy / gn) - vely);
+        double hs, hc;
+        sg_sincos(L.ctrl[SG_C_PED_HEAD_ROT][sl], hs, hc, K);
+        const double radius = L.ctrl[SG_C_PED_RADIUS][sl];
+#pragma unroll
+        for (int w = 0; w < WV; ++w) {
+            uint64_t m = nbr[w];
+            while (m) {
+                const int j = tile0 + w * 64 + __builtin_ctzll(m);
+                m &= m - 1;
+                if (!L.isped[j]) continue; // PedestrianSensor: pedestrians only (sensor.py:60-62)
+                const double ox = L.px[j], oy = L.py[j], ovx = L.vx[j], ovy = L.vy[j];
+                if (!sg_in_radius(pose[0], pose[1], radius, ox, oy, p.gon)) continue;
+                // view direction = the neighbour's velocity rotated by the head angle (:59-62, X.dot(R.T))
+                double vx = __builtin_fma(ovx, hc, ovy * (-hs)), vy = __builtin_fma(ovx, hs, ovy * hc);
+                double vn = sg_norm2(vx, vy) + 0.0000000001;
+                double ux = vx / vn, uy = vy / vn;
+                double rx = pose[0] - ox, ry = pose[1] - oy; // _force_pedestrian_repulsion, :140-176
+                double rn = sg_norm2(rx, ry);
+                double vmag = sg_norm2(ovx, ovy) + 0.0000000001;
+                double odx = ovx / vmag, ody = ovy / vmag;
+                double step = vmag * (next_t - t);
+                double qx = rx - step * odx, qy = ry - step * ody;
+                double qn = sg_norm2(qx, qy) + 0.0000000001;
+                double sum = rn + qn;
+                double b = (1.0 / 2) * __builtin_sqrt(sum * sum - step * step);
+                double k1 = (1.0 / 4) * (1 / b) * sum;
+                double dbx = k1 * (rx / rn + qx / qn), dby = k1 * (ry / rn + qy / qn);
+                double k2 = sf.ped_repulse_V / sf.ped_repulse_sigma * sg_exp(-b / sf.ped_repulse_sigma);
+                double repx = k2 * dbx, repy = k2 * dby;
+                double k3 = 2 * sf.ped_attract_C; // _force_pedestrian_attraction, :178-188
+                double attx = k3 * rx, atty = k3 * ry;
+                if (sf.sight_weight_use != 0.0) { // _sight_weight, :213-222
+                    double w1 = __builtin_fma(uy, repy, ux * repx) / (sg_norm2(repx, repy) + 0.0000000001) >= sf.cos_sight
+                                    ? 1.0 : sf.sight_weight;
+                    fx += w1 * repx; fy += w1 * repy;
+                    double w2 = __builtin_fma(uy, atty, ux * attx) / (sg_norm2(attx, atty) + 0.0000000001) >= sf.cos_sight
+                                    ? 1.0 : sf.sight_weight;
+                    fx += w2 * attx; fy += w2 * atty;
+                } else {
+                    fx += attx; fy += atty;
+                    fx += repx; fy += repy;
+                }
+            }
+        }
+        speed = __builtin_fmin(sg_norm2(fx, fy) + sf.bias_lon, vdes * sf.max_speed_factor);
+        heading = sg_atan2(fy, fx) + sf.bias_lat;
+        fxo = fx;
+        fyo = fy;
+    } else { // reached the goal, agent.py:65-68
+        fxo = fyo = 0.0;
+    }
+    const double maxs = L.ctrl[SG_C_PED_MAX_SPEED][sl]; // PedestrianController._step
+    cspeed = __builtin_fmin(__builtin_fmax(speed, -maxs), maxs);
+    double hs2, hc2;
+    sg_sincos(heading, hs2, hc2, K);
+    const double sd = cspeed * state_dt;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) np_[c] = pose[c];
+    np_[0] += sd * hc2;
+    np_[1] += sd * hs2;
+    np_[3] = heading;
 }
 
 // ------------------------------------------------------------------------------------------------
 // State.collisions() for one tile (state.py:306-310 -> state/utils.py:10-49 -> utils.py:28-62).
-// Returns this lane's adjacency row (bit j = tile slot j).
+// Fills this lane's adjacency row (bit j of word j/64 = tile slot j) and, for PED, the lane's
+// neighbour candidate row for the next step's social force.
 //
 //   broad phase  fp32 bounding circles about the box centres, all pairs inside the tile: every
-//                lane walks the tile's centres through wave-uniform LDS reads (broadcast) and the
-//                v_cmp result IS the ballot of column j; columns without a hit cost 5 VALU ops.
+//                lane walks the tile's centres through wave-uniform LDS broadcasts, packed fp32.
 //   filter       fp32 rectangle-rectangle separating-axis test (4 axes) on the candidate pairs
 //                with a conservative error margin: certain-overlap / certain-separation decide.
 //   exact        pairs inside the margin (touching, or bit-identical boxes) take the fp64
 //                8-edge test on the corners -- the same operation sequence as the CPU oracle.
 // The fp32 stages are strictly conservative, so the result equals the fp64 test on every pair.
+// With WV > 1 the tile spans WV wavefronts of one workgroup; only the decisions that gate LDS
+// writes are workgroup-uniform (block_any), the candidate loops run per wavefront.
 // ------------------------------------------------------------------------------------------------
-template <int G>
-__device__ __forceinline__ uint64_t tile_collisions(bool present, double x, double y, double s, double c,
-                                                    double bcx, double bcy, float rad_thr,
-                                                    int lane, CollLds &L, uint64_t *mult_rows)
+template <int WV>
+__device__ __forceinline__ bool block_any(bool x)
 {
-    const int base = lane & ~(G - 1), slot = lane & (G - 1);
+    if (WV == 1) return __any(x);
+    return __syncthreads_or(x);
+}
+
+template <int G, int WV, bool PED, typename LDS>
+__device__ __forceinline__ void tile_collisions(bool present, const double *pose, double velx, double vely,
+                                                double s, double c, double bcx, double bcy, float rad_thr,
+                                                float nbr_thr, bool is_ped_type, int sl, int tile0, LDS &L,
+                                                uint64_t (&rows_out)[WV], uint64_t (&mult_rows)[WV],
+                                                uint64_t (&nbr_out)[WV])
+{
+    constexpr int TS = G * WV; // tile slots
+    const int slot = sl - tile0;
+    const double x = pose[0], y = pose[1];
     // box centre; bounding circle radius + margins live in rad_thr (static per lane)
     const double ccx = x + (bcx * c - bcy * s), ccy = y + (bcx * s + bcy * c);
     const float nanf_ = __builtin_nanf("");
@@ -474,9 +694,13 @@ __device__ __forceinline__ uint64_t tile_collisions(bool present, double x, doub
     const float reach = rad_thr + 1.9073486e-6f * mag;
     const float thr = reach * reach;
     __syncthreads();
-    L.cx[lane] = fx;
-    L.cy[lane] = fy;
-    L.sc[lane] = make_float2(fs, fc);
+    L.cx[sl] = fx;
+    L.cy[sl] = fy;
+    L.sc[sl] = make_float2(fs, fc);
+    if (PED) {
+        L.px[sl] = x; L.py[sl] = y; L.vx[sl] = velx; L.vy[sl] = vely;
+        L.isped[sl] = present && is_ped_type;
+    }
     __syncthreads();
     // All pairs of the tile: lane i tests itself against slots j..j+3 per iteration (wave-uniform
     // LDS broadcast reads, one ds_read_b128 per coordinate, two iterations prefetched), everything in
@@ -484,115 +708,177 @@ __device__ __forceinline__ uint64_t tile_collisions(bool present, double x, doub
     // "outside"; the sign bits are shifted into the lane's row with one v_alignbit_b32 per column
     // (columns walked high -> low).  3.5 VALU ops per column, no branches, no compares.
     const v2f fx2 = {fx, fx}, fy2 = {fy, fy}, thr2 = {thr, thr};
-    uint32_t out_w[2] = {0u, 0u}; // bit j = 1: slot j is OUTSIDE this lane's reach
-    v4f xs = *reinterpret_cast<const v4f *>(&L.cx[base + G - 4]);
-    v4f ys = *reinterpret_cast<const v4f *>(&L.cy[base + G - 4]);
+    const float nreach = nbr_thr + 1.9073486e-6f * mag;
+    const v2f nthr2 = {nreach * nreach, nreach * nreach};
+    uint32_t out_w[2 * WV], nout_w[2 * WV]; // bit j = 1: slot j is OUTSIDE this lane's reach
+#pragma unroll
+    for (int w = 0; w < 2 * WV; ++w) { out_w[w] = 0u; nout_w[w] = 0u; }
+    v4f xs = *reinterpret_cast<const v4f *>(&L.cx[tile0 + TS - 4]);
+    v4f ys = *reinterpret_cast<const v4f *>(&L.cy[tile0 + TS - 4]);
     v4f xs1 = xs, ys1 = ys;
-    if (G >= 8) {
-        xs1 = *reinterpret_cast<const v4f *>(&L.cx[base + G - 8]);
-        ys1 = *reinterpret_cast<const v4f *>(&L.cy[base + G - 8]);
+    if (TS >= 8) {
+        xs1 = *reinterpret_cast<const v4f *>(&L.cx[tile0 + TS - 8]);
+        ys1 = *reinterpret_cast<const v4f *>(&L.cy[tile0 + TS - 8]);
     }
 #pragma unroll
-    for (int jb = G - 4; jb >= 0; jb -= 4) {
+    for (int jb = TS - 4; jb >= 0; jb -= 4) {
         v4f xs2 = xs1, ys2 = ys1; // two groups of four slots stay in flight
         if (jb >= 8) {
-            xs2 = *reinterpret_cast<const v4f *>(&L.cx[base + jb - 8]);
-            ys2 = *reinterpret_cast<const v4f *>(&L.cy[base + jb - 8]);
+            xs2 = *reinterpret_cast<const v4f *>(&L.cx[tile0 + jb - 8]);
+            ys2 = *reinterpret_cast<const v4f *>(&L.cy[tile0 + jb - 8]);
         }
 #ifndef SG_NO_SCHED_BARRIER
         __builtin_amdgcn_sched_barrier(0); // keep the prefetch above the arithmetic it overlaps with
 #endif
         v2f dxa = v2f{xs.x, xs.y} - fx2, dya = v2f{ys.x, ys.y} - fy2;
         v2f dxb = v2f{xs.z, xs.w} - fx2, dyb = v2f{ys.z, ys.w} - fy2;
-        v2f ma = thr2 - __builtin_elementwise_fma(dya, dya, dxa * dxa);
-        v2f mb = thr2 - __builtin_elementwise_fma(dyb, dyb, dxb * dxb);
+        v2f d2a = __builtin_elementwise_fma(dya, dya, dxa * dxa);
+        v2f d2b = __builtin_elementwise_fma(dyb, dyb, dxb * dxb);
+        v2f ma = thr2 - d2a, mb = thr2 - d2b;
         uint32_t w = out_w[jb >> 5];
         w = __builtin_amdgcn_alignbit(w, __float_as_uint(mb.y), 31); // w = (w << 1) | sign
         w = __builtin_amdgcn_alignbit(w, __float_as_uint(mb.x), 31);
         w = __builtin_amdgcn_alignbit(w, __float_as_uint(ma.y), 31);
         w = __builtin_amdgcn_alignbit(w, __float_as_uint(ma.x), 31);
         out_w[jb >> 5] = w;
+        if (PED) { // second reach: PedestrianSensor.distance_threshold
+            v2f na = nthr2 - d2a, nb = nthr2 - d2b;
+            uint32_t v = nout_w[jb >> 5];
+            v = __builtin_amdgcn_alignbit(v, __float_as_uint(nb.y), 31);
+            v = __builtin_amdgcn_alignbit(v, __float_as_uint(nb.x), 31);
+            v = __builtin_amdgcn_alignbit(v, __float_as_uint(na.y), 31);
+            v = __builtin_amdgcn_alignbit(v, __float_as_uint(na.x), 31);
+            nout_w[jb >> 5] = v;
+        }
         xs = xs1; ys = ys1;
         xs1 = xs2; ys1 = ys2;
     }
-    // absent slots hold NaN centres (sign bit clear): mask them with the tile's presence bits
-    uint64_t pres_tile = __ballot(present) >> base;
-    uint64_t inside = ~(((uint64_t)out_w[1] << 32) | out_w[0]);
-    if (G < 64) inside &= (1ull << (G & 63)) - 1;
-    const uint32_t cand_w[2] = {(uint32_t)(inside & pres_tile), (uint32_t)((inside & pres_tile) >> 32)};
+    // absent slots hold NaN centres (sign bit unspecified): mask them with the tile's presence bits
+    uint64_t cand[WV];
+    bool any_cand = false;
+#pragma unroll
+    for (int w = 0; w < WV; ++w) {
+        uint64_t pres_w;
+        if (WV == 1) {
+            pres_w = __ballot(present) >> tile0;
+            if (G < 64) pres_w &= (1ull << (G & 63)) - 1;
+        } else {
+            pres_w = ~0ull; // cross-wave presence: filtered by the NaN-safe compare in the narrow phase
+        }
+        uint64_t inside = ~(((uint64_t)out_w[2 * w + 1] << 32) | out_w[2 * w]) & pres_w;
+        if (WV == 1 && G < 64) inside &= (1ull << (G & 63)) - 1;
+        if ((slot >> 6) == w) inside &= ~(1ull << (slot & 63)); // not with itself
+        cand[w] = present ? inside : 0;
+        if (PED) {
+            uint64_t nin = ~(((uint64_t)nout_w[2 * w + 1] << 32) | nout_w[2 * w]) & pres_w;
+            if (WV == 1 && G < 64) nin &= (1ull << (G & 63)) - 1;
+            if ((slot >> 6) == w) nin &= ~(1ull << (slot & 63));
+            nbr_out[w] = present ? nin : 0;
+        } else {
+            nbr_out[w] = 0;
+        }
+        rows_out[w] = 0;
+        mult_rows[w] = 0;
+        any_cand = any_cand || cand[w] != 0;
+    }
 #ifdef SG_ABL_NO_NARROW
-    *mult_rows = 0;
-    return ((uint64_t)cand_w[1] << 32) | cand_w[0];
+#pragma unroll
+    for (int w = 0; w < WV; ++w) rows_out[w] = cand[w];
+    return;
 #endif
-    uint64_t cand = ((uint64_t)cand_w[1] << 32) | cand_w[0];
-    cand &= ~(1ull << slot); // not with itself
-    cand = present ? cand : 0;
-    *mult_rows = 0;
-    if (!__any(cand != 0)) return 0; // wave-uniform
-
-    const float2 myh = L.half[lane];
+    // ---- filter: per wavefront, LDS reads only ----
+    const float2 myh = L.half[sl];
     const float hl = myh.x, hw = myh.y;
-    uint64_t rows = 0, fuzzy = 0;
-    while (__any(cand != 0)) {
-        if (cand) {
-            int j = __builtin_ctzll(cand);
-            cand &= cand - 1;
-            float2 oc = make_float2(L.cx[base + j], L.cy[base + j]), os = L.sc[base + j], oh = L.half[base + j];
-            float dx = oc.x - fx, dy = oc.y - fy;
-            float cd = __builtin_fabsf(fc * os.y + fs * os.x);  // |cos(delta heading)|
-            float sd = __builtin_fabsf(fs * os.y - fc * os.x);  // |sin(delta heading)|
-            float g0 = __builtin_fabsf(dx * fc + dy * fs) - (hl + oh.x * cd + oh.y * sd);
-            float g1 = __builtin_fabsf(dy * fc - dx * fs) - (hw + oh.x * sd + oh.y * cd);
-            float g2 = __builtin_fabsf(dx * os.y + dy * os.x) - (oh.x + hl * cd + hw * sd);
-            float g3 = __builtin_fabsf(dy * os.y - dx * os.x) - (oh.y + hl * sd + hw * cd);
-            float gap = __builtin_fmaxf(__builtin_fmaxf(g0, g1), __builtin_fmaxf(g2, g3));
-            float eps = 1e-3f + 1.9073486e-6f * (mag + __builtin_fabsf(oc.x) + __builtin_fabsf(oc.y));
-            bool unsure = !(gap > eps) && !(gap < -eps);
-            unsure = unsure || (dx == 0.0f && dy == 0.0f); // possibly bit-identical boxes
-            if (unsure) fuzzy |= 1ull << j;
-            else if (gap < -eps) rows |= 1ull << j;
+    uint64_t fuzzy[WV];
+#pragma unroll
+    for (int w = 0; w < WV; ++w) fuzzy[w] = 0;
+    bool any_fuzzy = false;
+    if (__any(any_cand)) {
+#pragma unroll
+        for (int w = 0; w < WV; ++w) {
+            while (__any(cand[w] != 0)) {
+                if (cand[w]) {
+                    const int jl = __builtin_ctzll(cand[w]);
+                    cand[w] &= cand[w] - 1;
+                    const int j = tile0 + w * 64 + jl;
+                    float2 oc = make_float2(L.cx[j], L.cy[j]), os = L.sc[j], oh = L.half[j];
+                    float dx = oc.x - fx, dy = oc.y - fy;
+                    float cd = __builtin_fabsf(fc * os.y + fs * os.x);  // |cos(delta heading)|
+                    float sd = __builtin_fabsf(fs * os.y - fc * os.x);  // |sin(delta heading)|
+                    float g0 = __builtin_fabsf(dx * fc + dy * fs) - (hl + oh.x * cd + oh.y * sd);
+                    float g1 = __builtin_fabsf(dy * fc - dx * fs) - (hw + oh.x * sd + oh.y * cd);
+                    float g2 = __builtin_fabsf(dx * os.y + dy * os.x) - (oh.x + hl * cd + hw * sd);
+                    float g3 = __builtin_fabsf(dy * os.y - dx * os.x) - (oh.y + hl * sd + hw * cd);
+                    float gap = __builtin_fmaxf(__builtin_fmaxf(g0, g1), __builtin_fmaxf(g2, g3));
+                    float eps = 1e-3f + 1.9073486e-6f * (mag + __builtin_fabsf(oc.x) + __builtin_fabsf(oc.y));
+                    // an absent slot has NaN centres: gap is NaN, neither branch below fires
+                    bool unsure = (gap <= eps) && (gap >= -eps);
+                    unsure = unsure || (dx == 0.0f && dy == 0.0f); // possibly bit-identical boxes
+                    if (unsure) fuzzy[w] |= 1ull << jl;
+                    else if (gap < -eps) rows_out[w] |= 1ull << jl;
+                }
+            }
+            any_fuzzy = any_fuzzy || fuzzy[w] != 0;
         }
     }
-    *mult_rows = rows;
-    if (!__any(fuzzy != 0)) return rows; // wave-uniform; the rest is the rare exact path
+#pragma unroll
+    for (int w = 0; w < WV; ++w) mult_rows[w] = rows_out[w];
+    if (!block_any<WV>(any_fuzzy)) return; // workgroup-uniform; the rest is the rare exact path
 
     double A[8];
-    sg_corners(x, y, s, c, L.boxwl[0][lane], L.boxwl[1][lane], bcx, bcy, A);
-    __syncthreads();
+    sg_corners(x, y, s, c, L.boxwl[0][sl], L.boxwl[1][sl], bcx, bcy, A);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) L.cor[k][lane] = A[k];
+    for (int k = 0; k < 8; ++k) L.cor[k][sl] = A[k];
     __syncthreads();
-    uint64_t eq = 0;
-    while (__any(fuzzy != 0)) {
-        if (fuzzy) {
-            int j = __builtin_ctzll(fuzzy);
-            fuzzy &= fuzzy - 1;
-            double B[8];
-            bool same = true;
+    uint64_t eq[WV];
+    bool any_eq = false;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                B[k] = L.cor[k][base + j];
-                same = same && (B[k] == A[k]);
+    for (int w = 0; w < WV; ++w) {
+        eq[w] = 0;
+        while (__any(fuzzy[w] != 0)) {
+            if (fuzzy[w]) {
+                const int jl = __builtin_ctzll(fuzzy[w]);
+                fuzzy[w] &= fuzzy[w] - 1;
+                const int j = tile0 + w * 64 + jl;
+                double B[8];
+                bool same = true;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    B[k] = L.cor[k][j];
+                    same = same && (B[k] == A[k]);
+                }
+                if (same) eq[w] |= 1ull << jl;                      // g == g_prime: never listed (utils.py:59)
+                else if (sg_quads_intersect(A, B)) rows_out[w] |= 1ull << jl;
             }
-            if (same) eq |= 1ull << j;                      // g == g_prime: never listed (utils.py:59)
-            else if (sg_quads_intersect(A, B)) rows |= 1ull << j;
         }
+        any_eq = any_eq || eq[w] != 0;
+        mult_rows[w] = rows_out[w];
     }
-    *mult_rows = rows;
-    if (__any(eq != 0)) { // geometry -> LAST entity owning it (state/utils.py:32-40)
-        int last = 63 - __builtin_clzll(eq | (1ull << slot));
+    if (block_any<WV>(any_eq)) { // geometry -> LAST entity owning it (state/utils.py:32-40)
+        int last = slot;
+#pragma unroll
+        for (int w = 0; w < WV; ++w)
+            if (eq[w]) last = max(last, w * 64 + 63 - __builtin_clzll(eq[w]));
+        L.last[sl] = last;
         __syncthreads();
-        L.last[lane] = last;
-        __syncthreads();
-        uint64_t nr = 0, tmp = rows;
-        while (tmp) {
-            int j = __builtin_ctzll(tmp);
-            tmp &= tmp - 1;
-            nr |= 1ull << L.last[base + j];
+        uint64_t nr[WV];
+#pragma unroll
+        for (int w = 0; w < WV; ++w) nr[w] = 0;
+#pragma unroll
+        for (int w = 0; w < WV; ++w) {
+            uint64_t tmp = rows_out[w];
+            while (tmp) {
+                int jl = __builtin_ctzll(tmp);
+                tmp &= tmp - 1;
+                int o = L.last[tile0 + w * 64 + jl];
+#pragma unroll
+                for (int v = 0; v < WV; ++v)
+                    if ((o >> 6) == v) nr[v] |= 1ull << (o & 63);
+            }
         }
-        rows = nr;
+#pragma unroll
+        for (int w = 0; w < WV; ++w) rows_out[w] = nr[w];
     }
-    return rows;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -647,13 +933,15 @@ __global__ void build_grid_kernel(Params p, const int32_t *row_scen /*[totalN]*/
 }
 
 // ------------------------------------------------------------------------------------------------
-// The rollout kernel: ScenarioGym.reset_scenario / step / rollout (scenario_gym.py:217-267) for
-// 64/G scenarios per wavefront.  do_reset: State.reset first.  force: step done scenarios too
-// (gym.step()); otherwise each scenario stops at is_done (gym.rollout()).
+// The rollout kernel: ScenarioGym.reset_scenario / step / rollout (scenario_gym.py:217-267).
+//   WV == 1: one 64-lane workgroup carries 64/G scenarios of up to G entities each (tiles of G lanes)
+//   WV  > 1: one workgroup of WV wavefronts carries ONE scenario of up to 64*WV entities
+// do_reset: State.reset first.  force: step done scenarios too (gym.step()); otherwise each scenario
+// stops at is_done (gym.rollout()).  PED: pedestrian agents (social force) are compiled in.
 //
 // Register-resident per lane across the time loop: pose, distance, the knot segment (x_lo, x_hi,
-// y_lo[6], slope[6]), the clock.  Controller state, metric accumulators and event cursors are only
-// touched by the one or two lanes that own them and live in HBM/L2.
+// y_lo[6], slope[6]), the clock, controller state, ego metric accumulators.  Controller parameters
+// and box extents live in LDS; there is no global load in a steady-state step.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ Table lane_table(const Params &p, int kind, const ScenStatic &ss, int slot,
                                             const LanePtr &st)
@@ -674,25 +962,33 @@ __device__ __forceinline__ Table lane_table(const Params &p, int kind, const Sce
     return T;
 }
 
-template <int G>
-__global__ __launch_bounds__(64, SG_WAVES_PER_SIMD) void rollout_kernel(Params p, double timestep, int n_steps, int do_reset,
-                                                     int force, const double *actions /*[n][R][2]*/)
+template <int G, int WV, bool PED>
+__global__ __launch_bounds__(64 * WV, PED ? 1 : SG_WAVES_PER_SIMD) void rollout_kernel(Params p, double timestep, int n_steps,
+                                                                            int do_reset, int force,
+                                                                            const double *actions /*[n][R][2]*/)
 {
-    __shared__ CollLds lds;
-    const int lane = threadIdx.x;
+    constexpr int NS = 64 * WV;
+    __shared__ TileLds<NS, PED> lds;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t voff = lane * 8u;
     // one wavefront = one 64-slot block of the state arrays: wave-uniform block pointers
-    const double *st_blk = p.stat + (size_t)blockIdx.x * (ST_COUNT * 64);
+    const size_t blk = (size_t)blockIdx.x * WV + wave;
+    const double *st_blk = p.stat + blk * (ST_COUNT * 64);
     const LanePtr st(st_blk, voff);
-    const LanePtr dy(p.dyn + (size_t)blockIdx.x * (SG_F_COUNT * 64), voff);
-    const int gl = blockIdx.x * 64 + lane;
-    const int r_raw = gl / G, slot = gl & (G - 1), base = lane & ~(G - 1);
+    const LanePtr dy(p.dyn + blk * ((size_t)(SG_F_COLL + WV) * 64), voff);
+    // scenario / slot of this lane
+    const int gl = blockIdx.x * NS + tid;
+    const int r_raw = WV == 1 ? gl / G : blockIdx.x;
+    const int slot = WV == 1 ? (gl & (G - 1)) : tid;
+    const int tile0 = WV == 1 ? (lane & ~(G - 1)) : 0; // first LDS slot of this lane's tile
+    const int sl = tid;                                 // this lane's LDS slot
     const bool in_range = r_raw < p.R;
     const uint32_t r = in_range ? r_raw : p.R - 1;
     const ScenStatic &ss = p.sstat[r];
     sg_scenario_state &sd = p.sdyn[r];
     const int64_t meta = fld<int64_t>(st, ST_META);
     const int kind = (in_range && slot < p.E) ? (int)(meta & 0xff) : SG_KIND_NONE;
+    const bool is_ped_type = ((meta >> 8) & 0xff) == 1;
     const bool is_ego = in_range && slot == ss.ego;
     const double bcx = fld(st, ST_BCX), bcy = fld(st, ST_BCY);
     const double min_t = fld(st, ST_MIN_T), max_t = fld(st, ST_MAX_T);
@@ -701,30 +997,53 @@ __global__ __launch_bounds__(64, SG_WAVES_PER_SIMD) void rollout_kernel(Params p
     const bool is_agent = kind >= SG_KIND_AGENT_REPLAY;
     // per-launch LDS tables: box extents, controller parameters; broad-phase reach of this lane =
     // own bounding-circle radius + the largest radius in the tile + slack
-    float rad_thr;
+    float rad_thr, nbr_thr = 0.0f;
     {
         const double bw = fld(st, ST_BW), bl = fld(st, ST_BL);
         float rad = (float)(0.5 * __builtin_sqrt(bl * bl + bw * bw)) * 1.000001f;
-        float rmax = rad;
+        float off = (float)__builtin_sqrt(bcx * bcx + bcy * bcy) * 1.000001f;
+        float rmax = rad, omax = off;
 #pragma unroll
-        for (int o = 1; o < G; o <<= 1) rmax = __builtin_fmaxf(rmax, __shfl_xor(rmax, o, 64));
+        for (int o = 1; o < G; o <<= 1) {
+            rmax = __builtin_fmaxf(rmax, __shfl_xor(rmax, o, 64));
+            omax = __builtin_fmaxf(omax, __shfl_xor(omax, o, 64));
+        }
+        if (WV > 1) { // across the workgroup's wavefronts
+            float *red = reinterpret_cast<float *>(lds.cor);
+            if (lane == 0) { red[wave] = rmax; red[8 + wave] = omax; }
+            __syncthreads();
+            for (int w = 0; w < WV; ++w) { rmax = __builtin_fmaxf(rmax, red[w]); omax = __builtin_fmaxf(omax, red[8 + w]); }
+            __syncthreads();
+        }
         rad_thr = rad + rmax + 2e-3f;
-        lds.half[lane] = make_float2((float)(0.5 * bl), (float)(0.5 * bw));
-        lds.boxwl[0][lane] = bw;
-        lds.boxwl[1][lane] = bl;
+        lds.half[sl] = make_float2((float)(0.5 * bl), (float)(0.5 * bw));
+        lds.boxwl[0][sl] = bw;
+        lds.boxwl[1][sl] = bl;
 #pragma unroll
-        for (int q = 0; q < 9; ++q) lds.ctrl[q][lane] = fld(st, ST_CTRL + q);
+        for (int q = 0; q < NCTRL_ROWS; ++q) lds.ctrl[q][sl] = fld(st, ST_CTRL + q);
+        if (PED) // PedestrianSensor radius is measured between reference points; centres differ by the box offsets
+            nbr_thr = kind == SG_KIND_AGENT_PEDESTRIAN
+                          ? (float)fld(st, ST_CTRL + SG_C_PED_RADIUS) * 1.000001f + off + omax + 2e-3f : 0.0f;
+    }
+    // pedestrian route (pedestrian/agent.py:43-47)
+    const double *wp = nullptr;
+    int nwp = 0;
+    if (PED && kind == SG_KIND_AGENT_PEDESTRIAN) {
+        int64_t rt = fld<int64_t>(st, ST_ROUTE);
+        wp = p.routes + (rt & 0xffffffffffffll) * 2;
+        nwp = (int)(rt >> 48);
     }
 
     // register-resident across the time loop
     double pose[6], dist, t, prev_t;
-    CtrlState cs;                 // controller state (agent lanes)
+    double velx = 0.0, vely = 0.0; // current velocity (social force input), PED only
+    CtrlState cs;                 // controller state (agent lanes); pedestrians: speed, goal_idx
     double m_avg, m_max, m_t;     // ego metric accumulators (ego lane)
-    uint64_t last_row;            // CollisionMetric.last_timestep (ego lane)
-    int n_ev;
+    uint64_t last_row[WV];        // CollisionMetric.last_timestep (ego lane)
+    int n_ev, goal_idx = 0;
     bool present;
     int done, steps;
-    uint64_t row = 0, mult_rows = 0;
+    uint64_t row[WV], mult_rows[WV], nbr[WV];
     double sin_h, cos_h;
 
     if (do_reset) {
@@ -756,20 +1075,29 @@ __global__ __launch_bounds__(64, SG_WAVES_PER_SIMD) void rollout_kernel(Params p
         dist = 0.0;
         done = 0;
         steps = 0;
+        velx = vel[0];
+        vely = vel[1];
         cs.speed = present ? sg_norm2(vel[0], vel[1]) : 0.0; // controller.py:100-103
+        if (kind == SG_KIND_AGENT_PEDESTRIAN) cs.speed = 0.0; // pedestrian/controller.py:21-23
         cs.e_lon_prev = cs.e_lat_prev = cs.e_lon_int = 0.0;   // controller.py:198-203
+        goal_idx = 0;                                         // pedestrian/agent.py:38
         m_avg = m_max = present ? sg_norm3(vel[0], vel[1], vel[2]) : __builtin_nan(""); // metrics/trajectory.py:13-17,36-39
         m_t = 0.0;
-        last_row = 0; // metrics/collision.py:64-68
+#pragma unroll
+        for (int w = 0; w < WV; ++w) last_row[w] = 0; // metrics/collision.py:64-68
         n_ev = 0;
         sg_sincos(pose[3], sin_h, cos_h);
-        row = tile_collisions<G>(present, pose[0], pose[1], sin_h, cos_h, bcx, bcy, rad_thr, lane, lds, &mult_rows);
+        tile_collisions<G, WV, PED>(present, pose, velx, vely, sin_h, cos_h, bcx, bcy, rad_thr, nbr_thr, is_ped_type,
+                                    sl, tile0, lds, row, mult_rows, nbr);
         if (in_range) {
 #pragma unroll
-            for (int c = 0; c < 6; ++c) { stf(dy, SG_F_POSE + c, (pose[c])); stf(dy, SG_F_VEL + c, (vel[c])); }
-            stf(dy, SG_F_DIST, (dist));
-            stf(dy, SG_F_COLL, (uint64_t)(row));
-            stf(dy, SG_F_PRESENT, (uint64_t)(present));
+            for (int c = 0; c < 6; ++c) { stf(dy, SG_F_POSE + c, pose[c]); stf(dy, SG_F_VEL + c, vel[c]); }
+            stf(dy, SG_F_DIST, dist);
+#pragma unroll
+            for (int w = 0; w < WV; ++w) stf(dy, SG_F_COLL + w, row[w]);
+            stf(dy, SG_F_PRESENT, (uint64_t)present);
+            stf(dy, SG_F_FORCE + 0, 0.0);
+            stf(dy, SG_F_FORCE + 1, 0.0);
             if (p.rec_cap > 0) {
 #pragma unroll
                 for (int c = 0; c < 6; ++c)
@@ -787,16 +1115,26 @@ __global__ __launch_bounds__(64, SG_WAVES_PER_SIMD) void rollout_kernel(Params p
         present = fld<uint64_t>(dy, SG_F_PRESENT) != 0;
 #pragma unroll
         for (int c = 0; c < 6; ++c) pose[c] = fld(dy, SG_F_POSE + c);
+        velx = fld(dy, SG_F_VEL + 0);
+        vely = fld(dy, SG_F_VEL + 1);
         dist = fld(dy, SG_F_DIST);
         cs.speed = fld(dy, SG_F_CTRL + 0); cs.e_lon_prev = fld(dy, SG_F_CTRL + 1);
         cs.e_lat_prev = fld(dy, SG_F_CTRL + 2); cs.e_lon_int = fld(dy, SG_F_CTRL + 3);
+        goal_idx = (int)cs.e_lon_prev; // pedestrians keep goal_idx in the second controller row
         m_avg = sd.ego_avg_speed; m_max = sd.ego_max_speed; m_t = sd.avg_t;
-        last_row = sd.last_row;
+#pragma unroll
+        for (int w = 0; w < WV; ++w) last_row[w] = sd.last_row[w];
         n_ev = sd.n_events;
         done = sd.done;
         steps = sd.n_steps;
-        row = fld<uint64_t>(dy, SG_F_COLL);
         sg_sincos(pose[3], sin_h, cos_h);
+        if (PED) { // the neighbour candidates (and LDS positions) of the current state
+            uint64_t tmp_rows[WV];
+            tile_collisions<G, WV, PED>(present, pose, velx, vely, sin_h, cos_h, bcx, bcy, rad_thr, nbr_thr,
+                                        is_ped_type, sl, tile0, lds, tmp_rows, mult_rows, nbr);
+        }
+#pragma unroll
+        for (int w = 0; w < WV; ++w) row[w] = fld<uint64_t>(dy, SG_F_COLL + w);
     }
 
     Segment S;
@@ -808,7 +1146,7 @@ __global__ __launch_bounds__(64, SG_WAVES_PER_SIMD) void rollout_kernel(Params p
 
     for (int k = 0; k < n_steps; ++k) {
         const bool run = in_range && (force || !done);
-        if (!__any(run)) break;
+        if (!block_any<WV>(run)) break;
         // coefficient table: opaque per step so the scalar loads stay inside the loop (SGPRs for a few
         // dozen instructions instead of VGPRs for the whole kernel); constant address space => s_load
         const double *Kp = SG_TRIG;
@@ -845,6 +1183,7 @@ __global__ __launch_bounds__(64, SG_WAVES_PER_SIMD) void rollout_kernel(Params p
 
         // ---- new poses: scenario_gym.py:233-245 ----
         bool npres = false;
+        double fpx = 0.0, fpy = 0.0; // PedestrianAgent.force
         if (kind == SG_KIND_REPLAY) { // BatchReplayEntity.step, batch.py:34-53
             npres = p.persist || is_static || (next_t >= min_t && next_t <= max_t);
         } else if (is_agent) {
@@ -854,11 +1193,14 @@ __global__ __launch_bounds__(64, SG_WAVES_PER_SIMD) void rollout_kernel(Params p
                     const double tx = np_[0], ty = np_[1];
 #pragma unroll
                     for (int c = 0; c < 6; ++c) np_[c] = pose[c];
-                    const double bl = lds.boxwl[1][lane];
+                    const double bl = lds.boxwl[1][sl];
                     if (kind == SG_KIND_AGENT_PID)
-                        pid_step(cs, lds, lane, bl, state_dt, dt, tx, ty, sin_h, cos_h, np_, K);
-                    else
-                        vehicle_step(cs, lds, lane, bl, dt, act_a, act_s, sin_h, cos_h, np_, K);
+                        pid_step(cs, lds, sl, bl, state_dt, dt, tx, ty, sin_h, cos_h, np_, K);
+                    else if (kind == SG_KIND_AGENT_VEHICLE)
+                        vehicle_step(cs, lds, sl, bl, dt, act_a, act_s, sin_h, cos_h, np_, K);
+                    else if (PED)
+                        ped_step<WV>(p, lds, sl, tile0, nbr, pose, velx, vely, t, next_t, state_dt, wp, nwp, goal_idx,
+                                     cs.speed, fpx, fpy, np_, K);
                 }
             } else if (min_t >= t) { // scenario_gym.py:240-244: spawn at trajectory start
                 npres = true;
@@ -901,19 +1243,24 @@ __global__ __launch_bounds__(64, SG_WAVES_PER_SIMD) void rollout_kernel(Params p
 #pragma unroll
                 for (int c = 0; c < 6; ++c) pose[c] = np_[c];
                 dist += sg_norm3(d[0], d[1], d[2]);
+                if (PED) { velx = vel[0]; vely = vel[1]; }
             }
             prev_t = t;
             t = next_t;
             ++steps;
             // ---- step-materialised state (everything except the collision row, see below) ----
 #pragma unroll
-            for (int c = 0; c < 6; ++c) stf(dy, SG_F_POSE + c, (pose[c]));
+            for (int c = 0; c < 6; ++c) stf(dy, SG_F_POSE + c, pose[c]);
             if (present) {
 #pragma unroll
-                for (int c = 0; c < 6; ++c) stf(dy, SG_F_VEL + c, (vel[c]));
+                for (int c = 0; c < 6; ++c) stf(dy, SG_F_VEL + c, vel[c]);
             }
-            stf(dy, SG_F_DIST, (dist));
-            stf(dy, SG_F_PRESENT, (uint64_t)(present));
+            stf(dy, SG_F_DIST, dist);
+            stf(dy, SG_F_PRESENT, (uint64_t)present);
+            if (PED && kind == SG_KIND_AGENT_PEDESTRIAN) {
+                stf(dy, SG_F_FORCE + 0, fpx);
+                stf(dy, SG_F_FORCE + 1, fpy);
+            }
             if (p.rec_cap > 0 && steps < p.rec_cap) {
 #pragma unroll
                 for (int c = 0; c < 6; ++c)
@@ -930,66 +1277,102 @@ __global__ __launch_bounds__(64, SG_WAVES_PER_SIMD) void rollout_kernel(Params p
                 m_max = __builtin_fmax(speed, m_max); // EgoMaxSpeed, :41-44
             }
         }
+#ifndef SG_ABL_NO_SINCOS
         sg_sincos(pose[3], sin_h, cos_h, K);
+#endif
 
         // ---- State.collisions ----
-        uint64_t nrow = tile_collisions<G>(present, pose[0], pose[1], sin_h, cos_h, bcx, bcy, rad_thr, lane, lds, &mult_rows);
+        uint64_t nrow[WV];
+#ifdef SG_ABL_NO_COLL
+#pragma unroll
+        for (int w = 0; w < WV; ++w) nrow[w] = 0;
+#else
+        tile_collisions<G, WV, PED>(present, pose, velx, vely, sin_h, cos_h, bcx, bcy, rad_thr, nbr_thr, is_ped_type,
+                                    sl, tile0, lds, nrow, mult_rows, nbr);
+#endif
         if (run) {
-            row = nrow;
-            stf(dy, SG_F_COLL, (uint64_t)(row));
+#pragma unroll
+            for (int w = 0; w < WV; ++w) {
+                row[w] = nrow[w];
+                stf(dy, SG_F_COLL + w, row[w]);
+            }
         }
 
         // ---- check_terminal, state.py:268-270, 397-408 ----
         int ndone = 0;
         if ((p.term_mask & SG_TERM_MAX_LENGTH) && (t + dt > length)) ndone = 1;
         if (p.term_mask & (SG_TERM_COLLISION | SG_TERM_EGO_COLLISION)) {
-            uint64_t any_row = __ballot(row != 0) >> base;
-            if (G < 64) any_row &= (1ull << (G & 63)) - 1;
-            if ((p.term_mask & SG_TERM_COLLISION) && any_row) ndone = 1;
-            uint64_t row0 = __shfl(row, base, 64);
-            bool pres0 = (__ballot(present) >> base) & 1;
-            if ((p.term_mask & SG_TERM_EGO_COLLISION) && pres0 && row0) ndone = 1;
+            bool any_mine = false;
+#pragma unroll
+            for (int w = 0; w < WV; ++w) any_mine = any_mine || row[w] != 0;
+            bool any_tile, ego0;
+            if (WV == 1) {
+                uint64_t m = __ballot(any_mine) >> tile0;
+                if (G < 64) m &= (1ull << (G & 63)) - 1;
+                any_tile = m != 0;
+                uint64_t row0 = __shfl(row[0], tile0, 64);
+                ego0 = ((__ballot(present) >> tile0) & 1) && row0 != 0;
+            } else {
+                any_tile = __syncthreads_or(any_mine);
+                ego0 = __syncthreads_or(tid == 0 && present && any_mine);
+            }
+            if ((p.term_mask & SG_TERM_COLLISION) && any_tile) ndone = 1;
+            if ((p.term_mask & SG_TERM_EGO_COLLISION) && ego0) ndone = 1;
         }
         if (run) done = ndone;
 
         // ---- CollisionMetric._step, metrics/collision.py:70-75 (ego lane only) ----
         if (run && is_ego && present) {
-            uint64_t fresh = row & ~last_row;
-            while (fresh) {
-                int j = __builtin_ctzll(fresh);
-                fresh &= fresh - 1;
-                int mult = 1;
-                if (mult_rows != row) { // aliased geometries are listed once per owner
-                    mult = 0;
-                    uint64_t tmp = mult_rows;
-                    while (tmp) { int q = __builtin_ctzll(tmp); tmp &= tmp - 1; mult += lds.last[base + q] == j; }
-                }
-                // catalog type of the other entity (same block: lanes base + j)
-                int64_t ometa = reinterpret_cast<const int64_t *>(st_blk)[ST_META * 64 + base + j];
-                for (int q = 0; q < mult; ++q) {
-                    if (n_ev < p.ev_cap) {
-                        sg_event ev;
-                        ev.t = t; ev.scenario = r; ev.other = j;
-                        ev.type = ((ometa >> 8) & 0xff) == 0 ? -1 : 5;
-                        ev.reserved = 0;
-                        p.events[(size_t)r * p.ev_cap + n_ev] = ev;
+#pragma unroll
+            for (int w = 0; w < WV; ++w) {
+                uint64_t fresh = row[w] & ~last_row[w];
+                while (fresh) {
+                    int j = w * 64 + __builtin_ctzll(fresh);
+                    fresh &= fresh - 1;
+                    int mult = 1;
+                    bool aliased = false;
+#pragma unroll
+                    for (int v = 0; v < WV; ++v) aliased = aliased || mult_rows[v] != row[v];
+                    if (aliased) { // aliased geometries are listed once per owner
+                        mult = 0;
+#pragma unroll
+                        for (int v = 0; v < WV; ++v) {
+                            uint64_t tmp = mult_rows[v];
+                            while (tmp) { int q = __builtin_ctzll(tmp); tmp &= tmp - 1; mult += lds.last[tile0 + v * 64 + q] == j; }
+                        }
                     }
-                    ++n_ev;
+                    // catalog type of the other entity (slot j of this scenario)
+                    const int oj = (WV == 1 ? tile0 : 0) + j; // slot inside the workgroup's blocks
+                    const double *oblk = p.stat + ((size_t)blockIdx.x * WV + (oj >> 6)) * (ST_COUNT * 64);
+                    int64_t ometa = reinterpret_cast<const int64_t *>(oblk)[ST_META * 64 + (oj & 63)];
+                    for (int q = 0; q < mult; ++q) {
+                        if (n_ev < p.ev_cap) {
+                            sg_event ev;
+                            ev.t = t; ev.scenario = r; ev.other = j;
+                            ev.type = ((ometa >> 8) & 0xff) == 0 ? -1 : 5;
+                            ev.reserved = 0;
+                            p.events[(size_t)r * p.ev_cap + n_ev] = ev;
+                        }
+                        ++n_ev;
+                    }
                 }
+                last_row[w] = row[w];
             }
-            last_row = row;
         }
     }
 
     // ---- write back what lives in registers during the loop ----
     if (in_range) {
-        stf(dy, SG_F_CTRL + 0, (cs.speed)); stf(dy, SG_F_CTRL + 1, (cs.e_lon_prev));
-        stf(dy, SG_F_CTRL + 2, (cs.e_lat_prev)); stf(dy, SG_F_CTRL + 3, (cs.e_lon_int));
+        if (PED && kind == SG_KIND_AGENT_PEDESTRIAN) cs.e_lon_prev = (double)goal_idx;
+        stf(dy, SG_F_CTRL + 0, cs.speed); stf(dy, SG_F_CTRL + 1, cs.e_lon_prev);
+        stf(dy, SG_F_CTRL + 2, cs.e_lat_prev); stf(dy, SG_F_CTRL + 3, cs.e_lon_int);
         if (slot == 0) { sd.t = t; sd.prev_t = prev_t; sd.done = done; sd.n_steps = steps; }
         if (is_ego) {
             sd.ego_avg_speed = m_avg; sd.ego_max_speed = m_max; sd.avg_t = m_t;
             if (steps > 0 && present) sd.ego_distance_travelled = dist; // EgoDistanceTravelled, :60-62
-            sd.last_row = last_row; sd.n_events = n_ev;
+#pragma unroll
+            for (int w = 0; w < WV; ++w) sd.last_row[w] = last_row[w];
+            sd.n_events = n_ev;
         }
     }
 }

@@ -18,7 +18,10 @@ using sg::Params;
 
 struct sg_handle {
     sg_config cfg{};
-    int R = 0, E = 0, EP = 0, G = 0;
+    int R = 0, E = 0, EP = 0, G = 0, WV = 1;
+    bool has_ped = false;
+    sg_social_force sf{};
+    double *d_gon = nullptr;
     size_t NE = 0; // padded entity count
     bool uploaded = false;
     hipStream_t stream = nullptr;
@@ -93,8 +96,8 @@ extern "C" int sg_create(const sg_config *cfg, sg_handle **out)
     *out = nullptr;
     if (cfg->n_scenarios <= 0 || cfg->n_entities <= 0)
         return fail(nullptr, SG_ERR_INVALID, "sg_create: n_scenarios and n_entities must be positive");
-    if (cfg->n_entities > 64)
-        return fail(nullptr, SG_ERR_INVALID, "sg_create: n_entities=%d > 64 is not supported by ABI version %d",
+    if (cfg->n_entities > 256)
+        return fail(nullptr, SG_ERR_INVALID, "sg_create: n_entities=%d > 256 is not supported by ABI version %d",
                     cfg->n_entities, SG_ABI_VERSION);
     if (!(cfg->timestep > 0.0)) return fail(nullptr, SG_ERR_INVALID, "sg_create: timestep must be > 0");
     int ndev = 0;
@@ -113,9 +116,12 @@ extern "C" int sg_create(const sg_config *cfg, sg_handle **out)
     h->R = cfg->n_scenarios;
     h->E = cfg->n_entities;
     int G = 4;
-    while (G < h->E) G <<= 1;
+    while (G < h->E && G < 64) G <<= 1;
     h->G = G;
-    h->EP = G;
+    h->WV = h->E <= 64 ? 1 : (h->E <= 128 ? 2 : 4); // wavefronts per scenario
+    h->EP = G * h->WV;
+    // SocialForceParameters defaults, pedestrian/social_force.py:16-30 (noise off)
+    h->sf = sg_social_force{1.5, 1.0, 1.0, 0.0, 0.5, 1.0, std::cos(200.0 / 2 * M_PI / 180), 1.3, 0.0, 0.0, {0.0, 0.0}};
     h->NE = (((size_t)h->R * h->EP + 63) / 64) * 64;
     if (hipSetDevice(cfg->device) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess ||
         hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {
@@ -134,6 +140,7 @@ extern "C" int sg_destroy(sg_handle *h)
     free_pool(h->static_allocs);
     free_pool(h->state_allocs);
     if (h->d_actions) (void)hipFree(h->d_actions);
+    if (h->d_gon) (void)hipFree(h->d_gon);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -142,22 +149,44 @@ extern "C" int sg_destroy(sg_handle *h)
 }
 
 // reference defaults: VehicleController.__init__ controller.py:64-70, PIDController.__init__ :154-161
-static const double kDefaultCtrl[SG_NCTRL] = {0.7, 5.0, NAN, 0.0, 0.03054, 1.5709, 0.3753, 1.8970, 0.0204, 0, 0, 0};
+// + PedestrianAgent / PedestrianController defaults, pedestrian/agent.py:18-27
+static const double kDefaultCtrl[SG_NCTRL] = {0.7, 5.0, NAN, 0.0, 0.03054, 1.5709, 0.3753, 1.8970, 0.0204,
+                                              0.0, 5.0, 0.0, 1.0, 0, 0, 0};
+
+template <int G, int WV>
+static void launch_variant(sg_handle *h, dim3 grid, int n_steps, int do_reset, int force, const double *d_actions)
+{
+    dim3 block(64 * WV);
+    if (h->has_ped)
+        sg::rollout_kernel<(WV > 1 || G >= 16) ? G : 16, WV, true><<<grid, block, 0, h->stream>>>(h->p, h->cfg.timestep, n_steps, do_reset, force, d_actions);
+    else
+        sg::rollout_kernel<G, WV, false><<<grid, block, 0, h->stream>>>(h->p, h->cfg.timestep, n_steps, do_reset, force, d_actions);
+}
 
 static int launch_rollout(sg_handle *h, int n_steps, int do_reset, int force, const double *d_actions)
 {
-    dim3 block(64), grid((unsigned)(h->NE / 64));
+    dim3 grid(h->WV == 1 ? (unsigned)(h->NE / 64) : (unsigned)h->R);
     HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
-    switch (h->G) {
-    case 4: sg::rollout_kernel<4><<<grid, block, 0, h->stream>>>(h->p, h->cfg.timestep, n_steps, do_reset, force, d_actions); break;
-    case 8: sg::rollout_kernel<8><<<grid, block, 0, h->stream>>>(h->p, h->cfg.timestep, n_steps, do_reset, force, d_actions); break;
-    case 16: sg::rollout_kernel<16><<<grid, block, 0, h->stream>>>(h->p, h->cfg.timestep, n_steps, do_reset, force, d_actions); break;
-    case 32: sg::rollout_kernel<32><<<grid, block, 0, h->stream>>>(h->p, h->cfg.timestep, n_steps, do_reset, force, d_actions); break;
-    default: sg::rollout_kernel<64><<<grid, block, 0, h->stream>>>(h->p, h->cfg.timestep, n_steps, do_reset, force, d_actions); break;
+    if (h->WV == 4) launch_variant<64, 4>(h, grid, n_steps, do_reset, force, d_actions);
+    else if (h->WV == 2) launch_variant<64, 2>(h, grid, n_steps, do_reset, force, d_actions);
+    else switch (h->G) {
+    case 4: launch_variant<4, 1>(h, grid, n_steps, do_reset, force, d_actions); break;
+    case 8: launch_variant<8, 1>(h, grid, n_steps, do_reset, force, d_actions); break;
+    case 16: launch_variant<16, 1>(h, grid, n_steps, do_reset, force, d_actions); break;
+    case 32: launch_variant<32, 1>(h, grid, n_steps, do_reset, force, d_actions); break;
+    default: launch_variant<64, 1>(h, grid, n_steps, do_reset, force, d_actions); break;
     }
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
     h->timed = true;
+    return SG_OK;
+}
+
+extern "C" int sg_set_social_force(sg_handle *h, const sg_social_force *params)
+{
+    if (!h || !params) return SG_ERR_INVALID;
+    h->sf = *params;
+    h->p.sf = *params;
     return SG_OK;
 }
 
@@ -171,6 +200,11 @@ extern "C" int sg_upload(sg_handle *h, const sg_scenarios *sc)
     free_pool(h->static_allocs);
     free_pool(h->state_allocs);
     h->uploaded = false;
+    // pedestrian agents are compiled for tiles of >= 16 lanes
+    h->has_ped = false;
+    for (size_t i = 0; i < (size_t)h->R * h->E; ++i) h->has_ped = h->has_ped || sc->kind[i] == SG_KIND_AGENT_PEDESTRIAN;
+    if (h->has_ped && h->WV == 1 && h->G < 16) { h->G = 16; h->EP = 16; h->NE = (((size_t)h->R * h->EP + 63) / 64) * 64; }
+    if (h->has_ped && (!sc->route_off || !sc->routes)) return fail(h, SG_ERR_INVALID, "sg_upload: pedestrian agents need route_off/routes");
     const int R = h->R, E = h->E, EP = h->EP;
     const size_t NE = h->NE;
 
@@ -181,7 +215,7 @@ extern "C" int sg_upload(sg_handle *h, const sg_scenarios *sc)
     auto SI = [&](size_t ent, int f) -> int64_t & { return *reinterpret_cast<int64_t *>(&S(ent, f)); };
     for (size_t o = 0; o < NE; ++o) {
         for (int q = 0; q < 4; ++q) S(o, sg::ST_BW + q) = 1.0;
-        for (int q = 0; q < 9; ++q) S(o, sg::ST_CTRL + q) = kDefaultCtrl[q];
+        for (int q = 0; q < sg::NCTRL_ROWS; ++q) S(o, sg::ST_CTRL + q) = kDefaultCtrl[q];
         SI(o, sg::ST_META) = SG_KIND_NONE | (2 << 8);
     }
     std::vector<sg::ScenStatic> sstat(R);
@@ -194,14 +228,19 @@ extern "C" int sg_upload(sg_handle *h, const sg_scenarios *sc)
         for (int e = 0; e < E; ++e) {
             size_t i = (size_t)r * E + e, o = (size_t)r * EP + e;
             int k = sc->kind[i];
-            if (k < SG_KIND_NONE || k > SG_KIND_AGENT_VEHICLE) return fail(h, SG_ERR_INVALID, "sg_upload: kind[%zu]=%d unknown", i, k);
+            if (k < SG_KIND_NONE || k > SG_KIND_AGENT_PEDESTRIAN) return fail(h, SG_ERR_INVALID, "sg_upload: kind[%zu]=%d unknown", i, k);
+            if (k == SG_KIND_AGENT_PEDESTRIAN) {
+                int64_t ra = sc->route_off[i], rb = sc->route_off[i + 1];
+                if (ra < 0 || rb <= ra) return fail(h, SG_ERR_INVALID, "sg_upload: pedestrian agent %zu has no route", i);
+                SI(o, sg::ST_ROUTE) = ra | ((rb - ra) << 48);
+            }
             int64_t a = sc->knot_off[i], b = sc->knot_off[i + 1];
             if (a < 0 || b < a || b > rows_total) return fail(h, SG_ERR_INVALID, "sg_upload: knot_off not monotone at %zu", i);
             if (k != SG_KIND_NONE && b == a) return fail(h, SG_ERR_INVALID, "sg_upload: entity %zu has no knots", i);
             SI(o, sg::ST_META) = (int64_t)k | ((int64_t)(sc->etype[i] & 0xff) << 8) | ((int64_t)(b - a) << 32);
             SI(o, sg::ST_KNOT_OFF) = a;
             for (int q = 0; q < 4; ++q) S(o, sg::ST_BW + q) = sc->bbox[i * 4 + q];
-            if (sc->ctrl) for (int q = 0; q < 9; ++q) S(o, sg::ST_CTRL + q) = sc->ctrl[i * SG_NCTRL + q];
+            if (sc->ctrl) for (int q = 0; q < sg::NCTRL_ROWS; ++q) S(o, sg::ST_CTRL + q) = sc->ctrl[i * SG_NCTRL + q];
             if (b > a) {
                 S(o, sg::ST_MIN_T) = sc->knots[(size_t)a * 7];
                 S(o, sg::ST_MAX_T) = sc->knots[(size_t)(b - 1) * 7];
@@ -255,6 +294,8 @@ extern "C" int sg_upload(sg_handle *h, const sg_scenarios *sc)
     Params &p = h->p;
     p = Params{};
     p.R = R; p.E = E; p.EP = EP;
+    p.WV = h->WV; p.FROWS = SG_F_COLL + h->WV;
+    p.sf = h->sf;
     p.persist = h->cfg.persist;
     p.term_mask = h->cfg.terminal_mask;
     p.rec_cap = h->cfg.record_capacity > 0 ? h->cfg.record_capacity : 0;
@@ -276,8 +317,17 @@ extern "C" int sg_upload(sg_handle *h, const sg_scenarios *sc)
         h->total_rows = total_rows;
         if ((rc = dev_alloc(h, SA, &p.grid_y, (size_t)total_rows * 6 * EP, false))) return rc;
     }
+    {   // pedestrian routes + the 64-gon table of Point.buffer (host libm, as shapely's caller sees it)
+        size_t rrows = sc->route_off ? (size_t)sc->route_off[(size_t)R * E] : 0;
+        std::vector<double> routes(sc->routes, sc->routes + rrows * 2);
+        if (routes.empty()) routes.assign(2, 0.0);
+        if ((rc = dev_upload(h, SA, &p.routes, routes))) return rc;
+        std::vector<double> gon(128);
+        for (int i = 0; i < 64; ++i) { double a = 2.0 * 3.141592653589793 * i / 64; gon[2 * i] = std::cos(a); gon[2 * i + 1] = std::sin(a); }
+        if ((rc = dev_upload(h, SA, &p.gon, gon))) return rc;
+    }
     auto &M = h->state_allocs;
-    if ((rc = dev_alloc(h, M, &p.dyn, nblk * SG_F_COUNT * 64))) return rc;
+    if ((rc = dev_alloc(h, M, &p.dyn, nblk * (size_t)p.FROWS * 64))) return rc;
     if ((rc = dev_alloc(h, M, &p.sdyn, (size_t)R))) return rc;
     if ((rc = dev_alloc(h, M, &p.events, (size_t)R * std::max(p.ev_cap, 1)))) return rc;
     if ((rc = dev_alloc(h, M, &p.rec_t, (size_t)std::max(p.rec_cap, 1) * R))) return rc;
@@ -384,6 +434,8 @@ extern "C" int sg_state_view_get(sg_handle *h, sg_state_view *out)
     if (!h->uploaded) return fail(h, SG_ERR_STATE, "sg_state_view_get: no scenarios uploaded");
     out->n_scenarios = h->R; out->n_entities = h->E; out->entity_stride = h->EP;
     out->n_blocks = (int32_t)(h->NE / 64);
+    out->row_words = h->WV;
+    out->block_rows = h->p.FROWS;
     out->blocks = h->p.dyn;
     out->scen = h->p.sdyn;
     return SG_OK;

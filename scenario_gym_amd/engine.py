@@ -13,10 +13,12 @@ TERMINAL_BITS = {"max_length": L.TERM_MAX_LENGTH, "collision": L.TERM_COLLISION,
 # VehicleController / PIDController constructor defaults (reference controller.py:64-70, 157-161)
 SCEN_DTYPE = np.dtype([  # sg_scenario_state
     ("t", "f8"), ("prev_t", "f8"), ("ego_avg_speed", "f8"), ("ego_max_speed", "f8"), ("avg_t", "f8"),
-    ("ego_distance_travelled", "f8"), ("last_row", "u8"), ("done", "i4"), ("n_steps", "i4"),
+    ("ego_distance_travelled", "f8"), ("last_row", "u8", (4,)), ("done", "i4"), ("n_steps", "i4"),
     ("n_events", "i4"), ("rec_rows", "i4"), ("reserved", "i8")])
 
-DEFAULT_CTRL = np.array([0.7, 5.0, np.nan, 0.0, 0.03054, 1.5709, 0.3753, 1.8970, 0.0204, 0, 0, 0])
+# + PedestrianAgent / PedestrianController defaults (pedestrian/agent.py:18-27): speed_desired (set per agent),
+# max_speed 5.0, head_rot_angle 0.0, distance_threshold 1.0
+DEFAULT_CTRL = np.array([0.7, 5.0, np.nan, 0.0, 0.03054, 1.5709, 0.3753, 1.8970, 0.0204, 0.0, 5.0, 0.0, 1.0, 0, 0, 0])
 
 
 @dataclass
@@ -33,8 +35,10 @@ class PackedScenarios:
     ego: np.ndarray       # [R] int32
     t0: np.ndarray        # [R]
     length: np.ndarray    # [R]
-    ctrl: Optional[np.ndarray] = None  # [R*E, 12]
+    ctrl: Optional[np.ndarray] = None  # [R*E, 16]
     refs: list = field(default_factory=list)
+    route_off: Optional[np.ndarray] = None  # [R*E+1] int64, pedestrian agents' waypoint rows
+    routes: Optional[np.ndarray] = None     # [rows, 2]
 
     def validate(self):
         R, E = self.n_scenarios, self.n_entities
@@ -43,17 +47,22 @@ class PackedScenarios:
         assert self.knots.ndim == 2 and self.knots.shape[1] == 7
         assert self.ego.shape == (R,) and self.t0.shape == (R,) and self.length.shape == (R,)
         assert self.ctrl is None or self.ctrl.shape == (R * E, L.NCTRL)
+        assert self.route_off is None or (self.route_off.shape == (R * E + 1,) and self.routes.shape[1] == 2)
         return self
 
     def shard(self, lo, hi):
         """Scenarios [lo, hi) as an independent batch (replica sharding across GPUs)."""
         E = self.n_entities
         a, b = int(self.knot_off[lo * E]), int(self.knot_off[hi * E])
+        ro = rt = None
+        if self.route_off is not None:
+            ra, rb = int(self.route_off[lo * E]), int(self.route_off[hi * E])
+            ro, rt = self.route_off[lo * E:hi * E + 1] - ra, self.routes[ra:rb]
         return PackedScenarios(
             hi - lo, E, self.kind[lo * E:hi * E], self.etype[lo * E:hi * E], self.bbox[lo * E:hi * E],
             self.knot_off[lo * E:hi * E + 1] - a, self.knots[a:b], self.ego[lo:hi], self.t0[lo:hi],
             self.length[lo:hi], None if self.ctrl is None else self.ctrl[lo * E:hi * E],
-            self.refs[lo:hi] if self.refs else [],
+            self.refs[lo:hi] if self.refs else [], ro, rt,
         )
 
 
@@ -73,7 +82,7 @@ class RolloutEngine:
     """ScenarioGym's step loop for a whole batch, resident on one MI355X."""
 
     def __init__(self, n_scenarios, n_entities, timestep=1.0 / 30.0, persist=False,
-                 terminal_conditions=None, record_capacity=0, event_capacity=16, device=0):
+                 terminal_conditions=None, record_capacity=0, event_capacity=16, device=0, social_force=None):
         self.lib = L.load()
         self.R, self.E = int(n_scenarios), int(n_entities)
         self.cfg = L.SgConfig(int(device), self.R, self.E, int(bool(persist)),
@@ -87,6 +96,18 @@ class RolloutEngine:
             raise RuntimeError(f"sg_create failed ({rc}): {msg}")
         self._view = None
         self._keep = None
+        if social_force is not None:
+            self.set_social_force(**social_force)
+
+    def set_social_force(self, relaxation_time=1.5, ped_repulse_V=1.0, ped_repulse_sigma=1.0, ped_attract_C=0.0,
+                         sight_weight=0.5, sight_weight_use=True, sight_angle=200, max_speed_factor=1.3,
+                         bias_lon=0.0, bias_lat=0.0):
+        """SocialForceParameters of every pedestrian agent on this handle (pedestrian/social_force.py:16-30);
+        call before upload()."""
+        sf = L.SgSocialForce(relaxation_time, ped_repulse_V, ped_repulse_sigma, ped_attract_C, sight_weight,
+                             float(bool(sight_weight_use)), float(np.cos(sight_angle / 2 * np.pi / 180)),
+                             max_speed_factor, bias_lon, bias_lat, 0.0, 0.0)
+        self._check(self.lib.sg_set_social_force(self.h, C.byref(sf)), "sg_set_social_force")
 
     # ------------------------------------------------------------------ plumbing
     def _check(self, rc, what):
@@ -116,6 +137,8 @@ class RolloutEngine:
             ctrl=None if packed.ctrl is None else np.ascontiguousarray(packed.ctrl, np.float64),
             ego=np.ascontiguousarray(packed.ego, np.int32), t0=np.ascontiguousarray(packed.t0, np.float64),
             length=np.ascontiguousarray(packed.length, np.float64),
+            route_off=None if packed.route_off is None else np.ascontiguousarray(packed.route_off, np.int64),
+            routes=None if packed.routes is None else np.ascontiguousarray(packed.routes, np.float64),
         )
         sc = L.SgScenarios(*[None if arrs[n] is None else arrs[n].ctypes.data for n, _ in L.SgScenarios._fields_])
         self._check(self.lib.sg_upload(self.h, C.byref(sc)), "sg_upload")
@@ -158,10 +181,11 @@ class RolloutEngine:
         return out
 
     def state(self):
-        """Host copy of the step-materialised state: dict of [R, E, ...] arrays (NaN = absent)."""
+        """Host copy of the step-materialised state: dict of [R, E, ...] arrays (NaN = absent).
+        `coll` is [R, E] uint64 for up to 64 entities, else [R, E, row_words]."""
         v, R, E, EP = self._view, self.R, self.E, self._view.entity_stride
         n = R * EP
-        blocks = self._d2h(v.blocks, (v.n_blocks, L.F_COUNT, 64), np.float64)
+        blocks = self._d2h(v.blocks, (v.n_blocks, v.block_rows, 64), np.float64)
 
         def rows(f, k=1, dtype=np.float64):
             a = blocks[:, f:f + k, :].view(dtype)                      # [nblk, k, 64]
@@ -169,11 +193,12 @@ class RolloutEngine:
 
         present = rows(L.F_PRESENT, 1, np.uint64)[..., 0] != 0
         scen = self._d2h(v.scen, R, SCEN_DTYPE)
+        coll = rows(L.F_COLL, v.row_words, np.uint64)
         return dict(
             poses=np.where(present[..., None], rows(L.F_POSE, 6), np.nan),
             vels=np.where(present[..., None], rows(L.F_VEL, 6), np.nan),
-            present=present, dists=rows(L.F_DIST)[..., 0], coll=rows(L.F_COLL, 1, np.uint64)[..., 0],
-            ctrl_state=rows(L.F_CTRL, 4), t=scen["t"].copy(), prev_t=scen["prev_t"].copy(),
+            present=present, dists=rows(L.F_DIST)[..., 0], coll=coll[..., 0] if v.row_words == 1 else coll,
+            ctrl_state=rows(L.F_CTRL, 4), force=rows(L.F_FORCE, 2), t=scen["t"].copy(), prev_t=scen["prev_t"].copy(),
             done=scen["done"].astype(bool), n_steps=scen["n_steps"].copy(),
         )
 
@@ -198,7 +223,7 @@ class RolloutEngine:
         return t, poses
 
     def torch_state(self):
-        """Zero-copy torch view [n_blocks, SG_F_COUNT, 64] (fp64) over the device state blocks;
+        """Zero-copy torch view [n_blocks, block_rows, 64] (fp64) over the device state blocks;
         field f of entity i is view[i // 64, f, i % 64].  torch is only the container."""
         import torch
 
@@ -208,4 +233,4 @@ class RolloutEngine:
             def __init__(self, ptr, shape, typestr):
                 self.__cuda_array_interface__ = dict(shape=shape, typestr=typestr, data=(int(ptr), False), version=2)
 
-        return torch.as_tensor(_Arr(v.blocks, (v.n_blocks, L.F_COUNT, 64), "<f8"), device=f"cuda:{self.cfg.device}")
+        return torch.as_tensor(_Arr(v.blocks, (v.n_blocks, v.block_rows, 64), "<f8"), device=f"cuda:{self.cfg.device}")

@@ -73,10 +73,15 @@ class BatchedScenarioGym:
         for c in dev_terms:
             if c not in TERMINAL_BITS:
                 raise ValueError(f"terminal condition {c!r} is not supported (needs the road network)")
+        sf = None
+        for sc_agents in agents:  # one SocialForce parameter set per batch (the first pedestrian agent's)
+            for a in sc_agents.values():
+                if hasattr(a, "behaviour"):
+                    sf = sf or a.behaviour.device_params()
         self.engine = RolloutEngine(
             packed.n_scenarios, packed.n_entities, timestep=self._timestep, persist=self.persist,
             terminal_conditions=dev_terms, record_capacity=(self.max_steps + 1) if self.record else 0,
-            event_capacity=self.event_capacity, device=self.device)
+            event_capacity=self.event_capacity, device=self.device, social_force=sf)
         self.engine.upload(packed)
         self.states = [State(self, i, sc, agents[i], self.persist) for i, sc in enumerate(self.scenarios)]
         self.metrics = [list(self.metric_factory()) for _ in self.scenarios]

@@ -50,7 +50,22 @@ def pack_arrays(scenarios: Sequence[dict], kinds: Optional[Sequence[np.ndarray]]
         rows += int(off[-1])
         ego[r], t0[r], length[r] = s["ego"], s["t0"], s["length"]
     knots = np.concatenate(chunks, axis=0) if chunks else np.zeros((0, 7))
-    return PackedScenarios(R, E, kind, etype, bbox, knot_off, knots, ego, t0, length, ctrl).validate()
+    route_off = routes = None
+    if any("routes" in s and s["routes"] is not None for s in scenarios):
+        route_off = np.zeros(R * E + 1, np.int64)
+        rchunks, rrows = [], 0
+        for r, s in enumerate(scenarios):
+            ro = s.get("route_off")
+            for e in range(E):
+                if ro is not None and e < len(s["etype"]):
+                    n = int(ro[e + 1] - ro[e])
+                    if n:
+                        rchunks.append(np.asarray(s["routes"], np.float64).reshape(-1, 2)[ro[e]:ro[e + 1]])
+                        rrows += n
+                route_off[r * E + e + 1] = rrows
+        routes = np.concatenate(rchunks, axis=0) if rchunks else np.zeros((0, 2))
+    return PackedScenarios(R, E, kind, etype, bbox, knot_off, knots, ego, t0, length, ctrl,
+                           route_off=route_off, routes=routes).validate()
 
 
 def unpack_scenario(packed: PackedScenarios, r: int) -> dict:
@@ -65,6 +80,8 @@ def unpack_scenario(packed: PackedScenarios, r: int) -> dict:
         etype=packed.etype[r * E:r * E + n], kind=kind[:n], ego=int(packed.ego[r]), t0=float(packed.t0[r]),
         length=float(packed.length[r]),
         ctrl=None if packed.ctrl is None else packed.ctrl[r * E:r * E + n],
+        route_off=None if packed.route_off is None else packed.route_off[r * E:r * E + n + 1] - packed.route_off[r * E],
+        routes=None if packed.route_off is None else packed.routes[packed.route_off[r * E]:packed.route_off[r * E + n]],
     )
 
 
@@ -88,9 +105,13 @@ def pack_scenarios(scenarios, create_agent=None):
             agent = create_agent(sc, e)
             if agent is not None:
                 kind[i] = agent.device_kind()
-                ctrl[i] = agent.controller.ctrl_row()
+                ctrl[i] = agent.ctrl_row() if hasattr(agent, "ctrl_row") else agent.controller.ctrl_row()
                 sc_agents[e] = agent
+        routes = [np.asarray(sc_agents[e].route, np.float64).reshape(-1, 2) if e in sc_agents and hasattr(sc_agents[e], "route")
+                  else np.zeros((0, 2)) for e in ents]
         arrays.append(dict(
+            route_off=np.concatenate([[0], np.cumsum([len(x) for x in routes])]).astype(np.int64),
+            routes=np.concatenate(routes, axis=0) if any(len(x) for x in routes) else None,
             knot_off=off, knots=np.concatenate([e.trajectory.data for e in ents], axis=0),
             bbox=np.array([[e.bounding_box.width, e.bounding_box.length, e.bounding_box.center_x,
                             e.bounding_box.center_y] for e in ents], np.float64),

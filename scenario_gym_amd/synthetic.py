@@ -96,3 +96,42 @@ def make_actions(n_steps, n_scenarios, seed=SEED, first_scenario=0):
         a = np.stack([rng.uniform(-5, 5, (n_steps, CHUNK)), rng.uniform(-0.7, 0.7, (n_steps, CHUNK))], -1)
         out[:, c0:c0 + n] = a[:, :n]
     return out
+
+
+PEDESTRIAN1_BBOX = (0.69, 0.7, 0.0, 0.0)  # width, length, center_x, center_y of the reference's pedestrian1 entry
+
+
+def make_crowd(n_scenarios, n_entities=256, n_steps=10000, timestep=1.0 / 30.0, side=40.0, radius=3.0,
+               seed=SEED, first_scenario=0) -> PackedScenarios:
+    """BASELINE config 5: every entity is a PedestrianAgent with the social force model.
+
+    Starts ~ U on a side x side square, two-waypoint routes from the start to a random point on the
+    opposite half, desired speed ~ U[0.5, 1.5] * 1.3, SocialForceParameters defaults with the noise off,
+    neighbour radius passed explicitly, empty road network, pedestrian1 bounding boxes."""
+    R, E = int(n_scenarios), int(n_entities)
+    length = n_steps * timestep
+    assert first_scenario % CHUNK == 0
+    kn, routes, ctrl = [], [], []
+    for c0 in range(0, R, CHUNK):
+        n = min(CHUNK, R - c0)
+        rng = np.random.default_rng([seed, 5, (first_scenario + c0) // CHUNK])
+        start = rng.uniform(-side / 2, side / 2, (CHUNK, E, 2))
+        goal = -start * rng.uniform(0.3, 1.0, (CHUNK, E, 1)) + rng.normal(0, 2.0, (CHUNK, E, 2))
+        h0 = rng.uniform(-np.pi, np.pi, (CHUNK, E))
+        vdes = rng.uniform(0.5, 1.5, (CHUNK, E)) * 1.3
+        k = np.zeros((CHUNK, E, 2, 7))
+        k[:, :, 1, 0] = length
+        k[:, :, :, 1:3] = start[:, :, None, :]
+        k[:, :, :, 4] = h0[:, :, None]
+        kn.append(k[:n].reshape(-1, 7))
+        routes.append(np.stack([start, goal], axis=2)[:n].reshape(-1, 2))
+        row = np.tile(DEFAULT_CTRL, (n * E, 1))
+        row[:, L.C_PED_SPEED_DESIRED] = vdes[:n].ravel()
+        row[:, L.C_PED_RADIUS] = radius
+        ctrl.append(row)
+    return PackedScenarios(
+        R, E, np.full(R * E, L.KIND_AGENT_PEDESTRIAN, np.int32), np.ones(R * E, np.int32),
+        np.tile(np.array(PEDESTRIAN1_BBOX), (R * E, 1)), np.arange(R * E + 1, dtype=np.int64) * 2,
+        np.concatenate(kn), np.zeros(R, np.int32), np.zeros(R), np.full(R, length), np.concatenate(ctrl),
+        route_off=np.arange(R * E + 1, dtype=np.int64) * 2, routes=np.concatenate(routes),
+    ).validate()

@@ -47,6 +47,7 @@ from scenario_gym.trajectory import Trajectory  # noqa: E402
 from scenario_gym.xosc_interface import import_scenario  # noqa: E402
 
 assert scenario_gym.__version__ == "0.3.1"
+ONLY = set(sys.argv[1:])  # e.g. `make_golden.py pedestrian`
 SCEN_DIR = "/root/reference/tests/input_files/Scenarios"
 
 ETYPE = {"Vehicle": 0, "Pedestrian": 1}
@@ -446,8 +447,133 @@ def g_collision(rng):
     return out
 
 
+def g_pedestrian(rng):
+    """Social force (pedestrian/social_force.py), PedestrianAgent goal update and PedestrianController.
+
+    Noise is switched off (std_lon = std_lat = 0: np.random.normal(b, 0) returns b exactly), the road
+    network is an empty RoadNetwork (no boundary forces, pedestrian/social_force.py:86-104) and the
+    shapely stand-ins answer LineString.project analytically and Point.buffer/contains with the exact
+    64-gon rule, so every number below is the reference's own arithmetic."""
+    from types import SimpleNamespace as NS
+
+    from scenario_gym.entity import Pedestrian
+    from scenario_gym.pedestrian.agent import PedestrianAgent
+    from scenario_gym.pedestrian.controller import PedestrianController
+    from scenario_gym.pedestrian.social_force import SocialForce, SocialForceParameters
+    from scenario_gym.road_network import RoadNetwork
+    from shapely.geometry import MultiPolygon
+
+    out = {}
+    params = SocialForceParameters(std_lon=0.0, std_lat=0.0)
+    sf = SocialForce(params)
+    out["params"] = np.array([params.relaxation_time, params.ped_repulse_V, params.ped_repulse_sigma,
+                              params.ped_attract_C, params.sight_weight, float(params.sight_weight_use),
+                              params.sight_angle, params.max_speed_factor, params.bias_lon, params.bias_lat])
+    # ---- (a) one behaviour step on random observations with 0..6 neighbours ----
+    n = 600
+    poses = np.concatenate([rng.uniform(-20, 20, (n, 2)), np.zeros((n, 1)), rng.uniform(-3, 3, (n, 1)), np.zeros((n, 2))], 1)
+    vels = np.concatenate([rng.normal(0, 1.2, (n, 2)), np.zeros((n, 4))], 1)
+    goals = poses[:, :2] + rng.normal(0, 8, (n, 2))
+    vdes = rng.uniform(0.5, 2.0, n)
+    head = np.where(rng.random(n) < 0.5, 0.0, rng.uniform(-0.6, 0.6, n))
+    dts = np.where(rng.random(n) < 0.5, 1 / 30, 0.1)
+    nn = rng.integers(0, 7, n)
+    nb_pose = np.full((n, 6, 6), np.nan)
+    nb_vel = np.full((n, 6, 6), np.nan)
+    res = np.empty((n, 4))
+    for i in range(n):
+        near = []
+        for k in range(nn[i]):
+            pp = np.zeros(6)
+            pp[:2] = poses[i, :2] + rng.normal(0, 1.5, 2)
+            vv = np.zeros(6)
+            vv[:2] = rng.normal(0, 1.2, 2) if k % 3 else 0.0  # some neighbours stand still
+            nb_pose[i, k], nb_vel[i, k] = pp, vv
+            near.append((None, pp, vv))
+        obs = NS(pose=poses[i], velocity=vels[i], t=1.0, next_t=1.0 + dts[i], head_rot_angle=head[i], near_peds=near,
+                 walkable_surface=MultiPolygon(), impenetrable_surface=MultiPolygon())
+        agent = NS(route=[goals[i]], goal_idx=0, speed_desired=vdes[i], force=None)
+        speed, heading = sf._step(obs, agent)
+        res[i] = [speed, heading, agent.force[0], agent.force[1]]
+    out.update({"step/pose": poses, "step/vel": vels, "step/goal": goals, "step/vdes": vdes, "step/head": head,
+                "step/dt": dts, "step/n": nn, "step/nb_pose": nb_pose, "step/nb_vel": nb_vel, "step/out": res})
+
+    # ---- (b) closed loop: 12 pedestrians + 1 replayed vehicle, empty road network ----
+    def scene(seed, n_ped, side, n_wp):
+        r = np.random.default_rng(seed)
+        ents = [make_entity(np.array([[0.0, -side, 0.3, 0, 0.0, 0, 0], [12.0, side, 0.5, 0, 0.0, 0, 0]]), "ego", ctype="Vehicle")]
+        routes, vds = {}, {}
+        for i in range(n_ped):
+            start = r.uniform(-side, side, 2)
+            ce = CatalogEntry(None, "p", "p", "Pedestrian", BoundingBox(0.69, 0.7, 0.0, 0.0), {}, [])
+            t_end = 12.0
+            e = Pedestrian(ce, Trajectory(np.array([[0.0, *start, 0, r.uniform(-3, 3), 0, 0],
+                                                    [t_end, *(start + r.normal(0, 0.5, 2)), 0, 0.0, 0, 0]])), ref=f"ped_{i}")
+            wps = [start + r.normal(0, 0.05, 2)]
+            for _ in range(n_wp - 1):
+                wps.append(-wps[-1] * r.uniform(0.3, 1.0) + r.normal(0, 1.0, 2))
+            routes[e.ref] = np.array(wps)
+            vds[e.ref] = r.uniform(0.5, 1.5) * 1.3
+            ents.append(e)
+        return Scenario(ents, name="crowd", road_network=RoadNetwork(roads=[], intersections=[])), routes, vds
+
+    for si, (seed, n_ped, side, n_wp, thr) in enumerate([(1, 12, 3.0, 3, 3.0), (2, 20, 4.0, 2, 1.0)]):
+        sc, routes, vds = scene(seed, n_ped, side, n_wp)
+        out.update(flat(f"loop{si}/scenario", export_scenario(sc)))
+        refs = [e.ref for e in sc.entities]
+        R = np.full((len(refs), n_wp, 2), np.nan)
+        for k, ref in enumerate(refs):
+            if ref in routes:
+                R[k] = routes[ref]
+        out[f"loop{si}/routes"] = R
+        out[f"loop{si}/vdes"] = np.array([vds.get(ref, np.nan) for ref in refs])
+        out[f"loop{si}/distance_threshold"] = np.float64(thr)
+        for dt_name, dt in (("dt30", 1.0 / 30.0), ("dt10", 0.1)):
+            def create_agent(s, e, routes=routes, vds=vds, thr=thr):
+                if e.ref == "ego":
+                    return _create_agent(s, e)
+                return PedestrianAgent(e, routes[e.ref], vds[e.ref], SocialForce(SocialForceParameters(std_lon=0.0, std_lat=0.0)),
+                                       distance_threshold=thr)
+
+            def extra(g):
+                rows = []
+                for e in g.state.scenario.entities:
+                    a = g.state.agents.get(e)
+                    if isinstance(a, PedestrianAgent):
+                        rows.append([a.controller.speed, float(a.goal_idx), a.force[0], a.force[1]])
+                    else:
+                        rows.append([np.nan] * 4)
+                return rows
+
+            gym = ScenarioGym(timestep=dt, metrics=std_metrics())
+            gym.set_scenario(sc, create_agent=create_agent)
+            out.update(flat(f"loop{si}/{dt_name}", record_rollout(gym, extra=extra)))
+
+    # ---- (c) PedestrianController._step in isolation ----
+    m = 300
+    cp = np.concatenate([rng.uniform(-50, 50, (m, 3)), rng.uniform(-3, 3, (m, 3))], 1)
+    act = np.stack([rng.uniform(-7, 7, m), rng.uniform(-7, 7, m)], 1)
+    cdt = rng.uniform(0.01, 0.2, m)
+    cout = np.empty((m, 7))
+    ent = make_entity(np.zeros((1, 7)), "p", ctype="Pedestrian")
+    for i in range(m):
+        ctl = PedestrianController(ent, max_speed=5.0)
+        st = NS(poses={ent: cp[i]}, dt=cdt[i])
+        cout[i, :6] = ctl._step(st, NS(speed=act[i, 0], heading=act[i, 1]))
+        cout[i, 6] = ctl.speed
+    out.update({"ctrl/pose": cp, "ctrl/action": act, "ctrl/dt": cdt, "ctrl/out": cout})
+    return out
+
+
 def main():
     rng = np.random.default_rng(20240807)
+    if ONLY:  # regenerate a single group without touching the others
+        groups = {"pedestrian": g_pedestrian(np.random.default_rng(20240808))} if "pedestrian" in ONLY else {}
+        for name, d in groups.items():
+            path = os.path.join(HERE, name + ".npz")
+            np.savez_compressed(path, **d)
+            print(f"{name}: {len(d)} arrays, {os.path.getsize(path) / 1e6:.2f} MB")
+        return
     groups = dict(
         trajectory=g_trajectory(rng),
         batch=g_batch(rng),
@@ -456,6 +582,7 @@ def main():
         pid_xosc=g_pid_xosc(),
         collision=g_collision(rng),
     )
+    groups["pedestrian"] = g_pedestrian(np.random.default_rng(20240808))
     for name, d in groups.items():
         path = os.path.join(HERE, name + ".npz")
         np.savez_compressed(path, **d)

@@ -318,3 +318,150 @@ def test_full_size_invariants(sga, oracle):
         assert bits_equal(st["poses"][r], o["poses"][-1]) and bits_equal(st["vels"][r], o["vels"][-1])
         assert np.array_equal(st["coll"][r], o["coll"][-1, :, 0])
         assert rows["ego_distance_travelled"][r] == o["metric_ego_distance_travelled"]
+
+
+# --------------------------------------------------------------------------- wide tiles (E > 64)
+def _oracle_one(oracle, packed, r, dt, n_max, **kw):
+    from scenario_gym_amd.packing import unpack_scenario
+
+    s = unpack_scenario(packed, r)
+    return oracle.rollout(s["knot_off"], s["knots"], s["bbox"], s["etype"], s["kind"], s["ego"], s["t0"], s["length"],
+                          dt, ctrl=s["ctrl"], max_steps=n_max, route_off=s.get("route_off"), routes=s.get("routes"), **kw)
+
+
+def _dense_words(coll, E):
+    """[E, W] uint64 rows -> [E, E] adjacency."""
+    coll = coll.reshape(E, -1)
+    bits = np.unpackbits(np.ascontiguousarray(coll).view(np.uint8), axis=-1, bitorder="little")
+    return bits[:, :E]
+
+
+@pytest.mark.parametrize("R,E,steps,ego_kind", [(24, 100, 150, "pid"), (16, 200, 100, "replay"), (12, 256, 80, "pid")])
+def test_wide_scenarios_match_oracle(sga, oracle, R, E, steps, ego_kind):
+    """Scenarios of 65..256 entities span 2 or 4 wavefronts of one workgroup: same bits as the oracle."""
+    import scenario_gym_amd._lib as L
+    from scenario_gym_amd import synthetic
+
+    kind = dict(replay=L.KIND_AGENT_REPLAY, pid=L.KIND_AGENT_PID)[ego_kind]
+    packed = synthetic.make_batch(R, E, n_steps=steps, ego_kind=kind, static_frac=0.15, vanish_frac=0.2, extent=50.0)
+    st, rows, events, t, poses = _engine_run(sga, packed, 1 / 30, steps, ev_cap=256)
+    n_ev = 0
+    for r in range(R):
+        o = _oracle_one(oracle, packed, r, 1 / 30, steps)
+        n = o["n_steps"]
+        assert rows["n_steps"][r] == n and rows["final_t"][r] == o["final_t"], r
+        assert bits_equal(poses[: n + 1, r], o["poses"]), r
+        assert bits_equal(st["vels"][r], o["vels"][-1]) and bits_equal(st["dists"][r], o["dists"][-1]), r
+        assert np.array_equal(_dense_words(st["coll"][r], E), oracle.coll_to_dense(o["coll"], E)[-1]), r
+        for k in ("ego_avg_speed", "ego_max_speed", "ego_distance_travelled"):
+            assert rows[k][r] == o["metric_" + k], (r, k)
+        ev = events[events["scenario"] == r]
+        assert np.array_equal(ev["t"], o["ev_t"]) and np.array_equal(ev["other"], o["ev_other"]), r
+        n_ev += len(ev)
+    assert n_ev > 0
+
+
+def test_wide_scenario_collision_terminal(sga, oracle):
+    """terminal_conditions=["collision"] across wavefronts (workgroup-wide OR)."""
+    import scenario_gym_amd._lib as L
+    from scenario_gym_amd import synthetic
+
+    packed = synthetic.make_batch(8, 130, n_steps=200, ego_kind=L.KIND_AGENT_REPLAY, extent=80.0)
+    st, rows, events, t, poses = _engine_run(sga, packed, 1 / 30, 200, terminal=["max_length", "collision"])
+    for r in range(8):
+        o = _oracle_one(oracle, packed, r, 1 / 30, 200, terminal_mask=3)
+        assert rows["n_steps"][r] == o["n_steps"] and bool(rows["done"][r]) == o["is_done"], r
+        assert bits_equal(st["poses"][r], o["poses"][-1]), r
+
+
+# --------------------------------------------------------------------------- pedestrians / social force
+def _ped_packed(g, si):
+    from scenario_gym_amd.engine import DEFAULT_CTRL
+    from scenario_gym_amd.packing import default_kinds, pack_arrays
+    import scenario_gym_amd._lib as L
+
+    sc = scenario_arrays(g, f"loop{si}/scenario")
+    E = len(sc["etype"])
+    Rt, vdes, thr = g[f"loop{si}/routes"], g[f"loop{si}/vdes"], float(g[f"loop{si}/distance_threshold"])
+    kind = default_kinds(E, sc["ego"])
+    ctrl = np.tile(DEFAULT_CTRL, (E, 1))
+    roff, rows = [0], []
+    for i in range(E):
+        isped = not np.isnan(vdes[i])
+        if isped:
+            kind[i] = L.KIND_AGENT_PEDESTRIAN
+            ctrl[i, L.C_PED_SPEED_DESIRED], ctrl[i, L.C_PED_RADIUS] = vdes[i], thr
+            rows.append(Rt[i])
+        roff.append(roff[-1] + (len(Rt[i]) if isped else 0))
+    sc = dict(sc, route_off=np.array(roff, np.int64), routes=np.concatenate(rows))
+    return pack_arrays([sc], kinds=[kind], ctrls=[ctrl]), E
+
+
+@pytest.mark.parametrize("si", [0, 1])
+def test_pedestrian_closed_loops_match_reference(sga, oracle, si):
+    """SocialForce closed loops captured from the reference: poses/velocities <= 1e-8 (contract 1e-5),
+    goal indices, collisions and CollisionMetric events exact; bit-identical to the oracle."""
+    g = load_golden("pedestrian")
+    packed, E = _ped_packed(g, si)
+    for dtn, dt in (("dt30", 1 / 30), ("dt10", 0.1)):
+        p = f"loop{si}/{dtn}"
+        n = int(g[p + "/n_steps"])
+        st, rows, events, t, poses = _engine_run(sga, packed, dt, n + 2, ev_cap=128)
+        assert rows["n_steps"][0] == n and bits_equal(t[: n + 1, 0], g[p + "/t"])
+        ref = g[p + "/poses"]
+        assert np.array_equal(np.isnan(poses[: n + 1, 0]), np.isnan(ref))
+        assert np.nanmax(np.abs(poses[: n + 1, 0] - ref)) < 1e-8
+        assert np.nanmax(np.abs(st["vels"][0] - g[p + "/vels"][-1])) < 1e-8
+        ex = g[p + "/extra"][-1]
+        ped = ~np.isnan(ex[:, 0])
+        assert np.array_equal(st["ctrl_state"][0, ped, 1], ex[ped, 1])                    # goal_idx
+        assert np.abs(st["ctrl_state"][0, ped, 0] - ex[ped, 0]).max() < 1e-8              # controller speed
+        assert np.abs(st["force"][0, ped] - ex[ped, 2:]).max() < 1e-8                     # PedestrianAgent.force
+        assert np.array_equal(_dense(st["coll"][0], E), g[p + "/coll"][-1])
+        assert np.array_equal(events["t"], g[p + "/ev_t"]) and np.array_equal(events["other"], g[p + "/ev_other"])
+        assert (events["type"] == 5).all()
+        o = _oracle_one(oracle, packed, 0, dt, n + 2)
+        assert bits_equal(poses[: n + 1, 0], o["poses"]) and bits_equal(st["vels"][0], o["vels"][-1])
+        assert bits_equal(st["force"][0, ped], o["extra"][-1, ped, 2:])
+
+
+@pytest.mark.parametrize("R,E,steps,side", [(32, 40, 120, 12.0), (6, 256, 60, 30.0), (10, 100, 80, 20.0)])
+def test_crowd_matches_oracle(sga, oracle, R, E, steps, side):
+    """BASELINE config 5 family (all-pedestrian crowds, up to 256 per scenario): bit-identical to the oracle."""
+    from scenario_gym_amd import synthetic
+
+    packed = synthetic.make_crowd(R, E, n_steps=steps, side=side)
+    st, rows, events, t, poses = _engine_run(sga, packed, 1 / 30, steps, ev_cap=512)
+    for r in range(R):
+        o = _oracle_one(oracle, packed, r, 1 / 30, steps)
+        n = o["n_steps"]
+        assert rows["n_steps"][r] == n, r
+        assert bits_equal(poses[: n + 1, r], o["poses"]), r
+        assert bits_equal(st["vels"][r], o["vels"][-1]) and bits_equal(st["dists"][r], o["dists"][-1]), r
+        assert bits_equal(st["force"][r], o["extra"][-1, :, 2:]) and np.array_equal(st["ctrl_state"][r, :, 1], o["extra"][-1, :, 1])
+        assert np.array_equal(_dense_words(st["coll"][r], E), oracle.coll_to_dense(o["coll"], E)[-1]), r
+        ev = events[events["scenario"] == r]
+        assert rows["n_collisions"][r] == o["n_events"]
+        assert np.array_equal(ev["t"], o["ev_t"]) and np.array_equal(ev["other"], o["ev_other"]), r
+    assert (rows["n_collisions"] > 0).any()
+
+
+def test_pedestrian_stepwise_equals_single_launch(sga):
+    """gym.step() one launch per step reproduces the single-launch rollout (neighbour candidates and
+    goal indices survive the kernel boundary)."""
+    from scenario_gym_amd import synthetic
+
+    packed = synthetic.make_crowd(8, 24, n_steps=40, side=8.0)
+    a = sga.RolloutEngine(8, 24)
+    a.upload(packed)
+    a.rollout(40)
+    b = sga.RolloutEngine(8, 24)
+    b.upload(packed)
+    for _ in range(40):
+        b.step(1)
+    sa, sb = a.state(), b.state()
+    for k in ("poses", "vels", "dists", "force", "ctrl_state"):
+        assert bits_equal(sa[k], sb[k]), k
+    assert np.array_equal(sa["coll"], sb["coll"])
+    a.close()
+    b.close()

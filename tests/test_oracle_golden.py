@@ -224,3 +224,77 @@ def test_pair_intersections_exact(oracle):
     ])
     assert np.array_equal(own, lab)
     assert 0.2 < lab.mean() < 0.5
+
+
+# ---------------------------------------------------------------- F1-F4 pedestrians / social force
+def ped_inputs(g, si, oracle):
+    """Arrays for the closed-loop pedestrian goldens: kinds, controller rows, routes."""
+    sc = scenario_arrays(g, f"loop{si}/scenario")
+    E = len(sc["etype"])
+    R, vdes, thr = g[f"loop{si}/routes"], g[f"loop{si}/vdes"], float(g[f"loop{si}/distance_threshold"])
+    kind = oracle.default_kinds(E, sc["ego"])
+    ctrl = np.tile(oracle.DEFAULT_CTRL, (E, 1))
+    roff, rows = [0], []
+    for i in range(E):
+        if not np.isnan(vdes[i]):
+            kind[i] = oracle.KIND_AGENT_PEDESTRIAN
+            ctrl[i, 9], ctrl[i, 12] = vdes[i], thr
+            rows.append(R[i])
+        roff.append(roff[-1] + (len(R[i]) if not np.isnan(vdes[i]) else 0))
+    return sc, kind, ctrl, np.array(roff, np.int64), np.concatenate(rows)
+
+
+PED_TOL = 1e-8  # measured worst 1.6e-10 (velocities); the contract for controller-integrated poses is 1e-5
+
+
+@pytest.mark.parametrize("si", [0, 1])
+def test_pedestrian_closed_loops(oracle, si):
+    """PedestrianAgent + SocialForce + PedestrianController closed loops captured from the reference
+    (12 / 20 pedestrians + a replayed vehicle, empty road network, noise off)."""
+    g = load_golden("pedestrian")
+    sc, kind, ctrl, roff, routes = ped_inputs(g, si, oracle)
+    E = len(kind)
+    for dtn, dt in (("dt30", 1 / 30), ("dt10", 0.1)):
+        p = f"loop{si}/{dtn}"
+        o = oracle.rollout(**sc, kind=kind, dt=dt, ctrl=ctrl, route_off=roff, routes=routes)
+        assert o["n_steps"] == int(g[p + "/n_steps"]) and bits_equal(o["t"], g[p + "/t"])
+        for k in ("poses", "vels", "dists"):
+            assert np.array_equal(np.isnan(o[k]), np.isnan(g[p + "/" + k]))
+            assert np.nanmax(np.abs(o[k] - g[p + "/" + k])) < PED_TOL, (p, k)
+        ex = g[p + "/extra"]
+        ped = ~np.isnan(ex[0, :, 0])
+        assert np.array_equal(o["extra"][:, ped, 1], ex[:, ped, 1])              # goal_idx exact
+        assert np.abs(o["extra"][:, ped] - ex[:, ped]).max() < PED_TOL           # speed, force
+        assert np.array_equal(oracle.coll_to_dense(o["coll"], E), g[p + "/coll"])
+        assert np.array_equal(o["ev_t"], g[p + "/ev_t"]) and np.array_equal(o["ev_other"], g[p + "/ev_other"])
+        assert set(g[p + "/ev_type"]) <= {"non_vehicle"} and (o["ev_type"] == 5).all()
+
+
+def test_social_force_math_accuracy(oracle):
+    """exp / atan2 / tan shared with the kernels: < 2 ulp against 50-digit mpmath."""
+    import mpmath as mp
+
+    mp.mp.dps = 50
+    rng = np.random.default_rng(3)
+
+    def ulps(got, ref):
+        return abs(float((mp.mpf(got) - ref) / np.spacing(abs(float(ref)))))
+
+    w = max(ulps(oracle.exp(x), mp.e ** mp.mpf(float(x))) for x in rng.uniform(-30, 5, 1500))
+    assert w < 1.0
+    w = max(ulps(oracle.atan2(y, x), mp.atan2(mp.mpf(float(y)), mp.mpf(float(x)))) for y, x in rng.normal(0, 3, (1500, 2)))
+    assert w < 2.0
+    w = max(ulps(oracle.tan(x), mp.tan(mp.mpf(float(x)))) for x in rng.uniform(-1.4, 1.4, 1500))
+    assert w < 2.0
+    assert oracle.atan2(0.0, 0.0) == 0.0 and oracle.atan2(1.0, 0.0) == np.arctan2(1.0, 0.0) and oracle.exp(0.0) == 1.0
+
+
+def test_radius_query_known_answers(oracle):
+    """tests/test_state.py:74-101 style: strictly inside the 64-gon buffer, not the circle."""
+    assert oracle.in_radius(0, 0, 10.0, 3.0, 4.0) and not oracle.in_radius(0, 0, 10.0, 30.0, 4.0)
+    r = 10.0
+    apothem = r * np.cos(np.pi / 64)
+    mid = np.pi / 64  # direction of an edge midpoint
+    assert oracle.in_radius(0, 0, r, (apothem - 1e-9) * np.cos(mid), -(apothem - 1e-9) * np.sin(mid))
+    assert not oracle.in_radius(0, 0, r, (apothem + 1e-9) * np.cos(mid), -(apothem + 1e-9) * np.sin(mid))
+    assert oracle.in_radius(0, 0, r, r - 1e-9, 0.0) and not oracle.in_radius(0, 0, r, r, 0.0)  # a vertex is not inside
