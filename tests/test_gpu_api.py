@@ -216,5 +216,5 @@ def test_torch_zero_copy_view():
     st = eng.state()
     x = view[:, L.F_POSE, :].reshape(-1)[: 64 * 16].reshape(64, 16).cpu().numpy()
     assert np.array_equal(np.where(st["present"], x, np.nan), st["poses"][..., 0], equal_nan=True)
-    assert view.is_cuda and view.dtype.is_floating_point and view.shape[1] == L.F_COUNT
+    assert view.is_cuda and view.dtype.is_floating_point and view.shape[1] == L.F_COLL + 1
     eng.close()

@@ -451,7 +451,7 @@ def test_pedestrian_stepwise_equals_single_launch(sga):
     goal indices survive the kernel boundary)."""
     from scenario_gym_amd import synthetic
 
-    packed = synthetic.make_crowd(8, 24, n_steps=40, side=8.0)
+    packed = synthetic.make_crowd(8, 24, n_steps=80, side=8.0)  # nobody reaches max_length in 40 steps
     a = sga.RolloutEngine(8, 24)
     a.upload(packed)
     a.rollout(40)
@@ -460,6 +460,7 @@ def test_pedestrian_stepwise_equals_single_launch(sga):
     for _ in range(40):
         b.step(1)
     sa, sb = a.state(), b.state()
+    assert (sa["n_steps"] == 40).all() and (sb["n_steps"] == 40).all()
     for k in ("poses", "vels", "dists", "force", "ctrl_state"):
         assert bits_equal(sa[k], sb[k]), k
     assert np.array_equal(sa["coll"], sb["coll"])
