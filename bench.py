@@ -39,14 +39,18 @@ def cpu_baseline(workload, seconds_budget=20.0):
     O.lib()
     cores = os.cpu_count() or 1
     E, T = workload["E"], workload["T"]
-    t_sample = T
-    n_scen = max(cores, 1) * 4
-    packed = synthetic.make_batch(n_scen, E, n_steps=t_sample, ego_kind=workload["ego_kind"])
+    if workload.get("crowd"):
+        t_sample, n_scen = min(T, 1000), max(cores, 1)
+        packed = synthetic.make_crowd(n_scen, E, n_steps=t_sample)
+    else:
+        t_sample, n_scen = T, max(cores, 1) * 4
+        packed = synthetic.make_batch(n_scen, E, n_steps=t_sample, ego_kind=workload["ego_kind"])
     scen = [unpack_scenario(packed, r) for r in range(n_scen)]
 
     def one(s):
         o = O.rollout(s["knot_off"], s["knots"], s["bbox"], s["etype"], s["kind"], s["ego"], s["t0"],
-                      s["length"], workload["dt"], ctrl=s["ctrl"], max_steps=t_sample, record=False)
+                      s["length"], workload["dt"], ctrl=s["ctrl"], max_steps=t_sample, record=False,
+                      route_off=s.get("route_off"), routes=s.get("routes"))
         return o["n_steps"]
 
     one(scen[0])  # warm
@@ -83,6 +87,9 @@ def main():
     ap.add_argument("--entities", type=int, default=64)
     ap.add_argument("--sim-steps", type=int, default=10000)
     ap.add_argument("--ego", default="pid", choices=["pid", "replay"])
+    ap.add_argument("--workload", default="c3", choices=["c3", "c2", "c5"],
+                    help="BASELINE.json configs: c3 = 4096x64 PID ego (default, the headline), c2 = 256x16 replay, "
+                         "c5 = 1024x256 social-force crowd")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -95,6 +102,10 @@ def main():
 
     from scenario_gym_amd import distributed as D
 
+    if args.workload == "c2":
+        args.scenarios, args.entities, args.ego = 256, 16, "replay"
+    elif args.workload == "c5":
+        args.scenarios, args.entities = 1024, 256
     rank, world, local_rank, dist = D.init()
     if args.gpus != world and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
@@ -106,8 +117,12 @@ def main():
     R, E, T, ego_kind, seed = D.dispatch_config(
         [args.scenarios, args.entities, args.sim_steps, ego_kind, synthetic.SEED], dist)
 
-    packed = synthetic.make_batch(R, E, n_steps=T, timestep=dt, ego_kind=ego_kind, seed=seed,
-                                  first_scenario=rank * R)
+    crowd = args.workload == "c5"
+    if crowd:
+        packed = synthetic.make_crowd(R, E, n_steps=T, timestep=dt, seed=seed, first_scenario=rank * R)
+    else:
+        packed = synthetic.make_batch(R, E, n_steps=T, timestep=dt, ego_kind=ego_kind, seed=seed,
+                                      first_scenario=rank * R)
     eng = sga.RolloutEngine(R, E, timestep=dt, terminal_conditions=["max_length"], event_capacity=64,
                             device=local_rank)
     eng.upload(packed)
@@ -146,7 +161,8 @@ def main():
     if rank == 0:
         per_launch = ent_steps / args.steps
         avg_ms = sum(kernel_ms) / len(kernel_ms)
-        achieved = per_launch * B_ALG / (avg_ms * 1e-3) / 1e9
+        b_alg = 154.0 if crowd else B_ALG  # +24 B of collision row words, +16 B force vector
+        achieved = per_launch * b_alg / (avg_ms * 1e-3) / 1e9
         line = {
             "metric": "entity-steps/sec (batched rollout)",
             "value": total / elapsed,
@@ -161,22 +177,26 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"{R} scenarios x {E} entities x {T} steps per GPU, "
-                            f"{'PIDAgent' if ego_kind == L.KIND_AGENT_PID else 'ReplayTrajectoryAgent'} ego + batch replay "
-                            "others, all-pairs OBB collisions, CollisionMetric + EgoAvgSpeed/MaxSpeed/DistanceTravelled, "
-                            "terminal max_length (BASELINE.json configs[2])",
+                "workload": (f"{R} scenarios x {E} pedestrians x {T} steps per GPU, PedestrianAgent + SocialForce "
+                             "(radius 3 m, noise off) + PedestrianController, all-pairs OBB collisions, CollisionMetric, "
+                             "terminal max_length (BASELINE.json configs[4])") if crowd else
+                            (f"{R} scenarios x {E} entities x {T} steps per GPU, "
+                             f"{'PIDAgent' if ego_kind == L.KIND_AGENT_PID else 'ReplayTrajectoryAgent'} ego + batch replay "
+                             "others, all-pairs OBB collisions, CollisionMetric + EgoAvgSpeed/MaxSpeed/DistanceTravelled, "
+                             f"terminal max_length (BASELINE.json configs[{1 if args.workload == 'c2' else 2}])"),
                 "scenarios_per_gpu": R, "entities": E, "sim_steps": T, "timestep": dt,
                 "sharding": f"replicas x{world}, no data-path collective",
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(R, E, T),
-                "kernel": f"sg::rollout_kernel<{max(4, 1 << (E - 1).bit_length())}>", "kernel_ms": avg_ms,
-                "bytes_per_entity_step": B_ALG, "entity_steps_per_launch": per_launch,
+                "kernel": f"sg::rollout_kernel<{min(64, max(4, 1 << (E - 1).bit_length()))}, {1 if E <= 64 else 2 if E <= 128 else 4}, {str(crowd).lower()}>",
+                "kernel_ms": avg_ms,
+                "bytes_per_entity_step": b_alg, "entity_steps_per_launch": per_launch,
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(dict(E=E, T=T, dt=dt, ego_kind=ego_kind))
+            line["cpu_baseline"] = cpu_baseline(dict(E=E, T=T, dt=dt, ego_kind=ego_kind, crowd=crowd))
         print(json.dumps(line))
     eng.close()
     if dist is not None:

@@ -77,7 +77,8 @@ typedef struct {
     int32_t persist;         /* ScenarioGym(persist=...) */
     uint32_t terminal_mask;  /* SG_TERM_* */
     int32_t record_capacity; /* rows of State._recorded_poses kept on device (0 = off), state.py:227-228 */
-    int32_t event_capacity;  /* CollisionMetric events kept per scenario (metrics/collision.py:70-75) */
+    int32_t event_capacity;  /* CollisionMetric events kept per scenario (metrics/collision.py:70-75); later events are
+                                counted in sg_metrics.n_collisions but not stored */
     int32_t reserved;
     double timestep;         /* ScenarioGym(timestep=...) */
 } sg_config;

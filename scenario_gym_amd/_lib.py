@@ -80,6 +80,10 @@ def load():
             f"{LIB_PATH} is missing: build it with `make -C scenario_gym_amd/csrc` "
             "(or __graft_entry__.build()).  scenario_gym_amd has no CPU fallback."
         )
+    try:  # PyTorch bundles its own libamdhip64: let it load first so that both share ONE HIP runtime
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     H = C.c_void_p
     lib.sg_version.restype = C.c_int

@@ -19,8 +19,11 @@ def init(backend: Optional[str] = None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world == 1:
+    if world == 1 and not os.environ.get("SGYM_FORCE_DIST"):  # SGYM_FORCE_DIST=1: exercise the collectives with one rank
         return rank, world, local_rank, None
+    os.environ.setdefault("MASTER_PORT", "29511")
+    os.environ.setdefault("RANK", "0")
+    os.environ.setdefault("WORLD_SIZE", "1")
     import torch
     import torch.distributed as dist
 

@@ -218,3 +218,36 @@ def test_torch_zero_copy_view():
     assert np.array_equal(np.where(st["present"], x, np.nan), st["poses"][..., 0], equal_nan=True)
     assert view.is_cuda and view.dtype.is_floating_point and view.shape[1] == L.F_COLL + 1
     eng.close()
+
+
+def test_pedestrian_agents_through_the_gym_api():
+    """PedestrianAgent / SocialForce descriptors through ScenarioGym (tests/pedestrian/test_social_force.py style),
+    checked against the reference closed loop."""
+    import scenario_gym_amd as sga
+
+    g = load_golden("pedestrian")
+    sc = _scenario(g, "loop0/scenario")
+    routes, vdes, thr = g["loop0/routes"], g["loop0/vdes"], float(g["loop0/distance_threshold"])
+    idx = {e.ref: i for i, e in enumerate(sc.entities)}
+
+    def create_agent(s, e):
+        if e.ref == "ego":
+            return sga.ReplayTrajectoryAgent(e)
+        i = idx[e.ref]
+        return sga.PedestrianAgent(e, routes[i], vdes[i], sga.SocialForce(sga.SocialForceParameters(std_lon=0.0, std_lat=0.0)),
+                                   distance_threshold=thr)
+
+    gym = sga.ScenarioGym(timestep=0.1, metrics=[sga.CollisionMetric()])
+    gym.set_scenario(sc, create_agent=create_agent)
+    gym.step()
+    first = gym.state.poses
+    assert all(np.abs(first[e] - g["loop0/dt10/poses"][1, i]).max() < 1e-9 for e, i in ((e, idx[e.ref]) for e in sc.entities))
+    gym.rollout()
+    p = "loop0/dt10"
+    for e in sc.entities:
+        assert np.abs(gym.state.poses[e] - g[p + "/poses"][-1, idx[e.ref]]).max() < 1e-8
+    refs = list(g["loop0/scenario/refs"])
+    got = gym.get_metrics()["collisions"]
+    assert [(t, refs.index(r), ty) for t, r, ty in got] == [(t, int(o), "non_vehicle") for t, o in zip(g[p + "/ev_t"], g[p + "/ev_other"])]
+    with pytest.raises(NotImplementedError):  # the device model is deterministic
+        sga.SocialForce(sga.SocialForceParameters()).device_params()
