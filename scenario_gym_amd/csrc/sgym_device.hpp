@@ -399,7 +399,9 @@ struct TileLds {
     // social force inputs of the CURRENT state (pedestrian/sensor.py:55-64): reference point, velocity
     double px[PED ? NS : 1], py[PED ? NS : 1], vx[PED ? NS : 1], vy[PED ? NS : 1];
     unsigned char isped[PED ? NS : 1]; // entity.type == "Pedestrian" and present
-    int flag[4];
+    // broad-phase stripe masks: bit set of the slots whose centre lies in x- (y-) stripe k (mod 64)
+    unsigned long long xtab[64][NS / 64], ytab[64][NS / 64];
+    float2 cen[NS];         // box centres again, interleaved, for single-read gathers
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -677,7 +679,7 @@ __device__ __forceinline__ bool block_any(bool x)
 template <int G, int WV, bool PED, typename LDS>
 __device__ __forceinline__ void tile_collisions(bool present, const double *pose, double velx, double vely,
                                                 double s, double c, double bcx, double bcy, float rad_thr,
-                                                float nbr_thr, bool is_ped_type, int sl, int tile0, LDS &L,
+                                                float nbr_thr, float cell_inv, bool is_ped_type, int sl, int tile0, LDS &L,
                                                 uint64_t (&rows_out)[WV], uint64_t (&mult_rows)[WV],
                                                 uint64_t (&nbr_out)[WV])
 {
@@ -693,26 +695,81 @@ __device__ __forceinline__ void tile_collisions(bool present, const double *pose
     const float mag = __builtin_fabsf(fx) + __builtin_fabsf(fy);
     const float reach = rad_thr + 1.9073486e-6f * mag;
     const float thr = reach * reach;
+    const float nreach = nbr_thr + 1.9073486e-6f * mag;
+    const float nthr = nreach * nreach;
+    // stripe coordinates: cells of side 1/cell_inv >= every reach in the tile, so two slots within reach
+    // of each other sit in the same or in adjacent x-stripes AND y-stripes
+    const float ax = fx * cell_inv, ay = fy * cell_inv;
+    const int ix = present ? (int)__builtin_floorf(ax) : 0, iy = present ? (int)__builtin_floorf(ay) : 0;
+    const bool far_out = present && !(__builtin_fabsf(ax) < 4000.0f && __builtin_fabsf(ay) < 4000.0f);
     __syncthreads();
     L.cx[sl] = fx;
     L.cy[sl] = fy;
+    L.cen[sl] = make_float2(fx, fy);
     L.sc[sl] = make_float2(fs, fc);
+    reinterpret_cast<unsigned long long *>(L.xtab)[sl] = 0ull;
+    reinterpret_cast<unsigned long long *>(L.ytab)[sl] = 0ull;
     if (PED) {
         L.px[sl] = x; L.py[sl] = y; L.vx[sl] = velx; L.vy[sl] = vely;
         L.isped[sl] = present && is_ped_type;
     }
-    __syncthreads();
-    // All pairs of the tile: lane i tests itself against slots j..j+3 per iteration (wave-uniform
-    // LDS broadcast reads, one ds_read_b128 per coordinate, two iterations prefetched), everything in
-    // packed fp32 (2 columns per v_pk_* op): d2 = dx*dx + dy*dy, then thr - d2 whose SIGN bit says
-    // "outside"; the sign bits are shifted into the lane's row with one v_alignbit_b32 per column
-    // (columns walked high -> low).  3.5 VALU ops per column, no branches, no compares.
+    uint64_t cand[WV];
+    bool any_cand = false;
+#pragma unroll
+    for (int w = 0; w < WV; ++w) { rows_out[w] = 0; mult_rows[w] = 0; nbr_out[w] = 0; cand[w] = 0; }
+    if (!block_any<WV>(far_out)) { // block_any / the barrier below also publish the LDS writes above
+        // ---- stripe masks: O(tile) instead of O(tile^2) ----
+        if (WV == 1) __syncthreads();
+        const int wsl = (WV == 1) ? 0 : (slot >> 6);              // word of this slot inside the tile's row
+        const uint64_t mybit = 1ull << ((WV == 1) ? (sl & 63) : (slot & 63));
+        if (present) {
+            atomicOr(&L.xtab[ix & 63][wsl], mybit);
+            atomicOr(&L.ytab[iy & 63][wsl], mybit);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < WV; ++w) {
+            uint64_t mx = L.xtab[(ix - 1) & 63][w] | L.xtab[ix & 63][w] | L.xtab[(ix + 1) & 63][w];
+            uint64_t my = L.ytab[(iy - 1) & 63][w] | L.ytab[iy & 63][w] | L.ytab[(iy + 1) & 63][w];
+            uint64_t m = mx & my;
+            if (WV == 1) { // several tiles share the wave: keep this tile's slots, tile-local bit positions
+                m >>= tile0;
+                if (G < 64) m &= (1ull << (G & 63)) - 1;
+            }
+            if ((slot >> 6) == w) m &= ~(1ull << (slot & 63)); // not with itself
+            cand[w] = present ? m : 0;
+        }
+        // ---- bounding circles of the cell neighbours: per wavefront, LDS reads only ----
+        uint64_t close[WV];
+#pragma unroll
+        for (int w = 0; w < WV; ++w) {
+            close[w] = 0;
+            while (__any(cand[w] != 0)) {
+                if (cand[w]) {
+                    const int jl = __builtin_ctzll(cand[w]);
+                    cand[w] &= cand[w] - 1;
+                    const float2 o = L.cen[tile0 + w * 64 + jl];
+                    const float dx = o.x - fx, dy = o.y - fy;
+                    const float d2 = __builtin_fmaf(dy, dy, dx * dx);
+                    if (d2 <= thr) close[w] |= 1ull << jl;
+                    if (PED && d2 <= nthr) nbr_out[w] |= 1ull << jl;
+                }
+            }
+            cand[w] = close[w];
+            any_cand = any_cand || cand[w] != 0;
+        }
+    } else {
+    // ---- fallback for coordinates beyond 4000 cells: all pairs of the tile ----
+    // lane i tests itself against slots j..j+3 per iteration (wave-uniform LDS broadcast reads, one
+    // ds_read_b128 per coordinate, two iterations prefetched), everything in packed fp32 (2 columns per
+    // v_pk_* op): d2 = dx*dx + dy*dy, then thr - d2 whose SIGN bit says "outside"; the sign bits are
+    // shifted into the lane's row with one v_alignbit_b32 per column (columns walked high -> low).
     const v2f fx2 = {fx, fx}, fy2 = {fy, fy}, thr2 = {thr, thr};
-    const float nreach = nbr_thr + 1.9073486e-6f * mag;
-    const v2f nthr2 = {nreach * nreach, nreach * nreach};
+    const v2f nthr2 = {nthr, nthr};
     uint32_t out_w[2 * WV], nout_w[2 * WV]; // bit j = 1: slot j is OUTSIDE this lane's reach
 #pragma unroll
     for (int w = 0; w < 2 * WV; ++w) { out_w[w] = 0u; nout_w[w] = 0u; }
+    if (WV == 1) __syncthreads();
     v4f xs = *reinterpret_cast<const v4f *>(&L.cx[tile0 + TS - 4]);
     v4f ys = *reinterpret_cast<const v4f *>(&L.cy[tile0 + TS - 4]);
     v4f xs1 = xs, ys1 = ys;
@@ -720,16 +777,13 @@ __device__ __forceinline__ void tile_collisions(bool present, const double *pose
         xs1 = *reinterpret_cast<const v4f *>(&L.cx[tile0 + TS - 8]);
         ys1 = *reinterpret_cast<const v4f *>(&L.cy[tile0 + TS - 8]);
     }
-#pragma unroll
+#pragma unroll 4
     for (int jb = TS - 4; jb >= 0; jb -= 4) {
         v4f xs2 = xs1, ys2 = ys1; // two groups of four slots stay in flight
         if (jb >= 8) {
             xs2 = *reinterpret_cast<const v4f *>(&L.cx[tile0 + jb - 8]);
             ys2 = *reinterpret_cast<const v4f *>(&L.cy[tile0 + jb - 8]);
         }
-#ifndef SG_NO_SCHED_BARRIER
-        __builtin_amdgcn_sched_barrier(0); // keep the prefetch above the arithmetic it overlaps with
-#endif
         v2f dxa = v2f{xs.x, xs.y} - fx2, dya = v2f{ys.x, ys.y} - fy2;
         v2f dxb = v2f{xs.z, xs.w} - fx2, dyb = v2f{ys.z, ys.w} - fy2;
         v2f d2a = __builtin_elementwise_fma(dya, dya, dxa * dxa);
@@ -754,8 +808,6 @@ __device__ __forceinline__ void tile_collisions(bool present, const double *pose
         xs1 = xs2; ys1 = ys2;
     }
     // absent slots hold NaN centres (sign bit unspecified): mask them with the tile's presence bits
-    uint64_t cand[WV];
-    bool any_cand = false;
 #pragma unroll
     for (int w = 0; w < WV; ++w) {
         uint64_t pres_w;
@@ -774,12 +826,9 @@ __device__ __forceinline__ void tile_collisions(bool present, const double *pose
             if (WV == 1 && G < 64) nin &= (1ull << (G & 63)) - 1;
             if ((slot >> 6) == w) nin &= ~(1ull << (slot & 63));
             nbr_out[w] = present ? nin : 0;
-        } else {
-            nbr_out[w] = 0;
         }
-        rows_out[w] = 0;
-        mult_rows[w] = 0;
         any_cand = any_cand || cand[w] != 0;
+    }
     }
 #ifdef SG_ABL_NO_NARROW
 #pragma unroll
@@ -1025,6 +1074,21 @@ __global__ __launch_bounds__(64 * WV, PED ? 1 : SG_WAVES_PER_SIMD) void rollout_
             nbr_thr = kind == SG_KIND_AGENT_PEDESTRIAN
                           ? (float)fld(st, ST_CTRL + SG_C_PED_RADIUS) * 1.000001f + off + omax + 2e-3f : 0.0f;
     }
+    // broad-phase cell size: >= every reach in the tile (+5 % so that fp32 cell coordinates stay consistent)
+    float cell_inv;
+    {
+        float tmax = __builtin_fmaxf(rad_thr, nbr_thr);
+#pragma unroll
+        for (int o = 1; o < G; o <<= 1) tmax = __builtin_fmaxf(tmax, __shfl_xor(tmax, o, 64));
+        if (WV > 1) {
+            float *red = reinterpret_cast<float *>(lds.cor);
+            if (lane == 0) red[wave] = tmax;
+            __syncthreads();
+            for (int w = 0; w < WV; ++w) tmax = __builtin_fmaxf(tmax, red[w]);
+            __syncthreads();
+        }
+        cell_inv = 1.0f / (1.05f * tmax + 0.05f);
+    }
     // pedestrian route (pedestrian/agent.py:43-47)
     const double *wp = nullptr;
     int nwp = 0;
@@ -1087,7 +1151,7 @@ __global__ __launch_bounds__(64 * WV, PED ? 1 : SG_WAVES_PER_SIMD) void rollout_
         for (int w = 0; w < WV; ++w) last_row[w] = 0; // metrics/collision.py:64-68
         n_ev = 0;
         sg_sincos(pose[3], sin_h, cos_h);
-        tile_collisions<G, WV, PED>(present, pose, velx, vely, sin_h, cos_h, bcx, bcy, rad_thr, nbr_thr, is_ped_type,
+        tile_collisions<G, WV, PED>(present, pose, velx, vely, sin_h, cos_h, bcx, bcy, rad_thr, nbr_thr, cell_inv, is_ped_type,
                                     sl, tile0, lds, row, mult_rows, nbr);
         if (in_range) {
 #pragma unroll
@@ -1131,7 +1195,7 @@ __global__ __launch_bounds__(64 * WV, PED ? 1 : SG_WAVES_PER_SIMD) void rollout_
         if (PED) { // the neighbour candidates (and LDS positions) of the current state
             uint64_t tmp_rows[WV];
             tile_collisions<G, WV, PED>(present, pose, velx, vely, sin_h, cos_h, bcx, bcy, rad_thr, nbr_thr,
-                                        is_ped_type, sl, tile0, lds, tmp_rows, mult_rows, nbr);
+                                        cell_inv, is_ped_type, sl, tile0, lds, tmp_rows, mult_rows, nbr);
         }
 #pragma unroll
         for (int w = 0; w < WV; ++w) row[w] = fld<uint64_t>(dy, SG_F_COLL + w);
@@ -1287,7 +1351,7 @@ __global__ __launch_bounds__(64 * WV, PED ? 1 : SG_WAVES_PER_SIMD) void rollout_
 #pragma unroll
         for (int w = 0; w < WV; ++w) nrow[w] = 0;
 #else
-        tile_collisions<G, WV, PED>(present, pose, velx, vely, sin_h, cos_h, bcx, bcy, rad_thr, nbr_thr, is_ped_type,
+        tile_collisions<G, WV, PED>(present, pose, velx, vely, sin_h, cos_h, bcx, bcy, rad_thr, nbr_thr, cell_inv, is_ped_type,
                                     sl, tile0, lds, nrow, mult_rows, nbr);
 #endif
         if (run) {
