@@ -527,21 +527,20 @@ __device__ __forceinline__ bool sg_in_radius(double cx, double cy, double r, dou
     double dx = px - cx, dy = py - cy, d2 = dx * dx + dy * dy, r2 = r * r;
     if (d2 > r2 * (1.0 + 1e-9)) return false;
     if (d2 < r2 * 0.9975) return true;
-    double o = 0.0;
-    for (int i = 0; i < 64; ++i) {
-        int j = (i + 1) & 63;
-        double ax = cx + r * gon[2 * i], ay = cy - r * gon[2 * i + 1];
-        double bx = cx + r * gon[2 * j], by = cy - r * gon[2 * j + 1];
-        o += ax * by - bx * ay;
-    }
-    for (int i = 0; i < 64; ++i) {
-        int j = (i + 1) & 63;
+    // On the thin ring between the inscribed circle and the vertices only the edges facing the point can
+    // cut it off: test the edge of its sector and both neighbours with the oracle's cross product (the
+    // other 61 edges hold with a margin of ~r*sin(pi/32)).  Vertices run clockwise: (cx + r*C_i, cy - r*S_i).
+    float phi = atan2f((float)(-dy), (float)dx);
+    int k0 = (int)__builtin_floorf(phi * 10.185916f); // 64 / (2*pi)
+    bool inside = true;
+    for (int e = -1; e <= 1; ++e) {
+        int i = (k0 + e) & 63, j = (i + 1) & 63;
         double ax = cx + r * gon[2 * i], ay = cy - r * gon[2 * i + 1];
         double bx = cx + r * gon[2 * j], by = cy - r * gon[2 * j + 1];
         double cr = (bx - ax) * (py - ay) - (by - ay) * (px - ax);
-        if (o > 0 ? !(cr > 0) : !(cr < 0)) return false;
+        inside = inside && (cr < 0);
     }
-    return true;
+    return inside;
 }
 
 // LineString(route).project(Point) + the goal update of PedestrianAgent._step (pedestrian/agent.py:59-62)
@@ -594,12 +593,22 @@ __device__ __forceinline__ void ped_step(const Params &p, const LDS &L, int sl, 
         double hs, hc;
         sg_sincos(L.ctrl[SG_C_PED_HEAD_ROT][sl], hs, hc, K);
         const double radius = L.ctrl[SG_C_PED_RADIUS][sl];
+        // neighbours in entity order, one per iteration across all row words (the wavefront iterates
+        // max-over-lanes of the TOTAL candidate count, not the sum of per-word maxima)
+        uint64_t m[WV];
 #pragma unroll
-        for (int w = 0; w < WV; ++w) {
-            uint64_t m = nbr[w];
-            while (m) {
-                const int j = tile0 + w * 64 + __builtin_ctzll(m);
-                m &= m - 1;
+        for (int w = 0; w < WV; ++w) m[w] = nbr[w];
+        for (;;) {
+            int j = -1;
+#pragma unroll
+            for (int w = WV - 1; w >= 0; --w)
+                if (m[w]) j = w * 64 + __builtin_ctzll(m[w]);
+            if (j < 0) break;
+#pragma unroll
+            for (int w = 0; w < WV; ++w)
+                if ((j >> 6) == w) m[w] &= m[w] - 1;
+            j += tile0;
+            {
                 if (!L.isped[j]) continue; // PedestrianSensor: pedestrians only (sensor.py:60-62)
                 const double ox = L.px[j], oy = L.py[j], ovx = L.vx[j], ovy = L.vy[j];
                 if (!sg_in_radius(pose[0], pose[1], radius, ox, oy, p.gon)) continue;
