@@ -466,3 +466,107 @@ def test_pedestrian_stepwise_equals_single_launch(sga):
     assert np.array_equal(sa["coll"], sb["coll"])
     a.close()
     b.close()
+
+
+# --------------------------------------------------------------------------- edge cases
+def _mini(knots_per_entity, bbox=(2.0, 4.2, 1.37, 0.0), etype=2, length=None, t0=None, ego=0):
+    off = np.concatenate([[0], np.cumsum([len(k) for k in knots_per_entity])]).astype(np.int64)
+    knots = np.concatenate([np.asarray(k, np.float64) for k in knots_per_entity])
+    E = len(knots_per_entity)
+    return dict(knot_off=off, knots=knots, bbox=np.tile(bbox, (E, 1)), etype=np.full(E, etype, np.int32), ego=ego,
+                t0=max(0.0, float(knots[off[ego], 0])) if t0 is None else t0,
+                length=float(max(k[-1][0] for k in knots_per_entity)) if length is None else length)
+
+
+def _row(t, x, y, h=0.0):
+    return [t, x, y, 0.0, h, 0.0, 0.0]
+
+
+def _check_against_oracle(sga, oracle, scs, dt, n_max, **kw):
+    from scenario_gym_amd.packing import default_kinds, pack_arrays
+
+    packed = pack_arrays(scs)
+    st, rows, events, t, poses = _engine_run(sga, packed, dt, n_max, **kw)
+    for r, sc in enumerate(scs):
+        E = len(sc["etype"])
+        o = oracle.rollout(sc["knot_off"], sc["knots"], sc["bbox"], sc["etype"], default_kinds(E, sc["ego"]), sc["ego"],
+                           sc["t0"], sc["length"], dt, max_steps=n_max, persist=kw.get("persist", False))
+        n = o["n_steps"]
+        assert rows["n_steps"][r] == n and bool(rows["done"][r]) == o["is_done"], r
+        assert bits_equal(poses[: n + 1, r, :E], o["poses"]), r
+        assert bits_equal(st["vels"][r, :E], o["vels"][-1]) and bits_equal(st["dists"][r, :E], o["dists"][-1]), r
+        assert np.array_equal(st["coll"][r, :E], o["coll"][-1, :, 0]), r
+        assert np.isnan(poses[: n + 1, r, E:]).all()  # padding slots are never present
+    return st, rows, events
+
+
+def test_degenerate_and_ragged_scenarios(sga, oracle):
+    """One-entity scenario, all-static scenario, zero-length scenario, an entity that ended before t0,
+    an ego that starts late, ragged widths padded in one batch (tile of 8 lanes, partial last wavefront)."""
+    scs = [
+        _mini([[_row(0, 0, 0), _row(3, 30, 0)]]),                                             # ego alone
+        _mini([[_row(0, 0, 0)], [_row(0, 1, 0)], [_row(2, 50, 50)]], length=1.0),             # everything static
+        _mini([[_row(1.0, 5, 5)]], length=1.0),                                               # zero length: one step
+        _mini([[_row(2, 0, 0), _row(4, 10, 0)], [_row(0, 3, 0), _row(1, 4, 0)], [_row(0, 9, 9), _row(9, 0, 0)]]),  # #1 ended before t0 = 2
+        _mini([[_row(0, 0, 0), _row(2, 5, 1)], [_row(0.5, 2, 0.5), _row(1.5, 2, 0.4)], [_row(0, 2.5, 0.6)],
+               [_row(0, -3, 0), _row(2, 8, 1.2)], [_row(1.0, 4, 1), _row(1.9, 4, 1.1)]]),    # 5 wide: crossings, vanishing
+    ]
+    for persist in (False, True):
+        _check_against_oracle(sga, oracle, scs, 0.1, 100, persist=persist)
+    _check_against_oracle(sga, oracle, scs * 3, 1 / 30, 300)  # 15 scenarios x 8 lanes = partial second wavefront
+
+
+def test_far_from_origin_uses_the_all_pairs_fallback(sga, oracle):
+    """Coordinates beyond 4000 broad-phase cells (~4e4 m) leave the stripe masks for the all-pairs path;
+    beyond 1e5 rad the shared sin/cos defers to libm/ocml (not bit-pinned): stay below that."""
+    rng = np.random.default_rng(5)
+    scs = []
+    for k, origin in enumerate((3.0e4, 2.0e5, -7.5e5)):
+        ents = []
+        for i in range(12):
+            x0, y0 = origin + rng.uniform(-15, 15), -origin + rng.uniform(-15, 15)
+            ents.append([_row(0, x0, y0, 0.3 * i), _row(4, x0 + rng.uniform(-20, 20), y0 + rng.uniform(-20, 20), 0.3 * i + 1)])
+        scs.append(_mini(ents))
+    st, rows, events = _check_against_oracle(sga, oracle, scs, 1 / 30, 130, ev_cap=256)
+    assert (st["coll"] != 0).any()
+
+
+def test_abi_rejects_bad_input(sga):
+    import scenario_gym_amd._lib as L
+    from scenario_gym_amd.packing import pack_arrays
+
+    with pytest.raises(RuntimeError, match="n_entities"):
+        sga.RolloutEngine(4, 300)
+    with pytest.raises(RuntimeError, match="timestep"):
+        sga.RolloutEngine(4, 4, timestep=0.0)
+    with pytest.raises(ValueError):
+        sga.RolloutEngine(4, 4, terminal_conditions=["ego_off_road"])
+    good = _mini([[_row(0, 0, 0), _row(1, 1, 0)], [_row(0, 5, 0)]])
+    eng = sga.RolloutEngine(1, 2)
+    with pytest.raises(RuntimeError, match="no scenarios uploaded"):
+        eng.rollout(3)
+    bad = pack_arrays([good])
+    bad.kind = bad.kind.copy()
+    bad.kind[1] = 9
+    with pytest.raises(RuntimeError, match="unknown"):
+        eng.upload(bad)
+    bad = pack_arrays([good])
+    bad.knots = bad.knots.copy()
+    bad.knots[1, 0] = 0.0  # not strictly increasing
+    with pytest.raises(RuntimeError, match="strictly increasing"):
+        eng.upload(bad)
+    bad = pack_arrays([good])
+    bad.ego = np.array([5], np.int32)
+    with pytest.raises(RuntimeError, match="ego"):
+        eng.upload(bad)
+    bad = pack_arrays([good])
+    bad.kind = bad.kind.copy()
+    bad.kind[0] = L.KIND_AGENT_PEDESTRIAN  # pedestrian agent without a route
+    with pytest.raises(RuntimeError, match="route"):
+        eng.upload(bad)
+    eng.upload(pack_arrays([good]))  # the handle is still usable
+    eng.rollout(50)
+    assert eng.state()["done"].all()
+    with pytest.raises(RuntimeError, match="record_capacity"):
+        eng.record(5)
+    eng.close()
