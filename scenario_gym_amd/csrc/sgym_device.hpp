@@ -392,9 +392,11 @@ struct TileLds {
     float cx[NS], cy[NS];   // box centres (NaN when absent), SoA for packed-fp32 pair math
     float2 sc[NS];          // sin, cos of the heading
     float2 half[NS];        // half length, half width (static)
-    double cor[8][NS];      // fp64 corners, only filled on the exact path
+    // fp64 corners of the exact path: a single wavefront exchanges them with cross-lane reads instead;
+    // the 8 floats that remain are scratch for the launch-time reductions across wavefronts
+    double cor[8][NS > 64 ? NS : 2];
     int last[NS];
-    double ctrl[NCTRL_ROWS][NS]; // controller parameters (SG_C_*) of every slot, copied once per launch
+    double ctrl[PED ? NCTRL_ROWS : 9][NS]; // controller parameters (SG_C_*) of every slot, copied once per launch
     double boxwl[2][NS];    // bounding box width, length (exact path and controllers only)
     // social force inputs of the CURRENT state (pedestrian/sensor.py:55-64): reference point, velocity
     double px[PED ? NS : 1], py[PED ? NS : 1], vx[PED ? NS : 1], vy[PED ? NS : 1];
@@ -885,26 +887,30 @@ __device__ __forceinline__ void tile_collisions(bool present, const double *pose
 
     double A[8];
     sg_corners(x, y, s, c, L.boxwl[0][sl], L.boxwl[1][sl], bcx, bcy, A);
+    if (WV > 1) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) L.cor[k][sl] = A[k];
-    __syncthreads();
+        for (int k = 0; k < 8; ++k) L.cor[k][sl] = A[k];
+        __syncthreads();
+    }
     uint64_t eq[WV];
     bool any_eq = false;
 #pragma unroll
     for (int w = 0; w < WV; ++w) {
         eq[w] = 0;
         while (__any(fuzzy[w] != 0)) {
-            if (fuzzy[w]) {
-                const int jl = __builtin_ctzll(fuzzy[w]);
-                fuzzy[w] &= fuzzy[w] - 1;
-                const int j = tile0 + w * 64 + jl;
-                double B[8];
-                bool same = true;
+            // every lane takes part in the cross-lane reads; idle lanes read their own corners
+            const bool act = fuzzy[w] != 0;
+            const int jl = act ? __builtin_ctzll(fuzzy[w]) : (slot & 63);
+            if (act) fuzzy[w] &= fuzzy[w] - 1;
+            const int j = tile0 + w * 64 + jl;
+            double B[8];
+            bool same = true;
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    B[k] = L.cor[k][j];
-                    same = same && (B[k] == A[k]);
-                }
+            for (int k = 0; k < 8; ++k) {
+                B[k] = WV > 1 ? L.cor[k][j] : shfl_d(A[k], j);
+                same = same && (B[k] == A[k]);
+            }
+            if (act) {
                 if (same) eq[w] |= 1ull << jl;                      // g == g_prime: never listed (utils.py:59)
                 else if (sg_quads_intersect(A, B)) rows_out[w] |= 1ull << jl;
             }
@@ -1078,7 +1084,7 @@ __global__ __launch_bounds__(64 * WV, PED ? 1 : SG_WAVES_PER_SIMD) void rollout_
         lds.boxwl[0][sl] = bw;
         lds.boxwl[1][sl] = bl;
 #pragma unroll
-        for (int q = 0; q < NCTRL_ROWS; ++q) lds.ctrl[q][sl] = fld(st, ST_CTRL + q);
+        for (int q = 0; q < (PED ? NCTRL_ROWS : 9); ++q) lds.ctrl[q][sl] = fld(st, ST_CTRL + q);
         if (PED) // PedestrianSensor radius is measured between reference points; centres differ by the box offsets
             nbr_thr = kind == SG_KIND_AGENT_PEDESTRIAN
                           ? (float)fld(st, ST_CTRL + SG_C_PED_RADIUS) * 1.000001f + off + omax + 2e-3f : 0.0f;
