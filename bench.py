@@ -65,8 +65,8 @@ def cpu_baseline(workload, seconds_budget=20.0):
     }
 
 
-def measured_traffic(R, E, T):
-    """HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE x2 for wide reads +
+def measured_traffic(R, E, T, launches_per_rollout=1.0):
+    """HBM bytes per rollout-kernel launch from the PMC passes committed under profiles/ (FETCH_SIZE +
     WRITE_SIZE, MI355X_MICROARCH.md HBM section), if that profile was taken on this workload."""
     path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if not os.path.exists(path):
@@ -75,6 +75,8 @@ def measured_traffic(R, E, T):
         rec = json.load(f)
     if (rec.get("scenarios"), rec.get("entities"), rec.get("sim_steps")) != (R, E, T):
         return None
+    if "hbm_bytes_per_rollout" in rec:  # summed over the launches of one rollout
+        return rec["hbm_bytes_per_rollout"] / launches_per_rollout
     return rec.get("hbm_bytes_per_launch")
 
 
@@ -136,7 +138,8 @@ def main():
         D.gather_rows(np.stack([rows["ego_avg_speed"], rows["ego_max_speed"], rows["ego_distance_travelled"],
                                 rows["n_collisions"].astype(np.float64), rows["n_steps"].astype(np.float64)],
                                axis=1), dist)
-        return rows, eng.last_kernel_ms()
+        n_launch, launch_ms = eng.last_launch_stats()
+        return rows, (eng.last_kernel_ms(), n_launch, launch_ms)
 
     for _ in range(args.warmup):
         one_pass()
@@ -159,8 +162,13 @@ def main():
     total = D.sum_over_ranks(float(ent_steps), dist)
 
     if rank == 0:
-        per_launch = ent_steps / args.steps
-        avg_ms = sum(kernel_ms) / len(kernel_ms)
+        # dominant kernel = sg::rollout_kernel.  A long rollout is cut into chunks of steps (one launch each, so that the
+        # controller pre-pass of the next chunk overlaps it): per-launch units and duration are averages over the
+        # launches of the timed passes, each launch timed with its own HIP event pair on the handle's stream.
+        n_launches = sum(k[1] for k in kernel_ms)
+        per_launch = ent_steps / n_launches
+        avg_ms = sum(k[2] for k in kernel_ms) / n_launches
+        rollout_ms = sum(k[0] for k in kernel_ms) / len(kernel_ms)  # everything one sg_rollout enqueues
         b_alg = 154.0 if crowd else B_ALG  # +24 B of collision row words, +16 B force vector
         achieved = per_launch * b_alg / (avg_ms * 1e-3) / 1e9
         line = {
@@ -189,9 +197,9 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(R, E, T),
-                "kernel": f"sg::rollout_kernel<{min(64, max(4, 1 << (E - 1).bit_length()))}, {1 if E <= 64 else 2 if E <= 128 else 4}, {str(crowd).lower()}>",
-                "kernel_ms": avg_ms,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(R, E, T, n_launches / args.steps),
+                "kernel": f"sg::rollout_kernel<{min(64, max(4, 1 << (E - 1).bit_length()))}, {1 if E <= 64 else 2 if E <= 128 else 4}, {str(crowd).lower()}, {str(not crowd).lower()}>",
+                "kernel_ms": avg_ms, "launches_per_rollout": n_launches / args.steps, "rollout_device_ms": rollout_ms,
                 "bytes_per_entity_step": b_alg, "entity_steps_per_launch": per_launch,
             },
         }

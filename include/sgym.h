@@ -197,7 +197,8 @@ int sg_set_timestep(sg_handle *h, double timestep);
 int sg_step(sg_handle *h, int32_t n_steps, const double *actions, int32_t actions_device);
 
 /* ScenarioGym.rollout(): reset, then step each scenario while it is not done, at most max_steps
- * (scenario_gym.py:256-267).  One kernel launch for the whole batch. */
+ * (scenario_gym.py:256-267).  The time loop runs inside the kernels: one launch of the rollout kernel per chunk of
+ * steps (all of them for short runs), preceded by the controller pre-pass when the batch has PID / vehicle agents. */
 int sg_rollout(sg_handle *h, int32_t max_steps);
 /* Same without the reset and without waiting: enqueue on the handle's stream (bench timing) */
 int sg_rollout_async(sg_handle *h, int32_t max_steps, int32_t do_reset);
@@ -217,8 +218,27 @@ int sg_read_record(sg_handle *h, int32_t n_rows, double *t_out, double *pose_out
  * synchronising the handle's stream); lets a ctypes caller read state without any GPU array library */
 int sg_copy_to_host(sg_handle *h, const void *device_ptr, void *host_ptr, uint64_t bytes);
 
-/* time of the last sg_rollout / sg_step kernel in milliseconds (HIP events on the handle's stream) */
+/* device time of the last sg_rollout / sg_step call in milliseconds (HIP events on the handle's stream around
+ * everything the call enqueued) */
 int sg_last_kernel_ms(sg_handle *h, float *ms);
+
+/* the rollout-kernel launches of that call (long rollouts are cut into chunks of steps so that the controller
+ * pre-pass of chunk c+1 overlaps the rollout kernel of chunk c): how many, and the sum of their durations, each
+ * measured with its own HIP event pair on the handle's stream */
+int sg_last_launch_stats(sg_handle *h, int32_t *n_launches, float *kernel_ms_total);
+
+/* Launch policy of sg_rollout / sg_step (results do not depend on it; negative / zero values keep the current one).
+ *   tab_min_steps  calls with at least this many steps integrate PID / vehicle agents in the controller pre-pass
+ *                  (one lane per agent, 64 agents to a wavefront) instead of inside the rollout kernel
+ *                  (default 16, env SG_TAB_MIN_STEPS); scenarios with pedestrian agents always take the in-kernel path
+ *   chunk_steps    steps per pre-pass chunk (default 1024, env SG_CHUNK_STEPS)
+ *   overlap        1: pre-pass of chunk c+1 runs on a second stream beside the rollout kernel of chunk c (default) */
+int sg_set_tuning(sg_handle *h, int32_t tab_min_steps, int32_t chunk_steps, int32_t overlap);
+
+/* test hook: the fp32 sin/cos the collision broad phase and filter use (hardware v_sin_f32 / v_cos_f32 on the
+ * fp64-reduced heading).  HOST arrays of n values.  The fp64 results the reference would see
+ * (Entity.get_bounding_box_points, entity/base.py:113) are only needed for pairs the fp32 filter cannot decide. */
+int sg_debug_trig32(sg_handle *h, int64_t n, const double *heading, float *sin_out, float *cos_out);
 
 #ifdef __cplusplus
 }

@@ -23,6 +23,11 @@
 #ifndef SG_WAVES_PER_SIMD
 #define SG_WAVES_PER_SIMD 2 // register budget of the rollout kernel: 512 / SG_WAVES_PER_SIMD VGPRs per lane
 #endif
+// controlled lanes per wavefront the table variant of the rollout kernel serves: one per scenario of the wavefront, at most 4
+#define SG_TAB_LANES(G, WV) ((WV) > 1 || (G) >= 64 ? 1 : ((G) >= 32 ? 2 : 4))
+#ifndef SG_WAVES_PER_SIMD_TAB
+#define SG_WAVES_PER_SIMD_TAB 2 // same for the variant without in-kernel controllers
+#endif
 
 namespace sg {
 
@@ -33,9 +38,10 @@ enum {
     ST_KNOT_OFF,                        // int64 first row of the entity's own knots
     ST_META,                            // int64: kind | etype << 8 | knot_n << 32
     ST_ROUTE,                           // int64: first route waypoint | n_waypoints << 48 (pedestrian agents)
+    ST_CTL,                             // int64: column of this slot in the controller table (PID / vehicle agents), -1 = none
     ST_CTRL,                            // NCTRL_ROWS rows of controller parameters (SG_C_*)
     NCTRL_ROWS = 13,
-    ST_COUNT = ST_CTRL + NCTRL_ROWS     // 22 rows
+    ST_COUNT = ST_CTRL + NCTRL_ROWS     // 23 rows
 };
 constexpr uint32_t ROW = 512; // bytes of one field row of a block (64 lanes x 8 B)
 
@@ -63,7 +69,16 @@ struct Params {
     const double *gon;       // [64][2] cos, sin of 2*pi*i/64 (host libm): Point.buffer(r) vertices
     int WV, FROWS;           // waves per scenario (1, 2, 4); rows per state block = SG_F_COLL + WV
     sg_social_force sf;
+    // controller pre-pass (control_kernel): the PID / vehicle agents of the whole batch, 64 to a wavefront
+    const int32_t *ctl_ent;  // [n_ctl_pad] padded entity index r*EP + slot of controlled lane q, -1 = padding
+    double *ctl_state;       // [CS_COUNT][n_ctl_pad] lane state carried from one chunk of steps to the next
+    int n_ctl_pad;           // multiple of 64
 };
+
+// controller table written by control_kernel, read by rollout_kernel<.., TAB = true>: one row per step
+//   tab[(k * CT_COUNT + c) * n_ctl_pad + q],  c = x, y, h after step k, then the controller state after step k
+enum { CT_X = 0, CT_Y, CT_H, CT_SPEED, CT_ELON, CT_ELAT, CT_EINT, CT_COUNT };
+enum { CS_POSE = 0, CS_PRESENT = 6, CS_CTRL = 7, CS_T = 11, CS_PREV_T = 12, CS_COUNT = 13 };
 
 // Lane pointers into one 64-slot block.  Global loads/stores carry an immediate offset (the compiler
 // only uses 0..4095 of it), so a lane keeps three 64-bit addresses per block -- rows 0-7, 8-15 and
@@ -189,6 +204,25 @@ __device__ __forceinline__ double sg_tan(double x, ConstTbl K)
     return x + r;
 }
 
+// fp32 sin/cos of an fp64 heading for the collision broad phase and filter (never for stored state):
+// the angle is reduced to revolutions in fp64 (|error| < 4e-12 rev for |h| < 1e5), rounded to fp32
+// (2^-25 rev) and fed to the hardware v_sin_f32 / v_cos_f32, whose argument is in revolutions.
+// Absolute error <= SG_TRIG32_ERR; tests/test_gpu_parity.py measures it through sg_debug_trig32.
+#define SG_TRIG32_ERR 4.0e-6f
+__device__ __forceinline__ void sg_sincos_f32(double h, float &s, float &c)
+{
+    if (!(__builtin_fabs(h) < 1.0e5)) { // huge / non-finite headings: the fp64 path's own fallback
+        double2 sc = sg_sincos_slow(h);
+        s = (float)sc.x;
+        c = (float)sc.y;
+        return;
+    }
+    const double rev = h * 1.59154943091895345554e-01; // 1 / (2 pi)
+    const float f = (float)(rev - __builtin_rint(rev));
+    s = __builtin_amdgcn_sinf(f);
+    c = __builtin_amdgcn_cosf(f);
+}
+
 __device__ __forceinline__ double sg_pred(double x) // nextafter(x, -inf) for finite x
 {
     long long b = __double_as_longlong(x);
@@ -198,6 +232,15 @@ __device__ __forceinline__ double sg_pred(double x) // nextafter(x, -inf) for fi
 }
 
 __device__ __forceinline__ double shfl_d(double v, int src) { return __shfl(v, src, 64); }
+
+// s_waitcnt vmcnt(0) (expcnt / lgkmcnt untouched).  Placed after every RARE block of global loads whose results
+// stay in registers across the time loop: the state stores of the steady state share vmcnt with those loads, and
+// without an explicit wait at the load site the compiler has to wait for vmcnt(0) -- i.e. for every store of the
+// previous step -- at the first use of such a register inside each step.
+__device__ __forceinline__ void sg_loads_done() { __builtin_amdgcn_s_waitcnt(0x0F70); }
+// s_waitcnt lgkmcnt(0): same idea for LDS / scalar-memory results at the end of a step, so that the scalar
+// table loads issued at the top of the next step are not waited for on the spot
+__device__ __forceinline__ void sg_lgkm_done() { __builtin_amdgcn_s_waitcnt(0xC07F); }
 
 // ------------------------------------------------------------------------------------------------
 // x / d for many numerators and one denominator.  `a / b` on gfx950 expands to
@@ -680,6 +723,21 @@ __device__ __forceinline__ void ped_step(const Params &p, const LDS &L, int sl, 
 // With WV > 1 the tile spans WV wavefronts of one workgroup; only the decisions that gate LDS
 // writes are workgroup-uniform (block_any), the candidate loops run per wavefront.
 // ------------------------------------------------------------------------------------------------
+// Barrier between the lanes of one tile's workgroup.  A single wavefront (WV == 1) needs no s_barrier and no
+// s_waitcnt: the LDS executes the instructions of one wavefront in issue order, so a ds_read issued after another
+// lane's ds_write / ds_or already sees it; a wavefront-scope fence keeps the compiler from reordering them.
+template <int WV>
+__device__ __forceinline__ void tile_sync()
+{
+    if (WV == 1) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+        __syncthreads();
+    }
+}
+
 template <int WV>
 __device__ __forceinline__ bool block_any(bool x)
 {
@@ -689,7 +747,7 @@ __device__ __forceinline__ bool block_any(bool x)
 
 template <int G, int WV, bool PED, typename LDS>
 __device__ __forceinline__ void tile_collisions(bool present, const double *pose, double velx, double vely,
-                                                double s, double c, double bcx, double bcy, float rad_thr,
+                                                double bcx, double bcy, float rad_thr, float trig_eps,
                                                 float nbr_thr, float cell_inv, bool is_ped_type, int sl, int tile0, LDS &L,
                                                 uint64_t (&rows_out)[WV], uint64_t (&mult_rows)[WV],
                                                 uint64_t (&nbr_out)[WV])
@@ -697,11 +755,14 @@ __device__ __forceinline__ void tile_collisions(bool present, const double *pose
     constexpr int TS = G * WV; // tile slots
     const int slot = sl - tile0;
     const double x = pose[0], y = pose[1];
-    // box centre; bounding circle radius + margins live in rad_thr (static per lane)
-    const double ccx = x + (bcx * c - bcy * s), ccy = y + (bcx * s + bcy * c);
+    // box centre in fp32 from the hardware sin/cos; the bounding circle radius and every error margin
+    // (fp32 rounding, SG_TRIG32_ERR x centre offset) live in rad_thr (static per lane)
+    float fs, fc;
+    sg_sincos_f32(pose[3], fs, fc);
+    const float bcxf = (float)bcx, bcyf = (float)bcy;
     const float nanf_ = __builtin_nanf("");
-    const float fx = present ? (float)ccx : nanf_, fy = present ? (float)ccy : nanf_;
-    const float fs = (float)s, fc = (float)c;
+    const float fx = present ? (float)x + (bcxf * fc - bcyf * fs) : nanf_;
+    const float fy = present ? (float)y + (bcxf * fs + bcyf * fc) : nanf_;
     // fp32 conversion error of the centre grows with |coordinate|: 2^-19 * (|x| + |y|) covers both lanes
     const float mag = __builtin_fabsf(fx) + __builtin_fabsf(fy);
     const float reach = rad_thr + 1.9073486e-6f * mag;
@@ -713,7 +774,7 @@ __device__ __forceinline__ void tile_collisions(bool present, const double *pose
     const float ax = fx * cell_inv, ay = fy * cell_inv;
     const int ix = present ? (int)__builtin_floorf(ax) : 0, iy = present ? (int)__builtin_floorf(ay) : 0;
     const bool far_out = present && !(__builtin_fabsf(ax) < 4000.0f && __builtin_fabsf(ay) < 4000.0f);
-    __syncthreads();
+    tile_sync<WV>();
     L.cx[sl] = fx;
     L.cy[sl] = fy;
     L.cen[sl] = make_float2(fx, fy);
@@ -730,14 +791,14 @@ __device__ __forceinline__ void tile_collisions(bool present, const double *pose
     for (int w = 0; w < WV; ++w) { rows_out[w] = 0; mult_rows[w] = 0; nbr_out[w] = 0; cand[w] = 0; }
     if (!block_any<WV>(far_out)) { // block_any / the barrier below also publish the LDS writes above
         // ---- stripe masks: O(tile) instead of O(tile^2) ----
-        if (WV == 1) __syncthreads();
+        if (WV == 1) tile_sync<WV>();
         const int wsl = (WV == 1) ? 0 : (slot >> 6);              // word of this slot inside the tile's row
         const uint64_t mybit = 1ull << ((WV == 1) ? (sl & 63) : (slot & 63));
         if (present) {
             atomicOr(&L.xtab[ix & 63][wsl], mybit);
             atomicOr(&L.ytab[iy & 63][wsl], mybit);
         }
-        __syncthreads();
+        tile_sync<WV>();
 #pragma unroll
         for (int w = 0; w < WV; ++w) {
             uint64_t mx = L.xtab[(ix - 1) & 63][w] | L.xtab[ix & 63][w] | L.xtab[(ix + 1) & 63][w];
@@ -780,7 +841,7 @@ __device__ __forceinline__ void tile_collisions(bool present, const double *pose
     uint32_t out_w[2 * WV], nout_w[2 * WV]; // bit j = 1: slot j is OUTSIDE this lane's reach
 #pragma unroll
     for (int w = 0; w < 2 * WV; ++w) { out_w[w] = 0u; nout_w[w] = 0u; }
-    if (WV == 1) __syncthreads();
+    if (WV == 1) tile_sync<WV>();
     v4f xs = *reinterpret_cast<const v4f *>(&L.cx[tile0 + TS - 4]);
     v4f ys = *reinterpret_cast<const v4f *>(&L.cy[tile0 + TS - 4]);
     v4f xs1 = xs, ys1 = ys;
@@ -870,7 +931,8 @@ __device__ __forceinline__ void tile_collisions(bool present, const double *pose
                     float g2 = __builtin_fabsf(dx * os.y + dy * os.x) - (oh.x + hl * cd + hw * sd);
                     float g3 = __builtin_fabsf(dy * os.y - dx * os.x) - (oh.y + hl * sd + hw * cd);
                     float gap = __builtin_fmaxf(__builtin_fmaxf(g0, g1), __builtin_fmaxf(g2, g3));
-                    float eps = 1e-3f + 1.9073486e-6f * (mag + __builtin_fabsf(oc.x) + __builtin_fabsf(oc.y));
+                    // fp32 rounding of the centres + trig_eps: the hardware sin/cos error on every product
+                    float eps = 1e-3f + 1.9073486e-6f * (mag + __builtin_fabsf(oc.x) + __builtin_fabsf(oc.y)) + trig_eps;
                     // an absent slot has NaN centres: gap is NaN, neither branch below fires
                     bool unsure = (gap <= eps) && (gap >= -eps);
                     unsure = unsure || (dx == 0.0f && dy == 0.0f); // possibly bit-identical boxes
@@ -886,11 +948,17 @@ __device__ __forceinline__ void tile_collisions(bool present, const double *pose
     if (!block_any<WV>(any_fuzzy)) return; // workgroup-uniform; the rest is the rare exact path
 
     double A[8];
-    sg_corners(x, y, s, c, L.boxwl[0][sl], L.boxwl[1][sl], bcx, bcy, A);
+    {
+        double s, c; // fp64 sin/cos of the heading: only here, on the exact path
+        const double *Kp = SG_TRIG; // opaque: the coefficients are scalar-loaded here instead of living in VGPRs
+        asm volatile("" : "+s"(Kp));
+        sg_sincos(pose[3], s, c, (ConstTbl)Kp);
+        sg_corners(x, y, s, c, L.boxwl[0][sl], L.boxwl[1][sl], bcx, bcy, A);
+    }
     if (WV > 1) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) L.cor[k][sl] = A[k];
-        __syncthreads();
+        tile_sync<WV>();
     }
     uint64_t eq[WV];
     bool any_eq = false;
@@ -924,7 +992,7 @@ __device__ __forceinline__ void tile_collisions(bool present, const double *pose
         for (int w = 0; w < WV; ++w)
             if (eq[w]) last = max(last, w * 64 + 63 - __builtin_clzll(eq[w]));
         L.last[sl] = last;
-        __syncthreads();
+        tile_sync<WV>();
         uint64_t nr[WV];
 #pragma unroll
         for (int w = 0; w < WV; ++w) nr[w] = 0;
@@ -1026,11 +1094,15 @@ __device__ __forceinline__ Table lane_table(const Params &p, int kind, const Sce
     return T;
 }
 
-template <int G, int WV, bool PED>
-__global__ __launch_bounds__(64 * WV, PED ? 1 : SG_WAVES_PER_SIMD) void rollout_kernel(Params p, double timestep, int n_steps,
-                                                                            int do_reset, int force,
-                                                                            const double *actions /*[n][R][2]*/)
+//
+// TAB: the PID / vehicle agents were integrated by control_kernel; their lanes read (x, y, h) per step from
+// its table `tab` instead of running the controller with 1 of 64 lanes active.  TAB launches never reset.
+template <int G, int WV, bool PED, bool TAB>
+__global__ __launch_bounds__(64 * WV, PED ? 1 : (TAB ? SG_WAVES_PER_SIMD_TAB : SG_WAVES_PER_SIMD)) void rollout_kernel(
+    Params p, double timestep, int n_steps, int do_reset, int force, const double *actions /*[n][R][2]*/,
+    const double *tab /*[n][CT_COUNT][n_ctl_pad]*/)
 {
+    static_assert(!(PED && TAB), "pedestrian scenarios run their controllers in the rollout kernel");
     constexpr int NS = 64 * WV;
     __shared__ TileLds<NS, PED> lds;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1061,7 +1133,7 @@ __global__ __launch_bounds__(64 * WV, PED ? 1 : SG_WAVES_PER_SIMD) void rollout_
     const bool is_agent = kind >= SG_KIND_AGENT_REPLAY;
     // per-launch LDS tables: box extents, controller parameters; broad-phase reach of this lane =
     // own bounding-circle radius + the largest radius in the tile + slack
-    float rad_thr, nbr_thr = 0.0f;
+    float rad_thr, trig_eps, nbr_thr = 0.0f;
     {
         const double bw = fld(st, ST_BW), bl = fld(st, ST_BL);
         float rad = (float)(0.5 * __builtin_sqrt(bl * bl + bw * bw)) * 1.000001f;
@@ -1079,12 +1151,17 @@ __global__ __launch_bounds__(64 * WV, PED ? 1 : SG_WAVES_PER_SIMD) void rollout_
             for (int w = 0; w < WV; ++w) { rmax = __builtin_fmaxf(rmax, red[w]); omax = __builtin_fmaxf(omax, red[8 + w]); }
             __syncthreads();
         }
-        rad_thr = rad + rmax + 2e-3f;
+        // hardware sin/cos (error d = SG_TRIG32_ERR per value): each centre moves by <= 2 d off, so the reach grows
+        // by 2 d (off + omax); in the filter every gap is a sum of (length <= reach) x (trig product, error <= 4 d)
+        rad_thr = rad + rmax + 2e-3f + 2.0f * SG_TRIG32_ERR * (off + omax);
+        trig_eps = SG_TRIG32_ERR * (12.0f * rad_thr + 4.0f * (off + omax));
         lds.half[sl] = make_float2((float)(0.5 * bl), (float)(0.5 * bw));
         lds.boxwl[0][sl] = bw;
         lds.boxwl[1][sl] = bl;
+        if (!TAB) {
 #pragma unroll
-        for (int q = 0; q < (PED ? NCTRL_ROWS : 9); ++q) lds.ctrl[q][sl] = fld(st, ST_CTRL + q);
+            for (int q = 0; q < (PED ? NCTRL_ROWS : 9); ++q) lds.ctrl[q][sl] = fld(st, ST_CTRL + q);
+        }
         if (PED) // PedestrianSensor radius is measured between reference points; centres differ by the box offsets
             nbr_thr = kind == SG_KIND_AGENT_PEDESTRIAN
                           ? (float)fld(st, ST_CTRL + SG_C_PED_RADIUS) * 1.000001f + off + omax + 2e-3f : 0.0f;
@@ -1123,9 +1200,47 @@ __global__ __launch_bounds__(64 * WV, PED ? 1 : SG_WAVES_PER_SIMD) void rollout_
     bool present;
     int done, steps;
     uint64_t row[WV], mult_rows[WV], nbr[WV];
-    double sin_h, cos_h;
+    // column of this lane in the controller table (TAB): PID / vehicle agents only
+    // The table rows are fetched with SCALAR loads, one controlled lane at a time (at most SG_TAB_LANES per
+    // wavefront and wavefront of a wide scenario, checked by the host), one step ahead, and moved into the lane's registers at the end of the step.  A vector load inside the loop would share vmcnt with the state stores and make every
+    // step wait for the stores of the previous one.
+    const int64_t ctl_q = TAB ? fld<int64_t>(st, ST_CTL) : -1;
+    const bool tab_lane = TAB && ctl_q >= 0 && (kind == SG_KIND_AGENT_PID || kind == SG_KIND_AGENT_VEHICLE);
+    const size_t tab_np = (size_t)p.n_ctl_pad;
+    const size_t tab_row = (size_t)CT_COUNT * tab_np; // doubles per step
+    int last_k = -1;                                  // last step of this launch the scenario executed
+    constexpr int TL = SG_TAB_LANES(G, WV);
+    int cl[TL];                       // wave-uniform: the controlled lanes of this wavefront
+    const double *cb[TL];             // wave-uniform: their table columns
+    double sx[TL], sy[TL], sh[TL];    // wave-uniform: row of the coming step
+    if (TAB) {
+        uint64_t cm = __ballot(tab_lane);
+#pragma unroll
+        for (int j = 0; j < TL; ++j) {
+            cl[j] = -1;
+            cb[j] = tab;
+            sx[j] = sy[j] = sh[j] = 0.0;
+            if (cm) {
+                const int l = __builtin_ctzll(cm);
+                cm &= cm - 1;
+                cl[j] = l;
+                const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)ctl_q, l);
+                const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(ctl_q >> 32), l);
+                cb[j] = tab + (((uint64_t)hi << 32) | lo);
+            }
+        }
+    }
+    auto tab_issue = [&](int k) { // s_load the rows of step k (unconditional: an unused entry reads column 0)
+#pragma unroll
+        for (int j = 0; j < TL; ++j) {
+            ConstTbl rowp = (ConstTbl)(cb[j] + (size_t)k * tab_row);
+            sx[j] = rowp[CT_X * tab_np];
+            sy[j] = rowp[CT_Y * tab_np];
+            sh[j] = rowp[CT_H * tab_np];
+        }
+    };
 
-    if (do_reset) {
+    if (!TAB && do_reset) {
         // ---- State.reset(t0), state.py:106-143 ----
         const double *kn = p.knots + fld<int64_t>(st, ST_KNOT_OFF) * 7;
         const int nk = (int)(meta >> 32);
@@ -1165,8 +1280,7 @@ __global__ __launch_bounds__(64 * WV, PED ? 1 : SG_WAVES_PER_SIMD) void rollout_
 #pragma unroll
         for (int w = 0; w < WV; ++w) last_row[w] = 0; // metrics/collision.py:64-68
         n_ev = 0;
-        sg_sincos(pose[3], sin_h, cos_h);
-        tile_collisions<G, WV, PED>(present, pose, velx, vely, sin_h, cos_h, bcx, bcy, rad_thr, nbr_thr, cell_inv, is_ped_type,
+        tile_collisions<G, WV, PED>(present, pose, velx, vely, bcx, bcy, rad_thr, trig_eps, nbr_thr, cell_inv, is_ped_type,
                                     sl, tile0, lds, row, mult_rows, nbr);
         if (in_range) {
 #pragma unroll
@@ -1197,19 +1311,20 @@ __global__ __launch_bounds__(64 * WV, PED ? 1 : SG_WAVES_PER_SIMD) void rollout_
         velx = fld(dy, SG_F_VEL + 0);
         vely = fld(dy, SG_F_VEL + 1);
         dist = fld(dy, SG_F_DIST);
-        cs.speed = fld(dy, SG_F_CTRL + 0); cs.e_lon_prev = fld(dy, SG_F_CTRL + 1);
-        cs.e_lat_prev = fld(dy, SG_F_CTRL + 2); cs.e_lon_int = fld(dy, SG_F_CTRL + 3);
-        goal_idx = (int)cs.e_lon_prev; // pedestrians keep goal_idx in the second controller row
+        if (!TAB) { // the table variant never touches the controller state of lanes it does not own
+            cs.speed = fld(dy, SG_F_CTRL + 0); cs.e_lon_prev = fld(dy, SG_F_CTRL + 1);
+            cs.e_lat_prev = fld(dy, SG_F_CTRL + 2); cs.e_lon_int = fld(dy, SG_F_CTRL + 3);
+        }
+        goal_idx = PED ? (int)cs.e_lon_prev : 0; // pedestrians keep goal_idx in the second controller row
         m_avg = sd.ego_avg_speed; m_max = sd.ego_max_speed; m_t = sd.avg_t;
 #pragma unroll
         for (int w = 0; w < WV; ++w) last_row[w] = sd.last_row[w];
         n_ev = sd.n_events;
         done = sd.done;
         steps = sd.n_steps;
-        sg_sincos(pose[3], sin_h, cos_h);
         if (PED) { // the neighbour candidates (and LDS positions) of the current state
             uint64_t tmp_rows[WV];
-            tile_collisions<G, WV, PED>(present, pose, velx, vely, sin_h, cos_h, bcx, bcy, rad_thr, nbr_thr,
+            tile_collisions<G, WV, PED>(present, pose, velx, vely, bcx, bcy, rad_thr, trig_eps, nbr_thr,
                                         cell_inv, is_ped_type, sl, tile0, lds, tmp_rows, mult_rows, nbr);
         }
 #pragma unroll
@@ -1223,15 +1338,52 @@ __global__ __launch_bounds__(64 * WV, PED ? 1 : SG_WAVES_PER_SIMD) void rollout_
         seg_load(T, S);
     }
 
-    for (int k = 0; k < n_steps; ++k) {
+    // controller table row of the coming step in the controlled lanes' registers
+    double tb_x = 0.0, tb_y = 0.0, tb_h = 0.0;
+    auto tab_commit = [&]() {
+#pragma unroll
+        for (int j = 0; j < TL; ++j) { // wave-uniform values into one lane: v_cmp + v_cndmask with scalar sources
+            const bool me = lane == cl[j];
+            tb_x = me ? sx[j] : tb_x;
+            tb_y = me ? sy[j] : tb_y;
+            tb_h = me ? sh[j] : tb_h;
+        }
+    };
+    if (TAB && n_steps > 0) {
+        tab_issue(0);
+        tab_commit();
+    }
+
+    // Two nested loops over the same step counter.  The inner one is the steady state and only READS the knot
+    // segment S; when some lane's clock is about to cross a knot the wavefront drops to the outer loop, which
+    // advances that lane's segment and re-enters.  With the conditional update inside a single loop the compiler
+    // keeps two copies of S (28 VGPRs) and moves one onto the other on every step.
+    int k = 0;
+    bool all_done = false;
+    sg_loads_done(); // everything loaded so far is in its registers before the first store is issued
+    sg_lgkm_done();
+    while (k < n_steps && !all_done) {
+    if (t + timestep > S.x_hi) { // rare: next knot segment
+        // opaque copies keep the table address arithmetic inside this branch (otherwise ~15 invariant
+        // 64-bit row addresses are hoisted out of the time loop and held in VGPRs / spilled)
+        int kind_o = kind, slot_o = slot;
+        LanePtr st_o = st;
+        asm volatile("" : "+v"(kind_o), "+v"(slot_o), "+v"(st_o.a[0]));
+        Table T = lane_table(p, kind_o, ss, slot_o, st_o);
+        seg_advance(T, S, t + timestep);
+        sg_loads_done();
+    }
+    for (; k < n_steps; ++k) {
+        // per wavefront and before any workgroup barrier of the step: does a lane need its next segment?
+        if (__any(t + timestep > S.x_hi)) break;
         const bool run = in_range && (force || !done);
-        if (!block_any<WV>(run)) break;
+        if (!block_any<WV>(run)) { all_done = true; break; }
+        const double cx_ = tb_x, cy_ = tb_y, ch_ = tb_h;
+        if (TAB) tab_issue(k + 1 < n_steps ? k + 1 : k); // consumed by tab_commit() at the end of this step
         // coefficient table: opaque per step so the scalar loads stay inside the loop (SGPRs for a few
         // dozen instructions instead of VGPRs for the whole kernel); constant address space => s_load
         const double *Kp = SG_TRIG;
-#ifndef SG_HOIST_TRIG
-        asm volatile("" : "+s"(Kp));
-#endif
+        if (!TAB) asm volatile("" : "+s"(Kp));
         ConstTbl K = (ConstTbl)Kp;
 
         const double next_t = t + timestep; // scenario_gym.py:229
@@ -1239,19 +1391,10 @@ __global__ __launch_bounds__(64 * WV, PED ? 1 : SG_WAVES_PER_SIMD) void rollout_
         const double dt = next_t - t;       // = State.dt after this step
         // external actions are the only global loads of a steady-state step: issue them first
         double act_a = 0.0, act_s = 0.0;
-        if (kind == SG_KIND_AGENT_VEHICLE && actions) {
+        if (!TAB && kind == SG_KIND_AGENT_VEHICLE && actions) {
             const double *a = actions + ((size_t)k * p.R + r) * 2;
             act_a = a[0];
             act_s = a[1];
-        }
-        if (next_t > S.x_hi) { // rare: next knot segment
-            // opaque copies keep the table address arithmetic inside this branch (otherwise ~15 invariant
-            // 64-bit row addresses are hoisted out of the time loop and held in VGPRs / spilled)
-            int kind_o = kind, slot_o = slot;
-            LanePtr st_o = st;
-            asm volatile("" : "+v"(kind_o), "+v"(slot_o), "+v"(st_o.a[0]));
-            Table T = lane_table(p, kind_o, ss, slot_o, st_o);
-            seg_advance(T, S, next_t);
         }
         double np_[6];
         {
@@ -1268,16 +1411,25 @@ __global__ __launch_bounds__(64 * WV, PED ? 1 : SG_WAVES_PER_SIMD) void rollout_
         } else if (is_agent) {
             if (present) {
                 npres = true;
-                if (kind != SG_KIND_AGENT_REPLAY && run) {
+                if (TAB) {
+                    if (tab_lane && run) { // integrated by control_kernel: z, p, r stay (controller.py:126-131)
+#pragma unroll
+                        for (int c = 0; c < 6; ++c) np_[c] = pose[c];
+                        np_[0] = cx_; np_[1] = cy_; np_[3] = ch_;
+                    }
+                } else if (kind != SG_KIND_AGENT_REPLAY && run) {
                     const double tx = np_[0], ty = np_[1];
 #pragma unroll
                     for (int c = 0; c < 6; ++c) np_[c] = pose[c];
-                    const double bl = lds.boxwl[1][sl];
-                    if (kind == SG_KIND_AGENT_PID)
-                        pid_step(cs, lds, sl, bl, state_dt, dt, tx, ty, sin_h, cos_h, np_, K);
-                    else if (kind == SG_KIND_AGENT_VEHICLE)
-                        vehicle_step(cs, lds, sl, bl, dt, act_a, act_s, sin_h, cos_h, np_, K);
-                    else if (PED)
+                    if (kind == SG_KIND_AGENT_PID || kind == SG_KIND_AGENT_VEHICLE) {
+                        const double bl = lds.boxwl[1][sl];
+                        double sin_h, cos_h; // of the current heading
+                        sg_sincos(pose[3], sin_h, cos_h, K);
+                        if (kind == SG_KIND_AGENT_PID)
+                            pid_step(cs, lds, sl, bl, state_dt, dt, tx, ty, sin_h, cos_h, np_, K);
+                        else
+                            vehicle_step(cs, lds, sl, bl, dt, act_a, act_s, sin_h, cos_h, np_, K);
+                    } else if (PED)
                         ped_step<WV>(p, lds, sl, tile0, nbr, pose, velx, vely, t, next_t, state_dt, wp, nwp, goal_idx,
                                      cs.speed, fpx, fpy, np_, K);
                 }
@@ -1327,7 +1479,9 @@ __global__ __launch_bounds__(64 * WV, PED ? 1 : SG_WAVES_PER_SIMD) void rollout_
             prev_t = t;
             t = next_t;
             ++steps;
+            last_k = k;
             // ---- step-materialised state (everything except the collision row, see below) ----
+#ifndef SG_ABL_NO_STORES
 #pragma unroll
             for (int c = 0; c < 6; ++c) stf(dy, SG_F_POSE + c, pose[c]);
             if (present) {
@@ -1336,6 +1490,14 @@ __global__ __launch_bounds__(64 * WV, PED ? 1 : SG_WAVES_PER_SIMD) void rollout_
             }
             stf(dy, SG_F_DIST, dist);
             stf(dy, SG_F_PRESENT, (uint64_t)present);
+#else
+            if (k == n_steps - 1 || (steps & 1023) == 0) { // timing ablation only: keep the values live
+#pragma unroll
+                for (int c = 0; c < 6; ++c) { stf(dy, SG_F_POSE + c, pose[c]); stf(dy, SG_F_VEL + c, vel[c]); }
+                stf(dy, SG_F_DIST, dist);
+                stf(dy, SG_F_PRESENT, (uint64_t)present);
+            }
+#endif
             if (PED && kind == SG_KIND_AGENT_PEDESTRIAN) {
                 stf(dy, SG_F_FORCE + 0, fpx);
                 stf(dy, SG_F_FORCE + 1, fpy);
@@ -1356,17 +1518,13 @@ __global__ __launch_bounds__(64 * WV, PED ? 1 : SG_WAVES_PER_SIMD) void rollout_
                 m_max = __builtin_fmax(speed, m_max); // EgoMaxSpeed, :41-44
             }
         }
-#ifndef SG_ABL_NO_SINCOS
-        sg_sincos(pose[3], sin_h, cos_h, K);
-#endif
-
         // ---- State.collisions ----
         uint64_t nrow[WV];
 #ifdef SG_ABL_NO_COLL
 #pragma unroll
         for (int w = 0; w < WV; ++w) nrow[w] = 0;
 #else
-        tile_collisions<G, WV, PED>(present, pose, velx, vely, sin_h, cos_h, bcx, bcy, rad_thr, nbr_thr, cell_inv, is_ped_type,
+        tile_collisions<G, WV, PED>(present, pose, velx, vely, bcx, bcy, rad_thr, trig_eps, nbr_thr, cell_inv, is_ped_type,
                                     sl, tile0, lds, nrow, mult_rows, nbr);
 #endif
         if (run) {
@@ -1438,13 +1596,26 @@ __global__ __launch_bounds__(64 * WV, PED ? 1 : SG_WAVES_PER_SIMD) void rollout_
                 last_row[w] = row[w];
             }
         }
+        if (TAB) {
+            tab_commit();
+            sg_lgkm_done();
+        }
+    }
     }
 
     // ---- write back what lives in registers during the loop ----
     if (in_range) {
         if (PED && kind == SG_KIND_AGENT_PEDESTRIAN) cs.e_lon_prev = (double)goal_idx;
-        stf(dy, SG_F_CTRL + 0, cs.speed); stf(dy, SG_F_CTRL + 1, cs.e_lon_prev);
-        stf(dy, SG_F_CTRL + 2, cs.e_lat_prev); stf(dy, SG_F_CTRL + 3, cs.e_lon_int);
+        if (TAB) {
+            if (tab_lane && last_k >= 0) { // controller state after the last executed step
+                const double *lr = tab + ctl_q + (size_t)last_k * tab_row;
+                stf(dy, SG_F_CTRL + 0, lr[CT_SPEED * tab_np]); stf(dy, SG_F_CTRL + 1, lr[CT_ELON * tab_np]);
+                stf(dy, SG_F_CTRL + 2, lr[CT_ELAT * tab_np]); stf(dy, SG_F_CTRL + 3, lr[CT_EINT * tab_np]);
+            }
+        } else {
+            stf(dy, SG_F_CTRL + 0, cs.speed); stf(dy, SG_F_CTRL + 1, cs.e_lon_prev);
+            stf(dy, SG_F_CTRL + 2, cs.e_lat_prev); stf(dy, SG_F_CTRL + 3, cs.e_lon_int);
+        }
         if (slot == 0) { sd.t = t; sd.prev_t = prev_t; sd.done = done; sd.n_steps = steps; }
         if (is_ego) {
             sd.ego_avg_speed = m_avg; sd.ego_max_speed = m_max; sd.avg_t = m_t;
@@ -1454,6 +1625,141 @@ __global__ __launch_bounds__(64 * WV, PED ? 1 : SG_WAVES_PER_SIMD) void rollout_
             sd.n_events = n_ev;
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Controller pre-pass.  A PIDAgent / external-action VehicleController lane never looks at another
+// entity (agent.py:131-148, controller.py:105-140, 205-258: own trajectory, own pose, own controller
+// state), so the controlled lanes of the whole batch are gathered 64 to a wavefront and integrated
+// here for a chunk of steps; rollout_kernel<.., TAB> then replays the table.  Inside rollout_kernel
+// the same work would occupy a full wavefront instruction stream for 1 active lane in 64.
+// The step arithmetic is the rollout kernel's own (same device functions, same clock recurrence), so
+// both paths produce identical bits.  The lane assumes its scenario keeps running; a scenario that
+// terminates early simply stops consuming the table.
+//   first: take the lane state from the state blocks (start of an API call); otherwise from
+//          p.ctl_state (previous chunk of the same call).   k0: step offset into `actions`.
+// ------------------------------------------------------------------------------------------------
+struct CtlLds { double ctrl[9][64]; };
+
+__global__ __launch_bounds__(64) void control_kernel(Params p, double timestep, int n_steps, int first, int k0,
+                                                     const double *actions /*[n][R][2]*/, double *tab)
+{
+    __shared__ CtlLds lds;
+    const int lane = threadIdx.x;
+    const size_t q = (size_t)blockIdx.x * 64 + lane;
+    const int ent_raw = p.ctl_ent[q];
+    const bool active = ent_raw >= 0;
+    const uint32_t ent = active ? (uint32_t)ent_raw : 0u;
+    const uint32_t r = ent / (uint32_t)p.EP;
+    const LanePtr st(p.stat + (size_t)(ent >> 6) * (ST_COUNT * 64), (ent & 63) * 8u);
+    const LanePtr dy(p.dyn + (size_t)(ent >> 6) * ((size_t)p.FROWS * 64), (ent & 63) * 8u);
+    const int64_t meta = fld<int64_t>(st, ST_META);
+    const int kind = active ? (int)(meta & 0xff) : SG_KIND_NONE;
+    const double min_t = fld(st, ST_MIN_T), bl = fld(st, ST_BL);
+#pragma unroll
+    for (int c = 0; c < 9; ++c) lds.ctrl[c][lane] = fld(st, ST_CTRL + c); // own column only: no barrier needed
+    const size_t NP = (size_t)p.n_ctl_pad;
+    double *cst = p.ctl_state + q;
+
+    double pose[6], t, prev_t;
+    bool present;
+    CtrlState cs;
+    if (first) {
+        const sg_scenario_state &sd = p.sdyn[r];
+        t = sd.t;
+        prev_t = sd.prev_t;
+        present = fld<uint64_t>(dy, SG_F_PRESENT) != 0;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) pose[c] = fld(dy, SG_F_POSE + c);
+        cs.speed = fld(dy, SG_F_CTRL + 0); cs.e_lon_prev = fld(dy, SG_F_CTRL + 1);
+        cs.e_lat_prev = fld(dy, SG_F_CTRL + 2); cs.e_lon_int = fld(dy, SG_F_CTRL + 3);
+    } else {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) pose[c] = cst[(CS_POSE + c) * NP];
+        present = cst[CS_PRESENT * NP] != 0.0;
+        cs.speed = cst[(CS_CTRL + 0) * NP]; cs.e_lon_prev = cst[(CS_CTRL + 1) * NP];
+        cs.e_lat_prev = cst[(CS_CTRL + 2) * NP]; cs.e_lon_int = cst[(CS_CTRL + 3) * NP];
+        t = cst[CS_T * NP];
+        prev_t = cst[CS_PREV_T * NP];
+    }
+    if (!active) present = false;
+
+    Table T; // the lane's own knots (PIDAgent target, agent.py:145-148; spawn pose, scenario_gym.py:240-244)
+    {
+        const double *kn = p.knots + fld<int64_t>(st, ST_KNOT_OFF) * 7;
+        T.x = kn; T.xs = 7; T.y = kn + 1; T.ys = 7; T.cs = 1;
+        T.n = active ? (int)(meta >> 32) : 0;
+    }
+    Segment S;
+    S.cur = seg_locate(T, t);
+    seg_load(T, S);
+    double *out = tab + q;
+    sg_loads_done();
+
+    for (int k = 0; k < n_steps; ++k) {
+        const double *Kp = SG_TRIG;
+        asm volatile("" : "+s"(Kp));
+        ConstTbl K = (ConstTbl)Kp;
+        const double next_t = t + timestep; // the rollout kernel's clock, scenario_gym.py:229
+        const double state_dt = t - prev_t;
+        const double dt = next_t - t;
+        double act_a = 0.0, act_s = 0.0;
+        if (kind == SG_KIND_AGENT_VEHICLE && actions) {
+            const double *a = actions + ((size_t)(k0 + k) * p.R + r) * 2;
+            act_a = a[0];
+            act_s = a[1];
+        }
+        if (next_t > S.x_hi) {
+            seg_advance(T, S, next_t);
+            sg_loads_done();
+        }
+        double np_[6];
+        {
+            double dq = next_t - S.x_lo;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) np_[c] = S.sl[c] * dq + S.ylo[c];
+        }
+        bool npres = false;
+        if (present) {
+            npres = true;
+            const double tx = np_[0], ty = np_[1];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) np_[c] = pose[c];
+            double sin_h, cos_h;
+            sg_sincos(pose[3], sin_h, cos_h, K);
+            if (kind == SG_KIND_AGENT_PID)
+                pid_step(cs, lds, lane, bl, state_dt, dt, tx, ty, sin_h, cos_h, np_, K);
+            else
+                vehicle_step(cs, lds, lane, bl, dt, act_a, act_s, sin_h, cos_h, np_, K);
+        } else if (active && min_t >= t) { // spawn at the trajectory position
+            npres = true;
+        }
+        present = npres;
+        if (npres) {
+#pragma unroll
+            for (int c = 0; c < 6; ++c) pose[c] = np_[c];
+        }
+        prev_t = t;
+        t = next_t;
+        double *o = out + (size_t)k * CT_COUNT * NP;
+        o[CT_X * NP] = pose[0]; o[CT_Y * NP] = pose[1]; o[CT_H * NP] = pose[3];
+        o[CT_SPEED * NP] = cs.speed; o[CT_ELON * NP] = cs.e_lon_prev;
+        o[CT_ELAT * NP] = cs.e_lat_prev; o[CT_EINT * NP] = cs.e_lon_int;
+    }
+#pragma unroll
+    for (int c = 0; c < 6; ++c) cst[(CS_POSE + c) * NP] = pose[c];
+    cst[CS_PRESENT * NP] = present ? 1.0 : 0.0;
+    cst[(CS_CTRL + 0) * NP] = cs.speed; cst[(CS_CTRL + 1) * NP] = cs.e_lon_prev;
+    cst[(CS_CTRL + 2) * NP] = cs.e_lat_prev; cst[(CS_CTRL + 3) * NP] = cs.e_lon_int;
+    cst[CS_T * NP] = t;
+    cst[CS_PREV_T * NP] = prev_t;
+}
+
+// sg_debug_trig32: the broad phase's hardware sin/cos, exposed so that the parity tests can bound its error
+__global__ void trig32_kernel(const double *h, float *s, float *c, int64_t n)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) sg_sincos_f32(h[i], s[i], c[i]);
 }
 
 } // namespace sg

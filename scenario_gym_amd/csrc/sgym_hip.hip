@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -33,8 +34,24 @@ struct sg_handle {
     int64_t total_rows = 0;
     double *d_actions = nullptr;
     size_t actions_cap = 0;
+    // controller pre-pass (sg::control_kernel): controlled lanes of the batch, its own stream, two table buffers
+    int n_ctl = 0;
+    int max_ctl_per_block = 0; // controlled lanes in the fullest 64-slot block
+    hipStream_t ctl_stream = nullptr;
+    double *d_tab[2] = {nullptr, nullptr};
+    size_t tab_cap = 0; // doubles per buffer
+    std::vector<hipEvent_t> ev_pool;
+    int tab_min = 16, chunk_steps = 1024, overlap = 1; // sg_set_tuning
+    int n_launches = 0;           // rollout_kernel launches of the last call
+    std::vector<int> launch_ev;   // their (start, stop) event indices into ev_pool
     std::string err;
 };
+
+static int env_int(const char *name, int dflt)
+{
+    const char *v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
 
 static thread_local std::string g_create_err;
 
@@ -123,7 +140,11 @@ extern "C" int sg_create(const sg_config *cfg, sg_handle **out)
     // SocialForceParameters defaults, pedestrian/social_force.py:16-30 (noise off)
     h->sf = sg_social_force{1.5, 1.0, 1.0, 0.0, 0.5, 1.0, std::cos(200.0 / 2 * M_PI / 180), 1.3, 0.0, 0.0, {0.0, 0.0}};
     h->NE = (((size_t)h->R * h->EP + 63) / 64) * 64;
+    h->tab_min = env_int("SG_TAB_MIN_STEPS", h->tab_min);
+    h->chunk_steps = env_int("SG_CHUNK_STEPS", h->chunk_steps);
+    h->overlap = env_int("SG_OVERLAP", h->overlap);
     if (hipSetDevice(cfg->device) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess ||
+        hipStreamCreate(&h->ctl_stream) != hipSuccess ||
         hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {
         delete h;
         return fail(nullptr, SG_ERR_HIP, "sg_create: stream/event creation failed");
@@ -139,8 +160,13 @@ extern "C" int sg_destroy(sg_handle *h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     free_pool(h->static_allocs);
     free_pool(h->state_allocs);
+    if (h->ctl_stream) (void)hipStreamSynchronize(h->ctl_stream);
     if (h->d_actions) (void)hipFree(h->d_actions);
     if (h->d_gon) (void)hipFree(h->d_gon);
+    for (int b = 0; b < 2; ++b)
+        if (h->d_tab[b]) (void)hipFree(h->d_tab[b]);
+    for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
+    if (h->ctl_stream) (void)hipStreamDestroy(h->ctl_stream);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -154,29 +180,127 @@ static const double kDefaultCtrl[SG_NCTRL] = {0.7, 5.0, NAN, 0.0, 0.03054, 1.570
                                               0.0, 5.0, 0.0, 1.0, 0, 0, 0};
 
 template <int G, int WV>
-static void launch_variant(sg_handle *h, dim3 grid, int n_steps, int do_reset, int force, const double *d_actions)
+static void launch_variant(sg_handle *h, dim3 grid, int n_steps, int do_reset, int force, const double *d_actions,
+                           const double *d_tab, bool use_tab)
 {
     dim3 block(64 * WV);
     if (h->has_ped)
-        sg::rollout_kernel<(WV > 1 || G >= 16) ? G : 16, WV, true><<<grid, block, 0, h->stream>>>(h->p, h->cfg.timestep, n_steps, do_reset, force, d_actions);
+        sg::rollout_kernel<(WV > 1 || G >= 16) ? G : 16, WV, true, false><<<grid, block, 0, h->stream>>>(
+            h->p, h->cfg.timestep, n_steps, do_reset, force, d_actions, nullptr);
+    else if (use_tab)
+        sg::rollout_kernel<G, WV, false, true><<<grid, block, 0, h->stream>>>(h->p, h->cfg.timestep, n_steps, 0, force,
+                                                                               nullptr, d_tab);
     else
-        sg::rollout_kernel<G, WV, false><<<grid, block, 0, h->stream>>>(h->p, h->cfg.timestep, n_steps, do_reset, force, d_actions);
+        sg::rollout_kernel<G, WV, false, false><<<grid, block, 0, h->stream>>>(h->p, h->cfg.timestep, n_steps, do_reset,
+                                                                                force, d_actions, nullptr);
 }
 
-static int launch_rollout(sg_handle *h, int n_steps, int do_reset, int force, const double *d_actions)
+static int get_event(sg_handle *h, size_t idx, hipEvent_t *out)
+{
+    while (h->ev_pool.size() <= idx) {
+        hipEvent_t e;
+        HIP_TRY(h, hipEventCreate(&e));
+        h->ev_pool.push_back(e);
+    }
+    *out = h->ev_pool[idx];
+    return SG_OK;
+}
+
+// one rollout_kernel launch on the handle's stream, bracketed by its own pair of timing events
+static int launch_main(sg_handle *h, int n_steps, int do_reset, int force, const double *d_actions, const double *d_tab,
+                       bool use_tab, size_t *ev_next)
 {
     dim3 grid(h->WV == 1 ? (unsigned)(h->NE / 64) : (unsigned)h->R);
-    HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
-    if (h->WV == 4) launch_variant<64, 4>(h, grid, n_steps, do_reset, force, d_actions);
-    else if (h->WV == 2) launch_variant<64, 2>(h, grid, n_steps, do_reset, force, d_actions);
+    hipEvent_t e0, e1;
+    int rc;
+    if ((rc = get_event(h, *ev_next, &e0)) || (rc = get_event(h, *ev_next + 1, &e1))) return rc;
+    HIP_TRY(h, hipEventRecord(e0, h->stream));
+    if (h->WV == 4) launch_variant<64, 4>(h, grid, n_steps, do_reset, force, d_actions, d_tab, use_tab);
+    else if (h->WV == 2) launch_variant<64, 2>(h, grid, n_steps, do_reset, force, d_actions, d_tab, use_tab);
     else switch (h->G) {
-    case 4: launch_variant<4, 1>(h, grid, n_steps, do_reset, force, d_actions); break;
-    case 8: launch_variant<8, 1>(h, grid, n_steps, do_reset, force, d_actions); break;
-    case 16: launch_variant<16, 1>(h, grid, n_steps, do_reset, force, d_actions); break;
-    case 32: launch_variant<32, 1>(h, grid, n_steps, do_reset, force, d_actions); break;
-    default: launch_variant<64, 1>(h, grid, n_steps, do_reset, force, d_actions); break;
+    case 4: launch_variant<4, 1>(h, grid, n_steps, do_reset, force, d_actions, d_tab, use_tab); break;
+    case 8: launch_variant<8, 1>(h, grid, n_steps, do_reset, force, d_actions, d_tab, use_tab); break;
+    case 16: launch_variant<16, 1>(h, grid, n_steps, do_reset, force, d_actions, d_tab, use_tab); break;
+    case 32: launch_variant<32, 1>(h, grid, n_steps, do_reset, force, d_actions, d_tab, use_tab); break;
+    default: launch_variant<64, 1>(h, grid, n_steps, do_reset, force, d_actions, d_tab, use_tab); break;
     }
     HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipEventRecord(e1, h->stream));
+    if (n_steps > 0) { // reset-only launches are not counted as hot-path launches
+        h->launch_ev.push_back((int)*ev_next);
+        ++h->n_launches;
+    }
+    *ev_next += 2;
+    return SG_OK;
+}
+
+// ScenarioGym.rollout / n x step for the whole batch.  Scenarios without pedestrians and with at least
+// SG_TAB_MIN_STEPS steps to do take the two-kernel path: control_kernel integrates the PID / vehicle agents
+// for a chunk of steps on its own stream while rollout_kernel<TAB> consumes the previous chunk's table.
+static int launch_rollout(sg_handle *h, int n_steps, int do_reset, int force, const double *d_actions)
+{
+    const int tab_min = h->tab_min, chunk_steps = std::max(1, h->chunk_steps), no_overlap = !h->overlap;
+    h->n_launches = 0;
+    h->launch_ev.clear();
+    size_t ev_next = 0;
+    HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
+    // the table variant serves SG_TAB_LANES controlled lanes per wavefront; denser batches keep their controllers
+    // in the rollout kernel, where they fill the wavefront anyway
+    const bool use_tab = !h->has_ped && n_steps >= tab_min && h->max_ctl_per_block <= SG_TAB_LANES(h->G, h->WV);
+    int rc = SG_OK;
+    if (!use_tab) {
+        rc = launch_main(h, n_steps, do_reset, force, d_actions, nullptr, false, &ev_next);
+    } else {
+        if (do_reset && (rc = launch_main(h, 0, 1, 0, nullptr, nullptr, false, &ev_next))) return rc;
+        if (h->n_ctl == 0) { // nothing to integrate: the table variant reads (and ignores) one dummy row
+            if (!h->d_tab[0]) {
+                HIP_TRY(h, hipMalloc((void **)&h->d_tab[0], 64 * sizeof(double)));
+                HIP_TRY(h, hipMemsetAsync(h->d_tab[0], 0, 64 * sizeof(double), h->stream));
+                h->tab_cap = 64;
+            }
+            rc = launch_main(h, n_steps, 0, force, nullptr, h->d_tab[0], true, &ev_next);
+        } else {
+            const size_t np = (size_t)h->p.n_ctl_pad, row = (size_t)sg::CT_COUNT * np;
+            // chunk length: SG_CHUNK_STEPS, capped so that one table buffer stays under 1 GiB
+            int ch = (int)std::min<size_t>((size_t)chunk_steps, std::max<size_t>(1, ((size_t)1 << 27) / row));
+            ch = std::min(ch, n_steps);
+            if ((size_t)ch * row > h->tab_cap) {
+                HIP_TRY(h, hipStreamSynchronize(h->stream));
+                HIP_TRY(h, hipStreamSynchronize(h->ctl_stream));
+                for (int b = 0; b < 2; ++b) {
+                    if (h->d_tab[b]) HIP_TRY(h, hipFree(h->d_tab[b]));
+                    h->d_tab[b] = nullptr;
+                }
+                for (int b = 0; b < 2; ++b) HIP_TRY(h, hipMalloc((void **)&h->d_tab[b], (size_t)ch * row * sizeof(double)));
+                h->tab_cap = (size_t)ch * row;
+            }
+            hipStream_t cs = no_overlap ? h->stream : h->ctl_stream;
+            hipEvent_t e;
+            if (!no_overlap) { // the controller stream starts after everything queued so far (reset, uploads)
+                if ((rc = get_event(h, ev_next++, &e))) return rc;
+                HIP_TRY(h, hipEventRecord(e, h->stream));
+                HIP_TRY(h, hipStreamWaitEvent(cs, e, 0));
+            }
+            std::vector<hipEvent_t> main_done;
+            const dim3 cgrid((unsigned)(np / 64)), cblock(64);
+            int c = 0;
+            for (int k0 = 0; k0 < n_steps; k0 += ch, ++c) {
+                const int n = std::min(ch, n_steps - k0);
+                double *tab = h->d_tab[c & 1];
+                if (!no_overlap && c >= 2) HIP_TRY(h, hipStreamWaitEvent(cs, main_done[c - 2], 0)); // table buffer free
+                sg::control_kernel<<<cgrid, cblock, 0, cs>>>(h->p, h->cfg.timestep, n, c == 0, k0, d_actions, tab);
+                HIP_TRY(h, hipGetLastError());
+                if (!no_overlap) {
+                    if ((rc = get_event(h, ev_next++, &e))) return rc;
+                    HIP_TRY(h, hipEventRecord(e, cs));
+                    HIP_TRY(h, hipStreamWaitEvent(h->stream, e, 0));
+                }
+                if ((rc = launch_main(h, n, 0, force, nullptr, tab, true, &ev_next))) return rc;
+                main_done.push_back(h->ev_pool[ev_next - 1]);
+            }
+        }
+    }
+    if (rc) return rc;
     HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
     h->timed = true;
     return SG_OK;
@@ -197,6 +321,7 @@ extern "C" int sg_upload(sg_handle *h, const sg_scenarios *sc)
         return fail(h, SG_ERR_INVALID, "sg_upload: null array in sg_scenarios");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->ctl_stream));
     free_pool(h->static_allocs);
     free_pool(h->state_allocs);
     h->uploaded = false;
@@ -217,7 +342,9 @@ extern "C" int sg_upload(sg_handle *h, const sg_scenarios *sc)
         for (int q = 0; q < 4; ++q) S(o, sg::ST_BW + q) = 1.0;
         for (int q = 0; q < sg::NCTRL_ROWS; ++q) S(o, sg::ST_CTRL + q) = kDefaultCtrl[q];
         SI(o, sg::ST_META) = SG_KIND_NONE | (2 << 8);
+        SI(o, sg::ST_CTL) = -1;
     }
+    std::vector<int32_t> ctl_ent; // controlled lanes (PID / vehicle agents) in entity order
     std::vector<sg::ScenStatic> sstat(R);
     const int64_t rows_total = sc->knot_off[(size_t)R * E];
     for (int r = 0; r < R; ++r) {
@@ -238,6 +365,10 @@ extern "C" int sg_upload(sg_handle *h, const sg_scenarios *sc)
             if (a < 0 || b < a || b > rows_total) return fail(h, SG_ERR_INVALID, "sg_upload: knot_off not monotone at %zu", i);
             if (k != SG_KIND_NONE && b == a) return fail(h, SG_ERR_INVALID, "sg_upload: entity %zu has no knots", i);
             SI(o, sg::ST_META) = (int64_t)k | ((int64_t)(sc->etype[i] & 0xff) << 8) | ((int64_t)(b - a) << 32);
+            if (k == SG_KIND_AGENT_PID || k == SG_KIND_AGENT_VEHICLE) {
+                SI(o, sg::ST_CTL) = (int64_t)ctl_ent.size();
+                ctl_ent.push_back((int32_t)o);
+            }
             SI(o, sg::ST_KNOT_OFF) = a;
             for (int q = 0; q < 4; ++q) S(o, sg::ST_BW + q) = sc->bbox[i * 4 + q];
             if (sc->ctrl) for (int q = 0; q < sg::NCTRL_ROWS; ++q) S(o, sg::ST_CTRL + q) = sc->ctrl[i * SG_NCTRL + q];
@@ -326,7 +457,17 @@ extern "C" int sg_upload(sg_handle *h, const sg_scenarios *sc)
         for (int i = 0; i < 64; ++i) { double a = 2.0 * 3.141592653589793 * i / 64; gon[2 * i] = std::cos(a); gon[2 * i + 1] = std::sin(a); }
         if ((rc = dev_upload(h, SA, &p.gon, gon))) return rc;
     }
+    h->n_ctl = (int)ctl_ent.size();
+    h->max_ctl_per_block = 0;
+    for (size_t i = 0, run = 0; i < ctl_ent.size(); ++i) { // ctl_ent is sorted by entity index
+        run = (i > 0 && (ctl_ent[i] >> 6) == (ctl_ent[i - 1] >> 6)) ? run + 1 : 1;
+        h->max_ctl_per_block = std::max(h->max_ctl_per_block, (int)run);
+    }
+    ctl_ent.resize(((ctl_ent.size() + 63) / 64) * 64, -1);
+    p.n_ctl_pad = (int)ctl_ent.size();
+    if ((rc = dev_upload(h, SA, &p.ctl_ent, ctl_ent))) return rc;
     auto &M = h->state_allocs;
+    if ((rc = dev_alloc(h, M, &p.ctl_state, (size_t)sg::CS_COUNT * std::max(p.n_ctl_pad, 1)))) return rc;
     if ((rc = dev_alloc(h, M, &p.dyn, nblk * (size_t)p.FROWS * 64))) return rc;
     if ((rc = dev_alloc(h, M, &p.sdyn, (size_t)R))) return rc;
     if ((rc = dev_alloc(h, M, &p.events, (size_t)R * std::max(p.ev_cap, 1)))) return rc;
@@ -516,5 +657,54 @@ extern "C" int sg_last_kernel_ms(sg_handle *h, float *ms)
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     HIP_TRY(h, hipEventSynchronize(h->ev1));
     HIP_TRY(h, hipEventElapsedTime(ms, h->ev0, h->ev1));
+    return SG_OK;
+}
+
+extern "C" int sg_last_launch_stats(sg_handle *h, int32_t *n_launches, float *kernel_ms_total)
+{
+    if (!h || !n_launches || !kernel_ms_total) return SG_ERR_INVALID;
+    if (!h->timed) return fail(h, SG_ERR_STATE, "sg_last_launch_stats: nothing launched yet");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, hipEventSynchronize(h->ev1));
+    float total = 0.0f;
+    for (int i : h->launch_ev) {
+        float ms = 0.0f;
+        HIP_TRY(h, hipEventElapsedTime(&ms, h->ev_pool[i], h->ev_pool[i + 1]));
+        total += ms;
+    }
+    *n_launches = h->n_launches;
+    *kernel_ms_total = total;
+    return SG_OK;
+}
+
+extern "C" int sg_debug_trig32(sg_handle *h, int64_t n, const double *heading, float *sin_out, float *cos_out)
+{
+    if (!h || n < 0 || !heading || !sin_out || !cos_out) return SG_ERR_INVALID;
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    double *d_h = nullptr;
+    float *d_s = nullptr, *d_c = nullptr;
+    const size_t m = (size_t)std::max<int64_t>(n, 1);
+    HIP_TRY(h, hipMalloc((void **)&d_h, m * sizeof(double)));
+    HIP_TRY(h, hipMalloc((void **)&d_s, m * sizeof(float)));
+    HIP_TRY(h, hipMalloc((void **)&d_c, m * sizeof(float)));
+    int rc = SG_OK;
+    do {
+        if (hipMemcpy(d_h, heading, (size_t)n * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) { rc = SG_ERR_HIP; break; }
+        if (n > 0) sg::trig32_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream>>>(d_h, d_s, d_c, n);
+        if (hipStreamSynchronize(h->stream) != hipSuccess) { rc = SG_ERR_HIP; break; }
+        if (hipMemcpy(sin_out, d_s, (size_t)n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) { rc = SG_ERR_HIP; break; }
+        if (hipMemcpy(cos_out, d_c, (size_t)n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) { rc = SG_ERR_HIP; break; }
+    } while (0);
+    (void)hipFree(d_h); (void)hipFree(d_s); (void)hipFree(d_c);
+    if (rc) return fail(h, rc, "sg_debug_trig32: HIP copy/launch failed");
+    return SG_OK;
+}
+
+extern "C" int sg_set_tuning(sg_handle *h, int32_t tab_min_steps, int32_t chunk_steps, int32_t overlap)
+{
+    if (!h) return SG_ERR_INVALID;
+    if (tab_min_steps >= 0) h->tab_min = tab_min_steps;
+    if (chunk_steps > 0) h->chunk_steps = chunk_steps;
+    if (overlap >= 0) h->overlap = overlap != 0;
     return SG_OK;
 }

@@ -174,6 +174,24 @@ class RolloutEngine:
         self._check(self.lib.sg_last_kernel_ms(self.h, C.byref(ms)), "sg_last_kernel_ms")
         return ms.value
 
+    def set_tuning(self, tab_min_steps=-1, chunk_steps=0, overlap=-1):
+        """Launch policy (sg_set_tuning); results never depend on it."""
+        self._check(self.lib.sg_set_tuning(self.h, int(tab_min_steps), int(chunk_steps), int(overlap)), "sg_set_tuning")
+
+    def last_launch_stats(self):
+        """(number of rollout-kernel launches of the last call, sum of their durations in ms)."""
+        n, ms = C.c_int32(), C.c_float()
+        self._check(self.lib.sg_last_launch_stats(self.h, C.byref(n), C.byref(ms)), "sg_last_launch_stats")
+        return n.value, ms.value
+
+    def debug_trig32(self, heading):
+        """The broad phase's fp32 (sin, cos) of fp64 headings (test hook)."""
+        h = np.ascontiguousarray(heading, np.float64).ravel()
+        s, c = np.empty(h.size, np.float32), np.empty(h.size, np.float32)
+        self._check(self.lib.sg_debug_trig32(self.h, h.size, h.ctypes.data, s.ctypes.data, c.ctypes.data),
+                    "sg_debug_trig32")
+        return s, c
+
     # ------------------------------------------------------------------ reads
     def _d2h(self, ptr, shape, dtype):
         out = np.empty(shape, dtype)

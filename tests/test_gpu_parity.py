@@ -24,10 +24,12 @@ def sga():
     return sga
 
 
-def _engine_run(sga, packed, dt, n_max, persist=False, terminal=None, actions=None, ev_cap=64):
+def _engine_run(sga, packed, dt, n_max, persist=False, terminal=None, actions=None, ev_cap=64, tuning=None):
     """reset + rollout with full recording; returns per-scenario results shaped like the goldens."""
     eng = sga.RolloutEngine(packed.n_scenarios, packed.n_entities, timestep=dt, persist=persist,
                             terminal_conditions=terminal, record_capacity=n_max + 1, event_capacity=ev_cap)
+    if tuning is not None:
+        eng.set_tuning(**tuning)
     eng.upload(packed)
     if actions is None:
         eng.rollout(n_max)
@@ -569,4 +571,78 @@ def test_abi_rejects_bad_input(sga):
     assert eng.state()["done"].all()
     with pytest.raises(RuntimeError, match="record_capacity"):
         eng.record(5)
+    eng.close()
+
+
+# --------------------------------------------------------------------------- launch policy / fp32 trig
+INLINE = dict(tab_min_steps=1 << 30)                       # controllers inside the rollout kernel
+TABLE_SMALL_CHUNKS = dict(tab_min_steps=1, chunk_steps=7)  # controller pre-pass, many chunk boundaries, 2 streams
+TABLE_SERIAL = dict(tab_min_steps=1, chunk_steps=64, overlap=0)
+
+
+@pytest.mark.parametrize("ego_kind,terminal", [("pid", None), ("vehicle", None), ("pid", ["max_length", "ego_collision"])])
+def test_controller_prepass_equals_inline_controllers(sga, ego_kind, terminal):
+    """control_kernel + rollout_kernel<TAB> (any chunking, with or without stream overlap) produce the bits of the
+    single-kernel path: poses of every step, final state, controller state, metrics, events."""
+    import scenario_gym_amd._lib as L
+    from scenario_gym_amd import synthetic
+
+    R, E, steps = 96, 24, 150
+    kind = dict(pid=L.KIND_AGENT_PID, vehicle=L.KIND_AGENT_VEHICLE)[ego_kind]
+    packed = synthetic.make_batch(R, E, n_steps=steps, ego_kind=kind, static_frac=0.15, vanish_frac=0.2, extent=25.0)
+    acts = synthetic.make_actions(steps, R) if ego_kind == "vehicle" else None
+    runs = [_engine_run(sga, packed, 1 / 30, steps, terminal=terminal, actions=acts, ev_cap=128, tuning=tn)
+            for tn in (INLINE, TABLE_SMALL_CHUNKS, TABLE_SERIAL)]
+    st0, rows0, ev0, t0, poses0 = runs[0]
+    if terminal:
+        assert (rows0["n_steps"] < steps).any() and (rows0["n_steps"] == steps).any()  # some stop early, some do not
+    for st, rows, ev, t, poses in runs[1:]:
+        for k in ("poses", "vels", "dists", "ctrl_state", "t", "prev_t"):
+            assert bits_equal(st[k], st0[k]), k
+        assert np.array_equal(st["coll"], st0["coll"]) and np.array_equal(st["present"], st0["present"])
+        assert rows.tobytes() == rows0.tobytes() and ev.tobytes() == ev0.tobytes()
+        assert bits_equal(t, t0) and bits_equal(poses, poses0)
+
+
+def test_prepass_resumes_from_the_state_blocks(sga):
+    """A rollout that ends early followed by forced steps (gym.step on a done scenario), and a rollout continued in
+    pieces: the controller pre-pass restarts from the device state at every call."""
+    import scenario_gym_amd._lib as L
+    from scenario_gym_amd import synthetic
+
+    R, E, steps = 64, 16, 120
+    packed = synthetic.make_batch(R, E, n_steps=steps, ego_kind=L.KIND_AGENT_PID, extent=20.0)
+    out = []
+    for tn in (INLINE, TABLE_SMALL_CHUNKS):
+        eng = sga.RolloutEngine(R, E, terminal_conditions=["max_length", "ego_collision"], event_capacity=64)
+        eng.set_tuning(**tn)
+        eng.upload(packed)
+        eng.rollout(60)
+        eng.rollout_async(30, do_reset=False)   # continue the unfinished scenarios
+        eng.step(25)                            # then force everybody
+        st = eng.state()
+        rows, ev = eng.metrics()
+        eng.close()
+        out.append((st, rows, ev))
+    (a, ra, ea), (b, rb, eb) = out
+    assert len(set(ra["n_steps"].tolist())) > 1
+    for k in ("poses", "vels", "dists", "ctrl_state", "t"):
+        assert bits_equal(a[k], b[k]), k
+    assert np.array_equal(a["coll"], b["coll"]) and ra.tobytes() == rb.tobytes() and ea.tobytes() == eb.tobytes()
+
+
+def test_trig32_error_bound(sga):
+    """The hardware sin/cos of the broad phase stays inside SG_TRIG32_ERR (sgym_device.hpp), the bound its
+    conservative margins are built on: dense sweep of one turn, random headings up to 1e5 rad, edge values."""
+    eng = sga.RolloutEngine(1, 4)
+    rng = np.random.default_rng(7)
+    h = np.concatenate([
+        np.linspace(-np.pi, np.pi, 1 << 22), rng.uniform(-40.0, 40.0, 1 << 21), rng.uniform(-1e5, 1e5, 1 << 21),
+        np.arange(-64, 65) * (np.pi / 32), [0.0, -0.0, 1e-300, 99999.999, -99999.999, 1e5, 3e7, -1e12],
+    ])
+    s, c = eng.debug_trig32(h)
+    err = max(np.abs(s - np.sin(h)).max(), np.abs(c - np.cos(h)).max())
+    assert err <= 4.0e-6, err
+    s, c = eng.debug_trig32(np.array([np.nan, np.inf]))
+    assert np.isnan(s).all() and np.isnan(c).all()
     eng.close()

@@ -1,0 +1,27 @@
+#!/bin/bash
+# Usage (GPU box): bash tools/pmc_sq.sh <tag> [bench args...]   -> gpurun_out/<tag>_pmc_sq.txt
+# SQ instruction mix of the rollout kernel per wave-step, summed over all its dispatches of one 2000-step rollout.
+tag=${1:-x}; shift
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" && mkdir -p gpurun_out
+timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_SMEM --output-format csv -d gpurun_out/${tag}_pmc_sq -o p -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline "$@" --steps 1 --warmup 0 --sim-steps 2000 > gpurun_out/${tag}_pmc_sq.log 2>&1
+python3 - "$tag" <<'PY'
+import csv, glob, json, sys, collections
+tag = sys.argv[1]
+line = json.loads([l for l in open(f"gpurun_out/{tag}_pmc_sq.log") if l.startswith("{")][-1])
+cfg = line["config"]
+E = cfg["entities"]
+EP = max(4, 1 << (E - 1).bit_length()) if E <= 64 else (128 if E <= 128 else 256)  # entity stride (tile lanes)
+waves = -(-cfg["scenarios_per_gpu"] * EP // 64)
+f = glob.glob(f"gpurun_out/{tag}_pmc_sq/**/*counter_collection.csv", recursive=True)[0]
+agg = collections.defaultdict(float)
+for r in csv.DictReader(open(f)):
+    k = "rollout" if "rollout_kernel" in r["Kernel_Name"] else ("control" if "control_kernel" in r["Kernel_Name"] else None)
+    if k:
+        agg[(k, r["Counter_Name"])] += float(r["Counter_Value"])
+ws = waves * 2000
+out = {k[1]: round(v / ws, 1) for k, v in agg.items() if k[0] == "rollout"}
+ctl = {k[1]: round(v / 2000, 1) for k, v in agg.items() if k[0] == "control"}
+txt = "rollout_kernel per wave-step (%d waves x 2000 steps; *_CYCLES / ACTIVE / WAIT in quad-cycles): %s\ncontrol_kernel per step, all waves: %s\n" % (waves, out, ctl)
+open(f"gpurun_out/{tag}_pmc_sq.txt", "w").write(txt)
+print(txt)
+PY

@@ -1,45 +1,39 @@
 #!/bin/bash
-# Usage (on the GPU box): bash tools/profile_round.sh <tag>
-# Produces under gpurun_out/: <tag>_kernel_stats.csv (rocprofv3 --kernel-trace --stats of `python3 bench.py`),
-# <tag>_pmc_sq.txt (SQ instruction mix per wave-step) and <tag>_hbm_traffic.json (FETCH_SIZE / WRITE_SIZE passes).
-tag=${1:-r01}
+# Usage (on the GPU box): bash tools/profile_round.sh <tag> [bench args, e.g. --workload c5 --steps 1]
+# Produces under gpurun_out/ (copy what is to be judged into profiles/):
+#   <tag>_bench.json         the plain bench line (no profiler attached)
+#   <tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats of the same command
+#   <tag>_hbm_traffic.json   FETCH_SIZE / WRITE_SIZE (separate --pmc passes), summed over the rollout-kernel
+#                            launches of ONE rollout (a long rollout is cut into chunks of steps)
+#   <tag>_pmc_sq.txt         SQ instruction mix per wave-step (tools/pmc_sq.sh)
+tag=${1:-r01}; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" && mkdir -p gpurun_out
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_trace -o t -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/${tag}_bench_under_trace.log 2>&1
+python3 bench.py "$@" > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
+cut -c1-300 gpurun_out/${tag}_bench.json
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_trace -o t -- python3 bench.py --no-cpu-baseline "$@" > gpurun_out/${tag}_bench_under_trace.log 2>&1
 f=$(find gpurun_out/${tag}_trace -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/${tag}_kernel_stats.csv
-tail -1 gpurun_out/${tag}_bench_under_trace.log | cut -c1-400
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 300 rocprofv3 --pmc $c --output-format csv -d gpurun_out/${tag}_pmc_$c -o p -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/${tag}_pmc_$c.log 2>&1
+  timeout 600 rocprofv3 --pmc $c --output-format csv -d gpurun_out/${tag}_pmc_$c -o p -- python3 bench.py --no-cpu-baseline "$@" --steps 1 --warmup 0 > gpurun_out/${tag}_pmc_$c.log 2>&1
 done
 python3 - "$tag" <<'PY'
 import csv, glob, json, sys
 tag = sys.argv[1]
+line = json.loads([l for l in open(f"gpurun_out/{tag}_pmc_WRITE_SIZE.log") if l.startswith("{")][-1])
+cfg = line["config"]
 out = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     f = glob.glob(f"gpurun_out/{tag}_pmc_{c}/**/*counter_collection.csv", recursive=True)
-    rows = [r for r in csv.DictReader(open(f[0])) if "rollout_kernel" in r["Kernel_Name"] and r["Counter_Name"] == c]
-    by = {}
-    for r in rows:
-        by[r["Dispatch_Id"]] = by.get(r["Dispatch_Id"], 0.0) + float(r["Counter_Value"])
-    out[c] = max(by.values())  # the full-length rollout launch (the reset-only launch is tiny)
-rec = dict(scenarios=4096, entities=64, sim_steps=10000, fetch_size_kb=out["FETCH_SIZE"], write_size_kb=out["WRITE_SIZE"],
-           hbm_bytes_per_launch=(out["FETCH_SIZE"] + out["WRITE_SIZE"]) * 1024,
-           note="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, KB units x1024; the kernel's loads are 8 B/lane, "
-                "so the x2 FETCH_SIZE correction calibrated for 16-B/lane streams (MI355X_MICROARCH.md, HBM) is NOT applied")
+    out[c] = sum(float(r["Counter_Value"]) for r in csv.DictReader(open(f[0]))
+                 if "rollout_kernel" in r["Kernel_Name"] and r["Counter_Name"] == c)
+rec = dict(scenarios=cfg["scenarios_per_gpu"], entities=cfg["entities"], sim_steps=cfg["sim_steps"],
+           fetch_size_kb=out["FETCH_SIZE"], write_size_kb=out["WRITE_SIZE"],
+           hbm_bytes_per_rollout=(out["FETCH_SIZE"] + out["WRITE_SIZE"]) * 1024,
+           launches_per_rollout=line["roofline"]["launches_per_rollout"],
+           note="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of one rollout (bench.py --steps 1 --warmup 0), "
+                "summed over every rollout_kernel dispatch (the reset-only launch included, it is tiny); KB units x1024. "
+                "The kernel's HBM reads are 8 B/lane knot rows and scalar table rows, so the x2 FETCH_SIZE correction "
+                "calibrated for 16-B/lane streams (MI355X_MICROARCH.md, HBM) is NOT applied; reads are 2 % of the traffic.")
 json.dump(rec, open(f"gpurun_out/{tag}_hbm_traffic.json", "w"), indent=1)
 print(rec)
 PY
-timeout 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VMEM_WR --output-format csv -d gpurun_out/${tag}_pmc_sq -o p -- python3 bench.py --steps 1 --warmup 0 --sim-steps 2000 --no-cpu-baseline > gpurun_out/${tag}_pmc_sq.log 2>&1
-python3 - "$tag" <<'PY'
-import csv, glob, sys, collections
-tag = sys.argv[1]
-f = glob.glob(f"gpurun_out/{tag}_pmc_sq/**/*counter_collection.csv", recursive=True)[0]
-agg = collections.defaultdict(float)
-for r in csv.DictReader(open(f)):
-    if "rollout_kernel" in r["Kernel_Name"]:
-        agg[(r["Dispatch_Id"], r["Counter_Name"])] += float(r["Counter_Value"])
-d = sorted({k[0] for k in agg}, key=int)[-1]
-ws = 4096 * 2000
-line = {k[1]: round(v / ws, 1) for k, v in agg.items() if k[0] == d}
-open(f"gpurun_out/{tag}_pmc_sq.txt", "w").write("per wave-step (4096 waves x 2000 steps; *_CYCLES and ACTIVE/WAIT in quad-cycles): %s\n" % line)
-print(line)
-PY
+bash tools/pmc_sq.sh "$tag" "$@" | cut -c1-400
