@@ -73,11 +73,14 @@ struct Params {
     const int32_t *ctl_ent;  // [n_ctl_pad] padded entity index r*EP + slot of controlled lane q, -1 = padding
     double *ctl_state;       // [CS_COUNT][n_ctl_pad] lane state carried from one chunk of steps to the next
     int n_ctl_pad;           // multiple of 64
+    int tab_steps;           // steps per table chunk (rows per lane = tab_steps + 1: the prefetch of the last step reads one row ahead)
 };
 
-// controller table written by control_kernel, read by rollout_kernel<.., TAB = true>: one row per step
-//   tab[(k * CT_COUNT + c) * n_ctl_pad + q],  c = x, y, h after step k, then the controller state after step k
-enum { CT_X = 0, CT_Y, CT_H, CT_SPEED, CT_ELON, CT_ELAT, CT_EINT, CT_COUNT };
+// controller table written by control_kernel, read by rollout_kernel<.., TAB = true>.  Two planes of
+// [n_ctl_pad][tab_steps + 1][4] doubles (the steps of one lane are contiguous: 32 B per step, so the scalar loads of
+// two consecutive steps share a cache line):
+//   plane 0: x, y, h after step k, controller speed      plane 1: e_lon_prev, e_lat_prev, e_lon_int, unused
+enum { CT_X = 0, CT_Y, CT_H, CT_SPEED, CT_W = 4, CT_ELON = 0, CT_ELAT, CT_EINT };
 enum { CS_POSE = 0, CS_PRESENT = 6, CS_CTRL = 7, CS_T = 11, CS_PREV_T = 12, CS_COUNT = 13 };
 
 // Lane pointers into one 64-slot block.  Global loads/stores carry an immediate offset (the compiler
@@ -1206,9 +1209,8 @@ __global__ __launch_bounds__(64 * WV, PED ? 1 : (TAB ? SG_WAVES_PER_SIMD_TAB : S
     // step wait for the stores of the previous one.
     const int64_t ctl_q = TAB ? fld<int64_t>(st, ST_CTL) : -1;
     const bool tab_lane = TAB && ctl_q >= 0 && (kind == SG_KIND_AGENT_PID || kind == SG_KIND_AGENT_VEHICLE);
-    const size_t tab_np = (size_t)p.n_ctl_pad;
-    const size_t tab_row = (size_t)CT_COUNT * tab_np; // doubles per step
-    int last_k = -1;                                  // last step of this launch the scenario executed
+    const size_t tab_lane_stride = (size_t)(p.tab_steps + 1) * CT_W; // doubles per lane
+    int last_k = -1;                                                 // last step of this launch the scenario executed
     constexpr int TL = SG_TAB_LANES(G, WV);
     int cl[TL];                       // wave-uniform: the controlled lanes of this wavefront
     const double *cb[TL];             // wave-uniform: their table columns
@@ -1225,18 +1227,18 @@ __global__ __launch_bounds__(64 * WV, PED ? 1 : (TAB ? SG_WAVES_PER_SIMD_TAB : S
                 cm &= cm - 1;
                 cl[j] = l;
                 const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)ctl_q, l);
-                const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(ctl_q >> 32), l);
-                cb[j] = tab + (((uint64_t)hi << 32) | lo);
+                cb[j] = tab + (size_t)lo * tab_lane_stride;
             }
         }
     }
-    auto tab_issue = [&](int k) { // s_load the rows of step k (unconditional: an unused entry reads column 0)
+    auto tab_issue = [&]() { // s_load the next row of every controlled lane (an unused entry re-reads the first row)
 #pragma unroll
         for (int j = 0; j < TL; ++j) {
-            ConstTbl rowp = (ConstTbl)(cb[j] + (size_t)k * tab_row);
-            sx[j] = rowp[CT_X * tab_np];
-            sy[j] = rowp[CT_Y * tab_np];
-            sh[j] = rowp[CT_H * tab_np];
+            ConstTbl rowp = (ConstTbl)cb[j];
+            sx[j] = rowp[CT_X];
+            sy[j] = rowp[CT_Y];
+            sh[j] = rowp[CT_H];
+            cb[j] += cl[j] >= 0 ? CT_W : 0;
         }
     };
 
@@ -1350,7 +1352,7 @@ __global__ __launch_bounds__(64 * WV, PED ? 1 : (TAB ? SG_WAVES_PER_SIMD_TAB : S
         }
     };
     if (TAB && n_steps > 0) {
-        tab_issue(0);
+        tab_issue();
         tab_commit();
     }
 
@@ -1379,7 +1381,7 @@ __global__ __launch_bounds__(64 * WV, PED ? 1 : (TAB ? SG_WAVES_PER_SIMD_TAB : S
         const bool run = in_range && (force || !done);
         if (!block_any<WV>(run)) { all_done = true; break; }
         const double cx_ = tb_x, cy_ = tb_y, ch_ = tb_h;
-        if (TAB) tab_issue(k + 1 < n_steps ? k + 1 : k); // consumed by tab_commit() at the end of this step
+        if (TAB) tab_issue(); // row k + 1 (the table has one spare row), consumed by tab_commit() at the end of this step
         // coefficient table: opaque per step so the scalar loads stay inside the loop (SGPRs for a few
         // dozen instructions instead of VGPRs for the whole kernel); constant address space => s_load
         const double *Kp = SG_TRIG;
@@ -1608,9 +1610,10 @@ __global__ __launch_bounds__(64 * WV, PED ? 1 : (TAB ? SG_WAVES_PER_SIMD_TAB : S
         if (PED && kind == SG_KIND_AGENT_PEDESTRIAN) cs.e_lon_prev = (double)goal_idx;
         if (TAB) {
             if (tab_lane && last_k >= 0) { // controller state after the last executed step
-                const double *lr = tab + ctl_q + (size_t)last_k * tab_row;
-                stf(dy, SG_F_CTRL + 0, lr[CT_SPEED * tab_np]); stf(dy, SG_F_CTRL + 1, lr[CT_ELON * tab_np]);
-                stf(dy, SG_F_CTRL + 2, lr[CT_ELAT * tab_np]); stf(dy, SG_F_CTRL + 3, lr[CT_EINT * tab_np]);
+                const double *lr = tab + (size_t)ctl_q * tab_lane_stride + (size_t)last_k * CT_W;
+                const double *lr1 = lr + (size_t)p.n_ctl_pad * tab_lane_stride; // plane 1
+                stf(dy, SG_F_CTRL + 0, lr[CT_SPEED]); stf(dy, SG_F_CTRL + 1, lr1[CT_ELON]);
+                stf(dy, SG_F_CTRL + 2, lr1[CT_ELAT]); stf(dy, SG_F_CTRL + 3, lr1[CT_EINT]);
             }
         } else {
             stf(dy, SG_F_CTRL + 0, cs.speed); stf(dy, SG_F_CTRL + 1, cs.e_lon_prev);
@@ -1693,7 +1696,8 @@ __global__ __launch_bounds__(64) void control_kernel(Params p, double timestep, 
     Segment S;
     S.cur = seg_locate(T, t);
     seg_load(T, S);
-    double *out = tab + q;
+    double *out = tab + q * ((size_t)(p.tab_steps + 1) * CT_W);                      // plane 0 rows of this lane
+    double *out1 = out + (size_t)p.n_ctl_pad * ((size_t)(p.tab_steps + 1) * CT_W); // plane 1
     sg_loads_done();
 
     for (int k = 0; k < n_steps; ++k) {
@@ -1741,10 +1745,8 @@ __global__ __launch_bounds__(64) void control_kernel(Params p, double timestep, 
         }
         prev_t = t;
         t = next_t;
-        double *o = out + (size_t)k * CT_COUNT * NP;
-        o[CT_X * NP] = pose[0]; o[CT_Y * NP] = pose[1]; o[CT_H * NP] = pose[3];
-        o[CT_SPEED * NP] = cs.speed; o[CT_ELON * NP] = cs.e_lon_prev;
-        o[CT_ELAT * NP] = cs.e_lat_prev; o[CT_EINT * NP] = cs.e_lon_int;
+        *reinterpret_cast<double4 *>(out + (size_t)k * CT_W) = make_double4(pose[0], pose[1], pose[3], cs.speed);
+        *reinterpret_cast<double4 *>(out1 + (size_t)k * CT_W) = make_double4(cs.e_lon_prev, cs.e_lat_prev, cs.e_lon_int, 0.0);
     }
 #pragma unroll
     for (int c = 0; c < 6; ++c) cst[(CS_POSE + c) * NP] = pose[c];

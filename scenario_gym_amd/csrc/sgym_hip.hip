@@ -39,7 +39,6 @@ struct sg_handle {
     int max_ctl_per_block = 0; // controlled lanes in the fullest 64-slot block
     hipStream_t ctl_stream = nullptr;
     double *d_tab[2] = {nullptr, nullptr};
-    size_t tab_cap = 0; // doubles per buffer
     std::vector<hipEvent_t> ev_pool;
     int tab_min = 16, chunk_steps = 1024, overlap = 1; // sg_set_tuning
     int n_launches = 0;           // rollout_kernel launches of the last call
@@ -256,23 +255,22 @@ static int launch_rollout(sg_handle *h, int n_steps, int do_reset, int force, co
             if (!h->d_tab[0]) {
                 HIP_TRY(h, hipMalloc((void **)&h->d_tab[0], 64 * sizeof(double)));
                 HIP_TRY(h, hipMemsetAsync(h->d_tab[0], 0, 64 * sizeof(double), h->stream));
-                h->tab_cap = 64;
             }
             rc = launch_main(h, n_steps, 0, force, nullptr, h->d_tab[0], true, &ev_next);
         } else {
-            const size_t np = (size_t)h->p.n_ctl_pad, row = (size_t)sg::CT_COUNT * np;
+            const size_t np = (size_t)h->p.n_ctl_pad, row = (size_t)2 * sg::CT_W * np; // doubles per step, both planes
             // chunk length: SG_CHUNK_STEPS, capped so that one table buffer stays under 1 GiB
             int ch = (int)std::min<size_t>((size_t)chunk_steps, std::max<size_t>(1, ((size_t)1 << 27) / row));
             ch = std::min(ch, n_steps);
-            if ((size_t)ch * row > h->tab_cap) {
+            if (ch > h->p.tab_steps) { // grow: tab_steps + 1 rows per lane is part of the table addressing
                 HIP_TRY(h, hipStreamSynchronize(h->stream));
                 HIP_TRY(h, hipStreamSynchronize(h->ctl_stream));
                 for (int b = 0; b < 2; ++b) {
                     if (h->d_tab[b]) HIP_TRY(h, hipFree(h->d_tab[b]));
                     h->d_tab[b] = nullptr;
                 }
-                for (int b = 0; b < 2; ++b) HIP_TRY(h, hipMalloc((void **)&h->d_tab[b], (size_t)ch * row * sizeof(double)));
-                h->tab_cap = (size_t)ch * row;
+                for (int b = 0; b < 2; ++b) HIP_TRY(h, hipMalloc((void **)&h->d_tab[b], (size_t)(ch + 1) * row * sizeof(double)));
+                h->p.tab_steps = ch;
             }
             hipStream_t cs = no_overlap ? h->stream : h->ctl_stream;
             hipEvent_t e;
@@ -324,6 +322,10 @@ extern "C" int sg_upload(sg_handle *h, const sg_scenarios *sc)
     HIP_TRY(h, hipStreamSynchronize(h->ctl_stream));
     free_pool(h->static_allocs);
     free_pool(h->state_allocs);
+    for (int b = 0; b < 2; ++b) { // the controller table geometry depends on the batch
+        if (h->d_tab[b]) HIP_TRY(h, hipFree(h->d_tab[b]));
+        h->d_tab[b] = nullptr;
+    }
     h->uploaded = false;
     // pedestrian agents are compiled for tiles of >= 16 lanes
     h->has_ped = false;
