@@ -272,7 +272,7 @@ struct RecipDiv {
     __device__ __forceinline__ bool safe(double a) const
     {
         uint32_t e = ((uint32_t)__double2hiint(a) >> 20) & 0x7ffu;
-        return ok && ((e - 64u) < 1920u || a == 0.0);
+        return ok & (((e - 64u) < 1920u) | (a == 0.0)); // bitwise: straight-line code, no short-circuit branches
     }
     __device__ __forceinline__ double div(double a) const
     {
@@ -1134,6 +1134,8 @@ __global__ __launch_bounds__(64 * WV, PED ? 1 : (TAB ? SG_WAVES_PER_SIMD_TAB : S
     const double length = ss.length;
     const bool is_static = (int)(meta >> 32) == 1;
     const bool is_agent = kind >= SG_KIND_AGENT_REPLAY;
+    const bool is_replay = kind == SG_KIND_REPLAY;
+    const bool replay_always = p.persist || is_static; // BatchReplayEntity keeps persistent / static entities (batch.py:45-52)
     // per-launch LDS tables: box extents, controller parameters; broad-phase reach of this lane =
     // own bounding-circle radius + the largest radius in the tile + slack
     float rad_thr, trig_eps, nbr_thr = 0.0f;
@@ -1408,18 +1410,28 @@ __global__ __launch_bounds__(64 * WV, PED ? 1 : (TAB ? SG_WAVES_PER_SIMD_TAB : S
         // ---- new poses: scenario_gym.py:233-245 ----
         bool npres = false;
         double fpx = 0.0, fpy = 0.0; // PedestrianAgent.force
-        if (kind == SG_KIND_REPLAY) { // BatchReplayEntity.step, batch.py:34-53
+        if (TAB) {
+            // Straight-line lane masks (the kernel is bound by instruction issue, branches included):
+            // BatchReplayEntity.step (batch.py:34-53) for replay lanes; an agent stays once present and spawns at its
+            // trajectory start (scenario_gym.py:240-244); controlled lanes take the pre-pass row, z / p / r unchanged
+            // (controller.py:126-131).
+            const bool in_window = (next_t >= min_t) & (next_t <= max_t);
+            const bool np_replay = replay_always | in_window;
+            const bool np_agent = present | (min_t >= t);
+            npres = (is_replay & np_replay) | (is_agent & np_agent);
+            const bool take = tab_lane & present & run;
+            np_[0] = take ? cx_ : np_[0];
+            np_[1] = take ? cy_ : np_[1];
+            np_[2] = take ? pose[2] : np_[2];
+            np_[3] = take ? ch_ : np_[3];
+            np_[4] = take ? pose[4] : np_[4];
+            np_[5] = take ? pose[5] : np_[5];
+        } else if (kind == SG_KIND_REPLAY) { // BatchReplayEntity.step, batch.py:34-53
             npres = p.persist || is_static || (next_t >= min_t && next_t <= max_t);
         } else if (is_agent) {
             if (present) {
                 npres = true;
-                if (TAB) {
-                    if (tab_lane && run) { // integrated by control_kernel: z, p, r stay (controller.py:126-131)
-#pragma unroll
-                        for (int c = 0; c < 6; ++c) np_[c] = pose[c];
-                        np_[0] = cx_; np_[1] = cy_; np_[3] = ch_;
-                    }
-                } else if (kind != SG_KIND_AGENT_REPLAY && run) {
+                if (kind != SG_KIND_AGENT_REPLAY && run) {
                     const double tx = np_[0], ty = np_[1];
 #pragma unroll
                     for (int c = 0; c < 6; ++c) np_[c] = pose[c];
@@ -1457,12 +1469,20 @@ __global__ __launch_bounds__(64 * WV, PED ? 1 : (TAB ? SG_WAVES_PER_SIMD_TAB : S
         double vel[6];
         {
             RecipDiv rd(dt);
-            bool safe = true;
-#pragma unroll
-            for (int c = 0; c < 6; ++c) safe = safe && rd.safe(d[c]);
+            // z, pitch and roll rarely move: when their deltas are +0.0 in every lane, +0 / dt (dt > 0) is +0 and the
+            // three divisions and range checks are skipped
+            const uint32_t zbits = (uint32_t)(__double2hiint(d[2]) | __double2hiint(d[4]) | __double2hiint(d[5])) |
+                                   (uint32_t)(__double2loint(d[2]) | __double2loint(d[4]) | __double2loint(d[5]));
+            const bool flat = __all(zbits == 0 && dt > 0.0);
+            bool safe = rd.safe(d[0]) & rd.safe(d[1]) & rd.safe(d[3]);
+            if (!flat) safe = safe & rd.safe(d[2]) & rd.safe(d[4]) & rd.safe(d[5]);
             if (__all(safe)) {
-#pragma unroll
-                for (int c = 0; c < 6; ++c) vel[c] = rd.div(d[c]);
+                vel[0] = rd.div(d[0]); vel[1] = rd.div(d[1]); vel[3] = rd.div(d[3]);
+                if (flat) {
+                    vel[2] = vel[4] = vel[5] = 0.0;
+                } else {
+                    vel[2] = rd.div(d[2]); vel[4] = rd.div(d[4]); vel[5] = rd.div(d[5]);
+                }
             } else {
 #pragma unroll
                 for (int c = 0; c < 6; ++c) vel[c] = d[c] / dt;
