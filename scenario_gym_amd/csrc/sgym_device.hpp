@@ -24,6 +24,9 @@
 #define SG_WAVES_PER_SIMD 2 // register budget of the rollout kernel: 512 / SG_WAVES_PER_SIMD VGPRs per lane
 #endif
 // controlled lanes per wavefront the table variant of the rollout kernel serves: one per scenario of the wavefront, at most 4
+#ifndef SG_WAVES_PER_SIMD_PED
+#define SG_WAVES_PER_SIMD_PED 2 // pedestrian variant
+#endif
 #define SG_TAB_LANES(G, WV) ((WV) > 1 || (G) >= 64 ? 1 : ((G) >= 32 ? 2 : 4))
 #ifndef SG_WAVES_PER_SIMD_TAB
 #define SG_WAVES_PER_SIMD_TAB 2 // same for the variant without in-kernel controllers
@@ -367,6 +370,7 @@ __device__ __forceinline__ void own_position_extrap(const double *kn, int n, dou
 {
     if (n == 1) { // trajectory.py:175-177: knot duplicated at t + 1e-3
         double x_lo = kn[0];
+#pragma unroll
         for (int c = 0; c < 6; ++c) {
             double slope = kn[1 + c] - kn[1 + c]; // (y - y)/(x_hi - x_lo): +0, or NaN for a non-finite knot
             out[c] = slope * (t - x_lo) + kn[1 + c];
@@ -380,6 +384,7 @@ __device__ __forceinline__ void own_position_extrap(const double *kn, int n, dou
     }
     int idx = lo < 1 ? 1 : (lo > n - 1 ? n - 1 : lo);
     const double *a = kn + (size_t)(idx - 1) * 7, *b = kn + (size_t)idx * 7;
+#pragma unroll
     for (int c = 0; c < 6; ++c) {
         double slope = (b[1 + c] - a[1 + c]) / (b[0] - a[0]);
         out[c] = slope * (t - a[0]) + a[1 + c];
@@ -442,10 +447,15 @@ struct TileLds {
     // the 8 floats that remain are scratch for the launch-time reductions across wavefronts
     double cor[8][NS > 64 ? NS : 2];
     int last[NS];
-    double ctrl[PED ? NCTRL_ROWS : 9][NS]; // controller parameters (SG_C_*) of every slot, copied once per launch
+    // controller parameters of every slot, copied once per launch: the 9 vehicle / PID rows, or -- in pedestrian
+    // scenes -- the 4 pedestrian rows SG_C_PED_* (index q - SG_C_PED_SPEED_DESIRED)
+    double ctrl[PED ? 4 : 9][NS];
     double boxwl[2][NS];    // bounding box width, length (exact path and controllers only)
     // social force inputs of the CURRENT state (pedestrian/sensor.py:55-64): reference point, velocity
     double px[PED ? NS : 1], py[PED ? NS : 1], vx[PED ? NS : 1], vy[PED ? NS : 1];
+    // per NEIGHBOUR terms of the repulsion force, computed once by the neighbour itself (social_force.py:148-155):
+    // unit velocity o = v / (|v| + 1e-10) and step = (|v| + 1e-10) * (next_t - t)
+    double ox[PED ? NS : 1], oy[PED ? NS : 1], stp[PED ? NS : 1];
     unsigned char isped[PED ? NS : 1]; // entity.type == "Pedestrian" and present
     // broad-phase stripe masks: bit set of the slots whose centre lies in x- (y-) stripe k (mod 64)
     unsigned long long xtab[64][NS / 64], ytab[64][NS / 64];
@@ -458,14 +468,14 @@ struct TileLds {
 struct CtrlState { double speed, e_lon_prev, e_lat_prev, e_lon_int; };
 
 // VehicleController._step (controller.py:105-140); sin_h/cos_h of the current heading come from
-// the previous step's corner computation.  cp = this slot's column of the LDS parameter table.
-template <typename LDS>
-__device__ __forceinline__ void vehicle_step(CtrlState &cs, const LDS &st, int sl, double l,
+// the caller.  cp(q) = controller parameter SG_C_q of this slot (LDS table, or the static rows in pedestrian scenes).
+template <typename CP>
+__device__ __forceinline__ void vehicle_step(CtrlState &cs, const CP &cp, double l,
                                              double dt, double accel, double steer, double sin_h,
                                              double cos_h, double *pose, ConstTbl K)
 {
-    double max_steer = st.ctrl[SG_C_MAX_STEER][sl], max_accel = st.ctrl[SG_C_MAX_ACCEL][sl];
-    double max_speed = st.ctrl[SG_C_MAX_SPEED][sl], allow_rev = st.ctrl[SG_C_ALLOW_REVERSE][sl];
+    double max_steer = cp(SG_C_MAX_STEER), max_accel = cp(SG_C_MAX_ACCEL);
+    double max_speed = cp(SG_C_MAX_SPEED), allow_rev = cp(SG_C_ALLOW_REVERSE);
     accel = __builtin_fmin(__builtin_fmax(accel, -max_accel), max_accel);
     steer = __builtin_fmin(__builtin_fmax(steer, -max_steer), max_steer);
     double dx = cs.speed * cos_h;
@@ -481,8 +491,8 @@ __device__ __forceinline__ void vehicle_step(CtrlState &cs, const LDS &st, int s
 }
 
 // PIDController._step (controller.py:205-258)
-template <typename LDS>
-__device__ __forceinline__ void pid_step(CtrlState &cs, const LDS &st, int sl, double l,
+template <typename CP>
+__device__ __forceinline__ void pid_step(CtrlState &cs, const CP &cp, double l,
                                          double state_dt, double dt, double tx, double ty,
                                          double sin_h, double cos_h, double *pose, ConstTbl K)
 {
@@ -496,24 +506,60 @@ __device__ __forceinline__ void pid_step(CtrlState &cs, const LDS &st, int sl, d
     const RecipDiv rd(state_dt); // both derivative terms divide by State.dt
     const bool fast = rd.safe(e_lat - cs.e_lat_prev) && rd.safe(e_lon - cs.e_lon_prev);
     double e_lat_D = fast ? rd.div(e_lat - cs.e_lat_prev) : (e_lat - cs.e_lat_prev) / state_dt;
-    double kp = st.ctrl[SG_C_STEER_KP][sl] * gain, kd = st.ctrl[SG_C_STEER_KD][sl] * gain;
+    double kp = cp(SG_C_STEER_KP) * gain, kd = cp(SG_C_STEER_KD) * gain;
     double steer = kp * e_lat + kd * e_lat_D;
     double e_lon_D = fast ? rd.div(e_lon - cs.e_lon_prev) : (e_lon - cs.e_lon_prev) / state_dt;
     double e_lon_I = cs.e_lon_int + e_lon * state_dt;
     double accel = 0.0;
     if (__builtin_fabs(e_lon) > 0.1)
-        accel = st.ctrl[SG_C_ACCEL_KP][sl] * e_lon + st.ctrl[SG_C_ACCEL_KD][sl] * e_lon_D +
-                st.ctrl[SG_C_ACCEL_KI][sl] * e_lon_I;
+        accel = cp(SG_C_ACCEL_KP) * e_lon + cp(SG_C_ACCEL_KD) * e_lon_D + cp(SG_C_ACCEL_KI) * e_lon_I;
     cs.e_lat_prev = e_lat;
     cs.e_lon_prev = e_lon;
     cs.e_lon_int = e_lon_I;
-    vehicle_step(cs, st, sl, l, dt, accel, steer, sin_h, cos_h, pose, K);
+    vehicle_step(cs, cp, l, dt, accel, steer, sin_h, cos_h, pose, K);
 }
 
 // ------------------------------------------------------------------------------------------------
 // pedestrians: exp / atan2 shared (by restatement) with the oracle's sgo_exp / sgo_atan2
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ double sg_exp(double x)
+// Division policy of the social-force pair terms.  Exact: plain IEEE '/'.  Fast: the same quotients through
+// RecipDiv (correctly rounded inside its operand range); an operand outside the range only raises `bad`, and the
+// caller recomputes that pair with Exact.  Keeps the common case free of branches.
+struct ExactArith {
+    bool bad = false;
+    __device__ __forceinline__ double div(double a, double d) { return a / d; }
+    __device__ __forceinline__ void div2(double a, double b, double d, double &qa, double &qb) { qa = a / d; qb = b / d; }
+    // fl(a / m) >= c
+    __device__ __forceinline__ bool quotient_ge(double a, double m, double c) { return a / m >= c; }
+};
+struct FastArith {
+    bool bad = false;
+    __device__ __forceinline__ double div(double a, double d)
+    {
+        const RecipDiv rd(d);
+        bad |= !rd.safe(a);
+        return rd.div(a);
+    }
+    __device__ __forceinline__ void div2(double a, double b, double d, double &qa, double &qb)
+    {
+        const RecipDiv rd(d);
+        bad |= !(rd.safe(a) & rd.safe(b));
+        qa = rd.div(a);
+        qb = rd.div(b);
+    }
+    // m > 0.  Rounding is monotone: a >= c*m*(1 + 2^-50) implies fl(a/m) >= c, a <= c*m*(1 - 2^-50) implies
+    // fl(a/m) < c (8 ulp margins); the sliver in between (and c*m outside the normal range) is `bad`.
+    __device__ __forceinline__ bool quotient_ge(double a, double m, double c)
+    {
+        const double cm = c * m, acm = __builtin_fabs(cm), slack = acm * 0x1p-50;
+        const bool yes = a >= cm + slack, no = a <= cm - slack;
+        bad |= !((yes | no) & (acm < 0x1p1000) & ((acm > 0x1p-900) | (c == 0.0)));
+        return yes;
+    }
+};
+
+template <typename AR>
+__device__ __forceinline__ double sg_exp(double x, AR &A)
 {
     const double LN2HI = 6.93147180369123816490e-01, LN2LO = 1.90821492927058770002e-10,
                  INVLN2 = 1.44269504088896338700e+00;
@@ -529,8 +575,64 @@ __device__ __forceinline__ double sg_exp(double x)
     double r = hi - lo;
     double t = r * r;
     double c = r - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))));
-    double y = 1.0 - ((lo - (r * c) / (2.0 - c)) - hi);
+    double y = 1.0 - ((lo - A.div(r * c, 2.0 - c)) - hi);
     return ldexp(y, (int)k);
+}
+__device__ __forceinline__ double sg_exp(double x)
+{
+    ExactArith A;
+    return sg_exp(x, A);
+}
+
+// One neighbour's terms of SocialForce._step (social_force.py:59-62, 140-188, 213-222): the weighted repulsion
+// (c1) and attraction (c2) this neighbour adds to the force, in the reference's operation order.
+// STRAIGHT: head rotation 0 in every lane (hs == 0, hc == 1): the rotated velocity is the velocity itself, so the view
+// direction is the neighbour's own unit velocity (odx, ody), bit for bit.  NOATT: ped_attract_C == 0 with a positive
+// sight weight: the attraction is a signed zero and w2 * (+-0) == +-0, whatever w2 is.
+template <bool STRAIGHT, bool NOATT, typename AR>
+__device__ __forceinline__ void ped_pair(AR &A, const sg_social_force &sf, double k2_scale, double px, double py,
+                                         double hs, double hc, double ox, double oy, double ovx, double ovy,
+                                         double odx, double ody, double step, double &c1x, double &c1y,
+                                         double &c2x, double &c2y)
+{
+    // view direction = the neighbour's velocity rotated by the head angle (:59-62, X.dot(R.T))
+    double ux = odx, uy = ody;
+    if (!STRAIGHT) {
+        double vx = __builtin_fma(ovx, hc, ovy * (-hs)), vy = __builtin_fma(ovx, hs, ovy * hc);
+        double vn = sg_norm2(vx, vy) + 0.0000000001;
+        A.div2(vx, vy, vn, ux, uy);
+    }
+    double rx = px - ox, ry = py - oy; // _force_pedestrian_repulsion, :140-176
+    double rn = sg_norm2(rx, ry);
+    double qx = rx - step * odx, qy = ry - step * ody;
+    double qn = sg_norm2(qx, qy) + 0.0000000001;
+    double sum = rn + qn;
+    double b = (1.0 / 2) * __builtin_sqrt(sum * sum - step * step);
+    double k1 = (1.0 / 4) * A.div(1.0, b) * sum;
+    double rxn, ryn, qxn, qyn;
+    A.div2(rx, ry, rn, rxn, ryn);
+    A.div2(qx, qy, qn, qxn, qyn);
+    double dbx = k1 * (rxn + qxn), dby = k1 * (ryn + qyn);
+    double k2 = k2_scale * sg_exp(A.div(-b, sf.ped_repulse_sigma), A);
+    double repx = k2 * dbx, repy = k2 * dby;
+    double k3 = 2 * sf.ped_attract_C; // _force_pedestrian_attraction, :178-188
+    double attx = k3 * rx, atty = k3 * ry;
+    double w1 = 1.0, w2 = 1.0;
+    if (sf.sight_weight_use != 0.0) { // _sight_weight, :213-222 (wave-uniform)
+        w1 = A.quotient_ge(__builtin_fma(uy, repy, ux * repx), sg_norm2(repx, repy) + 0.0000000001, sf.cos_sight)
+                 ? 1.0 : sf.sight_weight;
+        c1x = w1 * repx; c1y = w1 * repy;
+        if (NOATT) {
+            c2x = attx; c2y = atty;
+        } else {
+            w2 = A.quotient_ge(__builtin_fma(uy, atty, ux * attx), sg_norm2(attx, atty) + 0.0000000001, sf.cos_sight)
+                     ? 1.0 : sf.sight_weight;
+            c2x = w2 * attx; c2y = w2 * atty;
+        }
+    } else {
+        c1x = repx; c1y = repy;
+        c2x = attx; c2y = atty;
+    }
 }
 
 __device__ __forceinline__ double sg_atan_pos(double ax)
@@ -634,13 +736,17 @@ __device__ __forceinline__ void ped_step(const Params &p, const LDS &L, int sl, 
         double gx = wp[2 * goal_idx] - pose[0], gy = wp[2 * goal_idx + 1] - pose[1]; // _force_to_goal, :119-138
         double gn = sg_norm2(gx, gy);
         if (gn == 0) gn += 0.000000001;
-        const double vdes = L.ctrl[SG_C_PED_SPEED_DESIRED][sl];
+        const double vdes = L.ctrl[SG_C_PED_SPEED_DESIRED - SG_C_PED_SPEED_DESIRED][sl];
         const double inv_tau = 1 / sf.relaxation_time;
         double fx = inv_tau * (vdes * (gx / gn) - velx);
         double fy = inv_tau * (vdes * (gy / gn) - vely);
         double hs, hc;
-        sg_sincos(L.ctrl[SG_C_PED_HEAD_ROT][sl], hs, hc, K);
-        const double radius = L.ctrl[SG_C_PED_RADIUS][sl];
+        sg_sincos(L.ctrl[SG_C_PED_HEAD_ROT - SG_C_PED_SPEED_DESIRED][sl], hs, hc, K);
+        const double radius = L.ctrl[SG_C_PED_RADIUS - SG_C_PED_SPEED_DESIRED][sl];
+        const double k2_scale = sf.ped_repulse_V / sf.ped_repulse_sigma;
+        // the shortcuts of ped_pair need the sight-weight branch (c2 = w2 * att) and hold for the whole wavefront
+        const bool plain = __all(hs == 0.0 && hc == 1.0) && sf.ped_attract_C == 0.0 && sf.sight_weight > 0.0 &&
+                           sf.sight_weight_use != 0.0;
         // neighbours in entity order, one per iteration across all row words (the wavefront iterates
         // max-over-lanes of the TOTAL candidate count, not the sum of per-word maxima)
         uint64_t m[WV];
@@ -658,37 +764,28 @@ __device__ __forceinline__ void ped_step(const Params &p, const LDS &L, int sl, 
             j += tile0;
             {
                 if (!L.isped[j]) continue; // PedestrianSensor: pedestrians only (sensor.py:60-62)
-                const double ox = L.px[j], oy = L.py[j], ovx = L.vx[j], ovy = L.vy[j];
+                const double ox = L.px[j], oy = L.py[j];
                 if (!sg_in_radius(pose[0], pose[1], radius, ox, oy, p.gon)) continue;
-                // view direction = the neighbour's velocity rotated by the head angle (:59-62, X.dot(R.T))
-                double vx = __builtin_fma(ovx, hc, ovy * (-hs)), vy = __builtin_fma(ovx, hs, ovy * hc);
-                double vn = sg_norm2(vx, vy) + 0.0000000001;
-                double ux = vx / vn, uy = vy / vn;
-                double rx = pose[0] - ox, ry = pose[1] - oy; // _force_pedestrian_repulsion, :140-176
-                double rn = sg_norm2(rx, ry);
-                double vmag = sg_norm2(ovx, ovy) + 0.0000000001;
-                double odx = ovx / vmag, ody = ovy / vmag;
-                double step = vmag * (next_t - t);
-                double qx = rx - step * odx, qy = ry - step * ody;
-                double qn = sg_norm2(qx, qy) + 0.0000000001;
-                double sum = rn + qn;
-                double b = (1.0 / 2) * __builtin_sqrt(sum * sum - step * step);
-                double k1 = (1.0 / 4) * (1 / b) * sum;
-                double dbx = k1 * (rx / rn + qx / qn), dby = k1 * (ry / rn + qy / qn);
-                double k2 = sf.ped_repulse_V / sf.ped_repulse_sigma * sg_exp(-b / sf.ped_repulse_sigma);
-                double repx = k2 * dbx, repy = k2 * dby;
-                double k3 = 2 * sf.ped_attract_C; // _force_pedestrian_attraction, :178-188
-                double attx = k3 * rx, atty = k3 * ry;
-                if (sf.sight_weight_use != 0.0) { // _sight_weight, :213-222
-                    double w1 = __builtin_fma(uy, repy, ux * repx) / (sg_norm2(repx, repy) + 0.0000000001) >= sf.cos_sight
-                                    ? 1.0 : sf.sight_weight;
-                    fx += w1 * repx; fy += w1 * repy;
-                    double w2 = __builtin_fma(uy, atty, ux * attx) / (sg_norm2(attx, atty) + 0.0000000001) >= sf.cos_sight
-                                    ? 1.0 : sf.sight_weight;
-                    fx += w2 * attx; fy += w2 * atty;
-                } else {
-                    fx += attx; fy += atty;
-                    fx += repx; fy += repy;
+                const double ovx = L.vx[j], ovy = L.vy[j];
+                const double odx = L.ox[j], ody = L.oy[j], step = L.stp[j];
+                double c1x, c1y, c2x, c2y;
+                FastArith FA;
+                if (plain) // wave-uniform: default head rotation and no attraction
+                    ped_pair<true, true>(FA, sf, k2_scale, pose[0], pose[1], hs, hc, ox, oy, ovx, ovy, odx, ody, step, c1x, c1y, c2x, c2y);
+                else
+                    ped_pair<false, false>(FA, sf, k2_scale, pose[0], pose[1], hs, hc, ox, oy, ovx, ovy, odx, ody, step, c1x, c1y, c2x, c2y);
+                if (__any(FA.bad)) { // rare: some operand outside RecipDiv's range, or a sight weight on its threshold
+                    if (FA.bad) {
+                        ExactArith EA;
+                        ped_pair<false, false>(EA, sf, k2_scale, pose[0], pose[1], hs, hc, ox, oy, ovx, ovy, odx, ody, step, c1x, c1y, c2x, c2y);
+                    }
+                }
+                if (sf.sight_weight_use != 0.0) {
+                    fx += c1x; fy += c1y;
+                    fx += c2x; fy += c2y;
+                } else { // without sight weights the reference adds the attraction first (:72-80)
+                    fx += c2x; fy += c2y;
+                    fx += c1x; fy += c1y;
                 }
             }
         }
@@ -699,7 +796,7 @@ __device__ __forceinline__ void ped_step(const Params &p, const LDS &L, int sl, 
     } else { // reached the goal, agent.py:65-68
         fxo = fyo = 0.0;
     }
-    const double maxs = L.ctrl[SG_C_PED_MAX_SPEED][sl]; // PedestrianController._step
+    const double maxs = L.ctrl[SG_C_PED_MAX_SPEED - SG_C_PED_SPEED_DESIRED][sl]; // PedestrianController._step
     cspeed = __builtin_fmin(__builtin_fmax(speed, -maxs), maxs);
     double hs2, hc2;
     sg_sincos(heading, hs2, hc2, K);
@@ -750,6 +847,7 @@ __device__ __forceinline__ bool block_any(bool x)
 
 template <int G, int WV, bool PED, typename LDS>
 __device__ __forceinline__ void tile_collisions(bool present, const double *pose, double velx, double vely,
+                                                double dtn /* next_t - t of the coming step (PED) */,
                                                 double bcx, double bcy, float rad_thr, float trig_eps,
                                                 float nbr_thr, float cell_inv, bool is_ped_type, int sl, int tile0, LDS &L,
                                                 uint64_t (&rows_out)[WV], uint64_t (&mult_rows)[WV],
@@ -787,6 +885,10 @@ __device__ __forceinline__ void tile_collisions(bool present, const double *pose
     if (PED) {
         L.px[sl] = x; L.py[sl] = y; L.vx[sl] = velx; L.vy[sl] = vely;
         L.isped[sl] = present && is_ped_type;
+        const double vmag = sg_norm2(velx, vely) + 0.0000000001; // social_force.py:148-155, once per neighbour
+        L.ox[sl] = velx / vmag;
+        L.oy[sl] = vely / vmag;
+        L.stp[sl] = vmag * dtn;
     }
     uint64_t cand[WV];
     bool any_cand = false;
@@ -1101,7 +1203,7 @@ __device__ __forceinline__ Table lane_table(const Params &p, int kind, const Sce
 // TAB: the PID / vehicle agents were integrated by control_kernel; their lanes read (x, y, h) per step from
 // its table `tab` instead of running the controller with 1 of 64 lanes active.  TAB launches never reset.
 template <int G, int WV, bool PED, bool TAB>
-__global__ __launch_bounds__(64 * WV, PED ? 1 : (TAB ? SG_WAVES_PER_SIMD_TAB : SG_WAVES_PER_SIMD)) void rollout_kernel(
+__global__ __launch_bounds__(64 * WV, PED ? SG_WAVES_PER_SIMD_PED : (TAB ? SG_WAVES_PER_SIMD_TAB : SG_WAVES_PER_SIMD)) void rollout_kernel(
     Params p, double timestep, int n_steps, int do_reset, int force, const double *actions /*[n][R][2]*/,
     const double *tab /*[n][CT_COUNT][n_ctl_pad]*/)
 {
@@ -1165,7 +1267,7 @@ __global__ __launch_bounds__(64 * WV, PED ? 1 : (TAB ? SG_WAVES_PER_SIMD_TAB : S
         lds.boxwl[1][sl] = bl;
         if (!TAB) {
 #pragma unroll
-            for (int q = 0; q < (PED ? NCTRL_ROWS : 9); ++q) lds.ctrl[q][sl] = fld(st, ST_CTRL + q);
+            for (int q = 0; q < (PED ? 4 : 9); ++q) lds.ctrl[q][sl] = fld(st, ST_CTRL + (PED ? SG_C_PED_SPEED_DESIRED : 0) + q);
         }
         if (PED) // PedestrianSensor radius is measured between reference points; centres differ by the box offsets
             nbr_thr = kind == SG_KIND_AGENT_PEDESTRIAN
@@ -1258,6 +1360,7 @@ __global__ __launch_bounds__(64 * WV, PED ? 1 : (TAB ? SG_WAVES_PER_SIMD_TAB : S
             if (is_static || inside) { own_position_extrap(kn, nk, t, pose); present = true; }
             else if (p.persist) { // extrapolate=(False, False): clamp
                 const double *rowp = t < min_t ? kn : kn + (size_t)(nk - 1) * 7;
+#pragma unroll
                 for (int c = 0; c < 6; ++c) pose[c] = rowp[1 + c];
                 present = true;
             }
@@ -1266,6 +1369,7 @@ __global__ __launch_bounds__(64 * WV, PED ? 1 : (TAB ? SG_WAVES_PER_SIMD_TAB : S
                 double a[6], b[6];
                 own_position_extrap(kn, nk, t + eps / 2, a);
                 own_position_extrap(kn, nk, t - eps / 2, b);
+#pragma unroll
                 for (int c = 0; c < 6; ++c) vel[c] = (a[c] - b[c]) / eps;
             }
         }
@@ -1284,7 +1388,7 @@ __global__ __launch_bounds__(64 * WV, PED ? 1 : (TAB ? SG_WAVES_PER_SIMD_TAB : S
 #pragma unroll
         for (int w = 0; w < WV; ++w) last_row[w] = 0; // metrics/collision.py:64-68
         n_ev = 0;
-        tile_collisions<G, WV, PED>(present, pose, velx, vely, bcx, bcy, rad_thr, trig_eps, nbr_thr, cell_inv, is_ped_type,
+        tile_collisions<G, WV, PED>(present, pose, velx, vely, (t + timestep) - t, bcx, bcy, rad_thr, trig_eps, nbr_thr, cell_inv, is_ped_type,
                                     sl, tile0, lds, row, mult_rows, nbr);
         if (in_range) {
 #pragma unroll
@@ -1328,7 +1432,7 @@ __global__ __launch_bounds__(64 * WV, PED ? 1 : (TAB ? SG_WAVES_PER_SIMD_TAB : S
         steps = sd.n_steps;
         if (PED) { // the neighbour candidates (and LDS positions) of the current state
             uint64_t tmp_rows[WV];
-            tile_collisions<G, WV, PED>(present, pose, velx, vely, bcx, bcy, rad_thr, trig_eps, nbr_thr,
+            tile_collisions<G, WV, PED>(present, pose, velx, vely, (t + timestep) - t, bcx, bcy, rad_thr, trig_eps, nbr_thr,
                                         cell_inv, is_ped_type, sl, tile0, lds, tmp_rows, mult_rows, nbr);
         }
 #pragma unroll
@@ -1439,10 +1543,16 @@ __global__ __launch_bounds__(64 * WV, PED ? 1 : (TAB ? SG_WAVES_PER_SIMD_TAB : S
                         const double bl = lds.boxwl[1][sl];
                         double sin_h, cos_h; // of the current heading
                         sg_sincos(pose[3], sin_h, cos_h, K);
+                        // controller parameters: LDS table; pedestrian scenes keep only the pedestrian rows in LDS and
+                        // read these (rare lanes there) from the static rows
+                        LanePtr st_c = st;
+                        auto cp = [&](int q) -> double {
+                            return PED ? fld(st_c, ST_CTRL + q) : lds.ctrl[PED ? 0 : q][sl];
+                        };
                         if (kind == SG_KIND_AGENT_PID)
-                            pid_step(cs, lds, sl, bl, state_dt, dt, tx, ty, sin_h, cos_h, np_, K);
+                            pid_step(cs, cp, bl, state_dt, dt, tx, ty, sin_h, cos_h, np_, K);
                         else
-                            vehicle_step(cs, lds, sl, bl, dt, act_a, act_s, sin_h, cos_h, np_, K);
+                            vehicle_step(cs, cp, bl, dt, act_a, act_s, sin_h, cos_h, np_, K);
                     } else if (PED)
                         ped_step<WV>(p, lds, sl, tile0, nbr, pose, velx, vely, t, next_t, state_dt, wp, nwp, goal_idx,
                                      cs.speed, fpx, fpy, np_, K);
@@ -1546,7 +1656,7 @@ __global__ __launch_bounds__(64 * WV, PED ? 1 : (TAB ? SG_WAVES_PER_SIMD_TAB : S
 #pragma unroll
         for (int w = 0; w < WV; ++w) nrow[w] = 0;
 #else
-        tile_collisions<G, WV, PED>(present, pose, velx, vely, bcx, bcy, rad_thr, trig_eps, nbr_thr, cell_inv, is_ped_type,
+        tile_collisions<G, WV, PED>(present, pose, velx, vely, (t + timestep) - t, bcx, bcy, rad_thr, trig_eps, nbr_thr, cell_inv, is_ped_type,
                                     sl, tile0, lds, nrow, mult_rows, nbr);
 #endif
         if (run) {
@@ -1751,10 +1861,11 @@ __global__ __launch_bounds__(64) void control_kernel(Params p, double timestep, 
             for (int c = 0; c < 6; ++c) np_[c] = pose[c];
             double sin_h, cos_h;
             sg_sincos(pose[3], sin_h, cos_h, K);
+            auto cp = [&](int q) -> double { return lds.ctrl[q][lane]; };
             if (kind == SG_KIND_AGENT_PID)
-                pid_step(cs, lds, lane, bl, state_dt, dt, tx, ty, sin_h, cos_h, np_, K);
+                pid_step(cs, cp, bl, state_dt, dt, tx, ty, sin_h, cos_h, np_, K);
             else
-                vehicle_step(cs, lds, lane, bl, dt, act_a, act_s, sin_h, cos_h, np_, K);
+                vehicle_step(cs, cp, bl, dt, act_a, act_s, sin_h, cos_h, np_, K);
         } else if (active && min_t >= t) { // spawn at the trajectory position
             npres = true;
         }

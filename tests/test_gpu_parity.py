@@ -448,6 +448,37 @@ def test_crowd_matches_oracle(sga, oracle, R, E, steps, side):
     assert (rows["n_collisions"] > 0).any()
 
 
+@pytest.mark.parametrize("sf", [
+    dict(ped_attract_C=0.05),                                   # attraction on: both sight weights are evaluated
+    dict(sight_weight_use=False, ped_attract_C=0.02),           # reference adds attraction before repulsion
+    dict(relaxation_time=0.8, ped_repulse_V=2.0, ped_repulse_sigma=0.7, sight_weight=0.3, sight_angle=120),
+])
+def test_crowd_with_non_default_social_force(sga, oracle, sf):
+    """The generic neighbour terms (head rotation != 0, attraction, sight weights on/off, other constants): the
+    default-parameter shortcuts of the kernel must not be taken, results stay bit-identical to the oracle."""
+    import scenario_gym_amd._lib as L
+    from scenario_gym_amd import synthetic
+
+    R, E, steps = 12, 48, 90
+    packed = synthetic.make_crowd(R, E, n_steps=steps, side=10.0)
+    rng = np.random.default_rng(11)
+    packed.ctrl[:, L.C_PED_HEAD_ROT] = rng.uniform(-0.6, 0.6, R * E)  # PedestrianAgent(head_rot_angle=...)
+    eng = sga.RolloutEngine(R, E, record_capacity=steps + 1, event_capacity=256, social_force=sf)
+    eng.upload(packed)
+    eng.rollout(steps)
+    st = eng.state()
+    rows, events = eng.metrics()
+    t, poses = eng.record(steps + 1)
+    eng.close()
+    for r in range(R):
+        o = _oracle_one(oracle, packed, r, 1 / 30, steps, sf=oracle.social_force_params(**sf))
+        n = o["n_steps"]
+        assert rows["n_steps"][r] == n, r
+        assert bits_equal(poses[: n + 1, r], o["poses"]), r
+        assert bits_equal(st["force"][r], o["extra"][-1, :, 2:]), r
+        assert np.array_equal(_dense_words(st["coll"][r], E), oracle.coll_to_dense(o["coll"], E)[-1]), r
+
+
 def test_pedestrian_stepwise_equals_single_launch(sga):
     """gym.step() one launch per step reproduces the single-launch rollout (neighbour candidates and
     goal indices survive the kernel boundary)."""
