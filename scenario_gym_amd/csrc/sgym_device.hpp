@@ -1770,12 +1770,14 @@ __global__ __launch_bounds__(64 * WV, PED ? SG_WAVES_PER_SIMD_PED : (TAB ? SG_WA
 // both paths produce identical bits.  The lane assumes its scenario keeps running; a scenario that
 // terminates early simply stops consuming the table.
 //   first: take the lane state from the state blocks (start of an API call); otherwise from
-//          p.ctl_state (previous chunk of the same call).   k0: step offset into `actions`.
+//          p.ctl_state (previous launch of the same call).   k0: step offset into `actions`.
+//   row0:  first table row this launch writes (a chunk of the table is filled by several short launches, so
+//          that the 64 wavefronts of the pre-pass do not sit on the same SIMDs for a whole chunk).
 // ------------------------------------------------------------------------------------------------
 struct CtlLds { double ctrl[9][64]; };
 
 __global__ __launch_bounds__(64) void control_kernel(Params p, double timestep, int n_steps, int first, int k0,
-                                                     const double *actions /*[n][R][2]*/, double *tab)
+                                                     const double *actions /*[n][R][2]*/, double *tab, int row0)
 {
     __shared__ CtlLds lds;
     const int lane = threadIdx.x;
@@ -1826,7 +1828,7 @@ __global__ __launch_bounds__(64) void control_kernel(Params p, double timestep, 
     Segment S;
     S.cur = seg_locate(T, t);
     seg_load(T, S);
-    double *out = tab + q * ((size_t)(p.tab_steps + 1) * CT_W);                      // plane 0 rows of this lane
+    double *out = tab + (q * (size_t)(p.tab_steps + 1) + (size_t)row0) * CT_W;      // plane 0 rows of this lane
     double *out1 = out + (size_t)p.n_ctl_pad * ((size_t)(p.tab_steps + 1) * CT_W); // plane 1
     sg_loads_done();
 

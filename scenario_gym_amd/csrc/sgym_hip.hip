@@ -41,6 +41,7 @@ struct sg_handle {
     double *d_tab[2] = {nullptr, nullptr};
     std::vector<hipEvent_t> ev_pool;
     int tab_min = 16, chunk_steps = 1024, overlap = 1; // sg_set_tuning
+    int ctl_slice = 64;                                // steps per control_kernel launch (env SG_CTL_SLICE)
     int n_launches = 0;           // rollout_kernel launches of the last call
     std::vector<int> launch_ev;   // their (start, stop) event indices into ev_pool
     std::string err;
@@ -142,6 +143,7 @@ extern "C" int sg_create(const sg_config *cfg, sg_handle **out)
     h->tab_min = env_int("SG_TAB_MIN_STEPS", h->tab_min);
     h->chunk_steps = env_int("SG_CHUNK_STEPS", h->chunk_steps);
     h->overlap = env_int("SG_OVERLAP", h->overlap);
+    h->ctl_slice = std::max(1, env_int("SG_CTL_SLICE", h->ctl_slice));
     if (hipSetDevice(cfg->device) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess ||
         hipStreamCreate(&h->ctl_stream) != hipSuccess ||
         hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {
@@ -286,7 +288,11 @@ static int launch_rollout(sg_handle *h, int n_steps, int do_reset, int force, co
                 const int n = std::min(ch, n_steps - k0);
                 double *tab = h->d_tab[c & 1];
                 if (!no_overlap && c >= 2) HIP_TRY(h, hipStreamWaitEvent(cs, main_done[c - 2], 0)); // table buffer free
-                sg::control_kernel<<<cgrid, cblock, 0, cs>>>(h->p, h->cfg.timestep, n, c == 0, k0, d_actions, tab);
+                for (int s0 = 0; s0 < n; s0 += h->ctl_slice) { // short launches: the pre-pass load moves between SIMDs
+                    const int ns = std::min(h->ctl_slice, n - s0);
+                    sg::control_kernel<<<cgrid, cblock, 0, cs>>>(h->p, h->cfg.timestep, ns, c == 0 && s0 == 0, k0 + s0,
+                                                                 d_actions, tab, s0);
+                }
                 HIP_TRY(h, hipGetLastError());
                 if (!no_overlap) {
                     if ((rc = get_event(h, ev_next++, &e))) return rc;
