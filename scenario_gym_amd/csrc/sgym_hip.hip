@@ -283,9 +283,10 @@ static int launch_rollout(sg_handle *h, int n_steps, int do_reset, int force, co
             }
             std::vector<hipEvent_t> main_done;
             const dim3 cgrid((unsigned)(np / 64)), cblock(64);
+            // the first chunk is short: the rollout kernel cannot start before its table exists
             int c = 0;
-            for (int k0 = 0; k0 < n_steps; k0 += ch, ++c) {
-                const int n = std::min(ch, n_steps - k0);
+            for (int k0 = 0, n = 0; k0 < n_steps; k0 += n, ++c) {
+                n = std::min(c == 0 ? std::min(ch, 2 * h->ctl_slice) : ch, n_steps - k0);
                 double *tab = h->d_tab[c & 1];
                 if (!no_overlap && c >= 2) HIP_TRY(h, hipStreamWaitEvent(cs, main_done[c - 2], 0)); // table buffer free
                 for (int s0 = 0; s0 < n; s0 += h->ctl_slice) { // short launches: the pre-pass load moves between SIMDs
