@@ -24,6 +24,9 @@
 #define SG_WAVES_PER_SIMD 2 // register budget of the rollout kernel: 512 / SG_WAVES_PER_SIMD VGPRs per lane
 #endif
 // controlled lanes per wavefront the table variant of the rollout kernel serves: one per scenario of the wavefront, at most 4
+#ifndef SG_CTL_WAVES
+#define SG_CTL_WAVES 5 // control_kernel: <= 96 VGPRs, so that one of its wavefronts fits beside two of the rollout kernel (2 x 200 + 96 <= 512)
+#endif
 #ifndef SG_WAVES_PER_SIMD_PED
 #define SG_WAVES_PER_SIMD_PED 2 // pedestrian variant
 #endif
@@ -83,8 +86,10 @@ struct Params {
 // [n_ctl_pad][tab_steps + 1][4] doubles (the steps of one lane are contiguous: 32 B per step, so the scalar loads of
 // two consecutive steps share a cache line):
 //   plane 0: x, y, h after step k, controller speed      plane 1: e_lon_prev, e_lat_prev, e_lon_int, unused
-enum { CT_X = 0, CT_Y, CT_H, CT_SPEED, CT_W = 4, CT_ELON = 0, CT_ELAT, CT_EINT };
-enum { CS_POSE = 0, CS_PRESENT = 6, CS_CTRL = 7, CS_T = 11, CS_PREV_T = 12, CS_COUNT = 13 };
+//   plane 2 (lanes that are their scenario's ego): EgoAvgSpeed, EgoMaxSpeed, EgoAvgSpeed.t after step k
+// Planes 1 and 2 are read once, at the row of the last step the scenario executed.
+enum { CT_X = 0, CT_Y, CT_H, CT_SPEED, CT_W = 4, CT_ELON = 0, CT_ELAT, CT_EINT, CT_MAVG = 0, CT_MMAX, CT_MT, CT_PLANES = 3 };
+enum { CS_POSE = 0, CS_PRESENT = 6, CS_CTRL = 7, CS_T = 11, CS_PREV_T = 12, CS_METRIC = 13, CS_COUNT = 16 };
 
 // Lane pointers into one 64-slot block.  Global loads/stores carry an immediate offset (the compiler
 // only uses 0..4095 of it), so a lane keeps three 64-bit addresses per block -- rows 0-7, 8-15 and
@@ -438,7 +443,7 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 
 // Workgroup-shared tile data.  NS = slots of the tile set a workgroup owns: 64 when one wavefront
 // carries 64/G scenarios (WV = 1), 64*WV when WV wavefronts carry one scenario of up to 64*WV entities.
-template <int NS, bool PED>
+template <int NS, bool PED, bool TAB = false>
 struct TileLds {
     float cx[NS], cy[NS];   // box centres (NaN when absent), SoA for packed-fp32 pair math
     float2 sc[NS];          // sin, cos of the heading
@@ -460,6 +465,10 @@ struct TileLds {
     // broad-phase stripe masks: bit set of the slots whose centre lies in x- (y-) stripe k (mod 64)
     unsigned long long xtab[64][NS / 64], ytab[64][NS / 64];
     float2 cen[NS];         // box centres again, interleaved, for single-read gathers
+    // table variant: the ego metric accumulators (EgoAvgSpeed, EgoMaxSpeed, EgoAvgSpeed.t) of the lanes that still
+    // update them in this kernel live here, not in 6 VGPRs: with <= 192 VGPRs two wavefronts of this kernel leave room
+    // for one of control_kernel on the same SIMD
+    double met[TAB ? 3 : 1][TAB ? NS : 1];
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -1202,14 +1211,17 @@ __device__ __forceinline__ Table lane_table(const Params &p, int kind, const Sce
 //
 // TAB: the PID / vehicle agents were integrated by control_kernel; their lanes read (x, y, h) per step from
 // its table `tab` instead of running the controller with 1 of 64 lanes active.  TAB launches never reset.
+// Register budgets: 2 wavefronts of the table variant (<= 192 VGPRs each) + 1 of control_kernel (<= 128) fill the 512
+// VGPRs of a SIMD exactly, so the pre-pass of the next chunk is co-resident instead of waiting for a rollout wavefront
+// to retire.
 template <int G, int WV, bool PED, bool TAB>
-__global__ __launch_bounds__(64 * WV, PED ? SG_WAVES_PER_SIMD_PED : (TAB ? SG_WAVES_PER_SIMD_TAB : SG_WAVES_PER_SIMD)) void rollout_kernel(
-    Params p, double timestep, int n_steps, int do_reset, int force, const double *actions /*[n][R][2]*/,
-    const double *tab /*[n][CT_COUNT][n_ctl_pad]*/)
+__device__ __forceinline__ void rollout_body(
+    const Params &p, double timestep, int n_steps, int do_reset, int force, const double *actions /*[n][R][2]*/,
+    const double *tab /*controller table planes*/)
 {
     static_assert(!(PED && TAB), "pedestrian scenarios run their controllers in the rollout kernel");
     constexpr int NS = 64 * WV;
-    __shared__ TileLds<NS, PED> lds;
+    __shared__ TileLds<NS, PED, TAB> lds;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t voff = lane * 8u;
     // one wavefront = one 64-slot block of the state arrays: wave-uniform block pointers
@@ -1425,6 +1437,7 @@ __global__ __launch_bounds__(64 * WV, PED ? SG_WAVES_PER_SIMD_PED : (TAB ? SG_WA
         }
         goal_idx = PED ? (int)cs.e_lon_prev : 0; // pedestrians keep goal_idx in the second controller row
         m_avg = sd.ego_avg_speed; m_max = sd.ego_max_speed; m_t = sd.avg_t;
+        if (TAB) { lds.met[0][sl] = m_avg; lds.met[1][sl] = m_max; lds.met[2][sl] = m_t; }
 #pragma unroll
         for (int w = 0; w < WV; ++w) last_row[w] = sd.last_row[w];
         n_ev = sd.n_events;
@@ -1642,12 +1655,20 @@ __global__ __launch_bounds__(64 * WV, PED ? SG_WAVES_PER_SIMD_PED : (TAB ? SG_WA
                 if (slot == 0) { p.rec_t[(size_t)steps * p.R + r] = t; sd.rec_rows = steps + 1; }
             }
             // ---- ego metrics, scenario_gym.py:251-252 ----
-            if (is_ego && present) {
+            if (is_ego && present && !tab_lane) { // a controlled ego's metrics come with its table (control_kernel)
                 double speed = sg_norm3(vel[0], vel[1], vel[2]);
-                double w = m_t / t; // EgoAvgSpeed._step, metrics/trajectory.py:19-24
-                m_avg += (1.0 - w) * (speed - m_avg);
-                m_t = t;
-                m_max = __builtin_fmax(speed, m_max); // EgoMaxSpeed, :41-44
+                if (TAB) {
+                    double a = lds.met[0][sl];
+                    double w = lds.met[2][sl] / t;
+                    lds.met[0][sl] = a + (1.0 - w) * (speed - a);
+                    lds.met[2][sl] = t;
+                    lds.met[1][sl] = __builtin_fmax(speed, lds.met[1][sl]);
+                } else {
+                    double w = m_t / t; // EgoAvgSpeed._step, metrics/trajectory.py:19-24
+                    m_avg += (1.0 - w) * (speed - m_avg);
+                    m_t = t;
+                    m_max = __builtin_fmax(speed, m_max); // EgoMaxSpeed, :41-44
+                }
             }
         }
         // ---- State.collisions ----
@@ -1744,6 +1765,10 @@ __global__ __launch_bounds__(64 * WV, PED ? SG_WAVES_PER_SIMD_PED : (TAB ? SG_WA
                 const double *lr1 = lr + (size_t)p.n_ctl_pad * tab_lane_stride; // plane 1
                 stf(dy, SG_F_CTRL + 0, lr[CT_SPEED]); stf(dy, SG_F_CTRL + 1, lr1[CT_ELON]);
                 stf(dy, SG_F_CTRL + 2, lr1[CT_ELAT]); stf(dy, SG_F_CTRL + 3, lr1[CT_EINT]);
+                if (is_ego) { // ego metrics after the last executed step
+                    const double *lr2 = lr1 + (size_t)p.n_ctl_pad * tab_lane_stride; // plane 2
+                    m_avg = lr2[CT_MAVG]; m_max = lr2[CT_MMAX]; m_t = lr2[CT_MT];
+                }
             }
         } else {
             stf(dy, SG_F_CTRL + 0, cs.speed); stf(dy, SG_F_CTRL + 1, cs.e_lon_prev);
@@ -1751,6 +1776,7 @@ __global__ __launch_bounds__(64 * WV, PED ? SG_WAVES_PER_SIMD_PED : (TAB ? SG_WA
         }
         if (slot == 0) { sd.t = t; sd.prev_t = prev_t; sd.done = done; sd.n_steps = steps; }
         if (is_ego) {
+            if (TAB && !(tab_lane && last_k >= 0)) { m_avg = lds.met[0][sl]; m_max = lds.met[1][sl]; m_t = lds.met[2][sl]; }
             sd.ego_avg_speed = m_avg; sd.ego_max_speed = m_max; sd.avg_t = m_t;
             if (steps > 0 && present) sd.ego_distance_travelled = dist; // EgoDistanceTravelled, :60-62
 #pragma unroll
@@ -1758,6 +1784,23 @@ __global__ __launch_bounds__(64 * WV, PED ? SG_WAVES_PER_SIMD_PED : (TAB ? SG_WA
             sd.n_events = n_ev;
         }
     }
+}
+
+template <int G, int WV, bool PED, bool TAB>
+__global__ __launch_bounds__(64 * WV, PED ? SG_WAVES_PER_SIMD_PED : (TAB ? SG_WAVES_PER_SIMD_TAB : SG_WAVES_PER_SIMD)) void rollout_kernel(
+    Params p, double timestep, int n_steps, int do_reset, int force, const double *actions, const double *tab)
+{
+    rollout_body<G, WV, PED, TAB>(p, timestep, n_steps, do_reset, force, actions, tab);
+}
+
+// The table variant with one wavefront per tile (C2 / C3 shapes) under a 192-VGPR cap: two of its wavefronts and one of
+// control_kernel (<= 128) fill the 512 VGPRs of a SIMD exactly, so the pre-pass of the next chunk is co-resident with
+// the rollout kernel instead of waiting for one of its wavefronts to retire.
+template <int G>
+__global__ __launch_bounds__(64, 2) void rollout_kernel_tab(
+    Params p, double timestep, int n_steps, int do_reset, int force, const double *actions, const double *tab)
+{
+    rollout_body<G, 1, false, true>(p, timestep, n_steps, do_reset, force, actions, tab);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1774,9 +1817,12 @@ __global__ __launch_bounds__(64 * WV, PED ? SG_WAVES_PER_SIMD_PED : (TAB ? SG_WA
 //   row0:  first table row this launch writes (a chunk of the table is filled by several short launches, so
 //          that the 64 wavefronts of the pre-pass do not sit on the same SIMDs for a whole chunk).
 // ------------------------------------------------------------------------------------------------
-struct CtlLds { double ctrl[9][64]; };
+// controller parameters and the x / y channels of the knot segment (x_lo, y_lo[2], slope[2]: the PID target) of every
+// lane: own column only, no barriers.  With the segment out of the VGPRs (and the LDS under 8 KB per wavefront) the
+// kernel compiles for 5 wavefronts per SIMD = 96 VGPRs, which is what fits beside two wavefronts of the rollout kernel.
+struct CtlLds { double ctrl[9][64]; double seg[5][64]; };
 
-__global__ __launch_bounds__(64) void control_kernel(Params p, double timestep, int n_steps, int first, int k0,
+__global__ __launch_bounds__(64, SG_CTL_WAVES) void control_kernel(Params p, double timestep, int n_steps, int first, int k0,
                                                      const double *actions /*[n][R][2]*/, double *tab, int row0)
 {
     __shared__ CtlLds lds;
@@ -1791,18 +1837,22 @@ __global__ __launch_bounds__(64) void control_kernel(Params p, double timestep, 
     const int64_t meta = fld<int64_t>(st, ST_META);
     const int kind = active ? (int)(meta & 0xff) : SG_KIND_NONE;
     const double min_t = fld(st, ST_MIN_T), bl = fld(st, ST_BL);
+    // the scenario's ego: its EgoAvgSpeed / EgoMaxSpeed recurrences (metrics/trajectory.py:8-48) run here as well
+    const bool is_ego = active && (int)(ent - r * (uint32_t)p.EP) == p.sstat[r].ego;
 #pragma unroll
     for (int c = 0; c < 9; ++c) lds.ctrl[c][lane] = fld(st, ST_CTRL + c); // own column only: no barrier needed
     const size_t NP = (size_t)p.n_ctl_pad;
     double *cst = p.ctl_state + q;
 
     double pose[6], t, prev_t;
+    double m_avg, m_max, m_t;
     bool present;
     CtrlState cs;
     if (first) {
         const sg_scenario_state &sd = p.sdyn[r];
         t = sd.t;
         prev_t = sd.prev_t;
+        m_avg = sd.ego_avg_speed; m_max = sd.ego_max_speed; m_t = sd.avg_t;
         present = fld<uint64_t>(dy, SG_F_PRESENT) != 0;
 #pragma unroll
         for (int c = 0; c < 6; ++c) pose[c] = fld(dy, SG_F_POSE + c);
@@ -1816,6 +1866,7 @@ __global__ __launch_bounds__(64) void control_kernel(Params p, double timestep, 
         cs.e_lat_prev = cst[(CS_CTRL + 2) * NP]; cs.e_lon_int = cst[(CS_CTRL + 3) * NP];
         t = cst[CS_T * NP];
         prev_t = cst[CS_PREV_T * NP];
+        m_avg = cst[(CS_METRIC + 0) * NP]; m_max = cst[(CS_METRIC + 1) * NP]; m_t = cst[(CS_METRIC + 2) * NP];
     }
     if (!active) present = false;
 
@@ -1825,11 +1876,24 @@ __global__ __launch_bounds__(64) void control_kernel(Params p, double timestep, 
         T.x = kn; T.xs = 7; T.y = kn + 1; T.ys = 7; T.cs = 1;
         T.n = active ? (int)(meta >> 32) : 0;
     }
-    Segment S;
-    S.cur = seg_locate(T, t);
-    seg_load(T, S);
+    double seg_hi;
+    int seg_cur;
+    auto seg_publish = [&](const Segment &S) {
+        lds.seg[0][lane] = S.x_lo;
+        lds.seg[1][lane] = S.ylo[0]; lds.seg[2][lane] = S.ylo[1];
+        lds.seg[3][lane] = S.sl[0]; lds.seg[4][lane] = S.sl[1];
+        seg_hi = S.x_hi;
+        seg_cur = S.cur;
+    };
+    {
+        Segment S;
+        S.cur = seg_locate(T, t);
+        seg_load(T, S);
+        seg_publish(S);
+    }
     double *out = tab + (q * (size_t)(p.tab_steps + 1) + (size_t)row0) * CT_W;      // plane 0 rows of this lane
     double *out1 = out + (size_t)p.n_ctl_pad * ((size_t)(p.tab_steps + 1) * CT_W); // plane 1
+    double *out2 = out1 + (size_t)p.n_ctl_pad * ((size_t)(p.tab_steps + 1) * CT_W); // plane 2
     sg_loads_done();
 
     for (int k = 0; k < n_steps; ++k) {
@@ -1845,16 +1909,18 @@ __global__ __launch_bounds__(64) void control_kernel(Params p, double timestep, 
             act_a = a[0];
             act_s = a[1];
         }
-        if (next_t > S.x_hi) {
+        if (next_t > seg_hi) {
+            Segment S;
+            S.x_hi = seg_hi;
+            S.cur = seg_cur;
             seg_advance(T, S, next_t);
+            seg_publish(S);
             sg_loads_done();
         }
         double np_[6];
-        {
-            double dq = next_t - S.x_lo;
-#pragma unroll
-            for (int c = 0; c < 6; ++c) np_[c] = S.sl[c] * dq + S.ylo[c];
-        }
+        const double dq = next_t - lds.seg[0][lane];
+        np_[0] = lds.seg[3][lane] * dq + lds.seg[1][lane]; // PID target (x, y) at next_t
+        np_[1] = lds.seg[4][lane] * dq + lds.seg[2][lane];
         bool npres = false;
         if (present) {
             npres = true;
@@ -1868,8 +1934,31 @@ __global__ __launch_bounds__(64) void control_kernel(Params p, double timestep, 
                 pid_step(cs, cp, bl, state_dt, dt, tx, ty, sin_h, cos_h, np_, K);
             else
                 vehicle_step(cs, cp, bl, dt, act_a, act_s, sin_h, cos_h, np_, K);
-        } else if (active && min_t >= t) { // spawn at the trajectory position
+        } else if (active && min_t >= t) { // spawn at the trajectory position: all six channels of the bracket
             npres = true;
+            Segment S;
+            S.cur = seg_cur;
+            seg_load(T, S);
+            sg_loads_done();
+            const double dqs = next_t - S.x_lo;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) np_[c] = S.sl[c] * dqs + S.ylo[c];
+        }
+        if (is_ego && npres) { // State.update_statistics for this lane (state.py:230-239) + the ego metrics
+            double prev[6];
+            if (!present) { // newcomer: previous pose from the extrapolated trajectory, state.py:219-222
+                own_position_extrap(T.x, T.n, t, prev);
+                sg_loads_done();
+            } else {
+#pragma unroll
+                for (int c = 0; c < 6; ++c) prev[c] = pose[c];
+            }
+            const double v0 = (np_[0] - prev[0]) / dt, v1 = (np_[1] - prev[1]) / dt, v2 = (np_[2] - prev[2]) / dt;
+            const double speed = sg_norm3(v0, v1, v2);
+            const double w = m_t / next_t; // EgoAvgSpeed._step, metrics/trajectory.py:19-24
+            m_avg += (1.0 - w) * (speed - m_avg);
+            m_t = next_t;
+            m_max = __builtin_fmax(speed, m_max); // EgoMaxSpeed, :41-44
         }
         present = npres;
         if (npres) {
@@ -1880,6 +1969,7 @@ __global__ __launch_bounds__(64) void control_kernel(Params p, double timestep, 
         t = next_t;
         *reinterpret_cast<double4 *>(out + (size_t)k * CT_W) = make_double4(pose[0], pose[1], pose[3], cs.speed);
         *reinterpret_cast<double4 *>(out1 + (size_t)k * CT_W) = make_double4(cs.e_lon_prev, cs.e_lat_prev, cs.e_lon_int, 0.0);
+        if (is_ego) *reinterpret_cast<double4 *>(out2 + (size_t)k * CT_W) = make_double4(m_avg, m_max, m_t, 0.0);
     }
 #pragma unroll
     for (int c = 0; c < 6; ++c) cst[(CS_POSE + c) * NP] = pose[c];
@@ -1888,6 +1978,7 @@ __global__ __launch_bounds__(64) void control_kernel(Params p, double timestep, 
     cst[(CS_CTRL + 2) * NP] = cs.e_lat_prev; cst[(CS_CTRL + 3) * NP] = cs.e_lon_int;
     cst[CS_T * NP] = t;
     cst[CS_PREV_T * NP] = prev_t;
+    cst[(CS_METRIC + 0) * NP] = m_avg; cst[(CS_METRIC + 1) * NP] = m_max; cst[(CS_METRIC + 2) * NP] = m_t;
 }
 
 // sg_debug_trig32: the broad phase's hardware sin/cos, exposed so that the parity tests can bound its error

@@ -188,6 +188,8 @@ static void launch_variant(sg_handle *h, dim3 grid, int n_steps, int do_reset, i
     if (h->has_ped)
         sg::rollout_kernel<(WV > 1 || G >= 16) ? G : 16, WV, true, false><<<grid, block, 0, h->stream>>>(
             h->p, h->cfg.timestep, n_steps, do_reset, force, d_actions, nullptr);
+    else if (use_tab && WV == 1)
+        sg::rollout_kernel_tab<G><<<grid, block, 0, h->stream>>>(h->p, h->cfg.timestep, n_steps, 0, force, nullptr, d_tab);
     else if (use_tab)
         sg::rollout_kernel<G, WV, false, true><<<grid, block, 0, h->stream>>>(h->p, h->cfg.timestep, n_steps, 0, force,
                                                                                nullptr, d_tab);
@@ -260,7 +262,7 @@ static int launch_rollout(sg_handle *h, int n_steps, int do_reset, int force, co
             }
             rc = launch_main(h, n_steps, 0, force, nullptr, h->d_tab[0], true, &ev_next);
         } else {
-            const size_t np = (size_t)h->p.n_ctl_pad, row = (size_t)2 * sg::CT_W * np; // doubles per step, both planes
+            const size_t np = (size_t)h->p.n_ctl_pad, row = (size_t)sg::CT_PLANES * sg::CT_W * np; // doubles per step, all planes
             // chunk length: SG_CHUNK_STEPS, capped so that one table buffer stays under 1 GiB
             int ch = (int)std::min<size_t>((size_t)chunk_steps, std::max<size_t>(1, ((size_t)1 << 27) / row));
             ch = std::min(ch, n_steps);
@@ -283,10 +285,12 @@ static int launch_rollout(sg_handle *h, int n_steps, int do_reset, int force, co
             }
             std::vector<hipEvent_t> main_done;
             const dim3 cgrid((unsigned)(np / 64)), cblock(64);
-            // the first chunk is short: the rollout kernel cannot start before its table exists
+            // chunk lengths double from two slices up to `ch`: the rollout kernel cannot start before the table of
+            // its chunk exists, and the pre-pass of chunk c+1 (about 0.4x the rollout kernel's time per step) then
+            // always finishes under the rollout kernel of chunk c
             int c = 0;
             for (int k0 = 0, n = 0; k0 < n_steps; k0 += n, ++c) {
-                n = std::min(c == 0 ? std::min(ch, 2 * h->ctl_slice) : ch, n_steps - k0);
+                n = std::min(std::min(ch, c < 20 ? (2 * h->ctl_slice) << c : ch), n_steps - k0);
                 double *tab = h->d_tab[c & 1];
                 if (!no_overlap && c >= 2) HIP_TRY(h, hipStreamWaitEvent(cs, main_done[c - 2], 0)); // table buffer free
                 for (int s0 = 0; s0 < n; s0 += h->ctl_slice) { // short launches: the pre-pass load moves between SIMDs
