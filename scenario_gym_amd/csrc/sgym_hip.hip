@@ -618,13 +618,16 @@ extern "C" int sg_read_metrics(sg_handle *h, sg_metrics *out, sg_event *events, 
     }
     if (n_events) *n_events = (int32_t)total;
     if (events && cap > 0 && p.ev_cap > 0 && total > 0) {
-        std::vector<sg_event> all((size_t)R * p.ev_cap);
-        HIP_TRY(h, hipMemcpy(all.data(), p.events, all.size() * sizeof(sg_event), hipMemcpyDeviceToHost));
+        int width = 0; // only the columns in use travel over PCIe
+        for (int r = 0; r < R; ++r) width = std::max(width, std::min(sd[r].n_events, p.ev_cap));
+        std::vector<sg_event> all((size_t)R * width);
+        HIP_TRY(h, hipMemcpy2D(all.data(), (size_t)width * sizeof(sg_event), p.events, (size_t)p.ev_cap * sizeof(sg_event),
+                               (size_t)width * sizeof(sg_event), (size_t)R, hipMemcpyDeviceToHost));
         int64_t k = 0;
         for (int r = 0; r < R; ++r)
             for (int i = 0; i < std::min(sd[r].n_events, p.ev_cap); ++i) {
                 if (k >= cap) return fail(h, SG_ERR_CAPACITY, "sg_read_metrics: %lld events do not fit cap=%d", (long long)total, cap);
-                events[k++] = all[(size_t)r * p.ev_cap + i];
+                events[k++] = all[(size_t)r * width + i];
             }
     }
     // more than event_capacity events in one scenario: the count (n_collisions) is exact, the table keeps the first ones

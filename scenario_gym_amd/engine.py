@@ -220,18 +220,19 @@ class RolloutEngine:
             done=scen["done"].astype(bool), n_steps=scen["n_steps"].copy(),
         )
 
+    METRIC_DTYPE = np.dtype([("ego_avg_speed", "f8"), ("ego_max_speed", "f8"), ("ego_distance_travelled", "f8"),
+                             ("final_t", "f8"), ("n_steps", "i4"), ("done", "i4"), ("n_collisions", "i4"), ("reserved", "i4")])
+    EVENT_DTYPE = np.dtype([("t", "f8"), ("scenario", "i4"), ("other", "i4"), ("type", "i4"), ("reserved", "i4")])
+
     def metrics(self, event_cap=None):
-        m = (L.SgMetrics * self.R)()
+        """(per-scenario metric rows, CollisionMetric events) as structured arrays (sg_metrics / sg_event layout)."""
         cap = self.R * max(self.cfg.event_capacity, 1) if event_cap is None else int(event_cap)
-        ev = (L.SgEvent * cap)()
+        rows = np.empty(self.R, self.METRIC_DTYPE)   # uninitialised host buffers: the library fills what it reports
+        ev = np.empty(cap, self.EVENT_DTYPE)
         n_ev = C.c_int32()
-        self._check(self.lib.sg_read_metrics(self.h, m, ev, cap, C.byref(n_ev)), "sg_read_metrics")
-        rows = np.frombuffer(m, dtype=np.dtype([
-            ("ego_avg_speed", "f8"), ("ego_max_speed", "f8"), ("ego_distance_travelled", "f8"),
-            ("final_t", "f8"), ("n_steps", "i4"), ("done", "i4"), ("n_collisions", "i4"), ("reserved", "i4")])).copy()
-        events = np.frombuffer(ev, dtype=np.dtype([
-            ("t", "f8"), ("scenario", "i4"), ("other", "i4"), ("type", "i4"), ("reserved", "i4")]))[: n_ev.value].copy()
-        return rows, events
+        self._check(self.lib.sg_read_metrics(self.h, rows.ctypes.data_as(C.POINTER(L.SgMetrics)),
+                                             ev.ctypes.data_as(C.POINTER(L.SgEvent)), cap, C.byref(n_ev)), "sg_read_metrics")
+        return rows, ev[: n_ev.value].copy()
 
     def record(self, n_rows):
         """State.recorded_poses for the whole batch: t [n, R], poses [n, R, E, 6]."""
