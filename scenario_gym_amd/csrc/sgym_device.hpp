@@ -25,7 +25,7 @@
 #endif
 // controlled lanes per wavefront the table variant of the rollout kernel serves: one per scenario of the wavefront, at most 4
 #ifndef SG_CTL_WAVES
-#define SG_CTL_WAVES 5 // control_kernel: <= 96 VGPRs, so that one of its wavefronts fits beside two of the rollout kernel (2 x 200 + 96 <= 512)
+#define SG_CTL_WAVES 4 // control_kernel: <= 128 VGPRs; two wavefronts of rollout_kernel_tab (<= 192 each) + one of these fill a SIMD's 512
 #endif
 #ifndef SG_WAVES_PER_SIMD_PED
 #define SG_WAVES_PER_SIMD_PED 2 // pedestrian variant
@@ -1459,21 +1459,9 @@ __device__ __forceinline__ void rollout_body(
         seg_load(T, S);
     }
 
-    // controller table row of the coming step in the controlled lanes' registers
-    double tb_x = 0.0, tb_y = 0.0, tb_h = 0.0;
-    auto tab_commit = [&]() {
-#pragma unroll
-        for (int j = 0; j < TL; ++j) { // wave-uniform values into one lane: v_cmp + v_cndmask with scalar sources
-            const bool me = lane == cl[j];
-            tb_x = me ? sx[j] : tb_x;
-            tb_y = me ? sy[j] : tb_y;
-            tb_h = me ? sh[j] : tb_h;
-        }
-    };
-    if (TAB && n_steps > 0) {
-        tab_issue();
-        tab_commit();
-    }
+    // The row of the coming step waits in SGPRs (sx, sy, sh); the step selects it into the controlled lane with
+    // scalar-source v_cndmask and then issues the loads of the row after it.
+    if (TAB && n_steps > 0) tab_issue();
 
     // Two nested loops over the same step counter.  The inner one is the steady state and only READS the knot
     // segment S; when some lane's clock is about to cross a knot the wavefront drops to the outer loop, which
@@ -1499,8 +1487,6 @@ __device__ __forceinline__ void rollout_body(
         if (__any(t + timestep > S.x_hi)) break;
         const bool run = in_range && (force || !done);
         if (!block_any<WV>(run)) { all_done = true; break; }
-        const double cx_ = tb_x, cy_ = tb_y, ch_ = tb_h;
-        if (TAB) tab_issue(); // row k + 1 (the table has one spare row), consumed by tab_commit() at the end of this step
         // coefficient table: opaque per step so the scalar loads stay inside the loop (SGPRs for a few
         // dozen instructions instead of VGPRs for the whole kernel); constant address space => s_load
         const double *Kp = SG_TRIG;
@@ -1537,12 +1523,17 @@ __device__ __forceinline__ void rollout_body(
             const bool np_agent = present | (min_t >= t);
             npres = (is_replay & np_replay) | (is_agent & np_agent);
             const bool take = tab_lane & present & run;
-            np_[0] = take ? cx_ : np_[0];
-            np_[1] = take ? cy_ : np_[1];
+#pragma unroll
+            for (int j = 0; j < TL; ++j) { // wave-uniform table row into its lane: v_cndmask with scalar sources
+                const bool tj = take & (lane == cl[j]);
+                np_[0] = tj ? sx[j] : np_[0];
+                np_[1] = tj ? sy[j] : np_[1];
+                np_[3] = tj ? sh[j] : np_[3];
+            }
             np_[2] = take ? pose[2] : np_[2];
-            np_[3] = take ? ch_ : np_[3];
             np_[4] = take ? pose[4] : np_[4];
             np_[5] = take ? pose[5] : np_[5];
+            tab_issue(); // row k + 1 (the table has one spare row), consumed by the next step
         } else if (kind == SG_KIND_REPLAY) { // BatchReplayEntity.step, batch.py:34-53
             npres = p.persist || is_static || (next_t >= min_t && next_t <= max_t);
         } else if (is_agent) {
@@ -1749,10 +1740,7 @@ __device__ __forceinline__ void rollout_body(
                 last_row[w] = row[w];
             }
         }
-        if (TAB) {
-            tab_commit();
-            sg_lgkm_done();
-        }
+        if (TAB) sg_lgkm_done();
     }
     }
 
