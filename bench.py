@@ -65,12 +65,13 @@ def cpu_baseline(workload, seconds_budget=20.0):
     }
 
 
-def kernel_name(E, crowd):
-    """Entry point the library launches for this shape (sgym_hip.hip launch_variant): tile lanes G, wavefronts per tile."""
+def kernel_name(E, crowd, controlled):
+    """Entry point the library launches for this shape (sgym_hip.hip launch_variant): tile lanes G, wavefronts per tile;
+    `controlled`: the batch has PID / vehicle agents (their pre-pass table is replayed by rollout_kernel_tab)."""
     G, WV = min(64, max(4, 1 << (E - 1).bit_length())), (1 if E <= 64 else 2 if E <= 128 else 4)
     if crowd:
         return f"sg::rollout_kernel<{max(G, 16) if WV == 1 else G}, {WV}, true, false>"
-    return f"sg::rollout_kernel_tab<{G}>" if WV == 1 else f"sg::rollout_kernel<{G}, {WV}, false, true>"
+    return f"sg::rollout_kernel_tab<{G}>" if (WV == 1 and controlled) else f"sg::rollout_kernel<{G}, {WV}, false, true>"
 
 
 def measured_traffic(R, E, T, launches_per_rollout=1.0):
@@ -206,7 +207,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(R, E, T, n_launches / args.steps),
-                "kernel": kernel_name(E, crowd),
+                "kernel": kernel_name(E, crowd, ego_kind == L.KIND_AGENT_PID),
                 "kernel_ms": avg_ms, "launches_per_rollout": n_launches / args.steps, "rollout_device_ms": rollout_ms,
                 "bytes_per_entity_step": b_alg, "entity_steps_per_launch": per_launch,
             },

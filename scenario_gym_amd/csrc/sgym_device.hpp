@@ -443,7 +443,7 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 
 // Workgroup-shared tile data.  NS = slots of the tile set a workgroup owns: 64 when one wavefront
 // carries 64/G scenarios (WV = 1), 64*WV when WV wavefronts carry one scenario of up to 64*WV entities.
-template <int NS, bool PED, bool TAB = false>
+template <int NS, bool PED>
 struct TileLds {
     float cx[NS], cy[NS];   // box centres (NaN when absent), SoA for packed-fp32 pair math
     float2 sc[NS];          // sin, cos of the heading
@@ -465,10 +465,6 @@ struct TileLds {
     // broad-phase stripe masks: bit set of the slots whose centre lies in x- (y-) stripe k (mod 64)
     unsigned long long xtab[64][NS / 64], ytab[64][NS / 64];
     float2 cen[NS];         // box centres again, interleaved, for single-read gathers
-    // table variant: the ego metric accumulators (EgoAvgSpeed, EgoMaxSpeed, EgoAvgSpeed.t) of the lanes that still
-    // update them in this kernel live here, not in 6 VGPRs: with <= 192 VGPRs two wavefronts of this kernel leave room
-    // for one of control_kernel on the same SIMD
-    double met[TAB ? 3 : 1][TAB ? NS : 1];
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -1214,14 +1210,16 @@ __device__ __forceinline__ Table lane_table(const Params &p, int kind, const Sce
 // Register budgets: 2 wavefronts of the table variant (<= 192 VGPRs each) + 1 of control_kernel (<= 128) fill the 512
 // VGPRs of a SIMD exactly, so the pre-pass of the next chunk is co-resident instead of waiting for a rollout wavefront
 // to retire.
-template <int G, int WV, bool PED, bool TAB>
+// HAST (TAB only): the batch has controlled lanes, i.e. there is a table to replay; without it the table code is
+// compiled out (batches of replay entities only: the C2 shape).
+template <int G, int WV, bool PED, bool TAB, bool HAST>
 __device__ __forceinline__ void rollout_body(
     const Params &p, double timestep, int n_steps, int do_reset, int force, const double *actions /*[n][R][2]*/,
     const double *tab /*controller table planes*/)
 {
     static_assert(!(PED && TAB), "pedestrian scenarios run their controllers in the rollout kernel");
     constexpr int NS = 64 * WV;
-    __shared__ TileLds<NS, PED, TAB> lds;
+    __shared__ TileLds<NS, PED> lds;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t voff = lane * 8u;
     // one wavefront = one 64-slot block of the state arrays: wave-uniform block pointers
@@ -1323,15 +1321,15 @@ __device__ __forceinline__ void rollout_body(
     // The table rows are fetched with SCALAR loads, one controlled lane at a time (at most SG_TAB_LANES per
     // wavefront and wavefront of a wide scenario, checked by the host), one step ahead, and moved into the lane's registers at the end of the step.  A vector load inside the loop would share vmcnt with the state stores and make every
     // step wait for the stores of the previous one.
-    const int64_t ctl_q = TAB ? fld<int64_t>(st, ST_CTL) : -1;
-    const bool tab_lane = TAB && ctl_q >= 0 && (kind == SG_KIND_AGENT_PID || kind == SG_KIND_AGENT_VEHICLE);
+    const int64_t ctl_q = (TAB && HAST) ? fld<int64_t>(st, ST_CTL) : -1;
+    const bool tab_lane = TAB && HAST && ctl_q >= 0 && (kind == SG_KIND_AGENT_PID || kind == SG_KIND_AGENT_VEHICLE);
     const size_t tab_lane_stride = (size_t)(p.tab_steps + 1) * CT_W; // doubles per lane
     int last_k = -1;                                                 // last step of this launch the scenario executed
     constexpr int TL = SG_TAB_LANES(G, WV);
     int cl[TL];                       // wave-uniform: the controlled lanes of this wavefront
     const double *cb[TL];             // wave-uniform: their table columns
     double sx[TL], sy[TL], sh[TL];    // wave-uniform: row of the coming step
-    if (TAB) {
+    if (TAB && HAST) {
         uint64_t cm = __ballot(tab_lane);
 #pragma unroll
         for (int j = 0; j < TL; ++j) {
@@ -1437,7 +1435,6 @@ __device__ __forceinline__ void rollout_body(
         }
         goal_idx = PED ? (int)cs.e_lon_prev : 0; // pedestrians keep goal_idx in the second controller row
         m_avg = sd.ego_avg_speed; m_max = sd.ego_max_speed; m_t = sd.avg_t;
-        if (TAB) { lds.met[0][sl] = m_avg; lds.met[1][sl] = m_max; lds.met[2][sl] = m_t; }
 #pragma unroll
         for (int w = 0; w < WV; ++w) last_row[w] = sd.last_row[w];
         n_ev = sd.n_events;
@@ -1461,7 +1458,8 @@ __device__ __forceinline__ void rollout_body(
 
     // The row of the coming step waits in SGPRs (sx, sy, sh); the step selects it into the controlled lane with
     // scalar-source v_cndmask and then issues the loads of the row after it.
-    if (TAB && n_steps > 0) tab_issue();
+    constexpr bool has_tab = TAB && HAST;
+    if (has_tab && n_steps > 0) tab_issue();
 
     // Two nested loops over the same step counter.  The inner one is the steady state and only READS the knot
     // segment S; when some lane's clock is about to cross a knot the wavefront drops to the outer loop, which
@@ -1469,6 +1467,7 @@ __device__ __forceinline__ void rollout_body(
     // keeps two copies of S (28 VGPRs) and moves one onto the other on every step.
     int k = 0;
     bool all_done = false;
+    bool vel_clean_prev = false; // wave-uniform
     sg_loads_done(); // everything loaded so far is in its registers before the first store is issued
     sg_lgkm_done();
     while (k < n_steps && !all_done) {
@@ -1522,18 +1521,20 @@ __device__ __forceinline__ void rollout_body(
             const bool np_replay = replay_always | in_window;
             const bool np_agent = present | (min_t >= t);
             npres = (is_replay & np_replay) | (is_agent & np_agent);
-            const bool take = tab_lane & present & run;
+            if (has_tab) {
+                const bool take = tab_lane & present & run;
 #pragma unroll
-            for (int j = 0; j < TL; ++j) { // wave-uniform table row into its lane: v_cndmask with scalar sources
-                const bool tj = take & (lane == cl[j]);
-                np_[0] = tj ? sx[j] : np_[0];
-                np_[1] = tj ? sy[j] : np_[1];
-                np_[3] = tj ? sh[j] : np_[3];
+                for (int j = 0; j < TL; ++j) { // wave-uniform table row into its lane: v_cndmask with scalar sources
+                    const bool tj = take & (lane == cl[j]);
+                    np_[0] = tj ? sx[j] : np_[0];
+                    np_[1] = tj ? sy[j] : np_[1];
+                    np_[3] = tj ? sh[j] : np_[3];
+                }
+                np_[2] = take ? pose[2] : np_[2];
+                np_[4] = take ? pose[4] : np_[4];
+                np_[5] = take ? pose[5] : np_[5];
+                tab_issue(); // row k + 1 (the table has one spare row), consumed by the next step
             }
-            np_[2] = take ? pose[2] : np_[2];
-            np_[4] = take ? pose[4] : np_[4];
-            np_[5] = take ? pose[5] : np_[5];
-            tab_issue(); // row k + 1 (the table has one spare row), consumed by the next step
         } else if (kind == SG_KIND_REPLAY) { // BatchReplayEntity.step, batch.py:34-53
             npres = p.persist || is_static || (next_t >= min_t && next_t <= max_t);
         } else if (is_agent) {
@@ -1581,13 +1582,17 @@ __device__ __forceinline__ void rollout_body(
             for (int c = 0; c < 6; ++c) d[c] = np_[c] - pose[c];
         }
         double vel[6];
+        // z, pitch and roll rarely move.  `flat`: in every lane that commits a pose this step they keep their value
+        // (delta +0.0, entity already present).  Then +0 / dt (dt > 0) is +0 -- the three divisions and range checks
+        // are skipped -- and the state blocks already hold these pose rows (and, after one flat step, the +0 velocity
+        // rows): they are not stored again.  Memory stays the exact step-materialised state; a steady step issues 9
+        // row stores instead of 15.
+        bool flat;
         {
             RecipDiv rd(dt);
-            // z, pitch and roll rarely move: when their deltas are +0.0 in every lane, +0 / dt (dt > 0) is +0 and the
-            // three divisions and range checks are skipped
             const uint32_t zbits = (uint32_t)(__double2hiint(d[2]) | __double2hiint(d[4]) | __double2hiint(d[5])) |
                                    (uint32_t)(__double2loint(d[2]) | __double2loint(d[4]) | __double2loint(d[5]));
-            const bool flat = __all(zbits == 0 && dt > 0.0);
+            flat = __all((!run | !npres | (present & (zbits == 0))) & (dt > 0.0));
             bool safe = rd.safe(d[0]) & rd.safe(d[1]) & rd.safe(d[3]);
             if (!flat) safe = safe & rd.safe(d[2]) & rd.safe(d[4]) & rd.safe(d[5]);
             if (__all(safe)) {
@@ -1604,6 +1609,8 @@ __device__ __forceinline__ void rollout_body(
         }
 
         // commit (lanes of scenarios that are already done keep their state)
+        const bool vel_zpr_clean = vel_clean_prev; // did the previous step leave +0 in every stored z/pitch/roll velocity row?
+        vel_clean_prev = flat;
         if (run) {
             present = npres;
             if (npres) {
@@ -1618,11 +1625,13 @@ __device__ __forceinline__ void rollout_body(
             last_k = k;
             // ---- step-materialised state (everything except the collision row, see below) ----
 #ifndef SG_ABL_NO_STORES
-#pragma unroll
-            for (int c = 0; c < 6; ++c) stf(dy, SG_F_POSE + c, pose[c]);
+            stf(dy, SG_F_POSE + 0, pose[0]); stf(dy, SG_F_POSE + 1, pose[1]); stf(dy, SG_F_POSE + 3, pose[3]);
+            if (!flat) { stf(dy, SG_F_POSE + 2, pose[2]); stf(dy, SG_F_POSE + 4, pose[4]); stf(dy, SG_F_POSE + 5, pose[5]); }
             if (present) {
-#pragma unroll
-                for (int c = 0; c < 6; ++c) stf(dy, SG_F_VEL + c, vel[c]);
+                stf(dy, SG_F_VEL + 0, vel[0]); stf(dy, SG_F_VEL + 1, vel[1]); stf(dy, SG_F_VEL + 3, vel[3]);
+                if (!(flat && vel_zpr_clean)) { // the rows hold +0 since the previous flat step
+                    stf(dy, SG_F_VEL + 2, vel[2]); stf(dy, SG_F_VEL + 4, vel[4]); stf(dy, SG_F_VEL + 5, vel[5]);
+                }
             }
             stf(dy, SG_F_DIST, dist);
             stf(dy, SG_F_PRESENT, (uint64_t)present);
@@ -1648,18 +1657,10 @@ __device__ __forceinline__ void rollout_body(
             // ---- ego metrics, scenario_gym.py:251-252 ----
             if (is_ego && present && !tab_lane) { // a controlled ego's metrics come with its table (control_kernel)
                 double speed = sg_norm3(vel[0], vel[1], vel[2]);
-                if (TAB) {
-                    double a = lds.met[0][sl];
-                    double w = lds.met[2][sl] / t;
-                    lds.met[0][sl] = a + (1.0 - w) * (speed - a);
-                    lds.met[2][sl] = t;
-                    lds.met[1][sl] = __builtin_fmax(speed, lds.met[1][sl]);
-                } else {
-                    double w = m_t / t; // EgoAvgSpeed._step, metrics/trajectory.py:19-24
-                    m_avg += (1.0 - w) * (speed - m_avg);
-                    m_t = t;
-                    m_max = __builtin_fmax(speed, m_max); // EgoMaxSpeed, :41-44
-                }
+                double w = m_t / t; // EgoAvgSpeed._step, metrics/trajectory.py:19-24
+                m_avg += (1.0 - w) * (speed - m_avg);
+                m_t = t;
+                m_max = __builtin_fmax(speed, m_max); // EgoMaxSpeed, :41-44
             }
         }
         // ---- State.collisions ----
@@ -1740,7 +1741,7 @@ __device__ __forceinline__ void rollout_body(
                 last_row[w] = row[w];
             }
         }
-        if (TAB) sg_lgkm_done();
+        if (has_tab) sg_lgkm_done();
     }
     }
 
@@ -1764,7 +1765,6 @@ __device__ __forceinline__ void rollout_body(
         }
         if (slot == 0) { sd.t = t; sd.prev_t = prev_t; sd.done = done; sd.n_steps = steps; }
         if (is_ego) {
-            if (TAB && !(tab_lane && last_k >= 0)) { m_avg = lds.met[0][sl]; m_max = lds.met[1][sl]; m_t = lds.met[2][sl]; }
             sd.ego_avg_speed = m_avg; sd.ego_max_speed = m_max; sd.avg_t = m_t;
             if (steps > 0 && present) sd.ego_distance_travelled = dist; // EgoDistanceTravelled, :60-62
 #pragma unroll
@@ -1778,7 +1778,8 @@ template <int G, int WV, bool PED, bool TAB>
 __global__ __launch_bounds__(64 * WV, PED ? SG_WAVES_PER_SIMD_PED : (TAB ? SG_WAVES_PER_SIMD_TAB : SG_WAVES_PER_SIMD)) void rollout_kernel(
     Params p, double timestep, int n_steps, int do_reset, int force, const double *actions, const double *tab)
 {
-    rollout_body<G, WV, PED, TAB>(p, timestep, n_steps, do_reset, force, actions, tab);
+    // one wavefront per tile: this entry point serves the batches WITHOUT controlled lanes (rollout_kernel_tab the others)
+    rollout_body<G, WV, PED, TAB, (TAB && WV > 1)>(p, timestep, n_steps, do_reset, force, actions, tab);
 }
 
 // The table variant with one wavefront per tile (C2 / C3 shapes) under a 192-VGPR cap: two of its wavefronts and one of
@@ -1788,7 +1789,7 @@ template <int G>
 __global__ __launch_bounds__(64, 2) void rollout_kernel_tab(
     Params p, double timestep, int n_steps, int do_reset, int force, const double *actions, const double *tab)
 {
-    rollout_body<G, 1, false, true>(p, timestep, n_steps, do_reset, force, actions, tab);
+    rollout_body<G, 1, false, true, true>(p, timestep, n_steps, do_reset, force, actions, tab);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -188,7 +188,7 @@ static void launch_variant(sg_handle *h, dim3 grid, int n_steps, int do_reset, i
     if (h->has_ped)
         sg::rollout_kernel<(WV > 1 || G >= 16) ? G : 16, WV, true, false><<<grid, block, 0, h->stream>>>(
             h->p, h->cfg.timestep, n_steps, do_reset, force, d_actions, nullptr);
-    else if (use_tab && WV == 1)
+    else if (use_tab && WV == 1 && h->n_ctl > 0)
         sg::rollout_kernel_tab<G><<<grid, block, 0, h->stream>>>(h->p, h->cfg.timestep, n_steps, 0, force, nullptr, d_tab);
     else if (use_tab)
         sg::rollout_kernel<G, WV, false, true><<<grid, block, 0, h->stream>>>(h->p, h->cfg.timestep, n_steps, 0, force,
