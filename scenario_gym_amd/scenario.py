@@ -45,6 +45,21 @@ class Scenario:
         """scenario.py:88-91."""
         return max(e.trajectory.max_t for e in self._entities)
 
+    def translate(self, x):
+        """scenario.py:157-177: every entity's trajectory translated by `x` ([t, x, y, z, h, p, r] offsets)."""
+        new = self.copy()
+        for e in new._entities:
+            e.trajectory = e.trajectory.translate(x)
+        new.name = self.name
+        return new
+
+    def reset_start(self, entity=None):
+        """scenario.py:179-184: shift time so that `entity` (default: the ego) starts at t = 0."""
+        import numpy as np
+
+        start = (self.ego if entity is None else entity).trajectory.min_t
+        return self.translate(np.array([-start, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0]))
+
     def copy(self):
         return self.__class__([e.copy() for e in self._entities],
                               name=f"Copy of {self.name}" if self.name is not None else None,

@@ -110,6 +110,46 @@ class State:
     def get_entity_box_points(self, e: Entity) -> np.ndarray:
         return e.get_bounding_box_points(self.poses[e])
 
+    def get_entities_in_area(self, area) -> List[Entity]:
+        """state.py:340-354: entities whose centre point lies strictly inside `area`.  The reference takes a shapely
+        (Multi)Polygon; here `area` is anything with `.exterior.coords`, or an (n, 2) array of ring vertices (simple
+        polygon, either orientation; holes are not supported)."""
+        ring = np.asarray(area.exterior.coords if hasattr(area, "exterior") else area, np.float64)[:, :2]
+        if len(ring) > 1 and np.array_equal(ring[0], ring[-1]):
+            ring = ring[:-1]
+        ax, ay = ring[:, 0], ring[:, 1]
+        bx, by = np.roll(ax, -1), np.roll(ay, -1)
+        out = []
+        for e, pose in self.poses.items():
+            px, py = pose[0], pose[1]
+            cr = (bx - ax) * (py - ay) - (by - ay) * (px - ax)
+            on_edge = (cr == 0) & (np.minimum(ax, bx) <= px) & (px <= np.maximum(ax, bx)) & \
+                      (np.minimum(ay, by) <= py) & (py <= np.maximum(ay, by))
+            if on_edge.any():
+                continue  # shapely `contains`: boundary points are outside
+            cross = ((ay > py) != (by > py)) & (px < (bx - ax) * (py - ay) / np.where(by == ay, 1.0, by - ay) + ax)
+            if cross.sum() % 2 == 1:
+                out.append(e)
+        return out
+
+    def to_scenario(self, name: Optional[str] = None) -> Scenario:
+        """state.py:374-394: a scenario whose trajectories are the recorded poses (stationary entities keep one
+        knot).  Needs the gym's pose record (`record=True`, the default of ScenarioGym)."""
+        from copy import deepcopy
+
+        from .trajectory import Trajectory, is_stationary
+
+        if name is None:
+            name = f"Simulation of {self.scenario.name}" if self.scenario.name is None else None
+        entities = []
+        for entity, poses in self.recorded_poses().items():
+            new_entity = deepcopy(entity)
+            if is_stationary(poses):
+                poses = poses[None, 0]
+            new_entity.trajectory = Trajectory(poses)
+            entities.append(new_entity)
+        return Scenario(entities, name=name, road_network=self.scenario.road_network, actions=self.scenario.actions)
+
     def get_entities_in_radius(self, x: float, y: float, r: float) -> List[Entity]:
         """state.py:356-372.  The reference tests the centre against the 64-gon Point(x, y).buffer(r)."""
         ang = 2.0 * np.pi * np.arange(64) / 64

@@ -109,6 +109,10 @@ class Trajectory:
     def is_stationary(self):
         return is_stationary(self._data)
 
+    def translate(self, x):
+        """trajectory.py:287-306: new trajectory with `x` (scalar, (7,) or (n, 7)) added to the data."""
+        return self.__class__(self.data + x)
+
     def copy(self):
         return self.__class__(self._data.copy())
 

@@ -251,3 +251,61 @@ def test_pedestrian_agents_through_the_gym_api():
     assert [(t, refs.index(r), ty) for t, r, ty in got] == [(t, int(o), "non_vehicle") for t, o in zip(g[p + "/ev_t"], g[p + "/ev_other"])]
     with pytest.raises(NotImplementedError):  # the device model is deterministic
         sga.SocialForce(sga.SocialForceParameters()).device_params()
+
+
+def test_to_scenario_round_trip():
+    """tests/test_state.py:210-260: roll out, write the recording back as a scenario (State.to_scenario), roll the
+    recording out again: same entities, the ego follows the recorded poses."""
+    import scenario_gym_amd as sga
+    from scenario_gym_amd.trajectory import is_stationary
+
+    g = load_golden("scenarios")
+    scenario = _scenario(g, "a5e43fe4/scenario").reset_start()
+    gym = sga.ScenarioGym()
+    gym.set_scenario(scenario)
+    gym.rollout()
+    poses = gym.state.recorded_poses()[scenario.entities[0]]
+    assert np.unique(poses, axis=0).shape[0] == poses.shape[0]
+    new_scenario = gym.state.to_scenario()
+    ego = new_scenario.entities[0]
+    assert len(ego.trajectory.t) == ego.trajectory.data.shape[0] == poses.shape[0]
+    assert len(new_scenario.entities) == len(scenario.entities)
+    assert all(type(a) is type(b) and a.ref == b.ref for a, b in zip(scenario.entities, new_scenario.entities))
+    for old, new in zip(scenario.entities, new_scenario.entities):
+        assert (len(new.trajectory) == 1) == is_stationary(gym.state.recorded_poses()[old])
+    d = ego.trajectory.data  # Trajectory.__init__ normalises (heading unwrap): positions and times stay bit-identical
+    assert bits_equal(d[:, :4], poses[:, :4]) and np.abs(np.angle(np.exp(1j * (d[:, 4] - poses[:, 4])))).max() < 1e-12
+    gym2 = sga.ScenarioGym()
+    gym2.set_scenario(new_scenario)
+    gym2.rollout()
+    again = gym2.state.recorded_poses()[new_scenario.entities[0]]
+    n = min(len(again), len(poses))
+    assert n >= len(poses) - 1 and bits_equal(again[:n, 0], poses[:n, 0])      # same clock
+    assert np.abs(again[:n, 1:4] - poses[:n, 1:4]).max() < 1e-9                # knots are the recorded poses
+    gym.close()
+    gym2.close()
+
+
+def test_entities_in_area_and_radius():
+    """tests/test_state.py:82-97 (radius counts) and state.py:340-354 with a polygon given by its vertices."""
+    import scenario_gym_amd as sga
+
+    g = load_golden("scenarios")
+    gym = sga.ScenarioGym()
+    gym.set_scenario(_scenario(g, "a5e43fe4/scenario"))
+    gym.reset_scenario()
+    gym.step()
+    st = gym.state
+    ego = st.scenario.entities[0]
+    pose = st.poses[ego]
+    others = {e: p for e, p in st.poses.items() if e is not ego}
+    d = np.array([np.hypot(*(p[:2] - pose[:2])) for p in others.values()])
+    assert len(st.get_entities_in_radius(*pose[:2], d.min() - 0.1)) == 1
+    # Point.buffer(r) is the 64-gon INSCRIBED in the circle: its apothem is r cos(pi/64)
+    assert len(st.get_entities_in_radius(*pose[:2], (d.max() + 1) / np.cos(np.pi / 64))) == len(st.poses)
+    x, y = pose[:2]
+    square = np.array([[x - 1, y - 1], [x + 1, y - 1], [x + 1, y + 1], [x - 1, y + 1]])
+    inside = st.get_entities_in_area(square)
+    assert ego in inside and all(abs(st.poses[e][0] - x) < 1 and abs(st.poses[e][1] - y) < 1 for e in inside)
+    assert len(st.get_entities_in_area(square + 1e6)) == 0
+    gym.close()

@@ -266,3 +266,28 @@ def test_terminal_condition_names():
     assert terminal_mask(None) == 1 and terminal_mask(["max_length", "collision", "ego_collision"]) == 7
     with pytest.raises(ValueError):
         terminal_mask(["ego_off_road"])
+
+
+def test_scenario_translate_and_reset_start():
+    """scenario.py:157-184 / trajectory.py:287-306 (used by tests/test_state.py:218 before to_scenario)."""
+    g = load_golden("scenarios")
+    sc = scenario_from_arrays(scenario_arrays(g, "a5e43fe4/scenario"), g["a5e43fe4/scenario/refs"])
+    t0 = sc.ego.trajectory.min_t
+    assert t0 > 0
+    new = sc.reset_start()
+    assert new.ego.trajectory.min_t == 0.0 and sc.ego.trajectory.min_t == t0  # the original is untouched
+    for a, b in zip(sc.entities, new.entities):
+        assert np.array_equal(a.trajectory.data[:, 1:], b.trajectory.data[:, 1:])
+        assert np.array_equal(a.trajectory.data[:, 0] - t0, b.trajectory.data[:, 0])
+    shifted = sc.translate(np.array([0.0, 1.5, -2.0, 0.0, 0.0, 0.0, 0.0]))
+    assert np.array_equal(shifted.ego.trajectory.data[:, 1], sc.ego.trajectory.data[:, 1] + 1.5)
+
+
+def test_is_stationary():
+    """trajectory.py:472-490: NaNs count as zeros."""
+    from scenario_gym_amd.trajectory import is_stationary
+
+    a = np.array([[0.0, 1.0, 2.0, np.nan, 0.3, 0.0, 0.0], [1.0, 1.0, 2.0, 0.0, 0.3, np.nan, 0.0]])
+    assert is_stationary(a)
+    a[1, 1] = 1.1
+    assert not is_stationary(a)
