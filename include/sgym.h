@@ -43,6 +43,8 @@ typedef enum {
     SG_KIND_AGENT_PID = 3,     /* PIDAgent + PIDController, agent.py:131-148, controller.py:143-258 */
     SG_KIND_AGENT_VEHICLE = 4, /* external (accel, steer) -> VehicleController, controller.py:57-140; integrations/openaigym.py:197-204 */
     SG_KIND_AGENT_PEDESTRIAN = 5, /* PedestrianAgent + SocialForce + PedestrianController, pedestrian/{agent,social_force,controller}.py */
+    SG_KIND_AGENT_EXTERNAL = 6,   /* any other Agent subclass (agent.py:18-116): agent.step(state) runs in the caller, one
+                                     sg_step per tick, and its pose enters through sg_set_external_poses */
 } sg_kind;
 
 /* TERMINAL_CONDITIONS, scenario_gym/state/state.py:397-408 */
@@ -195,6 +197,14 @@ int sg_set_timestep(sg_handle *h, double timestep);
  * actions: HOST [n_steps][R][2] (accel, steer) for SG_KIND_AGENT_VEHICLE slots or NULL;
  * actions_device != 0 means `actions` is a DEVICE pointer of the same shape. */
 int sg_step(sg_handle *h, int32_t n_steps, const double *actions, int32_t actions_device);
+
+/* Poses returned by the caller's own agents (Agent.step(state) -> Controller.step(state, action), agent.py:52-57,
+ * controller.py:30-42) for the SG_KIND_AGENT_EXTERNAL slots, consumed by every following sg_step until replaced.
+ * poses: HOST [R*E][6], entity index scenario*E + slot; rows of other slots are ignored; x = NaN means the agent
+ * returned None (the entity vanishes, or keeps its pose under `persist`; scenario_gym.py:233-239).  An agent that is not
+ * present yet spawns at its trajectory start like every other agent (:240-244).  sg_rollout refuses batches with such
+ * slots (SG_ERR_STATE): they have to be driven tick by tick. */
+int sg_set_external_poses(sg_handle *h, const double *poses);
 
 /* ScenarioGym.rollout(): reset, then step each scenario while it is not done, at most max_steps
  * (scenario_gym.py:256-267).  The time loop runs inside the kernels: one launch of the rollout kernel per chunk of

@@ -1,7 +1,14 @@
 """scenario_gym_amd: MI355X-native batched rollout engine behind scenario_gym's Python API."""
 from .agent import (  # noqa: F401
+    Action,
     Agent,
+    Controller,
+    EgoLocalizationSensor,
     ExternalVehicleAgent,
+    PIDController,
+    ReplayTrajectoryController,
+    Sensor,
+    VehicleController,
     PedestrianAgent,
     PIDAgent,
     ReplayTrajectoryAgent,

@@ -10,7 +10,8 @@ LIB_PATH = os.environ.get("SGYM_LIB") or os.path.join(HERE, "lib", "libsgym_hip.
 
 SG_OK = 0
 ABI_VERSION = 1
-KIND_NONE, KIND_REPLAY, KIND_AGENT_REPLAY, KIND_AGENT_PID, KIND_AGENT_VEHICLE, KIND_AGENT_PEDESTRIAN = range(6)
+(KIND_NONE, KIND_REPLAY, KIND_AGENT_REPLAY, KIND_AGENT_PID, KIND_AGENT_VEHICLE, KIND_AGENT_PEDESTRIAN,
+ KIND_AGENT_EXTERNAL) = range(7)
 TERM_MAX_LENGTH, TERM_COLLISION, TERM_EGO_COLLISION = 1, 2, 4
 NCTRL = 16
 (C_MAX_STEER, C_MAX_ACCEL, C_MAX_SPEED, C_ALLOW_REVERSE, C_STEER_KP, C_STEER_KD, C_ACCEL_KP,
@@ -24,7 +25,7 @@ SYMBOLS = (
     "sg_version", "sg_last_error", "sg_create", "sg_destroy", "sg_upload", "sg_set_social_force", "sg_reset",
     "sg_set_timestep", "sg_step", "sg_rollout", "sg_rollout_async", "sg_synchronize", "sg_stream",
     "sg_state_view_get", "sg_read_metrics", "sg_read_record", "sg_copy_to_host", "sg_last_kernel_ms",
-    "sg_last_launch_stats", "sg_debug_trig32", "sg_set_tuning",
+    "sg_last_launch_stats", "sg_debug_trig32", "sg_set_tuning", "sg_set_external_poses",
 )
 
 
@@ -109,6 +110,7 @@ def load():
     lib.sg_last_kernel_ms.argtypes = [H, C.POINTER(C.c_float)]
     lib.sg_last_launch_stats.argtypes = [H, C.POINTER(C.c_int32), C.POINTER(C.c_float)]
     lib.sg_set_tuning.argtypes = [H, C.c_int32, C.c_int32, C.c_int32]
+    lib.sg_set_external_poses.argtypes = [H, C.c_void_p]
     lib.sg_debug_trig32.argtypes = [H, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
     for name in SYMBOLS:
         if name not in ("sg_last_error", "sg_stream", "sg_version"):

@@ -1,10 +1,12 @@
-"""Agents, controllers, actions: the reference's plugin classes as *descriptors*.
+"""Agents, controllers, sensors, actions: the reference's plugin classes.
 
 In the reference these objects compute one pose per step in Python (agent.py:52-57,
 controller.py:30-42).  Here the built-in kinds are recognised by type when a scenario is packed
-and lowered to device lanes (SG_KIND_*); the objects only carry their parameters.  Class names,
-constructor signatures and defaults follow the reference (agent.py:18-169, controller.py:12-258,
-action.py:12-83, sensor/common.py:39-50).
+and lowered to device lanes (SG_KIND_*): for them the objects only carry their parameters.  Any OTHER
+`Agent` subclass (a Python `_step`) keeps the reference protocol -- sensor.step -> _step -> controller.step
+-- on the host, once per tick, and its pose is injected into the device step (SG_KIND_AGENT_EXTERNAL).
+Class names, constructor signatures and defaults follow the reference (agent.py:18-169,
+controller.py:12-258, action.py:12-83, sensor/base.py:9-54, sensor/common.py:39-50).
 """
 from typing import Optional
 
@@ -44,19 +46,50 @@ class VehicleAction(Action):
 
 
 class Sensor:
+    """sensor/base.py:9-54: reset(state) / step(state) -> observation around the _reset / _step hooks."""
+
     def __init__(self, entity: Entity):
         self.entity = entity
+
+    def reset(self, state):
+        return self._reset(state)
+
+    def step(self, state):
+        return self._step(state)
+
+    def _reset(self, state):
+        return self._step(state)
+
+    def _step(self, state):
+        return None
 
 
 class EgoLocalizationSensor(Sensor):
     """sensor/common.py:39-50: the observation is State.get_entity_data(entity)."""
 
+    def _step(self, state):
+        return state.get_entity_data(self.entity)
+
 
 class Controller:
+    """controller.py:12-42: reset(state) / step(state, action) -> pose around the _reset / _step hooks."""
+
     device_kind = None
 
     def __init__(self, entity: Entity):
         self.entity = entity
+
+    def reset(self, state) -> None:
+        self._reset(state)
+
+    def step(self, state, action):
+        return self._step(state, action)
+
+    def _reset(self, state) -> None:
+        pass
+
+    def _step(self, state, action):
+        raise NotImplementedError
 
     def ctrl_row(self) -> np.ndarray:
         from .engine import DEFAULT_CTRL
@@ -68,6 +101,9 @@ class ReplayTrajectoryController(Controller):
     """controller.py:45-54: pose = action.pose."""
 
     device_kind = L.KIND_AGENT_REPLAY
+
+    def _step(self, state, action):
+        return action.pose
 
 
 class VehicleController(Controller):
@@ -87,6 +123,32 @@ class VehicleController(Controller):
         row[L.C_MAX_SPEED] = np.nan if self.max_speed is None else self.max_speed
         row[L.C_ALLOW_REVERSE] = float(bool(self.allow_reverse))
         return row
+
+    # host execution (only for caller-run agents that pair a Python _step with this controller)
+    def _reset(self, state) -> None:
+        """controller.py:100-103."""
+        self.speed = float(np.linalg.norm(state.velocities[self.entity][:2]))
+        self.l = self.entity.bounding_box.length
+
+    def _step(self, state, action):
+        """controller.py:105-140: the kinematic bicycle step from (accel, steer)."""
+        accel = float(np.clip(action.acceleration, -self.max_accel, self.max_accel))
+        steer = float(np.clip(action.steering, -self.max_steer, self.max_steer))
+        pose = state.poses[self.entity].copy()
+        dt = state.next_t - state.t
+        h = pose[3]
+        dx, dy = self.speed * np.cos(h), self.speed * np.sin(h)
+        dh = self.speed * np.tan(steer) / self.l
+        pose[0] += dx * dt
+        pose[1] += dy * dt
+        pose[3] += dh * dt
+        speed = self.speed + accel * dt
+        if not self.allow_reverse:
+            speed = max(0.0, speed)
+        if self.max_speed is not None:
+            speed = min(self.max_speed, speed)
+        self.speed = speed
+        return pose
 
 
 class PIDController(VehicleController):
@@ -108,7 +170,8 @@ class PIDController(VehicleController):
 
 
 class Agent:
-    """agent.py:18-116.  Subclasses with a custom Python `_step` cannot run on the device path."""
+    """agent.py:18-116.  The built-in subclasses below are lowered to device lanes; any other subclass runs its
+    sensor -> _step -> controller chain on the host every tick (device_kind() == KIND_AGENT_EXTERNAL)."""
 
     def __init__(self, entity: Entity, controller: Controller, sensor: Sensor):
         self.entity, self.controller, self.sensor = entity, controller, sensor
@@ -116,9 +179,37 @@ class Agent:
         self.last_reward = None
 
     def device_kind(self) -> int:
-        raise NotImplementedError(
-            f"{type(self).__name__} has a Python _step: only ReplayTrajectoryAgent, PIDAgent and "
-            "ExternalVehicleAgent are lowered to device lanes in this version")
+        return L.KIND_AGENT_EXTERNAL
+
+    def reset(self, state) -> None:
+        """agent.py:43-50."""
+        self.last_action = None
+        self.last_reward = None
+        self.sensor.reset(state)
+        self.controller.reset(state)
+        self._reset()
+
+    def step(self, state):
+        """agent.py:52-57: observation -> action -> pose."""
+        obs = self.sensor.step(state)
+        action = self._step(obs)
+        self.last_action = action
+        return self.controller.step(state, action)
+
+    def _reset(self) -> None:
+        pass
+
+    def _step(self, observation):
+        raise NotImplementedError
+
+    def reward(self, state):
+        r = self._reward(state)
+        if r is not None:
+            self.last_reward = r
+        return r
+
+    def _reward(self, state):
+        return None
 
     def finish(self, state) -> None:
         pass

@@ -79,6 +79,7 @@ struct Params {
     const int32_t *ctl_ent;  // [n_ctl_pad] padded entity index r*EP + slot of controlled lane q, -1 = padding
     double *ctl_state;       // [CS_COUNT][n_ctl_pad] lane state carried from one chunk of steps to the next
     int n_ctl_pad;           // multiple of 64
+    const double *ext_pose;  // [NE][6] poses of the caller-run agents (SG_KIND_AGENT_EXTERNAL), x = NaN: agent returned None
     int tab_steps;           // steps per table chunk (rows per lane = tab_steps + 1: the prefetch of the last step reads one row ahead)
 };
 
@@ -1538,7 +1539,21 @@ __device__ __forceinline__ void rollout_body(
         } else if (kind == SG_KIND_REPLAY) { // BatchReplayEntity.step, batch.py:34-53
             npres = p.persist || is_static || (next_t >= min_t && next_t <= max_t);
         } else if (is_agent) {
-            if (present) {
+            if (present && kind == SG_KIND_AGENT_EXTERNAL) {
+                // the caller ran agent.step(state) (agent.py:52-57): its pose, or None = NaN (scenario_gym.py:233-239)
+                const double *ep = p.ext_pose + ((size_t)r * p.EP + slot) * 6;
+                const double e0 = ep[0];
+                if (e0 == e0) {
+                    npres = true;
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) np_[c] = ep[c];
+                } else if (p.persist) {
+                    npres = true;
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) np_[c] = pose[c];
+                }
+                sg_loads_done();
+            } else if (present) {
                 npres = true;
                 if (kind != SG_KIND_AGENT_REPLAY && run) {
                     const double tx = np_[0], ty = np_[1];

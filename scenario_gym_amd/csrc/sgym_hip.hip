@@ -36,6 +36,8 @@ struct sg_handle {
     size_t actions_cap = 0;
     // controller pre-pass (sg::control_kernel): controlled lanes of the batch, its own stream, two table buffers
     int n_ctl = 0;
+    int n_ext = 0;            // SG_KIND_AGENT_EXTERNAL slots in the batch
+    double *d_ext = nullptr;  // [NE][6]
     int max_ctl_per_block = 0; // controlled lanes in the fullest 64-slot block
     hipStream_t ctl_stream = nullptr;
     double *d_tab[2] = {nullptr, nullptr};
@@ -249,7 +251,7 @@ static int launch_rollout(sg_handle *h, int n_steps, int do_reset, int force, co
     HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
     // the table variant serves SG_TAB_LANES controlled lanes per wavefront; denser batches keep their controllers
     // in the rollout kernel, where they fill the wavefront anyway
-    const bool use_tab = !h->has_ped && n_steps >= tab_min && h->max_ctl_per_block <= SG_TAB_LANES(h->G, h->WV);
+    const bool use_tab = !h->has_ped && h->n_ext == 0 && n_steps >= tab_min && h->max_ctl_per_block <= SG_TAB_LANES(h->G, h->WV);
     int rc = SG_OK;
     if (!use_tab) {
         rc = launch_main(h, n_steps, do_reset, force, d_actions, nullptr, false, &ev_next);
@@ -358,6 +360,7 @@ extern "C" int sg_upload(sg_handle *h, const sg_scenarios *sc)
         SI(o, sg::ST_CTL) = -1;
     }
     std::vector<int32_t> ctl_ent; // controlled lanes (PID / vehicle agents) in entity order
+    int n_ext = 0;
     std::vector<sg::ScenStatic> sstat(R);
     const int64_t rows_total = sc->knot_off[(size_t)R * E];
     for (int r = 0; r < R; ++r) {
@@ -368,7 +371,8 @@ extern "C" int sg_upload(sg_handle *h, const sg_scenarios *sc)
         for (int e = 0; e < E; ++e) {
             size_t i = (size_t)r * E + e, o = (size_t)r * EP + e;
             int k = sc->kind[i];
-            if (k < SG_KIND_NONE || k > SG_KIND_AGENT_PEDESTRIAN) return fail(h, SG_ERR_INVALID, "sg_upload: kind[%zu]=%d unknown", i, k);
+            if (k < SG_KIND_NONE || k > SG_KIND_AGENT_EXTERNAL) return fail(h, SG_ERR_INVALID, "sg_upload: kind[%zu]=%d unknown", i, k);
+            if (k == SG_KIND_AGENT_EXTERNAL) ++n_ext;
             if (k == SG_KIND_AGENT_PEDESTRIAN) {
                 int64_t ra = sc->route_off[i], rb = sc->route_off[i + 1];
                 if (ra < 0 || rb <= ra) return fail(h, SG_ERR_INVALID, "sg_upload: pedestrian agent %zu has no route", i);
@@ -470,6 +474,14 @@ extern "C" int sg_upload(sg_handle *h, const sg_scenarios *sc)
         for (int i = 0; i < 64; ++i) { double a = 2.0 * 3.141592653589793 * i / 64; gon[2 * i] = std::cos(a); gon[2 * i + 1] = std::sin(a); }
         if ((rc = dev_upload(h, SA, &p.gon, gon))) return rc;
     }
+    h->n_ext = n_ext;
+    {   // external poses start as "None" for every slot
+        std::vector<double> none(NE * 6, NAN);
+        const double *d = nullptr;
+        if ((rc = dev_upload(h, SA, &d, none))) return rc;
+        h->d_ext = const_cast<double *>(d);
+        p.ext_pose = d;
+    }
     h->n_ctl = (int)ctl_ent.size();
     h->max_ctl_per_block = 0;
     for (size_t i = 0, run = 0; i < ctl_ent.size(); ++i) { // ctl_ent is sorted by entity index
@@ -554,10 +566,29 @@ extern "C" int sg_step(sg_handle *h, int32_t n_steps, const double *actions, int
     return SG_OK;
 }
 
+extern "C" int sg_set_external_poses(sg_handle *h, const double *poses)
+{
+    if (!h || !poses) return SG_ERR_INVALID;
+    if (!h->uploaded) return fail(h, SG_ERR_STATE, "sg_set_external_poses: no scenarios uploaded");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    const size_t row = (size_t)h->E * 6 * sizeof(double);
+    if (h->EP == h->E) {
+        HIP_TRY(h, hipMemcpyAsync(h->d_ext, poses, (size_t)h->R * row, hipMemcpyHostToDevice, h->stream));
+    } else { // padded entity stride on the device
+        HIP_TRY(h, hipMemcpy2DAsync(h->d_ext, (size_t)h->EP * 6 * sizeof(double), poses, row, row, (size_t)h->R,
+                                    hipMemcpyHostToDevice, h->stream));
+    }
+    HIP_TRY(h, hipStreamSynchronize(h->stream)); // the caller's buffer is free on return
+    return SG_OK;
+}
+
 extern "C" int sg_rollout_async(sg_handle *h, int32_t max_steps, int32_t do_reset)
 {
     if (!h) return SG_ERR_INVALID;
     if (!h->uploaded) return fail(h, SG_ERR_STATE, "sg_rollout: no scenarios uploaded");
+    if (h->n_ext > 0 && max_steps > 0)
+        return fail(h, SG_ERR_STATE, "sg_rollout: %d slots are driven by the caller's agents (SG_KIND_AGENT_EXTERNAL): "
+                                     "use sg_set_external_poses + sg_step tick by tick", h->n_ext);
     if (max_steps < 0) return fail(h, SG_ERR_INVALID, "sg_rollout: max_steps < 0");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     // external-action slots are fed (0, 0) here; drive them with sg_step(actions)

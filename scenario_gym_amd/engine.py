@@ -160,6 +160,11 @@ class RolloutEngine:
             ptr = actions.ctypes.data
         self._check(self.lib.sg_step(self.h, int(n_steps), ptr, 0), "sg_step")
 
+    def set_external_poses(self, poses):
+        """Poses [R, E, 6] of the caller-run agents (KIND_AGENT_EXTERNAL slots; NaN x = the agent returned None)."""
+        poses = np.ascontiguousarray(poses, np.float64).reshape(self.R, self.E, 6)
+        self._check(self.lib.sg_set_external_poses(self.h, poses.ctypes.data), "sg_set_external_poses")
+
     def rollout(self, max_steps):
         self._check(self.lib.sg_rollout(self.h, int(max_steps)), "sg_rollout")
 

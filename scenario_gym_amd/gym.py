@@ -37,6 +37,7 @@ class BatchedScenarioGym:
         self.device = device
         self.engine: Optional[RolloutEngine] = None
         self.scenarios: List[Scenario] = []
+        self._host_agents: list = []
         self.states: List[State] = []
         self.metrics: List[List[Metric]] = []
         self._cache = None
@@ -59,7 +60,21 @@ class BatchedScenarioGym:
 
     def _per_step_host_path(self) -> bool:
         custom_metric = any(not isinstance(m, _DeviceMetric) for ms in self.metrics for m in ms)
-        return bool(custom_metric or self.state_callbacks or self._host_terminals())
+        return bool(custom_metric or self.state_callbacks or self._host_terminals() or self._host_agents)
+
+    def _push_host_agents(self):
+        """scenario_gym.py:233-239 for the agents that run in Python: agent.step(state) of every present one, its pose
+        (or None -> NaN) handed to the next device step."""
+        if not self._host_agents:
+            return
+        poses = np.full((len(self.states), self._packed.n_entities, 6), np.nan)
+        for i, slot, agent in self._host_agents:
+            st = self.states[i]
+            if agent.entity in st.poses:
+                pose = agent.step(st)
+                if pose is not None:
+                    poses[i, slot] = np.asarray(pose, np.float64)
+        self.engine.set_external_poses(poses)
 
     # ------------------------------------------------------------------ set up
     def set_scenarios(self, scenarios: Sequence[Scenario], create_agent=_create_agent, max_steps: Optional[int] = None):
@@ -84,6 +99,9 @@ class BatchedScenarioGym:
             event_capacity=self.event_capacity, device=self.device, social_force=sf)
         self.engine.upload(packed)
         self.states = [State(self, i, sc, agents[i], self.persist) for i, sc in enumerate(self.scenarios)]
+        from . import _lib as L
+        self._host_agents = [(i, sc.entities.index(e), a) for i, sc in enumerate(self.scenarios)
+                             for e, a in agents[i].items() if a.device_kind() == L.KIND_AGENT_EXTERNAL]
         self.metrics = [list(self.metric_factory()) for _ in self.scenarios]
         self._invalidate()
         self._prev_state = None
@@ -107,6 +125,8 @@ class BatchedScenarioGym:
         return self._rec
 
     def _reset_host_side(self):
+        for i, _, agent in self._host_agents:  # Agent.reset -> sensor / controller reset (scenario_gym.py:217-225)
+            agent.reset(self.states[i])
         for st, ms in zip(self.states, self.metrics):
             for m in ms:
                 m.reset(st)
@@ -137,6 +157,7 @@ class BatchedScenarioGym:
         """n x ScenarioGym.step() for every scenario; actions [n, R, 2] for ExternalVehicleAgent egos."""
         if n == 1 or not self._per_step_host_path():
             self._prev_state = self._fetch_state() if self._per_step_host_path() or n == 1 else None
+            self._push_host_agents()
             self.engine.step(n, actions)
             self._invalidate()
             if self._per_step_host_path():
@@ -158,6 +179,7 @@ class BatchedScenarioGym:
             for _ in range(max_steps):
                 # a scenario that finished keeps stepping on the device but is frozen for the caller
                 self._prev_state = self._fetch_state()
+                self._push_host_agents()
                 self.engine.step(1)
                 self._invalidate()
                 done |= self._after_host_step() | self._fetch_state()["done"]

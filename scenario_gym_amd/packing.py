@@ -105,7 +105,10 @@ def pack_scenarios(scenarios, create_agent=None):
             agent = create_agent(sc, e)
             if agent is not None:
                 kind[i] = agent.device_kind()
-                ctrl[i] = agent.ctrl_row() if hasattr(agent, "ctrl_row") else agent.controller.ctrl_row()
+                if hasattr(agent, "ctrl_row"):
+                    ctrl[i] = agent.ctrl_row()
+                elif hasattr(agent.controller, "ctrl_row"):  # caller-run agents may bring any controller object
+                    ctrl[i] = agent.controller.ctrl_row()
                 sc_agents[e] = agent
         routes = [np.asarray(sc_agents[e].route, np.float64).reshape(-1, 2) if e in sc_agents and hasattr(sc_agents[e], "route")
                   else np.zeros((0, 2)) for e in ents]

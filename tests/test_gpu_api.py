@@ -309,3 +309,120 @@ def test_entities_in_area_and_radius():
     assert ego in inside and all(abs(st.poses[e][0] - x) < 1 and abs(st.poses[e][1] - y) < 1 for e in inside)
     assert len(st.get_entities_in_area(square + 1e6)) == 0
     gym.close()
+
+
+# --------------------------------------------------------------------------- caller-run (Python) agents
+def _python_replay_agent(sga):
+    class PyReplayAgent(sga.Agent):
+        """ReplayTrajectoryAgent (agent.py:118-128) written as a user would: a Python _step."""
+
+        def __init__(self, entity):
+            super().__init__(entity, sga.ReplayTrajectoryController(entity), sga.EgoLocalizationSensor(entity))
+            self.calls = 0
+
+        def _step(self, observation):
+            t, next_t = observation[0], observation[1]
+            self.calls += 1
+            return sga.TeleportAction(pose=self.entity.trajectory.position_at_t(next_t))
+
+    return PyReplayAgent
+
+
+def test_python_agent_equals_device_replay_agent():
+    """An Agent subclass with a Python _step (sensor -> _step -> controller on the host, pose injected into the device
+    step) reproduces the built-in ReplayTrajectoryAgent bit for bit: same poses, velocities, metrics, collisions."""
+    import scenario_gym_amd as sga
+
+    g = load_golden("scenarios")
+    Py = _python_replay_agent(sga)
+    made = []
+
+    def create_py(scenario, entity):
+        if entity.ref == "ego":
+            made.append(Py(entity))
+            return made[-1]
+
+    out = []
+    for create in (None, create_py):
+        gym = sga.ScenarioGym(metrics=[sga.EgoAvgSpeed(), sga.EgoMaxSpeed(), sga.EgoDistanceTravelled(), sga.CollisionMetric()])
+        kw = {} if create is None else dict(create_agent=create)
+        gym.set_scenario(_scenario(g, "a5e43fe4/scenario"), **kw)
+        gym.rollout()
+        st = gym.state
+        out.append((st.recorded_poses(), st.velocities, st.distances, gym.get_metrics(), st.t))
+        gym.close()
+    (pa, va, da, ma, ta), (pb, vb, db, mb, tb) = out
+    assert made and made[0].calls > 100 and ta == tb
+    for (ea, ra), (eb, rb) in zip(pa.items(), pb.items()):
+        assert ea.ref == eb.ref and bits_equal(ra, rb), ea.ref
+    for (ea, xa), (eb, xb) in zip(va.items(), vb.items()):
+        assert bits_equal(xa, xb) and da[ea] == db[eb]
+    assert ma == mb
+    assert bits_equal(pa[next(iter(pa))][:, 1:], g["a5e43fe4/dt30/poses"][:, 0][~np.isnan(g["a5e43fe4/dt30/poses"][:, 0, 0])])
+
+
+@pytest.mark.parametrize("persist", [False, True])
+def test_python_agent_returning_none(persist):
+    """scenario_gym.py:233-239: an agent that returns None vanishes, or keeps its pose under persist."""
+    import scenario_gym_amd as sga
+
+    g = load_golden("scenarios")
+
+    class Quitter(sga.Agent):
+        def __init__(self, entity):
+            super().__init__(entity, sga.ReplayTrajectoryController(entity), sga.EgoLocalizationSensor(entity))
+
+        def step(self, state):  # overriding step itself is allowed too
+            if state.t > self.entity.trajectory.min_t + 1.0:
+                return None
+            return self.entity.trajectory.position_at_t(state.next_t)
+
+    gym = sga.ScenarioGym(persist=persist)
+    gym.set_scenario(_scenario(g, "a5e43fe4/scenario"), create_agent=lambda sc, e: Quitter(e) if e.ref == "ego" else None)
+    gym.reset_scenario()
+    ego = gym.state.scenario.entities[0]
+    last = None
+    for _ in range(60):
+        if ego in gym.state.poses:
+            last = gym.state.poses[ego].copy()
+        gym.step()
+    if persist:
+        assert ego in gym.state.poses and bits_equal(gym.state.poses[ego], last)
+        assert np.all(gym.state.velocities[ego] == 0)
+    else:
+        assert ego not in gym.state.poses
+    gym.close()
+
+
+def test_python_agent_with_host_vehicle_controller():
+    """A Python policy emitting VehicleAction through the built-in VehicleController (run on the host for caller-run
+    agents) follows the same kinematics as the device ExternalVehicleAgent fed the same actions (<= 1e-9)."""
+    import scenario_gym_amd as sga
+
+    g = load_golden("scenarios")
+    acts = np.random.default_rng(3).uniform([-2, -0.3], [2, 0.3], (50, 2))
+
+    class Policy(sga.Agent):
+        def __init__(self, entity):
+            super().__init__(entity, sga.VehicleController(entity), sga.EgoLocalizationSensor(entity))
+            self.k = 0
+
+        def _step(self, observation):
+            a = sga.VehicleAction(*acts[self.k])
+            self.k += 1
+            return a
+
+    gym = sga.ScenarioGym()
+    gym.set_scenario(_scenario(g, "a5e43fe4/scenario"), create_agent=lambda sc, e: Policy(e) if e.ref == "ego" else None)
+    gym.reset_scenario()
+    ref = sga.ScenarioGym()
+    ref.set_scenario(_scenario(g, "a5e43fe4/scenario"),
+                     create_agent=lambda sc, e: sga.ExternalVehicleAgent(e) if e.ref == "ego" else None)
+    ref.reset_scenario()
+    for k in range(50):
+        gym.step()
+        ref.step(acts[k])
+    a, b = gym.state.poses[gym.state.scenario.entities[0]], ref.state.poses[ref.state.scenario.entities[0]]
+    assert np.abs(a - b).max() < 1e-9 and np.abs(a[:2] - g["a5e43fe4/scenario/knots"][0, 1:3]).max() > 0.1
+    gym.close()
+    ref.close()

@@ -133,11 +133,15 @@ def test_agent_descriptors_lower_to_device_kinds():
     assert row[L.C_ACCEL_KP] == 2.0 and row[L.C_MAX_ACCEL] == 5.0 and row[L.C_MAX_STEER] == np.pi / 90
     assert row[L.C_STEER_KP] == 0.03054 and np.isnan(row[L.C_MAX_SPEED])
 
-    class MyAgent(sga.Agent):
-        pass
+    class MyAgent(sga.Agent):  # a Python _step: runs in the caller, its slot takes injected poses
+        def __init__(self, entity):
+            super().__init__(entity, sga.ReplayTrajectoryController(entity), sga.EgoLocalizationSensor(entity))
 
-    with pytest.raises(NotImplementedError):
-        pack_scenarios([sc], lambda s, e: MyAgent(e, None, None) if e.ref == "ego" else None)
+        def _step(self, observation):
+            return sga.TeleportAction(pose=np.zeros(6))
+
+    packed, agents = pack_scenarios([sc], lambda s, e: MyAgent(e) if e.ref == "ego" else None)
+    assert packed.kind[packed.ego[0]] == L.KIND_AGENT_EXTERNAL and isinstance(agents[0][sc.ego], MyAgent)
     a = sga.TeleportAction(pose=np.arange(6.0))
     assert np.array_equal(a.pose, np.arange(6.0))
 
