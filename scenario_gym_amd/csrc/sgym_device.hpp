@@ -857,7 +857,7 @@ __device__ __forceinline__ void tile_collisions(bool present, const double *pose
                                                 double bcx, double bcy, float rad_thr, float trig_eps,
                                                 float nbr_thr, float cell_inv, bool is_ped_type, int sl, int tile0, LDS &L,
                                                 uint64_t (&rows_out)[WV], uint64_t (&mult_rows)[WV],
-                                                uint64_t (&nbr_out)[WV])
+                                                uint64_t (&nbr_out)[WV], bool &dense)
 {
     constexpr int TS = G * WV; // tile slots
     const int slot = sl - tile0;
@@ -900,7 +900,12 @@ __device__ __forceinline__ void tile_collisions(bool present, const double *pose
     bool any_cand = false;
 #pragma unroll
     for (int w = 0; w < WV; ++w) { rows_out[w] = 0; mult_rows[w] = 0; nbr_out[w] = 0; cand[w] = 0; }
-    if (!block_any<WV>(far_out)) { // block_any / the barrier below also publish the LDS writes above
+    // `dense` (workgroup-uniform, pedestrian scenes): a crowd packed tighter than the stripe cells makes almost the
+    // whole tile a cell neighbour, and the all-pairs walk below (fixed cost, packed fp32, 4 slots per LDS read) is then
+    // cheaper than one circle test per candidate.  Either way the result is a conservative candidate set that the same
+    // exact tests refine, so the switch cannot change any output.
+    const bool all_pairs = block_any<WV>(far_out) || (PED && dense);
+    if (!all_pairs) { // block_any / the barrier below also publish the LDS writes above
         // ---- stripe masks: O(tile) instead of O(tile^2) ----
         if (WV == 1) tile_sync<WV>();
         const int wsl = (WV == 1) ? 0 : (slot >> 6);              // word of this slot inside the tile's row
@@ -924,10 +929,12 @@ __device__ __forceinline__ void tile_collisions(bool present, const double *pose
         }
         // ---- bounding circles of the cell neighbours: per wavefront, LDS reads only ----
         uint64_t close[WV];
+        int iters = 0; // wave-uniform
 #pragma unroll
         for (int w = 0; w < WV; ++w) {
             close[w] = 0;
             while (__any(cand[w] != 0)) {
+                ++iters;
                 if (cand[w]) {
                     const int jl = __builtin_ctzll(cand[w]);
                     cand[w] &= cand[w] - 1;
@@ -941,6 +948,7 @@ __device__ __forceinline__ void tile_collisions(bool present, const double *pose
             cand[w] = close[w];
             any_cand = any_cand || cand[w] != 0;
         }
+        if (PED) dense = block_any<WV>(iters > (2 * TS) / 5); // ~ where 25 instructions per candidate overtake the walk
     } else {
     // ---- fallback for coordinates beyond 4000 cells: all pairs of the tile ----
     // lane i tests itself against slots j..j+3 per iteration (wave-uniform LDS broadcast reads, one
@@ -1011,6 +1019,12 @@ __device__ __forceinline__ void tile_collisions(bool present, const double *pose
             nbr_out[w] = present ? nin : 0;
         }
         any_cand = any_cand || cand[w] != 0;
+    }
+    if (PED) { // back to the stripe masks once nobody has more than TS/12 neighbour candidates (hysteresis)
+        int cnt = 0;
+#pragma unroll
+        for (int w = 0; w < WV; ++w) cnt += __builtin_popcountll(nbr_out[w]);
+        dense = block_any<WV>(cnt > TS / 12);
     }
     }
 #ifdef SG_ABL_NO_NARROW
@@ -1318,6 +1332,7 @@ __device__ __forceinline__ void rollout_body(
     bool present;
     int done, steps;
     uint64_t row[WV], mult_rows[WV], nbr[WV];
+    bool dense = false; // broad-phase strategy of the pedestrian variant (workgroup-uniform), see tile_collisions
     // column of this lane in the controller table (TAB): PID / vehicle agents only
     // The table rows are fetched with SCALAR loads, one controlled lane at a time (at most SG_TAB_LANES per
     // wavefront and wavefront of a wide scenario, checked by the host), one step ahead, and moved into the lane's registers at the end of the step.  A vector load inside the loop would share vmcnt with the state stores and make every
@@ -1400,7 +1415,7 @@ __device__ __forceinline__ void rollout_body(
         for (int w = 0; w < WV; ++w) last_row[w] = 0; // metrics/collision.py:64-68
         n_ev = 0;
         tile_collisions<G, WV, PED>(present, pose, velx, vely, (t + timestep) - t, bcx, bcy, rad_thr, trig_eps, nbr_thr, cell_inv, is_ped_type,
-                                    sl, tile0, lds, row, mult_rows, nbr);
+                                    sl, tile0, lds, row, mult_rows, nbr, dense);
         if (in_range) {
 #pragma unroll
             for (int c = 0; c < 6; ++c) { stf(dy, SG_F_POSE + c, pose[c]); stf(dy, SG_F_VEL + c, vel[c]); }
@@ -1444,7 +1459,7 @@ __device__ __forceinline__ void rollout_body(
         if (PED) { // the neighbour candidates (and LDS positions) of the current state
             uint64_t tmp_rows[WV];
             tile_collisions<G, WV, PED>(present, pose, velx, vely, (t + timestep) - t, bcx, bcy, rad_thr, trig_eps, nbr_thr,
-                                        cell_inv, is_ped_type, sl, tile0, lds, tmp_rows, mult_rows, nbr);
+                                        cell_inv, is_ped_type, sl, tile0, lds, tmp_rows, mult_rows, nbr, dense);
         }
 #pragma unroll
         for (int w = 0; w < WV; ++w) row[w] = fld<uint64_t>(dy, SG_F_COLL + w);
@@ -1685,7 +1700,7 @@ __device__ __forceinline__ void rollout_body(
         for (int w = 0; w < WV; ++w) nrow[w] = 0;
 #else
         tile_collisions<G, WV, PED>(present, pose, velx, vely, (t + timestep) - t, bcx, bcy, rad_thr, trig_eps, nbr_thr, cell_inv, is_ped_type,
-                                    sl, tile0, lds, nrow, mult_rows, nbr);
+                                    sl, tile0, lds, nrow, mult_rows, nbr, dense);
 #endif
         if (run) {
 #pragma unroll
