@@ -77,6 +77,37 @@ class BatchedScenarioGym:
         self.engine.set_external_poses(poses)
 
     # ------------------------------------------------------------------ set up
+    @classmethod
+    def run_scenarios(cls, paths: Sequence[str], create_agent=_create_agent, relabel: bool = True, workers: int = 8,
+                      **kwargs) -> List[Dict[str, Any]]:
+        """ScenarioGym.run_scenarios (scenario_gym.py:16-27) for a list of OpenSCENARIO files as ONE device batch:
+        parse (in parallel), pack, roll every scenario out, return the metrics of each."""
+        gym = cls(**kwargs)
+        try:
+            gym.load_scenarios(paths, create_agent=create_agent, relabel=relabel, workers=workers)
+            gym.rollout()
+            return gym.get_metrics()
+        finally:
+            gym.close()
+
+    def load_scenarios(self, paths: Sequence[str], create_agent=_create_agent, relabel: bool = True, workers: int = 8,
+                       max_steps: Optional[int] = None):
+        """ScenarioGym.load_scenario (scenario_gym.py:119-155) for many files: the XML is parsed on `workers`
+        threads (ElementTree releases the GIL while it reads), the batch is packed once."""
+        from concurrent.futures import ThreadPoolExecutor
+
+        from .xosc import import_scenario
+
+        paths = list(paths)
+        if workers > 1 and len(paths) > 1:
+            with ThreadPoolExecutor(min(workers, len(paths))) as ex:
+                scenarios = list(ex.map(lambda f: import_scenario(f, relabel=relabel), paths))
+        else:
+            scenarios = [import_scenario(f, relabel=relabel) for f in paths]
+        self.set_scenarios(scenarios, create_agent=create_agent, max_steps=max_steps)
+        for st, f in zip(self.states, paths):
+            st.scenario_path = f
+
     def set_scenarios(self, scenarios: Sequence[Scenario], create_agent=_create_agent, max_steps: Optional[int] = None):
         self.close()
         self.scenarios = list(scenarios)

@@ -426,3 +426,27 @@ def test_python_agent_with_host_vehicle_controller():
     assert np.abs(a - b).max() < 1e-9 and np.abs(a[:2] - g["a5e43fe4/scenario/knots"][0, 1:3]).max() > 0.1
     gym.close()
     ref.close()
+
+
+def test_batched_run_scenarios_from_files(tmp_path):
+    """scenario_gym.py:16-27 (`ScenarioGym.run_scenarios(paths)`) as one device batch: every file's metrics equal
+    the one-scenario-at-a-time ScenarioGym run."""
+    import scenario_gym_amd as sga
+    from test_host_api import CATALOG, XOSC
+
+    (tmp_path / "cats").mkdir()
+    (tmp_path / "cats" / "c.xosc").write_text(CATALOG)
+    paths = []
+    for k in range(5):  # the same small scenario with the ego's middle vertex moved
+        f = tmp_path / f"s{k}.xosc"
+        f.write_text(XOSC.replace('x="5"', f'x="{5 + k}"'))
+        paths.append(str(f))
+    metrics = lambda: [sga.EgoAvgSpeed(), sga.EgoMaxSpeed(), sga.EgoDistanceTravelled(), sga.CollisionMetric()]
+    batch = sga.BatchedScenarioGym.run_scenarios(paths, metrics=metrics, timestep=0.05)
+    assert len(batch) == 5 and len({m["ego_distance_travelled"] for m in batch}) == 5
+    for f, mb in zip(paths, batch):
+        gym = sga.ScenarioGym(timestep=0.05, metrics=metrics())
+        gym.load_scenario(f, relabel=True)
+        gym.rollout()
+        assert gym.get_metrics() == mb, f
+        gym.close()
