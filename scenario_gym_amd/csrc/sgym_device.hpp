@@ -245,11 +245,6 @@ __device__ __forceinline__ double sg_pred(double x) // nextafter(x, -inf) for fi
 
 __device__ __forceinline__ double shfl_d(double v, int src) { return __shfl(v, src, 64); }
 
-// wave votes on a lane predicate straight from the compare mask (the generic __any / __all take an int: the mask is
-// expanded to a VGPR and compared again -- two VALU and a scalar instruction per vote, ten votes per step)
-__device__ __forceinline__ bool wave_any(bool x) { return __builtin_amdgcn_ballot_w64(x) != 0; }
-__device__ __forceinline__ bool wave_all(bool x) { return __builtin_amdgcn_ballot_w64(!x) == 0; }
-
 // s_waitcnt vmcnt(0) (expcnt / lgkmcnt untouched).  Placed after every RARE block of global loads whose results
 // stay in registers across the time loop: the state stores of the steady state share vmcnt with those loads, and
 // without an explicit wait at the load site the compiler has to wait for vmcnt(0) -- i.e. for every store of the
@@ -756,7 +751,7 @@ __device__ __forceinline__ void ped_step(const Params &p, const LDS &L, int sl, 
         const double radius = L.ctrl[SG_C_PED_RADIUS - SG_C_PED_SPEED_DESIRED][sl];
         const double k2_scale = sf.ped_repulse_V / sf.ped_repulse_sigma;
         // the shortcuts of ped_pair need the sight-weight branch (c2 = w2 * att) and hold for the whole wavefront
-        const bool plain = wave_all(hs == 0.0 && hc == 1.0) && sf.ped_attract_C == 0.0 && sf.sight_weight > 0.0 &&
+        const bool plain = __all(hs == 0.0 && hc == 1.0) && sf.ped_attract_C == 0.0 && sf.sight_weight > 0.0 &&
                            sf.sight_weight_use != 0.0;
         // neighbours in entity order, one per iteration across all row words (the wavefront iterates
         // max-over-lanes of the TOTAL candidate count, not the sum of per-word maxima)
@@ -785,7 +780,7 @@ __device__ __forceinline__ void ped_step(const Params &p, const LDS &L, int sl, 
                     ped_pair<true, true>(FA, sf, k2_scale, pose[0], pose[1], hs, hc, ox, oy, ovx, ovy, odx, ody, step, c1x, c1y, c2x, c2y);
                 else
                     ped_pair<false, false>(FA, sf, k2_scale, pose[0], pose[1], hs, hc, ox, oy, ovx, ovy, odx, ody, step, c1x, c1y, c2x, c2y);
-                if (wave_any(FA.bad)) { // rare: some operand outside RecipDiv's range, or a sight weight on its threshold
+                if (__any(FA.bad)) { // rare: some operand outside RecipDiv's range, or a sight weight on its threshold
                     if (FA.bad) {
                         ExactArith EA;
                         ped_pair<false, false>(EA, sf, k2_scale, pose[0], pose[1], hs, hc, ox, oy, ovx, ovy, odx, ody, step, c1x, c1y, c2x, c2y);
@@ -852,7 +847,7 @@ __device__ __forceinline__ void tile_sync()
 template <int WV>
 __device__ __forceinline__ bool block_any(bool x)
 {
-    if (WV == 1) return wave_any(x);
+    if (WV == 1) return __any(x);
     return __syncthreads_or(x);
 }
 
@@ -938,7 +933,7 @@ __device__ __forceinline__ void tile_collisions(bool present, const double *pose
 #pragma unroll
         for (int w = 0; w < WV; ++w) {
             close[w] = 0;
-            while (wave_any(cand[w] != 0)) {
+            while (__any(cand[w] != 0)) {
                 ++iters;
                 if (cand[w]) {
                     const int jl = __builtin_ctzll(cand[w]);
@@ -1044,10 +1039,10 @@ __device__ __forceinline__ void tile_collisions(bool present, const double *pose
 #pragma unroll
     for (int w = 0; w < WV; ++w) fuzzy[w] = 0;
     bool any_fuzzy = false;
-    if (wave_any(any_cand)) {
+    if (__any(any_cand)) {
 #pragma unroll
         for (int w = 0; w < WV; ++w) {
-            while (wave_any(cand[w] != 0)) {
+            while (__any(cand[w] != 0)) {
                 if (cand[w]) {
                     const int jl = __builtin_ctzll(cand[w]);
                     cand[w] &= cand[w] - 1;
@@ -1095,7 +1090,7 @@ __device__ __forceinline__ void tile_collisions(bool present, const double *pose
 #pragma unroll
     for (int w = 0; w < WV; ++w) {
         eq[w] = 0;
-        while (wave_any(fuzzy[w] != 0)) {
+        while (__any(fuzzy[w] != 0)) {
             // every lane takes part in the cross-lane reads; idle lanes read their own corners
             const bool act = fuzzy[w] != 0;
             const int jl = act ? __builtin_ctzll(fuzzy[w]) : (slot & 63);
@@ -1504,7 +1499,7 @@ __device__ __forceinline__ void rollout_body(
     }
     for (; k < n_steps; ++k) {
         // per wavefront and before any workgroup barrier of the step: does a lane need its next segment?
-        if (wave_any(t + timestep > S.x_hi)) break;
+        if (__any(t + timestep > S.x_hi)) break;
         const bool run = in_range && (force || !done);
         if (!block_any<WV>(run)) { all_done = true; break; }
         // coefficient table: opaque per step so the scalar loads stay inside the loop (SGPRs for a few
@@ -1627,10 +1622,10 @@ __device__ __forceinline__ void rollout_body(
             RecipDiv rd(dt);
             const uint32_t zbits = (uint32_t)(__double2hiint(d[2]) | __double2hiint(d[4]) | __double2hiint(d[5])) |
                                    (uint32_t)(__double2loint(d[2]) | __double2loint(d[4]) | __double2loint(d[5]));
-            flat = wave_all((!run | !npres | (present & (zbits == 0))) & (dt > 0.0));
+            flat = __all((!run | !npres | (present & (zbits == 0))) & (dt > 0.0));
             bool safe = rd.safe(d[0]) & rd.safe(d[1]) & rd.safe(d[3]);
             if (!flat) safe = safe & rd.safe(d[2]) & rd.safe(d[4]) & rd.safe(d[5]);
-            if (wave_all(safe)) {
+            if (__all(safe)) {
                 vel[0] = rd.div(d[0]); vel[1] = rd.div(d[1]); vel[3] = rd.div(d[3]);
                 if (flat) {
                     vel[2] = vel[4] = vel[5] = 0.0;
