@@ -124,32 +124,6 @@ class VehicleController(Controller):
         row[L.C_ALLOW_REVERSE] = float(bool(self.allow_reverse))
         return row
 
-    # host execution (only for caller-run agents that pair a Python _step with this controller)
-    def _reset(self, state) -> None:
-        """controller.py:100-103."""
-        self.speed = float(np.linalg.norm(state.velocities[self.entity][:2]))
-        self.l = self.entity.bounding_box.length
-
-    def _step(self, state, action):
-        """controller.py:105-140: the kinematic bicycle step from (accel, steer)."""
-        accel = float(np.clip(action.acceleration, -self.max_accel, self.max_accel))
-        steer = float(np.clip(action.steering, -self.max_steer, self.max_steer))
-        pose = state.poses[self.entity].copy()
-        dt = state.next_t - state.t
-        h = pose[3]
-        dx, dy = self.speed * np.cos(h), self.speed * np.sin(h)
-        dh = self.speed * np.tan(steer) / self.l
-        pose[0] += dx * dt
-        pose[1] += dy * dt
-        pose[3] += dh * dt
-        speed = self.speed + accel * dt
-        if not self.allow_reverse:
-            speed = max(0.0, speed)
-        if self.max_speed is not None:
-            speed = min(self.max_speed, speed)
-        self.speed = speed
-        return pose
-
 
 class PIDController(VehicleController):
     """controller.py:143-258."""
@@ -179,14 +153,26 @@ class Agent:
         self.last_reward = None
 
     def device_kind(self) -> int:
+        """A Python `_step` over the built-in VehicleController: the policy runs in the caller, the controller on the
+        device (the (accel, steer) action goes down with every tick, like ExternalVehicleAgent).  Anything else with a
+        Python `_step`: the whole chain runs in the caller and the pose is injected (KIND_AGENT_EXTERNAL)."""
+        if type(self.controller) is VehicleController and type(self).step is Agent.step:
+            return L.KIND_AGENT_VEHICLE
         return L.KIND_AGENT_EXTERNAL
+
+    def host_action(self, state):
+        """sensor -> _step for agents whose controller runs on the device: the VehicleAction of this tick."""
+        action = self._step(self.sensor.step(state))
+        self.last_action = action
+        return action
 
     def reset(self, state) -> None:
         """agent.py:43-50."""
         self.last_action = None
         self.last_reward = None
         self.sensor.reset(state)
-        self.controller.reset(state)
+        if self.device_kind() == L.KIND_AGENT_EXTERNAL:
+            self.controller.reset(state)  # built-in controllers are reset on the device (sg_reset)
         self._reset()
 
     def step(self, state):
@@ -244,6 +230,8 @@ class ExternalVehicleAgent(Agent):
 
     def device_kind(self):
         return L.KIND_AGENT_VEHICLE
+
+    host_action = None  # the caller of step(actions) supplies the action
 
 
 def _create_agent(scenario: Scenario, entity: Entity) -> Optional[Agent]:

@@ -38,6 +38,7 @@ class BatchedScenarioGym:
         self.engine: Optional[RolloutEngine] = None
         self.scenarios: List[Scenario] = []
         self._host_agents: list = []
+        self._policy_agents: list = []
         self.states: List[State] = []
         self.metrics: List[List[Metric]] = []
         self._cache = None
@@ -60,21 +61,30 @@ class BatchedScenarioGym:
 
     def _per_step_host_path(self) -> bool:
         custom_metric = any(not isinstance(m, _DeviceMetric) for ms in self.metrics for m in ms)
-        return bool(custom_metric or self.state_callbacks or self._host_terminals() or self._host_agents)
+        return bool(custom_metric or self.state_callbacks or self._host_terminals() or self._host_agents
+                    or self._policy_agents)
 
-    def _push_host_agents(self):
-        """scenario_gym.py:233-239 for the agents that run in Python: agent.step(state) of every present one, its pose
-        (or None -> NaN) handed to the next device step."""
-        if not self._host_agents:
-            return
-        poses = np.full((len(self.states), self._packed.n_entities, 6), np.nan)
-        for i, slot, agent in self._host_agents:
-            st = self.states[i]
-            if agent.entity in st.poses:
-                pose = agent.step(st)
-                if pose is not None:
-                    poses[i, slot] = np.asarray(pose, np.float64)
-        self.engine.set_external_poses(poses)
+    def _push_host_agents(self, actions):
+        """scenario_gym.py:233-239 for the agents that run in Python.  Pose agents: agent.step(state) of every present
+        one, its pose (or None -> NaN) handed to the next device step.  Policy agents (Python `_step` over the built-in
+        VehicleController): their (accel, steer) of this tick; returns the action array for sg_step."""
+        if self._host_agents:
+            poses = np.full((len(self.states), self._packed.n_entities, 6), np.nan)
+            for i, slot, agent in self._host_agents:
+                st = self.states[i]
+                if agent.entity in st.poses:
+                    pose = agent.step(st)
+                    if pose is not None:
+                        poses[i, slot] = np.asarray(pose, np.float64)
+            self.engine.set_external_poses(poses)
+        if self._policy_agents:
+            actions = np.zeros((1, len(self.states), 2)) if actions is None else np.array(actions, np.float64).reshape(1, -1, 2)
+            for i, agent in self._policy_agents:
+                st = self.states[i]
+                if agent.entity in st.poses:
+                    a = agent.host_action(st)
+                    actions[0, i] = (a.acceleration, a.steering)
+        return actions
 
     # ------------------------------------------------------------------ set up
     @classmethod
@@ -133,6 +143,11 @@ class BatchedScenarioGym:
         from . import _lib as L
         self._host_agents = [(i, sc.entities.index(e), a) for i, sc in enumerate(self.scenarios)
                              for e, a in agents[i].items() if a.device_kind() == L.KIND_AGENT_EXTERNAL]
+        # a Python policy over the device VehicleController: the action array carries one (accel, steer) per scenario
+        self._policy_agents = [(i, a) for i, sc in enumerate(self.scenarios) for e, a in agents[i].items()
+                               if a.device_kind() == L.KIND_AGENT_VEHICLE and getattr(a, "host_action", None) is not None]
+        if len({i for i, _ in self._policy_agents}) != len(self._policy_agents):
+            raise NotImplementedError("one external-action vehicle agent per scenario (sg_step actions are [n][R][2])")
         self.metrics = [list(self.metric_factory()) for _ in self.scenarios]
         self._invalidate()
         self._prev_state = None
@@ -157,6 +172,8 @@ class BatchedScenarioGym:
 
     def _reset_host_side(self):
         for i, _, agent in self._host_agents:  # Agent.reset -> sensor / controller reset (scenario_gym.py:217-225)
+            agent.reset(self.states[i])
+        for i, agent in self._policy_agents:
             agent.reset(self.states[i])
         for st, ms in zip(self.states, self.metrics):
             for m in ms:
@@ -188,7 +205,8 @@ class BatchedScenarioGym:
         """n x ScenarioGym.step() for every scenario; actions [n, R, 2] for ExternalVehicleAgent egos."""
         if n == 1 or not self._per_step_host_path():
             self._prev_state = self._fetch_state() if self._per_step_host_path() or n == 1 else None
-            self._push_host_agents()
+            if n == 1:
+                actions = self._push_host_agents(actions)
             self.engine.step(n, actions)
             self._invalidate()
             if self._per_step_host_path():
@@ -210,8 +228,7 @@ class BatchedScenarioGym:
             for _ in range(max_steps):
                 # a scenario that finished keeps stepping on the device but is frozen for the caller
                 self._prev_state = self._fetch_state()
-                self._push_host_agents()
-                self.engine.step(1)
+                self.engine.step(1, self._push_host_agents(None))
                 self._invalidate()
                 done |= self._after_host_step() | self._fetch_state()["done"]
                 if done.all():

@@ -394,10 +394,11 @@ def test_python_agent_returning_none(persist):
     gym.close()
 
 
-def test_python_agent_with_host_vehicle_controller():
-    """A Python policy emitting VehicleAction through the built-in VehicleController (run on the host for caller-run
-    agents) follows the same kinematics as the device ExternalVehicleAgent fed the same actions (<= 1e-9)."""
+def test_python_policy_over_device_vehicle_controller():
+    """A Python policy (`_step` -> VehicleAction) paired with the built-in VehicleController: the policy runs in the
+    caller every tick, the controller stays on the device -- the same bits as ExternalVehicleAgent fed the same actions."""
     import scenario_gym_amd as sga
+    import scenario_gym_amd._lib as L
 
     g = load_golden("scenarios")
     acts = np.random.default_rng(3).uniform([-2, -0.3], [2, 0.3], (50, 2))
@@ -408,12 +409,16 @@ def test_python_agent_with_host_vehicle_controller():
             self.k = 0
 
         def _step(self, observation):
+            assert observation[2] is not None  # the ego's pose from State.get_entity_data
             a = sga.VehicleAction(*acts[self.k])
             self.k += 1
             return a
 
+    made = []
     gym = sga.ScenarioGym()
-    gym.set_scenario(_scenario(g, "a5e43fe4/scenario"), create_agent=lambda sc, e: Policy(e) if e.ref == "ego" else None)
+    gym.set_scenario(_scenario(g, "a5e43fe4/scenario"),
+                     create_agent=lambda sc, e: (made.append(Policy(e)) or made[-1]) if e.ref == "ego" else None)
+    assert made[0].device_kind() == L.KIND_AGENT_VEHICLE
     gym.reset_scenario()
     ref = sga.ScenarioGym()
     ref.set_scenario(_scenario(g, "a5e43fe4/scenario"),
@@ -423,7 +428,7 @@ def test_python_agent_with_host_vehicle_controller():
         gym.step()
         ref.step(acts[k])
     a, b = gym.state.poses[gym.state.scenario.entities[0]], ref.state.poses[ref.state.scenario.entities[0]]
-    assert np.abs(a - b).max() < 1e-9 and np.abs(a[:2] - g["a5e43fe4/scenario/knots"][0, 1:3]).max() > 0.1
+    assert made[0].k == 50 and bits_equal(a, b) and np.abs(a[:2] - g["a5e43fe4/scenario/knots"][0, 1:3]).max() > 0.1
     gym.close()
     ref.close()
 
