@@ -1,0 +1,23 @@
+import sys, time
+sys.path.insert(0, '.')
+import numpy as np
+import scenario_gym_amd as sga
+import scenario_gym_amd._lib as L
+from scenario_gym_amd import synthetic
+R, E = 4096, 64
+packed = synthetic.make_batch(R, E, n_steps=2000, ego_kind=L.KIND_AGENT_VEHICLE)
+eng = sga.RolloutEngine(R, E)
+eng.upload(packed)
+acts = synthetic.make_actions(1200, R)
+for k in range(100):
+    eng.step(1, acts[k:k+1])
+t0 = time.perf_counter()
+for k in range(100, 1100):
+    eng.step(1, acts[k:k+1])
+dt = (time.perf_counter() - t0) / 1000
+print(f"tick (sg_step(1) with host actions, {R}x{E}): {dt*1e6:.1f} us -> {R*E/dt/1e9:.2f} G entity-steps/s")
+t0 = time.perf_counter()
+eng.step(1000, acts[100:1100])
+dt = (time.perf_counter() - t0)
+print(f"sg_step(1000) with host actions: {dt*1e3:.2f} ms -> {R*E*1000/dt/1e9:.2f} G entity-steps/s")
+eng.close()
