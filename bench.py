@@ -101,6 +101,10 @@ def main():
     ap.add_argument("--workload", default="c3", choices=["c3", "c2", "c5"],
                     help="BASELINE.json configs: c3 = 4096x64 PID ego (default, the headline), c2 = 256x16 replay, "
                          "c5 = 1024x256 social-force crowd")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak (default): --scenarios per GPU; strong: --scenarios in total, split evenly over the ranks "
+                         "(BASELINE.json configs[3] read literally: 4096 replicas over 8 GPUs = 512 per GPU, half a "
+                         "wavefront per SIMD)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -121,6 +125,10 @@ def main():
     if args.gpus != world and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
     dev = torch.device("cuda", local_rank)
+    if args.scaling == "strong":
+        if args.scenarios % world:
+            raise SystemExit(f"--scaling strong: {args.scenarios} scenarios do not split evenly over {world} ranks")
+        args.scenarios //= world
 
     dt = 1.0 / 30.0
     ego_kind = L.KIND_AGENT_PID if args.ego == "pid" else L.KIND_AGENT_REPLAY
@@ -189,7 +197,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
