@@ -217,6 +217,12 @@ void *sg_stream(sg_handle *h); /* hipStream_t */
 
 int sg_state_view_get(sg_handle *h, sg_state_view *out);
 
+/* FutureCollisionDetector._step (sensor/common.py:59-106) for the ego of every scenario at its current State.t:
+ * out[r] = 1 iff, at one of the n_samples times np.linspace(t, t + horizon, n_samples), the ego's box at
+ * trajectory.position_at_t(t_j) overlaps another entity's box at that entity's own position_at_t(t_j) (reference
+ * defaults: horizon 5.0, 10 samples).  out: HOST [R]. */
+int sg_future_collision(sg_handle *h, double horizon, int32_t n_samples, uint8_t *out);
+
 /* ScenarioGym.get_metrics (scenario_gym.py:308-319): out [R]; events [cap] (may be NULL) */
 int sg_read_metrics(sg_handle *h, sg_metrics *out, sg_event *events, int32_t cap, int32_t *n_events);
 

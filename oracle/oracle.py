@@ -204,6 +204,21 @@ def corners(pose, bbox):
     return out
 
 
+def future_collision(knot_off, knots, bbox, kind, ego, t, horizon=5.0, n_samples=10):
+    """FutureCollisionDetector._step (sensor/common.py:87-106) for one scenario at state time t."""
+    E = int(len(kind))
+    knot_off = np.ascontiguousarray(knot_off, np.int64)
+    knots = np.ascontiguousarray(knots, np.float64)
+    bbox = np.ascontiguousarray(bbox, np.float64)
+    kind = np.ascontiguousarray(kind, np.int32)
+    etype = np.zeros(E, np.int32)
+    ctrl = np.zeros((E, 16))
+    sc = _Scenario(E, int(ego), _p(kind), _p(etype), _p(bbox), _p(knot_off), _p(knots), _p(ctrl), 0.0, 0.0, None, None)
+    L = lib()
+    L.sgo_future_collision.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_int]
+    return bool(L.sgo_future_collision(C.byref(sc), float(t), float(horizon), int(n_samples)))
+
+
 def quads_intersect(a, b):
     a = np.ascontiguousarray(a, np.float64)
     b = np.ascontiguousarray(b, np.float64)

@@ -406,6 +406,35 @@ static int corners_equal(const double *a, const double *b)
     return 1;
 }
 
+/* FutureCollisionDetector._step (scenario_gym/sensor/common.py:87-106): the ego's box at
+ * trajectory.position_at_t(t_j) against every other entity's box at ITS position_at_t(t_j) (clamped outside the
+ * trajectory, presence is not consulted), t_j = np.linspace(t, t + horizon, n): any closed-set overlap whose geometry
+ * differs from the ego's (utils.py:59).  np.linspace (numpy/_core/function_base.py): step = (stop - start) / (n - 1),
+ * y_j = j * step + start, y_{n-1} = stop. */
+int sgo_future_collision(const sgo_scenario *sc, double t, double horizon, int n)
+{
+    const int E = sc->n_entities, ego = sc->ego;
+    const double start = t, stop = t + horizon;
+    const double step = n > 1 ? (stop - start) / (double)(n - 1) : 0.0;
+    for (int j = 0; j < n; ++j) {
+        double tj = (double)j * step + start;
+        if (n > 1 && j == n - 1) tj = stop;
+        double pe[6], ce[8];
+        const double *ke = sc->knots + sc->knot_off[ego] * 7;
+        sgo_position_at_t(ke, (int)(sc->knot_off[ego + 1] - sc->knot_off[ego]), tj, 0, 0, 0, pe);
+        sgo_corners(pe, sc->bbox + (size_t)ego * 4, ce);
+        for (int i = 0; i < E; ++i) {
+            if (i == ego || sc->kind[i] == 0) continue;
+            double pi[6], ci[8];
+            const double *ki = sc->knots + sc->knot_off[i] * 7;
+            sgo_position_at_t(ki, (int)(sc->knot_off[i + 1] - sc->knot_off[i]), tj, 0, 0, 0, pi);
+            sgo_corners(pi, sc->bbox + (size_t)i * 4, ci);
+            if (!corners_equal(ce, ci) && sgo_quads_intersect(ce, ci)) return 1;
+        }
+    }
+    return 0;
+}
+
 /* State.collisions -> detect_collisions -> detect_geom_collisions
  * (scenario_gym/state/state.py:306-310, state/utils.py:10-49, utils.py:28-62).
  * rows[i] bit j set <=> entity j is listed for entity i.  Geometry-equality quirks:

@@ -5,6 +5,7 @@ from .agent import (  # noqa: F401
     Controller,
     EgoLocalizationSensor,
     ExternalVehicleAgent,
+    FutureCollisionDetector,
     PIDController,
     ReplayTrajectoryController,
     Sensor,

@@ -71,6 +71,22 @@ class EgoLocalizationSensor(Sensor):
         return state.get_entity_data(self.entity)
 
 
+class FutureCollisionDetector(Sensor):
+    """sensor/common.py:59-106: the localisation observation plus `future_collision` -- does the entity's box, moved along
+    its trajectory over `horizon` seconds (10 samples), meet another entity's box at that entity's trajectory position?
+    The look-ahead runs on the device for the whole batch (sg_future_collision); the sensor's entity must be the
+    scenario's ego."""
+
+    def __init__(self, entity: Entity, horizon: float = 5.0):
+        super().__init__(entity)
+        self.horizon = horizon
+
+    def _step(self, state):
+        if state.scenario.ego is not self.entity:
+            raise NotImplementedError("the device look-ahead is evaluated for the ego of each scenario")
+        return tuple(state.get_entity_data(self.entity)) + (state.future_collision(self.horizon),)
+
+
 class Controller:
     """controller.py:12-42: reset(state) / step(state, action) -> pose around the _reset / _step hooks."""
 

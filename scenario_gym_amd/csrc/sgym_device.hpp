@@ -2000,6 +2000,71 @@ __global__ __launch_bounds__(64, SG_CTL_WAVES) void control_kernel(Params p, dou
     cst[(CS_METRIC + 0) * NP] = m_avg; cst[(CS_METRIC + 1) * NP] = m_max; cst[(CS_METRIC + 2) * NP] = m_t;
 }
 
+// ------------------------------------------------------------------------------------------------
+// FutureCollisionDetector._step (sensor/common.py:87-106), SURVEY 8f N2: does the ego's box, moved along its
+// trajectory to n sample times in [t, t + horizon] (np.linspace), overlap any other entity's box at that entity's own
+// trajectory position (clamped outside the trajectory; presence is not consulted)?  One workgroup per scenario, one
+// thread per entity slot, exact fp64 predicate (the operation sequence of the oracle), geometry equal to the ego's
+// never counts (utils.py:59).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void own_position_clamped(const double *kn, int n, double t, double (&out)[6])
+{
+    // Trajectory.position_at_t with the default extrapolate=(False, False): trajectory.py:185-196
+    const double *last = kn + (size_t)(n - 1) * 7;
+    if (t < kn[0]) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) out[c] = kn[1 + c];
+    } else if (t > last[0]) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) out[c] = last[1 + c];
+    } else {
+        own_position_extrap(kn, n, t, out);
+    }
+}
+
+__global__ __launch_bounds__(256) void future_kernel(Params p, double horizon, int n_samples, unsigned char *out /*[R]*/)
+{
+    __shared__ double ego_c[8];
+    const int r = blockIdx.x, e = threadIdx.x;
+    const ScenStatic &ss = p.sstat[r];
+    const uint32_t idx = (uint32_t)r * p.EP + (e < p.EP ? e : 0);
+    const LanePtr st(p.stat + (size_t)(idx >> 6) * (ST_COUNT * 64), (idx & 63) * 8u);
+    const int64_t meta = fld<int64_t>(st, ST_META);
+    const bool active = e < p.E && (int)(meta & 0xff) != SG_KIND_NONE;
+    const double *kn = p.knots + fld<int64_t>(st, ST_KNOT_OFF) * 7;
+    const int nk = (int)(meta >> 32);
+    const double bw = fld(st, ST_BW), bl = fld(st, ST_BL), bcx = fld(st, ST_BCX), bcy = fld(st, ST_BCY);
+    const double start = p.sdyn[r].t, stop = start + horizon;
+    const double step = n_samples > 1 ? (stop - start) / (double)(n_samples - 1) : 0.0; // np.linspace
+    bool hit = false;
+    for (int j = 0; j < n_samples; ++j) {
+        double tj = (double)j * step + start;
+        if (n_samples > 1 && j == n_samples - 1) tj = stop;
+        double C[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (active) {
+            double pose[6], s, c;
+            own_position_clamped(kn, nk, tj, pose);
+            sg_sincos(pose[3], s, c);
+            sg_corners(pose[0], pose[1], s, c, bw, bl, bcx, bcy, C);
+            if (e == ss.ego) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) ego_c[k] = C[k];
+            }
+        }
+        __syncthreads();
+        if (active && e != ss.ego) {
+            double A[8];
+            bool same = true;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { A[k] = ego_c[k]; same = same && (A[k] == C[k]); }
+            if (!same && sg_quads_intersect(A, C)) hit = true;
+        }
+        __syncthreads();
+    }
+    const int any = __syncthreads_or(hit);
+    if (e == 0) out[r] = (unsigned char)(any != 0);
+}
+
 // sg_debug_trig32: the broad phase's hardware sin/cos, exposed so that the parity tests can bound its error
 __global__ void trig32_kernel(const double *h, float *s, float *c, int64_t n)
 {

@@ -755,3 +755,19 @@ extern "C" int sg_set_tuning(sg_handle *h, int32_t tab_min_steps, int32_t chunk_
     if (overlap >= 0) h->overlap = overlap != 0;
     return SG_OK;
 }
+
+extern "C" int sg_future_collision(sg_handle *h, double horizon, int32_t n_samples, uint8_t *out)
+{
+    if (!h || !out || n_samples < 1 || !(horizon >= 0.0)) return h ? fail(h, SG_ERR_INVALID, "sg_future_collision: bad argument") : SG_ERR_INVALID;
+    if (!h->uploaded) return fail(h, SG_ERR_STATE, "sg_future_collision: no scenarios uploaded");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    unsigned char *d = nullptr;
+    HIP_TRY(h, hipMalloc((void **)&d, (size_t)h->R));
+    sg::future_kernel<<<dim3((unsigned)h->R), dim3(256), 0, h->stream>>>(h->p, horizon, n_samples, d);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d, (size_t)h->R, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(h, SG_ERR_HIP, "sg_future_collision: %s", hipGetErrorString(e));
+    return SG_OK;
+}

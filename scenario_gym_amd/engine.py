@@ -165,6 +165,12 @@ class RolloutEngine:
         poses = np.ascontiguousarray(poses, np.float64).reshape(self.R, self.E, 6)
         self._check(self.lib.sg_set_external_poses(self.h, poses.ctypes.data), "sg_set_external_poses")
 
+    def future_collision(self, horizon=5.0, n_samples=10):
+        """FutureCollisionDetector (sensor/common.py:59-106) for the ego of every scenario at the current time: bool [R]."""
+        out = np.zeros(self.R, np.uint8)
+        self._check(self.lib.sg_future_collision(self.h, float(horizon), int(n_samples), out.ctypes.data), "sg_future_collision")
+        return out.astype(bool)
+
     def rollout(self, max_steps):
         self._check(self.lib.sg_rollout(self.h, int(max_steps)), "sg_rollout")
 

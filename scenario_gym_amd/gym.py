@@ -44,6 +44,7 @@ class BatchedScenarioGym:
         self._cache = None
         self._prev_state = None
         self._rec = None
+        self._fut = None
 
     # ------------------------------------------------------------------ properties
     @property
@@ -156,11 +157,19 @@ class BatchedScenarioGym:
     def _invalidate(self):
         self._cache = None
         self._rec = None
+        self._fut = None
 
     def _fetch_state(self):
         if self._cache is None:
             self._cache = self.engine.state()
         return self._cache
+
+    def _future(self, horizon: float, n_samples: int):
+        key = (horizon, n_samples)
+        if self._fut is None or key not in self._fut:
+            self._fut = dict(self._fut or {})
+            self._fut[key] = self.engine.future_collision(horizon, n_samples)
+        return self._fut[key]
 
     def _fetch_record(self):
         if not self.record:

@@ -110,6 +110,10 @@ class State:
     def get_entity_box_points(self, e: Entity) -> np.ndarray:
         return e.get_bounding_box_points(self.poses[e])
 
+    def future_collision(self, horizon: float = 5.0, n_samples: int = 10) -> bool:
+        """FutureCollisionDetector(ego, horizon) at the current time (sensor/common.py:87-106), computed on the device."""
+        return bool(self._gym._future(float(horizon), int(n_samples))[self._i])
+
     def get_entities_in_area(self, area) -> List[Entity]:
         """state.py:340-354: entities whose centre point lies strictly inside `area`.  The reference takes a shapely
         (Multi)Polygon; here `area` is anything with `.exterior.coords`, or an (n, 2) array of ring vertices (simple

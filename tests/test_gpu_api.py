@@ -455,3 +455,31 @@ def test_batched_run_scenarios_from_files(tmp_path):
         gym.rollout()
         assert gym.get_metrics() == mb, f
         gym.close()
+
+
+def test_future_collision_detector_matches_reference():
+    """FutureCollisionDetector (sensor/common.py:59-106) evaluated on the device after reset and after every step of the
+    reference's own rollouts (five XOSC scenarios, two time steps, horizons 5.0 and 1.0): every flag equals the
+    reference's; the sensor object returns it inside the observation."""
+    import scenario_gym_amd as sga
+
+    gs, g = load_golden("scenarios"), load_golden("sensors")
+    n_pos = 0
+    for name in g["names"]:
+        for dtn, dt in (("dt30", 1 / 30), ("dt10", 0.1)):
+            ts, want = g[f"{name}/{dtn}/t"], g[f"{name}/{dtn}/future"].astype(bool)
+            gym = sga.ScenarioGym(timestep=dt)
+            gym.set_scenario(_scenario(gs, f"{name}/scenario"))
+            gym.reset_scenario()
+            sensor = sga.FutureCollisionDetector(gym.state.scenario.entities[0], horizon=5.0)
+            for k, t in enumerate(ts):
+                assert gym.state.t == t
+                got = [gym.state.future_collision(h) for h in g["horizons"]]
+                assert got == list(want[k]), (name, dtn, k)
+                if k % 50 == 0:
+                    assert sensor.step(gym.state)[-1] == want[k, 0]
+                n_pos += sum(got)
+                if k + 1 < len(ts):
+                    gym.step()
+            gym.close()
+    assert n_pos > 300

@@ -733,3 +733,29 @@ def test_full_horizon_matches_oracle(sga, oracle):
         assert rows["n_collisions"][r] == o["n_events"]
         m = min(len(ev), 64)
         assert np.array_equal(ev["t"][:m], o["ev_t"][:m]) and np.array_equal(ev["other"][:m], o["ev_other"][:m]), r
+
+
+def test_future_collision_batch_matches_oracle(sga, oracle):
+    """sg_future_collision on a synthetic batch (512 x 24, dense scenes) at three state times and three horizons:
+    every scenario's flag equals the oracle's; both outcomes occur."""
+    from scenario_gym_amd import synthetic
+    from scenario_gym_amd.packing import unpack_scenario
+
+    R, E = 512, 24
+    packed = synthetic.make_batch(R, E, n_steps=300, static_frac=0.15, vanish_frac=0.2, extent=25.0)
+    eng = sga.RolloutEngine(R, E)
+    eng.upload(packed)
+    seen = set()
+    for n_adv in (0, 70, 90):
+        if n_adv:
+            eng.step(n_adv)
+        t = eng.state()["t"]
+        for horizon, n in ((5.0, 10), (1.0, 10), (0.5, 4)):
+            got = eng.future_collision(horizon, n)
+            for r in range(0, R, 3):
+                s = unpack_scenario(packed, r)
+                want = oracle.future_collision(s["knot_off"], s["knots"], s["bbox"], s["kind"], s["ego"], t[r], horizon, n)
+                assert got[r] == want, (n_adv, horizon, r)
+                seen.add(bool(want))
+    eng.close()
+    assert seen == {True, False}

@@ -298,3 +298,22 @@ def test_radius_query_known_answers(oracle):
     assert oracle.in_radius(0, 0, r, (apothem - 1e-9) * np.cos(mid), -(apothem - 1e-9) * np.sin(mid))
     assert not oracle.in_radius(0, 0, r, (apothem + 1e-9) * np.cos(mid), -(apothem + 1e-9) * np.sin(mid))
     assert oracle.in_radius(0, 0, r, r - 1e-9, 0.0) and not oracle.in_radius(0, 0, r, r, 0.0)  # a vertex is not inside
+
+
+def test_future_collision_detector_matches_reference(oracle):
+    """FutureCollisionDetector (sensor/common.py:59-106) along the reference's own rollouts of five XOSC scenarios at two
+    time steps and two horizons: the oracle's flag at every state time equals the reference's (2 x 3849 evaluations)."""
+    from scenario_gym_amd.packing import default_kinds
+
+    gs, g = load_golden("scenarios"), load_golden("sensors")
+    n_pos = 0
+    for name in g["names"]:
+        s = scenario_arrays(gs, f"{name}/scenario")
+        kind = default_kinds(len(s["bbox"]), int(s["ego"]))
+        for dtn in ("dt30", "dt10"):
+            ts, want = g[f"{name}/{dtn}/t"], g[f"{name}/{dtn}/future"]
+            for hi, h in enumerate(g["horizons"]):
+                got = np.array([oracle.future_collision(s["knot_off"], s["knots"], s["bbox"], kind, s["ego"], t, h) for t in ts])
+                assert np.array_equal(got, want[:, hi].astype(bool)), (name, dtn, h)
+                n_pos += int(got.sum())
+    assert n_pos > 300

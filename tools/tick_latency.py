@@ -21,3 +21,16 @@ eng.step(1000, acts[100:1100])
 dt = (time.perf_counter() - t0)
 print(f"sg_step(1000) with host actions: {dt*1e3:.2f} ms -> {R*E*1000/dt/1e9:.2f} G entity-steps/s")
 eng.close()
+
+# FutureCollisionDetector look-ahead for the ego of every scenario
+eng = sga.RolloutEngine(R, E)
+eng.upload(packed)
+eng.step(300)
+eng.future_collision()
+t0 = time.perf_counter()
+for _ in range(50):
+    f = eng.future_collision(5.0, 10)
+dt = (time.perf_counter() - t0) / 50
+print(f"sg_future_collision (horizon 5 s, 10 samples, {R}x{E}): {dt*1e6:.0f} us per call = {R*(E-1)*10/dt/1e9:.2f} G box pairs/s, "
+      f"{int(f.sum())} of {R} scenarios flagged")
+eng.close()
