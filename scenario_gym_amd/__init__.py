@@ -6,6 +6,7 @@ from .agent import (  # noqa: F401
     EgoLocalizationSensor,
     ExternalVehicleAgent,
     FutureCollisionDetector,
+    GlobalCollisionDetector,
     PIDController,
     ReplayTrajectoryController,
     Sensor,

@@ -87,6 +87,13 @@ class FutureCollisionDetector(Sensor):
         return tuple(state.get_entity_data(self.entity)) + (state.future_collision(self.horizon),)
 
 
+class GlobalCollisionDetector(Sensor):
+    """sensor/common.py:115-129: the localisation observation plus State.collisions() (the device's adjacency rows)."""
+
+    def _step(self, state):
+        return tuple(state.get_entity_data(self.entity)) + (state.collisions(),)
+
+
 class Controller:
     """controller.py:12-42: reset(state) / step(state, action) -> pose around the _reset / _step hooks."""
 

@@ -112,6 +112,8 @@ def test_collision_scene_and_terminal_condition():
     gym.rollout()
     assert gym.state.collisions()[ego] == [haz] and gym.state.collisions()[haz] == [ego]
     assert gym.get_metrics()["collisions"] == [(8.799999999999985, "entity_1", "non_vehicle")]
+    obs = sga.GlobalCollisionDetector(ego).step(gym.state)  # sensor/common.py:115-129
+    assert obs[-1] == gym.state.collisions() and np.array_equal(obs[2], gym.state.poses[ego])
     gym2 = sga.ScenarioGym(timestep=0.1, terminal_conditions=["max_length", "collision"])
     gym2.set_scenario(sc)
     gym2.rollout()
