@@ -223,6 +223,12 @@ int sg_state_view_get(sg_handle *h, sg_state_view *out);
  * defaults: horizon 5.0, 10 samples).  out: HOST [R]. */
 int sg_future_collision(sg_handle *h, double horizon, int32_t n_samples, uint8_t *out);
 
+/* RasterizedMapSensor "entity" layer (sensor/map.py:120-192) for the ego of every scenario at the current state:
+ * out[r][i][j] = 1 iff the point (linspace(-width/2, width/2, nw)[j], linspace(-height/2, height/2, nh)[i]) of the ego's
+ * frame (rotated by heading + pi/2) lies strictly inside the bounding box of a present entity, the ego included;
+ * all zeros for a scenario whose ego is absent.  The reference sensor has nw == nh.  out: HOST [R][nh][nw] bytes. */
+int sg_raster_entities(sg_handle *h, double width, double height, int32_t nw, int32_t nh, uint8_t *out);
+
 /* ScenarioGym.get_metrics (scenario_gym.py:308-319): out [R]; events [cap] (may be NULL) */
 int sg_read_metrics(sg_handle *h, sg_metrics *out, sg_event *events, int32_t cap, int32_t *n_events);
 

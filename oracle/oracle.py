@@ -219,6 +219,18 @@ def future_collision(knot_off, knots, bbox, kind, ego, t, horizon=5.0, n_samples
     return bool(L.sgo_future_collision(C.byref(sc), float(t), float(horizon), int(n_samples)))
 
 
+def raster_entities(poses, bbox, ego, width=20.0, height=20.0, nw=20, nh=20):
+    """RasterizedMapSensor "entity" layer (sensor/map.py:120-192): [nh][nw] bool; poses [E][6], NaN = absent."""
+    poses = np.ascontiguousarray(poses, np.float64)
+    bbox = np.ascontiguousarray(bbox, np.float64)
+    out = np.zeros((nh, nw), np.uint8)
+    L = lib()
+    L.sgo_raster_entities.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.c_void_p]
+    L.sgo_raster_entities.restype = None
+    L.sgo_raster_entities(_p(poses), _p(bbox), len(poses), int(ego), float(width), float(height), int(nw), int(nh), _p(out))
+    return out.astype(bool)
+
+
 def quads_intersect(a, b):
     a = np.ascontiguousarray(a, np.float64)
     b = np.ascontiguousarray(b, np.float64)

@@ -435,6 +435,50 @@ int sgo_future_collision(const sgo_scenario *sc, double t, double horizon, int n
     return 0;
 }
 
+static double linspace_at(double start, double stop, int n, int j)
+{ /* np.linspace: step = (stop - start) / (n - 1); y_j = j * step + start; y_{n-1} = stop */
+    if (n > 1 && j == n - 1) return stop;
+    const double step = n > 1 ? (stop - start) / (double)(n - 1) : 0.0;
+    return (double)j * step + start;
+}
+
+/* RasterizedMapSensor, "entity" layer (scenario_gym/sensor/map.py:120-192): out[i][j] = 1 iff the grid point
+ *   X[i][j] = (linspace(-width/2, width/2, nw)[j], linspace(-height/2, height/2, nh)[i])
+ * rotated by theta = ego heading + pi/2 and moved to the ego (`(X @ R.T) + xy`; numpy's matmul evaluates each
+ * coordinate as fma(X1, R.T[1][k], X0 * R.T[0][k]) -- probed 11537/11537) lies strictly inside the bounding box of a
+ * present entity (the ego included; shapely `contains`: boundary points are outside).
+ * poses [E][6] with NaN x for absent entities. */
+void sgo_raster_entities(const double *poses, const double *bbox, int E, int ego, double width, double height, int nw,
+                         int nh, uint8_t *out)
+{
+    const double *pe = poses + (size_t)ego * 6;
+    double s, c;
+    sgo_sincos(pe[3] + 3.14159265358979311600e+00 / 2, &s, &c);
+    double *cor = (double *)malloc((size_t)E * 8 * sizeof(double));
+    for (int e = 0; e < E; ++e)
+        if (poses[(size_t)e * 6] == poses[(size_t)e * 6]) sgo_corners(poses + (size_t)e * 6, bbox + (size_t)e * 4, cor + (size_t)e * 8);
+    for (int i = 0; i < nh; ++i)
+        for (int j = 0; j < nw; ++j) {
+            const double x0 = linspace_at(-width / 2, width / 2, nw, j), x1 = linspace_at(-height / 2, height / 2, nh, i);
+            const double px = fma(x1, -s, x0 * c) + pe[0], py = fma(x1, c, x0 * s) + pe[1];
+            int hit = 0;
+            for (int e = 0; e < E && !hit; ++e) {
+                if (poses[(size_t)e * 6] != poses[(size_t)e * 6]) continue;
+                const double *P = cor + (size_t)e * 8;
+                const double o = (P[4] - P[0]) * (P[7] - P[3]) - (P[5] - P[1]) * (P[6] - P[2]); /* ring orientation */
+                int inside = o != 0;
+                for (int k = 0; k < 4 && inside; ++k) {
+                    const int m = (k + 1) & 3;
+                    const double cr = (P[2 * m] - P[2 * k]) * (py - P[2 * k + 1]) - (P[2 * m + 1] - P[2 * k + 1]) * (px - P[2 * k]);
+                    if (o > 0 ? !(cr > 0) : !(cr < 0)) inside = 0;
+                }
+                hit = inside;
+            }
+            out[(size_t)i * nw + j] = (uint8_t)hit;
+        }
+    free(cor);
+}
+
 /* State.collisions -> detect_collisions -> detect_geom_collisions
  * (scenario_gym/state/state.py:306-310, state/utils.py:10-49, utils.py:28-62).
  * rows[i] bit j set <=> entity j is listed for entity i.  Geometry-equality quirks:

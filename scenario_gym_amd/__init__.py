@@ -8,6 +8,7 @@ from .agent import (  # noqa: F401
     FutureCollisionDetector,
     GlobalCollisionDetector,
     PIDController,
+    RasterizedMapSensor,
     ReplayTrajectoryController,
     Sensor,
     VehicleController,

@@ -25,7 +25,7 @@ SYMBOLS = (
     "sg_version", "sg_last_error", "sg_create", "sg_destroy", "sg_upload", "sg_set_social_force", "sg_reset",
     "sg_set_timestep", "sg_step", "sg_rollout", "sg_rollout_async", "sg_synchronize", "sg_stream",
     "sg_state_view_get", "sg_read_metrics", "sg_read_record", "sg_copy_to_host", "sg_last_kernel_ms",
-    "sg_last_launch_stats", "sg_debug_trig32", "sg_set_tuning", "sg_set_external_poses", "sg_future_collision",
+    "sg_last_launch_stats", "sg_debug_trig32", "sg_set_tuning", "sg_set_external_poses", "sg_future_collision", "sg_raster_entities",
 )
 
 
@@ -112,6 +112,7 @@ def load():
     lib.sg_set_tuning.argtypes = [H, C.c_int32, C.c_int32, C.c_int32]
     lib.sg_set_external_poses.argtypes = [H, C.c_void_p]
     lib.sg_future_collision.argtypes = [H, C.c_double, C.c_int32, C.c_void_p]
+    lib.sg_raster_entities.argtypes = [H, C.c_double, C.c_double, C.c_int32, C.c_int32, C.c_void_p]
     lib.sg_debug_trig32.argtypes = [H, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
     for name in SYMBOLS:
         if name not in ("sg_last_error", "sg_stream", "sg_version"):

@@ -87,6 +87,38 @@ class FutureCollisionDetector(Sensor):
         return tuple(state.get_entity_data(self.entity)) + (state.future_collision(self.horizon),)
 
 
+class RasterizedMapSensor(Sensor):
+    """sensor/map.py:26-135 with the "entity" layer (:176-192): an n x n occupancy grid of bounding boxes in the
+    entity's frame, computed on the device for the ego of every scenario (sg_raster_entities).  The road-network layers
+    (driveable_surface, road, lane, ...) need the road polygons and are not available."""
+
+    _all_layers = ["entity"]
+
+    def __init__(self, entity: Entity, layers=None, height: float = 20.0, width: float = 20.0, freq: Optional[float] = 1.0,
+                 n: Optional[int] = None, channels_first: bool = False):
+        super().__init__(entity)
+        self.layers = ["entity"] if layers is None else list(layers)
+        for layer in self.layers:
+            if layer not in self._all_layers:
+                raise NotImplementedError(f"Layer {layer} does not have a get and/or a prepare method.")
+        self.height, self.width, self.channels_first = height, width, channels_first
+        if n is None:
+            assert freq is not None, "At least one of n and freq must be provided."
+            self.nw, self.nh = int(freq * width), int(freq * height)
+        else:
+            self.nw = self.nh = n
+
+    @property
+    def output_shape(self):
+        return (len(self.layers), self.nw, self.nh) if self.channels_first else (self.nw, self.nh, len(self.layers))
+
+    def _step(self, state):
+        if state.scenario.ego is not self.entity:
+            raise NotImplementedError("the device raster is evaluated for the ego of each scenario")
+        m = np.stack([state.entity_raster(self.width, self.height, self.nw, self.nh) for _ in self.layers])
+        return tuple(state.get_entity_data(self.entity)) + (m if self.channels_first else m.transpose(1, 2, 0),)
+
+
 class GlobalCollisionDetector(Sensor):
     """sensor/common.py:115-129: the localisation observation plus State.collisions() (the device's adjacency rows)."""
 

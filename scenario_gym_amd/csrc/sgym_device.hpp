@@ -2065,6 +2065,72 @@ __global__ __launch_bounds__(256) void future_kernel(Params p, double horizon, i
     if (e == 0) out[r] = (unsigned char)(any != 0);
 }
 
+// ------------------------------------------------------------------------------------------------
+// RasterizedMapSensor, "entity" layer (sensor/map.py:120-192), SURVEY 8f N2: for the ego of every scenario an
+// nh x nw occupancy grid in the ego's frame (rotated by heading + pi/2): cell = 1 iff the grid point lies strictly inside
+// the bounding box of a present entity (the ego included).  One workgroup per scenario: the boxes' corners (fp64, the
+// oracle's operation sequence) are staged in LDS once, then the threads stride over the grid points; the output
+// [R][nh][nw] bytes is written coalesced.  np.linspace / numpy matmul arithmetic as probed (see the oracle).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double sg_linspace_at(double start, double stop, int n, int j)
+{
+    if (n > 1 && j == n - 1) return stop;
+    const double step = n > 1 ? (stop - start) / (double)(n - 1) : 0.0;
+    return (double)j * step + start;
+}
+
+__global__ __launch_bounds__(256) void raster_kernel(Params p, double width, double height, int nw, int nh,
+                                                     unsigned char *out /*[R][nh][nw]*/)
+{
+    __shared__ double cor[8][256];
+    __shared__ unsigned char pres[256];
+    __shared__ double ego_pose[4]; // x, y, sin(theta), cos(theta)
+    const int r = blockIdx.x, e = threadIdx.x;
+    const ScenStatic &ss = p.sstat[r];
+    const uint32_t idx = (uint32_t)r * p.EP + (e < p.EP ? e : 0);
+    const LanePtr st(p.stat + (size_t)(idx >> 6) * (ST_COUNT * 64), (idx & 63) * 8u);
+    const LanePtr dy(p.dyn + (size_t)(idx >> 6) * ((size_t)p.FROWS * 64), (idx & 63) * 8u);
+    const bool present = e < p.E && fld<uint64_t>(dy, SG_F_PRESENT) != 0;
+    pres[e] = present;
+    if (present) {
+        const double x = fld(dy, SG_F_POSE + 0), y = fld(dy, SG_F_POSE + 1), h = fld(dy, SG_F_POSE + 3);
+        double s, c, C[8];
+        sg_sincos(h, s, c);
+        sg_corners(x, y, s, c, fld(st, ST_BW), fld(st, ST_BL), fld(st, ST_BCX), fld(st, ST_BCY), C);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) cor[k][e] = C[k];
+    }
+    if (e == ss.ego) {
+        double s, c;
+        sg_sincos(fld(dy, SG_F_POSE + 3) + 3.14159265358979311600e+00 / 2, s, c); // pose[3] + math.pi / 2
+        ego_pose[0] = fld(dy, SG_F_POSE + 0); ego_pose[1] = fld(dy, SG_F_POSE + 1);
+        ego_pose[2] = s; ego_pose[3] = c;
+    }
+    __syncthreads();
+    const double ex = ego_pose[0], ey = ego_pose[1], s = ego_pose[2], c = ego_pose[3];
+    const bool ego_present = pres[ss.ego] != 0;
+    unsigned char *o = out + (size_t)r * nw * nh;
+    for (int q = e; q < nw * nh; q += 256) {
+        const int i = q / nw, j = q - i * nw;
+        const double x0 = sg_linspace_at(-width / 2, width / 2, nw, j), x1 = sg_linspace_at(-height / 2, height / 2, nh, i);
+        const double px = __builtin_fma(x1, -s, x0 * c) + ex, py = __builtin_fma(x1, c, x0 * s) + ey;
+        bool hit = false;
+        for (int k = 0; k < p.E && !hit; ++k) {
+            if (!pres[k]) continue;
+            const double ax = cor[0][k], ay = cor[1][k], bx = cor[2][k], by = cor[3][k];
+            const double cx = cor[4][k], cy = cor[5][k], dx = cor[6][k], dyy = cor[7][k];
+            const double orient = (cx - ax) * (dyy - by) - (cy - ay) * (dx - bx);
+            const double c0 = (bx - ax) * (py - ay) - (by - ay) * (px - ax);
+            const double c1 = (cx - bx) * (py - by) - (cy - by) * (px - bx);
+            const double c2 = (dx - cx) * (py - cy) - (dyy - cy) * (px - cx);
+            const double c3 = (ax - dx) * (py - dyy) - (ay - dyy) * (px - dx);
+            hit = orient > 0 ? (c0 > 0 && c1 > 0 && c2 > 0 && c3 > 0)
+                             : (orient < 0 && c0 < 0 && c1 < 0 && c2 < 0 && c3 < 0);
+        }
+        o[q] = ego_present ? (unsigned char)hit : 0; // the reference sensor needs state.poses[entity]
+    }
+}
+
 // sg_debug_trig32: the broad phase's hardware sin/cos, exposed so that the parity tests can bound its error
 __global__ void trig32_kernel(const double *h, float *s, float *c, int64_t n)
 {

@@ -771,3 +771,21 @@ extern "C" int sg_future_collision(sg_handle *h, double horizon, int32_t n_sampl
     if (e != hipSuccess) return fail(h, SG_ERR_HIP, "sg_future_collision: %s", hipGetErrorString(e));
     return SG_OK;
 }
+
+extern "C" int sg_raster_entities(sg_handle *h, double width, double height, int32_t nw, int32_t nh, uint8_t *out)
+{
+    if (!h || !out || nw < 1 || nh < 1 || !(width >= 0.0) || !(height >= 0.0))
+        return h ? fail(h, SG_ERR_INVALID, "sg_raster_entities: bad argument") : SG_ERR_INVALID;
+    if (!h->uploaded) return fail(h, SG_ERR_STATE, "sg_raster_entities: no scenarios uploaded");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    const size_t bytes = (size_t)h->R * nw * nh;
+    unsigned char *d = nullptr;
+    HIP_TRY(h, hipMalloc((void **)&d, bytes));
+    sg::raster_kernel<<<dim3((unsigned)h->R), dim3(256), 0, h->stream>>>(h->p, width, height, nw, nh, d);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d, bytes, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(h, SG_ERR_HIP, "sg_raster_entities: %s", hipGetErrorString(e));
+    return SG_OK;
+}

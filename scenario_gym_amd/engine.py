@@ -171,6 +171,13 @@ class RolloutEngine:
         self._check(self.lib.sg_future_collision(self.h, float(horizon), int(n_samples), out.ctypes.data), "sg_future_collision")
         return out.astype(bool)
 
+    def raster_entities(self, width=20.0, height=20.0, nw=20, nh=20):
+        """RasterizedMapSensor "entity" layer (sensor/map.py:120-192) around the ego of every scenario: bool [R, nh, nw]."""
+        out = np.zeros((self.R, int(nh), int(nw)), np.uint8)
+        self._check(self.lib.sg_raster_entities(self.h, float(width), float(height), int(nw), int(nh), out.ctypes.data),
+                    "sg_raster_entities")
+        return out.astype(bool)
+
     def rollout(self, max_steps):
         self._check(self.lib.sg_rollout(self.h, int(max_steps)), "sg_rollout")
 

@@ -171,6 +171,13 @@ class BatchedScenarioGym:
             self._fut[key] = self.engine.future_collision(horizon, n_samples)
         return self._fut[key]
 
+    def _raster(self, width, height, nw, nh):
+        key = ("raster", width, height, nw, nh)
+        if self._fut is None or key not in self._fut:
+            self._fut = dict(self._fut or {})
+            self._fut[key] = self.engine.raster_entities(width, height, nw, nh)
+        return self._fut[key]
+
     def _fetch_record(self):
         if not self.record:
             raise RuntimeError("recorded_poses needs BatchedScenarioGym(record=True)")

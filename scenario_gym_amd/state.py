@@ -114,6 +114,10 @@ class State:
         """FutureCollisionDetector(ego, horizon) at the current time (sensor/common.py:87-106), computed on the device."""
         return bool(self._gym._future(float(horizon), int(n_samples))[self._i])
 
+    def entity_raster(self, width: float = 20.0, height: float = 20.0, nw: int = 20, nh: int = 20) -> np.ndarray:
+        """RasterizedMapSensor "entity" layer around the ego (sensor/map.py:120-192), computed on the device: bool [nh, nw]."""
+        return self._gym._raster(float(width), float(height), int(nw), int(nh))[self._i]
+
     def get_entities_in_area(self, area) -> List[Entity]:
         """state.py:340-354: entities whose centre point lies strictly inside `area`.  The reference takes a shapely
         (Multi)Polygon; here `area` is anything with `.exterior.coords`, or an (n, 2) array of ring vertices (simple

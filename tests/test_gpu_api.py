@@ -485,3 +485,35 @@ def test_future_collision_detector_matches_reference():
                     gym.step()
             gym.close()
     assert n_pos > 300
+
+
+def test_raster_entity_layer_matches_reference():
+    """RasterizedMapSensor(ego, layers=["entity"]) (sensor/map.py:120-192) on the device, on every 4th state of the
+    reference's own dt = 0.1 rollouts of five XOSC scenarios, in both recorded grid configurations: every cell equals the
+    reference's; the sensor object returns the map inside the observation."""
+    import scenario_gym_amd as sga
+
+    gs, g = load_golden("scenarios"), load_golden("sensors")
+    ones = 0
+    for name in g["names"]:
+        gym = sga.ScenarioGym(timestep=0.1)
+        gym.set_scenario(_scenario(gs, f"{name}/scenario"))
+        gym.reset_scenario()
+        ego = gym.state.scenario.entities[0]
+        w0, h0, n0 = g["raster_cfg"][0]
+        sensor = sga.RasterizedMapSensor(ego, layers=["entity"], width=w0, height=h0, freq=None, n=int(n0))
+        steps = list(g[f"{name}/dt10/map_steps"])
+        for k in range(int(steps[-1]) + 1):
+            if k in steps:
+                f = steps.index(k)
+                for c, (w, h, n) in enumerate(g["raster_cfg"]):
+                    got = gym.state.entity_raster(w, h, int(n), int(n))
+                    want = g[f"{name}/dt10/map{c}"][f].astype(bool)
+                    assert np.array_equal(got, want), (name, c, k, int((got != want).sum()))
+                    ones += int(got.sum())
+                if f % 10 == 0:
+                    m = sensor.step(gym.state)[-1]
+                    assert m.shape == (int(n0), int(n0), 1) and np.array_equal(m[:, :, 0], g[f"{name}/dt10/map0"][f].astype(bool))
+            gym.step()
+        gym.close()
+    assert ones > 10000

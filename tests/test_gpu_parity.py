@@ -759,3 +759,30 @@ def test_future_collision_batch_matches_oracle(sga, oracle):
                 seen.add(bool(want))
     eng.close()
     assert seen == {True, False}
+
+
+def test_raster_entities_batch_matches_oracle(sga, oracle):
+    """sg_raster_entities on a synthetic batch (256 x 40, dense scenes, vanishing entities) at two state times and two
+    grids (one not square): every cell of every scenario equals the oracle's."""
+    from scenario_gym_amd import synthetic
+    from scenario_gym_amd.packing import unpack_scenario
+
+    R, E = 256, 40
+    packed = synthetic.make_batch(R, E, n_steps=300, static_frac=0.15, vanish_frac=0.2, extent=20.0)
+    eng = sga.RolloutEngine(R, E)
+    eng.upload(packed)
+    total = 0
+    for n_adv in (0, 85):
+        if n_adv:
+            eng.step(n_adv)
+        st = eng.state()
+        for (w, h, nw, nh) in ((20.0, 20.0, 20, 20), (40.0, 16.0, 33, 12)):
+            got = eng.raster_entities(w, h, nw, nh)
+            assert got.shape == (R, nh, nw)
+            for r in range(0, R, 2):
+                s = unpack_scenario(packed, r)
+                want = oracle.raster_entities(st["poses"][r, :len(s["bbox"])], s["bbox"], s["ego"], w, h, nw, nh)
+                assert np.array_equal(got[r], want), (n_adv, w, r, int((got[r] != want).sum()))
+                total += int(want.sum())
+    eng.close()
+    assert total > 2000

@@ -317,3 +317,21 @@ def test_future_collision_detector_matches_reference(oracle):
                 assert np.array_equal(got, want[:, hi].astype(bool)), (name, dtn, h)
                 n_pos += int(got.sum())
     assert n_pos > 300
+
+
+def test_raster_entity_layer_matches_reference(oracle):
+    """RasterizedMapSensor "entity" layer (sensor/map.py:120-192) on every 4th state of the reference's dt = 0.1 rollouts
+    of five XOSC scenarios, 30 x 30 over 30 m and 24 x 24 over 12 m: every cell equals the reference's."""
+    gs, g = load_golden("scenarios"), load_golden("sensors")
+    cells = ones = 0
+    for name in g["names"]:
+        s = scenario_arrays(gs, f"{name}/scenario")
+        poses = gs[f"{name}/dt10/poses"]
+        for k, (w, h, n) in enumerate(g["raster_cfg"]):
+            want = g[f"{name}/dt10/map{k}"].astype(bool)
+            for f, step in enumerate(g[f"{name}/dt10/map_steps"]):
+                got = oracle.raster_entities(poses[step], s["bbox"], s["ego"], w, h, int(n), int(n))
+                assert np.array_equal(got, want[f]), (name, k, step, int((got != want[f]).sum()))
+                cells += got.size
+                ones += int(got.sum())
+    assert cells > 300000 and ones > 10000

@@ -34,3 +34,17 @@ dt = (time.perf_counter() - t0) / 50
 print(f"sg_future_collision (horizon 5 s, 10 samples, {R}x{E}): {dt*1e6:.0f} us per call = {R*(E-1)*10/dt/1e9:.2f} G box pairs/s, "
       f"{int(f.sum())} of {R} scenarios flagged")
 eng.close()
+
+# RasterizedMapSensor "entity" layer around every ego
+eng = sga.RolloutEngine(R, E)
+eng.upload(packed)
+eng.step(300)
+for (w, n) in ((20.0, 20), (64.0, 128)):
+    eng.raster_entities(w, w, n, n)
+    t0 = time.perf_counter()
+    for _ in range(10):
+        m = eng.raster_entities(w, w, n, n)
+    dt = (time.perf_counter() - t0) / 10
+    print(f"sg_raster_entities ({n}x{n} over {w:.0f} m, {R}x{E}): {dt*1e3:.2f} ms per call incl. the {m.size/1e6:.1f} MB copy to the host "
+          f"= {R*n*n/dt/1e9:.2f} G cells/s, {100*m.mean():.1f} % occupied")
+eng.close()
