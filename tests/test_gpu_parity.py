@@ -786,3 +786,52 @@ def test_raster_entities_batch_matches_oracle(sga, oracle):
                 total += int(want.sum())
     eng.close()
     assert total > 2000
+
+
+def test_lattice_scenes_touching_boxes_every_step(sga, oracle):
+    """Adversarial geometry for the fp32 filter / exact path split: axis-aligned 2 x 4 boxes on an integer lattice, moving
+    by exact lattice fractions, so that boxes touch along whole edges, at single corners, coincide exactly or slide past
+    at zero gap for many steps (closed-set semantics: touching collides; identical geometries never list each other).
+    Collision rows of every scenario are compared with the oracle after EVERY step."""
+    from scenario_gym_amd.packing import default_kinds, pack_arrays
+
+    rng = np.random.default_rng(5)
+    R, E, steps, dt = 48, 12, 40, 0.25
+    scs = []
+    for r in range(R):
+        knots, off = [], [0]
+        for e in range(E):
+            x0, y0 = rng.integers(-6, 7) * 2.0, rng.integers(-3, 4) * 2.0       # box length 4 along x, width 2 along y
+            vx, vy = rng.choice([0.0, 1.0, -1.0, 2.0]), rng.choice([0.0, 0.0, 1.0, -1.0])
+            h = rng.choice([0.0, 0.0, 0.0, np.pi])                                # pi: the same box up to rounding
+            if rng.random() < 0.25:
+                knots.append([0.0, x0, y0, 0, h, 0, 0])                          # static
+                off.append(off[-1] + 1)
+            else:
+                T = steps * dt
+                knots += [[0.0, x0, y0, 0, h, 0, 0], [T, x0 + vx * T, y0 + vy * T, 0, h, 0, 0]]
+                off.append(off[-1] + 2)
+        scs.append(dict(knot_off=np.array(off), knots=np.array(knots, np.float64), bbox=np.tile([2.0, 4.0, 0.0, 0.0], (E, 1)),
+                        etype=np.full(E, 2, np.int32), ego=0, t0=0.0, length=steps * dt))
+    packed = pack_arrays(scs)
+    eng = sga.RolloutEngine(R, E, timestep=dt, event_capacity=256)
+    eng.upload(packed)
+    ref = [oracle.rollout(s["knot_off"], s["knots"], s["bbox"], s["etype"], default_kinds(E, 0), 0, 0.0, s["length"], dt,
+                          max_steps=steps, event_cap=512) for s in scs]
+    n_touch = 0
+    for k in range(1, steps + 1):
+        eng.step(1)
+        st = eng.state()
+        for r in range(R):
+            if k <= ref[r]["n_steps"]:
+                assert np.array_equal(st["coll"][r], ref[r]["coll"][k, :, 0]), (r, k)
+                n_touch += int(np.count_nonzero(st["coll"][r]))
+    rows, events = eng.metrics()
+    eng.close()
+    for r in range(R):
+        ev = events[events["scenario"] == r]
+        n = min(len(ev), 256)
+        assert rows["n_collisions"][r] >= ref[r]["n_events"] or ref[r]["n_steps"] < steps
+        if ref[r]["n_steps"] == steps:
+            assert rows["n_collisions"][r] == ref[r]["n_events"] and np.array_equal(ev["t"][:n], ref[r]["ev_t"][:n]), r
+    assert n_touch > 2000
