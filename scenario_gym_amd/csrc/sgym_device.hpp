@@ -769,9 +769,11 @@ __device__ __forceinline__ void ped_step(const Params &p, const LDS &L, int sl, 
                 if ((j >> 6) == w) m[w] &= m[w] - 1;
             j += tile0;
             {
-                if (!L.isped[j]) continue; // PedestrianSensor: pedestrians only (sensor.py:60-62)
+                // PedestrianSensor: pedestrians only, inside the radius (sensor.py:55-64).  A candidate that fails still
+                // runs through the arithmetic below (its lane would idle anyway) and is masked at the accumulation:
+                // fewer branches in a loop that is bound by instruction issue.
                 const double ox = L.px[j], oy = L.py[j];
-                if (!sg_in_radius(pose[0], pose[1], radius, ox, oy, p.gon)) continue;
+                const bool act = (L.isped[j] != 0) & sg_in_radius(pose[0], pose[1], radius, ox, oy, p.gon);
                 const double ovx = L.vx[j], ovy = L.vy[j];
                 const double odx = L.ox[j], ody = L.oy[j], step = L.stp[j];
                 double c1x, c1y, c2x, c2y;
@@ -780,18 +782,20 @@ __device__ __forceinline__ void ped_step(const Params &p, const LDS &L, int sl, 
                     ped_pair<true, true>(FA, sf, k2_scale, pose[0], pose[1], hs, hc, ox, oy, ovx, ovy, odx, ody, step, c1x, c1y, c2x, c2y);
                 else
                     ped_pair<false, false>(FA, sf, k2_scale, pose[0], pose[1], hs, hc, ox, oy, ovx, ovy, odx, ody, step, c1x, c1y, c2x, c2y);
-                if (__any(FA.bad)) { // rare: some operand outside RecipDiv's range, or a sight weight on its threshold
-                    if (FA.bad) {
+                if (__any(FA.bad & act)) { // rare: some operand outside RecipDiv's range, or a sight weight on its threshold
+                    if (FA.bad & act) {
                         ExactArith EA;
                         ped_pair<false, false>(EA, sf, k2_scale, pose[0], pose[1], hs, hc, ox, oy, ovx, ovy, odx, ody, step, c1x, c1y, c2x, c2y);
                     }
                 }
-                if (sf.sight_weight_use != 0.0) {
-                    fx += c1x; fy += c1y;
-                    fx += c2x; fy += c2y;
-                } else { // without sight weights the reference adds the attraction first (:72-80)
-                    fx += c2x; fy += c2y;
-                    fx += c1x; fy += c1y;
+                if (act) {
+                    if (sf.sight_weight_use != 0.0) {
+                        fx += c1x; fy += c1y;
+                        fx += c2x; fy += c2y;
+                    } else { // without sight weights the reference adds the attraction first (:72-80)
+                        fx += c2x; fy += c2y;
+                        fx += c1x; fy += c1y;
+                    }
                 }
             }
         }
