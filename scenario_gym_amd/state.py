@@ -92,11 +92,12 @@ class State:
         """state.py:272-290: (n, 7) rows [t, x, y, z, h, p, r] of the steps the entity was present."""
         t, poses = self._gym._fetch_record()
         ents = self._scenario.entities
+        rows = int(self._s()["n_steps"][self._i]) + 1  # a scenario that ended before the batch did has no later rows
 
         def one(k):
-            p = poses[:, self._i, k]
+            p = poses[:rows, self._i, k]
             ok = ~np.isnan(p[:, 0])
-            return np.concatenate([t[ok, self._i, None], p[ok]], axis=1) if ok.any() else np.empty((0, 7))
+            return np.concatenate([t[:rows][ok, self._i, None], p[ok]], axis=1) if ok.any() else np.empty((0, 7))
 
         if entity is not None:
             return one(ents.index(entity))

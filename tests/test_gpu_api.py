@@ -517,3 +517,44 @@ def test_raster_entity_layer_matches_reference():
             gym.step()
         gym.close()
     assert ones > 10000
+
+
+def test_all_reference_scenarios_as_one_batch():
+    """The reference's tests/test_scenarios.py rolls out each of its 23 OpenSCENARIO files in turn; here they are ONE
+    ragged device batch (1 ... 9 entities, different lengths and start times): clock, poses of every 25th step and of the
+    last, final velocities / distances / collisions and the ego metrics equal the real reference's, bit for bit."""
+    import scenario_gym_amd as sga
+
+    g = load_golden("all_scenarios")
+    names = list(g["names"])
+    scs = [scenario_from_arrays(scenario_arrays(g, f"{n}/scenario"), g[f"{n}/scenario/refs"]) for n in names]
+    gym = sga.BatchedScenarioGym(record=True, metrics=lambda: [sga.EgoAvgSpeed(), sga.EgoMaxSpeed(), sga.EgoDistanceTravelled()])
+    gym.set_scenarios(scs)
+    gym.rollout()
+    metrics = gym.get_metrics()
+    for i, n in enumerate(names):
+        st = gym.states[i]
+        ents = st.scenario.entities
+        ts = g[f"{n}/t"]
+        rec = st.recorded_poses()
+        assert st.t == ts[-1] and st.is_done, n
+        final = g[f"{n}/final_poses"]
+        for k, e in enumerate(ents):
+            present = not np.isnan(final[k, 0])
+            assert (e in st.poses) == present, (n, e.ref)
+            if present:
+                assert bits_equal(st.poses[e], final[k]) and bits_equal(st.velocities[e], g[f"{n}/final_vels"][k]), (n, e.ref)
+            assert st.distances[e] == g[f"{n}/final_dists"][k], (n, e.ref)
+            # every 25th recorded step of the entity: rows [t, pose] of the steps it was present
+            kf = g[f"{n}/keyframes"][:, k]
+            want = np.array([np.concatenate([[ts[25 * j]], kf[j]]) for j in range(len(kf)) if not np.isnan(kf[j, 0])]).reshape(-1, 7)
+            got = rec[e][np.isin(rec[e][:, 0], ts[::25])]
+            assert bits_equal(got, want), (n, e.ref)
+        coll = st.collisions()
+        A = g[f"{n}/final_coll"]
+        for k, e in enumerate(ents):
+            if e in coll:
+                assert sorted(ents.index(o) for o in coll[e]) == list(np.nonzero(A[k])[0]), (n, e.ref)
+        for key in ("ego_avg_speed", "ego_max_speed", "ego_distance_travelled"):
+            assert metrics[i][key] == float(g[f"{n}/metric_{key}"]), (n, key)
+    gym.close()

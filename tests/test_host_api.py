@@ -223,6 +223,24 @@ def test_xosc_reader_on_reference_inputs():
         assert [e.ref for e in s.entities] == list(g[f"{n}/scenario/refs"])
 
 
+@pytest.mark.skipif(not os.path.isdir("/root/reference/tests/input_files"), reason="build container only")
+def test_xosc_reader_on_all_reference_inputs():
+    """All 23 OpenSCENARIO files of the reference's tests: knots, boxes, catalog types, refs, ego and length read by
+    scenario_gym_amd.xosc equal what the reference's own import_scenario produced (all_scenarios.npz)."""
+    from scenario_gym_amd.entity import catalog_type_code
+    from scenario_gym_amd.xosc import import_scenario
+
+    g = load_golden("all_scenarios")
+    for n in g["names"]:
+        s = import_scenario(f"/root/reference/tests/input_files/Scenarios/{n}.xosc")
+        assert np.array_equal(np.concatenate([e.trajectory.data for e in s.entities]), g[f"{n}/scenario/knots"]), n
+        assert [e.ref for e in s.entities] == list(g[f"{n}/scenario/refs"]), n
+        assert np.array_equal([[e.bounding_box.width, e.bounding_box.length, e.bounding_box.center_x, e.bounding_box.center_y]
+                               for e in s.entities], g[f"{n}/scenario/bbox"]), n
+        assert [catalog_type_code(e) for e in s.entities] == list(g[f"{n}/scenario/etype"]), n
+        assert s.entities.index(s.ego) == int(g[f"{n}/scenario/ego"]) and s.length == float(g[f"{n}/scenario/length"]), n
+
+
 # ---------------------------------------------------------------- the C ABI
 def test_library_exports_every_declared_symbol():
     import ctypes
