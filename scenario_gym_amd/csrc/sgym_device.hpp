@@ -16,6 +16,7 @@
 // the only fused operations are the explicit fma() chains of np.linalg.norm (see sg_norm3).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 
 #include "../../include/sgym.h"
@@ -80,6 +81,7 @@ struct Params {
     double *ctl_state;       // [CS_COUNT][n_ctl_pad] lane state carried from one chunk of steps to the next
     int n_ctl_pad;           // multiple of 64
     const double *ext_pose;  // [NE][6] poses of the caller-run agents (SG_KIND_AGENT_EXTERNAL), x = NaN: agent returned None
+    int ped_serial;          // 1: pedestrian pair loop one pedestrian per lane (env SG_PED_SERIAL; default 0: balanced over the wavefront)
     int tab_steps;           // steps per table chunk (rows per lane = tab_steps + 1: the prefetch of the last step reads one row ahead)
 };
 
@@ -446,12 +448,19 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 // carries 64/G scenarios (WV = 1), 64*WV when WV wavefronts carry one scenario of up to 64*WV entities.
 template <int NS, bool PED>
 struct TileLds {
+    // ---- collision scratch: rewritten by every tile_collisions call and dead once it returns (its last reads sit
+    // before its last workgroup barrier).  Contiguous, in this order: the pedestrian pair balancer (ped_pairs_balanced)
+    // borrows the block between two collision passes. ----
     float cx[NS], cy[NS];   // box centres (NaN when absent), SoA for packed-fp32 pair math
     float2 sc[NS];          // sin, cos of the heading
-    float2 half[NS];        // half length, half width (static)
+    float2 cen[NS];         // box centres again, interleaved, for single-read gathers
+    // broad-phase stripe masks: bit set of the slots whose centre lies in x- (y-) stripe k (mod 64)
+    unsigned long long xtab[64][NS / 64], ytab[64][NS / 64];
     // fp64 corners of the exact path: a single wavefront exchanges them with cross-lane reads instead;
     // the 8 floats that remain are scratch for the launch-time reductions across wavefronts
     double cor[8][NS > 64 ? NS : 2];
+    // ---- end of the collision scratch ----
+    float2 half[NS];        // half length, half width (static)
     int last[NS];
     // controller parameters of every slot, copied once per launch: the 9 vehicle / PID rows, or -- in pedestrian
     // scenes -- the 4 pedestrian rows SG_C_PED_* (index q - SG_C_PED_SPEED_DESIRED)
@@ -463,10 +472,18 @@ struct TileLds {
     // unit velocity o = v / (|v| + 1e-10) and step = (|v| + 1e-10) * (next_t - t)
     double ox[PED ? NS : 1], oy[PED ? NS : 1], stp[PED ? NS : 1];
     unsigned char isped[PED ? NS : 1]; // entity.type == "Pedestrian" and present
-    // broad-phase stripe masks: bit set of the slots whose centre lies in x- (y-) stripe k (mod 64)
-    unsigned long long xtab[64][NS / 64], ytab[64][NS / 64];
-    float2 cen[NS];         // box centres again, interleaved, for single-read gathers
+
+    static constexpr int SLOTS = NS;
+    static constexpr int SCRATCH_BYTES = NS * 40 + 64 * (NS > 64 ? NS : 2); // cx ... cor
+    // pairs one wavefront can hand over to its idle lanes: 4 B (who, whom, flags) + 16 B (result) each
+    static constexpr int PAIR_CAP = NS > 64 ? 320 : 128;
+    __device__ __forceinline__ char *wave_scratch(int wave) { return reinterpret_cast<char *>(cx) + wave * (PAIR_CAP * 20); }
 };
+static_assert(TileLds<256, true>::PAIR_CAP * 20 * 4 <= TileLds<256, true>::SCRATCH_BYTES, "pair scratch");
+static_assert(TileLds<128, true>::PAIR_CAP * 20 * 2 <= TileLds<128, true>::SCRATCH_BYTES, "pair scratch");
+static_assert(TileLds<64, true>::PAIR_CAP * 20 <= TileLds<64, true>::SCRATCH_BYTES, "pair scratch");
+typedef TileLds<256, true> TileLdsWide;
+static_assert(offsetof(TileLdsWide, half) == TileLdsWide::SCRATCH_BYTES, "collision scratch is contiguous");
 
 // ------------------------------------------------------------------------------------------------
 // controllers
@@ -726,87 +743,244 @@ __device__ __forceinline__ int ped_goal_update(const double *wp, int nwp, double
     return last + 1;
 }
 
-// PedestrianAgent.step for one lane: SocialForce._step (pedestrian/social_force.py:44-222, boundary
-// terms off) over the neighbour candidates `nbr` of the tile + PedestrianController._step
-// (pedestrian/controller.py:25-46).  All inputs are the CURRENT state (LDS px/py/vx/vy).
+// Barrier between the lanes of one tile's workgroup.  A single wavefront (WV == 1) needs no s_barrier and no
+// s_waitcnt: the LDS executes the instructions of one wavefront in issue order, so a ds_read issued after another
+// lane's ds_write / ds_or already sees it; a wavefront-scope fence keeps the compiler from reordering them.
+template <int WV>
+__device__ __forceinline__ void tile_sync()
+{
+    if (WV == 1) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+        __syncthreads();
+    }
+}
+
+template <int WV>
+__device__ __forceinline__ bool block_any(bool x)
+{
+    if (WV == 1) return __any(x);
+    return __syncthreads_or(x);
+}
+
+// One (pedestrian, neighbour) pair: the PedestrianSensor filter (pedestrians only, inside the radius, sensor.py:55-64)
+// and the neighbour's two force terms.  (ipx, ipy, irad, hs, hc) describe the pedestrian the force acts on, j is the
+// neighbour's LDS slot.  A candidate that fails the filter still runs through the arithmetic (its lane would idle
+// anyway) and is masked by the returned flag: fewer branches in a loop that is bound by instruction issue.
+template <typename LDS>
+__device__ __forceinline__ bool ped_pair_eval(const Params &p, const LDS &L, bool plain, double k2_scale, double ipx,
+                                              double ipy, double irad, double hs, double hc, int j, bool valid,
+                                              double &c1x, double &c1y, double &c2x, double &c2y)
+{
+    const sg_social_force &sf = p.sf;
+    const double ox = L.px[j], oy = L.py[j];
+    const bool act = valid & (L.isped[j] != 0) & sg_in_radius(ipx, ipy, irad, ox, oy, p.gon);
+    const double ovx = L.vx[j], ovy = L.vy[j];
+    const double odx = L.ox[j], ody = L.oy[j], step = L.stp[j];
+    FastArith FA;
+    if (plain) // wave-uniform: default head rotation and no attraction
+        ped_pair<true, true>(FA, sf, k2_scale, ipx, ipy, hs, hc, ox, oy, ovx, ovy, odx, ody, step, c1x, c1y, c2x, c2y);
+    else
+        ped_pair<false, false>(FA, sf, k2_scale, ipx, ipy, hs, hc, ox, oy, ovx, ovy, odx, ody, step, c1x, c1y, c2x, c2y);
+    if (__any(FA.bad & act)) { // rare: some operand outside RecipDiv's range, or a sight weight on its threshold
+        if (FA.bad & act) {
+            ExactArith EA;
+            ped_pair<false, false>(EA, sf, k2_scale, ipx, ipy, hs, hc, ox, oy, ovx, ovy, odx, ody, step, c1x, c1y, c2x, c2y);
+        }
+    }
+    return act;
+}
+
+// SocialForce._step :64-84: the neighbour's terms join the force in the reference's order
+__device__ __forceinline__ void ped_accumulate(const sg_social_force &sf, double c1x, double c1y, double c2x, double c2y,
+                                               double &fx, double &fy)
+{
+    if (sf.sight_weight_use != 0.0) {
+        fx += c1x; fy += c1y;
+        fx += c2x; fy += c2y;
+    } else { // without sight weights the reference adds the attraction first (:72-80)
+        fx += c2x; fy += c2y;
+        fx += c1x; fy += c1y;
+    }
+}
+
+// Neighbour loop, one pedestrian per lane: neighbours in entity order, one per iteration across all row words (the
+// wavefront iterates max-over-lanes of the TOTAL candidate count, not the sum of per-word maxima).
 template <int WV, typename LDS>
-__device__ __forceinline__ void ped_step(const Params &p, const LDS &L, int sl, int tile0, const uint64_t (&nbr)[WV],
-                                         const double *pose, double velx, double vely, double t, double next_t,
-                                         double state_dt, const double *wp, int nwp, int &goal_idx,
-                                         double &cspeed, double &fxo, double &fyo, double *np_, ConstTbl K)
+__device__ __forceinline__ void ped_pairs_serial(const Params &p, const LDS &L, int tile0, const uint64_t (&nbr)[WV],
+                                                 bool go, bool plain, double k2_scale, double ipx, double ipy,
+                                                 double irad, double hs, double hc, double &fx, double &fy)
+{
+    uint64_t m[WV];
+#pragma unroll
+    for (int w = 0; w < WV; ++w) m[w] = go ? nbr[w] : 0;
+    for (;;) {
+        int j = -1;
+#pragma unroll
+        for (int w = WV - 1; w >= 0; --w)
+            if (m[w]) j = w * 64 + __builtin_ctzll(m[w]);
+        if (j < 0) break;
+#pragma unroll
+        for (int w = 0; w < WV; ++w)
+            if ((j >> 6) == w) m[w] &= m[w] - 1;
+        double c1x, c1y, c2x, c2y;
+        if (ped_pair_eval(p, L, plain, k2_scale, ipx, ipy, irad, hs, hc, j + tile0, true, c1x, c1y, c2x, c2y))
+            ped_accumulate(p.sf, c1x, c1y, c2x, c2y, fx, fy);
+    }
+}
+
+// The same sums with the pairs of one wavefront spread evenly over its 64 lanes.  A crowd gives the lanes of a wavefront
+// very different neighbour counts (mean ~24, maximum ~45 in the 1024 x 256 benchmark) and the serial loop runs the
+// maximum.  Here every lane works through T = ceil(total / 64) pairs: a lane with n > T neighbours keeps its first
+// n - o (entity order) and lists the last o in LDS; lanes with n < T (and lanes that are no stepping pedestrian at
+// all) evaluate listed pairs for their owners and leave the two force terms in LDS; each owner then adds the terms it
+// handed over, in entity order, after its own.  Every pair goes through the same ped_pair_eval and every sum keeps
+// the reference's order, so the result is bit-identical to ped_pairs_serial.  Only the "plain" case (no head
+// rotation, no attraction: c2 is a signed zero, kept as a sign bit) -- the reference's defaults.
+// Wave-collective: all 64 lanes call it in uniform control flow; LDS traffic stays inside the wavefront's own
+// slice of the (then idle) collision scratch, so no workgroup barrier is involved.
+template <int WV, typename LDS>
+__device__ __forceinline__ void ped_pairs_balanced(const Params &p, LDS &L, int sl, int tile0, const uint64_t (&nbr)[WV],
+                                                   bool go, double k2_scale, double ipx, double ipy, double irad,
+                                                   double &fx, double &fy)
+{
+    constexpr int CAP = LDS::PAIR_CAP;
+    const int lane = threadIdx.x & 63;
+    uint32_t *list = reinterpret_cast<uint32_t *>(L.wave_scratch(WV == 1 ? 0 : (int)(threadIdx.x >> 6)));
+    double2 *res = reinterpret_cast<double2 *>(list + CAP);
+    uint64_t m[WV];
+    int n = 0;
+#pragma unroll
+    for (int w = 0; w < WV; ++w) {
+        m[w] = go ? nbr[w] : 0;
+        n += __builtin_popcountll(m[w]);
+    }
+    int total = n;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) total += __shfl_xor(total, o, 64);
+    const int T = (total + 63) >> 6;
+    const int excess = max(n - T, 0), spare = max(T - n, 0);
+    int scan = excess | (spare << 16); // both prefix sums at once (each < 2^15)
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int u = __shfl_up(scan, o, 64);
+        if (lane >= o) scan += u;
+    }
+    const int listed_all = min(__shfl(scan, 63, 64) & 0xffff, CAP);
+    const int e0 = (scan & 0xffff) - excess;              // first list position of this lane's hand-over
+    const int out = min(max(CAP - e0, 0), excess);        // pairs handed over (all of the excess unless the list is full)
+    int h = min((scan >> 16) - spare, listed_all);        // listed pairs this lane evaluates: [h, h_end)
+    const int h_end = min((scan >> 16), listed_all);
+    // hand over the LAST `out` neighbours: walk them from the top, write them in entity order
+    for (int q = 0; __any(q < out); ++q) {
+        if (q < out) {
+            int j = 0;
+#pragma unroll
+            for (int w = 0; w < WV; ++w)
+                if (m[w]) j = w * 64 + 63 - __builtin_clzll(m[w]);
+#pragma unroll
+            for (int w = 0; w < WV; ++w)
+                if ((j >> 6) == w) m[w] &= ~(1ull << (j & 63));
+            list[e0 + out - 1 - q] = (uint32_t)(j + tile0) | ((uint32_t)lane << 8);
+        }
+    }
+    tile_sync<1>();
+    const int wave_sl = sl - lane; // LDS slot of lane 0
+    for (;;) {
+        int j = -1;
+#pragma unroll
+        for (int w = WV - 1; w >= 0; --w)
+            if (m[w]) j = w * 64 + __builtin_ctzll(m[w]);
+        const bool own = j >= 0, help = !own & (h < h_end);
+        if (!__any(own | help)) break;
+#pragma unroll
+        for (int w = 0; w < WV; ++w)
+            if ((j >> 6) == w) m[w] &= m[w] - 1; // j = -1 matches no word
+        const int hi = min(h, CAP - 1);
+        const uint32_t ent = list[hi];
+        const int isl = wave_sl + (int)((ent >> 8) & 63);
+        const int jj = own ? j + tile0 : (int)(ent & (LDS::SLOTS - 1));
+        const double qx = own ? ipx : L.px[isl], qy = own ? ipy : L.py[isl];
+        const double qr = own ? irad : L.ctrl[SG_C_PED_RADIUS - SG_C_PED_SPEED_DESIRED][isl];
+        double c1x, c1y, c2x, c2y;
+        const bool act = ped_pair_eval(p, L, true, k2_scale, qx, qy, qr, 0.0, 1.0, jj, own | help, c1x, c1y, c2x, c2y);
+        if (own & act) ped_accumulate(p.sf, c1x, c1y, c2x, c2y, fx, fy);
+        if (help) {
+            res[hi] = make_double2(c1x, c1y);
+            list[hi] = ent | (act ? 0u : 1u << 16) | (__builtin_signbit(c2x) ? 1u << 17 : 0u) |
+                       (__builtin_signbit(c2y) ? 1u << 18 : 0u);
+            ++h;
+        }
+    }
+    tile_sync<1>();
+    for (int q = 0; __any(q < out); ++q) {
+        if (q < out) {
+            const uint32_t ent = list[e0 + q];
+            const double2 c1 = res[e0 + q];
+            if (!(ent & (1u << 16)))
+                ped_accumulate(p.sf, c1.x, c1.y, (ent & (1u << 17)) ? -0.0 : 0.0, (ent & (1u << 18)) ? -0.0 : 0.0, fx, fy);
+        }
+    }
+    tile_sync<1>(); // the collision pass that follows rewrites the scratch
+}
+
+// PedestrianAgent.step, part 1: SocialForce._step (pedestrian/social_force.py:44-222, boundary terms off) over the
+// neighbour candidates `nbr` of the tile.  All inputs are the CURRENT state (LDS px/py/vx/vy).  Wave-collective (every
+// lane calls it; `stepping` = this lane is a present pedestrian agent of a running scenario); go = goal not reached yet.
+template <int WV, typename LDS>
+__device__ __forceinline__ void ped_force(const Params &p, LDS &L, int sl, int tile0, const uint64_t (&nbr)[WV],
+                                          bool stepping, const double *pose, double velx, double vely, const double *wp,
+                                          int nwp, int &goal_idx, bool &go, double &fx, double &fy, double &vdes,
+                                          ConstTbl K)
+{
+    const sg_social_force &sf = p.sf;
+    go = false;
+    fx = fy = 0.0;
+    vdes = 0.0;
+    double hs = 0.0, hc = 1.0, radius = 0.0;
+    if (stepping) {
+        if (goal_idx <= nwp - 1) goal_idx = ped_goal_update(wp, nwp, pose[0], pose[1]);
+        if (goal_idx <= nwp - 1) {
+            go = true;
+            double gx = wp[2 * goal_idx] - pose[0], gy = wp[2 * goal_idx + 1] - pose[1]; // _force_to_goal, :119-138
+            double gn = sg_norm2(gx, gy);
+            if (gn == 0) gn += 0.000000001;
+            vdes = L.ctrl[SG_C_PED_SPEED_DESIRED - SG_C_PED_SPEED_DESIRED][sl];
+            const double inv_tau = 1 / sf.relaxation_time;
+            fx = inv_tau * (vdes * (gx / gn) - velx);
+            fy = inv_tau * (vdes * (gy / gn) - vely);
+            sg_sincos(L.ctrl[SG_C_PED_HEAD_ROT - SG_C_PED_SPEED_DESIRED][sl], hs, hc, K);
+            radius = L.ctrl[SG_C_PED_RADIUS - SG_C_PED_SPEED_DESIRED][sl];
+        }
+    }
+    const double k2_scale = sf.ped_repulse_V / sf.ped_repulse_sigma;
+    // the shortcuts of ped_pair need the sight-weight branch (c2 = w2 * att) and hold for the whole wavefront
+    const bool plain = __all(hs == 0.0 && hc == 1.0) && sf.ped_attract_C == 0.0 && sf.sight_weight > 0.0 &&
+                       sf.sight_weight_use != 0.0;
+    if (plain && !p.ped_serial)
+        ped_pairs_balanced<WV>(p, L, sl, tile0, nbr, go, k2_scale, pose[0], pose[1], radius, fx, fy);
+    else
+        ped_pairs_serial<WV>(p, L, tile0, nbr, go, plain, k2_scale, pose[0], pose[1], radius, hs, hc, fx, fy);
+}
+
+// PedestrianAgent.step, part 2 (one lane): speed and heading from the force (:110-114, or zero at the goal,
+// agent.py:65-68) + PedestrianController._step (pedestrian/controller.py:25-46).
+__device__ __forceinline__ void ped_move(const Params &p, bool go, double fx, double fy, double vdes, double maxs,
+                                         const double *pose, double state_dt, double &cspeed, double &fxo, double &fyo,
+                                         double *np_, ConstTbl K)
 {
     const sg_social_force &sf = p.sf;
     double speed = 0.0, heading = 0.0;
-    if (goal_idx <= nwp - 1) goal_idx = ped_goal_update(wp, nwp, pose[0], pose[1]);
-    if (goal_idx <= nwp - 1) {
-        double gx = wp[2 * goal_idx] - pose[0], gy = wp[2 * goal_idx + 1] - pose[1]; // _force_to_goal, :119-138
-        double gn = sg_norm2(gx, gy);
-        if (gn == 0) gn += 0.000000001;
-        const double vdes = L.ctrl[SG_C_PED_SPEED_DESIRED - SG_C_PED_SPEED_DESIRED][sl];
-        const double inv_tau = 1 / sf.relaxation_time;
-        double fx = inv_tau * (vdes * (gx / gn) - velx);
-        double fy = inv_tau * (vdes * (gy / gn) - vely);
-        double hs, hc;
-        sg_sincos(L.ctrl[SG_C_PED_HEAD_ROT - SG_C_PED_SPEED_DESIRED][sl], hs, hc, K);
-        const double radius = L.ctrl[SG_C_PED_RADIUS - SG_C_PED_SPEED_DESIRED][sl];
-        const double k2_scale = sf.ped_repulse_V / sf.ped_repulse_sigma;
-        // the shortcuts of ped_pair need the sight-weight branch (c2 = w2 * att) and hold for the whole wavefront
-        const bool plain = __all(hs == 0.0 && hc == 1.0) && sf.ped_attract_C == 0.0 && sf.sight_weight > 0.0 &&
-                           sf.sight_weight_use != 0.0;
-        // neighbours in entity order, one per iteration across all row words (the wavefront iterates
-        // max-over-lanes of the TOTAL candidate count, not the sum of per-word maxima)
-        uint64_t m[WV];
-#pragma unroll
-        for (int w = 0; w < WV; ++w) m[w] = nbr[w];
-        for (;;) {
-            int j = -1;
-#pragma unroll
-            for (int w = WV - 1; w >= 0; --w)
-                if (m[w]) j = w * 64 + __builtin_ctzll(m[w]);
-            if (j < 0) break;
-#pragma unroll
-            for (int w = 0; w < WV; ++w)
-                if ((j >> 6) == w) m[w] &= m[w] - 1;
-            j += tile0;
-            {
-                // PedestrianSensor: pedestrians only, inside the radius (sensor.py:55-64).  A candidate that fails still
-                // runs through the arithmetic below (its lane would idle anyway) and is masked at the accumulation:
-                // fewer branches in a loop that is bound by instruction issue.
-                const double ox = L.px[j], oy = L.py[j];
-                const bool act = (L.isped[j] != 0) & sg_in_radius(pose[0], pose[1], radius, ox, oy, p.gon);
-                const double ovx = L.vx[j], ovy = L.vy[j];
-                const double odx = L.ox[j], ody = L.oy[j], step = L.stp[j];
-                double c1x, c1y, c2x, c2y;
-                FastArith FA;
-                if (plain) // wave-uniform: default head rotation and no attraction
-                    ped_pair<true, true>(FA, sf, k2_scale, pose[0], pose[1], hs, hc, ox, oy, ovx, ovy, odx, ody, step, c1x, c1y, c2x, c2y);
-                else
-                    ped_pair<false, false>(FA, sf, k2_scale, pose[0], pose[1], hs, hc, ox, oy, ovx, ovy, odx, ody, step, c1x, c1y, c2x, c2y);
-                if (__any(FA.bad & act)) { // rare: some operand outside RecipDiv's range, or a sight weight on its threshold
-                    if (FA.bad & act) {
-                        ExactArith EA;
-                        ped_pair<false, false>(EA, sf, k2_scale, pose[0], pose[1], hs, hc, ox, oy, ovx, ovy, odx, ody, step, c1x, c1y, c2x, c2y);
-                    }
-                }
-                if (act) {
-                    if (sf.sight_weight_use != 0.0) {
-                        fx += c1x; fy += c1y;
-                        fx += c2x; fy += c2y;
-                    } else { // without sight weights the reference adds the attraction first (:72-80)
-                        fx += c2x; fy += c2y;
-                        fx += c1x; fy += c1y;
-                    }
-                }
-            }
-        }
+    if (go) {
         speed = __builtin_fmin(sg_norm2(fx, fy) + sf.bias_lon, vdes * sf.max_speed_factor);
         heading = sg_atan2(fy, fx) + sf.bias_lat;
         fxo = fx;
         fyo = fy;
-    } else { // reached the goal, agent.py:65-68
+    } else {
         fxo = fyo = 0.0;
     }
-    const double maxs = L.ctrl[SG_C_PED_MAX_SPEED - SG_C_PED_SPEED_DESIRED][sl]; // PedestrianController._step
     cspeed = __builtin_fmin(__builtin_fmax(speed, -maxs), maxs);
     double hs2, hc2;
     sg_sincos(heading, hs2, hc2, K);
@@ -833,28 +1007,6 @@ __device__ __forceinline__ void ped_step(const Params &p, const LDS &L, int sl, 
 // With WV > 1 the tile spans WV wavefronts of one workgroup; only the decisions that gate LDS
 // writes are workgroup-uniform (block_any), the candidate loops run per wavefront.
 // ------------------------------------------------------------------------------------------------
-// Barrier between the lanes of one tile's workgroup.  A single wavefront (WV == 1) needs no s_barrier and no
-// s_waitcnt: the LDS executes the instructions of one wavefront in issue order, so a ds_read issued after another
-// lane's ds_write / ds_or already sees it; a wavefront-scope fence keeps the compiler from reordering them.
-template <int WV>
-__device__ __forceinline__ void tile_sync()
-{
-    if (WV == 1) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    } else {
-        __syncthreads();
-    }
-}
-
-template <int WV>
-__device__ __forceinline__ bool block_any(bool x)
-{
-    if (WV == 1) return __any(x);
-    return __syncthreads_or(x);
-}
-
 template <int G, int WV, bool PED, typename LDS>
 __device__ __forceinline__ void tile_collisions(bool present, const double *pose, double velx, double vely,
                                                 double dtn /* next_t - t of the coming step (PED) */,
@@ -1532,6 +1684,11 @@ __device__ __forceinline__ void rollout_body(
         // ---- new poses: scenario_gym.py:233-245 ----
         bool npres = false;
         double fpx = 0.0, fpy = 0.0; // PedestrianAgent.force
+        bool ped_go = false;
+        double ped_fx = 0.0, ped_fy = 0.0, ped_vdes = 0.0;
+        if (PED) // the social force of every stepping pedestrian of the wavefront (wave-collective)
+            ped_force<WV>(p, lds, sl, tile0, nbr, is_agent && kind == SG_KIND_AGENT_PEDESTRIAN && present && run, pose,
+                          velx, vely, wp, nwp, goal_idx, ped_go, ped_fx, ped_fy, ped_vdes, K);
         if (TAB) {
             // Straight-line lane masks (the kernel is bound by instruction issue, branches included):
             // BatchReplayEntity.step (batch.py:34-53) for replay lanes; an agent stays once present and spawns at its
@@ -1593,8 +1750,9 @@ __device__ __forceinline__ void rollout_body(
                         else
                             vehicle_step(cs, cp, bl, dt, act_a, act_s, sin_h, cos_h, np_, K);
                     } else if (PED)
-                        ped_step<WV>(p, lds, sl, tile0, nbr, pose, velx, vely, t, next_t, state_dt, wp, nwp, goal_idx,
-                                     cs.speed, fpx, fpy, np_, K);
+                        ped_move(p, ped_go, ped_fx, ped_fy, ped_vdes,
+                                 lds.ctrl[PED ? SG_C_PED_MAX_SPEED - SG_C_PED_SPEED_DESIRED : 0][sl], pose, state_dt,
+                                 cs.speed, fpx, fpy, np_, K);
                 }
             } else if (min_t >= t) { // scenario_gym.py:240-244: spawn at trajectory start
                 npres = true;

@@ -43,6 +43,7 @@ struct sg_handle {
     double *d_tab[2] = {nullptr, nullptr};
     std::vector<hipEvent_t> ev_pool;
     int tab_min = 16, chunk_steps = 1024, overlap = 1; // sg_set_tuning
+    int ped_serial = 0;                                // env SG_PED_SERIAL: pedestrian pair loop one pedestrian per lane
     int ctl_slice = 64;                                // steps per control_kernel launch (env SG_CTL_SLICE)
     int n_launches = 0;           // rollout_kernel launches of the last call
     std::vector<int> launch_ev;   // their (start, stop) event indices into ev_pool
@@ -146,6 +147,7 @@ extern "C" int sg_create(const sg_config *cfg, sg_handle **out)
     h->chunk_steps = env_int("SG_CHUNK_STEPS", h->chunk_steps);
     h->overlap = env_int("SG_OVERLAP", h->overlap);
     h->ctl_slice = std::max(1, env_int("SG_CTL_SLICE", h->ctl_slice));
+    h->ped_serial = env_int("SG_PED_SERIAL", 0) != 0;
     if (hipSetDevice(cfg->device) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess ||
         hipStreamCreate(&h->ctl_stream) != hipSuccess ||
         hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {
@@ -444,6 +446,7 @@ extern "C" int sg_upload(sg_handle *h, const sg_scenarios *sc)
     p.R = R; p.E = E; p.EP = EP;
     p.WV = h->WV; p.FROWS = SG_F_COLL + h->WV;
     p.sf = h->sf;
+    p.ped_serial = h->ped_serial;
     p.persist = h->cfg.persist;
     p.term_mask = h->cfg.terminal_mask;
     p.rec_cap = h->cfg.record_capacity > 0 ? h->cfg.record_capacity : 0;

@@ -930,3 +930,37 @@ def test_mixed_pedestrians_and_vehicles_match_oracle(sga, oracle, E, side):
         m = min(len(ev), 512)
         assert np.array_equal(ev["t"][:m], o["ev_t"][:m]) and np.array_equal(ev["other"][:m], o["ev_other"][:m]), r
     assert rows["n_collisions"].sum() > 0  # the car does plough through the crowd
+
+
+@pytest.mark.parametrize("E,side,cluster", [(256, 40.0, 0), (256, 30.0, 150), (128, 16.0, 70), (64, 10.0, 30), (40, 6.0, 0)])
+def test_pedestrian_pair_balancing_is_invisible(sga, oracle, monkeypatch, E, side, cluster):
+    """The crowd kernel spreads the (pedestrian, neighbour) pairs of a wavefront evenly over its lanes; SG_PED_SERIAL=1
+    keeps one pedestrian per lane.  Same bits either way and as the oracle -- also when a tight cluster inside a sparse
+    crowd gives a few lanes far more neighbours than the hand-over list of a wavefront holds."""
+    from scenario_gym_amd import synthetic
+
+    R, steps = 6, 70
+    packed = synthetic.make_crowd(R, E, n_steps=steps, side=side)
+    if cluster:  # the first `cluster` pedestrians of every scenario start inside a 2.5 m square
+        rng = np.random.default_rng(5)
+        kn = packed.knots.reshape(R, E, 2, 7)
+        rt = packed.routes.reshape(R, E, 2, 2)
+        start = rng.uniform(-1.25, 1.25, (R, cluster, 2))
+        kn[:, :cluster, :, 1:3] = start[:, :, None, :]
+        rt[:, :cluster, 0] = start
+    out = []
+    for serial in ("1", "0"):
+        monkeypatch.setenv("SG_PED_SERIAL", serial)
+        eng = sga.RolloutEngine(R, E, record_capacity=steps + 1, event_capacity=2048)
+        eng.upload(packed)
+        eng.rollout(steps)
+        out.append((eng.state(), eng.metrics(), eng.record(steps + 1)))
+        eng.close()
+    (sa, (ra, ea), (_, pa)), (sb, (rb, eb), (_, pb)) = out
+    assert bits_equal(pa, pb) and np.array_equal(ea, eb) and np.array_equal(ra, rb)
+    for k in ("poses", "vels", "dists", "force", "ctrl_state"):
+        assert bits_equal(sa[k], sb[k]), k
+    assert np.array_equal(sa["coll"], sb["coll"])
+    for r in range(2):
+        o = _oracle_one(oracle, packed, r, 1 / 30, steps)
+        assert bits_equal(pb[: o["n_steps"] + 1, r], o["poses"]) and bits_equal(sb["force"][r], o["extra"][-1, :, 2:]), r
