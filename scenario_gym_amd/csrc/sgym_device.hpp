@@ -959,6 +959,9 @@ __device__ __forceinline__ void ped_force(const Params &p, LDS &L, int sl, int t
     // the shortcuts of ped_pair need the sight-weight branch (c2 = w2 * att) and hold for the whole wavefront
     const bool plain = __all(hs == 0.0 && hc == 1.0) && sf.ped_attract_C == 0.0 && sf.sight_weight > 0.0 &&
                        sf.sight_weight_use != 0.0;
+#ifdef SG_ABL_NO_PAIRS
+    return;
+#endif
     if (plain && !p.ped_serial)
         ped_pairs_balanced<WV>(p, L, sl, tile0, nbr, go, k2_scale, pose[0], pose[1], radius, fx, fy);
     else
