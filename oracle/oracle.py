@@ -56,7 +56,68 @@ class _Scenario(C.Structure):
         ("length", C.c_double),
         ("route_off", C.c_void_p),
         ("routes", C.c_void_p),
+        ("road", C.c_void_p),
     ]
+
+
+class _RoadNetwork(C.Structure):
+    _fields_ = [("n_polygons", C.c_int32), ("ring_off", C.c_void_p), ("vert_off", C.c_void_p), ("verts", C.c_void_p),
+                ("layers", C.c_void_p)]
+
+
+(LAYER_DRIVEABLE, LAYER_ROAD, LAYER_INTERSECTION, LAYER_LANE, LAYER_WALKABLE, LAYER_PAVEMENT, LAYER_CROSSING,
+ LAYER_IMPENETRABLE) = (1 << i for i in range(8))
+TERM_EGO_OFF_ROAD = 8
+
+
+class RoadNetworkArrays:
+    """The polygons of one road network as the C structs want them.  arrays: dict with ring_off [P+1], vert_off [rings+1],
+    verts [n][2], layers [P] (the layout of scenario_gym_amd.road_network.RoadNetwork.polygon_arrays())."""
+
+    def __init__(self, arrays):
+        self.ring_off = np.ascontiguousarray(arrays["ring_off"], np.int64)
+        self.vert_off = np.ascontiguousarray(arrays["vert_off"], np.int64)
+        self.verts = np.ascontiguousarray(arrays["verts"], np.float64).reshape(-1, 2)
+        self.layers = np.ascontiguousarray(arrays["layers"], np.uint32)
+        self.struct = _RoadNetwork(len(self.layers), _p(self.ring_off), _p(self.vert_off), _p(self.verts), _p(self.layers))
+
+    def ref(self):
+        return C.addressof(self.struct)
+
+
+def _road(net):
+    if net is None or isinstance(net, RoadNetworkArrays):
+        return net
+    return RoadNetworkArrays(net)
+
+
+def surface_contains(net, layer, xs, ys):
+    """Points strictly inside the union of the polygons of `layer` (LAYER_* bit)."""
+    net = _road(net)
+    L = lib()
+    L.sgo_surface_contains_points.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.sgo_surface_contains_points.restype = None
+    xs = np.ascontiguousarray(np.atleast_1d(xs), np.float64)
+    ys = np.ascontiguousarray(np.atleast_1d(ys), np.float64)
+    out = np.zeros(len(xs), np.uint8)
+    L.sgo_surface_contains_points(None if net is None else net.ref(), int(layer), len(xs), _p(xs), _p(ys), _p(out))
+    return out.astype(bool)
+
+
+def raster_map(poses, bbox, ego, net, layers, width=20.0, height=20.0, nw=20, nh=20):
+    """RasterizedMapSensor._step (sensor/map.py:136-149): [n_layers][nh][nw] bool; layers: 0 = entity, else a LAYER_* bit."""
+    net = _road(net)
+    poses = np.ascontiguousarray(poses, np.float64)
+    bbox = np.ascontiguousarray(bbox, np.float64)
+    layers = np.ascontiguousarray(layers, np.int32)
+    out = np.zeros((len(layers), nh, nw), np.uint8)
+    L = lib()
+    L.sgo_raster_map.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int,
+                                 C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.sgo_raster_map.restype = None
+    L.sgo_raster_map(_p(poses), _p(bbox), len(poses), int(ego), float(width), float(height), int(nw), int(nh),
+                     None if net is None else net.ref(), len(layers), _p(layers), _p(out))
+    return out.astype(bool)
 
 
 class _Config(C.Structure):
@@ -120,7 +181,7 @@ def default_kinds(n, ego=0):
 
 def rollout(knot_off, knots, bbox, etype, kind, ego, t0, length, dt, persist=False,
             terminal_mask=TERM_MAX_LENGTH, ctrl=None, actions=None, max_steps=None,
-            force_steps=False, record=True, event_cap=256, route_off=None, routes=None, sf=None):
+            force_steps=False, record=True, event_cap=256, route_off=None, routes=None, sf=None, road=None):
     """One scenario through the oracle.  Returns a dict shaped like make_golden.record_rollout."""
     L = lib()
     E = int(len(kind))
@@ -139,7 +200,10 @@ def rollout(knot_off, knots, bbox, etype, kind, ego, t0, length, dt, persist=Fal
         routes = np.ascontiguousarray(routes, np.float64).reshape(-1, 2)
     sc = _Scenario(E, int(ego), _p(kind), _p(etype), _p(bbox), _p(knot_off), _p(knots), _p(ctrl),
                    float(t0), float(length), None if route_off is None else _p(route_off),
-                   None if route_off is None else _p(routes))
+                   None if route_off is None else _p(routes), None)
+    road = _road(road)
+    if road is not None:
+        sc.road = road.ref()
     sf = social_force_params() if sf is None else np.ascontiguousarray(sf, np.float64)
     cfg = _Config(float(dt), int(bool(persist)), int(terminal_mask), (C.c_double * NSF)(*sf))
     S = max_steps + 1

@@ -479,6 +479,136 @@ void sgo_raster_entities(const double *poses, const double *bbox, int E, int ego
     free(cor);
 }
 
+/* ---- road surfaces: point in the union of polygons ------------------------------------------------------------
+ * RoadNetwork.driveable_surface & co are unary_union()s of the boundary polygons (road_network.py:306-328) and the
+ * callers ask `contains(Point)` (state.py:401-407, sensor/map.py:198-271).  shapely/GEOS is not part of the reference
+ * sources; its published algorithm for this predicate is JTS/GEOS RayCrossingCounter with the robust orientation
+ * index: a point is inside a polygon iff a ray towards +x crosses its rings an odd number of times, and a point ON a
+ * ring is not contained.  Restated here with an exact orientation sign (fp64 filter, then an exact expansion sum),
+ * so the answer is the mathematical one for the given fp64 coordinates.  A point is in the union iff it is strictly
+ * inside one of the polygons (points on an edge shared by two polygons of the same union are the measure-zero
+ * exception: GEOS dissolves such edges, this restatement reports them outside). */
+static void two_sum(double a, double b, double *s, double *e)
+{
+    double x = a + b, bb = x - a;
+    *s = x;
+    *e = (a - (x - bb)) + (b - bb);
+}
+
+/* sign of (ax - px) * (by - py) - (ay - py) * (bx - px), exactly */
+static int orient_sign(double ax, double ay, double bx, double by, double px, double py)
+{
+    const double dl = (ax - px) * (by - py), dr = (ay - py) * (bx - px), det = dl - dr;
+    const double bound = 1e-15 * (fabs(dl) + fabs(dr)); /* > (3 + 16 eps) eps of Shewchuk's stage-A bound */
+    if (det > bound) return 1;
+    if (det < -bound) return -1;
+    /* = ax*by - ax*py - px*by - ay*bx + ay*px + py*bx  (px*py cancels): six exact products, summed exactly */
+    const double fa[6] = {ax, -ax, -px, -ay, ay, py}, fb[6] = {by, py, by, bx, px, bx};
+    double e[12];
+    int n = 0;
+    for (int k = 0; k < 6; ++k) {
+        const double hi = fa[k] * fb[k], lo = fma(fa[k], fb[k], -hi);
+        const double term[2] = {lo, hi};
+        for (int u = 0; u < 2; ++u) { /* grow-expansion: e stays non-overlapping, increasing magnitude */
+            double q = term[u];
+            for (int i = 0; i < n; ++i) two_sum(q, e[i], &q, &e[i]);
+            e[n++] = q;
+        }
+    }
+    for (int i = n - 1; i >= 0; --i)
+        if (e[i] != 0.0) return e[i] > 0 ? 1 : -1;
+    return 0;
+}
+
+/* RayCrossingCounter.countSegment for one edge: *cross toggles on a crossing; returns 1 if the point is ON the edge */
+static int ray_edge(double x1, double y1, double x2, double y2, double px, double py, int *cross)
+{
+    if (x1 < px && x2 < px) return 0; /* strictly to the left of the point */
+    if (px == x2 && py == y2) return 1;
+    if (y1 == py && y2 == py) { /* horizontal edge at the ray's height */
+        const double lo = x1 < x2 ? x1 : x2, hi = x1 < x2 ? x2 : x1;
+        return px >= lo && px <= hi;
+    }
+    if ((y1 > py && y2 <= py) || (y2 > py && y1 <= py)) {
+        int o = orient_sign(x1, y1, x2, y2, px, py);
+        if (o == 0) return 1;
+        if (y2 < y1) o = -o;
+        if (o > 0) *cross ^= 1;
+    }
+    return 0;
+}
+
+static int polygon_contains(const sgo_road_network *net, int k, double x, double y)
+{
+    int cross = 0;
+    for (int64_t r = net->ring_off[k]; r < net->ring_off[k + 1]; ++r) {
+        const int64_t a = net->vert_off[r], b = net->vert_off[r + 1];
+        for (int64_t i = a; i < b; ++i) {
+            const int64_t j = i + 1 < b ? i + 1 : a;
+            if (ray_edge(net->verts[2 * i], net->verts[2 * i + 1], net->verts[2 * j], net->verts[2 * j + 1], x, y, &cross))
+                return 0; /* on the boundary */
+        }
+    }
+    return cross;
+}
+
+int sgo_surface_contains(const sgo_road_network *net, uint32_t layer, double x, double y)
+{
+    if (!net) return 0;
+    for (int k = 0; k < net->n_polygons; ++k)
+        if ((net->layers[k] & layer) && polygon_contains(net, k, x, y)) return 1;
+    return 0;
+}
+
+/* the same for many points; polygons whose bounding box misses the point are skipped (test speed only) */
+void sgo_surface_contains_points(const sgo_road_network *net, uint32_t layer, int n, const double *xs, const double *ys,
+                                 uint8_t *out)
+{
+    memset(out, 0, (size_t)n);
+    if (!net) return;
+    double *bb = (double *)malloc((size_t)(net->n_polygons > 0 ? net->n_polygons : 1) * 4 * sizeof(double));
+    for (int k = 0; k < net->n_polygons; ++k) {
+        double *b = bb + (size_t)k * 4;
+        b[0] = b[1] = INFINITY;
+        b[2] = b[3] = -INFINITY;
+        for (int64_t i = net->vert_off[net->ring_off[k]]; i < net->vert_off[net->ring_off[k + 1]]; ++i) {
+            b[0] = fmin(b[0], net->verts[2 * i]); b[1] = fmin(b[1], net->verts[2 * i + 1]);
+            b[2] = fmax(b[2], net->verts[2 * i]); b[3] = fmax(b[3], net->verts[2 * i + 1]);
+        }
+    }
+    for (int q = 0; q < n; ++q)
+        for (int k = 0; k < net->n_polygons && !out[q]; ++k) {
+            const double *b = bb + (size_t)k * 4;
+            if (!(net->layers[k] & layer) || xs[q] < b[0] || xs[q] > b[2] || ys[q] < b[1] || ys[q] > b[3]) continue;
+            out[q] = (uint8_t)polygon_contains(net, k, xs[q], ys[q]);
+        }
+    free(bb);
+}
+
+void sgo_raster_map(const double *poses, const double *bbox, int E, int ego, double width, double height, int nw, int nh,
+                    const sgo_road_network *net, int n_layers, const int32_t *layers, uint8_t *out)
+{
+    const double *pe = poses + (size_t)ego * 6;
+    double s, c;
+    sgo_sincos(pe[3] + 3.14159265358979311600e+00 / 2, &s, &c);
+    for (int l = 0; l < n_layers; ++l) {
+        uint8_t *o = out + (size_t)l * nw * nh;
+        if (layers[l] == 0) {
+            sgo_raster_entities(poses, bbox, E, ego, width, height, nw, nh, o);
+            continue;
+        }
+        double *xs = (double *)malloc((size_t)nw * nh * 2 * sizeof(double)), *ys = xs + (size_t)nw * nh;
+        for (int i = 0; i < nh; ++i)
+            for (int j = 0; j < nw; ++j) {
+                const double x0 = linspace_at(-width / 2, width / 2, nw, j), x1 = linspace_at(-height / 2, height / 2, nh, i);
+                xs[(size_t)i * nw + j] = fma(x1, -s, x0 * c) + pe[0];
+                ys[(size_t)i * nw + j] = fma(x1, c, x0 * s) + pe[1];
+            }
+        sgo_surface_contains_points(net, (uint32_t)layers[l], nw * nh, xs, ys, o);
+        free(xs);
+    }
+}
+
 /* State.collisions -> detect_collisions -> detect_geom_collisions
  * (scenario_gym/state/state.py:306-310, state/utils.py:10-49, utils.py:28-62).
  * rows[i] bit j set <=> entity j is listed for entity i.  Geometry-equality quirks:
@@ -898,6 +1028,10 @@ int sgo_rollout(const sgo_scenario *sc, const sgo_config *cfg, int max_steps, in
             for (int k = 0; k < E * W; ++k) if (rows[k]) done = 1;
         if ((cfg->terminal_mask & SGO_TERM_EGO_COLLISION) && present[0])
             for (int k = 0; k < W; ++k) if (rows[k]) done = 1;
+        /* ego_off_road looks at entities[0] (not Scenario.ego) and fires when it is absent, state.py:401-407 */
+        if ((cfg->terminal_mask & SGO_TERM_EGO_OFF_ROAD) &&
+            !(present[0] && sgo_surface_contains(sc->road, SGO_LAYER_DRIVEABLE, poses[0], poses[1])))
+            done = 1;
         /* metrics, scenario_gym.py:251-252 */
         if (present[ego]) {
             const double *v = vels + (size_t)ego * 6;

@@ -20,6 +20,7 @@ from typing import Dict, Tuple
 
 import numpy as np
 
+from .road_network import RoadNetwork
 from .entity import BoundingBox, CatalogEntry, Entity, MiscObject, Pedestrian, Vehicle
 from .scenario import Scenario
 from .trajectory import Trajectory
@@ -125,5 +126,18 @@ def import_scenario(osc_file: str, relabel: bool = True) -> Scenario:
                 pts = [_traj_point(float(v.attrib["time"]), v.find("Position/WorldPosition")) for v in verts]
                 entity.trajectory = Trajectory(np.stack(pts, axis=0))
 
-    scenario = Scenario(list(entities.values()), name=os.path.splitext(os.path.basename(osc_file))[0])
+    # road network: RoadNetwork/SceneGraphFile or LogicFile, ".json" when there is no extension (read.py:65-85)
+    road_network = None
+    rn = root.find("RoadNetwork/SceneGraphFile")
+    if rn is None:
+        rn = root.find("RoadNetwork/LogicFile")
+    if rn is not None and rn.attrib.get("filepath"):
+        path = rn.attrib["filepath"]
+        path = path if os.path.isabs(path) else os.path.join(cwd, path)
+        if os.path.splitext(path)[1] == "":
+            path += ".json"
+        if os.path.exists(path) and path.endswith(".json"):
+            road_network = RoadNetwork.create_from_json(path)
+    scenario = Scenario(list(entities.values()), name=os.path.splitext(os.path.basename(osc_file))[0],
+                        road_network=road_network)
     return relabel_scenario(scenario) if relabel else scenario

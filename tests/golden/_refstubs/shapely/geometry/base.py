@@ -207,18 +207,63 @@ def convex_intersects_exact(A, B):
     return True
 
 
+def _rings(poly):
+    out = [list(poly.exterior.coords[:-1])]
+    for h in getattr(poly, "interiors", []):
+        c = list(h.coords)
+        out.append(c[:-1] if len(c) > 1 and c[0] == c[-1] else c)
+    return out
+
+
 def _contains_xy(poly, xs, ys):
-    """Strict interior test of points in a convex ring (exact rational)."""
-    ring = poly._ring()
-    o = _orient(ring)
-    Rf = [(_F(x), _F(y)) for x, y in ring]
-    out = []
-    for x, y in zip(xs, ys):
-        px, py = _F(x), _F(y)
-        inside = o != 0
-        for (ax, ay), (bx, by) in zip(Rf, Rf[1:] + Rf[:1]):
-            if o * ((bx - ax) * (py - ay) - (by - ay) * (px - ax)) <= 0:
-                inside = False
-                break
-        out.append(inside)
-    return np.array(out, dtype=bool)
+    """Strict interior test of points in a polygon with holes: crossing number of the ray towards +x over all rings,
+    points on a ring are outside.  numpy fp64 with an error bound on the orientation determinant; whatever falls inside
+    the bound is decided in exact rational arithmetic."""
+    xs, ys = np.asarray(xs, np.float64).ravel(), np.asarray(ys, np.float64).ravel()
+    out = np.zeros(len(xs), dtype=bool)
+    if len(xs) == 0 or len(poly.exterior.coords) < 4:
+        return out
+    rings = _rings(poly)
+    E = np.array([(r[i] + r[(i + 1) % len(r)]) for r in rings for i in range(len(r))], np.float64)  # x1 y1 x2 y2
+    x0, y0, x1, y1 = poly.bounds
+    cand = np.nonzero((xs >= x0) & (xs <= x1) & (ys >= y0) & (ys <= y1))[0]
+    for c0 in range(0, len(cand), 4096):
+        idx = cand[c0:c0 + 4096]
+        px, py = xs[idx, None], ys[idx, None]
+        ax, ay, bx, by = E[None, :, 0], E[None, :, 1], E[None, :, 2], E[None, :, 3]
+        straddle = ((ay > py) & (by <= py)) | ((by > py) & (ay <= py))
+        dl, dr = (ax - px) * (by - py), (ay - py) * (bx - px)
+        det = dl - dr
+        unsure = straddle & (np.abs(det) <= 1e-14 * (np.abs(dl) + np.abs(dr)))
+        on_vertex = ((px == bx) & (py == by)).any(axis=1)
+        horiz = ((ay == py) & (by == py) & (px >= np.minimum(ax, bx)) & (px <= np.maximum(ax, bx))).any(axis=1)
+        left = np.where(by < ay, -det, det) > 0
+        inside = (np.count_nonzero(straddle & left, axis=1) % 2) == 1
+        res = inside & ~on_vertex & ~horiz
+        for k in np.nonzero(unsure.any(axis=1) | on_vertex | horiz)[0]:
+            res[k] = _contains_exact(rings, float(px[k, 0]), float(py[k, 0]))
+        out[idx] = res
+    return out
+
+
+def _contains_exact(rings, x, y):
+    px, py = _F(x), _F(y)
+    cross = 0
+    for r in rings:
+        R = [(_F(a), _F(b)) for a, b in r]
+        for (ax, ay), (bx, by) in zip(R, R[1:] + R[:1]):
+            if (px, py) == (bx, by):
+                return False
+            if ay == py and by == py:
+                if min(ax, bx) <= px <= max(ax, bx):
+                    return False
+                continue
+            if (ay > py and by <= py) or (by > py and ay <= py):
+                det = (ax - px) * (by - py) - (ay - py) * (bx - px)
+                if det == 0:
+                    return False
+                if by < ay:
+                    det = -det
+                if det > 0:
+                    cross += 1
+    return cross % 2 == 1

@@ -241,6 +241,26 @@ def test_xosc_reader_on_all_reference_inputs():
         assert s.entities.index(s.ego) == int(g[f"{n}/scenario/ego"]) and s.length == float(g[f"{n}/scenario/length"]), n
 
 
+@pytest.mark.skipif(not os.path.isdir("/root/reference/tests/input_files/Road_Networks"), reason="build container only")
+def test_road_network_reader_on_all_reference_inputs():
+    """The six road-network JSON files of the reference's tests: every geometry, its rings and the unions it belongs to
+    (driveable / walkable / impenetrable surface, road, intersection, lane, pavement, crossing) as the reference's own
+    RoadNetwork.create_from_json composed them (roads.npz)."""
+    from scenario_gym_amd.road_network import RoadNetwork
+
+    g = load_golden("roads")
+    for n in g["networks"]:
+        a = RoadNetwork.create_from_json(f"/root/reference/tests/input_files/Road_Networks/{n}.json").polygon_arrays()
+
+        def by_id(ids, ring_off, vert_off, verts, layers):
+            return {str(i): (int(layers[k]), [verts[vert_off[r]:vert_off[r + 1]].tobytes() for r in range(ring_off[k], ring_off[k + 1])])
+                    for k, i in enumerate(ids)}
+
+        mine = by_id(a["ids"], a["ring_off"], a["vert_off"], a["verts"], a["layers"])
+        ref = by_id(*(g[f"net/{n}/{k}"] for k in ("ids", "ring_off", "vert_off", "verts", "layers")))
+        assert mine == ref, n
+
+
 # ---------------------------------------------------------------- the C ABI
 def test_library_exports_every_declared_symbol():
     import ctypes

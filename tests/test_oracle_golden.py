@@ -357,3 +357,87 @@ def test_all_reference_scenarios_roll_out(oracle):
         assert np.array_equal(oracle.coll_to_dense(o["coll"], E)[-1], g[f"{name}/final_coll"]), name
         for k in ("ego_avg_speed", "ego_max_speed", "ego_distance_travelled"):
             assert o["metric_" + k] == float(g[f"{name}/metric_{k}"]), (name, k)
+
+
+# ---------------------------------------------------------------- road surfaces (N2 map layers, N4 ego_off_road)
+ROAD_BITS = dict(driveable_surface=1, road=2, intersection=4, lane=8, walkable_surface=16, pavement=32, crossing=64)
+
+
+def road_arrays(g, net):
+    return {k: g[f"net/{net}/{k}"] for k in ("ring_off", "vert_off", "verts", "layers")}
+
+
+def test_surface_contains_known_answers(oracle):
+    """Every union the reference takes of its road-network polygons (driveable / walkable surface, the map layers), on the
+    six shipped networks: 2,300 points each -- random, ON polygon vertices, a nanometre beside them, on edge midpoints --
+    answered exactly as the exact-rational crossing number of the golden generator."""
+    g = load_golden("roads")
+    for net in g["networks"]:
+        arr = oracle.RoadNetworkArrays(road_arrays(g, net))
+        pts = g[f"net/{net}/points"]
+        for name, bit in ROAD_BITS.items():
+            got = oracle.surface_contains(arr, bit, pts[:, 0], pts[:, 1])
+            assert np.array_equal(got, g[f"net/{net}/contains_{name}"].astype(bool)), (net, name)
+    assert not oracle.surface_contains(None, 1, [0.0], [0.0])[0]  # no road network: every surface is empty
+
+
+def test_orientation_sign_is_exact(oracle):
+    """Points a few ulps off long edges: the fp64 determinant is noise there, the expansion sum decides."""
+    from fractions import Fraction as F
+
+    rng = np.random.default_rng(3)
+    for _ in range(300):
+        a, b = rng.uniform(-1000, 1000, 2), rng.uniform(-1000, 1000, 2)
+        c = a + (b - a) * rng.uniform(0.1, 0.9)  # (nearly) on the edge a-b of the triangle a, b, far
+        c = np.nextafter(c, c + rng.choice([-1, 1], 2) * rng.integers(0, 3, 2))
+        far = a + np.array([-(b - a)[1], (b - a)[0]])  # to the left of a->b
+        tri = dict(ring_off=[0, 1], vert_off=[0, 3], verts=[a, b, far], layers=[1])
+        det = (F(a[0]) - F(c[0])) * (F(b[1]) - F(c[1])) - (F(a[1]) - F(c[1])) * (F(b[0]) - F(c[0]))
+        # strictly left of a->b (and far from the other two edges) <=> strictly inside
+        assert oracle.surface_contains(tri, 1, [c[0]], [c[1]])[0] == (det > 0)
+
+
+def test_raster_map_layers_match_reference(oracle):
+    """RasterizedMapSensor with all eight layers (sensor/map.py:136-271; the case of tests/test_sensor.py:38-77 and the
+    default 20 x 20 grid) along the reference's rollouts of one scenario per shipped road network."""
+    from scenario_gym_amd.packing import default_kinds
+
+    g = load_golden("roads")
+    layers = [0] + [ROAD_BITS[str(x)] for x in g["layers"][1:]]
+    for n in g["scenarios"]:
+        s = scenario_arrays(g, f"{n}/scenario")
+        E = len(s["bbox"])
+        o = oracle.rollout(s["knot_off"], s["knots"], s["bbox"], s["etype"], default_kinds(E, s["ego"]), s["ego"], s["t0"],
+                           s["length"], 0.1)
+        net = oracle.RoadNetworkArrays(road_arrays(g, str(g[f"{n}/network"])))
+        for c, (w, h, k) in enumerate(g["raster_cfg"]):
+            want = g[f"{n}/map{c}"].astype(bool)
+            for f, step in enumerate(g[f"{n}/map_steps"]):
+                got = oracle.raster_map(o["poses"][step], s["bbox"], 0, net, layers, width=w, height=h, nw=int(k), nh=int(k))
+                assert np.array_equal(got, want[f]), (n, c, step)
+        assert want[:, 1].any() and want[0, 0, int(k) // 2, int(k) // 2]  # tests/test_sensor.py:55-61
+
+
+def test_ego_off_road_terminal_matches_reference(oracle):
+    """terminal_conditions=["max_length", "ego_off_road"] (state/state.py:397-407): the recorded egos stay on the road to
+    the end; copies drifting sideways stop at the reference's step."""
+    from scenario_gym_amd.packing import default_kinds
+
+    g = load_golden("roads")
+    stopped_early = 0
+    for n in g["scenarios"]:
+        net = oracle.RoadNetworkArrays(road_arrays(g, str(g[f"{n}/network"])))
+        for tag in ("onroad", "drift"):
+            s = scenario_arrays(g, f"{n}/{tag}/scenario")
+            E = len(s["bbox"])
+            o = oracle.rollout(s["knot_off"], s["knots"], s["bbox"], s["etype"], default_kinds(E, s["ego"]), s["ego"],
+                               s["t0"], s["length"], 0.1, terminal_mask=oracle.TERM_MAX_LENGTH | oracle.TERM_EGO_OFF_ROAD,
+                               road=net)
+            assert bits_equal(o["t"], g[f"{n}/{tag}/t"]), (n, tag)
+            assert bits_equal(o["poses"][-1, s["ego"]], g[f"{n}/{tag}/final_ego"]), (n, tag)
+            stopped_early += o["t"][-1] + 0.2 < s["length"]
+        # without a road network the driveable surface is empty: off the road at once
+        o = oracle.rollout(s["knot_off"], s["knots"], s["bbox"], s["etype"], default_kinds(E, s["ego"]), s["ego"], s["t0"],
+                           s["length"], 0.1, terminal_mask=oracle.TERM_EGO_OFF_ROAD)
+        assert o["n_steps"] == 1
+    assert stopped_early >= 2
