@@ -51,6 +51,34 @@ typedef enum {
 #define SG_TERM_MAX_LENGTH 1u
 #define SG_TERM_COLLISION 2u
 #define SG_TERM_EGO_COLLISION 4u
+#define SG_TERM_EGO_OFF_ROAD 8u /* entities[0] absent or not strictly inside RoadNetwork.driveable_surface (sg_set_road_networks) */
+
+/* The unions of RoadGeometry boundaries the reference takes: RoadNetwork.driveable_surface / walkable_surface /
+ * impenetrable_surface (road_network/road_network.py:306-328, flags in road_network/objects.py) and the per-layer
+ * unions of RasterizedMapSensor (sensor/map.py:194-271).  A polygon carries the bits of every union it is part of. */
+#define SG_LAYER_DRIVEABLE 1u    /* roads, intersections and all lanes */
+#define SG_LAYER_ROAD 2u
+#define SG_LAYER_INTERSECTION 4u
+#define SG_LAYER_LANE 8u         /* the lanes of the roads */
+#define SG_LAYER_WALKABLE 16u    /* pavements, crossings, buildings */
+#define SG_LAYER_PAVEMENT 32u
+#define SG_LAYER_CROSSING 64u
+#define SG_LAYER_IMPENETRABLE 128u
+
+/* The boundary polygons of the scenarios' road networks (Scenario.road_network; JSON format of
+ * road_network/utils.py:6-41).  Networks are shared: scenario r uses network net_of_scenario[r] (-1: none, every
+ * surface empty).  Polygon q of network n = polygons [poly_off[n], poly_off[n+1]); its rings (exterior first, then
+ * holes) = rings [ring_off[q], ring_off[q+1]); ring vertices = verts[vert_off[ring] .. vert_off[ring+1]), rings OPEN
+ * (last vertex != first).  HOST arrays, copied by the call. */
+typedef struct sg_road_networks {
+    int32_t n_networks;
+    const int32_t *net_of_scenario; /* [n_scenarios] */
+    const int64_t *poly_off;        /* [n_networks + 1] */
+    const int64_t *ring_off;        /* [n_polygons + 1] */
+    const int64_t *vert_off;        /* [n_rings + 1] */
+    const double *verts;            /* [n_verts][2] x, y */
+    const uint32_t *layers;         /* [n_polygons] SG_LAYER_* */
+} sg_road_networks;
 
 /* controller parameter slots (VehicleController.__init__ controller.py:64-98, PIDController.__init__ :154-196) */
 enum {
@@ -228,6 +256,21 @@ int sg_future_collision(sg_handle *h, double horizon, int32_t n_samples, uint8_t
  * frame (rotated by heading + pi/2) lies strictly inside the bounding box of a present entity, the ego included;
  * all zeros for a scenario whose ego is absent.  The reference sensor has nw == nh.  out: HOST [R][nh][nw] bytes. */
 int sg_raster_entities(sg_handle *h, double width, double height, int32_t nw, int32_t nh, uint8_t *out);
+
+/* Scenario.road_network for the uploaded batch: after sg_upload (which forgets the previous networks), before the
+ * first step that needs them.  `contains(Point)` on a union (state.py:401-407, sensor/map.py:198-271) is answered as
+ * shapely answers it for points that are not on a polygon's boundary: strictly inside one of the polygons of the union,
+ * by the crossing number of its rings with an exact orientation sign (JTS/GEOS RayCrossingCounter); points ON a ring are
+ * outside.  The library lays a uniform grid over each network (cells wholly inside / wholly outside a union answer at
+ * once, the others test the polygons that cross them) -- an index only, the answers are those of the plain test. */
+int sg_set_road_networks(sg_handle *h, const sg_road_networks *nets);
+
+/* RasterizedMapSensor._step (sensor/map.py:136-149) for the ego (entities[0] of the reference's tests = the scenario's
+ * ego) of every scenario: layers[k] = 0 is the "entity" layer of sg_raster_entities, otherwise ONE SG_LAYER_* bit
+ * ("driveable_surface", "road", "intersection", "lane", "walkable_surface", "pavement", "crossing");
+ * out[r][k][i][j] as in sg_raster_entities (the sensor's channels_first layout).  out: HOST [R][n_layers][nh][nw]. */
+int sg_raster_map(sg_handle *h, double width, double height, int32_t nw, int32_t nh, int32_t n_layers,
+                  const int32_t *layers, uint8_t *out);
 
 /* ScenarioGym.get_metrics (scenario_gym.py:308-319): out [R]; events [cap] (may be NULL) */
 int sg_read_metrics(sg_handle *h, sg_metrics *out, sg_event *events, int32_t cap, int32_t *n_events);

@@ -12,7 +12,7 @@ SG_OK = 0
 ABI_VERSION = 1
 (KIND_NONE, KIND_REPLAY, KIND_AGENT_REPLAY, KIND_AGENT_PID, KIND_AGENT_VEHICLE, KIND_AGENT_PEDESTRIAN,
  KIND_AGENT_EXTERNAL) = range(7)
-TERM_MAX_LENGTH, TERM_COLLISION, TERM_EGO_COLLISION = 1, 2, 4
+TERM_MAX_LENGTH, TERM_COLLISION, TERM_EGO_COLLISION, TERM_EGO_OFF_ROAD = 1, 2, 4, 8
 NCTRL = 16
 (C_MAX_STEER, C_MAX_ACCEL, C_MAX_SPEED, C_ALLOW_REVERSE, C_STEER_KP, C_STEER_KD, C_ACCEL_KP,
  C_ACCEL_KD, C_ACCEL_KI, C_PED_SPEED_DESIRED, C_PED_MAX_SPEED, C_PED_HEAD_ROT, C_PED_RADIUS) = range(13)
@@ -26,6 +26,7 @@ SYMBOLS = (
     "sg_set_timestep", "sg_step", "sg_rollout", "sg_rollout_async", "sg_synchronize", "sg_stream",
     "sg_state_view_get", "sg_read_metrics", "sg_read_record", "sg_copy_to_host", "sg_last_kernel_ms",
     "sg_last_launch_stats", "sg_debug_trig32", "sg_set_tuning", "sg_set_external_poses", "sg_future_collision", "sg_raster_entities",
+    "sg_set_road_networks", "sg_raster_map",
 )
 
 
@@ -40,6 +41,11 @@ class SgConfig(C.Structure):
 class SgScenarios(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in
                 ("kind", "etype", "bbox", "knot_off", "knots", "ctrl", "ego", "t0", "length", "route_off", "routes")]
+
+
+class SgRoadNetworks(C.Structure):
+    _fields_ = [("n_networks", C.c_int32)] + [(n, C.c_void_p) for n in
+                                              ("net_of_scenario", "poly_off", "ring_off", "vert_off", "verts", "layers")]
 
 
 class SgSocialForce(C.Structure):
@@ -113,6 +119,8 @@ def load():
     lib.sg_set_external_poses.argtypes = [H, C.c_void_p]
     lib.sg_future_collision.argtypes = [H, C.c_double, C.c_int32, C.c_void_p]
     lib.sg_raster_entities.argtypes = [H, C.c_double, C.c_double, C.c_int32, C.c_int32, C.c_void_p]
+    lib.sg_set_road_networks.argtypes = [H, C.POINTER(SgRoadNetworks)]
+    lib.sg_raster_map.argtypes = [H, C.c_double, C.c_double, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
     lib.sg_debug_trig32.argtypes = [H, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
     for name in SYMBOLS:
         if name not in ("sg_last_error", "sg_stream", "sg_version"):

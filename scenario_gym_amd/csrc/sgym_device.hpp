@@ -58,6 +58,21 @@ struct ScenStatic { // per scenario, read-only
     int32_t grid_n, ego;
 };
 
+// Road surfaces (sg_set_road_networks): the polygons as edge soup + one uniform cell grid per network.
+struct RoadNet { double x0, y0, inv_cell; int32_t nx, ny; int64_t cell_base; };
+struct RoadIndex {
+    const RoadNet *nets;            // [n_nets]
+    const int32_t *net_of_scen;     // [R], -1 = no road network
+    const uint16_t *cells;          // per cell: low byte = layers some polygon covers the WHOLE cell with, high byte = layers
+                                    // with a polygon whose boundary touches the cell (candidates below)
+    const uint32_t *cell_off;       // CSR over all cells of all networks
+    const int32_t *cell_poly;       // candidate polygons (global index) of the cells
+    const double *edges;            // [n_edges][4] x1, y1, x2, y2; the rings of a polygon are contiguous
+    const int64_t *poly_edge_off;   // [n_polygons + 1]
+    const uint32_t *poly_layers;    // [n_polygons] SG_LAYER_*
+    int32_t n_nets;
+};
+
 struct Params {
     int R, E, EP;
     int persist;
@@ -81,6 +96,7 @@ struct Params {
     double *ctl_state;       // [CS_COUNT][n_ctl_pad] lane state carried from one chunk of steps to the next
     int n_ctl_pad;           // multiple of 64
     const double *ext_pose;  // [NE][6] poses of the caller-run agents (SG_KIND_AGENT_EXTERNAL), x = NaN: agent returned None
+    const RoadIndex *road;   // device copy of the road index, nullptr = no road networks set
     int ped_serial;          // 1: pedestrian pair loop one pedestrian per lane (env SG_PED_SERIAL; default 0: balanced over the wavefront)
     int tab_steps;           // steps per table chunk (rows per lane = tab_steps + 1: the prefetch of the last step reads one row ahead)
 };
@@ -2231,6 +2247,107 @@ __global__ __launch_bounds__(256) void future_kernel(Params p, double horizon, i
 }
 
 // ------------------------------------------------------------------------------------------------
+// Road surfaces: point strictly inside the union of the polygons of a layer.
+// shapely contains(Point) (state.py:401-407, sensor/map.py:198-271) = JTS/GEOS RayCrossingCounter: the ray towards +x
+// crosses the polygon's rings an odd number of times; a point ON a ring is not contained.  The orientation sign is
+// exact: fp64 determinant with Shewchuk's stage-A error bound, else the six products of the expanded determinant as
+// two-term expansions, summed exactly (grow-expansion); the sign of the sum is the sign of its largest component.
+// Host and device share these functions (the host uses them to classify the grid cells, sgym_hip.hip).
+// ------------------------------------------------------------------------------------------------
+__host__ __device__ inline void rn_two_sum(double a, double b, double &s, double &e)
+{
+    const double x = a + b, bb = x - a;
+    s = x;
+    e = (a - (x - bb)) + (b - bb);
+}
+
+__host__ __device__ __attribute__((noinline)) inline int rn_orient_exact(double ax, double ay, double bx, double by, double px, double py)
+{
+    // (ax - px)(by - py) - (ay - py)(bx - px) = ax*by - ax*py - px*by - ay*bx + ay*px + py*bx
+    const double fa[6] = {ax, -ax, -px, -ay, ay, py}, fb[6] = {by, py, by, bx, px, bx};
+    double e[12];
+    int n = 0;
+    for (int k = 0; k < 6; ++k) {
+        const double hi = fa[k] * fb[k], lo = __builtin_fma(fa[k], fb[k], -hi);
+        for (int u = 0; u < 2; ++u) {
+            double q = u ? hi : lo;
+            for (int i = 0; i < n; ++i) rn_two_sum(q, e[i], q, e[i]);
+            e[n++] = q;
+        }
+    }
+    for (int i = n - 1; i >= 0; --i)
+        if (e[i] != 0.0) return e[i] > 0 ? 1 : -1;
+    return 0;
+}
+
+__host__ __device__ inline int rn_orient_sign(double ax, double ay, double bx, double by, double px, double py)
+{
+    const double dl = (ax - px) * (by - py), dr = (ay - py) * (bx - px), det = dl - dr;
+    const double bound = 1e-15 * (__builtin_fabs(dl) + __builtin_fabs(dr));
+    if (det > bound) return 1;
+    if (det < -bound) return -1;
+    return rn_orient_exact(ax, ay, bx, by, px, py);
+}
+
+// RayCrossingCounter.countSegment: toggles `cross` on a crossing, returns true if the point is ON the edge
+__host__ __device__ inline bool rn_ray_edge(double x1, double y1, double x2, double y2, double px, double py, bool &cross)
+{
+    if (x1 < px && x2 < px) return false;
+    if (px == x2 && py == y2) return true;
+    if (y1 == py && y2 == py) {
+        const double lo = x1 < x2 ? x1 : x2, hi = x1 < x2 ? x2 : x1;
+        return px >= lo && px <= hi;
+    }
+    if ((y1 > py && y2 <= py) || (y2 > py && y1 <= py)) {
+        int o = rn_orient_sign(x1, y1, x2, y2, px, py);
+        if (o == 0) return true;
+        if (y2 < y1) o = -o;
+        if (o > 0) cross = !cross;
+    }
+    return false;
+}
+
+__host__ __device__ inline bool rn_polygon_contains(const double *edges, int64_t e0, int64_t e1, double px, double py)
+{
+    bool cross = false;
+    for (int64_t i = e0; i < e1; ++i) {
+        const double *e = edges + i * 4;
+        if (rn_ray_edge(e[0], e[1], e[2], e[3], px, py, cross)) return false;
+    }
+    return cross;
+}
+
+// cell of a point; false = outside the grid (the grid covers every polygon with a margin, so: outside every surface)
+__host__ __device__ inline bool rn_cell_of(const RoadNet &N, double px, double py, int64_t &cell)
+{
+    const double fx = (px - N.x0) * N.inv_cell, fy = (py - N.y0) * N.inv_cell;
+    if (!(fx >= 0.0 && fx < (double)N.nx && fy >= 0.0 && fy < (double)N.ny)) return false;
+    cell = N.cell_base + (int64_t)(int)fy * N.nx + (int)fx;
+    return true;
+}
+
+// the layers of `want` whose union strictly contains the point (one thread)
+__device__ inline uint32_t rn_layers_at(const RoadIndex &R, int net, uint32_t want, double px, double py)
+{
+    if (net < 0) return 0u;
+    int64_t cell;
+    if (!rn_cell_of(R.nets[net], px, py, cell)) return 0u;
+    const uint32_t m = R.cells[cell];
+    uint32_t in = m & 0xffu & want, todo = (m >> 8) & want & ~in;
+    if (todo) {
+        for (uint32_t k = R.cell_off[cell]; k < R.cell_off[cell + 1] && todo; ++k) {
+            const int q = R.cell_poly[k];
+            const uint32_t L = R.poly_layers[q] & todo;
+            if (L && rn_polygon_contains(R.edges, R.poly_edge_off[q], R.poly_edge_off[q + 1], px, py)) {
+                in |= L;
+                todo &= ~L;
+            }
+        }
+    }
+    return in;
+}
+
+// ------------------------------------------------------------------------------------------------
 // RasterizedMapSensor, "entity" layer (sensor/map.py:120-192), SURVEY 8f N2: for the ego of every scenario an
 // nh x nw occupancy grid in the ego's frame (rotated by heading + pi/2): cell = 1 iff the grid point lies strictly inside
 // the bounding box of a present entity (the ego included).  One workgroup per scenario: the boxes' corners (fp64, the
@@ -2245,7 +2362,8 @@ __device__ __forceinline__ double sg_linspace_at(double start, double stop, int 
 }
 
 __global__ __launch_bounds__(256) void raster_kernel(Params p, double width, double height, int nw, int nh,
-                                                     unsigned char *out /*[R][nh][nw]*/)
+                                                     unsigned char *out /*[R][nh][nw] at stride bytes per scenario*/,
+                                                     int64_t stride)
 {
     __shared__ double cor[8][256];
     __shared__ unsigned char pres[256];
@@ -2274,7 +2392,7 @@ __global__ __launch_bounds__(256) void raster_kernel(Params p, double width, dou
     __syncthreads();
     const double ex = ego_pose[0], ey = ego_pose[1], s = ego_pose[2], c = ego_pose[3];
     const bool ego_present = pres[ss.ego] != 0;
-    unsigned char *o = out + (size_t)r * nw * nh;
+    unsigned char *o = out + (size_t)r * stride;
     for (int q = e; q < nw * nh; q += 256) {
         const int i = q / nw, j = q - i * nw;
         const double x0 = sg_linspace_at(-width / 2, width / 2, nw, j), x1 = sg_linspace_at(-height / 2, height / 2, nh, i);
@@ -2293,6 +2411,41 @@ __global__ __launch_bounds__(256) void raster_kernel(Params p, double width, dou
                              : (orient < 0 && c0 < 0 && c1 < 0 && c2 < 0 && c3 < 0);
         }
         o[q] = ego_present ? (unsigned char)hit : 0; // the reference sensor needs state.poses[entity]
+    }
+}
+
+// The road-surface layers of RasterizedMapSensor (sensor/map.py:194-271) on the same grid: one thread per grid point
+// looks its cell up once for all requested layers; out[r][k] for the layers[k] != 0 (the entity layer is raster_kernel's).
+__global__ __launch_bounds__(256) void raster_surface_kernel(Params p, RoadIndex R, double width, double height, int nw, int nh,
+                                                             int n_layers, const int32_t *layers,
+                                                             unsigned char *out /*[R][n_layers][nh][nw]*/)
+{
+    __shared__ double ego_pose[4];
+    __shared__ int ego_present;
+    const int r = blockIdx.x;
+    const ScenStatic &ss = p.sstat[r];
+    if (threadIdx.x == 0) {
+        const uint32_t idx = (uint32_t)r * p.EP + ss.ego;
+        const LanePtr dy(p.dyn + (size_t)(idx >> 6) * ((size_t)p.FROWS * 64), (idx & 63) * 8u);
+        double s, c;
+        sg_sincos(fld(dy, SG_F_POSE + 3) + 3.14159265358979311600e+00 / 2, s, c);
+        ego_pose[0] = fld(dy, SG_F_POSE + 0); ego_pose[1] = fld(dy, SG_F_POSE + 1);
+        ego_pose[2] = s; ego_pose[3] = c;
+        ego_present = fld<uint64_t>(dy, SG_F_PRESENT) != 0;
+    }
+    __syncthreads();
+    const double ex = ego_pose[0], ey = ego_pose[1], s = ego_pose[2], c = ego_pose[3];
+    uint32_t want = 0;
+    for (int k = 0; k < n_layers; ++k) want |= (uint32_t)layers[k];
+    const int net = R.net_of_scen ? R.net_of_scen[r] : -1;
+    unsigned char *o = out + (size_t)r * n_layers * nw * nh;
+    for (int q = threadIdx.x; q < nw * nh; q += 256) {
+        const int i = q / nw, j = q - i * nw;
+        const double x0 = sg_linspace_at(-width / 2, width / 2, nw, j), x1 = sg_linspace_at(-height / 2, height / 2, nh, i);
+        const double px = __builtin_fma(x1, -s, x0 * c) + ex, py = __builtin_fma(x1, c, x0 * s) + ey;
+        const uint32_t in = ego_present ? rn_layers_at(R, net, want, px, py) : 0u;
+        for (int k = 0; k < n_layers; ++k)
+            if (layers[k]) o[(size_t)k * nw * nh + q] = (in & (uint32_t)layers[k]) != 0;
     }
 }
 

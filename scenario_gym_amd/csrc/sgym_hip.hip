@@ -43,6 +43,9 @@ struct sg_handle {
     double *d_tab[2] = {nullptr, nullptr};
     std::vector<hipEvent_t> ev_pool;
     int tab_min = 16, chunk_steps = 1024, overlap = 1; // sg_set_tuning
+    std::vector<void *> road_allocs;                   // sg_set_road_networks
+    sg::RoadIndex road{};                              // host copy of the device pointers (raster kernels take it by value)
+    bool has_road = false;
     int ped_serial = 0;                                // env SG_PED_SERIAL: pedestrian pair loop one pedestrian per lane
     int ctl_slice = 64;                                // steps per control_kernel launch (env SG_CTL_SLICE)
     int n_launches = 0;           // rollout_kernel launches of the last call
@@ -165,6 +168,7 @@ extern "C" int sg_destroy(sg_handle *h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     free_pool(h->static_allocs);
     free_pool(h->state_allocs);
+    free_pool(h->road_allocs);
     if (h->ctl_stream) (void)hipStreamSynchronize(h->ctl_stream);
     if (h->d_actions) (void)hipFree(h->d_actions);
     if (h->d_gon) (void)hipFree(h->d_gon);
@@ -337,6 +341,9 @@ extern "C" int sg_upload(sg_handle *h, const sg_scenarios *sc)
     HIP_TRY(h, hipStreamSynchronize(h->ctl_stream));
     free_pool(h->static_allocs);
     free_pool(h->state_allocs);
+    free_pool(h->road_allocs); // the networks belong to a batch (net_of_scenario)
+    h->has_road = false;
+    h->road = sg::RoadIndex{};
     for (int b = 0; b < 2; ++b) { // the controller table geometry depends on the batch
         if (h->d_tab[b]) HIP_TRY(h, hipFree(h->d_tab[b]));
         h->d_tab[b] = nullptr;
@@ -775,6 +782,216 @@ extern "C" int sg_future_collision(sg_handle *h, double horizon, int32_t n_sampl
     return SG_OK;
 }
 
+// ---- road surfaces -------------------------------------------------------------------------------
+// Index of one network: a uniform grid; per polygon the cells its edges touch (boxes grown by a margin far above the
+// rounding of the device's cell lookup) become candidates of that polygon, the other cells of its bounding box are
+// wholly inside or wholly outside -- decided with the exact test at the cell centre, once per run of untouched cells.
+namespace {
+struct RoadBuild {
+    std::vector<sg::RoadNet> nets;
+    std::vector<uint16_t> cells;
+    std::vector<uint32_t> cell_off;
+    std::vector<int32_t> cell_poly;
+    std::vector<double> edges;
+    std::vector<int64_t> poly_edge_off;
+    std::vector<uint32_t> poly_layers;
+};
+
+void build_road_network(const sg_road_networks *in, int n, RoadBuild &B)
+{
+    const int64_t q0 = in->poly_off[n], q1 = in->poly_off[n + 1];
+    double lo[2] = {INFINITY, INFINITY}, hi[2] = {-INFINITY, -INFINITY};
+    for (int64_t q = q0; q < q1; ++q) {
+        for (int64_t r = in->ring_off[q]; r < in->ring_off[q + 1]; ++r) {
+            const int64_t a = in->vert_off[r], b = in->vert_off[r + 1];
+            for (int64_t i = a; i < b; ++i) {
+                const int64_t j = i + 1 < b ? i + 1 : a;
+                const double *v = in->verts + 2 * i, *w = in->verts + 2 * j;
+                B.edges.insert(B.edges.end(), {v[0], v[1], w[0], w[1]});
+                for (int c = 0; c < 2; ++c) { lo[c] = std::min(lo[c], v[c]); hi[c] = std::max(hi[c], v[c]); }
+            }
+        }
+        B.poly_edge_off.push_back((int64_t)B.edges.size() / 4);
+        B.poly_layers.push_back(in->layers[q]);
+    }
+    sg::RoadNet N{};
+    N.cell_base = (int64_t)B.cells.size();
+    if (!(lo[0] <= hi[0])) { // no geometry: an empty 1 x 1 grid
+        N.x0 = N.y0 = 0.0; N.inv_cell = 1.0; N.nx = N.ny = 1;
+        B.nets.push_back(N);
+        B.cells.push_back(0);
+        B.cell_off.push_back((uint32_t)B.cell_poly.size());
+        return;
+    }
+    double c = 1.0; // cell side: 1 m unless the network is so large that this would take more than 2^21 cells
+    while (((hi[0] - lo[0]) / c + 4) * ((hi[1] - lo[1]) / c + 4) > 2097152.0) c *= 2;
+    const double eps = 1e-6; // >> rounding of (p - x0) * inv_cell for coordinates below 1e9 cells
+    N.x0 = std::floor(lo[0] / c) * c - c;
+    N.y0 = std::floor(lo[1] / c) * c - c;
+    N.inv_cell = 1.0 / c;
+    N.nx = (int32_t)std::ceil((hi[0] - N.x0) / c) + 2;
+    N.ny = (int32_t)std::ceil((hi[1] - N.y0) / c) + 2;
+    const size_t ncell = (size_t)N.nx * N.ny;
+    B.cells.resize((size_t)N.cell_base + ncell, 0);
+    uint16_t *cells = B.cells.data() + N.cell_base;
+    std::vector<std::pair<uint32_t, int32_t>> pairs; // (local cell, global polygon)
+    auto cix = [&](double x, double x0, int nmax) { return std::max(0, std::min(nmax - 1, (int)std::floor((x - x0) / c))); };
+    std::vector<uint8_t> touched;
+    const int64_t gq0 = (int64_t)B.poly_layers.size() - (q1 - q0);
+    for (int64_t q = q0; q < q1; ++q) {
+        const int64_t gq = gq0 + (q - q0);
+        const int64_t e0 = B.poly_edge_off[gq], e1 = B.poly_edge_off[gq + 1];
+        const uint32_t L = B.poly_layers[gq] & 0xffu;
+        if (e1 <= e0 || !L) continue;
+        double plo[2] = {INFINITY, INFINITY}, phi[2] = {-INFINITY, -INFINITY};
+        for (int64_t i = e0; i < e1; ++i)
+            for (int c2 = 0; c2 < 2; ++c2) { plo[c2] = std::min(plo[c2], B.edges[4 * i + c2]); phi[c2] = std::max(phi[c2], B.edges[4 * i + c2]); }
+        const int ix0 = cix(plo[0] - eps, N.x0, N.nx), ix1 = cix(phi[0] + eps, N.x0, N.nx);
+        const int iy0 = cix(plo[1] - eps, N.y0, N.ny), iy1 = cix(phi[1] + eps, N.y0, N.ny);
+        const int w = ix1 - ix0 + 1, hgt = iy1 - iy0 + 1;
+        touched.assign((size_t)w * hgt, 0);
+        for (int64_t i = e0; i < e1; ++i) {
+            const double ax = B.edges[4 * i], ay = B.edges[4 * i + 1], bx = B.edges[4 * i + 2], by = B.edges[4 * i + 3];
+            const int jx0 = cix(std::min(ax, bx) - eps, N.x0, N.nx), jx1 = cix(std::max(ax, bx) + eps, N.x0, N.nx);
+            const int jy0 = cix(std::min(ay, by) - eps, N.y0, N.ny), jy1 = cix(std::max(ay, by) + eps, N.y0, N.ny);
+            for (int iy = jy0; iy <= jy1; ++iy)
+                for (int ix = jx0; ix <= jx1; ++ix) {
+                    // the grown cell box and the segment overlap in x and in y (by the ranges above); they are disjoint
+                    // iff the box lies strictly on one side of the segment's line
+                    const double bx0 = N.x0 + ix * c - eps, bx1 = N.x0 + (ix + 1) * c + eps;
+                    const double by0 = N.y0 + iy * c - eps, by1 = N.y0 + (iy + 1) * c + eps;
+                    const double dx = bx - ax, dy = by - ay;
+                    const double d0 = dx * (by0 - ay) - dy * (bx0 - ax), d1 = dx * (by0 - ay) - dy * (bx1 - ax);
+                    const double d2 = dx * (by1 - ay) - dy * (bx0 - ax), d3 = dx * (by1 - ay) - dy * (bx1 - ax);
+                    const double tol = 1e-9 * (std::fabs(dx) + std::fabs(dy)) * (c + std::fabs(bx0 - ax) + std::fabs(by0 - ay) + 1.0);
+                    const double mn = std::min(std::min(d0, d1), std::min(d2, d3)), mx = std::max(std::max(d0, d1), std::max(d2, d3));
+                    if (mn > tol || mx < -tol) continue;
+                    touched[(size_t)(iy - iy0) * w + (ix - ix0)] = 1;
+                }
+        }
+        for (int iy = iy0; iy <= iy1; ++iy) {
+            bool known = false, inside = false;
+            for (int ix = ix0; ix <= ix1; ++ix) {
+                const uint32_t cell = (uint32_t)((size_t)iy * N.nx + ix);
+                if (touched[(size_t)(iy - iy0) * w + (ix - ix0)]) {
+                    cells[cell] |= (uint16_t)(L << 8);
+                    pairs.emplace_back(cell, (int32_t)gq);
+                    known = false;
+                } else {
+                    if (!known) {
+                        inside = sg::rn_polygon_contains(B.edges.data(), e0, e1, N.x0 + (ix + 0.5) * c, N.y0 + (iy + 0.5) * c);
+                        known = true;
+                    }
+                    if (inside) cells[cell] |= (uint16_t)L;
+                }
+            }
+        }
+    }
+    std::sort(pairs.begin(), pairs.end());
+    // CSR (global over all networks: cell_off has one entry per cell + a final one appended by the caller)
+    size_t k = 0;
+    for (size_t cell = 0; cell < ncell; ++cell) {
+        B.cell_off.push_back((uint32_t)B.cell_poly.size());
+        while (k < pairs.size() && pairs[k].first == cell) B.cell_poly.push_back(pairs[k++].second);
+    }
+    B.nets.push_back(N);
+}
+} // namespace
+
+extern "C" int sg_set_road_networks(sg_handle *h, const sg_road_networks *in)
+{
+    if (!h || !in) return h ? fail(h, SG_ERR_INVALID, "sg_set_road_networks: null argument") : SG_ERR_INVALID;
+    if (!h->uploaded) return fail(h, SG_ERR_STATE, "sg_set_road_networks: no scenarios uploaded");
+    if (in->n_networks < 0 || !in->net_of_scenario || (in->n_networks > 0 && (!in->poly_off || !in->ring_off || !in->vert_off || !in->layers)))
+        return fail(h, SG_ERR_INVALID, "sg_set_road_networks: null array");
+    for (int r = 0; r < h->R; ++r)
+        if (in->net_of_scenario[r] < -1 || in->net_of_scenario[r] >= in->n_networks)
+            return fail(h, SG_ERR_INVALID, "sg_set_road_networks: net_of_scenario[%d]=%d out of range", r, in->net_of_scenario[r]);
+    const int64_t n_poly = in->n_networks ? in->poly_off[in->n_networks] : 0;
+    for (int n = 0; n < in->n_networks; ++n)
+        if (in->poly_off[n + 1] < in->poly_off[n] || in->poly_off[0] != 0) return fail(h, SG_ERR_INVALID, "sg_set_road_networks: poly_off not monotone");
+    for (int64_t q = 0; q < n_poly; ++q) {
+        if (in->ring_off[q + 1] < in->ring_off[q] || in->ring_off[0] != 0) return fail(h, SG_ERR_INVALID, "sg_set_road_networks: ring_off not monotone");
+        for (int64_t r = in->ring_off[q]; r < in->ring_off[q + 1]; ++r)
+            if (in->vert_off[r + 1] < in->vert_off[r] || in->vert_off[0] != 0) return fail(h, SG_ERR_INVALID, "sg_set_road_networks: vert_off not monotone");
+    }
+    const int64_t n_vert = n_poly ? in->vert_off[in->ring_off[n_poly]] : 0;
+    if (n_vert > 0 && !in->verts) return fail(h, SG_ERR_INVALID, "sg_set_road_networks: null verts");
+    for (int64_t i = 0; i < 2 * n_vert; ++i)
+        if (!std::isfinite(in->verts[i])) return fail(h, SG_ERR_INVALID, "sg_set_road_networks: vertex %lld is not finite", (long long)(i / 2));
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    free_pool(h->road_allocs);
+    h->has_road = false;
+    h->p.road = nullptr;
+    RoadBuild B;
+    B.poly_edge_off.push_back(0);
+    for (int n = 0; n < in->n_networks; ++n) build_road_network(in, n, B);
+    B.cell_off.push_back((uint32_t)B.cell_poly.size());
+    if (B.cell_poly.empty()) B.cell_poly.push_back(0);
+    if (B.edges.empty()) B.edges.assign(4, 0.0);
+    if (B.nets.empty()) { B.nets.push_back(sg::RoadNet{0.0, 0.0, 1.0, 1, 1, 0}); B.cells.push_back(0); B.cell_off.insert(B.cell_off.begin(), 0u); }
+    std::vector<int32_t> nos(in->net_of_scenario, in->net_of_scenario + h->R);
+    auto &A = h->road_allocs;
+    sg::RoadIndex R{};
+    int rc = 0;
+    if ((rc = dev_upload(h, A, &R.nets, B.nets))) return rc;
+    if ((rc = dev_upload(h, A, &R.net_of_scen, nos))) return rc;
+    if ((rc = dev_upload(h, A, &R.cells, B.cells))) return rc;
+    if ((rc = dev_upload(h, A, &R.cell_off, B.cell_off))) return rc;
+    if ((rc = dev_upload(h, A, &R.cell_poly, B.cell_poly))) return rc;
+    if ((rc = dev_upload(h, A, &R.edges, B.edges))) return rc;
+    if ((rc = dev_upload(h, A, &R.poly_edge_off, B.poly_edge_off))) return rc;
+    if ((rc = dev_upload(h, A, &R.poly_layers, B.poly_layers))) return rc;
+    R.n_nets = in->n_networks;
+    std::vector<sg::RoadIndex> one(1, R);
+    const sg::RoadIndex *dR = nullptr;
+    if ((rc = dev_upload(h, A, &dR, one))) return rc;
+    HIP_TRY(h, hipStreamSynchronize(h->stream)); // host vectors go out of scope
+    h->road = R;
+    h->p.road = dR;
+    h->has_road = true;
+    return SG_OK;
+}
+
+extern "C" int sg_raster_map(sg_handle *h, double width, double height, int32_t nw, int32_t nh, int32_t n_layers,
+                             const int32_t *layers, uint8_t *out)
+{
+    if (!h || !out || !layers || n_layers < 1 || nw < 1 || nh < 1 || !(width >= 0.0) || !(height >= 0.0))
+        return h ? fail(h, SG_ERR_INVALID, "sg_raster_map: bad argument") : SG_ERR_INVALID;
+    if (!h->uploaded) return fail(h, SG_ERR_STATE, "sg_raster_map: no scenarios uploaded");
+    bool any_surface = false;
+    for (int k = 0; k < n_layers; ++k) {
+        const uint32_t L = (uint32_t)layers[k];
+        if (layers[k] < 0 || L > 255u || (L & (L - 1))) return fail(h, SG_ERR_INVALID, "sg_raster_map: layers[%d]=%d is not 0 or one SG_LAYER_* bit", k, layers[k]);
+        any_surface = any_surface || L != 0;
+    }
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    const size_t plane = (size_t)nw * nh, bytes = (size_t)h->R * n_layers * plane;
+    unsigned char *d = nullptr;
+    int32_t *dl = nullptr;
+    HIP_TRY(h, hipMalloc((void **)&d, bytes));
+    hipError_t e = hipMalloc((void **)&dl, (size_t)n_layers * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMemcpyAsync(dl, layers, (size_t)n_layers * sizeof(int32_t), hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess && any_surface && !h->has_road) e = hipMemsetAsync(d, 0, bytes, h->stream); // no networks: empty surfaces
+    for (int k = 0; k < n_layers && e == hipSuccess; ++k)
+        if (layers[k] == 0) {
+            sg::raster_kernel<<<dim3((unsigned)h->R), dim3(256), 0, h->stream>>>(h->p, width, height, nw, nh, d + (size_t)k * plane,
+                                                                               (int64_t)(n_layers * plane));
+            e = hipGetLastError();
+        }
+    if (e == hipSuccess && any_surface && h->has_road) {
+        sg::raster_surface_kernel<<<dim3((unsigned)h->R), dim3(256), 0, h->stream>>>(h->p, h->road, width, height, nw, nh, n_layers, dl, d);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d, bytes, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    (void)hipFree(d);
+    if (dl) (void)hipFree(dl);
+    if (e != hipSuccess) return fail(h, SG_ERR_HIP, "sg_raster_map: %s", hipGetErrorString(e));
+    return SG_OK;
+}
+
 extern "C" int sg_raster_entities(sg_handle *h, double width, double height, int32_t nw, int32_t nh, uint8_t *out)
 {
     if (!h || !out || nw < 1 || nh < 1 || !(width >= 0.0) || !(height >= 0.0))
@@ -784,7 +1001,7 @@ extern "C" int sg_raster_entities(sg_handle *h, double width, double height, int
     const size_t bytes = (size_t)h->R * nw * nh;
     unsigned char *d = nullptr;
     HIP_TRY(h, hipMalloc((void **)&d, bytes));
-    sg::raster_kernel<<<dim3((unsigned)h->R), dim3(256), 0, h->stream>>>(h->p, width, height, nw, nh, d);
+    sg::raster_kernel<<<dim3((unsigned)h->R), dim3(256), 0, h->stream>>>(h->p, width, height, nw, nh, d, (int64_t)nw * nh);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(out, d, bytes, hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);

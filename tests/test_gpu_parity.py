@@ -964,3 +964,99 @@ def test_pedestrian_pair_balancing_is_invisible(sga, oracle, monkeypatch, E, sid
     for r in range(2):
         o = _oracle_one(oracle, packed, r, 1 / 30, steps)
         assert bits_equal(pb[: o["n_steps"] + 1, r], o["poses"]) and bits_equal(sb["force"][r], o["extra"][-1, :, 2:]), r
+
+
+# ---------------------------------------------------------------- road surfaces
+ROAD_BITS = dict(driveable_surface=1, road=2, intersection=4, lane=8, walkable_surface=16, pavement=32, crossing=64)
+
+
+def _road_arrays(g, net):
+    return {k: g[f"net/{net}/{k}"] for k in ("ring_off", "vert_off", "verts", "layers")}
+
+
+def test_raster_map_layers_match_reference_and_oracle(sga, oracle):
+    """sg_raster_map with all eight RasterizedMapSensor layers: the four scenarios of roads.npz (one per shipped road
+    network) as ONE batch sharing/alternating networks, at every recorded frame of the reference's rollouts and on both
+    grids, equal the reference's maps cell for cell."""
+    from scenario_gym_amd.packing import default_kinds, pack_arrays
+
+    g = load_golden("roads")
+    names = [str(n) for n in g["scenarios"]]
+    scs = []
+    for n in names:
+        s = scenario_arrays(g, f"{n}/scenario")
+        s["kind"] = default_kinds(len(s["bbox"]), s["ego"])
+        scs.append(s)
+    packed = pack_arrays(scs)
+    nets = sorted({str(g[f"{n}/network"]) for n in names})
+    eng = sga.RolloutEngine(packed.n_scenarios, packed.n_entities, timestep=0.1)
+    eng.upload(packed)
+    eng.set_road_networks([_road_arrays(g, k) for k in nets], [nets.index(str(g[f"{n}/network"])) for n in names])
+    layers = [0] + [ROAD_BITS[str(x)] for x in g["layers"][1:]]
+    frames = sorted({int(s) for n in names for s in g[f"{n}/map_steps"]})
+    done, cells = 0, 0
+    for f in frames:
+        eng.step(f - done)
+        done = f
+        for c, (w, h, k) in enumerate(g["raster_cfg"]):
+            got = eng.raster_map(layers, w, h, int(k), int(k))
+            for r, n in enumerate(names):
+                steps = list(g[f"{n}/map_steps"])
+                if f in steps:
+                    want = g[f"{n}/map{c}"][steps.index(f)].astype(bool)
+                    assert np.array_equal(got[r], want), (n, f, c, int((got[r] != want).sum()))
+                    cells += want.size
+    eng.close()
+    assert cells > 500000
+
+
+def test_surface_raster_on_synthetic_polygons_matches_oracle(sga, oracle):
+    """Random star-shaped and ring-shaped (with a hole) polygons, many networks, egos placed ON vertices and edges so
+    that grid points hit boundaries exactly: device = oracle on every cell, every layer; scenarios without a network
+    give empty surfaces."""
+    from scenario_gym_amd import synthetic
+
+    rng = np.random.default_rng(17)
+    R, E = 64, 4
+    packed = synthetic.make_batch(R, E, n_steps=50, extent=5.0)
+    nets = []
+    for n in range(5):
+        rings, ring_off, layers = [], [0], []
+        for q in range(12):
+            c = rng.uniform(-40, 40, 2)
+            m = int(rng.integers(3, 40))
+            ang = np.sort(rng.uniform(0, 2 * np.pi, m))
+            rad = rng.uniform(4, 25) * rng.uniform(0.4, 1.0, m)
+            rings.append(np.round(c + rad[:, None] * np.stack([np.cos(ang), np.sin(ang)], 1), 2))  # 1 cm lattice
+            if q % 3 == 0:  # a hole well inside
+                rings.append(np.round(c + 0.2 * rad.min() * np.stack([np.cos(ang[::-1]), np.sin(ang[::-1])], 1), 2))
+            ring_off.append(len(rings))
+            layers.append(int(rng.integers(1, 128)))
+        vert_off = np.concatenate([[0], np.cumsum([len(r) for r in rings])])
+        nets.append(dict(ring_off=np.array(ring_off), vert_off=vert_off, verts=np.concatenate(rings), layers=np.array(layers)))
+    net_of = rng.integers(-1, len(nets), R)
+    # egos on the 1 cm lattice, heading 0 or pi/2, a 1 cm grid pitch: grid points fall on vertices and axis-parallel edges
+    for r in range(R):
+        a, b = packed.knot_off[r * E], packed.knot_off[r * E + 1]  # the ego's knots
+        xy = np.round(rng.uniform(-30, 30, 2), 2)
+        if r % 3 == 0 and net_of[r] >= 0:  # some egos exactly on a polygon vertex of their network
+            v = nets[net_of[r]]["verts"]
+            xy = v[rng.integers(0, len(v))]
+        packed.knots[a:b, 1:3] = xy
+        packed.knots[a:b, 4] = rng.choice([0.0, np.pi / 2])
+    eng = sga.RolloutEngine(R, E)
+    eng.upload(packed)
+    eng.set_road_networks(nets, net_of)
+    st = eng.state()
+    layers = [1, 0, 2, 4, 8, 16, 32, 64]
+    on = 0
+    for (w, h, k) in ((0.4, 0.4, 41), (60.0, 60.0, 25)):
+        got = eng.raster_map(layers, w, h, k, k)
+        for r in range(R):
+            net = None if net_of[r] < 0 else nets[net_of[r]]
+            want = oracle.raster_map(st["poses"][r], packed.bbox[r * E:(r + 1) * E], 0, net, layers, w, h, k, k)
+            assert np.array_equal(got[r], want), (r, w, int((got[r] != want).sum()))
+            on += int(want[0].sum())
+        assert not got[net_of < 0][:, [0, 2, 3, 4, 5, 6, 7]].any()
+    eng.close()
+    assert on > 1000

@@ -306,8 +306,9 @@ def test_terminal_condition_names():
     from scenario_gym_amd.engine import terminal_mask
 
     assert terminal_mask(None) == 1 and terminal_mask(["max_length", "collision", "ego_collision"]) == 7
+    assert terminal_mask(["ego_off_road", "max_length"]) == 9
     with pytest.raises(ValueError):
-        terminal_mask(["ego_off_road"])
+        terminal_mask(["ego_in_the_air"])
 
 
 def test_scenario_translate_and_reset_start():
