@@ -88,16 +88,17 @@ class FutureCollisionDetector(Sensor):
 
 
 class RasterizedMapSensor(Sensor):
-    """sensor/map.py:26-135 with the "entity" layer (:176-192): an n x n occupancy grid of bounding boxes in the
-    entity's frame, computed on the device for the ego of every scenario (sg_raster_entities).  The road-network layers
-    (driveable_surface, road, lane, ...) need the road polygons and are not available."""
+    """sensor/map.py:26-271: an n x n grid in the entity's frame with one plane per layer -- the bounding boxes of the
+    present entities ("entity") and the unions of road-network polygons ("driveable_surface", "road", "intersection",
+    "lane", "walkable_surface", "pavement", "crossing") -- computed on the device for the ego of every scenario
+    (sg_raster_map).  Default layers as in the reference: entity + driveable_surface."""
 
-    _all_layers = ["entity"]
+    _all_layers = ["entity", "driveable_surface", "road", "intersection", "lane", "walkable_surface", "pavement", "crossing"]
 
     def __init__(self, entity: Entity, layers=None, height: float = 20.0, width: float = 20.0, freq: Optional[float] = 1.0,
                  n: Optional[int] = None, channels_first: bool = False):
         super().__init__(entity)
-        self.layers = ["entity"] if layers is None else list(layers)
+        self.layers = ["entity", "driveable_surface"] if layers is None else list(layers)
         for layer in self.layers:
             if layer not in self._all_layers:
                 raise NotImplementedError(f"Layer {layer} does not have a get and/or a prepare method.")
@@ -115,7 +116,7 @@ class RasterizedMapSensor(Sensor):
     def _step(self, state):
         if state.scenario.ego is not self.entity:
             raise NotImplementedError("the device raster is evaluated for the ego of each scenario")
-        m = np.stack([state.entity_raster(self.width, self.height, self.nw, self.nh) for _ in self.layers])
+        m = state.raster_map(self.layers, self.width, self.height, self.nw, self.nh)
         return tuple(state.get_entity_data(self.entity)) + (m if self.channels_first else m.transpose(1, 2, 0),)
 
 

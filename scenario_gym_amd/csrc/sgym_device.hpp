@@ -1365,6 +1365,107 @@ __global__ void build_grid_kernel(Params p, const int32_t *row_scen /*[totalN]*/
 }
 
 // ------------------------------------------------------------------------------------------------
+// Road surfaces: point strictly inside the union of the polygons of a layer.
+// shapely contains(Point) (state.py:401-407, sensor/map.py:198-271) = JTS/GEOS RayCrossingCounter: the ray towards +x
+// crosses the polygon's rings an odd number of times; a point ON a ring is not contained.  The orientation sign is
+// exact: fp64 determinant with Shewchuk's stage-A error bound, else the six products of the expanded determinant as
+// two-term expansions, summed exactly (grow-expansion); the sign of the sum is the sign of its largest component.
+// Host and device share these functions (the host uses them to classify the grid cells, sgym_hip.hip).
+// ------------------------------------------------------------------------------------------------
+__host__ __device__ inline void rn_two_sum(double a, double b, double &s, double &e)
+{
+    const double x = a + b, bb = x - a;
+    s = x;
+    e = (a - (x - bb)) + (b - bb);
+}
+
+__host__ __device__ __attribute__((noinline)) inline int rn_orient_exact(double ax, double ay, double bx, double by, double px, double py)
+{
+    // (ax - px)(by - py) - (ay - py)(bx - px) = ax*by - ax*py - px*by - ay*bx + ay*px + py*bx
+    const double fa[6] = {ax, -ax, -px, -ay, ay, py}, fb[6] = {by, py, by, bx, px, bx};
+    double e[12];
+    int n = 0;
+    for (int k = 0; k < 6; ++k) {
+        const double hi = fa[k] * fb[k], lo = __builtin_fma(fa[k], fb[k], -hi);
+        for (int u = 0; u < 2; ++u) {
+            double q = u ? hi : lo;
+            for (int i = 0; i < n; ++i) rn_two_sum(q, e[i], q, e[i]);
+            e[n++] = q;
+        }
+    }
+    for (int i = n - 1; i >= 0; --i)
+        if (e[i] != 0.0) return e[i] > 0 ? 1 : -1;
+    return 0;
+}
+
+__host__ __device__ inline int rn_orient_sign(double ax, double ay, double bx, double by, double px, double py)
+{
+    const double dl = (ax - px) * (by - py), dr = (ay - py) * (bx - px), det = dl - dr;
+    const double bound = 1e-15 * (__builtin_fabs(dl) + __builtin_fabs(dr));
+    if (det > bound) return 1;
+    if (det < -bound) return -1;
+    return rn_orient_exact(ax, ay, bx, by, px, py);
+}
+
+// RayCrossingCounter.countSegment: toggles `cross` on a crossing, returns true if the point is ON the edge
+__host__ __device__ inline bool rn_ray_edge(double x1, double y1, double x2, double y2, double px, double py, bool &cross)
+{
+    if (x1 < px && x2 < px) return false;
+    if (px == x2 && py == y2) return true;
+    if (y1 == py && y2 == py) {
+        const double lo = x1 < x2 ? x1 : x2, hi = x1 < x2 ? x2 : x1;
+        return px >= lo && px <= hi;
+    }
+    if ((y1 > py && y2 <= py) || (y2 > py && y1 <= py)) {
+        int o = rn_orient_sign(x1, y1, x2, y2, px, py);
+        if (o == 0) return true;
+        if (y2 < y1) o = -o;
+        if (o > 0) cross = !cross;
+    }
+    return false;
+}
+
+__host__ __device__ inline bool rn_polygon_contains(const double *edges, int64_t e0, int64_t e1, double px, double py)
+{
+    bool cross = false;
+    for (int64_t i = e0; i < e1; ++i) {
+        const double *e = edges + i * 4;
+        if (rn_ray_edge(e[0], e[1], e[2], e[3], px, py, cross)) return false;
+    }
+    return cross;
+}
+
+// cell of a point; false = outside the grid (the grid covers every polygon with a margin, so: outside every surface)
+__host__ __device__ inline bool rn_cell_of(const RoadNet &N, double px, double py, int64_t &cell)
+{
+    const double fx = (px - N.x0) * N.inv_cell, fy = (py - N.y0) * N.inv_cell;
+    if (!(fx >= 0.0 && fx < (double)N.nx && fy >= 0.0 && fy < (double)N.ny)) return false;
+    cell = N.cell_base + (int64_t)(int)fy * N.nx + (int)fx;
+    return true;
+}
+
+// the layers of `want` whose union strictly contains the point (one thread)
+__device__ inline uint32_t rn_layers_at(const RoadIndex &R, int net, uint32_t want, double px, double py)
+{
+    if (net < 0) return 0u;
+    int64_t cell;
+    if (!rn_cell_of(R.nets[net], px, py, cell)) return 0u;
+    const uint32_t m = R.cells[cell];
+    uint32_t in = m & 0xffu & want, todo = (m >> 8) & want & ~in;
+    if (todo) {
+        for (uint32_t k = R.cell_off[cell]; k < R.cell_off[cell + 1] && todo; ++k) {
+            const int q = R.cell_poly[k];
+            const uint32_t L = R.poly_layers[q] & todo;
+            if (L && rn_polygon_contains(R.edges, R.poly_edge_off[q], R.poly_edge_off[q + 1], px, py)) {
+                in |= L;
+                todo &= ~L;
+            }
+        }
+    }
+    return in;
+}
+
+// ------------------------------------------------------------------------------------------------
 // The rollout kernel: ScenarioGym.reset_scenario / step / rollout (scenario_gym.py:217-267).
 //   WV == 1: one 64-lane workgroup carries 64/G scenarios of up to G entities each (tiles of G lanes)
 //   WV  > 1: one workgroup of WV wavefronts carries ONE scenario of up to 64*WV entities
@@ -1402,7 +1503,9 @@ __device__ __forceinline__ Table lane_table(const Params &p, int kind, const Sce
 // to retire.
 // HAST (TAB only): the batch has controlled lanes, i.e. there is a table to replay; without it the table code is
 // compiled out (batches of replay entities only: the C2 shape).
-template <int G, int WV, bool PED, bool TAB, bool HAST>
+// ROAD: the ego_off_road terminal condition is compiled in (its own entry point, rollout_kernel_road: the other
+// variants keep their register budgets).
+template <int G, int WV, bool PED, bool TAB, bool HAST, bool ROAD = false>
 __device__ __forceinline__ void rollout_body(
     const Params &p, double timestep, int n_steps, int do_reset, int force, const double *actions /*[n][R][2]*/,
     const double *tab /*controller table planes*/)
@@ -1912,6 +2015,23 @@ __device__ __forceinline__ void rollout_body(
             if ((p.term_mask & SG_TERM_COLLISION) && any_tile) ndone = 1;
             if ((p.term_mask & SG_TERM_EGO_COLLISION) && ego0) ndone = 1;
         }
+        if (ROAD && (p.term_mask & SG_TERM_EGO_OFF_ROAD)) {
+            // TERMINAL_CONDITIONS["ego_off_road"], state.py:401-407: entities[0] (slot 0 of the tile, not Scenario.ego)
+            // absent, or its reference point not strictly inside the driveable surface.  Slot 0 looks its cell up; only
+            // cells crossed by a polygon boundary run the exact test.
+            bool off = false;
+            if (sl == tile0 && in_range) {
+                off = true;
+                if (present && p.road) {
+                    const RoadIndex RI = *p.road;
+                    off = !(rn_layers_at(RI, RI.net_of_scen[r], SG_LAYER_DRIVEABLE, pose[0], pose[1]) & SG_LAYER_DRIVEABLE);
+                }
+            }
+            bool off_tile;
+            if (WV == 1) off_tile = (__ballot(off) >> tile0) & 1;
+            else off_tile = __syncthreads_or(off);
+            if (off_tile) ndone = 1;
+        }
         if (run) done = ndone;
 
         // ---- CollisionMetric._step, metrics/collision.py:70-75 (ego lane only) ----
@@ -1991,6 +2111,14 @@ __global__ __launch_bounds__(64 * WV, PED ? SG_WAVES_PER_SIMD_PED : (TAB ? SG_WA
 {
     // one wavefront per tile: this entry point serves the batches WITHOUT controlled lanes (rollout_kernel_tab the others)
     rollout_body<G, WV, PED, TAB, (TAB && WV > 1)>(p, timestep, n_steps, do_reset, force, actions, tab);
+}
+
+// terminal_conditions with "ego_off_road": controllers in the kernel, road index lookups for slot 0
+template <int G, int WV>
+__global__ __launch_bounds__(64 * WV, 1) void rollout_kernel_road(
+    Params p, double timestep, int n_steps, int do_reset, int force, const double *actions, const double *tab)
+{
+    rollout_body<G, WV, false, false, false, true>(p, timestep, n_steps, do_reset, force, actions, tab);
 }
 
 // The table variant with one wavefront per tile (C2 / C3 shapes) under a 192-VGPR cap: two of its wavefronts and one of
@@ -2244,107 +2372,6 @@ __global__ __launch_bounds__(256) void future_kernel(Params p, double horizon, i
     }
     const int any = __syncthreads_or(hit);
     if (e == 0) out[r] = (unsigned char)(any != 0);
-}
-
-// ------------------------------------------------------------------------------------------------
-// Road surfaces: point strictly inside the union of the polygons of a layer.
-// shapely contains(Point) (state.py:401-407, sensor/map.py:198-271) = JTS/GEOS RayCrossingCounter: the ray towards +x
-// crosses the polygon's rings an odd number of times; a point ON a ring is not contained.  The orientation sign is
-// exact: fp64 determinant with Shewchuk's stage-A error bound, else the six products of the expanded determinant as
-// two-term expansions, summed exactly (grow-expansion); the sign of the sum is the sign of its largest component.
-// Host and device share these functions (the host uses them to classify the grid cells, sgym_hip.hip).
-// ------------------------------------------------------------------------------------------------
-__host__ __device__ inline void rn_two_sum(double a, double b, double &s, double &e)
-{
-    const double x = a + b, bb = x - a;
-    s = x;
-    e = (a - (x - bb)) + (b - bb);
-}
-
-__host__ __device__ __attribute__((noinline)) inline int rn_orient_exact(double ax, double ay, double bx, double by, double px, double py)
-{
-    // (ax - px)(by - py) - (ay - py)(bx - px) = ax*by - ax*py - px*by - ay*bx + ay*px + py*bx
-    const double fa[6] = {ax, -ax, -px, -ay, ay, py}, fb[6] = {by, py, by, bx, px, bx};
-    double e[12];
-    int n = 0;
-    for (int k = 0; k < 6; ++k) {
-        const double hi = fa[k] * fb[k], lo = __builtin_fma(fa[k], fb[k], -hi);
-        for (int u = 0; u < 2; ++u) {
-            double q = u ? hi : lo;
-            for (int i = 0; i < n; ++i) rn_two_sum(q, e[i], q, e[i]);
-            e[n++] = q;
-        }
-    }
-    for (int i = n - 1; i >= 0; --i)
-        if (e[i] != 0.0) return e[i] > 0 ? 1 : -1;
-    return 0;
-}
-
-__host__ __device__ inline int rn_orient_sign(double ax, double ay, double bx, double by, double px, double py)
-{
-    const double dl = (ax - px) * (by - py), dr = (ay - py) * (bx - px), det = dl - dr;
-    const double bound = 1e-15 * (__builtin_fabs(dl) + __builtin_fabs(dr));
-    if (det > bound) return 1;
-    if (det < -bound) return -1;
-    return rn_orient_exact(ax, ay, bx, by, px, py);
-}
-
-// RayCrossingCounter.countSegment: toggles `cross` on a crossing, returns true if the point is ON the edge
-__host__ __device__ inline bool rn_ray_edge(double x1, double y1, double x2, double y2, double px, double py, bool &cross)
-{
-    if (x1 < px && x2 < px) return false;
-    if (px == x2 && py == y2) return true;
-    if (y1 == py && y2 == py) {
-        const double lo = x1 < x2 ? x1 : x2, hi = x1 < x2 ? x2 : x1;
-        return px >= lo && px <= hi;
-    }
-    if ((y1 > py && y2 <= py) || (y2 > py && y1 <= py)) {
-        int o = rn_orient_sign(x1, y1, x2, y2, px, py);
-        if (o == 0) return true;
-        if (y2 < y1) o = -o;
-        if (o > 0) cross = !cross;
-    }
-    return false;
-}
-
-__host__ __device__ inline bool rn_polygon_contains(const double *edges, int64_t e0, int64_t e1, double px, double py)
-{
-    bool cross = false;
-    for (int64_t i = e0; i < e1; ++i) {
-        const double *e = edges + i * 4;
-        if (rn_ray_edge(e[0], e[1], e[2], e[3], px, py, cross)) return false;
-    }
-    return cross;
-}
-
-// cell of a point; false = outside the grid (the grid covers every polygon with a margin, so: outside every surface)
-__host__ __device__ inline bool rn_cell_of(const RoadNet &N, double px, double py, int64_t &cell)
-{
-    const double fx = (px - N.x0) * N.inv_cell, fy = (py - N.y0) * N.inv_cell;
-    if (!(fx >= 0.0 && fx < (double)N.nx && fy >= 0.0 && fy < (double)N.ny)) return false;
-    cell = N.cell_base + (int64_t)(int)fy * N.nx + (int)fx;
-    return true;
-}
-
-// the layers of `want` whose union strictly contains the point (one thread)
-__device__ inline uint32_t rn_layers_at(const RoadIndex &R, int net, uint32_t want, double px, double py)
-{
-    if (net < 0) return 0u;
-    int64_t cell;
-    if (!rn_cell_of(R.nets[net], px, py, cell)) return 0u;
-    const uint32_t m = R.cells[cell];
-    uint32_t in = m & 0xffu & want, todo = (m >> 8) & want & ~in;
-    if (todo) {
-        for (uint32_t k = R.cell_off[cell]; k < R.cell_off[cell + 1] && todo; ++k) {
-            const int q = R.cell_poly[k];
-            const uint32_t L = R.poly_layers[q] & todo;
-            if (L && rn_polygon_contains(R.edges, R.poly_edge_off[q], R.poly_edge_off[q + 1], px, py)) {
-                in |= L;
-                todo &= ~L;
-            }
-        }
-    }
-    return in;
 }
 
 // ------------------------------------------------------------------------------------------------

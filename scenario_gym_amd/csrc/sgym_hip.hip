@@ -196,6 +196,8 @@ static void launch_variant(sg_handle *h, dim3 grid, int n_steps, int do_reset, i
     if (h->has_ped)
         sg::rollout_kernel<(WV > 1 || G >= 16) ? G : 16, WV, true, false><<<grid, block, 0, h->stream>>>(
             h->p, h->cfg.timestep, n_steps, do_reset, force, d_actions, nullptr);
+    else if (h->cfg.terminal_mask & SG_TERM_EGO_OFF_ROAD)
+        sg::rollout_kernel_road<G, WV><<<grid, block, 0, h->stream>>>(h->p, h->cfg.timestep, n_steps, do_reset, force, d_actions, nullptr);
     else if (use_tab && WV == 1 && h->n_ctl > 0)
         sg::rollout_kernel_tab<G><<<grid, block, 0, h->stream>>>(h->p, h->cfg.timestep, n_steps, 0, force, nullptr, d_tab);
     else if (use_tab)
@@ -257,7 +259,7 @@ static int launch_rollout(sg_handle *h, int n_steps, int do_reset, int force, co
     HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
     // the table variant serves SG_TAB_LANES controlled lanes per wavefront; denser batches keep their controllers
     // in the rollout kernel, where they fill the wavefront anyway
-    const bool use_tab = !h->has_ped && h->n_ext == 0 && n_steps >= tab_min && h->max_ctl_per_block <= SG_TAB_LANES(h->G, h->WV);
+    const bool use_tab = !h->has_ped && !(h->cfg.terminal_mask & SG_TERM_EGO_OFF_ROAD) && h->n_ext == 0 && n_steps >= tab_min && h->max_ctl_per_block <= SG_TAB_LANES(h->G, h->WV);
     int rc = SG_OK;
     if (!use_tab) {
         rc = launch_main(h, n_steps, do_reset, force, d_actions, nullptr, false, &ev_next);
@@ -354,6 +356,8 @@ extern "C" int sg_upload(sg_handle *h, const sg_scenarios *sc)
     for (size_t i = 0; i < (size_t)h->R * h->E; ++i) h->has_ped = h->has_ped || sc->kind[i] == SG_KIND_AGENT_PEDESTRIAN;
     if (h->has_ped && h->WV == 1 && h->G < 16) { h->G = 16; h->EP = 16; h->NE = (((size_t)h->R * h->EP + 63) / 64) * 64; }
     if (h->has_ped && (!sc->route_off || !sc->routes)) return fail(h, SG_ERR_INVALID, "sg_upload: pedestrian agents need route_off/routes");
+    if (h->has_ped && (h->cfg.terminal_mask & SG_TERM_EGO_OFF_ROAD))
+        return fail(h, SG_ERR_INVALID, "sg_upload: the ego_off_road terminal condition is not available for batches with pedestrian agents");
     const int R = h->R, E = h->E, EP = h->EP;
     const size_t NE = h->NE;
 

@@ -129,7 +129,7 @@ class BatchedScenarioGym:
         dev_terms = [c for c in self.terminal_conditions if not callable(c)]
         for c in dev_terms:
             if c not in TERMINAL_BITS:
-                raise ValueError(f"terminal condition {c!r} is not supported (needs the road network)")
+                raise ValueError(f"terminal condition {c!r} is not supported")
         sf = None
         for sc_agents in agents:  # one SocialForce parameter set per batch (the first pedestrian agent's)
             for a in sc_agents.values():
@@ -140,6 +140,9 @@ class BatchedScenarioGym:
             terminal_conditions=dev_terms, record_capacity=(self.max_steps + 1) if self.record else 0,
             event_capacity=self.event_capacity, device=self.device, social_force=sf)
         self.engine.upload(packed)
+        self._roads_set = False
+        if "ego_off_road" in dev_terms:
+            self._set_road_networks()
         self.states = [State(self, i, sc, agents[i], self.persist) for i, sc in enumerate(self.scenarios)]
         from . import _lib as L
         self._host_agents = [(i, sc.entities.index(e), a) for i, sc in enumerate(self.scenarios)
@@ -153,6 +156,36 @@ class BatchedScenarioGym:
         self._invalidate()
         self._prev_state = None
         self._reset_host_side()
+
+    def _set_road_networks(self):
+        """Scenario.road_network of every scenario -> the device (shared networks once); needed by the ego_off_road
+        terminal condition and the surface layers of the map sensor."""
+        if self._roads_set:
+            return
+        nets, index, net_of = [], {}, []
+        for sc in self.scenarios:
+            rn = sc.road_network
+            if rn is None:
+                net_of.append(-1)
+                continue
+            if id(rn) not in index:
+                index[id(rn)] = len(nets)
+                nets.append(rn.polygon_arrays())
+            net_of.append(index[id(rn)])
+        self.engine.set_road_networks(nets, net_of)
+        self._roads_set = True
+
+    def _raster_map(self, layers, width, height, nw, nh):
+        """[R][n_layers][nh][nw] of RasterizedMapSensor layers (names of sensor/map.py:44-53), cached per state."""
+        from .road_network import LAYER_CODES
+        codes = tuple(LAYER_CODES[l] for l in layers)
+        key = ("map", codes, width, height, nw, nh)
+        if self._fut is None or key not in self._fut:
+            if any(codes):
+                self._set_road_networks()
+            self._fut = dict(self._fut or {})
+            self._fut[key] = self.engine.raster_map(codes, width, height, nw, nh)
+        return self._fut[key]
 
     def _invalidate(self):
         self._cache = None

@@ -119,6 +119,11 @@ class State:
         """RasterizedMapSensor "entity" layer around the ego (sensor/map.py:120-192), computed on the device: bool [nh, nw]."""
         return self._gym._raster(float(width), float(height), int(nw), int(nh))[self._i]
 
+    def raster_map(self, layers, width: float = 20.0, height: float = 20.0, nw: int = 20, nh: int = 20) -> np.ndarray:
+        """RasterizedMapSensor layers around the ego (sensor/map.py:136-271; names of its `_all_layers`), computed on the
+        device from the scenario's road network: bool [n_layers, nh, nw]."""
+        return self._gym._raster_map(tuple(layers), float(width), float(height), int(nw), int(nh))[self._i]
+
     def get_entities_in_area(self, area) -> List[Entity]:
         """state.py:340-354: entities whose centre point lies strictly inside `area`.  The reference takes a shapely
         (Multi)Polygon; here `area` is anything with `.exterior.coords`, or an (n, 2) array of ring vertices (simple

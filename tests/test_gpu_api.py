@@ -558,3 +558,57 @@ def test_all_reference_scenarios_as_one_batch():
         for key in ("ego_avg_speed", "ego_max_speed", "ego_distance_travelled"):
             assert metrics[i][key] == float(g[f"{n}/metric_{key}"]), (n, key)
     gym.close()
+
+
+def _road_network_from_golden(g, name):
+    """A RoadNetwork carrying the exported polygon arrays (the JSON files do not travel to the GPU box)."""
+    from scenario_gym_amd.road_network import RoadNetwork
+
+    rn = RoadNetwork(name=name)
+    rn._arrays = {k: g[f"net/{name}/{k}"] for k in ("ring_off", "vert_off", "verts", "layers")}
+    return rn
+
+
+def test_map_sensor_and_ego_off_road_through_the_gym():
+    """tests/test_sensor.py:38-77 (RasterizedMapSensor, default layers and all layers, 61 x 61 over 30 m) and a gym with
+    terminal_conditions=["max_length", "ego_off_road"] (examples/ppo_agent.py:336), through the reference-shaped API."""
+    import scenario_gym_amd as sga
+
+    g = load_golden("roads")
+    names = [str(n) for n in g["scenarios"]]
+    nets = {}
+    for n in names:
+        k = str(g[f"{n}/network"])
+        nets.setdefault(k, _road_network_from_golden(g, k))
+    all_layers = [str(x) for x in g["layers"]]
+    assert sga.RasterizedMapSensor._all_layers == all_layers
+    for n in names:
+        sc = scenario_from_arrays(scenario_arrays(g, f"{n}/scenario"), g[f"{n}/scenario/refs"])
+        sc.road_network = nets[str(g[f"{n}/network"])]
+        gym = sga.ScenarioGym(timestep=0.1)
+        gym.set_scenario(sc)
+        e = gym.state.scenario.entities[0]
+        sensor = sga.RasterizedMapSensor(e, height=30, width=30, n=61)
+        out = sensor.reset(gym.state)[-1]
+        want = g[f"{n}/map0"][0].astype(bool)  # [layer][61][61]
+        assert out.shape == (61, 61, 2) and out[..., 1].any() and out[30, 30, 0]
+        assert np.array_equal(out.transpose(2, 0, 1), want[:2])
+        sensor = sga.RasterizedMapSensor(e, layers=all_layers, height=30, width=30, n=61, channels_first=True)
+        sensor.reset(gym.state)
+        for _ in range(30):
+            gym.step()
+        assert np.array_equal(sensor.step(gym.state)[-1], g[f"{n}/map0"][1].astype(bool))
+        gym.close()
+    # the terminal condition, four drifting egos as one batch
+    scs = []
+    for n in names:
+        sc = scenario_from_arrays(scenario_arrays(g, f"{n}/drift/scenario"), g[f"{n}/drift/scenario/refs"])
+        sc.road_network = nets[str(g[f"{n}/network"])]
+        scs.append(sc)
+    gym = sga.BatchedScenarioGym(timestep=0.1, terminal_conditions=["max_length", "ego_off_road"])
+    gym.set_scenarios(scs)
+    gym.rollout()
+    for i, n in enumerate(names):
+        assert gym.states[i].is_done and gym.states[i].t == g[f"{n}/drift/t"][-1], n
+        assert bits_equal(gym.states[i].poses[scs[i].ego], g[f"{n}/drift/final_ego"]), n
+    gym.close()

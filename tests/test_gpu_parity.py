@@ -573,11 +573,25 @@ def test_abi_rejects_bad_input(sga):
     with pytest.raises(RuntimeError, match="timestep"):
         sga.RolloutEngine(4, 4, timestep=0.0)
     with pytest.raises(ValueError):
-        sga.RolloutEngine(4, 4, terminal_conditions=["ego_off_road"])
+        sga.RolloutEngine(4, 4, terminal_conditions=["ego_in_the_air"])
     good = _mini([[_row(0, 0, 0), _row(1, 1, 0)], [_row(0, 5, 0)]])
     eng = sga.RolloutEngine(1, 2)
     with pytest.raises(RuntimeError, match="no scenarios uploaded"):
         eng.rollout(3)
+    tri = dict(ring_off=[0, 1], vert_off=[0, 3], verts=[[0, 0], [1, 0], [0, 1]], layers=[1])
+    with pytest.raises(RuntimeError, match="no scenarios uploaded"):
+        eng.set_road_networks([tri], [0])
+    eng.upload(pack_arrays([good]))
+    with pytest.raises(RuntimeError, match="out of range"):
+        eng.set_road_networks([tri], [1])
+    with pytest.raises(RuntimeError, match="not finite"):
+        eng.set_road_networks([dict(tri, verts=[[0, 0], [np.nan, 0], [0, 1]])], [0])
+    with pytest.raises(RuntimeError, match="SG_LAYER"):
+        eng.raster_map([3])
+    eng.set_road_networks([], [-1])  # no networks at all: empty surfaces
+    assert not eng.raster_map([1, 2]).any()
+    eng.close()
+    eng = sga.RolloutEngine(1, 2)
     bad = pack_arrays([good])
     bad.kind = bad.kind.copy()
     bad.kind[1] = 9
@@ -1060,3 +1074,80 @@ def test_surface_raster_on_synthetic_polygons_matches_oracle(sga, oracle):
         assert not got[net_of < 0][:, [0, 2, 3, 4, 5, 6, 7]].any()
     eng.close()
     assert on > 1000
+
+
+def test_ego_off_road_terminal_matches_reference_and_oracle(sga, oracle):
+    """terminal_conditions = max_length + ego_off_road (state/state.py:397-407): the eight reference rollouts of roads.npz
+    (recorded egos that stay on the road, copies drifting off it) as one batch over three road networks stop at the
+    reference's step with the reference's ego pose; a scenario without a network is off the road after its first step."""
+    from scenario_gym_amd.packing import default_kinds, pack_arrays
+
+    g = load_golden("roads")
+    keys = [f"{n}/{tag}" for n in g["scenarios"] for tag in ("onroad", "drift")]
+    scs = []
+    for k in keys + [keys[0]]:
+        s = scenario_arrays(g, f"{k}/scenario")
+        s["kind"] = default_kinds(len(s["bbox"]), s["ego"])
+        scs.append(s)
+    packed = pack_arrays(scs)
+    nets = sorted({str(g[f"{n}/network"]) for n in g["scenarios"]})
+    net_of = [nets.index(str(g[f"{k.split('/')[0]}/network"])) for k in keys] + [-1]
+    eng = sga.RolloutEngine(packed.n_scenarios, packed.n_entities, timestep=0.1, terminal_conditions=["max_length", "ego_off_road"],
+                            record_capacity=400)
+    eng.upload(packed)
+    eng.set_road_networks([_road_arrays(g, k) for k in nets], net_of)
+    eng.rollout(390)
+    st = eng.state()
+    t, poses = eng.record(391)
+    eng.close()
+    early = 0
+    for r, k in enumerate(keys):
+        want = g[f"{k}/t"]
+        n = len(want) - 1
+        assert st["n_steps"][r] == n and st["done"][r], k
+        assert bits_equal(t[: n + 1, r], want) and bits_equal(poses[n, r, scs[r]["ego"]], g[f"{k}/final_ego"]), k
+        early += want[-1] + 0.2 < scs[r]["length"]
+        o = oracle.rollout(scs[r]["knot_off"], scs[r]["knots"], scs[r]["bbox"], scs[r]["etype"], scs[r]["kind"], scs[r]["ego"],
+                           scs[r]["t0"], scs[r]["length"], 0.1, terminal_mask=9, road=_road_arrays(g, nets[net_of[r]]))
+        assert o["n_steps"] == n and bits_equal(poses[: n + 1, r, : len(scs[r]["bbox"])], o["poses"]), k
+    assert early >= 2 and st["n_steps"][-1] == 1 and st["done"][-1]
+
+
+def test_ego_off_road_with_controlled_egos_on_synthetic_roads(sga, oracle):
+    """PID egos (entity 0) wandering over random polygon "roads": every scenario stops at the oracle's step -- cells
+    wholly inside or outside answer from the grid, boundary cells through the exact test."""
+    import scenario_gym_amd._lib as L
+    from scenario_gym_amd import synthetic
+    from scenario_gym_amd.packing import unpack_scenario
+
+    rng = np.random.default_rng(23)
+    R, E, steps = 96, 8, 400
+    packed = synthetic.make_batch(R, E, n_steps=steps, ego_kind=L.KIND_AGENT_PID, extent=30.0)
+    nets = []
+    for n in range(6):
+        rings, layers = [], []
+        for q in range(10):
+            c = rng.uniform(-60, 60, 2)
+            m = int(rng.integers(5, 60))
+            ang = np.sort(rng.uniform(0, 2 * np.pi, m))
+            rad = rng.uniform(20, 60) * rng.uniform(0.6, 1.0, m)
+            rings.append(c + rad[:, None] * np.stack([np.cos(ang), np.sin(ang)], 1))
+            layers.append(1 if q < 7 else 16)
+        vert_off = np.concatenate([[0], np.cumsum([len(r) for r in rings])])
+        nets.append(dict(ring_off=np.arange(len(rings) + 1), vert_off=vert_off, verts=np.concatenate(rings), layers=np.array(layers)))
+    net_of = rng.integers(0, len(nets), R)
+    eng = sga.RolloutEngine(R, E, terminal_conditions=["ego_off_road"])
+    eng.upload(packed)
+    eng.set_road_networks(nets, net_of)
+    eng.rollout(steps)
+    st = eng.state()
+    eng.close()
+    stopped = 0
+    for r in range(R):
+        s = unpack_scenario(packed, r)
+        o = oracle.rollout(s["knot_off"], s["knots"], s["bbox"], s["etype"], s["kind"], s["ego"], s["t0"], s["length"], 1 / 30,
+                           terminal_mask=8, ctrl=s["ctrl"], max_steps=steps, road=nets[net_of[r]])
+        assert st["n_steps"][r] == o["n_steps"] and bool(st["done"][r]) == o["is_done"], r
+        assert bits_equal(st["poses"][r, : len(s["bbox"])], o["poses"][-1]), r
+        stopped += 1 < o["n_steps"] < steps
+    assert stopped > 10
