@@ -272,6 +272,13 @@ int sg_set_road_networks(sg_handle *h, const sg_road_networks *nets);
 int sg_raster_map(sg_handle *h, double width, double height, int32_t nw, int32_t nh, int32_t n_layers,
                   const int32_t *layers, uint8_t *out);
 
+/* The same maps left in device memory for a policy that runs on this GPU (the observation of
+ * integrations/openaigym.py:280-297 without the trip through the host): *d_out = DEVICE [R][n_layers][nh][nw] bytes inside
+ * the handle's observation scratch, written by kernels queued on sg_stream(h) -- not synchronised; valid until the next
+ * observation call (sg_raster_*, sg_future_collision) or sg_destroy. */
+int sg_raster_map_device(sg_handle *h, double width, double height, int32_t nw, int32_t nh, int32_t n_layers,
+                         const int32_t *layers, const uint8_t **d_out);
+
 /* ScenarioGym.get_metrics (scenario_gym.py:308-319): out [R]; events [cap] (may be NULL) */
 int sg_read_metrics(sg_handle *h, sg_metrics *out, sg_event *events, int32_t cap, int32_t *n_events);
 

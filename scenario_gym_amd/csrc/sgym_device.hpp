@@ -60,15 +60,18 @@ struct ScenStatic { // per scenario, read-only
 
 // Road surfaces (sg_set_road_networks): the polygons as edge soup + one uniform cell grid per network.
 struct RoadNet { double x0, y0, inv_cell; int32_t nx, ny; int64_t cell_base; };
+// a polygon whose boundary touches a cell: its edges there, and a reference point of the cell (one of RN_REF below) that is
+// not on the polygon's boundary, with its inside / outside status
+struct RoadCand { int32_t poly; uint32_t edge_off; uint16_t n_edges; uint8_t ref_sel, ref_inside; };
 struct RoadIndex {
     const RoadNet *nets;            // [n_nets]
     const int32_t *net_of_scen;     // [R], -1 = no road network
     const uint16_t *cells;          // per cell: low byte = layers some polygon covers the WHOLE cell with, high byte = layers
                                     // with a polygon whose boundary touches the cell (candidates below)
     const uint32_t *cell_off;       // CSR over all cells of all networks
-    const int32_t *cell_poly;       // candidate polygons (global index) of the cells
+    const RoadCand *cand;           // the candidates of the cells
+    const int32_t *cand_edges;      // their edge lists (indices into edges)
     const double *edges;            // [n_edges][4] x1, y1, x2, y2; the rings of a polygon are contiguous
-    const int64_t *poly_edge_off;   // [n_polygons + 1]
     const uint32_t *poly_layers;    // [n_polygons] SG_LAYER_*
     int32_t n_nets;
 };
@@ -1425,38 +1428,81 @@ __host__ __device__ inline bool rn_ray_edge(double x1, double y1, double x2, dou
     return false;
 }
 
-__host__ __device__ inline bool rn_polygon_contains(const double *edges, int64_t e0, int64_t e1, double px, double py)
+// 0 outside, 1 strictly inside, 2 on a ring -- the whole polygon (host: cell classification and reference points)
+__host__ __device__ inline int rn_polygon_locate(const double *edges, int64_t e0, int64_t e1, double px, double py)
 {
     bool cross = false;
     for (int64_t i = e0; i < e1; ++i) {
         const double *e = edges + i * 4;
-        if (rn_ray_edge(e[0], e[1], e[2], e[3], px, py, cross)) return false;
+        if (rn_ray_edge(e[0], e[1], e[2], e[3], px, py, cross)) return 2;
     }
-    return cross;
+    return cross ? 1 : 0;
 }
 
 // cell of a point; false = outside the grid (the grid covers every polygon with a margin, so: outside every surface)
-__host__ __device__ inline bool rn_cell_of(const RoadNet &N, double px, double py, int64_t &cell)
+__host__ __device__ inline bool rn_cell_of(const RoadNet &N, double px, double py, int &ix, int &iy)
 {
     const double fx = (px - N.x0) * N.inv_cell, fy = (py - N.y0) * N.inv_cell;
     if (!(fx >= 0.0 && fx < (double)N.nx && fy >= 0.0 && fy < (double)N.ny)) return false;
-    cell = N.cell_base + (int64_t)(int)fy * N.nx + (int)fx;
+    ix = (int)fx;
+    iy = (int)fy;
     return true;
+}
+
+// candidate reference points of a cell (fractions of the cell side; cell = 1 / inv_cell is a power of two, so the
+// products are exact and host and device agree bit for bit)
+#define RN_NREF 8
+__host__ __device__ inline void rn_ref_point(const RoadNet &N, int ix, int iy, int sel, double &x, double &y)
+{
+    const double FX[RN_NREF] = {0.5, 0.25, 0.75, 0.25, 0.75, 0.375, 0.625, 0.4375};
+    const double FY[RN_NREF] = {0.5, 0.25, 0.25, 0.75, 0.75, 0.5625, 0.3125, 0.6875};
+    const double c = 1.0 / N.inv_cell;
+    x = N.x0 + ((double)ix + FX[sel]) * c;
+    y = N.y0 + ((double)iy + FY[sel]) * c;
+}
+
+// Inside a cell whose reference point R has a known status: P has the same status unless the segment R -> P crosses the
+// polygon's boundary an odd number of times, and only edges that touch the cell can cross a segment inside it.
+// Crossing of edge (a, b): a and b on different sides of the line R-P (half-open: "left of" vs "not left of", so a
+// boundary passing through a vertex counts once) and R, P on different sides of the line a-b.  Returns 0 outside,
+// 1 inside, 2 = P lies on one of the edges.
+__host__ __device__ inline int rn_locate_in_cell(const double *edges, const int32_t *list, int n, double rx, double ry,
+                                                 bool r_inside, double px, double py)
+{
+    bool inside = r_inside;
+    for (int j = 0; j < n; ++j) {
+        const double *e = edges + (int64_t)list[j] * 4;
+        const double ax = e[0], ay = e[1], bx = e[2], by = e[3];
+        const int o2 = rn_orient_sign(ax, ay, bx, by, px, py);
+        if (o2 == 0 && px >= (ax < bx ? ax : bx) && px <= (ax < bx ? bx : ax) && py >= (ay < by ? ay : by) && py <= (ay < by ? by : ay))
+            return 2;
+        const bool sa = rn_orient_sign(rx, ry, px, py, ax, ay) > 0, sb = rn_orient_sign(rx, ry, px, py, bx, by) > 0;
+        if (sa != sb) {
+            const int o1 = rn_orient_sign(ax, ay, bx, by, rx, ry);
+            if ((o1 > 0) != (o2 > 0)) inside = !inside;
+        }
+    }
+    return inside ? 1 : 0;
 }
 
 // the layers of `want` whose union strictly contains the point (one thread)
 __device__ inline uint32_t rn_layers_at(const RoadIndex &R, int net, uint32_t want, double px, double py)
 {
     if (net < 0) return 0u;
-    int64_t cell;
-    if (!rn_cell_of(R.nets[net], px, py, cell)) return 0u;
+    const RoadNet N = R.nets[net];
+    int ix, iy;
+    if (!rn_cell_of(N, px, py, ix, iy)) return 0u;
+    const int64_t cell = N.cell_base + (int64_t)iy * N.nx + ix;
     const uint32_t m = R.cells[cell];
     uint32_t in = m & 0xffu & want, todo = (m >> 8) & want & ~in;
     if (todo) {
         for (uint32_t k = R.cell_off[cell]; k < R.cell_off[cell + 1] && todo; ++k) {
-            const int q = R.cell_poly[k];
-            const uint32_t L = R.poly_layers[q] & todo;
-            if (L && rn_polygon_contains(R.edges, R.poly_edge_off[q], R.poly_edge_off[q + 1], px, py)) {
+            const RoadCand cd = R.cand[k];
+            const uint32_t L = R.poly_layers[cd.poly] & todo;
+            if (!L) continue;
+            double rx, ry;
+            rn_ref_point(N, ix, iy, cd.ref_sel, rx, ry);
+            if (rn_locate_in_cell(R.edges, R.cand_edges + cd.edge_off, cd.n_edges, rx, ry, cd.ref_inside != 0, px, py) == 1) {
                 in |= L;
                 todo &= ~L;
             }
@@ -2395,6 +2441,7 @@ __global__ __launch_bounds__(256) void raster_kernel(Params p, double width, dou
     __shared__ double cor[8][256];
     __shared__ unsigned char pres[256];
     __shared__ double ego_pose[4]; // x, y, sin(theta), cos(theta)
+    __shared__ int near_n;
     const int r = blockIdx.x, e = threadIdx.x;
     const ScenStatic &ss = p.sstat[r];
     const uint32_t idx = (uint32_t)r * p.EP + (e < p.EP ? e : 0);
@@ -2402,13 +2449,13 @@ __global__ __launch_bounds__(256) void raster_kernel(Params p, double width, dou
     const LanePtr dy(p.dyn + (size_t)(idx >> 6) * ((size_t)p.FROWS * 64), (idx & 63) * 8u);
     const bool present = e < p.E && fld<uint64_t>(dy, SG_F_PRESENT) != 0;
     pres[e] = present;
+    if (e == 0) near_n = 0;
+    double C[8];
     if (present) {
         const double x = fld(dy, SG_F_POSE + 0), y = fld(dy, SG_F_POSE + 1), h = fld(dy, SG_F_POSE + 3);
-        double s, c, C[8];
+        double s, c;
         sg_sincos(h, s, c);
         sg_corners(x, y, s, c, fld(st, ST_BW), fld(st, ST_BL), fld(st, ST_BCX), fld(st, ST_BCY), C);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) cor[k][e] = C[k];
     }
     if (e == ss.ego) {
         double s, c;
@@ -2418,15 +2465,31 @@ __global__ __launch_bounds__(256) void raster_kernel(Params p, double width, dou
     }
     __syncthreads();
     const double ex = ego_pose[0], ey = ego_pose[1], s = ego_pose[2], c = ego_pose[3];
+    if (present) {
+        // only boxes that can reach the grid are tested per cell: every grid point lies within `reach` of the ego (the
+        // grid's half diagonal, generously rounded up), every point of a box within the largest corner distance of its
+        // first corner
+        const double reach = 0.5 * (__builtin_fabs(width) + __builtin_fabs(height)) * 1.0000001 + 1e-6;
+        double far = 0.0;
+#pragma unroll
+        for (int k = 1; k < 4; ++k) far = __builtin_fmax(far, __builtin_fabs(C[2 * k] - C[0]) + __builtin_fabs(C[2 * k + 1] - C[1]));
+        const double dx = C[0] - ex, dyy = C[1] - ey, lim = reach + far * 1.0000001 + 1e-6 * (1.0 + __builtin_fabs(ex) + __builtin_fabs(ey));
+        if (!(dx * dx + dyy * dyy > lim * lim)) { // NaN-safe: keeps the box
+            const int q = atomicAdd(&near_n, 1);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) cor[k][q] = C[k];
+        }
+    }
+    __syncthreads();
     const bool ego_present = pres[ss.ego] != 0;
+    const int nn = near_n;
     unsigned char *o = out + (size_t)r * stride;
     for (int q = e; q < nw * nh; q += 256) {
         const int i = q / nw, j = q - i * nw;
         const double x0 = sg_linspace_at(-width / 2, width / 2, nw, j), x1 = sg_linspace_at(-height / 2, height / 2, nh, i);
         const double px = __builtin_fma(x1, -s, x0 * c) + ex, py = __builtin_fma(x1, c, x0 * s) + ey;
         bool hit = false;
-        for (int k = 0; k < p.E && !hit; ++k) {
-            if (!pres[k]) continue;
+        for (int k = 0; k < nn && !hit; ++k) {
             const double ax = cor[0][k], ay = cor[1][k], bx = cor[2][k], by = cor[3][k];
             const double cx = cor[4][k], cy = cor[5][k], dx = cor[6][k], dyy = cor[7][k];
             const double orient = (cx - ax) * (dyy - by) - (cy - ay) * (dx - bx);

@@ -43,6 +43,8 @@ struct sg_handle {
     double *d_tab[2] = {nullptr, nullptr};
     std::vector<hipEvent_t> ev_pool;
     int tab_min = 16, chunk_steps = 1024, overlap = 1; // sg_set_tuning
+    void *obs_buf = nullptr;                           // device scratch of the observation calls (grown on demand)
+    size_t obs_cap = 0;
     std::vector<void *> road_allocs;                   // sg_set_road_networks
     sg::RoadIndex road{};                              // host copy of the device pointers (raster kernels take it by value)
     bool has_road = false;
@@ -169,6 +171,7 @@ extern "C" int sg_destroy(sg_handle *h)
     free_pool(h->static_allocs);
     free_pool(h->state_allocs);
     free_pool(h->road_allocs);
+    if (h->obs_buf) (void)hipFree(h->obs_buf);
     if (h->ctl_stream) (void)hipStreamSynchronize(h->ctl_stream);
     if (h->d_actions) (void)hipFree(h->d_actions);
     if (h->d_gon) (void)hipFree(h->d_gon);
@@ -770,18 +773,34 @@ extern "C" int sg_set_tuning(sg_handle *h, int32_t tab_min_steps, int32_t chunk_
     return SG_OK;
 }
 
+// device scratch shared by the observation entry points: a tick of an RL loop calls them once per step, a hipMalloc /
+// hipFree pair per call would cost more than the kernels
+static int obs_scratch(sg_handle *h, size_t bytes, unsigned char **out)
+{
+    if (bytes > h->obs_cap) {
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        if (h->obs_buf) HIP_TRY(h, hipFree(h->obs_buf));
+        h->obs_buf = nullptr;
+        h->obs_cap = 0;
+        HIP_TRY(h, hipMalloc(&h->obs_buf, bytes));
+        h->obs_cap = bytes;
+    }
+    *out = (unsigned char *)h->obs_buf;
+    return SG_OK;
+}
+
 extern "C" int sg_future_collision(sg_handle *h, double horizon, int32_t n_samples, uint8_t *out)
 {
     if (!h || !out || n_samples < 1 || !(horizon >= 0.0)) return h ? fail(h, SG_ERR_INVALID, "sg_future_collision: bad argument") : SG_ERR_INVALID;
     if (!h->uploaded) return fail(h, SG_ERR_STATE, "sg_future_collision: no scenarios uploaded");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     unsigned char *d = nullptr;
-    HIP_TRY(h, hipMalloc((void **)&d, (size_t)h->R));
+    int rc = obs_scratch(h, (size_t)h->R, &d);
+    if (rc) return rc;
     sg::future_kernel<<<dim3((unsigned)h->R), dim3(256), 0, h->stream>>>(h->p, horizon, n_samples, d);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(out, d, (size_t)h->R, hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-    (void)hipFree(d);
     if (e != hipSuccess) return fail(h, SG_ERR_HIP, "sg_future_collision: %s", hipGetErrorString(e));
     return SG_OK;
 }
@@ -795,13 +814,14 @@ struct RoadBuild {
     std::vector<sg::RoadNet> nets;
     std::vector<uint16_t> cells;
     std::vector<uint32_t> cell_off;
-    std::vector<int32_t> cell_poly;
+    std::vector<sg::RoadCand> cand;
+    std::vector<int32_t> cand_edges;
     std::vector<double> edges;
     std::vector<int64_t> poly_edge_off;
     std::vector<uint32_t> poly_layers;
 };
 
-void build_road_network(const sg_road_networks *in, int n, RoadBuild &B)
+int build_road_network(const sg_road_networks *in, int n, RoadBuild &B)
 {
     const int64_t q0 = in->poly_off[n], q1 = in->poly_off[n + 1];
     double lo[2] = {INFINITY, INFINITY}, hi[2] = {-INFINITY, -INFINITY};
@@ -824,8 +844,8 @@ void build_road_network(const sg_road_networks *in, int n, RoadBuild &B)
         N.x0 = N.y0 = 0.0; N.inv_cell = 1.0; N.nx = N.ny = 1;
         B.nets.push_back(N);
         B.cells.push_back(0);
-        B.cell_off.push_back((uint32_t)B.cell_poly.size());
-        return;
+        B.cell_off.push_back((uint32_t)B.cand.size());
+        return 0;
     }
     double c = 1.0; // cell side: 1 m unless the network is so large that this would take more than 2^21 cells
     while (((hi[0] - lo[0]) / c + 4) * ((hi[1] - lo[1]) / c + 4) > 2097152.0) c *= 2;
@@ -838,9 +858,11 @@ void build_road_network(const sg_road_networks *in, int n, RoadBuild &B)
     const size_t ncell = (size_t)N.nx * N.ny;
     B.cells.resize((size_t)N.cell_base + ncell, 0);
     uint16_t *cells = B.cells.data() + N.cell_base;
-    std::vector<std::pair<uint32_t, int32_t>> pairs; // (local cell, global polygon)
+    struct Entry { uint32_t cell; sg::RoadCand cd; };
+    std::vector<Entry> entries; // candidates of this network, sorted by cell below
     auto cix = [&](double x, double x0, int nmax) { return std::max(0, std::min(nmax - 1, (int)std::floor((x - x0) / c))); };
     std::vector<uint8_t> touched;
+    std::vector<std::pair<uint32_t, int32_t>> hits; // (local cell, edge) of one polygon
     const int64_t gq0 = (int64_t)B.poly_layers.size() - (q1 - q0);
     for (int64_t q = q0; q < q1; ++q) {
         const int64_t gq = gq0 + (q - q0);
@@ -854,6 +876,7 @@ void build_road_network(const sg_road_networks *in, int n, RoadBuild &B)
         const int iy0 = cix(plo[1] - eps, N.y0, N.ny), iy1 = cix(phi[1] + eps, N.y0, N.ny);
         const int w = ix1 - ix0 + 1, hgt = iy1 - iy0 + 1;
         touched.assign((size_t)w * hgt, 0);
+        hits.clear();
         for (int64_t i = e0; i < e1; ++i) {
             const double ax = B.edges[4 * i], ay = B.edges[4 * i + 1], bx = B.edges[4 * i + 2], by = B.edges[4 * i + 3];
             const int jx0 = cix(std::min(ax, bx) - eps, N.x0, N.nx), jx1 = cix(std::max(ax, bx) + eps, N.x0, N.nx);
@@ -871,19 +894,43 @@ void build_road_network(const sg_road_networks *in, int n, RoadBuild &B)
                     const double mn = std::min(std::min(d0, d1), std::min(d2, d3)), mx = std::max(std::max(d0, d1), std::max(d2, d3));
                     if (mn > tol || mx < -tol) continue;
                     touched[(size_t)(iy - iy0) * w + (ix - ix0)] = 1;
+                    hits.emplace_back((uint32_t)((size_t)iy * N.nx + ix), (int32_t)i);
                 }
+        }
+        std::sort(hits.begin(), hits.end());
+        for (size_t a = 0; a < hits.size();) { // one candidate per touched cell: its edges + a reference point off the boundary
+            size_t b = a;
+            while (b < hits.size() && hits[b].first == hits[a].first) ++b;
+            const uint32_t cell = hits[a].first;
+            const int ix = (int)(cell % (uint32_t)N.nx), iy = (int)(cell / (uint32_t)N.nx);
+            sg::RoadCand cd{};
+            cd.poly = (int32_t)gq;
+            cd.edge_off = (uint32_t)B.cand_edges.size();
+            if (b - a > 65535) return -1;
+            cd.n_edges = (uint16_t)(b - a);
+            int loc = 2;
+            for (int sel = 0; sel < RN_NREF && loc == 2; ++sel) {
+                double rx, ry;
+                sg::rn_ref_point(N, ix, iy, sel, rx, ry);
+                loc = sg::rn_polygon_locate(B.edges.data(), e0, e1, rx, ry);
+                cd.ref_sel = (uint8_t)sel;
+            }
+            if (loc == 2) return -2; // every reference point of the cell lies on this polygon's boundary
+            cd.ref_inside = (uint8_t)(loc == 1);
+            for (size_t k = a; k < b; ++k) B.cand_edges.push_back(hits[k].second);
+            cells[cell] |= (uint16_t)(L << 8);
+            entries.push_back({cell, cd});
+            a = b;
         }
         for (int iy = iy0; iy <= iy1; ++iy) {
             bool known = false, inside = false;
             for (int ix = ix0; ix <= ix1; ++ix) {
                 const uint32_t cell = (uint32_t)((size_t)iy * N.nx + ix);
                 if (touched[(size_t)(iy - iy0) * w + (ix - ix0)]) {
-                    cells[cell] |= (uint16_t)(L << 8);
-                    pairs.emplace_back(cell, (int32_t)gq);
                     known = false;
                 } else {
                     if (!known) {
-                        inside = sg::rn_polygon_contains(B.edges.data(), e0, e1, N.x0 + (ix + 0.5) * c, N.y0 + (iy + 0.5) * c);
+                        inside = sg::rn_polygon_locate(B.edges.data(), e0, e1, N.x0 + (ix + 0.5) * c, N.y0 + (iy + 0.5) * c) == 1;
                         known = true;
                     }
                     if (inside) cells[cell] |= (uint16_t)L;
@@ -891,14 +938,15 @@ void build_road_network(const sg_road_networks *in, int n, RoadBuild &B)
             }
         }
     }
-    std::sort(pairs.begin(), pairs.end());
+    std::stable_sort(entries.begin(), entries.end(), [](const Entry &x, const Entry &y) { return x.cell < y.cell; });
     // CSR (global over all networks: cell_off has one entry per cell + a final one appended by the caller)
     size_t k = 0;
     for (size_t cell = 0; cell < ncell; ++cell) {
-        B.cell_off.push_back((uint32_t)B.cell_poly.size());
-        while (k < pairs.size() && pairs[k].first == cell) B.cell_poly.push_back(pairs[k++].second);
+        B.cell_off.push_back((uint32_t)B.cand.size());
+        while (k < entries.size() && entries[k].cell == cell) B.cand.push_back(entries[k++].cd);
     }
     B.nets.push_back(N);
+    return 0;
 }
 } // namespace
 
@@ -930,9 +978,13 @@ extern "C" int sg_set_road_networks(sg_handle *h, const sg_road_networks *in)
     h->p.road = nullptr;
     RoadBuild B;
     B.poly_edge_off.push_back(0);
-    for (int n = 0; n < in->n_networks; ++n) build_road_network(in, n, B);
-    B.cell_off.push_back((uint32_t)B.cell_poly.size());
-    if (B.cell_poly.empty()) B.cell_poly.push_back(0);
+    for (int n = 0; n < in->n_networks; ++n)
+        if (int brc = build_road_network(in, n, B))
+            return fail(h, SG_ERR_INVALID, "sg_set_road_networks: network %d cannot be indexed (%s)", n,
+                        brc == -1 ? "more than 65535 edges of one polygon in one cell" : "a cell whose reference points all lie on a polygon boundary");
+    B.cell_off.push_back((uint32_t)B.cand.size());
+    if (B.cand.empty()) B.cand.push_back(sg::RoadCand{});
+    if (B.cand_edges.empty()) B.cand_edges.push_back(0);
     if (B.edges.empty()) B.edges.assign(4, 0.0);
     if (B.nets.empty()) { B.nets.push_back(sg::RoadNet{0.0, 0.0, 1.0, 1, 1, 0}); B.cells.push_back(0); B.cell_off.insert(B.cell_off.begin(), 0u); }
     std::vector<int32_t> nos(in->net_of_scenario, in->net_of_scenario + h->R);
@@ -943,9 +995,9 @@ extern "C" int sg_set_road_networks(sg_handle *h, const sg_road_networks *in)
     if ((rc = dev_upload(h, A, &R.net_of_scen, nos))) return rc;
     if ((rc = dev_upload(h, A, &R.cells, B.cells))) return rc;
     if ((rc = dev_upload(h, A, &R.cell_off, B.cell_off))) return rc;
-    if ((rc = dev_upload(h, A, &R.cell_poly, B.cell_poly))) return rc;
+    if ((rc = dev_upload(h, A, &R.cand, B.cand))) return rc;
+    if ((rc = dev_upload(h, A, &R.cand_edges, B.cand_edges))) return rc;
     if ((rc = dev_upload(h, A, &R.edges, B.edges))) return rc;
-    if ((rc = dev_upload(h, A, &R.poly_edge_off, B.poly_edge_off))) return rc;
     if ((rc = dev_upload(h, A, &R.poly_layers, B.poly_layers))) return rc;
     R.n_nets = in->n_networks;
     std::vector<sg::RoadIndex> one(1, R);
@@ -958,41 +1010,64 @@ extern "C" int sg_set_road_networks(sg_handle *h, const sg_road_networks *in)
     return SG_OK;
 }
 
-extern "C" int sg_raster_map(sg_handle *h, double width, double height, int32_t nw, int32_t nh, int32_t n_layers,
-                             const int32_t *layers, uint8_t *out)
+// the raster kernels of sg_raster_map / sg_raster_map_device on the handle's stream; *d_out = [R][n_layers][nh][nw]
+static int raster_map_launch(sg_handle *h, const char *who, double width, double height, int32_t nw, int32_t nh, int32_t n_layers,
+                             const int32_t *layers, unsigned char **d_out, size_t *bytes_out)
 {
-    if (!h || !out || !layers || n_layers < 1 || nw < 1 || nh < 1 || !(width >= 0.0) || !(height >= 0.0))
-        return h ? fail(h, SG_ERR_INVALID, "sg_raster_map: bad argument") : SG_ERR_INVALID;
-    if (!h->uploaded) return fail(h, SG_ERR_STATE, "sg_raster_map: no scenarios uploaded");
+    if (!layers || n_layers < 1 || nw < 1 || nh < 1 || !(width >= 0.0) || !(height >= 0.0))
+        return fail(h, SG_ERR_INVALID, "%s: bad argument", who);
+    if (!h->uploaded) return fail(h, SG_ERR_STATE, "%s: no scenarios uploaded", who);
     bool any_surface = false;
     for (int k = 0; k < n_layers; ++k) {
         const uint32_t L = (uint32_t)layers[k];
-        if (layers[k] < 0 || L > 255u || (L & (L - 1))) return fail(h, SG_ERR_INVALID, "sg_raster_map: layers[%d]=%d is not 0 or one SG_LAYER_* bit", k, layers[k]);
+        if (layers[k] < 0 || L > 255u || (L & (L - 1))) return fail(h, SG_ERR_INVALID, "%s: layers[%d]=%d is not 0 or one SG_LAYER_* bit", who, k, layers[k]);
         any_surface = any_surface || L != 0;
     }
     HIP_TRY(h, hipSetDevice(h->cfg.device));
-    const size_t plane = (size_t)nw * nh, bytes = (size_t)h->R * n_layers * plane;
+    const size_t plane = (size_t)nw * nh, bytes = (size_t)h->R * n_layers * plane, lay_off = (bytes + 15) & ~(size_t)15;
     unsigned char *d = nullptr;
-    int32_t *dl = nullptr;
-    HIP_TRY(h, hipMalloc((void **)&d, bytes));
-    hipError_t e = hipMalloc((void **)&dl, (size_t)n_layers * sizeof(int32_t));
-    if (e == hipSuccess) e = hipMemcpyAsync(dl, layers, (size_t)n_layers * sizeof(int32_t), hipMemcpyHostToDevice, h->stream);
-    if (e == hipSuccess && any_surface && !h->has_road) e = hipMemsetAsync(d, 0, bytes, h->stream); // no networks: empty surfaces
-    for (int k = 0; k < n_layers && e == hipSuccess; ++k)
+    int rc = obs_scratch(h, lay_off + (size_t)n_layers * sizeof(int32_t), &d);
+    if (rc) return rc;
+    int32_t *dl = reinterpret_cast<int32_t *>(d + lay_off);
+    HIP_TRY(h, hipMemcpyAsync(dl, layers, (size_t)n_layers * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    if (any_surface && !h->has_road) HIP_TRY(h, hipMemsetAsync(d, 0, bytes, h->stream)); // no networks: empty surfaces
+    for (int k = 0; k < n_layers; ++k)
         if (layers[k] == 0) {
             sg::raster_kernel<<<dim3((unsigned)h->R), dim3(256), 0, h->stream>>>(h->p, width, height, nw, nh, d + (size_t)k * plane,
                                                                                (int64_t)(n_layers * plane));
-            e = hipGetLastError();
+            HIP_TRY(h, hipGetLastError());
         }
-    if (e == hipSuccess && any_surface && h->has_road) {
+    if (any_surface && h->has_road) {
         sg::raster_surface_kernel<<<dim3((unsigned)h->R), dim3(256), 0, h->stream>>>(h->p, h->road, width, height, nw, nh, n_layers, dl, d);
-        e = hipGetLastError();
+        HIP_TRY(h, hipGetLastError());
     }
-    if (e == hipSuccess) e = hipMemcpyAsync(out, d, bytes, hipMemcpyDeviceToHost, h->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-    (void)hipFree(d);
-    if (dl) (void)hipFree(dl);
-    if (e != hipSuccess) return fail(h, SG_ERR_HIP, "sg_raster_map: %s", hipGetErrorString(e));
+    *d_out = d;
+    *bytes_out = bytes;
+    return SG_OK;
+}
+
+extern "C" int sg_raster_map(sg_handle *h, double width, double height, int32_t nw, int32_t nh, int32_t n_layers,
+                             const int32_t *layers, uint8_t *out)
+{
+    if (!h || !out) return h ? fail(h, SG_ERR_INVALID, "sg_raster_map: bad argument") : SG_ERR_INVALID;
+    unsigned char *d = nullptr;
+    size_t bytes = 0;
+    int rc = raster_map_launch(h, "sg_raster_map", width, height, nw, nh, n_layers, layers, &d, &bytes);
+    if (rc) return rc;
+    HIP_TRY(h, hipMemcpyAsync(out, d, bytes, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return SG_OK;
+}
+
+extern "C" int sg_raster_map_device(sg_handle *h, double width, double height, int32_t nw, int32_t nh, int32_t n_layers,
+                                    const int32_t *layers, const uint8_t **d_out)
+{
+    if (!h || !d_out) return h ? fail(h, SG_ERR_INVALID, "sg_raster_map_device: bad argument") : SG_ERR_INVALID;
+    unsigned char *d = nullptr;
+    size_t bytes = 0;
+    int rc = raster_map_launch(h, "sg_raster_map_device", width, height, nw, nh, n_layers, layers, &d, &bytes);
+    if (rc) return rc;
+    *d_out = d;
     return SG_OK;
 }
 
@@ -1004,12 +1079,12 @@ extern "C" int sg_raster_entities(sg_handle *h, double width, double height, int
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     const size_t bytes = (size_t)h->R * nw * nh;
     unsigned char *d = nullptr;
-    HIP_TRY(h, hipMalloc((void **)&d, bytes));
+    int rc = obs_scratch(h, bytes, &d);
+    if (rc) return rc;
     sg::raster_kernel<<<dim3((unsigned)h->R), dim3(256), 0, h->stream>>>(h->p, width, height, nw, nh, d, (int64_t)nw * nh);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(out, d, bytes, hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-    (void)hipFree(d);
     if (e != hipSuccess) return fail(h, SG_ERR_HIP, "sg_raster_entities: %s", hipGetErrorString(e));
     return SG_OK;
 }

@@ -154,11 +154,18 @@ class RolloutEngine:
 
     def step(self, n_steps=1, actions=None):
         """n x ScenarioGym.step(); actions [n, R, 2] (accel, steer) for external-action slots."""
-        ptr = None
-        if actions is not None:
+        ptr, on_device = None, 0
+        if actions is not None and hasattr(actions, "data_ptr") and getattr(actions, "is_cuda", False):
+            # a torch tensor on this GPU (fp64, contiguous): its device pointer goes down as it is
+            import torch
+
+            assert actions.dtype == torch.float64 and actions.is_contiguous() and actions.numel() == n_steps * self.R * 2
+            torch.cuda.current_stream(actions.device).synchronize()  # the policy's writes before the handle's stream reads
+            ptr, on_device = actions.data_ptr(), 1
+        elif actions is not None:
             actions = np.ascontiguousarray(actions, np.float64).reshape(n_steps, self.R, 2)
             ptr = actions.ctypes.data
-        self._check(self.lib.sg_step(self.h, int(n_steps), ptr, 0), "sg_step")
+        self._check(self.lib.sg_step(self.h, int(n_steps), ptr, on_device), "sg_step")
 
     def set_external_poses(self, poses):
         """Poses [R, E, 6] of the caller-run agents (KIND_AGENT_EXTERNAL slots; NaN x = the agent returned None)."""
@@ -208,6 +215,23 @@ class RolloutEngine:
         self._check(self.lib.sg_raster_map(self.h, float(width), float(height), int(nw), int(nh), len(lay), lay.ctypes.data,
                                            out.ctypes.data), "sg_raster_map")
         return out.astype(bool)
+
+    def raster_map_torch(self, layers, width=20.0, height=20.0, nw=20, nh=20):
+        """raster_map left on the device: a zero-copy torch uint8 view [R, n_layers, nh, nw] over the handle's observation
+        scratch (valid until the next observation call), ordered after the kernels that fill it.  torch is the container."""
+        import torch
+
+        lay = np.ascontiguousarray(layers, np.int32)
+        ptr = C.c_void_p()
+        self._check(self.lib.sg_raster_map_device(self.h, float(width), float(height), int(nw), int(nh), len(lay), lay.ctypes.data,
+                                                  C.byref(ptr)), "sg_raster_map_device")
+        self.synchronize()
+
+        class _Arr:
+            __cuda_array_interface__ = dict(shape=(self.R, len(lay), int(nh), int(nw)), typestr="|u1", data=(int(ptr.value), False),
+                                            version=2)
+
+        return torch.as_tensor(_Arr(), device=f"cuda:{self.cfg.device}")
 
     def rollout(self, max_steps):
         self._check(self.lib.sg_rollout(self.h, int(max_steps)), "sg_rollout")

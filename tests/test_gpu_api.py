@@ -612,3 +612,39 @@ def test_map_sensor_and_ego_off_road_through_the_gym():
         assert gym.states[i].is_done and gym.states[i].t == g[f"{n}/drift/t"][-1], n
         assert bits_equal(gym.states[i].poses[scs[i].ego], g[f"{n}/drift/final_ego"]), n
     gym.close()
+
+
+def test_device_resident_tick_equals_host_tick():
+    """One RL tick with the policy's actions and the map observation staying on the GPU (torch tensor in, torch view out)
+    gives the state and the map of the host-buffer calls."""
+    import torch
+
+    import scenario_gym_amd as sga
+    import scenario_gym_amd._lib as L
+    from scenario_gym_amd import synthetic
+
+    R, E = 48, 12
+    packed = synthetic.make_batch(R, E, n_steps=200, ego_kind=L.KIND_AGENT_VEHICLE, extent=15.0)
+    acts = synthetic.make_actions(30, R)
+    sq = np.array([[-20.0, -20.0], [25.0, -20.0], [25.0, 18.0], [-20.0, 18.0]])
+    net = dict(ring_off=[0, 1], vert_off=[0, 4], verts=sq, layers=[1])
+    engines = []
+    for _ in range(2):
+        eng = sga.RolloutEngine(R, E)
+        eng.upload(packed)
+        eng.set_road_networks([net], np.zeros(R, np.int32))
+        engines.append(eng)
+    a, b = engines
+    at = torch.as_tensor(acts, device="cuda:0")
+    for k in range(30):
+        a.step(1, acts[k:k + 1])
+        b.step(1, at[k:k + 1])
+        if k % 10 == 9:
+            want = a.raster_map([0, 1], 30.0, 30.0, 24, 24)
+            got = b.raster_map_torch([0, 1], 30.0, 30.0, 24, 24)
+            assert got.is_cuda and got.dtype == torch.uint8 and tuple(got.shape) == (R, 2, 24, 24)
+            assert np.array_equal(got.cpu().numpy().astype(bool), want) and want[:, 1].any() and not want[:, 1].all()
+    sa, sb = a.state(), b.state()
+    assert bits_equal(sa["poses"], sb["poses"]) and bits_equal(sa["vels"], sb["vels"])
+    a.close()
+    b.close()
