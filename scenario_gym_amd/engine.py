@@ -219,19 +219,24 @@ class RolloutEngine:
     def raster_map_torch(self, layers, width=20.0, height=20.0, nw=20, nh=20):
         """raster_map left on the device: a zero-copy torch uint8 view [R, n_layers, nh, nw] over the handle's observation
         scratch (valid until the next observation call), ordered after the kernels that fill it.  torch is the container."""
-        import torch
-
-        lay = np.ascontiguousarray(layers, np.int32)
-        ptr = C.c_void_p()
-        self._check(self.lib.sg_raster_map_device(self.h, float(width), float(height), int(nw), int(nh), len(lay), lay.ctypes.data,
+        key = (tuple(layers), int(nw), int(nh))
+        cache = self.__dict__.setdefault("_map_views", {})
+        ent = cache.get(key)
+        if ent is None:
+            ent = cache[key] = [np.ascontiguousarray(layers, np.int32), C.c_void_p(), None, None]
+        lay, ptr = ent[0], ent[1]
+        self._check(self.lib.sg_raster_map_device(self.h, float(width), float(height), key[1], key[2], len(lay), lay.ctypes.data,
                                                   C.byref(ptr)), "sg_raster_map_device")
-        self.synchronize()
+        self._check(self.lib.sg_synchronize(self.h), "sg_synchronize")
+        if ent[2] != ptr.value:  # the scratch moved (first call, or it grew): wrap the new address once
+            import torch
 
-        class _Arr:
-            __cuda_array_interface__ = dict(shape=(self.R, len(lay), int(nh), int(nw)), typestr="|u1", data=(int(ptr.value), False),
-                                            version=2)
+            class _Arr:
+                __cuda_array_interface__ = dict(shape=(self.R, len(lay), key[2], key[1]), typestr="|u1",
+                                                data=(int(ptr.value), False), version=2)
 
-        return torch.as_tensor(_Arr(), device=f"cuda:{self.cfg.device}")
+            ent[2], ent[3] = ptr.value, torch.as_tensor(_Arr(), device=f"cuda:{self.cfg.device}")
+        return ent[3]
 
     def rollout(self, max_steps):
         self._check(self.lib.sg_rollout(self.h, int(max_steps)), "sg_rollout")
