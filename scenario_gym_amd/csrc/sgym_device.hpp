@@ -2377,47 +2377,54 @@ __device__ __forceinline__ void own_position_clamped(const double *kn, int n, do
     }
 }
 
+// One workgroup per scenario; the (entity, sample) pairs are spread over its 256 threads (the binary searches over the
+// knots are chains of dependent loads: 10 samples one after the other per entity thread took 250 us for 4096 x 64).
+// Pass 1: the ego's corners at every sample time into LDS; pass 2: every other pair against them.
+#define SG_FUT_MAX_SAMPLES 64
 __global__ __launch_bounds__(256) void future_kernel(Params p, double horizon, int n_samples, unsigned char *out /*[R]*/)
 {
-    __shared__ double ego_c[8];
-    const int r = blockIdx.x, e = threadIdx.x;
+    __shared__ double ego_c[SG_FUT_MAX_SAMPLES][8];
+    const int r = blockIdx.x, tid = threadIdx.x;
     const ScenStatic &ss = p.sstat[r];
-    const uint32_t idx = (uint32_t)r * p.EP + (e < p.EP ? e : 0);
-    const LanePtr st(p.stat + (size_t)(idx >> 6) * (ST_COUNT * 64), (idx & 63) * 8u);
-    const int64_t meta = fld<int64_t>(st, ST_META);
-    const bool active = e < p.E && (int)(meta & 0xff) != SG_KIND_NONE;
-    const double *kn = p.knots + fld<int64_t>(st, ST_KNOT_OFF) * 7;
-    const int nk = (int)(meta >> 32);
-    const double bw = fld(st, ST_BW), bl = fld(st, ST_BL), bcx = fld(st, ST_BCX), bcy = fld(st, ST_BCY);
     const double start = p.sdyn[r].t, stop = start + horizon;
     const double step = n_samples > 1 ? (stop - start) / (double)(n_samples - 1) : 0.0; // np.linspace
-    bool hit = false;
-    for (int j = 0; j < n_samples; ++j) {
+    auto corners_at = [&](int e, int j, double *C) -> bool {
+        const uint32_t idx = (uint32_t)r * p.EP + e;
+        const LanePtr st(p.stat + (size_t)(idx >> 6) * (ST_COUNT * 64), (idx & 63) * 8u);
+        const int64_t meta = fld<int64_t>(st, ST_META);
+        if ((int)(meta & 0xff) == SG_KIND_NONE) return false;
         double tj = (double)j * step + start;
         if (n_samples > 1 && j == n_samples - 1) tj = stop;
-        double C[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (active) {
-            double pose[6], s, c;
-            own_position_clamped(kn, nk, tj, pose);
-            sg_sincos(pose[3], s, c);
-            sg_corners(pose[0], pose[1], s, c, bw, bl, bcx, bcy, C);
-            if (e == ss.ego) {
+        double pose[6], s, c;
+        own_position_clamped(p.knots + fld<int64_t>(st, ST_KNOT_OFF) * 7, (int)(meta >> 32), tj, pose);
+        sg_sincos(pose[3], s, c);
+        sg_corners(pose[0], pose[1], s, c, fld(st, ST_BW), fld(st, ST_BL), fld(st, ST_BCX), fld(st, ST_BCY), C);
+        return true;
+    };
+    bool hit = false;
+    for (int j0 = 0; j0 < n_samples; j0 += SG_FUT_MAX_SAMPLES) { // more samples than the LDS table holds: in rounds
+        const int nj = min(SG_FUT_MAX_SAMPLES, n_samples - j0);
+        if (tid < nj) {
+            double C[8];
+            corners_at(ss.ego, j0 + tid, C); // the ego is an entity of the scenario: never SG_KIND_NONE
 #pragma unroll
-                for (int k = 0; k < 8; ++k) ego_c[k] = C[k];
-            }
+            for (int k = 0; k < 8; ++k) ego_c[tid][k] = C[k];
         }
         __syncthreads();
-        if (active && e != ss.ego) {
+        for (int w = tid; w < nj * p.E; w += 256) {
+            const int j = w / p.E, e = w - j * p.E;
+            double C[8];
+            if (e == ss.ego || !corners_at(e, j0 + j, C)) continue;
             double A[8];
             bool same = true;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) { A[k] = ego_c[k]; same = same && (A[k] == C[k]); }
+            for (int k = 0; k < 8; ++k) { A[k] = ego_c[j][k]; same = same && (A[k] == C[k]); }
             if (!same && sg_quads_intersect(A, C)) hit = true;
         }
         __syncthreads();
     }
     const int any = __syncthreads_or(hit);
-    if (e == 0) out[r] = (unsigned char)(any != 0);
+    if (tid == 0) out[r] = (unsigned char)(any != 0);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -764,7 +764,7 @@ def test_future_collision_batch_matches_oracle(sga, oracle):
         if n_adv:
             eng.step(n_adv)
         t = eng.state()["t"]
-        for horizon, n in ((5.0, 10), (1.0, 10), (0.5, 4)):
+        for horizon, n in ((5.0, 10), (1.0, 10), (0.5, 4), (3.0, 70), (2.0, 1)):  # 70 samples: more than one LDS round
             got = eng.future_collision(horizon, n)
             for r in range(0, R, 3):
                 s = unpack_scenario(packed, r)
