@@ -291,7 +291,8 @@ int sg_read_record(sg_handle *h, int32_t n_rows, double *t_out, double *pose_out
 int sg_copy_to_host(sg_handle *h, const void *device_ptr, void *host_ptr, uint64_t bytes);
 
 /* device time of the last sg_rollout / sg_step call in milliseconds (HIP events on the handle's stream around
- * everything the call enqueued) */
+ * everything the call enqueued).  Calls of fewer than 16 steps are not timed (the event records would cost more than
+ * the kernel of a one-step tick): SG_ERR_STATE after such a call. */
 int sg_last_kernel_ms(sg_handle *h, float *ms);
 
 /* the rollout-kernel launches of that call (long rollouts are cut into chunks of steps so that the controller

@@ -27,6 +27,7 @@ struct sg_handle {
     bool uploaded = false;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timing_now = true;       // this call records its timing events (calls of >= 16 steps, and every table-path call)
     bool timed = false;
     Params p{};
     std::vector<void *> static_allocs, state_allocs;
@@ -227,10 +228,12 @@ static int launch_main(sg_handle *h, int n_steps, int do_reset, int force, const
                        bool use_tab, size_t *ev_next)
 {
     dim3 grid(h->WV == 1 ? (unsigned)(h->NE / 64) : (unsigned)h->R);
-    hipEvent_t e0, e1;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
     int rc;
-    if ((rc = get_event(h, *ev_next, &e0)) || (rc = get_event(h, *ev_next + 1, &e1))) return rc;
-    HIP_TRY(h, hipEventRecord(e0, h->stream));
+    if (h->timing_now) {
+        if ((rc = get_event(h, *ev_next, &e0)) || (rc = get_event(h, *ev_next + 1, &e1))) return rc;
+        HIP_TRY(h, hipEventRecord(e0, h->stream));
+    }
     if (h->WV == 4) launch_variant<64, 4>(h, grid, n_steps, do_reset, force, d_actions, d_tab, use_tab);
     else if (h->WV == 2) launch_variant<64, 2>(h, grid, n_steps, do_reset, force, d_actions, d_tab, use_tab);
     else switch (h->G) {
@@ -241,6 +244,7 @@ static int launch_main(sg_handle *h, int n_steps, int do_reset, int force, const
     default: launch_variant<64, 1>(h, grid, n_steps, do_reset, force, d_actions, d_tab, use_tab); break;
     }
     HIP_TRY(h, hipGetLastError());
+    if (!h->timing_now) return SG_OK;
     HIP_TRY(h, hipEventRecord(e1, h->stream));
     if (n_steps > 0) { // reset-only launches are not counted as hot-path launches
         h->launch_ev.push_back((int)*ev_next);
@@ -259,10 +263,12 @@ static int launch_rollout(sg_handle *h, int n_steps, int do_reset, int force, co
     h->n_launches = 0;
     h->launch_ev.clear();
     size_t ev_next = 0;
-    HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
     // the table variant serves SG_TAB_LANES controlled lanes per wavefront; denser batches keep their controllers
     // in the rollout kernel, where they fill the wavefront anyway
     const bool use_tab = !h->has_ped && !(h->cfg.terminal_mask & SG_TERM_EGO_OFF_ROAD) && h->n_ext == 0 && n_steps >= tab_min && h->max_ctl_per_block <= SG_TAB_LANES(h->G, h->WV);
+    // short calls (the per-tick loop of an RL driver) are not timed: four event records cost more than their kernel
+    h->timing_now = use_tab || n_steps >= 16;
+    if (h->timing_now) HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
     int rc = SG_OK;
     if (!use_tab) {
         rc = launch_main(h, n_steps, do_reset, force, d_actions, nullptr, false, &ev_next);
@@ -323,8 +329,8 @@ static int launch_rollout(sg_handle *h, int n_steps, int do_reset, int force, co
         }
     }
     if (rc) return rc;
-    HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
-    h->timed = true;
+    if (h->timing_now) HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
+    h->timed = h->timing_now;
     return SG_OK;
 }
 
@@ -717,7 +723,7 @@ extern "C" int sg_copy_to_host(sg_handle *h, const void *device_ptr, void *host_
 extern "C" int sg_last_kernel_ms(sg_handle *h, float *ms)
 {
     if (!h || !ms) return SG_ERR_INVALID;
-    if (!h->timed) return fail(h, SG_ERR_STATE, "sg_last_kernel_ms: nothing launched yet");
+    if (!h->timed) return fail(h, SG_ERR_STATE, "sg_last_kernel_ms: the last call was not timed (nothing launched yet, or fewer than 16 steps)");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     HIP_TRY(h, hipEventSynchronize(h->ev1));
     HIP_TRY(h, hipEventElapsedTime(ms, h->ev0, h->ev1));
@@ -727,7 +733,7 @@ extern "C" int sg_last_kernel_ms(sg_handle *h, float *ms)
 extern "C" int sg_last_launch_stats(sg_handle *h, int32_t *n_launches, float *kernel_ms_total)
 {
     if (!h || !n_launches || !kernel_ms_total) return SG_ERR_INVALID;
-    if (!h->timed) return fail(h, SG_ERR_STATE, "sg_last_launch_stats: nothing launched yet");
+    if (!h->timed) return fail(h, SG_ERR_STATE, "sg_last_launch_stats: the last call was not timed (nothing launched yet, or fewer than 16 steps)");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     HIP_TRY(h, hipEventSynchronize(h->ev1));
     float total = 0.0f;
