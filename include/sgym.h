@@ -218,6 +218,18 @@ int sg_set_social_force(sg_handle *h, const sg_social_force *params);
 /* ScenarioGym.reset_scenario -> State.reset(t0), Controller.reset, Metric.reset (scenario_gym.py:217-225) */
 int sg_reset(sg_handle *h);
 
+/* The same for the scenarios with mask[r] != 0 only (HOST [n_scenarios]): one environment of a vector of environments
+ * starts a new episode (`Env.reset` of integrations/openaigym.py:128-169) while the others keep their state. */
+int sg_reset_scenarios(sg_handle *h, const uint8_t *mask);
+
+/* TERMINAL_CONDITIONS (state/state.py:397-408) evaluated on the current state of every scenario, all four of them
+ * whatever the handle's terminal_mask: flags[r] = SG_TERM_* bits (EGO_OFF_ROAD against the networks of
+ * sg_set_road_networks; none set = empty surfaces = off the road).  This is what the reward of the reference's RL agent
+ * asks of a done state (integrations/openaigym.py:300-310).  out: HOST [n_scenarios] or NULL; d_out: if not NULL receives
+ * a DEVICE pointer to the same flags (owned by the handle, rewritten by the next call, stream-ordered, not synchronised
+ * unless `out` is given). */
+int sg_terminal_flags(sg_handle *h, uint32_t *out, const uint32_t **d_out);
+
 /* gym.timestep = x between steps (tests/test_scenario_gym.py:37-39) */
 int sg_set_timestep(sg_handle *h, double timestep);
 

@@ -27,5 +27,7 @@ from .metrics import CollisionMetric, EgoAvgSpeed, EgoDistanceTravelled, EgoMaxS
 from .scenario import Scenario  # noqa: F401
 from .state import State  # noqa: F401
 from .trajectory import Trajectory  # noqa: F401
+from .road_network import RoadNetwork  # noqa: F401
+from .vector_env import VectorScenarioEnv  # noqa: F401
 
 __version__ = "0.1.0"

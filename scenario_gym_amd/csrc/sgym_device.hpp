@@ -99,6 +99,7 @@ struct Params {
     double *ctl_state;       // [CS_COUNT][n_ctl_pad] lane state carried from one chunk of steps to the next
     int n_ctl_pad;           // multiple of 64
     const double *ext_pose;  // [NE][6] poses of the caller-run agents (SG_KIND_AGENT_EXTERNAL), x = NaN: agent returned None
+    const unsigned char *reset_mask; // [R] sg_reset_scenarios: the scenarios a do_reset == 2 launch resets
     const RoadIndex *road;   // device copy of the road index, nullptr = no road networks set
     int ped_serial;          // 1: pedestrian pair loop one pedestrian per lane (env SG_PED_SERIAL; default 0: balanced over the wavefront)
     int tab_steps;           // steps per table chunk (rows per lane = tab_steps + 1: the prefetch of the last step reads one row ahead)
@@ -1713,11 +1714,15 @@ __device__ __forceinline__ void rollout_body(
         }
     };
 
-    if (!TAB && do_reset) {
+    // do_reset: 0 = continue from the stored state, 1 = State.reset for every scenario, 2 = for the scenarios flagged in
+    // p.reset_mask only (one environment of a vector of environments starts a new episode).  The collision pass is a
+    // wavefront / workgroup collective and runs outside the per-scenario branch.
+    const bool rs = !TAB && (do_reset == 1 || (do_reset == 2 && p.reset_mask[r] != 0));
+    double vel[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    if (rs) {
         // ---- State.reset(t0), state.py:106-143 ----
         const double *kn = p.knots + fld<int64_t>(st, ST_KNOT_OFF) * 7;
         const int nk = (int)(meta >> 32);
-        double vel[6];
         t = ss.t0;
         present = false;
 #pragma unroll
@@ -1755,28 +1760,6 @@ __device__ __forceinline__ void rollout_body(
 #pragma unroll
         for (int w = 0; w < WV; ++w) last_row[w] = 0; // metrics/collision.py:64-68
         n_ev = 0;
-        tile_collisions<G, WV, PED>(present, pose, velx, vely, (t + timestep) - t, bcx, bcy, rad_thr, trig_eps, nbr_thr, cell_inv, is_ped_type,
-                                    sl, tile0, lds, row, mult_rows, nbr, dense);
-        if (in_range) {
-#pragma unroll
-            for (int c = 0; c < 6; ++c) { stf(dy, SG_F_POSE + c, pose[c]); stf(dy, SG_F_VEL + c, vel[c]); }
-            stf(dy, SG_F_DIST, dist);
-#pragma unroll
-            for (int w = 0; w < WV; ++w) stf(dy, SG_F_COLL + w, row[w]);
-            stf(dy, SG_F_PRESENT, (uint64_t)present);
-            stf(dy, SG_F_FORCE + 0, 0.0);
-            stf(dy, SG_F_FORCE + 1, 0.0);
-            if (p.rec_cap > 0) {
-#pragma unroll
-                for (int c = 0; c < 6; ++c)
-                    p.rec_pose[(size_t)c * p.R * p.EP + (size_t)r * p.EP + slot] = present ? pose[c] : __builtin_nan("");
-            }
-            if (slot == 0) {
-                sd.rec_rows = p.rec_cap > 0 ? 1 : 0;
-                if (p.rec_cap > 0) p.rec_t[r] = t;
-            }
-            if (is_ego) sd.ego_distance_travelled = __builtin_nan("");
-        }
     } else {
         t = sd.t;
         prev_t = sd.prev_t;
@@ -1797,13 +1780,41 @@ __device__ __forceinline__ void rollout_body(
         n_ev = sd.n_events;
         done = sd.done;
         steps = sd.n_steps;
-        if (PED) { // the neighbour candidates (and LDS positions) of the current state
-            uint64_t tmp_rows[WV];
-            tile_collisions<G, WV, PED>(present, pose, velx, vely, (t + timestep) - t, bcx, bcy, rad_thr, trig_eps, nbr_thr,
-                                        cell_inv, is_ped_type, sl, tile0, lds, tmp_rows, mult_rows, nbr, dense);
-        }
 #pragma unroll
         for (int w = 0; w < WV; ++w) row[w] = fld<uint64_t>(dy, SG_F_COLL + w);
+    }
+    if (!TAB && (do_reset != 0 || PED)) {
+        // collisions of the reset state; pedestrian scenes also need the neighbour candidates (and LDS positions) of the
+        // current state when they continue
+        uint64_t tmp_rows[WV];
+        tile_collisions<G, WV, PED>(present, pose, velx, vely, (t + timestep) - t, bcx, bcy, rad_thr, trig_eps, nbr_thr, cell_inv, is_ped_type,
+                                    sl, tile0, lds, tmp_rows, mult_rows, nbr, dense);
+        if (rs) {
+#pragma unroll
+            for (int w = 0; w < WV; ++w) row[w] = tmp_rows[w];
+        }
+    }
+    if (rs) {
+        if (in_range) {
+#pragma unroll
+            for (int c = 0; c < 6; ++c) { stf(dy, SG_F_POSE + c, pose[c]); stf(dy, SG_F_VEL + c, vel[c]); }
+            stf(dy, SG_F_DIST, dist);
+#pragma unroll
+            for (int w = 0; w < WV; ++w) stf(dy, SG_F_COLL + w, row[w]);
+            stf(dy, SG_F_PRESENT, (uint64_t)present);
+            stf(dy, SG_F_FORCE + 0, 0.0);
+            stf(dy, SG_F_FORCE + 1, 0.0);
+            if (p.rec_cap > 0) {
+#pragma unroll
+                for (int c = 0; c < 6; ++c)
+                    p.rec_pose[(size_t)c * p.R * p.EP + (size_t)r * p.EP + slot] = present ? pose[c] : __builtin_nan("");
+            }
+            if (slot == 0) {
+                sd.rec_rows = p.rec_cap > 0 ? 1 : 0;
+                if (p.rec_cap > 0) p.rec_t[r] = t;
+            }
+            if (is_ego) sd.ego_distance_travelled = __builtin_nan("");
+        }
     }
 
     Segment S;
@@ -2560,6 +2571,45 @@ __global__ __launch_bounds__(256) void raster_surface_kernel(Params p, RoadIndex
         const uint32_t in = ego_present ? rn_layers_at(R, net, want, px, py) : 0u;
         for (int k = 0; k < n_layers; ++k)
             if (layers[k]) o[(size_t)k * nw * nh + q] = (in & (uint32_t)layers[k]) != 0;
+    }
+}
+
+// TERMINAL_CONDITIONS (state/state.py:397-408), all four evaluated on the CURRENT state of every scenario, whatever the
+// handle's terminal mask says: out[r] = SG_TERM_* bits.  The reward of the reference's RL agent asks exactly this of a
+// done state (integrations/openaigym.py:300-310).  One wavefront per scenario.
+__global__ __launch_bounds__(64) void terminal_flags_kernel(Params p, double timestep, uint32_t *out)
+{
+    const int r = blockIdx.x, lane = threadIdx.x;
+    const sg_scenario_state &sd = p.sdyn[r];
+    const int W = p.FROWS - SG_F_COLL;
+    bool any_coll = false, ego_coll = false, e0_present = false;
+    double x0 = 0.0, y0 = 0.0;
+    for (int e = lane; e < p.E; e += 64) {
+        const uint32_t idx = (uint32_t)r * p.EP + e;
+        const LanePtr dy(p.dyn + (size_t)(idx >> 6) * ((size_t)p.FROWS * 64), (idx & 63) * 8u);
+        const bool present = fld<uint64_t>(dy, SG_F_PRESENT) != 0;
+        bool mine = false;
+        for (int w = 0; w < W; ++w) mine = mine || fld<uint64_t>(dy, SG_F_COLL + w) != 0;
+        any_coll = any_coll || (present && mine);
+        if (e == 0) {
+            e0_present = present;
+            ego_coll = present && mine;
+            x0 = fld(dy, SG_F_POSE + 0);
+            y0 = fld(dy, SG_F_POSE + 1);
+        }
+    }
+    uint32_t bits = 0;
+    if (sd.t + (sd.t - sd.prev_t) > p.sstat[r].length) bits |= SG_TERM_MAX_LENGTH; // s.t + s.dt > length, State.dt = t - prev_t
+    if (__any(any_coll)) bits |= SG_TERM_COLLISION;
+    if (lane == 0) {
+        if (ego_coll) bits |= SG_TERM_EGO_COLLISION;
+        bool on_road = false;
+        if (e0_present && p.road) {
+            const RoadIndex RI = *p.road;
+            on_road = (rn_layers_at(RI, RI.net_of_scen[r], SG_LAYER_DRIVEABLE, x0, y0) & SG_LAYER_DRIVEABLE) != 0;
+        }
+        if (!on_road) bits |= SG_TERM_EGO_OFF_ROAD;
+        out[r] = bits;
     }
 }
 

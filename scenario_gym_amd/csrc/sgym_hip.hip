@@ -44,6 +44,8 @@ struct sg_handle {
     double *d_tab[2] = {nullptr, nullptr};
     std::vector<hipEvent_t> ev_pool;
     int tab_min = 16, chunk_steps = 1024, overlap = 1; // sg_set_tuning
+    unsigned char *d_reset_mask = nullptr;             // [R] sg_reset_scenarios
+    uint32_t *d_term_flags = nullptr;                  // [R] sg_terminal_flags
     void *obs_buf = nullptr;                           // device scratch of the observation calls (grown on demand)
     size_t obs_cap = 0;
     std::vector<void *> road_allocs;                   // sg_set_road_networks
@@ -173,6 +175,8 @@ extern "C" int sg_destroy(sg_handle *h)
     free_pool(h->state_allocs);
     free_pool(h->road_allocs);
     if (h->obs_buf) (void)hipFree(h->obs_buf);
+    if (h->d_reset_mask) (void)hipFree(h->d_reset_mask);
+    if (h->d_term_flags) (void)hipFree(h->d_term_flags);
     if (h->ctl_stream) (void)hipStreamSynchronize(h->ctl_stream);
     if (h->d_actions) (void)hipFree(h->d_actions);
     if (h->d_gon) (void)hipFree(h->d_gon);
@@ -273,7 +277,7 @@ static int launch_rollout(sg_handle *h, int n_steps, int do_reset, int force, co
     if (!use_tab) {
         rc = launch_main(h, n_steps, do_reset, force, d_actions, nullptr, false, &ev_next);
     } else {
-        if (do_reset && (rc = launch_main(h, 0, 1, 0, nullptr, nullptr, false, &ev_next))) return rc;
+        if (do_reset && (rc = launch_main(h, 0, do_reset, 0, nullptr, nullptr, false, &ev_next))) return rc;
         if (h->n_ctl == 0) { // nothing to integrate: the table variant reads (and ignores) one dummy row
             if (!h->d_tab[0]) {
                 HIP_TRY(h, hipMalloc((void **)&h->d_tab[0], 64 * sizeof(double)));
@@ -467,6 +471,7 @@ extern "C" int sg_upload(sg_handle *h, const sg_scenarios *sc)
     p.WV = h->WV; p.FROWS = SG_F_COLL + h->WV;
     p.sf = h->sf;
     p.ped_serial = h->ped_serial;
+    p.reset_mask = h->d_reset_mask;
     p.persist = h->cfg.persist;
     p.term_mask = h->cfg.terminal_mask;
     p.rec_cap = h->cfg.record_capacity > 0 ? h->cfg.record_capacity : 0;
@@ -542,6 +547,36 @@ extern "C" int sg_reset(sg_handle *h)
     int rc = launch_rollout(h, 0, 1, 0, nullptr);
     if (rc) return rc;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return SG_OK;
+}
+
+extern "C" int sg_reset_scenarios(sg_handle *h, const uint8_t *mask)
+{
+    if (!h || !mask) return h ? fail(h, SG_ERR_INVALID, "sg_reset_scenarios: null mask") : SG_ERR_INVALID;
+    if (!h->uploaded) return fail(h, SG_ERR_STATE, "sg_reset_scenarios: no scenarios uploaded");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    if (!h->d_reset_mask) HIP_TRY(h, hipMalloc((void **)&h->d_reset_mask, (size_t)h->R));
+    HIP_TRY(h, hipMemcpyAsync(h->d_reset_mask, mask, (size_t)h->R, hipMemcpyHostToDevice, h->stream));
+    h->p.reset_mask = h->d_reset_mask;
+    int rc = launch_rollout(h, 0, 2, 0, nullptr);
+    if (rc) return rc;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return SG_OK;
+}
+
+extern "C" int sg_terminal_flags(sg_handle *h, uint32_t *out, const uint32_t **d_out)
+{
+    if (!h || (!out && !d_out)) return h ? fail(h, SG_ERR_INVALID, "sg_terminal_flags: no output given") : SG_ERR_INVALID;
+    if (!h->uploaded) return fail(h, SG_ERR_STATE, "sg_terminal_flags: no scenarios uploaded");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    if (!h->d_term_flags) HIP_TRY(h, hipMalloc((void **)&h->d_term_flags, (size_t)h->R * sizeof(uint32_t)));
+    sg::terminal_flags_kernel<<<dim3((unsigned)h->R), dim3(64), 0, h->stream>>>(h->p, h->cfg.timestep, h->d_term_flags);
+    HIP_TRY(h, hipGetLastError());
+    if (out) {
+        HIP_TRY(h, hipMemcpyAsync(out, h->d_term_flags, (size_t)h->R * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+    }
+    if (d_out) *d_out = h->d_term_flags;
     return SG_OK;
 }
 

@@ -185,6 +185,18 @@ class RolloutEngine:
                     "sg_raster_entities")
         return out.astype(bool)
 
+    def reset_scenarios(self, mask):
+        """State.reset for the scenarios with mask[r] != 0; the others keep their state."""
+        m = np.ascontiguousarray(mask, np.uint8)
+        assert m.shape == (self.R,)
+        self._check(self.lib.sg_reset_scenarios(self.h, m.ctypes.data), "sg_reset_scenarios")
+
+    def terminal_flags(self):
+        """TERM_* bits of every scenario's current state, all four conditions evaluated: uint32 [R]."""
+        out = np.zeros(self.R, np.uint32)
+        self._check(self.lib.sg_terminal_flags(self.h, out.ctypes.data, None), "sg_terminal_flags")
+        return out
+
     def set_road_networks(self, networks, net_of_scenario):
         """Scenario.road_network of the uploaded batch.  networks: list of polygon_arrays() dicts (ring_off, vert_off, verts,
         layers; scenario_gym_amd.road_network.RoadNetwork), net_of_scenario: [R] index into it, -1 = no road network.

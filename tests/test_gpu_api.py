@@ -648,3 +648,67 @@ def test_device_resident_tick_equals_host_tick():
     assert bits_equal(sa["poses"], sb["poses"]) and bits_equal(sa["vels"], sb["vels"])
     a.close()
     b.close()
+
+
+def test_vector_env_episodes_match_oracle(oracle):
+    """VectorScenarioEnv (the loop of integrations/openaigym.py:171-226 for a batch): seeded random policies drive the
+    egos of the road-network scenarios until their episodes end (off the road / collision / max_length), environments
+    restart one by one (sg_reset_scenarios) while the others run on.  Every episode of every environment -- its length,
+    the ego pose after every tick, reward and done -- equals an oracle rollout of the same scenario with the same slice of
+    actions; the observation is the map of the state it is returned with."""
+    import scenario_gym_amd as sga
+    import scenario_gym_amd._lib as L
+
+    g = load_golden("roads")
+    names = [str(n) for n in g["scenarios"]] * 2
+    nets = {}
+    scs, arrs = [], []
+    for n in names:
+        a = scenario_arrays(g, f"{n}/scenario")
+        sc = scenario_from_arrays(a, g[f"{n}/scenario/refs"])
+        k = str(g[f"{n}/network"])
+        nets.setdefault(k, _road_network_from_golden(g, k))
+        sc.road_network = nets[k]
+        scs.append(sc)
+        arrs.append(a)
+    R, ticks = len(scs), 220
+    env = sga.VectorScenarioEnv(scs, timestep=0.1, n=32)
+    rng = np.random.default_rng(4)
+    acts = np.stack([rng.uniform(-2, 3, (ticks, R)), rng.uniform(-0.5, 0.5, (ticks, R))], -1)
+    obs = env.reset()
+    assert obs.shape == (R, 2, 32, 32) and obs[:, 0, 16, 16].all() is not None
+    start = np.zeros(R, int)   # tick at which the current episode of each env began
+    episodes = 0
+    ego_poses = [[env.engine.state()["poses"][r, arrs[r]["ego"]].copy()] for r in range(R)]
+    for k in range(ticks):
+        obs, reward, done, info = env.step(acts[k])
+        st = env.engine.state()
+        want_map = env.engine.raster_map([0, 1], 30.0, 30.0, 32, 32)
+        assert np.array_equal(obs, want_map)
+        for r in range(R):
+            a = arrs[r]
+            if not done[r]:
+                ego_poses[r].append(st["poses"][r, a["ego"]].copy())
+                assert reward[r] == 0.01
+                continue
+            # the episode that just ended: ticks start[r] .. k, against the oracle
+            E = len(a["bbox"])
+            kind = np.full(E, L.KIND_REPLAY, np.int32)
+            kind[a["ego"]] = L.KIND_AGENT_VEHICLE
+            ctrl = np.tile(oracle.DEFAULT_CTRL, (E, 1))
+            ctrl[a["ego"], L.C_MAX_STEER], ctrl[a["ego"], L.C_MAX_ACCEL] = 0.9, 5.0
+            n = k - start[r] + 1
+            o = oracle.rollout(a["knot_off"], a["knots"], a["bbox"], a["etype"], kind, a["ego"], a["t0"], a["length"], 0.1,
+                               terminal_mask=1 | 4 | 8, ctrl=ctrl, actions=np.vstack([acts[start[r]:k + 1, r], np.zeros((4, 2))]),
+                               max_steps=n + 3, road=nets[str(g[f"{names[r]}/network"])]._arrays)
+            assert o["n_steps"] == n and o["is_done"], (r, k, o["n_steps"], n)
+            assert bits_equal(np.array(ego_poses[r]), o["poses"][:n, a["ego"]]), (r, k)
+            hit = info["terminal_flags"][r] & (4 | 8)
+            assert reward[r] == (-1.0 if hit else 0.01)
+            # auto reset: the env is back at its start state
+            assert st["n_steps"][r] == 0 and st["t"][r] == a["t0"] and not st["done"][r]
+            ego_poses[r] = [st["poses"][r, a["ego"]].copy()]
+            start[r] = k + 1
+            episodes += 1
+    env.close()
+    assert episodes >= R  # every environment finished at least one episode on average
