@@ -291,6 +291,15 @@ int sg_raster_map(sg_handle *h, double width, double height, int32_t nw, int32_t
 int sg_raster_map_device(sg_handle *h, double width, double height, int32_t nw, int32_t nh, int32_t n_layers,
                          const int32_t *layers, const uint8_t **d_out);
 
+/* One tick of the external-action loop (integrations/openaigym.py:171-226) for every scenario, as one captured hipGraph:
+ * sg_step(h, 1, actions) + sg_terminal_flags + sg_raster_map_device with the given observation geometry (1..8 layers).
+ * actions: [n_scenarios][2] HOST (actions_device = 0) or DEVICE, or NULL for (0, 0).  Asynchronous: the work is queued on
+ * sg_stream(h); *d_obs (DEVICE [R][n_layers][nh][nw] bytes) and *d_flags (DEVICE [R] SG_TERM_* bits) are valid after
+ * sg_synchronize(h) until the next observation call.  The graph is rebuilt when the batch, the networks, the time step or
+ * the geometry change.  Not for batches with SG_KIND_AGENT_EXTERNAL slots. */
+int sg_tick(sg_handle *h, const double *actions, int32_t actions_device, double width, double height, int32_t nw, int32_t nh,
+            int32_t n_layers, const int32_t *layers, const uint8_t **d_obs, const uint32_t **d_flags);
+
 /* ScenarioGym.get_metrics (scenario_gym.py:308-319): out [R]; events [cap] (may be NULL) */
 int sg_read_metrics(sg_handle *h, sg_metrics *out, sg_event *events, int32_t cap, int32_t *n_events);
 

@@ -26,7 +26,7 @@ SYMBOLS = (
     "sg_set_timestep", "sg_step", "sg_rollout", "sg_rollout_async", "sg_synchronize", "sg_stream",
     "sg_state_view_get", "sg_read_metrics", "sg_read_record", "sg_copy_to_host", "sg_last_kernel_ms",
     "sg_last_launch_stats", "sg_debug_trig32", "sg_set_tuning", "sg_set_external_poses", "sg_future_collision", "sg_raster_entities",
-    "sg_set_road_networks", "sg_raster_map", "sg_raster_map_device", "sg_reset_scenarios", "sg_terminal_flags",
+    "sg_set_road_networks", "sg_raster_map", "sg_raster_map_device", "sg_reset_scenarios", "sg_terminal_flags", "sg_tick",
 )
 
 
@@ -121,6 +121,8 @@ def load():
     lib.sg_raster_entities.argtypes = [H, C.c_double, C.c_double, C.c_int32, C.c_int32, C.c_void_p]
     lib.sg_set_road_networks.argtypes = [H, C.POINTER(SgRoadNetworks)]
     lib.sg_reset_scenarios.argtypes = [H, C.c_void_p]
+    lib.sg_tick.argtypes = [H, C.c_void_p, C.c_int32, C.c_double, C.c_double, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
+                            C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
     lib.sg_terminal_flags.argtypes = [H, C.c_void_p, C.POINTER(C.c_void_p)]
     lib.sg_raster_map.argtypes = [H, C.c_double, C.c_double, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
     lib.sg_raster_map_device.argtypes = [H, C.c_double, C.c_double, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]

@@ -44,6 +44,12 @@ struct sg_handle {
     double *d_tab[2] = {nullptr, nullptr};
     std::vector<hipEvent_t> ev_pool;
     int tab_min = 16, chunk_steps = 1024, overlap = 1; // sg_set_tuning
+    // sg_tick: the kernels of one RL tick captured once as a hipGraph and replayed with a single launch
+    hipGraphExec_t tick_exec = nullptr;
+    uint64_t generation = 0, tick_gen = ~0ull;         // bumped by every call that changes what the kernels are launched with
+    double tick_w = 0, tick_h = 0;
+    int tick_nw = 0, tick_nh = 0, tick_nl = 0;
+    int32_t tick_layers[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned char *d_reset_mask = nullptr;             // [R] sg_reset_scenarios
     uint32_t *d_term_flags = nullptr;                  // [R] sg_terminal_flags
     void *obs_buf = nullptr;                           // device scratch of the observation calls (grown on demand)
@@ -177,6 +183,7 @@ extern "C" int sg_destroy(sg_handle *h)
     if (h->obs_buf) (void)hipFree(h->obs_buf);
     if (h->d_reset_mask) (void)hipFree(h->d_reset_mask);
     if (h->d_term_flags) (void)hipFree(h->d_term_flags);
+    if (h->tick_exec) (void)hipGraphExecDestroy(h->tick_exec);
     if (h->ctl_stream) (void)hipStreamSynchronize(h->ctl_stream);
     if (h->d_actions) (void)hipFree(h->d_actions);
     if (h->d_gon) (void)hipFree(h->d_gon);
@@ -343,6 +350,7 @@ extern "C" int sg_set_social_force(sg_handle *h, const sg_social_force *params)
     if (!h || !params) return SG_ERR_INVALID;
     h->sf = *params;
     h->p.sf = *params;
+    ++h->generation;
     return SG_OK;
 }
 
@@ -364,6 +372,7 @@ extern "C" int sg_upload(sg_handle *h, const sg_scenarios *sc)
         h->d_tab[b] = nullptr;
     }
     h->uploaded = false;
+    ++h->generation;
     // pedestrian agents are compiled for tiles of >= 16 lanes
     h->has_ped = false;
     for (size_t i = 0; i < (size_t)h->R * h->E; ++i) h->has_ped = h->has_ped || sc->kind[i] == SG_KIND_AGENT_PEDESTRIAN;
@@ -584,6 +593,7 @@ extern "C" int sg_set_timestep(sg_handle *h, double timestep)
 {
     if (!h || !(timestep > 0.0)) return h ? fail(h, SG_ERR_INVALID, "sg_set_timestep: timestep must be > 0") : SG_ERR_INVALID;
     h->cfg.timestep = timestep;
+    ++h->generation;
     return SG_OK;
 }
 
@@ -621,6 +631,110 @@ extern "C" int sg_step(sg_handle *h, int32_t n_steps, const double *actions, int
     int rc = launch_rollout(h, n_steps, 0, 1, d_act);
     if (rc) return rc;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return SG_OK;
+}
+
+// device scratch shared by the observation entry points: a tick of an RL loop calls them once per step, a hipMalloc /
+// hipFree pair per call would cost more than the kernels
+static int obs_scratch(sg_handle *h, size_t bytes, unsigned char **out)
+{
+    if (bytes > h->obs_cap) {
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        if (h->obs_buf) HIP_TRY(h, hipFree(h->obs_buf));
+        h->obs_buf = nullptr;
+        h->obs_cap = 0;
+        HIP_TRY(h, hipMalloc(&h->obs_buf, bytes));
+        h->obs_cap = bytes;
+        ++h->generation;
+    }
+    *out = (unsigned char *)h->obs_buf;
+    return SG_OK;
+}
+
+// One tick of the RL loop (integrations/openaigym.py:171-226) as ONE graph launch: the step with the policy's actions, the
+// terminal conditions of the new state, the map observation.  Four short kernels whose launch and synchronisation
+// overheads exceed their run time when issued one by one; captured once per (batch, observation geometry) and replayed.
+extern "C" int sg_tick(sg_handle *h, const double *actions, int32_t actions_device, double width, double height, int32_t nw,
+                       int32_t nh, int32_t n_layers, const int32_t *layers, const uint8_t **d_obs, const uint32_t **d_flags)
+{
+    if (!h) return SG_ERR_INVALID;
+    if (!h->uploaded) return fail(h, SG_ERR_STATE, "sg_tick: no scenarios uploaded");
+    if (!layers || n_layers < 1 || n_layers > 8 || nw < 1 || nh < 1 || !(width >= 0.0) || !(height >= 0.0))
+        return fail(h, SG_ERR_INVALID, "sg_tick: bad observation geometry (1..8 layers)");
+    if (h->n_ext > 0) return fail(h, SG_ERR_STATE, "sg_tick: batches with caller-run agents are driven through sg_set_external_poses + sg_step");
+    bool any_surface = false;
+    for (int k = 0; k < n_layers; ++k) {
+        const uint32_t L = (uint32_t)layers[k];
+        if (layers[k] < 0 || L > 255u || (L & (L - 1))) return fail(h, SG_ERR_INVALID, "sg_tick: layers[%d]=%d is not 0 or one SG_LAYER_* bit", k, layers[k]);
+        any_surface = any_surface || L != 0;
+    }
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    // fixed device addresses for everything the graph's kernels read or write
+    const size_t n_act = (size_t)h->R * 2;
+    if (n_act > h->actions_cap) {
+        if (h->d_actions) HIP_TRY(h, hipFree(h->d_actions));
+        h->d_actions = nullptr;
+        HIP_TRY(h, hipMalloc((void **)&h->d_actions, std::max<size_t>(n_act, 2) * sizeof(double)));
+        h->actions_cap = n_act;
+        ++h->generation;
+    }
+    if (!h->d_term_flags) { HIP_TRY(h, hipMalloc((void **)&h->d_term_flags, (size_t)h->R * sizeof(uint32_t))); ++h->generation; }
+    const size_t plane = (size_t)nw * nh, bytes = (size_t)h->R * n_layers * plane, lay_off = (bytes + 15) & ~(size_t)15;
+    unsigned char *d = nullptr;
+    int rc = obs_scratch(h, lay_off + 8 * sizeof(int32_t), &d);
+    if (rc) return rc;
+    int32_t *dl = reinterpret_cast<int32_t *>(d + lay_off);
+    const bool same = h->tick_exec && h->tick_gen == h->generation && h->tick_w == width && h->tick_h == height &&
+                      h->tick_nw == nw && h->tick_nh == nh && h->tick_nl == n_layers &&
+                      std::equal(layers, layers + n_layers, h->tick_layers);
+    if (!same) {
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        if (h->tick_exec) { HIP_TRY(h, hipGraphExecDestroy(h->tick_exec)); h->tick_exec = nullptr; }
+        HIP_TRY(h, hipMemcpy(dl, layers, (size_t)n_layers * sizeof(int32_t), hipMemcpyHostToDevice));
+        hipGraph_t graph = nullptr;
+        HIP_TRY(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+        size_t ev_next = 0;
+        h->timing_now = false;
+        h->n_launches = 0;
+        h->launch_ev.clear();
+        rc = launch_main(h, 1, 0, 1, h->d_actions, nullptr, false, &ev_next);
+        hipError_t e = hipSuccess;
+        if (!rc) {
+            sg::terminal_flags_kernel<<<dim3((unsigned)h->R), dim3(64), 0, h->stream>>>(h->p, h->cfg.timestep, h->d_term_flags);
+            e = hipGetLastError();
+        }
+        if (!rc && e == hipSuccess && any_surface && !h->has_road) e = hipMemsetAsync(d, 0, bytes, h->stream);
+        for (int k = 0; k < n_layers && !rc && e == hipSuccess; ++k)
+            if (layers[k] == 0) {
+                sg::raster_kernel<<<dim3((unsigned)h->R), dim3(256), 0, h->stream>>>(h->p, width, height, nw, nh, d + (size_t)k * plane,
+                                                                                   (int64_t)(n_layers * plane));
+                e = hipGetLastError();
+            }
+        if (!rc && e == hipSuccess && any_surface && h->has_road) {
+            sg::raster_surface_kernel<<<dim3((unsigned)h->R), dim3(256), 0, h->stream>>>(h->p, h->road, width, height, nw, nh, n_layers, dl, d);
+            e = hipGetLastError();
+        }
+        hipError_t e2 = hipStreamEndCapture(h->stream, &graph);
+        if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+        if (e != hipSuccess || e2 != hipSuccess) {
+            if (graph) (void)hipGraphDestroy(graph);
+            return fail(h, SG_ERR_HIP, "sg_tick: capture failed: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+        }
+        e = hipGraphInstantiate(&h->tick_exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (e != hipSuccess) { h->tick_exec = nullptr; return fail(h, SG_ERR_HIP, "sg_tick: hipGraphInstantiate: %s", hipGetErrorString(e)); }
+        h->tick_gen = h->generation;
+        h->tick_w = width; h->tick_h = height; h->tick_nw = nw; h->tick_nh = nh; h->tick_nl = n_layers;
+        std::copy(layers, layers + n_layers, h->tick_layers);
+    }
+    if (actions)
+        HIP_TRY(h, hipMemcpyAsync(h->d_actions, actions, n_act * sizeof(double), actions_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
+    else
+        HIP_TRY(h, hipMemsetAsync(h->d_actions, 0, n_act * sizeof(double), h->stream));
+    HIP_TRY(h, hipGraphLaunch(h->tick_exec, h->stream));
+    h->timed = false;
+    if (d_obs) *d_obs = d;
+    if (d_flags) *d_flags = h->d_term_flags;
     return SG_OK;
 }
 
@@ -811,22 +925,7 @@ extern "C" int sg_set_tuning(sg_handle *h, int32_t tab_min_steps, int32_t chunk_
     if (tab_min_steps >= 0) h->tab_min = tab_min_steps;
     if (chunk_steps > 0) h->chunk_steps = chunk_steps;
     if (overlap >= 0) h->overlap = overlap != 0;
-    return SG_OK;
-}
-
-// device scratch shared by the observation entry points: a tick of an RL loop calls them once per step, a hipMalloc /
-// hipFree pair per call would cost more than the kernels
-static int obs_scratch(sg_handle *h, size_t bytes, unsigned char **out)
-{
-    if (bytes > h->obs_cap) {
-        HIP_TRY(h, hipStreamSynchronize(h->stream));
-        if (h->obs_buf) HIP_TRY(h, hipFree(h->obs_buf));
-        h->obs_buf = nullptr;
-        h->obs_cap = 0;
-        HIP_TRY(h, hipMalloc(&h->obs_buf, bytes));
-        h->obs_cap = bytes;
-    }
-    *out = (unsigned char *)h->obs_buf;
+    ++h->generation;
     return SG_OK;
 }
 
@@ -1048,6 +1147,7 @@ extern "C" int sg_set_road_networks(sg_handle *h, const sg_road_networks *in)
     h->road = R;
     h->p.road = dR;
     h->has_road = true;
+    ++h->generation;
     return SG_OK;
 }
 

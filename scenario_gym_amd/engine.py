@@ -250,6 +250,47 @@ class RolloutEngine:
             ent[2], ent[3] = ptr.value, torch.as_tensor(_Arr(), device=f"cuda:{self.cfg.device}")
         return ent[3]
 
+    def tick(self, actions, layers, width=20.0, height=20.0, nw=20, nh=20, torch_out=False):
+        """One RL tick as one graph launch (sg_tick): step(1, actions) + terminal_flags + raster_map.  actions [R, 2]: numpy,
+        a float64 torch tensor on the device, or None.  Returns (obs [R, n_layers, nh, nw], flags [R]): numpy arrays (bool /
+        uint32), or with torch_out zero-copy torch views (uint8 / int32) valid until the next observation call."""
+        key = ("tick", tuple(layers), int(nw), int(nh))
+        cache = self.__dict__.setdefault("_map_views", {})
+        ent = cache.get(key)
+        if ent is None:
+            ent = cache[key] = [np.ascontiguousarray(layers, np.int32), C.c_void_p(), C.c_void_p(), None, None, None]
+        lay, d_obs, d_fl = ent[0], ent[1], ent[2]
+        ptr, on_device = None, 0
+        if actions is not None and hasattr(actions, "data_ptr") and getattr(actions, "is_cuda", False):
+            import torch
+
+            assert actions.dtype == torch.float64 and actions.is_contiguous() and actions.numel() == self.R * 2
+            torch.cuda.current_stream(actions.device).synchronize()
+            ptr, on_device = actions.data_ptr(), 1
+        elif actions is not None:
+            actions = np.ascontiguousarray(actions, np.float64).reshape(self.R, 2)
+            ptr = actions.ctypes.data
+        self._check(self.lib.sg_tick(self.h, ptr, on_device, float(width), float(height), key[2], key[3], len(lay),
+                                     lay.ctypes.data, C.byref(d_obs), C.byref(d_fl)), "sg_tick")
+        self._check(self.lib.sg_synchronize(self.h), "sg_synchronize")
+        shape = (self.R, len(lay), key[3], key[2])
+        if not torch_out:
+            obs, fl = np.empty(shape, np.uint8), np.empty(self.R, np.uint32)
+            self._check(self.lib.sg_copy_to_host(self.h, d_obs, obs.ctypes.data, obs.nbytes), "sg_copy_to_host")
+            self._check(self.lib.sg_copy_to_host(self.h, d_fl, fl.ctypes.data, fl.nbytes), "sg_copy_to_host")
+            return obs.astype(bool), fl
+        if ent[3] != (d_obs.value, d_fl.value):
+            import torch
+
+            def view(p, shp, typestr):
+                class _Arr:
+                    __cuda_array_interface__ = dict(shape=shp, typestr=typestr, data=(int(p), False), version=2)
+                return torch.as_tensor(_Arr(), device=f"cuda:{self.cfg.device}")
+
+            ent[3] = (d_obs.value, d_fl.value)
+            ent[4], ent[5] = view(d_obs.value, shape, "|u1"), view(d_fl.value, (self.R,), "<i4")
+        return ent[4], ent[5]
+
     def rollout(self, max_steps):
         self._check(self.lib.sg_rollout(self.h, int(max_steps)), "sg_rollout")
 

@@ -6,9 +6,9 @@ ego's rasterized-map observation, the agent's reward and `state.is_done` (:171-2
 terminal_conditions ["max_length", "ego_collision", "ego_off_road"] (:93-94), `VehicleController(max_steer=0.9,
 max_accel=5.0)` and `MapOnlySensor(channels_first=True, height=30, width=30, n=128)` with the default layers
 (entity, driveable_surface) (:280-293), reward -1 for a done state that is off the road or in an ego collision and 0.01
-otherwise (:300-310).  `VectorScenarioEnv` is that loop for R scenarios at once: one `sg_step` with the [R, 2] actions,
-one `sg_terminal_flags`, one `sg_raster_map` per tick, and `sg_reset_scenarios` for the environments whose episode
-ended.  No arithmetic of the environment runs on the host.
+otherwise (:300-310).  `VectorScenarioEnv` is that loop for R scenarios at once: one `sg_tick` per tick (the step with the
+[R, 2] actions, the terminal conditions and the map observation replayed as one captured hipGraph) and
+`sg_reset_scenarios` for the environments whose episode ended.  No arithmetic of the environment runs on the host.
 """
 from typing import Optional, Sequence
 
@@ -80,11 +80,12 @@ class VectorScenarioEnv:
         `step` does."""
         if not self.auto_reset and self.done.any():
             raise ValueError("Step called when state is terminal.")
-        if hasattr(actions, "data_ptr"):
-            self.engine.step(1, actions.reshape(1, self.n_envs, 2))
-        else:
-            self.engine.step(1, np.asarray(actions, np.float64).reshape(1, self.n_envs, 2))
-        flags = self.engine.terminal_flags()
+        if not hasattr(actions, "data_ptr"):
+            actions = np.asarray(actions, np.float64).reshape(self.n_envs, 2)
+        # step + terminal conditions + observation: one captured graph launch (sg_tick)
+        obs, flags = self.engine.tick(actions, self._codes, self.width, self.height, self.n, self.n, torch_out=self.torch_obs)
+        if self.torch_obs:
+            flags = flags.cpu().numpy().astype(np.uint32)
         done = (flags & self._mask) != 0
         bad = (flags & (L.TERM_EGO_OFF_ROAD | L.TERM_EGO_COLLISION)) != 0
         reward = np.where(done & bad, -1.0, 0.01)  # RLAgent.reward, openaigym.py:300-310
@@ -92,7 +93,8 @@ class VectorScenarioEnv:
         if self.auto_reset and done.any():
             self.engine.reset_scenarios(done)
             self.done = np.zeros(self.n_envs, bool)
-        return self._observe(), reward, done, {"terminal_flags": flags}
+            obs = self._observe()  # the restarted environments return the first observation of their new episode
+        return obs, reward, done, {"terminal_flags": flags}
 
     def close(self):
         self.engine.close()

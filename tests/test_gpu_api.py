@@ -712,3 +712,60 @@ def test_vector_env_episodes_match_oracle(oracle):
             episodes += 1
     env.close()
     assert episodes >= R  # every environment finished at least one episode on average
+
+
+def test_graph_tick_equals_separate_calls():
+    """sg_tick (step + terminal flags + map observation replayed as one captured hipGraph) against the three separate calls,
+    tick by tick: same state, same flags, same maps -- through restarts of single scenarios, a change of the time step, a
+    change of the observation geometry and a new batch on the same handle (each rebuilds the graph)."""
+    import torch
+
+    import scenario_gym_amd as sga
+    import scenario_gym_amd._lib as L
+    from scenario_gym_amd import synthetic
+
+    R, E = 96, 10
+    packed = synthetic.make_batch(R, E, n_steps=150, ego_kind=L.KIND_AGENT_VEHICLE, extent=14.0)
+    acts = synthetic.make_actions(80, R)
+    sq = np.array([[-9.0, -9.0], [12.0, -9.0], [12.0, 10.0], [-9.0, 10.0]])
+    net = dict(ring_off=[0, 1], vert_off=[0, 4], verts=sq, layers=[1 | 2])
+    a, b = sga.RolloutEngine(R, E, terminal_conditions=["max_length", "ego_collision", "ego_off_road"]), \
+        sga.RolloutEngine(R, E, terminal_conditions=["max_length", "ego_collision", "ego_off_road"])
+    for e in (a, b):
+        e.upload(packed)
+        e.set_road_networks([net], np.zeros(R, np.int32))
+    geo = dict(layers=[0, 1], width=24.0, height=24.0, nw=16, nh=16)
+    at = torch.as_tensor(acts, device="cuda:0")
+    for k in range(60):
+        if k == 20:  # restart the scenarios that are done, on both
+            m = a.state()["done"]
+            assert m.any()
+            a.reset_scenarios(m)
+            b.reset_scenarios(m)
+        if k == 30:
+            a.lib.sg_set_timestep(a.h, 0.05)
+            b.lib.sg_set_timestep(b.h, 0.05)
+        if k == 40:
+            geo = dict(layers=[2, 0, 1], width=30.0, height=18.0, nw=20, nh=12)
+        a.step(1, acts[k:k + 1])
+        want_fl, want_map = a.terminal_flags(), a.raster_map(geo["layers"], geo["width"], geo["height"], geo["nw"], geo["nh"])
+        if k % 2:
+            obs, fl = b.tick(acts[k], **geo)
+        else:
+            obs, fl = b.tick(at[k], torch_out=True, **geo)
+            obs, fl = obs.cpu().numpy().astype(bool), fl.cpu().numpy().astype(np.uint32)
+        assert np.array_equal(fl, want_fl) and np.array_equal(obs, want_map), k
+    sa, sb = a.state(), b.state()
+    for key in ("poses", "vels", "dists", "ctrl_state", "t", "n_steps", "done"):
+        assert bits_equal(sa[key], sb[key]), key
+    # a new batch on the same handle
+    packed2 = synthetic.make_batch(R, E, n_steps=150, ego_kind=L.KIND_AGENT_VEHICLE, extent=14.0, seed=77)
+    for e in (a, b):
+        e.upload(packed2)
+        e.set_road_networks([net], np.zeros(R, np.int32))
+    a.step(1, acts[0:1])
+    obs, fl = b.tick(acts[0], **geo)
+    assert np.array_equal(fl, a.terminal_flags()) and bits_equal(a.state()["poses"], b.state()["poses"])
+    assert np.array_equal(obs, a.raster_map(geo["layers"], geo["width"], geo["height"], geo["nw"], geo["nh"]))
+    a.close()
+    b.close()

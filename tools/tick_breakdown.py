@@ -36,3 +36,26 @@ for k in range(N + 50):
     if k >= 50:
         T["step"] += t1 - t0; T["raster"] += t2 - t1; T["sync"] += t3 - t2
 print({k: round(v / N * 1e6, 1) for k, v in T.items()}, "us per tick; total", round(sum(T.values()) / N * 1e6, 1))
+
+# the same three pieces + terminal flags, separately vs as one captured graph (sg_tick), on an engine with the RL default
+# terminal conditions (rollout_kernel_road)
+eng.close()
+eng = sga.RolloutEngine(R, E, terminal_conditions=["max_length", "ego_collision", "ego_off_road"])
+eng.upload(packed); eng.set_road_networks([net], np.zeros(R, np.int32)); eng.step(300)
+lib, h = eng.lib, eng.h
+dfl = C.c_void_p()
+for mode in ("separate", "graph"):
+    t_acc = 0.0
+    for k in range(N + 50):
+        a = acts[k:k + 1]
+        t0 = time.perf_counter()
+        if mode == "separate":
+            lib.sg_step(h, 1, a.data_ptr(), 1)
+            lib.sg_terminal_flags(h, None, C.byref(dfl))
+            lib.sg_raster_map_device(h, 20.0, 20.0, 20, 20, 2, lay.ctypes.data, C.byref(ptr))
+        else:
+            lib.sg_tick(h, a.data_ptr(), 1, 20.0, 20.0, 20, 20, 2, lay.ctypes.data, C.byref(ptr), C.byref(dfl))
+        lib.sg_synchronize(h)
+        if k >= 50:
+            t_acc += time.perf_counter() - t0
+    print(mode, round(t_acc / N * 1e6, 1), "us per tick (C calls + final sync)")

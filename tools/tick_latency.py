@@ -102,3 +102,18 @@ dt = (time.perf_counter() - t0) / 500
 print(f"RL tick, device-resident (actions from a torch tensor, 20x20x2 map as a torch view, {R} envs): {dt*1e6:.0f} us = "
       f"{R/dt/1e6:.1f} M env-steps/s; obs {tuple(obs.shape)} {obs.dtype}, driveable {100*obs[:, 1].float().mean().item():.1f} %")
 eng.close()
+
+# the whole tick as one captured hipGraph (sg_tick): step + terminal flags + map, outputs left in HBM
+eng = sga.RolloutEngine(R, E, terminal_conditions=["max_length", "ego_collision", "ego_off_road"])
+eng.upload(packed)
+eng.set_road_networks([net], np.zeros(R, np.int32))
+eng.step(300)
+for k in range(20):
+    eng.tick(act_t[k], [0, 1], torch_out=True)
+t0 = time.perf_counter()
+for k in range(20, 520):
+    obs, fl = eng.tick(act_t[k], [0, 1], torch_out=True)
+dt = (time.perf_counter() - t0) / 500
+print(f"RL tick as one hipGraph launch (sg_tick: step + terminal flags + 20x20x2 map, device-resident, {R} envs): {dt*1e6:.0f} us = "
+      f"{R/dt/1e6:.1f} M env-steps/s; {int((fl != 0).sum())} envs terminal")
+eng.close()
