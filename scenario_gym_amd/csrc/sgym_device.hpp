@@ -2189,7 +2189,7 @@ __global__ __launch_bounds__(64 * WV, PED ? SG_WAVES_PER_SIMD_PED : (TAB ? SG_WA
 
 // terminal_conditions with "ego_off_road": controllers in the kernel, road index lookups for slot 0
 template <int G, int WV>
-__global__ __launch_bounds__(64 * WV, 1) void rollout_kernel_road(
+__global__ __launch_bounds__(64 * WV, SG_WAVES_PER_SIMD) void rollout_kernel_road(
     Params p, double timestep, int n_steps, int do_reset, int force, const double *actions, const double *tab)
 {
     rollout_body<G, WV, false, false, false, true>(p, timestep, n_steps, do_reset, force, actions, tab);
