@@ -770,6 +770,94 @@ static double route_project(const double *wp, int n, double px, double py)
     return best_s;
 }
 
+/* ---- boundary terms of the social force, pedestrian/social_force.py:86-104, 190-211 ------------------------------
+ * force += U / R * r_unit * exp(-|r| / R) with r = position - nearest_points(surface, Point(position))[0].
+ * shapely's nearest_points is GEOS DistanceOp (not part of the reference sources; restated from its published
+ * algorithm): a point inside (or on) an areal geometry is its own nearest point -- so the "walkable boundary" term,
+ * which the reference only evaluates for a pedestrian INSIDE the walkable surface, is always the zero vector, and so is
+ * the impenetrable term inside a building; outside, every ring segment is tried in order, Distance::pointToSegment
+ * picks the nearest (first one on ties) and LineSegment::closestPoint gives the point. */
+static double pt_dist(double ax, double ay, double bx, double by)
+{
+    const double dx = ax - bx, dy = ay - by;
+    return sqrt(dx * dx + dy * dy);
+}
+
+static double point_to_segment(double px, double py, double ax, double ay, double bx, double by)
+{
+    if (ax == bx && ay == by) return pt_dist(px, py, ax, ay);
+    const double len2 = (bx - ax) * (bx - ax) + (by - ay) * (by - ay);
+    const double r = ((px - ax) * (bx - ax) + (py - ay) * (by - ay)) / len2;
+    if (r <= 0.0) return pt_dist(px, py, ax, ay);
+    if (r >= 1.0) return pt_dist(px, py, bx, by);
+    const double s = ((ay - py) * (bx - ax) - (ax - px) * (by - ay)) / len2;
+    return fabs(s) * sqrt(len2);
+}
+
+static void segment_closest_point(double px, double py, double ax, double ay, double bx, double by, double *cx, double *cy)
+{
+    double factor;
+    if (px == ax && py == ay) factor = 0.0;
+    else if (px == bx && py == by) factor = 1.0;
+    else {
+        const double dx = bx - ax, dy = by - ay, len = dx * dx + dy * dy;
+        factor = len <= 0.0 ? NAN : ((px - ax) * dx + (py - ay) * dy) / len;
+    }
+    if (factor > 0.0 && factor < 1.0) { /* LineSegment::project */
+        *cx = ax + factor * (bx - ax);
+        *cy = ay + factor * (by - ay);
+        return;
+    }
+    if (pt_dist(ax, ay, px, py) < pt_dist(bx, by, px, py)) { *cx = ax; *cy = ay; }
+    else { *cx = bx; *cy = by; }
+}
+
+/* does the union of the polygons of `layer` have a positive area (`surface.area > 0`)? */
+static int surface_has_area(const sgo_road_network *net, uint32_t layer)
+{
+    if (!net) return 0;
+    for (int k = 0; k < net->n_polygons; ++k) {
+        if (!(net->layers[k] & layer)) continue;
+        double a2 = 0.0;
+        for (int64_t r = net->ring_off[k]; r < net->ring_off[k + 1]; ++r) {
+            const int64_t a = net->vert_off[r], b = net->vert_off[r + 1];
+            for (int64_t i = a; i < b; ++i) {
+                const int64_t j = i + 1 < b ? i + 1 : a;
+                a2 += net->verts[2 * i] * net->verts[2 * j + 1] - net->verts[2 * j] * net->verts[2 * i + 1];
+            }
+        }
+        if (a2 != 0.0) return 1;
+    }
+    return 0;
+}
+
+/* _force_boundary for a point OUTSIDE the surface: accumulates sign * force into (fx, fy) */
+static void boundary_force_outside(const sgo_road_network *net, uint32_t layer, double px, double py, double U, double R,
+                                   double sign, double *fx, double *fy)
+{
+    double best = INFINITY, cx = px, cy = py;
+    for (int k = 0; k < net->n_polygons; ++k) {
+        if (!(net->layers[k] & layer)) continue;
+        for (int64_t r = net->ring_off[k]; r < net->ring_off[k + 1]; ++r) {
+            const int64_t a = net->vert_off[r], b = net->vert_off[r + 1];
+            for (int64_t i = a; i < b; ++i) {
+                const int64_t j = i + 1 < b ? i + 1 : a;
+                const double ax = net->verts[2 * i], ay = net->verts[2 * i + 1], bx = net->verts[2 * j], by = net->verts[2 * j + 1];
+                const double d = point_to_segment(px, py, ax, ay, bx, by);
+                if (d < best) {
+                    best = d;
+                    segment_closest_point(px, py, ax, ay, bx, by, &cx, &cy);
+                }
+            }
+        }
+    }
+    const double rx = px - cx, ry = py - cy, rn = norm2(rx, ry);
+    const double ux = rx / (rn + 0.0000000001), uy = ry / (rn + 0.0000000001);
+    const double k = U / R, e = sgo_exp(-rn / R);
+    *fx += sign * (k * ux * e);
+    *fy += sign * (k * uy * e);
+}
+
 typedef struct { double speed; int goal_idx; double fx, fy; } ped_state;
 
 /* one PedestrianAgent.step: returns the new pose in np_ */
@@ -842,6 +930,21 @@ static void ped_step(const sgo_scenario *sc, const sgo_config *cfg, int i, const
             } else {
                 fx += attx; fy += atty;
                 fx += repx; fy += repy;
+            }
+        }
+        if (sc->road) { /* boundary terms, social_force.py:86-104 */
+            const double px = pose[0], py = pose[1];
+            if (surface_has_area(sc->road, SGO_LAYER_WALKABLE) && sgo_surface_contains(sc->road, SGO_LAYER_WALKABLE, px, py)) {
+                fx += 0.0; /* the point is its own nearest point: U / R * (0 / 1e-10) * exp(-0 / R) */
+                fy += 0.0;
+            }
+            if (surface_has_area(sc->road, SGO_LAYER_IMPENETRABLE)) {
+                if (sgo_surface_contains(sc->road, SGO_LAYER_IMPENETRABLE, px, py)) {
+                    fx += -0.0; /* sign -1, zero force */
+                    fy += -0.0;
+                } else {
+                    boundary_force_outside(sc->road, SGO_LAYER_IMPENETRABLE, px, py, sf[SGO_SF_IMP_U], sf[SGO_SF_IMP_R], 1.0, &fx, &fy);
+                }
             }
         }
         /* noise is off: np.random.normal(bias, 0) == bias */

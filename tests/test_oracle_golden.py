@@ -441,3 +441,30 @@ def test_ego_off_road_terminal_matches_reference(oracle):
                            s["length"], 0.1, terminal_mask=oracle.TERM_EGO_OFF_ROAD)
         assert o["n_steps"] == 1
     assert stopped_early >= 2
+
+
+@pytest.mark.parametrize("si", [0, 1])
+def test_pedestrians_beside_a_building(oracle, si):
+    """The boundary terms of the social force (pedestrian/social_force.py:86-104, 190-211) on the road network of
+    examples/crowds.py (road, pavements, one building): a crowd walking along the pavement beside the building wall, some
+    starting inside the building.  The repulsion from the wall reaches 19 (U / R = 20); reference closed loops at two time
+    steps.  Without the road network the same crowd walks elsewhere."""
+    g = load_golden("ped_roads")
+    sc, kind, ctrl, roff, routes = ped_inputs(g, si, oracle)
+    E = len(kind)
+    net = oracle.RoadNetworkArrays({k: g[f"net/{k}"] for k in ("ring_off", "vert_off", "verts", "layers")})
+    for dtn, dt in (("dt30", 1 / 30), ("dt10", 0.1)):
+        p = f"loop{si}/{dtn}"
+        o = oracle.rollout(**sc, kind=kind, dt=dt, ctrl=ctrl, route_off=roff, routes=routes, road=net)
+        assert o["n_steps"] == int(g[p + "/n_steps"]) and bits_equal(o["t"], g[p + "/t"])
+        for k in ("poses", "vels", "dists"):
+            assert np.array_equal(np.isnan(o[k]), np.isnan(g[p + "/" + k]))
+            assert np.nanmax(np.abs(o[k] - g[p + "/" + k])) < PED_TOL, (p, k)
+        ex = g[p + "/extra"]
+        ped = ~np.isnan(ex[0, :, 0])
+        assert np.array_equal(o["extra"][:, ped, 1], ex[:, ped, 1])
+        assert np.abs(o["extra"][:, ped] - ex[:, ped]).max() < PED_TOL
+        assert np.abs(ex[:, ped, 2:]).max() > 15  # the wall is felt
+        assert np.array_equal(oracle.coll_to_dense(o["coll"], E), g[p + "/coll"])
+        free = oracle.rollout(**sc, kind=kind, dt=dt, ctrl=ctrl, route_off=roff, routes=routes)
+        assert np.nanmax(np.abs(free["poses"] - g[p + "/poses"][: len(free["poses"])])) > 0.1
