@@ -137,7 +137,11 @@ typedef struct {
     double sight_weight, sight_weight_use;
     double cos_sight;        /* cos(sight_angle / 2 * pi / 180), computed by the caller */
     double max_speed_factor, bias_lon, bias_lat;
-    double reserved[2];
+    /* repulsion from the impenetrable surface (buildings) of the scenario's road network, social_force.py:97-104; acts
+     * when sg_set_road_networks has been called.  (The "walkable boundary" term :86-95 is evaluated only for a pedestrian
+     * inside the walkable surface, where shapely's nearest point is the pedestrian itself: it is the zero vector whatever
+     * boundary_repulse_U / R are, so they are not parameters here.) */
+    double imp_boundary_repulse_U, imp_boundary_repulse_R;
 } sg_social_force;
 
 /* Device-resident state after the latest step: the arrays behind State.poses / velocities /

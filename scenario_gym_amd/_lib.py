@@ -51,7 +51,7 @@ class SgRoadNetworks(C.Structure):
 class SgSocialForce(C.Structure):
     _fields_ = [(n, C.c_double) for n in
                 ("relaxation_time", "ped_repulse_V", "ped_repulse_sigma", "ped_attract_C", "sight_weight",
-                 "sight_weight_use", "cos_sight", "max_speed_factor", "bias_lon", "bias_lat", "reserved0", "reserved1")]
+                 "sight_weight_use", "cos_sight", "max_speed_factor", "bias_lon", "bias_lat", "imp_boundary_repulse_U", "imp_boundary_repulse_R")]
 
 
 class SgStateView(C.Structure):

@@ -345,7 +345,8 @@ class SocialForce:
         return dict(relaxation_time=p.relaxation_time, ped_repulse_V=p.ped_repulse_V,
                     ped_repulse_sigma=p.ped_repulse_sigma, ped_attract_C=p.ped_attract_C,
                     sight_weight=p.sight_weight, sight_weight_use=p.sight_weight_use, sight_angle=p.sight_angle,
-                    max_speed_factor=p.max_speed_factor, bias_lon=p.bias_lon, bias_lat=p.bias_lat)
+                    max_speed_factor=p.max_speed_factor, bias_lon=p.bias_lon, bias_lat=p.bias_lat,
+                    imp_boundary_repulse_U=p.imp_boundary_repulse_U, imp_boundary_repulse_R=p.imp_boundary_repulse_R)
 
 
 class PedestrianSensor(Sensor):
@@ -376,11 +377,29 @@ class PedestrianAgent(Agent):
                          PedestrianSensor(entity, head_rot_angle=head_rot_angle, distance_threshold=distance_threshold))
         if not isinstance(behaviour, SocialForce):
             raise NotImplementedError("only the SocialForce behaviour is lowered to the device")
-        self.goal_idx = 0
         self.speed_desired = speed_desired
         self.behaviour = behaviour
-        self.force = np.array([0.0, 0.0])
         self.route = np.asarray(route, np.float64).reshape(-1, 2)
+        self._bound = None  # (gym, scenario index, entity slot) once the scenario is on the device
+
+    def _bind(self, gym, i: int, slot: int):
+        self._bound = (gym, i, slot)
+
+    @property
+    def force(self) -> np.ndarray:
+        """PedestrianAgent.force (pedestrian/agent.py:63): the social force of the latest step, read from the device state."""
+        if self._bound is None:
+            return np.array([0.0, 0.0])
+        gym, i, slot = self._bound
+        return gym._fetch_state()["force"][i, slot].copy()
+
+    @property
+    def goal_idx(self) -> int:
+        """Index of the waypoint the pedestrian walks towards (pedestrian/agent.py:59-62), from the device state."""
+        if self._bound is None:
+            return 0
+        gym, i, slot = self._bound
+        return int(gym._fetch_state()["ctrl_state"][i, slot, 1])
 
     def device_kind(self):
         return L.KIND_AGENT_PEDESTRIAN

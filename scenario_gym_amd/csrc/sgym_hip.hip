@@ -155,7 +155,7 @@ extern "C" int sg_create(const sg_config *cfg, sg_handle **out)
     h->WV = h->E <= 64 ? 1 : (h->E <= 128 ? 2 : 4); // wavefronts per scenario
     h->EP = G * h->WV;
     // SocialForceParameters defaults, pedestrian/social_force.py:16-30 (noise off)
-    h->sf = sg_social_force{1.5, 1.0, 1.0, 0.0, 0.5, 1.0, std::cos(200.0 / 2 * M_PI / 180), 1.3, 0.0, 0.0, {0.0, 0.0}};
+    h->sf = sg_social_force{1.5, 1.0, 1.0, 0.0, 0.5, 1.0, std::cos(200.0 / 2 * M_PI / 180), 1.3, 0.0, 0.0, 2.0, 0.1};
     h->NE = (((size_t)h->R * h->EP + 63) / 64) * 64;
     h->tab_min = env_int("SG_TAB_MIN_STEPS", h->tab_min);
     h->chunk_steps = env_int("SG_CHUNK_STEPS", h->chunk_steps);
@@ -959,12 +959,16 @@ struct RoadBuild {
     std::vector<double> edges;
     std::vector<int64_t> poly_edge_off;
     std::vector<uint32_t> poly_layers;
+    std::vector<uint32_t> net_flags;   // bit 0: walkable surface has area, bit 1: impenetrable surface has area
+    std::vector<int64_t> imp_off;      // per network: range of imp_edges
+    std::vector<double> imp_edges;     // the ring edges of the impenetrable polygons, polygon by polygon
 };
 
 int build_road_network(const sg_road_networks *in, int n, RoadBuild &B)
 {
     const int64_t q0 = in->poly_off[n], q1 = in->poly_off[n + 1];
     double lo[2] = {INFINITY, INFINITY}, hi[2] = {-INFINITY, -INFINITY};
+    uint32_t flags = 0;
     for (int64_t q = q0; q < q1; ++q) {
         for (int64_t r = in->ring_off[q]; r < in->ring_off[q + 1]; ++r) {
             const int64_t a = in->vert_off[r], b = in->vert_off[r + 1];
@@ -977,7 +981,17 @@ int build_road_network(const sg_road_networks *in, int n, RoadBuild &B)
         }
         B.poly_edge_off.push_back((int64_t)B.edges.size() / 4);
         B.poly_layers.push_back(in->layers[q]);
+        {   // `surface.area > 0` (social_force.py:87, 97) and the edge list the nearest-point search walks
+            const int64_t e0 = B.poly_edge_off[B.poly_edge_off.size() - 2], e1 = B.poly_edge_off.back();
+            double a2 = 0.0;
+            for (int64_t i = e0; i < e1; ++i) a2 += B.edges[4 * i] * B.edges[4 * i + 3] - B.edges[4 * i + 2] * B.edges[4 * i + 1];
+            if (a2 != 0.0 && (in->layers[q] & SG_LAYER_WALKABLE)) flags |= 1u;
+            if (a2 != 0.0 && (in->layers[q] & SG_LAYER_IMPENETRABLE)) flags |= 2u;
+            if (in->layers[q] & SG_LAYER_IMPENETRABLE) B.imp_edges.insert(B.imp_edges.end(), B.edges.begin() + 4 * e0, B.edges.begin() + 4 * e1);
+        }
     }
+    B.net_flags.push_back(flags);
+    B.imp_off.push_back((int64_t)B.imp_edges.size() / 4);
     sg::RoadNet N{};
     N.cell_base = (int64_t)B.cells.size();
     if (!(lo[0] <= hi[0])) { // no geometry: an empty 1 x 1 grid
@@ -1118,6 +1132,7 @@ extern "C" int sg_set_road_networks(sg_handle *h, const sg_road_networks *in)
     h->p.road = nullptr;
     RoadBuild B;
     B.poly_edge_off.push_back(0);
+    B.imp_off.push_back(0);
     for (int n = 0; n < in->n_networks; ++n)
         if (int brc = build_road_network(in, n, B))
             return fail(h, SG_ERR_INVALID, "sg_set_road_networks: network %d cannot be indexed (%s)", n,
@@ -1126,7 +1141,8 @@ extern "C" int sg_set_road_networks(sg_handle *h, const sg_road_networks *in)
     if (B.cand.empty()) B.cand.push_back(sg::RoadCand{});
     if (B.cand_edges.empty()) B.cand_edges.push_back(0);
     if (B.edges.empty()) B.edges.assign(4, 0.0);
-    if (B.nets.empty()) { B.nets.push_back(sg::RoadNet{0.0, 0.0, 1.0, 1, 1, 0}); B.cells.push_back(0); B.cell_off.insert(B.cell_off.begin(), 0u); }
+    if (B.nets.empty()) { B.nets.push_back(sg::RoadNet{0.0, 0.0, 1.0, 1, 1, 0}); B.cells.push_back(0); B.cell_off.insert(B.cell_off.begin(), 0u); B.net_flags.push_back(0); B.imp_off.push_back(0); }
+    if (B.imp_edges.empty()) B.imp_edges.assign(4, 0.0);
     std::vector<int32_t> nos(in->net_of_scenario, in->net_of_scenario + h->R);
     auto &A = h->road_allocs;
     sg::RoadIndex R{};
@@ -1139,6 +1155,9 @@ extern "C" int sg_set_road_networks(sg_handle *h, const sg_road_networks *in)
     if ((rc = dev_upload(h, A, &R.cand_edges, B.cand_edges))) return rc;
     if ((rc = dev_upload(h, A, &R.edges, B.edges))) return rc;
     if ((rc = dev_upload(h, A, &R.poly_layers, B.poly_layers))) return rc;
+    if ((rc = dev_upload(h, A, &R.net_flags, B.net_flags))) return rc;
+    if ((rc = dev_upload(h, A, &R.imp_off, B.imp_off))) return rc;
+    if ((rc = dev_upload(h, A, &R.imp_edges, B.imp_edges))) return rc;
     R.n_nets = in->n_networks;
     std::vector<sg::RoadIndex> one(1, R);
     const sg::RoadIndex *dR = nullptr;

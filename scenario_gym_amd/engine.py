@@ -101,12 +101,12 @@ class RolloutEngine:
 
     def set_social_force(self, relaxation_time=1.5, ped_repulse_V=1.0, ped_repulse_sigma=1.0, ped_attract_C=0.0,
                          sight_weight=0.5, sight_weight_use=True, sight_angle=200, max_speed_factor=1.3,
-                         bias_lon=0.0, bias_lat=0.0):
+                         bias_lon=0.0, bias_lat=0.0, imp_boundary_repulse_U=2.0, imp_boundary_repulse_R=0.1):
         """SocialForceParameters of every pedestrian agent on this handle (pedestrian/social_force.py:16-30);
         call before upload()."""
         sf = L.SgSocialForce(relaxation_time, ped_repulse_V, ped_repulse_sigma, ped_attract_C, sight_weight,
                              float(bool(sight_weight_use)), float(np.cos(sight_angle / 2 * np.pi / 180)),
-                             max_speed_factor, bias_lon, bias_lat, 0.0, 0.0)
+                             max_speed_factor, bias_lon, bias_lat, imp_boundary_repulse_U, imp_boundary_repulse_R)
         self._check(self.lib.sg_set_social_force(self.h, C.byref(sf)), "sg_set_social_force")
 
     # ------------------------------------------------------------------ plumbing

@@ -141,9 +141,15 @@ class BatchedScenarioGym:
             event_capacity=self.event_capacity, device=self.device, social_force=sf)
         self.engine.upload(packed)
         self._roads_set = False
-        if "ego_off_road" in dev_terms:
+        # the road network reaches the device when the rollout itself needs it: the ego_off_road terminal condition, and
+        # pedestrian agents (the boundary terms of the social force, social_force.py:86-104)
+        if "ego_off_road" in dev_terms or (sf is not None and any(sc.road_network is not None for sc in self.scenarios)):
             self._set_road_networks()
         self.states = [State(self, i, sc, agents[i], self.persist) for i, sc in enumerate(self.scenarios)]
+        for i, sc in enumerate(self.scenarios):
+            for e, a in agents[i].items():
+                if hasattr(a, "_bind"):
+                    a._bind(self, i, sc.entities.index(e))
         from . import _lib as L
         self._host_agents = [(i, sc.entities.index(e), a) for i, sc in enumerate(self.scenarios)
                              for e, a in agents[i].items() if a.device_kind() == L.KIND_AGENT_EXTERNAL]

@@ -769,3 +769,35 @@ def test_graph_tick_equals_separate_calls():
     assert np.array_equal(obs, a.raster_map(geo["layers"], geo["width"], geo["height"], geo["nw"], geo["nh"]))
     a.close()
     b.close()
+
+
+def test_pedestrian_agents_beside_a_building_through_the_gym():
+    """PedestrianAgent + SocialForce on a scenario whose road network has a building (examples/crowds.py:149-205): the gym
+    hands the network to the device by itself; the reference's closed loop is reproduced (<= 1e-8)."""
+    import scenario_gym_amd as sga
+    from scenario_gym_amd.road_network import RoadNetwork
+
+    g = load_golden("ped_roads")
+    rn = RoadNetwork(name="crowds")
+    rn._arrays = {k: g[f"net/{k}"] for k in ("ring_off", "vert_off", "verts", "layers")}
+    si, dt, p = 0, 0.1, "loop0/dt10"
+    sc = scenario_from_arrays(scenario_arrays(g, f"loop{si}/scenario"), g[f"loop{si}/scenario/refs"])
+    sc.road_network = rn
+    routes, vdes, thr = g[f"loop{si}/routes"], g[f"loop{si}/vdes"], float(g[f"loop{si}/distance_threshold"])
+    idx = {e.ref: k for k, e in enumerate(sc.entities)}
+
+    def create_agent(s, e):
+        if e.ref == "ego":
+            return sga.ReplayTrajectoryAgent(e)
+        return sga.PedestrianAgent(e, routes[idx[e.ref]], vdes[idx[e.ref]],
+                                   sga.SocialForce(sga.SocialForceParameters(std_lon=0.0, std_lat=0.0)), distance_threshold=thr)
+
+    gym = sga.ScenarioGym(timestep=dt)
+    gym.set_scenario(sc, create_agent=create_agent)
+    gym.rollout()
+    ref = g[p + "/poses"][-1]
+    got = np.array([gym.state.poses[e] for e in sc.entities])
+    assert gym.state.t == g[p + "/t"][-1] and np.abs(got - ref).max() < 1e-8
+    forces = np.array([gym.state.agents[e].force for e in sc.entities[1:]])
+    assert np.abs(forces - g[p + "/extra"][-1][1:, 2:]).max() < 1e-8
+    gym.close()
