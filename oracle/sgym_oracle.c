@@ -967,6 +967,111 @@ static void ped_step(const sgo_scenario *sc, const sgo_config *cfg, int i, const
     np_[3] = heading;
 }
 
+/* ---- CollisionMetric.record_collision / get_collision_point / angle_between, metrics/collision.py:13-22, 81-203 --------
+ * The reference reads `hazard.pose` / `self.ego.pose` there, attributes Entity does not have at this commit (it raises for
+ * Vehicle hazards); restated with state.poses[...] in their place.  Geometry: the intersection of the
+ * two boxes (convex quadrilaterals, Sutherland-Hodgman) and its area centroid, summed over the triangle fan from the first
+ * vertex as GEOS does; box.centroid likewise. */
+static double pymod(double x, double m) /* Python float %: result has the sign of m */
+{
+    double r = fmod(x, m);
+    if (r != 0.0 && ((r < 0.0) != (m < 0.0))) r += m;
+    return r;
+}
+
+static int angle_between(double x, double lo, double hi)
+{
+    const double tau = 3.14159265358979311600e+00 * 2;
+    x = pymod(x, tau); lo = pymod(lo, tau); hi = pymod(hi, tau);
+    return lo >= hi ? (lo < x || x <= hi) : (lo <= x && x < hi);
+}
+
+static void poly_centroid(const double *P, int n, double *cx, double *cy)
+{
+    double a2 = 0.0, sx = 0.0, sy = 0.0;
+    for (int i = 1; i + 1 < n; ++i) {
+        const double t2 = (P[2 * i] - P[0]) * (P[2 * i + 3] - P[1]) - (P[2 * i + 2] - P[0]) * (P[2 * i + 1] - P[1]);
+        sx += t2 * (P[0] + P[2 * i] + P[2 * i + 2]);
+        sy += t2 * (P[1] + P[2 * i + 1] + P[2 * i + 3]);
+        a2 += t2;
+    }
+    if (a2 != 0.0) { *cx = sx / 3 / a2; *cy = sy / 3 / a2; return; }
+    sx = sy = 0.0; /* degenerate (touching boxes): mean of the vertices */
+    for (int i = 0; i < n; ++i) { sx += P[2 * i]; sy += P[2 * i + 1]; }
+    *cx = n ? sx / n : NAN;
+    *cy = n ? sy / n : NAN;
+}
+
+/* subject polygon S (4 vertices) clipped by the convex polygon C (4 vertices, either orientation); out: up to 8 vertices */
+static int clip_quads(const double *S, const double *C, double *out)
+{
+    double A[32], B[32];
+    int na = 4;
+    memcpy(A, S, 64);
+    double orient = 0.0;
+    for (int k = 0; k < 4; ++k) { const int m = (k + 1) & 3; orient += C[2 * k] * C[2 * m + 1] - C[2 * m] * C[2 * k + 1]; }
+    const double sgn = orient >= 0 ? 1.0 : -1.0;
+    for (int k = 0; k < 4 && na > 0; ++k) {
+        const int m = (k + 1) & 3;
+        const double ex = C[2 * m] - C[2 * k], ey = C[2 * m + 1] - C[2 * k + 1];
+        int nb = 0;
+        for (int i = 0; i < na; ++i) {
+            const int j = (i + 1) % na;
+            const double di = sgn * (ex * (A[2 * i + 1] - C[2 * k + 1]) - ey * (A[2 * i] - C[2 * k]));
+            const double dj = sgn * (ex * (A[2 * j + 1] - C[2 * k + 1]) - ey * (A[2 * j] - C[2 * k]));
+            if (di >= 0) { B[2 * nb] = A[2 * i]; B[2 * nb + 1] = A[2 * i + 1]; ++nb; }
+            if ((di > 0 && dj < 0) || (di < 0 && dj > 0)) {
+                const double u = di / (di - dj);
+                B[2 * nb] = A[2 * i] + u * (A[2 * j] - A[2 * i]);
+                B[2 * nb + 1] = A[2 * i + 1] + u * (A[2 * j + 1] - A[2 * i + 1]);
+                ++nb;
+            }
+        }
+        memcpy(A, B, (size_t)nb * 16);
+        na = nb;
+    }
+    memcpy(out, A, (size_t)na * 16);
+    return na;
+}
+
+enum { CP_FRONT = 0, CP_FRONT_CORNER, CP_SIDE, CP_BACK, CP_BACK_CORNER };
+
+static int collision_point_class(const double *box8, double angle, double heading, double c_tol)
+{
+    double bx, by, cor[4];
+    poly_centroid(box8, 4, &bx, &by);
+    for (int k = 0; k < 4; ++k) cor[k] = sgo_atan2(box8[2 * k + 1] - by, box8[2 * k] - bx) - heading;
+    if (angle_between(angle, cor[1] - c_tol, cor[1] + c_tol) || angle_between(angle, cor[2] - c_tol, cor[2] + c_tol)) return CP_FRONT_CORNER;
+    if (angle_between(angle, cor[0] - c_tol, cor[0] + c_tol) || angle_between(angle, cor[3] - c_tol, cor[3] + c_tol)) return CP_BACK_CORNER;
+    if (angle_between(angle, cor[0] + c_tol, cor[3] - c_tol)) return CP_BACK;
+    if (angle_between(angle, cor[2] - c_tol, cor[1] + c_tol)) return CP_FRONT;
+    return CP_SIDE;
+}
+
+/* CollisionTypes: 0 other, 1 t_bone, 2 head_on, 3 rear_end, 4 side_swipe (5 non_vehicle is decided by the caller) */
+int sgo_classify_collision(const double *ego_pose6, const double *ego_bbox4, const double *haz_pose6, const double *haz_bbox4,
+                           double c_tol)
+{
+    const double pi = 3.14159265358979311600e+00, tau = pi * 2;
+    double eb[8], hb[8], clip[16], px, py;
+    sgo_corners(ego_pose6, ego_bbox4, eb);
+    sgo_corners(haz_pose6, haz_bbox4, hb);
+    const int n = clip_quads(eb, hb, clip);
+    poly_centroid(clip, n, &px, &py);
+    const double collision_angle = pymod(haz_pose6[3] - ego_pose6[3], tau);
+    const double ego_angle = pymod(sgo_atan2(py - ego_pose6[1], px - ego_pose6[0]) - ego_pose6[3], tau);
+    const double haz_angle = pymod(sgo_atan2(py - haz_pose6[1], px - haz_pose6[0]) - haz_pose6[3], tau);
+    const int ep = collision_point_class(eb, ego_angle, ego_pose6[3], c_tol);
+    const int hp = collision_point_class(hb, haz_angle, haz_pose6[3], c_tol);
+    const int ef = ep == CP_FRONT || ep == CP_FRONT_CORNER, ebk = ep == CP_BACK || ep == CP_BACK_CORNER;
+    const int hf = hp == CP_FRONT || hp == CP_FRONT_CORNER, hbk = hp == CP_BACK || hp == CP_BACK_CORNER;
+    const int cross = angle_between(collision_angle, pi / 4, 3 * pi / 4) || angle_between(collision_angle, 5 * pi / 4, 7 * pi / 4);
+    if (ef && hf) return cross ? 1 : (angle_between(collision_angle, 7 * pi / 4, pi / 4) ? 4 : 2);
+    if ((ef || ebk) && (hf || hbk)) return cross ? 1 : 3;
+    if (ef || ebk || hf || hbk) return cross ? 1 : 4;
+    return 4;
+}
+
 int sgo_rollout(const sgo_scenario *sc, const sgo_config *cfg, int max_steps, int force_steps,
                 const double *actions, sgo_record *rec, sgo_event *events, int event_cap,
                 sgo_result *res)
@@ -1153,7 +1258,9 @@ int sgo_rollout(const sgo_scenario *sc, const sgo_config *cfg, int max_steps, in
                         if (events && n_events < event_cap) {
                             events[n_events].t = t;
                             events[n_events].other = j;
-                            events[n_events].type = sc->etype[j] == 0 ? -1 : 5;
+                            /* record_collision, metrics/collision.py:81-86: non_vehicle unless the hazard is a Vehicle */
+                            events[n_events].type = sc->etype[j] != 0 ? 5 : sgo_classify_collision(
+                                poses + (size_t)ego * 6, sc->bbox + (size_t)ego * 4, poses + (size_t)j * 6, sc->bbox + (size_t)j * 4, 0.4);
                         }
                         ++n_events;
                     }

@@ -136,16 +136,44 @@ class Polygon(BaseGeometry):
 
     @property
     def centroid(self):
+        """Area centroid summed over the triangle fan from the first vertex (the way GEOS accumulates it)."""
         c = self._ring()
-        a = cx = cy = 0.0
-        for (x0, y0), (x1, y1) in zip(c, c[1:] + c[:1]):
-            w = x0 * y1 - x1 * y0
-            a += w
-            cx += (x0 + x1) * w
-            cy += (y0 + y1) * w
-        if a == 0:
-            return Point(np.mean([p[0] for p in c]), np.mean([p[1] for p in c]))
-        return Point(cx / (3 * a), cy / (3 * a))
+        if not c:
+            return Point(float("nan"), float("nan"))
+        a2 = sx = sy = 0.0
+        x0, y0 = c[0]
+        for (x1, y1), (x2, y2) in zip(c[1:-1], c[2:]):
+            t2 = (x1 - x0) * (y2 - y0) - (x2 - x0) * (y1 - y0)
+            sx += t2 * (x0 + x1 + x2)
+            sy += t2 * (y0 + y1 + y2)
+            a2 += t2
+        if a2 != 0.0:
+            return Point(sx / 3 / a2, sy / 3 / a2)
+        return Point(sum(p[0] for p in c) / len(c), sum(p[1] for p in c) / len(c))
+
+    def intersection(self, other):
+        """Convex rings only (bounding boxes): Sutherland-Hodgman, self clipped by other."""
+        A = list(self._ring())
+        C = list(other._ring())
+        orient = sum(C[k][0] * C[(k + 1) % len(C)][1] - C[(k + 1) % len(C)][0] * C[k][1] for k in range(len(C)))
+        sgn = 1.0 if orient >= 0 else -1.0
+        for k in range(len(C)):
+            if not A:
+                break
+            (cx, cy), (mx, my) = C[k], C[(k + 1) % len(C)]
+            ex, ey = mx - cx, my - cy
+            B = []
+            for i in range(len(A)):
+                (ax, ay), (bx, by) = A[i], A[(i + 1) % len(A)]
+                di = sgn * (ex * (ay - cy) - ey * (ax - cx))
+                dj = sgn * (ex * (by - cy) - ey * (bx - cx))
+                if di >= 0:
+                    B.append((ax, ay))
+                if (di > 0 and dj < 0) or (di < 0 and dj > 0):
+                    u = di / (di - dj)
+                    B.append((ax + u * (bx - ax), ay + u * (by - ay)))
+            A = B
+        return Polygon(A)
 
     def contains(self, other):
         if isinstance(other, Point):
