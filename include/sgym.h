@@ -194,11 +194,16 @@ typedef struct {
     int32_t n_steps, done, n_collisions, reserved;
 } sg_metrics;
 
-/* one CollisionMetric entry (t, other entity, type): metrics/collision.py:81-86 */
+/* one CollisionMetric entry (t, other entity, type): metrics/collision.py:81-203.  type = CollisionTypes: 0 other,
+ * 1 t_bone, 2 head_on, 3 rear_end, 4 side_swipe, 5 non_vehicle (hazard's catalog type is not "Vehicle").  Vehicle hazards
+ * are classified by record_collision's tree with state.poses[...] where the reference writes the (missing) `.pose`
+ * attribute; the classification runs when the events are read (sg_read_metrics) from the ego pose the library keeps with
+ * every event (device side) and the hazard's pose at time t re-evaluated from its trajectory.  -2 = a Vehicle hazard whose pose cannot be re-evaluated (it is itself a controlled /
+ * caller-run agent): left unclassified.  Values <= -1 other than -2 never leave sg_read_metrics. */
 typedef struct {
     double t;
     int32_t scenario, other;
-    int32_t type; /* 5 = CollisionTypes.non_vehicle; -1 = Vehicle hazard, classification not done on device */
+    int32_t type;
     int32_t reserved;
 } sg_event;
 

@@ -92,6 +92,7 @@ struct Params {
     double *dyn;             // [n_blocks][FROWS][64]
     sg_scenario_state *sdyn; // [R]
     sg_event *events;        // [R][ev_cap]
+    double *ev_pose;         // [R][ev_cap][3] ego x, y, heading at the event (input of classify_events_kernel)
     double *rec_t, *rec_pose;
     const double *routes;    // [rows][2] pedestrian route waypoints
     const double *gon;       // [64][2] cos, sin of 2*pi*i/64 (host libm): Point.buffer(r) vertices
@@ -2195,11 +2196,20 @@ __device__ __forceinline__ void rollout_body(
                     int64_t ometa = reinterpret_cast<const int64_t *>(oblk)[ST_META * 64 + (oj & 63)];
                     for (int q = 0; q < mult; ++q) {
                         if (n_ev < p.ev_cap) {
-                            sg_event ev;
-                            ev.t = t; ev.scenario = r; ev.other = j;
-                            ev.type = ((ometa >> 8) & 0xff) == 0 ? -1 : 5;
-                            ev.reserved = 0;
-                            p.events[(size_t)r * p.ev_cap + n_ev] = ev;
+                            sg_event *dst = &p.events[(size_t)r * p.ev_cap + n_ev];
+                            struct { double t; int32_t scenario, other, type, reserved; } head;
+                            head.t = t; head.scenario = (int32_t)r; head.other = j;
+                            // Vehicle hazards wait for classify_events_kernel; the table variant notes the step of this
+                            // launch in the type (-10 - k): the row of the controller table that holds the ego's pose
+                            head.type = ((ometa >> 8) & 0xff) == 0 ? (TAB ? -10 - k : -1) : 5;
+                            head.reserved = 0;
+                            *reinterpret_cast<decltype(head) *>(dst) = head;
+                            if (!TAB) { // in-kernel controllers: the ego pose of the event goes along.  (Not in the table
+                                        // variant, which sits 1 VGPR under its 192 budget: its events are classified right
+                                        // after the launch, with the ego pose taken from the table row `reserved`.)
+                                double *ep = p.ev_pose + ((size_t)r * p.ev_cap + n_ev) * 3;
+                                ep[0] = pose[0]; ep[1] = pose[1]; ep[2] = pose[3];
+                            }
                         }
                         ++n_ev;
                     }
@@ -2632,6 +2642,176 @@ __global__ __launch_bounds__(256) void raster_surface_kernel(Params p, RoadIndex
         const uint32_t in = ego_present ? rn_layers_at(R, net, want, px, py) : 0u;
         for (int k = 0; k < n_layers; ++k)
             if (layers[k]) o[(size_t)k * nw * nh + q] = (in & (uint32_t)layers[k]) != 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// CollisionMetric.record_collision / get_collision_point / angle_between (metrics/collision.py:13-22, 81-203) for the
+// events of Vehicle hazards, run when the events are read.  The reference's `.pose` attributes do not exist; the poses of
+// the state at the event stand in: the ego's is stored with the event, the hazard's is its trajectory at the event time
+// (replay entities: the same table segment and arithmetic as the rollout kernel).  Same operation sequence as the oracle:
+// Sutherland-Hodgman clip of the ego box by the hazard box, area centroids over the triangle fan from the first vertex.
+// ------------------------------------------------------------------------------------------------
+__device__ inline double sg_pymod(double x, double m)
+{
+    double r = fmod(x, m);
+    if (r != 0.0 && ((r < 0.0) != (m < 0.0))) r += m;
+    return r;
+}
+
+__device__ inline bool sg_angle_between(double x, double lo, double hi)
+{
+    const double tau = 3.14159265358979311600e+00 * 2;
+    x = sg_pymod(x, tau); lo = sg_pymod(lo, tau); hi = sg_pymod(hi, tau);
+    return lo >= hi ? (lo < x || x <= hi) : (lo <= x && x < hi);
+}
+
+__device__ inline void sg_poly_centroid(const double *P, int n, double &cx, double &cy)
+{
+    double a2 = 0.0, sx = 0.0, sy = 0.0;
+    for (int i = 1; i + 1 < n; ++i) {
+        const double t2 = (P[2 * i] - P[0]) * (P[2 * i + 3] - P[1]) - (P[2 * i + 2] - P[0]) * (P[2 * i + 1] - P[1]);
+        sx += t2 * (P[0] + P[2 * i] + P[2 * i + 2]);
+        sy += t2 * (P[1] + P[2 * i + 1] + P[2 * i + 3]);
+        a2 += t2;
+    }
+    if (a2 != 0.0) { cx = sx / 3 / a2; cy = sy / 3 / a2; return; }
+    sx = sy = 0.0;
+    for (int i = 0; i < n; ++i) { sx += P[2 * i]; sy += P[2 * i + 1]; }
+    cx = n ? sx / n : __builtin_nan("");
+    cy = n ? sy / n : __builtin_nan("");
+}
+
+__device__ inline int sg_clip_quads(const double *S, const double *C, double *A /*[16]*/)
+{
+    double B[16];
+    int na = 4;
+    for (int i = 0; i < 8; ++i) A[i] = S[i];
+    double orient = 0.0;
+    for (int k = 0; k < 4; ++k) { const int m = (k + 1) & 3; orient += C[2 * k] * C[2 * m + 1] - C[2 * m] * C[2 * k + 1]; }
+    const double sgn = orient >= 0 ? 1.0 : -1.0;
+    for (int k = 0; k < 4 && na > 0; ++k) {
+        const int m = (k + 1) & 3;
+        const double ex = C[2 * m] - C[2 * k], ey = C[2 * m + 1] - C[2 * k + 1];
+        int nb = 0;
+        for (int i = 0; i < na; ++i) {
+            const int j = (i + 1) % na;
+            const double di = sgn * (ex * (A[2 * i + 1] - C[2 * k + 1]) - ey * (A[2 * i] - C[2 * k]));
+            const double dj = sgn * (ex * (A[2 * j + 1] - C[2 * k + 1]) - ey * (A[2 * j] - C[2 * k]));
+            if (di >= 0) { B[2 * nb] = A[2 * i]; B[2 * nb + 1] = A[2 * i + 1]; ++nb; }
+            if ((di > 0 && dj < 0) || (di < 0 && dj > 0)) {
+                const double u = di / (di - dj);
+                B[2 * nb] = A[2 * i] + u * (A[2 * j] - A[2 * i]);
+                B[2 * nb + 1] = A[2 * i + 1] + u * (A[2 * j + 1] - A[2 * i + 1]);
+                ++nb;
+            }
+        }
+        for (int i = 0; i < 2 * nb; ++i) A[i] = B[i];
+        na = nb;
+    }
+    return na;
+}
+
+// CollisionPoints: 0 front, 1 front_corner, 2 side, 3 back, 4 back_corner
+__device__ inline int sg_collision_point_class(const double *box8, double angle, double heading, double c_tol)
+{
+    double bx, by, cor[4];
+    sg_poly_centroid(box8, 4, bx, by);
+    for (int k = 0; k < 4; ++k) cor[k] = sg_atan2(box8[2 * k + 1] - by, box8[2 * k] - bx) - heading;
+    if (sg_angle_between(angle, cor[1] - c_tol, cor[1] + c_tol) || sg_angle_between(angle, cor[2] - c_tol, cor[2] + c_tol)) return 1;
+    if (sg_angle_between(angle, cor[0] - c_tol, cor[0] + c_tol) || sg_angle_between(angle, cor[3] - c_tol, cor[3] + c_tol)) return 4;
+    if (sg_angle_between(angle, cor[0] + c_tol, cor[3] - c_tol)) return 3;
+    if (sg_angle_between(angle, cor[2] - c_tol, cor[1] + c_tol)) return 0;
+    return 2;
+}
+
+__device__ inline int sg_classify_collision(const double *eb, double ex, double ey, double eh, const double *hb, double hx,
+                                            double hy, double hh, double c_tol)
+{
+    const double pi = 3.14159265358979311600e+00, tau = pi * 2;
+    double clip[16], px, py;
+    const int n = sg_clip_quads(eb, hb, clip);
+    sg_poly_centroid(clip, n, px, py);
+    const double collision_angle = sg_pymod(hh - eh, tau);
+    const double ego_angle = sg_pymod(sg_atan2(py - ey, px - ex) - eh, tau);
+    const double haz_angle = sg_pymod(sg_atan2(py - hy, px - hx) - hh, tau);
+    const int ep = sg_collision_point_class(eb, ego_angle, eh, c_tol), hp = sg_collision_point_class(hb, haz_angle, hh, c_tol);
+    const bool ef = ep == 0 || ep == 1, ebk = ep == 3 || ep == 4, hf = hp == 0 || hp == 1, hbk = hp == 3 || hp == 4;
+    const bool cross = sg_angle_between(collision_angle, pi / 4, 3 * pi / 4) || sg_angle_between(collision_angle, 5 * pi / 4, 7 * pi / 4);
+    if (ef && hf) return cross ? 1 : (sg_angle_between(collision_angle, 7 * pi / 4, pi / 4) ? 4 : 2);
+    if ((ef || ebk) && (hf || hbk)) return cross ? 1 : 3;
+    if (ef || ebk || hf || hbk) return cross ? 1 : 4;
+    return 4;
+}
+
+// Right after a table-variant launch, while its controller table is still there: the events it recorded for Vehicle hazards
+// (type -10 - k, k = step inside the launch) take the controlled ego's pose at that step from the table row and become
+// ordinary pending events (-1).  A few loads and stores per event; the classification itself waits for sg_read_metrics.
+__global__ __launch_bounds__(64) void event_ego_pose_kernel(Params p, const double *tab)
+{
+    const int r = blockIdx.x;
+    const int n = min(p.sdyn[r].n_events, p.ev_cap);
+    if (n == 0) return;
+    const uint32_t eidx = (uint32_t)r * p.EP + p.sstat[r].ego;
+    const LanePtr est(p.stat + (size_t)(eidx >> 6) * (ST_COUNT * 64), (eidx & 63) * 8u);
+    const int64_t ectl = fld<int64_t>(est, ST_CTL);
+    const int ekind = (int)(fld<int64_t>(est, ST_META) & 0xff);
+    const bool from_tab = ectl >= 0 && (ekind == SG_KIND_AGENT_PID || ekind == SG_KIND_AGENT_VEHICLE);
+    for (int i = threadIdx.x; i < n; i += 64) {
+        sg_event &ev = p.events[(size_t)r * p.ev_cap + i];
+        if (ev.type > -10) continue;
+        if (from_tab) {
+            const double *row = tab + ((size_t)ectl * (size_t)(p.tab_steps + 1) + (size_t)(-10 - ev.type)) * CT_W;
+            double *ep = p.ev_pose + ((size_t)r * p.ev_cap + i) * 3;
+            ep[0] = row[CT_X]; ep[1] = row[CT_Y]; ep[2] = row[CT_H];
+        }
+        ev.type = -1;
+    }
+}
+
+// one thread per (scenario, event slot): pending events (-1) get their type, or -2 when the hazard's pose cannot be
+// re-evaluated.  Ego pose: its trajectory (replay agents), else the pose stored with the event.
+__global__ __launch_bounds__(64) void classify_events_kernel(Params p, double c_tol)
+{
+    const int r = blockIdx.x;
+    const ScenStatic &ss = p.sstat[r];
+    const int n = min(p.sdyn[r].n_events, p.ev_cap);
+    for (int i = threadIdx.x; i < n; i += 64) {
+        sg_event &ev = p.events[(size_t)r * p.ev_cap + i];
+        if (ev.type != -1 && ev.type > -10) continue; // (<= -10: a table-variant launch without controlled lanes)
+        const uint32_t hidx = (uint32_t)r * p.EP + ev.other, eidx = (uint32_t)r * p.EP + ss.ego;
+        const LanePtr hst(p.stat + (size_t)(hidx >> 6) * (ST_COUNT * 64), (hidx & 63) * 8u);
+        const LanePtr est(p.stat + (size_t)(eidx >> 6) * (ST_COUNT * 64), (eidx & 63) * 8u);
+        const int64_t meta = fld<int64_t>(hst, ST_META);
+        const int kind = (int)(meta & 0xff);
+        double hp[6];
+        if (kind == SG_KIND_REPLAY) { // BatchReplayEntity: the union-grid segment containing t, as the rollout kernel has it
+            Table T = lane_table(p, kind, ss, ev.other, hst);
+            Segment S;
+            S.cur = seg_locate(T, ev.t);
+            seg_load(T, S);
+            const double dq = ev.t - S.x_lo;
+            for (int c = 0; c < 6; ++c) hp[c] = S.sl[c] * dq + S.ylo[c];
+        } else if (kind == SG_KIND_AGENT_REPLAY) {
+            own_position_clamped(p.knots + fld<int64_t>(hst, ST_KNOT_OFF) * 7, (int)(meta >> 32), ev.t, hp);
+        } else {
+            ev.type = -2; // a controlled hazard: its pose at the event is not recoverable from a trajectory
+            continue;
+        }
+        const int64_t emeta = fld<int64_t>(est, ST_META);
+        const double *ep = p.ev_pose + ((size_t)r * p.ev_cap + i) * 3;
+        double ex = ep[0], ey = ep[1], eh = ep[2];
+        if ((int)(emeta & 0xff) == SG_KIND_AGENT_REPLAY) {
+            double q[6];
+            own_position_clamped(p.knots + fld<int64_t>(est, ST_KNOT_OFF) * 7, (int)(emeta >> 32), ev.t, q);
+            ex = q[0]; ey = q[1]; eh = q[3];
+        }
+        double s, c, EB[8], HB[8];
+        sg_sincos(eh, s, c);
+        sg_corners(ex, ey, s, c, fld(est, ST_BW), fld(est, ST_BL), fld(est, ST_BCX), fld(est, ST_BCY), EB);
+        sg_sincos(hp[3], s, c);
+        sg_corners(hp[0], hp[1], s, c, fld(hst, ST_BW), fld(hst, ST_BL), fld(hst, ST_BCX), fld(hst, ST_BCY), HB);
+        ev.type = sg_classify_collision(EB, ex, ey, eh, HB, hp[0], hp[1], hp[3], c_tol);
     }
 }
 

@@ -255,6 +255,12 @@ static int launch_main(sg_handle *h, int n_steps, int do_reset, int force, const
     default: launch_variant<64, 1>(h, grid, n_steps, do_reset, force, d_actions, d_tab, use_tab); break;
     }
     HIP_TRY(h, hipGetLastError());
+    if (use_tab && d_tab && h->n_ctl > 0 && h->p.ev_cap > 0 && n_steps > 0) {
+        // a controlled ego's pose at an event of this chunk is a row of the chunk's controller table: copied into the event
+        // now -- before the event below, which the pre-pass of a later chunk waits for before it reuses the buffer
+        sg::event_ego_pose_kernel<<<dim3((unsigned)h->R), dim3(64), 0, h->stream>>>(h->p, d_tab);
+        HIP_TRY(h, hipGetLastError());
+    }
     if (!h->timing_now) return SG_OK;
     HIP_TRY(h, hipEventRecord(e1, h->stream));
     if (n_steps > 0) { // reset-only launches are not counted as hot-path launches
@@ -533,6 +539,7 @@ extern "C" int sg_upload(sg_handle *h, const sg_scenarios *sc)
     if ((rc = dev_alloc(h, M, &p.dyn, nblk * (size_t)p.FROWS * 64))) return rc;
     if ((rc = dev_alloc(h, M, &p.sdyn, (size_t)R))) return rc;
     if ((rc = dev_alloc(h, M, &p.events, (size_t)R * std::max(p.ev_cap, 1)))) return rc;
+    if ((rc = dev_alloc(h, M, &p.ev_pose, (size_t)R * std::max(p.ev_cap, 1) * 3))) return rc;
     if ((rc = dev_alloc(h, M, &p.rec_t, (size_t)std::max(p.rec_cap, 1) * R))) return rc;
     if ((rc = dev_alloc(h, M, &p.rec_pose, (size_t)std::max(p.rec_cap, 0) * 6 * R * EP + 1))) return rc;
 
@@ -803,6 +810,10 @@ extern "C" int sg_read_metrics(sg_handle *h, sg_metrics *out, sg_event *events, 
     if (!h || !out) return SG_ERR_INVALID;
     if (!h->uploaded) return fail(h, SG_ERR_STATE, "sg_read_metrics: no scenarios uploaded");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
+    if (events && h->p.ev_cap > 0) { // CollisionMetric.record_collision for the Vehicle hazards recorded since the last read
+        sg::classify_events_kernel<<<dim3((unsigned)h->R), dim3(64), 0, h->stream>>>(h->p, 0.4 /* CollisionMetric(c_tol=0.4) */);
+        HIP_TRY(h, hipGetLastError());
+    }
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     const int R = h->R;
     const Params &p = h->p;

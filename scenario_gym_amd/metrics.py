@@ -80,7 +80,8 @@ class EgoDistanceTravelled(_DeviceMetric):
     device_field = "ego_distance_travelled"
 
 
-COLLISION_TYPE_NAMES = {5: "non_vehicle", -1: "vehicle"}
+# CollisionTypes (metrics/collision.py:25-33); -1: a Vehicle hazard that is itself a controlled agent, left unclassified
+COLLISION_TYPE_NAMES = {0: "other", 1: "t_bone", 2: "head_on", 3: "rear_end", 4: "side_swipe", 5: "non_vehicle", -1: "vehicle", -2: "vehicle"}
 
 
 class CollisionMetric(_DeviceMetric):

@@ -1258,3 +1258,51 @@ def test_pedestrians_beside_a_building_match_reference(sga, oracle, si):
                 ped = ~np.isnan(g[p + "/extra"][-1][:, 0])
                 assert np.abs(st["force"][r, ped] - g[p + "/extra"][-1][ped, 2:]).max() < 1e-8
         assert np.nanmax(np.abs(o_road["poses"] - o_free["poses"])) > 0.1
+
+
+def test_collision_types_match_reference_code_and_oracle(sga, oracle):
+    """CollisionMetric's classification (t_bone / head_on / rear_end / side_swipe / non_vehicle) for the 47 scenes of
+    collision_types.npz as one ragged batch: times, hazards and types equal the output of the reference's own
+    record_collision code; on a dense synthetic batch of vehicles (replay egos and PID egos) the types equal the oracle's."""
+    import scenario_gym_amd._lib as L
+    from scenario_gym_amd import synthetic
+    from scenario_gym_amd.packing import default_kinds, pack_arrays, unpack_scenario
+
+    g = load_golden("collision_types")
+    names = list(g["names"])
+    scs = []
+    for n in names:
+        s = scenario_arrays(g, f"{n}/scenario")
+        s["kind"] = default_kinds(len(s["bbox"]), s["ego"])
+        scs.append(s)
+    packed = pack_arrays(scs)
+    eng = sga.RolloutEngine(packed.n_scenarios, packed.n_entities, timestep=0.05, event_capacity=16)
+    eng.upload(packed)
+    eng.rollout(200)
+    rows, events = eng.metrics()
+    eng.close()
+    seen = set()
+    for r, n in enumerate(names):
+        ev = events[events["scenario"] == r]
+        assert np.array_equal(ev["t"], g[f"{n}/ev_t"]) and np.array_equal(ev["other"], g[f"{n}/ev_other"]), n
+        assert np.array_equal(ev["type"], g[f"{n}/ev_type"]), (n, ev["type"], g[f"{n}/ev_type"])
+        seen |= set(ev["type"].tolist())
+    assert seen == {1, 2, 3, 4, 5}
+    for ego_kind in (L.KIND_AGENT_REPLAY, L.KIND_AGENT_PID):
+        R, E, steps = 96, 24, 300
+        packed = synthetic.make_batch(R, E, n_steps=steps, ego_kind=ego_kind, extent=14.0)
+        eng = sga.RolloutEngine(R, E, event_capacity=128)
+        eng.upload(packed)
+        eng.rollout(steps)
+        rows, events = eng.metrics()
+        eng.close()
+        n_ev = 0
+        for r in range(0, R, 3):
+            s = unpack_scenario(packed, r)
+            o = oracle.rollout(s["knot_off"], s["knots"], s["bbox"], s["etype"], s["kind"], s["ego"], s["t0"], s["length"], 1 / 30,
+                               ctrl=s["ctrl"], max_steps=steps, record=False, event_cap=128)
+            ev = events[events["scenario"] == r]
+            assert np.array_equal(ev["t"], o["ev_t"]) and np.array_equal(ev["other"], o["ev_other"]), r
+            assert np.array_equal(ev["type"], o["ev_type"]), (r, ev["type"], o["ev_type"])
+            n_ev += len(ev)
+        assert n_ev > 40
