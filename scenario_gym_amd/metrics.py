@@ -87,9 +87,11 @@ COLLISION_TYPE_NAMES = {0: "other", 1: "t_bone", 2: "head_on", 3: "rear_end", 4:
 class CollisionMetric(_DeviceMetric):
     """metrics/collision.py:46-79: list of (t, other ref, type) for every NEW collision with the ego.
 
-    `type` is "non_vehicle" exactly as in the reference; for Vehicle hazards the reference's
-    classification code raises (it reads Entity.pose, which does not exist: metrics/collision.py:94)
-    and the device reports "vehicle" (unclassified)."""
+    `type` is "non_vehicle" for hazards whose catalog type is not "Vehicle", otherwise the class of
+    record_collision (metrics/collision.py:81-203: "t_bone", "head_on", "rear_end", "side_swipe"), computed on the device
+    with state.poses[...] where the reference reads the missing `Entity.pose` attribute (it raises there at this commit).
+    A Vehicle hazard that is itself a controlled agent stays "vehicle" (unclassified).  c_tol other than the default 0.4
+    is not passed down."""
 
     name = "collisions"
     device_field = "n_collisions"
