@@ -28,6 +28,7 @@ from .scenario import Scenario  # noqa: F401
 from .state import State  # noqa: F401
 from .trajectory import Trajectory  # noqa: F401
 from .road_network import RoadNetwork  # noqa: F401
+from .route import RouteFinder  # noqa: F401
 from .vector_env import VectorScenarioEnv  # noqa: F401
 
 __version__ = "0.1.0"

@@ -46,6 +46,23 @@ class LineString(BaseGeometry):
         c = np.array(self.coords)
         return float(np.linalg.norm(np.diff(c, axis=0), axis=1).sum()) if len(c) > 1 else 0.0
 
+    def interpolate(self, s, normalized=False):
+        """Point at arc length s along the polyline (clamped to its ends)."""
+        c = np.array(self.coords)
+        seg = np.diff(c, axis=0)
+        ln = np.sqrt((seg ** 2).sum(axis=1))
+        if normalized:
+            s = s * float(ln.sum())
+        if s <= 0.0 or len(c) == 1:
+            return Point(c[0])
+        acc = 0.0
+        for k, L in enumerate(ln):
+            if s < acc + L or (k == len(ln) - 1 and s <= acc + L):
+                u = 0.0 if L == 0.0 else (s - acc) / L
+                return Point(c[k] + u * seg[k])
+            acc += L
+        return Point(c[-1])
+
     def project(self, pt):
         """Arclength of the nearest point of the polyline (analytic, fp64)."""
         p = np.array([pt.x, pt.y])

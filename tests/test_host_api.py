@@ -334,3 +334,51 @@ def test_is_stationary():
     assert is_stationary(a)
     a[1, 1] = 1.1
     assert not is_stationary(a)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/scenario_gym"), reason="build container only")
+def test_route_finder_matches_reference():
+    """pedestrian/route.py on the Greenwich network (5 pavements, 4 crossings): the connection graph, its node positions
+    and breadth-first routes between random points equal the reference's RouteFinder (imported with the stand-ins; the
+    centre-line interpolation it calls is the stand-in's)."""
+    import subprocess
+    import sys
+    import json
+
+    from scenario_gym_amd.road_network import RoadNetwork
+    from scenario_gym_amd.route import RouteFinder
+
+    path = "/root/reference/tests/input_files/Road_Networks/Greenwich_Road_Network_002.json"
+    rf = RouteFinder(RoadNetwork.create_from_json(path))
+    rng = np.random.default_rng(0)
+    lo, hi = np.array([290.0, 288.0]), np.array([591.0, 496.0])
+    queries = rng.uniform(lo, hi, (12, 2, 2))
+    code = f"""
+import sys, json
+sys.dont_write_bytecode = True
+sys.path[:0] = ["{ROOT}/tests/golden/_refstubs", "/root/reference"]
+import numpy as np
+from scenario_gym.road_network import RoadNetwork
+from scenario_gym.pedestrian.route import RouteFinder
+rf = RouteFinder(RoadNetwork.create_from_json("{path}"))
+q = np.array({queries.tolist()})
+routes = [rf.find_route(a, b) for a, b in q]
+print(json.dumps(dict(graph={{str(k): v for k, v in rf.graph.items()}}, idx=rf.node_to_idx,
+                      data={{str(k): list(map(float, v)) for k, v in rf.node_data.items()}},
+                      routes=[None if r is None else r.tolist() for r in routes])))
+"""
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, MPLBACKEND="Agg"))
+    assert out.returncode == 0, out.stderr[-2000:]
+    ref = json.loads(out.stdout.strip().splitlines()[-1])
+    assert rf.node_to_idx == ref["idx"] and len(rf.graph) > 100
+    assert {str(k): v for k, v in rf.graph.items()} == ref["graph"]
+    for k, v in rf.node_data.items():
+        assert np.allclose(v, ref["data"][str(k)], rtol=0, atol=1e-9)
+    found = 0
+    for (a, b), want in zip(queries, ref["routes"]):
+        got = rf.find_route(a, b)
+        assert (got is None) == (want is None)
+        if got is not None:
+            assert np.allclose(got, np.array(want), rtol=0, atol=1e-9)
+            found += 1
+    assert found > 0
