@@ -90,6 +90,43 @@ int main(void)
     }
     free(blocks);
 
+    /* road surfaces from C: one network (a 12 m x 6 m road rectangle around the ego's lane) shared by both scenarios;
+     * the final state has the ego at x = 10: 2 m past the road's end at x = 8 */
+    {
+        const int32_t net_of[R] = {0, 0};
+        const int64_t poly_off[2] = {0, 1}, ring_off[2] = {0, 1}, vert_off[2] = {0, 4};
+        const double verts[4][2] = {{-12.0, -3.0}, {8.0, -3.0}, {8.0, 3.0}, {-12.0, 3.0}};
+        const uint32_t layers[1] = {SG_LAYER_DRIVEABLE | SG_LAYER_ROAD};
+        sg_road_networks rn;
+        memset(&rn, 0, sizeof rn);
+        rn.n_networks = 1; rn.net_of_scenario = net_of; rn.poly_off = poly_off; rn.ring_off = ring_off; rn.vert_off = vert_off;
+        rn.verts = &verts[0][0]; rn.layers = layers;
+        CHECK(sg_set_road_networks(h, &rn));
+        uint32_t flags[R];
+        CHECK(sg_terminal_flags(h, flags, NULL));
+        for (int r = 0; r < R; ++r) bad |= !(flags[r] & SG_TERM_MAX_LENGTH) || !(flags[r] & SG_TERM_EGO_OFF_ROAD);
+        const int32_t lay[2] = {0, SG_LAYER_DRIVEABLE};
+        uint8_t map[R][2][5][5];
+        CHECK(sg_raster_map(h, 8.0, 8.0, 5, 5, 2, lay, &map[0][0][0][0]));
+        /* ego at (10, 0), heading 0: the grid frame is rotated by pi/2, rows run along -x ... the centre cell is the ego's
+         * own box; the driveable layer is set only on the side that looks back at the road (x <= 8) */
+        int on = 0;
+        for (int i = 0; i < 5; ++i) for (int j = 0; j < 5; ++j) on += map[0][1][i][j];
+        printf("map: centre entity cell %d, driveable cells %d of 25\n", map[0][0][2][2], on);
+        bad |= map[0][0][2][2] != 1 || on == 0 || on == 25;
+        /* restart scenario 1 only, then one tick of both as a captured graph with zero actions */
+        const uint8_t mask[R] = {0, 1};
+        CHECK(sg_reset_scenarios(h, mask));
+        const uint8_t *d_obs = NULL;
+        const uint32_t *d_fl = NULL;
+        CHECK(sg_tick(h, NULL, 0, 8.0, 8.0, 5, 5, 2, lay, &d_obs, &d_fl));
+        CHECK(sg_synchronize(h));
+        CHECK(sg_copy_to_host(h, d_fl, flags, sizeof flags));
+        printf("flags after restart + tick: %u %u\n", flags[0], flags[1]);
+        bad |= (flags[1] & (SG_TERM_MAX_LENGTH | SG_TERM_EGO_OFF_ROAD)) != 0; /* scenario 1 is back at x = -9.8, on the road */
+        bad |= !(flags[0] & SG_TERM_EGO_OFF_ROAD);
+    }
+
     /* error behaviour: a bad argument returns a negative status and a message, nothing aborts */
     int rc = sg_step(h, -1, NULL, 0);
     bad |= rc != SG_ERR_INVALID || strlen(sg_last_error(h)) == 0;
