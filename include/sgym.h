@@ -343,6 +343,24 @@ int sg_set_tuning(sg_handle *h, int32_t tab_min_steps, int32_t chunk_steps, int3
  * (Entity.get_bounding_box_points, entity/base.py:113) are only needed for pairs the fp32 filter cannot decide. */
 int sg_debug_trig32(sg_handle *h, int64_t n, const double *heading, float *sin_out, float *cos_out);
 
+/* ---- several devices from one process ----
+ * Scenarios are independent (scenario_gym.py:24-27, 178): the batch is cut into contiguous shards of scenarios, one handle
+ * per device of `devs`, no exchange during the step loop; cfg->n_scenarios is the TOTAL, cfg->device is ignored.
+ * sg_group_upload takes the arrays of the whole batch; sg_group_rollout launches every device before it waits for any;
+ * sg_group_read_metrics returns rows and events in whole-batch scenario order.  Everything else (state views, stepping,
+ * observations, road networks) goes through the shard's own handle, sg_group_handle(g, i), whose scenarios are
+ * [n_scenarios * i / n, n_scenarios * (i + 1) / n).  The multi-process form of the same sharding (one process per GPU,
+ * metrics gathered over RCCL) is scenario_gym_amd/distributed.py. */
+typedef struct sg_group sg_group;
+int sg_group_create(const sg_config *cfg, int32_t n_devices, const int32_t *devs, sg_group **out);
+int sg_group_destroy(sg_group *g);
+int32_t sg_group_size(const sg_group *g);
+sg_handle *sg_group_handle(sg_group *g, int32_t i);
+int sg_group_upload(sg_group *g, const sg_scenarios *all);
+int sg_group_rollout(sg_group *g, int32_t max_steps);
+int sg_group_read_metrics(sg_group *g, sg_metrics *out, sg_event *events, int32_t cap, int32_t *n_events);
+const char *sg_group_last_error(const sg_group *g);
+
 #ifdef __cplusplus
 }
 #endif

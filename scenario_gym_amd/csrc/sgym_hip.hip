@@ -1259,3 +1259,117 @@ extern "C" int sg_raster_entities(sg_handle *h, double width, double height, int
     if (e != hipSuccess) return fail(h, SG_ERR_HIP, "sg_raster_entities: %s", hipGetErrorString(e));
     return SG_OK;
 }
+
+// ---- several devices from one process ---------------------------------------------------------------
+// Scenarios never interact (one State per gym, scenario_gym.py:178; run_scenarios loops over them, :24-27): the replica
+// axis is cut into contiguous shards, one sg_handle per device, no exchange during the step loop.  (The multi-process
+// form of the same sharding is scenario_gym_amd/distributed.py over torch.distributed.)
+struct sg_group {
+    std::vector<sg_handle *> hs;
+    std::vector<int> first; // first[i] = first scenario of shard i, first[n] = total
+    int E = 0;
+    std::string err;
+};
+
+static int gfail(sg_group *g, int code, const std::string &msg)
+{
+    if (g) g->err = msg;
+    return code;
+}
+
+extern "C" const char *sg_group_last_error(const sg_group *g) { return g ? g->err.c_str() : g_create_err.c_str(); }
+
+extern "C" int sg_group_destroy(sg_group *g)
+{
+    if (!g) return SG_OK;
+    for (sg_handle *h : g->hs) (void)sg_destroy(h);
+    delete g;
+    return SG_OK;
+}
+
+extern "C" int sg_group_create(const sg_config *cfg, int32_t n_dev, const int32_t *devs, sg_group **out)
+{
+    if (!cfg || !out || n_dev < 1 || !devs) return fail(nullptr, SG_ERR_INVALID, "sg_group_create: bad argument");
+    if (cfg->n_scenarios < n_dev) return fail(nullptr, SG_ERR_INVALID, "sg_group_create: fewer scenarios (%d) than devices (%d)", cfg->n_scenarios, n_dev);
+    sg_group *g = new sg_group();
+    g->E = cfg->n_entities;
+    for (int i = 0; i <= n_dev; ++i) g->first.push_back((int)((int64_t)cfg->n_scenarios * i / n_dev));
+    for (int i = 0; i < n_dev; ++i) {
+        sg_config c = *cfg;
+        c.device = devs[i];
+        c.n_scenarios = g->first[i + 1] - g->first[i];
+        sg_handle *h = nullptr;
+        int rc = sg_create(&c, &h);
+        if (rc) { sg_group_destroy(g); return rc; } // message in sg_last_error(NULL)
+        g->hs.push_back(h);
+    }
+    *out = g;
+    return SG_OK;
+}
+
+extern "C" int32_t sg_group_size(const sg_group *g) { return g ? (int32_t)g->hs.size() : 0; }
+extern "C" sg_handle *sg_group_handle(sg_group *g, int32_t i) { return (g && i >= 0 && i < (int32_t)g->hs.size()) ? g->hs[i] : nullptr; }
+
+extern "C" int sg_group_upload(sg_group *g, const sg_scenarios *sc)
+{
+    if (!g || !sc || !sc->knot_off) return gfail(g, SG_ERR_INVALID, "sg_group_upload: null argument");
+    const int E = g->E;
+    for (size_t i = 0; i < g->hs.size(); ++i) {
+        const size_t r0 = (size_t)g->first[i], r1 = (size_t)g->first[i + 1], n = (r1 - r0) * E;
+        sg_scenarios s = *sc;
+        s.kind = sc->kind ? sc->kind + r0 * E : nullptr;
+        s.etype = sc->etype ? sc->etype + r0 * E : nullptr;
+        s.bbox = sc->bbox ? sc->bbox + r0 * E * 4 : nullptr;
+        s.ctrl = sc->ctrl ? sc->ctrl + r0 * E * SG_NCTRL : nullptr;
+        s.ego = sc->ego ? sc->ego + r0 : nullptr;
+        s.t0 = sc->t0 ? sc->t0 + r0 : nullptr;
+        s.length = sc->length ? sc->length + r0 : nullptr;
+        std::vector<int64_t> koff(n + 1), roff;
+        const int64_t kb = sc->knot_off[r0 * E];
+        for (size_t k = 0; k <= n; ++k) koff[k] = sc->knot_off[r0 * E + k] - kb;
+        s.knot_off = koff.data();
+        s.knots = sc->knots ? sc->knots + (size_t)kb * 7 : nullptr;
+        if (sc->route_off) {
+            roff.resize(n + 1);
+            const int64_t rb = sc->route_off[r0 * E];
+            for (size_t k = 0; k <= n; ++k) roff[k] = sc->route_off[r0 * E + k] - rb;
+            s.route_off = roff.data();
+            s.routes = sc->routes ? sc->routes + (size_t)rb * 2 : nullptr;
+        }
+        int rc = sg_upload(g->hs[i], &s);
+        if (rc) return gfail(g, rc, std::string("sg_group_upload: shard ") + std::to_string(i) + ": " + sg_last_error(g->hs[i]));
+    }
+    return SG_OK;
+}
+
+// ScenarioGym.rollout on every shard: all devices are launched before any is waited for
+extern "C" int sg_group_rollout(sg_group *g, int32_t max_steps)
+{
+    if (!g) return SG_ERR_INVALID;
+    for (size_t i = 0; i < g->hs.size(); ++i) {
+        int rc = sg_rollout_async(g->hs[i], max_steps, 1);
+        if (rc) return gfail(g, rc, std::string("sg_group_rollout: shard ") + std::to_string(i) + ": " + sg_last_error(g->hs[i]));
+    }
+    for (size_t i = 0; i < g->hs.size(); ++i) {
+        int rc = sg_synchronize(g->hs[i]);
+        if (rc) return gfail(g, rc, std::string("sg_group_rollout: shard ") + std::to_string(i) + ": " + sg_last_error(g->hs[i]));
+    }
+    return SG_OK;
+}
+
+// ScenarioGym.get_metrics of all shards, scenario indices of the whole batch
+extern "C" int sg_group_read_metrics(sg_group *g, sg_metrics *out, sg_event *events, int32_t cap, int32_t *n_events)
+{
+    if (!g || !out) return gfail(g, SG_ERR_INVALID, "sg_group_read_metrics: null argument");
+    int32_t total = 0;
+    for (size_t i = 0; i < g->hs.size(); ++i) {
+        int32_t n = 0;
+        int rc = sg_read_metrics(g->hs[i], out + g->first[i], events ? events + total : nullptr, events ? cap - total : 0, &n);
+        if (rc) return gfail(g, rc, std::string("sg_group_read_metrics: shard ") + std::to_string(i) + ": " + sg_last_error(g->hs[i]));
+        if (events)
+            for (int32_t k = 0; k < std::min(n, cap - total); ++k) events[total + k].scenario += g->first[i];
+        total += events ? std::min(n, cap - total) : n;
+    }
+    if (n_events) *n_events = total;
+    return SG_OK;
+}

@@ -1306,3 +1306,45 @@ def test_collision_types_match_reference_code_and_oracle(sga, oracle):
             assert np.array_equal(ev["type"], o["ev_type"]), (r, ev["type"], o["ev_type"])
             n_ev += len(ev)
         assert n_ev > 40
+
+
+def test_device_group_equals_single_handle(sga, oracle):
+    """sg_group_*: the batch cut into contiguous shards over several handles (here all on GPU 0, incl. uneven shards and a
+    pedestrian-free ragged batch with PID egos): rollout + metrics + events equal the single-handle run row for row."""
+    import ctypes as C
+
+    import scenario_gym_amd._lib as L
+    from scenario_gym_amd import synthetic
+
+    R, E, steps = 50, 12, 150
+    packed = synthetic.make_batch(R, E, n_steps=steps, ego_kind=L.KIND_AGENT_PID, extent=14.0)
+    eng = sga.RolloutEngine(R, E, event_capacity=32)
+    eng.upload(packed)
+    eng.rollout(steps)
+    rows1, ev1 = eng.metrics()
+    lib = eng.lib
+    for n_dev in (1, 3, 4):
+        cfg = L.SgConfig(0, R, E, 0, L.TERM_MAX_LENGTH, 0, 32, 0, 1 / 30)
+        devs = np.zeros(n_dev, np.int32)
+        g = C.c_void_p()
+        assert lib.sg_group_create(C.byref(cfg), n_dev, devs.ctypes.data, C.byref(g)) == 0
+        assert lib.sg_group_size(g) == n_dev
+        arrs = dict(kind=np.ascontiguousarray(packed.kind, np.int32), etype=np.ascontiguousarray(packed.etype, np.int32),
+                    bbox=np.ascontiguousarray(packed.bbox), knot_off=np.ascontiguousarray(packed.knot_off, np.int64),
+                    knots=np.ascontiguousarray(packed.knots), ctrl=np.ascontiguousarray(packed.ctrl),
+                    ego=np.ascontiguousarray(packed.ego, np.int32), t0=np.ascontiguousarray(packed.t0),
+                    length=np.ascontiguousarray(packed.length), route_off=None, routes=None)
+        sc = L.SgScenarios(*[None if arrs[k] is None else arrs[k].ctypes.data for k, _ in L.SgScenarios._fields_])
+        assert lib.sg_group_upload(g, C.byref(sc)) == 0, lib.sg_group_last_error(g)
+        assert lib.sg_group_rollout(g, steps) == 0, lib.sg_group_last_error(g)
+        rows = np.zeros(R, rows1.dtype)
+        ev = np.zeros(4096, ev1.dtype)
+        n_ev = C.c_int32()
+        assert lib.sg_group_read_metrics(g, rows.ctypes.data, ev.ctypes.data, 4096, C.byref(n_ev)) == 0
+        assert n_ev.value == len(ev1) and len(ev1) > 10
+        for k in rows1.dtype.names:
+            assert bits_equal(rows[k], rows1[k]), (n_dev, k)
+        for k in ("t", "scenario", "other", "type"):
+            assert np.array_equal(ev[: n_ev.value][k], ev1[k]), (n_dev, k)
+        assert lib.sg_group_destroy(g) == 0
+    eng.close()

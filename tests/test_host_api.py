@@ -268,7 +268,7 @@ def test_library_exports_every_declared_symbol():
     import scenario_gym_amd._lib as L
 
     header = open(os.path.join(ROOT, "include", "sgym.h")).read()
-    declared = set(re.findall(r"^\s*(?:int|void \*|const char \*)\s*(sg_[a-z0-9_]+)\(", header, re.M))
+    declared = set(re.findall(r"^\s*(?:int|int32_t|void \*|const char \*|sg_handle \*)\s*(sg_[a-z0-9_]+)\(", header, re.M))
     assert declared == set(L.SYMBOLS), declared ^ set(L.SYMBOLS)
     lib = L.load()
     for name in declared:
