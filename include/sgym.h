@@ -309,6 +309,10 @@ int sg_raster_map_device(sg_handle *h, double width, double height, int32_t nw, 
 int sg_tick(sg_handle *h, const double *actions, int32_t actions_device, double width, double height, int32_t nw, int32_t nh,
             int32_t n_layers, const int32_t *layers, const uint8_t **d_obs, const uint32_t **d_flags);
 
+/* CollisionMetric(c_tol) (metrics/collision.py:57-62, default 0.4 rad): the angular half-width of a box corner in
+ * get_collision_point; applies to the events classified by the following sg_read_metrics calls. */
+int sg_set_collision_tolerance(sg_handle *h, double c_tol);
+
 /* ScenarioGym.get_metrics (scenario_gym.py:308-319): out [R]; events [cap] (may be NULL) */
 int sg_read_metrics(sg_handle *h, sg_metrics *out, sg_event *events, int32_t cap, int32_t *n_events);
 

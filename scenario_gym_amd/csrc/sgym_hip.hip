@@ -50,6 +50,7 @@ struct sg_handle {
     double tick_w = 0, tick_h = 0;
     int tick_nw = 0, tick_nh = 0, tick_nl = 0;
     int32_t tick_layers[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    double c_tol = 0.4;                                // CollisionMetric(c_tol): angular half-width of a box corner, metrics/collision.py:57
     unsigned char *d_reset_mask = nullptr;             // [R] sg_reset_scenarios
     uint32_t *d_term_flags = nullptr;                  // [R] sg_terminal_flags
     void *obs_buf = nullptr;                           // device scratch of the observation calls (grown on demand)
@@ -811,7 +812,7 @@ extern "C" int sg_read_metrics(sg_handle *h, sg_metrics *out, sg_event *events, 
     if (!h->uploaded) return fail(h, SG_ERR_STATE, "sg_read_metrics: no scenarios uploaded");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     if (events && h->p.ev_cap > 0) { // CollisionMetric.record_collision for the Vehicle hazards recorded since the last read
-        sg::classify_events_kernel<<<dim3((unsigned)h->R), dim3(64), 0, h->stream>>>(h->p, 0.4 /* CollisionMetric(c_tol=0.4) */);
+        sg::classify_events_kernel<<<dim3((unsigned)h->R), dim3(64), 0, h->stream>>>(h->p, h->c_tol);
         HIP_TRY(h, hipGetLastError());
     }
     HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -937,6 +938,13 @@ extern "C" int sg_set_tuning(sg_handle *h, int32_t tab_min_steps, int32_t chunk_
     if (chunk_steps > 0) h->chunk_steps = chunk_steps;
     if (overlap >= 0) h->overlap = overlap != 0;
     ++h->generation;
+    return SG_OK;
+}
+
+extern "C" int sg_set_collision_tolerance(sg_handle *h, double c_tol)
+{
+    if (!h || !(c_tol >= 0.0)) return h ? fail(h, SG_ERR_INVALID, "sg_set_collision_tolerance: c_tol must be >= 0") : SG_ERR_INVALID;
+    h->c_tol = c_tol;
     return SG_OK;
 }
 

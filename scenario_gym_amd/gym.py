@@ -295,6 +295,12 @@ class BatchedScenarioGym:
     # ------------------------------------------------------------------ results
     def get_metrics(self) -> List[Dict[str, Any]]:
         """ScenarioGym.get_metrics (scenario_gym.py:308-319) per scenario."""
+        tols = {m.c_tol for ms in self.metrics for m in ms if hasattr(m, "c_tol")}
+        if len(tols) > 1:
+            raise NotImplementedError("one CollisionMetric.c_tol per batch")
+        if tols:
+            self.engine._check(self.engine.lib.sg_set_collision_tolerance(self.engine.h, float(tols.pop())),
+                               "sg_set_collision_tolerance")
         rows, events = self.engine.metrics()
         out = []
         for i, ms in enumerate(self.metrics):

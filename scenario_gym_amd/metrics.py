@@ -90,8 +90,7 @@ class CollisionMetric(_DeviceMetric):
     `type` is "non_vehicle" for hazards whose catalog type is not "Vehicle", otherwise the class of
     record_collision (metrics/collision.py:81-203: "t_bone", "head_on", "rear_end", "side_swipe"), computed on the device
     with state.poses[...] where the reference reads the missing `Entity.pose` attribute (it raises there at this commit).
-    A Vehicle hazard that is itself a controlled agent stays "vehicle" (unclassified).  c_tol other than the default 0.4
-    is not passed down."""
+    A Vehicle hazard that is itself a controlled agent stays "vehicle" (unclassified)."""
 
     name = "collisions"
     device_field = "n_collisions"

@@ -801,3 +801,29 @@ def test_pedestrian_agents_beside_a_building_through_the_gym():
     forces = np.array([gym.state.agents[e].force for e in sc.entities[1:]])
     assert np.abs(forces - g[p + "/extra"][-1][1:, 2:]).max() < 1e-8
     gym.close()
+
+
+def test_collision_metric_types_through_the_gym(oracle):
+    """CollisionMetric through ScenarioGym on the hand-made scenes of collision_types.npz: the names the reference's code
+    gave (head_on, rear_end, t_bone, side_swipe, non_vehicle); c_tol reaches the device (a huge tolerance turns every
+    contact point into a corner)."""
+    import scenario_gym_amd as sga
+
+    g = load_golden("collision_types")
+    types = [str(t) for t in g["types"]]
+    for n in ("head_on", "rear_end", "rear_ended", "t_bone", "t_boned", "side_swipe", "oblique", "rand3", "rand27"):
+        sc = scenario_from_arrays(scenario_arrays(g, f"{n}/scenario"), g[f"{n}/scenario/refs"])
+        gym = sga.ScenarioGym(timestep=0.05, metrics=[sga.CollisionMetric()])
+        gym.set_scenario(sc)
+        gym.rollout()
+        got = gym.get_metrics()["collisions"]
+        want = [(float(t), str(g[f"{n}/scenario/refs"][o]), types[k]) for t, o, k in zip(g[f"{n}/ev_t"], g[f"{n}/ev_other"], g[f"{n}/ev_type"])]
+        assert got == want, (n, got, want)
+        gym.close()
+    sc = scenario_from_arrays(scenario_arrays(g, "rear_end/scenario"), g["rear_end/scenario/refs"])
+    gym = sga.ScenarioGym(timestep=0.05, metrics=[sga.CollisionMetric(c_tol=3.0)])
+    gym.set_scenario(sc)
+    gym.rollout()
+    # every contact angle now falls into a front-corner window of both boxes: front/front at collision angle 0 is a side swipe
+    assert [c for _, _, c in gym.get_metrics()["collisions"]] == ["side_swipe"]
+    gym.close()
