@@ -316,6 +316,11 @@ int sg_set_collision_tolerance(sg_handle *h, double c_tol);
 /* ScenarioGym.get_metrics (scenario_gym.py:308-319): out [R]; events [cap] (may be NULL) */
 int sg_read_metrics(sg_handle *h, sg_metrics *out, sg_event *events, int32_t cap, int32_t *n_events);
 
+/* CollisionPointMetric (metrics/collision.py:206-253) for the same events, in the order sg_read_metrics lists them:
+ * out[k] = (x, y of the centroid of the two boxes' intersection, (hazard heading - ego heading) mod 2 pi); NaN for a hazard
+ * that is itself a controlled agent.  Unlike the type, this is computed for hazards of every catalog type.  HOST [cap][3]. */
+int sg_read_collision_points(sg_handle *h, double *out, int32_t cap, int32_t *n_events);
+
 /* State.recorded_poses (state.py:272-290): rows [0, n_rows) of the device record:
  * t_out [n_rows][R], pose_out [n_rows][R*E][6] with NaN for absent entities. HOST buffers. */
 int sg_read_record(sg_handle *h, int32_t n_rows, double *t_out, double *pose_out);

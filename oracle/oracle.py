@@ -125,7 +125,8 @@ class _Config(C.Structure):
 
 
 class _Event(C.Structure):
-    _fields_ = [("t", C.c_double), ("other", C.c_int32), ("type", C.c_int32)]
+    _fields_ = [("t", C.c_double), ("other", C.c_int32), ("type", C.c_int32), ("px", C.c_double), ("py", C.c_double),
+                ("angle", C.c_double)]
 
 
 class _Record(C.Structure):
@@ -236,6 +237,7 @@ def rollout(knot_off, knots, bbox, etype, kind, ego, t0, length, dt, persist=Fal
         ev_t=np.array([ev[i].t for i in range(min(res.n_events, event_cap))]),
         ev_other=np.array([ev[i].other for i in range(min(res.n_events, event_cap))], np.int64),
         ev_type=np.array([ev[i].type for i in range(min(res.n_events, event_cap))], np.int64),
+        ev_point=np.array([[ev[i].px, ev[i].py, ev[i].angle] for i in range(min(res.n_events, event_cap))]).reshape(-1, 3),
     )
     return out
 

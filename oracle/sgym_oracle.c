@@ -1048,6 +1048,18 @@ static int collision_point_class(const double *box8, double angle, double headin
     return CP_SIDE;
 }
 
+/* CollisionPointMetric.record_collision_position (metrics/collision.py:242-253): centroid of the boxes' intersection and
+ * (hazard heading - ego heading) mod 2 pi */
+void sgo_collision_point(const double *ego_pose6, const double *ego_bbox4, const double *haz_pose6, const double *haz_bbox4,
+                         double *px, double *py, double *angle)
+{
+    double eb[8], hb[8], clip[16];
+    sgo_corners(ego_pose6, ego_bbox4, eb);
+    sgo_corners(haz_pose6, haz_bbox4, hb);
+    poly_centroid(clip, clip_quads(eb, hb, clip), px, py);
+    *angle = pymod(haz_pose6[3] - ego_pose6[3], 3.14159265358979311600e+00 * 2);
+}
+
 /* CollisionTypes: 0 other, 1 t_bone, 2 head_on, 3 rear_end, 4 side_swipe (5 non_vehicle is decided by the caller) */
 int sgo_classify_collision(const double *ego_pose6, const double *ego_bbox4, const double *haz_pose6, const double *haz_bbox4,
                            double c_tol)
@@ -1259,6 +1271,8 @@ int sgo_rollout(const sgo_scenario *sc, const sgo_config *cfg, int max_steps, in
                             events[n_events].t = t;
                             events[n_events].other = j;
                             /* record_collision, metrics/collision.py:81-86: non_vehicle unless the hazard is a Vehicle */
+                            sgo_collision_point(poses + (size_t)ego * 6, sc->bbox + (size_t)ego * 4, poses + (size_t)j * 6,
+                                                sc->bbox + (size_t)j * 4, &events[n_events].px, &events[n_events].py, &events[n_events].angle);
                             events[n_events].type = sc->etype[j] != 0 ? 5 : sgo_classify_collision(
                                 poses + (size_t)ego * 6, sc->bbox + (size_t)ego * 4, poses + (size_t)j * 6, sc->bbox + (size_t)j * 4, 0.4);
                         }

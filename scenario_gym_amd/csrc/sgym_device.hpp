@@ -2199,9 +2199,10 @@ __device__ __forceinline__ void rollout_body(
                             sg_event *dst = &p.events[(size_t)r * p.ev_cap + n_ev];
                             struct { double t; int32_t scenario, other, type, reserved; } head;
                             head.t = t; head.scenario = (int32_t)r; head.other = j;
-                            // Vehicle hazards wait for classify_events_kernel; the table variant notes the step of this
-                            // launch in the type (-10 - k): the row of the controller table that holds the ego's pose
-                            head.type = ((ometa >> 8) & 0xff) == 0 ? (TAB ? -10 - k : -1) : 5;
+                            // 5 = non_vehicle; Vehicle hazards (15 here, -1 once unpacked) wait for classify_events_kernel.
+                            // The table variant packs the step of this launch above bit 4: the row of the controller
+                            // table that holds the ego's pose at the event (event_ego_pose_kernel unpacks it)
+                            head.type = (((ometa >> 8) & 0xff) == 0 ? (TAB ? 15 : -1) : 5) | (TAB ? (k + 1) << 4 : 0);
                             head.reserved = 0;
                             *reinterpret_cast<decltype(head) *>(dst) = head;
                             if (!TAB) { // in-kernel controllers: the ego pose of the event goes along.  (Not in the table
@@ -2726,13 +2727,13 @@ __device__ inline int sg_collision_point_class(const double *box8, double angle,
 }
 
 __device__ inline int sg_classify_collision(const double *eb, double ex, double ey, double eh, const double *hb, double hx,
-                                            double hy, double hh, double c_tol)
+                                            double hy, double hh, double c_tol, double &px, double &py, double &collision_angle)
 {
     const double pi = 3.14159265358979311600e+00, tau = pi * 2;
-    double clip[16], px, py;
+    double clip[16];
     const int n = sg_clip_quads(eb, hb, clip);
-    sg_poly_centroid(clip, n, px, py);
-    const double collision_angle = sg_pymod(hh - eh, tau);
+    sg_poly_centroid(clip, n, px, py); // CollisionPointMetric.record_collision_position, metrics/collision.py:242-253
+    collision_angle = sg_pymod(hh - eh, tau);
     const double ego_angle = sg_pymod(sg_atan2(py - ey, px - ex) - eh, tau);
     const double haz_angle = sg_pymod(sg_atan2(py - hy, px - hx) - hh, tau);
     const int ep = sg_collision_point_class(eb, ego_angle, eh, c_tol), hp = sg_collision_point_class(hb, haz_angle, hh, c_tol);
@@ -2745,8 +2746,8 @@ __device__ inline int sg_classify_collision(const double *eb, double ex, double 
 }
 
 // Right after a table-variant launch, while its controller table is still there: the events it recorded for Vehicle hazards
-// (type -10 - k, k = step inside the launch) take the controlled ego's pose at that step from the table row and become
-// ordinary pending events (-1).  A few loads and stores per event; the classification itself waits for sg_read_metrics.
+// (type packed with k, the step inside the launch) take the controlled ego's pose at that step from the table row and become
+// ordinary pending events.  A few loads and stores per event; the classification itself waits for sg_read_metrics.
 __global__ __launch_bounds__(64) void event_ego_pose_kernel(Params p, const double *tab)
 {
     const int r = blockIdx.x;
@@ -2759,13 +2760,14 @@ __global__ __launch_bounds__(64) void event_ego_pose_kernel(Params p, const doub
     const bool from_tab = ectl >= 0 && (ekind == SG_KIND_AGENT_PID || ekind == SG_KIND_AGENT_VEHICLE);
     for (int i = threadIdx.x; i < n; i += 64) {
         sg_event &ev = p.events[(size_t)r * p.ev_cap + i];
-        if (ev.type > -10) continue;
+        if (ev.type < 16) continue; // not packed: recorded by another launch
+        const int k_launch = (ev.type >> 4) - 1, base = ev.type & 15;
         if (from_tab) {
-            const double *row = tab + ((size_t)ectl * (size_t)(p.tab_steps + 1) + (size_t)(-10 - ev.type)) * CT_W;
+            const double *row = tab + ((size_t)ectl * (size_t)(p.tab_steps + 1) + (size_t)k_launch) * CT_W;
             double *ep = p.ev_pose + ((size_t)r * p.ev_cap + i) * 3;
             ep[0] = row[CT_X]; ep[1] = row[CT_Y]; ep[2] = row[CT_H];
         }
-        ev.type = -1;
+        ev.type = base == 15 ? -1 : base;
     }
 }
 
@@ -2778,7 +2780,11 @@ __global__ __launch_bounds__(64) void classify_events_kernel(Params p, double c_
     const int n = min(p.sdyn[r].n_events, p.ev_cap);
     for (int i = threadIdx.x; i < n; i += 64) {
         sg_event &ev = p.events[(size_t)r * p.ev_cap + i];
-        if (ev.type != -1 && ev.type > -10) continue; // (<= -10: a table-variant launch without controlled lanes)
+        if (ev.reserved != 0) continue; // done by an earlier read
+        if (ev.type >= 16) ev.type = (ev.type & 15) == 15 ? -1 : (ev.type & 15); // packed by a table-variant launch without controlled lanes
+        const bool vehicle = ev.type == -1;
+        ev.reserved = 1;
+        double *pt = p.ev_pose + ((size_t)r * p.ev_cap + i) * 3; // in: ego pose of the event, out: collision point + angle
         const uint32_t hidx = (uint32_t)r * p.EP + ev.other, eidx = (uint32_t)r * p.EP + ss.ego;
         const LanePtr hst(p.stat + (size_t)(hidx >> 6) * (ST_COUNT * 64), (hidx & 63) * 8u);
         const LanePtr est(p.stat + (size_t)(eidx >> 6) * (ST_COUNT * 64), (eidx & 63) * 8u);
@@ -2794,13 +2800,13 @@ __global__ __launch_bounds__(64) void classify_events_kernel(Params p, double c_
             for (int c = 0; c < 6; ++c) hp[c] = S.sl[c] * dq + S.ylo[c];
         } else if (kind == SG_KIND_AGENT_REPLAY) {
             own_position_clamped(p.knots + fld<int64_t>(hst, ST_KNOT_OFF) * 7, (int)(meta >> 32), ev.t, hp);
-        } else {
-            ev.type = -2; // a controlled hazard: its pose at the event is not recoverable from a trajectory
+        } else { // a controlled hazard: its pose at the event is not recoverable from a trajectory
+            if (vehicle) ev.type = -2;
+            pt[0] = pt[1] = pt[2] = __builtin_nan("");
             continue;
         }
         const int64_t emeta = fld<int64_t>(est, ST_META);
-        const double *ep = p.ev_pose + ((size_t)r * p.ev_cap + i) * 3;
-        double ex = ep[0], ey = ep[1], eh = ep[2];
+        double ex = pt[0], ey = pt[1], eh = pt[2];
         if ((int)(emeta & 0xff) == SG_KIND_AGENT_REPLAY) {
             double q[6];
             own_position_clamped(p.knots + fld<int64_t>(est, ST_KNOT_OFF) * 7, (int)(emeta >> 32), ev.t, q);
@@ -2811,7 +2817,10 @@ __global__ __launch_bounds__(64) void classify_events_kernel(Params p, double c_
         sg_corners(ex, ey, s, c, fld(est, ST_BW), fld(est, ST_BL), fld(est, ST_BCX), fld(est, ST_BCY), EB);
         sg_sincos(hp[3], s, c);
         sg_corners(hp[0], hp[1], s, c, fld(hst, ST_BW), fld(hst, ST_BL), fld(hst, ST_BCX), fld(hst, ST_BCY), HB);
-        ev.type = sg_classify_collision(EB, ex, ey, eh, HB, hp[0], hp[1], hp[3], c_tol);
+        double cpx, cpy, cang;
+        const int cls = sg_classify_collision(EB, ex, ey, eh, HB, hp[0], hp[1], hp[3], c_tol, cpx, cpy, cang);
+        if (vehicle) ev.type = cls;
+        pt[0] = cpx; pt[1] = cpy; pt[2] = cang;
     }
 }
 

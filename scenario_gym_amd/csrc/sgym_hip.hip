@@ -850,6 +850,33 @@ extern "C" int sg_read_metrics(sg_handle *h, sg_metrics *out, sg_event *events, 
     return SG_OK;
 }
 
+// CollisionPointMetric.get_state (metrics/collision.py:217-253) for the events sg_read_metrics lists, in its order
+extern "C" int sg_read_collision_points(sg_handle *h, double *out, int32_t cap, int32_t *n_events)
+{
+    if (!h || !out) return h ? fail(h, SG_ERR_INVALID, "sg_read_collision_points: null argument") : SG_ERR_INVALID;
+    if (!h->uploaded) return fail(h, SG_ERR_STATE, "sg_read_collision_points: no scenarios uploaded");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    const int R = h->R;
+    const Params &p = h->p;
+    if (p.ev_cap > 0) {
+        sg::classify_events_kernel<<<dim3((unsigned)R), dim3(64), 0, h->stream>>>(p, h->c_tol);
+        HIP_TRY(h, hipGetLastError());
+    }
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    std::vector<sg_scenario_state> sd(R);
+    HIP_TRY(h, hipMemcpy(sd.data(), p.sdyn, (size_t)R * sizeof(sg_scenario_state), hipMemcpyDeviceToHost));
+    std::vector<double> all((size_t)R * std::max(p.ev_cap, 1) * 3);
+    HIP_TRY(h, hipMemcpy(all.data(), p.ev_pose, all.size() * sizeof(double), hipMemcpyDeviceToHost));
+    int64_t k = 0;
+    for (int r = 0; r < R; ++r)
+        for (int i = 0; i < std::min(sd[r].n_events, p.ev_cap); ++i, ++k) {
+            if (k >= cap) return fail(h, SG_ERR_CAPACITY, "sg_read_collision_points: more events than cap=%d", cap);
+            for (int c = 0; c < 3; ++c) out[k * 3 + c] = all[((size_t)r * p.ev_cap + i) * 3 + c];
+        }
+    if (n_events) *n_events = (int32_t)k;
+    return SG_OK;
+}
+
 extern "C" int sg_read_record(sg_handle *h, int32_t n_rows, double *t_out, double *pose_out)
 {
     if (!h || n_rows < 0) return SG_ERR_INVALID;

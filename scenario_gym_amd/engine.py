@@ -365,6 +365,14 @@ class RolloutEngine:
                                              ev.ctypes.data_as(C.POINTER(L.SgEvent)), cap, C.byref(n_ev)), "sg_read_metrics")
         return rows, ev[: n_ev.value].copy()
 
+    def collision_points(self, event_cap=None):
+        """CollisionPointMetric for the events of metrics(), same order: [n_events, 3] = x, y, relative heading."""
+        cap = int(event_cap or self.R * max(int(self.cfg.event_capacity), 1))
+        out = np.empty((cap, 3))
+        n = C.c_int32()
+        self._check(self.lib.sg_read_collision_points(self.h, out.ctypes.data, cap, C.byref(n)), "sg_read_collision_points")
+        return out[: n.value].copy()
+
     def record(self, n_rows):
         """State.recorded_poses for the whole batch: t [n, R], poses [n, R, E, 6]."""
         t = np.empty((n_rows, self.R))

@@ -14,7 +14,7 @@ import numpy as np
 
 from .agent import _create_agent
 from .engine import TERMINAL_BITS, RolloutEngine
-from .metrics import Metric, _DeviceMetric
+from .metrics import CollisionPointMetric, Metric, _DeviceMetric
 from .packing import pack_scenarios
 from .scenario import Scenario
 from .state import State
@@ -302,12 +302,17 @@ class BatchedScenarioGym:
             self.engine._check(self.engine.lib.sg_set_collision_tolerance(self.engine.h, float(tols.pop())),
                                "sg_set_collision_tolerance")
         rows, events = self.engine.metrics()
+        want_points = any(isinstance(m, CollisionPointMetric) for ms in self.metrics for m in ms)
+        points = self.engine.collision_points() if want_points else None
         out = []
         for i, ms in enumerate(self.metrics):
-            ev = events[events["scenario"] == i]
+            sel = events["scenario"] == i
+            ev = events[sel]
             values = {}
             for m in ms:
-                if isinstance(m, _DeviceMetric):
+                if isinstance(m, CollisionPointMetric):
+                    m._load(rows[i], ev, self._packed.refs[i], points[sel])
+                elif isinstance(m, _DeviceMetric):
                     m._load(rows[i], ev, self._packed.refs[i])
                 v = m.get_state()
                 if isinstance(v, dict):

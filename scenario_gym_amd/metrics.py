@@ -5,6 +5,7 @@ rollout kernel; their `get_state()` reads the per-scenario row the gym fetched. 
 subclass is stepped on the host after every device step (ScenarioGym falls back to one launch per step).
 """
 from abc import ABC, abstractmethod
+import numpy as np
 from typing import Any, List, Optional, Tuple
 
 
@@ -106,6 +107,28 @@ class CollisionMetric(_DeviceMetric):
     def _load(self, row, events, refs) -> None:
         self.collisions = [(float(e["t"]), refs[int(e["other"])], COLLISION_TYPE_NAMES.get(int(e["type"]), "other"))
                            for e in events]
+
+    def get_state(self):
+        return list(self.collisions)
+
+
+class CollisionPointMetric(_DeviceMetric):
+    """metrics/collision.py:206-253: for every NEW collision with the ego (ref, collision point, relative heading): the
+    centroid of the intersection of the two bounding boxes and (hazard heading - ego heading) mod 2 pi, computed on the
+    device (sg_read_collision_points) with state.poses[...] where the reference reads the missing `Entity.pose`."""
+
+    name = "collision_points"
+    device_field = "n_collisions"
+
+    def __init__(self, name: Optional[str] = None):
+        super().__init__(name=name)
+        self.collisions = []
+
+    def _reset(self, state) -> None:
+        self.collisions = []
+
+    def _load(self, row, events, refs, points=None) -> None:
+        self.collisions = [(refs[int(e["other"])], np.array([p[0], p[1]]), float(p[2])) for e, p in zip(events, points)]
 
     def get_state(self):
         return list(self.collisions)

@@ -27,6 +27,7 @@ import make_golden as MG  # noqa: E402
 from scenario_gym import ScenarioGym  # noqa: E402
 from scenario_gym.entity import Entity  # noqa: E402
 from scenario_gym.metrics import CollisionMetric  # noqa: E402
+from scenario_gym.metrics.collision import CollisionPointMetric  # noqa: E402
 from scenario_gym.scenario import Scenario  # noqa: E402
 
 CURRENT = {}
@@ -68,16 +69,19 @@ def main():
         for i, h in enumerate(haz):
             ents.append(MG.make_entity(h, f"entity_{i}", ctype="Vehicle" if (i + len(name)) % 5 else "Misc"))
         sc = Scenario(ents, name=name)
-        gym = ScenarioGym(timestep=0.05, metrics=[CollisionMetric()])
+        gym = ScenarioGym(timestep=0.05, metrics=[CollisionMetric(), CollisionPointMetric()])
         CURRENT["gym"] = gym
         gym.set_scenario(sc)
         gym.rollout()
         ev = gym.get_metrics()["collisions"]
+        pts = gym.get_metrics()["collision_points"]  # (ref, point, angle), metrics/collision.py:242-253
+        assert [r for r, _, _ in pts] == [r for _, r, _ in ev]
         out.update(MG.flat(f"{name}/scenario", MG.export_scenario(sc)))
         refs = [e.ref for e in ents]
         out[f"{name}/ev_t"] = np.array([t for t, _, _ in ev], np.float64)
         out[f"{name}/ev_other"] = np.array([refs.index(r) for _, r, _ in ev], np.int64)
         out[f"{name}/ev_type"] = np.array([TYPES.index(c) for _, _, c in ev], np.int64)
+        out[f"{name}/ev_point"] = np.array([[p[0], p[1], a] for _, p, a in pts], np.float64).reshape(-1, 3)
         names.append(name)
         total += len(ev)
         print(name, [(round(t, 2), r, c) for t, r, c in ev])

@@ -813,10 +813,13 @@ def test_collision_metric_types_through_the_gym(oracle):
     types = [str(t) for t in g["types"]]
     for n in ("head_on", "rear_end", "rear_ended", "t_bone", "t_boned", "side_swipe", "oblique", "rand3", "rand27"):
         sc = scenario_from_arrays(scenario_arrays(g, f"{n}/scenario"), g[f"{n}/scenario/refs"])
-        gym = sga.ScenarioGym(timestep=0.05, metrics=[sga.CollisionMetric()])
+        gym = sga.ScenarioGym(timestep=0.05, metrics=[sga.CollisionMetric(), sga.CollisionPointMetric()])
         gym.set_scenario(sc)
         gym.rollout()
         got = gym.get_metrics()["collisions"]
+        pts = gym.get_metrics()["collision_points"]
+        assert [r for r, _, _ in pts] == [r for _, r, _ in got]
+        assert all(np.abs(np.array([*p, a]) - w).max() < 1e-10 for (_, p, a), w in zip(pts, g[f"{n}/ev_point"]))
         want = [(float(t), str(g[f"{n}/scenario/refs"][o]), types[k]) for t, o, k in zip(g[f"{n}/ev_t"], g[f"{n}/ev_other"], g[f"{n}/ev_type"])]
         assert got == want, (n, got, want)
         gym.close()

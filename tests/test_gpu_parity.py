@@ -1280,12 +1280,16 @@ def test_collision_types_match_reference_code_and_oracle(sga, oracle):
     eng.upload(packed)
     eng.rollout(200)
     rows, events = eng.metrics()
+    points = eng.collision_points()
     eng.close()
     seen = set()
     for r, n in enumerate(names):
-        ev = events[events["scenario"] == r]
+        sel = events["scenario"] == r
+        ev = events[sel]
         assert np.array_equal(ev["t"], g[f"{n}/ev_t"]) and np.array_equal(ev["other"], g[f"{n}/ev_other"]), n
         assert np.array_equal(ev["type"], g[f"{n}/ev_type"]), (n, ev["type"], g[f"{n}/ev_type"])
+        # CollisionPointMetric: the reference's (point, angle); box corners differ from numpy's by <= 1 ulp of sin / cos
+        assert len(ev) == 0 or np.abs(points[sel] - g[f"{n}/ev_point"]).max() < 1e-10, n
         seen |= set(ev["type"].tolist())
     assert seen == {1, 2, 3, 4, 5}
     for ego_kind in (L.KIND_AGENT_REPLAY, L.KIND_AGENT_PID):
@@ -1295,6 +1299,7 @@ def test_collision_types_match_reference_code_and_oracle(sga, oracle):
         eng.upload(packed)
         eng.rollout(steps)
         rows, events = eng.metrics()
+        points = eng.collision_points()
         eng.close()
         n_ev = 0
         for r in range(0, R, 3):
@@ -1304,6 +1309,7 @@ def test_collision_types_match_reference_code_and_oracle(sga, oracle):
             ev = events[events["scenario"] == r]
             assert np.array_equal(ev["t"], o["ev_t"]) and np.array_equal(ev["other"], o["ev_other"]), r
             assert np.array_equal(ev["type"], o["ev_type"]), (r, ev["type"], o["ev_type"])
+            assert bits_equal(points[events["scenario"] == r], o["ev_point"]), r  # non-vehicle hazards included
             n_ev += len(ev)
         assert n_ev > 40
 

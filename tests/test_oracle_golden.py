@@ -486,5 +486,9 @@ def test_collision_types_match_reference_code(oracle):
                            s["length"], 0.05, record=False)
         assert np.array_equal(o["ev_t"], g[f"{n}/ev_t"]) and np.array_equal(o["ev_other"], g[f"{n}/ev_other"]), n
         assert np.array_equal(o["ev_type"], g[f"{n}/ev_type"]), (n, o["ev_type"], g[f"{n}/ev_type"])
+        # CollisionPointMetric (:242-253): intersection centroid and relative heading (box corners differ from numpy's by
+        # <= 1 ulp of sin / cos)
+        assert o["ev_point"].shape == g[f"{n}/ev_point"].shape
+        assert len(o["ev_point"]) == 0 or np.abs(o["ev_point"] - g[f"{n}/ev_point"]).max() < 1e-10, n
         seen |= set(o["ev_type"].tolist())
     assert seen == {1, 2, 3, 4, 5}
