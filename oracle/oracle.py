@@ -297,6 +297,27 @@ def raster_entities(poses, bbox, ego, width=20.0, height=20.0, nw=20, nh=20):
     return out.astype(bool)
 
 
+def rss_rollout(o, bbox, ego=0):
+    """RSSDistances + RSS (metrics/rss) along an oracle rollout `o` (recorded): per step and entity the record code
+    (0 safe, 1 lateral, 2 longitudinal, 3 both, 4 unsafe_lateral, 5 unsafe_longitudinal, 6 found, -1 no update), the safe
+    (lateral, longitudinal) distances, and the two metric flags."""
+    L = lib()
+    L.sgo_rss_update.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 7
+    L.sgo_rss_update.restype = None
+    S, E = o["poses"].shape[:2]
+    bbox = np.ascontiguousarray(bbox, np.float64)
+    st = np.zeros((E, 2), np.int32)
+    codes, safes = np.full((S, E), -1, np.int32), np.full((S, E, 2), np.nan)
+    for k in range(S):
+        if o["t"][k] == 0.0:  # "Require at least two poses to calculate velocity", callback.py:76-78
+            continue
+        poses = np.ascontiguousarray(o["poses"][k])
+        present = np.ascontiguousarray(~np.isnan(poses[:, 0])).astype(np.uint8)
+        vels = np.ascontiguousarray(np.nan_to_num(o["vels"][k]))
+        L.sgo_rss_update(E, int(ego), _p(poses), _p(vels), _p(present), _p(bbox), _p(st), _p(safes[k]), _p(codes[k]))
+    return dict(code=codes, safe=safes, safe_lateral=not (st[:, 0] == 1).any(), safe_longitudinal=not (st[:, 0] == 2).any())
+
+
 def quads_intersect(a, b):
     a = np.ascontiguousarray(a, np.float64)
     b = np.ascontiguousarray(b, np.float64)

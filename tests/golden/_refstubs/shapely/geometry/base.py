@@ -198,6 +198,8 @@ class Polygon(BaseGeometry):
         raise NotImplementedError
 
     def intersects(self, other):
+        if isinstance(other, LineString) and not isinstance(other, LinearRing):
+            return convex_intersects_segment_exact(self._ring(), list(other.coords))
         return convex_intersects_exact(self._ring(), other._ring())
 
     def __eq__(self, o):
@@ -312,3 +314,34 @@ def _contains_exact(rings, x, y):
                 if det > 0:
                     cross += 1
     return cross % 2 == 1
+
+
+def convex_intersects_segment_exact(ring, seg):
+    """Closed convex ring against a closed 2-point segment, exact rational: an endpoint inside or on the ring, or the
+    segment meeting one of its edges."""
+    (ax, ay), (bx, by) = [(_F(x), _F(y)) for x, y in seg[:2]]
+    R = [(_F(x), _F(y)) for x, y in ring]
+
+    def orient(p, q, r):
+        v = (q[0] - p[0]) * (r[1] - p[1]) - (q[1] - p[1]) * (r[0] - p[0])
+        return (v > 0) - (v < 0)
+
+    def inside_closed(p):
+        signs = [orient(R[k], R[(k + 1) % len(R)], p) for k in range(len(R))]
+        return not (any(s > 0 for s in signs) and any(s < 0 for s in signs))
+
+    def on_seg(p, q, r):
+        return min(p[0], q[0]) <= r[0] <= max(p[0], q[0]) and min(p[1], q[1]) <= r[1] <= max(p[1], q[1])
+
+    A, B = (ax, ay), (bx, by)
+    if inside_closed(A) or inside_closed(B):
+        return True
+    for k in range(len(R)):
+        Cc, D = R[k], R[(k + 1) % len(R)]
+        o1, o2, o3, o4 = orient(A, B, Cc), orient(A, B, D), orient(Cc, D, A), orient(Cc, D, B)
+        if o1 * o2 < 0 and o3 * o4 < 0:
+            return True
+        if (o1 == 0 and on_seg(A, B, Cc)) or (o2 == 0 and on_seg(A, B, D)) or (o3 == 0 and on_seg(Cc, D, A)) or \
+                (o4 == 0 and on_seg(Cc, D, B)):
+            return True
+    return False

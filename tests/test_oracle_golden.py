@@ -492,3 +492,28 @@ def test_collision_types_match_reference_code(oracle):
         assert len(o["ev_point"]) == 0 or np.abs(o["ev_point"] - g[f"{n}/ev_point"]).max() < 1e-10, n
         seen |= set(o["ev_type"].tolist())
     assert seen == {1, 2, 3, 4, 5}
+
+
+def test_rss_distances_and_metric_match_reference(oracle):
+    """RSSDistances + RSS (metrics/rss/callback.py, rss.py; tests/test_rss.py:5-25) on the reference's shipped scenarios
+    and on synthetic traffic around the ego: every record the callback appended to its per-entity history (safe / lateral /
+    longitudinal / both / unsafe_lateral / unsafe_longitudinal / found), the safe distances it computed, and the two
+    metric flags."""
+    from scenario_gym_amd.packing import default_kinds
+
+    g = load_golden("rss")
+    n_unsafe = 0
+    for n in g["names"]:
+        s = scenario_arrays(g, f"{n}/scenario")
+        E = len(s["bbox"])
+        o = oracle.rollout(s["knot_off"], s["knots"], s["bbox"], s["etype"], default_kinds(E, s["ego"]), s["ego"], s["t0"],
+                           s["length"], 0.1)
+        assert bits_equal(o["t"], g[f"{n}/t"]), n
+        r = oracle.rss_rollout(o, s["bbox"], s["ego"])
+        want_code, want_safe = g[f"{n}/code"], g[f"{n}/safe"]
+        assert np.array_equal(r["code"], want_code), (n, np.argwhere(r["code"] != want_code)[:5])
+        upd = want_code >= 0
+        assert np.abs(r["safe"][upd] - want_safe[upd]).max() < 1e-9, n
+        assert r["safe_longitudinal"] == bool(g[f"{n}/safe_longitudinal"]) and r["safe_lateral"] == bool(g[f"{n}/safe_lateral"]), n
+        n_unsafe += (want_code == 4).sum() + (want_code == 5).sum()
+    assert n_unsafe > 30
