@@ -309,6 +309,18 @@ int sg_raster_map_device(sg_handle *h, double width, double height, int32_t nw, 
 int sg_tick(sg_handle *h, const double *actions, int32_t actions_device, double width, double height, int32_t nw, int32_t nh,
             int32_t n_layers, const int32_t *layers, const uint8_t **d_obs, const uint32_t **d_flags);
 
+/* RSSDistances.__call__ (metrics/rss/callback.py:58-128) on the current state of every scenario: safe lateral /
+ * longitudinal distances between the ego (which must be entity 0, as the reference's callback assumes) and every present
+ * entity, the record it appends to that entity's history, and the "unsafe" verdicts the RSS metric reads
+ * (metrics/rss/rss.py:70-104).  Call once after sg_reset (reset = 1: forget the histories) and once after every step;
+ * scenarios at t == 0.0 are skipped as in the reference.  Asynchronous on sg_stream(h). */
+int sg_rss_update(sg_handle *h, int32_t reset);
+/* flags [R]: bit 0 = RSS_safe_longitudinal, bit 1 = RSS_safe_lateral (no entity's history holds the corresponding
+ * "unsafe_*" record); codes [R*E] of the latest update: 0 safe, 1 lateral, 2 longitudinal, 3 both, 4 unsafe_lateral,
+ * 5 unsafe_longitudinal, 6 found, -1 not updated; safe [R*E][2]: lateral, longitudinal safe distance (NaN when not
+ * updated).  HOST buffers, each may be NULL. */
+int sg_rss_read(sg_handle *h, uint8_t *flags, int32_t *codes, double *safe);
+
 /* CollisionMetric(c_tol) (metrics/collision.py:57-62, default 0.4 rad): the angular half-width of a box corner in
  * get_collision_point; applies to the events classified by the following sg_read_metrics calls. */
 int sg_set_collision_tolerance(sg_handle *h, double c_tol);

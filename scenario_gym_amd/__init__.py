@@ -23,7 +23,9 @@ from .agent import (  # noqa: F401
 from .engine import PackedScenarios, RolloutEngine  # noqa: F401
 from .entity import BoundingBox, CatalogEntry, Entity, MiscObject, Pedestrian, Vehicle  # noqa: F401
 from .gym import BatchedScenarioGym, ScenarioGym  # noqa: F401
-from .metrics import CollisionMetric, CollisionPointMetric, EgoAvgSpeed, EgoDistanceTravelled, EgoMaxSpeed, Metric  # noqa: F401
+from .metrics import (  # noqa: F401
+    RSS, CollisionMetric, CollisionPointMetric, EgoAvgSpeed, EgoDistanceTravelled, EgoMaxSpeed, Metric, RSSDistances,
+)
 from .scenario import Scenario  # noqa: F401
 from .state import State  # noqa: F401
 from .trajectory import Trajectory  # noqa: F401

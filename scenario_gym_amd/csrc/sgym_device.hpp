@@ -2824,6 +2824,172 @@ __global__ __launch_bounds__(64) void classify_events_kernel(Params p, double c_
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// RSSDistances.__call__ (metrics/rss/callback.py:58-128) on the current state of every scenario, + the flags RSS reads
+// (metrics/rss/rss.py:70-104).  One workgroup per scenario, one thread per entity.  Ego frame: x lateral, y longitudinal;
+// np.dot of 2-vectors = fma(a1, b1, a0 * b0), norm([u, v]) = sqrt(fma(v, v, u * u)) (probed); the per-entity history list
+// is carried as (found, last): an "unsafe_*" entry exists / the latest "lateral" | "longitudinal" entry.  Same operation
+// sequence as the oracle's sgo_rss_update.
+// ------------------------------------------------------------------------------------------------
+__device__ inline double rss_dot2(double a0, double a1, double b0, double b1) { return __builtin_fma(a1, b1, a0 * b0); }
+__device__ inline void rss_inv_dir(double v0, double v1, double &o0, double &o1)
+{
+    const double n = sg_norm2(v1, v0);
+    o0 = v1 / n;
+    o1 = -v0 / n;
+}
+__device__ inline bool rss_on_segment(double ax, double ay, double bx, double by, double px, double py)
+{
+    return px >= __builtin_fmin(ax, bx) && px <= __builtin_fmax(ax, bx) && py >= __builtin_fmin(ay, by) && py <= __builtin_fmax(ay, by);
+}
+__device__ inline bool rss_point_in_quad(const double *Q, double px, double py)
+{
+    bool pos = false, neg = false;
+    for (int k = 0; k < 4; ++k) {
+        const int m = (k + 1) & 3, o = rn_orient_sign(Q[2 * k], Q[2 * k + 1], Q[2 * m], Q[2 * m + 1], px, py);
+        pos |= o > 0;
+        neg |= o < 0;
+    }
+    return !(pos && neg);
+}
+__device__ inline bool rss_seg_quad(const double *Q, double ax, double ay, double bx, double by)
+{
+    if (rss_point_in_quad(Q, ax, ay) || rss_point_in_quad(Q, bx, by)) return true;
+    for (int k = 0; k < 4; ++k) {
+        const int m = (k + 1) & 3;
+        const double cx = Q[2 * k], cy = Q[2 * k + 1], dx = Q[2 * m], dy = Q[2 * m + 1];
+        const int o1 = rn_orient_sign(ax, ay, bx, by, cx, cy), o2 = rn_orient_sign(ax, ay, bx, by, dx, dy);
+        const int o3 = rn_orient_sign(cx, cy, dx, dy, ax, ay), o4 = rn_orient_sign(cx, cy, dx, dy, bx, by);
+        if (o1 * o2 < 0 && o3 * o4 < 0) return true;
+        if ((o1 == 0 && rss_on_segment(ax, ay, bx, by, cx, cy)) || (o2 == 0 && rss_on_segment(ax, ay, bx, by, dx, dy)) ||
+            (o3 == 0 && rss_on_segment(cx, cy, dx, dy, ax, ay)) || (o4 == 0 && rss_on_segment(cx, cy, dx, dy, bx, by)))
+            return true;
+    }
+    return false;
+}
+
+// rss_state [NE] = found | last << 8; code [NE]: 0 safe, 1 lateral, 2 longitudinal, 3 both, 4 unsafe_lateral,
+// 5 unsafe_longitudinal, 6 found, -1 not updated; safe [NE][2] = lateral, longitudinal
+__global__ __launch_bounds__(256) void rss_kernel(Params p, int reset, int32_t *rss_state, int32_t *code, double *safe)
+{
+    __shared__ double ego[8]; // x, y, heading, vx, vy, width, length, present
+    const int r = blockIdx.x, e = threadIdx.x;
+    const ScenStatic &ss = p.sstat[r];
+    const uint32_t idx = (uint32_t)r * p.EP + (e < p.EP ? e : 0);
+    const LanePtr st(p.stat + (size_t)(idx >> 6) * (ST_COUNT * 64), (idx & 63) * 8u);
+    const LanePtr dy(p.dyn + (size_t)(idx >> 6) * ((size_t)p.FROWS * 64), (idx & 63) * 8u);
+    const bool in = e < p.E;
+    const bool present = in && fld<uint64_t>(dy, SG_F_PRESENT) != 0;
+    double hp[4] = {0, 0, 0, 0}, hv[2] = {0, 0};
+    if (in) {
+        hp[0] = fld(dy, SG_F_POSE + 0); hp[1] = fld(dy, SG_F_POSE + 1); hp[3] = fld(dy, SG_F_POSE + 3);
+        hv[0] = fld(dy, SG_F_VEL + 0); hv[1] = fld(dy, SG_F_VEL + 1);
+    }
+    if (e == ss.ego) {
+        ego[0] = hp[0]; ego[1] = hp[1]; ego[2] = hp[3]; ego[3] = hv[0]; ego[4] = hv[1];
+        ego[5] = fld(st, ST_BW); ego[6] = fld(st, ST_BL); ego[7] = present ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    if (!in) return;
+    int32_t state = reset ? 0 : rss_state[idx];
+    int cd = -1;
+    double s_lat = __builtin_nan(""), s_long = __builtin_nan("");
+    const bool skip = p.sdyn[r].t == 0.0 || ego[7] == 0.0 || e == ss.ego || !present; // callback.py:76-78
+    if (!skip) {
+        const double RESPONSE_TIME = 0.6, MIN_LONG_ACCEL = 1.2 * 9.81, MAX_LONG_ACCEL = 1.2 * 9.81, MIN_SAFE_CLEARANCE = 0.1;
+        const double ex = ego[0], ey = ego[1], ego_w = ego[5], ego_l = ego[6];
+        double es, ec, ei0, ei1;
+        sg_sincos(ego[2], es, ec);
+        const double eh0 = ec, eh1 = es;
+        rss_inv_dir(eh0, eh1, ei0, ei1);
+        const double ego_head0 = rss_dot2(eh0, eh1, ei0, ei1), ego_head1 = rss_dot2(eh0, eh1, eh0, eh1);
+        const double ego_vel0 = rss_dot2(ego[3], ego[4], ei0, ei1), ego_vel1 = rss_dot2(ego[3], ego[4], eh0, eh1);
+        const double ego_pos1 = rss_dot2(ex - ex, ey - ey, eh0, eh1);
+        double hs, hc;
+        sg_sincos(hp[3], hs, hc);
+        const double pos0 = rss_dot2(hp[0] - ex, hp[1] - ey, ei0, ei1), pos1 = rss_dot2(hp[0] - ex, hp[1] - ey, eh0, eh1);
+        const double head0 = rss_dot2(hc, hs, ei0, ei1), head1 = rss_dot2(hc, hs, eh0, eh1);
+        const double vel0 = rss_dot2(hv[0], hv[1], ei0, ei1), vel1 = rss_dot2(hv[0], hv[1], eh0, eh1);
+        double cor[8], Q[8];
+        sg_corners(hp[0], hp[1], hs, hc, fld(st, ST_BW), fld(st, ST_BL), fld(st, ST_BCX), fld(st, ST_BCY), cor);
+        for (int k = 0; k < 4; ++k) {
+            Q[2 * k] = rss_dot2(cor[2 * k] - ex, cor[2 * k + 1] - ey, ei0, ei1);
+            Q[2 * k + 1] = rss_dot2(cor[2 * k] - ex, cor[2 * k + 1] - ey, eh0, eh1);
+        }
+        { // safe_longitudinal_distance, :231-272
+            const double dd = rss_dot2(ego_head0, ego_head1, head0, head1);
+            const double m = __builtin_fabs(MAX_LONG_ACCEL * dd), rt = RESPONSE_TIME;
+            if (dd > 0) {
+                double vf, vr;
+                if (ego_pos1 > pos1) { vf = sg_norm2(ego_vel0, ego_vel1); vr = rss_dot2(vel0, vel1, ego_head0, ego_head1); }
+                else { vf = rss_dot2(vel0, vel1, ego_head0, ego_head1); vr = sg_norm2(ego_vel0, ego_vel1); }
+                if (vr == 0.0) s_long = MIN_SAFE_CLEARANCE + 0.5 * ego_l;
+                else {
+                    const double a = vr * rt + __builtin_fmin(vf * vf / (2 * m), 0.5 * m * (rt * rt)) +
+                                     ((vr + rt * m) * (vr + rt * m)) / (2 * MIN_LONG_ACCEL) - vf * vf / (2 * m);
+                    s_long = __builtin_fmax(0.0, a) + MIN_SAFE_CLEARANCE + 0.5 * ego_l;
+                }
+            } else {
+                const double v1 = __builtin_fabs(rss_dot2(ego_vel0, ego_vel1, ego_head0, ego_head1));
+                const double av2 = __builtin_fabs(-__builtin_fabs(rss_dot2(vel0, vel1, ego_head0, ego_head1)));
+                const int sp = (pos1 > 0) - (pos1 < 0), sv = (vel1 > 0) - (vel1 < 0);
+                if (sp == sv) s_long = MIN_SAFE_CLEARANCE + 0.5 * ego_l;
+                else {
+                    const double a = (2 * v1 + rt * m) * rt / 2 + ((v1 + rt * m) * (v1 + rt * m)) / (2 * MIN_LONG_ACCEL) +
+                                     (2 * av2 + rt * m) * rt / 2 + ((av2 + rt * m) * (av2 + rt * m)) / (2 * MIN_LONG_ACCEL);
+                    s_long = __builtin_fmax(0.0, a) + MIN_SAFE_CLEARANCE + 0.5 * ego_l;
+                }
+            }
+            s_long = __builtin_fabs(s_long);
+        }
+        { // safe_lateral_distance, :274-305
+            double v = vel0, i0, i1;
+            rss_inv_dir(ego_head0, ego_head1, i0, i1);
+            const double ad = __builtin_fabs(rss_dot2(i0, i1, head0, head1));
+            const double max_lat = MAX_LONG_ACCEL * ad, min_lat = MIN_LONG_ACCEL * ad, rt = RESPONSE_TIME;
+            const int sp = (-pos0 > 0) - (-pos0 < 0), sv = (v > 0) - (v < 0);
+            double d0 = 0;
+            bool parallel = false;
+            if (sp == sv) {
+                v = __builtin_fabs(v);
+                if (v == 0.0) parallel = true;
+                else
+                    d0 = __builtin_fmax(0.0, 0.5 * rt * (2 * v + rt * max_lat) + ((v + rt * max_lat) * (v + rt * max_lat)) / (2 * min_lat) -
+                                                 0.5 * (rt * rt) * max_lat - ((rt * max_lat) * (rt * max_lat)) / (2 * min_lat));
+            }
+            s_lat = __builtin_fabs(parallel ? MIN_SAFE_CLEARANCE + 0.5 * ego_w : d0 + MIN_SAFE_CLEARANCE + 0.5 * ego_w);
+        }
+        // unsafe_distance, :179-229
+        const int found = state & 0xff, last = (state >> 8) & 0xff;
+        if (found) {
+            cd = 6;
+        } else {
+            const double B[8] = {s_lat, s_long, -s_lat, s_long, -s_lat, -s_long, s_lat, -s_long};
+            if (sg_quads_intersect(Q, B)) {
+                if (last == 1) cd = 5;
+                else if (last == 2) cd = 4;
+                else {
+                    double j0, j1;
+                    rss_inv_dir(ego_w, ego_l, j0, j1);
+                    const double A = __builtin_fabs(__builtin_fabs(pos0) - __builtin_fabs(rss_dot2(pos0, pos1, ego_w, ego_l))) / s_lat;
+                    const double Bv = __builtin_fabs(__builtin_fabs(pos1 - rss_dot2(pos0, pos1, j0, j1)) / s_long);
+                    cd = A > Bv ? 5 : 4;
+                }
+                state = (state & ~0xff) | (cd == 4 ? 1 : 2);
+            } else { // write_intersections, :307-340 (the "length" lines are the buffer's stretched diagonals, as built)
+                const bool lat_i = rss_seg_quad(Q, B[0], 100 * B[1], B[4], 100 * B[5]) || rss_seg_quad(Q, B[2], 100 * B[3], B[6], 100 * B[7]);
+                const bool long_i = rss_seg_quad(Q, 100 * B[0], B[1], 100 * B[2], B[3]) || rss_seg_quad(Q, 100 * B[4], B[5], 100 * B[6], B[7]);
+                cd = lat_i && long_i ? 3 : (lat_i ? 1 : (long_i ? 2 : 0));
+                if (cd == 1 || cd == 2) state = (state & 0xff) | (cd << 8);
+            }
+        }
+    }
+    rss_state[idx] = state;
+    code[idx] = cd;
+    safe[(size_t)idx * 2] = s_lat;
+    safe[(size_t)idx * 2 + 1] = s_long;
+}
+
 // TERMINAL_CONDITIONS (state/state.py:397-408), all four evaluated on the CURRENT state of every scenario, whatever the
 // handle's terminal mask says: out[r] = SG_TERM_* bits.  The reward of the reference's RL agent asks exactly this of a
 // done state (integrations/openaigym.py:300-310).  One wavefront per scenario.

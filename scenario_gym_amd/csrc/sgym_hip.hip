@@ -50,6 +50,9 @@ struct sg_handle {
     double tick_w = 0, tick_h = 0;
     int tick_nw = 0, tick_nh = 0, tick_nl = 0;
     int32_t tick_layers[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int32_t *d_rss_state = nullptr, *d_rss_code = nullptr; // [NE] sg_rss_update
+    bool ego_first = true;                                 // every scenario's ego is its entity 0
+    double *d_rss_safe = nullptr;                          // [NE][2]
     double c_tol = 0.4;                                // CollisionMetric(c_tol): angular half-width of a box corner, metrics/collision.py:57
     unsigned char *d_reset_mask = nullptr;             // [R] sg_reset_scenarios
     uint32_t *d_term_flags = nullptr;                  // [R] sg_terminal_flags
@@ -184,6 +187,9 @@ extern "C" int sg_destroy(sg_handle *h)
     if (h->obs_buf) (void)hipFree(h->obs_buf);
     if (h->d_reset_mask) (void)hipFree(h->d_reset_mask);
     if (h->d_term_flags) (void)hipFree(h->d_term_flags);
+    if (h->d_rss_state) (void)hipFree(h->d_rss_state);
+    if (h->d_rss_code) (void)hipFree(h->d_rss_code);
+    if (h->d_rss_safe) (void)hipFree(h->d_rss_safe);
     if (h->tick_exec) (void)hipGraphExecDestroy(h->tick_exec);
     if (h->ctl_stream) (void)hipStreamSynchronize(h->ctl_stream);
     if (h->d_actions) (void)hipFree(h->d_actions);
@@ -372,6 +378,7 @@ extern "C" int sg_upload(sg_handle *h, const sg_scenarios *sc)
     free_pool(h->static_allocs);
     free_pool(h->state_allocs);
     free_pool(h->road_allocs); // the networks belong to a batch (net_of_scenario)
+    if (h->d_rss_state) { (void)hipFree(h->d_rss_state); (void)hipFree(h->d_rss_code); (void)hipFree(h->d_rss_safe); h->d_rss_state = nullptr; h->d_rss_code = nullptr; h->d_rss_safe = nullptr; }
     h->has_road = false;
     h->road = sg::RoadIndex{};
     for (int b = 0; b < 2; ++b) { // the controller table geometry depends on the batch
@@ -379,6 +386,7 @@ extern "C" int sg_upload(sg_handle *h, const sg_scenarios *sc)
         h->d_tab[b] = nullptr;
     }
     h->uploaded = false;
+    h->ego_first = true;
     ++h->generation;
     // pedestrian agents are compiled for tiles of >= 16 lanes
     h->has_ped = false;
@@ -408,6 +416,7 @@ extern "C" int sg_upload(sg_handle *h, const sg_scenarios *sc)
     for (int r = 0; r < R; ++r) {
         if (sc->ego[r] < 0 || sc->ego[r] >= E) return fail(h, SG_ERR_INVALID, "sg_upload: ego[%d]=%d out of range", r, sc->ego[r]);
         sstat[r].ego = sc->ego[r];
+        if (sc->ego[r] != 0) h->ego_first = false;
         sstat[r].t0 = sc->t0[r];
         sstat[r].length = sc->length[r];
         for (int e = 0; e < E; ++e) {
@@ -965,6 +974,49 @@ extern "C" int sg_set_tuning(sg_handle *h, int32_t tab_min_steps, int32_t chunk_
     if (chunk_steps > 0) h->chunk_steps = chunk_steps;
     if (overlap >= 0) h->overlap = overlap != 0;
     ++h->generation;
+    return SG_OK;
+}
+
+extern "C" int sg_rss_update(sg_handle *h, int32_t reset)
+{
+    if (!h) return SG_ERR_INVALID;
+    if (!h->uploaded) return fail(h, SG_ERR_STATE, "sg_rss_update: no scenarios uploaded");
+    if (!h->ego_first) return fail(h, SG_ERR_STATE, "sg_rss_update: RSSDistances keeps its records for entities[1:], the ego has to be entity 0 of every scenario");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    if (!h->d_rss_state) {
+        HIP_TRY(h, hipMalloc((void **)&h->d_rss_state, h->NE * sizeof(int32_t)));
+        HIP_TRY(h, hipMalloc((void **)&h->d_rss_code, h->NE * sizeof(int32_t)));
+        HIP_TRY(h, hipMalloc((void **)&h->d_rss_safe, h->NE * 2 * sizeof(double)));
+        reset = 1;
+    }
+    sg::rss_kernel<<<dim3((unsigned)h->R), dim3(256), 0, h->stream>>>(h->p, reset ? 1 : 0, h->d_rss_state, h->d_rss_code, h->d_rss_safe);
+    HIP_TRY(h, hipGetLastError());
+    return SG_OK;
+}
+
+extern "C" int sg_rss_read(sg_handle *h, uint8_t *flags, int32_t *codes, double *safe)
+{
+    if (!h) return SG_ERR_INVALID;
+    if (!h->uploaded || !h->d_rss_state) return fail(h, SG_ERR_STATE, "sg_rss_read: sg_rss_update has not run on this batch");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    const int R = h->R, E = h->E, EP = h->EP;
+    std::vector<int32_t> st(h->NE), cd(h->NE);
+    std::vector<double> sf(h->NE * 2);
+    HIP_TRY(h, hipMemcpy(st.data(), h->d_rss_state, h->NE * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (codes) HIP_TRY(h, hipMemcpy(cd.data(), h->d_rss_code, h->NE * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (safe) HIP_TRY(h, hipMemcpy(sf.data(), h->d_rss_safe, h->NE * 2 * sizeof(double), hipMemcpyDeviceToHost));
+    for (int r = 0; r < R; ++r) {
+        uint8_t f = 3;
+        for (int e = 0; e < E; ++e) {
+            const size_t i = (size_t)r * EP + e, o = (size_t)r * E + e;
+            if ((st[i] & 0xff) == 2) f &= ~1u; // some entity's history holds "unsafe_longitudinal", rss.py:70-86
+            if ((st[i] & 0xff) == 1) f &= ~2u;
+            if (codes) codes[o] = cd[i];
+            if (safe) { safe[o * 2] = sf[i * 2]; safe[o * 2 + 1] = sf[i * 2 + 1]; }
+        }
+        if (flags) flags[r] = f;
+    }
     return SG_OK;
 }
 

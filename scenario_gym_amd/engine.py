@@ -365,6 +365,18 @@ class RolloutEngine:
                                              ev.ctypes.data_as(C.POINTER(L.SgEvent)), cap, C.byref(n_ev)), "sg_read_metrics")
         return rows, ev[: n_ev.value].copy()
 
+    def rss_update(self, reset=False):
+        """RSSDistances.__call__ on the current state of every scenario (after a reset: reset=True)."""
+        self._check(self.lib.sg_rss_update(self.h, int(bool(reset))), "sg_rss_update")
+
+    def rss(self):
+        """(safe_longitudinal [R] bool, safe_lateral [R] bool, codes [R, E], safe distances [R, E, 2]) of the RSS callback."""
+        flags = np.zeros(self.R, np.uint8)
+        codes = np.zeros((self.R, self.E), np.int32)
+        safe = np.zeros((self.R, self.E, 2))
+        self._check(self.lib.sg_rss_read(self.h, flags.ctypes.data, codes.ctypes.data, safe.ctypes.data), "sg_rss_read")
+        return (flags & 1) != 0, (flags & 2) != 0, codes, safe
+
     def collision_points(self, event_cap=None):
         """CollisionPointMetric for the events of metrics(), same order: [n_events, 3] = x, y, relative heading."""
         cap = int(event_cap or self.R * max(int(self.cfg.event_capacity), 1))

@@ -14,7 +14,7 @@ import numpy as np
 
 from .agent import _create_agent
 from .engine import TERMINAL_BITS, RolloutEngine
-from .metrics import CollisionPointMetric, Metric, _DeviceMetric
+from .metrics import RSS, CollisionPointMetric, Metric, RSSDistances, _DeviceMetric
 from .packing import pack_scenarios
 from .scenario import Scenario
 from .state import State
@@ -45,6 +45,7 @@ class BatchedScenarioGym:
         self._prev_state = None
         self._rec = None
         self._fut = None
+        self._rss_done, self._rss_pending_reset, self._rss_cache = False, True, None
 
     # ------------------------------------------------------------------ properties
     @property
@@ -193,7 +194,22 @@ class BatchedScenarioGym:
             self._fut[key] = self.engine.raster_map(codes, width, height, nw, nh)
         return self._fut[key]
 
+    def _rss_tick(self):
+        """RSSDistances for the whole batch, once per state (the callback is invoked per scenario)."""
+        if not self._rss_done:
+            self.engine.rss_update(reset=self._rss_pending_reset)
+            self._rss_pending_reset = False
+            self._rss_done = True
+            self._rss_cache = None
+        self._rss_pending_reset = False  # the reset of the other scenarios of the batch rode along with the first one's
+
+    def _rss_results(self):
+        if self._rss_cache is None:
+            self._rss_cache = self.engine.rss()
+        return self._rss_cache
+
     def _invalidate(self):
+        self._rss_done = False
         self._cache = None
         self._rec = None
         self._fut = None
@@ -304,6 +320,11 @@ class BatchedScenarioGym:
         rows, events = self.engine.metrics()
         want_points = any(isinstance(m, CollisionPointMetric) for ms in self.metrics for m in ms)
         points = self.engine.collision_points() if want_points else None
+        rss = None
+        if any(isinstance(m, RSS) for ms in self.metrics for m in ms):
+            if not any(isinstance(cb, RSSDistances) for cb in self.state_callbacks):
+                raise ValueError("Callback RSSDistances is required for RSS.")  # StateCallback.reset, callback.py:27-33
+            rss = self._rss_results()
         out = []
         for i, ms in enumerate(self.metrics):
             sel = events["scenario"] == i
@@ -312,6 +333,8 @@ class BatchedScenarioGym:
             for m in ms:
                 if isinstance(m, CollisionPointMetric):
                     m._load(rows[i], ev, self._packed.refs[i], points[sel])
+                elif isinstance(m, RSS):
+                    m._load(rows[i], ev, self._packed.refs[i], (rss[0][i], rss[1][i]))
                 elif isinstance(m, _DeviceMetric):
                     m._load(rows[i], ev, self._packed.refs[i])
                 v = m.get_state()

@@ -132,3 +132,52 @@ class CollisionPointMetric(_DeviceMetric):
 
     def get_state(self):
         return list(self.collisions)
+
+
+class RSSDistances:
+    """metrics/rss/callback.py:34-128 as a state callback: after every step the safe lateral / longitudinal distances
+    between the ego and every present entity and the record the reference appends to that entity's history, computed on
+    the device for the whole batch (sg_rss_update; the first call of a tick does the work for every scenario)."""
+
+    CODES = ("safe", "lateral", "longitudinal", "both", "unsafe_lateral", "unsafe_longitudinal", "found")
+
+    def reset(self, state) -> None:
+        state._gym._rss_pending_reset = True
+
+    def __call__(self, state) -> None:
+        state._gym._rss_tick()
+
+    def safe_distances(self, state):
+        """{entity: [safe lateral, safe longitudinal]} of the latest update (entities it covered)."""
+        _, _, codes, safe = state._gym._rss_results()
+        ents = state.scenario.entities
+        return {e: list(safe[state._i, k]) for k, e in enumerate(ents) if codes[state._i, k] >= 0}
+
+    def latest_records(self, state):
+        """{entity: record appended by the latest update} ("safe", "lateral", ..., "found")."""
+        _, _, codes, _ = state._gym._rss_results()
+        ents = state.scenario.entities
+        return {e: self.CODES[codes[state._i, k]] for k, e in enumerate(ents) if codes[state._i, k] >= 0}
+
+
+class RSS(_DeviceMetric):
+    """metrics/rss/rss.py:106-163: {"safe_longitudinal": bool, "safe_lateral": bool} -- False once some entity's history
+    holds the corresponding "unsafe_*" record.  Needs the RSSDistances callback (required_callbacks)."""
+
+    name = "RSS"
+    device_field = "n_steps"
+    required_callbacks = [RSSDistances]
+
+    def __init__(self, name: Optional[str] = None):
+        super().__init__(name=name)
+        self._flags = {"safe_longitudinal": True, "safe_lateral": True}
+
+    def _reset(self, state) -> None:
+        self._flags = {"safe_longitudinal": True, "safe_lateral": True}
+
+    def _load(self, row, events, refs, flags=None) -> None:
+        if flags is not None:
+            self._flags = {"safe_longitudinal": bool(flags[0]), "safe_lateral": bool(flags[1])}
+
+    def get_state(self):
+        return dict(self._flags)

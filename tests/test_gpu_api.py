@@ -830,3 +830,38 @@ def test_collision_metric_types_through_the_gym(oracle):
     # every contact angle now falls into a front-corner window of both boxes: front/front at collision angle 0 is a side swipe
     assert [c for _, _, c in gym.get_metrics()["collisions"]] == ["side_swipe"]
     gym.close()
+
+
+def test_rss_metric_through_the_gym():
+    """tests/test_rss.py:5-25: ScenarioGym(state_callbacks=[RSSDistances()], metrics=[RSS()]) -- the metric dictionary has
+    the two boolean RSS entries; their values, and the callback's safe distances along the way, equal the reference's."""
+    import scenario_gym_amd as sga
+
+    g = load_golden("rss")
+    for n in ("a5e43fe4-646a-49ba-82ce-5f0063776566", "e1bdb607-206b-4f40-9bc4-59ded182ecc8", "synth3", "synth9"):
+        sc = scenario_from_arrays(scenario_arrays(g, f"{n}/scenario"), g[f"{n}/scenario/refs"])
+        cb = sga.RSSDistances()
+        gym = sga.ScenarioGym(timestep=0.1, state_callbacks=[cb], metrics=[sga.RSS()])
+        gym.set_scenario(sc)
+        k = 0
+        while not gym.state.is_done:
+            gym.step()
+            k += 1
+            if k % 25 == 0:
+                want_code, want_safe = g[f"{n}/code"][k], g[f"{n}/safe"][k]
+                sd = cb.safe_distances(gym.state)
+                recs = cb.latest_records(gym.state)
+                for j, e in enumerate(sc.entities):
+                    assert (e in sd) == (want_code[j] >= 0)
+                    if e in sd:
+                        assert np.abs(np.array(sd[e]) - want_safe[j]).max() < 1e-9 and recs[e] == cb.CODES[want_code[j]]
+        data = gym.get_metrics()
+        assert type(data["RSS_safe_longitudinal"]) is bool and type(data["RSS_safe_lateral"]) is bool
+        assert data["RSS_safe_longitudinal"] == bool(g[f"{n}/safe_longitudinal"]), n
+        assert data["RSS_safe_lateral"] == bool(g[f"{n}/safe_lateral"]), n
+        gym.close()
+    with pytest.raises(ValueError):
+        gym = sga.ScenarioGym(timestep=0.1, metrics=[sga.RSS()])
+        gym.set_scenario(sc)
+        gym.rollout()
+        gym.get_metrics()

@@ -1354,3 +1354,69 @@ def test_device_group_equals_single_handle(sga, oracle):
             assert np.array_equal(ev[: n_ev.value][k], ev1[k]), (n_dev, k)
         assert lib.sg_group_destroy(g) == 0
     eng.close()
+
+
+def test_rss_distances_match_reference_and_oracle(sga, oracle):
+    """sg_rss_update after every tick: the 46 scenarios of rss.npz as one ragged batch -- every record RSSDistances appended
+    (per step, per entity), its safe distances and the two RSS metric flags equal the reference's; a dense synthetic batch
+    with PID egos equals the oracle step by step."""
+    import scenario_gym_amd._lib as L
+    from scenario_gym_amd import synthetic
+    from scenario_gym_amd.packing import default_kinds, pack_arrays, unpack_scenario
+
+    g = load_golden("rss")
+    names = [str(n) for n in g["names"]]
+    scs = []
+    for n in names:
+        s = scenario_arrays(g, f"{n}/scenario")
+        s["kind"] = default_kinds(len(s["bbox"]), s["ego"])
+        scs.append(s)
+    packed = pack_arrays(scs)
+    R, E = packed.n_scenarios, packed.n_entities
+    steps = max(len(g[f"{n}/t"]) for n in names) - 1
+    eng = sga.RolloutEngine(R, E, timestep=0.1)
+    eng.upload(packed)
+    eng.rss_update(reset=True)
+    codes, safes = [eng.rss()[2]], [eng.rss()[3]]
+    for k in range(steps):
+        eng.lib.sg_rollout_async(eng.h, 1, 0)  # one step of the scenarios that are not done (as gym.rollout does)
+        eng.rss_update()
+        _, _, c, s = eng.rss()
+        codes.append(c)
+        safes.append(s)
+    slong, slat, _, _ = eng.rss()
+    n_steps = eng.state()["n_steps"]
+    eng.close()
+    codes, safes = np.array(codes), np.array(safes)
+    for r, n in enumerate(names):
+        want, ws = g[f"{n}/code"], g[f"{n}/safe"]
+        T, Er = want.shape
+        assert n_steps[r] == T - 1
+        assert np.array_equal(codes[:T, r, :Er], want), (n, np.argwhere(codes[:T, r, :Er] != want)[:5])
+        upd = want >= 0
+        assert np.abs(safes[:T, r, :Er][upd] - ws[upd]).max() < 1e-9, n
+        assert slong[r] == bool(g[f"{n}/safe_longitudinal"]) and slat[r] == bool(g[f"{n}/safe_lateral"]), n
+    # controlled egos, dense traffic: against the oracle
+    R, E, steps = 48, 16, 120
+    packed = synthetic.make_batch(R, E, n_steps=steps, ego_kind=L.KIND_AGENT_PID, extent=18.0)
+    eng = sga.RolloutEngine(R, E, timestep=1 / 30)
+    eng.upload(packed)
+    eng.rss_update(reset=True)
+    codes = [eng.rss()[2]]
+    for k in range(steps):
+        eng.step(1)
+        eng.rss_update()
+        codes.append(eng.rss()[2])
+    slong, slat, _, _ = eng.rss()
+    eng.close()
+    codes = np.array(codes)
+    unsafe = 0
+    for r in range(0, R, 2):
+        s = unpack_scenario(packed, r)
+        o = oracle.rollout(s["knot_off"], s["knots"], s["bbox"], s["etype"], s["kind"], s["ego"], s["t0"], s["length"], 1 / 30,
+                           ctrl=s["ctrl"], max_steps=steps, force_steps=True)
+        w = oracle.rss_rollout(o, s["bbox"], s["ego"])
+        assert np.array_equal(codes[:, r, : len(s["bbox"])], w["code"]), r
+        assert slong[r] == w["safe_longitudinal"] and slat[r] == w["safe_lateral"], r
+        unsafe += not (w["safe_longitudinal"] and w["safe_lateral"])
+    assert unsafe > 3
