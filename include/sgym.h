@@ -315,6 +315,10 @@ int sg_tick(sg_handle *h, const double *actions, int32_t actions_device, double 
  * (metrics/rss/rss.py:70-104).  Call once after sg_reset (reset = 1: forget the histories) and once after every step;
  * scenarios at t == 0.0 are skipped as in the reference.  Asynchronous on sg_stream(h). */
 int sg_rss_update(sg_handle *h, int32_t reset);
+/* enabled != 0: sg_reset / sg_rollout / sg_step run the callback themselves -- after the reset and after every step (one step
+ * per launch) -- as ScenarioGym(state_callbacks=[RSSDistances()]) does.  A scenario that has not stepped since its latest
+ * update (it is done) is left alone. */
+int sg_set_rss(sg_handle *h, int32_t enabled);
 /* flags [R]: bit 0 = RSS_safe_longitudinal, bit 1 = RSS_safe_lateral (no entity's history holds the corresponding
  * "unsafe_*" record); codes [R*E] of the latest update: 0 safe, 1 lateral, 2 longitudinal, 3 both, 4 unsafe_lateral,
  * 5 unsafe_longitudinal, 6 found, -1 not updated; safe [R*E][2]: lateral, longitudinal safe distance (NaN when not

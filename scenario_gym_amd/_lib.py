@@ -26,7 +26,7 @@ SYMBOLS = (
     "sg_set_timestep", "sg_step", "sg_rollout", "sg_rollout_async", "sg_synchronize", "sg_stream",
     "sg_state_view_get", "sg_read_metrics", "sg_read_record", "sg_copy_to_host", "sg_last_kernel_ms",
     "sg_last_launch_stats", "sg_debug_trig32", "sg_set_tuning", "sg_set_external_poses", "sg_future_collision", "sg_raster_entities",
-    "sg_set_road_networks", "sg_raster_map", "sg_raster_map_device", "sg_reset_scenarios", "sg_terminal_flags", "sg_tick", "sg_set_collision_tolerance", "sg_read_collision_points", "sg_rss_update", "sg_rss_read",
+    "sg_set_road_networks", "sg_raster_map", "sg_raster_map_device", "sg_reset_scenarios", "sg_terminal_flags", "sg_tick", "sg_set_collision_tolerance", "sg_read_collision_points", "sg_rss_update", "sg_rss_read", "sg_set_rss",
     "sg_group_create", "sg_group_destroy", "sg_group_size", "sg_group_handle", "sg_group_upload", "sg_group_rollout",
     "sg_group_read_metrics", "sg_group_last_error",
 )
@@ -125,6 +125,7 @@ def load():
     lib.sg_reset_scenarios.argtypes = [H, C.c_void_p]
     lib.sg_set_collision_tolerance.argtypes = [H, C.c_double]
     lib.sg_rss_update.argtypes = [H, C.c_int32]
+    lib.sg_set_rss.argtypes = [H, C.c_int32]
     lib.sg_rss_read.argtypes = [H, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.sg_read_collision_points.argtypes = [H, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
     lib.sg_group_create.argtypes = [C.POINTER(SgConfig), C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]

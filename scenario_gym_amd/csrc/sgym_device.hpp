@@ -2870,7 +2870,9 @@ __device__ inline bool rss_seg_quad(const double *Q, double ax, double ay, doubl
 
 // rss_state [NE] = found | last << 8; code [NE]: 0 safe, 1 lateral, 2 longitudinal, 3 both, 4 unsafe_lateral,
 // 5 unsafe_longitudinal, 6 found, -1 not updated; safe [NE][2] = lateral, longitudinal
-__global__ __launch_bounds__(256) void rss_kernel(Params p, int reset, int32_t *rss_state, int32_t *code, double *safe)
+// seen [R]: State.n_steps at the scenario's latest update -- a scenario that did not step since (it is done) is left alone,
+// as the reference stops calling the callback once its rollout loop has ended
+__global__ __launch_bounds__(256) void rss_kernel(Params p, int reset, int32_t *rss_state, int32_t *code, double *safe, int32_t *seen)
 {
     __shared__ double ego[8]; // x, y, heading, vx, vy, width, length, present
     const int r = blockIdx.x, e = threadIdx.x;
@@ -2889,8 +2891,11 @@ __global__ __launch_bounds__(256) void rss_kernel(Params p, int reset, int32_t *
         ego[0] = hp[0]; ego[1] = hp[1]; ego[2] = hp[3]; ego[3] = hv[0]; ego[4] = hv[1];
         ego[5] = fld(st, ST_BW); ego[6] = fld(st, ST_BL); ego[7] = present ? 1.0 : 0.0;
     }
+    const int steps_now = p.sdyn[r].n_steps;
+    const bool stale = !reset && seen[r] == steps_now;
     __syncthreads();
-    if (!in) return;
+    if (e == 0) seen[r] = steps_now;
+    if (!in || stale) return;
     int32_t state = reset ? 0 : rss_state[idx];
     int cd = -1;
     double s_lat = __builtin_nan(""), s_long = __builtin_nan("");

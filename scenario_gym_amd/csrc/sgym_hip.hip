@@ -51,6 +51,8 @@ struct sg_handle {
     int tick_nw = 0, tick_nh = 0, tick_nl = 0;
     int32_t tick_layers[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int32_t *d_rss_state = nullptr, *d_rss_code = nullptr; // [NE] sg_rss_update
+    int32_t *d_rss_seen = nullptr;                         // [R]
+    bool rss_enabled = false;                              // sg_set_rss: RSSDistances runs after every step of sg_rollout / sg_step
     bool ego_first = true;                                 // every scenario's ego is its entity 0
     double *d_rss_safe = nullptr;                          // [NE][2]
     double c_tol = 0.4;                                // CollisionMetric(c_tol): angular half-width of a box corner, metrics/collision.py:57
@@ -188,6 +190,7 @@ extern "C" int sg_destroy(sg_handle *h)
     if (h->d_reset_mask) (void)hipFree(h->d_reset_mask);
     if (h->d_term_flags) (void)hipFree(h->d_term_flags);
     if (h->d_rss_state) (void)hipFree(h->d_rss_state);
+    if (h->d_rss_seen) (void)hipFree(h->d_rss_seen);
     if (h->d_rss_code) (void)hipFree(h->d_rss_code);
     if (h->d_rss_safe) (void)hipFree(h->d_rss_safe);
     if (h->tick_exec) (void)hipGraphExecDestroy(h->tick_exec);
@@ -378,7 +381,7 @@ extern "C" int sg_upload(sg_handle *h, const sg_scenarios *sc)
     free_pool(h->static_allocs);
     free_pool(h->state_allocs);
     free_pool(h->road_allocs); // the networks belong to a batch (net_of_scenario)
-    if (h->d_rss_state) { (void)hipFree(h->d_rss_state); (void)hipFree(h->d_rss_code); (void)hipFree(h->d_rss_safe); h->d_rss_state = nullptr; h->d_rss_code = nullptr; h->d_rss_safe = nullptr; }
+    if (h->d_rss_state) { (void)hipFree(h->d_rss_state); (void)hipFree(h->d_rss_code); (void)hipFree(h->d_rss_safe); (void)hipFree(h->d_rss_seen); h->d_rss_state = nullptr; h->d_rss_code = nullptr; h->d_rss_safe = nullptr; h->d_rss_seen = nullptr; }
     h->has_road = false;
     h->road = sg::RoadIndex{};
     for (int b = 0; b < 2; ++b) { // the controller table geometry depends on the batch
@@ -571,6 +574,7 @@ extern "C" int sg_reset(sg_handle *h)
     if (!h->uploaded) return fail(h, SG_ERR_STATE, "sg_reset: no scenarios uploaded");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     int rc = launch_rollout(h, 0, 1, 0, nullptr);
+    if (!rc && h->rss_enabled) rc = sg_rss_update(h, 1);
     if (rc) return rc;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return SG_OK;
@@ -645,7 +649,13 @@ extern "C" int sg_step(sg_handle *h, int32_t n_steps, const double *actions, int
         if (n) HIP_TRY(h, hipMemsetAsync(h->d_actions, 0, n * sizeof(double), h->stream));
         d_act = h->d_actions;
     }
-    int rc = launch_rollout(h, n_steps, 0, 1, d_act);
+    int rc = SG_OK;
+    if (h->rss_enabled) {
+        for (int k = 0; k < n_steps && !rc; ++k)
+            if (!(rc = launch_rollout(h, 1, 0, 1, d_act + (size_t)k * h->R * 2))) rc = sg_rss_update(h, 0);
+    } else {
+        rc = launch_rollout(h, n_steps, 0, 1, d_act);
+    }
     if (rc) return rc;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return SG_OK;
@@ -780,6 +790,13 @@ extern "C" int sg_rollout_async(sg_handle *h, int32_t max_steps, int32_t do_rese
                                      "use sg_set_external_poses + sg_step tick by tick", h->n_ext);
     if (max_steps < 0) return fail(h, SG_ERR_INVALID, "sg_rollout: max_steps < 0");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
+    if (h->rss_enabled) { // the RSSDistances callback after the reset and after every step: one step per launch
+        int rc = SG_OK;
+        if (do_reset && ((rc = launch_rollout(h, 0, 1, 0, nullptr)) || (rc = sg_rss_update(h, 1)))) return rc;
+        for (int k = 0; k < max_steps; ++k)
+            if ((rc = launch_rollout(h, 1, 0, 0, nullptr)) || (rc = sg_rss_update(h, 0))) return rc;
+        return SG_OK;
+    }
     // external-action slots are fed (0, 0) here; drive them with sg_step(actions)
     return launch_rollout(h, max_steps, do_reset ? 1 : 0, 0, nullptr);
 }
@@ -987,10 +1004,18 @@ extern "C" int sg_rss_update(sg_handle *h, int32_t reset)
         HIP_TRY(h, hipMalloc((void **)&h->d_rss_state, h->NE * sizeof(int32_t)));
         HIP_TRY(h, hipMalloc((void **)&h->d_rss_code, h->NE * sizeof(int32_t)));
         HIP_TRY(h, hipMalloc((void **)&h->d_rss_safe, h->NE * 2 * sizeof(double)));
+        HIP_TRY(h, hipMalloc((void **)&h->d_rss_seen, (size_t)h->R * sizeof(int32_t)));
         reset = 1;
     }
-    sg::rss_kernel<<<dim3((unsigned)h->R), dim3(256), 0, h->stream>>>(h->p, reset ? 1 : 0, h->d_rss_state, h->d_rss_code, h->d_rss_safe);
+    sg::rss_kernel<<<dim3((unsigned)h->R), dim3(256), 0, h->stream>>>(h->p, reset ? 1 : 0, h->d_rss_state, h->d_rss_code, h->d_rss_safe, h->d_rss_seen);
     HIP_TRY(h, hipGetLastError());
+    return SG_OK;
+}
+
+extern "C" int sg_set_rss(sg_handle *h, int32_t enabled)
+{
+    if (!h) return SG_ERR_INVALID;
+    h->rss_enabled = enabled != 0;
     return SG_OK;
 }
 

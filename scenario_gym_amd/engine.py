@@ -365,6 +365,10 @@ class RolloutEngine:
                                              ev.ctypes.data_as(C.POINTER(L.SgEvent)), cap, C.byref(n_ev)), "sg_read_metrics")
         return rows, ev[: n_ev.value].copy()
 
+    def set_rss(self, enabled=True):
+        """reset / rollout / step run the RSSDistances callback themselves after the reset and after every step."""
+        self._check(self.lib.sg_set_rss(self.h, int(bool(enabled))), "sg_set_rss")
+
     def rss_update(self, reset=False):
         """RSSDistances.__call__ on the current state of every scenario (after a reset: reset=True)."""
         self._check(self.lib.sg_rss_update(self.h, int(bool(reset))), "sg_rss_update")

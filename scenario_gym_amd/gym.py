@@ -31,6 +31,9 @@ class BatchedScenarioGym:
         self.persist = persist
         self.terminal_conditions = ["max_length"] if terminal_conditions is None else list(terminal_conditions)
         self.state_callbacks = state_callbacks or []
+        # RSSDistances runs inside the library after every step (sg_set_rss); every other callback is a host callable
+        self._host_callbacks = [cb for cb in self.state_callbacks if not isinstance(cb, RSSDistances)]
+        self._rss_on = len(self._host_callbacks) != len(self.state_callbacks)
         self.metric_factory = metrics or (lambda: [])
         self.record = record
         self.event_capacity = event_capacity
@@ -45,7 +48,7 @@ class BatchedScenarioGym:
         self._prev_state = None
         self._rec = None
         self._fut = None
-        self._rss_done, self._rss_pending_reset, self._rss_cache = False, True, None
+        self._rss_cache = None
 
     # ------------------------------------------------------------------ properties
     @property
@@ -63,7 +66,7 @@ class BatchedScenarioGym:
 
     def _per_step_host_path(self) -> bool:
         custom_metric = any(not isinstance(m, _DeviceMetric) for ms in self.metrics for m in ms)
-        return bool(custom_metric or self.state_callbacks or self._host_terminals() or self._host_agents
+        return bool(custom_metric or self._host_callbacks or self._host_terminals() or self._host_agents
                     or self._policy_agents)
 
     def _push_host_agents(self, actions):
@@ -140,6 +143,8 @@ class BatchedScenarioGym:
             packed.n_scenarios, packed.n_entities, timestep=self._timestep, persist=self.persist,
             terminal_conditions=dev_terms, record_capacity=(self.max_steps + 1) if self.record else 0,
             event_capacity=self.event_capacity, device=self.device, social_force=sf)
+        if self._rss_on:
+            self.engine.set_rss(True)
         self.engine.upload(packed)
         self._roads_set = False
         # the road network reaches the device when the rollout itself needs it: the ego_off_road terminal condition, and
@@ -194,22 +199,13 @@ class BatchedScenarioGym:
             self._fut[key] = self.engine.raster_map(codes, width, height, nw, nh)
         return self._fut[key]
 
-    def _rss_tick(self):
-        """RSSDistances for the whole batch, once per state (the callback is invoked per scenario)."""
-        if not self._rss_done:
-            self.engine.rss_update(reset=self._rss_pending_reset)
-            self._rss_pending_reset = False
-            self._rss_done = True
-            self._rss_cache = None
-        self._rss_pending_reset = False  # the reset of the other scenarios of the batch rode along with the first one's
-
     def _rss_results(self):
         if self._rss_cache is None:
             self._rss_cache = self.engine.rss()
         return self._rss_cache
 
     def _invalidate(self):
-        self._rss_done = False
+        self._rss_cache = None
         self._cache = None
         self._rec = None
         self._fut = None
@@ -249,7 +245,7 @@ class BatchedScenarioGym:
         for st, ms in zip(self.states, self.metrics):
             for m in ms:
                 m.reset(st)
-            for cb in self.state_callbacks:
+            for cb in self._host_callbacks:
                 if hasattr(cb, "reset"):
                     cb.reset(st)
                 cb(st)
@@ -264,7 +260,7 @@ class BatchedScenarioGym:
     def _after_host_step(self):
         done_host = np.zeros(len(self.states), bool)
         for i, (st, ms) in enumerate(zip(self.states, self.metrics)):
-            for cb in self.state_callbacks:
+            for cb in self._host_callbacks:
                 cb(st)
             done_host[i] = any(c(st) for c in self._host_terminals())
             for m in ms:

@@ -137,15 +137,16 @@ class CollisionPointMetric(_DeviceMetric):
 class RSSDistances:
     """metrics/rss/callback.py:34-128 as a state callback: after every step the safe lateral / longitudinal distances
     between the ego and every present entity and the record the reference appends to that entity's history, computed on
-    the device for the whole batch (sg_rss_update; the first call of a tick does the work for every scenario)."""
+    the device for the whole batch: a gym that holds this callback switches the library to run it after the reset and after
+    every step of rollout / step (sg_set_rss), so it does not force the one-launch-per-step host path."""
 
     CODES = ("safe", "lateral", "longitudinal", "both", "unsafe_lateral", "unsafe_longitudinal", "found")
 
-    def reset(self, state) -> None:
-        state._gym._rss_pending_reset = True
+    def reset(self, state) -> None:  # the library resets and updates the records itself (sg_set_rss)
+        pass
 
     def __call__(self, state) -> None:
-        state._gym._rss_tick()
+        pass
 
     def safe_distances(self, state):
         """{entity: [safe lateral, safe longitudinal]} of the latest update (entities it covered)."""

@@ -865,3 +865,13 @@ def test_rss_metric_through_the_gym():
         gym.set_scenario(sc)
         gym.rollout()
         gym.get_metrics()
+    # the whole file list as one batch, one rollout() call (the callback does not force the per-step host path)
+    names = [str(x) for x in g["names"]]
+    scs = [scenario_from_arrays(scenario_arrays(g, f"{n}/scenario"), g[f"{n}/scenario/refs"]) for n in names]
+    gym = sga.BatchedScenarioGym(timestep=0.1, state_callbacks=[sga.RSSDistances()], metrics=lambda: [sga.RSS(), sga.EgoMaxSpeed()])
+    gym.set_scenarios(scs)
+    assert not gym._per_step_host_path()
+    gym.rollout()
+    for n, m in zip(names, gym.get_metrics()):
+        assert m["RSS_safe_longitudinal"] == bool(g[f"{n}/safe_longitudinal"]) and m["RSS_safe_lateral"] == bool(g[f"{n}/safe_lateral"]), n
+    gym.close()

@@ -1420,3 +1420,33 @@ def test_rss_distances_match_reference_and_oracle(sga, oracle):
         assert slong[r] == w["safe_longitudinal"] and slat[r] == w["safe_lateral"], r
         unsafe += not (w["safe_longitudinal"] and w["safe_lateral"])
     assert unsafe > 3
+
+
+def test_rss_inside_rollout_equals_tick_by_tick(sga):
+    """sg_set_rss: sg_rollout / sg_step run the callback themselves after the reset and after every step; flags, latest
+    records and safe distances equal driving sg_rss_update by hand, also when scenarios finish at different times and when
+    the call is repeated (a scenario that did not step is left alone)."""
+    import scenario_gym_amd._lib as L
+    from scenario_gym_amd import synthetic
+
+    R, E, steps = 40, 14, 90
+    packed = synthetic.make_batch(R, E, n_steps=steps, ego_kind=L.KIND_AGENT_PID, extent=16.0)
+    packed.length = packed.length * np.linspace(0.4, 1.0, R)  # ragged ends
+    a = sga.RolloutEngine(R, E)
+    a.upload(packed)
+    a.rss_update(reset=True)
+    for _ in range(steps + 5):
+        a.lib.sg_rollout_async(a.h, 1, 0)
+        a.rss_update()
+    a.rss_update()  # nothing stepped: no change
+    b = sga.RolloutEngine(R, E)
+    b.set_rss(True)
+    b.upload(packed)
+    b.rollout(steps + 5)
+    ra, rb = a.rss(), b.rss()
+    assert (a.state()["n_steps"] == b.state()["n_steps"]).all() and len(set(a.state()["n_steps"])) > 5
+    for x, y in zip(ra, rb):
+        assert np.array_equal(x, y, equal_nan=True)
+    assert not ra[0].all() or not ra[1].all()
+    a.close()
+    b.close()
