@@ -2868,55 +2868,28 @@ __device__ inline bool rss_seg_quad(const double *Q, double ax, double ay, doubl
     return false;
 }
 
-// rss_state [NE] = found | last << 8; code [NE]: 0 safe, 1 lateral, 2 longitudinal, 3 both, 4 unsafe_lateral,
-// 5 unsafe_longitudinal, 6 found, -1 not updated; safe [NE][2] = lateral, longitudinal
-// seen [R]: State.n_steps at the scenario's latest update -- a scenario that did not step since (it is done) is left alone,
-// as the reference stops calling the callback once its rollout loop has ended
-__global__ __launch_bounds__(256) void rss_kernel(Params p, int reset, int32_t *rss_state, int32_t *code, double *safe, int32_t *seen)
+// RSSDistances for ONE entity against the ego (both present, t != 0): safe distances, the record appended to the entity's
+// history, the updated (found | last << 8) state.  Shared by rss_kernel (one update per call) and the rollout variant that
+// runs the callback after every step itself.
+__device__ inline void rss_entity(double ex, double ey, double ego_heading, double ego_vx, double ego_vy, double ego_w, double ego_l,
+                                  double hx, double hy, double hh, double hvx, double hvy, double bw, double bl, double bcx,
+                                  double bcy, int32_t &state, int &cd, double &s_lat, double &s_long)
 {
-    __shared__ double ego[8]; // x, y, heading, vx, vy, width, length, present
-    const int r = blockIdx.x, e = threadIdx.x;
-    const ScenStatic &ss = p.sstat[r];
-    const uint32_t idx = (uint32_t)r * p.EP + (e < p.EP ? e : 0);
-    const LanePtr st(p.stat + (size_t)(idx >> 6) * (ST_COUNT * 64), (idx & 63) * 8u);
-    const LanePtr dy(p.dyn + (size_t)(idx >> 6) * ((size_t)p.FROWS * 64), (idx & 63) * 8u);
-    const bool in = e < p.E;
-    const bool present = in && fld<uint64_t>(dy, SG_F_PRESENT) != 0;
-    double hp[4] = {0, 0, 0, 0}, hv[2] = {0, 0};
-    if (in) {
-        hp[0] = fld(dy, SG_F_POSE + 0); hp[1] = fld(dy, SG_F_POSE + 1); hp[3] = fld(dy, SG_F_POSE + 3);
-        hv[0] = fld(dy, SG_F_VEL + 0); hv[1] = fld(dy, SG_F_VEL + 1);
-    }
-    if (e == ss.ego) {
-        ego[0] = hp[0]; ego[1] = hp[1]; ego[2] = hp[3]; ego[3] = hv[0]; ego[4] = hv[1];
-        ego[5] = fld(st, ST_BW); ego[6] = fld(st, ST_BL); ego[7] = present ? 1.0 : 0.0;
-    }
-    const int steps_now = p.sdyn[r].n_steps;
-    const bool stale = !reset && seen[r] == steps_now;
-    __syncthreads();
-    if (e == 0) seen[r] = steps_now;
-    if (!in || stale) return;
-    int32_t state = reset ? 0 : rss_state[idx];
-    int cd = -1;
-    double s_lat = __builtin_nan(""), s_long = __builtin_nan("");
-    const bool skip = p.sdyn[r].t == 0.0 || ego[7] == 0.0 || e == ss.ego || !present; // callback.py:76-78
-    if (!skip) {
         const double RESPONSE_TIME = 0.6, MIN_LONG_ACCEL = 1.2 * 9.81, MAX_LONG_ACCEL = 1.2 * 9.81, MIN_SAFE_CLEARANCE = 0.1;
-        const double ex = ego[0], ey = ego[1], ego_w = ego[5], ego_l = ego[6];
         double es, ec, ei0, ei1;
-        sg_sincos(ego[2], es, ec);
+        sg_sincos(ego_heading, es, ec);
         const double eh0 = ec, eh1 = es;
         rss_inv_dir(eh0, eh1, ei0, ei1);
         const double ego_head0 = rss_dot2(eh0, eh1, ei0, ei1), ego_head1 = rss_dot2(eh0, eh1, eh0, eh1);
-        const double ego_vel0 = rss_dot2(ego[3], ego[4], ei0, ei1), ego_vel1 = rss_dot2(ego[3], ego[4], eh0, eh1);
+        const double ego_vel0 = rss_dot2(ego_vx, ego_vy, ei0, ei1), ego_vel1 = rss_dot2(ego_vx, ego_vy, eh0, eh1);
         const double ego_pos1 = rss_dot2(ex - ex, ey - ey, eh0, eh1);
         double hs, hc;
-        sg_sincos(hp[3], hs, hc);
-        const double pos0 = rss_dot2(hp[0] - ex, hp[1] - ey, ei0, ei1), pos1 = rss_dot2(hp[0] - ex, hp[1] - ey, eh0, eh1);
+        sg_sincos(hh, hs, hc);
+        const double pos0 = rss_dot2(hx - ex, hy - ey, ei0, ei1), pos1 = rss_dot2(hx - ex, hy - ey, eh0, eh1);
         const double head0 = rss_dot2(hc, hs, ei0, ei1), head1 = rss_dot2(hc, hs, eh0, eh1);
-        const double vel0 = rss_dot2(hv[0], hv[1], ei0, ei1), vel1 = rss_dot2(hv[0], hv[1], eh0, eh1);
+        const double vel0 = rss_dot2(hvx, hvy, ei0, ei1), vel1 = rss_dot2(hvx, hvy, eh0, eh1);
         double cor[8], Q[8];
-        sg_corners(hp[0], hp[1], hs, hc, fld(st, ST_BW), fld(st, ST_BL), fld(st, ST_BCX), fld(st, ST_BCY), cor);
+        sg_corners(hx, hy, hs, hc, bw, bl, bcx, bcy, cor);
         for (int k = 0; k < 4; ++k) {
             Q[2 * k] = rss_dot2(cor[2 * k] - ex, cor[2 * k + 1] - ey, ei0, ei1);
             Q[2 * k + 1] = rss_dot2(cor[2 * k] - ex, cor[2 * k + 1] - ey, eh0, eh1);
@@ -2988,7 +2961,43 @@ __global__ __launch_bounds__(256) void rss_kernel(Params p, int reset, int32_t *
                 if (cd == 1 || cd == 2) state = (state & 0xff) | (cd << 8);
             }
         }
+}
+
+// rss_state [NE] = found | last << 8; code [NE]: 0 safe, 1 lateral, 2 longitudinal, 3 both, 4 unsafe_lateral,
+// 5 unsafe_longitudinal, 6 found, -1 not updated; safe [NE][2] = lateral, longitudinal
+// seen [R]: State.n_steps at the scenario's latest update -- a scenario that did not step since (it is done) is left alone,
+// as the reference stops calling the callback once its rollout loop has ended
+__global__ __launch_bounds__(256) void rss_kernel(Params p, int reset, int32_t *rss_state, int32_t *code, double *safe, int32_t *seen)
+{
+    __shared__ double ego[8]; // x, y, heading, vx, vy, width, length, present
+    const int r = blockIdx.x, e = threadIdx.x;
+    const ScenStatic &ss = p.sstat[r];
+    const uint32_t idx = (uint32_t)r * p.EP + (e < p.EP ? e : 0);
+    const LanePtr st(p.stat + (size_t)(idx >> 6) * (ST_COUNT * 64), (idx & 63) * 8u);
+    const LanePtr dy(p.dyn + (size_t)(idx >> 6) * ((size_t)p.FROWS * 64), (idx & 63) * 8u);
+    const bool in = e < p.E;
+    const bool present = in && fld<uint64_t>(dy, SG_F_PRESENT) != 0;
+    double hp[4] = {0, 0, 0, 0}, hv[2] = {0, 0};
+    if (in) {
+        hp[0] = fld(dy, SG_F_POSE + 0); hp[1] = fld(dy, SG_F_POSE + 1); hp[3] = fld(dy, SG_F_POSE + 3);
+        hv[0] = fld(dy, SG_F_VEL + 0); hv[1] = fld(dy, SG_F_VEL + 1);
     }
+    if (e == ss.ego) {
+        ego[0] = hp[0]; ego[1] = hp[1]; ego[2] = hp[3]; ego[3] = hv[0]; ego[4] = hv[1];
+        ego[5] = fld(st, ST_BW); ego[6] = fld(st, ST_BL); ego[7] = present ? 1.0 : 0.0;
+    }
+    const int steps_now = p.sdyn[r].n_steps;
+    const bool stale = !reset && seen[r] == steps_now;
+    __syncthreads();
+    if (e == 0) seen[r] = steps_now;
+    if (!in || stale) return;
+    int32_t state = reset ? 0 : rss_state[idx];
+    int cd = -1;
+    double s_lat = __builtin_nan(""), s_long = __builtin_nan("");
+    const bool skip = p.sdyn[r].t == 0.0 || ego[7] == 0.0 || e == ss.ego || !present; // callback.py:76-78
+    if (!skip)
+        rss_entity(ego[0], ego[1], ego[2], ego[3], ego[4], ego[5], ego[6], hp[0], hp[1], hp[3], hv[0], hv[1], fld(st, ST_BW),
+                   fld(st, ST_BL), fld(st, ST_BCX), fld(st, ST_BCY), state, cd, s_lat, s_long);
     rss_state[idx] = state;
     code[idx] = cd;
     safe[(size_t)idx * 2] = s_lat;
