@@ -103,6 +103,8 @@ struct Params {
     double *ctl_state;       // [CS_COUNT][n_ctl_pad] lane state carried from one chunk of steps to the next
     int n_ctl_pad;           // multiple of 64
     const double *ext_pose;  // [NE][6] poses of the caller-run agents (SG_KIND_AGENT_EXTERNAL), x = NaN: agent returned None
+    int32_t *rss_state, *rss_code, *rss_seen; // RSSDistances records (sg_rss_update / rollout_kernel_rss), nullptr before first use
+    double *rss_safe;
     const unsigned char *reset_mask; // [R] sg_reset_scenarios: the scenarios a do_reset == 2 launch resets
     const RoadIndex *road;   // device copy of the road index, nullptr = no road networks set
     int ped_serial;          // 1: pedestrian pair loop one pedestrian per lane (env SG_PED_SERIAL; default 0: balanced over the wavefront)
@@ -1592,6 +1594,153 @@ __global__ void build_grid_kernel(Params p, const int32_t *row_scen /*[totalN]*/
 }
 
 // ------------------------------------------------------------------------------------------------
+// RSSDistances.__call__ (metrics/rss/callback.py:58-128) on the current state of every scenario, + the flags RSS reads
+// (metrics/rss/rss.py:70-104).  One workgroup per scenario, one thread per entity.  Ego frame: x lateral, y longitudinal;
+// np.dot of 2-vectors = fma(a1, b1, a0 * b0), norm([u, v]) = sqrt(fma(v, v, u * u)) (probed); the per-entity history list
+// is carried as (found, last): an "unsafe_*" entry exists / the latest "lateral" | "longitudinal" entry.  Same operation
+// sequence as the oracle's sgo_rss_update.
+// ------------------------------------------------------------------------------------------------
+__device__ inline double rss_dot2(double a0, double a1, double b0, double b1) { return __builtin_fma(a1, b1, a0 * b0); }
+__device__ inline void rss_inv_dir(double v0, double v1, double &o0, double &o1)
+{
+    const double n = sg_norm2(v1, v0);
+    o0 = v1 / n;
+    o1 = -v0 / n;
+}
+__device__ inline bool rss_on_segment(double ax, double ay, double bx, double by, double px, double py)
+{
+    return px >= __builtin_fmin(ax, bx) && px <= __builtin_fmax(ax, bx) && py >= __builtin_fmin(ay, by) && py <= __builtin_fmax(ay, by);
+}
+__device__ inline bool rss_point_in_quad(const double *Q, double px, double py)
+{
+    bool pos = false, neg = false;
+    for (int k = 0; k < 4; ++k) {
+        const int m = (k + 1) & 3, o = rn_orient_sign(Q[2 * k], Q[2 * k + 1], Q[2 * m], Q[2 * m + 1], px, py);
+        pos |= o > 0;
+        neg |= o < 0;
+    }
+    return !(pos && neg);
+}
+__device__ inline bool rss_seg_quad(const double *Q, double ax, double ay, double bx, double by)
+{
+    { // disjoint bounding boxes cannot meet (exact comparisons): the common case, most entities are nowhere near the lines
+        const double qx0 = __builtin_fmin(__builtin_fmin(Q[0], Q[2]), __builtin_fmin(Q[4], Q[6]));
+        const double qx1 = __builtin_fmax(__builtin_fmax(Q[0], Q[2]), __builtin_fmax(Q[4], Q[6]));
+        const double qy0 = __builtin_fmin(__builtin_fmin(Q[1], Q[3]), __builtin_fmin(Q[5], Q[7]));
+        const double qy1 = __builtin_fmax(__builtin_fmax(Q[1], Q[3]), __builtin_fmax(Q[5], Q[7]));
+        if (qx1 < __builtin_fmin(ax, bx) || qx0 > __builtin_fmax(ax, bx) || qy1 < __builtin_fmin(ay, by) || qy0 > __builtin_fmax(ay, by))
+            return false;
+    }
+    if (rss_point_in_quad(Q, ax, ay) || rss_point_in_quad(Q, bx, by)) return true;
+    for (int k = 0; k < 4; ++k) {
+        const int m = (k + 1) & 3;
+        const double cx = Q[2 * k], cy = Q[2 * k + 1], dx = Q[2 * m], dy = Q[2 * m + 1];
+        const int o1 = rn_orient_sign(ax, ay, bx, by, cx, cy), o2 = rn_orient_sign(ax, ay, bx, by, dx, dy);
+        const int o3 = rn_orient_sign(cx, cy, dx, dy, ax, ay), o4 = rn_orient_sign(cx, cy, dx, dy, bx, by);
+        if (o1 * o2 < 0 && o3 * o4 < 0) return true;
+        if ((o1 == 0 && rss_on_segment(ax, ay, bx, by, cx, cy)) || (o2 == 0 && rss_on_segment(ax, ay, bx, by, dx, dy)) ||
+            (o3 == 0 && rss_on_segment(cx, cy, dx, dy, ax, ay)) || (o4 == 0 && rss_on_segment(cx, cy, dx, dy, bx, by)))
+            return true;
+    }
+    return false;
+}
+
+// RSSDistances for ONE entity against the ego (both present, t != 0): safe distances, the record appended to the entity's
+// history, the updated (found | last << 8) state.  Shared by rss_kernel (one update per call) and the rollout variant that
+// runs the callback after every step itself.
+__device__ inline void rss_entity(double ex, double ey, double ego_heading, double ego_vx, double ego_vy, double ego_w, double ego_l,
+                                  double hx, double hy, double hh, double hvx, double hvy, double bw, double bl, double bcx,
+                                  double bcy, int32_t &state, int &cd, double &s_lat, double &s_long)
+{
+        const double RESPONSE_TIME = 0.6, MIN_LONG_ACCEL = 1.2 * 9.81, MAX_LONG_ACCEL = 1.2 * 9.81, MIN_SAFE_CLEARANCE = 0.1;
+        double es, ec, ei0, ei1;
+        sg_sincos(ego_heading, es, ec);
+        const double eh0 = ec, eh1 = es;
+        rss_inv_dir(eh0, eh1, ei0, ei1);
+        const double ego_head0 = rss_dot2(eh0, eh1, ei0, ei1), ego_head1 = rss_dot2(eh0, eh1, eh0, eh1);
+        const double ego_vel0 = rss_dot2(ego_vx, ego_vy, ei0, ei1), ego_vel1 = rss_dot2(ego_vx, ego_vy, eh0, eh1);
+        const double ego_pos1 = rss_dot2(ex - ex, ey - ey, eh0, eh1);
+        double hs, hc;
+        sg_sincos(hh, hs, hc);
+        const double pos0 = rss_dot2(hx - ex, hy - ey, ei0, ei1), pos1 = rss_dot2(hx - ex, hy - ey, eh0, eh1);
+        const double head0 = rss_dot2(hc, hs, ei0, ei1), head1 = rss_dot2(hc, hs, eh0, eh1);
+        const double vel0 = rss_dot2(hvx, hvy, ei0, ei1), vel1 = rss_dot2(hvx, hvy, eh0, eh1);
+        double cor[8], Q[8];
+        sg_corners(hx, hy, hs, hc, bw, bl, bcx, bcy, cor);
+        for (int k = 0; k < 4; ++k) {
+            Q[2 * k] = rss_dot2(cor[2 * k] - ex, cor[2 * k + 1] - ey, ei0, ei1);
+            Q[2 * k + 1] = rss_dot2(cor[2 * k] - ex, cor[2 * k + 1] - ey, eh0, eh1);
+        }
+        { // safe_longitudinal_distance, :231-272
+            const double dd = rss_dot2(ego_head0, ego_head1, head0, head1);
+            const double m = __builtin_fabs(MAX_LONG_ACCEL * dd), rt = RESPONSE_TIME;
+            if (dd > 0) {
+                double vf, vr;
+                if (ego_pos1 > pos1) { vf = sg_norm2(ego_vel0, ego_vel1); vr = rss_dot2(vel0, vel1, ego_head0, ego_head1); }
+                else { vf = rss_dot2(vel0, vel1, ego_head0, ego_head1); vr = sg_norm2(ego_vel0, ego_vel1); }
+                if (vr == 0.0) s_long = MIN_SAFE_CLEARANCE + 0.5 * ego_l;
+                else {
+                    const double a = vr * rt + __builtin_fmin(vf * vf / (2 * m), 0.5 * m * (rt * rt)) +
+                                     ((vr + rt * m) * (vr + rt * m)) / (2 * MIN_LONG_ACCEL) - vf * vf / (2 * m);
+                    s_long = __builtin_fmax(0.0, a) + MIN_SAFE_CLEARANCE + 0.5 * ego_l;
+                }
+            } else {
+                const double v1 = __builtin_fabs(rss_dot2(ego_vel0, ego_vel1, ego_head0, ego_head1));
+                const double av2 = __builtin_fabs(-__builtin_fabs(rss_dot2(vel0, vel1, ego_head0, ego_head1)));
+                const int sp = (pos1 > 0) - (pos1 < 0), sv = (vel1 > 0) - (vel1 < 0);
+                if (sp == sv) s_long = MIN_SAFE_CLEARANCE + 0.5 * ego_l;
+                else {
+                    const double a = (2 * v1 + rt * m) * rt / 2 + ((v1 + rt * m) * (v1 + rt * m)) / (2 * MIN_LONG_ACCEL) +
+                                     (2 * av2 + rt * m) * rt / 2 + ((av2 + rt * m) * (av2 + rt * m)) / (2 * MIN_LONG_ACCEL);
+                    s_long = __builtin_fmax(0.0, a) + MIN_SAFE_CLEARANCE + 0.5 * ego_l;
+                }
+            }
+            s_long = __builtin_fabs(s_long);
+        }
+        { // safe_lateral_distance, :274-305
+            double v = vel0, i0, i1;
+            rss_inv_dir(ego_head0, ego_head1, i0, i1);
+            const double ad = __builtin_fabs(rss_dot2(i0, i1, head0, head1));
+            const double max_lat = MAX_LONG_ACCEL * ad, min_lat = MIN_LONG_ACCEL * ad, rt = RESPONSE_TIME;
+            const int sp = (-pos0 > 0) - (-pos0 < 0), sv = (v > 0) - (v < 0);
+            double d0 = 0;
+            bool parallel = false;
+            if (sp == sv) {
+                v = __builtin_fabs(v);
+                if (v == 0.0) parallel = true;
+                else
+                    d0 = __builtin_fmax(0.0, 0.5 * rt * (2 * v + rt * max_lat) + ((v + rt * max_lat) * (v + rt * max_lat)) / (2 * min_lat) -
+                                                 0.5 * (rt * rt) * max_lat - ((rt * max_lat) * (rt * max_lat)) / (2 * min_lat));
+            }
+            s_lat = __builtin_fabs(parallel ? MIN_SAFE_CLEARANCE + 0.5 * ego_w : d0 + MIN_SAFE_CLEARANCE + 0.5 * ego_w);
+        }
+        // unsafe_distance, :179-229
+        const int found = state & 0xff, last = (state >> 8) & 0xff;
+        if (found) {
+            cd = 6;
+        } else {
+            const double B[8] = {s_lat, s_long, -s_lat, s_long, -s_lat, -s_long, s_lat, -s_long};
+            if (sg_quads_intersect(Q, B)) {
+                if (last == 1) cd = 5;
+                else if (last == 2) cd = 4;
+                else {
+                    double j0, j1;
+                    rss_inv_dir(ego_w, ego_l, j0, j1);
+                    const double A = __builtin_fabs(__builtin_fabs(pos0) - __builtin_fabs(rss_dot2(pos0, pos1, ego_w, ego_l))) / s_lat;
+                    const double Bv = __builtin_fabs(__builtin_fabs(pos1 - rss_dot2(pos0, pos1, j0, j1)) / s_long);
+                    cd = A > Bv ? 5 : 4;
+                }
+                state = (state & ~0xff) | (cd == 4 ? 1 : 2);
+            } else { // write_intersections, :307-340 (the "length" lines are the buffer's stretched diagonals, as built)
+                const bool lat_i = rss_seg_quad(Q, B[0], 100 * B[1], B[4], 100 * B[5]) || rss_seg_quad(Q, B[2], 100 * B[3], B[6], 100 * B[7]);
+                const bool long_i = rss_seg_quad(Q, 100 * B[0], B[1], 100 * B[2], B[3]) || rss_seg_quad(Q, 100 * B[4], B[5], 100 * B[6], B[7]);
+                cd = lat_i && long_i ? 3 : (lat_i ? 1 : (long_i ? 2 : 0));
+                if (cd == 1 || cd == 2) state = (state & 0xff) | (cd << 8);
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
 // The rollout kernel: ScenarioGym.reset_scenario / step / rollout (scenario_gym.py:217-267).
 //   WV == 1: one 64-lane workgroup carries 64/G scenarios of up to G entities each (tiles of G lanes)
 //   WV  > 1: one workgroup of WV wavefronts carries ONE scenario of up to 64*WV entities
@@ -1631,7 +1780,8 @@ __device__ __forceinline__ Table lane_table(const Params &p, int kind, const Sce
 // compiled out (batches of replay entities only: the C2 shape).
 // ROAD: the ego_off_road terminal condition is compiled in (its own entry point, rollout_kernel_road: the other
 // variants keep their register budgets).
-template <int G, int WV, bool PED, bool TAB, bool HAST, bool ROAD = false>
+// RSSV: the RSSDistances callback (rss_entity) runs after the reset and after every step inside the kernel.
+template <int G, int WV, bool PED, bool TAB, bool HAST, bool ROAD = false, bool RSSV = false>
 __device__ __forceinline__ void rollout_body(
     const Params &p, double timestep, int n_steps, int do_reset, int force, const double *actions /*[n][R][2]*/,
     const double *tab /*controller table planes*/)
@@ -1878,6 +2028,56 @@ __device__ __forceinline__ void rollout_body(
             if (is_ego) sd.ego_distance_travelled = __builtin_nan("");
         }
     }
+
+    // ---- RSSDistances inside the kernel (RSSV) ----
+    const uint32_t rss_idx = (uint32_t)r * p.EP + slot;
+    int32_t rss_st = 0;
+    int rss_cd = -1;
+    bool rss_touched = false; // this scenario was updated at least once in this launch
+    double rss_lat = __builtin_nan(""), rss_long = __builtin_nan("");
+    double rss_bw = 0.0, rss_bl = 0.0, rss_ew = 0.0, rss_el = 0.0;
+    if (RSSV) {
+        if (!rs && in_range && slot < p.E) rss_st = p.rss_state[rss_idx];
+        rss_bw = fld(st, ST_BW);
+        rss_bl = fld(st, ST_BL);
+        if (WV == 1) { // the ego is slot 0 of the tile (sg_rss_update refuses anything else)
+            rss_ew = shfl_d(rss_bw, tile0);
+            rss_el = shfl_d(rss_bl, tile0);
+        } else {
+            if (tid == 0) { lds.cor[0][0] = rss_bw; lds.cor[1][0] = rss_bl; }
+            __syncthreads();
+            rss_ew = lds.cor[0][0];
+            rss_el = lds.cor[1][0];
+            __syncthreads();
+        }
+    }
+    // one RSSDistances.__call__ for this lane's entity; upd: its scenario is being updated (it was reset / it stepped)
+    auto rss_call = [&](bool upd, double tnow, double vx, double vy) {
+        double ex, ey, eh, evx, evy;
+        bool ego_pres;
+        if (WV == 1) {
+            ex = shfl_d(pose[0], tile0); ey = shfl_d(pose[1], tile0); eh = shfl_d(pose[3], tile0);
+            evx = shfl_d(vx, tile0); evy = shfl_d(vy, tile0);
+            ego_pres = (__ballot(present) >> tile0) & 1;
+        } else {
+            if (tid == 0) {
+                lds.cor[0][0] = pose[0]; lds.cor[1][0] = pose[1]; lds.cor[2][0] = pose[3];
+                lds.cor[3][0] = vx; lds.cor[4][0] = vy; lds.cor[5][0] = present ? 1.0 : 0.0;
+            }
+            __syncthreads();
+            ex = lds.cor[0][0]; ey = lds.cor[1][0]; eh = lds.cor[2][0]; evx = lds.cor[3][0]; evy = lds.cor[4][0];
+            ego_pres = lds.cor[5][0] != 0.0;
+            __syncthreads(); // the collision pass of the next step rewrites the scratch
+        }
+        if (!upd) return;
+        rss_touched = true;
+        rss_cd = -1;
+        rss_lat = rss_long = __builtin_nan("");
+        if (tnow == 0.0 || !ego_pres || !present || slot == 0 || slot >= p.E) return; // callback.py:76-78
+        rss_entity(ex, ey, eh, evx, evy, rss_ew, rss_el, pose[0], pose[1], pose[3], vx, vy, rss_bw, rss_bl, bcx, bcy, rss_st,
+                   rss_cd, rss_lat, rss_long);
+    };
+    if (RSSV && do_reset != 0) rss_call(rs, t, vel[0], vel[1]); // State.reset ends with update_callbacks(), state.py:138-140
 
     Segment S;
     {
@@ -2218,6 +2418,7 @@ __device__ __forceinline__ void rollout_body(
                 last_row[w] = row[w];
             }
         }
+        if (RSSV) rss_call(run, t, vel[0], vel[1]); // State.step ends with update_callbacks(), state.py:165-171
         if (has_tab) sg_lgkm_done();
     }
     }
@@ -2241,6 +2442,17 @@ __device__ __forceinline__ void rollout_body(
             stf(dy, SG_F_CTRL + 2, cs.e_lat_prev); stf(dy, SG_F_CTRL + 3, cs.e_lon_int);
         }
         if (slot == 0) { sd.t = t; sd.prev_t = prev_t; sd.done = done; sd.n_steps = steps; }
+        if (RSSV) {
+            if (slot < p.E) {
+                p.rss_state[rss_idx] = rss_st;
+                if (rss_touched) { // the records of the latest update
+                    p.rss_code[rss_idx] = rss_cd;
+                    p.rss_safe[(size_t)rss_idx * 2] = rss_lat;
+                    p.rss_safe[(size_t)rss_idx * 2 + 1] = rss_long;
+                }
+            }
+            if (slot == 0 && rss_touched) p.rss_seen[r] = steps;
+        }
         if (is_ego) {
             sd.ego_avg_speed = m_avg; sd.ego_max_speed = m_max; sd.avg_t = m_t;
             if (steps > 0 && present) sd.ego_distance_travelled = dist; // EgoDistanceTravelled, :60-62
@@ -2265,6 +2477,14 @@ __global__ __launch_bounds__(64 * WV, SG_WAVES_PER_SIMD) void rollout_kernel_roa
     Params p, double timestep, int n_steps, int do_reset, int force, const double *actions, const double *tab)
 {
     rollout_body<G, WV, false, false, false, true>(p, timestep, n_steps, do_reset, force, actions, tab);
+}
+
+// state_callbacks=[RSSDistances()]: controllers and the RSS callback in the kernel, any number of steps per launch
+template <int G, int WV>
+__global__ __launch_bounds__(64 * WV, 1) void rollout_kernel_rss(
+    Params p, double timestep, int n_steps, int do_reset, int force, const double *actions, const double *tab)
+{
+    rollout_body<G, WV, false, false, false, false, true>(p, timestep, n_steps, do_reset, force, actions, tab);
 }
 
 // The table variant with one wavefront per tile (C2 / C3 shapes) under a 192-VGPR cap: two of its wavefronts and one of
@@ -2822,145 +3042,6 @@ __global__ __launch_bounds__(64) void classify_events_kernel(Params p, double c_
         if (vehicle) ev.type = cls;
         pt[0] = cpx; pt[1] = cpy; pt[2] = cang;
     }
-}
-
-// ------------------------------------------------------------------------------------------------
-// RSSDistances.__call__ (metrics/rss/callback.py:58-128) on the current state of every scenario, + the flags RSS reads
-// (metrics/rss/rss.py:70-104).  One workgroup per scenario, one thread per entity.  Ego frame: x lateral, y longitudinal;
-// np.dot of 2-vectors = fma(a1, b1, a0 * b0), norm([u, v]) = sqrt(fma(v, v, u * u)) (probed); the per-entity history list
-// is carried as (found, last): an "unsafe_*" entry exists / the latest "lateral" | "longitudinal" entry.  Same operation
-// sequence as the oracle's sgo_rss_update.
-// ------------------------------------------------------------------------------------------------
-__device__ inline double rss_dot2(double a0, double a1, double b0, double b1) { return __builtin_fma(a1, b1, a0 * b0); }
-__device__ inline void rss_inv_dir(double v0, double v1, double &o0, double &o1)
-{
-    const double n = sg_norm2(v1, v0);
-    o0 = v1 / n;
-    o1 = -v0 / n;
-}
-__device__ inline bool rss_on_segment(double ax, double ay, double bx, double by, double px, double py)
-{
-    return px >= __builtin_fmin(ax, bx) && px <= __builtin_fmax(ax, bx) && py >= __builtin_fmin(ay, by) && py <= __builtin_fmax(ay, by);
-}
-__device__ inline bool rss_point_in_quad(const double *Q, double px, double py)
-{
-    bool pos = false, neg = false;
-    for (int k = 0; k < 4; ++k) {
-        const int m = (k + 1) & 3, o = rn_orient_sign(Q[2 * k], Q[2 * k + 1], Q[2 * m], Q[2 * m + 1], px, py);
-        pos |= o > 0;
-        neg |= o < 0;
-    }
-    return !(pos && neg);
-}
-__device__ inline bool rss_seg_quad(const double *Q, double ax, double ay, double bx, double by)
-{
-    if (rss_point_in_quad(Q, ax, ay) || rss_point_in_quad(Q, bx, by)) return true;
-    for (int k = 0; k < 4; ++k) {
-        const int m = (k + 1) & 3;
-        const double cx = Q[2 * k], cy = Q[2 * k + 1], dx = Q[2 * m], dy = Q[2 * m + 1];
-        const int o1 = rn_orient_sign(ax, ay, bx, by, cx, cy), o2 = rn_orient_sign(ax, ay, bx, by, dx, dy);
-        const int o3 = rn_orient_sign(cx, cy, dx, dy, ax, ay), o4 = rn_orient_sign(cx, cy, dx, dy, bx, by);
-        if (o1 * o2 < 0 && o3 * o4 < 0) return true;
-        if ((o1 == 0 && rss_on_segment(ax, ay, bx, by, cx, cy)) || (o2 == 0 && rss_on_segment(ax, ay, bx, by, dx, dy)) ||
-            (o3 == 0 && rss_on_segment(cx, cy, dx, dy, ax, ay)) || (o4 == 0 && rss_on_segment(cx, cy, dx, dy, bx, by)))
-            return true;
-    }
-    return false;
-}
-
-// RSSDistances for ONE entity against the ego (both present, t != 0): safe distances, the record appended to the entity's
-// history, the updated (found | last << 8) state.  Shared by rss_kernel (one update per call) and the rollout variant that
-// runs the callback after every step itself.
-__device__ inline void rss_entity(double ex, double ey, double ego_heading, double ego_vx, double ego_vy, double ego_w, double ego_l,
-                                  double hx, double hy, double hh, double hvx, double hvy, double bw, double bl, double bcx,
-                                  double bcy, int32_t &state, int &cd, double &s_lat, double &s_long)
-{
-        const double RESPONSE_TIME = 0.6, MIN_LONG_ACCEL = 1.2 * 9.81, MAX_LONG_ACCEL = 1.2 * 9.81, MIN_SAFE_CLEARANCE = 0.1;
-        double es, ec, ei0, ei1;
-        sg_sincos(ego_heading, es, ec);
-        const double eh0 = ec, eh1 = es;
-        rss_inv_dir(eh0, eh1, ei0, ei1);
-        const double ego_head0 = rss_dot2(eh0, eh1, ei0, ei1), ego_head1 = rss_dot2(eh0, eh1, eh0, eh1);
-        const double ego_vel0 = rss_dot2(ego_vx, ego_vy, ei0, ei1), ego_vel1 = rss_dot2(ego_vx, ego_vy, eh0, eh1);
-        const double ego_pos1 = rss_dot2(ex - ex, ey - ey, eh0, eh1);
-        double hs, hc;
-        sg_sincos(hh, hs, hc);
-        const double pos0 = rss_dot2(hx - ex, hy - ey, ei0, ei1), pos1 = rss_dot2(hx - ex, hy - ey, eh0, eh1);
-        const double head0 = rss_dot2(hc, hs, ei0, ei1), head1 = rss_dot2(hc, hs, eh0, eh1);
-        const double vel0 = rss_dot2(hvx, hvy, ei0, ei1), vel1 = rss_dot2(hvx, hvy, eh0, eh1);
-        double cor[8], Q[8];
-        sg_corners(hx, hy, hs, hc, bw, bl, bcx, bcy, cor);
-        for (int k = 0; k < 4; ++k) {
-            Q[2 * k] = rss_dot2(cor[2 * k] - ex, cor[2 * k + 1] - ey, ei0, ei1);
-            Q[2 * k + 1] = rss_dot2(cor[2 * k] - ex, cor[2 * k + 1] - ey, eh0, eh1);
-        }
-        { // safe_longitudinal_distance, :231-272
-            const double dd = rss_dot2(ego_head0, ego_head1, head0, head1);
-            const double m = __builtin_fabs(MAX_LONG_ACCEL * dd), rt = RESPONSE_TIME;
-            if (dd > 0) {
-                double vf, vr;
-                if (ego_pos1 > pos1) { vf = sg_norm2(ego_vel0, ego_vel1); vr = rss_dot2(vel0, vel1, ego_head0, ego_head1); }
-                else { vf = rss_dot2(vel0, vel1, ego_head0, ego_head1); vr = sg_norm2(ego_vel0, ego_vel1); }
-                if (vr == 0.0) s_long = MIN_SAFE_CLEARANCE + 0.5 * ego_l;
-                else {
-                    const double a = vr * rt + __builtin_fmin(vf * vf / (2 * m), 0.5 * m * (rt * rt)) +
-                                     ((vr + rt * m) * (vr + rt * m)) / (2 * MIN_LONG_ACCEL) - vf * vf / (2 * m);
-                    s_long = __builtin_fmax(0.0, a) + MIN_SAFE_CLEARANCE + 0.5 * ego_l;
-                }
-            } else {
-                const double v1 = __builtin_fabs(rss_dot2(ego_vel0, ego_vel1, ego_head0, ego_head1));
-                const double av2 = __builtin_fabs(-__builtin_fabs(rss_dot2(vel0, vel1, ego_head0, ego_head1)));
-                const int sp = (pos1 > 0) - (pos1 < 0), sv = (vel1 > 0) - (vel1 < 0);
-                if (sp == sv) s_long = MIN_SAFE_CLEARANCE + 0.5 * ego_l;
-                else {
-                    const double a = (2 * v1 + rt * m) * rt / 2 + ((v1 + rt * m) * (v1 + rt * m)) / (2 * MIN_LONG_ACCEL) +
-                                     (2 * av2 + rt * m) * rt / 2 + ((av2 + rt * m) * (av2 + rt * m)) / (2 * MIN_LONG_ACCEL);
-                    s_long = __builtin_fmax(0.0, a) + MIN_SAFE_CLEARANCE + 0.5 * ego_l;
-                }
-            }
-            s_long = __builtin_fabs(s_long);
-        }
-        { // safe_lateral_distance, :274-305
-            double v = vel0, i0, i1;
-            rss_inv_dir(ego_head0, ego_head1, i0, i1);
-            const double ad = __builtin_fabs(rss_dot2(i0, i1, head0, head1));
-            const double max_lat = MAX_LONG_ACCEL * ad, min_lat = MIN_LONG_ACCEL * ad, rt = RESPONSE_TIME;
-            const int sp = (-pos0 > 0) - (-pos0 < 0), sv = (v > 0) - (v < 0);
-            double d0 = 0;
-            bool parallel = false;
-            if (sp == sv) {
-                v = __builtin_fabs(v);
-                if (v == 0.0) parallel = true;
-                else
-                    d0 = __builtin_fmax(0.0, 0.5 * rt * (2 * v + rt * max_lat) + ((v + rt * max_lat) * (v + rt * max_lat)) / (2 * min_lat) -
-                                                 0.5 * (rt * rt) * max_lat - ((rt * max_lat) * (rt * max_lat)) / (2 * min_lat));
-            }
-            s_lat = __builtin_fabs(parallel ? MIN_SAFE_CLEARANCE + 0.5 * ego_w : d0 + MIN_SAFE_CLEARANCE + 0.5 * ego_w);
-        }
-        // unsafe_distance, :179-229
-        const int found = state & 0xff, last = (state >> 8) & 0xff;
-        if (found) {
-            cd = 6;
-        } else {
-            const double B[8] = {s_lat, s_long, -s_lat, s_long, -s_lat, -s_long, s_lat, -s_long};
-            if (sg_quads_intersect(Q, B)) {
-                if (last == 1) cd = 5;
-                else if (last == 2) cd = 4;
-                else {
-                    double j0, j1;
-                    rss_inv_dir(ego_w, ego_l, j0, j1);
-                    const double A = __builtin_fabs(__builtin_fabs(pos0) - __builtin_fabs(rss_dot2(pos0, pos1, ego_w, ego_l))) / s_lat;
-                    const double Bv = __builtin_fabs(__builtin_fabs(pos1 - rss_dot2(pos0, pos1, j0, j1)) / s_long);
-                    cd = A > Bv ? 5 : 4;
-                }
-                state = (state & ~0xff) | (cd == 4 ? 1 : 2);
-            } else { // write_intersections, :307-340 (the "length" lines are the buffer's stretched diagonals, as built)
-                const bool lat_i = rss_seg_quad(Q, B[0], 100 * B[1], B[4], 100 * B[5]) || rss_seg_quad(Q, B[2], 100 * B[3], B[6], 100 * B[7]);
-                const bool long_i = rss_seg_quad(Q, 100 * B[0], B[1], 100 * B[2], B[3]) || rss_seg_quad(Q, 100 * B[4], B[5], 100 * B[6], B[7]);
-                cd = lat_i && long_i ? 3 : (lat_i ? 1 : (long_i ? 2 : 0));
-                if (cd == 1 || cd == 2) state = (state & 0xff) | (cd << 8);
-            }
-        }
 }
 
 // rss_state [NE] = found | last << 8; code [NE]: 0 safe, 1 lateral, 2 longitudinal, 3 both, 4 unsafe_lateral,

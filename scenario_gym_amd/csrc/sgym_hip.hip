@@ -52,6 +52,7 @@ struct sg_handle {
     int32_t tick_layers[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int32_t *d_rss_state = nullptr, *d_rss_code = nullptr; // [NE] sg_rss_update
     int32_t *d_rss_seen = nullptr;                         // [R]
+    bool rss_fused = false;                                // this launch runs the callback inside rollout_kernel_rss
     bool rss_enabled = false;                              // sg_set_rss: RSSDistances runs after every step of sg_rollout / sg_step
     bool ego_first = true;                                 // every scenario's ego is its entity 0
     double *d_rss_safe = nullptr;                          // [NE][2]
@@ -108,6 +109,8 @@ static int dev_alloc(sg_handle *h, std::vector<void *> &pool, T **out, size_t n,
     *out = (T *)ptr;
     return SG_OK;
 }
+
+static int ensure_rss(sg_handle *h, bool *fresh);
 
 template <typename T>
 static int dev_upload(sg_handle *h, std::vector<void *> &pool, const T **out, const std::vector<T> &v)
@@ -221,6 +224,8 @@ static void launch_variant(sg_handle *h, dim3 grid, int n_steps, int do_reset, i
     if (h->has_ped)
         sg::rollout_kernel<(WV > 1 || G >= 16) ? G : 16, WV, true, false><<<grid, block, 0, h->stream>>>(
             h->p, h->cfg.timestep, n_steps, do_reset, force, d_actions, nullptr);
+    else if (h->rss_fused)
+        sg::rollout_kernel_rss<G, WV><<<grid, block, 0, h->stream>>>(h->p, h->cfg.timestep, n_steps, do_reset, force, d_actions, nullptr);
     else if (h->cfg.terminal_mask & SG_TERM_EGO_OFF_ROAD)
         sg::rollout_kernel_road<G, WV><<<grid, block, 0, h->stream>>>(h->p, h->cfg.timestep, n_steps, do_reset, force, d_actions, nullptr);
     else if (use_tab && WV == 1 && h->n_ctl > 0)
@@ -292,7 +297,7 @@ static int launch_rollout(sg_handle *h, int n_steps, int do_reset, int force, co
     size_t ev_next = 0;
     // the table variant serves SG_TAB_LANES controlled lanes per wavefront; denser batches keep their controllers
     // in the rollout kernel, where they fill the wavefront anyway
-    const bool use_tab = !h->has_ped && !(h->cfg.terminal_mask & SG_TERM_EGO_OFF_ROAD) && h->n_ext == 0 && n_steps >= tab_min && h->max_ctl_per_block <= SG_TAB_LANES(h->G, h->WV);
+    const bool use_tab = !h->has_ped && !h->rss_fused && !(h->cfg.terminal_mask & SG_TERM_EGO_OFF_ROAD) && h->n_ext == 0 && n_steps >= tab_min && h->max_ctl_per_block <= SG_TAB_LANES(h->G, h->WV);
     // short calls (the per-tick loop of an RL driver) are not timed: four event records cost more than their kernel
     h->timing_now = use_tab || n_steps >= 16;
     if (h->timing_now) HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
@@ -573,8 +578,17 @@ extern "C" int sg_reset(sg_handle *h)
     if (!h) return SG_ERR_INVALID;
     if (!h->uploaded) return fail(h, SG_ERR_STATE, "sg_reset: no scenarios uploaded");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
-    int rc = launch_rollout(h, 0, 1, 0, nullptr);
-    if (!rc && h->rss_enabled) rc = sg_rss_update(h, 1);
+    int rc;
+    if (h->rss_enabled && !h->has_ped && !(h->cfg.terminal_mask & SG_TERM_EGO_OFF_ROAD) && h->ego_first) {
+        bool fresh = false;
+        if ((rc = ensure_rss(h, &fresh))) return rc;
+        h->rss_fused = true;
+        rc = launch_rollout(h, 0, 1, 0, nullptr);
+        h->rss_fused = false;
+    } else {
+        rc = launch_rollout(h, 0, 1, 0, nullptr);
+        if (!rc && h->rss_enabled) rc = sg_rss_update(h, 1);
+    }
     if (rc) return rc;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return SG_OK;
@@ -650,7 +664,13 @@ extern "C" int sg_step(sg_handle *h, int32_t n_steps, const double *actions, int
         d_act = h->d_actions;
     }
     int rc = SG_OK;
-    if (h->rss_enabled) {
+    if (h->rss_enabled && !h->has_ped && !(h->cfg.terminal_mask & SG_TERM_EGO_OFF_ROAD) && h->ego_first && h->d_rss_state) {
+        bool fresh = false;
+        rc = ensure_rss(h, &fresh);
+        h->rss_fused = true;
+        if (!rc) rc = launch_rollout(h, n_steps, 0, 1, d_act);
+        h->rss_fused = false;
+    } else if (h->rss_enabled) {
         for (int k = 0; k < n_steps && !rc; ++k)
             if (!(rc = launch_rollout(h, 1, 0, 1, d_act + (size_t)k * h->R * 2))) rc = sg_rss_update(h, 0);
     } else {
@@ -790,7 +810,17 @@ extern "C" int sg_rollout_async(sg_handle *h, int32_t max_steps, int32_t do_rese
                                      "use sg_set_external_poses + sg_step tick by tick", h->n_ext);
     if (max_steps < 0) return fail(h, SG_ERR_INVALID, "sg_rollout: max_steps < 0");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
-    if (h->rss_enabled) { // the RSSDistances callback after the reset and after every step: one step per launch
+    if (h->rss_enabled && !h->has_ped && !(h->cfg.terminal_mask & SG_TERM_EGO_OFF_ROAD) && h->ego_first) {
+        // the callback inside the rollout kernel (rollout_kernel_rss): after the reset and after every step of ONE launch
+        bool fresh = false;
+        int rc = ensure_rss(h, &fresh);
+        if (rc) return rc;
+        h->rss_fused = true;
+        rc = launch_rollout(h, max_steps, do_reset || fresh ? 1 : 0, 0, nullptr);
+        h->rss_fused = false;
+        return rc;
+    }
+    if (h->rss_enabled) { // (pedestrian batches, ego_off_road) the callback after the reset and after every step: one step per launch
         int rc = SG_OK;
         if (do_reset && ((rc = launch_rollout(h, 0, 1, 0, nullptr)) || (rc = sg_rss_update(h, 1)))) return rc;
         for (int k = 0; k < max_steps; ++k)
@@ -994,19 +1024,35 @@ extern "C" int sg_set_tuning(sg_handle *h, int32_t tab_min_steps, int32_t chunk_
     return SG_OK;
 }
 
+// the RSS record arrays of the current batch (freed by sg_upload); returns 1 in *fresh when they were just created
+static int ensure_rss(sg_handle *h, bool *fresh)
+{
+    *fresh = false;
+    if (!h->d_rss_state) {
+        HIP_TRY(h, hipMalloc((void **)&h->d_rss_state, h->NE * sizeof(int32_t)));
+        HIP_TRY(h, hipMalloc((void **)&h->d_rss_code, h->NE * sizeof(int32_t)));
+        HIP_TRY(h, hipMalloc((void **)&h->d_rss_safe, h->NE * 2 * sizeof(double)));
+        HIP_TRY(h, hipMalloc((void **)&h->d_rss_seen, (size_t)h->R * sizeof(int32_t)));
+        HIP_TRY(h, hipMemsetAsync(h->d_rss_state, 0, h->NE * sizeof(int32_t), h->stream));
+        HIP_TRY(h, hipMemsetAsync(h->d_rss_code, 0xff, h->NE * sizeof(int32_t), h->stream));
+        HIP_TRY(h, hipMemsetAsync(h->d_rss_safe, 0xff, h->NE * 2 * sizeof(double), h->stream));
+        HIP_TRY(h, hipMemsetAsync(h->d_rss_seen, 0xff, (size_t)h->R * sizeof(int32_t), h->stream));
+        *fresh = true;
+    }
+    h->p.rss_state = h->d_rss_state; h->p.rss_code = h->d_rss_code; h->p.rss_safe = h->d_rss_safe; h->p.rss_seen = h->d_rss_seen;
+    return SG_OK;
+}
+
 extern "C" int sg_rss_update(sg_handle *h, int32_t reset)
 {
     if (!h) return SG_ERR_INVALID;
     if (!h->uploaded) return fail(h, SG_ERR_STATE, "sg_rss_update: no scenarios uploaded");
     if (!h->ego_first) return fail(h, SG_ERR_STATE, "sg_rss_update: RSSDistances keeps its records for entities[1:], the ego has to be entity 0 of every scenario");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
-    if (!h->d_rss_state) {
-        HIP_TRY(h, hipMalloc((void **)&h->d_rss_state, h->NE * sizeof(int32_t)));
-        HIP_TRY(h, hipMalloc((void **)&h->d_rss_code, h->NE * sizeof(int32_t)));
-        HIP_TRY(h, hipMalloc((void **)&h->d_rss_safe, h->NE * 2 * sizeof(double)));
-        HIP_TRY(h, hipMalloc((void **)&h->d_rss_seen, (size_t)h->R * sizeof(int32_t)));
-        reset = 1;
-    }
+    bool fresh = false;
+    int rc0 = ensure_rss(h, &fresh);
+    if (rc0) return rc0;
+    if (fresh) reset = 1;
     sg::rss_kernel<<<dim3((unsigned)h->R), dim3(256), 0, h->stream>>>(h->p, reset ? 1 : 0, h->d_rss_state, h->d_rss_code, h->d_rss_safe, h->d_rss_seen);
     HIP_TRY(h, hipGetLastError());
     return SG_OK;
