@@ -1456,3 +1456,42 @@ def test_rss_inside_rollout_equals_tick_by_tick(sga):
     assert not ra[0].all() or not ra[1].all()
     a.close()
     b.close()
+
+
+@pytest.mark.parametrize("R,E,ego", [(30, 3, "pid"), (12, 40, "replay"), (6, 100, "pid"), (4, 200, "replay"), (20, 64, "vehicle")])
+def test_rss_fused_rollout_matches_oracle(sga, oracle, R, E, ego):
+    """rollout_kernel_rss over the tile widths (4 ... 64 lanes) and the two- / four-wavefront scenarios, replay, PID and
+    external-action egos: records of the latest update, safe distances and metric flags equal the oracle's callback run
+    over the oracle's rollout; a second rollout() (reset included) gives the same again."""
+    import scenario_gym_amd._lib as L
+    from scenario_gym_amd import synthetic
+    from scenario_gym_amd.packing import unpack_scenario
+
+    steps = 70
+    kind = dict(replay=L.KIND_AGENT_REPLAY, pid=L.KIND_AGENT_PID, vehicle=L.KIND_AGENT_VEHICLE)[ego]
+    packed = synthetic.make_batch(R, E, n_steps=steps, ego_kind=kind, extent=20.0 if E < 100 else 45.0, vanish_frac=0.3)
+    packed.length = packed.length * np.linspace(0.5, 1.0, R)
+    acts = synthetic.make_actions(steps, R) if ego == "vehicle" else None
+    eng = sga.RolloutEngine(R, E)
+    eng.set_rss(True)
+    eng.upload(packed)
+    for rep in range(2):
+        if ego == "vehicle":
+            eng.reset()
+            eng.step(steps, acts)
+        else:
+            eng.rollout(steps)
+        slong, slat, codes, safe = eng.rss()
+        n_steps = eng.state()["n_steps"]
+        for r in range(R):
+            s = unpack_scenario(packed, r)
+            kw = dict(actions=acts[:, r], force_steps=True) if ego == "vehicle" else {}
+            o = oracle.rollout(s["knot_off"], s["knots"], s["bbox"], s["etype"], s["kind"], s["ego"], s["t0"], s["length"], 1 / 30,
+                               ctrl=s["ctrl"], max_steps=steps, **kw)
+            w = oracle.rss_rollout(o, s["bbox"], s["ego"])
+            n = len(s["bbox"])
+            assert n_steps[r] == o["n_steps"]
+            assert np.array_equal(codes[r, :n], w["code"][-1]), (rep, r, codes[r, :n], w["code"][-1])
+            assert np.array_equal(safe[r, :n], w["safe"][-1], equal_nan=True), (rep, r)
+            assert slong[r] == w["safe_longitudinal"] and slat[r] == w["safe_lateral"], (rep, r)
+    eng.close()
