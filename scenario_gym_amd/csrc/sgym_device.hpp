@@ -2481,7 +2481,7 @@ __global__ __launch_bounds__(64 * WV, SG_WAVES_PER_SIMD) void rollout_kernel_roa
 
 // state_callbacks=[RSSDistances()]: controllers and the RSS callback in the kernel, any number of steps per launch
 template <int G, int WV>
-__global__ __launch_bounds__(64 * WV, 1) void rollout_kernel_rss(
+__global__ __launch_bounds__(64 * WV, SG_WAVES_PER_SIMD) void rollout_kernel_rss(
     Params p, double timestep, int n_steps, int do_reset, int force, const double *actions, const double *tab)
 {
     rollout_body<G, WV, false, false, false, false, true>(p, timestep, n_steps, do_reset, force, actions, tab);
