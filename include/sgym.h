@@ -305,7 +305,8 @@ int sg_raster_map_device(sg_handle *h, double width, double height, int32_t nw, 
  * actions: [n_scenarios][2] HOST (actions_device = 0) or DEVICE, or NULL for (0, 0).  Asynchronous: the work is queued on
  * sg_stream(h); *d_obs (DEVICE [R][n_layers][nh][nw] bytes) and *d_flags (DEVICE [R] SG_TERM_* bits) are valid after
  * sg_synchronize(h) until the next observation call.  The graph is rebuilt when the batch, the networks, the time step or
- * the geometry change.  Not for batches with SG_KIND_AGENT_EXTERNAL slots. */
+ * the geometry change.  Not for batches with SG_KIND_AGENT_EXTERNAL slots; the RSS callback of sg_set_rss is not part of the
+ * graph (call sg_rss_update after the tick if it is wanted). */
 int sg_tick(sg_handle *h, const double *actions, int32_t actions_device, double width, double height, int32_t nw, int32_t nh,
             int32_t n_layers, const int32_t *layers, const uint8_t **d_obs, const uint32_t **d_flags);
 
