@@ -1454,8 +1454,19 @@ def test_rss_inside_rollout_equals_tick_by_tick(sga):
     for x, y in zip(ra, rb):
         assert np.array_equal(x, y, equal_nan=True)
     assert not ra[0].all() or not ra[1].all()
+    # a new batch on the same handle starts from empty histories
+    packed2 = synthetic.make_batch(R, E, n_steps=steps, ego_kind=L.KIND_AGENT_PID, extent=16.0, seed=5)
+    b.upload(packed2)
+    b.rollout(steps)
+    c = sga.RolloutEngine(R, E)
+    c.set_rss(True)
+    c.upload(packed2)
+    c.rollout(steps)
+    for x, y in zip(b.rss(), c.rss()):
+        assert np.array_equal(x, y, equal_nan=True)
     a.close()
     b.close()
+    c.close()
 
 
 @pytest.mark.parametrize("R,E,ego", [(30, 3, "pid"), (12, 40, "replay"), (6, 100, "pid"), (4, 200, "replay"), (20, 64, "vehicle")])
