@@ -3085,6 +3085,100 @@ __global__ __launch_bounds__(256) void rss_kernel(Params p, int reset, int32_t *
     safe[(size_t)idx * 2 + 1] = s_long;
 }
 
+// The observation of one RL tick in ONE launch (sg_tick): every requested map layer -- the entity layer of raster_kernel and
+// the surface layers of raster_surface_kernel, same arithmetic, the grid point computed once -- and the terminal flags of
+// terminal_flags_kernel.  One workgroup per scenario.  has_road: road networks are set (else the surface layers are empty).
+__global__ __launch_bounds__(256) void observe_kernel(Params p, RoadIndex R, int has_road, double width, double height, int nw,
+                                                      int nh, int n_layers, const int32_t *layers,
+                                                      unsigned char *out /*[R][n_layers][nh][nw]*/, uint32_t *flags /*[R]*/)
+{
+    __shared__ double cor[8][256];
+    __shared__ double ego_pose[4]; // x, y, sin(theta), cos(theta)
+    __shared__ int near_n, ego_present, any_coll;
+    const int r = blockIdx.x, e = threadIdx.x;
+    const ScenStatic &ss = p.sstat[r];
+    const uint32_t idx = (uint32_t)r * p.EP + (e < p.EP ? e : 0);
+    const LanePtr st(p.stat + (size_t)(idx >> 6) * (ST_COUNT * 64), (idx & 63) * 8u);
+    const LanePtr dy(p.dyn + (size_t)(idx >> 6) * ((size_t)p.FROWS * 64), (idx & 63) * 8u);
+    const bool present = e < p.E && fld<uint64_t>(dy, SG_F_PRESENT) != 0;
+    if (e == 0) { near_n = 0; ego_present = 0; any_coll = 0; }
+    __syncthreads();
+    double C[8], x = 0.0, y = 0.0;
+    bool mine = false;
+    if (e < p.E) {
+        const int W = p.FROWS - SG_F_COLL;
+        for (int w = 0; w < W; ++w) mine = mine || fld<uint64_t>(dy, SG_F_COLL + w) != 0;
+        if (present && mine) any_coll = 1;
+    }
+    if (present) {
+        x = fld(dy, SG_F_POSE + 0); y = fld(dy, SG_F_POSE + 1);
+        const double h = fld(dy, SG_F_POSE + 3);
+        double s, c;
+        sg_sincos(h, s, c);
+        sg_corners(x, y, s, c, fld(st, ST_BW), fld(st, ST_BL), fld(st, ST_BCX), fld(st, ST_BCY), C);
+    }
+    if (e == ss.ego) {
+        double s, c;
+        sg_sincos(fld(dy, SG_F_POSE + 3) + 3.14159265358979311600e+00 / 2, s, c); // pose[3] + math.pi / 2
+        ego_pose[0] = fld(dy, SG_F_POSE + 0); ego_pose[1] = fld(dy, SG_F_POSE + 1);
+        ego_pose[2] = s; ego_pose[3] = c;
+        ego_present = present;
+    }
+    const int net = (has_road && R.net_of_scen) ? R.net_of_scen[r] : -1;
+    if (e == 0 && flags) { // TERMINAL_CONDITIONS of entities[0], state/state.py:397-408 (terminal_flags_kernel)
+        const sg_scenario_state &sd = p.sdyn[r];
+        uint32_t bits = 0;
+        if (sd.t + (sd.t - sd.prev_t) > ss.length) bits |= SG_TERM_MAX_LENGTH;
+        if (present && mine) bits |= SG_TERM_EGO_COLLISION;
+        bool on_road = false;
+        if (present && has_road) on_road = (rn_layers_at(R, net, SG_LAYER_DRIVEABLE, x, y) & SG_LAYER_DRIVEABLE) != 0;
+        if (!on_road) bits |= SG_TERM_EGO_OFF_ROAD;
+        flags[r] = bits; // SG_TERM_COLLISION joins below, once every entity has reported
+    }
+    __syncthreads();
+    if (e == 0 && flags && any_coll) flags[r] |= SG_TERM_COLLISION;
+    const double ex = ego_pose[0], ey = ego_pose[1], s = ego_pose[2], c = ego_pose[3];
+    bool want_entity = false;
+    uint32_t want = 0;
+    for (int k = 0; k < n_layers; ++k) { want_entity = want_entity || layers[k] == 0; want |= (uint32_t)layers[k]; }
+    if (present && want_entity) { // the boxes that can reach the grid (raster_kernel)
+        const double reach = 0.5 * (__builtin_fabs(width) + __builtin_fabs(height)) * 1.0000001 + 1e-6;
+        double far = 0.0;
+#pragma unroll
+        for (int k = 1; k < 4; ++k) far = __builtin_fmax(far, __builtin_fabs(C[2 * k] - C[0]) + __builtin_fabs(C[2 * k + 1] - C[1]));
+        const double dx = C[0] - ex, dyy = C[1] - ey, lim = reach + far * 1.0000001 + 1e-6 * (1.0 + __builtin_fabs(ex) + __builtin_fabs(ey));
+        if (!(dx * dx + dyy * dyy > lim * lim)) {
+            const int q = atomicAdd(&near_n, 1);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) cor[k][q] = C[k];
+        }
+    }
+    __syncthreads();
+    const int nn = near_n;
+    const bool ego_pres = ego_present != 0;
+    unsigned char *o = out + (size_t)r * n_layers * nw * nh;
+    for (int q = e; q < nw * nh; q += 256) {
+        const int i = q / nw, j = q - i * nw;
+        const double x0 = sg_linspace_at(-width / 2, width / 2, nw, j), x1 = sg_linspace_at(-height / 2, height / 2, nh, i);
+        const double px = __builtin_fma(x1, -s, x0 * c) + ex, py = __builtin_fma(x1, c, x0 * s) + ey;
+        bool hit = false;
+        for (int k = 0; k < nn && !hit; ++k) {
+            const double ax = cor[0][k], ay = cor[1][k], bx = cor[2][k], by = cor[3][k];
+            const double cx = cor[4][k], cy = cor[5][k], dx = cor[6][k], dyy = cor[7][k];
+            const double orient = (cx - ax) * (dyy - by) - (cy - ay) * (dx - bx);
+            const double c0 = (bx - ax) * (py - ay) - (by - ay) * (px - ax);
+            const double c1 = (cx - bx) * (py - by) - (cy - by) * (px - bx);
+            const double c2 = (dx - cx) * (py - cy) - (dyy - cy) * (px - cx);
+            const double c3 = (ax - dx) * (py - dyy) - (ay - dyy) * (px - dx);
+            hit = orient > 0 ? (c0 > 0 && c1 > 0 && c2 > 0 && c3 > 0)
+                             : (orient < 0 && c0 < 0 && c1 < 0 && c2 < 0 && c3 < 0);
+        }
+        const uint32_t in = (ego_pres && want && has_road) ? rn_layers_at(R, net, want, px, py) : 0u;
+        for (int k = 0; k < n_layers; ++k)
+            o[(size_t)k * nw * nh + q] = layers[k] == 0 ? (unsigned char)(ego_pres && hit) : (unsigned char)((in & (uint32_t)layers[k]) != 0);
+    }
+}
+
 // TERMINAL_CONDITIONS (state/state.py:397-408), all four evaluated on the CURRENT state of every scenario, whatever the
 // handle's terminal mask says: out[r] = SG_TERM_* bits.  The reward of the reference's RL agent asks exactly this of a
 // done state (integrations/openaigym.py:300-310).  One wavefront per scenario.

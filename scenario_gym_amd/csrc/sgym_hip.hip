@@ -746,19 +746,9 @@ extern "C" int sg_tick(sg_handle *h, const double *actions, int32_t actions_devi
         h->launch_ev.clear();
         rc = launch_main(h, 1, 0, 1, h->d_actions, nullptr, false, &ev_next);
         hipError_t e = hipSuccess;
-        if (!rc) {
-            sg::terminal_flags_kernel<<<dim3((unsigned)h->R), dim3(64), 0, h->stream>>>(h->p, h->cfg.timestep, h->d_term_flags);
-            e = hipGetLastError();
-        }
-        if (!rc && e == hipSuccess && any_surface && !h->has_road) e = hipMemsetAsync(d, 0, bytes, h->stream);
-        for (int k = 0; k < n_layers && !rc && e == hipSuccess; ++k)
-            if (layers[k] == 0) {
-                sg::raster_kernel<<<dim3((unsigned)h->R), dim3(256), 0, h->stream>>>(h->p, width, height, nw, nh, d + (size_t)k * plane,
-                                                                                   (int64_t)(n_layers * plane));
-                e = hipGetLastError();
-            }
-        if (!rc && e == hipSuccess && any_surface && h->has_road) {
-            sg::raster_surface_kernel<<<dim3((unsigned)h->R), dim3(256), 0, h->stream>>>(h->p, h->road, width, height, nw, nh, n_layers, dl, d);
+        if (!rc) { // the whole observation (map layers + terminal flags) in one launch
+            sg::observe_kernel<<<dim3((unsigned)h->R), dim3(256), 0, h->stream>>>(h->p, h->road, h->has_road ? 1 : 0, width, height, nw,
+                                                                                nh, n_layers, dl, d, h->d_term_flags);
             e = hipGetLastError();
         }
         hipError_t e2 = hipStreamEndCapture(h->stream, &graph);
