@@ -1506,3 +1506,64 @@ def test_rss_fused_rollout_matches_oracle(sga, oracle, R, E, ego):
             assert np.array_equal(safe[r, :n], w["safe"][-1], equal_nan=True), (rep, r)
             assert slong[r] == w["safe_longitudinal"] and slat[r] == w["safe_lateral"], (rep, r)
     eng.close()
+
+
+def _random_crowds(n, seed=77):
+    rng = np.random.default_rng(seed)
+    out = []
+    for k in range(n):
+        E = int([20, 64, 100, 256, 40, 130][k % 6])
+        out.append(dict(E=E, R=int(rng.integers(2, 7 if E <= 64 else 4)), steps=int(rng.integers(30, 90)),
+                        side=float(rng.choice([6.0, 12.0, 25.0])), roads=bool(rng.integers(0, 2)), seed=int(rng.integers(1, 1 << 30)),
+                        dt=float(rng.choice([1 / 30, 0.1]))))
+    return out
+
+
+@pytest.mark.parametrize("cfg", _random_crowds(int(os.environ.get("SG_FUZZ_CROWDS", "8")), int(os.environ.get("SG_FUZZ_SEED", "77"))),
+                         ids=lambda c: f"E{c['E']}-s{c['side']:.0f}-{'roads' if c['roads'] else 'free'}")
+def test_randomized_crowds_match_oracle(sga, oracle, cfg):
+    """Random social-force crowds (tile widths up to four wavefronts, sparse to packed), half of them on a road network with
+    random convex buildings and pavements among the pedestrians: poses of every step, forces, collision rows and events
+    bit-identical to the oracle (balanced pair loop, boundary terms, density-adaptive broad phase)."""
+    from scenario_gym_amd import synthetic
+    from scenario_gym_amd.packing import unpack_scenario
+
+    rng = np.random.default_rng(cfg["seed"])
+    R, E, steps, dt = cfg["R"], cfg["E"], cfg["steps"], cfg["dt"]
+    packed = synthetic.make_crowd(R, E, n_steps=steps, timestep=dt, side=cfg["side"], seed=cfg["seed"] % 1000)
+    nets, net_of = [], np.full(R, -1, np.int32)
+    if cfg["roads"]:
+        for n in range(2):
+            rings, layers = [], []
+            for q in range(int(rng.integers(2, 7))):
+                c = rng.uniform(-cfg["side"], cfg["side"], 2)
+                m = int(rng.integers(3, 9))
+                ang = np.sort(rng.uniform(0, 2 * np.pi, m))
+                rad = rng.uniform(0.8, 0.35 * cfg["side"] + 1.0)
+                rings.append(c + rad * np.stack([np.cos(ang), np.sin(ang)], 1))
+                layers.append(int(rng.choice([16 | 128, 16 | 128, 16 | 32])))  # building (walkable + impenetrable) or pavement
+            nets.append(dict(ring_off=np.arange(len(rings) + 1), vert_off=np.concatenate([[0], np.cumsum([len(r) for r in rings])]),
+                             verts=np.concatenate(rings), layers=np.array(layers)))
+        net_of = rng.integers(-1, 2, R).astype(np.int32)
+    eng = sga.RolloutEngine(R, E, timestep=dt, record_capacity=steps + 1, event_capacity=512)
+    eng.upload(packed)
+    if nets:
+        eng.set_road_networks(nets, net_of)
+    eng.rollout(steps)
+    st = eng.state()
+    rows, events = eng.metrics()
+    t, poses = eng.record(steps + 1)
+    eng.close()
+    for r in range(R):
+        s = unpack_scenario(packed, r)
+        road = nets[net_of[r]] if (nets and net_of[r] >= 0) else None
+        o = oracle.rollout(s["knot_off"], s["knots"], s["bbox"], s["etype"], s["kind"], s["ego"], s["t0"], s["length"], dt,
+                           ctrl=s["ctrl"], route_off=s["route_off"], routes=s["routes"], max_steps=steps, event_cap=512, road=road)
+        n = o["n_steps"]
+        assert rows["n_steps"][r] == n, r
+        assert bits_equal(poses[: n + 1, r], o["poses"]), (r, "poses")
+        assert bits_equal(st["force"][r], o["extra"][-1, :, 2:]) and bits_equal(st["dists"][r], o["dists"][-1]), r
+        assert np.array_equal(_dense_words(st["coll"][r], E), oracle.coll_to_dense(o["coll"], E)[-1]), r
+        ev = events[events["scenario"] == r]
+        m = min(len(ev), 512)
+        assert rows["n_collisions"][r] == o["n_events"] and np.array_equal(ev["t"][:m], o["ev_t"][:m]), r

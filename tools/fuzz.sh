@@ -6,3 +6,7 @@ seeds=${@:-"7 8 9"}
 for s in $seeds; do
   SG_FUZZ_N=$n SG_FUZZ_SEED=$s python -m pytest tests/test_gpu_parity.py -q -x -k randomized_configurations 2>&1 | tail -2
 done
+# the social-force crowds (balanced pair loop, boundary terms), same idea
+for s in $seeds; do
+  SG_FUZZ_CROWDS=$n SG_FUZZ_SEED=$s python -m pytest tests/test_gpu_parity.py -q -x -k randomized_crowds 2>&1 | tail -2
+done
