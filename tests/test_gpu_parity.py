@@ -1567,3 +1567,43 @@ def test_randomized_crowds_match_oracle(sga, oracle, cfg):
         ev = events[events["scenario"] == r]
         m = min(len(ev), 512)
         assert rows["n_collisions"][r] == o["n_events"] and np.array_equal(ev["t"][:m], o["ev_t"][:m]), r
+
+
+@pytest.mark.parametrize("cfg", _random_configs(int(os.environ.get("SG_FUZZ_RSS", "12")), int(os.environ.get("SG_FUZZ_SEED", "2024")) + 1),
+                         ids=lambda c: f"E{c['E']}-{c['ego']}-{'p' if c['persist'] else 'n'}-{len(c['terminal'])}{c['terminal'][-1][0]}")
+def test_randomized_rss_matches_oracle(sga, oracle, cfg):
+    """The RSS callback inside the rollout kernel over the configuration space of the randomized sweep (tile widths, persist,
+    terminal conditions that end scenarios early, ego kinds, time steps): records of the latest update, safe distances and
+    metric flags equal the oracle's callback run along the oracle's rollout."""
+    import scenario_gym_amd._lib as L
+    from scenario_gym_amd import synthetic
+    from scenario_gym_amd.engine import TERMINAL_BITS
+
+    kind = dict(replay=L.KIND_AGENT_REPLAY, pid=L.KIND_AGENT_PID, vehicle=L.KIND_AGENT_VEHICLE)[cfg["ego"]]
+    R, E, steps, dt = cfg["R"], cfg["E"], cfg["steps"], cfg["dt"]
+    packed = synthetic.make_batch(R, E, n_steps=steps, timestep=dt, n_knots=cfg["knots"], ego_kind=kind,
+                                  static_frac=cfg["static"], vanish_frac=cfg["vanish"], extent=cfg["extent"], seed=cfg["seed"])
+    force = cfg["ego"] == "vehicle"
+    acts = synthetic.make_actions(steps, R, seed=cfg["seed"]) if force else None
+    eng = sga.RolloutEngine(R, E, timestep=dt, persist=cfg["persist"], terminal_conditions=cfg["terminal"])
+    eng.set_rss(True)
+    eng.upload(packed)
+    if force:
+        eng.step(steps, acts)
+    else:
+        eng.rollout(steps)
+    slong, slat, codes, safe = eng.rss()
+    n_steps = eng.state()["n_steps"]
+    eng.close()
+    mask = sum(TERMINAL_BITS[c] for c in cfg["terminal"])
+    for r in range(R):
+        kw = dict(actions=acts[:, r], force_steps=True) if force else {}
+        o = _oracle_one(oracle, packed, r, dt, steps, persist=cfg["persist"], terminal_mask=mask, event_cap=64, **kw)
+        from scenario_gym_amd.packing import unpack_scenario
+        s = unpack_scenario(packed, r)
+        w = oracle.rss_rollout(o, s["bbox"], s["ego"])
+        n = len(s["bbox"])
+        assert n_steps[r] == o["n_steps"], r
+        assert np.array_equal(codes[r, :n], w["code"][-1]), (r, codes[r, :n], w["code"][-1])
+        assert np.array_equal(safe[r, :n], w["safe"][-1], equal_nan=True), r
+        assert slong[r] == w["safe_longitudinal"] and slat[r] == w["safe_lateral"], r

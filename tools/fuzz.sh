@@ -10,3 +10,7 @@ done
 for s in $seeds; do
   SG_FUZZ_CROWDS=$n SG_FUZZ_SEED=$s python -m pytest tests/test_gpu_parity.py -q -x -k randomized_crowds 2>&1 | tail -2
 done
+# the RSS callback inside the rollout kernel
+for s in $seeds; do
+  SG_FUZZ_RSS=$n SG_FUZZ_SEED=$s python -m pytest tests/test_gpu_parity.py -q -x -k randomized_rss 2>&1 | tail -2
+done
