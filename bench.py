@@ -94,8 +94,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--scenarios", type=int, default=4096, help="scenarios per GPU")
-    ap.add_argument("--entities", type=int, default=64)
+    ap.add_argument("--scenarios", type=int, default=None, help="scenarios per GPU (default: the workload's own, 4096 for c3)")
+    ap.add_argument("--entities", type=int, default=None)
     ap.add_argument("--sim-steps", type=int, default=10000)
     ap.add_argument("--ego", default="pid", choices=["pid", "replay"])
     ap.add_argument("--workload", default="c3", choices=["c3", "c2", "c5"],
@@ -117,10 +117,11 @@ def main():
 
     from scenario_gym_amd import distributed as D
 
+    shape = {"c2": (256, 16), "c3": (4096, 64), "c5": (1024, 256)}[args.workload]  # BASELINE.json configs
+    args.scenarios = args.scenarios or shape[0]  # (explicit --scenarios / --entities: size sweeps of the same family)
+    args.entities = args.entities or shape[1]
     if args.workload == "c2":
-        args.scenarios, args.entities, args.ego = 256, 16, "replay"
-    elif args.workload == "c5":
-        args.scenarios, args.entities = 1024, 256
+        args.ego = "replay"
     rank, world, local_rank, dist = D.init()
     if args.gpus != world and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)

@@ -109,7 +109,25 @@ struct Params {
     const RoadIndex *road;   // device copy of the road index, nullptr = no road networks set
     int ped_serial;          // 1: pedestrian pair loop one pedestrian per lane (env SG_PED_SERIAL; default 0: balanced over the wavefront)
     int tab_steps;           // steps per table chunk (rows per lane = tab_steps + 1: the prefetch of the last step reads one row ahead)
+#ifdef SG_PHASE_TIMERS
+    unsigned long long *phase_cycles; // [16] experiment builds: s_memtime cycles per phase of the step, summed over wavefronts
+#endif
 };
+
+// Experiment builds (-DSG_PHASE_TIMERS, tools/ab_build.sh): where do the cycles of a step go?  PH(i) closes phase i: the
+// cycles since the previous mark are added to counter i (wave-uniform scalar work); flushed once at the end of the kernel.
+#ifdef SG_PHASE_TIMERS
+struct PhaseTimers {
+    unsigned long long acc[16], last;
+    __device__ __forceinline__ void start() { for (int i = 0; i < 16; ++i) acc[i] = 0; last = __builtin_amdgcn_s_memtime(); }
+    __device__ __forceinline__ void mark(int i) { const unsigned long long now = __builtin_amdgcn_s_memtime(); acc[i] += now - last; last = now; }
+    __device__ __forceinline__ void flush(unsigned long long *out) { if ((threadIdx.x & 63) == 0) for (int i = 0; i < 16; ++i) if (acc[i]) atomicAdd(out + i, acc[i]); }
+};
+#define PH(i) ptm.mark(i)
+#else
+struct PhaseTimers {};
+#define PH(i) ((void)0)
+#endif
 
 // controller table written by control_kernel, read by rollout_kernel<.., TAB = true>.  Two planes of
 // [n_ctl_pad][tab_steps + 1][4] doubles (the steps of one lane are contiguous: 32 B per step, so the scalar loads of
@@ -472,7 +490,7 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 
 // Workgroup-shared tile data.  NS = slots of the tile set a workgroup owns: 64 when one wavefront
 // carries 64/G scenarios (WV = 1), 64*WV when WV wavefronts carry one scenario of up to 64*WV entities.
-template <int NS, bool PED>
+template <int NS, bool PED, bool CROWD = false>
 struct TileLds {
     // ---- collision scratch: rewritten by every tile_collisions call and dead once it returns (its last reads sit
     // before its last workgroup barrier).  Contiguous, in this order: the pedestrian pair balancer (ped_pairs_balanced)
@@ -488,6 +506,7 @@ struct TileLds {
     // ---- end of the collision scratch ----
     float2 half[NS];        // half length, half width (static)
     int last[NS];
+    int vote[4][4];         // block_vote: one row per vote site, one word per wavefront
     // controller parameters of every slot, copied once per launch: the 9 vehicle / PID rows, or -- in pedestrian
     // scenes -- the 4 pedestrian rows SG_C_PED_* (index q - SG_C_PED_SPEED_DESIRED)
     double ctrl[PED ? 4 : 9][NS];
@@ -498,6 +517,13 @@ struct TileLds {
     // unit velocity o = v / (|v| + 1e-10) and step = (|v| + 1e-10) * (next_t - t)
     double ox[PED ? NS : 1], oy[PED ? NS : 1], stp[PED ? NS : 1];
     unsigned char isped[PED ? NS : 1]; // entity.type == "Pedestrian" and present
+    // all-pedestrian scenes (rollout_kernel_crowd): more per-NEIGHBOUR products hoisted out of the pair (stp * o, stp * stp),
+    // the thresholds of the radius rule of every pedestrian (r*r*(1 + 1e-9), r*r*0.9975: sg_in_radius) and, per lane, the
+    // non-empty 32-bit words of its neighbour candidate row (crowd_pairs walks them as a queue), word-major: the bank of
+    // an access depends on the lane only
+    double sx[CROWD ? NS : 1], sy[CROWD ? NS : 1], ss[CROWD ? NS : 1];
+    double r2hi[CROWD ? NS : 1], r2lo[CROWD ? NS : 1];
+    uint32_t nq[CROWD ? 8 : 1][CROWD ? NS : 1];
 
     static constexpr int SLOTS = NS;
     static constexpr int SCRATCH_BYTES = NS * 40 + 64 * (NS > 64 ? NS : 2); // cx ... cor
@@ -1009,6 +1035,23 @@ __device__ __forceinline__ bool block_any(bool x)
     return __syncthreads_or(x);
 }
 
+// OR of a two-bit value over the workgroup with ONE barrier (__syncthreads_or is three barriers and an LDS atomic): every
+// wavefront leaves its own OR in its word of the site's row, the barrier publishes the row, everybody reads it.  A row is
+// rewritten only by the next use of the same site, and every wavefront has read the row before it reaches any later
+// barrier -- callers keep at least one barrier between two uses of a site (tile_collisions opens with one).
+template <int WV, typename LDS>
+__device__ __forceinline__ int block_vote(LDS &L, int site, bool b0, bool b1 = false)
+{
+    const int mine = (__any(b0) ? 1 : 0) | (__any(b1) ? 2 : 0);
+    if (WV == 1) return mine;
+    if ((threadIdx.x & 63) == 0) L.vote[site][threadIdx.x >> 6] = mine;
+    __syncthreads();
+    int r = 0;
+#pragma unroll
+    for (int w = 0; w < WV; ++w) r |= L.vote[site][w];
+    return r;
+}
+
 // One (pedestrian, neighbour) pair: the PedestrianSensor filter (pedestrians only, inside the radius, sensor.py:55-64)
 // and the neighbour's two force terms.  (ipx, ipy, irad, hs, hc) describe the pedestrian the force acts on, j is the
 // neighbour's LDS slot.  A candidate that fails the filter still runs through the arithmetic (its lane would idle
@@ -1170,15 +1213,294 @@ __device__ __forceinline__ void ped_pairs_balanced(const Params &p, LDS &L, int 
     tile_sync<1>(); // the collision pass that follows rewrites the scratch
 }
 
+// ------------------------------------------------------------------------------------------------
+// All-pedestrian scenes (rollout_kernel_crowd, BASELINE config 5).
+//
+// crowd_pair is ped_pair<true, true> (default head rotation, no attraction, sight weights on: the reference's defaults)
+// with FastArith's operation sequence -- bit for bit -- but (i) the products that depend on the neighbour alone
+// (stp * o, stp * stp) are read from LDS, computed once by the neighbour itself, and (ii) FastArith's operand range checks
+// are replaced by GUARDS that are established once per step for the whole tile (crowd_sane, voted in tile_collisions) and
+// once per launch for the parameters (crowd_params_ok), plus four exponent compares per pair.  Why that suffices, for a pair
+// that is ACTIVE (inside the radius rule, so |r| <= radius * (1 + 1e-9) < 2^21); inactive pairs are masked, garbage is fine:
+//   guards: every coordinate and every product stp * o of a present pedestrian is 0 or has magnitude in [2^-800, 2^400)
+//           (coordinates) / [2^-800, 2^20) (products); radius < 2^20; sigma, |cos_sight| in [2^-100, 2^100] (cos_sight may be
+//           0); V / sigma <= 2^100.  So rx, ry, qx, qy are 0 or multiples of 2^-852 of magnitude < 2^22: safe numerators of
+//           RecipDiv (zero, or |a| in [2^-959, 2^961)).
+//   checks: the arguments of the first three square roots are >= 2^-100 (else `bad`): then rn >= 2^-50, qn >= 1e-10,
+//           b >= 2^-51 are safe denominators, 1 / b <= 2^51, k1 <= 2^72, |rep| <= 2^173, every sqrt argument is inside
+//           [2^-700, 2^1000) where the bare rsq + Goldschmidt core equals the compiler's sqrt (FastArith::sqrt); the argument
+//           of the fourth (|rep|^2) is checked against 2^-700.  exp: x = -b / sigma is in [-2^122, -2^-151]; its internal
+//           quotient r*c / (2 - c) has 2 - c in (1.6, 2.4) and r*c = 0 or |r*c| >= 2^-302 (k = 0: r = x; k != 0: r is a
+//           multiple of 2^-85) -- safe; x < -745.2 returns 0 before the quotient matters.  The sight-weight comparison keeps
+//           FastArith's sliver test (`bad` when the quotient is within 8 ulps of cos_sight).
+// A `bad` pair is recomputed with plain IEEE divisions (ped_pair<.., ExactArith>) under one wave-uniform branch.
+// ------------------------------------------------------------------------------------------------
+struct CrowdConsts {
+    double k2_scale, sig_b, sig_r; // V / sigma; RecipDiv(sigma)
+    double cos_sight, sight_weight, k3;
+};
+
+__device__ __forceinline__ double sg_sqrt_core(double x) // FastArith::sqrt without the range check
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = y * 0.5;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    double d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    d = __builtin_fma(-g, g, x);
+    return __builtin_fma(d, h, g);
+}
+
+__device__ __forceinline__ double crowd_exp(double x) // sg_exp for x < 0 finite (see the guards above)
+{
+    const double LN2HI = 6.93147180369123816490e-01, LN2LO = 1.90821492927058770002e-10,
+                 INVLN2 = 1.44269504088896338700e+00;
+    const double P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03,
+                 P3 = 6.61375632143793436117e-05, P4 = -1.65339022054652515390e-06,
+                 P5 = 4.13813679705723846039e-08;
+    const double k = __builtin_rint(x * INVLN2);
+    const double hi = x - k * LN2HI;
+    const double lo = k * LN2LO;
+    const double r = hi - lo;
+    const double t = r * r;
+    const double c = r - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))));
+    const RecipDiv rd(2.0 - c);
+    const double y = 1.0 - ((lo - rd.div(r * c)) - hi);
+    const double e = ldexp(y, (int)k);
+    return x < -745.13321910194110842 ? 0.0 : e;
+}
+
+__device__ __forceinline__ bool crowd_params_ok(const sg_social_force &sf)
+{
+    const double sg_ = sf.ped_repulse_sigma, ac = __builtin_fabs(sf.cos_sight), k2s = sf.ped_repulse_V / sf.ped_repulse_sigma;
+    return sg_ >= 0x1p-100 && sg_ <= 0x1p100 && (ac == 0.0 || (ac >= 0x1p-100 && ac <= 0x1p100)) &&
+           __builtin_fabs(k2s) <= 0x1p100 && sf.ped_attract_C == 0.0 && sf.sight_weight > 0.0 && sf.sight_weight_use != 0.0;
+}
+
+// the per-entity guard of crowd_pair: c = coordinate / product of a present pedestrian
+__device__ __forceinline__ bool crowd_sane(double v, double hi_bound)
+{
+    const double a = __builtin_fabs(v);
+    return (v == 0.0) | ((a >= 0x1p-800) & (a < hi_bound));
+}
+
+// (rx, ry) = owner - neighbour.  d2: the squared distance of the radius rule (sg_in_radius: dx*dx + dy*dy, and
+// (-a)*(-a) == a*a), sharing the product rx*rx with the first norm.
+__device__ __forceinline__ void crowd_pair(const CrowdConsts &C, double rx, double ry, double odx, double ody, double sx,
+                                           double sy, double ss, double &c1x, double &c1y, double &c2x, double &c2y,
+                                           double &d2, bool &bad)
+{
+    const double rxx = rx * rx;
+    d2 = rxx + ry * ry;
+    const double a_rn = __builtin_fma(ry, ry, rxx);
+    const double rn = sg_sqrt_core(a_rn);
+    const double qx = rx - sx, qy = ry - sy;
+    const double a_qn = __builtin_fma(qy, qy, qx * qx);
+    const double qn = sg_sqrt_core(a_qn) + 0.0000000001;
+    const double sum = rn + qn;
+    const double a_b = sum * sum - ss;
+    const double b = (1.0 / 2) * sg_sqrt_core(a_b);
+    const RecipDiv rb(b);
+    const double k1 = (1.0 / 4) * rb.div(1.0) * sum;
+    const RecipDiv rrn(rn), rqn(qn);
+    const double rxn = rrn.div(rx), ryn = rrn.div(ry), qxn = rqn.div(qx), qyn = rqn.div(qy);
+    const double dbx = k1 * (rxn + qxn), dby = k1 * (ryn + qyn);
+    RecipDiv rsig(1.0);
+    rsig.b = C.sig_b;
+    rsig.r = C.sig_r;
+    const double k2 = C.k2_scale * crowd_exp(rsig.div(-b));
+    const double repx = k2 * dbx, repy = k2 * dby;
+    c2x = C.k3 * rx; // the attraction with C == 0: a signed zero
+    c2y = C.k3 * ry;
+    const double a_rep = __builtin_fma(repy, repy, repx * repx);
+    const double m = sg_sqrt_core(a_rep) + 0.0000000001;
+    const double a = __builtin_fma(ody, repy, odx * repx);
+    const double cm = C.cos_sight * m, slack = __builtin_fabs(cm) * 0x1p-50;
+    const bool yes = a >= cm + slack, no = a <= cm - slack;
+    const double w1 = yes ? 1.0 : C.sight_weight;
+    c1x = w1 * repx;
+    c1y = w1 * repy;
+    const int h123 = min(min(__double2hiint(a_rn), __double2hiint(a_qn)), __double2hiint(a_b));
+    bad = !((h123 >= 0x39B00000) & (__double2hiint(a_rep) >= 0x14300000) & (yes | no)); // 2^-100, 2^-700
+}
+
+#ifndef SG_CROWD_ILP
+#define SG_CROWD_ILP 2 // (pedestrian, neighbour) pairs a lane evaluates side by side: independent fp64 dependency chains
+#endif
+
+// The neighbour sums of one wavefront of an all-pedestrian scene: ped_pairs_balanced's scheme (every lane works through
+// ceil(total / 64) pairs; a lane with more neighbours hands its LAST ones over through LDS, the owner adds the returned
+// terms after its own, in entity order: bit-identical to the serial loop) with
+//   - the candidate row walked as a queue of its non-empty 32-bit words in LDS (one ffbl + one conditional refill per
+//     neighbour instead of a scan over the row's 2 * WV words),
+//   - SG_CROWD_ILP pairs per loop round (the pair is one chain of dependent fp64 operations; at two wavefronts per SIMD one
+//     chain per wavefront leaves a third of the issue slots empty),
+//   - crowd_pair for the arithmetic.
+// Wave-collective; LDS traffic stays inside the wavefront's own slice of the (idle) collision scratch + its own nq columns.
+template <int WV, typename LDS>
+__device__ __forceinline__ void crowd_pairs(const Params &p, LDS &L, const CrowdConsts &C, int sl, const uint64_t (&nbr)[WV],
+                                            bool go, double k2_scale, double ipx, double ipy, double &fx, double &fy)
+{
+    constexpr int CAP = LDS::PAIR_CAP, ND = 2 * WV;
+    const int lane = threadIdx.x & 63;
+    uint32_t *list = reinterpret_cast<uint32_t *>(L.wave_scratch(WV == 1 ? 0 : (int)(threadIdx.x >> 6)));
+    double2 *res = reinterpret_cast<double2 *>(list + CAP);
+    // ---- the queue: non-empty words of the row, in order; idxs = their word numbers, 3 bits each ----
+    int n = 0, nw = 0;
+    uint32_t idxs = 0;
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+        const uint32_t d = go ? (uint32_t)(nbr[i >> 1] >> ((i & 1) * 32)) : 0u;
+        if (d) {
+            L.nq[nw & 7][sl] = d;
+            idxs |= (uint32_t)i << (3 * nw);
+            ++nw;
+        }
+        n += __builtin_popcount(d);
+    }
+    int total = n;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) total += __shfl_xor(total, o, 64);
+    if (total == 0) return; // wave-uniform
+    const int T = (total + 63) >> 6;
+    const int excess = max(n - T, 0), spare = max(T - n, 0);
+    int scan = excess | (spare << 16); // both prefix sums at once (each < 2^15)
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int u = __shfl_up(scan, o, 64);
+        if (lane >= o) scan += u;
+    }
+    const int listed_all = min(__shfl(scan, 63, 64) & 0xffff, CAP);
+    const int e0 = (scan & 0xffff) - excess;              // first list position of this lane's hand-over
+    const int out = min(max(CAP - e0, 0), excess);        // pairs handed over (all of the excess unless the list is full)
+    int h = min((scan >> 16) - spare, listed_all);        // listed pairs this lane evaluates: [h, h_end)
+    const int h_end = min((scan >> 16), listed_all);
+    const int keep = n - out;
+    tile_sync<1>(); // own nq column written above
+    // ---- hand over the LAST `out` neighbours: walk the queue from its top, write them in entity order ----
+    if (__any(out > 0)) {
+        int qe = nw - 1;
+        uint32_t curh = L.nq[max(qe, 0)][sl];
+        for (int q = 0; __any(q < out); ++q) {
+            if (q < out) {
+                const int bit = 31 - __builtin_clz(curh);
+                const int j = (int)((idxs >> (3 * qe)) & 7u) * 32 + bit;
+                list[e0 + out - 1 - q] = (uint32_t)j | ((uint32_t)lane << 8);
+                curh &= ~(1u << bit);
+                if (curh == 0) {
+                    qe = max(qe - 1, 0);
+                    curh = L.nq[qe][sl];
+                }
+            }
+        }
+    }
+    tile_sync<1>();
+    const int wave_sl = sl - lane; // LDS slot of lane 0
+    // ---- own pairs first (in order), then listed pairs for other lanes ----
+    int k = 0, qi = 0;
+    uint32_t cur = L.nq[0][sl];
+    const double own_r2hi = L.r2hi[sl], own_r2lo = L.r2lo[sl];
+    while (__any((k < keep) | (h < h_end))) {
+        bool own[SG_CROWD_ILP], help[SG_CROWD_ILP], act[SG_CROWD_ILP], bad[SG_CROWD_ILP], ring[SG_CROWD_ILP];
+        int jj[SG_CROWD_ILP], osl[SG_CROWD_ILP], hi_[SG_CROWD_ILP];
+        uint32_t ent[SG_CROWD_ILP];
+        double c1x[SG_CROWD_ILP], c1y[SG_CROWD_ILP], c2x[SG_CROWD_ILP], c2y[SG_CROWD_ILP];
+#pragma unroll
+        for (int u = 0; u < SG_CROWD_ILP; ++u) {
+            own[u] = k < keep;
+            help[u] = !own[u] & (h < h_end);
+            // next own neighbour: lowest bit of the current word; an emptied word is replaced by the next of the queue
+            const int bit = __builtin_ctz(cur | 0x80000000u);
+            const int jo = (int)((idxs >> (3 * qi)) & 7u) * 32 + bit;
+            const uint32_t nxt = L.nq[min(qi + 1, 7)][sl];
+            const uint32_t rest = cur & (cur - 1);
+            const bool adv = own[u] & (rest == 0);
+            cur = own[u] ? (adv ? nxt : rest) : cur;
+            qi += adv;
+            k += own[u];
+            hi_[u] = min(h, CAP - 1);
+            ent[u] = list[hi_[u]];
+            h += help[u];
+            jj[u] = own[u] ? jo : (int)(ent[u] & (LDS::SLOTS - 1));
+            osl[u] = own[u] ? sl : wave_sl + (int)((ent[u] >> 8) & 63);
+        }
+#pragma unroll
+        for (int u = 0; u < SG_CROWD_ILP; ++u) {
+            const int j = jj[u], o = osl[u];
+            const double rx = L.px[o] - L.px[j], ry = L.py[o] - L.py[j];
+            double d2;
+            crowd_pair(C, rx, ry, L.ox[j], L.oy[j], L.sx[j], L.sy[j], L.ss[j], c1x[u], c1y[u], c2x[u], c2y[u], d2, bad[u]);
+            const bool valid = own[u] | help[u];
+            const bool outside = d2 > L.r2hi[o], inside = d2 < L.r2lo[o];
+            ring[u] = valid & !(outside | inside);
+            act[u] = valid & inside;
+        }
+        bool any_ring = false, any_bad = false;
+#pragma unroll
+        for (int u = 0; u < SG_CROWD_ILP; ++u) any_ring |= ring[u];
+        if (__any(any_ring)) { // rare: between the inscribed circle and the vertices of the 64-gon Point.buffer(r)
+#pragma unroll
+            for (int u = 0; u < SG_CROWD_ILP; ++u)
+                if (ring[u])
+                    act[u] = sg_in_radius(L.px[osl[u]], L.py[osl[u]], L.ctrl[SG_C_PED_RADIUS - SG_C_PED_SPEED_DESIRED][osl[u]],
+                                          L.px[jj[u]], L.py[jj[u]], p.gon);
+        }
+#pragma unroll
+        for (int u = 0; u < SG_CROWD_ILP; ++u) any_bad |= bad[u] & act[u];
+        if (__any(any_bad)) { // rare: an operand outside crowd_pair's range, or a sight weight on its threshold
+#pragma unroll
+            for (int u = 0; u < SG_CROWD_ILP; ++u)
+                if (bad[u] & act[u]) {
+                    ExactArith EA;
+                    const int j = jj[u], o = osl[u];
+                    ped_pair<false, false>(EA, p.sf, k2_scale, L.px[o], L.py[o], 0.0, 1.0, L.px[j], L.py[j], L.vx[j], L.vy[j], L.ox[j],
+                                           L.oy[j], L.stp[j], c1x[u], c1y[u], c2x[u], c2y[u]);
+                }
+        }
+#pragma unroll
+        for (int u = 0; u < SG_CROWD_ILP; ++u) {
+            if (own[u] & act[u]) { // SocialForce._step :64-84 with sight weights: repulsion, then attraction
+                fx += c1x[u]; fy += c1y[u];
+                fx += c2x[u]; fy += c2y[u];
+            }
+            if (help[u]) {
+                res[hi_[u]] = make_double2(c1x[u], c1y[u]);
+                list[hi_[u]] = ent[u] | (act[u] ? 0u : 1u << 16) | (__builtin_signbit(c2x[u]) ? 1u << 17 : 0u) |
+                               (__builtin_signbit(c2y[u]) ? 1u << 18 : 0u);
+            }
+        }
+    }
+    (void)own_r2hi; (void)own_r2lo; (void)ipx; (void)ipy;
+    tile_sync<1>();
+    for (int q = 0; __any(q < out); ++q) {
+        if (q < out) {
+            const uint32_t e = list[e0 + q];
+            const double2 c1 = res[e0 + q];
+            if (!(e & (1u << 16))) {
+                fx += c1.x; fy += c1.y;
+                fx += (e & (1u << 17)) ? -0.0 : 0.0; fy += (e & (1u << 18)) ? -0.0 : 0.0;
+            }
+        }
+    }
+    tile_sync<1>(); // the collision pass that follows rewrites the scratch
+}
+
 // PedestrianAgent.step, part 1: SocialForce._step (pedestrian/social_force.py:44-222, boundary terms off) over the
 // neighbour candidates `nbr` of the tile.  All inputs are the CURRENT state (LDS px/py/vx/vy).  Wave-collective (every
 // lane calls it; `stepping` = this lane is a present pedestrian agent of a running scenario); go = goal not reached yet.
-template <int WV, typename LDS>
+template <int WV, bool CROWD = false, typename LDS>
 __device__ __forceinline__ void ped_force(const Params &p, LDS &L, int r, int sl, int tile0, const uint64_t (&nbr)[WV],
                                           bool stepping, const double *pose, double velx, double vely, const double *wp,
                                           int nwp, int &goal_idx, bool &go, double &fx, double &fy, double &vdes,
-                                          ConstTbl K)
+                                          ConstTbl K, bool crowd_fast = false, const CrowdConsts &CC = CrowdConsts{},
+                                          PhaseTimers *ptp = nullptr)
 {
+#ifdef SG_PHASE_TIMERS
+    PhaseTimers ptm_dummy;
+    PhaseTimers &ptm = ptp ? *ptp : ptm_dummy;
+#endif
     const sg_social_force &sf = p.sf;
     go = false;
     fx = fy = 0.0;
@@ -1195,22 +1517,33 @@ __device__ __forceinline__ void ped_force(const Params &p, LDS &L, int r, int sl
             const double inv_tau = 1 / sf.relaxation_time;
             fx = inv_tau * (vdes * (gx / gn) - velx);
             fy = inv_tau * (vdes * (gy / gn) - vely);
-            sg_sincos(L.ctrl[SG_C_PED_HEAD_ROT - SG_C_PED_SPEED_DESIRED][sl], hs, hc, K);
+            if (!CROWD) sg_sincos(L.ctrl[SG_C_PED_HEAD_ROT - SG_C_PED_SPEED_DESIRED][sl], hs, hc, K);
             radius = L.ctrl[SG_C_PED_RADIUS - SG_C_PED_SPEED_DESIRED][sl];
         }
     }
     const double k2_scale = sf.ped_repulse_V / sf.ped_repulse_sigma;
+    if (CROWD) {
+        if (crowd_fast) { // wave-uniform: the guards of crowd_pair hold
+            PH(0);
+#ifndef SG_ABL_NO_PAIRS
+            crowd_pairs<WV>(p, L, CC, sl, nbr, go, k2_scale, pose[0], pose[1], fx, fy);
+#endif
+            PH(6);
+            return; // (no road network in a crowd launch: no boundary terms)
+        }
+        if (go) sg_sincos(L.ctrl[SG_C_PED_HEAD_ROT - SG_C_PED_SPEED_DESIRED][sl], hs, hc, K);
+    }
     // the shortcuts of ped_pair need the sight-weight branch (c2 = w2 * att) and hold for the whole wavefront
     const bool plain = __all(hs == 0.0 && hc == 1.0) && sf.ped_attract_C == 0.0 && sf.sight_weight > 0.0 &&
                        sf.sight_weight_use != 0.0;
 #ifdef SG_ABL_NO_PAIRS
     return;
 #endif
-    if (plain && !p.ped_serial)
+    if (!CROWD && plain && !p.ped_serial)
         ped_pairs_balanced<WV>(p, L, sl, tile0, nbr, go, k2_scale, pose[0], pose[1], radius, fx, fy);
-    else
+    else // (CROWD: the guards of crowd_pair do not hold, or SG_PED_SERIAL: the plain serial loop)
         ped_pairs_serial<WV>(p, L, tile0, nbr, go, plain, k2_scale, pose[0], pose[1], radius, hs, hc, fx, fy);
-    if (go) ped_boundary_terms(p, r, pose[0], pose[1], fx, fy); // after the neighbours, social_force.py:83-104
+    if (!CROWD && go) ped_boundary_terms(p, r, pose[0], pose[1], fx, fy); // after the neighbours, social_force.py:83-104
 }
 
 // PedestrianAgent.step, part 2 (one lane): speed and heading from the force (:110-114, or zero at the goal,
@@ -1255,14 +1588,20 @@ __device__ __forceinline__ void ped_move(const Params &p, bool go, double fx, do
 // With WV > 1 the tile spans WV wavefronts of one workgroup; only the decisions that gate LDS
 // writes are workgroup-uniform (block_any), the candidate loops run per wavefront.
 // ------------------------------------------------------------------------------------------------
-template <int G, int WV, bool PED, typename LDS>
+template <int G, int WV, bool PED, bool CROWD = false, typename LDS>
 __device__ __forceinline__ void tile_collisions(bool present, const double *pose, double velx, double vely,
                                                 double dtn /* next_t - t of the coming step (PED) */,
                                                 double bcx, double bcy, float rad_thr, float trig_eps,
                                                 float nbr_thr, float cell_inv, bool is_ped_type, int sl, int tile0, LDS &L,
                                                 uint64_t (&rows_out)[WV], uint64_t (&mult_rows)[WV],
-                                                uint64_t (&nbr_out)[WV], bool &dense)
+                                                uint64_t (&nbr_out)[WV], bool &dense /* in: this lane's wish from the previous call,
+                                                out: its wish for the next one; see all_pairs */, bool *crowd_ok = nullptr,
+                                                PhaseTimers *ptp = nullptr)
 {
+#ifdef SG_PHASE_TIMERS
+    PhaseTimers ptm_dummy;
+    PhaseTimers &ptm = ptp ? *ptp : ptm_dummy;
+#endif
     constexpr int TS = G * WV; // tile slots
     const int slot = sl - tile0;
     const double x = pose[0], y = pose[1];
@@ -1285,20 +1624,33 @@ __device__ __forceinline__ void tile_collisions(bool present, const double *pose
     const float ax = fx * cell_inv, ay = fy * cell_inv;
     const int ix = present ? (int)__builtin_floorf(ax) : 0, iy = present ? (int)__builtin_floorf(ay) : 0;
     const bool far_out = present && !(__builtin_fabsf(ax) < 4000.0f && __builtin_fabsf(ay) < 4000.0f);
-    tile_sync<WV>();
+    PH(8); tile_sync<WV>(); PH(11);
     L.cx[sl] = fx;
     L.cy[sl] = fy;
     L.cen[sl] = make_float2(fx, fy);
     L.sc[sl] = make_float2(fs, fc);
     reinterpret_cast<unsigned long long *>(L.xtab)[sl] = 0ull;
     reinterpret_cast<unsigned long long *>(L.ytab)[sl] = 0ull;
+    bool insane = false; // CROWD: this lane breaks a guard of crowd_pair
     if (PED) {
-        L.px[sl] = x; L.py[sl] = y; L.vx[sl] = velx; L.vy[sl] = vely;
+        // (CROWD: an absent slot can reach a candidate row through the all-pairs walk, whose masks do not know the presence
+        // of other wavefronts' slots; crowd_pairs has no isped test, a NaN position fails its radius rule)
+        L.px[sl] = (!CROWD || present) ? x : __builtin_nan("");
+        L.py[sl] = y; L.vx[sl] = velx; L.vy[sl] = vely;
         L.isped[sl] = present && is_ped_type;
         const double vmag = sg_norm2(velx, vely) + 0.0000000001; // social_force.py:148-155, once per neighbour
-        L.ox[sl] = velx / vmag;
-        L.oy[sl] = vely / vmag;
-        L.stp[sl] = vmag * dtn;
+        const double uox = velx / vmag, uoy = vely / vmag, stp = vmag * dtn;
+        L.ox[sl] = uox;
+        L.oy[sl] = uoy;
+        L.stp[sl] = stp;
+        if (CROWD) { // the neighbour's products of ped_pair, once per neighbour: step * odx, step * ody, step * step
+            const double sx = stp * uox, sy = stp * uoy;
+            L.sx[sl] = sx;
+            L.sy[sl] = sy;
+            L.ss[sl] = stp * stp;
+            insane = present & !(crowd_sane(x, 0x1p400) & crowd_sane(y, 0x1p400) & crowd_sane(sx, 0x1p20) & crowd_sane(sy, 0x1p20) &
+                                 (stp < 0x1p20));
+        }
     }
     uint64_t cand[WV];
     bool any_cand = false;
@@ -1308,7 +1660,21 @@ __device__ __forceinline__ void tile_collisions(bool present, const double *pose
     // whole tile a cell neighbour, and the all-pairs walk below (fixed cost, packed fp32, 4 slots per LDS read) is then
     // cheaper than one circle test per candidate.  Either way the result is a conservative candidate set that the same
     // exact tests refine, so the switch cannot change any output.
-    const bool all_pairs = block_any<WV>(far_out) || (PED && dense);
+    // (CROWD: the same vote also carries the guards of crowd_pair: a scene beyond 4000 cells is no crowd to be fast on;
+    // PED: and the broad-phase strategy, which some lane asked for at the end of the previous call)
+    PH(2);
+    const int voted = block_vote<WV>(L, 0, far_out | insane, PED && dense);
+    const bool odd = voted & 1;
+    dense = (voted & 2) != 0;
+    PH(12);
+    if (CROWD) *crowd_ok = !odd;
+#if defined(SG_DENSE_NEVER)
+    const bool all_pairs = odd;
+#elif defined(SG_DENSE_ALWAYS)
+    const bool all_pairs = true;
+#else
+    const bool all_pairs = odd || (PED && dense);
+#endif
     if (!all_pairs) { // block_any / the barrier below also publish the LDS writes above
         // ---- stripe masks: O(tile) instead of O(tile^2) ----
         if (WV == 1) tile_sync<WV>();
@@ -1318,7 +1684,7 @@ __device__ __forceinline__ void tile_collisions(bool present, const double *pose
             atomicOr(&L.xtab[ix & 63][wsl], mybit);
             atomicOr(&L.ytab[iy & 63][wsl], mybit);
         }
-        tile_sync<WV>();
+        PH(2); tile_sync<WV>(); PH(13);
 #pragma unroll
         for (int w = 0; w < WV; ++w) {
             uint64_t mx = L.xtab[(ix - 1) & 63][w] | L.xtab[ix & 63][w] | L.xtab[(ix + 1) & 63][w];
@@ -1352,7 +1718,8 @@ __device__ __forceinline__ void tile_collisions(bool present, const double *pose
             cand[w] = close[w];
             any_cand = any_cand || cand[w] != 0;
         }
-        if (PED) dense = block_any<WV>(iters > (2 * TS) / 5); // ~ where 25 instructions per candidate overtake the walk
+        if (PED) dense = iters > (2 * TS) / 5; // ~ where 25 instructions per candidate overtake the walk (voted by the next call)
+        PH(9);
     } else {
     // ---- fallback for coordinates beyond 4000 cells: all pairs of the tile ----
     // lane i tests itself against slots j..j+3 per iteration (wave-uniform LDS broadcast reads, one
@@ -1372,36 +1739,55 @@ __device__ __forceinline__ void tile_collisions(bool present, const double *pose
         xs1 = *reinterpret_cast<const v4f *>(&L.cx[tile0 + TS - 8]);
         ys1 = *reinterpret_cast<const v4f *>(&L.cy[tile0 + TS - 8]);
     }
-#pragma unroll 4
-    for (int jb = TS - 4; jb >= 0; jb -= 4) {
-        v4f xs2 = xs1, ys2 = ys1; // two groups of four slots stay in flight
-        if (jb >= 8) {
-            xs2 = *reinterpret_cast<const v4f *>(&L.cx[tile0 + jb - 8]);
-            ys2 = *reinterpret_cast<const v4f *>(&L.cy[tile0 + jb - 8]);
+    // one 32-bit word of the row at a time, both loops unrolled: every index into out_w / nout_w is a constant (a dynamic
+    // index would put the two arrays into scratch memory, with a load and a store per group of four slots)
+    constexpr int NW32 = (TS + 31) / 32, PER = TS >= 32 ? 8 : TS / 4;
+#ifdef SG_ABL_WALK_TWICE // timing experiment: the cost of one walk = the difference to the normal build
+    for (int rep_ = 0; rep_ < 2; ++rep_) {
+    asm volatile("" : "+v"(xs), "+v"(ys), "+v"(xs1), "+v"(ys1));
+#endif
+#pragma unroll
+    for (int w2 = NW32 - 1; w2 >= 0; --w2) {
+        uint32_t w = 0u, v = 0u;
+#pragma unroll
+        for (int q = PER - 1; q >= 0; --q) {
+            const int jb = w2 * 32 + q * 4;
+            v4f xs2 = xs1, ys2 = ys1; // two groups of four slots stay in flight
+            if (jb >= 8) {
+                xs2 = *reinterpret_cast<const v4f *>(&L.cx[tile0 + jb - 8]);
+                ys2 = *reinterpret_cast<const v4f *>(&L.cy[tile0 + jb - 8]);
+            }
+            v2f dxa = v2f{xs.x, xs.y} - fx2, dya = v2f{ys.x, ys.y} - fy2;
+            v2f dxb = v2f{xs.z, xs.w} - fx2, dyb = v2f{ys.z, ys.w} - fy2;
+            v2f d2a = __builtin_elementwise_fma(dya, dya, dxa * dxa);
+            v2f d2b = __builtin_elementwise_fma(dyb, dyb, dxb * dxb);
+            v2f ma = thr2 - d2a, mb = thr2 - d2b;
+            w = __builtin_amdgcn_alignbit(w, __float_as_uint(mb.y), 31); // w = (w << 1) | sign
+            w = __builtin_amdgcn_alignbit(w, __float_as_uint(mb.x), 31);
+            w = __builtin_amdgcn_alignbit(w, __float_as_uint(ma.y), 31);
+            w = __builtin_amdgcn_alignbit(w, __float_as_uint(ma.x), 31);
+            if (PED) { // second reach: PedestrianSensor.distance_threshold
+                v2f na = nthr2 - d2a, nb = nthr2 - d2b;
+                v = __builtin_amdgcn_alignbit(v, __float_as_uint(nb.y), 31);
+                v = __builtin_amdgcn_alignbit(v, __float_as_uint(nb.x), 31);
+                v = __builtin_amdgcn_alignbit(v, __float_as_uint(na.y), 31);
+                v = __builtin_amdgcn_alignbit(v, __float_as_uint(na.x), 31);
+            }
+            xs = xs1; ys = ys1;
+            xs1 = xs2; ys1 = ys2;
         }
-        v2f dxa = v2f{xs.x, xs.y} - fx2, dya = v2f{ys.x, ys.y} - fy2;
-        v2f dxb = v2f{xs.z, xs.w} - fx2, dyb = v2f{ys.z, ys.w} - fy2;
-        v2f d2a = __builtin_elementwise_fma(dya, dya, dxa * dxa);
-        v2f d2b = __builtin_elementwise_fma(dyb, dyb, dxb * dxb);
-        v2f ma = thr2 - d2a, mb = thr2 - d2b;
-        uint32_t w = out_w[jb >> 5];
-        w = __builtin_amdgcn_alignbit(w, __float_as_uint(mb.y), 31); // w = (w << 1) | sign
-        w = __builtin_amdgcn_alignbit(w, __float_as_uint(mb.x), 31);
-        w = __builtin_amdgcn_alignbit(w, __float_as_uint(ma.y), 31);
-        w = __builtin_amdgcn_alignbit(w, __float_as_uint(ma.x), 31);
-        out_w[jb >> 5] = w;
-        if (PED) { // second reach: PedestrianSensor.distance_threshold
-            v2f na = nthr2 - d2a, nb = nthr2 - d2b;
-            uint32_t v = nout_w[jb >> 5];
-            v = __builtin_amdgcn_alignbit(v, __float_as_uint(nb.y), 31);
-            v = __builtin_amdgcn_alignbit(v, __float_as_uint(nb.x), 31);
-            v = __builtin_amdgcn_alignbit(v, __float_as_uint(na.y), 31);
-            v = __builtin_amdgcn_alignbit(v, __float_as_uint(na.x), 31);
-            nout_w[jb >> 5] = v;
-        }
-        xs = xs1; ys = ys1;
-        xs1 = xs2; ys1 = ys2;
+        out_w[w2] = w;
+        if (PED) nout_w[w2] = v;
     }
+#ifdef SG_ABL_WALK_TWICE
+    if (rep_ == 0) {
+        xs = *reinterpret_cast<const v4f *>(&L.cx[tile0 + TS - 4]);
+        ys = *reinterpret_cast<const v4f *>(&L.cy[tile0 + TS - 4]);
+        xs1 = *reinterpret_cast<const v4f *>(&L.cx[tile0 + TS - 8]);
+        ys1 = *reinterpret_cast<const v4f *>(&L.cy[tile0 + TS - 8]);
+    }
+    }
+#endif
     // absent slots hold NaN centres (sign bit unspecified): mask them with the tile's presence bits
 #pragma unroll
     for (int w = 0; w < WV; ++w) {
@@ -1428,7 +1814,8 @@ __device__ __forceinline__ void tile_collisions(bool present, const double *pose
         int cnt = 0;
 #pragma unroll
         for (int w = 0; w < WV; ++w) cnt += __builtin_popcountll(nbr_out[w]);
-        dense = block_any<WV>(cnt > TS / 12);
+        dense = cnt > TS / 12; // (a wish: voted by the next call)
+        PH(10);
     }
     }
 #ifdef SG_ABL_NO_NARROW
@@ -1436,6 +1823,7 @@ __device__ __forceinline__ void tile_collisions(bool present, const double *pose
     for (int w = 0; w < WV; ++w) rows_out[w] = cand[w];
     return;
 #endif
+    PH(2);
     // ---- filter: per wavefront, LDS reads only ----
     const float2 myh = L.half[sl];
     const float hl = myh.x, hw = myh.y;
@@ -1474,7 +1862,10 @@ __device__ __forceinline__ void tile_collisions(bool present, const double *pose
     }
 #pragma unroll
     for (int w = 0; w < WV; ++w) mult_rows[w] = rows_out[w];
-    if (!block_any<WV>(any_fuzzy)) return; // workgroup-uniform; the rest is the rare exact path
+    PH(3);
+    const bool any_fuzzy_wg = block_vote<WV>(L, 1, any_fuzzy) != 0;
+    PH(15);
+    if (!any_fuzzy_wg) return; // workgroup-uniform; the rest is the rare exact path
 
     double A[8];
     {
@@ -1515,7 +1906,7 @@ __device__ __forceinline__ void tile_collisions(bool present, const double *pose
         any_eq = any_eq || eq[w] != 0;
         mult_rows[w] = rows_out[w];
     }
-    if (block_any<WV>(any_eq)) { // geometry -> LAST entity owning it (state/utils.py:32-40)
+    if (block_vote<WV>(L, 2, any_eq)) { // geometry -> LAST entity owning it (state/utils.py:32-40)
         int last = slot;
 #pragma unroll
         for (int w = 0; w < WV; ++w)
@@ -1540,6 +1931,7 @@ __device__ __forceinline__ void tile_collisions(bool present, const double *pose
 #pragma unroll
         for (int w = 0; w < WV; ++w) rows_out[w] = nr[w];
     }
+    PH(4);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1781,14 +2173,17 @@ __device__ __forceinline__ Table lane_table(const Params &p, int kind, const Sce
 // ROAD: the ego_off_road terminal condition is compiled in (its own entry point, rollout_kernel_road: the other
 // variants keep their register budgets).
 // RSSV: the RSSDistances callback (rss_entity) runs after the reset and after every step inside the kernel.
-template <int G, int WV, bool PED, bool TAB, bool HAST, bool ROAD = false, bool RSSV = false>
+// CROWD (PED only): every entity of the batch is a pedestrian agent (or padding), default head rotation, no road network:
+// no knot segment, no vehicle / replay code, crowd_pairs for the neighbour sums (rollout_kernel_crowd, BASELINE config 5).
+template <int G, int WV, bool PED, bool TAB, bool HAST, bool ROAD = false, bool RSSV = false, bool CROWD = false>
 __device__ __forceinline__ void rollout_body(
     const Params &p, double timestep, int n_steps, int do_reset, int force, const double *actions /*[n][R][2]*/,
     const double *tab /*controller table planes*/)
 {
     static_assert(!(PED && TAB), "pedestrian scenarios run their controllers in the rollout kernel");
+    static_assert(!CROWD || (PED && G == 64 && !ROAD && !RSSV), "the crowd variant is a pedestrian variant with 64-lane tiles");
     constexpr int NS = 64 * WV;
-    __shared__ TileLds<NS, PED> lds;
+    __shared__ TileLds<NS, PED, CROWD> lds;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t voff = lane * 8u;
     // one wavefront = one 64-slot block of the state arrays: wave-uniform block pointers
@@ -1851,7 +2246,29 @@ __device__ __forceinline__ void rollout_body(
         if (PED) // PedestrianSensor radius is measured between reference points; centres differ by the box offsets
             nbr_thr = kind == SG_KIND_AGENT_PEDESTRIAN
                           ? (float)fld(st, ST_CTRL + SG_C_PED_RADIUS) * 1.000001f + off + omax + 2e-3f : 0.0f;
+        if (CROWD) { // thresholds of the radius rule (sg_in_radius), per pedestrian
+            const double rr = fld(st, ST_CTRL + SG_C_PED_RADIUS), r2 = rr * rr;
+            lds.r2hi[sl] = r2 * (1.0 + 1e-9);
+            lds.r2lo[sl] = r2 * 0.9975;
+        }
     }
+    // CROWD: may this wavefront use crowd_pairs at all?  Default head rotation in every lane, a radius and parameters inside
+    // the guards of crowd_pair (wave-uniform, fixed for the launch); the per-step guards are voted in tile_collisions.
+    bool crowd_static_ok = false;
+    CrowdConsts CC{};
+    if (CROWD) {
+        const double rr = fld(st, ST_CTRL + SG_C_PED_RADIUS), hr = fld(st, ST_CTRL + SG_C_PED_HEAD_ROT);
+        crowd_static_ok = __all(kind != SG_KIND_AGENT_PEDESTRIAN || (hr == 0.0 && rr > 0.0 && rr < 0x1p20)) &&
+                          crowd_params_ok(p.sf) && !p.ped_serial;
+        const RecipDiv rs(p.sf.ped_repulse_sigma);
+        CC.k2_scale = p.sf.ped_repulse_V / p.sf.ped_repulse_sigma;
+        CC.sig_b = rs.b;
+        CC.sig_r = rs.r;
+        CC.cos_sight = p.sf.cos_sight;
+        CC.sight_weight = p.sf.sight_weight;
+        CC.k3 = 2 * p.sf.ped_attract_C;
+    }
+    bool crowd_ok = false; // workgroup-uniform, per step: the guards of crowd_pair hold for every pedestrian of the tile
     // broad-phase cell size: >= every reach in the tile (+5 % so that fp32 cell coordinates stay consistent)
     float cell_inv;
     {
@@ -1999,8 +2416,8 @@ __device__ __forceinline__ void rollout_body(
         // collisions of the reset state; pedestrian scenes also need the neighbour candidates (and LDS positions) of the
         // current state when they continue
         uint64_t tmp_rows[WV];
-        tile_collisions<G, WV, PED>(present, pose, velx, vely, (t + timestep) - t, bcx, bcy, rad_thr, trig_eps, nbr_thr, cell_inv, is_ped_type,
-                                    sl, tile0, lds, tmp_rows, mult_rows, nbr, dense);
+        tile_collisions<G, WV, PED, CROWD>(present, pose, velx, vely, (t + timestep) - t, bcx, bcy, rad_thr, trig_eps, nbr_thr, cell_inv,
+                                           is_ped_type, sl, tile0, lds, tmp_rows, mult_rows, nbr, dense, &crowd_ok);
         if (rs) {
 #pragma unroll
             for (int w = 0; w < WV; ++w) row[w] = tmp_rows[w];
@@ -2080,7 +2497,7 @@ __device__ __forceinline__ void rollout_body(
     if (RSSV && do_reset != 0) rss_call(rs, t, vel[0], vel[1]); // State.reset ends with update_callbacks(), state.py:138-140
 
     Segment S;
-    {
+    if (!CROWD) { // (a crowd has no replay lanes: its only trajectory lookup is the rare spawn, done on the spot)
         Table T = lane_table(p, kind, ss, slot, st);
         S.cur = seg_locate(T, t);
         seg_load(T, S);
@@ -2098,10 +2515,15 @@ __device__ __forceinline__ void rollout_body(
     int k = 0;
     bool all_done = false;
     bool vel_clean_prev = false; // wave-uniform
+    PhaseTimers ptm;
+#ifdef SG_PHASE_TIMERS
+    ptm.start();
+    if (lane == 0 && blockIdx.x < 1024) p.phase_cycles[16 + blockIdx.x * 4 + wave] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); // HW_REG_HW_ID
+#endif
     sg_loads_done(); // everything loaded so far is in its registers before the first store is issued
     sg_lgkm_done();
     while (k < n_steps && !all_done) {
-    if (t + timestep > S.x_hi) { // rare: next knot segment
+    if (!CROWD && t + timestep > S.x_hi) { // rare: next knot segment
         // opaque copies keep the table address arithmetic inside this branch (otherwise ~15 invariant
         // 64-bit row addresses are hoisted out of the time loop and held in VGPRs / spilled)
         int kind_o = kind, slot_o = slot;
@@ -2113,9 +2535,13 @@ __device__ __forceinline__ void rollout_body(
     }
     for (; k < n_steps; ++k) {
         // per wavefront and before any workgroup barrier of the step: does a lane need its next segment?
-        if (__any(t + timestep > S.x_hi)) break;
+        if (!CROWD && __any(t + timestep > S.x_hi)) break;
         const bool run = in_range && (force || !done);
-        if (!block_any<WV>(run)) { all_done = true; break; }
+        PH(5);
+        // (a workgroup of several wavefronts carries ONE scenario: `run` is already uniform, nothing to vote)
+        const bool any_run_ = WV == 1 ? __any(run) : run;
+        PH(7);
+        if (!any_run_) { all_done = true; break; }
         // coefficient table: opaque per step so the scalar loads stay inside the loop (SGPRs for a few
         // dozen instructions instead of VGPRs for the whole kernel); constant address space => s_load
         const double *Kp = SG_TRIG;
@@ -2132,8 +2558,8 @@ __device__ __forceinline__ void rollout_body(
             act_a = a[0];
             act_s = a[1];
         }
-        double np_[6];
-        {
+        double np_[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        if (!CROWD) {
             double dq = next_t - S.x_lo;
 #pragma unroll
             for (int c = 0; c < 6; ++c) np_[c] = S.sl[c] * dq + S.ylo[c];
@@ -2145,8 +2571,8 @@ __device__ __forceinline__ void rollout_body(
         bool ped_go = false;
         double ped_fx = 0.0, ped_fy = 0.0, ped_vdes = 0.0;
         if (PED) // the social force of every stepping pedestrian of the wavefront (wave-collective)
-            ped_force<WV>(p, lds, (int)r, sl, tile0, nbr, is_agent && kind == SG_KIND_AGENT_PEDESTRIAN && present && run, pose,
-                          velx, vely, wp, nwp, goal_idx, ped_go, ped_fx, ped_fy, ped_vdes, K);
+            ped_force<WV, CROWD>(p, lds, (int)r, sl, tile0, nbr, is_agent && kind == SG_KIND_AGENT_PEDESTRIAN && present && run, pose,
+                                 velx, vely, wp, nwp, goal_idx, ped_go, ped_fx, ped_fy, ped_vdes, K, crowd_static_ok && crowd_ok, CC, &ptm);
         if (TAB) {
             // Straight-line lane masks (the kernel is bound by instruction issue, branches included):
             // BatchReplayEntity.step (batch.py:34-53) for replay lanes; an agent stays once present and spawns at its
@@ -2169,6 +2595,27 @@ __device__ __forceinline__ void rollout_body(
                 np_[4] = take ? pose[4] : np_[4];
                 np_[5] = take ? pose[5] : np_[5];
                 tab_issue(); // row k + 1 (the table has one spare row), consumed by the next step
+            }
+        } else if (CROWD) {
+            if (kind == SG_KIND_AGENT_PEDESTRIAN) {
+                if (present) {
+                    npres = true;
+                    if (run)
+                        ped_move(p, ped_go, ped_fx, ped_fy, ped_vdes, lds.ctrl[PED ? SG_C_PED_MAX_SPEED - SG_C_PED_SPEED_DESIRED : 0][sl],
+                                 pose, state_dt, cs.speed, fpx, fpy, np_, K);
+                } else if (min_t >= t) { // scenario_gym.py:240-244: spawn at the trajectory position of next_t (clamped)
+                    npres = true;
+                    LanePtr st_o = st;
+                    asm volatile("" : "+v"(st_o.a[0]));
+                    Table T = lane_table(p, SG_KIND_AGENT_PEDESTRIAN, ss, slot, st_o);
+                    Segment S2;
+                    S2.cur = seg_locate(T, next_t);
+                    seg_load(T, S2);
+                    sg_loads_done();
+                    const double dq = next_t - S2.x_lo;
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) np_[c] = S2.sl[c] * dq + S2.ylo[c];
+                }
             }
         } else if (kind == SG_KIND_REPLAY) { // BatchReplayEntity.step, batch.py:34-53
             npres = p.persist || is_static || (next_t >= min_t && next_t <= max_t);
@@ -2313,14 +2760,15 @@ __device__ __forceinline__ void rollout_body(
                 m_max = __builtin_fmax(speed, m_max); // EgoMaxSpeed, :41-44
             }
         }
+        PH(1);
         // ---- State.collisions ----
         uint64_t nrow[WV];
 #ifdef SG_ABL_NO_COLL
 #pragma unroll
         for (int w = 0; w < WV; ++w) nrow[w] = 0;
 #else
-        tile_collisions<G, WV, PED>(present, pose, velx, vely, (t + timestep) - t, bcx, bcy, rad_thr, trig_eps, nbr_thr, cell_inv, is_ped_type,
-                                    sl, tile0, lds, nrow, mult_rows, nbr, dense);
+        tile_collisions<G, WV, PED, CROWD>(present, pose, velx, vely, (t + timestep) - t, bcx, bcy, rad_thr, trig_eps, nbr_thr, cell_inv,
+                                           is_ped_type, sl, tile0, lds, nrow, mult_rows, nbr, dense, &crowd_ok, &ptm);
 #endif
         if (run) {
 #pragma unroll
@@ -2420,8 +2868,12 @@ __device__ __forceinline__ void rollout_body(
         }
         if (RSSV) rss_call(run, t, vel[0], vel[1]); // State.step ends with update_callbacks(), state.py:165-171
         if (has_tab) sg_lgkm_done();
+        PH(5);
     }
     }
+#ifdef SG_PHASE_TIMERS
+    ptm.flush(p.phase_cycles);
+#endif
 
     // ---- write back what lives in registers during the loop ----
     if (in_range) {
@@ -2469,6 +2921,14 @@ __global__ __launch_bounds__(64 * WV, PED ? SG_WAVES_PER_SIMD_PED : (TAB ? SG_WA
 {
     // one wavefront per tile: this entry point serves the batches WITHOUT controlled lanes (rollout_kernel_tab the others)
     rollout_body<G, WV, PED, TAB, (TAB && WV > 1)>(p, timestep, n_steps, do_reset, force, actions, tab);
+}
+
+// All-pedestrian batches without road networks (BASELINE config 5): see rollout_body, CROWD
+template <int WV>
+__global__ __launch_bounds__(64 * WV, SG_WAVES_PER_SIMD_PED) void rollout_kernel_crowd(
+    Params p, double timestep, int n_steps, int do_reset, int force, const double *actions, const double *tab)
+{
+    rollout_body<64, WV, true, false, false, false, false, true>(p, timestep, n_steps, do_reset, force, actions, tab);
 }
 
 // terminal_conditions with "ego_off_road": controllers in the kernel, road index lookups for slot 0

@@ -22,6 +22,8 @@ struct sg_handle {
     sg_config cfg{};
     int R = 0, E = 0, EP = 0, G = 0, WV = 1;
     bool has_ped = false;
+    bool all_ped = false;     // every entity of the batch is a pedestrian agent of catalog type Pedestrian (or padding)
+    int crowd_kernel = 1;     // env SG_CROWD_KERNEL=0: all-pedestrian batches take the general pedestrian variant too
     sg_social_force sf{};
     double *d_gon = nullptr;
     size_t NE = 0; // padded entity count
@@ -172,6 +174,7 @@ extern "C" int sg_create(const sg_config *cfg, sg_handle **out)
     h->overlap = env_int("SG_OVERLAP", h->overlap);
     h->ctl_slice = std::max(1, env_int("SG_CTL_SLICE", h->ctl_slice));
     h->ped_serial = env_int("SG_PED_SERIAL", 0) != 0;
+    h->crowd_kernel = env_int("SG_CROWD_KERNEL", 1);
     if (hipSetDevice(cfg->device) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess ||
         hipStreamCreate(&h->ctl_stream) != hipSuccess ||
         hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {
@@ -187,6 +190,24 @@ extern "C" int sg_destroy(sg_handle *h)
     if (!h) return SG_OK;
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+#ifdef SG_PHASE_TIMERS
+    if (h->p.phase_cycles) {
+        unsigned long long c[16];
+        (void)hipMemcpy(c, h->p.phase_cycles, sizeof c, hipMemcpyDeviceToHost);
+        unsigned long long tot = 0;
+        for (int i = 0; i < 16; ++i) tot += c[i];
+        fprintf(stderr, "phase cycles (s_memtime, summed over wavefronts):");
+        for (int i = 0; i < 16; ++i) fprintf(stderr, " [%d] %.1f%%", i, tot ? 100.0 * c[i] / tot : 0.0);
+        fprintf(stderr, "  total %.3e\n", (double)tot);
+        std::vector<unsigned long long> hw(4096);
+        (void)hipMemcpy(hw.data(), h->p.phase_cycles + 16, 4096 * 8, hipMemcpyDeviceToHost);
+        for (int b = 0; b < 12; ++b) {
+            fprintf(stderr, "block %d:", b);
+            for (int w = 0; w < 4; ++w) { unsigned v = (unsigned)hw[b * 4 + w]; fprintf(stderr, " [wave %u simd %u cu %u se %u xcc?%x]", v & 15, (v >> 4) & 3, (v >> 8) & 15, (v >> 13) & 7, v >> 16); }
+            fprintf(stderr, "\n");
+        }
+    }
+#endif
     free_pool(h->static_allocs);
     free_pool(h->state_allocs);
     free_pool(h->road_allocs);
@@ -222,7 +243,13 @@ static void launch_variant(sg_handle *h, dim3 grid, int n_steps, int do_reset, i
                            const double *d_tab, bool use_tab)
 {
     dim3 block(64 * WV);
-    if (h->has_ped)
+#ifdef SG_ONLY_CROWD // experiment builds (tools/ab_build.sh): only the crowd variant is compiled
+    sg::rollout_kernel_crowd<WV><<<grid, block, 0, h->stream>>>(h->p, h->cfg.timestep, n_steps, do_reset, force, d_actions, nullptr);
+    return;
+#endif
+    if (h->has_ped && h->all_ped && G == 64 && !h->has_road && h->crowd_kernel)
+        sg::rollout_kernel_crowd<WV><<<grid, block, 0, h->stream>>>(h->p, h->cfg.timestep, n_steps, do_reset, force, d_actions, nullptr);
+    else if (h->has_ped)
         sg::rollout_kernel<(WV > 1 || G >= 16) ? G : 16, WV, true, false><<<grid, block, 0, h->stream>>>(
             h->p, h->cfg.timestep, n_steps, do_reset, force, d_actions, nullptr);
     else if (h->rss_fused)
@@ -399,7 +426,11 @@ extern "C" int sg_upload(sg_handle *h, const sg_scenarios *sc)
     ++h->generation;
     // pedestrian agents are compiled for tiles of >= 16 lanes
     h->has_ped = false;
-    for (size_t i = 0; i < (size_t)h->R * h->E; ++i) h->has_ped = h->has_ped || sc->kind[i] == SG_KIND_AGENT_PEDESTRIAN;
+    h->all_ped = true;
+    for (size_t i = 0; i < (size_t)h->R * h->E; ++i) {
+        h->has_ped = h->has_ped || sc->kind[i] == SG_KIND_AGENT_PEDESTRIAN;
+        h->all_ped = h->all_ped && (sc->kind[i] == SG_KIND_NONE || (sc->kind[i] == SG_KIND_AGENT_PEDESTRIAN && sc->etype[i] == 1));
+    }
     if (h->has_ped && h->WV == 1 && h->G < 16) { h->G = 16; h->EP = 16; h->NE = (((size_t)h->R * h->EP + 63) / 64) * 64; }
     if (h->has_ped && (!sc->route_off || !sc->routes)) return fail(h, SG_ERR_INVALID, "sg_upload: pedestrian agents need route_off/routes");
     if (h->has_ped && (h->cfg.terminal_mask & SG_TERM_EGO_OFF_ROAD))
@@ -605,6 +636,9 @@ extern "C" int sg_upload(sg_handle *h, const sg_scenarios *sc)
     if ((rc = dev_alloc(h, M, &p.rec_t, (size_t)std::max(p.rec_cap, 1) * R))) return rc;
     if ((rc = dev_alloc(h, M, &p.rec_pose, (size_t)std::max(p.rec_cap, 0) * 6 * R * EP + 1))) return rc;
 
+#ifdef SG_PHASE_TIMERS
+    if ((rc = dev_alloc(h, M, &p.phase_cycles, 16 + 4096))) return rc;
+#endif
     if (trace) { (void)hipStreamSynchronize(h->stream); stage("allocations + copies"); }
     // stage-1 resample on device
     if (total_rows > 0) {

@@ -1,11 +1,16 @@
-"""Routes for pedestrian agents along the walkable part of a road network: pedestrian/route.py.
+"""Pedestrian routing over the walkable part of a road network (host-side scenario setup).
 
-Host-side scenario setup (the device consumes the finished routes as PedestrianAgent.route): nodes every ~1 m along the
-centre lines of pavements and crossings, edges between consecutive nodes and between a crossing and the pavements it
-connects (at their closest nodes), breadth-first shortest paths.
+Mirrors the behaviour of the reference's `scenario_gym/pedestrian/route.py:10-190`: sample points roughly every metre
+along the centre line of every pavement and crossing, connect consecutive samples, connect each crossing to the
+pavements it lists at their mutually closest samples, and answer "route from a to b" with a breadth-first search between
+the samples closest to a and b.  The finished routes are what the device consumes (`PedestrianAgent.route`).
+
+The walk graph is kept as arrays: sample coordinates `xy[n, 2]`, string labels `"<object id>_<k>"`, and a CSR
+adjacency (`adj_off`, `adj`) whose per-node neighbour order is the insertion order the reference's dict-of-lists ends up
+with -- breadth-first tie-breaking depends on it.  The dict views the reference exposes (`graph`, `node_to_idx`,
+`node_data`) are derived from the arrays on demand.
 """
 import random
-from itertools import chain
 from typing import Dict, List, Optional, Tuple
 
 import numpy as np
@@ -13,103 +18,155 @@ import numpy as np
 from .road_network import RoadNetwork
 
 
-def _interpolate(line: np.ndarray, s: float) -> np.ndarray:
-    """LineString.interpolate(s, normalized=False): the point at arc length s (clamped to the ends)."""
-    seg = np.diff(line, axis=0)
-    length = np.sqrt((seg ** 2).sum(axis=1))
-    if s <= 0.0 or len(line) == 1:
-        return line[0].copy()
-    acc = 0.0
-    for k, L in enumerate(length):
-        if s < acc + L or (k == len(length) - 1 and s <= acc + L):
-            u = 0.0 if L == 0.0 else (s - acc) / L
-            return line[k] + u * seg[k]
-        acc += L
-    return line[-1].copy()
+def sample_centre_line(line: np.ndarray) -> np.ndarray:
+    """Points at arc lengths np.linspace(0, L, int(L)) of a polyline (shapely `interpolate(s, normalized=False)`)."""
+    line = np.asarray(line, dtype=float).reshape(-1, 2)
+    step = np.diff(line, axis=0)
+    seg_len = np.hypot(step[:, 0], step[:, 1]) if len(step) else np.zeros(0)
+    cum = np.concatenate([[0.0], np.cumsum(seg_len)])
+    total = float(seg_len.sum())
+    s = np.linspace(0.0, total, int(total))
+    if s.size == 0:
+        return np.zeros((0, 2))
+    if len(line) == 1:
+        return np.repeat(line[:1], s.size, axis=0)
+    # segment holding each arc length: the first one whose end lies beyond s (the last segment also takes s == total)
+    seg = np.clip(np.searchsorted(cum, s, side="right") - 1, 0, len(seg_len) - 1)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        frac = np.where(seg_len[seg] > 0.0, (s - cum[seg]) / seg_len[seg], 0.0)
+    pts = line[seg] + frac[:, None] * step[seg]
+    pts[s <= 0.0] = line[0]
+    return pts
 
 
-def _center_nodes(center: np.ndarray) -> np.ndarray:
-    total = float(np.sqrt((np.diff(center, axis=0) ** 2).sum(axis=1)).sum())
-    return np.array([_interpolate(center, x) for x in np.linspace(0.0, total, int(total))]).reshape(-1, 2)
+class WalkGraph:
+    """Array form of the pedestrian connection graph (reference `make_pedestrian_connection_graph`, route.py:53-128)."""
+
+    def __init__(self, rn: RoadNetwork):
+        strips = [(p.id, sample_centre_line(p.center)) for p in rn.pavements]
+        n_pavements = len(strips)
+        strips += [(c.id, sample_centre_line(c.center)) for c in rn.crossings]
+        first: Dict[str, int] = {}  # object id -> index of its first sample
+        labels: List[str] = []
+        coords = []
+        for oid, pts in strips:
+            first[oid] = len(labels)
+            labels.extend(f"{oid}_{k}" for k in range(len(pts)))
+            coords.append(pts)
+        self.labels = labels
+        self.xy = np.concatenate(coords, axis=0) if coords else np.zeros((0, 2))
+        count = {oid: len(pts) for oid, pts in strips}
+        # directed edges in the order the reference appends them
+        src: List[np.ndarray] = []
+        dst: List[np.ndarray] = []
+        for oid, pts in strips:
+            if len(pts) > 1:
+                a = first[oid] + np.arange(len(pts) - 1)
+                src.append(np.stack([a, a + 1], axis=1).ravel())
+                dst.append(np.stack([a + 1, a], axis=1).ravel())
+        by_id = dict(strips)
+        for crossing in rn.crossings:
+            cpts = by_id[crossing.id]
+            for pid in crossing.pavements:
+                ppts = by_id[pid]
+                gap = np.linalg.norm(cpts[:, None, :] - ppts[None, :, :], axis=-1)
+                ci, pi = divmod(int(gap.argmin()), count[pid])  # row-major argmin == np.unravel_index
+                u, v = first[crossing.id] + ci, first[pid] + pi
+                src.append(np.array([u, v]))
+                dst.append(np.array([v, u]))
+        n = len(labels)
+        s = np.concatenate(src) if src else np.zeros(0, np.int64)
+        d = np.concatenate(dst) if dst else np.zeros(0, np.int64)
+        order = np.argsort(s, kind="stable")  # per-node neighbour order = insertion order
+        self.adj = d[order].astype(np.int64)
+        self.adj_off = np.concatenate([[0], np.cumsum(np.bincount(s.astype(np.int64), minlength=n))]).astype(np.int64)
+        self.n_pavement_strips = n_pavements
+
+    def __len__(self) -> int:
+        return len(self.labels)
+
+    def neighbours(self, node: int) -> np.ndarray:
+        return self.adj[self.adj_off[node]:self.adj_off[node + 1]]
+
+    def nearest(self, point) -> int:
+        """Index of the sample closest to `point` (first one on ties, like min() over the reference's dict)."""
+        d = self.xy - np.asarray(point, dtype=float)[None, :]
+        return int(np.argmin(np.sqrt(d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1])))
+
+    def bfs_path(self, start: int, goal: int) -> Optional[List[int]]:
+        """Breadth-first path with parent pointers, O(V + E).  Equal to the reference's list-of-paths search
+        (route.py:131-158): nodes are expanded in the order of their first discovery, neighbours in adjacency order, and
+        the search ends the moment the goal is discovered."""
+        if start == goal:
+            return [start]
+        parent = np.full(len(self), -1, np.int64)
+        parent[start] = start
+        frontier = [start]
+        adj, off = self.adj, self.adj_off
+        while frontier:
+            nxt: List[int] = []
+            for u in frontier:
+                for v in adj[off[u]:off[u + 1]]:
+                    v = int(v)
+                    if parent[v] >= 0:
+                        continue
+                    parent[v] = u
+                    if v == goal:
+                        path = [v]
+                        while path[-1] != start:
+                            path.append(int(parent[path[-1]]))
+                        return path[::-1]
+                    nxt.append(v)
+            frontier = nxt
+        return None
+
+    # ---- the reference's dict views ------------------------------------------------------------------
+    def as_dicts(self) -> Tuple[Dict[int, List[int]], Dict[str, int], Dict[int, Tuple[float, float]]]:
+        graph = {i: [int(v) for v in self.neighbours(i)] for i in range(len(self))}
+        node_to_idx = {lab: i for i, lab in enumerate(self.labels)}
+        node_data = {i: (float(self.xy[i, 0]), float(self.xy[i, 1])) for i in range(len(self))}
+        return graph, node_to_idx, node_data
 
 
 def make_pedestrian_connection_graph(rn: RoadNetwork):
-    """route.py:53-128: (graph {node: [neighbours]}, node_to_idx {"<object id>_<i>": node}, node_data {node: (x, y)})."""
-    graph: Dict[int, List[int]] = {}
-    node_to_idx: Dict[str, int] = {}
-    node_data: Dict[int, Tuple[float, float]] = {}
-    pavement_coords = {p.id: _center_nodes(p.center) for p in rn.pavements}
-    crossing_coords = {c.id: _center_nodes(c.center) for c in rn.crossings}
-    for obj, coords in chain(pavement_coords.items(), crossing_coords.items()):
-        for i, (x, y) in enumerate(coords):
-            node_to_idx[f"{obj}_{i}"] = len(node_to_idx)
-            graph[node_to_idx[f"{obj}_{i}"]] = []
-            node_data[node_to_idx[f"{obj}_{i}"]] = (x, y)
-    for obj, coords in chain(pavement_coords.items(), crossing_coords.items()):
-        for i in range(len(coords) - 1):
-            graph[node_to_idx[f"{obj}_{i}"]].append(node_to_idx[f"{obj}_{i + 1}"])
-            graph[node_to_idx[f"{obj}_{i + 1}"]].append(node_to_idx[f"{obj}_{i}"])
-    for c in rn.crossings:
-        for p in c.pavements:
-            c_coords, p_coords = crossing_coords[c.id], pavement_coords[p]
-            c_idx, p_idx = np.unravel_index(
-                np.linalg.norm(c_coords[:, None, :] - p_coords[None, :, :], axis=-1).argmin(),
-                (c_coords.shape[0], p_coords.shape[0]))
-            graph[node_to_idx[f"{c.id}_{c_idx}"]].append(node_to_idx[f"{p}_{p_idx}"])
-            graph[node_to_idx[f"{p}_{p_idx}"]].append(node_to_idx[f"{c.id}_{c_idx}"])
-    return graph, node_to_idx, node_data
+    """(graph, node_to_idx, node_data) in the reference's dict form."""
+    return WalkGraph(rn).as_dicts()
 
 
-def shortest_path(graph: Dict[int, List[int]], start: int, goal: int) -> Optional[List[int]]:
-    """route.py:131-158: breadth-first search; None when start and goal are not connected."""
-    if start == goal:
-        return [start]
-    explored, queue = set(), [[start]]
-    while queue:
-        path = queue.pop(0)
-        node = path[-1]
-        if node not in explored:
-            for neighbour in graph[node]:
-                new_path = path + [neighbour]
-                queue.append(new_path)
-                if neighbour == goal:
-                    return new_path
-            explored.add(node)
-    return None
-
-
-def find_route(graph, node_data, start: np.ndarray, finish: np.ndarray) -> Optional[np.ndarray]:
-    """route.py:161-190: start, the shortest node path between the nodes closest to start and finish, finish."""
-    if not node_data:
-        return np.array([start] + [finish])
-    start_node = min(node_data, key=lambda n: np.linalg.norm(np.array(node_data[n]) - start))
-    end_node = min(node_data, key=lambda n: np.linalg.norm(np.array(node_data[n]) - finish))
-    route = shortest_path(graph, start_node, end_node)
-    if route is None:
+def find_route(walk: WalkGraph, start: np.ndarray, finish: np.ndarray) -> Optional[np.ndarray]:
+    """start, the samples of the breadth-first path between the samples nearest to start and finish, finish; None when
+    they are not connected; the straight pair when the network has no walkable strips (reference route.py:161-190)."""
+    start, finish = np.asarray(start, dtype=float), np.asarray(finish, dtype=float)
+    if len(walk) == 0:
+        return np.stack([start, finish])
+    nodes = walk.bfs_path(walk.nearest(start), walk.nearest(finish))
+    if nodes is None:
         return None
-    return np.array([start] + [list(node_data[n]) for n in route] + [finish])
+    return np.concatenate([start[None, :], walk.xy[nodes], finish[None, :]], axis=0)
 
 
 class RouteFinder:
-    """route.py:10-50."""
+    """Routes along the walkable areas of a road network (reference `RouteFinder`, route.py:10-50)."""
 
     def __init__(self, rn: RoadNetwork):
         self.rn = rn
-        self.graph, self.node_to_idx, self.node_data = make_pedestrian_connection_graph(rn)
+        self.walk = WalkGraph(rn)
+        self.graph, self.node_to_idx, self.node_data = self.walk.as_dicts()
 
     def find_route(self, start: np.ndarray, finish: np.ndarray) -> Optional[np.ndarray]:
-        return find_route(self.graph, self.node_data, np.asarray(start, float), np.asarray(finish, float))
+        return find_route(self.walk, start, finish)
 
     def generate_route(self, n: int, start: Optional[np.ndarray] = None, no_repeat: bool = False):
-        if start is not None:
-            route = [min(self.node_data, key=lambda x: np.linalg.norm(self.node_data[x] - start))]
-        else:
-            route = [random.choice(list(self.graph.keys()))]
-        while len(route) < n:
-            suc = self.graph[route[-1]]
+        """Random walk of at most n samples from the sample nearest to `start` (or a random one)."""
+        walk = self.walk
+        here = walk.nearest(start) if start is not None else random.randrange(len(walk))
+        visited = [here]
+        while len(visited) < n:
+            options = [int(v) for v in walk.neighbours(here)]
             if no_repeat:
-                suc = list(set(suc).difference(route))
-            if not suc:
+                options = list(set(options).difference(visited))
+            if not options:
                 break
-            route.append(random.choice(suc))
-        return [self.node_data[i] for i in route]
+            here = random.choice(options)
+            visited.append(here)
+        return [self.node_data[i] for i in visited]
