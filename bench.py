@@ -7,10 +7,12 @@
 One bench "step" = one full pass of the hot path over the batch: sg_rollout of R x E x T
 (reset + T simulated steps, every scenario running to its end) with the scenarios resident in HBM.
 Every rank owns its own R scenarios (weak scaling: replicas are independent); RCCL is
-used only to dispatch the run configuration and to collect the per-replica metric rows.
-Prints ONE JSON line on rank 0.
+used only to dispatch the run configuration and to collect the per-replica metric rows.  With N > 1 the
+same run also times BASELINE.json configs[3] read literally (the 4096 scenarios split over the N ranks:
+"strong") and reports it beside the headline.  Prints ONE JSON line on rank 0.
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -19,8 +21,16 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-B_ALG = 114.0        # algorithmic bytes per entity-step: pose 48 + vel 48 + dist 8 + row 8 + knots 2
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# BASELINE.json configs: scenarios, entities; algorithmic bytes per entity-step (pose 48 + velocity 48 +
+# distance 8 + collision row 8 x words + knots 2 [+ force 16]); bytes the kernel actually stores per steady entity-step
+# (unchanged z / pitch / roll rows are not stored again: x, y, h of pose and velocity, distance,
+# presence, the collision row words [+ the force])
+WORKLOADS = {
+    "c2": dict(R=256, E=16, b_alg=114.0, stored=72.0, config=1),
+    "c3": dict(R=4096, E=64, b_alg=114.0, stored=72.0, config=2),
+    "c5": dict(R=1024, E=256, b_alg=154.0, stored=112.0, config=4),
+}
 
 
 def cpu_baseline(workload, seconds_budget=20.0):
@@ -28,9 +38,6 @@ def cpu_baseline(workload, seconds_budget=20.0):
     sample of the same workload: one scenario per host thread, the same E, shortened T."""
     import concurrent.futures as cf
 
-    import numpy as np
-
-    import scenario_gym_amd._lib as L
     from oracle import oracle as O
     from scenario_gym_amd import synthetic
     from scenario_gym_amd.packing import unpack_scenario
@@ -58,11 +65,22 @@ def cpu_baseline(workload, seconds_budget=20.0):
     with cf.ThreadPoolExecutor(cores) as ex:  # ctypes releases the GIL: real parallelism
         steps = list(ex.map(one, scen))
     dt = time.perf_counter() - t0
-    return {
+    out = {
         "value": float(sum(steps)) * E / dt, "unit": "entity-steps/s", "cores": cores, "kind": "port",
         "sample": f"{n_scen} scenarios x {E} entities x {t_sample} steps of the same seeded family, "
                   f"{cores} threads, C oracle (oracle/sgym_oracle.c), {dt:.1f}s",
     }
+    ref = os.path.join(ROOT, "profiles", "reference_cpu.json")
+    if os.path.exists(ref):  # the real reference cannot travel to the GPU box: its number from the build container
+        with open(ref) as f:
+            r = json.load(f)
+        out["reference"] = {
+            "value": r["entity_steps_per_s_box"], "per_core": r["entity_steps_per_s_per_core"], "cores": r["processes"],
+            "unit": "entity-steps/s",
+            "note": f"driskai/scenario_gym v0.3.1 itself, E = {r['entities']}, default agents + 3 ego metrics, NO collision "
+                    "detection, timed in the build container (tools/time_reference.py, profiles/reference_cpu.json)",
+        }
+    return out
 
 
 def kernel_name(E, crowd, controlled):
@@ -70,30 +88,76 @@ def kernel_name(E, crowd, controlled):
     `controlled`: the batch has PID / vehicle agents (their pre-pass table is replayed by rollout_kernel_tab)."""
     G, WV = min(64, max(4, 1 << (E - 1).bit_length())), (1 if E <= 64 else 2 if E <= 128 else 4)
     if crowd:
-        return f"sg::rollout_kernel<{max(G, 16) if WV == 1 else G}, {WV}, true, false>"
+        return f"sg::rollout_kernel_crowd<{WV}>" if G == 64 else f"sg::rollout_kernel<{max(G, 16)}, {WV}, true, false>"
     return f"sg::rollout_kernel_tab<{G}>" if (WV == 1 and controlled) else f"sg::rollout_kernel<{G}, {WV}, false, true>"
 
 
-def measured_traffic(R, E, T, launches_per_rollout=1.0):
-    """HBM bytes per rollout-kernel launch from the PMC passes committed under profiles/ (FETCH_SIZE +
-    WRITE_SIZE, MI355X_MICROARCH.md HBM section), if that profile was taken on this workload."""
-    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+def committed_profile(workload, kind, R, E, T=None):
+    """profiles/latest_<workload>_<kind>.json (written by tools/profile_round.sh on the GPU box and committed), or None
+    when it was taken on another shape or on other kernel sources than the ones this run was built from."""
+    import scenario_gym_amd._lib as L
+
+    path = os.path.join(ROOT, "profiles", f"latest_{workload}_{kind}.json")
     if not os.path.exists(path):
         return None
     with open(path) as f:
         rec = json.load(f)
-    if (rec.get("scenarios"), rec.get("entities"), rec.get("sim_steps")) != (R, E, T):
+    if (rec.get("scenarios"), rec.get("entities")) != (R, E) or (T is not None and rec.get("sim_steps") != T):
         return None
-    if "hbm_bytes_per_rollout" in rec:  # summed over the launches of one rollout
-        return rec["hbm_bytes_per_rollout"] / launches_per_rollout
-    return rec.get("hbm_bytes_per_launch")
+    if rec.get("src_sha16") != L.source_sha16():
+        return None
+    return rec
 
 
-def main():
+def valu_peak(device):
+    """tools/valu_peak.hip run live on this GPU: peak vector-ALU wavefront-instructions / s (and what one dependent fp64
+    chain per wavefront reaches at the rollout kernels' two wavefronts per SIMD)."""
+    path = os.path.join(ROOT, "scenario_gym_amd", "lib", "libvalu_peak.so")
+    if not os.path.exists(path):
+        return None
+    lib = ctypes.CDLL(path)
+    out = (ctypes.c_double * 4)()
+    if lib.valu_peak_measure(ctypes.c_int(device), ctypes.c_int(2), out) != 0:
+        return None
+    return {"instr_per_s": out[0], "fp64_tflops": out[1], "dependent_chain_instr_per_s_2_waves": out[2], "cus": int(out[3])}
+
+
+def timed_passes(one_pass, steps, warmup, dist, sync):
+    """W untimed + K timed passes bracketed by barrier + device synchronisation; returns the local wall time, the
+    entity-steps this rank processed and the per-pass kernel statistics."""
+    for _ in range(warmup):
+        one_pass()
+    if dist is not None:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    stats, ent_steps = [], 0
+    for _ in range(steps):
+        n, ms = one_pass()
+        stats.append(ms)
+        ent_steps += n
+    sync()
+    if dist is not None:
+        dist.barrier()
+    return time.perf_counter() - t0, ent_steps, stats
+
+
+def collect(elapsed, ent_steps, dist):
+    """max-over-ranks time, whole-job entity-steps, and every rank's own throughput (rank 0 gets the list)."""
+    import numpy as np
+
+    from scenario_gym_amd import distributed as D
+
+    per_rank = D.gather_rows(np.array([[ent_steps / elapsed]]), dist)
+    return D.max_over_ranks(elapsed, dist), D.sum_over_ranks(float(ent_steps), dist), \
+        (None if per_rank is None else [float(v) for v in per_rank[:, 0]])
+
+
+def main(argv=None, make_engine=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--scenarios", type=int, default=None, help="scenarios per GPU (default: the workload's own, 4096 for c3)")
     ap.add_argument("--entities", type=int, default=None)
     ap.add_argument("--sim-steps", type=int, default=10000)
@@ -102,131 +166,183 @@ def main():
                     help="BASELINE.json configs: c3 = 4096x64 PID ego (default, the headline), c2 = 256x16 replay, "
                          "c5 = 1024x256 social-force crowd")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="weak (default): --scenarios per GPU; strong: --scenarios in total, split evenly over the ranks "
-                         "(BASELINE.json configs[3] read literally: 4096 replicas over 8 GPUs = 512 per GPU, half a "
-                         "wavefront per SIMD)")
+                    help="what `value` is: weak (default) = --scenarios per GPU; strong = --scenarios in total, split evenly "
+                         "over the ranks (BASELINE.json configs[3] read literally: 4096 replicas over 8 GPUs = 512 per GPU)."
+                         "  With N > 1 the other one is timed too and reported under its own key")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    ap.add_argument("--ped-noise", default="off", choices=["off", "device"],
+                    help="c5: SocialForce noise terms (social_force.py:106-114): off = std 0 (parity runs), device = the "
+                         "reference's default std with the counter-based device RNG")
+    args = ap.parse_args(argv)
 
     import numpy as np
-    import torch
 
-    import scenario_gym_amd as sga
     import scenario_gym_amd._lib as L
+    from scenario_gym_amd import distributed as D
     from scenario_gym_amd import synthetic
 
-    from scenario_gym_amd import distributed as D
-
-    shape = {"c2": (256, 16), "c3": (4096, 64), "c5": (1024, 256)}[args.workload]  # BASELINE.json configs
-    args.scenarios = args.scenarios or shape[0]  # (explicit --scenarios / --entities: size sweeps of the same family)
-    args.entities = args.entities or shape[1]
+    wl = WORKLOADS[args.workload]
+    args.scenarios = args.scenarios or wl["R"]  # (explicit --scenarios / --entities: size sweeps of the same family)
+    args.entities = args.entities or wl["E"]
     if args.workload == "c2":
         args.ego = "replay"
+    crowd = args.workload == "c5"
     rank, world, local_rank, dist = D.init()
     if args.gpus != world and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
-    dev = torch.device("cuda", local_rank)
-    if args.scaling == "strong":
-        if args.scenarios % world:
-            raise SystemExit(f"--scaling strong: {args.scenarios} scenarios do not split evenly over {world} ranks")
-        args.scenarios //= world
-
     dt = 1.0 / 30.0
     ego_kind = L.KIND_AGENT_PID if args.ego == "pid" else L.KIND_AGENT_REPLAY
     # dispatch: rank 0 broadcasts the run configuration (RCCL); each rank generates exactly its own shard
-    R, E, T, ego_kind, seed = D.dispatch_config(
+    R_arg, E, T, ego_kind, seed = D.dispatch_config(
         [args.scenarios, args.entities, args.sim_steps, ego_kind, synthetic.SEED], dist)
+    if R_arg % world:
+        raise SystemExit(f"{R_arg} scenarios do not split evenly over {world} ranks")
+    shapes = {"weak": R_arg, "strong": R_arg // world}  # scenarios per rank
 
-    crowd = args.workload == "c5"
-    if crowd:
-        packed = synthetic.make_crowd(R, E, n_steps=T, timestep=dt, seed=seed, first_scenario=rank * R)
-    else:
-        packed = synthetic.make_batch(R, E, n_steps=T, timestep=dt, ego_kind=ego_kind, seed=seed,
-                                      first_scenario=rank * R)
-    eng = sga.RolloutEngine(R, E, timestep=dt, terminal_conditions=["max_length"], event_capacity=64,
-                            device=local_rank)
-    eng.upload(packed)
-    del packed
+    live = make_engine is None
+    if live:
+        import torch
 
-    def one_pass():
-        eng.rollout_async(T, do_reset=True)
-        eng.synchronize()
-        rows, _ = eng.metrics()
-        # collection: every rank's per-replica metric rows to rank 0 (RCCL gather)
-        D.gather_rows(np.stack([rows["ego_avg_speed"], rows["ego_max_speed"], rows["ego_distance_travelled"],
-                                rows["n_collisions"].astype(np.float64), rows["n_steps"].astype(np.float64)],
-                               axis=1), dist)
-        n_launch, launch_ms = eng.last_launch_stats()
-        return rows, (eng.last_kernel_ms(), n_launch, launch_ms)
+        import scenario_gym_amd as sga
 
-    for _ in range(args.warmup):
-        one_pass()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    kernel_ms = []
-    ent_steps = 0
-    for _ in range(args.steps):
-        rows, ms = one_pass()
-        kernel_ms.append(ms)
-        ent_steps += int(rows["n_steps"].sum()) * E
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
+        def sync():
+            torch.cuda.synchronize()
 
-    elapsed = D.max_over_ranks(elapsed, dist)
-    total = D.sum_over_ranks(float(ent_steps), dist)
+        def make_engine(R, first):
+            if crowd:
+                packed = synthetic.make_crowd(R, E, n_steps=T, timestep=dt, seed=seed, first_scenario=first)
+            else:
+                packed = synthetic.make_batch(R, E, n_steps=T, timestep=dt, ego_kind=ego_kind, seed=seed, first_scenario=first)
+            kw = {}
+            if crowd and args.ped_noise == "device":
+                kw["social_force"] = dict(std_lon=0.1, std_lat=0.1, noise="device")
+            eng = sga.RolloutEngine(R, E, timestep=dt, terminal_conditions=["max_length"], event_capacity=64,
+                                    device=local_rank, **kw)
+            eng.upload(packed)
+            return eng
+    else:  # tests drive the dispatch / timing / collection code with a stand-in engine on CPU
+        def sync():
+            pass
 
+    def measure(R):
+        first = rank * R  # rank r owns scenarios [r R, (r + 1) R) of the seeded family (chunk-aligned: R % 64 == 0 or 1 rank)
+        eng = make_engine(R, first)
+
+        def one_pass():
+            eng.rollout_async(T, do_reset=True)
+            eng.synchronize()
+            rows, _ = eng.metrics()
+            # collection: every rank's per-replica metric rows to rank 0 (RCCL gather)
+            D.gather_rows(np.stack([rows["ego_avg_speed"], rows["ego_max_speed"], rows["ego_distance_travelled"],
+                                    rows["n_collisions"].astype(np.float64), rows["n_steps"].astype(np.float64)],
+                                   axis=1), dist)
+            n_launch, launch_ms = eng.last_launch_stats()
+            return int(rows["n_steps"].sum()) * E, (eng.last_kernel_ms(), n_launch, launch_ms)
+
+        elapsed, ent_steps, stats = timed_passes(one_pass, args.steps, args.warmup, dist, sync)
+        eng.close()
+        worst, total, per_rank = collect(elapsed, ent_steps, dist)
+        return dict(elapsed=worst, total=total, per_rank=per_rank, ent_steps=ent_steps, stats=stats, R=R)
+
+    main_run = measure(shapes[args.scaling])
+    other_run = None
+    if world > 1:
+        other = "strong" if args.scaling == "weak" else "weak"
+        other_run = (other, measure(shapes[other]))
+
+    line = None
     if rank == 0:
-        # dominant kernel = sg::rollout_kernel.  A long rollout is cut into chunks of steps (one launch each, so that the
+        m = main_run
+        R = m["R"]
+        # dominant kernel = the rollout kernel.  A long rollout is cut into chunks of steps (one launch each, so that the
         # controller pre-pass of the next chunk overlaps it): per-launch units and duration are averages over the
         # launches of the timed passes, each launch timed with its own HIP event pair on the handle's stream.
-        n_launches = sum(k[1] for k in kernel_ms)
-        per_launch = ent_steps / n_launches
-        avg_ms = sum(k[2] for k in kernel_ms) / n_launches
-        rollout_ms = sum(k[0] for k in kernel_ms) / len(kernel_ms)  # everything one sg_rollout enqueues
-        b_alg = 154.0 if crowd else B_ALG  # +24 B of collision row words, +16 B force vector
+        n_launches = sum(k[1] for k in m["stats"])
+        per_launch = m["ent_steps"] / n_launches
+        avg_ms = sum(k[2] for k in m["stats"]) / n_launches
+        rollout_ms = sum(k[0] for k in m["stats"]) / len(m["stats"])  # everything one sg_rollout enqueues
+        b_alg = wl["b_alg"]
         achieved = per_launch * b_alg / (avg_ms * 1e-3) / 1e9
+        launches_per_rollout = n_launches / args.steps
+        # measured HBM traffic and instruction mix: only from a committed profile of THESE kernel sources on THIS shape
+        hbm = committed_profile(args.workload, "hbm_traffic", R, E, T)
+        traffic = hbm["hbm_bytes_per_rollout"] / launches_per_rollout if hbm else None
+        sq = committed_profile(args.workload, "pmc_sq", R, E)
+        peak = valu_peak(local_rank) if live else None
+        secondary = None
+        if sq and peak:
+            EP = E if E > 64 else max(4, 1 << (E - 1).bit_length())
+            wave_steps_per_s = (m["ent_steps"] / E * EP / 64) / (sum(k[2] for k in m["stats"]) * 1e-3)
+            pws = sq["per_wave_step"]
+            valu = pws["SQ_INSTS_VALU"] * wave_steps_per_s
+            secondary = {
+                "bound": "valu_issue", "unit": "wavefront-instructions/s", "peak": peak["instr_per_s"], "achieved": valu,
+                "frac": valu / peak["instr_per_s"], "valu_per_wave_step": pws["SQ_INSTS_VALU"],
+                "salu_per_wave_step": pws["SQ_INSTS_SALU"],
+                "all_instr_frac": (pws["SQ_INSTS_VALU"] + pws["SQ_INSTS_SALU"] + pws.get("SQ_INSTS_LDS", 0.0)) *
+                                  wave_steps_per_s / peak["instr_per_s"],
+                "peak_fp64_tflops": peak["fp64_tflops"],
+                "dependent_chain_peak": peak["dependent_chain_instr_per_s_2_waves"],
+                "profile": f"profiles/latest_{args.workload}_pmc_sq.json ({sq.get('sim_steps')} steps)",
+                "note": "peak: tools/valu_peak.hip run in this process; achieved: SQ_INSTS_VALU per wavefront-step of the "
+                        "committed rocprofv3 --pmc pass x wavefront-steps / s of this run's rollout-kernel launches",
+            }
+        elif peak:
+            secondary = {"bound": "valu_issue", "unit": "wavefront-instructions/s", "peak": peak["instr_per_s"],
+                         "achieved": None, "frac": None, "peak_fp64_tflops": peak["fp64_tflops"],
+                         "note": "no committed SQ profile of these kernel sources on this shape (profiles/latest_*_pmc_sq.json)"}
         line = {
             "metric": "entity-steps/sec (batched rollout)",
-            "value": total / elapsed,
+            "value": m["total"] / m["elapsed"],
             "unit": "entity-steps/s",
             "n_gpus": world,
+            "ranks": world if dist is None else dist.get_world_size(),
+            "backend": "none" if dist is None else dist.get_backend(),
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step": m["elapsed"] / args.steps * 1e3,
             "higher_is_better": True,
             "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
+            "per_rank_value": m["per_rank"],
             "config": {
                 "workload": (f"{R} scenarios x {E} pedestrians x {T} steps per GPU, PedestrianAgent + SocialForce "
-                             "(radius 3 m, noise off) + PedestrianController, all-pairs OBB collisions, CollisionMetric, "
-                             "terminal max_length (BASELINE.json configs[4])") if crowd else
+                             f"(radius 3 m, noise {args.ped_noise}) + PedestrianController, all-pairs OBB collisions, "
+                             "CollisionMetric, terminal max_length (BASELINE.json configs[4])") if crowd else
                             (f"{R} scenarios x {E} entities x {T} steps per GPU, "
                              f"{'PIDAgent' if ego_kind == L.KIND_AGENT_PID else 'ReplayTrajectoryAgent'} ego + batch replay "
                              "others, all-pairs OBB collisions, CollisionMetric + EgoAvgSpeed/MaxSpeed/DistanceTravelled, "
-                             f"terminal max_length (BASELINE.json configs[{1 if args.workload == 'c2' else 2}])"),
+                             f"terminal max_length (BASELINE.json configs[{wl['config']}])"),
                 "scenarios_per_gpu": R, "entities": E, "sim_steps": T, "timestep": dt,
                 "sharding": f"replicas x{world}, no data-path collective",
             },
             "roofline": {
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(R, E, T, n_launches / args.steps),
+                # `frac` is the contract's figure (algorithmic bytes over the HBM peak).  What binds is vector-ALU
+                # instruction issue: the rewritten state lives in L2 (traffic_ratio), see `secondary`.
+                "bound": "valu_issue", "contract_bound": "hbm",
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic,
+                "traffic_ratio": (traffic / (per_launch * b_alg)) if traffic else None,
+                "stored_bytes_per_entity_step": wl["stored"],
+                "secondary": secondary,
                 "kernel": kernel_name(E, crowd, ego_kind == L.KIND_AGENT_PID),
-                "kernel_ms": avg_ms, "launches_per_rollout": n_launches / args.steps, "rollout_device_ms": rollout_ms,
+                "kernel_ms": avg_ms, "launches_per_rollout": launches_per_rollout, "rollout_device_ms": rollout_ms,
                 "bytes_per_entity_step": b_alg, "entity_steps_per_launch": per_launch,
+                "src_sha16": L.source_sha16(),
             },
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if other_run:
+            name, o = other_run
+            line[name] = {"value": o["total"] / o["elapsed"], "ms_per_step": o["elapsed"] / args.steps * 1e3,
+                          "scenarios_per_gpu": o["R"], "per_rank_value": o["per_rank"]}
+        if live and world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(dict(E=E, T=T, dt=dt, ego_kind=ego_kind, crowd=crowd))
         print(json.dumps(line))
-    eng.close()
-    if dist is not None:
+    if dist is not None and live:
         dist.destroy_process_group()
+    return line
 
 
 if __name__ == "__main__":

@@ -80,6 +80,18 @@ class SgEvent(C.Structure):
 _lib = None
 
 
+def source_sha16() -> str:
+    """sha256[:16] of the kernel sources the library is built from (csrc/*.hpp, *.hip, include/sgym.h).  Profiles committed
+    under profiles/ carry it; bench.py reports a profile's numbers only when it matches the tree it runs from."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for rel in ("csrc/sgym_device.hpp", "csrc/sgym_hip.hip", "../include/sgym.h"):
+        with open(os.path.join(HERE, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def load():
     """Load libsgym_hip.so and declare its prototypes.  Raises if it is not there."""
     global _lib

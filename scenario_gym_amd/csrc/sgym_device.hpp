@@ -1663,9 +1663,14 @@ __device__ __forceinline__ void tile_collisions(bool present, const double *pose
     // (CROWD: the same vote also carries the guards of crowd_pair: a scene beyond 4000 cells is no crowd to be fast on;
     // PED: and the broad-phase strategy, which some lane asked for at the end of the previous call)
     PH(2);
-    const int voted = block_vote<WV>(L, 0, far_out | insane, PED && dense);
-    const bool odd = voted & 1;
-    dense = (voted & 2) != 0;
+    bool odd;
+    if (WV == 1 && !PED) {
+        odd = __any(far_out);
+    } else {
+        const int voted = block_vote<WV>(L, 0, far_out | insane, PED && dense);
+        odd = voted & 1;
+        dense = (voted & 2) != 0;
+    }
     PH(12);
     if (CROWD) *crowd_ok = !odd;
 #if defined(SG_DENSE_NEVER)
@@ -1739,6 +1744,7 @@ __device__ __forceinline__ void tile_collisions(bool present, const double *pose
         xs1 = *reinterpret_cast<const v4f *>(&L.cx[tile0 + TS - 8]);
         ys1 = *reinterpret_cast<const v4f *>(&L.cy[tile0 + TS - 8]);
     }
+    if (PED) {
     // one 32-bit word of the row at a time, both loops unrolled: every index into out_w / nout_w is a constant (a dynamic
     // index would put the two arrays into scratch memory, with a load and a store per group of four slots)
     constexpr int NW32 = (TS + 31) / 32, PER = TS >= 32 ? 8 : TS / 4;
@@ -1788,6 +1794,31 @@ __device__ __forceinline__ void tile_collisions(bool present, const double *pose
     }
     }
 #endif
+    } else {
+    // (vehicle scenes only come here with coordinates beyond 4000 cells; this form of the loop keeps rollout_kernel_tab
+    // inside the 192 registers its co-residency with control_kernel depends on)
+#pragma unroll 4
+    for (int jb = TS - 4; jb >= 0; jb -= 4) {
+        v4f xs2 = xs1, ys2 = ys1; // two groups of four slots stay in flight
+        if (jb >= 8) {
+            xs2 = *reinterpret_cast<const v4f *>(&L.cx[tile0 + jb - 8]);
+            ys2 = *reinterpret_cast<const v4f *>(&L.cy[tile0 + jb - 8]);
+        }
+        v2f dxa = v2f{xs.x, xs.y} - fx2, dya = v2f{ys.x, ys.y} - fy2;
+        v2f dxb = v2f{xs.z, xs.w} - fx2, dyb = v2f{ys.z, ys.w} - fy2;
+        v2f d2a = __builtin_elementwise_fma(dya, dya, dxa * dxa);
+        v2f d2b = __builtin_elementwise_fma(dyb, dyb, dxb * dxb);
+        v2f ma = thr2 - d2a, mb = thr2 - d2b;
+        uint32_t w = out_w[jb >> 5];
+        w = __builtin_amdgcn_alignbit(w, __float_as_uint(mb.y), 31); // w = (w << 1) | sign
+        w = __builtin_amdgcn_alignbit(w, __float_as_uint(mb.x), 31);
+        w = __builtin_amdgcn_alignbit(w, __float_as_uint(ma.y), 31);
+        w = __builtin_amdgcn_alignbit(w, __float_as_uint(ma.x), 31);
+        out_w[jb >> 5] = w;
+        xs = xs1; ys = ys1;
+        xs1 = xs2; ys1 = ys2;
+    }
+    }
     // absent slots hold NaN centres (sign bit unspecified): mask them with the tile's presence bits
 #pragma unroll
     for (int w = 0; w < WV; ++w) {
@@ -2951,7 +2982,7 @@ __global__ __launch_bounds__(64 * WV, SG_WAVES_PER_SIMD) void rollout_kernel_rss
 // control_kernel (<= 128) fill the 512 VGPRs of a SIMD exactly, so the pre-pass of the next chunk is co-resident with
 // the rollout kernel instead of waiting for one of its wavefronts to retire.
 template <int G>
-__global__ __launch_bounds__(64, 2) void rollout_kernel_tab(
+__global__ __launch_bounds__(64, 2) __attribute__((amdgpu_num_vgpr(96))) void rollout_kernel_tab(
     Params p, double timestep, int n_steps, int do_reset, int force, const double *actions, const double *tab)
 {
     rollout_body<G, 1, false, true, true>(p, timestep, n_steps, do_reset, force, actions, tab);

@@ -63,3 +63,85 @@ def test_two_rank_sharding_and_collection(tmp_path, oracle):
     assert got["total"] == R_TOTAL and got["worst"] == 1.0
     whole = synthetic.make_batch(R_TOTAL, E, n_steps=STEPS, ego_kind=3, extent=20.0)
     assert np.array_equal(got["rows"], _rows_for(whole, oracle))  # same bits as one unsharded run
+
+
+class _StandInEngine:
+    """What bench.py's one_pass() needs of a RolloutEngine, without a GPU: every scenario runs its T steps."""
+
+    def __init__(self, R, first, E, T):
+        self.R, self.first, self.E, self.T = R, first, E, T
+        self.passes = 0
+
+    def rollout_async(self, T, do_reset=True):
+        assert T == self.T and do_reset
+        self.passes += 1
+
+    def synchronize(self):
+        pass
+
+    def metrics(self):
+        idx = np.arange(self.first, self.first + self.R, dtype=np.float64)
+        rows = dict(ego_avg_speed=idx, ego_max_speed=idx * 2, ego_distance_travelled=idx * 3,
+                    n_collisions=np.zeros(self.R, np.int32), n_steps=np.full(self.R, self.T, np.int32))
+        return rows, None
+
+    def last_launch_stats(self):
+        return 2, 1.0
+
+    def last_kernel_ms(self):
+        return 1.25
+
+    def close(self):
+        pass
+
+
+def _bench_worker(rank, world, port, out_path):
+    import json
+    import sys
+
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import bench
+    from scenario_gym_amd import distributed as D
+
+    D.init("gloo")  # bench.main() finds the process group initialised
+    made = []
+
+    def make_engine(R, first):
+        made.append((R, first))
+        return _StandInEngine(R, first, 6, 40)
+
+    line = bench.main(["--gpus", str(world), "--scenarios", "128", "--entities", "6", "--sim-steps", "40", "--steps", "2",
+                       "--warmup", "1", "--scaling", "strong", "--no-cpu-baseline"], make_engine=make_engine)
+    assert made == [(64, rank * 64), (128, rank * 128)]  # the strong shape first (it is `value`), then the weak one
+    if rank == 0:
+        with open(out_path, "w") as f:
+            json.dump(line, f)
+    else:
+        assert line is None
+    import torch.distributed as dist
+
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_dispatch_and_collection_strong_scaling(tmp_path):
+    """bench.py's own dispatch / timed passes / gather / aggregation with --scaling strong on two gloo ranks: `value` is
+    the 128 scenarios split 64 + 64, the weak shape (128 per rank) is reported beside it, ranks / backend / per-rank
+    values are in the line."""
+    import json
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "line.json")
+    mp.spawn(_bench_worker, args=(2, port, out), nprocs=2, join=True)
+    line = json.load(open(out))
+    assert line["scaling"] == "strong" and line["ranks"] == 2 and line["n_gpus"] == 2 and line["backend"] == "gloo"
+    assert line["config"]["scenarios_per_gpu"] == 64 and line["weak"]["scenarios_per_gpu"] == 128
+    assert len(line["per_rank_value"]) == 2 and len(line["weak"]["per_rank_value"]) == 2
+    ent_steps = 2 * 64 * 6 * 40 * 2  # ranks x scenarios x entities x T x timed passes
+    assert abs(line["value"] * line["ms_per_step"] * 1e-3 * 2 - ent_steps) < 1e-6 * ent_steps
+    assert line["roofline"]["bound"] == "valu_issue" and line["roofline"]["traffic"] is None
+    assert line["roofline"]["entity_steps_per_launch"] == 64 * 6 * 40 / 2

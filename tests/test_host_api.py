@@ -382,3 +382,69 @@ print(json.dumps(dict(graph={{str(k): v for k, v in rf.graph.items()}}, idx=rf.n
             assert np.allclose(got, np.array(want), rtol=0, atol=1e-9)
             found += 1
     assert found > 0
+
+
+def test_register_budgets_of_the_two_kernel_path():
+    """rollout_kernel_tab (<= 192 VGPRs, twice) + control_kernel (<= 128) = the 512 VGPRs of a SIMD: the controller pre-pass
+    of the next chunk is co-resident with the rollout kernel only inside these budgets (one register more
+    in rollout_kernel_tab<64> cost 7 % of the headline number during round 2).  Read from the built code object."""
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from kernel_resources import table
+
+    t = table()
+    tabs = {n: r for n, r in t.items() if "rollout_kernel_tab<" in n}
+    assert len(tabs) == 5
+    for n, r in tabs.items():
+        assert r["vgpr"] + r["agpr"] <= 192, (n, r)
+    assert tabs["void sg::rollout_kernel_tab<64>"]["scratch"] == 0
+    ctl = t["sg::control_kernel"]
+    assert ctl["vgpr"] + ctl["agpr"] <= 128 and ctl["scratch"] == 0
+    crowd = t["void sg::rollout_kernel_crowd<4>"]
+    assert crowd["lds"] <= 80 * 1024  # two workgroups per CU (160 KB of LDS)
+
+
+def test_walk_graph_bfs_equals_list_of_paths_search():
+    """scenario_gym_amd/route.py: the parent-pointer BFS returns the path the reference's list-of-paths search
+    (pedestrian/route.py:131-158) returns -- restated here as the textbook FIFO of paths -- on random graphs whose
+    adjacency order matters, including unreachable goals."""
+    from types import SimpleNamespace
+
+    from scenario_gym_amd.route import WalkGraph, find_route
+
+    def fifo_of_paths(graph, start, goal):
+        if start == goal:
+            return [start]
+        seen, queue = [], [[start]]
+        while queue:
+            path = queue.pop(0)
+            node = path[-1]
+            if node not in seen:
+                for nb in graph[node]:
+                    new = path + [nb]
+                    queue.append(new)
+                    if nb == goal:
+                        return new
+                seen.append(node)
+        return None
+
+    rng = np.random.default_rng(3)
+    # a "road network" of two pavements and one crossing joining them, plus one pavement nothing leads to
+    line = lambda a, b: np.array([a, b], dtype=float)
+    rn = SimpleNamespace(
+        pavements=[SimpleNamespace(id="p0", center=line((0, 0), (30, 0))), SimpleNamespace(id="p1", center=line((0, 12), (30, 12))),
+                   SimpleNamespace(id="p2", center=line((100, 100), (108, 100)))],
+        crossings=[SimpleNamespace(id="c0", center=line((15, 0.5), (15, 11.5)), pavements=["p0", "p1"])])
+    walk = WalkGraph(rn)
+    graph, idx, data = walk.as_dicts()
+    assert len(walk) == 30 + 30 + 8 + 11 and idx["p1_0"] == 30 and idx["c0_0"] == 68
+    assert graph[idx["c0_0"]][-1] == idx["p0_15"] or graph[idx["c0_0"]][-1] == idx["p0_14"]  # the closest pavement sample
+    for _ in range(200):
+        a, b = (int(v) for v in rng.integers(0, len(walk), 2))
+        assert walk.bfs_path(a, b) == fifo_of_paths(graph, a, b), (a, b)
+    assert walk.bfs_path(idx["p0_3"], idx["p2_1"]) is None
+    r = find_route(walk, np.array([1.0, -1.0]), np.array([29.0, 13.0]))
+    assert r is not None and np.allclose(r[0], [1, -1]) and np.allclose(r[-1], [29, 13]) and len(r) > 20
+    empty = WalkGraph(SimpleNamespace(pavements=[], crossings=[]))
+    assert np.array_equal(find_route(empty, np.zeros(2), np.ones(2)), np.array([[0.0, 0.0], [1.0, 1.0]]))

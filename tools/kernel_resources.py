@@ -1,41 +1,40 @@
 #!/usr/bin/env python3
-"""Per-kernel register / LDS / scratch usage from the device assembly of libsgym_hip.so's source.
+"""Per-kernel register / LDS / scratch usage read from the code object inside the built libsgym_hip.so.
 
-    python tools/kernel_resources.py [file.s]     (without an argument: compiles csrc/sgym_hip.hip to /tmp/isa/sgym.s first)
+    python tools/kernel_resources.py [path/to/lib.so]       prints one line per kernel
+    from tools.kernel_resources import table                 -> {demangled name: dict(vgpr, agpr, sgpr, lds, scratch)}
+
+(rollout_kernel_tab has to stay within 192 VGPRs and control_kernel within 128 for the two to be co-resident on a SIMD:
+tests/test_host_api.py checks it on every build.)
 """
 import os
 import re
 import subprocess
 import sys
+import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-FLAGS = ("--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math -Wno-unused-function -Wno-array-bounds "
-         "-Wno-bitwise-instead-of-logical -Wno-unused-command-line-argument -mllvm --disable-promote-alloca-to-lds -S --cuda-device-only").split()
+LLVM = "/opt/rocm/lib/llvm/bin"
 
 
-def emit(path, extra=()):
-    os.makedirs(os.path.dirname(path), exist_ok=True)
-    subprocess.check_call(["/opt/rocm/bin/hipcc", *FLAGS, *extra, "-o", path,
-                           os.path.join(ROOT, "scenario_gym_amd", "csrc", "sgym_hip.hip")])
-
-
-def table(path):
-    txt = open(path).read()
-    meta = txt[txt.find("amdhsa.kernels"):]
-    rows = []
-    for k in meta.split("  - .agpr_count")[1:]:
+def table(lib=None):
+    lib = lib or os.path.join(ROOT, "scenario_gym_amd", "lib", "libsgym_hip.so")
+    with tempfile.TemporaryDirectory() as d:
+        fat, co = os.path.join(d, "fat.bin"), os.path.join(d, "dev.co")
+        subprocess.check_call([f"{LLVM}/llvm-objcopy", "--dump-section", f".hip_fatbin={fat}", lib, os.path.join(d, "x.so")])
+        subprocess.check_call([f"{LLVM}/clang-offload-bundler", "--unbundle", "--type=o", f"--input={fat}",
+                               "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"])
+        notes = subprocess.run([f"{LLVM}/llvm-readelf", "--notes", co], capture_output=True, text=True, check=True).stdout
+    rows = {}
+    for k in notes.split("  - .agpr_count")[1:]:
         g = lambda key: int(re.search(r"\.%s:\s+(\d+)" % key, k).group(1))
         name = re.search(r"\.name:\s+(\S+)", k).group(1)
-        rows.append((name, g("vgpr_count"), int(re.match(r":\s+(\d+)", k).group(1)), g("sgpr_count"),
-                     g("group_segment_fixed_size"), g("private_segment_fixed_size")))
-    names = subprocess.run(["c++filt"], input="\n".join(r[0] for r in rows), capture_output=True, text=True).stdout.split("\n")
-    for r, n in zip(rows, names):
-        n = re.sub(r"\(sg::Params.*", "", n)
-        print(f"{n[:72]:72s} vgpr={r[1]:3d} agpr={r[2]:3d} sgpr={r[3]:3d} lds={r[4]:6d} scratch={r[5]}")
+        rows[name] = dict(vgpr=g("vgpr_count"), agpr=int(re.match(r":\s+(\d+)", k).group(1)), sgpr=g("sgpr_count"),
+                          lds=g("group_segment_fixed_size"), scratch=g("private_segment_fixed_size"))
+    names = subprocess.run(["c++filt"], input="\n".join(rows), capture_output=True, text=True).stdout.split("\n")
+    return {re.sub(r"\(sg::Params.*", "", n): v for n, v in zip(names, rows.values())}
 
 
 if __name__ == "__main__":
-    p = sys.argv[1] if len(sys.argv) > 1 else "/tmp/isa/sgym.s"
-    if len(sys.argv) <= 1:
-        emit(p)
-    table(p)
+    for n, r in table(sys.argv[1] if len(sys.argv) > 1 else None).items():
+        print(f"{n[:72]:72s} vgpr={r['vgpr']:3d} agpr={r['agpr']:3d} sgpr={r['sgpr']:3d} lds={r['lds']:6d} scratch={r['scratch']}")

@@ -5,7 +5,8 @@
 #   <tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats of the same command
 #   <tag>_hbm_traffic.json   FETCH_SIZE / WRITE_SIZE (separate --pmc passes), summed over the rollout-kernel
 #                            launches of ONE rollout (a long rollout is cut into chunks of steps)
-#   <tag>_pmc_sq.txt         SQ instruction mix per wave-step (tools/pmc_sq.sh)
+#   <tag>_pmc_sq.txt/.json   SQ instruction mix per wave-step (tools/pmc_sq.sh)
+#   latest_<workload>_{hbm_traffic,pmc_sq}.json   the same two records under the names bench.py reads from profiles/
 tag=${1:-r01}; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" && mkdir -p gpurun_out
 python3 bench.py "$@" > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
@@ -25,7 +26,9 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     f = glob.glob(f"gpurun_out/{tag}_pmc_{c}/**/*counter_collection.csv", recursive=True)
     out[c] = sum(float(r["Counter_Value"]) for r in csv.DictReader(open(f[0]))
                  if "rollout_kernel" in r["Kernel_Name"] and r["Counter_Name"] == c)
+wl = "c5" if cfg["entities"] == 256 else ("c2" if cfg["entities"] == 16 else "c3")
 rec = dict(scenarios=cfg["scenarios_per_gpu"], entities=cfg["entities"], sim_steps=cfg["sim_steps"],
+           src_sha16=line["roofline"]["src_sha16"], kernel=line["roofline"]["kernel"],
            fetch_size_kb=out["FETCH_SIZE"], write_size_kb=out["WRITE_SIZE"],
            hbm_bytes_per_rollout=(out["FETCH_SIZE"] + out["WRITE_SIZE"]) * 1024,
            launches_per_rollout=line["roofline"]["launches_per_rollout"],
@@ -34,6 +37,7 @@ rec = dict(scenarios=cfg["scenarios_per_gpu"], entities=cfg["entities"], sim_ste
                 "The kernel's HBM reads are 8 B/lane knot rows and scalar table rows, so the x2 FETCH_SIZE correction "
                 "calibrated for 16-B/lane streams (MI355X_MICROARCH.md, HBM) is NOT applied; reads are 2 % of the traffic.")
 json.dump(rec, open(f"gpurun_out/{tag}_hbm_traffic.json", "w"), indent=1)
+json.dump(rec, open(f"gpurun_out/latest_{wl}_hbm_traffic.json", "w"), indent=1)  # what bench.py looks for under profiles/
 print(rec)
 PY
 bash tools/pmc_sq.sh "$tag" "$@" | cut -c1-400
