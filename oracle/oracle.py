@@ -121,7 +121,9 @@ def raster_map(poses, bbox, ego, net, layers, width=20.0, height=20.0, nw=20, nh
 
 
 class _Config(C.Structure):
-    _fields_ = [("dt", C.c_double), ("persist", C.c_int32), ("terminal_mask", C.c_int32), ("sf", C.c_double * NSF)]
+    _fields_ = [("dt", C.c_double), ("persist", C.c_int32), ("terminal_mask", C.c_int32), ("sf", C.c_double * NSF),
+                ("noise_mode", C.c_int32), ("scenario_index", C.c_int32), ("std_lon", C.c_double), ("std_lat", C.c_double),
+                ("normals", C.c_void_p), ("n_normals", C.c_int64), ("noise_seed", C.c_uint64)]
 
 
 class _Event(C.Structure):
@@ -142,6 +144,7 @@ class _Result(C.Structure):
         ("n_steps", C.c_int32),
         ("done", C.c_int32),
         ("n_events", C.c_int32),
+        ("noise_used", C.c_int64),
     ]
 
 
@@ -182,8 +185,10 @@ def default_kinds(n, ego=0):
 
 def rollout(knot_off, knots, bbox, etype, kind, ego, t0, length, dt, persist=False,
             terminal_mask=TERM_MAX_LENGTH, ctrl=None, actions=None, max_steps=None,
-            force_steps=False, record=True, event_cap=256, route_off=None, routes=None, sf=None, road=None):
-    """One scenario through the oracle.  Returns a dict shaped like make_golden.record_rollout."""
+            force_steps=False, record=True, event_cap=256, route_off=None, routes=None, sf=None, road=None, noise=None):
+    """One scenario through the oracle.  Returns a dict shaped like make_golden.record_rollout.
+    noise: None, or dict(mode="stream", std_lon, std_lat, normals=[...]) / dict(mode="device", std_lon, std_lat, seed,
+    scenario_index): the random fluctuations of SocialForce._step (see sgo_config)."""
     L = lib()
     E = int(len(kind))
     W = (E + 63) // 64
@@ -207,6 +212,16 @@ def rollout(knot_off, knots, bbox, etype, kind, ego, t0, length, dt, persist=Fal
         sc.road = road.ref()
     sf = social_force_params() if sf is None else np.ascontiguousarray(sf, np.float64)
     cfg = _Config(float(dt), int(bool(persist)), int(terminal_mask), (C.c_double * NSF)(*sf))
+    normals = None
+    if noise is not None:
+        cfg.std_lon, cfg.std_lat = float(noise["std_lon"]), float(noise["std_lat"])
+        if noise["mode"] == "stream":
+            normals = np.ascontiguousarray(noise["normals"], np.float64)
+            cfg.noise_mode, cfg.normals, cfg.n_normals = 1, _p(normals), len(normals)
+        elif noise["mode"] == "device":
+            cfg.noise_mode, cfg.noise_seed, cfg.scenario_index = 2, int(noise.get("seed", 0)), int(noise.get("scenario_index", 0))
+        else:
+            raise ValueError(noise["mode"])
     S = max_steps + 1
     out = {}
     rec = None
@@ -231,7 +246,7 @@ def rollout(knot_off, knots, bbox, etype, kind, ego, t0, length, dt, persist=Fal
     for k in list(out):
         out[k] = out[k][: n + 1]
     out.update(
-        n_steps=n, is_done=bool(res.done), final_t=res.final_t,
+        n_steps=n, is_done=bool(res.done), final_t=res.final_t, noise_used=int(res.noise_used),
         metric_ego_avg_speed=res.ego_avg_speed, metric_ego_max_speed=res.ego_max_speed,
         metric_ego_distance_travelled=res.ego_distance, n_events=res.n_events,
         ev_t=np.array([ev[i].t for i in range(min(res.n_events, event_cap))]),
@@ -363,3 +378,20 @@ def batch_eval(knot_off, knots, ts, persist=False):
     pres = np.empty((len(ts), E), np.uint8)
     lib().sgo_batch_eval(_p(knot_off), _p(knots), E, int(persist), _p(ts), len(ts), _p(out), _p(pres))
     return out, pres.astype(bool)
+
+
+def log(x):
+    f = lib().sgo_log
+    f.restype = C.c_double
+    f.argtypes = [C.c_double]
+    return f(float(x))
+
+
+def noise_pair(seed, scenario, entity, step):
+    """The two standard normal variates of the counter-based generator (noise mode "device") for one (scenario, entity, step)."""
+    out = np.empty(2)
+    f = lib().sgo_noise_pair
+    f.restype = None
+    f.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+    f(int(seed), int(scenario), int(entity), int(step), _p(out))
+    return out

@@ -15,6 +15,64 @@
 #define MAXE 1024
 
 /* ------------------------------------------------------------------------------------------
+ * log for the Box-Muller transform of noise_mode 2: the classic Sun fdlibm __ieee754_log restated
+ * (argument reduction to [sqrt(2)/2, sqrt(2)], degree-14 minimax in s = f / (2 + f)); domain: finite
+ * normal x > 0.  Shared by restatement with the device (sg_log): plain add / mul / div only.
+ * ---------------------------------------------------------------------------------------- */
+double sgo_log(double x)
+{
+    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
+                 Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
+                 Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+                 Lg7 = 1.479819860511658591e-01;
+    uint64_t bits;
+    memcpy(&bits, &x, 8);
+    int32_t hx = (int32_t)(bits >> 32);
+    int k = (hx >> 20) - 1023;
+    hx &= 0x000fffff;
+    const int32_t i0 = (hx + 0x95f64) & 0x100000;
+    bits = ((uint64_t)(uint32_t)(hx | (i0 ^ 0x3ff00000)) << 32) | (bits & 0xffffffffu); /* normalize x or x/2 */
+    memcpy(&x, &bits, 8);
+    k += i0 >> 20;
+    const double f = x - 1.0, dk = (double)k;
+    if ((0x000fffff & (2 + hx)) < 3) { /* |f| < 2**-20 */
+        if (f == 0.0) return k == 0 ? 0.0 : dk * ln2_hi + dk * ln2_lo;
+        const double R = f * f * (0.5 - 0.33333333333333333 * f);
+        return k == 0 ? f - R : dk * ln2_hi - ((R - dk * ln2_lo) - f);
+    }
+    const double s = f / (2.0 + f), z = s * s, w = z * z;
+    const int32_t i = (hx - 0x6147a) | (0x6b851 - hx);
+    const double t1 = w * (Lg2 + w * (Lg4 + w * Lg6)), t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
+    const double R = t2 + t1;
+    if (i > 0) {
+        const double hfsq = 0.5 * f * f;
+        return k == 0 ? f - (hfsq - s * (hfsq + R)) : dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
+    }
+    return k == 0 ? f - s * (f - R) : dk * ln2_hi - ((s * (f - R) - dk * ln2_lo) - f);
+}
+
+/* Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11): counter (entity, step, 0, 0),
+ * key (seed_lo ^ scenario, seed_hi).  Two 53-bit uniforms in (0, 1) from the four output words, Box-Muller. */
+void sgo_noise_pair(uint64_t seed, uint32_t scenario, uint32_t entity, uint32_t step, double *z2)
+{
+    uint32_t c0 = entity, c1 = step, c2 = 0, c3 = 0, k0 = (uint32_t)seed ^ scenario, k1 = (uint32_t)(seed >> 32);
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    const double u1 = ((double)((((uint64_t)c0 << 32) | c1) >> 11) + 0.5) * 0x1p-53;
+    const double u2 = ((double)((((uint64_t)c2 << 32) | c3) >> 11) + 0.5) * 0x1p-53;
+    const double r = sqrt(-2.0 * sgo_log(u1));
+    double sn, cs;
+    sgo_sincos(6.28318530717958623200e+00 * u2, &sn, &cs);
+    z2[0] = r * cs;
+    z2[1] = r * sn;
+}
+
+/* ------------------------------------------------------------------------------------------
  * sin/cos.  numpy's np.cos/np.sin (entity/base.py:113, controller.py:126-127) are platform
  * SIMD routines accurate to <1 ulp but not bit-reproducible across libms.  The oracle and the
  * HIP kernels therefore both use this fixed plain-fp64 algorithm (two-step Cody-Waite
@@ -862,7 +920,8 @@ typedef struct { double speed; int goal_idx; double fx, fy; } ped_state;
 
 /* one PedestrianAgent.step: returns the new pose in np_ */
 static void ped_step(const sgo_scenario *sc, const sgo_config *cfg, int i, const double *poses, const double *vels,
-                     const uint8_t *present, double t, double next_t, double state_dt, ped_state *ps, double *np_)
+                     const uint8_t *present, double t, double next_t, double state_dt, ped_state *ps, double *np_,
+                     int step_index, int64_t *noise_pos)
 {
     const int E = sc->n_entities;
     const double *sf = cfg->sf, *ct = sc->ctrl + (size_t)i * SGO_NCTRL;
@@ -947,9 +1006,22 @@ static void ped_step(const sgo_scenario *sc, const sgo_config *cfg, int i, const
                 }
             }
         }
-        /* noise is off: np.random.normal(bias, 0) == bias */
-        speed = fmin(norm2(fx, fy) + sf[SGO_SF_BIAS_LON], vdes * sf[SGO_SF_MAX_SPEED_FACTOR]);
-        heading = sgo_atan2(fy, fx) + sf[SGO_SF_BIAS_LAT];
+        /* random fluctuations, social_force.py:106-108: np.random.normal(loc, scale) = loc + scale * z; std 0: == bias */
+        double speed_rand = sf[SGO_SF_BIAS_LON], heading_rand = sf[SGO_SF_BIAS_LAT];
+        if (cfg->noise_mode == 1) {
+            const int64_t k = *noise_pos;
+            const double z0 = k + 1 < cfg->n_normals ? cfg->normals[k] : 0.0, z1 = k + 1 < cfg->n_normals ? cfg->normals[k + 1] : 0.0;
+            *noise_pos = k + 2;
+            speed_rand = sf[SGO_SF_BIAS_LON] + cfg->std_lon * z0;
+            heading_rand = sf[SGO_SF_BIAS_LAT] + cfg->std_lat * z1;
+        } else if (cfg->noise_mode == 2) {
+            double z[2];
+            sgo_noise_pair(cfg->noise_seed, (uint32_t)cfg->scenario_index, (uint32_t)i, (uint32_t)step_index, z);
+            speed_rand = sf[SGO_SF_BIAS_LON] + cfg->std_lon * z[0];
+            heading_rand = sf[SGO_SF_BIAS_LAT] + cfg->std_lat * z[1];
+        }
+        speed = fmin(norm2(fx, fy) + speed_rand, vdes * sf[SGO_SF_MAX_SPEED_FACTOR]);
+        heading = sgo_atan2(fy, fx) + heading_rand;
         ps->fx = fx;
         ps->fy = fy;
     } else { /* reached the goal, agent.py:65-68 */
@@ -1309,6 +1381,7 @@ int sgo_rollout(const sgo_scenario *sc, const sgo_config *cfg, int max_steps, in
         avg = vmax = norm3(v[0], v[1], v[2]);
     }
     int n_events = 0, n_steps = 0, done = 0;
+    int64_t noise_pos = 0;
     memset(last_row, 0, (size_t)W * 8);
     detect_collisions(E, W, present, poses, sc->bbox, rows, mult, scratch);
 
@@ -1361,7 +1434,7 @@ int sgo_rollout(const sgo_scenario *sc, const sgo_config *cfg, int max_steps, in
             case SGO_KIND_AGENT_PEDESTRIAN:
                 if (present[i]) { /* scenario_gym.py:234-239 */
                     if (sc->kind[i] == SGO_KIND_AGENT_PEDESTRIAN) {
-                        ped_step(sc, cfg, i, poses, vels, present, t, next_t, state_dt, &ps[i], np_);
+                        ped_step(sc, cfg, i, poses, vels, present, t, next_t, state_dt, &ps[i], np_, n_steps, &noise_pos);
                     } else if (sc->kind[i] == SGO_KIND_AGENT_REPLAY) {
                         sgo_position_at_t(KN(i), n, next_t, 0, 0, 0, np_); /* agent.py:125-128 */
                     } else {
@@ -1457,6 +1530,7 @@ int sgo_rollout(const sgo_scenario *sc, const sgo_config *cfg, int max_steps, in
         res->ego_max_speed = vmax;
         res->ego_distance = ego_dist;
         res->n_steps = n_steps;
+        res->noise_used = noise_pos;
         res->done = done;
         res->n_events = n_events;
     }

@@ -70,8 +70,12 @@ class LineString(BaseGeometry):
         best, best_s, acc = None, 0.0, 0.0
         for a, b in zip(c[:-1], c[1:]):
             d = b - a
-            L2 = float(d @ d)
-            u = 0.0 if L2 == 0 else min(1.0, max(0.0, float((p - a) @ d) / L2))
+            # GEOS arithmetic (LineSegment::projectionFactor, Coordinate::distance): plain products and sums.  numpy's
+            # `@` on 2-vectors is a BLAS dot (an fma chain on this box) and can differ by one ulp -- enough to make the
+            # projection of a point beyond the end of the line come out one ulp SHORT of the line's own length, which
+            # PedestrianAgent compares with np.linalg.norm-based arc lengths (pedestrian/agent.py:59-62).
+            L2 = float(d[0] * d[0] + d[1] * d[1])
+            u = 0.0 if L2 == 0 else min(1.0, max(0.0, float((p[0] - a[0]) * d[0] + (p[1] - a[1]) * d[1]) / L2))
             q = a + u * d
             dist = float(np.hypot(*(p - q)))
             if best is None or dist < best:

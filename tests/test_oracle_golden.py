@@ -517,3 +517,49 @@ def test_rss_distances_and_metric_match_reference(oracle):
         assert r["safe_longitudinal"] == bool(g[f"{n}/safe_longitudinal"]) and r["safe_lateral"] == bool(g[f"{n}/safe_lateral"]), n
         n_unsafe += (want_code == 4).sum() + (want_code == 5).sum()
     assert n_unsafe > 30
+
+
+@pytest.mark.parametrize("si", [0, 1, 2])
+def test_pedestrian_noise_closed_loops(oracle, si):
+    """The random fluctuations of SocialForce._step (pedestrian/social_force.py:106-114): closed loops of the reference
+    with std_lon / std_lat > 0 after np.random.seed(k) (the third one with the reference's DEFAULT std).  The oracle
+    consumes the same legacy stream -- np.random.RandomState(k).standard_normal -- two variates per walking pedestrian per
+    step in agent order, and lands on the reference's trajectories; it consumes exactly as many variates as numpy did."""
+    g = load_golden("ped_noise")
+    sc, kind, ctrl, roff, routes = ped_inputs(g, si, oracle)
+    E = len(kind)
+    std_lon, std_lat, seed = g[f"loop{si}/noise"]
+    used = int(g[f"loop{si}/variates_used"])
+    normals = np.random.RandomState(int(seed)).standard_normal(used + 64)
+    p = f"loop{si}/dt30"
+    o = oracle.rollout(**sc, kind=kind, dt=1 / 30, ctrl=ctrl, route_off=roff, routes=routes,
+                       noise=dict(mode="stream", std_lon=std_lon, std_lat=std_lat, normals=normals))
+    assert o["n_steps"] == int(g[p + "/n_steps"]) and bits_equal(o["t"], g[p + "/t"])
+    assert o["noise_used"] == used
+    for k in ("poses", "vels", "dists"):
+        assert np.array_equal(np.isnan(o[k]), np.isnan(g[p + "/" + k]))
+        assert np.nanmax(np.abs(o[k] - g[p + "/" + k])) < PED_TOL, (p, k)
+    ex = g[p + "/extra"]
+    ped = ~np.isnan(ex[0, :, 0])
+    assert np.array_equal(o["extra"][:, ped, 1], ex[:, ped, 1])              # goal_idx exact
+    assert np.abs(o["extra"][:, ped] - ex[:, ped]).max() < PED_TOL           # speed, force
+    assert np.array_equal(oracle.coll_to_dense(o["coll"], E), g[p + "/coll"])
+    assert np.array_equal(o["ev_t"], g[p + "/ev_t"]) and np.array_equal(o["ev_other"], g[p + "/ev_other"])
+    # without the noise the trajectories differ (the test would pass trivially otherwise)
+    o0 = oracle.rollout(**sc, kind=kind, dt=1 / 30, ctrl=ctrl, route_off=roff, routes=routes)
+    assert np.nanmax(np.abs(o0["poses"][: o["n_steps"] + 1] - o["poses"])) > (1e-3 if si < 2 else 1e-9)
+
+
+def test_counter_based_noise_generator(oracle):
+    """The timing-run generator (noise mode "device": Philox4x32-10 + Box-Muller with the shared log / sin / cos): standard
+    normal moments over 2 x 10^5 variates, no correlation between the two outputs, different streams per scenario, and
+    log within 1 ulp of libm."""
+    import math
+
+    z = np.array([oracle.noise_pair(2024, s, e, k) for s in range(8) for e in range(64) for k in range(200)])
+    assert abs(z.mean()) < 0.01 and abs(z.std() - 1.0) < 0.01 and abs(np.corrcoef(z.T)[0, 1]) < 0.01
+    assert abs((z ** 3).mean()) < 0.03 and abs((z ** 4).mean() - 3.0) < 0.1
+    assert not np.array_equal(oracle.noise_pair(1, 0, 3, 5), oracle.noise_pair(1, 1, 3, 5))
+    assert np.array_equal(oracle.noise_pair(1, 0, 3, 5), oracle.noise_pair(1, 0, 3, 5))
+    for x in np.concatenate([np.random.default_rng(0).uniform(1e-16, 1, 3000), np.random.default_rng(1).uniform(0.5, 2, 3000)]):
+        assert abs(oracle.log(x) - math.log(x)) <= np.spacing(abs(math.log(x)))
