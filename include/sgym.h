@@ -130,8 +130,8 @@ typedef struct {
 } sg_scenarios;
 
 /* SocialForceParameters (pedestrian/social_force.py:16-30; behaviour.py max_speed_factor; random_walk.py bias):
- * one set per handle.  The Gaussian noise of the reference (np.random.normal on the global numpy RNG,
- * social_force.py:107-108) is not reproduced: std_lon = std_lat = 0. */
+ * one set per handle.  The Gaussian noise terms (std_lon, std_lat; social_force.py:106-108) are set with
+ * sg_set_ped_noise; without that call they are off (std 0: np.random.normal(b, 0) == b). */
 typedef struct {
     double relaxation_time, ped_repulse_V, ped_repulse_sigma, ped_attract_C;
     double sight_weight, sight_weight_use;
@@ -176,7 +176,7 @@ typedef struct {
     int32_t n_steps;               /* steps since reset */
     int32_t n_events;              /* len(CollisionMetric.collisions) */
     int32_t rec_rows;              /* rows written to the pose record */
-    int64_t reserved;
+    int64_t noise_pos;             /* variates of the scenario's noise stream consumed so far (sg_set_ped_noise, SG_NOISE_STREAM) */
 } sg_scenario_state;               /* 104 bytes */
 
 typedef struct {
@@ -223,6 +223,25 @@ int sg_upload(sg_handle *h, const sg_scenarios *sc);
 
 /* SocialForce(params) shared by every pedestrian agent of the handle; call before sg_upload (defaults otherwise) */
 int sg_set_social_force(sg_handle *h, const sg_social_force *params);
+
+/* The random fluctuations of SocialForce._step (pedestrian/social_force.py:106-114): every pedestrian that is still
+ * walking adds np.random.normal(bias_lon, std_lon) to its speed and np.random.normal(bias_lat, std_lat) to its heading, in
+ * agent (entity) order, from numpy's global legacy generator: loc + scale * z.
+ *   SG_NOISE_OFF     std = 0.
+ *   SG_NOISE_STREAM  parity runs.  normals: HOST [n_scenarios][per_scenario] standard normal variates, copied by the call;
+ *                    scenario r consumes row r in order, two per walking pedestrian per step -- with row r =
+ *                    np.random.RandomState(k_r).standard_normal(n) the scenario reproduces the reference's rollout after
+ *                    np.random.seed(k_r).  A reset rewinds the rows of the scenarios it resets.  A scenario that runs out of
+ *                    variates makes sg_read_metrics fail with SG_ERR_CAPACITY (its later draws were taken as 0).
+ *   SG_NOISE_DEVICE  timing / production runs: a counter-based generator on the device -- Philox4x32-10 keyed by
+ *                    (seed, scenario) at counter (entity, step), Box-Muller in fp64 -- the same distribution, its own
+ *                    stream, no state, no host traffic.  normals / per_scenario are ignored.
+ * May be called before or after sg_upload; stays in force until the next call. */
+#define SG_NOISE_OFF 0
+#define SG_NOISE_STREAM 1
+#define SG_NOISE_DEVICE 2
+int sg_set_ped_noise(sg_handle *h, int32_t mode, double std_lon, double std_lat, const double *normals, int64_t per_scenario,
+                     uint64_t seed);
 
 /* ScenarioGym.reset_scenario -> State.reset(t0), Controller.reset, Metric.reset (scenario_gym.py:217-225) */
 int sg_reset(sg_handle *h);

@@ -309,9 +309,15 @@ class BehaviourParameters:
 
 
 class SocialForceParameters(BehaviourParameters):
-    """pedestrian/social_force.py:16-30 + random_walk.py:13-19.  The Gaussian noise terms
-    (std_lon / std_lat, drawn from the global numpy RNG in the reference) are not reproduced on the
-    device: construct with std_lon=0, std_lat=0 (the device path refuses anything else)."""
+    """pedestrian/social_force.py:16-30 + random_walk.py:13-19.
+
+    The Gaussian fluctuations (std_lon / std_lat; the reference draws them from numpy's global generator,
+    social_force.py:106-108) run on the device.  Two extra attributes choose where the variates come from:
+      noise = "device" (default)  a counter-based generator on the GPU keyed by (noise_seed, scenario, entity, step):
+                                  the same distribution, its own stream;
+      noise = "numpy"             parity with a reference run: scenario i of the batch uses the variates numpy's legacy
+                                  generator hands out after np.random.seed(noise_seed + i)
+                                  (noise_seed may also be a sequence, one seed per scenario)."""
 
     bias_lon = 0.0
     bias_lat = 0.0
@@ -329,6 +335,8 @@ class SocialForceParameters(BehaviourParameters):
     boundary_repulse_R = 0.2
     imp_boundary_repulse_U = 2.0
     imp_boundary_repulse_R = 0.1
+    noise = "device"
+    noise_seed = 0
 
 
 class SocialForce:
@@ -340,13 +348,16 @@ class SocialForce:
 
     def device_params(self) -> dict:
         p = self.params
-        if p.std_lon != 0 or p.std_lat != 0:
-            raise NotImplementedError("the device social force is deterministic: use std_lon=0, std_lat=0")
+        noisy = p.std_lon != 0 or p.std_lat != 0
+        if noisy and p.noise not in ("device", "numpy"):
+            raise ValueError(f"SocialForceParameters.noise = {p.noise!r}: 'device' or 'numpy'")
         return dict(relaxation_time=p.relaxation_time, ped_repulse_V=p.ped_repulse_V,
                     ped_repulse_sigma=p.ped_repulse_sigma, ped_attract_C=p.ped_attract_C,
                     sight_weight=p.sight_weight, sight_weight_use=p.sight_weight_use, sight_angle=p.sight_angle,
                     max_speed_factor=p.max_speed_factor, bias_lon=p.bias_lon, bias_lat=p.bias_lat,
-                    imp_boundary_repulse_U=p.imp_boundary_repulse_U, imp_boundary_repulse_R=p.imp_boundary_repulse_R)
+                    imp_boundary_repulse_U=p.imp_boundary_repulse_U, imp_boundary_repulse_R=p.imp_boundary_repulse_R,
+                    std_lon=p.std_lon, std_lat=p.std_lat,
+                    noise=("off" if not noisy else ("stream" if p.noise == "numpy" else "device")), noise_seed=p.noise_seed)
 
 
 class PedestrianSensor(Sensor):

@@ -109,6 +109,13 @@ struct Params {
     const RoadIndex *road;   // device copy of the road index, nullptr = no road networks set
     int ped_serial;          // 1: pedestrian pair loop one pedestrian per lane (env SG_PED_SERIAL; default 0: balanced over the wavefront)
     int tab_steps;           // steps per table chunk (rows per lane = tab_steps + 1: the prefetch of the last step reads one row ahead)
+    // random fluctuations of the social force (sg_set_ped_noise): 0 off, 1 stream of standard normal variates per scenario,
+    // 2 counter-based generator
+    int noise_mode;
+    double noise_std_lon, noise_std_lat;
+    const double *noise_normals; // [R][noise_len]
+    long long noise_len;
+    unsigned long long noise_seed;
 #ifdef SG_PHASE_TIMERS
     unsigned long long *phase_cycles; // [16] experiment builds: s_memtime cycles per phase of the step, summed over wavefronts
 #endif
@@ -725,6 +732,61 @@ __device__ __forceinline__ void ped_pair(AR &A, const sg_social_force &sf, doubl
         c1x = repx; c1y = repy;
         c2x = attx; c2y = atty;
     }
+}
+
+// log for the Box-Muller transform of the counter-based noise generator: fdlibm's __ieee754_log restated, domain finite
+// normal x > 0; the same operation sequence as the oracle's sgo_log.
+__device__ __forceinline__ double sg_log(double x)
+{
+    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
+                 Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
+                 Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+                 Lg7 = 1.479819860511658591e-01;
+    int hx = __double2hiint(x);
+    int k = (hx >> 20) - 1023;
+    hx &= 0x000fffff;
+    const int i0 = (hx + 0x95f64) & 0x100000;
+    x = __hiloint2double(hx | (i0 ^ 0x3ff00000), __double2loint(x)); // normalize x or x/2
+    k += i0 >> 20;
+    const double f = x - 1.0, dk = (double)k;
+    if ((0x000fffff & (2 + hx)) < 3) { // |f| < 2**-20
+        if (f == 0.0) return k == 0 ? 0.0 : dk * ln2_hi + dk * ln2_lo;
+        const double R = f * f * (0.5 - 0.33333333333333333 * f);
+        return k == 0 ? f - R : dk * ln2_hi - ((R - dk * ln2_lo) - f);
+    }
+    const double s = f / (2.0 + f), z = s * s, w = z * z;
+    const int i = (hx - 0x6147a) | (0x6b851 - hx);
+    const double t1 = w * (Lg2 + w * (Lg4 + w * Lg6)), t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
+    const double R = t2 + t1;
+    if (i > 0) {
+        const double hfsq = 0.5 * f * f;
+        return k == 0 ? f - (hfsq - s * (hfsq + R)) : dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
+    }
+    return k == 0 ? f - s * (f - R) : dk * ln2_hi - ((s * (f - R) - dk * ln2_lo) - f);
+}
+
+// The two standard normal variates of noise mode 2 for (seed, scenario, entity, step): Philox4x32-10 (Salmon et al., SC'11)
+// at counter (entity, step, 0, 0) under key (seed_lo ^ scenario, seed_hi), two 53-bit uniforms in (0, 1), Box-Muller.
+// Same operation sequence as the oracle's sgo_noise_pair.
+__device__ __forceinline__ void sg_noise_pair(unsigned long long seed, uint32_t scenario, uint32_t entity, uint32_t step,
+                                              double &z0, double &z1, ConstTbl K)
+{
+    uint32_t c0 = entity, c1 = step, c2 = 0, c3 = 0, k0 = (uint32_t)seed ^ scenario, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    const double u1 = ((double)((((uint64_t)c0 << 32) | c1) >> 11) + 0.5) * 0x1p-53;
+    const double u2 = ((double)((((uint64_t)c2 << 32) | c3) >> 11) + 0.5) * 0x1p-53;
+    const double r = __builtin_sqrt(-2.0 * sg_log(u1));
+    double sn, cs;
+    sg_sincos(6.28318530717958623200e+00 * u2, sn, cs, K);
+    z0 = r * cs;
+    z1 = r * sn;
 }
 
 __device__ __forceinline__ double sg_atan_pos(double ax)
@@ -1548,15 +1610,16 @@ __device__ __forceinline__ void ped_force(const Params &p, LDS &L, int r, int sl
 
 // PedestrianAgent.step, part 2 (one lane): speed and heading from the force (:110-114, or zero at the goal,
 // agent.py:65-68) + PedestrianController._step (pedestrian/controller.py:25-46).
+// speed_rand / heading_rand: the random fluctuations np.random.normal(bias, std) of :106-108 (== the bias when std is 0).
 __device__ __forceinline__ void ped_move(const Params &p, bool go, double fx, double fy, double vdes, double maxs,
                                          const double *pose, double state_dt, double &cspeed, double &fxo, double &fyo,
-                                         double *np_, ConstTbl K)
+                                         double *np_, ConstTbl K, double speed_rand, double heading_rand)
 {
     const sg_social_force &sf = p.sf;
     double speed = 0.0, heading = 0.0;
     if (go) {
-        speed = __builtin_fmin(sg_norm2(fx, fy) + sf.bias_lon, vdes * sf.max_speed_factor);
-        heading = sg_atan2(fy, fx) + sf.bias_lat;
+        speed = __builtin_fmin(sg_norm2(fx, fy) + speed_rand, vdes * sf.max_speed_factor);
+        heading = sg_atan2(fy, fx) + heading_rand;
         fxo = fx;
         fyo = fy;
     } else {
@@ -2330,6 +2393,7 @@ __device__ __forceinline__ void rollout_body(
     CtrlState cs;                 // controller state (agent lanes); pedestrians: speed, goal_idx
     double m_avg, m_max, m_t;     // ego metric accumulators (ego lane)
     uint64_t last_row[WV];        // CollisionMetric.last_timestep (ego lane)
+    long long noise_pos = 0;      // variates of the scenario's noise stream consumed so far (PED, noise mode 1)
     int n_ev, goal_idx = 0;
     bool present;
     int done, steps;
@@ -2420,6 +2484,7 @@ __device__ __forceinline__ void rollout_body(
 #pragma unroll
         for (int w = 0; w < WV; ++w) last_row[w] = 0; // metrics/collision.py:64-68
         n_ev = 0;
+        noise_pos = 0;
     } else {
         t = sd.t;
         prev_t = sd.prev_t;
@@ -2438,6 +2503,7 @@ __device__ __forceinline__ void rollout_body(
 #pragma unroll
         for (int w = 0; w < WV; ++w) last_row[w] = sd.last_row[w];
         n_ev = sd.n_events;
+        noise_pos = PED ? sd.noise_pos : 0;
         done = sd.done;
         steps = sd.n_steps;
 #pragma unroll
@@ -2604,6 +2670,46 @@ __device__ __forceinline__ void rollout_body(
         if (PED) // the social force of every stepping pedestrian of the wavefront (wave-collective)
             ped_force<WV, CROWD>(p, lds, (int)r, sl, tile0, nbr, is_agent && kind == SG_KIND_AGENT_PEDESTRIAN && present && run, pose,
                                  velx, vely, wp, nwp, goal_idx, ped_go, ped_fx, ped_fy, ped_vdes, K, crowd_static_ok && crowd_ok, CC, &ptm);
+        // random fluctuations of the speed and the heading (social_force.py:106-108): np.random.normal(loc, scale) is
+        // loc + scale * z; z from the scenario's stream of variates -- two per walking pedestrian, in agent order, as the
+        // reference draws them from numpy's global generator -- or from the counter-based generator
+        double speed_rand = p.sf.bias_lon, heading_rand = p.sf.bias_lat;
+        if (PED && p.noise_mode == 1) { // (launch-uniform branch)
+            const uint64_t walk = __ballot(ped_go);
+            int before, count;
+            if (WV == 1) {
+                uint64_t m = walk >> tile0;
+                if (G < 64) m &= (1ull << (G & 63)) - 1;
+                before = __builtin_popcountll(m & ((1ull << (slot & 63)) - 1));
+                count = __builtin_popcountll(m);
+            } else { // walkers in the wavefronts before this one: through the fourth vote row
+                if (lane == 0) lds.vote[3][wave] = __builtin_popcountll(walk);
+                __syncthreads();
+                before = __builtin_popcountll(walk & ((1ull << lane) - 1));
+                count = 0;
+#pragma unroll
+                for (int w = 0; w < WV; ++w) {
+                    const int c = lds.vote[3][w];
+                    before += w < wave ? c : 0;
+                    count += c;
+                }
+                __syncthreads(); // (the row is rewritten next step; stream runs are parity runs, not timing runs)
+            }
+            const long long at = noise_pos + 2 * before;
+            if (ped_go) {
+                const bool inside = at + 1 < p.noise_len;
+                const double *z = p.noise_normals + (size_t)r * (size_t)p.noise_len + (inside ? at : 0);
+                speed_rand = p.sf.bias_lon + p.noise_std_lon * (inside ? z[0] : 0.0);
+                heading_rand = p.sf.bias_lat + p.noise_std_lat * (inside ? z[1] : 0.0);
+                sg_loads_done();
+            }
+            if (run) noise_pos += 2 * count;
+        } else if (PED && p.noise_mode == 2) {
+            double z0, z1;
+            sg_noise_pair(p.noise_seed, r, (uint32_t)slot, (uint32_t)steps, z0, z1, K);
+            speed_rand = p.sf.bias_lon + p.noise_std_lon * z0;
+            heading_rand = p.sf.bias_lat + p.noise_std_lat * z1;
+        }
         if (TAB) {
             // Straight-line lane masks (the kernel is bound by instruction issue, branches included):
             // BatchReplayEntity.step (batch.py:34-53) for replay lanes; an agent stays once present and spawns at its
@@ -2633,7 +2739,7 @@ __device__ __forceinline__ void rollout_body(
                     npres = true;
                     if (run)
                         ped_move(p, ped_go, ped_fx, ped_fy, ped_vdes, lds.ctrl[PED ? SG_C_PED_MAX_SPEED - SG_C_PED_SPEED_DESIRED : 0][sl],
-                                 pose, state_dt, cs.speed, fpx, fpy, np_, K);
+                                 pose, state_dt, cs.speed, fpx, fpy, np_, K, speed_rand, heading_rand);
                 } else if (min_t >= t) { // scenario_gym.py:240-244: spawn at the trajectory position of next_t (clamped)
                     npres = true;
                     LanePtr st_o = st;
@@ -2688,7 +2794,7 @@ __device__ __forceinline__ void rollout_body(
                     } else if (PED)
                         ped_move(p, ped_go, ped_fx, ped_fy, ped_vdes,
                                  lds.ctrl[PED ? SG_C_PED_MAX_SPEED - SG_C_PED_SPEED_DESIRED : 0][sl], pose, state_dt,
-                                 cs.speed, fpx, fpy, np_, K);
+                                 cs.speed, fpx, fpy, np_, K, speed_rand, heading_rand);
                 }
             } else if (min_t >= t) { // scenario_gym.py:240-244: spawn at trajectory start
                 npres = true;
@@ -2924,7 +3030,7 @@ __device__ __forceinline__ void rollout_body(
             stf(dy, SG_F_CTRL + 0, cs.speed); stf(dy, SG_F_CTRL + 1, cs.e_lon_prev);
             stf(dy, SG_F_CTRL + 2, cs.e_lat_prev); stf(dy, SG_F_CTRL + 3, cs.e_lon_int);
         }
-        if (slot == 0) { sd.t = t; sd.prev_t = prev_t; sd.done = done; sd.n_steps = steps; }
+        if (slot == 0) { sd.t = t; sd.prev_t = prev_t; sd.done = done; sd.n_steps = steps; if (PED) sd.noise_pos = noise_pos; }
         if (RSSV) {
             if (slot < p.E) {
                 p.rss_state[rss_idx] = rss_st;

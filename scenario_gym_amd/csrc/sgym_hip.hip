@@ -25,6 +25,11 @@ struct sg_handle {
     bool all_ped = false;     // every entity of the batch is a pedestrian agent of catalog type Pedestrian (or padding)
     int crowd_kernel = 1;     // env SG_CROWD_KERNEL=0: all-pedestrian batches take the general pedestrian variant too
     sg_social_force sf{};
+    int noise_mode = 0;           // sg_set_ped_noise
+    double noise_std[2] = {0.0, 0.0};
+    double *d_normals = nullptr;  // [R][noise_len]
+    long long noise_len = 0;
+    unsigned long long noise_seed = 0;
     double *d_gon = nullptr;
     size_t NE = 0; // padded entity count
     bool uploaded = false;
@@ -222,6 +227,7 @@ extern "C" int sg_destroy(sg_handle *h)
     if (h->ctl_stream) (void)hipStreamSynchronize(h->ctl_stream);
     if (h->d_actions) (void)hipFree(h->d_actions);
     if (h->d_gon) (void)hipFree(h->d_gon);
+    if (h->d_normals) (void)hipFree(h->d_normals);
     for (int b = 0; b < 2; ++b)
         if (h->d_tab[b]) (void)hipFree(h->d_tab[b]);
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
@@ -403,6 +409,43 @@ extern "C" int sg_set_social_force(sg_handle *h, const sg_social_force *params)
     return SG_OK;
 }
 
+static void apply_noise(sg_handle *h)
+{
+    h->p.noise_mode = h->noise_mode;
+    h->p.noise_std_lon = h->noise_std[0];
+    h->p.noise_std_lat = h->noise_std[1];
+    h->p.noise_normals = h->d_normals;
+    h->p.noise_len = h->noise_len;
+    h->p.noise_seed = h->noise_seed;
+}
+
+extern "C" int sg_set_ped_noise(sg_handle *h, int32_t mode, double std_lon, double std_lat, const double *normals,
+                                int64_t per_scenario, uint64_t seed)
+{
+    if (!h) return SG_ERR_INVALID;
+    if (mode < SG_NOISE_OFF || mode > SG_NOISE_DEVICE) return fail(h, SG_ERR_INVALID, "sg_set_ped_noise: unknown mode %d", mode);
+    if (!(std_lon >= 0.0) || !(std_lat >= 0.0)) return fail(h, SG_ERR_INVALID, "sg_set_ped_noise: std must be >= 0");
+    if (mode == SG_NOISE_STREAM && (!normals || per_scenario < 2))
+        return fail(h, SG_ERR_INVALID, "sg_set_ped_noise: SG_NOISE_STREAM needs [n_scenarios][per_scenario >= 2] variates");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (h->d_normals) { (void)hipFree(h->d_normals); h->d_normals = nullptr; }
+    h->noise_len = 0;
+    if (mode == SG_NOISE_STREAM) {
+        const size_t n = (size_t)h->R * (size_t)per_scenario;
+        HIP_TRY(h, hipMalloc((void **)&h->d_normals, n * sizeof(double)));
+        HIP_TRY(h, hipMemcpy(h->d_normals, normals, n * sizeof(double), hipMemcpyHostToDevice));
+        h->noise_len = per_scenario;
+    }
+    h->noise_mode = mode;
+    h->noise_std[0] = mode == SG_NOISE_OFF ? 0.0 : std_lon;
+    h->noise_std[1] = mode == SG_NOISE_OFF ? 0.0 : std_lat;
+    h->noise_seed = seed;
+    apply_noise(h);
+    ++h->generation;
+    return SG_OK;
+}
+
 extern "C" int sg_upload(sg_handle *h, const sg_scenarios *sc)
 {
     if (!h || !sc) return SG_ERR_INVALID;
@@ -578,6 +621,7 @@ extern "C" int sg_upload(sg_handle *h, const sg_scenarios *sc)
     p.R = R; p.E = E; p.EP = EP;
     p.WV = h->WV; p.FROWS = SG_F_COLL + h->WV;
     p.sf = h->sf;
+    apply_noise(h);
     p.ped_serial = h->ped_serial;
     p.reset_mask = h->d_reset_mask;
     p.persist = h->cfg.persist;
@@ -956,6 +1000,9 @@ extern "C" int sg_read_metrics(sg_handle *h, sg_metrics *out, sg_event *events, 
         out[r].final_t = sd[r].t; out[r].n_steps = sd[r].n_steps; out[r].done = sd[r].done;
         out[r].n_collisions = sd[r].n_events;
         out[r].reserved = 0;
+        if (h->noise_mode == SG_NOISE_STREAM && h->has_ped && sd[r].noise_pos > h->noise_len)
+            return fail(h, SG_ERR_CAPACITY, "sg_read_metrics: scenario %d needed %lld noise variates, the stream of sg_set_ped_noise holds %lld",
+                        r, (long long)sd[r].noise_pos, (long long)h->noise_len);
         if (sd[r].n_events > p.ev_cap) overflow = true;
         total += std::min(sd[r].n_events, p.ev_cap);
     }

@@ -14,7 +14,7 @@ TERMINAL_BITS = {"max_length": L.TERM_MAX_LENGTH, "collision": L.TERM_COLLISION,
 SCEN_DTYPE = np.dtype([  # sg_scenario_state
     ("t", "f8"), ("prev_t", "f8"), ("ego_avg_speed", "f8"), ("ego_max_speed", "f8"), ("avg_t", "f8"),
     ("ego_distance_travelled", "f8"), ("last_row", "u8", (4,)), ("done", "i4"), ("n_steps", "i4"),
-    ("n_events", "i4"), ("rec_rows", "i4"), ("reserved", "i8")])
+    ("n_events", "i4"), ("rec_rows", "i4"), ("noise_pos", "i8")])
 
 # + PedestrianAgent / PedestrianController defaults (pedestrian/agent.py:18-27): speed_desired (set per agent),
 # max_speed 5.0, head_rot_angle 0.0, distance_threshold 1.0
@@ -101,13 +101,31 @@ class RolloutEngine:
 
     def set_social_force(self, relaxation_time=1.5, ped_repulse_V=1.0, ped_repulse_sigma=1.0, ped_attract_C=0.0,
                          sight_weight=0.5, sight_weight_use=True, sight_angle=200, max_speed_factor=1.3,
-                         bias_lon=0.0, bias_lat=0.0, imp_boundary_repulse_U=2.0, imp_boundary_repulse_R=0.1):
+                         bias_lon=0.0, bias_lat=0.0, imp_boundary_repulse_U=2.0, imp_boundary_repulse_R=0.1,
+                         std_lon=0.0, std_lat=0.0, noise=None, noise_seed=0, normals=None):
         """SocialForceParameters of every pedestrian agent on this handle (pedestrian/social_force.py:16-30);
-        call before upload()."""
+        call before upload().  std_lon / std_lat with noise="device" (counter-based generator on the GPU, the default when
+        a std is non-zero) or noise="stream" + normals[R, n] (the variates numpy's legacy generator would hand out:
+        np.random.RandomState(k).standard_normal(n) per scenario) are the random fluctuations of :106-108."""
         sf = L.SgSocialForce(relaxation_time, ped_repulse_V, ped_repulse_sigma, ped_attract_C, sight_weight,
                              float(bool(sight_weight_use)), float(np.cos(sight_angle / 2 * np.pi / 180)),
                              max_speed_factor, bias_lon, bias_lat, imp_boundary_repulse_U, imp_boundary_repulse_R)
         self._check(self.lib.sg_set_social_force(self.h, C.byref(sf)), "sg_set_social_force")
+        if noise is None:
+            noise = "device" if (std_lon != 0 or std_lat != 0) else "off"
+        self.set_ped_noise(noise, std_lon, std_lat, normals=normals, seed=noise_seed)
+
+    def set_ped_noise(self, mode="off", std_lon=0.0, std_lat=0.0, normals=None, seed=0):
+        """sg_set_ped_noise: "off", "stream" (normals[R, n] standard normal variates per scenario) or "device"."""
+        code = {"off": L.NOISE_OFF, "stream": L.NOISE_STREAM, "device": L.NOISE_DEVICE}[mode]
+        ptr, n = None, 0
+        if code == L.NOISE_STREAM:
+            normals = np.ascontiguousarray(normals, np.float64)
+            if normals.ndim != 2 or normals.shape[0] != self.R:
+                raise ValueError(f"normals must be [n_scenarios = {self.R}, n]")
+            ptr, n = normals.ctypes.data_as(C.c_void_p), normals.shape[1]
+        self._check(self.lib.sg_set_ped_noise(self.h, code, float(std_lon), float(std_lat), ptr, int(n), int(seed) & (2 ** 64 - 1)),
+                    "sg_set_ped_noise")
 
     # ------------------------------------------------------------------ plumbing
     def _check(self, rc, what):
@@ -348,7 +366,7 @@ class RolloutEngine:
             vels=np.where(present[..., None], rows(L.F_VEL, 6), np.nan),
             present=present, dists=rows(L.F_DIST)[..., 0], coll=coll[..., 0] if v.row_words == 1 else coll,
             ctrl_state=rows(L.F_CTRL, 4), force=rows(L.F_FORCE, 2), t=scen["t"].copy(), prev_t=scen["prev_t"].copy(),
-            done=scen["done"].astype(bool), n_steps=scen["n_steps"].copy(),
+            done=scen["done"].astype(bool), n_steps=scen["n_steps"].copy(), noise_pos=scen["noise_pos"].copy(),
         )
 
     METRIC_DTYPE = np.dtype([("ego_avg_speed", "f8"), ("ego_max_speed", "f8"), ("ego_distance_travelled", "f8"),

@@ -139,6 +139,13 @@ class BatchedScenarioGym:
             for a in sc_agents.values():
                 if hasattr(a, "behaviour"):
                     sf = sf or a.behaviour.device_params()
+        if sf is not None and sf.get("noise") == "stream":
+            # parity with the reference's global generator: scenario i draws what numpy hands out after seed(noise_seed + i)
+            seeds = sf.pop("noise_seed")
+            seeds = list(seeds) if hasattr(seeds, "__len__") else [int(seeds) + i for i in range(packed.n_scenarios)]
+            n_ped = int((packed.kind.reshape(packed.n_scenarios, -1) == 5).sum(axis=1).max())
+            n = 2 * n_ped * (self.max_steps + 1)
+            sf["normals"] = np.stack([np.random.RandomState(int(k)).standard_normal(n) for k in seeds])
         self.engine = RolloutEngine(
             packed.n_scenarios, packed.n_entities, timestep=self._timestep, persist=self.persist,
             terminal_conditions=dev_terms, record_capacity=(self.max_steps + 1) if self.record else 0,

@@ -251,8 +251,41 @@ def test_pedestrian_agents_through_the_gym_api():
     refs = list(g["loop0/scenario/refs"])
     got = gym.get_metrics()["collisions"]
     assert [(t, refs.index(r), ty) for t, r, ty in got] == [(t, int(o), "non_vehicle") for t, o in zip(g[p + "/ev_t"], g[p + "/ev_other"])]
-    with pytest.raises(NotImplementedError):  # the device model is deterministic
-        sga.SocialForce(sga.SocialForceParameters()).device_params()
+    gym.close()
+
+
+def test_social_force_with_the_reference_default_noise():
+    """SocialForce(SocialForceParameters()) -- the reference's DEFAULT std_lon / std_lat (random_walk.py:13-19) -- runs:
+    noise="numpy" reproduces the reference's own rollout after np.random.seed(k) (golden ped_noise/loop2: 70 pedestrians,
+    the crowd kernel), the default noise="device" draws the same distribution on the GPU and stays within the noise's
+    reach of it."""
+    import scenario_gym_amd as sga
+
+    g = load_golden("ped_noise")
+    sc = _scenario(g, "loop2/scenario")
+    routes, vdes, thr = g["loop2/routes"], g["loop2/vdes"], float(g["loop2/distance_threshold"])
+    std_lon, std_lat, seed = g["loop2/noise"]
+    assert (std_lon, std_lat) == (sga.SocialForceParameters.std_lon, sga.SocialForceParameters.std_lat)
+    idx = {e.ref: i for i, e in enumerate(sc.entities)}
+    ref = g["loop2/dt30/poses"]
+    for mode in ("numpy", "device"):
+        def create_agent(s, e, mode=mode):
+            i = idx[e.ref]
+            return sga.PedestrianAgent(e, routes[i], vdes[i], sga.SocialForce(sga.SocialForceParameters(noise=mode, noise_seed=int(seed))),
+                                       distance_threshold=thr)
+
+        gym = sga.ScenarioGym(timestep=1 / 30, metrics=[sga.CollisionMetric()])
+        gym.set_scenario(sc, create_agent=create_agent)
+        for _ in range(30):
+            gym.step()
+        early = np.array([gym.state.poses[e] for e in sc.entities])
+        gym.rollout()
+        end = np.array([gym.state.poses[e] for e in sc.entities])
+        gym.close()
+        if mode == "numpy":
+            assert np.abs(early - ref[30]).max() < 1e-9 and np.abs(end - ref[-1]).max() < 1e-8
+        else:  # another stream of the same tiny noise: different bits, the same walk while the crowd's chaos lets it be
+            assert 0 < np.abs(early - ref[30]).max() < 1e-3 and np.isfinite(end).all()
 
 
 def test_to_scenario_round_trip():

@@ -429,6 +429,73 @@ def test_pedestrian_closed_loops_match_reference(sga, oracle, si):
         assert bits_equal(st["force"][0, ped], o["extra"][-1, ped, 2:])
 
 
+@pytest.mark.parametrize("si", [0, 1, 2])
+def test_pedestrian_noise_closed_loops_match_reference(sga, oracle, si):
+    """The random fluctuations of SocialForce._step (social_force.py:106-114) on the device, stream mode: closed loops of
+    the reference with std > 0 after np.random.seed(k) (loop 2: the reference's default std, 70 pedestrians = the crowd
+    kernel with two wavefronts per scenario).  The device consumes np.random.RandomState(k).standard_normal in the
+    reference's order: poses <= 1e-8 of the reference, bit-identical to the oracle, the same number of variates."""
+    g = load_golden("ped_noise")
+    packed, E = _ped_packed(g, si)
+    std_lon, std_lat, seed = g[f"loop{si}/noise"]
+    used = int(g[f"loop{si}/variates_used"])
+    normals = np.random.RandomState(int(seed)).standard_normal(used + 64)
+    p = f"loop{si}/dt30"
+    n = int(g[p + "/n_steps"])
+    eng = sga.RolloutEngine(1, E, timestep=1 / 30, record_capacity=n + 3, event_capacity=256,
+                            social_force=dict(std_lon=std_lon, std_lat=std_lat, noise="stream", normals=normals[None, :]))
+    eng.upload(packed)
+    eng.rollout(n + 2)
+    st = eng.state()
+    rows, events = eng.metrics()
+    t, poses = eng.record(n + 3)
+    assert rows["n_steps"][0] == n and st["noise_pos"][0] == used
+    ref = g[p + "/poses"]
+    assert np.array_equal(np.isnan(poses[: n + 1, 0]), np.isnan(ref)) and np.nanmax(np.abs(poses[: n + 1, 0] - ref)) < 1e-8
+    ex = g[p + "/extra"][-1]
+    ped = ~np.isnan(ex[:, 0])
+    assert np.array_equal(st["ctrl_state"][0, ped, 1], ex[ped, 1]) and np.abs(st["force"][0, ped] - ex[ped, 2:]).max() < 1e-8
+    assert np.array_equal(events["t"], g[p + "/ev_t"]) and np.array_equal(events["other"], g[p + "/ev_other"])
+    o = _oracle_one(oracle, packed, 0, 1 / 30, n + 2, noise=dict(mode="stream", std_lon=std_lon, std_lat=std_lat, normals=normals))
+    assert bits_equal(poses[: n + 1, 0], o["poses"]) and bits_equal(st["force"][0, ped], o["extra"][-1, ped, 2:])
+    # a masked reset rewinds the stream: the same rollout again
+    eng.reset()
+    eng.rollout(n + 2)
+    t2, poses2 = eng.record(n + 3)
+    assert bits_equal(poses2, poses)
+    # a stream that is too short is an error when the metrics are read, not a silent zero
+    eng.set_ped_noise("stream", std_lon, std_lat, normals=normals[None, : used // 2])
+    eng.reset()
+    eng.rollout(n + 2)
+    with pytest.raises(RuntimeError, match="noise variates"):
+        eng.metrics()
+    eng.close()
+
+
+@pytest.mark.parametrize("R,E,steps,side", [(6, 256, 70, 30.0), (16, 40, 100, 10.0), (5, 100, 60, 14.0)])
+def test_crowd_with_device_noise_matches_oracle(sga, oracle, R, E, steps, side):
+    """Noise mode "device" (timing / production runs): the counter-based generator -- Philox4x32-10 keyed by (seed,
+    scenario) at counter (entity, step), Box-Muller with the shared log / sin / cos -- is restated in the oracle: crowds
+    walk the same bits, and differently from the noise-free run."""
+    from scenario_gym_amd import synthetic
+
+    packed = synthetic.make_crowd(R, E, n_steps=steps, side=side)
+    kw = dict(std_lon=0.2, std_lat=0.1, noise="device", noise_seed=0xC0FFEE1234)
+    eng = sga.RolloutEngine(R, E, record_capacity=steps + 1, event_capacity=512, social_force=kw)
+    eng.upload(packed)
+    eng.rollout(steps)
+    st = eng.state()
+    t, poses = eng.record(steps + 1)
+    eng.close()
+    for r in range(R):
+        o = _oracle_one(oracle, packed, r, 1 / 30, steps,
+                        noise=dict(mode="device", std_lon=0.2, std_lat=0.1, seed=0xC0FFEE1234, scenario_index=r))
+        assert bits_equal(poses[: o["n_steps"] + 1, r], o["poses"]), r
+        assert bits_equal(st["force"][r], o["extra"][-1, :, 2:]), r
+    o0 = _oracle_one(oracle, packed, 0, 1 / 30, steps)
+    assert np.abs(o0["poses"][-1] - poses[steps, 0]).max() > 1e-3
+
+
 @pytest.mark.parametrize("R,E,steps,side", [(32, 40, 120, 12.0), (6, 256, 60, 30.0), (10, 100, 80, 20.0)])
 def test_crowd_matches_oracle(sga, oracle, R, E, steps, side):
     """BASELINE config 5 family (all-pedestrian crowds, up to 256 per scenario): bit-identical to the oracle."""
