@@ -28,6 +28,9 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # presence, the collision row words [+ the force])
 WORKLOADS = {
     "c2": dict(R=256, E=16, b_alg=114.0, stored=72.0, config=1),
+    # the same batch through the time-sliced replay path (sg_set_slicing): final state + metrics + events, NO per-step state in
+    # memory -- its own accounting: per entity-step one 8-byte |delta pose| term written by the slices and read by the ordered pass
+    "c2s": dict(R=256, E=16, b_alg=16.0, stored=8.0, config=1, sliced=True),
     "c3": dict(R=4096, E=64, b_alg=114.0, stored=72.0, config=2),
     "c5": dict(R=1024, E=256, b_alg=154.0, stored=112.0, config=4),
 }
@@ -162,9 +165,10 @@ def main(argv=None, make_engine=None):
     ap.add_argument("--entities", type=int, default=None)
     ap.add_argument("--sim-steps", type=int, default=10000)
     ap.add_argument("--ego", default="pid", choices=["pid", "replay"])
-    ap.add_argument("--workload", default="c3", choices=["c3", "c2", "c5"],
-                    help="BASELINE.json configs: c3 = 4096x64 PID ego (default, the headline), c2 = 256x16 replay, "
-                         "c5 = 1024x256 social-force crowd")
+    ap.add_argument("--workload", default="c3", choices=["c3", "c2", "c2s", "c5"],
+                    help="BASELINE.json configs: c3 = 4096x64 PID ego (default, the headline), c2 = 256x16 replay (state of "
+                         "every step materialised), c5 = 1024x256 social-force crowd; c2s = the c2 batch through the "
+                         "time-sliced replay path (final state + metrics + events only: a separate mode, never the headline)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="what `value` is: weak (default) = --scenarios per GPU; strong = --scenarios in total, split evenly "
                          "over the ranks (BASELINE.json configs[3] read literally: 4096 replicas over 8 GPUs = 512 per GPU)."
@@ -184,7 +188,7 @@ def main(argv=None, make_engine=None):
     wl = WORKLOADS[args.workload]
     args.scenarios = args.scenarios or wl["R"]  # (explicit --scenarios / --entities: size sweeps of the same family)
     args.entities = args.entities or wl["E"]
-    if args.workload == "c2":
+    if args.workload in ("c2", "c2s"):
         args.ego = "replay"
     crowd = args.workload == "c5"
     rank, world, local_rank, dist = D.init()
@@ -218,6 +222,7 @@ def main(argv=None, make_engine=None):
                 kw["social_force"] = dict(std_lon=0.1, std_lat=0.1, noise="device")
             eng = sga.RolloutEngine(R, E, timestep=dt, terminal_conditions=["max_length"], event_capacity=64,
                                     device=local_rank, **kw)
+            eng.set_slicing(bool(wl.get("sliced")))  # every other workload materialises the state of every step
             eng.upload(packed)
             return eng
     else:  # tests drive the dispatch / timing / collection code with a stand-in engine on CPU
@@ -314,20 +319,23 @@ def main(argv=None, make_engine=None):
                             (f"{R} scenarios x {E} entities x {T} steps per GPU, "
                              f"{'PIDAgent' if ego_kind == L.KIND_AGENT_PID else 'ReplayTrajectoryAgent'} ego + batch replay "
                              "others, all-pairs OBB collisions, CollisionMetric + EgoAvgSpeed/MaxSpeed/DistanceTravelled, "
-                             f"terminal max_length (BASELINE.json configs[{wl['config']}])"),
+                             f"terminal max_length (BASELINE.json configs[{wl['config']}])"
+                             + ("; TIME-SLICED replay path: final state + metrics + events, bit-identical to the step-by-step "
+                                "kernel, the states of the intermediate steps are not written to memory" if wl.get("sliced") else "")),
                 "scenarios_per_gpu": R, "entities": E, "sim_steps": T, "timestep": dt,
                 "sharding": f"replicas x{world}, no data-path collective",
             },
             "roofline": {
                 # `frac` is the contract's figure (algorithmic bytes over the HBM peak).  What binds is vector-ALU
                 # instruction issue: the rewritten state lives in L2 (traffic_ratio), see `secondary`.
-                "bound": "valu_issue", "contract_bound": "hbm",
+                "bound": "ordered_sum_latency" if wl.get("sliced") else "valu_issue", "contract_bound": "hbm",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
                 "traffic_ratio": (traffic / (per_launch * b_alg)) if traffic else None,
                 "stored_bytes_per_entity_step": wl["stored"],
                 "secondary": secondary,
-                "kernel": kernel_name(E, crowd, ego_kind == L.KIND_AGENT_PID),
+                "kernel": (f"sg::rollout_kernel_slice<{min(64, max(4, 1 << (E - 1).bit_length()))}>" if wl.get("sliced") else
+                           kernel_name(E, crowd, ego_kind == L.KIND_AGENT_PID)),
                 "kernel_ms": avg_ms, "launches_per_rollout": launches_per_rollout, "rollout_device_ms": rollout_ms,
                 "bytes_per_entity_step": b_alg, "entity_steps_per_launch": per_launch,
                 "src_sha16": L.source_sha16(),

@@ -375,6 +375,15 @@ int sg_last_kernel_ms(sg_handle *h, float *ms);
  * measured with its own HIP event pair on the handle's stream */
 int sg_last_launch_stats(sg_handle *h, int32_t *n_launches, float *kernel_ms_total);
 
+/* ScenarioGym.rollout (scenario_gym.py:256-267) of a batch whose entities are all replay entities / replay agents is a
+ * pure function of the clock except for three ordered sums (State.distances, EgoAvgSpeed, the event list).  sg_rollout
+ * cuts the time axis of such a batch into slices that run side by side when the batch alone cannot fill the GPU (fewer
+ * than 1024 wavefronts, >= 512 steps, no pose recording, no RSS callback): final state, metrics and events are bit-identical
+ * to the step-by-step launch; the states of the intermediate steps are not written to memory (a caller that wants them uses
+ * sg_step, record_capacity, or mode 0).  mode: 0 = never, 1 = automatic (default; env SG_SLICE), 2 = whenever the batch
+ * is eligible, however short the rollout (tests). */
+int sg_set_slicing(sg_handle *h, int32_t mode);
+
 /* Launch policy of sg_rollout / sg_step (results do not depend on it; negative / zero values keep the current one).
  *   tab_min_steps  calls with at least this many steps integrate PID / vehicle agents in the controller pre-pass
  *                  (one lane per agent, 64 agents to a wavefront) instead of inside the rollout kernel

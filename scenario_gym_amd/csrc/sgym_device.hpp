@@ -2267,13 +2267,41 @@ __device__ __forceinline__ Table lane_table(const Params &p, int kind, const Sce
 // ROAD: the ego_off_road terminal condition is compiled in (its own entry point, rollout_kernel_road: the other
 // variants keep their register budgets).
 // RSSV: the RSSDistances callback (rss_entity) runs after the reset and after every step inside the kernel.
+// ------------------------------------------------------------------------------------------------
+// Time-sliced replay (launch_sliced in sgym_hip.hip): a batch whose lanes are all replay entities / replay agents is a
+// pure function of the clock -- pose_j = interpolant(t_j), presence_j = rule(t_j) -- except for three ORDERED sums
+// (State.distances, EgoAvgSpeed, the event list) and the step at which a terminal condition first holds.  A small batch
+// (BASELINE config 2: 64 wavefronts on a 1024-SIMD chip) therefore cuts the time axis: the clock t_j = t_{j-1} + dt is
+// accumulated once (clock_kernel, the same additions as the step loop), slice s of the steps runs in its own wavefronts
+// from a warm-up step that rebuilds state a = s * len out of the clock alone, leaves |delta pose| / ego speed / events per
+// step, and an ordered pass (replay_fixup_kernel) adds them up in step order; the state of the last executed step is
+// materialised by one more launch (mode 1).  Results are bit-identical to the step-by-step kernel; what is NOT produced is
+// the state of every intermediate step in memory.
+// ------------------------------------------------------------------------------------------------
+struct SliceArgs {
+    int mode;            // 0: slices (per-step terms go to the slice arrays), 1: the last executed step with the full state stores
+    int n_slices, len;   // slice s covers steps (s * len, min((s + 1) * len, n_total)]
+    int n_total;         // steps of the call
+    const double *tt;    // [n_clocks][n_total + 1] the clocks: tt[c][j] = State.t after j steps of a scenario that starts at t0_c
+    const int *clock_of; // [R] the clock of scenario r (scenarios with the same start time share one)
+    double *dnorm;       // [n_blocks][n_total + 1][64] |delta pose[:3]| of step j per lane (+0 when the entity has no pose)
+    double2 *espeed;     // [n_total + 1][R] ego speed after step j (NaN: the ego has no pose) and 1 - t_prev / t of
+                         // EgoAvgSpeed when the ego's previous update was the previous step (else NaN: the fix-up divides)
+    int *first_done;     // [R][n_slices] the step of the slice at which the scenario became done (0x7f7f7f7f: none)
+    sg_event *ev;        // [R][n_slices][ev_cap] CollisionMetric events of the slice
+    int *nev;            // [R][n_slices]
+    const int *n_final;  // [R] (mode 1) the scenario's last executed step
+};
+
 // CROWD (PED only): every entity of the batch is a pedestrian agent (or padding), default head rotation, no road network:
 // no knot segment, no vehicle / replay code, crowd_pairs for the neighbour sums (rollout_kernel_crowd, BASELINE config 5).
-template <int G, int WV, bool PED, bool TAB, bool HAST, bool ROAD = false, bool RSSV = false, bool CROWD = false>
+// SLICE (TAB without a table, one wavefront per tile): one slice of a time-sliced replay, see SliceArgs.
+template <int G, int WV, bool PED, bool TAB, bool HAST, bool ROAD = false, bool RSSV = false, bool CROWD = false, bool SLICE = false>
 __device__ __forceinline__ void rollout_body(
     const Params &p, double timestep, int n_steps, int do_reset, int force, const double *actions /*[n][R][2]*/,
-    const double *tab /*controller table planes*/)
+    const double *tab /*controller table planes*/, const SliceArgs &sa = SliceArgs{})
 {
+    static_assert(!SLICE || (TAB && !HAST && WV == 1 && !PED && !ROAD && !RSSV), "slices replay batches without controlled lanes");
     static_assert(!(PED && TAB), "pedestrian scenarios run their controllers in the rollout kernel");
     static_assert(!CROWD || (PED && G == 64 && !ROAD && !RSSV), "the crowd variant is a pedestrian variant with 64-lane tiles");
     constexpr int NS = 64 * WV;
@@ -2509,6 +2537,27 @@ __device__ __forceinline__ void rollout_body(
 #pragma unroll
         for (int w = 0; w < WV; ++w) row[w] = fld<uint64_t>(dy, SG_F_COLL + w);
     }
+    // SLICE: the lane has to be in state `a` (after a steps) before its real steps.  a <= 1: the reset state just loaded
+    // (a == 1: + the warm-up step); a >= 2: state a - 1 rebuilt from the clock -- time, and the presence of an agent lane
+    // (it has its pose from the reset on, or spawns at step 1: scenario_gym.py:240-244); everything else about that state
+    // is either recomputed by the warm-up step (pose, presence of replay lanes, collision row) or not used by it.
+    int slice_a = 0;
+    const int slice_s = SLICE ? (int)blockIdx.y : 0;
+    if (SLICE) {
+        slice_a = sa.mode == 0 ? slice_s * sa.len : sa.n_final[r] - 1;
+        n_ev = 0;
+        if (slice_a >= 2) {
+            const double *clk = sa.tt + (size_t)sa.clock_of[r] * (size_t)(sa.n_total + 1);
+            t = clk[slice_a - 1];
+            prev_t = clk[slice_a - 2];
+            present = is_agent ? (present || min_t >= ss.t0) : true; // (a replay lane's presence is recomputed by the warm-up step)
+            steps = slice_a - 1;
+#pragma unroll
+            for (int w = 0; w < WV; ++w) { last_row[w] = 0; row[w] = 0; }
+        }
+        n_steps = sa.mode == 0 ? 1 + min(sa.len, sa.n_total - slice_a) : 2;
+        sg_loads_done();
+    }
     if (!TAB && (do_reset != 0 || PED)) {
         // collisions of the reset state; pedestrian scenes also need the neighbour candidates (and LDS positions) of the
         // current state when they continue
@@ -2633,10 +2682,13 @@ __device__ __forceinline__ void rollout_body(
     for (; k < n_steps; ++k) {
         // per wavefront and before any workgroup barrier of the step: does a lane need its next segment?
         if (!CROWD && __any(t + timestep > S.x_hi)) break;
-        const bool run = in_range && (force || !done);
+        // SLICE: round 0 is the warm-up step (state a - 1 -> a, nothing recorded); a lane that starts from the reset state
+        // itself (a == 0) sits it out
+        const bool warm = SLICE && k == 0;
+        const bool run = in_range && (force || !done) && !(SLICE && k == 0 && slice_a == 0);
         PH(5);
         // (a workgroup of several wavefronts carries ONE scenario: `run` is already uniform, nothing to vote)
-        const bool any_run_ = WV == 1 ? __any(run) : run;
+        const bool any_run_ = WV == 1 ? __any(run || (SLICE && k == 0 && in_range && !done)) : run;
         PH(7);
         if (!any_run_) { all_done = true; break; }
         // coefficient table: opaque per step so the scalar loads stay inside the loop (SGPRs for a few
@@ -2826,7 +2878,7 @@ __device__ __forceinline__ void rollout_body(
             RecipDiv rd(dt);
             const uint32_t zbits = (uint32_t)(__double2hiint(d[2]) | __double2hiint(d[4]) | __double2hiint(d[5])) |
                                    (uint32_t)(__double2loint(d[2]) | __double2loint(d[4]) | __double2loint(d[5]));
-            flat = __all((!run | !npres | (present & (zbits == 0))) & (dt > 0.0));
+            flat = !SLICE && __all((!run | !npres | (present & (zbits == 0))) & (dt > 0.0));
             bool safe = rd.safe(d[0]) & rd.safe(d[1]) & rd.safe(d[3]);
             if (!flat) safe = safe & rd.safe(d[2]) & rd.safe(d[4]) & rd.safe(d[5]);
             if (__all(safe)) {
@@ -2845,20 +2897,29 @@ __device__ __forceinline__ void rollout_body(
         // commit (lanes of scenarios that are already done keep their state)
         const bool vel_zpr_clean = vel_clean_prev; // did the previous step leave +0 in every stored z/pitch/roll velocity row?
         vel_clean_prev = flat;
+        const bool was_present = present;
         if (run) {
             present = npres;
             if (npres) {
 #pragma unroll
                 for (int c = 0; c < 6; ++c) pose[c] = np_[c];
-                dist += sg_norm3(d[0], d[1], d[2]);
+                if (!SLICE) dist += sg_norm3(d[0], d[1], d[2]);
                 if (PED) { velx = vel[0]; vely = vel[1]; }
             }
             prev_t = t;
             t = next_t;
             ++steps;
             last_k = k;
+            if (SLICE && sa.mode == 0 && !warm) { // the terms of the ordered sums of step `steps` (replay_fixup_kernel)
+                sa.dnorm[((size_t)blk * (size_t)(sa.n_total + 1) + (size_t)steps) * 64 + lane] = npres ? sg_norm3(d[0], d[1], d[2]) : 0.0;
+                if (is_ego) // (prev_t is the clock before this step; steps == 1: the reset left EgoAvgSpeed.t = 0, the fix-up's case)
+                    sa.espeed[(size_t)steps * p.R + r] =
+                        make_double2(present ? sg_norm3(vel[0], vel[1], vel[2]) : __builtin_nan(""),
+                                     (was_present && steps > 1) ? 1.0 - prev_t / t : __builtin_nan(""));
+            }
             // ---- step-materialised state (everything except the collision row, see below) ----
 #ifndef SG_ABL_NO_STORES
+            if (!SLICE || (sa.mode == 1 && !warm)) {
             stf(dy, SG_F_POSE + 0, pose[0]); stf(dy, SG_F_POSE + 1, pose[1]); stf(dy, SG_F_POSE + 3, pose[3]);
             if (!flat) { stf(dy, SG_F_POSE + 2, pose[2]); stf(dy, SG_F_POSE + 4, pose[4]); stf(dy, SG_F_POSE + 5, pose[5]); }
             if (present) {
@@ -2869,6 +2930,7 @@ __device__ __forceinline__ void rollout_body(
             }
             stf(dy, SG_F_DIST, dist);
             stf(dy, SG_F_PRESENT, (uint64_t)present);
+            }
 #else
             if (k == n_steps - 1 || (steps & 1023) == 0) { // timing ablation only: keep the values live
 #pragma unroll
@@ -2889,7 +2951,7 @@ __device__ __forceinline__ void rollout_body(
                 if (slot == 0) { p.rec_t[(size_t)steps * p.R + r] = t; sd.rec_rows = steps + 1; }
             }
             // ---- ego metrics, scenario_gym.py:251-252 ----
-            if (is_ego && present && !tab_lane) { // a controlled ego's metrics come with its table (control_kernel)
+            if (!SLICE && is_ego && present && !tab_lane) { // a controlled ego's metrics come with its table (control_kernel)
                 double speed = sg_norm3(vel[0], vel[1], vel[2]);
                 double w = m_t / t; // EgoAvgSpeed._step, metrics/trajectory.py:19-24
                 m_avg += (1.0 - w) * (speed - m_avg);
@@ -2911,7 +2973,7 @@ __device__ __forceinline__ void rollout_body(
 #pragma unroll
             for (int w = 0; w < WV; ++w) {
                 row[w] = nrow[w];
-                stf(dy, SG_F_COLL + w, row[w]);
+                if (!SLICE || (sa.mode == 1 && !warm)) stf(dy, SG_F_COLL + w, row[w]);
             }
         }
 
@@ -2954,12 +3016,15 @@ __device__ __forceinline__ void rollout_body(
             if (off_tile) ndone = 1;
         }
         if (run) done = ndone;
+        if (SLICE && sa.mode == 0 && !warm && run && ndone && sl == tile0)
+            sa.first_done[(size_t)r * sa.n_slices + slice_s] = steps; // (once: the scenario does not run after this)
 
         // ---- CollisionMetric._step, metrics/collision.py:70-75 (ego lane only) ----
         if (run && is_ego && present) {
 #pragma unroll
             for (int w = 0; w < WV; ++w) {
                 uint64_t fresh = row[w] & ~last_row[w];
+                if (SLICE && (warm || sa.mode == 1)) fresh = 0; // the events of these steps belong to other launches
                 while (fresh) {
                     int j = w * 64 + __builtin_ctzll(fresh);
                     fresh &= fresh - 1;
@@ -2981,7 +3046,8 @@ __device__ __forceinline__ void rollout_body(
                     int64_t ometa = reinterpret_cast<const int64_t *>(oblk)[ST_META * 64 + (oj & 63)];
                     for (int q = 0; q < mult; ++q) {
                         if (n_ev < p.ev_cap) {
-                            sg_event *dst = &p.events[(size_t)r * p.ev_cap + n_ev];
+                            sg_event *dst = SLICE ? &sa.ev[((size_t)r * sa.n_slices + slice_s) * p.ev_cap + n_ev]
+                                                  : &p.events[(size_t)r * p.ev_cap + n_ev];
                             struct { double t; int32_t scenario, other, type, reserved; } head;
                             head.t = t; head.scenario = (int32_t)r; head.other = j;
                             // 5 = non_vehicle; Vehicle hazards (15 here, -1 once unpacked) wait for classify_events_kernel.
@@ -3012,6 +3078,16 @@ __device__ __forceinline__ void rollout_body(
     ptm.flush(p.phase_cycles);
 #endif
 
+    if (SLICE) { // the per-scenario results of a sliced replay are written by replay_fixup_kernel
+        if (in_range && is_ego) {
+            if (sa.mode == 0) sa.nev[(size_t)r * sa.n_slices + slice_s] = n_ev;
+            else {
+#pragma unroll
+                for (int w = 0; w < WV; ++w) sd.last_row[w] = last_row[w];
+            }
+        }
+        return;
+    }
     // ---- write back what lives in registers during the loop ----
     if (in_range) {
         if (PED && kind == SG_KIND_AGENT_PEDESTRIAN) cs.e_lon_prev = (double)goal_idx;
@@ -3092,6 +3168,166 @@ __global__ __launch_bounds__(64, 2) __attribute__((amdgpu_num_vgpr(96))) void ro
     Params p, double timestep, int n_steps, int do_reset, int force, const double *actions, const double *tab)
 {
     rollout_body<G, 1, false, true, true>(p, timestep, n_steps, do_reset, force, actions, tab);
+}
+
+// One slice of a time-sliced replay (grid.y = slices; SliceArgs), or its last step with the full state stores
+template <int G>
+__global__ __launch_bounds__(64, SG_WAVES_PER_SIMD_TAB) void rollout_kernel_slice(Params p, double timestep, SliceArgs sa)
+{
+    rollout_body<G, 1, false, true, false, false, false, false, true>(p, timestep, 0, 0, 0, nullptr, nullptr, sa);
+}
+
+// The clocks of a sliced replay: tt[c][j] = State.t after j steps = t0_c + dt + dt + ... (scenario_gym.py:229), the
+// additions of the step loop itself; scenarios with the same start time share a clock (launch_sliced).  One lane per clock.
+__global__ __launch_bounds__(64) void clock_kernel(const double *t0 /*[n_clocks]*/, int n_clocks, double timestep, int n_total, double *tt)
+{
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= n_clocks) return;
+    double *row = tt + (size_t)c * (size_t)(n_total + 1);
+    double t = t0[c];
+    row[0] = t;
+    int j = 1;
+    for (; j + 15 <= n_total; j += 16) {
+        double v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { t = t + timestep; v[u] = t; }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) row[j + u] = v[u];
+    }
+    for (; j <= n_total; ++j) { t = t + timestep; row[j] = t; }
+}
+
+// n_final[r] = the step at which scenario r became done (the first over its slices), else all n_total steps
+__global__ __launch_bounds__(64) void slice_final_kernel(Params p, SliceArgs sa, int *n_final, int *done_out)
+{
+    const int r = blockIdx.x * 64 + threadIdx.x;
+    if (r >= p.R) return;
+    int nf = 0x7f7f7f7f; // "never": what launch_sliced fills first_done with
+    for (int s = 0; s < sa.n_slices; ++s) nf = min(nf, sa.first_done[(size_t)r * sa.n_slices + s]);
+    done_out[r] = nf != 0x7f7f7f7f;
+    n_final[r] = min(nf, sa.n_total);
+}
+
+// The ordered pass of a sliced replay, after the last step has been materialised.  replay_fixup_kernel: per entity
+// State.distances = the |delta pose| terms added up in step order (state.py:237-239), 32 rows of the block in flight.
+// replay_scenario_fixup_kernel: one lane per scenario: the EgoAvgSpeed / EgoMaxSpeed recurrences (metrics/trajectory.py:19-24,
+// 41-44; an absent ego skips its update) over the ego's speeds and the clock (two contiguous streams, 16 steps in flight),
+// the event lists of the slices concatenated in step order (metrics/collision.py:70-75), and the scenario record.
+template <int G>
+__global__ __launch_bounds__(64) void replay_fixup_kernel(Params p, SliceArgs sa, const int *n_final)
+{
+    const int lane = threadIdx.x;
+    {
+        const size_t blk = blockIdx.x;
+        const int gl = (int)blk * 64 + lane;
+        const int r_raw = gl / G, slot = gl & (G - 1);
+        const bool in_range = r_raw < p.R;
+        const int r = in_range ? r_raw : p.R - 1;
+        const LanePtr dy(p.dyn + blk * ((size_t)(SG_F_COLL + 1) * 64), lane * 8u);
+        const int nf = in_range ? n_final[r] : 0;
+        int nf_max = nf;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) nf_max = max(nf_max, __shfl_xor(nf_max, o, 64));
+        const double *dn = sa.dnorm + (blk * (size_t)(sa.n_total + 1)) * 64 + lane;
+        double dist = 0.0; // State.reset: distances 0 (state.py:136)
+        // two buffers of 16 rows: the loads of one are in flight while the other is added up (the additions wait for their
+        // own buffer only: loads return in order)
+        constexpr int NB = 16;
+        double va[NB], vb[NB];
+        auto fetch = [&](double (&v)[NB], int j0) {
+#pragma unroll
+            for (int u = 0; u < NB; ++u) v[u] = dn[(size_t)min(j0 + u, sa.n_total) * 64];
+        };
+        auto add_up = [&](const double (&v)[NB], int j0) {
+#pragma unroll
+            for (int u = 0; u < NB; ++u) dist += (j0 + u <= nf) ? v[u] : 0.0; // (x + 0.0 == x for x >= +0: straight-line code)
+        };
+        int j = 1;
+        fetch(va, j);
+        for (; j <= nf_max; j += 2 * NB) {
+            fetch(vb, j + NB);
+            add_up(va, j);
+            fetch(va, j + 2 * NB);
+            add_up(vb, j + NB);
+        }
+        if (in_range && slot < p.E) {
+            stf(dy, SG_F_DIST, dist);
+            if (slot == p.sstat[r].ego && nf > 0 && fld<uint64_t>(dy, SG_F_PRESENT) != 0)
+                p.sdyn[r].ego_distance_travelled = dist; // EgoDistanceTravelled, metrics/trajectory.py:60-62
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void replay_scenario_fixup_kernel(Params p, SliceArgs sa, const int *n_final, const int *done_in)
+{
+    const int lane = threadIdx.x;
+    const int r = (int)blockIdx.x * 64 + lane;
+    if (r >= p.R) return;
+    sg_scenario_state &sd = p.sdyn[r];
+    const int nf = n_final[r];
+    double m_avg = sd.ego_avg_speed, m_max = sd.ego_max_speed, m_t = sd.avg_t; // the reset values
+    const double2 *es = sa.espeed + r; // [step][R]: the 64 scenarios of the wavefront read one row together
+    const double *tr = sa.tt + (size_t)sa.clock_of[r] * (size_t)(sa.n_total + 1);
+    // EgoAvgSpeed._step: w = t_prev / t; avg += (1 - w) * (speed - avg).  The slices leave 1 - w whenever t_prev is the
+    // previous step's clock (the ego had its pose then): the ordered part is three dependent operations per step.
+    auto update = [&](double2 e, double t, bool divide) {
+        const bool valid = e.x == e.x;
+        double c = e.y;
+        if (divide) c = (c != c) ? 1.0 - m_t / t : c; // first update, or the ego was absent in between
+        const double a = m_avg + c * (e.x - m_avg);
+        m_avg = valid ? a : m_avg;
+        m_t = valid ? t : m_t;
+        m_max = valid ? __builtin_fmax(e.x, m_max) : m_max;
+    };
+    // batches of 16 steps, the loads of the next batch in flight while this one is worked through
+    constexpr int NB = 16;
+    double2 spa[NB], spb[NB];
+    double tqa[NB], tqb[NB];
+    auto fetch = [&](double2 (&sp)[NB], double (&tq)[NB], int q0) {
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int qq = min(q0 + u, sa.n_total);
+            sp[u] = es[(size_t)qq * p.R];
+            tq[u] = tr[qq];
+        }
+    };
+    auto work = [&](const double2 (&sp)[NB], const double (&tq)[NB]) {
+        bool need = false; // does a step of the batch have to divide?  (one wave-uniform branch per batch)
+#pragma unroll
+        for (int u = 0; u < NB; ++u) need |= (sp[u].x == sp[u].x) & (sp[u].y != sp[u].y);
+        if (__any(need)) {
+#pragma unroll
+            for (int u = 0; u < NB; ++u) update(sp[u], tq[u], true);
+        } else {
+#pragma unroll
+            for (int u = 0; u < NB; ++u) update(sp[u], tq[u], false);
+        }
+    };
+    int q = 1;
+    if (nf >= NB) fetch(spa, tqa, q);
+    for (; q + 2 * NB - 1 <= nf; q += 2 * NB) {
+        fetch(spb, tqb, q + NB);
+        work(spa, tqa);
+        fetch(spa, tqa, q + 2 * NB);
+        work(spb, tqb);
+    }
+    if (q + NB - 1 <= nf) { work(spa, tqa); q += NB; }
+    for (; q <= nf; ++q) update(es[(size_t)q * p.R], tr[q], true);
+    sd.ego_avg_speed = m_avg; sd.ego_max_speed = m_max; sd.avg_t = m_t;
+    // events: the slices that lie before the last executed step, in order
+    int n_ev = 0;
+    for (int s = 0; s < sa.n_slices && s * sa.len < nf; ++s) {
+        const int cnt = sa.nev[(size_t)r * sa.n_slices + s];
+        const sg_event *src = sa.ev + ((size_t)r * sa.n_slices + s) * p.ev_cap;
+        for (int i = 0; i < min(cnt, p.ev_cap); ++i)
+            if (n_ev + i < p.ev_cap) p.events[(size_t)r * p.ev_cap + n_ev + i] = src[i];
+        n_ev += cnt;
+    }
+    sd.n_events = n_ev;
+    sd.t = tr[nf];
+    sd.prev_t = nf > 0 ? tr[nf - 1] : sd.prev_t;
+    sd.done = done_in[r];
+    sd.n_steps = nf;
 }
 
 // ------------------------------------------------------------------------------------------------

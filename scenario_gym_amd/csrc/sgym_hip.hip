@@ -22,6 +22,15 @@ struct sg_handle {
     sg_config cfg{};
     int R = 0, E = 0, EP = 0, G = 0, WV = 1;
     bool has_ped = false;
+    bool all_replay = false;  // every entity is a replay entity / replay agent (or padding): the batch can be time-sliced
+    int slice_mode = 1;       // sg_set_tuning / env SG_SLICE: 0 never, 1 automatic (small batches, long rollouts)
+    std::vector<void *> slice_allocs; // device arrays of launch_sliced, kept between calls of the same shape
+    int slice_T = -1, slice_S = 0;
+    sg::SliceArgs slice_args{};
+    int *d_n_final = nullptr, *d_slice_done = nullptr;
+    std::vector<double> clock_t0;  // distinct scenario start times (ScenarioGym.get_start_time): one clock each
+    std::vector<int> clock_of;     // [R]
+    double *d_clock_t0 = nullptr;
     bool all_ped = false;     // every entity of the batch is a pedestrian agent of catalog type Pedestrian (or padding)
     int crowd_kernel = 1;     // env SG_CROWD_KERNEL=0: all-pedestrian batches take the general pedestrian variant too
     sg_social_force sf{};
@@ -180,6 +189,7 @@ extern "C" int sg_create(const sg_config *cfg, sg_handle **out)
     h->ctl_slice = std::max(1, env_int("SG_CTL_SLICE", h->ctl_slice));
     h->ped_serial = env_int("SG_PED_SERIAL", 0) != 0;
     h->crowd_kernel = env_int("SG_CROWD_KERNEL", 1);
+    h->slice_mode = env_int("SG_SLICE", 1);
     if (hipSetDevice(cfg->device) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess ||
         hipStreamCreate(&h->ctl_stream) != hipSuccess ||
         hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {
@@ -216,6 +226,7 @@ extern "C" int sg_destroy(sg_handle *h)
     free_pool(h->static_allocs);
     free_pool(h->state_allocs);
     free_pool(h->road_allocs);
+    free_pool(h->slice_allocs);
     if (h->obs_buf) (void)hipFree(h->obs_buf);
     if (h->d_reset_mask) (void)hipFree(h->d_reset_mask);
     if (h->d_term_flags) (void)hipFree(h->d_term_flags);
@@ -400,6 +411,126 @@ static int launch_rollout(sg_handle *h, int n_steps, int do_reset, int force, co
     return SG_OK;
 }
 
+// ScenarioGym.rollout for a batch of replay entities / replay agents only, time-sliced (sgym_device.hpp, SliceArgs): the
+// reset launch, the clock, the slices of the time axis side by side, the last executed step with the full state stores,
+// the ordered sums.  Worth it when the batch alone cannot fill the chip (BASELINE config 2: 64 wavefronts); the results
+// are bit-identical to launch_rollout's, the intermediate states are not written anywhere.
+template <int G>
+static void launch_slice_kernels(sg_handle *h, const sg::SliceArgs &sa, dim3 grid)
+{
+    sg::rollout_kernel_slice<G><<<grid, dim3(64), 0, h->stream>>>(h->p, h->cfg.timestep, sa);
+}
+template <int G>
+static void launch_fixup_kernel(sg_handle *h, const sg::SliceArgs &sa)
+{
+    sg::replay_fixup_kernel<G><<<dim3((unsigned)(h->NE / 64)), dim3(64), 0, h->stream>>>(h->p, sa, h->d_n_final);
+}
+
+static bool slicing_pays(const sg_handle *h, int n_steps)
+{
+    if (!h->slice_mode || !h->all_replay || h->WV != 1 || h->p.rec_cap > 0 || h->rss_enabled || h->n_ext > 0 ||
+        (h->cfg.terminal_mask & SG_TERM_EGO_OFF_ROAD) || n_steps < (h->slice_mode == 2 ? 2 : 512))
+        return false;
+    const size_t nblk = h->NE / 64;
+    if (nblk >= 1024 && h->slice_mode != 2) return false; // the batch fills the chip by itself (two wavefronts per SIMD on half of it)
+    const size_t bytes = nblk * (size_t)(n_steps + 1) * 512; // the |delta pose| rows
+    return bytes <= ((size_t)8 << 30);
+}
+
+static int launch_sliced(sg_handle *h, int n_steps)
+{
+    const int R = h->R;
+    const size_t nblk = h->NE / 64;
+    // enough slices for ~4096 wavefronts, at least 64 steps each (mode 2, the tests' "always": short slices too)
+    int S = (int)std::min<size_t>(std::max<size_t>(1, 4096 / nblk), (size_t)std::max(1, n_steps / (h->slice_mode == 2 ? 7 : 64)));
+    const int len = (n_steps + S - 1) / S;
+    S = (n_steps + len - 1) / len;
+    int rc;
+    if (h->slice_T != n_steps || h->slice_S != S) {
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        free_pool(h->slice_allocs);
+        auto &A = h->slice_allocs;
+        sg::SliceArgs sa{};
+        double *tt = nullptr;
+        if ((rc = dev_alloc(h, A, &tt, (size_t)(n_steps + 1) * h->clock_t0.size(), false))) return rc;
+        sa.tt = tt;
+        if ((rc = dev_upload(h, A, &sa.clock_of, h->clock_of))) return rc;
+        const double *ct0 = nullptr;
+        if ((rc = dev_upload(h, A, &ct0, h->clock_t0))) return rc;
+        h->d_clock_t0 = const_cast<double *>(ct0);
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        if ((rc = dev_alloc(h, A, &sa.dnorm, nblk * (size_t)(n_steps + 1) * 64, false))) return rc;
+        if ((rc = dev_alloc(h, A, &sa.espeed, (size_t)R * (n_steps + 1), false))) return rc;
+        if ((rc = dev_alloc(h, A, &sa.first_done, (size_t)R * S, false))) return rc;
+        if ((rc = dev_alloc(h, A, &sa.ev, (size_t)R * S * std::max(h->p.ev_cap, 1), false))) return rc;
+        if ((rc = dev_alloc(h, A, &sa.nev, (size_t)R * S, false))) return rc;
+        if ((rc = dev_alloc(h, A, &h->d_n_final, (size_t)R, false))) return rc;
+        if ((rc = dev_alloc(h, A, &h->d_slice_done, (size_t)R, false))) return rc;
+        sa.n_slices = S; sa.len = len; sa.n_total = n_steps;
+        h->slice_args = sa;
+        h->slice_T = n_steps;
+        h->slice_S = S;
+    }
+    sg::SliceArgs sa = h->slice_args;
+    h->n_launches = 0;
+    h->launch_ev.clear();
+    h->timing_now = true;
+    size_t ev_next = 0;
+    HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
+    if ((rc = launch_main(h, 0, 1, 0, nullptr, nullptr, false, &ev_next))) return rc; // State.reset (not counted as a hot-path launch)
+    HIP_TRY(h, hipMemsetAsync(sa.first_done, 0x7f, (size_t)R * S * sizeof(int), h->stream)); // 0x7f7f7f7f: "never"
+    HIP_TRY(h, hipMemsetAsync(sa.nev, 0, (size_t)R * S * sizeof(int), h->stream));
+    const int n_clocks = (int)h->clock_t0.size();
+    sg::clock_kernel<<<dim3((unsigned)((n_clocks + 63) / 64)), dim3(64), 0, h->stream>>>(h->d_clock_t0, n_clocks, h->cfg.timestep, n_steps,
+                                                                                        const_cast<double *>(sa.tt));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if ((rc = get_event(h, ev_next, &e0)) || (rc = get_event(h, ev_next + 1, &e1))) return rc;
+    HIP_TRY(h, hipEventRecord(e0, h->stream));
+    const dim3 grid((unsigned)nblk, (unsigned)S);
+    sa.mode = 0;
+    switch (h->G) {
+    case 4: launch_slice_kernels<4>(h, sa, grid); break;
+    case 8: launch_slice_kernels<8>(h, sa, grid); break;
+    case 16: launch_slice_kernels<16>(h, sa, grid); break;
+    case 32: launch_slice_kernels<32>(h, sa, grid); break;
+    default: launch_slice_kernels<64>(h, sa, grid); break;
+    }
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipEventRecord(e1, h->stream));
+    h->launch_ev.push_back((int)ev_next);
+    ++h->n_launches;
+    ev_next += 2;
+    sg::slice_final_kernel<<<dim3((unsigned)((R + 63) / 64)), dim3(64), 0, h->stream>>>(h->p, sa, h->d_n_final, h->d_slice_done);
+    {   // the per-scenario ordered pass (a serial recurrence per scenario) on the second stream, beside the last step and the
+        // per-entity pass
+        hipEvent_t e_nf = nullptr;
+        if ((rc = get_event(h, ev_next++, &e_nf))) return rc;
+        HIP_TRY(h, hipEventRecord(e_nf, h->stream));
+        HIP_TRY(h, hipStreamWaitEvent(h->ctl_stream, e_nf, 0));
+        sg::replay_scenario_fixup_kernel<<<dim3((unsigned)((R + 63) / 64)), dim3(64), 0, h->ctl_stream>>>(h->p, sa, h->d_n_final, h->d_slice_done);
+    }
+    sa.mode = 1;
+    sa.n_final = h->d_n_final;
+    const dim3 grid1((unsigned)nblk, 1);
+    switch (h->G) {
+    case 4: launch_slice_kernels<4>(h, sa, grid1); launch_fixup_kernel<4>(h, sa); break;
+    case 8: launch_slice_kernels<8>(h, sa, grid1); launch_fixup_kernel<8>(h, sa); break;
+    case 16: launch_slice_kernels<16>(h, sa, grid1); launch_fixup_kernel<16>(h, sa); break;
+    case 32: launch_slice_kernels<32>(h, sa, grid1); launch_fixup_kernel<32>(h, sa); break;
+    default: launch_slice_kernels<64>(h, sa, grid1); launch_fixup_kernel<64>(h, sa); break;
+    }
+    HIP_TRY(h, hipGetLastError());
+    {
+        hipEvent_t e_sc = nullptr;
+        if ((rc = get_event(h, ev_next++, &e_sc))) return rc;
+        HIP_TRY(h, hipEventRecord(e_sc, h->ctl_stream));
+        HIP_TRY(h, hipStreamWaitEvent(h->stream, e_sc, 0));
+    }
+    HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
+    h->timed = true;
+    return SG_OK;
+}
+
 extern "C" int sg_set_social_force(sg_handle *h, const sg_social_force *params)
 {
     if (!h || !params) return SG_ERR_INVALID;
@@ -470,7 +601,11 @@ extern "C" int sg_upload(sg_handle *h, const sg_scenarios *sc)
     // pedestrian agents are compiled for tiles of >= 16 lanes
     h->has_ped = false;
     h->all_ped = true;
+    h->all_replay = true;
+    free_pool(h->slice_allocs);
+    h->slice_T = -1;
     for (size_t i = 0; i < (size_t)h->R * h->E; ++i) {
+        h->all_replay = h->all_replay && (sc->kind[i] == SG_KIND_NONE || sc->kind[i] == SG_KIND_REPLAY || sc->kind[i] == SG_KIND_AGENT_REPLAY);
         h->has_ped = h->has_ped || sc->kind[i] == SG_KIND_AGENT_PEDESTRIAN;
         h->all_ped = h->all_ped && (sc->kind[i] == SG_KIND_NONE || (sc->kind[i] == SG_KIND_AGENT_PEDESTRIAN && sc->etype[i] == 1));
     }
@@ -614,6 +749,17 @@ extern "C" int sg_upload(sg_handle *h, const sg_scenarios *sc)
         std::fill(row_scen.begin() + grid_off[r], row_scen.begin() + grid_off[r + 1], r);
     }
 
+    {   // scenarios that start at the same time run on the same clock (launch_sliced)
+        std::vector<std::pair<uint64_t, int>> key(R);
+        for (int r = 0; r < R; ++r) { uint64_t b; std::memcpy(&b, &sstat[r].t0, 8); key[r] = {b, r}; }
+        std::sort(key.begin(), key.end());
+        h->clock_t0.clear();
+        h->clock_of.assign(R, 0);
+        for (int i = 0; i < R; ++i) {
+            if (i == 0 || key[i].first != key[i - 1].first) h->clock_t0.push_back(sstat[key[i].second].t0);
+            h->clock_of[key[i].second] = (int)h->clock_t0.size() - 1;
+        }
+    }
     stage("union grids");
     // ---- device copies ----
     Params &p = h->p;
@@ -943,6 +1089,7 @@ extern "C" int sg_rollout_async(sg_handle *h, int32_t max_steps, int32_t do_rese
             if ((rc = launch_rollout(h, 1, 0, 0, nullptr)) || (rc = sg_rss_update(h, 0))) return rc;
         return SG_OK;
     }
+    if (do_reset && slicing_pays(h, max_steps)) return launch_sliced(h, max_steps);
     // external-action slots are fed (0, 0) here; drive them with sg_step(actions)
     return launch_rollout(h, max_steps, do_reset ? 1 : 0, 0, nullptr);
 }
@@ -1130,6 +1277,13 @@ extern "C" int sg_debug_trig32(sg_handle *h, int64_t n, const double *heading, f
     } while (0);
     (void)hipFree(d_h); (void)hipFree(d_s); (void)hipFree(d_c);
     if (rc) return fail(h, rc, "sg_debug_trig32: HIP copy/launch failed");
+    return SG_OK;
+}
+
+extern "C" int sg_set_slicing(sg_handle *h, int32_t mode)
+{
+    if (!h || mode < 0 || mode > 2) return h ? fail(h, SG_ERR_INVALID, "sg_set_slicing: mode 0, 1 or 2") : SG_ERR_INVALID;
+    h->slice_mode = mode;
     return SG_OK;
 }
 

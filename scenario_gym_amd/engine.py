@@ -327,6 +327,11 @@ class RolloutEngine:
         """Launch policy (sg_set_tuning); results never depend on it."""
         self._check(self.lib.sg_set_tuning(self.h, int(tab_min_steps), int(chunk_steps), int(overlap)), "sg_set_tuning")
 
+    def set_slicing(self, on=True):
+        """sg_set_slicing: may sg_rollout cut the time axis of a small replay-only batch into slices (results never depend on
+        it; the intermediate states are not written to memory when it does)."""
+        self._check(self.lib.sg_set_slicing(self.h, 2 if on == "always" else int(bool(on))), "sg_set_slicing")
+
     def last_launch_stats(self):
         """(number of rollout-kernel launches of the last call, sum of their durations in ms)."""
         n, ms = C.c_int32(), C.c_float()

@@ -1674,3 +1674,92 @@ def test_randomized_rss_matches_oracle(sga, oracle, cfg):
         assert np.array_equal(codes[r, :n], w["code"][-1]), (r, codes[r, :n], w["code"][-1])
         assert np.array_equal(safe[r, :n], w["safe"][-1], equal_nan=True), r
         assert slong[r] == w["safe_longitudinal"] and slat[r] == w["safe_lateral"], r
+
+
+# ---------------------------------------------------------------- time-sliced replay (sg_set_slicing)
+def _final_results(eng, steps):
+    eng.rollout(steps)
+    st = eng.state()
+    rows, events = eng.metrics()
+    return st, rows, events
+
+
+@pytest.mark.parametrize("R,E,steps,terminal,persist,dt", [
+    (256, 16, 400, ["max_length"], False, 1 / 30),                   # BASELINE config 2 shape
+    (96, 5, 333, ["max_length", "collision"], False, 1 / 30),        # scenarios end at different steps (first collision)
+    (70, 30, 250, ["max_length", "ego_collision"], True, 0.1),       # persist, tile of 32 lanes, ego collisions end some
+    (40, 64, 200, ["max_length"], False, 1 / 30),                    # full 64-lane tiles
+    (33, 3, 777, ["max_length"], False, 0.02),                       # tile of 4 lanes, slices of unequal length
+])
+def test_sliced_replay_equals_stepwise_and_oracle(sga, oracle, R, E, steps, terminal, persist, dt):
+    """sg_rollout of a replay-only batch with the time axis cut into slices (clock, slices side by side, last step
+    materialised, ordered sums): final state, metrics, events and the step each scenario stopped at are bit-identical to the
+    step-by-step kernel and to the oracle.  Event lists longer than the capacity (2 here) keep their first entries."""
+    import scenario_gym_amd._lib as L
+    from scenario_gym_amd import synthetic
+
+    packed = synthetic.make_batch(R, E, n_steps=steps, timestep=dt, ego_kind=L.KIND_AGENT_REPLAY, static_frac=0.15,
+                                  vanish_frac=0.2, extent=25.0 if E > 8 else 12.0)
+    out = {}
+    for mode in (False, "always"):
+        eng = sga.RolloutEngine(R, E, timestep=dt, persist=persist, terminal_conditions=terminal, event_capacity=2)
+        eng.set_slicing(mode)
+        eng.upload(packed)
+        out[mode] = _final_results(eng, steps)
+        if mode == "always":  # again on the same handle (its slice arrays are reused), then stepwise continues from the state
+            again = _final_results(eng, steps)
+            for k in ("poses", "vels", "dists", "coll", "t", "prev_t", "n_steps", "done", "present"):
+                assert bits_equal(again[0][k], out[mode][0][k]) if again[0][k].dtype.kind == "f" else np.array_equal(again[0][k], out[mode][0][k]), k
+            assert np.array_equal(again[1], out[mode][1]) and np.array_equal(again[2], out[mode][2])
+        eng.close()
+    (sa, ra, ea), (sb, rb, eb) = out[False], out["always"]
+    for k in ("poses", "vels", "dists", "t", "prev_t"):
+        assert bits_equal(sa[k], sb[k]), k
+    for k in ("coll", "n_steps", "done", "present"):
+        assert np.array_equal(sa[k], sb[k]), k
+    assert np.array_equal(ra, rb) and np.array_equal(ea, eb)
+    assert len(ea) > 0 and ((ra["n_collisions"] > 2).any() or len(terminal) > 1 or E < 16)  # some lists overflow the capacity of 2
+    if len(terminal) > 1:
+        assert len(set(ra["n_steps"])) > 3  # scenarios do stop at different steps
+    mask = sum(dict(max_length=1, collision=2, ego_collision=4)[c] for c in terminal)
+    for r in range(0, R, 7):
+        o = _oracle_batch(oracle, packed, dt, steps, [r], persist=persist, terminal_mask=mask)[r]
+        assert rb["n_steps"][r] == o["n_steps"] and rb["final_t"][r] == o["final_t"] and bool(rb["done"][r]) == o["is_done"], r
+        assert bits_equal(sb["poses"][r], o["poses"][-1]) and bits_equal(sb["vels"][r], o["vels"][-1]), r
+        assert bits_equal(sb["dists"][r], o["dists"][-1]) and np.array_equal(sb["coll"][r], o["coll"][-1, :, 0]), r
+        for k in ("ego_avg_speed", "ego_max_speed", "ego_distance_travelled"):
+            assert rb[k][r] == o["metric_" + k] or (np.isnan(rb[k][r]) and np.isnan(o["metric_" + k])), (r, k)
+        ev = eb[eb["scenario"] == r]
+        assert rb["n_collisions"][r] == o["n_events"] and np.array_equal(ev["t"], o["ev_t"][:2]) and np.array_equal(ev["other"], o["ev_other"][:2]), r
+
+
+def test_sliced_replay_on_the_reference_scenarios(sga, oracle):
+    """The 23 OpenSCENARIO files of the reference's tests as one ragged batch (1 ... 9 entities, different lengths and start
+    times, egos that appear late), sliced: clock, final poses / velocities / distances / collisions and the ego metrics are
+    the real reference's (golden all_scenarios), bit for bit."""
+    from scenario_gym_amd.packing import default_kinds, pack_arrays
+
+    g = load_golden("all_scenarios")
+    names = list(g["names"])
+    scs = []
+    for n in names:
+        s = scenario_arrays(g, f"{n}/scenario")
+        s["kind"] = default_kinds(len(s["bbox"]), s["ego"])
+        scs.append(s)
+    packed = pack_arrays(scs)
+    n_max = max(len(g[f"{n}/t"]) for n in names) + 4
+    eng = sga.RolloutEngine(packed.n_scenarios, packed.n_entities, timestep=1 / 30)
+    eng.set_slicing("always")
+    eng.upload(packed)
+    st, rows, events = _final_results(eng, n_max)
+    eng.close()
+    for i, n in enumerate(names):
+        ts = g[f"{n}/t"]
+        assert st["t"][i] == ts[-1] and rows["n_steps"][i] == len(ts) - 1 and rows["done"][i], n
+        final = g[f"{n}/final_poses"]
+        E = len(final)
+        assert bits_equal(st["poses"][i, :E], final) and bits_equal(st["vels"][i, :E], np.where(np.isnan(final[:, :1]), np.nan, g[f"{n}/final_vels"])), n
+        assert bits_equal(st["dists"][i, :E], g[f"{n}/final_dists"]), n
+        assert np.array_equal(_dense(st["coll"][i, :E], E), g[f"{n}/final_coll"]), n
+        for key in ("ego_avg_speed", "ego_max_speed", "ego_distance_travelled"):
+            assert rows[key][i] == float(g[f"{n}/metric_{key}"]), (n, key)
