@@ -24,7 +24,7 @@ from .engine import PackedScenarios, RolloutEngine  # noqa: F401
 from .entity import BoundingBox, CatalogEntry, Entity, MiscObject, Pedestrian, Vehicle  # noqa: F401
 from .gym import BatchedScenarioGym, ScenarioGym  # noqa: F401
 from .metrics import (  # noqa: F401
-    RSS, CollisionMetric, CollisionPointMetric, EgoAvgSpeed, EgoDistanceTravelled, EgoMaxSpeed, Metric, RSSDistances,
+    RSS, CollisionMetric, CollisionPointMetric, EgoAvgSpeed, EgoDistanceTravelled, EgoMaxSpeed, Metric, RSSDistances, StateCallback,
 )
 from .scenario import Scenario  # noqa: F401
 from .state import State  # noqa: F401

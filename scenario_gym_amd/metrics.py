@@ -134,7 +134,34 @@ class CollisionPointMetric(_DeviceMetric):
         return list(self.collisions)
 
 
-class RSSDistances:
+class StateCallback(ABC):
+    """callback.py:9-41: a callback that derives additional information from the state.  `reset(state)` resolves
+    `required_callbacks` through `state.get_callback` (ValueError when one is missing) and calls `_reset`; the gym calls the
+    object itself after the reset and after every step.  User subclasses run on the host (one launch per step)."""
+
+    required_callbacks: List[type] = []
+
+    def __init__(self):
+        self.callbacks: list = []
+
+    def reset(self, state) -> None:
+        self.callbacks = []
+        for req in self.required_callbacks:
+            cb = state.get_callback(req)
+            if cb is None:
+                raise ValueError(f"Callback {req.__name__} is required for {self.__class__}.")
+            self.callbacks.append(cb)
+        self._reset(state)
+
+    def _reset(self, state) -> None:
+        pass
+
+    @abstractmethod
+    def __call__(self, state) -> None:
+        raise NotImplementedError
+
+
+class RSSDistances(StateCallback):
     """metrics/rss/callback.py:34-128 as a state callback: after every step the safe lateral / longitudinal distances
     between the ego and every present entity and the record the reference appends to that entity's history, computed on
     the device for the whole batch: a gym that holds this callback switches the library to run it after the reset and after
@@ -142,7 +169,7 @@ class RSSDistances:
 
     CODES = ("safe", "lateral", "longitudinal", "both", "unsafe_lateral", "unsafe_longitudinal", "found")
 
-    def reset(self, state) -> None:  # the library resets and updates the records itself (sg_set_rss)
+    def _reset(self, state) -> None:  # the library resets and updates the records itself (sg_set_rss)
         pass
 
     def __call__(self, state) -> None:

@@ -23,6 +23,13 @@ class State:
     def _s(self):
         return self._gym._fetch_state()
 
+    def get_callback(self, cls):
+        """state/state.py:272-282: the state callback of class `cls`, or None."""
+        for cb in self._gym.state_callbacks:
+            if isinstance(cb, cls):
+                return cb
+        return None
+
     @property
     def scenario(self) -> Scenario:
         return self._scenario

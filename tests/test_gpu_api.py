@@ -169,6 +169,33 @@ def test_user_defined_python_metric_and_callback():
     assert m["max_other_speed_value"] == np.nanmax(np.linalg.norm(v, axis=-1))
     assert m["ego_max_speed"] == float(g[p + "/metric_ego_max_speed"])
     assert seen[0] == g[p + "/t"][0] and seen[-1] == g[p + "/t"][-1]
+    gym.close()
+
+    # StateCallback subclasses (callback.py:9-41): required_callbacks are resolved through state.get_callback at reset
+    class Clock(sga.StateCallback):
+        def _reset(self, state):
+            self.ts = []
+
+        def __call__(self, state):
+            self.ts.append(state.t)
+
+    class NeedsClock(sga.StateCallback):
+        required_callbacks = [Clock]
+
+        def __call__(self, state):
+            self.last = self.callbacks[0].ts[-1]
+
+    clock, dep = Clock(), NeedsClock()
+    gym = sga.ScenarioGym(timestep=0.1, state_callbacks=[clock, dep])
+    gym.set_scenario(_scenario(g, "3fee6507/scenario"))
+    gym.rollout()
+    assert bits_equal(np.array(clock.ts), g[p + "/t"]) and dep.last == g[p + "/t"][-1] and dep.callbacks == [clock]
+    assert gym.state.get_callback(Clock) is clock and gym.state.get_callback(sga.RSSDistances) is None
+    gym.close()
+    gym = sga.ScenarioGym(timestep=0.1, state_callbacks=[NeedsClock()])
+    with pytest.raises(ValueError, match="Callback Clock is required"):
+        gym.set_scenario(_scenario(g, "3fee6507/scenario"))
+    gym.close()
 
 
 def test_batched_gym_with_external_actions_and_mixed_agents():

@@ -324,6 +324,56 @@ def test_full_size_invariants(sga, oracle):
         assert rows["ego_distance_travelled"][r] == o["metric_ego_distance_travelled"]
 
 
+def test_full_size_crowd_invariants(sga, oracle):
+    """BASELINE config 5 at its full width (1024 scenarios x 256 pedestrians, the crowd kernel) for 300 steps, through the
+    densest phase: size-independent properties of the state + oracle spot checks on scattered scenarios."""
+    from scenario_gym_amd import synthetic
+
+    R, E, steps = 1024, 256, 300
+    packed = synthetic.make_crowd(R, E, n_steps=steps)
+    eng = sga.RolloutEngine(R, E, event_capacity=64)
+    eng.upload(packed)
+    eng.rollout(steps)
+    st = eng.state()
+    rows, events = eng.metrics()
+    assert (rows["n_steps"] == steps).all() and rows["done"].all() and st["present"].all()
+    tt = 0.0
+    for _ in range(steps):
+        tt += 1 / 30
+    assert (rows["final_t"] == tt).all()
+    bits = np.unpackbits(np.ascontiguousarray(st["coll"]).view(np.uint8), axis=-1, bitorder="little").reshape(R, E, -1)[:, :, :E].astype(bool)
+    assert np.array_equal(bits, bits.transpose(0, 2, 1)) and not bits[:, np.arange(E), np.arange(E)].any()
+    assert bits.any(axis=(1, 2)).mean() > 0.9                      # almost every crowd has colliding boxes by now
+    # overlapping boxes have centres within one box diagonal; pedestrians further apart than that never collide
+    xy = st["poses"][:, :, :2]
+    d = np.linalg.norm(xy[:, :, None, :] - xy[:, None, :, :], axis=-1)
+    diag = float(np.hypot(*synthetic.PEDESTRIAN1_BBOX[:2]))
+    assert (d[bits] <= diag + 1e-12).all()
+    assert not bits[d > diag + 1e-12].any()
+    goal = st["ctrl_state"][:, :, 1]
+    arrived = goal > 1
+    assert set(np.unique(goal)) <= {1.0, 2.0} and 0 < arrived.mean() < 0.5
+    assert (st["force"][arrived] == 0).all() and (st["ctrl_state"][:, :, 0][arrived] == 0).all()   # agent.py:65-68
+    vdes = packed.ctrl[:, 9].reshape(R, E)
+    assert (st["ctrl_state"][:, :, 0] <= vdes * 1.3 + 1e-12).all()  # speed = min(|F|, speed_desired * max_speed_factor)
+    assert (st["dists"] >= 0).all() and (st["dists"][~arrived] > 0).all()
+    ev_r = np.bincount(events["scenario"], minlength=R)
+    assert (rows["n_collisions"] >= ev_r).all() and (events["type"] == 5).all()   # pedestrians: "non_vehicle"
+    # idempotence: a second rollout from reset reproduces the same bits
+    eng.rollout(steps)
+    st2 = eng.state()
+    for k in ("poses", "vels", "dists", "force"):
+        assert bits_equal(st[k], st2[k]), k
+    assert np.array_equal(st["coll"], st2["coll"])
+    eng.close()
+    for r in (0, 511, 1023):
+        o = _oracle_one(oracle, packed, r, 1 / 30, steps)
+        assert bits_equal(st["poses"][r], o["poses"][-1]) and bits_equal(st["vels"][r], o["vels"][-1]), r
+        assert bits_equal(st["force"][r], o["extra"][-1, :, 2:]) and bits_equal(st["dists"][r], o["dists"][-1]), r
+        assert np.array_equal(_dense_words(st["coll"][r], E), oracle.coll_to_dense(o["coll"], E)[-1]), r
+        assert rows["n_collisions"][r] == o["n_events"], r
+
+
 # --------------------------------------------------------------------------- wide tiles (E > 64)
 def _oracle_one(oracle, packed, r, dt, n_max, **kw):
     from scenario_gym_amd.packing import unpack_scenario
