@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <chrono>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <thread>
 #include <vector>
@@ -17,6 +18,17 @@
 #include "sgym_device.hpp"
 
 using sg::Params;
+
+// Device allocations of one upload, kept across uploads: a pipeline that feeds batch after batch of the same shape through
+// a handle must not pay hipFree / hipMalloc each time (both wait for the WHOLE device, i.e. for the rollout another handle
+// is running: the double-buffered upload of tools/upload_time.py would serialise with it).  sg_upload requests its buffers
+// in a fixed order; request i reuses slot i when it is large enough.
+struct ReusePool {
+    std::vector<void *> ptr;
+    std::vector<size_t> cap;
+    size_t cursor = 0;
+    void rewind() { cursor = 0; }
+};
 
 struct sg_handle {
     sg_config cfg{};
@@ -47,7 +59,7 @@ struct sg_handle {
     bool timing_now = true;       // this call records its timing events (calls of >= 16 steps, and every table-path call)
     bool timed = false;
     Params p{};
-    std::vector<void *> static_allocs, state_allocs;
+    ReusePool static_allocs, state_allocs;
     int32_t *d_row_scen = nullptr;
     int64_t total_rows = 0;
     double *d_actions = nullptr;
@@ -59,6 +71,7 @@ struct sg_handle {
     int max_ctl_per_block = 0; // controlled lanes in the fullest 64-slot block
     hipStream_t ctl_stream = nullptr;
     double *d_tab[2] = {nullptr, nullptr};
+    size_t tab_bytes = 0;     // bytes of each table buffer
     std::vector<hipEvent_t> ev_pool;
     int tab_min = 16, chunk_steps = 1024, overlap = 1; // sg_set_tuning
     // sg_tick: the kernels of one RL tick captured once as a hipGraph and replayed with a single launch
@@ -138,6 +151,44 @@ static int dev_upload(sg_handle *h, std::vector<void *> &pool, const T **out, co
     if (!v.empty()) HIP_TRY(h, hipMemcpyAsync(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, h->stream));
     *out = d;
     return SG_OK;
+}
+
+template <typename T>
+static int dev_alloc(sg_handle *h, ReusePool &pool, T **out, size_t n, bool zero = true)
+{
+    const size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
+    const size_t i = pool.cursor++;
+    if (i == pool.ptr.size()) { pool.ptr.push_back(nullptr); pool.cap.push_back(0); }
+    if (pool.cap[i] < bytes) {
+        if (pool.ptr[i]) HIP_TRY(h, hipFree(pool.ptr[i]));
+        pool.ptr[i] = nullptr;
+        pool.cap[i] = 0;
+        HIP_TRY(h, hipMalloc(&pool.ptr[i], bytes));
+        pool.cap[i] = bytes;
+    }
+    if (zero) HIP_TRY(h, hipMemsetAsync(pool.ptr[i], 0, bytes, h->stream));
+    *out = (T *)pool.ptr[i];
+    return SG_OK;
+}
+
+template <typename T>
+static int dev_upload(sg_handle *h, ReusePool &pool, const T **out, const std::vector<T> &v)
+{
+    T *d = nullptr;
+    int rc = dev_alloc(h, pool, &d, v.size(), false);
+    if (rc) return rc;
+    if (!v.empty()) HIP_TRY(h, hipMemcpyAsync(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, h->stream));
+    *out = d;
+    return SG_OK;
+}
+
+static void free_pool(ReusePool &pool)
+{
+    for (void *ptr : pool.ptr)
+        if (ptr) (void)hipFree(ptr);
+    pool.ptr.clear();
+    pool.cap.clear();
+    pool.cursor = 0;
 }
 
 static void free_pool(std::vector<void *> &pool)
@@ -354,6 +405,8 @@ static int launch_rollout(sg_handle *h, int n_steps, int do_reset, int force, co
         if (h->n_ctl == 0) { // nothing to integrate: the table variant reads (and ignores) one dummy row
             if (!h->d_tab[0]) {
                 HIP_TRY(h, hipMalloc((void **)&h->d_tab[0], 64 * sizeof(double)));
+                HIP_TRY(h, hipMalloc((void **)&h->d_tab[1], 64 * sizeof(double)));
+                h->tab_bytes = 64 * sizeof(double);
                 HIP_TRY(h, hipMemsetAsync(h->d_tab[0], 0, 64 * sizeof(double), h->stream));
             }
             rc = launch_main(h, n_steps, 0, force, nullptr, h->d_tab[0], true, &ev_next);
@@ -363,13 +416,18 @@ static int launch_rollout(sg_handle *h, int n_steps, int do_reset, int force, co
             int ch = (int)std::min<size_t>((size_t)chunk_steps, std::max<size_t>(1, ((size_t)1 << 27) / row));
             ch = std::min(ch, n_steps);
             if (ch > h->p.tab_steps) { // grow: tab_steps + 1 rows per lane is part of the table addressing
-                HIP_TRY(h, hipStreamSynchronize(h->stream));
-                HIP_TRY(h, hipStreamSynchronize(h->ctl_stream));
-                for (int b = 0; b < 2; ++b) {
-                    if (h->d_tab[b]) HIP_TRY(h, hipFree(h->d_tab[b]));
-                    h->d_tab[b] = nullptr;
+                const size_t need = (size_t)(ch + 1) * row * sizeof(double);
+                if (need > h->tab_bytes) { // (the buffers outlive sg_upload: the next batch of the same shape reuses them)
+                    HIP_TRY(h, hipStreamSynchronize(h->stream));
+                    HIP_TRY(h, hipStreamSynchronize(h->ctl_stream));
+                    for (int b = 0; b < 2; ++b) {
+                        if (h->d_tab[b]) HIP_TRY(h, hipFree(h->d_tab[b]));
+                        h->d_tab[b] = nullptr;
+                    }
+                    h->tab_bytes = 0;
+                    for (int b = 0; b < 2; ++b) HIP_TRY(h, hipMalloc((void **)&h->d_tab[b], need));
+                    h->tab_bytes = need;
                 }
-                for (int b = 0; b < 2; ++b) HIP_TRY(h, hipMalloc((void **)&h->d_tab[b], (size_t)(ch + 1) * row * sizeof(double)));
                 h->p.tab_steps = ch;
             }
             hipStream_t cs = no_overlap ? h->stream : h->ctl_stream;
@@ -585,17 +643,13 @@ extern "C" int sg_upload(sg_handle *h, const sg_scenarios *sc)
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->ctl_stream));
-    free_pool(h->static_allocs);
-    free_pool(h->state_allocs);
+    h->static_allocs.rewind(); // (buffers of the previous batch are reused where they are large enough)
+    h->state_allocs.rewind();
     free_pool(h->road_allocs); // the networks belong to a batch (net_of_scenario)
     if (h->d_rss_state) { (void)hipFree(h->d_rss_state); (void)hipFree(h->d_rss_code); (void)hipFree(h->d_rss_safe); (void)hipFree(h->d_rss_seen); h->d_rss_state = nullptr; h->d_rss_code = nullptr; h->d_rss_safe = nullptr; h->d_rss_seen = nullptr; }
     h->has_road = false;
     h->road = sg::RoadIndex{};
-    for (int b = 0; b < 2; ++b) { // the controller table geometry depends on the batch
-        if (h->d_tab[b]) HIP_TRY(h, hipFree(h->d_tab[b]));
-        h->d_tab[b] = nullptr;
-    }
-    h->uploaded = false;
+    h->uploaded = false; // (the controller table buffers stay: launch_rollout regrows them when the new batch needs more)
     h->ego_first = true;
     ++h->generation;
     // pedestrian agents are compiled for tiles of >= 16 lanes
@@ -624,24 +678,52 @@ extern "C" int sg_upload(sg_handle *h, const sg_scenarios *sc)
         t_last = now;
     };
 
-    // ---- validate + block re-layout (host): [n_blocks][ST_COUNT][64] ----
+    // ---- the knots (by far the largest array: 1.6 GB for 4096 x 64 x 128) start crossing PCIe NOW, from a thread of their
+    // own on the second stream, while the host validates the batch and builds the union grids below.  Their extent comes
+    // from knot_off, which is checked first (a bad offset must not turn into an out-of-bounds read of the copy).
+    const int64_t rows_total = sc->knot_off[(size_t)R * E];
+    {
+        bool ok = sc->knot_off[0] >= 0;
+        for (size_t i = 0; i < (size_t)R * E && ok; ++i) ok = sc->knot_off[i + 1] >= sc->knot_off[i];
+        if (!ok) return fail(h, SG_ERR_INVALID, "sg_upload: knot_off is not monotone");
+    }
+    double *d_knots = nullptr;
+    {
+        int rc0 = dev_alloc(h, h->static_allocs, &d_knots, (size_t)std::max<int64_t>(rows_total, 1) * 7, false);
+        if (rc0) return rc0;
+    }
+    hipError_t copy_err = hipSuccess;
+    std::thread copier([&]() {
+        if (rows_total <= 0) return;
+        copy_err = hipSetDevice(h->cfg.device);
+        if (copy_err == hipSuccess)
+            copy_err = hipMemcpyAsync(d_knots, sc->knots, (size_t)rows_total * 7 * sizeof(double), hipMemcpyHostToDevice, h->ctl_stream);
+        if (copy_err == hipSuccess) copy_err = hipStreamSynchronize(h->ctl_stream);
+    });
+    struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } copier_guard{copier}; // every return path waits
+
+    // ---- validate + block re-layout + union knot grids (host, one parallel pass over the scenarios) ----
     const size_t nblk = NE / 64;
-    std::vector<double> stat(nblk * sg::ST_COUNT * 64, 0.0);
+    const size_t stat_n = nblk * sg::ST_COUNT * 64;
+    std::unique_ptr<double[]> stat_buf(new double[stat_n]); // (48 MB for 4096 x 64: every slot is written by the pass below)
+    double *stat = stat_buf.get();
     auto S = [&](size_t ent, int f) -> double & { return stat[(ent >> 6) * sg::ST_COUNT * 64 + (size_t)f * 64 + (ent & 63)]; };
     auto SI = [&](size_t ent, int f) -> int64_t & { return *reinterpret_cast<int64_t *>(&S(ent, f)); };
-    for (size_t o = 0; o < NE; ++o) {
+    auto slot_defaults = [&](size_t o) { // a padding slot: never present
+        for (int f = 0; f < sg::ST_COUNT; ++f) S(o, f) = 0.0;
         for (int q = 0; q < 4; ++q) S(o, sg::ST_BW + q) = 1.0;
         for (int q = 0; q < sg::NCTRL_ROWS; ++q) S(o, sg::ST_CTRL + q) = kDefaultCtrl[q];
         SI(o, sg::ST_META) = SG_KIND_NONE | (2 << 8);
         SI(o, sg::ST_CTL) = -1;
-    }
+    };
+    for (size_t o = (size_t)R * EP; o < NE; ++o) slot_defaults(o); // the tail of the last block
     std::vector<int32_t> ctl_ent; // controlled lanes (PID / vehicle agents) in entity order
     int n_ext = 0;
     std::vector<sg::ScenStatic> sstat(R);
-    const int64_t rows_total = sc->knot_off[(size_t)R * E];
-    {   // scenarios are validated and re-laid out in parallel (the strictly-increasing check walks every knot: 33 M for the
-        // 4096 x 64 x 128 batch); the first error by scenario index is reported
-        const unsigned nthr = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+    std::vector<std::vector<double>> grids(R); // BatchReplayEntity union knot grid per scenario (entity/batch.py:83-95)
+    {   // scenarios are validated, re-laid out and given their union grid in parallel (the strictly-increasing check walks
+        // every knot: 33 M for the 4096 x 64 x 128 batch; the grid sorts them); the first error by scenario index is reported
+        const unsigned nthr = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
         std::vector<std::string> errs(nthr);
         std::vector<int> err_r(nthr, R), ext_cnt(nthr, 0);
         std::vector<char> ego_nz(nthr, 0);
@@ -658,6 +740,7 @@ extern "C" int sg_upload(sg_handle *h, const sg_scenarios *sc)
                 if (sc->ego[r] != 0) ego_nz[w] = 1;
                 sstat[r].t0 = sc->t0[r];
                 sstat[r].length = sc->length[r];
+                for (int e = 0; e < EP; ++e) slot_defaults((size_t)r * EP + e);
                 for (int e = 0; e < E; ++e) {
                     size_t i = (size_t)r * E + e, o = (size_t)r * EP + e;
                     int k = sc->kind[i];
@@ -683,6 +766,19 @@ extern "C" int sg_upload(sg_handle *h, const sg_scenarios *sc)
                                 return bad(r, "sg_upload: knot times of entity %zu are not strictly increasing (%d)", i, 0);
                     }
                 }
+                std::vector<double> &g = grids[r]; // the union grid, while the scenario's knots are in cache
+                for (int e = 0; e < E; ++e) {
+                    size_t i = (size_t)r * E + e;
+                    if (sc->kind[i] != SG_KIND_REPLAY) continue;
+                    int64_t a = sc->knot_off[i], b = sc->knot_off[i + 1];
+                    for (int64_t j = a; j < b; ++j) {
+                        double v = sc->knots[(size_t)j * 7];
+                        g.push_back(v == v ? v : 0.0); // np.nan_to_num
+                    }
+                    if (b - a == 1) g.push_back(sc->knots[(size_t)a * 7] + 1e-1); // batch.py:85-88
+                }
+                std::sort(g.begin(), g.end());
+                g.erase(std::unique(g.begin(), g.end()), g.end());
             }
         };
         std::vector<std::thread> pool;
@@ -709,32 +805,7 @@ extern "C" int sg_upload(sg_handle *h, const sg_scenarios *sc)
             }
     }
 
-    stage("validate + re-layout");
-    // ---- BatchReplayEntity union knot grid per scenario (entity/batch.py:83-95), threaded ----
-    std::vector<std::vector<double>> grids(R);
-    {
-        unsigned nthr = std::max(1u, std::min(48u, std::thread::hardware_concurrency()));
-        std::vector<std::thread> pool;
-        for (unsigned w = 0; w < nthr; ++w)
-            pool.emplace_back([&, w]() {
-                for (int r = w; r < R; r += nthr) {
-                    std::vector<double> &g = grids[r];
-                    for (int e = 0; e < E; ++e) {
-                        size_t i = (size_t)r * E + e;
-                        if (sc->kind[i] != SG_KIND_REPLAY) continue;
-                        int64_t a = sc->knot_off[i], b = sc->knot_off[i + 1];
-                        for (int64_t j = a; j < b; ++j) {
-                            double v = sc->knots[(size_t)j * 7];
-                            g.push_back(v == v ? v : 0.0); // np.nan_to_num
-                        }
-                        if (b - a == 1) g.push_back(sc->knots[(size_t)a * 7] + 1e-1); // batch.py:85-88
-                    }
-                    std::sort(g.begin(), g.end());
-                    g.erase(std::unique(g.begin(), g.end()), g.end());
-                }
-            });
-        for (auto &th : pool) th.join();
-    }
+    stage("validate + re-layout + union grids");
     std::vector<int64_t> grid_off(R + 1, 0);
     for (int r = 0; r < R; ++r) {
         sstat[r].grid_n = (int32_t)grids[r].size();
@@ -776,15 +847,16 @@ extern "C" int sg_upload(sg_handle *h, const sg_scenarios *sc)
     p.ev_cap = h->cfg.event_capacity > 0 ? h->cfg.event_capacity : 0;
     auto &SA = h->static_allocs;
     int rc = 0;
-    if ((rc = dev_upload(h, SA, &p.stat, stat))) return rc;
+    {
+        double *d_stat = nullptr;
+        if ((rc = dev_alloc(h, SA, &d_stat, stat_n, false))) return rc;
+        HIP_TRY(h, hipMemcpyAsync(d_stat, stat, stat_n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        p.stat = d_stat;
+    }
     if ((rc = dev_upload(h, SA, &p.sstat, sstat))) return rc;
     if ((rc = dev_upload(h, SA, &p.grid_t, grid_t))) return rc;
     {
-        double *d = nullptr;
-        if ((rc = dev_alloc(h, SA, &d, (size_t)std::max<int64_t>(rows_total, 1) * 7, false))) return rc;
-        if (rows_total > 0)
-            HIP_TRY(h, hipMemcpyAsync(d, sc->knots, (size_t)rows_total * 7 * sizeof(double), hipMemcpyHostToDevice, h->stream));
-        p.knots = d;
+        p.knots = d_knots; // (on its way since the top of the call)
         const int32_t *drs = nullptr;
         if ((rc = dev_upload(h, SA, &drs, row_scen))) return rc;
         h->d_row_scen = const_cast<int32_t *>(drs);
@@ -801,11 +873,11 @@ extern "C" int sg_upload(sg_handle *h, const sg_scenarios *sc)
         if ((rc = dev_upload(h, SA, &p.gon, gon))) return rc;
     }
     h->n_ext = n_ext;
-    {   // external poses start as "None" for every slot
-        std::vector<double> none(NE * 6, NAN);
-        const double *d = nullptr;
-        if ((rc = dev_upload(h, SA, &d, none))) return rc;
-        h->d_ext = const_cast<double *>(d);
+    {   // external poses start as "None" (NaN: all-ones bytes) for every slot
+        double *d = nullptr;
+        if ((rc = dev_alloc(h, SA, &d, NE * 6, false))) return rc;
+        HIP_TRY(h, hipMemsetAsync(d, 0xFF, NE * 6 * sizeof(double), h->stream));
+        h->d_ext = d;
         p.ext_pose = d;
     }
     h->n_ctl = (int)ctl_ent.size();
@@ -829,7 +901,9 @@ extern "C" int sg_upload(sg_handle *h, const sg_scenarios *sc)
 #ifdef SG_PHASE_TIMERS
     if ((rc = dev_alloc(h, M, &p.phase_cycles, 16 + 4096))) return rc;
 #endif
-    if (trace) { (void)hipStreamSynchronize(h->stream); stage("allocations + copies"); }
+    copier.join();
+    if (copy_err != hipSuccess) return fail(h, SG_ERR_HIP, "sg_upload: copying the knots failed: %s", hipGetErrorString(copy_err));
+    if (trace) { (void)hipStreamSynchronize(h->stream); stage("allocations + copies (knots: since the start)"); }
     // stage-1 resample on device
     if (total_rows > 0) {
         int64_t threads = total_rows * EP;
