@@ -1,0 +1,322 @@
+// sgym_xosc.cpp -- libsgym_xosc.so: one-pass scan of an OpenSCENARIO file for what the rollout engine consumes
+// (include/sgym_xosc.h).  A tag tokenizer with a stack of the element names that matter; no DOM, no allocation per node.
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/sgym_xosc.h"
+
+namespace {
+
+enum Tag : int8_t {
+    T_OTHER = 0, T_CATALOG_LOCATIONS, T_DIRECTORY, T_ROAD_NETWORK, T_SCENE_GRAPH_FILE, T_LOGIC_FILE, T_ENTITIES,
+    T_SCENARIO_OBJECT, T_CATALOG_REFERENCE, T_VEHICLE, T_PEDESTRIAN, T_MISC_OBJECT, T_BOUNDING_BOX, T_CENTER, T_DIMENSIONS,
+    T_STORYBOARD, T_INIT, T_ACTIONS, T_PRIVATE, T_PRIVATE_ACTION, T_TELEPORT_ACTION, T_POSITION, T_WORLD_POSITION, T_STORY,
+    T_ACT, T_MANEUVER_GROUP, T_ACTORS, T_ENTITY_REF, T_MANEUVER, T_EVENT, T_ACTION, T_ROUTING_ACTION,
+    T_FOLLOW_TRAJECTORY_ACTION, T_TRAJECTORY_REF, T_TRAJECTORY, T_SHAPE, T_POLYLINE, T_VERTEX
+};
+
+struct Name { const char *s; Tag t; };
+const Name kNames[] = {
+    {"CatalogLocations", T_CATALOG_LOCATIONS}, {"Directory", T_DIRECTORY}, {"RoadNetwork", T_ROAD_NETWORK},
+    {"SceneGraphFile", T_SCENE_GRAPH_FILE}, {"LogicFile", T_LOGIC_FILE}, {"Entities", T_ENTITIES},
+    {"ScenarioObject", T_SCENARIO_OBJECT}, {"CatalogReference", T_CATALOG_REFERENCE}, {"Vehicle", T_VEHICLE},
+    {"Pedestrian", T_PEDESTRIAN}, {"MiscObject", T_MISC_OBJECT}, {"BoundingBox", T_BOUNDING_BOX}, {"Center", T_CENTER},
+    {"Dimensions", T_DIMENSIONS}, {"Storyboard", T_STORYBOARD}, {"Init", T_INIT}, {"Actions", T_ACTIONS},
+    {"Private", T_PRIVATE}, {"PrivateAction", T_PRIVATE_ACTION}, {"TeleportAction", T_TELEPORT_ACTION},
+    {"Position", T_POSITION}, {"WorldPosition", T_WORLD_POSITION}, {"Story", T_STORY}, {"Act", T_ACT},
+    {"ManeuverGroup", T_MANEUVER_GROUP}, {"Actors", T_ACTORS}, {"EntityRef", T_ENTITY_REF}, {"Maneuver", T_MANEUVER},
+    {"Event", T_EVENT}, {"Action", T_ACTION}, {"RoutingAction", T_ROUTING_ACTION},
+    {"FollowTrajectoryAction", T_FOLLOW_TRAJECTORY_ACTION}, {"TrajectoryRef", T_TRAJECTORY_REF}, {"Trajectory", T_TRAJECTORY},
+    {"Shape", T_SHAPE}, {"Polyline", T_POLYLINE}, {"Vertex", T_VERTEX},
+};
+
+Tag tag_of(const char *s, int n)
+{
+    for (const Name &k : kNames)
+        if ((int)strlen(k.s) == n && memcmp(k.s, s, n) == 0) return k.t;
+    return T_OTHER;
+}
+
+struct Attr { const char *name; int nlen; const char *val; int vlen; };
+
+struct Scanner {
+    const char *text;
+    int64_t len;
+    std::vector<Tag> stack;
+
+    // does the stack end with the given tags (innermost last)?
+    template <int N>
+    bool ends(const Tag (&want)[N]) const
+    {
+        if ((int)stack.size() < N) return false;
+        for (int i = 0; i < N; ++i)
+            if (stack[stack.size() - N + i] != want[i]) return false;
+        return true;
+    }
+    bool under(Tag t) const
+    {
+        for (Tag s : stack)
+            if (s == t) return true;
+        return false;
+    }
+};
+
+bool attr_is(const Attr &a, const char *name) { return (int)strlen(name) == a.nlen && memcmp(a.name, name, a.nlen) == 0; }
+
+double to_double(const Attr &a)
+{
+    char buf[64];
+    if (a.vlen < (int)sizeof buf) { // (attribute values are not NUL-terminated)
+        memcpy(buf, a.val, a.vlen);
+        buf[a.vlen] = 0;
+        char *end = nullptr;
+        const double v = strtod(buf, &end);
+        if (end != buf) return v;
+    }
+    return std::nan("");
+}
+
+sgx_str slice(const char *base, const char *p, int n) { return sgx_str{(int32_t)(p - base), n}; }
+
+} // namespace
+
+extern "C" int sgx_version(void) { return 1; }
+
+extern "C" int sgx_parse(const char *text, int64_t len, sgx_counts *counts, sgx_str *dirs, int32_t cap_dirs, sgx_object *objects,
+                         int32_t cap_objects, sgx_teleport *teleports, int32_t cap_teleports, sgx_trajectory *trajectories,
+                         int32_t cap_trajectories, double *vertices, int64_t cap_vertices)
+{
+    if (!text || !counts || len < 0 || len > 0x7fffffff) return SGX_ERR_SYNTAX;
+    sgx_counts C{};
+    C.road_file = sgx_str{0, -1};
+    Scanner S{text, len, {}};
+    S.stack.reserve(32);
+    const sgx_str none{0, -1};
+    // state of the elements being read
+    int cur_obj = -1;             // ScenarioObject
+    sgx_str private_ref = none;   // Init/Actions/Private@entityRef
+    sgx_str group_ref = none;     // first Actors/EntityRef of the ManeuverGroup
+    int group_first_traj = 0;     // trajectories of the current group get group_ref when the group closes
+    bool event_has_fta = false;   // the Event already met its first FollowTrajectoryAction
+    bool in_first_fta = false;    // ... and we are inside it
+    int fta_depth = 0;
+    int64_t traj_v0 = 0;
+    double vertex_time = 0.0;
+    bool road_from_scene_graph = false;
+    std::vector<Attr> attrs;
+    attrs.reserve(16);
+
+    const char *p = text, *end = text + len;
+    while (p < end) {
+        const char *lt = (const char *)memchr(p, '<', end - p);
+        if (!lt) break;
+        p = lt + 1;
+        if (p >= end) break;
+        if (*p == '?') { // declaration / processing instruction
+            const char *q = p;
+            while (q + 1 < end && !(q[0] == '?' && q[1] == '>')) ++q;
+            p = q + 2;
+            continue;
+        }
+        if (*p == '!') { // comment, CDATA, DOCTYPE
+            if (end - p >= 3 && p[1] == '-' && p[2] == '-') {
+                const char *q = p + 3;
+                while (q + 2 < end && !(q[0] == '-' && q[1] == '-' && q[2] == '>')) ++q;
+                p = q + 3;
+            } else {
+                const char *q = (const char *)memchr(p, '>', end - p);
+                p = q ? q + 1 : end;
+            }
+            continue;
+        }
+        if (*p == '/') { // closing tag
+            const char *q = (const char *)memchr(p, '>', end - p);
+            if (!q || S.stack.empty()) return SGX_ERR_SYNTAX;
+            const Tag t = S.stack.back();
+            S.stack.pop_back();
+            if (t == T_SCENARIO_OBJECT) cur_obj = -1;
+            else if (t == T_PRIVATE) private_ref = none;
+            else if (t == T_FOLLOW_TRAJECTORY_ACTION && in_first_fta && (int)S.stack.size() == fta_depth) {
+                in_first_fta = false;
+                if (C.n_vertices > traj_v0) { // an Event whose first FollowTrajectoryAction has vertices
+                    if (C.n_trajectories < cap_trajectories) trajectories[C.n_trajectories] = sgx_trajectory{none, traj_v0, C.n_vertices};
+                    ++C.n_trajectories;
+                }
+            } else if (t == T_EVENT) event_has_fta = false;
+            else if (t == T_MANEUVER_GROUP) {
+                for (int i = group_first_traj; i < C.n_trajectories && i < cap_trajectories; ++i) trajectories[i].entity = group_ref;
+                group_ref = none;
+            }
+            p = q + 1;
+            continue;
+        }
+        // opening (or self-closing) tag: name
+        const char *n0 = p;
+        while (p < end && !isspace((unsigned char)*p) && *p != '>' && *p != '/') ++p;
+        const Tag t = tag_of(n0, (int)(p - n0));
+        const char *tag_name = n0;
+        const int tag_len = (int)(p - n0);
+        // attributes
+        attrs.clear();
+        bool self_close = false;
+        for (;;) {
+            while (p < end && isspace((unsigned char)*p)) ++p;
+            if (p >= end) return SGX_ERR_SYNTAX;
+            if (*p == '>') { ++p; break; }
+            if (*p == '/') { self_close = true; ++p; continue; }
+            const char *a0 = p;
+            while (p < end && *p != '=' && !isspace((unsigned char)*p) && *p != '>') ++p;
+            const int an = (int)(p - a0);
+            while (p < end && isspace((unsigned char)*p)) ++p;
+            if (p >= end || *p != '=') return SGX_ERR_SYNTAX;
+            ++p;
+            while (p < end && isspace((unsigned char)*p)) ++p;
+            if (p >= end || (*p != '"' && *p != '\'')) return SGX_ERR_SYNTAX;
+            const char quote = *p++;
+            const char *v0 = p;
+            const char *v1 = (const char *)memchr(p, quote, end - p);
+            if (!v1) return SGX_ERR_SYNTAX;
+            if (t != T_OTHER) attrs.push_back(Attr{a0, an, v0, (int)(v1 - v0)});
+            p = v1 + 1;
+        }
+        auto attr = [&](const char *name) -> const Attr * {
+            for (const Attr &a : attrs)
+                if (attr_is(a, name)) return &a;
+            return nullptr;
+        };
+        auto attr_str = [&](const char *name) -> sgx_str {
+            const Attr *a = attr(name);
+            return a ? slice(text, a->val, a->vlen) : none;
+        };
+        const int depth = (int)S.stack.size(); // depth of the parent
+        const Tag parent = depth ? S.stack.back() : T_OTHER;
+        switch (t) {
+        case T_DIRECTORY:
+            if (depth >= 2 && S.stack[depth - 2] == T_CATALOG_LOCATIONS) {
+                if (C.n_dirs < cap_dirs) dirs[C.n_dirs] = attr_str("path");
+                ++C.n_dirs;
+            }
+            break;
+        case T_SCENE_GRAPH_FILE:
+        case T_LOGIC_FILE:
+            if (parent == T_ROAD_NETWORK && depth == 2 && (t == T_SCENE_GRAPH_FILE || !road_from_scene_graph)) {
+                if (t == T_SCENE_GRAPH_FILE || C.road_file.len < 0) C.road_file = attr_str("filepath");
+                road_from_scene_graph = road_from_scene_graph || t == T_SCENE_GRAPH_FILE;
+            }
+            break;
+        case T_SCENARIO_OBJECT:
+            if (parent == T_ENTITIES && depth == 2) {
+                cur_obj = C.n_objects;
+                if (cur_obj < cap_objects) {
+                    sgx_object o{};
+                    o.name = attr_str("name");
+                    o.catalog = o.entry = o.inline_tag = o.inline_name = o.inline_category = none;
+                    objects[cur_obj] = o;
+                }
+                ++C.n_objects;
+            }
+            break;
+        case T_CATALOG_REFERENCE:
+            if (parent == T_SCENARIO_OBJECT && cur_obj >= 0 && cur_obj < cap_objects && objects[cur_obj].catalog.len < 0) {
+                objects[cur_obj].catalog = attr_str("catalogName");
+                objects[cur_obj].entry = attr_str("entryName");
+            }
+            break;
+        case T_VEHICLE:
+        case T_PEDESTRIAN:
+        case T_MISC_OBJECT:
+            if (parent == T_SCENARIO_OBJECT && cur_obj >= 0 && cur_obj < cap_objects) { // inline definition (the last one counts)
+                sgx_object &o = objects[cur_obj];
+                o.inline_tag = slice(text, tag_name, tag_len);
+                o.inline_name = attr_str("name");
+                o.inline_category = attr_str(t == T_VEHICLE ? "vehicleCategory" : t == T_PEDESTRIAN ? "pedestrianCategory" : "miscObjectCategory");
+                o.has_inline_bbox = 0;
+            }
+            break;
+        case T_CENTER:
+        case T_DIMENSIONS:
+            if (parent == T_BOUNDING_BOX && depth >= 3 && S.stack[depth - 3] == T_SCENARIO_OBJECT && cur_obj >= 0 && cur_obj < cap_objects) {
+                sgx_object &o = objects[cur_obj];
+                if (t == T_CENTER) {
+                    const Attr *x = attr("x"), *y = attr("y");
+                    o.bbox[2] = x ? to_double(*x) : std::nan("");
+                    o.bbox[3] = y ? to_double(*y) : std::nan("");
+                    o.has_inline_bbox |= 1;
+                } else {
+                    const Attr *w = attr("width"), *l = attr("length");
+                    o.bbox[0] = w ? to_double(*w) : std::nan("");
+                    o.bbox[1] = l ? to_double(*l) : std::nan("");
+                    o.has_inline_bbox |= 2;
+                }
+            }
+            break;
+        case T_PRIVATE: {
+            const Tag want[] = {T_STORYBOARD, T_INIT, T_ACTIONS};
+            if (S.ends(want)) private_ref = attr_str("entityRef");
+            break;
+        }
+        case T_MANEUVER_GROUP: {
+            const Tag want[] = {T_STORYBOARD, T_STORY, T_ACT};
+            if (S.ends(want)) { group_ref = none; group_first_traj = C.n_trajectories; }
+            break;
+        }
+        case T_ENTITY_REF: {
+            const Tag want[] = {T_MANEUVER_GROUP, T_ACTORS};
+            if (S.ends(want) && group_ref.len < 0) group_ref = attr_str("entityRef");
+            break;
+        }
+        case T_FOLLOW_TRAJECTORY_ACTION: {
+            const Tag want[] = {T_MANEUVER_GROUP, T_MANEUVER, T_EVENT, T_ACTION, T_PRIVATE_ACTION, T_ROUTING_ACTION};
+            if (S.ends(want) && !event_has_fta) {
+                event_has_fta = true;
+                in_first_fta = !self_close;
+                fta_depth = depth;
+                traj_v0 = C.n_vertices;
+            }
+            break;
+        }
+        case T_VERTEX: {
+            const Tag a[] = {T_FOLLOW_TRAJECTORY_ACTION, T_TRAJECTORY, T_SHAPE, T_POLYLINE};
+            const Tag b[] = {T_FOLLOW_TRAJECTORY_ACTION, T_TRAJECTORY_REF, T_TRAJECTORY, T_SHAPE, T_POLYLINE};
+            if (in_first_fta && (S.ends(a) || S.ends(b))) {
+                const Attr *tm = attr("time");
+                vertex_time = tm ? to_double(*tm) : std::nan("");
+            }
+            break;
+        }
+        case T_WORLD_POSITION: {
+            const Attr *x = attr("x"), *y = attr("y"), *z = attr("z"), *h = attr("h"), *pp = attr("p"), *r = attr("r");
+            const Tag vtx[] = {T_POLYLINE, T_VERTEX, T_POSITION};
+            const Tag tele[] = {T_PRIVATE, T_PRIVATE_ACTION, T_TELEPORT_ACTION, T_POSITION};
+            double row[7] = {0.0, x ? to_double(*x) : std::nan(""), y ? to_double(*y) : std::nan(""), z ? to_double(*z) : std::nan(""),
+                             h ? to_double(*h) : std::nan(""), pp ? to_double(*pp) : std::nan(""), r ? to_double(*r) : std::nan("")};
+            if (in_first_fta && S.ends(vtx)) {
+                if (!x || !y) return SGX_ERR_SYNTAX;
+                row[0] = vertex_time;
+                if (C.n_vertices < cap_vertices) memcpy(vertices + C.n_vertices * 7, row, sizeof row);
+                ++C.n_vertices;
+            } else if (private_ref.len >= 0 && S.ends(tele)) {
+                if (!x || !y) return SGX_ERR_SYNTAX;
+                if (C.n_teleports < cap_teleports) {
+                    teleports[C.n_teleports].entity = private_ref;
+                    memcpy(teleports[C.n_teleports].knot, row, sizeof row);
+                }
+                ++C.n_teleports;
+            }
+            break;
+        }
+        default:
+            break;
+        }
+        if (!self_close) S.stack.push_back(t);
+        else if (t == T_FOLLOW_TRAJECTORY_ACTION) in_first_fta = false;
+    }
+    *counts = C;
+    if (C.n_dirs > cap_dirs || C.n_objects > cap_objects || C.n_teleports > cap_teleports || C.n_trajectories > cap_trajectories ||
+        C.n_vertices > cap_vertices)
+        return SGX_ERR_CAPACITY;
+    return SGX_OK;
+}

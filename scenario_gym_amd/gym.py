@@ -106,17 +106,21 @@ class BatchedScenarioGym:
             gym.close()
 
     def load_scenarios(self, paths: Sequence[str], create_agent=_create_agent, relabel: bool = True, workers: int = 8,
-                       max_steps: Optional[int] = None):
-        """ScenarioGym.load_scenario (scenario_gym.py:119-155) for many files: the XML is parsed on `workers`
-        threads (ElementTree releases the GIL while it reads), the batch is packed once."""
-        from concurrent.futures import ThreadPoolExecutor
+                       max_steps: Optional[int] = None, processes: bool = False):
+        """ScenarioGym.load_scenario (scenario_gym.py:119-155) for many files: every file goes through the native scan
+        (libsgym_xosc.so, which runs without the GIL) on `workers` threads -- or, for directories of thousands of files,
+        `workers` processes (`processes=True`: the Python side of the import scales too; tools/ingest_rate.py) -- and the
+        batch is packed once."""
+        from concurrent.futures import ProcessPoolExecutor, ThreadPoolExecutor
+        from functools import partial
 
         from .xosc import import_scenario
 
         paths = list(paths)
         if workers > 1 and len(paths) > 1:
-            with ThreadPoolExecutor(min(workers, len(paths))) as ex:
-                scenarios = list(ex.map(lambda f: import_scenario(f, relabel=relabel), paths))
+            pool = ProcessPoolExecutor if processes else ThreadPoolExecutor
+            with pool(min(workers, len(paths))) as ex:
+                scenarios = list(ex.map(partial(import_scenario, relabel=relabel), paths, **(dict(chunksize=32) if processes else {})))
         else:
             scenarios = [import_scenario(f, relabel=relabel) for f in paths]
         self.set_scenarios(scenarios, create_agent=create_agent, max_steps=max_steps)

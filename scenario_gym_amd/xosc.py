@@ -1,4 +1,5 @@
-"""Minimal OpenSCENARIO ingest for the rollout path (stdlib xml.etree only).
+"""OpenSCENARIO ingest for the rollout path: a native one-pass scan of the file (libsgym_xosc.so, include/sgym_xosc.h)
+for entities, teleports and trajectory vertices; catalogs (a few tiny files, cached) through xml.etree.
 
 Reads what the device engine consumes -- entities, their catalog bounding boxes and their
 trajectories -- from an .xosc file laid out like the reference's inputs:
@@ -72,7 +73,8 @@ def relabel_scenario(scenario: Scenario) -> Scenario:
     return scenario
 
 
-def import_scenario(osc_file: str, relabel: bool = True) -> Scenario:
+def import_scenario_et(osc_file: str, relabel: bool = True) -> Scenario:
+    """The same reader on xml.etree (a DOM per file, one Python object per vertex): the second opinion of the tests."""
     if not os.path.exists(osc_file):
         raise FileNotFoundError(osc_file)
     cwd = os.path.dirname(osc_file)
@@ -133,6 +135,141 @@ def import_scenario(osc_file: str, relabel: bool = True) -> Scenario:
         rn = root.find("RoadNetwork/LogicFile")
     if rn is not None and rn.attrib.get("filepath"):
         path = rn.attrib["filepath"]
+        path = path if os.path.isabs(path) else os.path.join(cwd, path)
+        if os.path.splitext(path)[1] == "":
+            path += ".json"
+        if os.path.exists(path) and path.endswith(".json"):
+            road_network = RoadNetwork.create_from_json(path)
+    scenario = Scenario(list(entities.values()), name=os.path.splitext(os.path.basename(osc_file))[0],
+                        road_network=road_network)
+    return relabel_scenario(scenario) if relabel else scenario
+
+
+# ---------------------------------------------------------------------------------------------- native scan
+import ctypes as _C  # noqa: E402
+from xml.sax.saxutils import unescape as _unescape  # noqa: E402
+
+_XLIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libsgym_xosc.so")
+_xlib = None
+
+
+class _Str(_C.Structure):
+    _fields_ = [("off", _C.c_int32), ("len", _C.c_int32)]
+
+
+class _Object(_C.Structure):
+    _fields_ = [("name", _Str), ("catalog", _Str), ("entry", _Str), ("inline_tag", _Str), ("inline_name", _Str),
+                ("inline_category", _Str), ("bbox", _C.c_double * 4), ("has_inline_bbox", _C.c_int32), ("reserved", _C.c_int32)]
+
+
+class _Teleport(_C.Structure):
+    _fields_ = [("entity", _Str), ("knot", _C.c_double * 7)]
+
+
+class _Trajectory(_C.Structure):
+    _fields_ = [("entity", _Str), ("v0", _C.c_int64), ("v1", _C.c_int64)]
+
+
+class _Counts(_C.Structure):
+    _fields_ = [("road_file", _Str), ("n_dirs", _C.c_int32), ("n_objects", _C.c_int32), ("n_teleports", _C.c_int32),
+                ("n_trajectories", _C.c_int32), ("n_vertices", _C.c_int64)]
+
+
+XOSC_SYMBOLS = ("sgx_version", "sgx_parse")
+
+
+def load_native():
+    """libsgym_xosc.so (no fallback: the ElementTree reader above is for the tests)."""
+    global _xlib
+    if _xlib is None:
+        if not os.path.exists(_XLIB_PATH):
+            raise RuntimeError(f"{_XLIB_PATH} is missing: build it with `make -C scenario_gym_amd/csrc`")
+        lib = _C.CDLL(_XLIB_PATH)
+        lib.sgx_parse.argtypes = [_C.c_char_p, _C.c_int64, _C.POINTER(_Counts), _C.POINTER(_Str), _C.c_int32, _C.POINTER(_Object),
+                                  _C.c_int32, _C.POINTER(_Teleport), _C.c_int32, _C.POINTER(_Trajectory), _C.c_int32, _C.c_void_p,
+                                  _C.c_int64]
+        lib.sgx_parse.restype = _C.c_int
+        _xlib = lib
+    return _xlib
+
+
+def scan_xosc(text: bytes):
+    """sgx_parse on the bytes of one file: dict(dirs, road_file, objects, teleports, trajectories) with decoded strings and
+    the trajectory vertices as [n, 7] arrays."""
+    lib = load_native()
+    caps = [8, max(16, text.count(b"<ScenarioObject")), max(16, text.count(b"<Private ")), max(16, text.count(b"<Event")),
+            max(64, text.count(b"<Vertex"))]
+    for _ in range(2):
+        dirs, objs = (_Str * caps[0])(), (_Object * caps[1])()
+        tele, traj = (_Teleport * caps[2])(), (_Trajectory * caps[3])()
+        verts = np.empty((caps[4], 7))
+        cnt = _Counts()
+        rc = lib.sgx_parse(text, len(text), _C.byref(cnt), dirs, caps[0], objs, caps[1], tele, caps[2], traj, caps[3],
+                           verts.ctypes.data, caps[4])
+        if rc == 0:
+            break
+        if rc != -1:
+            raise ValueError("not a well-formed OpenSCENARIO file")
+        caps = [cnt.n_dirs, cnt.n_objects, cnt.n_teleports, cnt.n_trajectories, cnt.n_vertices]
+    else:
+        raise ValueError("sgx_parse: capacity")
+
+    def st(x):
+        if x.len < 0:
+            return None
+        v = text[x.off:x.off + x.len].decode("utf-8")
+        return _unescape(v, {"&quot;": '"', "&apos;": "'"}) if "&" in v else v
+
+    return dict(
+        dirs=[st(dirs[i]) for i in range(cnt.n_dirs)], road_file=st(cnt.road_file),
+        objects=[dict(name=st(o.name), catalog=st(o.catalog), entry=st(o.entry), inline_tag=st(o.inline_tag),
+                      inline_name=st(o.inline_name), inline_category=st(o.inline_category), bbox=tuple(o.bbox),
+                      has_bbox=o.has_inline_bbox == 3) for o in (objs[i] for i in range(cnt.n_objects))],
+        teleports=[(st(t.entity), np.array(t.knot)) for t in (tele[i] for i in range(cnt.n_teleports))],
+        trajectories=[(st(t.entity), verts[t.v0:t.v1].copy()) for t in (traj[i] for i in range(cnt.n_trajectories))],
+    )
+
+
+def import_scenario(osc_file: str, relabel: bool = True) -> Scenario:
+    """xosc_interface/read.py:20-217 through the native scan: entities with their catalog boxes, Init teleports, the
+    vertices of the FollowTrajectoryActions, the road network file."""
+    if not os.path.exists(osc_file):
+        raise FileNotFoundError(osc_file)
+    cwd = os.path.dirname(osc_file)
+    with open(osc_file, "rb") as f:
+        scan = scan_xosc(f.read())
+    catalogs: Dict[str, Dict[str, Entity]] = {}
+    for path in scan["dirs"]:
+        path = path if os.path.isabs(path) else os.path.join(cwd, path)
+        for f in sorted(os.listdir(path)):
+            if f.endswith(".xosc"):
+                name, entries = read_catalog(os.path.join(path, f))
+                catalogs[name] = entries
+    entities: Dict[str, Entity] = {}
+    for o in scan["objects"]:
+        ent = None
+        if o["catalog"] is None:
+            if o["has_bbox"]:  # inline Vehicle / Pedestrian / MiscObject definition
+                w, l, cx, cy = o["bbox"]
+                ce = CatalogEntry(None, o["inline_name"], o["inline_category"], o["inline_tag"], BoundingBox(w, l, cx, cy), {}, [])
+                ent = _ENTITY_CLASSES.get(o["inline_tag"], Entity)(ce)
+        else:
+            try:
+                ent = catalogs[o["catalog"]][o["entry"]].copy()
+            except KeyError:
+                warnings.warn(f"Could not find {o['entry']} in catalog {o['catalog']}")
+        if ent is not None:
+            ent.ref = o["name"]
+            entities[o["name"]] = ent
+    for ref, knot in scan["teleports"]:
+        if ref in entities:
+            entities[ref].trajectory = Trajectory(knot[None, :])
+    for ref, verts in scan["trajectories"]:
+        if ref in entities and len(verts):
+            entities[ref].trajectory = Trajectory(verts)
+    road_network = None
+    if scan["road_file"]:
+        path = scan["road_file"]
         path = path if os.path.isabs(path) else os.path.join(cwd, path)
         if os.path.splitext(path)[1] == "":
             path += ".json"

@@ -448,3 +448,82 @@ def test_walk_graph_bfs_equals_list_of_paths_search():
     assert r is not None and np.allclose(r[0], [1, -1]) and np.allclose(r[-1], [29, 13]) and len(r) > 20
     empty = WalkGraph(SimpleNamespace(pavements=[], crossings=[]))
     assert np.array_equal(find_route(empty, np.zeros(2), np.ones(2)), np.array([[0.0, 0.0], [1.0, 1.0]]))
+
+
+def test_native_xosc_scan_equals_the_elementtree_reader(tmp_path):
+    """libsgym_xosc.so (include/sgym_xosc.h): exports what the header declares, and import_scenario through it returns what
+    the ElementTree reader returns -- on generated directories (tools/ingest_rate.py layout) and on a hand-written file with
+    the corners of the format: comments, an XML entity in a name, an inline entity definition, a TrajectoryRef, an Event
+    without vertices, a second Event that replaces the first trajectory, a teleport only, attributes in single quotes."""
+    import ctypes
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from ingest_rate import make_directory
+    from scenario_gym_amd import xosc
+
+    lib = ctypes.CDLL(os.path.join(ROOT, "scenario_gym_amd", "lib", "libsgym_xosc.so"))
+    header = open(os.path.join(ROOT, "include", "sgym_xosc.h")).read()
+    for sym in xosc.XOSC_SYMBOLS:
+        assert hasattr(lib, sym) and f"int {sym}(" in header
+    assert lib.sgx_version() == 1
+
+    def same(a, b):
+        assert a.name == b.name and [e.ref for e in a.entities] == [e.ref for e in b.entities]
+        for x, y in zip(a.entities, b.entities):
+            assert type(x) is type(y) and bits_equal(x.trajectory.data, y.trajectory.data)
+            bx, by = x.catalog_entry.bounding_box, y.catalog_entry.bounding_box
+            assert (bx.width, bx.length, bx.center_x, bx.center_y) == (by.width, by.length, by.center_x, by.center_y)
+            assert (x.catalog_entry.catalog_type, x.catalog_entry.catalog_entry) == (y.catalog_entry.catalog_type, y.catalog_entry.catalog_entry)
+
+    paths = make_directory(str(tmp_path / "gen"), 12, 5, 40)
+    for p in paths:
+        same(xosc.import_scenario(p), xosc.import_scenario_et(p))
+    # the corners
+    wp = lambda x, y, extra="": f'<Position><WorldPosition x="{x}" y="{y}"{extra}/></Position>'
+    H = ' h="0.25"'
+    vtx = lambda t, x, y: f"<Vertex time='{t}'>{wp(x, y, H)}</Vertex>"
+    fta = lambda body: ("<Action name='a'><PrivateAction><RoutingAction><FollowTrajectoryAction>" + body +
+                        "</FollowTrajectoryAction></RoutingAction></PrivateAction></Action>")
+    traj = lambda vs: "<Trajectory name='t' closed='false'><Shape><Polyline>" + "".join(vs) + "</Polyline></Shape></Trajectory>"
+    tele_a, tele_b = wp(3.5, -2.25, ' z="0" h="1.5" p="0" r="0"'), wp(0, 0)
+    ev0 = fta(traj([vtx(0.0, 1.0, 2.0), vtx(1.5, 4.0, 2.5)]))
+    ev2 = fta("<TrajectoryRef>" + traj([vtx(0.5, -1.0, 0.0), vtx(2.5, -3.0, 1e1), vtx(4.0, -6.5, 2.0e1)]) + "</TrajectoryRef>")
+    ev3 = fta(traj([vtx(0.0, 10.0, 10.0), vtx(3.0, 11.0, 12.0)]))
+    text = f"""<?xml version="1.0"?>
+<!-- a comment with <Vertex time="9"> inside -->
+<OpenSCENARIO><FileHeader description="x &lt; y"/>
+<CatalogLocations><VehicleCatalog><Directory path="../Catalogs"/></VehicleCatalog></CatalogLocations>
+<Entities>
+ <ScenarioObject name="A &amp; B"><CatalogReference catalogName="SyntheticVehicleCatalog" entryName="van"/></ScenarioObject>
+ <ScenarioObject name="walker"><Pedestrian name="p1" pedestrianCategory="pedestrian" mass="70" model="m">
+   <BoundingBox><Center x="0.1" y="0.0" z="0.9"/><Dimensions width="0.69" length="0.7" height="1.8"/></BoundingBox></Pedestrian></ScenarioObject>
+ <ScenarioObject name="parked"><CatalogReference catalogName="SyntheticVehicleCatalog" entryName="car1"/></ScenarioObject>
+ <ScenarioObject name="ghost"><CatalogReference catalogName="SyntheticVehicleCatalog" entryName="no_such_entry"/></ScenarioObject>
+</Entities>
+<Storyboard><Init><Actions>
+ <Private entityRef="parked"><PrivateAction><TeleportAction>{tele_a}</TeleportAction></PrivateAction></Private>
+ <Private entityRef="A &amp; B"><PrivateAction><TeleportAction>{tele_b}</TeleportAction></PrivateAction></Private>
+</Actions></Init>
+<Story name="s"><Act name="a">
+ <ManeuverGroup name="g0"><Actors><EntityRef entityRef="A &amp; B"/></Actors><Maneuver name="m">
+  <Event name="e0">{ev0}</Event>
+  <Event name="e1"><Action name="other"><UserDefinedAction/></Action></Event>
+  <Event name="e2">{ev2}</Event>
+ </Maneuver></ManeuverGroup>
+ <ManeuverGroup name="g1"><Actors><EntityRef entityRef="walker"/></Actors><Maneuver name="m">
+  <Event name="e">{ev3}</Event></Maneuver></ManeuverGroup>
+</Act></Story></Storyboard></OpenSCENARIO>
+"""
+    p = tmp_path / "gen" / "Scenarios" / "corners.xosc"
+    p.write_text(text)
+    with pytest.warns(UserWarning, match="no_such_entry"):
+        a = xosc.import_scenario(str(p), relabel=False)
+    with pytest.warns(UserWarning):
+        b = xosc.import_scenario_et(str(p), relabel=False)
+    same(a, b)
+    assert [e.ref for e in a.entities] == ["A & B", "walker", "parked"]
+    assert a.entities[0].trajectory.data.shape == (3, 7) and a.entities[0].trajectory.data[1, 2] == 10.0   # the later Event wins
+    assert type(a.entities[1]).__name__ == "Pedestrian" and a.entities[2].trajectory.data.shape == (1, 7)
+    with pytest.raises(ValueError):
+        xosc.scan_xosc(b"<OpenSCENARIO><Entities><ScenarioObject name=oops></Entities>")
