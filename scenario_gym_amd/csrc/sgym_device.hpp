@@ -93,6 +93,8 @@ struct Params {
     sg_scenario_state *sdyn; // [R]
     sg_event *events;        // [R][ev_cap]
     double *ev_pose;         // [R][ev_cap][3] ego x, y, heading at the event (input of classify_events_kernel)
+    double *ev_hpose;        // [R][ev_cap][3] the hazard's x, y, heading at the event when it is a controlled agent (its pose
+                             // cannot be re-derived from a trajectory); NaN: not saved
     double *rec_t, *rec_pose;
     const double *routes;    // [rows][2] pedestrian route waypoints
     const double *gon;       // [64][2] cos, sin of 2*pi*i/64 (host libm): Point.buffer(r) vertices
@@ -3020,11 +3022,15 @@ __device__ __forceinline__ void rollout_body(
             sa.first_done[(size_t)r * sa.n_slices + slice_s] = steps; // (once: the scenario does not run after this)
 
         // ---- CollisionMetric._step, metrics/collision.py:70-75 (ego lane only) ----
+        uint64_t ev_fresh0 = 0;   // (ego lane) the hazards of this step's new events, first row word
+        int ev_base = -1;         // (ego lane) index of the first of them in the event list; -1: none / not representable
         if (run && is_ego && present) {
+            if (!TAB) ev_base = n_ev;
 #pragma unroll
             for (int w = 0; w < WV; ++w) {
                 uint64_t fresh = row[w] & ~last_row[w];
                 if (SLICE && (warm || sa.mode == 1)) fresh = 0; // the events of these steps belong to other launches
+                if (!TAB && w == 0) ev_fresh0 = fresh;
                 while (fresh) {
                     int j = w * 64 + __builtin_ctzll(fresh);
                     fresh &= fresh - 1;
@@ -3033,6 +3039,7 @@ __device__ __forceinline__ void rollout_body(
 #pragma unroll
                     for (int v = 0; v < WV; ++v) aliased = aliased || mult_rows[v] != row[v];
                     if (aliased) { // aliased geometries are listed once per owner
+                        if (!TAB) ev_base = -1;
                         mult = 0;
 #pragma unroll
                         for (int v = 0; v < WV; ++v) {
@@ -3056,6 +3063,10 @@ __device__ __forceinline__ void rollout_body(
                             head.type = (((ometa >> 8) & 0xff) == 0 ? (TAB ? 15 : -1) : 5) | (TAB ? (k + 1) << 4 : 0);
                             head.reserved = 0;
                             *reinterpret_cast<decltype(head) *>(dst) = head;
+                            if (!TAB) { // (overwritten below when the hazard is a controlled agent; table launches: event_ego_pose_kernel)
+                                double *hp = p.ev_hpose + ((size_t)r * p.ev_cap + n_ev) * 3;
+                                hp[0] = hp[1] = hp[2] = __builtin_nan("");
+                            }
                             if (!TAB) { // in-kernel controllers: the ego pose of the event goes along.  (Not in the table
                                         // variant, which sits 1 VGPR under its 192 budget: its events are classified right
                                         // after the launch, with the ego pose taken from the table row `reserved`.)
@@ -3067,6 +3078,23 @@ __device__ __forceinline__ void rollout_body(
                     }
                 }
                 last_row[w] = row[w];
+            }
+        }
+        if (!TAB && WV == 1 && p.ev_cap > 0) {
+            // A hazard that is itself a controlled agent (PID / vehicle controller) has no trajectory its pose at the event
+            // could be re-derived from: it leaves the pose it has right now beside the event (classify_events_kernel).  The
+            // ego lane's new-event mask and list position go to the lanes of its tile; rare, one ballot per step otherwise.
+            if (__any(ev_base >= 0 && ev_fresh0 != 0)) {
+                const int ego_lane = tile0 + ss.ego;
+                const uint64_t fr = __shfl(ev_fresh0, ego_lane, 64);
+                const int base = __shfl(ev_base, ego_lane, 64);
+                if (in_range && base >= 0 && ((fr >> slot) & 1) && (kind == SG_KIND_AGENT_PID || kind == SG_KIND_AGENT_VEHICLE)) {
+                    const int at = base + __builtin_popcountll(fr & ((1ull << slot) - 1));
+                    if (at < p.ev_cap) {
+                        double *hp = p.ev_hpose + ((size_t)r * p.ev_cap + at) * 3;
+                        hp[0] = pose[0]; hp[1] = pose[1]; hp[2] = pose[3];
+                    }
+                }
             }
         }
         if (RSSV) rss_call(run, t, vel[0], vel[1]); // State.step ends with update_callbacks(), state.py:165-171
@@ -3820,6 +3848,19 @@ __global__ __launch_bounds__(64) void event_ego_pose_kernel(Params p, const doub
             double *ep = p.ev_pose + ((size_t)r * p.ev_cap + i) * 3;
             ep[0] = row[CT_X]; ep[1] = row[CT_Y]; ep[2] = row[CT_H];
         }
+        {   // a hazard that is a controlled agent: its pose at that step is a row of the table as well
+            const uint32_t hidx = (uint32_t)r * p.EP + ev.other;
+            const LanePtr hst(p.stat + (size_t)(hidx >> 6) * (ST_COUNT * 64), (hidx & 63) * 8u);
+            const int64_t hctl = fld<int64_t>(hst, ST_CTL);
+            const int hkind = (int)(fld<int64_t>(hst, ST_META) & 0xff);
+            double *hp = p.ev_hpose + ((size_t)r * p.ev_cap + i) * 3;
+            if (hctl >= 0 && (hkind == SG_KIND_AGENT_PID || hkind == SG_KIND_AGENT_VEHICLE)) {
+                const double *row = tab + ((size_t)hctl * (size_t)(p.tab_steps + 1) + (size_t)k_launch) * CT_W;
+                hp[0] = row[CT_X]; hp[1] = row[CT_Y]; hp[2] = row[CT_H];
+            } else {
+                hp[0] = hp[1] = hp[2] = __builtin_nan("");
+            }
+        }
         ev.type = base == 15 ? -1 : base;
     }
 }
@@ -3853,10 +3894,15 @@ __global__ __launch_bounds__(64) void classify_events_kernel(Params p, double c_
             for (int c = 0; c < 6; ++c) hp[c] = S.sl[c] * dq + S.ylo[c];
         } else if (kind == SG_KIND_AGENT_REPLAY) {
             own_position_clamped(p.knots + fld<int64_t>(hst, ST_KNOT_OFF) * 7, (int)(meta >> 32), ev.t, hp);
-        } else { // a controlled hazard: its pose at the event is not recoverable from a trajectory
-            if (vehicle) ev.type = -2;
-            pt[0] = pt[1] = pt[2] = __builtin_nan("");
-            continue;
+        } else { // a controlled hazard: the pose it left beside the event (rollout kernel / event_ego_pose_kernel)
+            const double *hq = p.ev_hpose + ((size_t)r * p.ev_cap + i) * 3;
+            if (!(hq[0] == hq[0])) { // not saved (wide tiles with in-kernel controllers, aliased geometries)
+                if (vehicle) ev.type = -2;
+                pt[0] = pt[1] = pt[2] = __builtin_nan("");
+                continue;
+            }
+            hp[0] = hq[0]; hp[1] = hq[1]; hp[3] = hq[2];
+            hp[2] = hp[4] = hp[5] = 0.0;
         }
         const int64_t emeta = fld<int64_t>(est, ST_META);
         double ex = pt[0], ey = pt[1], eh = pt[2];

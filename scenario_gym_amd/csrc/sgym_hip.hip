@@ -895,6 +895,8 @@ extern "C" int sg_upload(sg_handle *h, const sg_scenarios *sc)
     if ((rc = dev_alloc(h, M, &p.sdyn, (size_t)R))) return rc;
     if ((rc = dev_alloc(h, M, &p.events, (size_t)R * std::max(p.ev_cap, 1)))) return rc;
     if ((rc = dev_alloc(h, M, &p.ev_pose, (size_t)R * std::max(p.ev_cap, 1) * 3))) return rc;
+    if ((rc = dev_alloc(h, M, &p.ev_hpose, (size_t)R * std::max(p.ev_cap, 1) * 3, false))) return rc;
+    HIP_TRY(h, hipMemsetAsync(p.ev_hpose, 0xFF, (size_t)R * std::max(p.ev_cap, 1) * 3 * sizeof(double), h->stream));
     if ((rc = dev_alloc(h, M, &p.rec_t, (size_t)std::max(p.rec_cap, 1) * R))) return rc;
     if ((rc = dev_alloc(h, M, &p.rec_pose, (size_t)std::max(p.rec_cap, 0) * 6 * R * EP + 1))) return rc;
 

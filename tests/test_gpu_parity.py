@@ -1437,6 +1437,53 @@ def test_collision_types_match_reference_code_and_oracle(sga, oracle):
         assert n_ev > 40
 
 
+@pytest.mark.parametrize("path", ["table", "inline", "per_tick"])
+def test_collisions_with_controlled_hazards_are_classified(sga, oracle, path):
+    """CollisionMetric.record_collision (metrics/collision.py:81-203) when the hazard is itself a controlled agent (a second
+    and a third PIDAgent per scenario, beside the PID ego): its pose at the event cannot be re-derived from a trajectory, it
+    is saved beside the event -- from the controller table (two-kernel path), by the hazard's own lane (controllers in the
+    rollout kernel), also when the rollout is driven tick by tick.  Types and collision points equal the oracle's."""
+    import scenario_gym_amd._lib as L
+    from scenario_gym_amd import synthetic
+    from scenario_gym_amd.packing import unpack_scenario
+
+    R, E, steps = 64, 24, 260
+    packed = synthetic.make_batch(R, E, n_steps=steps, ego_kind=L.KIND_AGENT_PID, extent=13.0, static_frac=0.05, vanish_frac=0.1)
+    kind = packed.kind.reshape(R, E)
+    if path == "table":
+        # the two-kernel path serves two controlled lanes per wavefront of two 24-entity scenarios: every other scenario has
+        # a PID ego and a PID hazard, the ones between them replay
+        kind[0::2, 1] = L.KIND_AGENT_PID
+        kind[1::2, 0] = L.KIND_AGENT_REPLAY
+    else:
+        kind[:, 1] = L.KIND_AGENT_PID      # entities 1 and 2 drive under their own PID controllers
+        kind[:, 2] = L.KIND_AGENT_PID
+    eng = sga.RolloutEngine(R, E, event_capacity=128)
+    eng.upload(packed)
+    if path == "per_tick":
+        eng.reset()
+        for _ in range(steps):
+            eng.step(1)
+    else:
+        eng.rollout(steps)
+        assert (eng.last_launch_stats()[0] > 1) == (path == "table")   # chunks of the controller table, or one launch
+    rows, events = eng.metrics()
+    points = eng.collision_points()
+    eng.close()
+    n_ctl_events = 0
+    for r in range(R):
+        s = unpack_scenario(packed, r)
+        o = oracle.rollout(s["knot_off"], s["knots"], s["bbox"], s["etype"], s["kind"], s["ego"], s["t0"], s["length"], 1 / 30,
+                           ctrl=s["ctrl"], max_steps=steps, record=False, event_cap=128, force_steps=path == "per_tick")
+        sel = events["scenario"] == r
+        ev = events[sel]
+        assert np.array_equal(ev["t"], o["ev_t"]) and np.array_equal(ev["other"], o["ev_other"]), r
+        assert np.array_equal(ev["type"], o["ev_type"]), (r, ev["type"], o["ev_type"])
+        assert bits_equal(points[sel], o["ev_point"]), r
+        n_ctl_events += int(np.isin(ev["other"], (1, 2)).sum())
+    assert n_ctl_events > 10 and (events["type"] >= 1).all()
+
+
 def test_device_group_equals_single_handle(sga, oracle):
     """sg_group_*: the batch cut into contiguous shards over several handles (here all on GPU 0, incl. uneven shards and a
     pedestrian-free ragged batch with PID egos): rollout + metrics + events equal the single-handle run row for row."""
