@@ -1026,6 +1026,18 @@ def test_randomized_configurations_match_oracle(sga, oracle, cfg):
         # collision classes: controlled egos take their event pose from the controller table (two-kernel path) or from the
         # rollout kernel (short chunks run the controllers in-kernel)
         assert np.array_equal(ev["type"][:m], o["ev_type"][:m]), (r, ev["type"][:m], o["ev_type"][:m])
+    if cfg["ego"] == "replay" and E <= 64:  # the same batch through the time-sliced path: the same final results
+        eng = sga.RolloutEngine(R, E, timestep=dt, persist=cfg["persist"], terminal_conditions=cfg["terminal"], event_capacity=256)
+        eng.set_slicing("always")
+        eng.upload(packed)
+        eng.rollout(steps)
+        st2 = eng.state()
+        rows2, events2 = eng.metrics()
+        eng.close()
+        for k in ("poses", "vels", "dists", "t", "prev_t"):
+            assert bits_equal(st[k], st2[k]), k
+        assert np.array_equal(st["coll"], st2["coll"]) and np.array_equal(st["present"], st2["present"])
+        assert np.array_equal(rows, rows2) and np.array_equal(events, events2)
 
 
 @pytest.mark.parametrize("E,side", [(12, 8.0), (40, 12.0), (150, 22.0)])
@@ -1679,22 +1691,39 @@ def _random_crowds(n, seed=77):
         E = int([20, 64, 100, 256, 40, 130][k % 6])
         out.append(dict(E=E, R=int(rng.integers(2, 7 if E <= 64 else 4)), steps=int(rng.integers(30, 90)),
                         side=float(rng.choice([6.0, 12.0, 25.0])), roads=bool(rng.integers(0, 2)), seed=int(rng.integers(1, 1 << 30)),
-                        dt=float(rng.choice([1 / 30, 0.1]))))
+                        dt=float(rng.choice([1 / 30, 0.1])), noise=str(rng.choice(["off", "off", "device", "stream"])),
+                        radii=bool(rng.integers(0, 2)), late=bool(rng.integers(0, 3) == 0)))
     return out
 
 
 @pytest.mark.parametrize("cfg", _random_crowds(int(os.environ.get("SG_FUZZ_CROWDS", "8")), int(os.environ.get("SG_FUZZ_SEED", "77"))),
-                         ids=lambda c: f"E{c['E']}-s{c['side']:.0f}-{'roads' if c['roads'] else 'free'}")
+                         ids=lambda c: f"E{c['E']}-s{c['side']:.0f}-{'roads' if c['roads'] else 'free'}-{c['noise']}")
 def test_randomized_crowds_match_oracle(sga, oracle, cfg):
     """Random social-force crowds (tile widths up to four wavefronts, sparse to packed), half of them on a road network with
     random convex buildings and pavements among the pedestrians: poses of every step, forces, collision rows and events
-    bit-identical to the oracle (balanced pair loop, boundary terms, density-adaptive broad phase)."""
+    bit-identical to the oracle (crowd kernel and the general pedestrian variant, balanced pair loops, boundary terms,
+    density-adaptive broad phase); a quarter each with the counter-based noise generator and with a stream of variates,
+    half with per-pedestrian sensor radii, a third with pedestrians that join the scene late (the spawn rule)."""
+    import scenario_gym_amd._lib as L
     from scenario_gym_amd import synthetic
     from scenario_gym_amd.packing import unpack_scenario
 
     rng = np.random.default_rng(cfg["seed"])
     R, E, steps, dt = cfg["R"], cfg["E"], cfg["steps"], cfg["dt"]
     packed = synthetic.make_crowd(R, E, n_steps=steps, timestep=dt, side=cfg["side"], seed=cfg["seed"] % 1000)
+    if cfg["radii"]:
+        packed.ctrl[:, L.C_PED_RADIUS] = rng.uniform(0.8, 3.5, R * E)
+    if cfg["late"]:  # every fifth pedestrian's trajectory starts later: it is not in the scene at the reset and spawns
+        kn = packed.knots.reshape(R * E, 2, 7)
+        kn[::5, 0, 0] = rng.uniform(0.2, 1.0, len(kn[::5])) * steps * dt * 0.5
+    noise_kw, noise_o = {}, [None] * R
+    if cfg["noise"] == "device":
+        noise_kw = dict(std_lon=0.1, std_lat=0.05, noise="device", noise_seed=cfg["seed"])
+        noise_o = [dict(mode="device", std_lon=0.1, std_lat=0.05, seed=cfg["seed"], scenario_index=r) for r in range(R)]
+    elif cfg["noise"] == "stream":
+        normals = np.random.RandomState(cfg["seed"] % (1 << 31)).standard_normal((R, 2 * E * (steps + 1)))
+        noise_kw = dict(std_lon=0.05, std_lat=0.1, noise="stream", normals=normals)
+        noise_o = [dict(mode="stream", std_lon=0.05, std_lat=0.1, normals=normals[r]) for r in range(R)]
     nets, net_of = [], np.full(R, -1, np.int32)
     if cfg["roads"]:
         for n in range(2):
@@ -1709,7 +1738,7 @@ def test_randomized_crowds_match_oracle(sga, oracle, cfg):
             nets.append(dict(ring_off=np.arange(len(rings) + 1), vert_off=np.concatenate([[0], np.cumsum([len(r) for r in rings])]),
                              verts=np.concatenate(rings), layers=np.array(layers)))
         net_of = rng.integers(-1, 2, R).astype(np.int32)
-    eng = sga.RolloutEngine(R, E, timestep=dt, record_capacity=steps + 1, event_capacity=512)
+    eng = sga.RolloutEngine(R, E, timestep=dt, record_capacity=steps + 1, event_capacity=512, social_force=noise_kw or None)
     eng.upload(packed)
     if nets:
         eng.set_road_networks(nets, net_of)
@@ -1722,7 +1751,8 @@ def test_randomized_crowds_match_oracle(sga, oracle, cfg):
         s = unpack_scenario(packed, r)
         road = nets[net_of[r]] if (nets and net_of[r] >= 0) else None
         o = oracle.rollout(s["knot_off"], s["knots"], s["bbox"], s["etype"], s["kind"], s["ego"], s["t0"], s["length"], dt,
-                           ctrl=s["ctrl"], route_off=s["route_off"], routes=s["routes"], max_steps=steps, event_cap=512, road=road)
+                           ctrl=s["ctrl"], route_off=s["route_off"], routes=s["routes"], max_steps=steps, event_cap=512, road=road,
+                           noise=noise_o[r])
         n = o["n_steps"]
         assert rows["n_steps"][r] == n, r
         assert bits_equal(poses[: n + 1, r], o["poses"]), (r, "poses")
