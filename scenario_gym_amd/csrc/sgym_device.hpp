@@ -2136,9 +2136,15 @@ __device__ inline bool rss_seg_quad(const double *Q, double ax, double ay, doubl
 // RSSDistances for ONE entity against the ego (both present, t != 0): safe distances, the record appended to the entity's
 // history, the updated (found | last << 8) state.  Shared by rss_kernel (one update per call) and the rollout variant that
 // runs the callback after every step itself.
+// DEFER (the rollout variant): the line tests are not run here.  cd = RSS_CD_ISECT: the entity entered the buffer, the
+// caller picks unsafe_lateral / unsafe_longitudinal from the history (`last`, else `ab`); otherwise `need` has bit L set for
+// every line L whose bounding box meets the entity's (0: cd = 0 is final) and Q is the entity's box in the ego frame.
+constexpr int RSS_CD_ISECT = -3;
+template <bool DEFER = false>
 __device__ inline void rss_entity(double ex, double ey, double ego_heading, double ego_vx, double ego_vy, double ego_w, double ego_l,
                                   double hx, double hy, double hh, double hvx, double hvy, double bw, double bl, double bcx,
-                                  double bcy, int32_t &state, int &cd, double &s_lat, double &s_long)
+                                  double bcy, int32_t &state, int &cd, double &s_lat, double &s_long, int *need = nullptr,
+                                  double *Qd = nullptr, bool *ab = nullptr)
 {
         const double RESPONSE_TIME = 0.6, MIN_LONG_ACCEL = 1.2 * 9.81, MAX_LONG_ACCEL = 1.2 * 9.81, MIN_SAFE_CLEARANCE = 0.1;
         double es, ec, ei0, ei1;
@@ -2206,6 +2212,35 @@ __device__ inline void rss_entity(double ex, double ey, double ego_heading, doub
         const int found = state & 0xff, last = (state >> 8) & 0xff;
         if (found) {
             cd = 6;
+        } else if (DEFER) {
+            const double B[8] = {s_lat, s_long, -s_lat, s_long, -s_lat, -s_long, s_lat, -s_long};
+            const double qx0 = __builtin_fmin(__builtin_fmin(Q[0], Q[2]), __builtin_fmin(Q[4], Q[6]));
+            const double qx1 = __builtin_fmax(__builtin_fmax(Q[0], Q[2]), __builtin_fmax(Q[4], Q[6]));
+            const double qy0 = __builtin_fmin(__builtin_fmin(Q[1], Q[3]), __builtin_fmin(Q[5], Q[7]));
+            const double qy1 = __builtin_fmax(__builtin_fmax(Q[1], Q[3]), __builtin_fmax(Q[5], Q[7]));
+            // A box strictly beside / above / below the (axis-parallel) buffer is separated by that edge of the buffer in
+            // sg_sat_pass(B, Q) too: with finite coordinates the cross products there are +-2 s * (q - +-s), signs exact.
+            const double INF = __builtin_inf();
+            const bool apart = (qx1 < -s_lat || qx0 > s_lat || qy1 < -s_long || qy0 > s_long) && qx0 > -INF && qx1 < INF &&
+                               qy0 > -INF && qy1 < INF && s_lat < INF && s_long < INF;
+            if (!apart && sg_quads_intersect(Q, B)) {
+                double j0, j1;
+                rss_inv_dir(ego_w, ego_l, j0, j1);
+                const double A = __builtin_fabs(__builtin_fabs(pos0) - __builtin_fabs(rss_dot2(pos0, pos1, ego_w, ego_l))) / s_lat;
+                const double Bv = __builtin_fabs(__builtin_fabs(pos1 - rss_dot2(pos0, pos1, j0, j1)) / s_long);
+                *ab = A > Bv;
+                cd = RSS_CD_ISECT;
+            } else { // the bounding-box test rss_seg_quad starts with, for the two "width" lines (0, 1) and the two "length" lines
+                const double lx = 100 * s_lat, ly = 100 * s_long;
+                const bool lat_far = qx1 < __builtin_fmin(s_lat, -s_lat) || qx0 > __builtin_fmax(s_lat, -s_lat) ||
+                                     qy1 < __builtin_fmin(ly, -ly) || qy0 > __builtin_fmax(ly, -ly);
+                const bool long_far = qx1 < __builtin_fmin(lx, -lx) || qx0 > __builtin_fmax(lx, -lx) ||
+                                      qy1 < __builtin_fmin(s_long, -s_long) || qy0 > __builtin_fmax(s_long, -s_long);
+                *need = (lat_far ? 0 : 3) | (long_far ? 0 : 12);
+                cd = 0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) Qd[k] = Q[k];
+            }
         } else {
             const double B[8] = {s_lat, s_long, -s_lat, s_long, -s_lat, -s_long, s_lat, -s_long};
             if (sg_quads_intersect(Q, B)) {
@@ -2226,6 +2261,80 @@ __device__ inline void rss_entity(double ex, double ey, double ego_heading, doub
                 if (cd == 1 || cd == 2) state = (state & 0xff) | (cd << 8);
             }
         }
+}
+
+// ---- the line tests of the callback inside the rollout kernel, deferred ----
+// write_intersections (callback.py:307-340) asks, for an entity outside the buffer, whether its box meets the buffer's two
+// "width" and two "length" lines: exact predicates, ~600 instructions per line, needed by a handful of the 64 lanes of a
+// wavefront at a step -- and their only effects are the record of THAT step (read back for the latest update only) and the
+// `last` entry of the history, which is looked at when the entity enters the buffer, once.  So a lane whose box meets a
+// line's bounding box queues a GROUP (its box, the safe distances, the lines wanted, the ordinal of the update) in its
+// wavefront's slice of LDS and goes on; rss_flush turns the queued groups into (group, line) items, one per lane, runs the
+// test once over full wavefronts and folds the results back per owner lane as max(ordinal << 3 | code) and
+// max(ordinal << 2 | code in {lateral, longitudinal}).  It runs when the queue passes RSSQ_FLUSH groups, when some lane
+// enters the buffer (its `last` must be current) and at the end of the launch.  Same predicates on the same operands as
+// the per-tick kernel: the results are the same bits.
+constexpr int RSSQ_CAP = 96, RSSQ_FLUSH = 32;
+struct RssQueue {
+    double q[10][RSSQ_CAP];           // Q[8], s_lat, s_long
+    int meta[RSSQ_CAP];               // owner lane | need << 8
+    unsigned key[RSSQ_CAP];           // ordinal of the update within the launch
+    int hits[RSSQ_CAP];               // bit L: line L meets the box (zero between flushes)
+    unsigned short item[4 * RSSQ_CAP];
+    unsigned lastword[64], stepcd[64];
+};
+typedef __attribute__((address_space(3))) RssQueue *RssQueueLds;
+
+__device__ __attribute__((noinline)) void rss_flush(RssQueueLds q, int n)
+{
+    const int lane = threadIdx.x & 63;
+    int n_items = 0;
+    for (int g0 = 0; g0 < n; g0 += 64) {
+        const int g = g0 + lane;
+        const int need = g < n ? (q->meta[g] >> 8) & 15 : 0;
+#pragma unroll
+        for (int L = 0; L < 4; ++L) {
+            const bool w = (need >> L) & 1;
+            const uint64_t b = __ballot(w);
+            if (w) q->item[n_items + __builtin_popcountll(b & ((1ull << lane) - 1))] = (unsigned short)(g | L << 8);
+            n_items += __builtin_popcountll(b);
+        }
+    }
+    tile_sync<1>();
+    for (int i0 = 0; i0 < n_items; i0 += 64) {
+        const int i = i0 + lane;
+        if (i < n_items) {
+            const int it = q->item[i], g = it & 255, L = it >> 8;
+            double Q[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) Q[k] = q->q[k][g];
+            const double sl = q->q[8][g], sg = q->q[9][g];
+            // B = {sl, sg, -sl, sg, -sl, -sg, sl, -sg}; line 0: (B0, 100 B1)-(B4, 100 B5), 1: (B2, 100 B3)-(B6, 100 B7),
+            // 2: (100 B0, B1)-(100 B2, B3), 3: (100 B4, B5)-(100 B6, B7)
+            const double lx = 100 * sl, ly = 100 * sg;
+            double ax, ay, bx, by;
+            if (L == 0) { ax = sl; ay = ly; bx = -sl; by = -ly; }
+            else if (L == 1) { ax = -sl; ay = ly; bx = sl; by = -ly; }
+            else if (L == 2) { ax = lx; ay = sg; bx = -lx; by = sg; }
+            else { ax = -lx; ay = -sg; bx = lx; by = -sg; }
+            if (rss_seg_quad(Q, ax, ay, bx, by)) __hip_atomic_fetch_or(&q->hits[g], 1 << L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        }
+    }
+    tile_sync<1>();
+    for (int g0 = 0; g0 < n; g0 += 64) {
+        const int g = g0 + lane;
+        if (g < n) {
+            const int bits = q->hits[g];
+            q->hits[g] = 0;
+            const bool lat_i = bits & 3, long_i = bits & 12;
+            const unsigned cd = lat_i && long_i ? 3 : (lat_i ? 1 : (long_i ? 2 : 0));
+            const int owner = q->meta[g] & 63;
+            const unsigned k = q->key[g];
+            __hip_atomic_fetch_max(&q->stepcd[owner], k << 3 | cd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            if (cd == 1 || cd == 2) __hip_atomic_fetch_max(&q->lastword[owner], k << 2 | cd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        }
+    }
+    tile_sync<1>();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2601,7 +2710,14 @@ __device__ __forceinline__ void rollout_body(
     bool rss_touched = false; // this scenario was updated at least once in this launch
     double rss_lat = __builtin_nan(""), rss_long = __builtin_nan("");
     double rss_bw = 0.0, rss_bl = 0.0, rss_ew = 0.0, rss_el = 0.0;
+    __shared__ __attribute__((aligned(8))) char rss_queues[RSSV ? sizeof(RssQueue) * WV : 8];
+    const RssQueueLds rss_q = (RssQueueLds)(rss_queues + (RSSV ? sizeof(RssQueue) * wave : 0));
+    int rss_gn = 0;          // groups queued by this wavefront (uniform)
+    unsigned rss_k = 0;      // ordinal of this lane's next update within the launch
     if (RSSV) {
+        rss_q->lastword[lane] = 0;
+        rss_q->stepcd[lane] = 0;
+        for (int g = lane; g < RSSQ_CAP; g += 64) rss_q->hits[g] = 0;
         if (!rs && in_range && slot < p.E) rss_st = p.rss_state[rss_idx];
         rss_bw = fld(st, ST_BW);
         rss_bl = fld(st, ST_BL);
@@ -2634,13 +2750,46 @@ __device__ __forceinline__ void rollout_body(
             ego_pres = lds.cor[5][0] != 0.0;
             __syncthreads(); // the collision pass of the next step rewrites the scratch
         }
-        if (!upd) return;
-        rss_touched = true;
-        rss_cd = -1;
-        rss_lat = rss_long = __builtin_nan("");
-        if (tnow == 0.0 || !ego_pres || !present || slot == 0 || slot >= p.E) return; // callback.py:76-78
-        rss_entity(ex, ey, eh, evx, evy, rss_ew, rss_el, pose[0], pose[1], pose[3], vx, vy, rss_bw, rss_bl, bcx, bcy, rss_st,
-                   rss_cd, rss_lat, rss_long);
+        int need = 0;
+        bool ab = false;
+        double Qd[8];
+        if (upd) {
+            rss_touched = true;
+            rss_cd = -1;
+            rss_lat = rss_long = __builtin_nan("");
+            ++rss_k;
+            if (!(tnow == 0.0 || !ego_pres || !present || slot == 0 || slot >= p.E)) // callback.py:76-78
+                rss_entity<true>(ex, ey, eh, evx, evy, rss_ew, rss_el, pose[0], pose[1], pose[3], vx, vy, rss_bw, rss_bl, bcx, bcy,
+                                 rss_st, rss_cd, rss_lat, rss_long, &need, Qd, &ab);
+        }
+        // line tests: queued (see RssQueue); at most 64 new groups, the queue holds <= RSSQ_FLUSH here
+        const uint64_t wants = __ballot(need != 0);
+        if (wants) {
+            if (need) {
+                const int at = rss_gn + __builtin_popcountll(wants & ((1ull << lane) - 1));
+#pragma unroll
+                for (int k = 0; k < 8; ++k) rss_q->q[k][at] = Qd[k];
+                rss_q->q[8][at] = rss_lat;
+                rss_q->q[9][at] = rss_long;
+                rss_q->meta[at] = lane | need << 8;
+                rss_q->key[at] = rss_k;
+                rss_cd = -4 - (int)rss_k; // "see stepcd of update rss_k"
+            }
+            rss_gn += __builtin_popcountll(wants);
+        }
+        const bool entered = rss_cd == RSS_CD_ISECT;
+        const bool any_entered = __any(entered);
+        if (rss_gn > RSSQ_FLUSH || (any_entered && rss_gn)) {
+            tile_sync<1>();
+            rss_flush(rss_q, rss_gn);
+            rss_gn = 0;
+        }
+        if (any_entered && entered) { // unsafe_distance, callback.py:196-213
+            const unsigned lw = rss_q->lastword[lane];
+            const int last = lw ? (int)(lw & 3) : (rss_st >> 8) & 0xff;
+            rss_cd = last == 1 ? 5 : (last == 2 ? 4 : (ab ? 5 : 4));
+            rss_st = (rss_st & ~0xff) | (rss_cd == 4 ? 1 : 2);
+        }
     };
     if (RSSV && do_reset != 0) rss_call(rs, t, vel[0], vel[1]); // State.reset ends with update_callbacks(), state.py:138-140
 
@@ -3116,6 +3265,10 @@ __device__ __forceinline__ void rollout_body(
         }
         return;
     }
+    if (RSSV && rss_gn) { // (uniform per wavefront)
+        tile_sync<1>();
+        rss_flush(rss_q, rss_gn);
+    }
     // ---- write back what lives in registers during the loop ----
     if (in_range) {
         if (PED && kind == SG_KIND_AGENT_PEDESTRIAN) cs.e_lon_prev = (double)goal_idx;
@@ -3136,6 +3289,14 @@ __device__ __forceinline__ void rollout_body(
         }
         if (slot == 0) { sd.t = t; sd.prev_t = prev_t; sd.done = done; sd.n_steps = steps; if (PED) sd.noise_pos = noise_pos; }
         if (RSSV) {
+            if (rss_cd <= -4) { // the line tests of the latest update were queued
+                const unsigned sc = rss_q->stepcd[lane];
+                rss_cd = (sc >> 3) == (unsigned)(-4 - rss_cd) ? (int)(sc & 7) : 0;
+            }
+            {
+                const unsigned lw = rss_q->lastword[lane];
+                if (lw) rss_st = (rss_st & 0xff) | (int)(lw & 3) << 8;
+            }
             if (slot < p.E) {
                 p.rss_state[rss_idx] = rss_st;
                 if (rss_touched) { // the records of the latest update
