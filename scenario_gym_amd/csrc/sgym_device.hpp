@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "../../include/sgym.h"
 
@@ -107,6 +108,9 @@ struct Params {
     const double *ext_pose;  // [NE][6] poses of the caller-run agents (SG_KIND_AGENT_EXTERNAL), x = NaN: agent returned None
     int32_t *rss_state, *rss_code, *rss_seen; // RSSDistances records (sg_rss_update / rollout_kernel_rss), nullptr before first use
     double *rss_safe;
+    double *rssq;      // [wavefronts][rssq_cap][RSSQ_REC] line-test queues of rollout_kernel_rss (rss_lines_kernel)
+    int32_t *rssq_n;   // [wavefronts] groups queued by the latest launch
+    int32_t rssq_cap;  // groups per wavefront
     const unsigned char *reset_mask; // [R] sg_reset_scenarios: the scenarios a do_reset == 2 launch resets
     const RoadIndex *road;   // device copy of the road index, nullptr = no road networks set
     int ped_serial;          // 1: pedestrian pair loop one pedestrian per lane (env SG_PED_SERIAL; default 0: balanced over the wavefront)
@@ -495,6 +499,7 @@ __device__ __forceinline__ bool sg_quads_intersect(const double *A, const double
 }
 
 typedef float v2f __attribute__((ext_vector_type(2)));
+typedef double v2d __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 
 // Workgroup-shared tile data.  NS = slots of the tile set a workgroup owns: 64 when one wavefront
@@ -2230,13 +2235,15 @@ __device__ inline void rss_entity(double ex, double ey, double ego_heading, doub
                 const double Bv = __builtin_fabs(__builtin_fabs(pos1 - rss_dot2(pos0, pos1, j0, j1)) / s_long);
                 *ab = A > Bv;
                 cd = RSS_CD_ISECT;
-            } else { // the bounding-box test rss_seg_quad starts with, for the two "width" lines (0, 1) and the two "length" lines
+            } else { // the bounding-box test rss_seg_quad starts with: the two "width" lines (0, 1) are the diagonals of one
+                // box, the two "length" lines (2, 3) are horizontal, y = s_long and y = -s_long
                 const double lx = 100 * s_lat, ly = 100 * s_long;
                 const bool lat_far = qx1 < __builtin_fmin(s_lat, -s_lat) || qx0 > __builtin_fmax(s_lat, -s_lat) ||
                                      qy1 < __builtin_fmin(ly, -ly) || qy0 > __builtin_fmax(ly, -ly);
-                const bool long_far = qx1 < __builtin_fmin(lx, -lx) || qx0 > __builtin_fmax(lx, -lx) ||
-                                      qy1 < __builtin_fmin(s_long, -s_long) || qy0 > __builtin_fmax(s_long, -s_long);
-                *need = (lat_far ? 0 : 3) | (long_far ? 0 : 12);
+                const bool long_x_far = qx1 < __builtin_fmin(lx, -lx) || qx0 > __builtin_fmax(lx, -lx);
+                const bool far2 = long_x_far || qy1 < __builtin_fmin(s_long, s_long) || qy0 > __builtin_fmax(s_long, s_long);
+                const bool far3 = long_x_far || qy1 < __builtin_fmin(-s_long, -s_long) || qy0 > __builtin_fmax(-s_long, -s_long);
+                *need = (lat_far ? 0 : 3) | (far2 ? 0 : 4) | (far3 ? 0 : 8);
                 cd = 0;
 #pragma unroll
                 for (int k = 0; k < 8; ++k) Qd[k] = Q[k];
@@ -2267,14 +2274,19 @@ __device__ inline void rss_entity(double ex, double ey, double ego_heading, doub
 // write_intersections (callback.py:307-340) asks, for an entity outside the buffer, whether its box meets the buffer's two
 // "width" and two "length" lines: exact predicates, ~600 instructions per line, needed by a handful of the 64 lanes of a
 // wavefront at a step -- and their only effects are the record of THAT step (read back for the latest update only) and the
-// `last` entry of the history, which is looked at when the entity enters the buffer, once.  So a lane whose box meets a
-// line's bounding box queues a GROUP (its box, the safe distances, the lines wanted, the ordinal of the update) in its
-// wavefront's slice of LDS and goes on; rss_flush turns the queued groups into (group, line) items, one per lane, runs the
-// test once over full wavefronts and folds the results back per owner lane as max(ordinal << 3 | code) and
-// max(ordinal << 2 | code in {lateral, longitudinal}).  It runs when the queue passes RSSQ_FLUSH groups, when some lane
-// enters the buffer (its `last` must be current) and at the end of the launch.  Same predicates on the same operands as
-// the per-tick kernel: the results are the same bits.
-constexpr int RSSQ_CAP = 96, RSSQ_FLUSH = 32;
+// `last` entry of the history, which is looked at when the entity enters the buffer, once.  Inside the step loop they cost
+// more than everything else together (every wavefront ran them for its few lanes, and their registers pushed the loop's
+// state into scratch).  So a lane whose box meets a line's bounding box only appends a GROUP (its box in the ego frame, the
+// safe distances, the lines wanted, the ordinal of the update) to its wavefront's queue in global memory (p.rssq: 96 B,
+// (steps of the launch + 1) x 64 groups per wavefront: launches are chunked to fit) and goes on; an entity that enters the
+// buffer is flagged in its state word.  rss_lines_kernel runs after the launch, one wavefront per queue: it turns the
+// groups into (group, line) items, one per lane, runs the test over full wavefronts, folds the results per owner lane as
+// max(ordinal << 3 | code) and max(ordinal << 2 | code in {lateral, longitudinal}) and finishes the records -- the code of
+// the latest update, `last`, the class of a pending entry (unsafe_lateral / unsafe_longitudinal from `last`, :196-213).
+// Same predicates on the same operands as the per-tick kernel: the results are the same bits.
+constexpr int RSSQ_REC = 12;                               // doubles per group record: Q[8], s_lat, s_long, (meta | key << 32), pad
+constexpr int RSS_ST_PENDING = 1 << 16, RSS_ST_AB = 1 << 17; // state word: entered the buffer in this launch; A > Bv (:208-212)
+constexpr int RSSQ_CAP = 64; // groups per round of rss_lines_kernel
 struct RssQueue {
     double q[10][RSSQ_CAP];           // Q[8], s_lat, s_long
     int meta[RSSQ_CAP];               // owner lane | need << 8
@@ -2284,8 +2296,14 @@ struct RssQueue {
     unsigned lastword[64], stepcd[64];
 };
 typedef __attribute__((address_space(3))) RssQueue *RssQueueLds;
+#ifdef SG_RSS_STATS
+__device__ unsigned long long sg_rss_stats[8]; // experiment builds: flushes, groups, items, passes, updates (per wavefront)
+#define RSS_STAT(i, v) do { if ((threadIdx.x & 63) == 0) atomicAdd(&sg_rss_stats[i], (unsigned long long)(v)); } while (0)
+#else
+#define RSS_STAT(i, v) ((void)0)
+#endif
 
-__device__ __attribute__((noinline)) void rss_flush(RssQueueLds q, int n)
+__device__ __forceinline__ void rss_flush_body(RssQueueLds q, int n)
 {
     const int lane = threadIdx.x & 63;
     int n_items = 0;
@@ -2301,6 +2319,7 @@ __device__ __attribute__((noinline)) void rss_flush(RssQueueLds q, int n)
         }
     }
     tile_sync<1>();
+    RSS_STAT(0, 1); RSS_STAT(1, n); RSS_STAT(2, n_items); RSS_STAT(3, (n_items + 63) / 64);
     for (int i0 = 0; i0 < n_items; i0 += 64) {
         const int i = i0 + lane;
         if (i < n_items) {
@@ -2317,7 +2336,12 @@ __device__ __attribute__((noinline)) void rss_flush(RssQueueLds q, int n)
             else if (L == 1) { ax = -sl; ay = ly; bx = sl; by = -ly; }
             else if (L == 2) { ax = lx; ay = sg; bx = -lx; by = sg; }
             else { ax = -lx; ay = -sg; bx = lx; by = -sg; }
-            if (rss_seg_quad(Q, ax, ay, bx, by)) __hip_atomic_fetch_or(&q->hits[g], 1 << L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+#ifdef SG_ABL_RSS_NO_EVAL
+            if (Q[0] == 1e300)
+#else
+            if (rss_seg_quad(Q, ax, ay, bx, by))
+#endif
+                __hip_atomic_fetch_or(&q->hits[g], 1 << L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         }
     }
     tile_sync<1>();
@@ -2336,6 +2360,7 @@ __device__ __attribute__((noinline)) void rss_flush(RssQueueLds q, int n)
     }
     tile_sync<1>();
 }
+
 
 // ------------------------------------------------------------------------------------------------
 // The rollout kernel: ScenarioGym.reset_scenario / step / rollout (scenario_gym.py:217-267).
@@ -2710,14 +2735,11 @@ __device__ __forceinline__ void rollout_body(
     bool rss_touched = false; // this scenario was updated at least once in this launch
     double rss_lat = __builtin_nan(""), rss_long = __builtin_nan("");
     double rss_bw = 0.0, rss_bl = 0.0, rss_ew = 0.0, rss_el = 0.0;
-    __shared__ __attribute__((aligned(8))) char rss_queues[RSSV ? sizeof(RssQueue) * WV : 8];
-    const RssQueueLds rss_q = (RssQueueLds)(rss_queues + (RSSV ? sizeof(RssQueue) * wave : 0));
     int rss_gn = 0;          // groups queued by this wavefront (uniform)
-    unsigned rss_k = 0;      // ordinal of this lane's next update within the launch
+    unsigned rss_k = 0;      // ordinal of this lane's latest update within the launch
+    const size_t rss_wave = (size_t)blockIdx.x * WV + wave;
+    SG_GLOBAL v2d *const rss_rec = RSSV ? (SG_GLOBAL v2d *)(p.rssq + rss_wave * (size_t)p.rssq_cap * RSSQ_REC) : nullptr;
     if (RSSV) {
-        rss_q->lastword[lane] = 0;
-        rss_q->stepcd[lane] = 0;
-        for (int g = lane; g < RSSQ_CAP; g += 64) rss_q->hits[g] = 0;
         if (!rs && in_range && slot < p.E) rss_st = p.rss_state[rss_idx];
         rss_bw = fld(st, ST_BW);
         rss_bl = fld(st, ST_BL);
@@ -2762,34 +2784,28 @@ __device__ __forceinline__ void rollout_body(
                 rss_entity<true>(ex, ey, eh, evx, evy, rss_ew, rss_el, pose[0], pose[1], pose[3], vx, vy, rss_bw, rss_bl, bcx, bcy,
                                  rss_st, rss_cd, rss_lat, rss_long, &need, Qd, &ab);
         }
-        // line tests: queued (see RssQueue); at most 64 new groups, the queue holds <= RSSQ_FLUSH here
+        // line tests: queued for rss_lines_kernel (see RssQueue)
+#ifdef SG_ABL_RSS_NO_PUSH
+        need = 0;
+#endif
+        RSS_STAT(4, 1); RSS_STAT(5, __builtin_popcountll(__ballot((need & 3) != 0))); RSS_STAT(6, __builtin_popcountll(__ballot((need & 12) != 0)));
         const uint64_t wants = __ballot(need != 0);
         if (wants) {
             if (need) {
                 const int at = rss_gn + __builtin_popcountll(wants & ((1ull << lane) - 1));
-#pragma unroll
-                for (int k = 0; k < 8; ++k) rss_q->q[k][at] = Qd[k];
-                rss_q->q[8][at] = rss_lat;
-                rss_q->q[9][at] = rss_long;
-                rss_q->meta[at] = lane | need << 8;
-                rss_q->key[at] = rss_k;
-                rss_cd = -4 - (int)rss_k; // "see stepcd of update rss_k"
+                if (at < p.rssq_cap) { // (always: the host sizes the queue for the steps of the launch)
+                    SG_GLOBAL v2d *rec = rss_rec + (size_t)at * (RSSQ_REC / 2);
+                    rec[0] = v2d{Qd[0], Qd[1]}; rec[1] = v2d{Qd[2], Qd[3]};
+                    rec[2] = v2d{Qd[4], Qd[5]}; rec[3] = v2d{Qd[6], Qd[7]};
+                    rec[4] = v2d{rss_lat, rss_long};
+                    rec[5] = v2d{__longlong_as_double((long long)((uint64_t)(uint32_t)(lane | need << 8) | (uint64_t)rss_k << 32)), 0.0};
+                }
+                rss_cd = -4 - (int)rss_k; // "the code of update rss_k is with rss_lines_kernel"
             }
             rss_gn += __builtin_popcountll(wants);
         }
-        const bool entered = rss_cd == RSS_CD_ISECT;
-        const bool any_entered = __any(entered);
-        if (rss_gn > RSSQ_FLUSH || (any_entered && rss_gn)) {
-            tile_sync<1>();
-            rss_flush(rss_q, rss_gn);
-            rss_gn = 0;
-        }
-        if (any_entered && entered) { // unsafe_distance, callback.py:196-213
-            const unsigned lw = rss_q->lastword[lane];
-            const int last = lw ? (int)(lw & 3) : (rss_st >> 8) & 0xff;
-            rss_cd = last == 1 ? 5 : (last == 2 ? 4 : (ab ? 5 : 4));
-            rss_st = (rss_st & ~0xff) | (rss_cd == 4 ? 1 : 2);
-        }
+        if (upd && rss_cd == RSS_CD_ISECT) // unsafe_distance, callback.py:196-213: the entry exists from now on, its class is pending
+            rss_st = (rss_st & 0xff00) | 3 | RSS_ST_PENDING | (ab ? RSS_ST_AB : 0);
     };
     if (RSSV && do_reset != 0) rss_call(rs, t, vel[0], vel[1]); // State.reset ends with update_callbacks(), state.py:138-140
 
@@ -3265,10 +3281,7 @@ __device__ __forceinline__ void rollout_body(
         }
         return;
     }
-    if (RSSV && rss_gn) { // (uniform per wavefront)
-        tile_sync<1>();
-        rss_flush(rss_q, rss_gn);
-    }
+    if (RSSV && lane == 0) p.rssq_n[rss_wave] = min(rss_gn, p.rssq_cap);
     // ---- write back what lives in registers during the loop ----
     if (in_range) {
         if (PED && kind == SG_KIND_AGENT_PEDESTRIAN) cs.e_lon_prev = (double)goal_idx;
@@ -3289,15 +3302,7 @@ __device__ __forceinline__ void rollout_body(
         }
         if (slot == 0) { sd.t = t; sd.prev_t = prev_t; sd.done = done; sd.n_steps = steps; if (PED) sd.noise_pos = noise_pos; }
         if (RSSV) {
-            if (rss_cd <= -4) { // the line tests of the latest update were queued
-                const unsigned sc = rss_q->stepcd[lane];
-                rss_cd = (sc >> 3) == (unsigned)(-4 - rss_cd) ? (int)(sc & 7) : 0;
-            }
-            {
-                const unsigned lw = rss_q->lastword[lane];
-                if (lw) rss_st = (rss_st & 0xff) | (int)(lw & 3) << 8;
-            }
-            if (slot < p.E) {
+            if (slot < p.E) { // (markers in rss_st / rss_cd: rss_lines_kernel finishes them)
                 p.rss_state[rss_idx] = rss_st;
                 if (rss_touched) { // the records of the latest update
                     p.rss_code[rss_idx] = rss_cd;
@@ -4123,6 +4128,56 @@ __global__ __launch_bounds__(256) void rss_kernel(Params p, int reset, int32_t *
     code[idx] = cd;
     safe[(size_t)idx * 2] = s_lat;
     safe[(size_t)idx * 2 + 1] = s_long;
+}
+
+// The queued line tests of one rollout_kernel_rss launch (see RssQueue): block w = the queue of rollout wavefront w, whose
+// lane l carries entity index w * 64 + l.
+__global__ __launch_bounds__(64) void rss_lines_kernel(Params p)
+{
+    __shared__ RssQueue q;
+    const RssQueueLds ql = (RssQueueLds)&q;
+    const int lane = threadIdx.x;
+    const size_t w = blockIdx.x;
+    const int n = p.rssq_n[w];
+    const uint32_t idx = (uint32_t)(w * 64 + lane);
+    int32_t st = p.rss_state[idx];
+    if (n == 0 && !__any(st & RSS_ST_PENDING)) return;
+    ql->lastword[lane] = 0;
+    ql->stepcd[lane] = 0;
+    ql->hits[lane] = 0;
+    const double *rec0 = p.rssq + w * (size_t)p.rssq_cap * RSSQ_REC;
+    for (int g0 = 0; g0 < n; g0 += RSSQ_CAP) {
+        const int m = min(RSSQ_CAP, n - g0);
+        if (lane < m) {
+            const double2 *rec = reinterpret_cast<const double2 *>(rec0 + (size_t)(g0 + lane) * RSSQ_REC);
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                const double2 v = rec[k];
+                ql->q[2 * k][lane] = v.x;
+                ql->q[2 * k + 1][lane] = v.y;
+            }
+            const uint64_t mk = (uint64_t)__double_as_longlong(rec[5].x);
+            ql->meta[lane] = (int)(uint32_t)mk;
+            ql->key[lane] = (unsigned)(mk >> 32);
+        }
+        tile_sync<1>();
+        rss_flush_body(ql, m);
+    }
+    tile_sync<1>();
+    const unsigned lw = ql->lastword[lane], sc = ql->stepcd[lane];
+    int cd = p.rss_code[idx];
+    const int32_t st0 = st;
+    const int cd0 = cd;
+    if (lw) st = (st & ~0xff00) | (int)(lw & 3) << 8;
+    if (st & RSS_ST_PENDING) { // the entity entered the buffer during the launch: unsafe_distance, callback.py:196-213
+        const int last = (st >> 8) & 0xff;
+        const int cls = last == 1 ? 5 : (last == 2 ? 4 : ((st & RSS_ST_AB) ? 5 : 4));
+        st = (st & 0xff00) | (cls == 4 ? 1 : 2);
+        if (cd == RSS_CD_ISECT) cd = cls;
+    }
+    if (cd <= -4) cd = (sc >> 3) == (unsigned)(-4 - cd) ? (int)(sc & 7) : 0; // the latest update's line tests were queued
+    if (st != st0) p.rss_state[idx] = st;
+    if (cd != cd0) p.rss_code[idx] = cd;
 }
 
 // The observation of one RL tick in ONE launch (sg_tick): every requested map layer -- the entity layer of raster_kernel and

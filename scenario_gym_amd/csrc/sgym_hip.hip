@@ -86,6 +86,9 @@ struct sg_handle {
     bool rss_enabled = false;                              // sg_set_rss: RSSDistances runs after every step of sg_rollout / sg_step
     bool ego_first = true;                                 // every scenario's ego is its entity 0
     double *d_rss_safe = nullptr;                          // [NE][2]
+    double *d_rssq = nullptr;                              // line-test queues of rollout_kernel_rss: [NE / 64][(rssq_steps + 1) * 64][12]
+    int32_t *d_rssq_n = nullptr;                           // [NE / 64]
+    int rssq_steps = 0;                                    // steps per launch the queues are sized for
     double c_tol = 0.4;                                // CollisionMetric(c_tol): angular half-width of a box corner, metrics/collision.py:57
     unsigned char *d_reset_mask = nullptr;             // [R] sg_reset_scenarios
     uint32_t *d_term_flags = nullptr;                  // [R] sg_terminal_flags
@@ -141,6 +144,7 @@ static int dev_alloc(sg_handle *h, std::vector<void *> &pool, T **out, size_t n,
 }
 
 static int ensure_rss(sg_handle *h, bool *fresh);
+static int ensure_rssq(sg_handle *h);
 
 template <typename T>
 static int dev_upload(sg_handle *h, std::vector<void *> &pool, const T **out, const std::vector<T> &v)
@@ -256,6 +260,13 @@ extern "C" int sg_destroy(sg_handle *h)
     if (!h) return SG_OK;
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+#ifdef SG_RSS_STATS
+    {
+        unsigned long long c[8];
+        (void)hipMemcpyFromSymbol(c, HIP_SYMBOL(sg::sg_rss_stats), sizeof c);
+        fprintf(stderr, "rss stats: flushes %llu groups %llu items %llu passes %llu wave-updates %llu lat-lanes %llu long-lanes %llu\n", c[0], c[1], c[2], c[3], c[4], c[5], c[6]);
+    }
+#endif
 #ifdef SG_PHASE_TIMERS
     if (h->p.phase_cycles) {
         unsigned long long c[16];
@@ -285,6 +296,8 @@ extern "C" int sg_destroy(sg_handle *h)
     if (h->d_rss_seen) (void)hipFree(h->d_rss_seen);
     if (h->d_rss_code) (void)hipFree(h->d_rss_code);
     if (h->d_rss_safe) (void)hipFree(h->d_rss_safe);
+    if (h->d_rssq) (void)hipFree(h->d_rssq);
+    if (h->d_rssq_n) (void)hipFree(h->d_rssq_n);
     if (h->tick_exec) (void)hipGraphExecDestroy(h->tick_exec);
     if (h->ctl_stream) (void)hipStreamSynchronize(h->ctl_stream);
     if (h->d_actions) (void)hipFree(h->d_actions);
@@ -372,6 +385,10 @@ static int launch_main(sg_handle *h, int n_steps, int do_reset, int force, const
         sg::event_ego_pose_kernel<<<dim3((unsigned)h->R), dim3(64), 0, h->stream>>>(h->p, d_tab);
         HIP_TRY(h, hipGetLastError());
     }
+    if (h->rss_fused && !h->has_ped && !(h->cfg.terminal_mask & SG_TERM_EGO_OFF_ROAD)) { // (launch_variant ran rollout_kernel_rss)
+        sg::rss_lines_kernel<<<dim3((unsigned)(h->NE / 64)), dim3(64), 0, h->stream>>>(h->p);
+        HIP_TRY(h, hipGetLastError());
+    }
     if (!h->timing_now) return SG_OK;
     HIP_TRY(h, hipEventRecord(e1, h->stream));
     if (n_steps > 0) { // reset-only launches are not counted as hot-path launches
@@ -398,7 +415,11 @@ static int launch_rollout(sg_handle *h, int n_steps, int do_reset, int force, co
     h->timing_now = use_tab || n_steps >= 16;
     if (h->timing_now) HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
     int rc = SG_OK;
-    if (!use_tab) {
+    if (!use_tab && h->rss_fused && n_steps > h->rssq_steps) { // the line-test queues hold rssq_steps steps per launch (ensure_rss)
+        for (int k0 = 0; k0 < n_steps && !rc; k0 += h->rssq_steps)
+            rc = launch_main(h, std::min(h->rssq_steps, n_steps - k0), k0 == 0 ? do_reset : 0, force,
+                             d_actions ? d_actions + (size_t)k0 * h->R * 2 : nullptr, nullptr, false, &ev_next);
+    } else if (!use_tab) {
         rc = launch_main(h, n_steps, do_reset, force, d_actions, nullptr, false, &ev_next);
     } else {
         if (do_reset && (rc = launch_main(h, 0, do_reset, 0, nullptr, nullptr, false, &ev_next))) return rc;
@@ -647,6 +668,7 @@ extern "C" int sg_upload(sg_handle *h, const sg_scenarios *sc)
     h->state_allocs.rewind();
     free_pool(h->road_allocs); // the networks belong to a batch (net_of_scenario)
     if (h->d_rss_state) { (void)hipFree(h->d_rss_state); (void)hipFree(h->d_rss_code); (void)hipFree(h->d_rss_safe); (void)hipFree(h->d_rss_seen); h->d_rss_state = nullptr; h->d_rss_code = nullptr; h->d_rss_safe = nullptr; h->d_rss_seen = nullptr; }
+    if (h->d_rssq) { (void)hipFree(h->d_rssq); (void)hipFree(h->d_rssq_n); h->d_rssq = nullptr; h->d_rssq_n = nullptr; h->p.rssq = nullptr; h->p.rssq_n = nullptr; }
     h->has_road = false;
     h->road = sg::RoadIndex{};
     h->uploaded = false; // (the controller table buffers stay: launch_rollout regrows them when the new batch needs more)
@@ -929,7 +951,7 @@ extern "C" int sg_reset(sg_handle *h)
     int rc;
     if (h->rss_enabled && !h->has_ped && !(h->cfg.terminal_mask & SG_TERM_EGO_OFF_ROAD) && h->ego_first) {
         bool fresh = false;
-        if ((rc = ensure_rss(h, &fresh))) return rc;
+        if ((rc = ensure_rss(h, &fresh)) || (rc = ensure_rssq(h))) return rc;
         h->rss_fused = true;
         rc = launch_rollout(h, 0, 1, 0, nullptr);
         h->rss_fused = false;
@@ -1014,7 +1036,7 @@ extern "C" int sg_step(sg_handle *h, int32_t n_steps, const double *actions, int
     int rc = SG_OK;
     if (h->rss_enabled && !h->has_ped && !(h->cfg.terminal_mask & SG_TERM_EGO_OFF_ROAD) && h->ego_first && h->d_rss_state) {
         bool fresh = false;
-        rc = ensure_rss(h, &fresh);
+        if (!(rc = ensure_rss(h, &fresh))) rc = ensure_rssq(h);
         h->rss_fused = true;
         if (!rc) rc = launch_rollout(h, n_steps, 0, 1, d_act);
         h->rss_fused = false;
@@ -1152,6 +1174,7 @@ extern "C" int sg_rollout_async(sg_handle *h, int32_t max_steps, int32_t do_rese
         // the callback inside the rollout kernel (rollout_kernel_rss): after the reset and after every step of ONE launch
         bool fresh = false;
         int rc = ensure_rss(h, &fresh);
+        if (!rc) rc = ensure_rssq(h);
         if (rc) return rc;
         h->rss_fused = true;
         rc = launch_rollout(h, max_steps, do_reset || fresh ? 1 : 0, 0, nullptr);
@@ -1389,6 +1412,23 @@ static int ensure_rss(sg_handle *h, bool *fresh)
         *fresh = true;
     }
     h->p.rss_state = h->d_rss_state; h->p.rss_code = h->d_rss_code; h->p.rss_safe = h->d_rss_safe; h->p.rss_seen = h->d_rss_seen;
+    return SG_OK;
+}
+
+// The line-test queues of rollout_kernel_rss (sgym_device.hpp, RssQueue): (steps + 1) x 64 groups of 96 B per wavefront, the
+// steps per launch chosen so that the queues of the batch stay under SG_RSSQ_BYTES (default 4 GiB).
+static int ensure_rssq(sg_handle *h)
+{
+    if (!h->d_rssq) {
+        const size_t nw = h->NE / 64, per_step = nw * 64 * sg::RSSQ_REC * sizeof(double);
+        const size_t budget = (size_t)env_int("SG_RSSQ_MB", 4096) << 20;
+        const int steps = (int)std::min<size_t>(256, std::max<size_t>(2, budget / per_step) - 1);
+        HIP_TRY(h, hipMalloc((void **)&h->d_rssq, per_step * (size_t)(steps + 1)));
+        HIP_TRY(h, hipMalloc((void **)&h->d_rssq_n, nw * sizeof(int32_t)));
+        HIP_TRY(h, hipMemsetAsync(h->d_rssq_n, 0, nw * sizeof(int32_t), h->stream));
+        h->rssq_steps = steps;
+    }
+    h->p.rssq = h->d_rssq; h->p.rssq_n = h->d_rssq_n; h->p.rssq_cap = (h->rssq_steps + 1) * 64;
     return SG_OK;
 }
 

@@ -1714,6 +1714,47 @@ def test_rss_fused_rollout_matches_oracle(sga, oracle, R, E, ego):
     eng.close()
 
 
+@pytest.mark.parametrize("E,ego", [(64, "pid"), (9, "replay"), (130, "pid")])
+def test_rss_line_test_queues_across_launches(sga, monkeypatch, E, ego):
+    """The line tests of rollout_kernel_rss are queued per wavefront and evaluated by rss_lines_kernel after each launch; the
+    queues hold a fixed number of steps.  One launch, launches of a few steps each (queues of 1 MiB), and a rollout resumed
+    in pieces by the caller: the same records, states and flags -- the `last` entry and a pending "unsafe" class carry over
+    from launch to launch."""
+    import scenario_gym_amd._lib as L
+    from scenario_gym_amd import synthetic
+
+    R, steps = 96, 80
+    kind = dict(replay=L.KIND_AGENT_REPLAY, pid=L.KIND_AGENT_PID)[ego]
+    packed = synthetic.make_batch(R, E, n_steps=steps, ego_kind=kind, extent=14.0 if E < 100 else 30.0, vanish_frac=0.2)
+    packed.length = packed.length * np.linspace(0.5, 1.0, R)
+    out = []
+    for mode in ("one", "chunked", "resumed"):
+        if mode == "chunked":
+            monkeypatch.setenv("SG_RSSQ_MB", "1")
+        else:
+            monkeypatch.delenv("SG_RSSQ_MB", raising=False)
+        eng = sga.RolloutEngine(R, E)
+        eng.set_rss(True)
+        eng.upload(packed)
+        if mode == "resumed":
+            eng.rollout(7)
+            for n in (1, 20, 3, steps):
+                eng.rollout_async(n, do_reset=False)
+            eng.synchronize()
+            launches = 0
+        else:
+            eng.rollout(steps)
+            launches = eng.last_launch_stats()[0]
+        out.append((eng.rss(), eng.state()["n_steps"].copy(), launches))
+        eng.close()
+    assert out[1][2] > out[0][2] >= 1  # the small queues did split the call
+    for k in (1, 2):
+        assert np.array_equal(out[0][1], out[k][1])
+        for x, y in zip(out[0][0], out[k][0]):
+            assert np.array_equal(x, y, equal_nan=True), k
+    assert (out[0][0][2] >= 4).any() and (out[0][0][2] == 1).any() and (out[0][0][2] == 2).any()  # unsafe, lateral, longitudinal
+
+
 def _random_crowds(n, seed=77):
     rng = np.random.default_rng(seed)
     out = []
