@@ -2094,11 +2094,16 @@ __global__ void build_grid_kernel(Params p, const int32_t *row_scen /*[totalN]*/
 // sequence as the oracle's sgo_rss_update.
 // ------------------------------------------------------------------------------------------------
 __device__ inline double rss_dot2(double a0, double a1, double b0, double b1) { return __builtin_fma(a1, b1, a0 * b0); }
+#ifdef SG_ABL_RSS_FASTDIV // experiment builds: what do the IEEE divisions of the callback cost (results are wrong)
+#define RSS_DIV(a, b) ((a) * __builtin_amdgcn_rcp(b))
+#else
+#define RSS_DIV(a, b) ((a) / (b))
+#endif
 __device__ inline void rss_inv_dir(double v0, double v1, double &o0, double &o1)
 {
     const double n = sg_norm2(v1, v0);
-    o0 = v1 / n;
-    o1 = -v0 / n;
+    o0 = RSS_DIV(v1, n);
+    o1 = RSS_DIV(-v0, n);
 }
 __device__ inline bool rss_on_segment(double ax, double ay, double bx, double by, double px, double py)
 {
@@ -2179,8 +2184,8 @@ __device__ inline void rss_entity(double ex, double ey, double ego_heading, doub
                 else { vf = rss_dot2(vel0, vel1, ego_head0, ego_head1); vr = sg_norm2(ego_vel0, ego_vel1); }
                 if (vr == 0.0) s_long = MIN_SAFE_CLEARANCE + 0.5 * ego_l;
                 else {
-                    const double a = vr * rt + __builtin_fmin(vf * vf / (2 * m), 0.5 * m * (rt * rt)) +
-                                     ((vr + rt * m) * (vr + rt * m)) / (2 * MIN_LONG_ACCEL) - vf * vf / (2 * m);
+                    const double a = vr * rt + __builtin_fmin(RSS_DIV(vf * vf, 2 * m), 0.5 * m * (rt * rt)) +
+                                     RSS_DIV((vr + rt * m) * (vr + rt * m), 2 * MIN_LONG_ACCEL) - RSS_DIV(vf * vf, 2 * m);
                     s_long = __builtin_fmax(0.0, a) + MIN_SAFE_CLEARANCE + 0.5 * ego_l;
                 }
             } else {
@@ -2189,8 +2194,8 @@ __device__ inline void rss_entity(double ex, double ey, double ego_heading, doub
                 const int sp = (pos1 > 0) - (pos1 < 0), sv = (vel1 > 0) - (vel1 < 0);
                 if (sp == sv) s_long = MIN_SAFE_CLEARANCE + 0.5 * ego_l;
                 else {
-                    const double a = (2 * v1 + rt * m) * rt / 2 + ((v1 + rt * m) * (v1 + rt * m)) / (2 * MIN_LONG_ACCEL) +
-                                     (2 * av2 + rt * m) * rt / 2 + ((av2 + rt * m) * (av2 + rt * m)) / (2 * MIN_LONG_ACCEL);
+                    const double a = (2 * v1 + rt * m) * rt / 2 + RSS_DIV((v1 + rt * m) * (v1 + rt * m), 2 * MIN_LONG_ACCEL) +
+                                     (2 * av2 + rt * m) * rt / 2 + RSS_DIV((av2 + rt * m) * (av2 + rt * m), 2 * MIN_LONG_ACCEL);
                     s_long = __builtin_fmax(0.0, a) + MIN_SAFE_CLEARANCE + 0.5 * ego_l;
                 }
             }
@@ -2208,8 +2213,8 @@ __device__ inline void rss_entity(double ex, double ey, double ego_heading, doub
                 v = __builtin_fabs(v);
                 if (v == 0.0) parallel = true;
                 else
-                    d0 = __builtin_fmax(0.0, 0.5 * rt * (2 * v + rt * max_lat) + ((v + rt * max_lat) * (v + rt * max_lat)) / (2 * min_lat) -
-                                                 0.5 * (rt * rt) * max_lat - ((rt * max_lat) * (rt * max_lat)) / (2 * min_lat));
+                    d0 = __builtin_fmax(0.0, 0.5 * rt * (2 * v + rt * max_lat) + RSS_DIV((v + rt * max_lat) * (v + rt * max_lat), 2 * min_lat) -
+                                                 0.5 * (rt * rt) * max_lat - RSS_DIV((rt * max_lat) * (rt * max_lat), 2 * min_lat));
             }
             s_lat = __builtin_fabs(parallel ? MIN_SAFE_CLEARANCE + 0.5 * ego_w : d0 + MIN_SAFE_CLEARANCE + 0.5 * ego_w);
         }
@@ -2228,7 +2233,11 @@ __device__ inline void rss_entity(double ex, double ey, double ego_heading, doub
             const double INF = __builtin_inf();
             const bool apart = (qx1 < -s_lat || qx0 > s_lat || qy1 < -s_long || qy0 > s_long) && qx0 > -INF && qx1 < INF &&
                                qy0 > -INF && qy1 < INF && s_lat < INF && s_long < INF;
+#ifdef SG_ABL_RSS_NO_SAT
+            if (false) {
+#else
             if (!apart && sg_quads_intersect(Q, B)) {
+#endif
                 double j0, j1;
                 rss_inv_dir(ego_w, ego_l, j0, j1);
                 const double A = __builtin_fabs(__builtin_fabs(pos0) - __builtin_fabs(rss_dot2(pos0, pos1, ego_w, ego_l))) / s_lat;
@@ -3352,6 +3361,20 @@ __global__ __launch_bounds__(64 * WV, SG_WAVES_PER_SIMD) void rollout_kernel_rss
     Params p, double timestep, int n_steps, int do_reset, int force, const double *actions, const double *tab)
 {
     rollout_body<G, WV, false, false, false, false, true>(p, timestep, n_steps, do_reset, force, actions, tab);
+}
+
+// ... with the ego_off_road terminal condition / with pedestrian agents (RSSDistances treats every entity alike)
+template <int G, int WV>
+__global__ __launch_bounds__(64 * WV, SG_WAVES_PER_SIMD) void rollout_kernel_rss_road(
+    Params p, double timestep, int n_steps, int do_reset, int force, const double *actions, const double *tab)
+{
+    rollout_body<G, WV, false, false, false, true, true>(p, timestep, n_steps, do_reset, force, actions, tab);
+}
+template <int G, int WV>
+__global__ __launch_bounds__(64 * WV, SG_WAVES_PER_SIMD_PED) void rollout_kernel_rss_ped(
+    Params p, double timestep, int n_steps, int do_reset, int force, const double *actions, const double *tab)
+{
+    rollout_body<G, WV, true, false, false, false, true>(p, timestep, n_steps, do_reset, force, actions, tab);
 }
 
 // The table variant with one wavefront per tile (C2 / C3 shapes) under a 192-VGPR cap: two of its wavefronts and one of

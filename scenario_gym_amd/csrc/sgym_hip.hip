@@ -328,8 +328,12 @@ static void launch_variant(sg_handle *h, dim3 grid, int n_steps, int do_reset, i
     sg::rollout_kernel_crowd<WV><<<grid, block, 0, h->stream>>>(h->p, h->cfg.timestep, n_steps, do_reset, force, d_actions, nullptr);
     return;
 #endif
-    if (h->has_ped && h->all_ped && G == 64 && !h->has_road && h->crowd_kernel)
+    if (h->has_ped && h->all_ped && G == 64 && !h->has_road && h->crowd_kernel && !h->rss_fused)
         sg::rollout_kernel_crowd<WV><<<grid, block, 0, h->stream>>>(h->p, h->cfg.timestep, n_steps, do_reset, force, d_actions, nullptr);
+    else if (h->has_ped && h->rss_fused)
+        sg::rollout_kernel_rss_ped<(WV > 1 || G >= 16) ? G : 16, WV><<<grid, block, 0, h->stream>>>(h->p, h->cfg.timestep, n_steps, do_reset, force, d_actions, nullptr);
+    else if (h->rss_fused && (h->cfg.terminal_mask & SG_TERM_EGO_OFF_ROAD))
+        sg::rollout_kernel_rss_road<G, WV><<<grid, block, 0, h->stream>>>(h->p, h->cfg.timestep, n_steps, do_reset, force, d_actions, nullptr);
     else if (h->has_ped)
         sg::rollout_kernel<(WV > 1 || G >= 16) ? G : 16, WV, true, false><<<grid, block, 0, h->stream>>>(
             h->p, h->cfg.timestep, n_steps, do_reset, force, d_actions, nullptr);
@@ -385,7 +389,7 @@ static int launch_main(sg_handle *h, int n_steps, int do_reset, int force, const
         sg::event_ego_pose_kernel<<<dim3((unsigned)h->R), dim3(64), 0, h->stream>>>(h->p, d_tab);
         HIP_TRY(h, hipGetLastError());
     }
-    if (h->rss_fused && !h->has_ped && !(h->cfg.terminal_mask & SG_TERM_EGO_OFF_ROAD)) { // (launch_variant ran rollout_kernel_rss)
+    if (h->rss_fused) { // (launch_variant ran a rollout_kernel_rss* variant)
         sg::rss_lines_kernel<<<dim3((unsigned)(h->NE / 64)), dim3(64), 0, h->stream>>>(h->p);
         HIP_TRY(h, hipGetLastError());
     }
@@ -949,7 +953,7 @@ extern "C" int sg_reset(sg_handle *h)
     if (!h->uploaded) return fail(h, SG_ERR_STATE, "sg_reset: no scenarios uploaded");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     int rc;
-    if (h->rss_enabled && !h->has_ped && !(h->cfg.terminal_mask & SG_TERM_EGO_OFF_ROAD) && h->ego_first) {
+    if (h->rss_enabled && h->ego_first) {
         bool fresh = false;
         if ((rc = ensure_rss(h, &fresh)) || (rc = ensure_rssq(h))) return rc;
         h->rss_fused = true;
@@ -1034,7 +1038,7 @@ extern "C" int sg_step(sg_handle *h, int32_t n_steps, const double *actions, int
         d_act = h->d_actions;
     }
     int rc = SG_OK;
-    if (h->rss_enabled && !h->has_ped && !(h->cfg.terminal_mask & SG_TERM_EGO_OFF_ROAD) && h->ego_first && h->d_rss_state) {
+    if (h->rss_enabled && h->ego_first && h->d_rss_state) {
         bool fresh = false;
         if (!(rc = ensure_rss(h, &fresh))) rc = ensure_rssq(h);
         h->rss_fused = true;
@@ -1170,7 +1174,7 @@ extern "C" int sg_rollout_async(sg_handle *h, int32_t max_steps, int32_t do_rese
                                      "use sg_set_external_poses + sg_step tick by tick", h->n_ext);
     if (max_steps < 0) return fail(h, SG_ERR_INVALID, "sg_rollout: max_steps < 0");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
-    if (h->rss_enabled && !h->has_ped && !(h->cfg.terminal_mask & SG_TERM_EGO_OFF_ROAD) && h->ego_first) {
+    if (h->rss_enabled && h->ego_first) {
         // the callback inside the rollout kernel (rollout_kernel_rss): after the reset and after every step of ONE launch
         bool fresh = false;
         int rc = ensure_rss(h, &fresh);
@@ -1181,7 +1185,7 @@ extern "C" int sg_rollout_async(sg_handle *h, int32_t max_steps, int32_t do_rese
         h->rss_fused = false;
         return rc;
     }
-    if (h->rss_enabled) { // (pedestrian batches, ego_off_road) the callback after the reset and after every step: one step per launch
+    if (h->rss_enabled) { // (sg_rss_update reports why not: the ego is not entity 0) one step per launch
         int rc = SG_OK;
         if (do_reset && ((rc = launch_rollout(h, 0, 1, 0, nullptr)) || (rc = sg_rss_update(h, 1)))) return rc;
         for (int k = 0; k < max_steps; ++k)

@@ -1714,6 +1714,71 @@ def test_rss_fused_rollout_matches_oracle(sga, oracle, R, E, ego):
     eng.close()
 
 
+@pytest.mark.parametrize("scene,E", [("crowd", 12), ("crowd", 40), ("crowd", 150), ("roads", 6), ("roads", 40), ("roads", 100)])
+def test_rss_inside_pedestrian_and_off_road_rollouts(sga, scene, E):
+    """sg_set_rss on batches with pedestrian agents (a PID car and a replayed car driving through a social-force crowd) and on
+    batches with the ego_off_road terminal condition: the callback runs inside those rollout variants too
+    (rollout_kernel_rss_ped / _road) and leaves what one step per launch + sg_rss_update by hand leaves."""
+    import scenario_gym_amd._lib as L
+    from scenario_gym_amd import synthetic
+
+    rng = np.random.default_rng(31)
+    R, steps, dt = 10, 80, 1 / 30
+    nets = net_of = None
+    if scene == "crowd":
+        side = {12: 8.0, 40: 12.0, 150: 22.0}[E]
+        packed = synthetic.make_crowd(R, E, n_steps=steps, side=side)
+        T = steps * dt
+        for r in range(R):
+            for slot, (kind, y, v) in enumerate([(L.KIND_AGENT_PID, -1.0, 4.0), (L.KIND_REPLAY, 2.5, -3.0)]):
+                i = r * E + slot
+                a = int(packed.knot_off[i])
+                x0 = -np.sign(v) * side / 2
+                packed.knots[a] = [0.0, x0, y, 0.0, 0.0 if v > 0 else np.pi, 0.0, 0.0]
+                packed.knots[a + 1] = [T, x0 + v * T, y, 0.0, 0.0 if v > 0 else np.pi, 0.0, 0.0]
+                packed.kind[i], packed.etype[i] = kind, 0
+                packed.bbox[i] = synthetic.CAR1_BBOX
+                packed.ctrl[i] = sga.engine.DEFAULT_CTRL
+        kw = {}
+    else:
+        packed = synthetic.make_batch(R, E, n_steps=steps, ego_kind=L.KIND_AGENT_PID, extent=25.0)
+        nets = []
+        for n in range(3):
+            rings = []
+            for q in range(6):
+                c = rng.uniform(-30, 30, 2)
+                ang = np.sort(rng.uniform(0, 2 * np.pi, 12))
+                rings.append(c + (rng.uniform(25, 50) * rng.uniform(0.7, 1.0, 12))[:, None] * np.stack([np.cos(ang), np.sin(ang)], 1))
+            vert_off = np.concatenate([[0], np.cumsum([len(r) for r in rings])])
+            nets.append(dict(ring_off=np.arange(len(rings) + 1), vert_off=vert_off, verts=np.concatenate(rings), layers=np.ones(len(rings), int)))
+        net_of = rng.integers(0, len(nets), R)
+        kw = dict(terminal_conditions=["max_length", "ego_off_road"])
+    a = sga.RolloutEngine(R, E, **kw)
+    a.upload(packed)
+    b = sga.RolloutEngine(R, E, **kw)
+    b.set_rss(True)
+    b.upload(packed)
+    if nets:
+        a.set_road_networks(nets, net_of)
+        b.set_road_networks(nets, net_of)
+    a.lib.sg_rollout_async(a.h, 0, 1)
+    a.rss_update(reset=True)
+    for _ in range(steps):
+        a.lib.sg_rollout_async(a.h, 1, 0)
+        a.rss_update()
+    b.rollout(steps)
+    assert b.last_launch_stats()[0] == 1  # one launch, not one per step
+    assert np.array_equal(a.state()["n_steps"], b.state()["n_steps"])
+    if scene == "roads":
+        assert len(set(a.state()["n_steps"])) > 2  # egos did leave the road at different times
+    ra, rb = a.rss(), b.rss()
+    for x, y in zip(ra, rb):
+        assert np.array_equal(x, y, equal_nan=True)
+    assert (ra[2] > 0).any()
+    a.close()
+    b.close()
+
+
 @pytest.mark.parametrize("E,ego", [(64, "pid"), (9, "replay"), (130, "pid")])
 def test_rss_line_test_queues_across_launches(sga, monkeypatch, E, ego):
     """The line tests of rollout_kernel_rss are queued per wavefront and evaluated by rss_lines_kernel after each launch; the
