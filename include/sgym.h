@@ -221,6 +221,13 @@ int sg_destroy(sg_handle *h);
  * (entity/batch.py:83-109), then resets (sg_reset). */
 int sg_upload(sg_handle *h, const sg_scenarios *sc);
 
+/* Page-locked host memory for the arrays handed to sg_upload (the knots above all: 1.6 GB for 4096 x 64 x 128).  The copy
+ * engine reads such memory directly at the PCIe rate; from ordinary (pageable) memory the runtime first copies every piece
+ * into a staging buffer on a CPU core, beside the host threads of sg_upload.  Ordinary memory keeps working.  No reference
+ * counterpart (the reference never leaves the host).  device: the GPU the memory is registered with. */
+int sg_host_alloc(int32_t device, uint64_t bytes, void **out);
+int sg_host_free(void *p);
+
 /* SocialForce(params) shared by every pedestrian agent of the handle; call before sg_upload (defaults otherwise) */
 int sg_set_social_force(sg_handle *h, const sg_social_force *params);
 

@@ -5,6 +5,8 @@ There is no CPU fallback: if the HIP library is missing or cannot be loaded this
 import ctypes as C
 import os
 
+import numpy as np
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SGYM_LIB") or os.path.join(HERE, "lib", "libsgym_hip.so")  # SGYM_LIB: A/B builds
 
@@ -29,7 +31,7 @@ SYMBOLS = (
     "sg_last_launch_stats", "sg_debug_trig32", "sg_set_tuning", "sg_set_slicing", "sg_set_external_poses", "sg_future_collision", "sg_raster_entities",
     "sg_set_road_networks", "sg_raster_map", "sg_raster_map_device", "sg_reset_scenarios", "sg_terminal_flags", "sg_tick", "sg_set_collision_tolerance", "sg_read_collision_points", "sg_rss_update", "sg_rss_read", "sg_set_rss",
     "sg_group_create", "sg_group_destroy", "sg_group_size", "sg_group_handle", "sg_group_upload", "sg_group_rollout",
-    "sg_group_read_metrics", "sg_group_last_error",
+    "sg_group_read_metrics", "sg_group_last_error", "sg_host_alloc", "sg_host_free",
 )
 
 
@@ -93,6 +95,23 @@ def source_sha16() -> str:
     return h.hexdigest()[:16]
 
 
+def pinned_empty(shape, dtype=np.float64, device=0):
+    """An uninitialised numpy array in page-locked host memory (sg_host_alloc): the copy engine reads it directly at the PCIe
+    rate, where ordinary memory goes through the runtime's staging copies.  Freed when the array (and its views) are gone."""
+    import weakref
+
+    lib = load()
+    dtype = np.dtype(dtype)
+    n = int(np.prod(shape))
+    ptr = C.c_void_p()
+    rc = lib.sg_host_alloc(int(device), max(n * dtype.itemsize, 1), C.byref(ptr))
+    if rc != 0:
+        raise RuntimeError(f"sg_host_alloc({n * dtype.itemsize} bytes) failed: {rc}")
+    buf = (C.c_char * max(n * dtype.itemsize, 1)).from_address(ptr.value)
+    weakref.finalize(buf, lib.sg_host_free, ptr.value)  # the array below keeps `buf` alive through .base
+    return np.frombuffer(buf, dtype=dtype, count=n).reshape(shape)
+
+
 def load():
     """Load libsgym_hip.so and declare its prototypes.  Raises if it is not there."""
     global _lib
@@ -133,6 +152,8 @@ def load():
     lib.sg_last_launch_stats.argtypes = [H, C.POINTER(C.c_int32), C.POINTER(C.c_float)]
     lib.sg_set_tuning.argtypes = [H, C.c_int32, C.c_int32, C.c_int32]
     lib.sg_set_slicing.argtypes = [H, C.c_int32]
+    lib.sg_host_alloc.argtypes = [C.c_int32, C.c_uint64, C.POINTER(C.c_void_p)]
+    lib.sg_host_free.argtypes = [C.c_void_p]
     lib.sg_set_external_poses.argtypes = [H, C.c_void_p]
     lib.sg_future_collision.argtypes = [H, C.c_double, C.c_int32, C.c_void_p]
     lib.sg_raster_entities.argtypes = [H, C.c_double, C.c_double, C.c_int32, C.c_int32, C.c_void_p]

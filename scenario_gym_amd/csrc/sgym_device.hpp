@@ -2039,12 +2039,12 @@ __device__ __forceinline__ void tile_collisions(bool present, const double *pose
 // BatchReplayEntity.add_entities stage 1 (entity/batch.py:83-109): resample every batch-replay
 // trajectory onto its scenario's union grid.  One thread per (grid row, entity slot).
 // ------------------------------------------------------------------------------------------------
-__global__ void build_grid_kernel(Params p, const int32_t *row_scen /*[totalN]*/, int64_t total_rows)
+__global__ void build_grid_kernel(Params p, const int32_t *row_scen /*[totalN]*/, int64_t row0, int64_t row_end)
 {
     int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    int64_t row = gid / p.EP;
-    int e = (int)(gid - row * p.EP);
-    if (row >= total_rows) return;
+    int64_t row = row0 + gid / p.EP; // grid rows [row0, row_end): sg_upload launches one range per chunk of the knot copy
+    int e = (int)(gid % p.EP);
+    if (row >= row_end) return;
     int r = row_scen[row];
     uint32_t idx = (uint32_t)r * p.EP + e;
     const LanePtr st(p.stat + (size_t)(idx >> 6) * ST_COUNT * 64, (idx & 63) * 8u);

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -61,6 +62,12 @@ struct sg_handle {
     Params p{};
     ReusePool static_allocs, state_allocs;
     int32_t *d_row_scen = nullptr;
+    std::vector<hipEvent_t> up_ev;  // sg_upload: one event per piece of the knot copy
+    std::vector<double> up_grid_t;  // host buffers of sg_upload, kept between calls
+    double *up_stat = nullptr;      // (page-locked)
+    size_t up_stat_cap = 0;
+    std::vector<int32_t> up_row_scen;
+    std::vector<std::vector<double>> up_grids;
     int64_t total_rows = 0;
     double *d_actions = nullptr;
     size_t actions_cap = 0;
@@ -306,6 +313,8 @@ extern "C" int sg_destroy(sg_handle *h)
     for (int b = 0; b < 2; ++b)
         if (h->d_tab[b]) (void)hipFree(h->d_tab[b]);
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
+    for (hipEvent_t e : h->up_ev) (void)hipEventDestroy(e);
+    if (h->up_stat) (void)hipHostFree(h->up_stat);
     if (h->ctl_stream) (void)hipStreamDestroy(h->ctl_stream);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -665,6 +674,7 @@ extern "C" int sg_upload(sg_handle *h, const sg_scenarios *sc)
     if (!h || !sc) return SG_ERR_INVALID;
     if (!sc->kind || !sc->etype || !sc->bbox || !sc->knot_off || !sc->knots || !sc->ego || !sc->t0 || !sc->length)
         return fail(h, SG_ERR_INVALID, "sg_upload: null array in sg_scenarios");
+    const auto t_entry = std::chrono::steady_clock::now();
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->ctl_stream));
@@ -696,7 +706,7 @@ extern "C" int sg_upload(sg_handle *h, const sg_scenarios *sc)
     const int R = h->R, E = h->E, EP = h->EP;
     const size_t NE = h->NE;
     const bool trace = env_int("SG_TRACE_UPLOAD", 0) != 0; // stage timings on stderr
-    auto t_last = std::chrono::steady_clock::now();
+    auto t_last = t_entry;
     auto stage = [&](const char *name) {
         if (!trace) return;
         auto now = std::chrono::steady_clock::now();
@@ -704,6 +714,7 @@ extern "C" int sg_upload(sg_handle *h, const sg_scenarios *sc)
         t_last = now;
     };
 
+    stage("entry (syncs, pools, kinds)");
     // ---- the knots (by far the largest array: 1.6 GB for 4096 x 64 x 128) start crossing PCIe NOW, from a thread of their
     // own on the second stream, while the host validates the batch and builds the union grids below.  Their extent comes
     // from knot_off, which is checked first (a bad offset must not turn into an out-of-bounds read of the copy).
@@ -718,21 +729,54 @@ extern "C" int sg_upload(sg_handle *h, const sg_scenarios *sc)
         int rc0 = dev_alloc(h, h->static_allocs, &d_knots, (size_t)std::max<int64_t>(rows_total, 1) * 7, false);
         if (rc0) return rc0;
     }
+    // The copy goes in UP_CHUNKS pieces on scenario boundaries, an event after each: the stage-1 resample of a piece's
+    // scenarios (build_grid_kernel, at the end of this function) runs while the later pieces are still crossing.
+    // Ordinary (pageable) host memory goes in one piece: the runtime stages it through its own buffers, and several large
+    // copies in flight from such memory disturbed the host threads below (every other upload took 60 ms instead of 34).
+    constexpr int UP_MAX = 4;
+    int UP_CHUNKS = 1;
+    {
+        hipPointerAttribute_t attr{};
+        if (hipPointerGetAttributes(&attr, sc->knots) == hipSuccess && attr.type == hipMemoryTypeHost) UP_CHUNKS = UP_MAX;
+        (void)hipGetLastError(); // (an unregistered pointer is reported as an error by some runtimes)
+    }
+    while (h->up_ev.size() < (size_t)UP_CHUNKS) {
+        hipEvent_t e;
+        HIP_TRY(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        h->up_ev.push_back(e);
+    }
+    int chunk_r[UP_MAX + 1];
+    for (int c = 0; c <= UP_CHUNKS; ++c) chunk_r[c] = (int)((int64_t)R * c / UP_CHUNKS);
     hipError_t copy_err = hipSuccess;
+    std::atomic<int> issued{0};
     std::thread copier([&]() {
-        if (rows_total <= 0) return;
-        copy_err = hipSetDevice(h->cfg.device);
-        if (copy_err == hipSuccess)
-            copy_err = hipMemcpyAsync(d_knots, sc->knots, (size_t)rows_total * 7 * sizeof(double), hipMemcpyHostToDevice, h->ctl_stream);
-        if (copy_err == hipSuccess) copy_err = hipStreamSynchronize(h->ctl_stream);
+        if (rows_total > 0) copy_err = hipSetDevice(h->cfg.device);
+        for (int c = 0; c < UP_CHUNKS && rows_total > 0 && copy_err == hipSuccess; ++c) {
+            const int64_t a = sc->knot_off[(size_t)chunk_r[c] * E], b = sc->knot_off[(size_t)chunk_r[c + 1] * E];
+            if (b > a)
+                copy_err = hipMemcpyAsync(d_knots + a * 7, sc->knots + a * 7, (size_t)(b - a) * 7 * sizeof(double), hipMemcpyHostToDevice, h->ctl_stream);
+            if (copy_err == hipSuccess) copy_err = hipEventRecord(h->up_ev[c], h->ctl_stream);
+            issued.store(c + 1, std::memory_order_release);
+        }
+        issued.store(UP_CHUNKS, std::memory_order_release); // (also after an error: nobody waits for a piece that will not come)
+        if (rows_total > 0 && copy_err == hipSuccess) copy_err = hipStreamSynchronize(h->ctl_stream);
     });
     struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } copier_guard{copier}; // every return path waits
 
     // ---- validate + block re-layout + union knot grids (host, one parallel pass over the scenarios) ----
     const size_t nblk = NE / 64;
     const size_t stat_n = nblk * sg::ST_COUNT * 64;
-    std::unique_ptr<double[]> stat_buf(new double[stat_n]); // (48 MB for 4096 x 64: every slot is written by the pass below)
-    double *stat = stat_buf.get();
+    // (48 MB for 4096 x 64: every slot is written by the pass below.  This and the other host buffers of an upload belong to
+    // the handle: mapping, faulting in and unmapping them anew took 6 ms of every call)
+    // It is page-locked: the copy engine takes it from where the pass wrote it.
+    if (h->up_stat_cap < stat_n) {
+        if (h->up_stat) HIP_TRY(h, hipHostFree(h->up_stat));
+        h->up_stat = nullptr;
+        h->up_stat_cap = 0;
+        HIP_TRY(h, hipHostMalloc((void **)&h->up_stat, stat_n * sizeof(double), hipHostMallocDefault));
+        h->up_stat_cap = stat_n;
+    }
+    double *stat = h->up_stat;
     auto S = [&](size_t ent, int f) -> double & { return stat[(ent >> 6) * sg::ST_COUNT * 64 + (size_t)f * 64 + (ent & 63)]; };
     auto SI = [&](size_t ent, int f) -> int64_t & { return *reinterpret_cast<int64_t *>(&S(ent, f)); };
     auto slot_defaults = [&](size_t o) { // a padding slot: never present
@@ -746,7 +790,9 @@ extern "C" int sg_upload(sg_handle *h, const sg_scenarios *sc)
     std::vector<int32_t> ctl_ent; // controlled lanes (PID / vehicle agents) in entity order
     int n_ext = 0;
     std::vector<sg::ScenStatic> sstat(R);
-    std::vector<std::vector<double>> grids(R); // BatchReplayEntity union knot grid per scenario (entity/batch.py:83-95)
+    std::vector<std::vector<double>> &grids = h->up_grids; // BatchReplayEntity union knot grid per scenario (entity/batch.py:83-95)
+    grids.resize(R);
+    for (auto &g : grids) g.clear(); // (capacity stays)
     {   // scenarios are validated, re-laid out and given their union grid in parallel (the strictly-increasing check walks
         // every knot: 33 M for the 4096 x 64 x 128 batch; the grid sorts them); the first error by scenario index is reported
         const unsigned nthr = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
@@ -839,8 +885,10 @@ extern "C" int sg_upload(sg_handle *h, const sg_scenarios *sc)
         grid_off[r + 1] = grid_off[r] + sstat[r].grid_n;
     }
     const int64_t total_rows = grid_off[R];
-    std::vector<double> grid_t((size_t)total_rows);
-    std::vector<int32_t> row_scen((size_t)total_rows);
+    std::vector<double> &grid_t = h->up_grid_t;
+    std::vector<int32_t> &row_scen = h->up_row_scen;
+    grid_t.resize((size_t)total_rows);
+    row_scen.resize((size_t)total_rows);
     for (int r = 0; r < R; ++r) {
         std::copy(grids[r].begin(), grids[r].end(), grid_t.begin() + grid_off[r]);
         std::fill(row_scen.begin() + grid_off[r], row_scen.begin() + grid_off[r + 1], r);
@@ -929,18 +977,20 @@ extern "C" int sg_upload(sg_handle *h, const sg_scenarios *sc)
 #ifdef SG_PHASE_TIMERS
     if ((rc = dev_alloc(h, M, &p.phase_cycles, 16 + 4096))) return rc;
 #endif
-    copier.join();
-    if (copy_err != hipSuccess) return fail(h, SG_ERR_HIP, "sg_upload: copying the knots failed: %s", hipGetErrorString(copy_err));
-    if (trace) { (void)hipStreamSynchronize(h->stream); stage("allocations + copies (knots: since the start)"); }
-    // stage-1 resample on device
-    if (total_rows > 0) {
-        int64_t threads = total_rows * EP;
-        dim3 block(256), grid((unsigned)((threads + 255) / 256));
-        sg::build_grid_kernel<<<grid, block, 0, h->stream>>>(p, h->d_row_scen, total_rows);
+    // stage-1 resample on the device, piece by piece behind the knot copy
+    for (int c = 0; c < UP_CHUNKS; ++c) {
+        while (issued.load(std::memory_order_acquire) <= c) std::this_thread::yield();
+        const int64_t row0 = grid_off[chunk_r[c]], row1 = grid_off[chunk_r[c + 1]];
+        if (rows_total <= 0 || row1 <= row0) continue;
+        HIP_TRY(h, hipStreamWaitEvent(h->stream, h->up_ev[c], 0));
+        const int64_t threads = (row1 - row0) * EP;
+        sg::build_grid_kernel<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, h->stream>>>(p, h->d_row_scen, row0, row1);
         HIP_TRY(h, hipGetLastError());
     }
+    copier.join();
+    if (copy_err != hipSuccess) return fail(h, SG_ERR_HIP, "sg_upload: copying the knots failed: %s", hipGetErrorString(copy_err));
     HIP_TRY(h, hipStreamSynchronize(h->stream)); // host vectors go out of scope
-    stage("stage-1 resample");
+    stage("knot copy (since the start) + stage-1 resample");
     h->uploaded = true;
     int rc_reset = sg_reset(h);
     stage("reset");
@@ -1381,6 +1431,20 @@ extern "C" int sg_debug_trig32(sg_handle *h, int64_t n, const double *heading, f
     (void)hipFree(d_h); (void)hipFree(d_s); (void)hipFree(d_c);
     if (rc) return fail(h, rc, "sg_debug_trig32: HIP copy/launch failed");
     return SG_OK;
+}
+
+extern "C" int sg_host_alloc(int32_t device, uint64_t bytes, void **out)
+{
+    if (!out || bytes == 0) return SG_ERR_INVALID;
+    *out = nullptr;
+    if (hipSetDevice(device) != hipSuccess) return SG_ERR_HIP;
+    return hipHostMalloc(out, (size_t)bytes, hipHostMallocDefault) == hipSuccess ? SG_OK : SG_ERR_HIP;
+}
+
+extern "C" int sg_host_free(void *p)
+{
+    if (!p) return SG_OK;
+    return hipHostFree(p) == hipSuccess ? SG_OK : SG_ERR_HIP;
 }
 
 extern "C" int sg_set_slicing(sg_handle *h, int32_t mode)

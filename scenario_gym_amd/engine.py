@@ -50,6 +50,14 @@ class PackedScenarios:
         assert self.route_off is None or (self.route_off.shape == (R * E + 1,) and self.routes.shape[1] == 2)
         return self
 
+    def pin(self, device=0):
+        """Move the knots -- nearly all of the bytes of a batch -- into page-locked host memory (sg_host_alloc), in place:
+        sg_upload then copies them at the PCIe rate without a staging copy on the host."""
+        pinned = L.pinned_empty(self.knots.shape, np.float64, device)
+        pinned[...] = self.knots
+        self.knots = pinned
+        return self
+
     def shard(self, lo, hi):
         """Scenarios [lo, hi) as an independent batch (replica sharding across GPUs)."""
         E = self.n_entities

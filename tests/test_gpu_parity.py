@@ -1145,6 +1145,42 @@ def test_crowd_kernel_equals_general_pedestrian_kernel(sga, monkeypatch, E, side
     assert np.array_equal(sa["coll"], sb["coll"])
 
 
+def test_upload_from_page_locked_memory(sga):
+    """PackedScenarios.pin() moves the knots into sg_host_alloc memory: sg_upload then sends them in pieces with the stage-1
+    resample of each piece behind its copy -- the same device state as the upload from ordinary memory, and the array is
+    released with its last view."""
+    import gc
+
+    import scenario_gym_amd._lib as L
+    from scenario_gym_amd import synthetic
+
+    R, E, steps = 37, 20, 60  # (37 scenarios: the pieces of the copy are not equal)
+    packed = synthetic.make_batch(R, E, n_steps=steps, ego_kind=L.KIND_AGENT_PID, extent=15.0, vanish_frac=0.3)
+    out = []
+    for pinned in (False, True):
+        if pinned:
+            before = packed.knots.copy()
+            packed.pin()
+            assert np.array_equal(before, packed.knots) and not packed.knots.flags.owndata
+        eng = sga.RolloutEngine(R, E, event_capacity=64)
+        eng.upload(packed)
+        s0 = eng.state()
+        eng.rollout(steps)
+        out.append((s0, eng.state(), eng.metrics()))
+        eng.close()
+    for k in ("poses", "vels", "dists"):
+        assert bits_equal(out[0][0][k], out[1][0][k]) and bits_equal(out[0][1][k], out[1][1][k]), k
+    assert np.array_equal(out[0][2][0], out[1][2][0]) and np.array_equal(out[0][2][1], out[1][2][1])
+    a = L.pinned_empty((1000, 7))
+    a[:] = 1.0
+    v = a[10:20]
+    del a
+    gc.collect()
+    assert v.sum() == 70.0  # the view keeps the allocation alive
+    del v
+    gc.collect()
+
+
 # ---------------------------------------------------------------- road surfaces
 ROAD_BITS =dict(driveable_surface=1, road=2, intersection=4, lane=8, walkable_surface=16, pavement=32, crossing=64)
 

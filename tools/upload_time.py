@@ -17,15 +17,20 @@ t = time.perf_counter()
 packed = synthetic.make_batch(R, E, ego_kind=sga._lib.KIND_AGENT_PID)
 print(f"generate {time.perf_counter() - t:.2f} s, knots {packed.knots.nbytes / 1e9:.2f} GB")
 eng = sga.RolloutEngine(R, E)
-times = []
-for i in range(8):
-    t = time.perf_counter()
-    eng.upload(packed)
-    times.append(time.perf_counter() - t)
-print("upload ms:", " ".join(f"{x * 1e3:.0f}" for x in times))
-steady = times[2:]
-print(f"sg_upload of {R} x {E} x 128 knots: median {statistics.median(steady) * 1e3:.1f} ms, min {min(steady) * 1e3:.1f} ms "
-      f"= {packed.knots.nbytes / min(steady) / 1e9:.1f} GB/s of knot data")
+for where in ("pageable", "page-locked"):
+    if where == "page-locked":
+        t = time.perf_counter()
+        packed.pin()  # the knots move into sg_host_alloc memory, once
+        print(f"PackedScenarios.pin(): {time.perf_counter() - t:.2f} s")
+    times = []
+    for i in range(8):
+        t = time.perf_counter()
+        eng.upload(packed)
+        times.append(time.perf_counter() - t)
+    print(f"upload ms ({where} knots):", " ".join(f"{x * 1e3:.0f}" for x in times))
+    steady = times[2:]
+    print(f"sg_upload of {R} x {E} x 128 knots, {where} host memory: median {statistics.median(steady) * 1e3:.1f} ms, "
+          f"min {min(steady) * 1e3:.1f} ms = {packed.knots.nbytes / min(steady) / 1e9:.1f} GB/s of knot data")
 t = time.perf_counter()
 eng.rollout(T)
 one = time.perf_counter() - t
