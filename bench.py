@@ -33,6 +33,9 @@ WORKLOADS = {
     "c2s": dict(R=256, E=16, b_alg=16.0, stored=8.0, config=1, sliced=True),
     "c3": dict(R=4096, E=64, b_alg=114.0, stored=72.0, config=2),
     "c5": dict(R=1024, E=256, b_alg=154.0, stored=112.0, config=4),
+    # the c3 batch with the RSSDistances state callback (metrics/rss/callback.py:58-128) after the reset and after every step,
+    # inside the rollout kernel: + one record per entity-step (code 4 B, safe lateral / longitudinal distance 16 B)
+    "c3rss": dict(R=4096, E=64, b_alg=134.0, stored=72.0, config=2, rss=True),
 }
 
 
@@ -49,9 +52,13 @@ def cpu_baseline(workload, seconds_budget=20.0):
     O.lib()
     cores = os.cpu_count() or 1
     E, T = workload["E"], workload["T"]
+    rss = bool(workload.get("rss"))
     if workload.get("crowd"):
         t_sample, n_scen = min(T, 1000), max(cores, 1)
         packed = synthetic.make_crowd(n_scen, E, n_steps=t_sample)
+    elif rss:  # (the oracle's callback runs over the recorded poses of its rollout)
+        t_sample, n_scen = min(T, 500), max(cores, 1)
+        packed = synthetic.make_batch(n_scen, E, n_steps=t_sample, ego_kind=workload["ego_kind"])
     else:
         t_sample, n_scen = T, max(cores, 1) * 4
         packed = synthetic.make_batch(n_scen, E, n_steps=t_sample, ego_kind=workload["ego_kind"])
@@ -59,8 +66,10 @@ def cpu_baseline(workload, seconds_budget=20.0):
 
     def one(s):
         o = O.rollout(s["knot_off"], s["knots"], s["bbox"], s["etype"], s["kind"], s["ego"], s["t0"],
-                      s["length"], workload["dt"], ctrl=s["ctrl"], max_steps=t_sample, record=False,
+                      s["length"], workload["dt"], ctrl=s["ctrl"], max_steps=t_sample, record=rss,
                       route_off=s.get("route_off"), routes=s.get("routes"))
+        if rss:
+            O.rss_rollout(o, s["bbox"], s["ego"])
         return o["n_steps"]
 
     one(scen[0])  # warm
@@ -86,10 +95,12 @@ def cpu_baseline(workload, seconds_budget=20.0):
     return out
 
 
-def kernel_name(E, crowd, controlled):
+def kernel_name(E, crowd, controlled, rss=False):
     """Entry point the library launches for this shape (sgym_hip.hip launch_variant): tile lanes G, wavefronts per tile;
     `controlled`: the batch has PID / vehicle agents (their pre-pass table is replayed by rollout_kernel_tab)."""
     G, WV = min(64, max(4, 1 << (E - 1).bit_length())), (1 if E <= 64 else 2 if E <= 128 else 4)
+    if rss:
+        return f"sg::rollout_kernel_rss<{G}, {WV}>"
     if crowd:
         return f"sg::rollout_kernel_crowd<{WV}>" if G == 64 else f"sg::rollout_kernel<{max(G, 16)}, {WV}, true, false>"
     return f"sg::rollout_kernel_tab<{G}>" if (WV == 1 and controlled) else f"sg::rollout_kernel<{G}, {WV}, false, true>"
@@ -165,10 +176,11 @@ def main(argv=None, make_engine=None):
     ap.add_argument("--entities", type=int, default=None)
     ap.add_argument("--sim-steps", type=int, default=10000)
     ap.add_argument("--ego", default="pid", choices=["pid", "replay"])
-    ap.add_argument("--workload", default="c3", choices=["c3", "c2", "c2s", "c5"],
+    ap.add_argument("--workload", default="c3", choices=["c3", "c2", "c2s", "c5", "c3rss"],
                     help="BASELINE.json configs: c3 = 4096x64 PID ego (default, the headline), c2 = 256x16 replay (state of "
                          "every step materialised), c5 = 1024x256 social-force crowd; c2s = the c2 batch through the "
-                         "time-sliced replay path (final state + metrics + events only: a separate mode, never the headline)")
+                         "time-sliced replay path (final state + metrics + events only: a separate mode, never the headline); c3rss = the c3 "
+                         "batch with the RSSDistances callback after every step")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="what `value` is: weak (default) = --scenarios per GPU; strong = --scenarios in total, split evenly "
                          "over the ranks (BASELINE.json configs[3] read literally: 4096 replicas over 8 GPUs = 512 per GPU)."
@@ -223,6 +235,8 @@ def main(argv=None, make_engine=None):
             eng = sga.RolloutEngine(R, E, timestep=dt, terminal_conditions=["max_length"], event_capacity=64,
                                     device=local_rank, **kw)
             eng.set_slicing(bool(wl.get("sliced")))  # every other workload materialises the state of every step
+            if wl.get("rss"):
+                eng.set_rss(True)
             eng.upload(packed)
             return eng
     else:  # tests drive the dispatch / timing / collection code with a stand-in engine on CPU
@@ -320,6 +334,9 @@ def main(argv=None, make_engine=None):
                              f"{'PIDAgent' if ego_kind == L.KIND_AGENT_PID else 'ReplayTrajectoryAgent'} ego + batch replay "
                              "others, all-pairs OBB collisions, CollisionMetric + EgoAvgSpeed/MaxSpeed/DistanceTravelled, "
                              f"terminal max_length (BASELINE.json configs[{wl['config']}])"
+                             + ("; + RSSDistances state callback (metrics/rss/callback.py:58-128) after the reset and after "
+                                "every step, inside the rollout kernel (rss_lines_kernel finishes the line tests after each "
+                                "launch, inside the timed launches)" if wl.get("rss") else "")
                              + ("; TIME-SLICED replay path: final state + metrics + events, bit-identical to the step-by-step "
                                 "kernel, the states of the intermediate steps are not written to memory" if wl.get("sliced") else "")),
                 "scenarios_per_gpu": R, "entities": E, "sim_steps": T, "timestep": dt,
@@ -335,7 +352,7 @@ def main(argv=None, make_engine=None):
                 "stored_bytes_per_entity_step": wl["stored"],
                 "secondary": secondary,
                 "kernel": (f"sg::rollout_kernel_slice<{min(64, max(4, 1 << (E - 1).bit_length()))}>" if wl.get("sliced") else
-                           kernel_name(E, crowd, ego_kind == L.KIND_AGENT_PID)),
+                           kernel_name(E, crowd, ego_kind == L.KIND_AGENT_PID, bool(wl.get("rss")))),
                 "kernel_ms": avg_ms, "launches_per_rollout": launches_per_rollout, "rollout_device_ms": rollout_ms,
                 "bytes_per_entity_step": b_alg, "entity_steps_per_launch": per_launch,
                 "src_sha16": L.source_sha16(),
@@ -346,7 +363,7 @@ def main(argv=None, make_engine=None):
             line[name] = {"value": o["total"] / o["elapsed"], "ms_per_step": o["elapsed"] / args.steps * 1e3,
                           "scenarios_per_gpu": o["R"], "per_rank_value": o["per_rank"]}
         if live and world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(dict(E=E, T=T, dt=dt, ego_kind=ego_kind, crowd=crowd))
+            line["cpu_baseline"] = cpu_baseline(dict(E=E, T=T, dt=dt, ego_kind=ego_kind, crowd=crowd, rss=bool(wl.get("rss"))))
         print(json.dumps(line))
     if dist is not None and live:
         dist.destroy_process_group()

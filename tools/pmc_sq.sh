@@ -25,7 +25,7 @@ out = {k[1]: round(v / ws, 1) for k, v in agg.items() if k[0] == "rollout"}
 ctl = {k[1]: round(v / T, 1) for k, v in agg.items() if k[0] == "control"}
 txt = "rollout_kernel per wave-step (%d waves x %d steps; *_CYCLES / ACTIVE / WAIT in quad-cycles): %s\ncontrol_kernel per step, all waves: %s\n" % (waves, T, out, ctl)
 open(f"gpurun_out/{tag}_pmc_sq.txt", "w").write(txt)
-wl = "c5" if E == 256 else (("c2s" if "TIME-SLICED" in cfg["workload"] else "c2") if E == 16 else "c3")
+wl = "c5" if E == 256 else (("c2s" if "TIME-SLICED" in cfg["workload"] else "c2") if E == 16 else ("c3rss" if "RSSDistances" in cfg["workload"] else "c3"))
 rec = dict(scenarios=cfg["scenarios_per_gpu"], entities=E, sim_steps=T, src_sha16=line["roofline"]["src_sha16"],
            kernel=line["roofline"]["kernel"], waves=waves, per_wave_step=out, control_kernel_per_step=ctl,
            note="rocprofv3 --pmc (SQ counters only) over one rollout of the workload, summed over the rollout-kernel dispatches and "

@@ -26,7 +26,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     f = glob.glob(f"gpurun_out/{tag}_pmc_{c}/**/*counter_collection.csv", recursive=True)
     out[c] = sum(float(r["Counter_Value"]) for r in csv.DictReader(open(f[0]))
                  if "rollout_kernel" in r["Kernel_Name"] and r["Counter_Name"] == c)
-wl = "c5" if cfg["entities"] == 256 else (("c2s" if "TIME-SLICED" in cfg["workload"] else "c2") if cfg["entities"] == 16 else "c3")
+wl = "c5" if cfg["entities"] == 256 else (("c2s" if "TIME-SLICED" in cfg["workload"] else "c2") if cfg["entities"] == 16 else ("c3rss" if "RSSDistances" in cfg["workload"] else "c3"))
 rec = dict(scenarios=cfg["scenarios_per_gpu"], entities=cfg["entities"], sim_steps=cfg["sim_steps"],
            src_sha16=line["roofline"]["src_sha16"], kernel=line["roofline"]["kernel"],
            fetch_size_kb=out["FETCH_SIZE"], write_size_kb=out["WRITE_SIZE"],
