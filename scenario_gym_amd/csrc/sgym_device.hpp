@@ -2154,18 +2154,21 @@ template <bool DEFER = false>
 __device__ inline void rss_entity(double ex, double ey, double ego_heading, double ego_vx, double ego_vy, double ego_w, double ego_l,
                                   double hx, double hy, double hh, double hvx, double hvy, double bw, double bl, double bcx,
                                   double bcy, int32_t &state, int &cd, double &s_lat, double &s_long, int *need = nullptr,
-                                  double *Qd = nullptr, bool *ab = nullptr)
+                                  double *Qd = nullptr, bool *ab = nullptr, const double *trig = nullptr /* DEFER: sin, cos of
+                                  the ego's and of the entity's heading (sg_sincos), computed by the caller */)
 {
         const double RESPONSE_TIME = 0.6, MIN_LONG_ACCEL = 1.2 * 9.81, MAX_LONG_ACCEL = 1.2 * 9.81, MIN_SAFE_CLEARANCE = 0.1;
         double es, ec, ei0, ei1;
-        sg_sincos(ego_heading, es, ec);
+        if (DEFER) { es = trig[0]; ec = trig[1]; }
+        else sg_sincos(ego_heading, es, ec);
         const double eh0 = ec, eh1 = es;
         rss_inv_dir(eh0, eh1, ei0, ei1);
         const double ego_head0 = rss_dot2(eh0, eh1, ei0, ei1), ego_head1 = rss_dot2(eh0, eh1, eh0, eh1);
         const double ego_vel0 = rss_dot2(ego_vx, ego_vy, ei0, ei1), ego_vel1 = rss_dot2(ego_vx, ego_vy, eh0, eh1);
         const double ego_pos1 = rss_dot2(ex - ex, ey - ey, eh0, eh1);
         double hs, hc;
-        sg_sincos(hh, hs, hc);
+        if (DEFER) { hs = trig[2]; hc = trig[3]; }
+        else sg_sincos(hh, hs, hc);
         const double pos0 = rss_dot2(hx - ex, hy - ey, ei0, ei1), pos1 = rss_dot2(hx - ex, hy - ey, eh0, eh1);
         const double head0 = rss_dot2(hc, hs, ei0, ei1), head1 = rss_dot2(hc, hs, eh0, eh1);
         const double vel0 = rss_dot2(hvx, hvy, ei0, ei1), vel1 = rss_dot2(hvx, hvy, eh0, eh1);
@@ -2765,20 +2768,26 @@ __device__ __forceinline__ void rollout_body(
     }
     // one RSSDistances.__call__ for this lane's entity; upd: its scenario is being updated (it was reset / it stepped)
     auto rss_call = [&](bool upd, double tnow, double vx, double vy) {
-        double ex, ey, eh, evx, evy;
+        double ex, ey, eh, evx, evy, trig[4];
         bool ego_pres;
+        // sin / cos of every lane's own heading: the entity's for its own box -- and, in the ego's lane, the ego's, which
+        // every lane of the tile needs: one evaluation instead of two
+        sg_sincos(pose[3], trig[2], trig[3]);
         if (WV == 1) {
             ex = shfl_d(pose[0], tile0); ey = shfl_d(pose[1], tile0); eh = shfl_d(pose[3], tile0);
             evx = shfl_d(vx, tile0); evy = shfl_d(vy, tile0);
+            trig[0] = shfl_d(trig[2], tile0); trig[1] = shfl_d(trig[3], tile0);
             ego_pres = (__ballot(present) >> tile0) & 1;
         } else {
             if (tid == 0) {
                 lds.cor[0][0] = pose[0]; lds.cor[1][0] = pose[1]; lds.cor[2][0] = pose[3];
                 lds.cor[3][0] = vx; lds.cor[4][0] = vy; lds.cor[5][0] = present ? 1.0 : 0.0;
+                lds.cor[6][0] = trig[2]; lds.cor[7][0] = trig[3];
             }
             __syncthreads();
             ex = lds.cor[0][0]; ey = lds.cor[1][0]; eh = lds.cor[2][0]; evx = lds.cor[3][0]; evy = lds.cor[4][0];
             ego_pres = lds.cor[5][0] != 0.0;
+            trig[0] = lds.cor[6][0]; trig[1] = lds.cor[7][0];
             __syncthreads(); // the collision pass of the next step rewrites the scratch
         }
         int need = 0;
@@ -2791,7 +2800,7 @@ __device__ __forceinline__ void rollout_body(
             ++rss_k;
             if (!(tnow == 0.0 || !ego_pres || !present || slot == 0 || slot >= p.E)) // callback.py:76-78
                 rss_entity<true>(ex, ey, eh, evx, evy, rss_ew, rss_el, pose[0], pose[1], pose[3], vx, vy, rss_bw, rss_bl, bcx, bcy,
-                                 rss_st, rss_cd, rss_lat, rss_long, &need, Qd, &ab);
+                                 rss_st, rss_cd, rss_lat, rss_long, &need, Qd, &ab, trig);
         }
         // line tests: queued for rss_lines_kernel (see RssQueue)
 #ifdef SG_ABL_RSS_NO_PUSH
