@@ -3040,7 +3040,11 @@ __device__ __forceinline__ void rollout_body(
 
         // ---- State.update_poses / update_statistics, state.py:203-239 ----
         double d[6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) d[c] = np_[c] - pose[c];
         if (npres && !present) { // newcomer: previous pose from the extrapolated trajectory, state.py:219-222
+            // (the rare case overwrites d: as an if / else the two subtractions were merged behind six copies pose -> prev
+            // that every step paid)
             double prev[6];
             LanePtr st_o = st;
             asm volatile("" : "+v"(st_o.a[0]));
@@ -3048,9 +3052,6 @@ __device__ __forceinline__ void rollout_body(
                                 (int)(fld<int64_t>(st_o, ST_META) >> 32), t, prev);
 #pragma unroll
             for (int c = 0; c < 6; ++c) d[c] = np_[c] - prev[c];
-        } else {
-#pragma unroll
-            for (int c = 0; c < 6; ++c) d[c] = np_[c] - pose[c];
         }
         double vel[6];
         // z, pitch and roll rarely move.  `flat`: in every lane that commits a pose this step they keep their value
@@ -3129,10 +3130,12 @@ __device__ __forceinline__ void rollout_body(
                 stf(dy, SG_F_FORCE + 1, fpy);
             }
             if (p.rec_cap > 0 && steps < p.rec_cap) {
+                int nan_hi = 0x7ff80000;
+                asm volatile("" : "+s"(nan_hi)); // (keeps the six selects inside this block: hoisted, they cost every step 18 moves)
+                const double absent = __hiloint2double(nan_hi, 0);
 #pragma unroll
                 for (int c = 0; c < 6; ++c)
-                    p.rec_pose[((size_t)steps * 6 + c) * p.R * p.EP + (size_t)r * p.EP + slot] =
-                        present ? pose[c] : __builtin_nan("");
+                    p.rec_pose[((size_t)steps * 6 + c) * p.R * p.EP + (size_t)r * p.EP + slot] = present ? pose[c] : absent;
                 if (slot == 0) { p.rec_t[(size_t)steps * p.R + r] = t; sd.rec_rows = steps + 1; }
             }
             // ---- ego metrics, scenario_gym.py:251-252 ----
