@@ -1,0 +1,13 @@
+#!/bin/bash
+# Usage (GPU box): bash tools/profile_all.sh <tag>   -- tools/profile_round.sh for every bench workload (c3 = <tag>_*, the others
+# <tag>_<workload>_*), + the upload and RSS timings.  ~15 minutes.  Copy gpurun_out/<tag>_* and gpurun_out/latest_* into profiles/.
+tag=${1:-rXX}
+bash tools/profile_round.sh ${tag} --steps 5 --warmup 1
+bash tools/profile_round.sh ${tag}_c5 --workload c5 --steps 2 --warmup 1
+bash tools/profile_round.sh ${tag}_c2 --workload c2 --steps 5 --warmup 1
+bash tools/profile_round.sh ${tag}_c2s --workload c2s --steps 5 --warmup 1
+bash tools/profile_round.sh ${tag}_c3rss --workload c3rss --steps 3 --warmup 1
+python3 tools/upload_time.py > gpurun_out/${tag}_upload_time.txt 2>&1
+python3 tools/rss_time.py > gpurun_out/${tag}_rss_time.txt 2>&1
+python3 bench.py --workload c5 --ped-noise device --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/${tag}_c5_noise_bench.json 2>/dev/null
+tail -3 gpurun_out/${tag}_upload_time.txt gpurun_out/${tag}_rss_time.txt
