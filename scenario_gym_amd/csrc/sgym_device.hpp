@@ -302,6 +302,12 @@ __device__ __forceinline__ double sg_pred(double x) // nextafter(x, -inf) for fi
     return -4.9406564584124654e-324;
 }
 
+// Wavefront votes on the builtin: HIP's __any / __all go through device-library functions (__ockl_wfany_i32) that are
+// linked in after the optimiser has run, and every vote on a predicate that already lives in a scalar mask then costs a
+// v_cndmask 0/1 + v_cmp round trip through the vector ALU (40 of them in the step loop of rollout_kernel_tab).
+__device__ __forceinline__ bool sg_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0; }
+__device__ __forceinline__ bool sg_all(bool p) { return __builtin_amdgcn_ballot_w64(!p) == 0; }
+
 __device__ __forceinline__ double shfl_d(double v, int src) { return __shfl(v, src, 64); }
 
 // s_waitcnt vmcnt(0) (expcnt / lgkmcnt untouched).  Placed after every RARE block of global loads whose results
@@ -1100,7 +1106,7 @@ __device__ __forceinline__ void tile_sync()
 template <int WV>
 __device__ __forceinline__ bool block_any(bool x)
 {
-    if (WV == 1) return __any(x);
+    if (WV == 1) return sg_any(x);
     return __syncthreads_or(x);
 }
 
@@ -1111,7 +1117,7 @@ __device__ __forceinline__ bool block_any(bool x)
 template <int WV, typename LDS>
 __device__ __forceinline__ int block_vote(LDS &L, int site, bool b0, bool b1 = false)
 {
-    const int mine = (__any(b0) ? 1 : 0) | (__any(b1) ? 2 : 0);
+    const int mine = (sg_any(b0) ? 1 : 0) | (sg_any(b1) ? 2 : 0);
     if (WV == 1) return mine;
     if ((threadIdx.x & 63) == 0) L.vote[site][threadIdx.x >> 6] = mine;
     __syncthreads();
@@ -1140,7 +1146,7 @@ __device__ __forceinline__ bool ped_pair_eval(const Params &p, const LDS &L, boo
         ped_pair<true, true>(FA, sf, k2_scale, ipx, ipy, hs, hc, ox, oy, ovx, ovy, odx, ody, step, c1x, c1y, c2x, c2y);
     else
         ped_pair<false, false>(FA, sf, k2_scale, ipx, ipy, hs, hc, ox, oy, ovx, ovy, odx, ody, step, c1x, c1y, c2x, c2y);
-    if (__any(FA.bad & act)) { // rare: some operand outside RecipDiv's range, or a sight weight on its threshold
+    if (sg_any(FA.bad & act)) { // rare: some operand outside RecipDiv's range, or a sight weight on its threshold
         if (FA.bad & act) {
             ExactArith EA;
             ped_pair<false, false>(EA, sf, k2_scale, ipx, ipy, hs, hc, ox, oy, ovx, ovy, odx, ody, step, c1x, c1y, c2x, c2y);
@@ -1230,7 +1236,7 @@ __device__ __forceinline__ void ped_pairs_balanced(const Params &p, LDS &L, int 
     int h = min((scan >> 16) - spare, listed_all);        // listed pairs this lane evaluates: [h, h_end)
     const int h_end = min((scan >> 16), listed_all);
     // hand over the LAST `out` neighbours: walk them from the top, write them in entity order
-    for (int q = 0; __any(q < out); ++q) {
+    for (int q = 0; sg_any(q < out); ++q) {
         if (q < out) {
             int j = 0;
 #pragma unroll
@@ -1250,7 +1256,7 @@ __device__ __forceinline__ void ped_pairs_balanced(const Params &p, LDS &L, int 
         for (int w = WV - 1; w >= 0; --w)
             if (m[w]) j = w * 64 + __builtin_ctzll(m[w]);
         const bool own = j >= 0, help = !own & (h < h_end);
-        if (!__any(own | help)) break;
+        if (!sg_any(own | help)) break;
 #pragma unroll
         for (int w = 0; w < WV; ++w)
             if ((j >> 6) == w) m[w] &= m[w] - 1; // j = -1 matches no word
@@ -1271,7 +1277,7 @@ __device__ __forceinline__ void ped_pairs_balanced(const Params &p, LDS &L, int 
         }
     }
     tile_sync<1>();
-    for (int q = 0; __any(q < out); ++q) {
+    for (int q = 0; sg_any(q < out); ++q) {
         if (q < out) {
             const uint32_t ent = list[e0 + q];
             const double2 c1 = res[e0 + q];
@@ -1449,10 +1455,10 @@ __device__ __forceinline__ void crowd_pairs(const Params &p, LDS &L, const Crowd
     const int keep = n - out;
     tile_sync<1>(); // own nq column written above
     // ---- hand over the LAST `out` neighbours: walk the queue from its top, write them in entity order ----
-    if (__any(out > 0)) {
+    if (sg_any(out > 0)) {
         int qe = nw - 1;
         uint32_t curh = L.nq[max(qe, 0)][sl];
-        for (int q = 0; __any(q < out); ++q) {
+        for (int q = 0; sg_any(q < out); ++q) {
             if (q < out) {
                 const int bit = 31 - __builtin_clz(curh);
                 const int j = (int)((idxs >> (3 * qe)) & 7u) * 32 + bit;
@@ -1471,7 +1477,7 @@ __device__ __forceinline__ void crowd_pairs(const Params &p, LDS &L, const Crowd
     int k = 0, qi = 0;
     uint32_t cur = L.nq[0][sl];
     const double own_r2hi = L.r2hi[sl], own_r2lo = L.r2lo[sl];
-    while (__any((k < keep) | (h < h_end))) {
+    while (sg_any((k < keep) | (h < h_end))) {
         bool own[SG_CROWD_ILP], help[SG_CROWD_ILP], act[SG_CROWD_ILP], bad[SG_CROWD_ILP], ring[SG_CROWD_ILP];
         int jj[SG_CROWD_ILP], osl[SG_CROWD_ILP], hi_[SG_CROWD_ILP];
         uint32_t ent[SG_CROWD_ILP];
@@ -1509,7 +1515,7 @@ __device__ __forceinline__ void crowd_pairs(const Params &p, LDS &L, const Crowd
         bool any_ring = false, any_bad = false;
 #pragma unroll
         for (int u = 0; u < SG_CROWD_ILP; ++u) any_ring |= ring[u];
-        if (__any(any_ring)) { // rare: between the inscribed circle and the vertices of the 64-gon Point.buffer(r)
+        if (sg_any(any_ring)) { // rare: between the inscribed circle and the vertices of the 64-gon Point.buffer(r)
 #pragma unroll
             for (int u = 0; u < SG_CROWD_ILP; ++u)
                 if (ring[u])
@@ -1518,7 +1524,7 @@ __device__ __forceinline__ void crowd_pairs(const Params &p, LDS &L, const Crowd
         }
 #pragma unroll
         for (int u = 0; u < SG_CROWD_ILP; ++u) any_bad |= bad[u] & act[u];
-        if (__any(any_bad)) { // rare: an operand outside crowd_pair's range, or a sight weight on its threshold
+        if (sg_any(any_bad)) { // rare: an operand outside crowd_pair's range, or a sight weight on its threshold
 #pragma unroll
             for (int u = 0; u < SG_CROWD_ILP; ++u)
                 if (bad[u] & act[u]) {
@@ -1543,7 +1549,7 @@ __device__ __forceinline__ void crowd_pairs(const Params &p, LDS &L, const Crowd
     }
     (void)own_r2hi; (void)own_r2lo; (void)ipx; (void)ipy;
     tile_sync<1>();
-    for (int q = 0; __any(q < out); ++q) {
+    for (int q = 0; sg_any(q < out); ++q) {
         if (q < out) {
             const uint32_t e = list[e0 + q];
             const double2 c1 = res[e0 + q];
@@ -1603,7 +1609,7 @@ __device__ __forceinline__ void ped_force(const Params &p, LDS &L, int r, int sl
         if (go) sg_sincos(L.ctrl[SG_C_PED_HEAD_ROT - SG_C_PED_SPEED_DESIRED][sl], hs, hc, K);
     }
     // the shortcuts of ped_pair need the sight-weight branch (c2 = w2 * att) and hold for the whole wavefront
-    const bool plain = __all(hs == 0.0 && hc == 1.0) && sf.ped_attract_C == 0.0 && sf.sight_weight > 0.0 &&
+    const bool plain = sg_all(hs == 0.0 && hc == 1.0) && sf.ped_attract_C == 0.0 && sf.sight_weight > 0.0 &&
                        sf.sight_weight_use != 0.0;
 #ifdef SG_ABL_NO_PAIRS
     return;
@@ -1735,7 +1741,7 @@ __device__ __forceinline__ void tile_collisions(bool present, const double *pose
     PH(2);
     bool odd;
     if (WV == 1 && !PED) {
-        odd = __any(far_out);
+        odd = sg_any(far_out);
     } else {
         const int voted = block_vote<WV>(L, 0, far_out | insane, PED && dense);
         odd = voted & 1;
@@ -1778,7 +1784,7 @@ __device__ __forceinline__ void tile_collisions(bool present, const double *pose
 #pragma unroll
         for (int w = 0; w < WV; ++w) {
             close[w] = 0;
-            while (__any(cand[w] != 0)) {
+            while (sg_any(cand[w] != 0)) {
                 ++iters;
                 if (cand[w]) {
                     const int jl = __builtin_ctzll(cand[w]);
@@ -1932,10 +1938,10 @@ __device__ __forceinline__ void tile_collisions(bool present, const double *pose
 #pragma unroll
     for (int w = 0; w < WV; ++w) fuzzy[w] = 0;
     bool any_fuzzy = false;
-    if (__any(any_cand)) {
+    if (sg_any(any_cand)) {
 #pragma unroll
         for (int w = 0; w < WV; ++w) {
-            while (__any(cand[w] != 0)) {
+            while (sg_any(cand[w] != 0)) {
                 if (cand[w]) {
                     const int jl = __builtin_ctzll(cand[w]);
                     cand[w] &= cand[w] - 1;
@@ -1986,7 +1992,7 @@ __device__ __forceinline__ void tile_collisions(bool present, const double *pose
 #pragma unroll
     for (int w = 0; w < WV; ++w) {
         eq[w] = 0;
-        while (__any(fuzzy[w] != 0)) {
+        while (sg_any(fuzzy[w] != 0)) {
             // every lane takes part in the cross-lane reads; idle lanes read their own corners
             const bool act = fuzzy[w] != 0;
             const int jl = act ? __builtin_ctzll(fuzzy[w]) : (slot & 63);
@@ -2528,7 +2534,7 @@ __device__ __forceinline__ void rollout_body(
     CrowdConsts CC{};
     if (CROWD) {
         const double rr = fld(st, ST_CTRL + SG_C_PED_RADIUS), hr = fld(st, ST_CTRL + SG_C_PED_HEAD_ROT);
-        crowd_static_ok = __all(kind != SG_KIND_AGENT_PEDESTRIAN || (hr == 0.0 && rr > 0.0 && rr < 0x1p20)) &&
+        crowd_static_ok = sg_all(kind != SG_KIND_AGENT_PEDESTRIAN || (hr == 0.0 && rr > 0.0 && rr < 0x1p20)) &&
                           crowd_params_ok(p.sf) && !p.ped_serial;
         const RecipDiv rs(p.sf.ped_repulse_sigma);
         CC.k2_scale = p.sf.ped_repulse_V / p.sf.ped_repulse_sigma;
@@ -2866,14 +2872,14 @@ __device__ __forceinline__ void rollout_body(
     }
     for (; k < n_steps; ++k) {
         // per wavefront and before any workgroup barrier of the step: does a lane need its next segment?
-        if (!CROWD && __any(t + timestep > S.x_hi)) break;
+        if (!CROWD && sg_any(t + timestep > S.x_hi)) break;
         // SLICE: round 0 is the warm-up step (state a - 1 -> a, nothing recorded); a lane that starts from the reset state
         // itself (a == 0) sits it out
         const bool warm = SLICE && k == 0;
         const bool run = in_range && (force || !done) && !(SLICE && k == 0 && slice_a == 0);
         PH(5);
         // (a workgroup of several wavefronts carries ONE scenario: `run` is already uniform, nothing to vote)
-        const bool any_run_ = WV == 1 ? __any(run || (SLICE && k == 0 && in_range && !done)) : run;
+        const bool any_run_ = WV == 1 ? sg_any(run || (SLICE && k == 0 && in_range && !done)) : run;
         PH(7);
         if (!any_run_) { all_done = true; break; }
         // coefficient table: opaque per step so the scalar loads stay inside the loop (SGPRs for a few
@@ -3064,10 +3070,10 @@ __device__ __forceinline__ void rollout_body(
             RecipDiv rd(dt);
             const uint32_t zbits = (uint32_t)(__double2hiint(d[2]) | __double2hiint(d[4]) | __double2hiint(d[5])) |
                                    (uint32_t)(__double2loint(d[2]) | __double2loint(d[4]) | __double2loint(d[5]));
-            flat = !SLICE && __all((!run | !npres | (present & (zbits == 0))) & (dt > 0.0));
+            flat = !SLICE && sg_all((!run | !npres | (present & (zbits == 0))) & (dt > 0.0));
             bool safe = rd.safe(d[0]) & rd.safe(d[1]) & rd.safe(d[3]);
             if (!flat) safe = safe & rd.safe(d[2]) & rd.safe(d[4]) & rd.safe(d[5]);
-            if (__all(safe)) {
+            if (sg_all(safe)) {
                 vel[0] = rd.div(d[0]); vel[1] = rd.div(d[1]); vel[3] = rd.div(d[3]);
                 if (flat) {
                     vel[2] = vel[4] = vel[5] = 0.0;
@@ -3270,7 +3276,7 @@ __device__ __forceinline__ void rollout_body(
             // A hazard that is itself a controlled agent (PID / vehicle controller) has no trajectory its pose at the event
             // could be re-derived from: it leaves the pose it has right now beside the event (classify_events_kernel).  The
             // ego lane's new-event mask and list position go to the lanes of its tile; rare, one ballot per step otherwise.
-            if (__any(ev_base >= 0 && ev_fresh0 != 0)) {
+            if (sg_any(ev_base >= 0 && ev_fresh0 != 0)) {
                 const int ego_lane = tile0 + ss.ego;
                 const uint64_t fr = __shfl(ev_fresh0, ego_lane, 64);
                 const int base = __shfl(ev_base, ego_lane, 64);
@@ -3524,7 +3530,7 @@ __global__ __launch_bounds__(64) void replay_scenario_fixup_kernel(Params p, Sli
         bool need = false; // does a step of the batch have to divide?  (one wave-uniform branch per batch)
 #pragma unroll
         for (int u = 0; u < NB; ++u) need |= (sp[u].x == sp[u].x) & (sp[u].y != sp[u].y);
-        if (__any(need)) {
+        if (sg_any(need)) {
 #pragma unroll
             for (int u = 0; u < NB; ++u) update(sp[u], tq[u], true);
         } else {
@@ -4176,7 +4182,7 @@ __global__ __launch_bounds__(64) void rss_lines_kernel(Params p)
     const int n = p.rssq_n[w];
     const uint32_t idx = (uint32_t)(w * 64 + lane);
     int32_t st = p.rss_state[idx];
-    if (n == 0 && !__any(st & RSS_ST_PENDING)) return;
+    if (n == 0 && !sg_any(st & RSS_ST_PENDING)) return;
     ql->lastword[lane] = 0;
     ql->stepcd[lane] = 0;
     ql->hits[lane] = 0;
@@ -4335,7 +4341,7 @@ __global__ __launch_bounds__(64) void terminal_flags_kernel(Params p, double tim
     }
     uint32_t bits = 0;
     if (sd.t + (sd.t - sd.prev_t) > p.sstat[r].length) bits |= SG_TERM_MAX_LENGTH; // s.t + s.dt > length, State.dt = t - prev_t
-    if (__any(any_coll)) bits |= SG_TERM_COLLISION;
+    if (sg_any(any_coll)) bits |= SG_TERM_COLLISION;
     if (lane == 0) {
         if (ego_coll) bits |= SG_TERM_EGO_COLLISION;
         bool on_road = false;
