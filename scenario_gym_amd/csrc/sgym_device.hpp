@@ -341,12 +341,13 @@ struct RecipDiv {
         double e1 = __builtin_fma(-den, r1, 1.0);
         r = __builtin_fma(r1, e1, r1);
     }
-    // numerator range in which the unscaled sequence is exactly the IEEE quotient: zero, or a biased
+    // numerator range in which the unscaled sequence is exactly the IEEE quotient: +0, or a biased
     // exponent in [64, 1983] (|a| in [2^-959, 2^961)); denormals, huge values, inf and nan fall back
     __device__ __forceinline__ bool safe(double a) const
     {
         uint32_t e = ((uint32_t)__double2hiint(a) >> 20) & 0x7ffu;
-        return ok & (((e - 64u) < 1920u) | (a == 0.0)); // bitwise: straight-line code, no short-circuit branches
+        // (+0 only: -0 / b is -0, the unscaled sequence gives +0)
+        return ok & (((e - 64u) < 1920u) | (__double_as_longlong(a) == 0)); // bitwise: straight-line code, no short-circuit branches
     }
     __device__ __forceinline__ double div(double a) const
     {
@@ -3046,8 +3047,10 @@ __device__ __forceinline__ void rollout_body(
 
         // ---- State.update_poses / update_statistics, state.py:203-239 ----
         double d[6];
+        if (!CROWD || !(npres && !present)) { // (the crowd variant keeps the if / else form: its registers are full)
 #pragma unroll
-        for (int c = 0; c < 6; ++c) d[c] = np_[c] - pose[c];
+            for (int c = 0; c < 6; ++c) d[c] = np_[c] - pose[c];
+        }
         if (npres && !present) { // newcomer: previous pose from the extrapolated trajectory, state.py:219-222
             // (the rare case overwrites d: as an if / else the two subtractions were merged behind six copies pose -> prev
             // that every step paid)
@@ -3137,7 +3140,8 @@ __device__ __forceinline__ void rollout_body(
             }
             if (p.rec_cap > 0 && steps < p.rec_cap) {
                 int nan_hi = 0x7ff80000;
-                asm volatile("" : "+s"(nan_hi)); // (keeps the six selects inside this block: hoisted, they cost every step 18 moves)
+                if (!CROWD) asm volatile("" : "+s"(nan_hi)); // (keeps the six selects inside this block: hoisted, they cost every
+                                                             // step 18 moves; the crowd variant has no register to spare for it)
                 const double absent = __hiloint2double(nan_hi, 0);
 #pragma unroll
                 for (int c = 0; c < 6; ++c)

@@ -1145,6 +1145,31 @@ def test_crowd_kernel_equals_general_pedestrian_kernel(sga, monkeypatch, E, side
     assert np.array_equal(sa["coll"], sb["coll"])
 
 
+def test_negative_zero_pose_delta_keeps_its_sign(sga):
+    """velocity = delta / dt (state.py:226-233) for a delta of -0.0 is -0.0: the shared-reciprocal shortcut of the velocity
+    division only takes +0 numerators (its fused correction step would turn -0 into +0)."""
+    import scenario_gym_amd._lib as L
+    from scenario_gym_amd import synthetic
+
+    R, E = 3, 5
+    packed = synthetic.make_batch(R, E, n_steps=10, ego_kind=L.KIND_AGENT_REPLAY, extent=30.0)
+    packed.kind[0::E] = L.KIND_AGENT_EXTERNAL  # the egos are run by the caller
+    eng = sga.RolloutEngine(R, E)
+    eng.upload(packed)
+    poses = np.full((R, E, 6), np.nan)
+    poses[:, 0] = [0.0, 3.0, 0.0, 0.5, 0.0, 0.0]
+    eng.set_external_poses(poses)
+    eng.step(1)
+    poses[:, 0] = [-0.0, 3.0, 0.0, 0.5, 0.0, 0.0]  # x: +0.0 -> -0.0, delta = (-0.0) - (+0.0) = -0.0
+    eng.set_external_poses(poses)
+    eng.step(1)
+    st = eng.state()
+    eng.close()
+    vx = st["vels"][:, 0, 0]
+    assert (vx == 0.0).all() and np.signbit(vx).all(), vx
+    assert np.signbit(st["poses"][:, 0, 0]).all()
+
+
 def test_upload_from_page_locked_memory(sga):
     """PackedScenarios.pin() moves the knots into sg_host_alloc memory: sg_upload then sends them in pieces with the stage-1
     resample of each piece behind its copy -- the same device state as the upload from ordinary memory, and the array is
