@@ -170,7 +170,7 @@ def collect(elapsed, ent_steps, dist):
 def main(argv=None, make_engine=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--scenarios", type=int, default=None, help="scenarios per GPU (default: the workload's own, 4096 for c3)")
     ap.add_argument("--entities", type=int, default=None)
