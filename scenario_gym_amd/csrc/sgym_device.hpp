@@ -3074,8 +3074,16 @@ __device__ __forceinline__ void rollout_body(
             const uint32_t zbits = (uint32_t)(__double2hiint(d[2]) | __double2hiint(d[4]) | __double2hiint(d[5])) |
                                    (uint32_t)(__double2loint(d[2]) | __double2loint(d[4]) | __double2loint(d[5]));
             flat = !SLICE && sg_all((!run | !npres | (present & (zbits == 0))) & (dt > 0.0));
-            bool safe = rd.safe(d[0]) & rd.safe(d[1]) & rd.safe(d[3]);
-            if (!flat) safe = safe & rd.safe(d[2]) & rd.safe(d[4]) & rd.safe(d[5]);
+            // RecipDiv::safe for three (six) numerators at once: every |d| below 2^961 through one maximum, and each either
+            // +0 or at least 2^-959 (NaN fails the second, infinity the first)
+            auto lo_ok = [](double a) { return (__builtin_fabs(a) >= 0x1p-959) | (__double_as_longlong(a) == 0); };
+            double dmax = __builtin_fmax(__builtin_fmax(__builtin_fabs(d[0]), __builtin_fabs(d[1])), __builtin_fabs(d[3]));
+            bool safe = rd.ok & lo_ok(d[0]) & lo_ok(d[1]) & lo_ok(d[3]);
+            if (!flat) {
+                dmax = __builtin_fmax(__builtin_fmax(dmax, __builtin_fabs(d[2])), __builtin_fmax(__builtin_fabs(d[4]), __builtin_fabs(d[5])));
+                safe = safe & lo_ok(d[2]) & lo_ok(d[4]) & lo_ok(d[5]);
+            }
+            safe = safe & (dmax < 0x1p961);
             if (sg_all(safe)) {
                 vel[0] = rd.div(d[0]); vel[1] = rd.div(d[1]); vel[3] = rd.div(d[3]);
                 if (flat) {
