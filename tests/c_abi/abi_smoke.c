@@ -127,6 +127,32 @@ int main(void)
         bad |= !(flags[0] & SG_TERM_EGO_OFF_ROAD);
     }
 
+    /* the same batch from page-locked memory (sg_host_alloc) with the RSSDistances callback inside the rollout (sg_set_rss):
+       the parked box of scenario 0 is run into -> an "unsafe" record and a cleared metric flag; scenario 1 stays safe */
+    {
+        double *pk = NULL;
+        CHECK(sg_host_alloc(0, sizeof knots, (void **)&pk));
+        memcpy(pk, knots, sizeof knots);
+        sc.knots = pk;
+        CHECK(sg_set_rss(h, 1));
+        CHECK(sg_upload(h, &sc));
+        CHECK(sg_rollout(h, 200));
+        uint8_t rss_flags[R];
+        int32_t codes[R * E];
+        double safe[R * E * 2];
+        CHECK(sg_rss_read(h, rss_flags, codes, safe));
+        printf("rss flags %u %u, codes of scenario 0: %d %d %d\n", rss_flags[0], rss_flags[1], codes[0], codes[1], codes[2]);
+        bad |= codes[0] != -1 || codes[1] < 4 || codes[E + 1] > 3; /* ego: no record; parked box: unsafe / found; far away: safe */
+        bad |= rss_flags[0] == 3 || rss_flags[1] != 3;
+        bad |= !(safe[2] > 0.0) || !(safe[3] > 0.0);
+        sg_metrics m2[R];
+        CHECK(sg_read_metrics(h, m2, ev, 16, &n_ev));
+        bad |= m2[0].n_steps != m[0].n_steps || m2[0].n_collisions != 1;
+        CHECK(sg_set_rss(h, 0));
+        sc.knots = &knots[0][0];
+        CHECK(sg_host_free(pk));
+    }
+
     /* error behaviour: a bad argument returns a negative status and a message, nothing aborts */
     int rc = sg_step(h, -1, NULL, 0);
     bad |= rc != SG_ERR_INVALID || strlen(sg_last_error(h)) == 0;
