@@ -86,6 +86,7 @@ struct sg_handle {
     uint64_t generation = 0, tick_gen = ~0ull;         // bumped by every call that changes what the kernels are launched with
     double tick_w = 0, tick_h = 0;
     int tick_nw = 0, tick_nh = 0, tick_nl = 0;
+    bool tick_rss = false;                             // the captured step runs the RSS callback (rollout_kernel_rss* + rss_lines_kernel)
     int32_t tick_layers[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int32_t *d_rss_state = nullptr, *d_rss_code = nullptr; // [NE] sg_rss_update
     int32_t *d_rss_seen = nullptr;                         // [R]
@@ -1155,8 +1156,15 @@ extern "C" int sg_tick(sg_handle *h, const double *actions, int32_t actions_devi
     int rc = obs_scratch(h, lay_off + 8 * sizeof(int32_t), &d);
     if (rc) return rc;
     int32_t *dl = reinterpret_cast<int32_t *>(d + lay_off);
+    // sg_set_rss: the callback runs after the step, inside the captured launch (like sg_step; without records of a reset --
+    // the callback was switched on after sg_upload -- through sg_rss_update after the graph)
+    const bool rss_tick = h->rss_enabled && h->ego_first && h->d_rss_state;
+    if (rss_tick) { // (allocations stay outside the capture)
+        bool fresh = false;
+        if ((rc = ensure_rss(h, &fresh)) || (rc = ensure_rssq(h))) return rc;
+    }
     const bool same = h->tick_exec && h->tick_gen == h->generation && h->tick_w == width && h->tick_h == height &&
-                      h->tick_nw == nw && h->tick_nh == nh && h->tick_nl == n_layers &&
+                      h->tick_rss == rss_tick && h->tick_nw == nw && h->tick_nh == nh && h->tick_nl == n_layers &&
                       std::equal(layers, layers + n_layers, h->tick_layers);
     if (!same) {
         HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -1168,7 +1176,9 @@ extern "C" int sg_tick(sg_handle *h, const double *actions, int32_t actions_devi
         h->timing_now = false;
         h->n_launches = 0;
         h->launch_ev.clear();
+        h->rss_fused = rss_tick;
         rc = launch_main(h, 1, 0, 1, h->d_actions, nullptr, false, &ev_next);
+        h->rss_fused = false;
         hipError_t e = hipSuccess;
         if (!rc) { // the whole observation (map layers + terminal flags) in one launch
             sg::observe_kernel<<<dim3((unsigned)h->R), dim3(256), 0, h->stream>>>(h->p, h->road, h->has_road ? 1 : 0, width, height, nw,
@@ -1185,6 +1195,7 @@ extern "C" int sg_tick(sg_handle *h, const double *actions, int32_t actions_devi
         (void)hipGraphDestroy(graph);
         if (e != hipSuccess) { h->tick_exec = nullptr; return fail(h, SG_ERR_HIP, "sg_tick: hipGraphInstantiate: %s", hipGetErrorString(e)); }
         h->tick_gen = h->generation;
+        h->tick_rss = rss_tick;
         h->tick_w = width; h->tick_h = height; h->tick_nw = nw; h->tick_nh = nh; h->tick_nl = n_layers;
         std::copy(layers, layers + n_layers, h->tick_layers);
     }
@@ -1193,6 +1204,7 @@ extern "C" int sg_tick(sg_handle *h, const double *actions, int32_t actions_devi
     else
         HIP_TRY(h, hipMemsetAsync(h->d_actions, 0, n_act * sizeof(double), h->stream));
     HIP_TRY(h, hipGraphLaunch(h->tick_exec, h->stream));
+    if (h->rss_enabled && !rss_tick && (rc = sg_rss_update(h, 0))) return rc;
     h->timed = false;
     if (d_obs) *d_obs = d;
     if (d_flags) *d_flags = h->d_term_flags;

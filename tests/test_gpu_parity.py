@@ -1840,6 +1840,36 @@ def test_rss_inside_pedestrian_and_off_road_rollouts(sga, scene, E):
     b.close()
 
 
+def test_rss_callback_inside_the_graph_tick(sga):
+    """sg_tick (one captured launch per RL tick) with sg_set_rss: the captured step is the RSS variant + rss_lines_kernel --
+    the records after every tick equal those of sg_step; switching the callback on or off re-captures the graph."""
+    import scenario_gym_amd._lib as L
+    from scenario_gym_amd import synthetic
+
+    R, E, steps = 24, 20, 40
+    packed = synthetic.make_batch(R, E, n_steps=steps, ego_kind=L.KIND_AGENT_VEHICLE, extent=14.0)
+    acts = synthetic.make_actions(steps, R)
+    a = sga.RolloutEngine(R, E)
+    b = sga.RolloutEngine(R, E)
+    for eng in (a, b):
+        eng.set_rss(True)
+        eng.upload(packed)
+    for k in range(steps):
+        a.tick(acts[k], [0], nw=4, nh=4)
+        b.step(1, acts[k:k + 1])
+        if k % 13 == 0 or k == steps - 1:
+            for x, y in zip(a.rss(), b.rss()):
+                assert np.array_equal(x, y, equal_nan=True), k
+    assert (a.rss()[2] > 0).any()
+    a.set_rss(False)  # the next tick runs the plain step again
+    before = [x.copy() for x in a.rss()]
+    a.tick(acts[0], [0], nw=4, nh=4)
+    for x, y in zip(a.rss(), before):
+        assert np.array_equal(x, y, equal_nan=True)
+    a.close()
+    b.close()
+
+
 @pytest.mark.parametrize("E,ego", [(64, "pid"), (9, "replay"), (130, "pid")])
 def test_rss_line_test_queues_across_launches(sga, monkeypatch, E, ego):
     """The line tests of rollout_kernel_rss are queued per wavefront and evaluated by rss_lines_kernel after each launch; the
