@@ -1027,7 +1027,16 @@ extern "C" int sg_reset_scenarios(sg_handle *h, const uint8_t *mask)
     if (!h->d_reset_mask) HIP_TRY(h, hipMalloc((void **)&h->d_reset_mask, (size_t)h->R));
     HIP_TRY(h, hipMemcpyAsync(h->d_reset_mask, mask, (size_t)h->R, hipMemcpyHostToDevice, h->stream));
     h->p.reset_mask = h->d_reset_mask;
-    int rc = launch_rollout(h, 0, 2, 0, nullptr);
+    int rc;
+    if (h->rss_enabled && h->ego_first && h->d_rss_state) { // the flagged scenarios' RSS histories start anew as well
+        bool fresh = false;
+        if ((rc = ensure_rss(h, &fresh)) || (rc = ensure_rssq(h))) return rc;
+        h->rss_fused = true;
+        rc = launch_rollout(h, 0, 2, 0, nullptr);
+        h->rss_fused = false;
+    } else {
+        rc = launch_rollout(h, 0, 2, 0, nullptr);
+    }
     if (rc) return rc;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return SG_OK;

@@ -1840,6 +1840,34 @@ def test_rss_inside_pedestrian_and_off_road_rollouts(sga, scene, E):
     b.close()
 
 
+def test_masked_reset_restarts_the_rss_histories(sga):
+    """sg_reset_scenarios with the RSS callback on: the flagged scenarios' histories (the "unsafe" entries behind the metric
+    flags, `last`) start anew with the reset-time update, the others carry on."""
+    import scenario_gym_amd._lib as L
+    from scenario_gym_amd import synthetic
+
+    R, E = 16, 12
+    packed = synthetic.make_batch(R, E, n_steps=60, ego_kind=L.KIND_AGENT_PID, extent=10.0)
+    mask = (np.arange(R) % 3 == 0).astype(np.uint8)
+    runs = {}
+    for name, plan in (("restarted", (30, "reset", 20)), ("fresh20", (20,)), ("straight50", (50,))):
+        eng = sga.RolloutEngine(R, E)
+        eng.set_rss(True)
+        eng.upload(packed)
+        for op in plan:
+            if op == "reset":
+                eng.reset_scenarios(mask)
+            else:
+                eng.step(op)
+        runs[name] = eng.rss()
+        eng.close()
+    m = mask.astype(bool)
+    assert not runs["straight50"][0][m].all() or not runs["straight50"][1][m].all()  # (some restarted scenario had an unsafe entry)
+    for k in range(4):
+        assert np.array_equal(runs["restarted"][k][m], runs["fresh20"][k][m], equal_nan=True), k
+        assert np.array_equal(runs["restarted"][k][~m], runs["straight50"][k][~m], equal_nan=True), k
+
+
 def test_rss_callback_inside_the_graph_tick(sga):
     """sg_tick (one captured launch per RL tick) with sg_set_rss: the captured step is the RSS variant + rss_lines_kernel --
     the records after every tick equal those of sg_step; switching the callback on or off re-captures the graph."""
