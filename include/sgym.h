@@ -331,8 +331,8 @@ int sg_raster_map_device(sg_handle *h, double width, double height, int32_t nw, 
  * actions: [n_scenarios][2] HOST (actions_device = 0) or DEVICE, or NULL for (0, 0).  Asynchronous: the work is queued on
  * sg_stream(h); *d_obs (DEVICE [R][n_layers][nh][nw] bytes) and *d_flags (DEVICE [R] SG_TERM_* bits) are valid after
  * sg_synchronize(h) until the next observation call.  The graph is rebuilt when the batch, the networks, the time step or
- * the geometry change.  Not for batches with SG_KIND_AGENT_EXTERNAL slots; the RSS callback of sg_set_rss is not part of the
- * graph (call sg_rss_update after the tick if it is wanted). */
+ * the geometry change (or sg_set_rss is switched).  Not for batches with SG_KIND_AGENT_EXTERNAL slots.  With sg_set_rss the
+ * captured step runs the RSS callback as sg_step does. */
 int sg_tick(sg_handle *h, const double *actions, int32_t actions_device, double width, double height, int32_t nw, int32_t nh,
             int32_t n_layers, const int32_t *layers, const uint8_t **d_obs, const uint32_t **d_flags);
 
@@ -342,9 +342,12 @@ int sg_tick(sg_handle *h, const double *actions, int32_t actions_device, double 
  * (metrics/rss/rss.py:70-104).  Call once after sg_reset (reset = 1: forget the histories) and once after every step;
  * scenarios at t == 0.0 are skipped as in the reference.  Asynchronous on sg_stream(h). */
 int sg_rss_update(sg_handle *h, int32_t reset);
-/* enabled != 0: sg_reset / sg_rollout / sg_step run the callback themselves -- after the reset and after every step (one step
- * per launch) -- as ScenarioGym(state_callbacks=[RSSDistances()]) does.  A scenario that has not stepped since its latest
- * update (it is done) is left alone. */
+/* enabled != 0: sg_upload / sg_reset / sg_reset_scenarios / sg_rollout / sg_step / sg_tick run the callback themselves --
+ * after the reset and after every step, inside the rollout kernel (any number of steps per launch; also with pedestrian
+ * agents and with SG_TERM_EGO_OFF_ROAD) -- as ScenarioGym(state_callbacks=[RSSDistances()]) does.  The line tests of the
+ * callback are queued on the device and finished by a second kernel after each launch (queues: env SG_RSSQ_MB, default
+ * 4096 MiB per handle; longer calls are cut into several launches).  A scenario that has not stepped since its latest
+ * update (it is done) is left alone.  The ego has to be entity 0 (else: one sg_rss_update per step, which says so). */
 int sg_set_rss(sg_handle *h, int32_t enabled);
 /* flags [R]: bit 0 = RSS_safe_longitudinal, bit 1 = RSS_safe_lateral (no entity's history holds the corresponding
  * "unsafe_*" record); codes [R*E] of the latest update: 0 safe, 1 lateral, 2 longitudinal, 3 both, 4 unsafe_lateral,
