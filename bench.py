@@ -39,6 +39,28 @@ WORKLOADS = {
 }
 
 
+def effective_cpus():
+    """Host CPUs this process may actually use: os.cpu_count() capped by the cgroup CPU quota (the GPU boxes show 256 logical
+    CPUs under a quota of 16: more busy threads than that are throttled, not run)."""
+    n = os.cpu_count() or 1
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:  # cgroup v2: "<quota> <period>" or "max <period>"
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        try:  # cgroup v1
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+                quota = int(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                period = int(f.read())
+            if quota > 0:
+                n = min(n, max(1, -(-quota // period)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_baseline(workload, seconds_budget=20.0):
     """The CPU oracle (a port of the reference's algorithm, NOT the thing measured) on a bounded
     sample of the same workload: one scenario per host thread, the same E, shortened T."""
@@ -50,17 +72,17 @@ def cpu_baseline(workload, seconds_budget=20.0):
 
     O.build()
     O.lib()
-    cores = os.cpu_count() or 1
+    cores = effective_cpus()
     E, T = workload["E"], workload["T"]
     rss = bool(workload.get("rss"))
     if workload.get("crowd"):
-        t_sample, n_scen = min(T, 1000), max(cores, 1)
+        t_sample, n_scen = min(T, 1000), min(max(cores, 1) * 16, 1024)
         packed = synthetic.make_crowd(n_scen, E, n_steps=t_sample)
     elif rss:  # (the oracle's callback runs over the recorded poses of its rollout)
-        t_sample, n_scen = min(T, 500), max(cores, 1)
+        t_sample, n_scen = min(T, 500), min(max(cores, 1) * 16, 1024)
         packed = synthetic.make_batch(n_scen, E, n_steps=t_sample, ego_kind=workload["ego_kind"])
     else:
-        t_sample, n_scen = T, max(cores, 1) * 4
+        t_sample, n_scen = T, min(max(cores, 1) * 64, 4096)
         packed = synthetic.make_batch(n_scen, E, n_steps=t_sample, ego_kind=workload["ego_kind"])
     scen = [unpack_scenario(packed, r) for r in range(n_scen)]
 
@@ -80,7 +102,8 @@ def cpu_baseline(workload, seconds_budget=20.0):
     out = {
         "value": float(sum(steps)) * E / dt, "unit": "entity-steps/s", "cores": cores, "kind": "port",
         "sample": f"{n_scen} scenarios x {E} entities x {t_sample} steps of the same seeded family, "
-                  f"{cores} threads, C oracle (oracle/sgym_oracle.c), {dt:.1f}s",
+                  f"{cores} threads (= the CPUs the cgroup quota grants of {os.cpu_count()} logical), C oracle "
+                  f"(oracle/sgym_oracle.c), {dt:.1f}s",
     }
     ref = os.path.join(ROOT, "profiles", "reference_cpu.json")
     if os.path.exists(ref):  # the real reference cannot travel to the GPU box: its number from the build container

@@ -9,7 +9,7 @@ packed = synthetic.make_batch(R, E, ego_kind=sga._lib.KIND_AGENT_PID)
 if len(sys.argv) < 2 or sys.argv[1] != "pageable":
     packed.pin()
 eng = sga.RolloutEngine(R, E)
-for i in range(5):
+for i in range(12):
     t = time.perf_counter()
     eng.upload(packed)
     print(f"--- upload {i}: {(time.perf_counter() - t) * 1e3:.1f} ms", file=sys.stderr, flush=True)
