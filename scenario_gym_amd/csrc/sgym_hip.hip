@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <chrono>
 #include <cstring>
+#include <iterator>
 #include <memory>
 #include <string>
 #include <thread>
@@ -807,6 +808,7 @@ extern "C" int sg_upload(sg_handle *h, const sg_scenarios *sc)
                 errs[w] = buf;
                 err_r[w] = r;
             };
+            std::vector<double> times, merged; // scratch of the union grid
             for (int r = (int)((int64_t)R * w / nthr); r < (int)((int64_t)R * (w + 1) / nthr); ++r) {
                 if (sc->ego[r] < 0 || sc->ego[r] >= E) return bad(r, "sg_upload: ego[%zu]=%d out of range", (size_t)r, sc->ego[r]);
                 sstat[r].ego = sc->ego[r];
@@ -839,19 +841,31 @@ extern "C" int sg_upload(sg_handle *h, const sg_scenarios *sc)
                                 return bad(r, "sg_upload: knot times of entity %zu are not strictly increasing (%d)", i, 0);
                     }
                 }
-                std::vector<double> &g = grids[r]; // the union grid, while the scenario's knots are in cache
+                // the union grid (np.unique of the concatenated knot times), while the scenario's knots are in cache.  Every
+                // entity's times are strictly increasing (checked above), so the union grows by merging sorted lists -- and
+                // an entity on the grid found so far (the usual case: one recording, one clock) costs one comparison per knot
+                std::vector<double> &g = grids[r];
                 for (int e = 0; e < E; ++e) {
                     size_t i = (size_t)r * E + e;
                     if (sc->kind[i] != SG_KIND_REPLAY) continue;
-                    int64_t a = sc->knot_off[i], b = sc->knot_off[i + 1];
-                    for (int64_t j = a; j < b; ++j) {
-                        double v = sc->knots[(size_t)j * 7];
-                        g.push_back(v == v ? v : 0.0); // np.nan_to_num
+                    const int64_t a = sc->knot_off[i], b = sc->knot_off[i + 1];
+                    const size_t n = (size_t)(b - a);
+                    if (n == 1) { // batch.py:85-88: a second knot 0.1 s later
+                        const double v0 = sc->knots[(size_t)a * 7], two[2] = {v0 == v0 ? v0 : 0.0 /* np.nan_to_num */, v0 + 1e-1};
+                        merged.clear();
+                        std::set_union(g.begin(), g.end(), two, two + 2, std::back_inserter(merged));
+                        g.swap(merged);
+                        continue;
                     }
-                    if (b - a == 1) g.push_back(sc->knots[(size_t)a * 7] + 1e-1); // batch.py:85-88
+                    bool same = g.size() == n;
+                    for (size_t j = 0; j < n && same; ++j) same = g[j] == sc->knots[(size_t)(a + (int64_t)j) * 7];
+                    if (same) continue;
+                    times.resize(n);
+                    for (size_t j = 0; j < n; ++j) times[j] = sc->knots[(size_t)(a + (int64_t)j) * 7];
+                    merged.clear();
+                    std::set_union(g.begin(), g.end(), times.begin(), times.end(), std::back_inserter(merged));
+                    g.swap(merged);
                 }
-                std::sort(g.begin(), g.end());
-                g.erase(std::unique(g.begin(), g.end()), g.end());
             }
         };
         std::vector<std::thread> pool;
