@@ -40,25 +40,10 @@ WORKLOADS = {
 
 
 def effective_cpus():
-    """Host CPUs this process may actually use: os.cpu_count() capped by the cgroup CPU quota (the GPU boxes show 256 logical
-    CPUs under a quota of 16: more busy threads than that are throttled, not run)."""
-    n = os.cpu_count() or 1
-    try:
-        with open("/sys/fs/cgroup/cpu.max") as f:  # cgroup v2: "<quota> <period>" or "max <period>"
-            quota, period = f.read().split()[:2]
-        if quota != "max":
-            n = min(n, max(1, -(-int(quota) // int(period))))
-    except (OSError, ValueError):
-        try:  # cgroup v1
-            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
-                quota = int(f.read())
-            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
-                period = int(f.read())
-            if quota > 0:
-                n = min(n, max(1, -(-quota // period)))
-        except (OSError, ValueError):
-            pass
-    return n
+    """os.cpu_count() capped by the cgroup CPU quota (the GPU boxes show 256 logical CPUs under a quota of 16)."""
+    from scenario_gym_amd.packing import effective_cpus as f
+
+    return f()
 
 
 def cpu_baseline(workload, seconds_budget=20.0):

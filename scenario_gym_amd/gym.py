@@ -105,18 +105,22 @@ class BatchedScenarioGym:
         finally:
             gym.close()
 
-    def load_scenarios(self, paths: Sequence[str], create_agent=_create_agent, relabel: bool = True, workers: int = 8,
+    def load_scenarios(self, paths: Sequence[str], create_agent=_create_agent, relabel: bool = True, workers: Optional[int] = None,
                        max_steps: Optional[int] = None, processes: bool = False):
         """ScenarioGym.load_scenario (scenario_gym.py:119-155) for many files: every file goes through the native scan
         (libsgym_xosc.so, which runs without the GIL) on `workers` threads -- or, for directories of thousands of files,
         `workers` processes (`processes=True`: the Python side of the import scales too; tools/ingest_rate.py) -- and the
-        batch is packed once."""
+        batch is packed once.  workers=None: 8 threads, or as many processes as the CPU quota grants."""
         from concurrent.futures import ProcessPoolExecutor, ThreadPoolExecutor
         from functools import partial
 
         from .xosc import import_scenario
 
         paths = list(paths)
+        if workers is None:
+            from .packing import effective_cpus
+
+            workers = effective_cpus() if processes else 8
         if workers > 1 and len(paths) > 1:
             pool = ProcessPoolExecutor if processes else ThreadPoolExecutor
             with pool(min(workers, len(paths))) as ex:

@@ -128,3 +128,27 @@ def pack_scenarios(scenarios, create_agent=None):
     packed = pack_arrays(arrays, kinds=kinds, ctrls=ctrls)
     packed.refs = [[e.ref for e in sc.entities] for sc in scenarios]
     return packed, agents
+
+
+def effective_cpus() -> int:
+    """Host CPUs this process may actually use: os.cpu_count() capped by the cgroup CPU quota (a box can show 256 logical
+    CPUs under a quota of 16: more busy threads or processes than that are throttled, not run)."""
+    import os
+
+    n = os.cpu_count() or 1
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:  # cgroup v2: "<quota> <period>" or "max <period>"
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        try:  # cgroup v1
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+                quota = int(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                period = int(f.read())
+            if quota > 0:
+                n = min(n, max(1, -(-quota // period)))
+        except (OSError, ValueError):
+            pass
+    return n

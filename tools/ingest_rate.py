@@ -4,7 +4,7 @@ reference's test inputs: a vehicle catalog, ScenarioObjects with CatalogReferenc
 per entity) and times `import_scenario` -- the native scan (libsgym_xosc.so) against the ElementTree reader, serial, and
 over a process pool.
 
-    python tools/ingest_rate.py [n_files=10000] [entities=8] [vertices=120] [workers=os.cpu_count()]
+    python tools/ingest_rate.py [n_files=10000] [entities=8] [vertices=120] [workers=the CPUs the cgroup quota grants]
 """
 import os
 import shutil
@@ -84,7 +84,9 @@ def main():
     n_files = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
     E = int(sys.argv[2]) if len(sys.argv) > 2 else 8
     V = int(sys.argv[3]) if len(sys.argv) > 3 else 120
-    workers = int(sys.argv[4]) if len(sys.argv) > 4 else (os.cpu_count() or 1)
+    from scenario_gym_amd.packing import effective_cpus
+
+    workers = int(sys.argv[4]) if len(sys.argv) > 4 else effective_cpus()
     root = tempfile.mkdtemp(prefix="sg_ingest_")
     try:
         t = time.perf_counter()
