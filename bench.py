@@ -175,6 +175,41 @@ def collect(elapsed, ent_steps, dist):
         (None if per_rank is None else [float(v) for v in per_rank[:, 0]])
 
 
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` outside a launcher: start the N ranks ourselves (one process per GPU, torch.distributed.run,
+    rendezvous on 127.0.0.1) as a CHILD of this process -- which has not imported torch nor touched HIP -- and relay rank
+    0's JSON line and the exit code.  Never exec, never spawn after a GPU call."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    for ln in proc.stdout.splitlines():
+        if ln not in lines:
+            print(ln, file=sys.stderr)
+    if lines:
+        print(lines[-1])
+        sys.stdout.flush()
+    return proc.returncode if (proc.returncode != 0 or lines) else 1
+
+
+def load_factory(spec):
+    """--engine-factory module:function (tests only: a stand-in engine so that the launch / dispatch / collection path runs
+    on a CPU box); the function is called as f(R, first_scenario, E, T) and returns an engine-like object."""
+    import importlib
+
+    mod, fn = spec.split(":")
+    return getattr(importlib.import_module(mod), fn)
+
+
 def main(argv=None, make_engine=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -194,10 +229,23 @@ def main(argv=None, make_engine=None):
                          "over the ranks (BASELINE.json configs[3] read literally: 4096 replicas over 8 GPUs = 512 per GPU)."
                          "  With N > 1 the other one is timed too and reported under its own key")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--verify", type=int, default=None,
+                    help="after the timed passes (outside the timed region) re-run this many scenarios spread over the batch "
+                         "through the CPU oracle for the full horizon and compare the final state / metric rows / events bit "
+                         "for bit; a mismatch makes the exit code non-zero.  Default 16 (c5, c3rss: 4); 0 = off")
+    ap.add_argument("--engine-factory", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--ped-noise", default="off", choices=["off", "device"],
                     help="c5: SocialForce noise terms (social_force.py:106-114): off = std 0 (parity runs), device = the "
                          "reference's default std with the counter-based device RNG")
     args = ap.parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and make_engine is None:
+        # not under a launcher: be the launcher (before torch / HIP are touched in this process)
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:] if argv is None else argv))
+    if args.engine_factory and make_engine is None:
+        factory = load_factory(args.engine_factory)
+
+        def make_engine(R, first):
+            return factory(R, first, args.entities, args.sim_steps)
 
     import numpy as np
 
@@ -246,10 +294,28 @@ def main(argv=None, make_engine=None):
             if wl.get("rss"):
                 eng.set_rss(True)
             eng.upload(packed)
+            eng._bench_packed = packed  # (kept for the oracle check after the timed passes)
             return eng
     else:  # tests drive the dispatch / timing / collection code with a stand-in engine on CPU
         def sync():
             pass
+
+    n_verify = args.verify if args.verify is not None else (4 if (crowd or wl.get("rss")) else 16)
+
+    def verify(eng, K):
+        """NOT timed: the state the last timed pass left against the CPU oracle, full horizon, K scenarios of this rank."""
+        from oracle import check
+
+        noise_of = None
+        if crowd and args.ped_noise == "device":
+            noise_of = lambda r: dict(mode="device", std_lon=0.1, std_lat=0.1, seed=0, scenario_index=r)  # noqa: E731
+        t0 = time.perf_counter()
+        v = check.verify_engine(eng, eng._bench_packed, dt, T, K=K, event_cap=64, ped=crowd, rss=bool(wl.get("rss")),
+                                noise_of=noise_of, threads=effective_cpus())
+        v["seconds"] = round(time.perf_counter() - t0, 2)
+        v["what"] = ("after the timed passes, outside the timed region: the device state left by the last timed rollout vs "
+                     "oracle/sgym_oracle.c run over the full horizon, bit for bit")
+        return v
 
     def measure(R):
         first = rank * R  # rank r owns scenarios [r R, (r + 1) R) of the seeded family (chunk-aligned: R % 64 == 0 or 1 rank)
@@ -267,9 +333,15 @@ def main(argv=None, make_engine=None):
             return int(rows["n_steps"].sum()) * E, (eng.last_kernel_ms(), n_launch, launch_ms)
 
         elapsed, ent_steps, stats = timed_passes(one_pass, args.steps, args.warmup, dist, sync)
+        ver = None
+        if n_verify > 0 and getattr(eng, "_bench_packed", None) is not None:
+            ver = verify(eng, max(2, -(-n_verify // world)))
         eng.close()
         worst, total, per_rank = collect(elapsed, ent_steps, dist)
-        return dict(elapsed=worst, total=total, per_rank=per_rank, ent_steps=ent_steps, stats=stats, R=R)
+        if ver is not None and dist is not None:  # every rank checks scenarios of its own shard
+            ver["equal"] = D.sum_over_ranks(0.0 if ver["equal"] else 1.0, dist) == 0.0
+            ver["scenarios"] = int(D.sum_over_ranks(float(ver["scenarios"]), dist))
+        return dict(elapsed=worst, total=total, per_rank=per_rank, ent_steps=ent_steps, stats=stats, R=R, verified=ver)
 
     main_run = measure(shapes[args.scaling])
     other_run = None
@@ -366,15 +438,20 @@ def main(argv=None, make_engine=None):
                 "src_sha16": L.source_sha16(),
             },
         }
+        line["verified"] = m["verified"]
         if other_run:
             name, o = other_run
             line[name] = {"value": o["total"] / o["elapsed"], "ms_per_step": o["elapsed"] / args.steps * 1e3,
-                          "scenarios_per_gpu": o["R"], "per_rank_value": o["per_rank"]}
+                          "scenarios_per_gpu": o["R"], "per_rank_value": o["per_rank"], "verified": o["verified"]}
         if live and world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(dict(E=E, T=T, dt=dt, ego_kind=ego_kind, crowd=crowd, rss=bool(wl.get("rss"))))
         print(json.dumps(line))
-    if dist is not None and live:
+    if dist is not None and (live or args.engine_factory):
         dist.destroy_process_group()
+    failed = [r for r in (main_run, other_run[1] if other_run else None) if r and r["verified"] and not r["verified"]["equal"]]
+    if failed:
+        print(f"bench: the device state DIFFERS from the oracle: {failed[0]['verified']['mismatches']}", file=sys.stderr)
+        raise SystemExit(3)
     return line
 
 

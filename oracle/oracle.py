@@ -132,7 +132,7 @@ class _Event(C.Structure):
 
 
 class _Record(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("t", "poses", "vels", "dists", "coll", "extra")]
+    _fields_ = [(n, C.c_void_p) for n in ("t", "poses", "vels", "dists", "coll", "extra")] + [("last_only", C.c_int32)]
 
 
 class _Result(C.Structure):
@@ -222,7 +222,8 @@ def rollout(knot_off, knots, bbox, etype, kind, ego, t0, length, dt, persist=Fal
             cfg.noise_mode, cfg.noise_seed, cfg.scenario_index = 2, int(noise.get("seed", 0)), int(noise.get("scenario_index", 0))
         else:
             raise ValueError(noise["mode"])
-    S = max_steps + 1
+    last_only = record == "last"  # the final state only, in row 0 (full-horizon checks of large batches)
+    S = 1 if last_only else max_steps + 1
     out = {}
     rec = None
     if record:
@@ -230,7 +231,7 @@ def rollout(knot_off, knots, bbox, etype, kind, ego, t0, length, dt, persist=Fal
             t=np.full(S, np.nan), poses=np.full((S, E, 6), np.nan), vels=np.full((S, E, 6), np.nan),
             dists=np.zeros((S, E)), coll=np.zeros((S, E, W), np.uint64), extra=np.zeros((S, E, 4)),
         )
-        rec = _Record(*[_p(out[k]) for k in ("t", "poses", "vels", "dists", "coll", "extra")])
+        rec = _Record(*[_p(out[k]) for k in ("t", "poses", "vels", "dists", "coll", "extra")], int(last_only))
     ev = (_Event * event_cap)()
     res = _Result()
     acts = None
@@ -244,7 +245,7 @@ def rollout(knot_off, knots, bbox, etype, kind, ego, t0, length, dt, persist=Fal
         raise RuntimeError(f"sgo_rollout failed: {rc}")
     n = res.n_steps
     for k in list(out):
-        out[k] = out[k][: n + 1]
+        out[k] = out[k][: 1 if last_only else n + 1]
     out.update(
         n_steps=n, is_done=bool(res.done), final_t=res.final_t, noise_used=int(res.noise_used),
         metric_ego_avg_speed=res.ego_avg_speed, metric_ego_max_speed=res.ego_max_speed,

@@ -1388,7 +1388,7 @@ int sgo_rollout(const sgo_scenario *sc, const sgo_config *cfg, int max_steps, in
 #define RECORD(row)                                                                             \
     do {                                                                                        \
         if (rec) {                                                                              \
-            size_t s_ = (size_t)(row);                                                          \
+            size_t s_ = rec->last_only ? 0 : (size_t)(row);                                     \
             if (rec->t) rec->t[s_] = t;                                                         \
             for (int i_ = 0; i_ < E; ++i_) {                                                    \
                 for (int c_ = 0; c_ < 6; ++c_) {                                                \

@@ -65,34 +65,7 @@ def test_two_rank_sharding_and_collection(tmp_path, oracle):
     assert np.array_equal(got["rows"], _rows_for(whole, oracle))  # same bits as one unsharded run
 
 
-class _StandInEngine:
-    """What bench.py's one_pass() needs of a RolloutEngine, without a GPU: every scenario runs its T steps."""
-
-    def __init__(self, R, first, E, T):
-        self.R, self.first, self.E, self.T = R, first, E, T
-        self.passes = 0
-
-    def rollout_async(self, T, do_reset=True):
-        assert T == self.T and do_reset
-        self.passes += 1
-
-    def synchronize(self):
-        pass
-
-    def metrics(self):
-        idx = np.arange(self.first, self.first + self.R, dtype=np.float64)
-        rows = dict(ego_avg_speed=idx, ego_max_speed=idx * 2, ego_distance_travelled=idx * 3,
-                    n_collisions=np.zeros(self.R, np.int32), n_steps=np.full(self.R, self.T, np.int32))
-        return rows, None
-
-    def last_launch_stats(self):
-        return 2, 1.0
-
-    def last_kernel_ms(self):
-        return 1.25
-
-    def close(self):
-        pass
+from standin_engine import StandInEngine as _StandInEngine  # noqa: E402
 
 
 def _bench_worker(rank, world, port, out_path):
@@ -145,3 +118,27 @@ def test_bench_dispatch_and_collection_strong_scaling(tmp_path):
     assert abs(line["value"] * line["ms_per_step"] * 1e-3 * 2 - ent_steps) < 1e-6 * ent_steps
     assert line["roofline"]["bound"] == "valu_issue" and line["roofline"]["traffic"] is None
     assert line["roofline"]["entity_steps_per_launch"] == 64 * 6 * 40 / 2
+
+
+def test_bench_py_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` the way the driver invokes it (no launcher, WORLD_SIZE unset): bench.py starts the two
+    ranks itself (torch.distributed.run as a child, gloo here), relays rank 0's line: ranks 2, n_gpus 2, the weak value and
+    the strong (batch split over the ranks) block."""
+    import json
+    import subprocess
+    import sys
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--scenarios", "128", "--entities", "6",
+                          "--sim-steps", "40", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                          "--engine-factory", "tests.standin_engine:make"],
+                         capture_output=True, text=True, timeout=300, env=env, cwd=str(tmp_path))
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    line = json.loads(lines[0])
+    assert line["ranks"] == 2 and line["n_gpus"] == 2 and line["backend"] == "gloo" and line["scaling"] == "weak"
+    assert line["config"]["scenarios_per_gpu"] == 128 and line["strong"]["scenarios_per_gpu"] == 64
+    assert len(line["per_rank_value"]) == 2 and len(line["strong"]["per_rank_value"]) == 2
+    ent_steps = 2 * 128 * 6 * 40 * 2
+    assert abs(line["value"] * line["ms_per_step"] * 1e-3 * 2 - ent_steps) < 1e-6 * ent_steps
