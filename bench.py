@@ -32,6 +32,10 @@ WORKLOADS = {
     # memory -- its own accounting: per entity-step one 8-byte |delta pose| term written by the slices and read by the ordered pass
     "c2s": dict(R=256, E=16, b_alg=16.0, stored=8.0, config=1, sliced=True),
     "c3": dict(R=4096, E=64, b_alg=114.0, stored=72.0, config=2),
+    # one GPU's shard of BASELINE.json configs[3] read literally (4096 scenarios over 8 GPUs = 512 each), PID egos, through the
+    # time-sliced path: the controller pre-pass fills one table for the whole horizon, the slices replay it.  Same accounting as
+    # c2s (final state + metrics + events, no per-step state in memory); never the headline
+    "c3s": dict(R=512, E=64, b_alg=16.0, stored=8.0, config=3, sliced=True),
     "c5": dict(R=1024, E=256, b_alg=154.0, stored=112.0, config=4),
     # the c3 batch with the RSSDistances state callback (metrics/rss/callback.py:58-128) after the reset and after every step,
     # inside the rollout kernel: + one record per entity-step (code 4 B, safe lateral / longitudinal distance 16 B)
@@ -219,7 +223,7 @@ def main(argv=None, make_engine=None):
     ap.add_argument("--entities", type=int, default=None)
     ap.add_argument("--sim-steps", type=int, default=10000)
     ap.add_argument("--ego", default="pid", choices=["pid", "replay"])
-    ap.add_argument("--workload", default="c3", choices=["c3", "c2", "c2s", "c5", "c3rss"],
+    ap.add_argument("--workload", default="c3", choices=["c3", "c2", "c2s", "c5", "c3rss", "c3s"],
                     help="BASELINE.json configs: c3 = 4096x64 PID ego (default, the headline), c2 = 256x16 replay (state of "
                          "every step materialised), c5 = 1024x256 social-force crowd; c2s = the c2 batch through the "
                          "time-sliced replay path (final state + metrics + events only: a separate mode, never the headline); c3rss = the c3 "
@@ -280,7 +284,7 @@ def main(argv=None, make_engine=None):
         def sync():
             torch.cuda.synchronize()
 
-        def make_engine(R, first):
+        def make_engine(R, first, sliced=None):
             if crowd:
                 packed = synthetic.make_crowd(R, E, n_steps=T, timestep=dt, seed=seed, first_scenario=first)
             else:
@@ -290,7 +294,8 @@ def main(argv=None, make_engine=None):
                 kw["social_force"] = dict(std_lon=0.1, std_lat=0.1, noise="device")
             eng = sga.RolloutEngine(R, E, timestep=dt, terminal_conditions=["max_length"], event_capacity=64,
                                     device=local_rank, **kw)
-            eng.set_slicing(bool(wl.get("sliced")))  # every other workload materialises the state of every step
+            # (every workload but c2s / c3s materialises the state of every step)
+            eng.set_slicing(bool(wl.get("sliced")) if sliced is None else sliced)
             if wl.get("rss"):
                 eng.set_rss(True)
             eng.upload(packed)
@@ -317,9 +322,9 @@ def main(argv=None, make_engine=None):
                      "oracle/sgym_oracle.c run over the full horizon, bit for bit")
         return v
 
-    def measure(R):
+    def measure(R, sliced=None):
         first = rank * R  # rank r owns scenarios [r R, (r + 1) R) of the seeded family (chunk-aligned: R % 64 == 0 or 1 rank)
-        eng = make_engine(R, first)
+        eng = make_engine(R, first) if sliced is None else make_engine(R, first, sliced)
 
         def one_pass():
             eng.rollout_async(T, do_reset=True)
@@ -348,6 +353,13 @@ def main(argv=None, make_engine=None):
     if world > 1:
         other = "strong" if args.scaling == "weak" else "weak"
         other_run = (other, measure(shapes[other]))
+
+    sliced_run = None
+    if world > 1 and live and args.workload == "c3":
+        # BASELINE.json configs[3] read literally leaves each GPU a shard that cannot fill it (512 wavefronts on 1024 SIMDs);
+        # the time-sliced path (workload c3s: its own accounting, final state + metrics + events) is what such a shard should
+        # run through: timed beside the step-materialised figure, never instead of it
+        sliced_run = measure(shapes["strong"], sliced=True)
 
     line = None
     if rank == 0:
@@ -407,6 +419,7 @@ def main(argv=None, make_engine=None):
             "data": "synthetic",
             "per_rank_value": m["per_rank"],
             "config": {
+                "name": args.workload,
                 "workload": (f"{R} scenarios x {E} pedestrians x {T} steps per GPU, PedestrianAgent + SocialForce "
                              f"(radius 3 m, noise {args.ped_noise}) + PedestrianController, all-pairs OBB collisions, "
                              "CollisionMetric, terminal max_length (BASELINE.json configs[4])") if crowd else
@@ -431,7 +444,7 @@ def main(argv=None, make_engine=None):
                 "traffic_ratio": (traffic / (per_launch * b_alg)) if traffic else None,
                 "stored_bytes_per_entity_step": wl["stored"],
                 "secondary": secondary,
-                "kernel": (f"sg::rollout_kernel_slice<{min(64, max(4, 1 << (E - 1).bit_length()))}>" if wl.get("sliced") else
+                "kernel": (f"sg::rollout_kernel_slice{'_tab' if ego_kind == L.KIND_AGENT_PID else ''}<{min(64, max(4, 1 << (E - 1).bit_length()))}>" if wl.get("sliced") else
                            kernel_name(E, crowd, ego_kind == L.KIND_AGENT_PID, bool(wl.get("rss")))),
                 "kernel_ms": avg_ms, "launches_per_rollout": launches_per_rollout, "rollout_device_ms": rollout_ms,
                 "bytes_per_entity_step": b_alg, "entity_steps_per_launch": per_launch,
@@ -443,12 +456,18 @@ def main(argv=None, make_engine=None):
             name, o = other_run
             line[name] = {"value": o["total"] / o["elapsed"], "ms_per_step": o["elapsed"] / args.steps * 1e3,
                           "scenarios_per_gpu": o["R"], "per_rank_value": o["per_rank"], "verified": o["verified"]}
+        if sliced_run:
+            o = sliced_run
+            line["strong_sliced"] = {"value": o["total"] / o["elapsed"], "ms_per_step": o["elapsed"] / args.steps * 1e3,
+                                     "scenarios_per_gpu": o["R"], "per_rank_value": o["per_rank"], "verified": o["verified"],
+                                     "accounting": "workload c3s: time-sliced rollout, final state + metrics + events bit-identical "
+                                                   "to the step-by-step path, the intermediate states are not written to memory"}
         if live and world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(dict(E=E, T=T, dt=dt, ego_kind=ego_kind, crowd=crowd, rss=bool(wl.get("rss"))))
         print(json.dumps(line))
     if dist is not None and (live or args.engine_factory):
         dist.destroy_process_group()
-    failed = [r for r in (main_run, other_run[1] if other_run else None) if r and r["verified"] and not r["verified"]["equal"]]
+    failed = [r for r in (main_run, other_run[1] if other_run else None, sliced_run) if r and r["verified"] and not r["verified"]["equal"]]
     if failed:
         print(f"bench: the device state DIFFERS from the oracle: {failed[0]['verified']['mismatches']}", file=sys.stderr)
         raise SystemExit(3)

@@ -29,8 +29,10 @@ def oracle_final(packed, r, dt, T, persist=False, terminal_mask=O.TERM_MAX_LENGT
     from scenario_gym_amd.packing import unpack_scenario
 
     s = unpack_scenario(packed, r)
+    # sg_rollout feeds external-action slots (0, 0) (sgym.h); the oracle wants the rows
+    actions = np.zeros((max(int(T), 1), 2)) if (np.asarray(s["kind"]) == O.KIND_AGENT_VEHICLE).any() else None
     return O.rollout(s["knot_off"], s["knots"], s["bbox"], s["etype"], s["kind"], s["ego"], s["t0"], s["length"], dt,
-                     persist=persist, terminal_mask=terminal_mask, ctrl=s["ctrl"], max_steps=T, record=record,
+                     persist=persist, terminal_mask=terminal_mask, ctrl=s["ctrl"], actions=actions, max_steps=T, record=record,
                      event_cap=event_cap, route_off=s.get("route_off"), routes=s.get("routes"), sf=sf, noise=noise)
 
 

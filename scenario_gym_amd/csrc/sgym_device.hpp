@@ -113,6 +113,7 @@ struct Params {
     int32_t rssq_cap;  // groups per wavefront
     const unsigned char *reset_mask; // [R] sg_reset_scenarios: the scenarios a do_reset == 2 launch resets
     const RoadIndex *road;   // device copy of the road index, nullptr = no road networks set
+    int ctl_general;         // 1: control_kernel without its straight-line fast path (env SG_CTL_FAST=0; the tests compare the two)
     int ped_serial;          // 1: pedestrian pair loop one pedestrian per lane (env SG_PED_SERIAL; default 0: balanced over the wavefront)
     int tab_steps;           // steps per table chunk (rows per lane = tab_steps + 1: the prefetch of the last step reads one row ahead)
     // random fluctuations of the social force (sg_set_ped_noise): 0 off, 1 stream of standard normal variates per scenario,
@@ -222,6 +223,9 @@ __constant__ double SG_TRIG[32] = {
 
 typedef const __attribute__((address_space(4))) double *ConstTbl; // constant address space: scalar loads
 
+// the kernel of sg_sincos for |x| < 1e5 (callers that have voted the range for the whole wavefront: no branch)
+__device__ __forceinline__ void sg_sincos_core(double x, double &s, double &c, ConstTbl K);
+
 __device__ __forceinline__ void sg_sincos(double x, double &s, double &c, ConstTbl K = (ConstTbl)SG_TRIG)
 {
     if (!(__builtin_fabs(x) < 1.0e5)) {
@@ -230,6 +234,11 @@ __device__ __forceinline__ void sg_sincos(double x, double &s, double &c, ConstT
         c = sc.y;
         return;
     }
+    sg_sincos_core(x, s, c, K);
+}
+
+__device__ __forceinline__ void sg_sincos_core(double x, double &s, double &c, ConstTbl K)
+{
     double fn = __builtin_rint(x * K[0]);
     int n = (int)fn;
     double t = x - fn * K[1];
@@ -256,14 +265,9 @@ __device__ __forceinline__ void sg_sincos(double x, double &s, double &c, ConstT
     c = ((n + 1) & 2) ? -cc : cc;
 }
 
-// tan(steer) of VehicleController._step (controller.py:128): same split as the oracle's sgo_tan
-__device__ __forceinline__ double sg_tan(double x, ConstTbl K)
+// the polynomial branch of sg_tan (|x| < 0.67434)
+__device__ __forceinline__ double sg_tan_poly(double x, ConstTbl K)
 {
-    if (!(__builtin_fabs(x) < 0.67434)) {
-        double s, c;
-        sg_sincos(x, s, c, K);
-        return s / c;
-    }
     ConstTbl T = K + 16;
     double z = x * x;
     double w = z * z;
@@ -273,6 +277,17 @@ __device__ __forceinline__ double sg_tan(double x, ConstTbl K)
     r = z * (s * (r + v));
     r = r + T[0] * s;
     return x + r;
+}
+
+// tan(steer) of VehicleController._step (controller.py:128): same split as the oracle's sgo_tan
+__device__ __forceinline__ double sg_tan(double x, ConstTbl K)
+{
+    if (!(__builtin_fabs(x) < 0.67434)) {
+        double s, c;
+        sg_sincos(x, s, c, K);
+        return s / c;
+    }
+    return sg_tan_poly(x, K);
 }
 
 // fp32 sin/cos of an fp64 heading for the collision broad phase and filter (never for stored state):
@@ -2446,17 +2461,22 @@ struct SliceArgs {
     sg_event *ev;        // [R][n_slices][ev_cap] CollisionMetric events of the slice
     int *nev;            // [R][n_slices]
     const int *n_final;  // [R] (mode 1) the scenario's last executed step
+    int slice0;          // first slice of this launch (blockIdx.y counts from it): batches with controlled lanes launch their
+                         // slices group by group, each group as soon as the controller pre-pass has reached its last step
 };
 
 // CROWD (PED only): every entity of the batch is a pedestrian agent (or padding), default head rotation, no road network:
 // no knot segment, no vehicle / replay code, crowd_pairs for the neighbour sums (rollout_kernel_crowd, BASELINE config 5).
-// SLICE (TAB without a table, one wavefront per tile): one slice of a time-sliced replay, see SliceArgs.
+// SLICE (TAB, one wavefront per tile): one slice of a time-sliced replay, see SliceArgs.  With HAST the controlled lanes
+// (PID / vehicle agents) replay a controller table that spans the WHOLE call -- row j - 1 = the lane after step j, written by
+// control_kernel launches that run ahead of the slices -- so a slice that starts at step a finds its lanes' poses there
+// like everything else it needs in the clock.
 template <int G, int WV, bool PED, bool TAB, bool HAST, bool ROAD = false, bool RSSV = false, bool CROWD = false, bool SLICE = false>
 __device__ __forceinline__ void rollout_body(
     const Params &p, double timestep, int n_steps, int do_reset, int force, const double *actions /*[n][R][2]*/,
     const double *tab /*controller table planes*/, const SliceArgs &sa = SliceArgs{})
 {
-    static_assert(!SLICE || (TAB && !HAST && WV == 1 && !PED && !ROAD && !RSSV), "slices replay batches without controlled lanes");
+    static_assert(!SLICE || (TAB && WV == 1 && !PED && !ROAD && !RSSV), "slices: the table variant, one wavefront per tile");
     static_assert(!(PED && TAB), "pedestrian scenarios run their controllers in the rollout kernel");
     static_assert(!CROWD || (PED && G == 64 && !ROAD && !RSSV), "the crowd variant is a pedestrian variant with 64-lane tiles");
     constexpr int NS = 64 * WV;
@@ -2610,14 +2630,17 @@ __device__ __forceinline__ void rollout_body(
             }
         }
     }
-    auto tab_issue = [&]() { // s_load the next row of every controlled lane (an unused entry re-reads the first row)
+    bool cb_hold[TL]; // wave-uniform (SLICE): the lane's slice starts at the reset state: its first row is consumed by round 1
+#pragma unroll
+    for (int j = 0; j < TL; ++j) cb_hold[j] = false;
+    auto tab_issue = [&](bool first = false) { // s_load the next row of every controlled lane (an unused entry re-reads the first row)
 #pragma unroll
         for (int j = 0; j < TL; ++j) {
             ConstTbl rowp = (ConstTbl)cb[j];
             sx[j] = rowp[CT_X];
             sy[j] = rowp[CT_Y];
             sh[j] = rowp[CT_H];
-            cb[j] += cl[j] >= 0 ? CT_W : 0;
+            cb[j] += (cl[j] >= 0 && !(SLICE && first && cb_hold[j])) ? CT_W : 0;
         }
     };
 
@@ -2697,7 +2720,7 @@ __device__ __forceinline__ void rollout_body(
     // (it has its pose from the reset on, or spawns at step 1: scenario_gym.py:240-244); everything else about that state
     // is either recomputed by the warm-up step (pose, presence of replay lanes, collision row) or not used by it.
     int slice_a = 0;
-    const int slice_s = SLICE ? (int)blockIdx.y : 0;
+    const int slice_s = SLICE ? (int)blockIdx.y + sa.slice0 : 0;
     if (SLICE) {
         slice_a = sa.mode == 0 ? slice_s * sa.len : sa.n_final[r] - 1;
         n_ev = 0;
@@ -2711,6 +2734,32 @@ __device__ __forceinline__ void rollout_body(
             for (int w = 0; w < WV; ++w) { last_row[w] = 0; row[w] = 0; }
         }
         n_steps = sa.mode == 0 ? 1 + min(sa.len, sa.n_total - slice_a) : 2;
+        if (TAB && HAST) {
+            // a controlled lane that spawns (scenario_gym.py:240-244: absent at the reset, min_t >= t0) took all six channels
+            // of its trajectory at the clock of step 1 and keeps z / pitch / roll from then on (controller.py:126-131)
+            if (slice_a >= 2 && tab_lane && fld<uint64_t>(dy, SG_F_PRESENT) == 0 && min_t >= ss.t0) {
+                const double *clk = sa.tt + (size_t)sa.clock_of[r] * (size_t)(sa.n_total + 1);
+                Table T1 = lane_table(p, kind, ss, slot, st);
+                Segment S1;
+                S1.cur = seg_locate(T1, clk[1]);
+                seg_load(T1, S1);
+                sg_loads_done();
+                const double dq1 = clk[1] - S1.x_lo;
+                pose[2] = S1.sl[2] * dq1 + S1.ylo[2];
+                pose[4] = S1.sl[4] * dq1 + S1.ylo[4];
+                pose[5] = S1.sl[5] * dq1 + S1.ylo[5];
+            }
+            // round k of this launch consumes row slice_a + k - 1 of the lane's table (round 0 is the warm-up step; a lane
+            // that starts from the reset state sits it out and holds row 0 for round 1)
+#pragma unroll
+            for (int j = 0; j < TL; ++j) {
+                if (cl[j] >= 0) {
+                    const int a_l = __builtin_amdgcn_readlane(slice_a, cl[j]);
+                    cb[j] += (size_t)max(a_l - 1, 0) * CT_W;
+                    cb_hold[j] = a_l == 0;
+                }
+            }
+        }
         sg_loads_done();
     }
     if (!TAB && (do_reset != 0 || PED)) {
@@ -2844,7 +2893,7 @@ __device__ __forceinline__ void rollout_body(
     // The row of the coming step waits in SGPRs (sx, sy, sh); the step selects it into the controlled lane with
     // scalar-source v_cndmask and then issues the loads of the row after it.
     constexpr bool has_tab = TAB && HAST;
-    if (has_tab && n_steps > 0) tab_issue();
+    if (has_tab && n_steps > 0) tab_issue(true);
 
     // Two nested loops over the same step counter.  The inner one is the steady state and only READS the knot
     // segment S; when some lane's clock is about to cross a knot the wavefront drops to the outer loop, which
@@ -3264,7 +3313,8 @@ __device__ __forceinline__ void rollout_body(
                             // 5 = non_vehicle; Vehicle hazards (15 here, -1 once unpacked) wait for classify_events_kernel.
                             // The table variant packs the step of this launch above bit 4: the row of the controller
                             // table that holds the ego's pose at the event (event_ego_pose_kernel unpacks it)
-                            head.type = (((ometa >> 8) & 0xff) == 0 ? (TAB ? 15 : -1) : 5) | (TAB ? (k + 1) << 4 : 0);
+                            // (slices: the table spans the call, the row is the step itself)
+                            head.type = (((ometa >> 8) & 0xff) == 0 ? (TAB ? 15 : -1) : 5) | (TAB ? (SLICE ? steps : k + 1) << 4 : 0);
                             head.reserved = 0;
                             *reinterpret_cast<decltype(head) *>(dst) = head;
                             if (!TAB) { // (overwritten below when the hazard is a controlled agent; table launches: event_ego_pose_kernel)
@@ -3317,6 +3367,12 @@ __device__ __forceinline__ void rollout_body(
 #pragma unroll
                 for (int w = 0; w < WV; ++w) sd.last_row[w] = last_row[w];
             }
+        }
+        if (TAB && HAST && sa.mode == 1 && in_range && tab_lane) { // controller state after the last executed step
+            const double *lr = tab + (size_t)ctl_q * tab_lane_stride + (size_t)(sa.n_final[r] - 1) * CT_W;
+            const double *lr1 = lr + (size_t)p.n_ctl_pad * tab_lane_stride; // plane 1
+            stf(dy, SG_F_CTRL + 0, lr[CT_SPEED]); stf(dy, SG_F_CTRL + 1, lr1[CT_ELON]);
+            stf(dy, SG_F_CTRL + 2, lr1[CT_ELAT]); stf(dy, SG_F_CTRL + 3, lr1[CT_EINT]);
         }
         return;
     }
@@ -3423,6 +3479,12 @@ __global__ __launch_bounds__(64, SG_WAVES_PER_SIMD_TAB) void rollout_kernel_slic
 {
     rollout_body<G, 1, false, true, false, false, false, false, true>(p, timestep, 0, 0, 0, nullptr, nullptr, sa);
 }
+// ... of a batch with controlled lanes: `tab` = the controller table of the whole call (p.tab_steps = sa.n_total)
+template <int G>
+__global__ __launch_bounds__(64, SG_WAVES_PER_SIMD_TAB) void rollout_kernel_slice_tab(Params p, double timestep, SliceArgs sa, const double *tab)
+{
+    rollout_body<G, 1, false, true, true, false, false, false, true>(p, timestep, 0, 0, 0, nullptr, tab, sa);
+}
 
 // The clocks of a sliced replay: tt[c][j] = State.t after j steps = t0_c + dt + dt + ... (scenario_gym.py:229), the
 // additions of the step loop itself; scenarios with the same start time share a clock (launch_sliced).  One lane per clock.
@@ -3505,6 +3567,7 @@ __global__ __launch_bounds__(64) void replay_fixup_kernel(Params p, SliceArgs sa
     }
 }
 
+// (a controlled ego is no different here: the slices leave its speeds like a replay ego's, the pre-pass skips the metrics)
 __global__ __launch_bounds__(64) void replay_scenario_fixup_kernel(Params p, SliceArgs sa, const int *n_final, const int *done_in)
 {
     const int lane = threadIdx.x;
@@ -3596,8 +3659,20 @@ __global__ __launch_bounds__(64) void replay_scenario_fixup_kernel(Params p, Sli
 // kernel compiles for 5 wavefronts per SIMD = 96 VGPRs, which is what fits beside two wavefronts of the rollout kernel.
 struct CtlLds { double ctrl[9][64]; double seg[5][64]; };
 
-__global__ __launch_bounds__(64, SG_CTL_WAVES) void control_kernel(Params p, double timestep, int n_steps, int first, int k0,
-                                                     const double *actions /*[n][R][2]*/, double *tab, int row0)
+//   metrics: run the ego's EgoAvgSpeed / EgoMaxSpeed recurrences here (plane 2).  The time-sliced path passes 0: its ordered
+//          pass computes them from the speeds the slices leave, and the pre-pass -- a chain of T dependent steps on a handful
+//          of wavefronts, the critical path of that mode -- is shorter without them.
+// The steady state of a PID lane runs as one straight-line block (`fast` below): every division with a step-invariant or
+// shared denominator through a refined reciprocal (RecipDiv: the same bits as `/` inside its operand range), the range
+// checks of sin / cos / tan and of the reciprocals as ONE wavefront vote, selects instead of lane branches.  A step in which
+// some lane spawns, crosses a knot, saturates its steering beyond the tangent polynomial's range or leaves RecipDiv's range
+// runs the general code below it.  Same operations on the same operands in the same order: same bits
+// (test_controller_prepass_equals_inline_controllers, SG_CTL_FAST=0 forces the general code).
+// FAST: compiled in for control_kernel_fast only (the time-sliced path, where the pre-pass is alone on the chip and has no
+// register budget to keep); control_kernel -- co-resident with the rollout kernel under 128 VGPRs -- stays as it was.
+template <bool FAST>
+__device__ __forceinline__ void control_body(const Params &p, double timestep, int n_steps, int first, int k0,
+                                             const double *actions /*[n][R][2]*/, double *tab, int row0, int metrics)
 {
     __shared__ CtlLds lds;
     const int lane = threadIdx.x;
@@ -3669,6 +3744,9 @@ __global__ __launch_bounds__(64, SG_CTL_WAVES) void control_kernel(Params p, dou
     double *out1 = out + (size_t)p.n_ctl_pad * ((size_t)(p.tab_steps + 1) * CT_W); // plane 1
     double *out2 = out1 + (size_t)p.n_ctl_pad * ((size_t)(p.tab_steps + 1) * CT_W); // plane 2
     sg_loads_done();
+    // launch-invariant part of the fast path's vote; reciprocals of the step-invariant denominators
+    const bool fast_kind = FAST && !p.ctl_general && sg_all(!active || (kind == SG_KIND_AGENT_PID && bl > 0.0 && bl < 0x1p400));
+    const RecipDiv rd_l(active ? bl : 1.0), rd_10(10.0);
 
     for (int k = 0; k < n_steps; ++k) {
         const double *Kp = SG_TRIG;
@@ -3677,6 +3755,74 @@ __global__ __launch_bounds__(64, SG_CTL_WAVES) void control_kernel(Params p, dou
         const double next_t = t + timestep; // the rollout kernel's clock, scenario_gym.py:229
         const double state_dt = t - prev_t;
         const double dt = next_t - t;
+        if (FAST && fast_kind && sg_all(!active || (present && !(next_t > seg_hi) && __builtin_fabs(pose[3]) < 1.0e5))) {
+            // ---- PIDController._step + VehicleController._step (controller.py:205-258, 105-140), straight line ----
+            const double dq = next_t - lds.seg[0][lane];
+            const double tx = lds.seg[3][lane] * dq + lds.seg[1][lane], ty = lds.seg[4][lane] * dq + lds.seg[2][lane];
+            double sin_h, cos_h;
+            sg_sincos_core(pose[3], sin_h, cos_h, K);
+            const double e0 = tx - pose[0], e1 = ty - pose[1];
+            const double e_lon = cos_h * e0 + sin_h * e1;
+            const double e_lat = -sin_h * e0 + cos_h * e1;
+            const double speed0 = cs.speed;
+            const double g_mid = 1.0 - rd_10.div(0.9 * (speed0 - 5.0)); // (speed in (5, 15]: the numerator is in RecipDiv's range)
+            const double gain = (speed0 > 5.0 && speed0 <= 15) ? g_mid : (speed0 > 15 ? 0.1 : 1.0);
+            const RecipDiv rd(state_dt);
+            const double d_lat = e_lat - cs.e_lat_prev, d_lon = e_lon - cs.e_lon_prev;
+            const double e_lat_D = rd.div(d_lat);
+            const double kp = lds.ctrl[SG_C_STEER_KP][lane] * gain, kd = lds.ctrl[SG_C_STEER_KD][lane] * gain;
+            double steer = kp * e_lat + kd * e_lat_D;
+            const double e_lon_D = rd.div(d_lon);
+            const double e_lon_I = cs.e_lon_int + e_lon * state_dt;
+            double accel = lds.ctrl[SG_C_ACCEL_KP][lane] * e_lon + lds.ctrl[SG_C_ACCEL_KD][lane] * e_lon_D + lds.ctrl[SG_C_ACCEL_KI][lane] * e_lon_I;
+            accel = __builtin_fabs(e_lon) > 0.1 ? accel : 0.0;
+            const double max_steer = lds.ctrl[SG_C_MAX_STEER][lane], max_accel = lds.ctrl[SG_C_MAX_ACCEL][lane];
+            const double max_speed = lds.ctrl[SG_C_MAX_SPEED][lane], allow_rev = lds.ctrl[SG_C_ALLOW_REVERSE][lane];
+            accel = __builtin_fmin(__builtin_fmax(accel, -max_accel), max_accel);
+            steer = __builtin_fmin(__builtin_fmax(steer, -max_steer), max_steer);
+            const double dxs = speed0 * cos_h, dys = speed0 * sin_h;
+            // tan(steer): the polynomial below 0.67434, sin / cos above (sg_tan); a saturated steering angle is common
+            // enough among 64 lanes that both live here, the second under a wave-uniform branch
+            double tan_s = sg_tan_poly(steer, K);
+            const bool steep = !(__builtin_fabs(steer) < 0.67434);
+            if (sg_any(steep & active)) {
+                double s2, c2;
+                sg_sincos_core(steer, s2, c2, K);
+                tan_s = steep ? s2 / c2 : tan_s;
+            }
+            const double hnum = speed0 * tan_s;
+            const double dh = hnum == 0.0 ? hnum : rd_l.div(hnum); // (+-0 / l = +-0 for l > 0)
+            const double nx = pose[0] + dxs * dt, ny = pose[1] + dys * dt, nh = pose[3] + dh * dt;
+            double nspeed = speed0 + accel * dt;
+            nspeed = allow_rev == 0.0 ? __builtin_fmax(0.0, nspeed) : nspeed;
+            nspeed = max_speed == max_speed ? __builtin_fmin(max_speed, nspeed) : nspeed;
+            // the one vote on everything the straight-line forms assumed
+            bool ok = rd.safe(d_lat) & rd.safe(d_lon) & (__builtin_fabs(steer) < 1.0e5) & (rd_l.safe(hnum) | (hnum == 0.0));
+            // State.update_statistics for the ego + its metrics (state.py:230-239, metrics/trajectory.py:19-24, 41-44)
+            double n_avg = m_avg, n_max = m_max, n_mt = m_t;
+            if (metrics) { // (launch-uniform)
+                const RecipDiv rdt(dt), rnt(next_t);
+                const double ax = nx - pose[0], ay = ny - pose[1];
+                const double az = pose[2] - pose[2]; // z stays (controller.py:126-131): +0 unless it is not finite
+                const double speed = sg_norm3(rdt.div(ax), rdt.div(ay), 0.0); // (+0 / dt = +0)
+                const double w = rnt.div(m_t);
+                n_avg = m_avg + (1.0 - w) * (speed - m_avg);
+                n_max = __builtin_fmax(speed, m_max);
+                n_mt = next_t;
+                ok = ok & (!is_ego | (rdt.safe(ax) & rdt.safe(ay) & rnt.safe(m_t) & (dt > 0.0) & (az == 0.0)));
+            }
+            if (sg_all(!active || ok)) {
+                cs.e_lat_prev = e_lat; cs.e_lon_prev = e_lon; cs.e_lon_int = e_lon_I; cs.speed = nspeed;
+                pose[0] = nx; pose[1] = ny; pose[3] = nh;
+                if (is_ego) { m_avg = n_avg; m_max = n_max; m_t = n_mt; }
+                prev_t = t;
+                t = next_t;
+                *reinterpret_cast<double4 *>(out + (size_t)k * CT_W) = make_double4(pose[0], pose[1], pose[3], cs.speed);
+                *reinterpret_cast<double4 *>(out1 + (size_t)k * CT_W) = make_double4(cs.e_lon_prev, cs.e_lat_prev, cs.e_lon_int, 0.0);
+                if (is_ego && metrics) *reinterpret_cast<double4 *>(out2 + (size_t)k * CT_W) = make_double4(m_avg, m_max, m_t, 0.0);
+                continue;
+            }
+        }
         double act_a = 0.0, act_s = 0.0;
         if (kind == SG_KIND_AGENT_VEHICLE && actions) {
             const double *a = actions + ((size_t)(k0 + k) * p.R + r) * 2;
@@ -3718,7 +3864,7 @@ __global__ __launch_bounds__(64, SG_CTL_WAVES) void control_kernel(Params p, dou
 #pragma unroll
             for (int c = 0; c < 6; ++c) np_[c] = S.sl[c] * dqs + S.ylo[c];
         }
-        if (is_ego && npres) { // State.update_statistics for this lane (state.py:230-239) + the ego metrics
+        if (is_ego && npres && metrics) { // State.update_statistics for this lane (state.py:230-239) + the ego metrics
             double prev[6];
             if (!present) { // newcomer: previous pose from the extrapolated trajectory, state.py:219-222
                 own_position_extrap(T.x, T.n, t, prev);
@@ -3743,7 +3889,7 @@ __global__ __launch_bounds__(64, SG_CTL_WAVES) void control_kernel(Params p, dou
         t = next_t;
         *reinterpret_cast<double4 *>(out + (size_t)k * CT_W) = make_double4(pose[0], pose[1], pose[3], cs.speed);
         *reinterpret_cast<double4 *>(out1 + (size_t)k * CT_W) = make_double4(cs.e_lon_prev, cs.e_lat_prev, cs.e_lon_int, 0.0);
-        if (is_ego) *reinterpret_cast<double4 *>(out2 + (size_t)k * CT_W) = make_double4(m_avg, m_max, m_t, 0.0);
+        if (is_ego && metrics) *reinterpret_cast<double4 *>(out2 + (size_t)k * CT_W) = make_double4(m_avg, m_max, m_t, 0.0);
     }
 #pragma unroll
     for (int c = 0; c < 6; ++c) cst[(CS_POSE + c) * NP] = pose[c];
@@ -3753,6 +3899,17 @@ __global__ __launch_bounds__(64, SG_CTL_WAVES) void control_kernel(Params p, dou
     cst[CS_T * NP] = t;
     cst[CS_PREV_T * NP] = prev_t;
     cst[(CS_METRIC + 0) * NP] = m_avg; cst[(CS_METRIC + 1) * NP] = m_max; cst[(CS_METRIC + 2) * NP] = m_t;
+}
+
+__global__ __launch_bounds__(64, SG_CTL_WAVES) void control_kernel(Params p, double timestep, int n_steps, int first, int k0,
+                                                     const double *actions /*[n][R][2]*/, double *tab, int row0, int metrics)
+{
+    control_body<false>(p, timestep, n_steps, first, k0, actions, tab, row0, metrics);
+}
+__global__ __launch_bounds__(64, 1) void control_kernel_fast(Params p, double timestep, int n_steps, int first, int k0,
+                                                             const double *actions /*[n][R][2]*/, double *tab, int row0, int metrics)
+{
+    control_body<true>(p, timestep, n_steps, first, k0, actions, tab, row0, metrics);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -36,12 +36,14 @@ struct sg_handle {
     sg_config cfg{};
     int R = 0, E = 0, EP = 0, G = 0, WV = 1;
     bool has_ped = false;
-    bool all_replay = false;  // every entity is a replay entity / replay agent (or padding): the batch can be time-sliced
+    bool sliceable = false;   // every entity is a replay entity / replay agent / PID or vehicle agent (or padding): the batch
+                              // can be time-sliced (launch_sliced)
     int slice_mode = 1;       // sg_set_tuning / env SG_SLICE: 0 never, 1 automatic (small batches, long rollouts)
     std::vector<void *> slice_allocs; // device arrays of launch_sliced, kept between calls of the same shape
     int slice_T = -1, slice_S = 0;
     sg::SliceArgs slice_args{};
     int *d_n_final = nullptr, *d_slice_done = nullptr;
+    double *d_slice_tab = nullptr; // the controller table of a whole sliced call (batches with PID / vehicle agents)
     std::vector<double> clock_t0;  // distinct scenario start times (ScenarioGym.get_start_time): one clock each
     std::vector<int> clock_of;     // [R]
     double *d_clock_t0 = nullptr;
@@ -486,7 +488,7 @@ static int launch_rollout(sg_handle *h, int n_steps, int do_reset, int force, co
                 for (int s0 = 0; s0 < n; s0 += h->ctl_slice) { // short launches: the pre-pass load moves between SIMDs
                     const int ns = std::min(h->ctl_slice, n - s0);
                     sg::control_kernel<<<cgrid, cblock, 0, cs>>>(h->p, h->cfg.timestep, ns, c == 0 && s0 == 0, k0 + s0,
-                                                                 d_actions, tab, s0);
+                                                                 d_actions, tab, s0, 1);
                 }
                 HIP_TRY(h, hipGetLastError());
                 if (!no_overlap) {
@@ -505,114 +507,190 @@ static int launch_rollout(sg_handle *h, int n_steps, int do_reset, int force, co
     return SG_OK;
 }
 
-// ScenarioGym.rollout for a batch of replay entities / replay agents only, time-sliced (sgym_device.hpp, SliceArgs): the
-// reset launch, the clock, the slices of the time axis side by side, the last executed step with the full state stores,
-// the ordered sums.  Worth it when the batch alone cannot fill the chip (BASELINE config 2: 64 wavefronts); the results
-// are bit-identical to launch_rollout's, the intermediate states are not written anywhere.
+// ScenarioGym.rollout time-sliced (sgym_device.hpp, SliceArgs): the reset launch, the clock, the slices of the time axis
+// side by side, the last executed step with the full state stores, the ordered sums.  For batches whose lanes are replay
+// entities / replay agents -- and PID / vehicle agents: their controller pre-pass (control_kernel) then fills ONE table for
+// the whole call, running ahead of the slices group by group.  Worth it when the batch alone cannot fill the chip (BASELINE
+// config 2: 64 wavefronts; config 4's shards: 512); the results are bit-identical to launch_rollout's, the intermediate
+// states are not written anywhere.
 template <int G>
-static void launch_slice_kernels(sg_handle *h, const sg::SliceArgs &sa, dim3 grid)
+static void launch_slice_kernels(sg_handle *h, const Params &ps, const sg::SliceArgs &sa, dim3 grid, const double *tab)
 {
-    sg::rollout_kernel_slice<G><<<grid, dim3(64), 0, h->stream>>>(h->p, h->cfg.timestep, sa);
+    if (tab) sg::rollout_kernel_slice_tab<G><<<grid, dim3(64), 0, h->stream>>>(ps, h->cfg.timestep, sa, tab);
+    else sg::rollout_kernel_slice<G><<<grid, dim3(64), 0, h->stream>>>(ps, h->cfg.timestep, sa);
 }
-template <int G>
-static void launch_fixup_kernel(sg_handle *h, const sg::SliceArgs &sa)
+static void launch_slice_kernels(sg_handle *h, const Params &ps, const sg::SliceArgs &sa, dim3 grid, const double *tab)
 {
-    sg::replay_fixup_kernel<G><<<dim3((unsigned)(h->NE / 64)), dim3(64), 0, h->stream>>>(h->p, sa, h->d_n_final);
+    switch (h->G) {
+    case 4: launch_slice_kernels<4>(h, ps, sa, grid, tab); break;
+    case 8: launch_slice_kernels<8>(h, ps, sa, grid, tab); break;
+    case 16: launch_slice_kernels<16>(h, ps, sa, grid, tab); break;
+    case 32: launch_slice_kernels<32>(h, ps, sa, grid, tab); break;
+    default: launch_slice_kernels<64>(h, ps, sa, grid, tab); break;
+    }
+}
+static void launch_fixup_kernel(sg_handle *h, const Params &ps, const sg::SliceArgs &sa)
+{
+    const dim3 grid((unsigned)(h->NE / 64)), block(64);
+    switch (h->G) {
+    case 4: sg::replay_fixup_kernel<4><<<grid, block, 0, h->stream>>>(ps, sa, h->d_n_final); break;
+    case 8: sg::replay_fixup_kernel<8><<<grid, block, 0, h->stream>>>(ps, sa, h->d_n_final); break;
+    case 16: sg::replay_fixup_kernel<16><<<grid, block, 0, h->stream>>>(ps, sa, h->d_n_final); break;
+    case 32: sg::replay_fixup_kernel<32><<<grid, block, 0, h->stream>>>(ps, sa, h->d_n_final); break;
+    default: sg::replay_fixup_kernel<64><<<grid, block, 0, h->stream>>>(ps, sa, h->d_n_final); break;
+    }
+}
+
+// slices, steps per slice and slices per launch group for a call of n_steps
+struct SlicePlan { int S, len, SG; size_t bytes; };
+
+static SlicePlan slice_plan(const sg_handle *h, int n_steps)
+{
+    const size_t nblk = h->NE / 64, R = (size_t)h->R, T1 = (size_t)n_steps + 1;
+    const bool ctl = h->n_ctl > 0;
+    SlicePlan pl{};
+    // enough slices for ~4096 wavefronts per launch (mode 2, the tests' "always": short slices too)
+    pl.SG = (int)std::max<size_t>(1, 4096 / nblk);
+    if (ctl && h->slice_mode == 2) pl.SG = std::min(pl.SG, 8); // (the tests: several groups even for short calls)
+    if (!ctl) { // one launch: all slices side by side, at least 64 steps each
+        int S = (int)std::min<size_t>((size_t)pl.SG, (size_t)std::max(1, n_steps / (h->slice_mode == 2 ? 7 : 64)));
+        pl.len = (n_steps + S - 1) / S;
+        pl.S = (n_steps + pl.len - 1) / pl.len;
+        pl.SG = pl.S;
+    } else { // groups of SG slices of ~160 steps: a group starts when the pre-pass has passed its last step
+        pl.len = std::min(n_steps, h->slice_mode == 2 ? 7 : std::max(16, env_int("SG_SLICE_LEN", 160)));
+        pl.S = (n_steps + pl.len - 1) / pl.len;
+    }
+    // every array of the sliced path: |delta pose| rows, clocks, ego speeds, per-slice events and flags, and
+    // the call-spanning controller table
+    pl.bytes = nblk * T1 * 512 + h->clock_t0.size() * T1 * 8 + R * T1 * 16 +
+               R * (size_t)pl.S * ((size_t)std::max(h->p.ev_cap, 1) * sizeof(sg_event) + 8) + R * 8 +
+               (ctl ? (size_t)sg::CT_PLANES * sg::CT_W * (size_t)h->p.n_ctl_pad * T1 * 8 : 0);
+    return pl;
 }
 
 static bool slicing_pays(const sg_handle *h, int n_steps)
 {
-    if (!h->slice_mode || !h->all_replay || h->WV != 1 || h->p.rec_cap > 0 || h->rss_enabled || h->n_ext > 0 ||
+    if (!h->slice_mode || !h->sliceable || h->WV != 1 || h->p.rec_cap > 0 || h->rss_enabled || h->n_ext > 0 ||
         (h->cfg.terminal_mask & SG_TERM_EGO_OFF_ROAD) || n_steps < (h->slice_mode == 2 ? 2 : 512))
         return false;
+    if (h->n_ctl > 0 && h->max_ctl_per_block > SG_TAB_LANES(h->G, h->WV)) return false; // (as launch_rollout's table path)
     const size_t nblk = h->NE / 64;
     if (nblk >= 1024 && h->slice_mode != 2) return false; // the batch fills the chip by itself (two wavefronts per SIMD on half of it)
-    const size_t bytes = nblk * (size_t)(n_steps + 1) * 512; // the |delta pose| rows
-    return bytes <= ((size_t)8 << 30);
+    return slice_plan(h, n_steps).bytes <= ((size_t)std::max(1, env_int("SG_SLICE_MB", 8192)) << 20);
 }
 
+// SG_OK, an error, or SG_SLICE_FALLBACK: the arrays could not be allocated -- the caller takes the step-by-step path
+#define SG_SLICE_FALLBACK 1
 static int launch_sliced(sg_handle *h, int n_steps)
 {
     const int R = h->R;
     const size_t nblk = h->NE / 64;
-    // enough slices for ~4096 wavefronts, at least 64 steps each (mode 2, the tests' "always": short slices too)
-    int S = (int)std::min<size_t>(std::max<size_t>(1, 4096 / nblk), (size_t)std::max(1, n_steps / (h->slice_mode == 2 ? 7 : 64)));
-    const int len = (n_steps + S - 1) / S;
-    S = (n_steps + len - 1) / len;
+    const bool ctl = h->n_ctl > 0;
+    const SlicePlan pl = slice_plan(h, n_steps);
+    const int S = pl.S, len = pl.len;
     int rc;
     if (h->slice_T != n_steps || h->slice_S != S) {
         HIP_TRY(h, hipStreamSynchronize(h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->ctl_stream));
         free_pool(h->slice_allocs);
+        h->slice_T = -1;
         auto &A = h->slice_allocs;
         sg::SliceArgs sa{};
         double *tt = nullptr;
-        if ((rc = dev_alloc(h, A, &tt, (size_t)(n_steps + 1) * h->clock_t0.size(), false))) return rc;
-        sa.tt = tt;
-        if ((rc = dev_upload(h, A, &sa.clock_of, h->clock_of))) return rc;
         const double *ct0 = nullptr;
-        if ((rc = dev_upload(h, A, &ct0, h->clock_t0))) return rc;
+        h->d_slice_tab = nullptr;
+        rc = dev_alloc(h, A, &tt, (size_t)(n_steps + 1) * h->clock_t0.size(), false);
+        sa.tt = tt;
+        if (!rc) rc = dev_upload(h, A, &sa.clock_of, h->clock_of);
+        if (!rc) rc = dev_upload(h, A, &ct0, h->clock_t0);
         h->d_clock_t0 = const_cast<double *>(ct0);
+        if (!rc) rc = dev_alloc(h, A, &sa.dnorm, nblk * (size_t)(n_steps + 1) * 64, false);
+        if (!rc) rc = dev_alloc(h, A, &sa.espeed, (size_t)R * (n_steps + 1), false);
+        if (!rc) rc = dev_alloc(h, A, &sa.first_done, (size_t)R * S, false);
+        if (!rc) rc = dev_alloc(h, A, &sa.ev, (size_t)R * S * std::max(h->p.ev_cap, 1), false);
+        if (!rc) rc = dev_alloc(h, A, &sa.nev, (size_t)R * S, false);
+        if (!rc) rc = dev_alloc(h, A, &h->d_n_final, (size_t)R, false);
+        if (!rc) rc = dev_alloc(h, A, &h->d_slice_done, (size_t)R, false);
+        if (!rc && ctl)
+            rc = dev_alloc(h, A, &h->d_slice_tab, (size_t)sg::CT_PLANES * sg::CT_W * (size_t)h->p.n_ctl_pad * (size_t)(n_steps + 1), false);
+        if (rc) { // out of device memory: not an error of the call -- the plain path needs none of these arrays
+            (void)hipGetLastError();
+            (void)hipStreamSynchronize(h->stream);
+            free_pool(h->slice_allocs);
+            h->err.clear();
+            return SG_SLICE_FALLBACK;
+        }
         HIP_TRY(h, hipStreamSynchronize(h->stream));
-        if ((rc = dev_alloc(h, A, &sa.dnorm, nblk * (size_t)(n_steps + 1) * 64, false))) return rc;
-        if ((rc = dev_alloc(h, A, &sa.espeed, (size_t)R * (n_steps + 1), false))) return rc;
-        if ((rc = dev_alloc(h, A, &sa.first_done, (size_t)R * S, false))) return rc;
-        if ((rc = dev_alloc(h, A, &sa.ev, (size_t)R * S * std::max(h->p.ev_cap, 1), false))) return rc;
-        if ((rc = dev_alloc(h, A, &sa.nev, (size_t)R * S, false))) return rc;
-        if ((rc = dev_alloc(h, A, &h->d_n_final, (size_t)R, false))) return rc;
-        if ((rc = dev_alloc(h, A, &h->d_slice_done, (size_t)R, false))) return rc;
         sa.n_slices = S; sa.len = len; sa.n_total = n_steps;
         h->slice_args = sa;
         h->slice_T = n_steps;
         h->slice_S = S;
     }
     sg::SliceArgs sa = h->slice_args;
+    Params ps = h->p;      // the kernels of this path address the controller table with the call's length
+    ps.tab_steps = n_steps;
+    const double *tab = ctl ? h->d_slice_tab : nullptr;
     h->n_launches = 0;
     h->launch_ev.clear();
     h->timing_now = true;
     size_t ev_next = 0;
     HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
     if ((rc = launch_main(h, 0, 1, 0, nullptr, nullptr, false, &ev_next))) return rc; // State.reset (not counted as a hot-path launch)
+    hipEvent_t e_reset = nullptr;
+    if (ctl) { // the pre-pass reads the reset state
+        if ((rc = get_event(h, ev_next++, &e_reset))) return rc;
+        HIP_TRY(h, hipEventRecord(e_reset, h->stream));
+        HIP_TRY(h, hipStreamWaitEvent(h->ctl_stream, e_reset, 0));
+    }
     HIP_TRY(h, hipMemsetAsync(sa.first_done, 0x7f, (size_t)R * S * sizeof(int), h->stream)); // 0x7f7f7f7f: "never"
     HIP_TRY(h, hipMemsetAsync(sa.nev, 0, (size_t)R * S * sizeof(int), h->stream));
     const int n_clocks = (int)h->clock_t0.size();
     sg::clock_kernel<<<dim3((unsigned)((n_clocks + 63) / 64)), dim3(64), 0, h->stream>>>(h->d_clock_t0, n_clocks, h->cfg.timestep, n_steps,
                                                                                         const_cast<double *>(sa.tt));
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if ((rc = get_event(h, ev_next, &e0)) || (rc = get_event(h, ev_next + 1, &e1))) return rc;
-    HIP_TRY(h, hipEventRecord(e0, h->stream));
-    const dim3 grid((unsigned)nblk, (unsigned)S);
     sa.mode = 0;
-    switch (h->G) {
-    case 4: launch_slice_kernels<4>(h, sa, grid); break;
-    case 8: launch_slice_kernels<8>(h, sa, grid); break;
-    case 16: launch_slice_kernels<16>(h, sa, grid); break;
-    case 32: launch_slice_kernels<32>(h, sa, grid); break;
-    default: launch_slice_kernels<64>(h, sa, grid); break;
+    const int ctl_len = std::max(1, env_int("SG_SLICE_CTL_STEPS", 2048)); // steps per control_kernel launch
+    for (int s0 = 0; s0 < S; s0 += pl.SG) {
+        const int ns = std::min(pl.SG, S - s0);
+        if (ctl) { // rows (s0 * len, (s0 + ns) * len] of the table, then the event the group waits for
+            const int k0 = s0 * len, k1 = std::min(n_steps, (s0 + ns) * len);
+            const dim3 cgrid((unsigned)(ps.n_ctl_pad / 64)), cblock(64);
+            for (int k = k0; k < k1; k += ctl_len)
+                sg::control_kernel_fast<<<cgrid, cblock, 0, h->ctl_stream>>>(ps, h->cfg.timestep, std::min(ctl_len, k1 - k), k == 0, k, nullptr,
+                                                                        h->d_slice_tab, k, 0);
+            HIP_TRY(h, hipGetLastError());
+            hipEvent_t e_c = nullptr;
+            if ((rc = get_event(h, ev_next++, &e_c))) return rc;
+            HIP_TRY(h, hipEventRecord(e_c, h->ctl_stream));
+            HIP_TRY(h, hipStreamWaitEvent(h->stream, e_c, 0));
+        }
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if ((rc = get_event(h, ev_next, &e0)) || (rc = get_event(h, ev_next + 1, &e1))) return rc;
+        HIP_TRY(h, hipEventRecord(e0, h->stream));
+        sa.slice0 = s0;
+        launch_slice_kernels(h, ps, sa, dim3((unsigned)nblk, (unsigned)ns), tab);
+        HIP_TRY(h, hipGetLastError());
+        HIP_TRY(h, hipEventRecord(e1, h->stream));
+        h->launch_ev.push_back((int)ev_next);
+        ++h->n_launches;
+        ev_next += 2;
     }
-    HIP_TRY(h, hipGetLastError());
-    HIP_TRY(h, hipEventRecord(e1, h->stream));
-    h->launch_ev.push_back((int)ev_next);
-    ++h->n_launches;
-    ev_next += 2;
-    sg::slice_final_kernel<<<dim3((unsigned)((R + 63) / 64)), dim3(64), 0, h->stream>>>(h->p, sa, h->d_n_final, h->d_slice_done);
+    sa.slice0 = 0;
+    sg::slice_final_kernel<<<dim3((unsigned)((R + 63) / 64)), dim3(64), 0, h->stream>>>(ps, sa, h->d_n_final, h->d_slice_done);
     {   // the per-scenario ordered pass (a serial recurrence per scenario) on the second stream, beside the last step and the
         // per-entity pass
         hipEvent_t e_nf = nullptr;
         if ((rc = get_event(h, ev_next++, &e_nf))) return rc;
         HIP_TRY(h, hipEventRecord(e_nf, h->stream));
         HIP_TRY(h, hipStreamWaitEvent(h->ctl_stream, e_nf, 0));
-        sg::replay_scenario_fixup_kernel<<<dim3((unsigned)((R + 63) / 64)), dim3(64), 0, h->ctl_stream>>>(h->p, sa, h->d_n_final, h->d_slice_done);
+        sg::replay_scenario_fixup_kernel<<<dim3((unsigned)((R + 63) / 64)), dim3(64), 0, h->ctl_stream>>>(ps, sa, h->d_n_final, h->d_slice_done);
+        if (ctl && h->p.ev_cap > 0) // the controlled egos' (and hazards') poses at the events: rows of the table
+            sg::event_ego_pose_kernel<<<dim3((unsigned)R), dim3(64), 0, h->ctl_stream>>>(ps, tab);
     }
     sa.mode = 1;
     sa.n_final = h->d_n_final;
-    const dim3 grid1((unsigned)nblk, 1);
-    switch (h->G) {
-    case 4: launch_slice_kernels<4>(h, sa, grid1); launch_fixup_kernel<4>(h, sa); break;
-    case 8: launch_slice_kernels<8>(h, sa, grid1); launch_fixup_kernel<8>(h, sa); break;
-    case 16: launch_slice_kernels<16>(h, sa, grid1); launch_fixup_kernel<16>(h, sa); break;
-    case 32: launch_slice_kernels<32>(h, sa, grid1); launch_fixup_kernel<32>(h, sa); break;
-    default: launch_slice_kernels<64>(h, sa, grid1); launch_fixup_kernel<64>(h, sa); break;
-    }
+    launch_slice_kernels(h, ps, sa, dim3((unsigned)nblk, 1), tab);
+    launch_fixup_kernel(h, ps, sa);
     HIP_TRY(h, hipGetLastError());
     {
         hipEvent_t e_sc = nullptr;
@@ -693,11 +771,12 @@ extern "C" int sg_upload(sg_handle *h, const sg_scenarios *sc)
     // pedestrian agents are compiled for tiles of >= 16 lanes
     h->has_ped = false;
     h->all_ped = true;
-    h->all_replay = true;
+    h->sliceable = true;
     free_pool(h->slice_allocs);
     h->slice_T = -1;
     for (size_t i = 0; i < (size_t)h->R * h->E; ++i) {
-        h->all_replay = h->all_replay && (sc->kind[i] == SG_KIND_NONE || sc->kind[i] == SG_KIND_REPLAY || sc->kind[i] == SG_KIND_AGENT_REPLAY);
+        h->sliceable = h->sliceable && (sc->kind[i] == SG_KIND_NONE || sc->kind[i] == SG_KIND_REPLAY || sc->kind[i] == SG_KIND_AGENT_REPLAY ||
+                                        sc->kind[i] == SG_KIND_AGENT_PID || sc->kind[i] == SG_KIND_AGENT_VEHICLE);
         h->has_ped = h->has_ped || sc->kind[i] == SG_KIND_AGENT_PEDESTRIAN;
         h->all_ped = h->all_ped && (sc->kind[i] == SG_KIND_NONE || (sc->kind[i] == SG_KIND_AGENT_PEDESTRIAN && sc->etype[i] == 1));
     }
@@ -929,6 +1008,7 @@ extern "C" int sg_upload(sg_handle *h, const sg_scenarios *sc)
     p.sf = h->sf;
     apply_noise(h);
     p.ped_serial = h->ped_serial;
+    p.ctl_general = env_int("SG_CTL_FAST", 1) == 0;
     p.reset_mask = h->d_reset_mask;
     p.persist = h->cfg.persist;
     p.term_mask = h->cfg.terminal_mask;
@@ -1277,7 +1357,10 @@ extern "C" int sg_rollout_async(sg_handle *h, int32_t max_steps, int32_t do_rese
             if ((rc = launch_rollout(h, 1, 0, 0, nullptr)) || (rc = sg_rss_update(h, 0))) return rc;
         return SG_OK;
     }
-    if (do_reset && slicing_pays(h, max_steps)) return launch_sliced(h, max_steps);
+    if (do_reset && slicing_pays(h, max_steps)) {
+        const int rc = launch_sliced(h, max_steps);
+        if (rc != SG_SLICE_FALLBACK) return rc;
+    }
     // external-action slots are fed (0, 0) here; drive them with sg_step(actions)
     return launch_rollout(h, max_steps, do_reset ? 1 : 0, 0, nullptr);
 }
@@ -1525,8 +1608,16 @@ static int ensure_rssq(sg_handle *h)
     if (!h->d_rssq) {
         const size_t nw = h->NE / 64, per_step = nw * 64 * sg::RSSQ_REC * sizeof(double);
         const size_t budget = (size_t)env_int("SG_RSSQ_MB", 4096) << 20;
-        const int steps = (int)std::min<size_t>(256, std::max<size_t>(2, budget / per_step) - 1);
-        HIP_TRY(h, hipMalloc((void **)&h->d_rssq, per_step * (size_t)(steps + 1)));
+        int steps = (int)std::min<size_t>(256, std::max<size_t>(2, budget / per_step) - 1);
+        // the queue only sets how many steps one launch covers: when the device is short of memory, shorter launches
+        //  instead of a failed sg_upload / sg_reset
+        for (;; steps = std::max(1, steps / 2)) {
+            const hipError_t e = hipMalloc((void **)&h->d_rssq, per_step * (size_t)(steps + 1));
+            if (e == hipSuccess) break;
+            (void)hipGetLastError();
+            h->d_rssq = nullptr;
+            if (steps == 1) return fail(h, SG_ERR_HIP, "sg_set_rss: no device memory for the line-test queue (%zu bytes per step)", per_step);
+        }
         HIP_TRY(h, hipMalloc((void **)&h->d_rssq_n, nw * sizeof(int32_t)));
         HIP_TRY(h, hipMemsetAsync(h->d_rssq_n, 0, nw * sizeof(int32_t), h->stream));
         h->rssq_steps = steps;

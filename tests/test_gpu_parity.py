@@ -2115,6 +2115,71 @@ def test_sliced_replay_equals_stepwise_and_oracle(sga, oracle, R, E, steps, term
         assert rb["n_collisions"][r] == o["n_events"] and np.array_equal(ev["t"], o["ev_t"][:2]) and np.array_equal(ev["other"], o["ev_other"][:2]), r
 
 
+@pytest.mark.parametrize("R,E,steps,terminal,dt,ego", [
+    (64, 64, 700, ["max_length"], 1 / 30, "pid"),                       # config 4's shard shape in small: 64-lane tiles, PID egos
+    (48, 30, 420, ["max_length", "ego_collision"], 1 / 30, "pid"),      # tiles of 32 lanes, scenarios stop at different steps
+    (40, 16, 333, ["max_length", "collision"], 0.1, "vehicle"),         # tiles of 16 lanes, VehicleController egos (zero actions)
+    (36, 64, 515, ["max_length"], 0.05, "late"),                        # a PID agent that is NOT the ego and spawns at step 1
+])
+def test_sliced_rollout_with_controlled_lanes(sga, oracle, R, E, steps, terminal, dt, ego):
+    """sg_rollout time-sliced for batches WITH controlled lanes (BASELINE config 4's shards: 512 x 64 with PID egos): the
+    controller pre-pass fills one table for the whole call, the slices replay it group by group.  Final state, controller
+    state, metrics, events (with their classes and collision points) and the step each scenario stopped at are bit-identical
+    to the step-by-step path and to the oracle."""
+    import scenario_gym_amd._lib as L
+    from oracle import check
+    from scenario_gym_amd import synthetic
+
+    kind = dict(pid=L.KIND_AGENT_PID, vehicle=L.KIND_AGENT_VEHICLE, late=L.KIND_AGENT_REPLAY)[ego]
+    packed = synthetic.make_batch(R, E, n_steps=steps, timestep=dt, ego_kind=kind, static_frac=0.15, vanish_frac=0.25,
+                                  extent=30.0 if E > 16 else 14.0)
+    if ego == "late":  # the first entity of each scenario that starts after t0 becomes the (only) PID agent
+        n_late = 0
+        for r in range(R):
+            for e in range(1, E):
+                i = r * E + e
+                a, b = packed.knot_off[i], packed.knot_off[i + 1]
+                if b - a > 1 and packed.knots[a, 0] > packed.t0[r] + 3 * dt:
+                    packed.kind[i] = L.KIND_AGENT_PID
+                    n_late += 1
+                    break
+        assert n_late > R // 2
+    mask = sum(dict(max_length=1, collision=2, ego_collision=4)[c] for c in terminal)
+    out = {}
+    for mode in (False, "always", True, "general"):
+        eng = sga.RolloutEngine(R, E, timestep=dt, terminal_conditions=terminal, event_capacity=8)
+        eng.set_slicing("always" if mode == "general" else mode)
+        if mode == "general":  # the pre-pass of the sliced path without its straight-line fast block (read at upload)
+            os.environ["SG_CTL_FAST"] = "0"
+        try:
+            eng.upload(packed)
+        finally:
+            os.environ.pop("SG_CTL_FAST", None)
+        st, rows, events = _final_results(eng, steps)
+        pts = eng.collision_points()
+        n_launch = eng.last_launch_stats()[0]
+        if mode:
+            ver = check.verify_engine(eng, packed, dt, steps, K=R, event_cap=8, terminal_mask=mask)
+            assert ver["equal"], ver["mismatches"]
+            st2, rows2, events2 = _final_results(eng, steps)  # again on the same handle: its arrays are reused
+            assert rows.tobytes() == rows2.tobytes() and events.tobytes() == events2.tobytes()
+            assert bits_equal(st["poses"], st2["poses"]) and bits_equal(st["ctrl_state"], st2["ctrl_state"])
+        out[mode] = (st, rows, events, pts, n_launch)
+        eng.close()
+    assert out["always"][4] > 3 and out[True][4] >= 1   # several groups of short slices / the default plan
+    for mode in ("always", True, "general"):
+        (sa, ra, ea, pa, _), (sb, rb, eb, pb, _) = out[False], out[mode]
+        for k in ("poses", "vels", "dists", "t", "prev_t", "ctrl_state"):
+            assert bits_equal(sa[k], sb[k]), (mode, k)
+        for k in ("coll", "n_steps", "done", "present"):
+            assert np.array_equal(sa[k], sb[k]), (mode, k)
+        assert ra.tobytes() == rb.tobytes() and ea.tobytes() == eb.tobytes(), mode
+        assert np.array_equal(pa, pb, equal_nan=True), mode
+    assert len(out[False][2]) > 0
+    if len(terminal) > 1:
+        assert len(set(out[False][1]["n_steps"])) > 3
+
+
 def test_sliced_replay_on_the_reference_scenarios(sga, oracle):
     """The 23 OpenSCENARIO files of the reference's tests as one ragged batch (1 ... 9 entities, different lengths and start
     times, egos that appear late), sliced: clock, final poses / velocities / distances / collisions and the ego metrics are

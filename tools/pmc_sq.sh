@@ -5,6 +5,7 @@
 tag=${1:-x}; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" && mkdir -p gpurun_out
 timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_SMEM --output-format csv -d gpurun_out/${tag}_pmc_sq -o p -- python3 bench.py --no-cpu-baseline "$@" --steps 1 --warmup 0 > gpurun_out/${tag}_pmc_sq.log 2>&1
+timeout 300 rocprofv3 --pmc SQ_INSTS_BRANCH SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_SCA SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_BUSY_CYCLES --output-format csv -d gpurun_out/${tag}_pmc_sq_b -o p -- python3 bench.py --no-cpu-baseline "$@" --steps 1 --warmup 0 > gpurun_out/${tag}_pmc_sq_b.log 2>&1
 python3 - "$tag" <<'PY'
 import csv, glob, json, sys, collections
 tag = sys.argv[1]
@@ -13,19 +14,20 @@ cfg = line["config"]
 E = cfg["entities"]
 EP = max(4, 1 << (E - 1).bit_length()) if E <= 64 else (128 if E <= 128 else 256)  # entity stride (tile lanes)
 waves = -(-cfg["scenarios_per_gpu"] * EP // 64)
-f = glob.glob(f"gpurun_out/{tag}_pmc_sq/**/*counter_collection.csv", recursive=True)[0]
 agg = collections.defaultdict(float)
-for r in csv.DictReader(open(f)):
-    k = "rollout" if "rollout_kernel" in r["Kernel_Name"] else ("control" if "control_kernel" in r["Kernel_Name"] else None)
-    if k:
-        agg[(k, r["Counter_Name"])] += float(r["Counter_Value"])
+for f in glob.glob(f"gpurun_out/{tag}_pmc_sq/**/*counter_collection.csv", recursive=True)[:1] + \
+        glob.glob(f"gpurun_out/{tag}_pmc_sq_b/**/*counter_collection.csv", recursive=True)[:1]:
+    for r in csv.DictReader(open(f)):
+        k = "rollout" if "rollout_kernel" in r["Kernel_Name"] else ("control" if "control_kernel" in r["Kernel_Name"] else None)
+        if k:
+            agg[(k, r["Counter_Name"])] += float(r["Counter_Value"])
 T = cfg["sim_steps"]
 ws = waves * T
 out = {k[1]: round(v / ws, 1) for k, v in agg.items() if k[0] == "rollout"}
 ctl = {k[1]: round(v / T, 1) for k, v in agg.items() if k[0] == "control"}
 txt = "rollout_kernel per wave-step (%d waves x %d steps; *_CYCLES / ACTIVE / WAIT in quad-cycles): %s\ncontrol_kernel per step, all waves: %s\n" % (waves, T, out, ctl)
 open(f"gpurun_out/{tag}_pmc_sq.txt", "w").write(txt)
-wl = "c5" if E == 256 else (("c2s" if "TIME-SLICED" in cfg["workload"] else "c2") if E == 16 else ("c3rss" if "RSSDistances" in cfg["workload"] else "c3"))
+wl = cfg["name"]
 rec = dict(scenarios=cfg["scenarios_per_gpu"], entities=E, sim_steps=T, src_sha16=line["roofline"]["src_sha16"],
            kernel=line["roofline"]["kernel"], waves=waves, per_wave_step=out, control_kernel_per_step=ctl,
            note="rocprofv3 --pmc (SQ counters only) over one rollout of the workload, summed over the rollout-kernel dispatches and "

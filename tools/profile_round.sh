@@ -26,16 +26,23 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     f = glob.glob(f"gpurun_out/{tag}_pmc_{c}/**/*counter_collection.csv", recursive=True)
     out[c] = sum(float(r["Counter_Value"]) for r in csv.DictReader(open(f[0]))
                  if "rollout_kernel" in r["Kernel_Name"] and r["Counter_Name"] == c)
-wl = "c5" if cfg["entities"] == 256 else (("c2s" if "TIME-SLICED" in cfg["workload"] else "c2") if cfg["entities"] == 16 else ("c3rss" if "RSSDistances" in cfg["workload"] else "c3"))
+wl = cfg["name"]
+# calibration on this library's access shape (512-byte rows, 8 B per lane; tools/hbm_calib.sh -> profiles/r03_counter_calibration.json):
+# FETCH_SIZE reports half of the bytes read (factor 2.0), WRITE_SIZE all of them (factor 1.0)
+try:
+    cal = json.load(open("profiles/r03_counter_calibration.json"))
+    ff, wf = round(cal["fetch_factor"], 3), round(cal["write_factor"], 3)
+except Exception:
+    ff, wf = 2.0, 1.0
 rec = dict(scenarios=cfg["scenarios_per_gpu"], entities=cfg["entities"], sim_steps=cfg["sim_steps"],
            src_sha16=line["roofline"]["src_sha16"], kernel=line["roofline"]["kernel"],
-           fetch_size_kb=out["FETCH_SIZE"], write_size_kb=out["WRITE_SIZE"],
-           hbm_bytes_per_rollout=(out["FETCH_SIZE"] + out["WRITE_SIZE"]) * 1024,
+           fetch_size_kb=out["FETCH_SIZE"], write_size_kb=out["WRITE_SIZE"], fetch_factor=ff, write_factor=wf,
+           hbm_bytes_per_rollout=(out["FETCH_SIZE"] * ff + out["WRITE_SIZE"] * wf) * 1024,
            launches_per_rollout=line["roofline"]["launches_per_rollout"],
            note="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of one rollout (bench.py --steps 1 --warmup 0), "
-                "summed over every rollout_kernel dispatch (the reset-only launch included, it is tiny); KB units x1024. "
-                "The kernel's HBM reads are 8 B/lane knot rows and scalar table rows, so the x2 FETCH_SIZE correction "
-                "calibrated for 16-B/lane streams (MI355X_MICROARCH.md, HBM) is NOT applied; reads are 2 % of the traffic.")
+                "summed over every rollout_kernel dispatch (the reset-only launch included, it is tiny); KB units x1024, "
+                "corrected by the factors measured on a known byte count in this library's access shape "
+                "(profiles/r03_counter_calibration.json: FETCH_SIZE x2.0, WRITE_SIZE x1.0)")
 json.dump(rec, open(f"gpurun_out/{tag}_hbm_traffic.json", "w"), indent=1)
 json.dump(rec, open(f"gpurun_out/latest_{wl}_hbm_traffic.json", "w"), indent=1)  # what bench.py looks for under profiles/
 print(rec)
