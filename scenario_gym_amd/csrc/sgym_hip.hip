@@ -121,6 +121,27 @@ static int env_int(const char *name, int dflt)
     return (v && *v) ? atoi(v) : dflt;
 }
 
+// Host threads for sg_upload's pass over the scenarios: the logical CPUs, capped at 64 and by the cgroup CPU quota (a box can
+// show 256 CPUs under a quota of 16: more busy threads than that are throttled, not run -- ADVICE r2); SG_UPLOAD_THREADS overrides.
+static unsigned host_threads()
+{
+    static const unsigned n = [] {
+        unsigned v = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
+        if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) { // cgroup v2: "<quota> <period>" or "max <period>"
+            char q[32] = {0};
+            long period = 0;
+            if (fscanf(f, "%31s %ld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) {
+                const long quota = atol(q);
+                if (quota > 0) v = std::min<unsigned>(v, (unsigned)std::max(1L, (quota + period - 1) / period));
+            }
+            fclose(f);
+        }
+        const int forced = env_int("SG_UPLOAD_THREADS", 0);
+        return forced > 0 ? (unsigned)forced : v;
+    }();
+    return n;
+}
+
 static thread_local std::string g_create_err;
 
 static int fail(sg_handle *h, int code, const char *fmt, ...)
@@ -876,7 +897,7 @@ extern "C" int sg_upload(sg_handle *h, const sg_scenarios *sc)
     for (auto &g : grids) g.clear(); // (capacity stays)
     {   // scenarios are validated, re-laid out and given their union grid in parallel (the strictly-increasing check walks
         // every knot: 33 M for the 4096 x 64 x 128 batch; the grid sorts them); the first error by scenario index is reported
-        const unsigned nthr = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
+        const unsigned nthr = host_threads();
         std::vector<std::string> errs(nthr);
         std::vector<int> err_r(nthr, R), ext_cnt(nthr, 0);
         std::vector<char> ego_nz(nthr, 0);

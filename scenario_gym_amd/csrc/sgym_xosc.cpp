@@ -1,5 +1,6 @@
 // sgym_xosc.cpp -- libsgym_xosc.so: one-pass scan of an OpenSCENARIO file for what the rollout engine consumes
 // (include/sgym_xosc.h).  A tag tokenizer with a stack of the element names that matter; no DOM, no allocation per node.
+#include <charconv>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -66,17 +67,28 @@ struct Scanner {
 
 bool attr_is(const Attr &a, const char *name) { return (int)strlen(name) == a.nlen && memcmp(a.name, name, a.nlen) == 0; }
 
-double to_double(const Attr &a)
+// A number as Python's float() -- what the ElementTree reader and the reference apply to these attributes -- accepts it:
+// optional surrounding whitespace, optional sign, decimal digits / point / exponent, or inf / infinity / nan in any case.
+// No hex, no trailing characters, no locale (std::from_chars), any length.  *bad is set on anything else: the file is then
+// rejected (SGX_ERR_SYNTAX) instead of loading with a silently different number.  (float() also takes digit-separating
+// underscores, "1_0"; not supported: such a file is rejected here and loads through import_scenario_et.)
+double to_double(const Attr &a, bool *bad)
 {
-    char buf[64];
-    if (a.vlen < (int)sizeof buf) { // (attribute values are not NUL-terminated)
-        memcpy(buf, a.val, a.vlen);
-        buf[a.vlen] = 0;
-        char *end = nullptr;
-        const double v = strtod(buf, &end);
-        if (end != buf) return v;
+    const char *p = a.val, *e = a.val + a.vlen;
+    while (p < e && isspace((unsigned char)*p)) ++p;
+    while (e > p && isspace((unsigned char)e[-1])) --e;
+    bool neg = false;
+    if (p < e && (*p == '+' || *p == '-')) { neg = *p == '-'; ++p; }
+    double v = 0.0;
+    bool ok = p < e && *p != '+' && *p != '-';
+    if (ok) {
+        const auto res = std::from_chars(p, e, v, std::chars_format::general);
+        ok = res.ec == std::errc() && res.ptr == e;
+        for (const char *q = p; ok && q < e; ++q) // from_chars also reads "nan(...)": float() does not
+            if (*q == '(' || *q == ')') ok = false;
     }
-    return std::nan("");
+    if (!ok) { *bad = true; return std::nan(""); }
+    return neg ? -v : v;
 }
 
 sgx_str slice(const char *base, const char *p, int n) { return sgx_str{(int32_t)(p - base), n}; }
@@ -100,6 +112,9 @@ extern "C" int sgx_parse(const char *text, int64_t len, sgx_counts *counts, sgx_
     sgx_str private_ref = none;   // Init/Actions/Private@entityRef
     sgx_str group_ref = none;     // first Actors/EntityRef of the ManeuverGroup
     int group_first_traj = 0;     // trajectories of the current group get group_ref when the group closes
+    int group_depth = -1;         // stack depth of the open Storyboard/Story/Act/ManeuverGroup, -1: none is open (a
+                                  // ManeuverGroup anywhere else is ignored, as the document readers ignore it)
+    bool bad_number = false;      // some numeric attribute did not parse (see to_double)
     bool event_has_fta = false;   // the Event already met its first FollowTrajectoryAction
     bool in_first_fta = false;    // ... and we are inside it
     int fta_depth = 0;
@@ -146,9 +161,10 @@ extern "C" int sgx_parse(const char *text, int64_t len, sgx_counts *counts, sgx_
                     ++C.n_trajectories;
                 }
             } else if (t == T_EVENT) event_has_fta = false;
-            else if (t == T_MANEUVER_GROUP) {
+            else if (t == T_MANEUVER_GROUP && group_depth == (int)S.stack.size()) { // the group that was opened under Story/Act
                 for (int i = group_first_traj; i < C.n_trajectories && i < cap_trajectories; ++i) trajectories[i].entity = group_ref;
                 group_ref = none;
+                group_depth = -1;
             }
             p = q + 1;
             continue;
@@ -242,13 +258,13 @@ extern "C" int sgx_parse(const char *text, int64_t len, sgx_counts *counts, sgx_
                 sgx_object &o = objects[cur_obj];
                 if (t == T_CENTER) {
                     const Attr *x = attr("x"), *y = attr("y");
-                    o.bbox[2] = x ? to_double(*x) : std::nan("");
-                    o.bbox[3] = y ? to_double(*y) : std::nan("");
+                    o.bbox[2] = x ? to_double(*x, &bad_number) : std::nan("");
+                    o.bbox[3] = y ? to_double(*y, &bad_number) : std::nan("");
                     o.has_inline_bbox |= 1;
                 } else {
                     const Attr *w = attr("width"), *l = attr("length");
-                    o.bbox[0] = w ? to_double(*w) : std::nan("");
-                    o.bbox[1] = l ? to_double(*l) : std::nan("");
+                    o.bbox[0] = w ? to_double(*w, &bad_number) : std::nan("");
+                    o.bbox[1] = l ? to_double(*l, &bad_number) : std::nan("");
                     o.has_inline_bbox |= 2;
                 }
             }
@@ -260,17 +276,17 @@ extern "C" int sgx_parse(const char *text, int64_t len, sgx_counts *counts, sgx_
         }
         case T_MANEUVER_GROUP: {
             const Tag want[] = {T_STORYBOARD, T_STORY, T_ACT};
-            if (S.ends(want)) { group_ref = none; group_first_traj = C.n_trajectories; }
+            if (S.ends(want) && group_depth < 0 && !self_close) { group_ref = none; group_first_traj = C.n_trajectories; group_depth = depth; }
             break;
         }
         case T_ENTITY_REF: {
             const Tag want[] = {T_MANEUVER_GROUP, T_ACTORS};
-            if (S.ends(want) && group_ref.len < 0) group_ref = attr_str("entityRef");
+            if (group_depth >= 0 && depth == group_depth + 2 && S.ends(want) && group_ref.len < 0) group_ref = attr_str("entityRef");
             break;
         }
         case T_FOLLOW_TRAJECTORY_ACTION: {
             const Tag want[] = {T_MANEUVER_GROUP, T_MANEUVER, T_EVENT, T_ACTION, T_PRIVATE_ACTION, T_ROUTING_ACTION};
-            if (S.ends(want) && !event_has_fta) {
+            if (group_depth >= 0 && depth == group_depth + 6 && S.ends(want) && !event_has_fta) {
                 event_has_fta = true;
                 in_first_fta = !self_close;
                 fta_depth = depth;
@@ -283,22 +299,25 @@ extern "C" int sgx_parse(const char *text, int64_t len, sgx_counts *counts, sgx_
             const Tag b[] = {T_FOLLOW_TRAJECTORY_ACTION, T_TRAJECTORY_REF, T_TRAJECTORY, T_SHAPE, T_POLYLINE};
             if (in_first_fta && (S.ends(a) || S.ends(b))) {
                 const Attr *tm = attr("time");
-                vertex_time = tm ? to_double(*tm) : std::nan("");
+                if (!tm) return SGX_ERR_SYNTAX; // (a Vertex without time: the document readers raise as well)
+                vertex_time = to_double(*tm, &bad_number);
             }
             break;
         }
         case T_WORLD_POSITION: {
-            const Attr *x = attr("x"), *y = attr("y"), *z = attr("z"), *h = attr("h"), *pp = attr("p"), *r = attr("r");
             const Tag vtx[] = {T_POLYLINE, T_VERTEX, T_POSITION};
             const Tag tele[] = {T_PRIVATE, T_PRIVATE_ACTION, T_TELEPORT_ACTION, T_POSITION};
-            double row[7] = {0.0, x ? to_double(*x) : std::nan(""), y ? to_double(*y) : std::nan(""), z ? to_double(*z) : std::nan(""),
-                             h ? to_double(*h) : std::nan(""), pp ? to_double(*pp) : std::nan(""), r ? to_double(*r) : std::nan("")};
-            if (in_first_fta && S.ends(vtx)) {
+            const bool is_vtx = in_first_fta && S.ends(vtx), is_tele = !is_vtx && private_ref.len >= 0 && S.ends(tele);
+            if (!is_vtx && !is_tele) break; // a position nobody reads: its numbers are not looked at either
+            const Attr *x = attr("x"), *y = attr("y"), *z = attr("z"), *h = attr("h"), *pp = attr("p"), *r = attr("r");
+            double row[7] = {0.0, x ? to_double(*x, &bad_number) : std::nan(""), y ? to_double(*y, &bad_number) : std::nan(""), z ? to_double(*z, &bad_number) : std::nan(""),
+                             h ? to_double(*h, &bad_number) : std::nan(""), pp ? to_double(*pp, &bad_number) : std::nan(""), r ? to_double(*r, &bad_number) : std::nan("")};
+            if (is_vtx) {
                 if (!x || !y) return SGX_ERR_SYNTAX;
                 row[0] = vertex_time;
                 if (C.n_vertices < cap_vertices) memcpy(vertices + C.n_vertices * 7, row, sizeof row);
                 ++C.n_vertices;
-            } else if (private_ref.len >= 0 && S.ends(tele)) {
+            } else {
                 if (!x || !y) return SGX_ERR_SYNTAX;
                 if (C.n_teleports < cap_teleports) {
                     teleports[C.n_teleports].entity = private_ref;
@@ -315,6 +334,7 @@ extern "C" int sgx_parse(const char *text, int64_t len, sgx_counts *counts, sgx_
         else if (t == T_FOLLOW_TRAJECTORY_ACTION) in_first_fta = false;
     }
     *counts = C;
+    if (bad_number) return SGX_ERR_SYNTAX;
     if (C.n_dirs > cap_dirs || C.n_objects > cap_objects || C.n_teleports > cap_teleports || C.n_trajectories > cap_trajectories ||
         C.n_vertices > cap_vertices)
         return SGX_ERR_CAPACITY;

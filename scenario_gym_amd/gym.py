@@ -107,26 +107,34 @@ class BatchedScenarioGym:
 
     def load_scenarios(self, paths: Sequence[str], create_agent=_create_agent, relabel: bool = True, workers: Optional[int] = None,
                        max_steps: Optional[int] = None, processes: bool = False):
-        """ScenarioGym.load_scenario (scenario_gym.py:119-155) for many files: every file goes through the native scan
+        """ScenarioGym.load_scenario (scenario_gym.py:119-155) for many files (.xosc, or .json written by Scenario.to_json):
+        every OpenSCENARIO file goes through the native scan
         (libsgym_xosc.so, which runs without the GIL) on `workers` threads -- or, for directories of thousands of files,
         `workers` processes (`processes=True`: the Python side of the import scales too; tools/ingest_rate.py) -- and the
         batch is packed once.  workers=None: 8 threads, or as many processes as the CPU quota grants."""
         from concurrent.futures import ProcessPoolExecutor, ThreadPoolExecutor
         from functools import partial
 
-        from .xosc import import_scenario
+        from .xosc import load_scenario_file
 
         paths = list(paths)
         if workers is None:
             from .packing import effective_cpus
 
             workers = effective_cpus() if processes else 8
-        if workers > 1 and len(paths) > 1:
-            pool = ProcessPoolExecutor if processes else ThreadPoolExecutor
-            with pool(min(workers, len(paths))) as ex:
-                scenarios = list(ex.map(partial(import_scenario, relabel=relabel), paths, **(dict(chunksize=32) if processes else {})))
+        load = partial(load_scenario_file, relabel=relabel)
+        if workers > 1 and len(paths) > 1 and processes:
+            # "spawn": a forked child would inherit this process's HIP runtime (its threads' locks, pinned buffers) once
+            # an engine exists (ADVICE r2); the importer is importable on its own, so fresh interpreters work
+            import multiprocessing
+
+            with ProcessPoolExecutor(min(workers, len(paths)), mp_context=multiprocessing.get_context("spawn")) as ex:
+                scenarios = list(ex.map(load, paths, chunksize=32))
+        elif workers > 1 and len(paths) > 1:
+            with ThreadPoolExecutor(min(workers, len(paths))) as ex:
+                scenarios = list(ex.map(load, paths))
         else:
-            scenarios = [import_scenario(f, relabel=relabel) for f in paths]
+            scenarios = [load(f) for f in paths]
         self.set_scenarios(scenarios, create_agent=create_agent, max_steps=max_steps)
         for st, f in zip(self.states, paths):
             st.scenario_path = f
@@ -401,9 +409,9 @@ class ScenarioGym:
         self._metrics.clear()
 
     def load_scenario(self, scenario_path: str, create_agent=_create_agent, relabel: bool = False, **kwargs) -> None:
-        from .xosc import import_scenario
+        from .xosc import load_scenario_file
 
-        self.set_scenario(import_scenario(scenario_path, relabel=relabel, **kwargs), scenario_path, create_agent)
+        self.set_scenario(load_scenario_file(scenario_path, relabel=relabel, **kwargs), scenario_path, create_agent)
 
     def set_scenario(self, scenario: Scenario, scenario_path: Optional[str] = None, create_agent=_create_agent) -> None:
         self._b.set_scenarios([scenario], create_agent=create_agent)

@@ -8,7 +8,10 @@ with their driveable / walkable / impenetrable flags, and the unions the referen
 and their layer bits to the device (`sg_set_road_networks`), which answers `contains` for the `ego_off_road` terminal
 condition and the RasterizedMapSensor layers.
 
-Not mirrored: OpenDRIVE import, elevation interpolation, lane graphs / routing, and the repair of invalid
+Elevation: geometries may carry an `Elevation` list of (x, y, z) samples; `elevation_at_point` interpolates them as the
+reference does (road_network.py:446-520) and the OpenSCENARIO reader uses it for trajectories without z.
+
+Not mirrored: OpenDRIVE import, lane graphs, and the repair of invalid
 (self-intersecting) boundaries through GEOS `make_valid` / `buffer` (base.py:94-118) -- rings are used as given, with
 the even-odd rule.
 """
@@ -63,11 +66,18 @@ class RoadGeometry(RoadObject):
     walkable = True
     impenetrable = False
 
-    def __init__(self, id: str, boundary: np.ndarray, interiors: Optional[List[np.ndarray]] = None, center=None):
+    has_center = False  # road-like objects (roads, lanes, pavements, crossings) write their centre line
+
+    def __init__(self, id: str, boundary: np.ndarray, interiors: Optional[List[np.ndarray]] = None, center=None,
+                 elevation=None):
         super().__init__(id)
         self.boundary = np.asarray(boundary, np.float64).reshape(-1, 2)
         self.interiors = [np.asarray(i, np.float64).reshape(-1, 2) for i in (interiors or [])]
         self.center = None if center is None else np.asarray(center, np.float64).reshape(-1, 2)
+        if elevation is not None:
+            elevation = np.asarray(elevation, np.float64)
+            assert elevation.ndim == 2 and elevation.shape[1] == 3, "Invalid shape for elevation profile."
+        self.elevation = elevation
 
     @classmethod
     def from_dict(cls, data: Dict[str, Any]):
@@ -79,31 +89,63 @@ class RoadGeometry(RoadObject):
         else:
             raise ValueError(f"Type {type(b)} is not supported for boundary.")
         center = np.array([[v["x"], v["y"]] for v in data["Center"]], np.float64) if "Center" in data else None
-        obj = cls(data["Id" if "Id" in data else "id"], ext, holes, center)
+        obj = cls(data["Id" if "Id" in data else "id"], ext, holes, center, data.get("Elevation"))
         obj._load_extra(data)
         return obj
 
     def _load_extra(self, data):
         pass
 
+    def to_dict(self) -> Dict[str, Any]:
+        """base.py:120-127, 159-165 + the per-class fields (objects.py:96-107, 137-141, 174-183, 225-229).  Rings are written
+        closed (first vertex repeated), as shapely hands them out."""
+        def pts(r):
+            return [{"x": float(x), "y": float(y)} for x, y in np.concatenate([r, r[:1]])]
+
+        out = {"id": self.id, "Boundary": pts(self.boundary) if not self.interiors else
+               {"exterior": pts(self.boundary), "interiors": [pts(i) for i in self.interiors]},
+               "Elevation": None if self.elevation is None else self.elevation.tolist()}
+        if self.has_center:
+            out["Center"] = [{"x": float(x), "y": float(y)} for x, y in (self.center if self.center is not None else [])]
+        out.update(self._extra_dict())
+        return out
+
+    def _extra_dict(self) -> Dict[str, Any]:
+        return {}
+
     def rings(self) -> List[np.ndarray]:
         return [self.boundary] + self.interiors
 
 
+# objects.py:14-43: the lane types the reference's enum knows; anything else loads as "driving"
+LANE_TYPES = ("driving", "none", "bidirectional", "biking", "border", "connectingRamp", "curb", "entry", "exit", "median",
+              "mwyEntry", "mwyExit", "offRamp", "onRamp", "parking", "rail", "restricted", "roadWorks", "shoulder", "sidewalk",
+              "special1", "special2", "special3", "stop", "taxi", "tram")
+
+
 class Lane(RoadGeometry):
     walkable = False
+    has_center = True
 
     def _load_extra(self, data):
         self.successors = list(set(data.get("successors", [])))
         self.predecessors = list(set(data.get("predecessors", [])))
-        self.type = data.get("type", "driving")
+        t = data.get("type", "driving")
+        self.type = t if t in LANE_TYPES else "driving"
+
+    def _extra_dict(self):
+        return {"successors": self.successors, "predecessors": self.predecessors, "type": self.type}
 
 
 class Road(RoadGeometry):
     walkable = False
+    has_center = True
 
     def _load_extra(self, data):
         self.lanes = [Lane.from_dict(l) for l in data[_key(data, "lanes")]]
+
+    def _extra_dict(self):
+        return {"lanes": [l.to_dict() for l in self.lanes]}
 
 
 class Intersection(RoadGeometry):
@@ -114,16 +156,24 @@ class Intersection(RoadGeometry):
         self.lanes = [Lane.from_dict(l) for l in data[_key(data, "lanes")]]
         self.connecting_roads = data.get("connecting_roads", [])
 
+    def _extra_dict(self):
+        return {"lanes": [l.to_dict() for l in self.lanes], "connecting_roads": self.connecting_roads}
+
 
 class Pavement(RoadGeometry):
     driveable = False
+    has_center = True
 
 
 class Crossing(RoadGeometry):
     driveable = False
+    has_center = True
 
     def _load_extra(self, data):
         self.pavements = data.get(_key(data, "pavements"), [])
+
+    def _extra_dict(self):
+        return {"pavements": self.pavements}
 
 
 class Building(RoadGeometry):
@@ -146,6 +196,7 @@ class RoadNetwork:
         self._lanes = list(lanes)
         self.pavements, self.crossings, self.buildings = list(pavements), list(crossings), list(buildings)
         self._arrays = None
+        self._elev = None
 
     @classmethod
     def create_from_file(cls, filepath: str):
@@ -189,6 +240,59 @@ class RoadNetwork:
     @property
     def road_network_geometries(self) -> List[RoadGeometry]:
         return self.roads + self.intersections + self.lanes + self.pavements + self.crossings + self.buildings
+
+    def to_dict(self) -> Dict[str, Any]:
+        """road_network.py:409-414."""
+        data = {"name": self.name, "properties": self.properties}
+        for key, objs in (("roads", self.roads), ("intersections", self.intersections), ("lanes", self.lanes),
+                          ("pavements", self.pavements), ("crossings", self.crossings), ("buildings", self.buildings)):
+            data[key] = [o.to_dict() for o in objs]
+        return data
+
+    def to_json(self, filepath: str) -> None:
+        with open(filepath, "w") as f:
+            json.dump(self.to_dict(), f)
+
+    # ------------------------------------------------------------------ elevation (road_network.py:446-520)
+    def _elevation_model(self):
+        """The (x, y, z) samples of every geometry that has them, thinned to at most ~5000 by a constant stride, triangulated
+        once: (Delaunay, piecewise-linear interpolant on it, nearest-sample interpolant).  Without samples a flat unit
+        square at z = 0 stands in.  (Order of the samples: roads, intersections, lanes, pavements, crossings, buildings, each
+        in file order.  The reference collects its lanes through a Python set, i.e. in a per-process hash order, so with
+        elevation on lanes its own sample order -- and with it the stride thinning -- varies from run to run.)"""
+        if self._elev is None:
+            from scipy.interpolate import LinearNDInterpolator, NearestNDInterpolator
+            from scipy.spatial import Delaunay
+
+            samples = [g.elevation for g in self.road_network_geometries if g.elevation is not None]
+            pts = np.concatenate(samples, axis=0) if samples else np.array([[0, 1, 0], [1, 0, 0], [1, 1, 0], [0, 0, 0]])
+            if pts.shape[0] > 5000:
+                pts = pts[:: int(np.ceil(pts.shape[0] / 5000))]
+            tri = Delaunay(pts[:, :2])
+            self._elev = (tri, LinearNDInterpolator(pts[:, :2], pts[:, 2]), NearestNDInterpolator(pts[:, :2], pts[:, 2]))
+        return self._elev
+
+    def elevation_at_point(self, x, y) -> np.ndarray:
+        """z at (x, y): linear on the triangle that contains the point, the nearest sample's z outside the samples' hull.
+        x, y: scalars or 1-d arrays (a scalar is broadcast against an array)."""
+        x, y = np.array(x), np.array(y)
+        if x.ndim > 1 or y.ndim > 1:
+            raise ValueError("x and y must be 0 or 1 dimensional.")
+        both_1d = x.ndim == y.ndim == 1
+        x, y = np.atleast_1d(x), np.atleast_1d(y)
+        if x.shape[0] == 1 and y.shape[0] > 1:
+            x = np.repeat(x, y.shape[0])
+        elif y.shape[0] == 1 and x.shape[0] > 1:
+            y = np.repeat(y, x.shape[0])
+        tri, inside_fn, outside_fn = self._elevation_model()
+        xy = np.column_stack((x, y))
+        inside = tri.find_simplex(xy) >= 0
+        z = np.empty(xy.shape[0])
+        if inside.any():
+            z[inside] = inside_fn(xy[inside])
+        if (~inside).any():
+            z[~inside] = outside_fn(xy[~inside])
+        return z.squeeze() if both_1d else z
 
     def polygon_arrays(self) -> Dict[str, np.ndarray]:
         """Every boundary polygon once, with the unions it belongs to as LAYER_* bits:

@@ -1,8 +1,32 @@
-"""Scenario container: the read API the rollout uses (reference scenario/scenario.py:20-100)."""
-from typing import Dict, List, Optional
+"""Scenario container: the read API the rollout uses (reference scenario/scenario.py:20-100) and its JSON form
+(scenario/scenario.py:186-319: from_dict / to_dict / from_json / to_json)."""
+import json
+import os
+from typing import Any, Dict, List, Optional, Tuple, Type
 
 from .entity import Entity, Pedestrian, Vehicle
 from .trajectory import Trajectory
+
+
+class ScenarioActionRecord:
+    """A scenario action as the files carry it (scenario/actions.py:12-110: t, action_class, entity_ref, action_variables).
+    Applying actions to a running state is not part of the device path; the record survives load / save unchanged.
+    kind: the reference class it stands for ("UserDefinedAction" from OpenSCENARIO, "UpdateStateVariableAction" from JSON)."""
+
+    def __init__(self, t: float, action_class: str, entity_ref: str, action_variables: Dict[str, Any],
+                 kind: str = "UpdateStateVariableAction"):
+        self.t, self.action_class, self.entity_ref, self.action_variables, self.kind = t, action_class, entity_ref, action_variables, kind
+
+    def to_dict(self) -> Dict[str, Any]:
+        return {"action_class": self.action_class, "entity_ref": self.entity_ref, "action_variables": self.action_variables,
+                "t": self.t}
+
+    @classmethod
+    def from_dict(cls, data: Dict[str, Any]):
+        return cls(data["t"], data["action_class"], data["entity_ref"], data["action_variables"])
+
+    def copy(self):
+        return ScenarioActionRecord(self.t, self.action_class, self.entity_ref, dict(self.action_variables), self.kind)
 
 
 class Scenario:
@@ -59,6 +83,68 @@ class Scenario:
 
         start = (self.ego if entity is None else entity).trajectory.min_t
         return self.translate(np.array([-start, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0]))
+
+    # ------------------------------------------------------------------ JSON (scenario/scenario.py:186-319)
+    @classmethod
+    def from_dict(cls, data: Dict[str, Any], e_classes: Tuple[Type[Entity], ...] = (Vehicle, Pedestrian, Entity)):
+        """Entities by their "entity_class" name among e_classes -- an unknown name (e.g. "MiscObject") falls to the LAST
+        class of the tuple, as the reference's search loop leaves it; the road network from its file ("path", when it
+        exists; else an empty network of that "name"; else none) or from the embedded dictionary."""
+        from .road_network import RoadNetwork
+
+        by_name = {c.__name__: c for c in e_classes}
+        entities = [by_name.get(d.get("entity_class"), e_classes[-1]).from_dict(d) for d in data["entities"]]
+        rn = data.get("road_network")
+        if rn is not None:
+            if rn.get("path") is not None:
+                if os.path.exists(rn["path"]):
+                    rn = RoadNetwork.create_from_file(str(rn["path"]))
+                elif rn.get("name") is not None:
+                    rn = RoadNetwork(name=rn["name"])
+                else:
+                    rn = None
+            else:
+                rn = RoadNetwork.create_from_dict(rn)
+        actions = [ScenarioActionRecord.from_dict(a) for a in data.get("actions", ())]
+        return cls(entities, name=data.get("name"), road_network=rn, actions=actions, properties=data.get("properties", {}))
+
+    def to_dict(self, road_network_path: Optional[str] = "../Road_Networks") -> Dict[str, Any]:
+        """road_network_path: a file, or a directory the network's "<name>.json" is looked for in (the default); None
+        embeds the whole network."""
+        if self.road_network is None:
+            rn = None
+        elif road_network_path is not None:
+            p = road_network_path
+            if not os.path.isfile(p):
+                p = os.path.join(p, f"{self.road_network.name}.json")
+            rn = {"path": p, "name": self.road_network.name}
+        else:
+            rn = self.road_network.to_dict()
+        return {"entities": [e.to_dict() for e in self._entities], "name": self.name,
+                "actions": [a.to_dict() for a in self.actions], "road_network": rn, "properties": self.properties}
+
+    @classmethod
+    def from_json(cls, path: str, road_network_dir: Optional[str] = None,
+                  e_classes: Tuple[Type[Entity], ...] = (Vehicle, Pedestrian, Entity)):
+        """A relative road-network path is taken from the file's directory, or from road_network_dir (itself relative to
+        the file's directory unless absolute)."""
+        with open(path) as f:
+            data = json.load(f)
+        rn = data.get("road_network")
+        if rn is not None and rn.get("path") is not None and not os.path.isabs(rn["path"]):
+            here = os.path.dirname(path)
+            if road_network_dir is None:
+                base = here
+            elif os.path.isabs(road_network_dir):
+                base = road_network_dir
+            else:
+                base = os.path.join(here, road_network_dir)
+            rn["path"] = os.path.join(base, rn["path"])
+        return cls.from_dict(data, e_classes=e_classes)
+
+    def to_json(self, path: str, road_network_path: Optional[str] = "../Road_Networks") -> None:
+        with open(path, "w") as f:
+            json.dump(self.to_dict(road_network_path=road_network_path), f)
 
     def copy(self):
         return self.__class__([e.copy() for e in self._entities],

@@ -22,22 +22,63 @@ from typing import Dict, Tuple
 import numpy as np
 
 from .road_network import RoadNetwork
-from .entity import BoundingBox, CatalogEntry, Entity, MiscObject, Pedestrian, Vehicle
-from .scenario import Scenario
+from .entity import Axle, BoundingBox, Catalog, CatalogEntry, Entity, MiscObject, Pedestrian, Vehicle
+from .scenario import Scenario, ScenarioActionRecord
 from .trajectory import Trajectory
 
 _ENTITY_CLASSES = {"Vehicle": Vehicle, "Pedestrian": Pedestrian, "MiscObject": MiscObject}
 _catalog_cache: Dict[str, Tuple[str, Dict[str, Entity]]] = {}
 
 
-def _entry_from_element(el, catalog_name):
+def _opt_float(v):
+    return None if v is None else float(v)
+
+
+def _properties(el):
+    """utils.py:65-103: Properties/Property@name,@value (a float when it parses as one) and Properties/File@filepath."""
+    props, files = {}, []
+    node = el.find("Properties")
+    if node is not None:
+        for c in node.findall("Property"):
+            if "value" not in c.attrib:
+                raise RuntimeError("Property could not be loaded without `value` key.")
+            v = c.attrib["value"]
+            try:
+                v = float(v)
+            except ValueError:
+                pass
+            props[c.attrib["name"]] = v
+        files = [f.attrib["filepath"] for f in node.findall("File")]
+    return props, files
+
+
+def _axle(el):
+    if el is None:
+        return None
+    return Axle(*[float(el.attrib[k]) for k in ("maxSteering", "wheelDiameter", "trackWidth", "positionX", "positionZ")])
+
+
+def _entry_from_element(el, catalog):
     bb = el.find("BoundingBox")
     if bb is None:
         return None
     c, d = bb.find("Center"), bb.find("Dimensions")
     box = BoundingBox(float(d.attrib["width"]), float(d.attrib["length"]), float(c.attrib["x"]), float(c.attrib["y"]))
     cname = el.tag.lower() + "Category"
-    ce = CatalogEntry(catalog_name, el.attrib["name"], el.attrib.get(cname), el.tag, box, {}, [])
+    props, files = _properties(el)
+    extra = {}
+    if el.tag in ("Vehicle", "Pedestrian", "MiscObject"):
+        extra["mass"] = _opt_float(el.attrib.get("mass"))
+    if el.tag == "Vehicle":
+        perf = el.find("Performance")
+        spd, dec, acc = (None, None, None) if perf is None else (
+            float(perf.attrib["maxSpeed"]), float(perf.attrib["maxDeceleration"]), float(perf.attrib["maxAcceleration"]))
+        # the reference hands (mass, max_dec, max_acc, max_speed) to a constructor that takes (mass, max_speed,
+        # max_deceleration, max_acceleration) (entity/vehicle.py:79-84 vs :116-123): the three land one field over.
+        # Kept, so that Scenario.to_json writes what the reference writes.
+        extra.update(max_speed=dec, max_deceleration=acc, max_acceleration=spd,
+                     front_axle=_axle(el.find("Axles/FrontAxle")), rear_axle=_axle(el.find("Axles/RearAxle")))
+    ce = CatalogEntry(catalog, el.attrib["name"], el.attrib.get(cname), el.tag, box, props, files, extra)
     return _ENTITY_CLASSES.get(el.tag, Entity)(ce)
 
 
@@ -46,9 +87,11 @@ def read_catalog(catalog_file: str):
     if catalog_file not in _catalog_cache:
         root = ET.parse(catalog_file).getroot()
         cat = root.find("Catalog")
+        parts = catalog_file.split(os.sep)  # catalogs.py:70-74: the directory two levels up names the catalog group
+        catalog = Catalog(cat.attrib["name"], parts[-3] if len(parts) >= 3 else "Catalog")
         entries = {}
         for el in list(cat):
-            ent = _entry_from_element(el, cat.attrib["name"])
+            ent = _entry_from_element(el, catalog)
             if ent is not None:
                 entries[ent.catalog_entry.catalog_entry] = ent
         _catalog_cache[catalog_file] = (cat.attrib["name"], entries)
@@ -59,6 +102,49 @@ def _traj_point(t, wp):
     g = wp.attrib.get
     return np.array([t, float(wp.attrib["x"]), float(wp.attrib["y"]), float(g("z", np.nan)),
                      float(g("h", np.nan)), float(g("p", np.nan)), float(g("r", np.nan))])
+
+
+def _fill_elevation(data: np.ndarray, road_network) -> np.ndarray:
+    """read.py:212-215: a FollowTrajectoryAction trajectory with ANY vertex lacking z, in a scenario that has a road network,
+    takes the network's interpolated elevation at EVERY vertex (z given at other vertices is overwritten too)."""
+    if road_network is not None and np.isnan(data[:, 3]).any():
+        data = data.copy()
+        data[:, 3] = road_network.elevation_at_point(data[:, 1], data[:, 2])
+    return data
+
+
+def _header_and_actions(root, entities):
+    """Scenario.properties from FileHeader (read.py:170-176) and the UserDefinedActions of the maneuver groups
+    (read.py:140-168, 219-241: only events whose FollowTrajectoryAction did not yield a trajectory are looked at)."""
+    properties = {}
+    header = root.find("FileHeader")
+    if header is not None:
+        properties, files = _properties(header)
+        if files and "files" not in properties:
+            properties["files"] = files
+    actions = []
+    for mg in root.iterfind("Storyboard/Story/Act/ManeuverGroup"):
+        er = mg.find("Actors/EntityRef")
+        entity = entities.get(er.attrib["entityRef"]) if er is not None else None
+        if entity is None:
+            continue
+        for event in mg.findall("Maneuver/Event"):
+            fta = event.find("Action/PrivateAction/RoutingAction/FollowTrajectoryAction")
+            if fta is not None and (fta.findall("TrajectoryRef/Trajectory/Shape/Polyline/Vertex") or
+                                    fta.findall("Trajectory/Shape/Polyline/Vertex")):
+                continue
+            ua = event.find("Action/UserDefinedAction")
+            if ua is None:
+                continue
+            # (the reference dereferences both without a check and dies on an event without them; skipped here)
+            trig = event.find("StartTrigger")
+            cond = None if trig is None else trig.find("ConditionGroup/Condition/ByValueCondition/SimulationTimeCondition")
+            if cond is None or cond.attrib.get("value") is None:
+                continue
+            t = float(cond.attrib.get("value"))
+            for child in list(ua):
+                actions.append(ScenarioActionRecord(t, child.tag, entity.ref, dict(child.attrib), "UserDefinedAction"))
+    return properties, actions
 
 
 def relabel_scenario(scenario: Scenario) -> Scenario:
@@ -89,6 +175,19 @@ def import_scenario_et(osc_file: str, relabel: bool = True) -> Scenario:
             if f.endswith(".xosc"):
                 name, entries = read_catalog(os.path.join(path, f))
                 catalogs[name] = entries
+
+    # road network: RoadNetwork/SceneGraphFile or LogicFile, ".json" when there is no extension (read.py:65-85)
+    road_network = None
+    rn = root.find("RoadNetwork/SceneGraphFile")
+    if rn is None:
+        rn = root.find("RoadNetwork/LogicFile")
+    if rn is not None and rn.attrib.get("filepath"):
+        path = rn.attrib["filepath"]
+        path = path if os.path.isabs(path) else os.path.join(cwd, path)
+        if os.path.splitext(path)[1] == "":
+            path += ".json"
+        if os.path.exists(path) and path.endswith(".json"):
+            road_network = RoadNetwork.create_from_json(path)
 
     entities: Dict[str, Entity] = {}
     for so in root.iterfind("Entities/ScenarioObject"):
@@ -126,28 +225,18 @@ def import_scenario_et(osc_file: str, relabel: bool = True) -> Scenario:
             verts += fta.findall("Trajectory/Shape/Polyline/Vertex")
             if verts:
                 pts = [_traj_point(float(v.attrib["time"]), v.find("Position/WorldPosition")) for v in verts]
-                entity.trajectory = Trajectory(np.stack(pts, axis=0))
+                entity.trajectory = Trajectory(_fill_elevation(np.stack(pts, axis=0), road_network))
 
-    # road network: RoadNetwork/SceneGraphFile or LogicFile, ".json" when there is no extension (read.py:65-85)
-    road_network = None
-    rn = root.find("RoadNetwork/SceneGraphFile")
-    if rn is None:
-        rn = root.find("RoadNetwork/LogicFile")
-    if rn is not None and rn.attrib.get("filepath"):
-        path = rn.attrib["filepath"]
-        path = path if os.path.isabs(path) else os.path.join(cwd, path)
-        if os.path.splitext(path)[1] == "":
-            path += ".json"
-        if os.path.exists(path) and path.endswith(".json"):
-            road_network = RoadNetwork.create_from_json(path)
+    properties, actions = _header_and_actions(root, entities)
     scenario = Scenario(list(entities.values()), name=os.path.splitext(os.path.basename(osc_file))[0],
-                        road_network=road_network)
+                        road_network=road_network, properties=properties, actions=actions)
     return relabel_scenario(scenario) if relabel else scenario
 
 
 # ---------------------------------------------------------------------------------------------- native scan
 import ctypes as _C  # noqa: E402
-from xml.sax.saxutils import unescape as _unescape  # noqa: E402
+import html as _html  # noqa: E402
+import re as _re  # noqa: E402
 
 _XLIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libsgym_xosc.so")
 _xlib = None
@@ -214,11 +303,15 @@ def scan_xosc(text: bytes):
     else:
         raise ValueError("sgx_parse: capacity")
 
+    # the encoding of the XML declaration (default UTF-8); character and entity references as a parser resolves them
+    m = _re.match(rb"\s*<\?xml[^>]*encoding\s*=\s*[\"']([A-Za-z0-9._-]+)[\"']", text[:200])
+    enc = m.group(1).decode("ascii") if m else "utf-8"
+
     def st(x):
         if x.len < 0:
             return None
-        v = text[x.off:x.off + x.len].decode("utf-8")
-        return _unescape(v, {"&quot;": '"', "&apos;": "'"}) if "&" in v else v
+        v = text[x.off:x.off + x.len].decode(enc)
+        return _html.unescape(v) if "&" in v else v
 
     return dict(
         dirs=[st(dirs[i]) for i in range(cnt.n_dirs)], road_file=st(cnt.road_file),
@@ -237,7 +330,17 @@ def import_scenario(osc_file: str, relabel: bool = True) -> Scenario:
         raise FileNotFoundError(osc_file)
     cwd = os.path.dirname(osc_file)
     with open(osc_file, "rb") as f:
-        scan = scan_xosc(f.read())
+        text = f.read()
+    try:
+        scan = scan_xosc(text)
+    except (ValueError, UnicodeDecodeError):
+        # the scan is strict (numbers as float() reads them, UTF-8): anything it does not take goes to the document reader,
+        # which loads it or raises the error the file deserves
+        return import_scenario_et(osc_file, relabel)
+    if any(o["catalog"] is None and o["has_bbox"] for o in scan["objects"]):
+        # entities defined inline carry their whole catalog entry (mass, performance, axles, properties) in the scenario
+        # file: rare, the document reader handles them
+        return import_scenario_et(osc_file, relabel)
     catalogs: Dict[str, Dict[str, Entity]] = {}
     for path in scan["dirs"]:
         path = path if os.path.isabs(path) else os.path.join(cwd, path)
@@ -261,12 +364,6 @@ def import_scenario(osc_file: str, relabel: bool = True) -> Scenario:
         if ent is not None:
             ent.ref = o["name"]
             entities[o["name"]] = ent
-    for ref, knot in scan["teleports"]:
-        if ref in entities:
-            entities[ref].trajectory = Trajectory(knot[None, :])
-    for ref, verts in scan["trajectories"]:
-        if ref in entities and len(verts):
-            entities[ref].trajectory = Trajectory(verts)
     road_network = None
     if scan["road_file"]:
         path = scan["road_file"]
@@ -275,6 +372,24 @@ def import_scenario(osc_file: str, relabel: bool = True) -> Scenario:
             path += ".json"
         if os.path.exists(path) and path.endswith(".json"):
             road_network = RoadNetwork.create_from_json(path)
+    for ref, knot in scan["teleports"]:
+        if ref in entities:
+            entities[ref].trajectory = Trajectory(knot[None, :])
+    for ref, verts in scan["trajectories"]:
+        if ref in entities and len(verts):
+            entities[ref].trajectory = Trajectory(_fill_elevation(verts, road_network))
+    properties, actions = {}, []
+    if b"<UserDefinedAction" in text or b"<Properties" in text[: text.find(b"<Entities")]:
+        # (rare) header properties / user-defined actions: not part of the native scan
+        properties, actions = _header_and_actions(ET.fromstring(text), entities)
     scenario = Scenario(list(entities.values()), name=os.path.splitext(os.path.basename(osc_file))[0],
-                        road_network=road_network)
+                        road_network=road_network, properties=properties, actions=actions)
     return relabel_scenario(scenario) if relabel else scenario
+
+
+def load_scenario_file(path: str, relabel: bool = True, **kwargs) -> Scenario:
+    """One scenario file by its extension: OpenSCENARIO (.xosc) through import_scenario, JSON (.json, Scenario.to_json's
+    format; scenario_gym.py:136-142) through Scenario.from_json."""
+    if os.path.splitext(path)[1].lower() == ".json":
+        return Scenario.from_json(path, **kwargs)  # (never relabelled, as in the reference)
+    return import_scenario(path, relabel=relabel, **kwargs)

@@ -527,3 +527,66 @@ def test_native_xosc_scan_equals_the_elementtree_reader(tmp_path):
     assert type(a.entities[1]).__name__ == "Pedestrian" and a.entities[2].trajectory.data.shape == (1, 7)
     with pytest.raises(ValueError):
         xosc.scan_xosc(b"<OpenSCENARIO><Entities><ScenarioObject name=oops></Entities>")
+
+
+def test_native_xosc_scan_stray_groups_numbers_and_references(tmp_path):
+    """ADVICE r2 on libsgym_xosc.so: (1) a ManeuverGroup outside Storyboard/Story/Act -- placed after a valid one -- is ignored,
+    it neither steals the earlier trajectory nor adds its own; (2) numbers are read as float() reads them: a value with
+    trailing characters, a hex value or a Vertex without time make the scan refuse the file (the document reader then
+    decides), a value longer than 64 characters is a number, not NaN; positions nobody reads are not parsed at all;
+    (3) numeric character references in names resolve as a parser resolves them."""
+    import numpy as np
+
+    from scenario_gym_amd import xosc
+    from scenario_gym_amd import xosc_write as W
+
+    root = tmp_path / "gen"
+    W.write_catalog(str(root / "Catalogs"))
+    (root / "Scenarios").mkdir()
+    wp = lambda x, y, extra="": f'<Position><WorldPosition x="{x}" y="{y}"{extra}/></Position>'
+    vtx = lambda t, x, y: f'<Vertex time="{t}">{wp(x, y)}</Vertex>'
+    fta = lambda vs: ("<Maneuver name='m'><Event name='e'><Action name='a'><PrivateAction><RoutingAction><FollowTrajectoryAction><Trajectory name='t' closed='false'>"
+                      "<Shape><Polyline>" + "".join(vs) + "</Polyline></Shape></Trajectory></FollowTrajectoryAction></RoutingAction></PrivateAction></Action></Event></Maneuver>")
+    group = lambda ref, vs: f'<ManeuverGroup name="g"><Actors><EntityRef entityRef="{ref}"/></Actors>{fta(vs)}</ManeuverGroup>'
+
+    def doc(story, extra="", names=("a", "b")):
+        objs = "".join(f'<ScenarioObject name="{n}"><CatalogReference catalogName="SyntheticVehicleCatalog" entryName="car1"/></ScenarioObject>' for n in names)
+        return (f'<?xml version="1.0"?><OpenSCENARIO><CatalogLocations><VehicleCatalog><Directory path="../Catalogs"/></VehicleCatalog>'
+                f'</CatalogLocations><Entities>{objs}</Entities><Storyboard><Init><Actions/></Init>{story}</Storyboard>{extra}</OpenSCENARIO>')
+
+    def load(name, text):
+        p = root / "Scenarios" / name
+        p.write_text(text)
+        return xosc.import_scenario(str(p), relabel=False), xosc.import_scenario_et(str(p), relabel=False)
+
+    good = group("a", [vtx(0, 1, 2), vtx(1, 3, 4)])
+    stray = group("b", [vtx(0, 9, 9), vtx(2, 8, 8)])
+    # (1) stray groups: directly under Storyboard, and under a Story without an Act
+    n, e = load("stray.xosc", doc(f'<Story name="s"><Act name="x">{good}</Act></Story>{stray}<Story name="t">{stray}</Story>'))
+    for s in (n, e):
+        assert [x.ref for x in s.entities] == ["a", "b"]
+        assert s.entities[0].trajectory.data.shape == (2, 7) and s.entities[0].trajectory.data[1, 1] == 3.0
+        assert s.entities[1].trajectory is None
+    scan = xosc.scan_xosc((root / "Scenarios" / "stray.xosc").read_bytes())
+    assert [(r, len(v)) for r, v in scan["trajectories"]] == [("a", 2)]
+    # (2) numbers
+    long_one = "1." + "0" * 80 + "5"
+    n, e = load("long.xosc", doc(f'<Story name="s"><Act name="x">{group("a", [vtx(0, long_one, 2), vtx(1, " 3.5 ", "+4e0")])}</Act></Story>'))
+    for s in (n, e):
+        assert np.array_equal(s.entities[0].trajectory.data[:, 1:3], [[float(long_one), 2.0], [3.5, 4.0]])
+    for bad in ("1.0abc", "0x10", "1e", "--1", ""):
+        text = doc(f'<Story name="s"><Act name="x">{group("a", [vtx(0, bad, 2), vtx(1, 3, 4)])}</Act></Story>').encode()
+        with pytest.raises(ValueError):
+            xosc.scan_xosc(text)
+    with pytest.raises(ValueError):   # a Vertex without time
+        xosc.scan_xosc(doc('<Story name="s"><Act name="x">' + group("a", [f"<Vertex>{wp(1, 2)}</Vertex>"]) + "</Act></Story>").encode())
+    # a malformed number in a position nobody reads does not matter (the document readers never look at it either)
+    n, e = load("unused.xosc", doc(f'<Story name="s"><Act name="x">{good}</Act></Story>', extra=f"<Junk>{wp('zzz', 'q')}</Junk>"))
+    assert n.entities[0].trajectory.data.shape == (2, 7) and e.entities[0].trajectory.data.shape == (2, 7)
+    # inf / nan spellings float() accepts are numbers for the scan too (Trajectory rejects them afterwards, in both readers)
+    scan = xosc.scan_xosc(doc(f'<Story name="s"><Act name="x">{group("a", [vtx(0, "-Infinity", "NaN"), vtx(1, 3, 4)])}</Act></Story>').encode())
+    assert scan["trajectories"][0][1][0, 1] == -np.inf and np.isnan(scan["trajectories"][0][1][0, 2])
+    # (3) character references
+    n, e = load("refs.xosc", doc(f'<Story name="s"><Act name="x">{group("c&#65;&#x42;", [vtx(0, 1, 2), vtx(1, 3, 4)])}</Act></Story>', names=("c&#65;&#x42;", "b")))
+    for s in (n, e):
+        assert [x.ref for x in s.entities] == ["cAB", "b"] and s.entities[0].trajectory.data.shape == (2, 7)

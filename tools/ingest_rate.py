@@ -17,57 +17,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-CATALOG = """<?xml version="1.0" encoding="utf-8"?>
-<OpenSCENARIO><FileHeader description="synthetic" author="tools/ingest_rate.py" revMajor="1" revMinor="0" date="2026-01-01T00:00:00"/>
-<Catalog name="SyntheticVehicleCatalog">
-<Vehicle name="car1" vehicleCategory="car"><BoundingBox><Center x="1.37" y="0" z="0.8"/><Dimensions width="2.0" length="4.2" height="1.6"/></BoundingBox></Vehicle>
-<Vehicle name="van" vehicleCategory="van"><BoundingBox><Center x="1.5" y="0" z="1.0"/><Dimensions width="2.2" length="5.6" height="2.2"/></BoundingBox></Vehicle>
-</Catalog></OpenSCENARIO>
-"""
-
-
-def write_scenario(path, rng, n_entities, n_vertices):
-    names = ["ego"] + [f"entity_{i}" for i in range(1, n_entities)]
-    out = ['<?xml version="1.0" encoding="utf-8"?>\n<OpenSCENARIO>\n<FileHeader description="synthetic &amp; seeded" author="x" revMajor="1" '
-           'revMinor="0" date="2026-01-01T00:00:00"/>\n<ParameterDeclarations/>\n<CatalogLocations><VehicleCatalog><Directory path="../Catalogs"/>'
-           '</VehicleCatalog></CatalogLocations>\n<RoadNetwork/>\n<Entities>\n']
-    for n in names:
-        out.append(f'<ScenarioObject name="{n}"><CatalogReference catalogName="SyntheticVehicleCatalog" entryName="{"car1" if rng.random() < 0.8 else "van"}"/></ScenarioObject>\n')
-    out.append("</Entities>\n<Storyboard>\n<Init><Actions>\n")
-    starts = rng.uniform(-100, 100, (n_entities, 2))
-    for n, (x, y) in zip(names, starts):
-        out.append(f'<Private entityRef="{n}"><PrivateAction><TeleportAction><Position><WorldPosition x="{float(x)!r}" y="{float(y)!r}" z="0" h="0.5"/>'
-                   "</Position></TeleportAction></PrivateAction></Private>\n")
-    out.append("</Actions></Init>\n<Story name=\"s\"><Act name=\"a\">\n")
-    for k, n in enumerate(names):
-        t = np.linspace(0.0, 20.0, n_vertices) + (0.0 if k == 0 else rng.uniform(0, 2))
-        h0, v = rng.uniform(-3, 3), rng.uniform(2, 12)
-        xs, ys = starts[k, 0] + v * t * np.cos(h0), starts[k, 1] + v * t * np.sin(h0)
-        out.append(f'<ManeuverGroup name="g{k}" maximumExecutionCount="1"><Actors selectTriggeringEntities="false"><EntityRef entityRef="{n}"/></Actors>'
-                   f'<Maneuver name="m"><Event name="e" priority="overwrite"><Action name="act"><PrivateAction><RoutingAction><FollowTrajectoryAction>'
-                   f'<Trajectory name="t" closed="false"><ParameterDeclarations/><Shape><Polyline>\n')
-        for ti, x, y in zip(t, xs, ys):
-            out.append(f'<Vertex time="{float(ti)!r}"><Position><WorldPosition x="{float(x)!r}" y="{float(y)!r}" h="{float(h0)!r}"/></Position></Vertex>\n')
-        out.append("</Polyline></Shape></Trajectory><TimeReference><Timing domainAbsoluteRelative=\"absolute\" scale=\"1\" offset=\"0\"/></TimeReference>"
-                   "<TrajectoryFollowingMode followingMode=\"position\"/></FollowTrajectoryAction></RoutingAction></PrivateAction></Action>"
-                   "</Event></Maneuver></ManeuverGroup>\n")
-    out.append("</Act></Story>\n<StopTrigger/>\n</Storyboard>\n</OpenSCENARIO>\n")
-    with open(path, "w") as f:
-        f.write("".join(out))
-
-
-def make_directory(root, n_files, n_entities, n_vertices, seed=7):
-    os.makedirs(os.path.join(root, "Catalogs"), exist_ok=True)
-    os.makedirs(os.path.join(root, "Scenarios"), exist_ok=True)
-    with open(os.path.join(root, "Catalogs", "catalog.xosc"), "w") as f:
-        f.write(CATALOG)
-    rng = np.random.default_rng(seed)
-    paths = []
-    for i in range(n_files):
-        p = os.path.join(root, "Scenarios", f"s{i:05d}.xosc")
-        write_scenario(p, rng, n_entities, n_vertices)
-        paths.append(p)
-    return paths
+from scenario_gym_amd.xosc_write import make_directory  # noqa: E402
 
 
 def _load_native(p):
