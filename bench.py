@@ -214,6 +214,184 @@ def load_factory(spec):
     return getattr(importlib.import_module(mod), fn)
 
 
+def _e2e_make_files(args):
+    """(not timed) one worker's share of the synthetic OpenSCENARIO directory."""
+    root, lo, hi, n_entities, n_vertices, duration = args
+    import numpy as np
+
+    from scenario_gym_amd import xosc_write as W
+
+    paths = []
+    for i in range(lo, hi):
+        rng = np.random.default_rng([20240807, i])
+        p = os.path.join(root, "Scenarios", f"s{i:05d}.xosc")
+        W.write_scenario(p, W.synthetic_entities(rng, n_entities, n_vertices, duration=duration, extent=60.0))
+        paths.append(p)
+    return paths
+
+
+def _e2e_load(path):
+    from scenario_gym_amd.xosc import load_scenario_file
+
+    return load_scenario_file(path, relabel=True)
+
+
+def _e2e_load_pack(arg):
+    """One worker task: import a handful of files and pack them (default agents) -- a few arrays travel back, not objects."""
+    from scenario_gym_amd.packing import load_and_pack
+
+    paths, E = arg
+    return load_and_pack(paths, E, relabel=True)
+
+
+def run_e2e(args):
+    """--workload e2e: files -> metrics, the one place the reference published a number ("around 43 scenarios
+    per second at around 400x realtime", scenario-gym.pdf IV-A, with hazard / RSS metrics; reference pipeline
+    manager.py:240-283).  A generated directory of OpenSCENARIO files (Argoverse-like: 40 entities, 11 s at 10 Hz) ->
+    import_scenario (native scan, a pool of processes) -> pack -> sg_upload -> rollout with the RSSDistances callback +
+    CollisionMetric (classified) + 3 ego metrics + RSS -> get_metrics(); the import of chunk k + 1 runs under the device
+    work of chunk k.  Not the headline."""
+    import concurrent.futures as cf
+    import multiprocessing
+    import shutil
+    import tempfile
+
+    import numpy as np
+
+    import scenario_gym_amd as sga
+    import scenario_gym_amd._lib as L
+    from scenario_gym_amd import metrics as M
+    from scenario_gym_amd import xosc_write as W
+
+    n_files, E, nv, duration, dt = args.files, 40, 111, 11.0, 1.0 / 30.0
+    cores = effective_cpus()
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > (n_files * 600_000 + (1 << 30)) else None
+    root = tempfile.mkdtemp(prefix="sgym_e2e_", dir=base)
+    ctx = multiprocessing.get_context("spawn")
+    try:
+        W.write_catalog(os.path.join(root, "Catalogs"))
+        os.makedirs(os.path.join(root, "Scenarios"))
+        t0 = time.perf_counter()
+        with cf.ProcessPoolExecutor(cores, mp_context=ctx) as ex:
+            shares = [(root, n_files * w // cores, n_files * (w + 1) // cores, E, nv, duration) for w in range(cores)]
+            paths = [p for ps in ex.map(_e2e_make_files, shares) for p in ps]
+        gen_s = time.perf_counter() - t0
+        n_bytes = sum(os.path.getsize(p) for p in paths[:16]) / 16 * len(paths)
+        chunk = min(args.chunk, n_files)
+        chunks = [paths[i:i + chunk] for i in range(0, n_files, chunk)]
+        stages = dict(ingest=0.0, merge=0.0, upload=0.0, device=0.0, readback=0.0)
+        all_metrics = []
+        SUB = 32  # files per worker task
+
+        def factory():
+            return [M.EgoAvgSpeed(), M.EgoMaxSpeed(), M.EgoDistanceTravelled(), M.CollisionMetric(), M.RSS()]
+
+        def tasks(ch):
+            return [(ch[i:i + SUB], E) for i in range(0, len(ch), SUB)]
+
+        def device_part(gym, parts):
+            from scenario_gym_amd.packing import merge_packed
+
+            t = time.perf_counter()
+            packed = merge_packed(parts)
+            stages["merge"] += time.perf_counter() - t
+            t = time.perf_counter()
+            gym.set_packed(packed)                         # sg_upload (+ the reset launch); the engine is reused
+            stages["upload"] += time.perf_counter() - t
+            t = time.perf_counter()
+            gym.rollout()
+            gym.engine.synchronize()
+            stages["device"] += time.perf_counter() - t
+            t = time.perf_counter()
+            out = gym.get_metrics()
+            stages["readback"] += time.perf_counter() - t
+            return out
+
+        with cf.ProcessPoolExecutor(cores, mp_context=ctx) as ex:
+            list(ex.map(_e2e_load_pack, [([p], E) for p in paths[:cores]]))   # (workers started and warm: imports, catalog cache)
+            gym = sga.BatchedScenarioGym(timestep=dt, state_callbacks=[M.RSSDistances()], metrics=factory, event_capacity=16)
+            device_part(gym, [_e2e_load_pack((chunks[0][:64], E))])           # warm: library load, first launches
+            for k in stages:
+                stages[k] = 0.0
+            import torch
+
+            torch.cuda.synchronize()
+            t_all = time.perf_counter()
+            t = time.perf_counter()
+            fut = ex.map(_e2e_load_pack, tasks(chunks[0]))
+            for c in range(len(chunks)):
+                parts = list(fut)                          # waits for the import of chunk c ...
+                stages["ingest"] += time.perf_counter() - t
+                if c + 1 < len(chunks):
+                    fut = ex.map(_e2e_load_pack, tasks(chunks[c + 1]))   # ... the next one runs under this chunk's device work
+                all_metrics.extend(device_part(gym, parts))
+                t = time.perf_counter()
+            wall = time.perf_counter() - t_all
+            gym.close()
+        assert len(all_metrics) == n_files
+        steps = int(np.ceil(duration / dt))
+        line = {
+            "metric": "scenarios/s (OpenSCENARIO files -> metrics, end to end)", "value": n_files / wall, "unit": "scenarios/s",
+            "n_gpus": 1, "steps": 1, "warmup": 1, "ms_per_step": wall * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "x_realtime": n_files * duration / wall,
+            "entity_steps_per_s": n_files * E * steps / wall,
+            "stage_seconds": {k: round(v, 4) for k, v in stages.items()},
+            "stage_note": "ingest = time the device loop waited for the import pool (native scan + Trajectory normalisation + packing "
+                          "in the workers; the import of chunk k + 1 overlaps the device work of chunk k); merge = concatenating "
+                          "the workers' arrays; upload = sg_upload + reset; device = sg_rollout incl. the RSS callback; "
+                          "readback = get_metrics (events classified on the device, one Python dict per scenario)",
+            "config": {"name": "e2e", "workload": f"{n_files} generated OpenSCENARIO files ({E} entities, {nv} vertices = {duration:g} s at 10 Hz, "
+                                                  f"~{n_bytes / n_files / 1e3:.0f} kB each) -> import_scenario (native scan, {cores} processes) -> "
+                                                  f"pack -> sg_upload -> rollout at dt = 1/30 ({steps} steps) with RSSDistances + CollisionMetric "
+                                                  f"(classified) + EgoAvgSpeed / MaxSpeed / DistanceTravelled + RSS -> get_metrics, chunks of {chunk}",
+                       "files": n_files, "entities": E, "sim_steps": steps, "timestep": dt, "chunk": chunk, "host_processes": cores,
+                       "bytes": int(n_bytes), "generate_seconds_not_timed": round(gen_s, 2)},
+            "published_reference": {"value": 43.0, "unit": "scenarios/s", "x_realtime": 400.0,
+                                    "note": "BASELINE.md 1 / scenario-gym.pdf IV-A: the reference's own figure on its hardware and the "
+                                            "Argoverse recordings, with hazard / RSS metrics -- other data, other machine: context, not a ratio"},
+            "sample_metrics": all_metrics[0],
+        }
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = e2e_cpu_baseline(paths, dt, steps, cores)
+        print(json.dumps(line, default=float))
+        return line
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+
+
+def e2e_cpu_baseline(paths, dt, steps, cores):
+    """The same pipeline with the CPU oracle in place of the device (a port, not the reference): import -> oracle rollout with
+    its per-step RSS callback -> metrics, one scenario per thread, on a bounded sample."""
+    import concurrent.futures as cf
+
+    from oracle import oracle as O
+    from scenario_gym_amd.packing import pack_scenarios, unpack_scenario
+    from scenario_gym_amd.xosc import load_scenario_file
+
+    O.build()
+    O.lib()
+    sample = paths[: max(cores * 4, 16)]
+
+    def one(p):
+        sc = load_scenario_file(p, relabel=True)
+        packed, _ = pack_scenarios([sc])
+        s = unpack_scenario(packed, 0)
+        o = O.rollout(s["knot_off"], s["knots"], s["bbox"], s["etype"], s["kind"], s["ego"], s["t0"], s["length"], dt,
+                      ctrl=s["ctrl"], max_steps=steps + 8, record=True)
+        O.rss_rollout(o, s["bbox"], s["ego"])
+        return o["n_steps"]
+
+    one(sample[0])
+    t0 = time.perf_counter()
+    with cf.ThreadPoolExecutor(cores) as ex:
+        n = list(ex.map(one, sample))
+    dtm = time.perf_counter() - t0
+    return {"value": len(sample) / dtm, "unit": "scenarios/s", "cores": cores, "kind": "port",
+            "sample": f"{len(sample)} of the files, {cores} threads: import_scenario + oracle/sgym_oracle.c rollout ({int(sum(n) / len(n))} steps) with "
+                      f"its RSS callback driven step by step from Python + metrics, {dtm:.1f}s"}
+
+
 def main(argv=None, make_engine=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -223,7 +401,7 @@ def main(argv=None, make_engine=None):
     ap.add_argument("--entities", type=int, default=None)
     ap.add_argument("--sim-steps", type=int, default=10000)
     ap.add_argument("--ego", default="pid", choices=["pid", "replay"])
-    ap.add_argument("--workload", default="c3", choices=["c3", "c2", "c2s", "c5", "c3rss", "c3s"],
+    ap.add_argument("--workload", default="c3", choices=["c3", "c2", "c2s", "c5", "c3rss", "c3s", "e2e"],
                     help="BASELINE.json configs: c3 = 4096x64 PID ego (default, the headline), c2 = 256x16 replay (state of "
                          "every step materialised), c5 = 1024x256 social-force crowd; c2s = the c2 batch through the "
                          "time-sliced replay path (final state + metrics + events only: a separate mode, never the headline); c3rss = the c3 "
@@ -238,6 +416,8 @@ def main(argv=None, make_engine=None):
                          "through the CPU oracle for the full horizon and compare the final state / metric rows / events bit "
                          "for bit; a mismatch makes the exit code non-zero.  Default 16 (c5, c3rss: 4); 0 = off")
     ap.add_argument("--engine-factory", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--files", type=int, default=4096, help="e2e: OpenSCENARIO files to generate and run")
+    ap.add_argument("--chunk", type=int, default=1024, help="e2e: scenarios per device batch")
     ap.add_argument("--ped-noise", default="off", choices=["off", "device"],
                     help="c5: SocialForce noise terms (social_force.py:106-114): off = std 0 (parity runs), device = the "
                          "reference's default std with the counter-based device RNG")
@@ -250,6 +430,9 @@ def main(argv=None, make_engine=None):
 
         def make_engine(R, first):
             return factory(R, first, args.entities, args.sim_steps)
+
+    if args.workload == "e2e":
+        return run_e2e(args)
 
     import numpy as np
 

@@ -2471,7 +2471,8 @@ struct SliceArgs {
 // (PID / vehicle agents) replay a controller table that spans the WHOLE call -- row j - 1 = the lane after step j, written by
 // control_kernel launches that run ahead of the slices -- so a slice that starts at step a finds its lanes' poses there
 // like everything else it needs in the clock.
-template <int G, int WV, bool PED, bool TAB, bool HAST, bool ROAD = false, bool RSSV = false, bool CROWD = false, bool SLICE = false>
+template <int G, int WV, bool PED, bool TAB, bool HAST, bool ROAD = false, bool RSSV = false, bool CROWD = false, bool SLICE = false,
+          bool PLANAR = false>
 __device__ __forceinline__ void rollout_body(
     const Params &p, double timestep, int n_steps, int do_reset, int force, const double *actions /*[n][R][2]*/,
     const double *tab /*controller table planes*/, const SliceArgs &sa = SliceArgs{})
@@ -2590,6 +2591,13 @@ __device__ __forceinline__ void rollout_body(
         nwp = (int)(rt >> 48);
     }
 
+    // PLANAR (table variant, one wavefront per tile; its own entry point, rollout_kernel_tab_planar): every knot of the
+    // batch has z = pitch = roll = +0.0 (sg_upload checks the bit patterns).  Those three channels are then +0.0 in every
+    // pose, previous pose and velocity the batch ever holds -- absent lanes included, their rows are zeroed by the reset --
+    // so the step neither interpolates, subtracts, tests nor stores them, and their 18 registers (pose, segment base and
+    // slope) do not exist.
+    static_assert(!PLANAR || (TAB && WV == 1 && !SLICE), "planar: the table variant");
+    constexpr bool planar = PLANAR;
     // register-resident across the time loop
     double pose[6], dist, t, prev_t;
     double velx = 0.0, vely = 0.0; // current velocity (social force input), PED only
@@ -2949,7 +2957,12 @@ __device__ __forceinline__ void rollout_body(
             act_s = a[1];
         }
         double np_[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-        if (!CROWD) {
+        if (PLANAR) {
+            double dq = next_t - S.x_lo;
+            np_[0] = S.sl[0] * dq + S.ylo[0];
+            np_[1] = S.sl[1] * dq + S.ylo[1];
+            np_[3] = S.sl[3] * dq + S.ylo[3];
+        } else if (!CROWD) {
             double dq = next_t - S.x_lo;
 #pragma unroll
             for (int c = 0; c < 6; ++c) np_[c] = S.sl[c] * dq + S.ylo[c];
@@ -3021,9 +3034,11 @@ __device__ __forceinline__ void rollout_body(
                     np_[1] = tj ? sy[j] : np_[1];
                     np_[3] = tj ? sh[j] : np_[3];
                 }
-                np_[2] = take ? pose[2] : np_[2];
-                np_[4] = take ? pose[4] : np_[4];
-                np_[5] = take ? pose[5] : np_[5];
+                if (!planar) {
+                    np_[2] = take ? pose[2] : np_[2];
+                    np_[4] = take ? pose[4] : np_[4];
+                    np_[5] = take ? pose[5] : np_[5];
+                }
                 tab_issue(); // row k + 1 (the table has one spare row), consumed by the next step
             }
         } else if (CROWD) {
@@ -3096,7 +3111,10 @@ __device__ __forceinline__ void rollout_body(
 
         // ---- State.update_poses / update_statistics, state.py:203-239 ----
         double d[6];
-        if (!CROWD || !(npres && !present)) { // (the crowd variant keeps the if / else form: its registers are full)
+        if (PLANAR) {
+            d[0] = np_[0] - pose[0]; d[1] = np_[1] - pose[1]; d[3] = np_[3] - pose[3];
+            d[2] = d[4] = d[5] = 0.0;
+        } else if (!CROWD || !(npres && !present)) { // (the crowd variant keeps the if / else form: its registers are full)
 #pragma unroll
             for (int c = 0; c < 6; ++c) d[c] = np_[c] - pose[c];
         }
@@ -3110,6 +3128,7 @@ __device__ __forceinline__ void rollout_body(
                                 (int)(fld<int64_t>(st_o, ST_META) >> 32), t, prev);
 #pragma unroll
             for (int c = 0; c < 6; ++c) d[c] = np_[c] - prev[c];
+            if (planar) d[2] = d[4] = d[5] = 0.0; // (0 - 0: the extrapolated channels are +0.0 as well)
         }
         double vel[6];
         // z, pitch and roll rarely move.  `flat`: in every lane that commits a pose this step they keep their value
@@ -3120,9 +3139,13 @@ __device__ __forceinline__ void rollout_body(
         bool flat;
         {
             RecipDiv rd(dt);
-            const uint32_t zbits = (uint32_t)(__double2hiint(d[2]) | __double2hiint(d[4]) | __double2hiint(d[5])) |
-                                   (uint32_t)(__double2loint(d[2]) | __double2loint(d[4]) | __double2loint(d[5]));
-            flat = !SLICE && sg_all((!run | !npres | (present & (zbits == 0))) & (dt > 0.0));
+            if (planar) {
+                flat = !SLICE && sg_all(dt > 0.0);
+            } else {
+                const uint32_t zbits = (uint32_t)(__double2hiint(d[2]) | __double2hiint(d[4]) | __double2hiint(d[5])) |
+                                       (uint32_t)(__double2loint(d[2]) | __double2loint(d[4]) | __double2loint(d[5]));
+                flat = !SLICE && sg_all((!run | !npres | (present & (zbits == 0))) & (dt > 0.0));
+            }
             // RecipDiv::safe for three (six) numerators at once: every |d| below 2^961 through one maximum, and each either
             // +0 or at least 2^-959 (NaN fails the second, infinity the first)
             auto lo_ok = [](double a) { return (__builtin_fabs(a) >= 0x1p-959) | (__double_as_longlong(a) == 0); };
@@ -3153,8 +3176,12 @@ __device__ __forceinline__ void rollout_body(
         if (run) {
             present = npres;
             if (npres) {
+                if (PLANAR) {
+                    pose[0] = np_[0]; pose[1] = np_[1]; pose[3] = np_[3];
+                } else {
 #pragma unroll
-                for (int c = 0; c < 6; ++c) pose[c] = np_[c];
+                    for (int c = 0; c < 6; ++c) pose[c] = np_[c];
+                }
                 if (!SLICE) dist += sg_norm3(d[0], d[1], d[2]);
                 if (PED) { velx = vel[0]; vely = vel[1]; }
             }
@@ -3471,6 +3498,13 @@ __global__ __launch_bounds__(64, 2) __attribute__((amdgpu_num_vgpr(96))) void ro
     Params p, double timestep, int n_steps, int do_reset, int force, const double *actions, const double *tab)
 {
     rollout_body<G, 1, false, true, true>(p, timestep, n_steps, do_reset, force, actions, tab);
+}
+// ... for batches whose knots all have z = pitch = roll = +0.0 (PLANAR)
+template <int G>
+__global__ __launch_bounds__(64, 2) __attribute__((amdgpu_num_vgpr(96))) void rollout_kernel_tab_planar(
+    Params p, double timestep, int n_steps, int do_reset, int force, const double *actions, const double *tab)
+{
+    rollout_body<G, 1, false, true, true, false, false, false, false, true>(p, timestep, n_steps, do_reset, force, actions, tab);
 }
 
 // One slice of a time-sliced replay (grid.y = slices; SliceArgs), or its last step with the full state stores

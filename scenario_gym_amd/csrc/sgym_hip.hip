@@ -36,6 +36,7 @@ struct sg_handle {
     sg_config cfg{};
     int R = 0, E = 0, EP = 0, G = 0, WV = 1;
     bool has_ped = false;
+    bool planar = false;      // every knot of the batch has z = pitch = roll = +0.0 (bit patterns): rollout_kernel_tab_planar
     bool sliceable = false;   // every entity is a replay entity / replay agent / PID or vehicle agent (or padding): the batch
                               // can be time-sliced (launch_sliced)
     int slice_mode = 1;       // sg_set_tuning / env SG_SLICE: 0 never, 1 automatic (small batches, long rollouts)
@@ -375,6 +376,8 @@ static void launch_variant(sg_handle *h, dim3 grid, int n_steps, int do_reset, i
         sg::rollout_kernel_rss<G, WV><<<grid, block, 0, h->stream>>>(h->p, h->cfg.timestep, n_steps, do_reset, force, d_actions, nullptr);
     else if (h->cfg.terminal_mask & SG_TERM_EGO_OFF_ROAD)
         sg::rollout_kernel_road<G, WV><<<grid, block, 0, h->stream>>>(h->p, h->cfg.timestep, n_steps, do_reset, force, d_actions, nullptr);
+    else if (use_tab && WV == 1 && h->n_ctl > 0 && h->planar)
+        sg::rollout_kernel_tab_planar<G><<<grid, block, 0, h->stream>>>(h->p, h->cfg.timestep, n_steps, 0, force, nullptr, d_tab);
     else if (use_tab && WV == 1 && h->n_ctl > 0)
         sg::rollout_kernel_tab<G><<<grid, block, 0, h->stream>>>(h->p, h->cfg.timestep, n_steps, 0, force, nullptr, d_tab);
     else if (use_tab)
@@ -890,6 +893,7 @@ extern "C" int sg_upload(sg_handle *h, const sg_scenarios *sc)
     };
     for (size_t o = (size_t)R * EP; o < NE; ++o) slot_defaults(o); // the tail of the last block
     std::vector<int32_t> ctl_ent; // controlled lanes (PID / vehicle agents) in entity order
+    std::vector<char> zpr_zero;   // [R] every knot of the scenario has z = pitch = roll = +0.0 (a planar recording: the usual case)
     int n_ext = 0;
     std::vector<sg::ScenStatic> sstat(R);
     std::vector<std::vector<double>> &grids = h->up_grids; // BatchReplayEntity union knot grid per scenario (entity/batch.py:83-95)
@@ -901,6 +905,7 @@ extern "C" int sg_upload(sg_handle *h, const sg_scenarios *sc)
         std::vector<std::string> errs(nthr);
         std::vector<int> err_r(nthr, R), ext_cnt(nthr, 0);
         std::vector<char> ego_nz(nthr, 0);
+        zpr_zero.assign(R, 1);
         auto work = [&](unsigned w) {
             auto bad = [&](int r, const char *fmt, size_t i, int v) {
                 char buf[256];
@@ -939,6 +944,13 @@ extern "C" int sg_upload(sg_handle *h, const sg_scenarios *sc)
                         for (int64_t j = a + 1; j < b; ++j)
                             if (!(sc->knots[(size_t)j * 7] > sc->knots[(size_t)(j - 1) * 7]))
                                 return bad(r, "sg_upload: knot times of entity %zu are not strictly increasing (%d)", i, 0);
+                        // the row is in cache: are z, pitch and roll +0.0 in every knot (bit patterns: -0.0 and NaN are not)?
+                        uint64_t any = 0;
+                        for (int64_t j = a; j < b; ++j) {
+                            const uint64_t *kr = reinterpret_cast<const uint64_t *>(sc->knots + (size_t)j * 7);
+                            any |= kr[3] | kr[5] | kr[6];
+                        }
+                        if (any) zpr_zero[r] = 0;
                     }
                 }
                 // the union grid (np.unique of the concatenated knot times), while the scenario's knots are in cache.  Every
@@ -1076,6 +1088,8 @@ extern "C" int sg_upload(sg_handle *h, const sg_scenarios *sc)
         run = (i > 0 && (ctl_ent[i] >> 6) == (ctl_ent[i - 1] >> 6)) ? run + 1 : 1;
         h->max_ctl_per_block = std::max(h->max_ctl_per_block, (int)run);
     }
+    h->planar = n_ext == 0 && env_int("SG_PLANAR", 1) != 0; // (the table variant of the rollout kernel: rollout_kernel_tab_planar)
+    for (int r = 0; r < R && h->planar; ++r) h->planar = zpr_zero[r] != 0;
     ctl_ent.resize(((ctl_ent.size() + 63) / 64) * 64, -1);
     p.n_ctl_pad = (int)ctl_ent.size();
     if ((rc = dev_upload(h, SA, &p.ctl_ent, ctl_ent))) return rc;

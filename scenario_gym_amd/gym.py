@@ -139,10 +139,46 @@ class BatchedScenarioGym:
         for st, f in zip(self.states, paths):
             st.scenario_path = f
 
+    def set_packed(self, packed, max_steps: Optional[int] = None):
+        """Throughput path (ScenarioManager.run_scenarios-style sweeps, manager.py:240-283): a batch that arrives already
+        packed -- `packing.load_and_pack` in worker processes, `packing.merge_packed` here -- with the reference's default
+        agents (ego replay agent, everyone else batch replay).  No Scenario / State objects are built: rollout() and
+        get_metrics() (device metrics only) are what such a sweep calls.  The engine of the previous batch is reused when the
+        shape is the same."""
+        if packed.kind.max(initial=0) > 2:
+            raise ValueError("set_packed: replay entities and replay agents only (the default create_agent)")
+        if self._host_callbacks or self._host_terminals():
+            raise ValueError("set_packed: device callbacks / terminal conditions only")
+        horizon = float(np.max(packed.length - packed.t0))
+        self.max_steps = int(max_steps or (math.ceil(max(horizon, 0.0) / self._timestep) + 8))
+        dev_terms = list(self.terminal_conditions)
+        reuse = (self.engine is not None and not self.record and not self.states and
+                 (self.engine.R, self.engine.E) == (packed.n_scenarios, packed.n_entities))
+        if not reuse:
+            self.close()
+            self.engine = RolloutEngine(packed.n_scenarios, packed.n_entities, timestep=self._timestep, persist=self.persist,
+                                        terminal_conditions=dev_terms, record_capacity=0, event_capacity=self.event_capacity,
+                                        device=self.device)
+            if self._rss_on:
+                self.engine.set_rss(True)
+        self.engine.upload(packed)
+        self._packed = packed
+        self.scenarios, self.states, self._host_agents, self._policy_agents = [], [], [], []
+        self._roads_set = True
+        self.metrics = [list(self.metric_factory()) for _ in range(packed.n_scenarios)]
+        if any(not isinstance(m, _DeviceMetric) for m in self.metrics[0]):
+            raise ValueError("set_packed: device metrics only")
+        self._invalidate()
+        self._prev_state = None
+
     def set_scenarios(self, scenarios: Sequence[Scenario], create_agent=_create_agent, max_steps: Optional[int] = None):
         self.close()
         self.scenarios = list(scenarios)
+        import time as _time
+
+        _t = _time.perf_counter()
         packed, agents = pack_scenarios(self.scenarios, create_agent)
+        self._timings = {"pack": _time.perf_counter() - _t}
         self._packed = packed
         horizon = float(np.max(packed.length - packed.t0))
         self.max_steps = int(max_steps or (math.ceil(max(horizon, 0.0) / self._timestep) + 8))

@@ -130,6 +130,58 @@ def pack_scenarios(scenarios, create_agent=None):
     return packed, agents
 
 
+def load_and_pack(paths: Sequence[str], n_entities: Optional[int] = None, relabel: bool = True) -> PackedScenarios:
+    """Import the files (xosc.load_scenario_file) and pack them with the reference's default agents: what a worker process
+    of a many-file sweep returns -- a few large arrays instead of thousands of Python objects."""
+    from .xosc import load_scenario_file
+
+    packed, _ = pack_scenarios([load_scenario_file(p, relabel=relabel) for p in paths])
+    if n_entities is not None and n_entities != packed.n_entities:
+        packed = widen_packed(packed, n_entities)
+    return packed
+
+
+def widen_packed(p: PackedScenarios, E: int) -> PackedScenarios:
+    """The same batch with E >= p.n_entities entity slots per scenario (padding slots: kind NONE)."""
+    R, E0 = p.n_scenarios, p.n_entities
+    if E < E0:
+        raise ValueError(f"batch has {E0} entities per scenario > {E}")
+
+    def pad(a, fill):
+        out = np.full((R, E) + a.shape[1:], fill, a.dtype)
+        out[:, :E0] = a.reshape((R, E0) + a.shape[1:])
+        return out.reshape((R * E,) + a.shape[1:])
+
+    off = p.knot_off[:-1].reshape(R, E0)
+    end = p.knot_off[1:].reshape(R, E0)[:, -1]                 # rows of a scenario's padding slots: empty, at its end
+    ko = np.concatenate([np.concatenate([off, np.repeat(end[:, None], E - E0, axis=1)], axis=1).ravel(), p.knot_off[-1:]])
+    ctrl = None
+    if p.ctrl is not None:
+        ctrl = np.tile(DEFAULT_CTRL, (R * E, 1)).reshape(R, E, -1)
+        ctrl[:, :E0] = p.ctrl.reshape(R, E0, -1)
+        ctrl = ctrl.reshape(R * E, -1)
+    if p.route_off is not None:
+        raise NotImplementedError("widen_packed: batches with pedestrian routes")
+    out = PackedScenarios(R, E, pad(p.kind, 0), pad(p.etype, 2), pad(p.bbox, 1.0), ko, p.knots, p.ego, p.t0, p.length, ctrl)
+    out.refs = p.refs
+    return out.validate()
+
+
+def merge_packed(parts: Sequence[PackedScenarios]) -> PackedScenarios:
+    """Batches of the same entity width, one after the other, as one batch."""
+    E = parts[0].n_entities
+    if any(q.n_entities != E for q in parts) or any(q.route_off is not None for q in parts):
+        raise ValueError("merge_packed: same n_entities, no pedestrian routes")
+    rows = np.cumsum([0] + [len(q.knots) for q in parts])
+    ko = np.concatenate([q.knot_off[:-1] + r for q, r in zip(parts, rows)] + [rows[-1:]])
+    cat = lambda f: np.concatenate([getattr(q, f) for q in parts])  # noqa: E731
+    out = PackedScenarios(sum(q.n_scenarios for q in parts), E, cat("kind"), cat("etype"), cat("bbox"), ko.astype(np.int64),
+                          cat("knots"), cat("ego"), cat("t0"), cat("length"),
+                          None if parts[0].ctrl is None else cat("ctrl"))
+    out.refs = [r for q in parts for r in q.refs]
+    return out.validate()
+
+
 def effective_cpus() -> int:
     """Host CPUs this process may actually use: os.cpu_count() capped by the cgroup CPU quota (a box can show 256 logical
     CPUs under a quota of 16: more busy threads or processes than that are throttled, not run)."""

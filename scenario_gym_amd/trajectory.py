@@ -40,6 +40,32 @@ class Trajectory:
 
     def __init__(self, data, fields: Tuple[str, ...] = _FIELDS):
         data = np.asarray(data)
+        if fields is _FIELDS and data.ndim == 2 and data.shape[1] == 7 and data.dtype == np.float64:
+            # the usual case (all seven columns, as the importers build them) without the per-column loop: same operations
+            t = data[:, 0]
+            if data.shape[0] > 1 and not (t[1:] > t[:-1]).all():
+                data = data[np.unique(t, return_index=True)[1]]  # trajectory.py:60
+            fin = np.isfinite(data).all(axis=0)
+            if not (fin[0] and fin[1] and fin[2]):
+                bad = "t" if not fin[0] else ("x" if not fin[1] else "y")
+                raise ValueError(f"Invalid values found for {bad}. Values required for xyt.")
+            out = data.copy()
+            n = out.shape[0]
+            for c in (3, 5, 6):
+                if not fin[c]:
+                    out[:, c] = 0.0
+            if not fin[4]:
+                if n == 1:
+                    out[:, 4] = 0.0
+                else:  # heading from the finite difference of xy, trajectory.py:69-78
+                    tt, xy = out[:, 0], out[:, 1:3]
+                    g = _lerp_rows(tt, xy, tt + 1e-2) - _lerp_rows(tt, xy, tt - 1e-2)
+                    out[:, 4] = _resolve_heading(np.arctan2(g[:, 1], g[:, 0]))
+            else:
+                out[:, 4] = _resolve_heading(out[:, 4])
+            self._data = out
+            self._data.flags.writeable = False
+            return
         fields = tuple(fields)
         if not all(f in fields for f in ("t", "x", "y")):
             raise ValueError("Trajectory cannot be created with t, x and y values.")

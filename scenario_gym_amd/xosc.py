@@ -286,8 +286,9 @@ def scan_xosc(text: bytes):
     """sgx_parse on the bytes of one file: dict(dirs, road_file, objects, teleports, trajectories) with decoded strings and
     the trajectory vertices as [n, 7] arrays."""
     lib = load_native()
-    caps = [8, max(16, text.count(b"<ScenarioObject")), max(16, text.count(b"<Private ")), max(16, text.count(b"<Event")),
-            max(64, text.count(b"<Vertex"))]
+    # capacities from the length alone (shortest possible element of each kind), a second pass only if one is exceeded
+    n = len(text)
+    caps = [8, n // 96 + 16, n // 112 + 16, n // 160 + 16, n // 72 + 64]
     for _ in range(2):
         dirs, objs = (_Str * caps[0])(), (_Object * caps[1])()
         tele, traj = (_Teleport * caps[2])(), (_Trajectory * caps[3])()
@@ -372,12 +373,17 @@ def import_scenario(osc_file: str, relabel: bool = True) -> Scenario:
             path += ".json"
         if os.path.exists(path) and path.endswith(".json"):
             road_network = RoadNetwork.create_from_json(path)
+    # the last assignment to an entity wins (a FollowTrajectoryAction replaces the Init teleport, a later Event an earlier
+    # one): only that one is normalised into a Trajectory
+    last = {}
     for ref, knot in scan["teleports"]:
         if ref in entities:
-            entities[ref].trajectory = Trajectory(knot[None, :])
+            last[ref] = (knot[None, :], False)
     for ref, verts in scan["trajectories"]:
         if ref in entities and len(verts):
-            entities[ref].trajectory = Trajectory(_fill_elevation(verts, road_network))
+            last[ref] = (verts, True)
+    for ref, (data, fill) in last.items():
+        entities[ref].trajectory = Trajectory(_fill_elevation(data, road_network) if fill else data)
     properties, actions = {}, []
     if b"<UserDefinedAction" in text or b"<Properties" in text[: text.find(b"<Entities")]:
         # (rare) header properties / user-defined actions: not part of the native scan
