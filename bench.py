@@ -37,6 +37,9 @@ WORKLOADS = {
     # c2s (final state + metrics + events, no per-step state in memory); never the headline
     "c3s": dict(R=512, E=64, b_alg=16.0, stored=8.0, config=3, sliced=True),
     "c5": dict(R=1024, E=256, b_alg=154.0, stored=112.0, config=4),
+    # the c5 crowd with ONE PID car per scenario among the 255 pedestrians: the all-pedestrian kernel does not apply, the
+    # general pedestrian variant (rollout_kernel<64, 4, true, false>) runs -- the cliff between the two, measured
+    "c5mix": dict(R=1024, E=256, b_alg=154.0, stored=112.0, config=4, mix=True),
     # the c3 batch with the RSSDistances state callback (metrics/rss/callback.py:58-128) after the reset and after every step,
     # inside the rollout kernel: + one record per entity-step (code 4 B, safe lateral / longitudinal distance 16 B)
     "c3rss": dict(R=4096, E=64, b_alg=134.0, stored=72.0, config=2, rss=True),
@@ -107,14 +110,14 @@ def cpu_baseline(workload, seconds_budget=20.0):
     return out
 
 
-def kernel_name(E, crowd, controlled, rss=False):
+def kernel_name(E, crowd, controlled, rss=False, mix=False):
     """Entry point the library launches for this shape (sgym_hip.hip launch_variant): tile lanes G, wavefronts per tile;
     `controlled`: the batch has PID / vehicle agents (their pre-pass table is replayed by rollout_kernel_tab)."""
     G, WV = min(64, max(4, 1 << (E - 1).bit_length())), (1 if E <= 64 else 2 if E <= 128 else 4)
     if rss:
         return f"sg::rollout_kernel_rss<{G}, {WV}>"
     if crowd:
-        return f"sg::rollout_kernel_crowd<{WV}>" if G == 64 else f"sg::rollout_kernel<{max(G, 16)}, {WV}, true, false>"
+        return f"sg::rollout_kernel_crowd<{WV}>" if (G == 64 and not mix) else f"sg::rollout_kernel<{max(G, 16)}, {WV}, true, false>"
     return f"sg::rollout_kernel_tab<{G}>" if (WV == 1 and controlled) else f"sg::rollout_kernel<{G}, {WV}, false, true>"
 
 
@@ -310,7 +313,9 @@ def run_e2e(args):
         with cf.ProcessPoolExecutor(cores, mp_context=ctx) as ex:
             list(ex.map(_e2e_load_pack, [([p], E) for p in paths[:cores]]))   # (workers started and warm: imports, catalog cache)
             gym = sga.BatchedScenarioGym(timestep=dt, state_callbacks=[M.RSSDistances()], metrics=factory, event_capacity=16)
-            device_part(gym, [_e2e_load_pack((chunks[0][:64], E))])           # warm: library load, first launches
+            # warm, not timed: library load, the engine of the chunk shape with its allocations (the RSS line-test queue alone
+            # is GiBs), first launches
+            device_part(gym, list(ex.map(_e2e_load_pack, tasks(chunks[0]))))
             for k in stages:
                 stages[k] = 0.0
             import torch
@@ -401,7 +406,7 @@ def main(argv=None, make_engine=None):
     ap.add_argument("--entities", type=int, default=None)
     ap.add_argument("--sim-steps", type=int, default=10000)
     ap.add_argument("--ego", default="pid", choices=["pid", "replay"])
-    ap.add_argument("--workload", default="c3", choices=["c3", "c2", "c2s", "c5", "c3rss", "c3s", "e2e"],
+    ap.add_argument("--workload", default="c3", choices=["c3", "c2", "c2s", "c5", "c5mix", "c3rss", "c3s", "e2e"],
                     help="BASELINE.json configs: c3 = 4096x64 PID ego (default, the headline), c2 = 256x16 replay (state of "
                          "every step materialised), c5 = 1024x256 social-force crowd; c2s = the c2 batch through the "
                          "time-sliced replay path (final state + metrics + events only: a separate mode, never the headline); c3rss = the c3 "
@@ -445,7 +450,7 @@ def main(argv=None, make_engine=None):
     args.entities = args.entities or wl["E"]
     if args.workload in ("c2", "c2s"):
         args.ego = "replay"
-    crowd = args.workload == "c5"
+    crowd = args.workload in ("c5", "c5mix")
     rank, world, local_rank, dist = D.init()
     if args.gpus != world and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
@@ -468,7 +473,9 @@ def main(argv=None, make_engine=None):
             torch.cuda.synchronize()
 
         def make_engine(R, first, sliced=None):
-            if crowd:
+            if crowd and wl.get("mix"):
+                packed = synthetic.make_crowd_with_car(R, E, n_steps=T, timestep=dt, seed=seed, first_scenario=first)
+            elif crowd:
                 packed = synthetic.make_crowd(R, E, n_steps=T, timestep=dt, seed=seed, first_scenario=first)
             else:
                 packed = synthetic.make_batch(R, E, n_steps=T, timestep=dt, ego_kind=ego_kind, seed=seed, first_scenario=first)
@@ -603,7 +610,10 @@ def main(argv=None, make_engine=None):
             "per_rank_value": m["per_rank"],
             "config": {
                 "name": args.workload,
-                "workload": (f"{R} scenarios x {E} pedestrians x {T} steps per GPU, PedestrianAgent + SocialForce "
+                "workload": (f"{R} scenarios x ({E - 1} pedestrians + 1 PID car) x {T} steps per GPU, PedestrianAgent + SocialForce / "
+                             f"PIDAgent, all-pairs OBB collisions, CollisionMetric, terminal max_length (BASELINE.json configs[4] "
+                             f"with a vehicle in the crowd)") if (crowd and wl.get("mix")) else
+                            (f"{R} scenarios x {E} pedestrians x {T} steps per GPU, PedestrianAgent + SocialForce "
                              f"(radius 3 m, noise {args.ped_noise}) + PedestrianController, all-pairs OBB collisions, "
                              "CollisionMetric, terminal max_length (BASELINE.json configs[4])") if crowd else
                             (f"{R} scenarios x {E} entities x {T} steps per GPU, "
@@ -628,7 +638,7 @@ def main(argv=None, make_engine=None):
                 "stored_bytes_per_entity_step": wl["stored"],
                 "secondary": secondary,
                 "kernel": (f"sg::rollout_kernel_slice{'_tab' if ego_kind == L.KIND_AGENT_PID else ''}<{min(64, max(4, 1 << (E - 1).bit_length()))}>" if wl.get("sliced") else
-                           kernel_name(E, crowd, ego_kind == L.KIND_AGENT_PID, bool(wl.get("rss")))),
+                           kernel_name(E, crowd, ego_kind == L.KIND_AGENT_PID, bool(wl.get("rss")), bool(wl.get("mix")))),
                 "kernel_ms": avg_ms, "launches_per_rollout": launches_per_rollout, "rollout_device_ms": rollout_ms,
                 "bytes_per_entity_step": b_alg, "entity_steps_per_launch": per_launch,
                 "src_sha16": L.source_sha16(),

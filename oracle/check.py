@@ -36,9 +36,10 @@ def oracle_final(packed, r, dt, T, persist=False, terminal_mask=O.TERM_MAX_LENGT
                      event_cap=event_cap, route_off=s.get("route_off"), routes=s.get("routes"), sf=sf, noise=noise)
 
 
-def compare_final(st, rows, events, r, o, E, event_cap=64, ped=False):
+def compare_final(st, rows, events, r, o, E, event_cap=64, ped=False, kind=None):
     """Mismatching fields of scenario r (device state / metric rows / events) against the oracle result `o`: [] = equal."""
     bad = []
+    E = int(o["poses"].shape[1])  # (a ragged batch: the scenario's own entities, the padding slots are not the oracle's)
     if int(rows["n_steps"][r]) != int(o["n_steps"]):
         bad.append(f"n_steps {rows['n_steps'][r]} != {o['n_steps']}")
     if rows["final_t"][r] != o["final_t"] or st["t"][r] != o["final_t"]:
@@ -48,15 +49,15 @@ def compare_final(st, rows, events, r, o, E, event_cap=64, ped=False):
     for k in ("poses", "vels", "dists"):
         if not _bits(st[k][r, :E], o[k][-1]):
             bad.append(k)
-    W = (E + 63) // 64
-    if not np.array_equal(np.asarray(st["coll"][r]).reshape(-1, W)[:E], o["coll"][-1].reshape(E, W)):
+    W = o["coll"].shape[-1]
+    if not np.array_equal(np.asarray(st["coll"][r]).reshape(len(st["poses"][r]), -1)[:E, :W], o["coll"][-1].reshape(E, W)):
         bad.append("coll")
-    if ped:
-        if not _bits(st["force"][r, :E], o["extra"][-1][:, 2:]):
-            bad.append("force")
-    else:
-        if not _bits(st["ctrl_state"][r, :E], o["extra"][-1]):
-            bad.append("ctrl_state")
+    # pedestrian lanes: the social force they were moved by; every other lane: the controller state
+    is_ped = np.full(E, bool(ped)) if kind is None else (np.asarray(kind)[:E] == O.KIND_AGENT_PEDESTRIAN)
+    if is_ped.any() and not _bits(st["force"][r, :E][is_ped], o["extra"][-1][:, 2:][is_ped]):
+        bad.append("force")
+    if (~is_ped).any() and not _bits(st["ctrl_state"][r, :E][~is_ped], o["extra"][-1][~is_ped]):
+        bad.append("ctrl_state")
     for k in ("ego_avg_speed", "ego_max_speed", "ego_distance_travelled"):
         a, b = rows[k][r], o["metric_" + k]
         if not (a == b or (np.isnan(a) and np.isnan(b))):
@@ -87,7 +88,7 @@ def verify_engine(eng, packed, dt, T, K=16, event_cap=64, ped=False, rss=False, 
     def one(r):
         o = oracle_final(packed, r, dt, T, persist=persist, terminal_mask=terminal_mask, event_cap=max(event_cap, 1), sf=sf,
                          noise=None if noise_of is None else noise_of(r), record=True if rss else "last")
-        bad = compare_final(st, rows, events, r, o, E, event_cap=event_cap, ped=ped)
+        bad = compare_final(st, rows, events, r, o, E, event_cap=event_cap, ped=ped, kind=packed.kind[r * E:(r + 1) * E])
         if rss:
             from scenario_gym_amd.packing import unpack_scenario
 

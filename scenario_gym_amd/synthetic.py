@@ -135,3 +135,30 @@ def make_crowd(n_scenarios, n_entities=256, n_steps=10000, timestep=1.0 / 30.0, 
         np.concatenate(kn), np.zeros(R, np.int32), np.zeros(R), np.full(R, length), np.concatenate(ctrl),
         route_off=np.arange(R * E + 1, dtype=np.int64) * 2, routes=np.concatenate(routes),
     ).validate()
+
+
+def make_crowd_with_car(n_scenarios, n_entities=256, n_steps=10000, timestep=1.0 / 30.0, side=40.0, radius=3.0,
+                        seed=SEED, first_scenario=0, car_kind=L.KIND_AGENT_PID) -> PackedScenarios:
+    """make_crowd with entity 0 of every scenario replaced by a car (car1, a PIDAgent by default) that crosses the square
+    on a straight line while the crowd walks: the all-pedestrian kernel no longer applies, the general pedestrian variant
+    runs (examples/crowds.py:149-205 has vehicles among its pedestrians too)."""
+    p = make_crowd(n_scenarios, n_entities, n_steps, timestep, side, radius, seed, first_scenario)
+    R, E = p.n_scenarios, p.n_entities
+    rng = np.random.default_rng([seed, 6, first_scenario // CHUNK])
+    length = n_steps * timestep
+    cars = np.arange(R) * E
+    y0 = rng.uniform(-side / 4, side / 4, R)
+    kn = p.knots.reshape(R * E, 2, 7)
+    kn[cars, 0, 1], kn[cars, 1, 1] = -side / 2 - 5.0, side / 2 + 5.0
+    kn[cars, :, 2] = y0[:, None]
+    kn[cars, :, 4] = 0.0
+    p.kind[cars] = car_kind
+    p.etype[cars] = 0
+    p.bbox[cars] = CAR1_BBOX
+    p.ctrl[cars] = DEFAULT_CTRL
+    # the cars have no route: their two waypoint rows leave the ragged array
+    keep = np.ones(R * E, bool)
+    keep[cars] = False
+    p.routes = p.routes.reshape(R * E, 2, 2)[keep].reshape(-1, 2)
+    p.route_off = np.concatenate([[0], np.cumsum(np.where(keep, 2, 0))]).astype(np.int64)
+    return p.validate()

@@ -2210,3 +2210,61 @@ def test_sliced_replay_on_the_reference_scenarios(sga, oracle):
         assert np.array_equal(_dense(st["coll"][i, :E], E), g[f"{n}/final_coll"]), n
         for key in ("ego_avg_speed", "ego_max_speed", "ego_distance_travelled"):
             assert rows[key][i] == float(g[f"{n}/metric_{key}"]), (n, key)
+
+
+# --------------------------------------------------------------------------- the timed shapes, oracle-checked
+def test_timed_shape_c3_full_horizon_32_scenarios(sga, oracle):
+    """BASELINE config 3 exactly as bench.py times it -- 4096 scenarios x 64 entities x 10,000 steps, PID egos, max_length,
+    event capacity 64 -- with 32 scenarios spread over the batch re-run through the oracle for the FULL horizon: step counts,
+    clock, every entity's final pose / velocity / distance / collision row / controller state, the ego metric rows and the
+    event lists, bit for bit.  (the timed configuration itself, not a narrower or shorter stand-in.)"""
+    import scenario_gym_amd._lib as L
+    from oracle import check
+    from scenario_gym_amd import synthetic
+
+    R, E, T = 4096, 64, 10000
+    packed = synthetic.make_batch(R, E, n_steps=T, ego_kind=L.KIND_AGENT_PID)
+    eng = sga.RolloutEngine(R, E, terminal_conditions=["max_length"], event_capacity=64)
+    eng.set_slicing(False)
+    eng.upload(packed)
+    eng.rollout(T)
+    ver = check.verify_engine(eng, packed, 1 / 30, T, K=32, event_cap=64, threads=16)
+    rows, _ = eng.metrics()
+    eng.close()
+    assert ver["scenarios"] == 32 and ver["equal"], ver["mismatches"]
+    assert (rows["n_steps"] >= T - 1).all() and rows["done"].all()
+
+
+def test_timed_shape_c5_crowd_2000_steps_8_scenarios(sga, oracle):
+    """BASELINE config 5 at its timed width -- 1024 scenarios x 256 pedestrians, the crowd kernel -- for 2,000 steps (through
+    the densest phase and well into the dispersal), 8 scenarios spread over the batch against the oracle: poses, velocities,
+    distances, collision rows (4 words per entity), social forces, ego metrics, events."""
+    from oracle import check
+    from scenario_gym_amd import synthetic
+
+    R, E, T = 1024, 256, 2000
+    packed = synthetic.make_crowd(R, E, n_steps=T)
+    eng = sga.RolloutEngine(R, E, terminal_conditions=["max_length"], event_capacity=64)
+    eng.upload(packed)
+    eng.rollout(T)
+    ver = check.verify_engine(eng, packed, 1 / 30, T, K=8, event_cap=64, ped=True, threads=16)
+    eng.close()
+    assert ver["scenarios"] == 8 and ver["equal"], ver["mismatches"]
+
+
+def test_crowd_with_a_car_matches_oracle(sga, oracle):
+    """bench.py --workload c5mix in small: crowds with one PID car each (the general pedestrian variant, not the crowd kernel),
+    64- and 256-lane tiles, every scenario against the oracle."""
+    from oracle import check
+    from scenario_gym_amd import synthetic
+
+    for R, E, T, side in ((12, 40, 150, 10.0), (4, 200, 120, 26.0)):
+        packed = synthetic.make_crowd_with_car(R, E, n_steps=T, side=side)
+        eng = sga.RolloutEngine(R, E, terminal_conditions=["max_length"], event_capacity=32)
+        eng.upload(packed)
+        eng.rollout(T)
+        ver = check.verify_engine(eng, packed, 1 / 30, T, K=R, event_cap=32, ped=True)
+        rows, events = eng.metrics()
+        eng.close()
+        assert ver["equal"], ver["mismatches"]
+        assert len(events) > 0   # the car does run into pedestrians
