@@ -386,9 +386,12 @@ int sg_last_kernel_ms(sg_handle *h, float *ms);
 int sg_last_launch_stats(sg_handle *h, int32_t *n_launches, float *kernel_ms_total);
 
 /* ScenarioGym.rollout (scenario_gym.py:256-267) of a batch whose entities are all replay entities / replay agents is a
- * pure function of the clock except for three ordered sums (State.distances, EgoAvgSpeed, the event list).  sg_rollout
+ * pure function of the clock except for three ordered sums (State.distances, EgoAvgSpeed, the event list); PID / vehicle
+ * agents (controller.py:100-258) never look at another entity, so their poses are a function of the step alone once the
+ * controller pre-pass has integrated them (one table for the whole call, filled ahead of the slices).  sg_rollout
  * cuts the time axis of such a batch into slices that run side by side when the batch alone cannot fill the GPU (fewer
- * than 1024 wavefronts, >= 512 steps, no pose recording, no RSS callback): final state, metrics and events are bit-identical
+ * than 1024 wavefronts -- e.g. one GPU's 512-scenario shard of BASELINE config 4 --, >= 512 steps, no pose recording, no RSS
+ * callback, no caller-run agents, no ego_off_road condition): final state, controller state, metrics and events are bit-identical
  * to the step-by-step launch; the states of the intermediate steps are not written to memory (a caller that wants them uses
  * sg_step, record_capacity, or mode 0).  mode: 0 = never, 1 = automatic (default; env SG_SLICE), 2 = whenever the batch
  * is eligible, however short the rollout (tests). */

@@ -3761,10 +3761,12 @@ __device__ __forceinline__ void control_body(const Params &p, double timestep, i
     }
     double seg_hi;
     int seg_cur;
+    double sgr[5] = {0.0, 0.0, 0.0, 0.0, 0.0}; // FAST: the published segment in registers as well (no LDS read, no wait, per step)
     auto seg_publish = [&](const Segment &S) {
         lds.seg[0][lane] = S.x_lo;
         lds.seg[1][lane] = S.ylo[0]; lds.seg[2][lane] = S.ylo[1];
         lds.seg[3][lane] = S.sl[0]; lds.seg[4][lane] = S.sl[1];
+        if (FAST) { sgr[0] = S.x_lo; sgr[1] = S.ylo[0]; sgr[2] = S.ylo[1]; sgr[3] = S.sl[0]; sgr[4] = S.sl[1]; }
         seg_hi = S.x_hi;
         seg_cur = S.cur;
     };
@@ -3781,18 +3783,22 @@ __device__ __forceinline__ void control_body(const Params &p, double timestep, i
     // launch-invariant part of the fast path's vote; reciprocals of the step-invariant denominators
     const bool fast_kind = FAST && !p.ctl_general && sg_all(!active || (kind == SG_KIND_AGENT_PID && bl > 0.0 && bl < 0x1p400));
     const RecipDiv rd_l(active ? bl : 1.0), rd_10(10.0);
+    double cpr[9]; // FAST: the controller parameters in registers
+#pragma unroll
+    for (int c = 0; c < 9; ++c) cpr[c] = FAST ? fld(st, ST_CTRL + c) : 0.0;
+    sg_loads_done();
 
     for (int k = 0; k < n_steps; ++k) {
         const double *Kp = SG_TRIG;
-        asm volatile("" : "+s"(Kp));
+        if (!FAST) asm volatile("" : "+s"(Kp)); // (FAST has registers to spare: the coefficients may live in them for the whole launch)
         ConstTbl K = (ConstTbl)Kp;
         const double next_t = t + timestep; // the rollout kernel's clock, scenario_gym.py:229
         const double state_dt = t - prev_t;
         const double dt = next_t - t;
         if (FAST && fast_kind && sg_all(!active || (present && !(next_t > seg_hi) && __builtin_fabs(pose[3]) < 1.0e5))) {
             // ---- PIDController._step + VehicleController._step (controller.py:205-258, 105-140), straight line ----
-            const double dq = next_t - lds.seg[0][lane];
-            const double tx = lds.seg[3][lane] * dq + lds.seg[1][lane], ty = lds.seg[4][lane] * dq + lds.seg[2][lane];
+            const double dq = next_t - sgr[0];
+            const double tx = sgr[3] * dq + sgr[1], ty = sgr[4] * dq + sgr[2];
             double sin_h, cos_h;
             sg_sincos_core(pose[3], sin_h, cos_h, K);
             const double e0 = tx - pose[0], e1 = ty - pose[1];
@@ -3804,14 +3810,14 @@ __device__ __forceinline__ void control_body(const Params &p, double timestep, i
             const RecipDiv rd(state_dt);
             const double d_lat = e_lat - cs.e_lat_prev, d_lon = e_lon - cs.e_lon_prev;
             const double e_lat_D = rd.div(d_lat);
-            const double kp = lds.ctrl[SG_C_STEER_KP][lane] * gain, kd = lds.ctrl[SG_C_STEER_KD][lane] * gain;
+            const double kp = cpr[SG_C_STEER_KP] * gain, kd = cpr[SG_C_STEER_KD] * gain;
             double steer = kp * e_lat + kd * e_lat_D;
             const double e_lon_D = rd.div(d_lon);
             const double e_lon_I = cs.e_lon_int + e_lon * state_dt;
-            double accel = lds.ctrl[SG_C_ACCEL_KP][lane] * e_lon + lds.ctrl[SG_C_ACCEL_KD][lane] * e_lon_D + lds.ctrl[SG_C_ACCEL_KI][lane] * e_lon_I;
+            double accel = cpr[SG_C_ACCEL_KP] * e_lon + cpr[SG_C_ACCEL_KD] * e_lon_D + cpr[SG_C_ACCEL_KI] * e_lon_I;
             accel = __builtin_fabs(e_lon) > 0.1 ? accel : 0.0;
-            const double max_steer = lds.ctrl[SG_C_MAX_STEER][lane], max_accel = lds.ctrl[SG_C_MAX_ACCEL][lane];
-            const double max_speed = lds.ctrl[SG_C_MAX_SPEED][lane], allow_rev = lds.ctrl[SG_C_ALLOW_REVERSE][lane];
+            const double max_steer = cpr[SG_C_MAX_STEER], max_accel = cpr[SG_C_MAX_ACCEL];
+            const double max_speed = cpr[SG_C_MAX_SPEED], allow_rev = cpr[SG_C_ALLOW_REVERSE];
             accel = __builtin_fmin(__builtin_fmax(accel, -max_accel), max_accel);
             steer = __builtin_fmin(__builtin_fmax(steer, -max_steer), max_steer);
             const double dxs = speed0 * cos_h, dys = speed0 * sin_h;

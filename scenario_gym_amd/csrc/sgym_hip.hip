@@ -600,7 +600,7 @@ static bool slicing_pays(const sg_handle *h, int n_steps)
         return false;
     if (h->n_ctl > 0 && h->max_ctl_per_block > SG_TAB_LANES(h->G, h->WV)) return false; // (as launch_rollout's table path)
     const size_t nblk = h->NE / 64;
-    if (nblk >= 1024 && h->slice_mode != 2) return false; // the batch fills the chip by itself (two wavefronts per SIMD on half of it)
+    if (nblk > 1024 && h->slice_mode != 2) return false; // more than one wavefront per SIMD: the batch fills the chip by itself
     return slice_plan(h, n_steps).bytes <= ((size_t)std::max(1, env_int("SG_SLICE_MB", 8192)) << 20);
 }
 
