@@ -37,8 +37,8 @@ WORKLOADS = {
     # c2s (final state + metrics + events, no per-step state in memory); never the headline
     "c3s": dict(R=512, E=64, b_alg=16.0, stored=8.0, config=3, sliced=True),
     "c5": dict(R=1024, E=256, b_alg=154.0, stored=112.0, config=4),
-    # the c5 crowd with ONE PID car per scenario among the 255 pedestrians: the all-pedestrian kernel does not apply, the
-    # general pedestrian variant (rollout_kernel<64, 4, true, false>) runs -- the cliff between the two, measured
+    # the c5 crowd with ONE PID car per scenario among the 255 pedestrians: the crowd kernel with riders (the car's poses come
+    # from the controller pre-pass); SG_CROWD_RIDERS=0 runs the general pedestrian variant instead -- the cliff, measured
     "c5mix": dict(R=1024, E=256, b_alg=154.0, stored=112.0, config=4, mix=True),
     # the c3 batch with the RSSDistances state callback (metrics/rss/callback.py:58-128) after the reset and after every step,
     # inside the rollout kernel: + one record per entity-step (code 4 B, safe lateral / longitudinal distance 16 B)
@@ -117,8 +117,13 @@ def kernel_name(E, crowd, controlled, rss=False, mix=False):
     if rss:
         return f"sg::rollout_kernel_rss<{G}, {WV}>"
     if crowd:
-        return f"sg::rollout_kernel_crowd<{WV}>" if (G == 64 and not mix) else f"sg::rollout_kernel<{max(G, 16)}, {WV}, true, false>"
-    return f"sg::rollout_kernel_tab<{G}>" if (WV == 1 and controlled) else f"sg::rollout_kernel<{G}, {WV}, false, true>"
+        if G == 64:  # (a crowd with riders -- lanes of other kinds on a pre-pass table -- has its own entry point)
+            return f"sg::rollout_kernel_crowd_riders<{WV}>" if mix and os.environ.get("SG_CROWD_RIDERS", "1") != "0" else \
+                (f"sg::rollout_kernel<64, {WV}, true, false>" if mix else f"sg::rollout_kernel_crowd<{WV}>")
+        return f"sg::rollout_kernel<{max(G, 16)}, {WV}, true, false>"
+    if WV == 1 and controlled:  # (the synthetic batches are planar: z = pitch = roll = +0.0 in every knot)
+        return f"sg::rollout_kernel_tab_planar<{G}>" if os.environ.get("SG_PLANAR", "1") != "0" else f"sg::rollout_kernel_tab<{G}>"
+    return f"sg::rollout_kernel<{G}, {WV}, false, true>"
 
 
 def committed_profile(workload, kind, R, E, T=None):

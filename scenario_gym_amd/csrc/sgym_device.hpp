@@ -1680,7 +1680,11 @@ __device__ __forceinline__ void ped_move(const Params &p, bool go, double fx, do
 // With WV > 1 the tile spans WV wavefronts of one workgroup; only the decisions that gate LDS
 // writes are workgroup-uniform (block_any), the candidate loops run per wavefront.
 // ------------------------------------------------------------------------------------------------
-template <int G, int WV, bool PED, bool CROWD = false, typename LDS>
+// REFINE (pedestrian variants that can hold entities of very different sizes -- a car among pedestrians): the broad phase
+// reaches own radius + the LARGEST radius of the tile, which for a pedestrian next to a car's tile-mate means every
+// pedestrian within ~3 m; `hetero` (static per tile, voted at launch) then runs one cheap circle test with the PAIR's radii
+// over the candidates before the filter.  Conservative like the broad phase itself, so it cannot change any output.
+template <int G, int WV, bool PED, bool CROWD = false, bool REFINE = false, typename LDS>
 __device__ __forceinline__ void tile_collisions(bool present, const double *pose, double velx, double vely,
                                                 double dtn /* next_t - t of the coming step (PED) */,
                                                 double bcx, double bcy, float rad_thr, float trig_eps,
@@ -1688,7 +1692,7 @@ __device__ __forceinline__ void tile_collisions(bool present, const double *pose
                                                 uint64_t (&rows_out)[WV], uint64_t (&mult_rows)[WV],
                                                 uint64_t (&nbr_out)[WV], bool &dense /* in: this lane's wish from the previous call,
                                                 out: its wish for the next one; see all_pairs */, bool *crowd_ok = nullptr,
-                                                PhaseTimers *ptp = nullptr)
+                                                PhaseTimers *ptp = nullptr, bool hetero = false, float rmax_t = 0.0f)
 {
 #ifdef SG_PHASE_TIMERS
     PhaseTimers ptm_dummy;
@@ -1727,7 +1731,8 @@ __device__ __forceinline__ void tile_collisions(bool present, const double *pose
     if (PED) {
         // (CROWD: an absent slot can reach a candidate row through the all-pairs walk, whose masks do not know the presence
         // of other wavefronts' slots; crowd_pairs has no isped test, a NaN position fails its radius rule)
-        L.px[sl] = (!CROWD || present) ? x : __builtin_nan("");
+        // (... and a rider that is not a pedestrian -- a car -- is nobody's social-force neighbour, pedestrian/sensor.py:56-63)
+        L.px[sl] = (!CROWD || (present && is_ped_type)) ? x : __builtin_nan("");
         L.py[sl] = y; L.vx[sl] = velx; L.vy[sl] = vely;
         L.isped[sl] = present && is_ped_type;
         const double vmag = sg_norm2(velx, vely) + 0.0000000001; // social_force.py:148-155, once per neighbour
@@ -1946,6 +1951,27 @@ __device__ __forceinline__ void tile_collisions(bool present, const double *pose
     for (int w = 0; w < WV; ++w) rows_out[w] = cand[w];
     return;
 #endif
+    if (REFINE && hetero) { // (uniform over the wavefront / workgroup, fixed for the launch)
+        any_cand = false;
+#pragma unroll
+        for (int w = 0; w < WV; ++w) {
+            uint64_t c = cand[w], keep = 0;
+            while (sg_any(c != 0)) {
+                if (c) {
+                    const int jl = __builtin_ctzll(c);
+                    c &= c - 1;
+                    const int j = tile0 + w * 64 + jl;
+                    const float2 o = L.cen[j], oh = L.half[j];
+                    const float rj = __builtin_sqrtf(__builtin_fmaf(oh.x, oh.x, oh.y * oh.y)) * 1.00001f; // >= the slot's radius
+                    const float dx = o.x - fx, dy = o.y - fy;
+                    const float pr = (reach - rmax_t) + rj; // own radius + every margin of `reach` + the other radius
+                    if (__builtin_fmaf(dy, dy, dx * dx) <= pr * pr) keep |= 1ull << jl; // (an absent slot: NaN, dropped -- as the filter would)
+                }
+            }
+            cand[w] = keep;
+            any_cand = any_cand || keep != 0;
+        }
+    }
     PH(2);
     // ---- filter: per wavefront, LDS reads only ----
     const float2 myh = L.half[sl];
@@ -2472,7 +2498,7 @@ struct SliceArgs {
 // control_kernel launches that run ahead of the slices -- so a slice that starts at step a finds its lanes' poses there
 // like everything else it needs in the clock.
 template <int G, int WV, bool PED, bool TAB, bool HAST, bool ROAD = false, bool RSSV = false, bool CROWD = false, bool SLICE = false,
-          bool PLANAR = false>
+          bool PLANAR = false, bool RIDERS = false>
 __device__ __forceinline__ void rollout_body(
     const Params &p, double timestep, int n_steps, int do_reset, int force, const double *actions /*[n][R][2]*/,
     const double *tab /*controller table planes*/, const SliceArgs &sa = SliceArgs{})
@@ -2480,6 +2506,12 @@ __device__ __forceinline__ void rollout_body(
     static_assert(!SLICE || (TAB && WV == 1 && !PED && !ROAD && !RSSV), "slices: the table variant, one wavefront per tile");
     static_assert(!(PED && TAB), "pedestrian scenarios run their controllers in the rollout kernel");
     static_assert(!CROWD || (PED && G == 64 && !ROAD && !RSSV), "the crowd variant is a pedestrian variant with 64-lane tiles");
+    // RIDERS (crowd variant; its own entry point, rollout_kernel_crowd_riders): the batch also has lanes that are NOT pedestrian
+    // agents -- replay entities, replay agents, PID / vehicle agents (a car driving through the crowd, recorded pedestrians).
+    // None of them ever looks at another entity (batch.py:34-53, agent.py:125-148, controller.py:105-258), so a pre-pass
+    // (control_kernel_riders) has put their pose and presence after every step of the chunk into the controller table, and
+    // here they only read their row: the crowd kernel stays free of knot segments and vehicle code.
+    static_assert(!RIDERS || CROWD, "riders ride the crowd variant");
     constexpr int NS = 64 * WV;
     __shared__ TileLds<NS, PED, CROWD> lds;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -2513,27 +2545,41 @@ __device__ __forceinline__ void rollout_body(
     // per-launch LDS tables: box extents, controller parameters; broad-phase reach of this lane =
     // own bounding-circle radius + the largest radius in the tile + slack
     float rad_thr, trig_eps, nbr_thr = 0.0f;
+    float rmax_tile = 0.0f;   // REFINE: the largest bounding-circle radius of the tile ...
+    bool hetero = false;      // ... and whether some real entity's is less than two thirds of it
+    constexpr bool REFINE = CROWD ? RIDERS : PED;
     {
         const double bw = fld(st, ST_BW), bl = fld(st, ST_BL);
         float rad = (float)(0.5 * __builtin_sqrt(bl * bl + bw * bw)) * 1.000001f;
         float off = (float)__builtin_sqrt(bcx * bcx + bcy * bcy) * 1.000001f;
-        float rmax = rad, omax = off;
+        // (PED) only entities of type Pedestrian can be somebody's social-force neighbour (pedestrian/sensor.py:56-63): the
+        // neighbour reach needs THEIR largest centre offset, not the car's that drives through the crowd
+        float rmax = rad, omax = off, omax_ped = (PED && is_ped_type) ? off : 0.0f;
 #pragma unroll
         for (int o = 1; o < G; o <<= 1) {
             rmax = __builtin_fmaxf(rmax, __shfl_xor(rmax, o, 64));
             omax = __builtin_fmaxf(omax, __shfl_xor(omax, o, 64));
+            if (PED) omax_ped = __builtin_fmaxf(omax_ped, __shfl_xor(omax_ped, o, 64));
         }
         if (WV > 1) { // across the workgroup's wavefronts
             float *red = reinterpret_cast<float *>(lds.cor);
-            if (lane == 0) { red[wave] = rmax; red[8 + wave] = omax; }
+            if (lane == 0) { red[wave] = rmax; red[8 + wave] = omax; red[16 + wave] = omax_ped; }
             __syncthreads();
-            for (int w = 0; w < WV; ++w) { rmax = __builtin_fmaxf(rmax, red[w]); omax = __builtin_fmaxf(omax, red[8 + w]); }
+            for (int w = 0; w < WV; ++w) {
+                rmax = __builtin_fmaxf(rmax, red[w]); omax = __builtin_fmaxf(omax, red[8 + w]);
+                omax_ped = __builtin_fmaxf(omax_ped, red[16 + w]);
+            }
             __syncthreads();
         }
         // hardware sin/cos (error d = SG_TRIG32_ERR per value): each centre moves by <= 2 d off, so the reach grows
         // by 2 d (off + omax); in the filter every gap is a sum of (length <= reach) x (trig product, error <= 4 d)
         rad_thr = rad + rmax + 2e-3f + 2.0f * SG_TRIG32_ERR * (off + omax);
         trig_eps = SG_TRIG32_ERR * (12.0f * rad_thr + 4.0f * (off + omax));
+        if (REFINE) {
+            rmax_tile = rmax;
+            const bool small = kind != SG_KIND_NONE && rad * 1.5f < rmax;
+            hetero = WV == 1 ? sg_any(small) : (__syncthreads_or(small) != 0);
+        }
         lds.half[sl] = make_float2((float)(0.5 * bl), (float)(0.5 * bw));
         lds.boxwl[0][sl] = bw;
         lds.boxwl[1][sl] = bl;
@@ -2543,7 +2589,8 @@ __device__ __forceinline__ void rollout_body(
         }
         if (PED) // PedestrianSensor radius is measured between reference points; centres differ by the box offsets
             nbr_thr = kind == SG_KIND_AGENT_PEDESTRIAN
-                          ? (float)fld(st, ST_CTRL + SG_C_PED_RADIUS) * 1.000001f + off + omax + 2e-3f : 0.0f;
+                          ? (float)fld(st, ST_CTRL + SG_C_PED_RADIUS) * 1.000001f + off + omax_ped + 2e-3f +
+                                2.0f * SG_TRIG32_ERR * (off + omax_ped) : 0.0f;
         if (CROWD) { // thresholds of the radius rule (sg_in_radius), per pedestrian
             const double rr = fld(st, ST_CTRL + SG_C_PED_RADIUS), r2 = rr * rr;
             lds.r2hi[sl] = r2 * (1.0 + 1e-9);
@@ -2617,6 +2664,9 @@ __device__ __forceinline__ void rollout_body(
     const int64_t ctl_q = (TAB && HAST) ? fld<int64_t>(st, ST_CTL) : -1;
     const bool tab_lane = TAB && HAST && ctl_q >= 0 && (kind == SG_KIND_AGENT_PID || kind == SG_KIND_AGENT_VEHICLE);
     const size_t tab_lane_stride = (size_t)(p.tab_steps + 1) * CT_W; // doubles per lane
+    // RIDERS: this lane's column of the table (plane 0: x, y, h, speed; plane 2: z, pitch, roll, present)
+    const bool rider = RIDERS && kind != SG_KIND_NONE && kind != SG_KIND_AGENT_PEDESTRIAN;
+    const double *rider_row = RIDERS ? tab + (size_t)(rider ? fld<int64_t>(st, ST_CTL) : 0) * tab_lane_stride : nullptr;
     int last_k = -1;                                                 // last step of this launch the scenario executed
     constexpr int TL = SG_TAB_LANES(G, WV);
     int cl[TL];                       // wave-uniform: the controlled lanes of this wavefront
@@ -2774,8 +2824,8 @@ __device__ __forceinline__ void rollout_body(
         // collisions of the reset state; pedestrian scenes also need the neighbour candidates (and LDS positions) of the
         // current state when they continue
         uint64_t tmp_rows[WV];
-        tile_collisions<G, WV, PED, CROWD>(present, pose, velx, vely, (t + timestep) - t, bcx, bcy, rad_thr, trig_eps, nbr_thr, cell_inv,
-                                           is_ped_type, sl, tile0, lds, tmp_rows, mult_rows, nbr, dense, &crowd_ok);
+        tile_collisions<G, WV, PED, CROWD, REFINE>(present, pose, velx, vely, (t + timestep) - t, bcx, bcy, rad_thr, trig_eps, nbr_thr, cell_inv,
+                                                   is_ped_type, sl, tile0, lds, tmp_rows, mult_rows, nbr, dense, &crowd_ok, nullptr, hetero, rmax_tile);
         if (rs) {
 #pragma unroll
             for (int w = 0; w < WV; ++w) row[w] = tmp_rows[w];
@@ -3042,7 +3092,14 @@ __device__ __forceinline__ void rollout_body(
                 tab_issue(); // row k + 1 (the table has one spare row), consumed by the next step
             }
         } else if (CROWD) {
-            if (kind == SG_KIND_AGENT_PEDESTRIAN) {
+            if (RIDERS && rider) { // the pre-pass row of this step: pose and presence after it
+                const double4 a = *reinterpret_cast<const double4 *>(rider_row + (size_t)k * CT_W);
+                const double4 b = *reinterpret_cast<const double4 *>(rider_row + (size_t)k * CT_W + 2 * (size_t)p.n_ctl_pad * tab_lane_stride);
+                sg_loads_done();
+                np_[0] = a.x; np_[1] = a.y; np_[3] = a.z;
+                np_[2] = b.x; np_[4] = b.y; np_[5] = b.z;
+                npres = b.w != 0.0;
+            } else if (kind == SG_KIND_AGENT_PEDESTRIAN) {
                 if (present) {
                     npres = true;
                     if (run)
@@ -3248,8 +3305,8 @@ __device__ __forceinline__ void rollout_body(
 #pragma unroll
         for (int w = 0; w < WV; ++w) nrow[w] = 0;
 #else
-        tile_collisions<G, WV, PED, CROWD>(present, pose, velx, vely, (t + timestep) - t, bcx, bcy, rad_thr, trig_eps, nbr_thr, cell_inv,
-                                           is_ped_type, sl, tile0, lds, nrow, mult_rows, nbr, dense, &crowd_ok, &ptm);
+        tile_collisions<G, WV, PED, CROWD, REFINE>(present, pose, velx, vely, (t + timestep) - t, bcx, bcy, rad_thr, trig_eps, nbr_thr, cell_inv,
+                                                   is_ped_type, sl, tile0, lds, nrow, mult_rows, nbr, dense, &crowd_ok, &ptm, hetero, rmax_tile);
 #endif
         if (run) {
 #pragma unroll
@@ -3418,6 +3475,13 @@ __device__ __forceinline__ void rollout_body(
                     m_avg = lr2[CT_MAVG]; m_max = lr2[CT_MMAX]; m_t = lr2[CT_MT];
                 }
             }
+        } else if (RIDERS && rider) {
+            if (last_k >= 0 && (kind == SG_KIND_AGENT_PID || kind == SG_KIND_AGENT_VEHICLE)) { // controller state after the last executed step
+                const double *lr = rider_row + (size_t)last_k * CT_W;
+                const double *lr1 = lr + (size_t)p.n_ctl_pad * tab_lane_stride; // plane 1
+                stf(dy, SG_F_CTRL + 0, lr[CT_SPEED]); stf(dy, SG_F_CTRL + 1, lr1[CT_ELON]);
+                stf(dy, SG_F_CTRL + 2, lr1[CT_ELAT]); stf(dy, SG_F_CTRL + 3, lr1[CT_EINT]);
+            }
         } else {
             stf(dy, SG_F_CTRL + 0, cs.speed); stf(dy, SG_F_CTRL + 1, cs.e_lon_prev);
             stf(dy, SG_F_CTRL + 2, cs.e_lat_prev); stf(dy, SG_F_CTRL + 3, cs.e_lon_int);
@@ -3458,6 +3522,14 @@ __global__ __launch_bounds__(64 * WV, SG_WAVES_PER_SIMD_PED) void rollout_kernel
     Params p, double timestep, int n_steps, int do_reset, int force, const double *actions, const double *tab)
 {
     rollout_body<64, WV, true, false, false, false, false, true>(p, timestep, n_steps, do_reset, force, actions, tab);
+}
+
+// ... with riders: lanes of other kinds whose poses come from the pre-pass table (see rollout_body, RIDERS)
+template <int WV>
+__global__ __launch_bounds__(64 * WV, SG_WAVES_PER_SIMD_PED) void rollout_kernel_crowd_riders(
+    Params p, double timestep, int n_steps, int do_reset, int force, const double *actions, const double *tab)
+{
+    rollout_body<64, WV, true, false, false, false, false, true, false, false, true>(p, timestep, n_steps, do_reset, force, actions, tab);
 }
 
 // terminal_conditions with "ego_off_road": controllers in the kernel, road index lookups for slot 0
@@ -3704,7 +3776,10 @@ struct CtlLds { double ctrl[9][64]; double seg[5][64]; };
 // (test_controller_prepass_equals_inline_controllers, SG_CTL_FAST=0 forces the general code).
 // FAST: compiled in for control_kernel_fast only (the time-sliced path, where the pre-pass is alone on the chip and has no
 // register budget to keep); control_kernel -- co-resident with the rollout kernel under 128 VGPRs -- stays as it was.
-template <bool FAST>
+// RIDERS (control_kernel_riders, for rollout_kernel_crowd_riders): the lanes are ALL non-pedestrian entities of a crowd batch
+// -- replay entities (the scenario's union grid, presence rule of batch.py:45-52) and replay agents (own knots, clamped;
+// agent.py:125-128) beside the PID / vehicle agents -- and every row also gets plane 2 = z, pitch, roll, presence.
+template <bool FAST, bool RIDERS = false>
 __device__ __forceinline__ void control_body(const Params &p, double timestep, int n_steps, int first, int k0,
                                              const double *actions /*[n][R][2]*/, double *tab, int row0, int metrics)
 {
@@ -3779,6 +3854,18 @@ __device__ __forceinline__ void control_body(const Params &p, double timestep, i
     double *out = tab + (q * (size_t)(p.tab_steps + 1) + (size_t)row0) * CT_W;      // plane 0 rows of this lane
     double *out1 = out + (size_t)p.n_ctl_pad * ((size_t)(p.tab_steps + 1) * CT_W); // plane 1
     double *out2 = out1 + (size_t)p.n_ctl_pad * ((size_t)(p.tab_steps + 1) * CT_W); // plane 2
+    // RIDERS: a replay lane's own table (union grid / own knots) and its current segment, all six channels
+    const bool replay_lane = RIDERS && (kind == SG_KIND_REPLAY || kind == SG_KIND_AGENT_REPLAY);
+    const double max_t = fld(st, ST_MAX_T);
+    const bool is_static = (int)(meta >> 32) == 1;
+    Table TR{};
+    Segment SR{};
+    if (RIDERS) {
+        TR = lane_table(p, replay_lane ? kind : SG_KIND_NONE, p.sstat[r], (int)(ent - r * (uint32_t)p.EP), st);
+        if (!replay_lane) TR.n = 0;
+        SR.cur = seg_locate(TR, t);
+        seg_load(TR, SR);
+    }
     sg_loads_done();
     // launch-invariant part of the fast path's vote; reciprocals of the step-invariant denominators
     const bool fast_kind = FAST && !p.ctl_general && sg_all(!active || (kind == SG_KIND_AGENT_PID && bl > 0.0 && bl < 0x1p400));
@@ -3882,7 +3969,14 @@ __device__ __forceinline__ void control_body(const Params &p, double timestep, i
         np_[0] = lds.seg[3][lane] * dq + lds.seg[1][lane]; // PID target (x, y) at next_t
         np_[1] = lds.seg[4][lane] * dq + lds.seg[2][lane];
         bool npres = false;
-        if (present) {
+        if (RIDERS && replay_lane) {
+            if (next_t > SR.x_hi) { seg_advance(TR, SR, next_t); sg_loads_done(); }
+            const double dqr = next_t - SR.x_lo;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) np_[c] = SR.sl[c] * dqr + SR.ylo[c];
+            npres = kind == SG_KIND_REPLAY ? (p.persist || is_static || (next_t >= min_t && next_t <= max_t))  // batch.py:45-52
+                                           : (present || min_t >= t);                                         // scenario_gym.py:233-244
+        } else if (present) {
             npres = true;
             const double tx = np_[0], ty = np_[1];
 #pragma unroll
@@ -3930,6 +4024,7 @@ __device__ __forceinline__ void control_body(const Params &p, double timestep, i
         *reinterpret_cast<double4 *>(out + (size_t)k * CT_W) = make_double4(pose[0], pose[1], pose[3], cs.speed);
         *reinterpret_cast<double4 *>(out1 + (size_t)k * CT_W) = make_double4(cs.e_lon_prev, cs.e_lat_prev, cs.e_lon_int, 0.0);
         if (is_ego && metrics) *reinterpret_cast<double4 *>(out2 + (size_t)k * CT_W) = make_double4(m_avg, m_max, m_t, 0.0);
+        if (RIDERS) *reinterpret_cast<double4 *>(out2 + (size_t)k * CT_W) = make_double4(pose[2], pose[4], pose[5], present ? 1.0 : 0.0);
     }
 #pragma unroll
     for (int c = 0; c < 6; ++c) cst[(CS_POSE + c) * NP] = pose[c];
@@ -3945,6 +4040,11 @@ __global__ __launch_bounds__(64, SG_CTL_WAVES) void control_kernel(Params p, dou
                                                      const double *actions /*[n][R][2]*/, double *tab, int row0, int metrics)
 {
     control_body<false>(p, timestep, n_steps, first, k0, actions, tab, row0, metrics);
+}
+__global__ __launch_bounds__(64, 2) void control_kernel_riders(Params p, double timestep, int n_steps, int first, int k0,
+                                                               const double *actions /*[n][R][2]*/, double *tab, int row0, int metrics)
+{
+    control_body<false, true>(p, timestep, n_steps, first, k0, actions, tab, row0, 0);
 }
 __global__ __launch_bounds__(64, 1) void control_kernel_fast(Params p, double timestep, int n_steps, int first, int k0,
                                                              const double *actions /*[n][R][2]*/, double *tab, int row0, int metrics)

@@ -49,6 +49,8 @@ struct sg_handle {
     std::vector<int> clock_of;     // [R]
     double *d_clock_t0 = nullptr;
     bool all_ped = false;     // every entity of the batch is a pedestrian agent of catalog type Pedestrian (or padding)
+    bool crowd_riders = false; // a crowd (64-lane tiles) whose other lanes are replay entities / replay agents / PID / vehicle agents:
+                               // rollout_kernel_crowd_riders + control_kernel_riders (env SG_CROWD_RIDERS=0: the general variant)
     int crowd_kernel = 1;     // env SG_CROWD_KERNEL=0: all-pedestrian batches take the general pedestrian variant too
     sg_social_force sf{};
     int noise_mode = 0;           // sg_set_ped_noise
@@ -365,6 +367,8 @@ static void launch_variant(sg_handle *h, dim3 grid, int n_steps, int do_reset, i
 #endif
     if (h->has_ped && h->all_ped && G == 64 && !h->has_road && h->crowd_kernel && !h->rss_fused)
         sg::rollout_kernel_crowd<WV><<<grid, block, 0, h->stream>>>(h->p, h->cfg.timestep, n_steps, do_reset, force, d_actions, nullptr);
+    else if (use_tab && h->has_ped && G == 64) // (launch_rollout: a crowd with riders, their table is d_tab)
+        sg::rollout_kernel_crowd_riders<WV><<<grid, block, 0, h->stream>>>(h->p, h->cfg.timestep, n_steps, 0, force, nullptr, d_tab);
     else if (h->has_ped && h->rss_fused)
         sg::rollout_kernel_rss_ped<(WV > 1 || G >= 16) ? G : 16, WV><<<grid, block, 0, h->stream>>>(h->p, h->cfg.timestep, n_steps, do_reset, force, d_actions, nullptr);
     else if (h->rss_fused && (h->cfg.terminal_mask & SG_TERM_EGO_OFF_ROAD))
@@ -451,7 +455,9 @@ static int launch_rollout(sg_handle *h, int n_steps, int do_reset, int force, co
     size_t ev_next = 0;
     // the table variant serves SG_TAB_LANES controlled lanes per wavefront; denser batches keep their controllers
     // in the rollout kernel, where they fill the wavefront anyway
-    const bool use_tab = !h->has_ped && !h->rss_fused && !(h->cfg.terminal_mask & SG_TERM_EGO_OFF_ROAD) && h->n_ext == 0 && n_steps >= tab_min && h->max_ctl_per_block <= SG_TAB_LANES(h->G, h->WV);
+    // (a crowd with riders: every launch that steps replays the riders' table, however short)
+    const bool riders = h->crowd_riders && !h->has_road && !h->rss_fused && h->n_ctl > 0 && n_steps > 0;
+    const bool use_tab = riders || (!h->has_ped && !h->rss_fused && !(h->cfg.terminal_mask & SG_TERM_EGO_OFF_ROAD) && h->n_ext == 0 && n_steps >= tab_min && h->max_ctl_per_block <= SG_TAB_LANES(h->G, h->WV));
     // short calls (the per-tick loop of an RL driver) are not timed: four event records cost more than their kernel
     h->timing_now = use_tab || n_steps >= 16;
     if (h->timing_now) HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
@@ -511,8 +517,12 @@ static int launch_rollout(sg_handle *h, int n_steps, int do_reset, int force, co
                 if (!no_overlap && c >= 2) HIP_TRY(h, hipStreamWaitEvent(cs, main_done[c - 2], 0)); // table buffer free
                 for (int s0 = 0; s0 < n; s0 += h->ctl_slice) { // short launches: the pre-pass load moves between SIMDs
                     const int ns = std::min(h->ctl_slice, n - s0);
-                    sg::control_kernel<<<cgrid, cblock, 0, cs>>>(h->p, h->cfg.timestep, ns, c == 0 && s0 == 0, k0 + s0,
-                                                                 d_actions, tab, s0, 1);
+                    if (riders)
+                        sg::control_kernel_riders<<<cgrid, cblock, 0, cs>>>(h->p, h->cfg.timestep, ns, c == 0 && s0 == 0, k0 + s0,
+                                                                            d_actions, tab, s0, 0);
+                    else
+                        sg::control_kernel<<<cgrid, cblock, 0, cs>>>(h->p, h->cfg.timestep, ns, c == 0 && s0 == 0, k0 + s0,
+                                                                     d_actions, tab, s0, 1);
                 }
                 HIP_TRY(h, hipGetLastError());
                 if (!no_overlap) {
@@ -805,6 +815,13 @@ extern "C" int sg_upload(sg_handle *h, const sg_scenarios *sc)
         h->all_ped = h->all_ped && (sc->kind[i] == SG_KIND_NONE || (sc->kind[i] == SG_KIND_AGENT_PEDESTRIAN && sc->etype[i] == 1));
     }
     if (h->has_ped && h->WV == 1 && h->G < 16) { h->G = 16; h->EP = 16; h->NE = (((size_t)h->R * h->EP + 63) / 64) * 64; }
+    h->crowd_riders = false;
+    if (h->has_ped && !h->all_ped && h->G == 64 && h->crowd_kernel && env_int("SG_CROWD_RIDERS", 1) != 0) {
+        bool ok = true; // pedestrian agents of catalog type Pedestrian, and nothing the pre-pass cannot ride for
+        for (size_t i = 0; i < (size_t)h->R * h->E && ok; ++i)
+            ok = sc->kind[i] == SG_KIND_AGENT_PEDESTRIAN ? sc->etype[i] == 1 : sc->kind[i] != SG_KIND_AGENT_EXTERNAL;
+        h->crowd_riders = ok;
+    }
     if (h->has_ped && (!sc->route_off || !sc->routes)) return fail(h, SG_ERR_INVALID, "sg_upload: pedestrian agents need route_off/routes");
     if (h->has_ped && (h->cfg.terminal_mask & SG_TERM_EGO_OFF_ROAD))
         return fail(h, SG_ERR_INVALID, "sg_upload: the ego_off_road terminal condition is not available for batches with pedestrian agents");
@@ -996,7 +1013,8 @@ extern "C" int sg_upload(sg_handle *h, const sg_scenarios *sc)
         for (int r = 0; r < R; ++r)
             for (int e = 0; e < E; ++e) {
                 const int k = sc->kind[(size_t)r * E + e];
-                if (k == SG_KIND_AGENT_PID || k == SG_KIND_AGENT_VEHICLE) {
+                if (k == SG_KIND_AGENT_PID || k == SG_KIND_AGENT_VEHICLE ||
+                    (h->crowd_riders && (k == SG_KIND_REPLAY || k == SG_KIND_AGENT_REPLAY))) {
                     const size_t o = (size_t)r * EP + e;
                     SI(o, sg::ST_CTL) = (int64_t)ctl_ent.size();
                     ctl_ent.push_back((int32_t)o);

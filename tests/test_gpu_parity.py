@@ -972,6 +972,7 @@ def test_lattice_scenes_touching_boxes_every_step(sga, oracle):
 
 def _random_configs(n, seed=2024):
     rng = np.random.default_rng(seed)
+    zrng = np.random.default_rng([seed, 3])  # (its own stream: the configurations of earlier rounds keep their draws)
     widths = [1, 3, 4, 5, 8, 9, 16, 17, 31, 33, 63, 64, 65, 100, 128, 129, 200, 256]
     out = []
     for k in range(n):
@@ -983,7 +984,8 @@ def _random_configs(n, seed=2024):
             terminal=[["max_length"], ["max_length", "collision"], ["max_length", "ego_collision"]][int(rng.integers(0, 3))],
             static=float(rng.choice([0.0, 0.15, 0.5])), vanish=float(rng.choice([0.0, 0.2, 0.6])),
             extent=float(rng.choice([8.0, 25.0, 60.0])), knots=int(rng.choice([6, 9, 40])), seed=int(rng.integers(1, 1 << 30)),
-            chunk=int(rng.choice([5, 16, 1024]))))
+            chunk=int(rng.choice([5, 16, 1024])),
+            zpr=bool(zrng.integers(0, 2))))  # knots with z / pitch / roll: the general table kernel instead of the planar one
     return out
 
 
@@ -1002,6 +1004,11 @@ def test_randomized_configurations_match_oracle(sga, oracle, cfg):
     R, E, steps, dt = cfg["R"], cfg["E"], cfg["steps"], cfg["dt"]
     packed = synthetic.make_batch(R, E, n_steps=steps, timestep=dt, n_knots=cfg["knots"], ego_kind=kind,
                                   static_frac=cfg["static"], vanish_frac=cfg["vanish"], extent=cfg["extent"], seed=cfg["seed"])
+    if cfg["zpr"]:
+        zr = np.random.default_rng([cfg["seed"], 11])
+        packed.knots[:, 3] = zr.uniform(-2.0, 2.0, len(packed.knots))
+        packed.knots[:, 5] = zr.uniform(-0.2, 0.2, len(packed.knots))
+        packed.knots[:, 6] = np.where(zr.random(len(packed.knots)) < 0.5, 0.0, zr.uniform(-0.1, 0.1, len(packed.knots)))
     force = cfg["ego"] == "vehicle"
     acts = synthetic.make_actions(steps, R, seed=cfg["seed"]) if force else None
     st, rows, events, t, poses = _engine_run(sga, packed, dt, steps, persist=cfg["persist"], terminal=cfg["terminal"],
@@ -1026,7 +1033,7 @@ def test_randomized_configurations_match_oracle(sga, oracle, cfg):
         # collision classes: controlled egos take their event pose from the controller table (two-kernel path) or from the
         # rollout kernel (short chunks run the controllers in-kernel)
         assert np.array_equal(ev["type"][:m], o["ev_type"][:m]), (r, ev["type"][:m], o["ev_type"][:m])
-    if cfg["ego"] == "replay" and E <= 64:  # the same batch through the time-sliced path: the same final results
+    if cfg["ego"] in ("replay", "pid") and E <= 64:  # the same batch through the time-sliced path: the same final results
         eng = sga.RolloutEngine(R, E, timestep=dt, persist=cfg["persist"], terminal_conditions=cfg["terminal"], event_capacity=256)
         eng.set_slicing("always")
         eng.upload(packed)
@@ -1034,7 +1041,7 @@ def test_randomized_configurations_match_oracle(sga, oracle, cfg):
         st2 = eng.state()
         rows2, events2 = eng.metrics()
         eng.close()
-        for k in ("poses", "vels", "dists", "t", "prev_t"):
+        for k in ("poses", "vels", "dists", "t", "prev_t", "ctrl_state"):
             assert bits_equal(st[k], st2[k]), k
         assert np.array_equal(st["coll"], st2["coll"]) and np.array_equal(st["present"], st2["present"])
         assert np.array_equal(rows, rows2) and np.array_equal(events, events2)
