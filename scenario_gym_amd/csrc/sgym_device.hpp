@@ -3404,6 +3404,14 @@ __device__ __forceinline__ void rollout_body(
                             if (!TAB) { // (overwritten below when the hazard is a controlled agent; table launches: event_ego_pose_kernel)
                                 double *hp = p.ev_hpose + ((size_t)r * p.ev_cap + n_ev) * 3;
                                 hp[0] = hp[1] = hp[2] = __builtin_nan("");
+                                if (RIDERS) { // a controlled rider as hazard: its pose after this step is a row of the riders' table
+                                    const int okind = (int)(ometa & 0xff);
+                                    if (okind == SG_KIND_AGENT_PID || okind == SG_KIND_AGENT_VEHICLE) {
+                                        const int64_t octl = reinterpret_cast<const int64_t *>(oblk)[ST_CTL * 64 + (oj & 63)];
+                                        const double *hrow = tab + (size_t)octl * tab_lane_stride + (size_t)k * CT_W;
+                                        hp[0] = hrow[CT_X]; hp[1] = hrow[CT_Y]; hp[2] = hrow[CT_H];
+                                    }
+                                }
                             }
                             if (!TAB) { // in-kernel controllers: the ego pose of the event goes along.  (Not in the table
                                         // variant, which sits 1 VGPR under its 192 budget: its events are classified right

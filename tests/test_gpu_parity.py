@@ -2275,3 +2275,113 @@ def test_crowd_with_a_car_matches_oracle(sga, oracle):
         eng.close()
         assert ver["equal"], ver["mismatches"]
         assert len(events) > 0   # the car does run into pedestrians
+
+
+@pytest.mark.parametrize("E,side,persist,terminal", [
+    (64, 10.0, False, ["max_length"]),
+    (150, 20.0, True, ["max_length"]),
+    (256, 26.0, False, ["max_length", "ego_collision"]),
+    (40, 7.0, False, ["max_length", "collision"]),
+])
+def test_crowd_riders_equal_general_variant_and_oracle(sga, oracle, monkeypatch, E, side, persist, terminal):
+    """Crowds with RIDERS -- a PID car (the ego), a car on external actions (zero here: sg_rollout), a replayed car that leaves
+    before the end, a static obstacle, a replay AGENT that spawns late, and two RECORDED pedestrians (replay entities of
+    type Pedestrian: social-force neighbours of the walking ones) -- run through rollout_kernel_crowd_riders with the riders'
+    poses from control_kernel_riders.  Poses of every step, forces, controller state, collision rows, metrics, events and
+    classes equal the general pedestrian variant (SG_CROWD_RIDERS=0) and the oracle, bit for bit; resumed in pieces too."""
+    import scenario_gym_amd._lib as L
+    from oracle import check
+    from scenario_gym_amd import synthetic
+    from scenario_gym_amd.engine import DEFAULT_CTRL, TERMINAL_BITS
+
+    R, steps, dt = 6, 100, 1 / 30
+    T = steps * dt
+    packed = synthetic.make_crowd(R, E, n_steps=steps, side=side)
+    rng = np.random.default_rng(E)
+    spec = [(L.KIND_AGENT_PID, 0, "car"), (L.KIND_AGENT_VEHICLE, 0, "car"), (L.KIND_REPLAY, 0, "car-leaves"),
+            (L.KIND_REPLAY, 2, "static"), (L.KIND_AGENT_REPLAY, 0, "late"), (L.KIND_REPLAY, 1, "ped"), (L.KIND_REPLAY, 1, "ped")]
+    knots = packed.knots.reshape(R * E, 2, 7).copy()
+    keep = np.ones(R * E, bool)
+    for r in range(R):
+        for slot, (kind, etype, what) in enumerate(spec):
+            i = r * E + slot
+            keep[i] = False
+            y = rng.uniform(-side / 3, side / 3)
+            v = rng.choice([-1.0, 1.0]) * rng.uniform(1.5, 4.0)
+            x0 = -np.sign(v) * side / 2
+            h = 0.0 if v > 0 else np.pi
+            t_a, t_b = 0.0, T
+            if what == "car-leaves":
+                t_b = 0.6 * T
+            if what == "late":
+                t_a = 0.25 * T
+            knots[i, 0] = [t_a, x0, y, 0.0, h, 0.0, 0.0]
+            knots[i, 1] = [t_b, x0 + v * (t_b - t_a), y, 0.0, h, 0.0, 0.0]
+            if what == "static":
+                knots[i, 1] = knots[i, 0]
+            packed.kind[i], packed.etype[i] = kind, etype
+            if etype != 1:
+                packed.bbox[i] = synthetic.CAR1_BBOX if etype == 0 else [1.0, 1.5, 0.2, 0.0]
+            packed.ctrl[i] = DEFAULT_CTRL
+    # the static obstacle has ONE knot: rebuild the ragged knot array; riders have no route
+    rows = [knots[i, :1] if (not keep[i] and spec[i % E][2] == "static") else knots[i] for i in range(R * E)]
+    packed.knots = np.concatenate(rows)
+    packed.knot_off = np.concatenate([[0], np.cumsum([len(x) for x in rows])]).astype(np.int64)
+    packed.routes = packed.routes.reshape(R * E, 2, 2)[keep].reshape(-1, 2)
+    packed.route_off = np.concatenate([[0], np.cumsum(np.where(keep, 2, 0))]).astype(np.int64)
+    packed.validate()
+    mask = sum(TERMINAL_BITS[c] for c in terminal)
+    out = {}
+    for mode in ("riders", "general", "pieces"):
+        monkeypatch.setenv("SG_CROWD_RIDERS", "0" if mode == "general" else "1")
+        eng = sga.RolloutEngine(R, E, persist=persist, terminal_conditions=terminal, record_capacity=steps + 1, event_capacity=64)
+        eng.upload(packed)
+        if mode == "pieces":   # reset + 3 resumed calls (the table restarts with every call)
+            eng.rollout(37)
+            eng.rollout_async(41, do_reset=False)
+            eng.rollout_async(steps - 78, do_reset=False)
+            eng.synchronize()
+        else:
+            eng.rollout(steps)
+        st, (rows_, ev), (tt, poses), pts = eng.state(), eng.metrics(), eng.record(steps + 1), eng.collision_points()
+        if mode == "riders":
+            ver = check.verify_engine(eng, packed, dt, steps, K=R, event_cap=64, ped=True, persist=persist, terminal_mask=mask)
+            assert ver["equal"], ver["mismatches"]
+        out[mode] = (st, rows_, ev, poses, pts)
+        eng.close()
+    for mode in ("general", "pieces"):
+        (sa, ra, ea, pa, qa), (sb, rb, eb, pb, qb) = out["riders"], out[mode]
+        assert bits_equal(pa, pb), mode
+        for k in ("poses", "vels", "dists", "force", "ctrl_state", "t"):
+            assert bits_equal(sa[k], sb[k]), (mode, k)
+        assert np.array_equal(sa["coll"], sb["coll"]) and np.array_equal(sa["present"], sb["present"]), mode
+        assert ra.tobytes() == rb.tobytes() and len(ea) == len(eb), mode
+        # (in tiles of several wavefronts the general variant cannot keep the pose of a hazard that is itself a controlled
+        # agent -- its events stay unclassified, type -2, no collision point; the riders' table has it)
+        open_ = (eb["type"] == -2) if mode == "general" else np.zeros(len(eb), bool)
+        assert E > 64 or not open_.any()
+        for f in ("t", "scenario", "other"):
+            assert np.array_equal(ea[f], eb[f]), (mode, f)
+        assert np.array_equal(ea["type"][~open_], eb["type"][~open_]) and np.array_equal(qa[~open_], qb[~open_], equal_nan=True), mode
+    # gym.step() with external actions for the VehicleController rider (integrations/openaigym.py:197-204): same bits both ways
+    acts = synthetic.make_actions(steps, R, seed=E)
+    stepped = {}
+    for mode in ("riders", "general"):
+        monkeypatch.setenv("SG_CROWD_RIDERS", "0" if mode == "general" else "1")
+        eng = sga.RolloutEngine(R, E, persist=persist, terminal_conditions=terminal, record_capacity=steps + 1, event_capacity=64)
+        eng.upload(packed)
+        eng.step(30, acts[:30])
+        eng.step(1, acts[30:31])
+        eng.step(steps - 31, acts[31:])
+        stepped[mode] = (eng.state(), eng.metrics()[0], eng.record(steps + 1)[1])
+        eng.close()
+    assert bits_equal(stepped["riders"][2], stepped["general"][2]) and stepped["riders"][1].tobytes() == stepped["general"][1].tobytes()
+    for k in ("poses", "vels", "dists", "force", "ctrl_state"):
+        assert bits_equal(stepped["riders"][0][k], stepped["general"][0][k]), k
+    assert not bits_equal(stepped["riders"][2], out["riders"][3])   # (the actions did steer the second car)
+    st, rows_, ev, poses, _ = out["riders"]
+    assert len(ev) > 0
+    for r in range(R):  # every recorded step against the oracle as well
+        o = _oracle_one(oracle, packed, r, dt, steps, persist=persist, terminal_mask=mask, event_cap=256,
+                        actions=np.zeros((steps, 2)))
+        assert bits_equal(poses[: o["n_steps"] + 1, r], o["poses"]), r
