@@ -2984,12 +2984,16 @@ __device__ __forceinline__ void rollout_body(
         // SLICE: round 0 is the warm-up step (state a - 1 -> a, nothing recorded); a lane that starts from the reset state
         // itself (a == 0) sits it out
         const bool warm = SLICE && k == 0;
-        const bool run = in_range && (force || !done) && !(SLICE && k == 0 && slice_a == 0);
+        const bool run_lane = in_range && (force || !done) && !(SLICE && k == 0 && slice_a == 0);
         PH(5);
         // (a workgroup of several wavefronts carries ONE scenario: `run` is already uniform, nothing to vote)
-        const bool any_run_ = WV == 1 ? sg_any(run || (SLICE && k == 0 && in_range && !done)) : run;
+        const bool any_run_ = WV == 1 ? sg_any(run_lane || (SLICE && k == 0 && in_range && !done)) : run_lane;
         PH(7);
         if (!any_run_) { all_done = true; break; }
+        // A wavefront that carries ONE scenario (64-lane tiles) has the same `done` in every lane, so past the vote every lane
+        // runs: said out loud, the `if (run)` blocks and selects below are not lane-divergent code any more (the compiler
+        // cannot see that the 64 copies of `done` agree)
+        const bool run = (G == 64 && WV == 1 && !SLICE) ? true : run_lane;
         // coefficient table: opaque per step so the scalar loads stay inside the loop (SGPRs for a few
         // dozen instructions instead of VGPRs for the whole kernel); constant address space => s_load
         const double *Kp = SG_TRIG;
@@ -3239,7 +3243,7 @@ __device__ __forceinline__ void rollout_body(
 #pragma unroll
                     for (int c = 0; c < 6; ++c) pose[c] = np_[c];
                 }
-                if (!SLICE) dist += sg_norm3(d[0], d[1], d[2]);
+                if (!SLICE) dist += PLANAR ? sg_norm2(d[0], d[1]) /* fma(+0, +0, s) == s for s >= +0 */ : sg_norm3(d[0], d[1], d[2]);
                 if (PED) { velx = vel[0]; vely = vel[1]; }
             }
             prev_t = t;

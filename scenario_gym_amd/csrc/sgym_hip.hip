@@ -455,8 +455,9 @@ static int launch_rollout(sg_handle *h, int n_steps, int do_reset, int force, co
     size_t ev_next = 0;
     // the table variant serves SG_TAB_LANES controlled lanes per wavefront; denser batches keep their controllers
     // in the rollout kernel, where they fill the wavefront anyway
-    // (a crowd with riders: every launch that steps replays the riders' table, however short)
-    const bool riders = h->crowd_riders && !h->has_road && !h->rss_fused && h->n_ctl > 0 && n_steps > 0;
+    // (a crowd with riders: lanes of other kinds ride the crowd kernel on a pre-pass table; short calls -- the per-tick loop of
+    // an RL driver -- keep the general pedestrian variant, like the table path keeps the in-kernel controllers)
+    const bool riders = h->crowd_riders && !h->has_road && !h->rss_fused && h->n_ctl > 0 && n_steps >= tab_min;
     const bool use_tab = riders || (!h->has_ped && !h->rss_fused && !(h->cfg.terminal_mask & SG_TERM_EGO_OFF_ROAD) && h->n_ext == 0 && n_steps >= tab_min && h->max_ctl_per_block <= SG_TAB_LANES(h->G, h->WV));
     // short calls (the per-tick loop of an RL driver) are not timed: four event records cost more than their kernel
     h->timing_now = use_tab || n_steps >= 16;

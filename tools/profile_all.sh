@@ -9,6 +9,7 @@ bash tools/profile_round.sh ${tag}_c2s --workload c2s --steps 5 --warmup 1
 bash tools/profile_round.sh ${tag}_c3rss --workload c3rss --steps 3 --warmup 1
 bash tools/profile_round.sh ${tag}_c3s --workload c3s --steps 5 --warmup 1
 bash tools/profile_round.sh ${tag}_c5mix --workload c5mix --steps 1 --warmup 1
+SG_CROWD_RIDERS=0 python3 bench.py --workload c5mix --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/${tag}_c5mix_general_bench.json 2>/dev/null
 python3 bench.py --workload e2e > gpurun_out/${tag}_e2e_bench.json 2> gpurun_out/${tag}_e2e.err
 for R in 512 1024 2048; do python3 bench.py --scenarios $R --steps 10 --warmup 2 --no-cpu-baseline > gpurun_out/${tag}_shard_${R}_bench.json 2>/dev/null; python3 bench.py --workload c3s --scenarios $R --steps 10 --warmup 2 --no-cpu-baseline > gpurun_out/${tag}_c3s_${R}_bench.json 2>/dev/null; done
 python3 tools/upload_time.py > gpurun_out/${tag}_upload_time.txt 2>&1
