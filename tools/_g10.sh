@@ -1,3 +1,2 @@
-bash tools/profile_all.sh r03d > gpurun_out/r03d_profile_all.log 2>&1
-tail -5 gpurun_out/r03d_profile_all.log
-ls gpurun_out | grep r03d | head -80
+bash tools/profile_all.sh r03f > gpurun_out/r03f_profile_all.log 2>&1
+tail -5 gpurun_out/r03f_profile_all.log
