@@ -432,6 +432,8 @@ def main(argv=None, make_engine=None):
                     help="c5: SocialForce noise terms (social_force.py:106-114): off = std 0 (parity runs), device = the "
                          "reference's default std with the counter-based device RNG")
     args = ap.parse_args(argv)
+    if args.workload == "e2e" and (args.gpus > 1 or int(os.environ.get("WORLD_SIZE", "1")) > 1):
+        raise SystemExit("--workload e2e is a one-GPU pipeline (its host side is the bottleneck); run one per GPU instead")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and make_engine is None:
         # not under a launcher: be the launcher (before torch / HIP are touched in this process)
         raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:] if argv is None else argv))
