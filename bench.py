@@ -104,8 +104,10 @@ def cpu_baseline(workload, seconds_budget=20.0):
         out["reference"] = {
             "value": r["entity_steps_per_s_box"], "per_core": r["entity_steps_per_s_per_core"], "cores": r["processes"],
             "unit": "entity-steps/s",
-            "note": f"driskai/scenario_gym v0.3.1 itself, E = {r['entities']}, default agents + 3 ego metrics, NO collision "
-                    "detection, timed in the build container (tools/time_reference.py, profiles/reference_cpu.json)",
+            "note": f"driskai/scenario_gym v0.3.1 itself, E = {r['entities']}, T = {r['sim_steps']} steps (its per-step cost grows with the "
+                    "step index -- sensor/common.py:46-50 rebuilds the recorded poses every step -- so a 10,000-step rollout is "
+                    "slower per step than this), default agents + 3 ego metrics, NO collision detection: conditions that flatter "
+                    "it; timed in the build container (tools/time_reference.py, profiles/reference_cpu.json)",
         }
     return out
 
