@@ -103,7 +103,8 @@ enum {
 typedef struct {
     int32_t device;          /* HIP device ordinal */
     int32_t n_scenarios;     /* R */
-    int32_t n_entities;      /* E, entity slots per scenario (<= 256 in this ABI version) */
+    int32_t n_entities;      /* E, entity slots per scenario (<= 512 in this ABI version; 257..512: replay entities, replay agents and
+                                PID / vehicle agents only -- no pedestrian agents, RSS callback, ego_off_road or observation calls) */
     int32_t persist;         /* ScenarioGym(persist=...) */
     uint32_t terminal_mask;  /* SG_TERM_* */
     int32_t record_capacity; /* rows of State._recorded_poses kept on device (0 = off), state.py:227-228 */
@@ -177,7 +178,8 @@ typedef struct {
     int32_t n_events;              /* len(CollisionMetric.collisions) */
     int32_t rec_rows;              /* rows written to the pose record */
     int64_t noise_pos;             /* variates of the scenario's noise stream consumed so far (sg_set_ped_noise, SG_NOISE_STREAM) */
-} sg_scenario_state;               /* 104 bytes */
+    uint64_t last_row_hi[4];       /* words 4..7 of last_row (scenarios of 257..512 entities) */
+} sg_scenario_state;               /* 136 bytes */
 
 typedef struct {
     int32_t n_scenarios, n_entities, entity_stride, n_blocks;

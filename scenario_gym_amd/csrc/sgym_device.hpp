@@ -168,15 +168,18 @@ struct LanePtr {
         asm("" : "+v"(a[1]), "+v"(a[2]));
     }
 };
+// (rows 24 and up -- the collision-row words 4..7 of tiles of 8 wavefronts -- hang off the third address with a larger offset)
 template <typename T = double>
 __device__ __forceinline__ T fld(const LanePtr &lp, int f)
 {
-    return *reinterpret_cast<SG_GLOBAL const T *>(lp.a[f >> 3] + (f & 7) * (int)ROW);
+    const int b = f < 24 ? f >> 3 : 2;
+    return *reinterpret_cast<SG_GLOBAL const T *>(lp.a[b] + (f - 8 * b) * (int)ROW);
 }
 template <typename T>
 __device__ __forceinline__ void stf(const LanePtr &lp, int f, T v)
 {
-    *reinterpret_cast<SG_GLOBAL T *>(lp.a[f >> 3] + (f & 7) * (int)ROW) = v;
+    const int b = f < 24 ? f >> 3 : 2;
+    *reinterpret_cast<SG_GLOBAL T *>(lp.a[b] + (f - 8 * b) * (int)ROW) = v;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -542,7 +545,7 @@ struct TileLds {
     // ---- end of the collision scratch ----
     float2 half[NS];        // half length, half width (static)
     int last[NS];
-    int vote[4][4];         // block_vote: one row per vote site, one word per wavefront
+    int vote[4][8];         // block_vote: one row per vote site, one word per wavefront (tiles of up to 8 wavefronts)
     // controller parameters of every slot, copied once per launch: the 9 vehicle / PID rows, or -- in pedestrian
     // scenes -- the 4 pedestrian rows SG_C_PED_* (index q - SG_C_PED_SPEED_DESIRED)
     double ctrl[PED ? 4 : 9][NS];
@@ -2765,7 +2768,7 @@ __device__ __forceinline__ void rollout_body(
         goal_idx = PED ? (int)cs.e_lon_prev : 0; // pedestrians keep goal_idx in the second controller row
         m_avg = sd.ego_avg_speed; m_max = sd.ego_max_speed; m_t = sd.avg_t;
 #pragma unroll
-        for (int w = 0; w < WV; ++w) last_row[w] = sd.last_row[w];
+        for (int w = 0; w < WV; ++w) last_row[w] = w < 4 ? sd.last_row[w & 3] : sd.last_row_hi[w & 3];
         n_ev = sd.n_events;
         noise_pos = PED ? sd.noise_pos : 0;
         done = sd.done;
@@ -3461,7 +3464,7 @@ __device__ __forceinline__ void rollout_body(
             if (sa.mode == 0) sa.nev[(size_t)r * sa.n_slices + slice_s] = n_ev;
             else {
 #pragma unroll
-                for (int w = 0; w < WV; ++w) sd.last_row[w] = last_row[w];
+                for (int w = 0; w < WV; ++w) (w < 4 ? sd.last_row[w & 3] : sd.last_row_hi[w & 3]) = last_row[w];
             }
         }
         if (TAB && HAST && sa.mode == 1 && in_range && tab_lane) { // controller state after the last executed step
@@ -3514,7 +3517,7 @@ __device__ __forceinline__ void rollout_body(
             sd.ego_avg_speed = m_avg; sd.ego_max_speed = m_max; sd.avg_t = m_t;
             if (steps > 0 && present) sd.ego_distance_travelled = dist; // EgoDistanceTravelled, :60-62
 #pragma unroll
-            for (int w = 0; w < WV; ++w) sd.last_row[w] = last_row[w];
+            for (int w = 0; w < WV; ++w) (w < 4 ? sd.last_row[w & 3] : sd.last_row_hi[w & 3]) = last_row[w];
             sd.n_events = n_ev;
         }
     }

@@ -246,9 +246,11 @@ extern "C" int sg_create(const sg_config *cfg, sg_handle **out)
     *out = nullptr;
     if (cfg->n_scenarios <= 0 || cfg->n_entities <= 0)
         return fail(nullptr, SG_ERR_INVALID, "sg_create: n_scenarios and n_entities must be positive");
-    if (cfg->n_entities > 256)
-        return fail(nullptr, SG_ERR_INVALID, "sg_create: n_entities=%d > 256 is not supported by ABI version %d",
+    if (cfg->n_entities > 512)
+        return fail(nullptr, SG_ERR_INVALID, "sg_create: n_entities=%d > 512 is not supported by ABI version %d",
                     cfg->n_entities, SG_ABI_VERSION);
+    if (cfg->n_entities > 256 && (cfg->terminal_mask & SG_TERM_EGO_OFF_ROAD))
+        return fail(nullptr, SG_ERR_INVALID, "sg_create: the ego_off_road terminal condition is available up to 256 entities per scenario");
     if (!(cfg->timestep > 0.0)) return fail(nullptr, SG_ERR_INVALID, "sg_create: timestep must be > 0");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -268,7 +270,9 @@ extern "C" int sg_create(const sg_config *cfg, sg_handle **out)
     int G = 4;
     while (G < h->E && G < 64) G <<= 1;
     h->G = G;
-    h->WV = h->E <= 64 ? 1 : (h->E <= 128 ? 2 : 4); // wavefronts per scenario
+    // wavefronts per scenario.  8 (257..512 entities): replay entities, replay agents and in-kernel PID / vehicle controllers
+    // through rollout_kernel<64, 8, false, false>; no pedestrian agents, RSS callback or observation kernels at that width
+    h->WV = h->E <= 64 ? 1 : (h->E <= 128 ? 2 : (h->E <= 256 ? 4 : 8));
     h->EP = G * h->WV;
     // SocialForceParameters defaults, pedestrian/social_force.py:16-30 (noise off)
     h->sf = sg_social_force{1.5, 1.0, 1.0, 0.0, 0.5, 1.0, std::cos(200.0 / 2 * M_PI / 180), 1.3, 0.0, 0.0, 2.0, 0.1};
@@ -414,7 +418,9 @@ static int launch_main(sg_handle *h, int n_steps, int do_reset, int force, const
         if ((rc = get_event(h, *ev_next, &e0)) || (rc = get_event(h, *ev_next + 1, &e1))) return rc;
         HIP_TRY(h, hipEventRecord(e0, h->stream));
     }
-    if (h->WV == 4) launch_variant<64, 4>(h, grid, n_steps, do_reset, force, d_actions, d_tab, use_tab);
+    if (h->WV == 8) // (launch_rollout never takes the table path at this width)
+        sg::rollout_kernel<64, 8, false, false><<<grid, dim3(512), 0, h->stream>>>(h->p, h->cfg.timestep, n_steps, do_reset, force, d_actions, nullptr);
+    else if (h->WV == 4) launch_variant<64, 4>(h, grid, n_steps, do_reset, force, d_actions, d_tab, use_tab);
     else if (h->WV == 2) launch_variant<64, 2>(h, grid, n_steps, do_reset, force, d_actions, d_tab, use_tab);
     else switch (h->G) {
     case 4: launch_variant<4, 1>(h, grid, n_steps, do_reset, force, d_actions, d_tab, use_tab); break;
@@ -458,7 +464,7 @@ static int launch_rollout(sg_handle *h, int n_steps, int do_reset, int force, co
     // (a crowd with riders: lanes of other kinds ride the crowd kernel on a pre-pass table; short calls -- the per-tick loop of
     // an RL driver -- keep the general pedestrian variant, like the table path keeps the in-kernel controllers)
     const bool riders = h->crowd_riders && !h->has_road && !h->rss_fused && h->n_ctl > 0 && n_steps >= tab_min;
-    const bool use_tab = riders || (!h->has_ped && !h->rss_fused && !(h->cfg.terminal_mask & SG_TERM_EGO_OFF_ROAD) && h->n_ext == 0 && n_steps >= tab_min && h->max_ctl_per_block <= SG_TAB_LANES(h->G, h->WV));
+    const bool use_tab = riders || (h->WV <= 4 && !h->has_ped && !h->rss_fused && !(h->cfg.terminal_mask & SG_TERM_EGO_OFF_ROAD) && h->n_ext == 0 && n_steps >= tab_min && h->max_ctl_per_block <= SG_TAB_LANES(h->G, h->WV));
     // short calls (the per-tick loop of an RL driver) are not timed: four event records cost more than their kernel
     h->timing_now = use_tab || n_steps >= 16;
     if (h->timing_now) HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
@@ -824,6 +830,7 @@ extern "C" int sg_upload(sg_handle *h, const sg_scenarios *sc)
         h->crowd_riders = ok;
     }
     if (h->has_ped && (!sc->route_off || !sc->routes)) return fail(h, SG_ERR_INVALID, "sg_upload: pedestrian agents need route_off/routes");
+    if (h->has_ped && h->WV > 4) return fail(h, SG_ERR_INVALID, "sg_upload: pedestrian agents are available up to 256 entities per scenario");
     if (h->has_ped && (h->cfg.terminal_mask & SG_TERM_EGO_OFF_ROAD))
         return fail(h, SG_ERR_INVALID, "sg_upload: the ego_off_road terminal condition is not available for batches with pedestrian agents");
     const int R = h->R, E = h->E, EP = h->EP;
@@ -1291,6 +1298,7 @@ extern "C" int sg_tick(sg_handle *h, const double *actions, int32_t actions_devi
     if (!layers || n_layers < 1 || n_layers > 8 || nw < 1 || nh < 1 || !(width >= 0.0) || !(height >= 0.0))
         return fail(h, SG_ERR_INVALID, "sg_tick: bad observation geometry (1..8 layers)");
     if (h->n_ext > 0) return fail(h, SG_ERR_STATE, "sg_tick: batches with caller-run agents are driven through sg_set_external_poses + sg_step");
+    if (h->WV > 4) return fail(h, SG_ERR_INVALID, "%s: available up to 256 entities per scenario", "sg_tick");
     bool any_surface = false;
     for (int k = 0; k < n_layers; ++k) {
         const uint32_t L = (uint32_t)layers[k];
@@ -1684,6 +1692,7 @@ extern "C" int sg_rss_update(sg_handle *h, int32_t reset)
 {
     if (!h) return SG_ERR_INVALID;
     if (!h->uploaded) return fail(h, SG_ERR_STATE, "sg_rss_update: no scenarios uploaded");
+    if (h->WV > 4) return fail(h, SG_ERR_INVALID, "%s: available up to 256 entities per scenario", "sg_rss_update");
     if (!h->ego_first) return fail(h, SG_ERR_STATE, "sg_rss_update: RSSDistances keeps its records for entities[1:], the ego has to be entity 0 of every scenario");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     bool fresh = false;
@@ -1698,6 +1707,7 @@ extern "C" int sg_rss_update(sg_handle *h, int32_t reset)
 extern "C" int sg_set_rss(sg_handle *h, int32_t enabled)
 {
     if (!h) return SG_ERR_INVALID;
+    if (enabled && h->WV > 4) return fail(h, SG_ERR_INVALID, "sg_set_rss: available up to 256 entities per scenario");
     h->rss_enabled = enabled != 0;
     return SG_OK;
 }
@@ -1739,6 +1749,7 @@ extern "C" int sg_future_collision(sg_handle *h, double horizon, int32_t n_sampl
 {
     if (!h || !out || n_samples < 1 || !(horizon >= 0.0)) return h ? fail(h, SG_ERR_INVALID, "sg_future_collision: bad argument") : SG_ERR_INVALID;
     if (!h->uploaded) return fail(h, SG_ERR_STATE, "sg_future_collision: no scenarios uploaded");
+    if (h->WV > 4) return fail(h, SG_ERR_INVALID, "%s: available up to 256 entities per scenario", "sg_future_collision");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     unsigned char *d = nullptr;
     int rc = obs_scratch(h, (size_t)h->R, &d);
@@ -1983,6 +1994,7 @@ static int raster_map_launch(sg_handle *h, const char *who, double width, double
     if (!layers || n_layers < 1 || nw < 1 || nh < 1 || !(width >= 0.0) || !(height >= 0.0))
         return fail(h, SG_ERR_INVALID, "%s: bad argument", who);
     if (!h->uploaded) return fail(h, SG_ERR_STATE, "%s: no scenarios uploaded", who);
+    if (h->WV > 4) return fail(h, SG_ERR_INVALID, "%s: available up to 256 entities per scenario", who);
     bool any_surface = false;
     for (int k = 0; k < n_layers; ++k) {
         const uint32_t L = (uint32_t)layers[k];
@@ -2042,6 +2054,7 @@ extern "C" int sg_raster_entities(sg_handle *h, double width, double height, int
     if (!h || !out || nw < 1 || nh < 1 || !(width >= 0.0) || !(height >= 0.0))
         return h ? fail(h, SG_ERR_INVALID, "sg_raster_entities: bad argument") : SG_ERR_INVALID;
     if (!h->uploaded) return fail(h, SG_ERR_STATE, "sg_raster_entities: no scenarios uploaded");
+    if (h->WV > 4) return fail(h, SG_ERR_INVALID, "%s: available up to 256 entities per scenario", "sg_raster_entities");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     const size_t bytes = (size_t)h->R * nw * nh;
     unsigned char *d = nullptr;

@@ -14,7 +14,7 @@ TERMINAL_BITS = {"max_length": L.TERM_MAX_LENGTH, "collision": L.TERM_COLLISION,
 SCEN_DTYPE = np.dtype([  # sg_scenario_state
     ("t", "f8"), ("prev_t", "f8"), ("ego_avg_speed", "f8"), ("ego_max_speed", "f8"), ("avg_t", "f8"),
     ("ego_distance_travelled", "f8"), ("last_row", "u8", (4,)), ("done", "i4"), ("n_steps", "i4"),
-    ("n_events", "i4"), ("rec_rows", "i4"), ("noise_pos", "i8")])
+    ("n_events", "i4"), ("rec_rows", "i4"), ("noise_pos", "i8"), ("last_row_hi", "u8", (4,))])
 
 # + PedestrianAgent / PedestrianController defaults (pedestrian/agent.py:18-27): speed_desired (set per agent),
 # max_speed 5.0, head_rot_angle 0.0, distance_threshold 1.0

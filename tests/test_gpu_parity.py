@@ -390,18 +390,21 @@ def _dense_words(coll, E):
     return bits[:, :E]
 
 
-@pytest.mark.parametrize("R,E,steps,ego_kind", [(24, 100, 150, "pid"), (16, 200, 100, "replay"), (12, 256, 80, "pid")])
+@pytest.mark.parametrize("R,E,steps,ego_kind", [(24, 100, 150, "pid"), (16, 200, 100, "replay"), (12, 256, 80, "pid"),
+                                                (6, 300, 90, "replay"), (5, 512, 70, "pid"), (4, 511, 60, "vehicle")])
 def test_wide_scenarios_match_oracle(sga, oracle, R, E, steps, ego_kind):
-    """Scenarios of 65..256 entities span 2 or 4 wavefronts of one workgroup: same bits as the oracle."""
+    """Scenarios of 65..512 entities span 2, 4 or 8 wavefronts of one workgroup: same bits as the oracle."""
     import scenario_gym_amd._lib as L
     from scenario_gym_amd import synthetic
 
-    kind = dict(replay=L.KIND_AGENT_REPLAY, pid=L.KIND_AGENT_PID)[ego_kind]
-    packed = synthetic.make_batch(R, E, n_steps=steps, ego_kind=kind, static_frac=0.15, vanish_frac=0.2, extent=50.0)
-    st, rows, events, t, poses = _engine_run(sga, packed, 1 / 30, steps, ev_cap=256)
+    kind = dict(replay=L.KIND_AGENT_REPLAY, pid=L.KIND_AGENT_PID, vehicle=L.KIND_AGENT_VEHICLE)[ego_kind]
+    packed = synthetic.make_batch(R, E, n_steps=steps, ego_kind=kind, static_frac=0.15, vanish_frac=0.2, extent=50.0 if E <= 256 else 75.0)
+    acts = synthetic.make_actions(steps, R, seed=E) if ego_kind == "vehicle" else None
+    st, rows, events, t, poses = _engine_run(sga, packed, 1 / 30, steps, ev_cap=256, actions=acts)
     n_ev = 0
     for r in range(R):
-        o = _oracle_one(oracle, packed, r, 1 / 30, steps)
+        kw = dict(actions=acts[:, r], force_steps=True) if acts is not None else {}
+        o = _oracle_one(oracle, packed, r, 1 / 30, steps, **kw)
         n = o["n_steps"]
         assert rows["n_steps"][r] == n and rows["final_t"][r] == o["final_t"], r
         assert bits_equal(poses[: n + 1, r], o["poses"]), r
@@ -688,7 +691,13 @@ def test_abi_rejects_bad_input(sga):
     from scenario_gym_amd.packing import pack_arrays
 
     with pytest.raises(RuntimeError, match="n_entities"):
-        sga.RolloutEngine(4, 300)
+        sga.RolloutEngine(4, 513)
+    with pytest.raises(RuntimeError, match="256 entities"):   # what tiles of 8 wavefronts do not offer
+        sga.RolloutEngine(4, 300, terminal_conditions=["max_length", "ego_off_road"])
+    wide = sga.RolloutEngine(2, 300)
+    with pytest.raises(RuntimeError, match="256 entities"):
+        wide.set_rss(True)
+    wide.close()
     with pytest.raises(RuntimeError, match="timestep"):
         sga.RolloutEngine(4, 4, timestep=0.0)
     with pytest.raises(ValueError):
@@ -973,12 +982,12 @@ def test_lattice_scenes_touching_boxes_every_step(sga, oracle):
 def _random_configs(n, seed=2024):
     rng = np.random.default_rng(seed)
     zrng = np.random.default_rng([seed, 3])  # (its own stream: the configurations of earlier rounds keep their draws)
-    widths = [1, 3, 4, 5, 8, 9, 16, 17, 31, 33, 63, 64, 65, 100, 128, 129, 200, 256]
+    widths = [1, 3, 4, 5, 8, 9, 16, 17, 31, 33, 63, 64, 65, 100, 128, 129, 200, 256, 257, 400, 512]
     out = []
     for k in range(n):
         E = int(widths[k % len(widths)])
         out.append(dict(
-            E=E, R=int(rng.integers(3, 20 if E <= 64 else 8)), steps=int(rng.integers(20, 110)),
+            E=E, R=int(rng.integers(3, 20 if E <= 64 else (8 if E <= 256 else 4))), steps=int(rng.integers(20, 110)),
             dt=float(rng.choice([1 / 30, 0.05, 0.1, 0.013])), persist=bool(rng.integers(0, 2)),
             ego=str(rng.choice(["replay", "pid", "vehicle"])),
             terminal=[["max_length"], ["max_length", "collision"], ["max_length", "ego_collision"]][int(rng.integers(0, 3))],

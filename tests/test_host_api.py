@@ -277,7 +277,7 @@ def test_library_exports_every_declared_symbol():
     assert ctypes.sizeof(L.SgConfig) == 40 and ctypes.sizeof(L.SgMetrics) == 48 and ctypes.sizeof(L.SgEvent) == 24
     from scenario_gym_amd.engine import SCEN_DTYPE
 
-    assert SCEN_DTYPE.itemsize == 104  # sg_scenario_state
+    assert SCEN_DTYPE.itemsize == 136  # sg_scenario_state
     assert ctypes.sizeof(L.SgSocialForce) == 96 and ctypes.sizeof(L.SgStateView) == 40
 
 
