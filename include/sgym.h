@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SG_ABI_VERSION 1
+#define SG_ABI_VERSION 2 /* 2: sg_scenario_state.last_row_hi (scenarios of up to 512 entities) */
 
 typedef enum {
     SG_OK = 0,
