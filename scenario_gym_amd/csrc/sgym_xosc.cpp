@@ -34,12 +34,35 @@ const Name kNames[] = {
     {"Shape", T_SHAPE}, {"Polyline", T_POLYLINE}, {"Vertex", T_VERTEX},
 };
 
+// element name -> tag.  Most tags of a scenario file are Vertex / Position / WorldPosition, and most of the rest are not in
+// the table at all: one switch on the length and the first character decides nearly all of them before any memcmp.
 Tag tag_of(const char *s, int n)
 {
-    for (const Name &k : kNames)
-        if ((int)strlen(k.s) == n && memcmp(k.s, s, n) == 0) return k.t;
+    static const struct Index {
+        int8_t first[32][8]; // per length (< 32): up to 8 candidate rows of kNames, -1 terminated
+        Index()
+        {
+            memset(first, -1, sizeof first);
+            for (int k = 0; k < (int)(sizeof kNames / sizeof kNames[0]); ++k) {
+                const int len = (int)strlen(kNames[k].s);
+                int8_t *row = first[len];
+                int j = 0;
+                while (row[j] >= 0) ++j;
+                row[j] = (int8_t)k;
+            }
+        }
+    } idx;
+    if (n <= 0 || n >= 32) return T_OTHER;
+    const int8_t *row = idx.first[n];
+    for (int j = 0; j < 8 && row[j] >= 0; ++j) {
+        const Name &k = kNames[row[j]];
+        if (k.s[0] == s[0] && memcmp(k.s, s, n) == 0) return k.t;
+    }
     return T_OTHER;
 }
+
+// XML white space (no locale, no call)
+inline bool is_ws(char c) { return c == ' ' || c == '\n' || c == '\t' || c == '\r'; }
 
 struct Attr { const char *name; int nlen; const char *val; int vlen; };
 
@@ -75,8 +98,8 @@ bool attr_is(const Attr &a, const char *name) { return (int)strlen(name) == a.nl
 double to_double(const Attr &a, bool *bad)
 {
     const char *p = a.val, *e = a.val + a.vlen;
-    while (p < e && isspace((unsigned char)*p)) ++p;
-    while (e > p && isspace((unsigned char)e[-1])) --e;
+    while (p < e && is_ws(*p)) ++p;
+    while (e > p && is_ws(e[-1])) --e;
     bool neg = false;
     if (p < e && (*p == '+' || *p == '-')) { neg = *p == '-'; ++p; }
     double v = 0.0;
@@ -171,7 +194,7 @@ extern "C" int sgx_parse(const char *text, int64_t len, sgx_counts *counts, sgx_
         }
         // opening (or self-closing) tag: name
         const char *n0 = p;
-        while (p < end && !isspace((unsigned char)*p) && *p != '>' && *p != '/') ++p;
+        while (p < end && !is_ws(*p) && *p != '>' && *p != '/') ++p;
         const Tag t = tag_of(n0, (int)(p - n0));
         const char *tag_name = n0;
         const int tag_len = (int)(p - n0);
@@ -179,17 +202,17 @@ extern "C" int sgx_parse(const char *text, int64_t len, sgx_counts *counts, sgx_
         attrs.clear();
         bool self_close = false;
         for (;;) {
-            while (p < end && isspace((unsigned char)*p)) ++p;
+            while (p < end && is_ws(*p)) ++p;
             if (p >= end) return SGX_ERR_SYNTAX;
             if (*p == '>') { ++p; break; }
             if (*p == '/') { self_close = true; ++p; continue; }
             const char *a0 = p;
-            while (p < end && *p != '=' && !isspace((unsigned char)*p) && *p != '>') ++p;
+            while (p < end && *p != '=' && !is_ws(*p) && *p != '>') ++p;
             const int an = (int)(p - a0);
-            while (p < end && isspace((unsigned char)*p)) ++p;
+            while (p < end && is_ws(*p)) ++p;
             if (p >= end || *p != '=') return SGX_ERR_SYNTAX;
             ++p;
-            while (p < end && isspace((unsigned char)*p)) ++p;
+            while (p < end && is_ws(*p)) ++p;
             if (p >= end || (*p != '"' && *p != '\'')) return SGX_ERR_SYNTAX;
             const char quote = *p++;
             const char *v0 = p;
