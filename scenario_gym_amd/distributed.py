@@ -29,8 +29,12 @@ def init(backend: Optional[str] = None):
 
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # SGYM_DIST_BACKEND=gloo + SGYM_DIST_ONE_DEVICE=1: several ranks on ONE GPU (RCCL refuses two ranks on a device; gloo moves
+    # the few dispatch / collection bytes over the host) -- how the live N > 1 path is exercised on a one-GPU box
+    if os.environ.get("SGYM_DIST_ONE_DEVICE"):
+        local_rank = 0
     if not dist.is_initialized():
-        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        backend = backend or os.environ.get("SGYM_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         kw = {}
         if backend == "nccl":
             torch.cuda.set_device(local_rank)

@@ -1,10 +1,12 @@
 """GPU tests of the scenario_gym-shaped API (ScenarioGym / BatchedScenarioGym / State / Metric views):
 they read like the reference's own tests (tests/test_metrics.py, test_state.py, test_scenario_gym.py,
 test_controller.py, test_utils.py) and are checked against the same golden vectors."""
+import os
+
 import numpy as np
 import pytest
 
-from conftest import bits_equal, load_golden, scenario_arrays
+from conftest import ROOT, bits_equal, load_golden, scenario_arrays
 from test_host_api import scenario_from_arrays
 
 pytestmark = pytest.mark.gpu
@@ -935,3 +937,26 @@ def test_rss_metric_through_the_gym():
     for n, m in zip(names, gym.get_metrics()):
         assert m["RSS_safe_longitudinal"] == bool(g[f"{n}/safe_longitudinal"]) and m["RSS_safe_lateral"] == bool(g[f"{n}/safe_lateral"]), n
     gym.close()
+
+
+def test_bench_two_live_ranks_on_one_gpu(tmp_path):
+    """`python bench.py --gpus 2` with the REAL engine: bench.py starts its two ranks itself; both share GPU 0 here
+    (SGYM_DIST_ONE_DEVICE; gloo carries the dispatch / collection bytes because RCCL refuses two ranks on one device).  Rank 0's
+    line has both ranks, the weak / strong / strong_sliced blocks, and every block's scenarios verified against the oracle."""
+    import json
+    import subprocess
+    import sys
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(SGYM_DIST_BACKEND="gloo", SGYM_DIST_ONE_DEVICE="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--scenarios", "1024", "--sim-steps", "2000",
+                          "--steps", "2", "--warmup", "1", "--verify", "4"], capture_output=True, text=True, timeout=600, env=env,
+                         cwd=str(tmp_path))
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["ranks"] == 2 and line["n_gpus"] == 2 and line["backend"] == "gloo" and line["scaling"] == "weak"
+    assert line["config"]["scenarios_per_gpu"] == 1024 and line["strong"]["scenarios_per_gpu"] == 512
+    assert line["strong_sliced"]["scenarios_per_gpu"] == 512
+    for blk in (line, line["strong"], line["strong_sliced"]):
+        assert blk["verified"]["equal"] and blk["verified"]["scenarios"] >= 4 and len(blk["per_rank_value"]) == 2
+    assert line["value"] > 0 and line["strong_sliced"]["value"] > 0
