@@ -1955,15 +1955,63 @@ def test_rss_line_test_queues_across_launches(sga, monkeypatch, E, ego):
     assert (out[0][0][2] >= 4).any() and (out[0][0][2] == 1).any() and (out[0][0][2] == 2).any()  # unsafe, lateral, longitudinal
 
 
+# --------------------------------------------------------------------------- crowds with riders
+_ALL_RIDERS = [("pid", 0, "car"), ("vehicle", 0, "car"), ("replay", 0, "car-leaves"), ("replay", 2, "static"),
+               ("agent_replay", 0, "late"), ("replay", 1, "ped"), ("replay", 1, "ped")]
+
+
+def _add_riders(packed, rng, side, T, spec):
+    """Turn the first len(spec) slots of every scenario of a make_crowd batch into riders: (kind, catalog type code, what) --
+    cars that cross the square (one leaves early, one appears late), a static obstacle (ONE knot), recorded pedestrians."""
+    import scenario_gym_amd._lib as L
+    from scenario_gym_amd import synthetic
+    from scenario_gym_amd.engine import DEFAULT_CTRL
+
+    kinds = dict(pid=L.KIND_AGENT_PID, vehicle=L.KIND_AGENT_VEHICLE, replay=L.KIND_REPLAY, agent_replay=L.KIND_AGENT_REPLAY)
+    R, E = packed.n_scenarios, packed.n_entities
+    knots = packed.knots.reshape(R * E, 2, 7).copy()
+    keep = np.ones(R * E, bool)
+    static = np.zeros(R * E, bool)
+    for r in range(R):
+        for slot, (kind, etype, what) in enumerate(spec):
+            i = r * E + slot
+            keep[i] = False
+            y = rng.uniform(-side / 3, side / 3)
+            v = rng.choice([-1.0, 1.0]) * rng.uniform(1.5, 4.0)
+            x0 = -np.sign(v) * side / 2
+            h = 0.0 if v > 0 else np.pi
+            t_a, t_b = 0.0, T
+            if what == "car-leaves":
+                t_b = 0.6 * T
+            if what == "late":
+                t_a = 0.25 * T
+            knots[i, 0] = [t_a, x0, y, 0.0, h, 0.0, 0.0]
+            knots[i, 1] = [t_b, x0 + v * (t_b - t_a), y, 0.0, h, 0.0, 0.0]
+            static[i] = what == "static"
+            packed.kind[i], packed.etype[i] = kinds[kind], etype
+            if etype != 1:
+                packed.bbox[i] = synthetic.CAR1_BBOX if etype == 0 else [1.0, 1.5, 0.2, 0.0]
+            packed.ctrl[i] = DEFAULT_CTRL
+    # the static obstacle has ONE knot: rebuild the ragged knot array; riders have no route
+    rows = [knots[i, :1] if static[i] else knots[i] for i in range(R * E)]
+    packed.knots = np.concatenate(rows)
+    packed.knot_off = np.concatenate([[0], np.cumsum([len(x) for x in rows])]).astype(np.int64)
+    packed.routes = packed.routes.reshape(R * E, 2, 2)[keep].reshape(-1, 2)
+    packed.route_off = np.concatenate([[0], np.cumsum(np.where(keep, 2, 0))]).astype(np.int64)
+    return packed.validate()
+
+
 def _random_crowds(n, seed=77):
     rng = np.random.default_rng(seed)
+    rrng = np.random.default_rng([seed, 9])  # (its own stream: earlier configurations keep their draws)
     out = []
     for k in range(n):
         E = int([20, 64, 100, 256, 40, 130][k % 6])
         out.append(dict(E=E, R=int(rng.integers(2, 7 if E <= 64 else 4)), steps=int(rng.integers(30, 90)),
                         side=float(rng.choice([6.0, 12.0, 25.0])), roads=bool(rng.integers(0, 2)), seed=int(rng.integers(1, 1 << 30)),
                         dt=float(rng.choice([1 / 30, 0.1])), noise=str(rng.choice(["off", "off", "device", "stream"])),
-                        radii=bool(rng.integers(0, 2)), late=bool(rng.integers(0, 3) == 0)))
+                        radii=bool(rng.integers(0, 2)), late=bool(rng.integers(0, 3) == 0),
+                        riders=int(rrng.integers(0, 8)) if rrng.integers(0, 2) else 0))  # how many of _ALL_RIDERS ride along
     return out
 
 
@@ -1987,6 +2035,8 @@ def test_randomized_crowds_match_oracle(sga, oracle, cfg):
     if cfg["late"]:  # every fifth pedestrian's trajectory starts later: it is not in the scene at the reset and spawns
         kn = packed.knots.reshape(R * E, 2, 7)
         kn[::5, 0, 0] = rng.uniform(0.2, 1.0, len(kn[::5])) * steps * dt * 0.5
+    if cfg["riders"]:  # cars / obstacles / recorded pedestrians among the walkers (64-lane tiles without roads: the riders' path)
+        _add_riders(packed, np.random.default_rng([cfg["seed"], 13]), cfg["side"], steps * dt, _ALL_RIDERS[: cfg["riders"]])
     noise_kw, noise_o = {}, [None] * R
     if cfg["noise"] == "device":
         noise_kw = dict(std_lon=0.1, std_lat=0.05, noise="device", noise_seed=cfg["seed"])
@@ -2023,11 +2073,13 @@ def test_randomized_crowds_match_oracle(sga, oracle, cfg):
         road = nets[net_of[r]] if (nets and net_of[r] >= 0) else None
         o = oracle.rollout(s["knot_off"], s["knots"], s["bbox"], s["etype"], s["kind"], s["ego"], s["t0"], s["length"], dt,
                            ctrl=s["ctrl"], route_off=s["route_off"], routes=s["routes"], max_steps=steps, event_cap=512, road=road,
-                           noise=noise_o[r])
+                           noise=noise_o[r], actions=np.zeros((steps, 2)) if (s["kind"] == L.KIND_AGENT_VEHICLE).any() else None)
         n = o["n_steps"]
         assert rows["n_steps"][r] == n, r
         assert bits_equal(poses[: n + 1, r], o["poses"]), (r, "poses")
-        assert bits_equal(st["force"][r], o["extra"][-1, :, 2:]) and bits_equal(st["dists"][r], o["dists"][-1]), r
+        ped = s["kind"] == L.KIND_AGENT_PEDESTRIAN   # (the oracle's extra columns are per kind: riders keep controller state there)
+        assert bits_equal(st["force"][r][ped], o["extra"][-1, ped, 2:]) and bits_equal(st["dists"][r], o["dists"][-1]), r
+        assert bits_equal(st["ctrl_state"][r][~ped], o["extra"][-1, ~ped]), r
         assert np.array_equal(_dense_words(st["coll"][r], E), oracle.coll_to_dense(o["coll"], E)[-1]), r
         ev = events[events["scenario"] == r]
         m = min(len(ev), 512)
@@ -2046,6 +2098,8 @@ def test_randomized_rss_matches_oracle(sga, oracle, cfg):
 
     kind = dict(replay=L.KIND_AGENT_REPLAY, pid=L.KIND_AGENT_PID, vehicle=L.KIND_AGENT_VEHICLE)[cfg["ego"]]
     R, E, steps, dt = cfg["R"], cfg["E"], cfg["steps"], cfg["dt"]
+    if E > 256:  # (the callback is offered up to 256 entities per scenario: sg_set_rss refuses wider handles)
+        E = 256
     packed = synthetic.make_batch(R, E, n_steps=steps, timestep=dt, n_knots=cfg["knots"], ego_kind=kind,
                                   static_frac=cfg["static"], vanish_frac=cfg["vanish"], extent=cfg["extent"], seed=cfg["seed"])
     force = cfg["ego"] == "vehicle"
@@ -2304,41 +2358,8 @@ def test_crowd_riders_equal_general_variant_and_oracle(sga, oracle, monkeypatch,
     from scenario_gym_amd.engine import DEFAULT_CTRL, TERMINAL_BITS
 
     R, steps, dt = 6, 100, 1 / 30
-    T = steps * dt
     packed = synthetic.make_crowd(R, E, n_steps=steps, side=side)
-    rng = np.random.default_rng(E)
-    spec = [(L.KIND_AGENT_PID, 0, "car"), (L.KIND_AGENT_VEHICLE, 0, "car"), (L.KIND_REPLAY, 0, "car-leaves"),
-            (L.KIND_REPLAY, 2, "static"), (L.KIND_AGENT_REPLAY, 0, "late"), (L.KIND_REPLAY, 1, "ped"), (L.KIND_REPLAY, 1, "ped")]
-    knots = packed.knots.reshape(R * E, 2, 7).copy()
-    keep = np.ones(R * E, bool)
-    for r in range(R):
-        for slot, (kind, etype, what) in enumerate(spec):
-            i = r * E + slot
-            keep[i] = False
-            y = rng.uniform(-side / 3, side / 3)
-            v = rng.choice([-1.0, 1.0]) * rng.uniform(1.5, 4.0)
-            x0 = -np.sign(v) * side / 2
-            h = 0.0 if v > 0 else np.pi
-            t_a, t_b = 0.0, T
-            if what == "car-leaves":
-                t_b = 0.6 * T
-            if what == "late":
-                t_a = 0.25 * T
-            knots[i, 0] = [t_a, x0, y, 0.0, h, 0.0, 0.0]
-            knots[i, 1] = [t_b, x0 + v * (t_b - t_a), y, 0.0, h, 0.0, 0.0]
-            if what == "static":
-                knots[i, 1] = knots[i, 0]
-            packed.kind[i], packed.etype[i] = kind, etype
-            if etype != 1:
-                packed.bbox[i] = synthetic.CAR1_BBOX if etype == 0 else [1.0, 1.5, 0.2, 0.0]
-            packed.ctrl[i] = DEFAULT_CTRL
-    # the static obstacle has ONE knot: rebuild the ragged knot array; riders have no route
-    rows = [knots[i, :1] if (not keep[i] and spec[i % E][2] == "static") else knots[i] for i in range(R * E)]
-    packed.knots = np.concatenate(rows)
-    packed.knot_off = np.concatenate([[0], np.cumsum([len(x) for x in rows])]).astype(np.int64)
-    packed.routes = packed.routes.reshape(R * E, 2, 2)[keep].reshape(-1, 2)
-    packed.route_off = np.concatenate([[0], np.cumsum(np.where(keep, 2, 0))]).astype(np.int64)
-    packed.validate()
+    _add_riders(packed, np.random.default_rng(E), side, steps * dt, _ALL_RIDERS)
     mask = sum(TERMINAL_BITS[c] for c in terminal)
     out = {}
     for mode in ("riders", "general", "pieces"):
