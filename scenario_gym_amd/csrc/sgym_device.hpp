@@ -2201,6 +2201,23 @@ __device__ inline bool rss_seg_quad(const double *Q, double ax, double ay, doubl
 // caller picks unsafe_lateral / unsafe_longitudinal from the history (`last`, else `ab`); otherwise `need` has bit L set for
 // every line L whose bounding box meets the entity's (0: cd = 0 is final) and Q is the entity's box in the ego frame.
 constexpr int RSS_CD_ISECT = -3;
+// The ego's half of one update: its heading and velocity in its own frame and the two inverse directions -- the same for
+// every entity of the scenario (callback.py:80-100; four IEEE divisions and three square roots).  (Round 3 moved it to the
+// controller pre-pass, once per ego and step, table planes 3-5: -3 % in the rollout kernel, more than that lost to the heavier
+// pre-pass beside it -- HISTORY.md.)
+struct RssEgo { double eh0, eh1, ei0, ei1, head0, head1, i0, i1, vnorm, vhead, pos1; };
+__device__ inline void rss_ego_chain(double es, double ec, double ego_vx, double ego_vy, double ex, double ey, RssEgo &o)
+{
+    o.eh0 = ec; o.eh1 = es;
+    rss_inv_dir(o.eh0, o.eh1, o.ei0, o.ei1);
+    o.head0 = rss_dot2(o.eh0, o.eh1, o.ei0, o.ei1);
+    o.head1 = rss_dot2(o.eh0, o.eh1, o.eh0, o.eh1);
+    const double ego_vel0 = rss_dot2(ego_vx, ego_vy, o.ei0, o.ei1), ego_vel1 = rss_dot2(ego_vx, ego_vy, o.eh0, o.eh1);
+    o.pos1 = rss_dot2(ex - ex, ey - ey, o.eh0, o.eh1);
+    rss_inv_dir(o.head0, o.head1, o.i0, o.i1);
+    o.vnorm = sg_norm2(ego_vel0, ego_vel1);
+    o.vhead = rss_dot2(ego_vel0, ego_vel1, o.head0, o.head1);
+}
 template <bool DEFER = false>
 __device__ inline void rss_entity(double ex, double ey, double ego_heading, double ego_vx, double ego_vy, double ego_w, double ego_l,
                                   double hx, double hy, double hh, double hvx, double hvy, double bw, double bl, double bcx,
@@ -2209,14 +2226,15 @@ __device__ inline void rss_entity(double ex, double ey, double ego_heading, doub
                                   the ego's and of the entity's heading (sg_sincos), computed by the caller */)
 {
         const double RESPONSE_TIME = 0.6, MIN_LONG_ACCEL = 1.2 * 9.81, MAX_LONG_ACCEL = 1.2 * 9.81, MIN_SAFE_CLEARANCE = 0.1;
-        double es, ec, ei0, ei1;
-        if (DEFER) { es = trig[0]; ec = trig[1]; }
-        else sg_sincos(ego_heading, es, ec);
-        const double eh0 = ec, eh1 = es;
-        rss_inv_dir(eh0, eh1, ei0, ei1);
-        const double ego_head0 = rss_dot2(eh0, eh1, ei0, ei1), ego_head1 = rss_dot2(eh0, eh1, eh0, eh1);
-        const double ego_vel0 = rss_dot2(ego_vx, ego_vy, ei0, ei1), ego_vel1 = rss_dot2(ego_vx, ego_vy, eh0, eh1);
-        const double ego_pos1 = rss_dot2(ex - ex, ey - ey, eh0, eh1);
+        RssEgo eg;
+        {
+            double es, ec;
+            if (DEFER) { es = trig[0]; ec = trig[1]; }
+            else sg_sincos(ego_heading, es, ec);
+            rss_ego_chain(es, ec, ego_vx, ego_vy, ex, ey, eg);
+        }
+        const double eh0 = eg.eh0, eh1 = eg.eh1, ei0 = eg.ei0, ei1 = eg.ei1;
+        const double ego_head0 = eg.head0, ego_head1 = eg.head1, ego_pos1 = eg.pos1;
         double hs, hc;
         if (DEFER) { hs = trig[2]; hc = trig[3]; }
         else sg_sincos(hh, hs, hc);
@@ -2234,8 +2252,8 @@ __device__ inline void rss_entity(double ex, double ey, double ego_heading, doub
             const double m = __builtin_fabs(MAX_LONG_ACCEL * dd), rt = RESPONSE_TIME;
             if (dd > 0) {
                 double vf, vr;
-                if (ego_pos1 > pos1) { vf = sg_norm2(ego_vel0, ego_vel1); vr = rss_dot2(vel0, vel1, ego_head0, ego_head1); }
-                else { vf = rss_dot2(vel0, vel1, ego_head0, ego_head1); vr = sg_norm2(ego_vel0, ego_vel1); }
+                if (ego_pos1 > pos1) { vf = eg.vnorm; vr = rss_dot2(vel0, vel1, ego_head0, ego_head1); }
+                else { vf = rss_dot2(vel0, vel1, ego_head0, ego_head1); vr = eg.vnorm; }
                 if (vr == 0.0) s_long = MIN_SAFE_CLEARANCE + 0.5 * ego_l;
                 else {
                     const double a = vr * rt + __builtin_fmin(RSS_DIV(vf * vf, 2 * m), 0.5 * m * (rt * rt)) +
@@ -2243,7 +2261,7 @@ __device__ inline void rss_entity(double ex, double ey, double ego_heading, doub
                     s_long = __builtin_fmax(0.0, a) + MIN_SAFE_CLEARANCE + 0.5 * ego_l;
                 }
             } else {
-                const double v1 = __builtin_fabs(rss_dot2(ego_vel0, ego_vel1, ego_head0, ego_head1));
+                const double v1 = __builtin_fabs(eg.vhead);
                 const double av2 = __builtin_fabs(-__builtin_fabs(rss_dot2(vel0, vel1, ego_head0, ego_head1)));
                 const int sp = (pos1 > 0) - (pos1 < 0), sv = (vel1 > 0) - (vel1 < 0);
                 if (sp == sv) s_long = MIN_SAFE_CLEARANCE + 0.5 * ego_l;
@@ -2256,8 +2274,8 @@ __device__ inline void rss_entity(double ex, double ey, double ego_heading, doub
             s_long = __builtin_fabs(s_long);
         }
         { // safe_lateral_distance, :274-305
-            double v = vel0, i0, i1;
-            rss_inv_dir(ego_head0, ego_head1, i0, i1);
+            double v = vel0;
+            const double i0 = eg.i0, i1 = eg.i1;
             const double ad = __builtin_fabs(rss_dot2(i0, i1, head0, head1));
             const double max_lat = MAX_LONG_ACCEL * ad, min_lat = MIN_LONG_ACCEL * ad, rt = RESPONSE_TIME;
             const int sp = (-pos0 > 0) - (-pos0 < 0), sv = (v > 0) - (v < 0);
@@ -2501,7 +2519,7 @@ struct SliceArgs {
 // control_kernel launches that run ahead of the slices -- so a slice that starts at step a finds its lanes' poses there
 // like everything else it needs in the clock.
 template <int G, int WV, bool PED, bool TAB, bool HAST, bool ROAD = false, bool RSSV = false, bool CROWD = false, bool SLICE = false,
-          bool PLANAR = false, bool RIDERS = false>
+          bool PLANAR = false, bool RIDERS = false, bool CTAB = false>
 __device__ __forceinline__ void rollout_body(
     const Params &p, double timestep, int n_steps, int do_reset, int force, const double *actions /*[n][R][2]*/,
     const double *tab /*controller table planes*/, const SliceArgs &sa = SliceArgs{})
@@ -2515,6 +2533,11 @@ __device__ __forceinline__ void rollout_body(
     // (control_kernel_riders) has put their pose and presence after every step of the chunk into the controller table, and
     // here they only read their row: the crowd kernel stays free of knot segments and vehicle code.
     static_assert(!RIDERS || CROWD, "riders ride the crowd variant");
+    // CTAB (variants with in-kernel controllers whose registers are full -- the RSS callback: rollout_kernel_rss_tab): the PID /
+    // vehicle agents were integrated by control_kernel, their lanes read x, y, h of the step from the controller table with a
+    // vector load, and the controller code (sin / cos, PID, tangent: ~220 instructions per wavefront-step for one active
+    // lane in 64) is not compiled into this kernel at all.
+    static_assert(!CTAB || (!TAB && !PED && !CROWD), "CTAB: table rows into an in-kernel-controller variant");
     constexpr int NS = 64 * WV;
     __shared__ TileLds<NS, PED, CROWD> lds;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -2668,8 +2691,9 @@ __device__ __forceinline__ void rollout_body(
     const bool tab_lane = TAB && HAST && ctl_q >= 0 && (kind == SG_KIND_AGENT_PID || kind == SG_KIND_AGENT_VEHICLE);
     const size_t tab_lane_stride = (size_t)(p.tab_steps + 1) * CT_W; // doubles per lane
     // RIDERS: this lane's column of the table (plane 0: x, y, h, speed; plane 2: z, pitch, roll, present)
-    const bool rider = RIDERS && kind != SG_KIND_NONE && kind != SG_KIND_AGENT_PEDESTRIAN;
-    const double *rider_row = RIDERS ? tab + (size_t)(rider ? fld<int64_t>(st, ST_CTL) : 0) * tab_lane_stride : nullptr;
+    const bool rider = (RIDERS && kind != SG_KIND_NONE && kind != SG_KIND_AGENT_PEDESTRIAN) ||
+                       (CTAB && (kind == SG_KIND_AGENT_PID || kind == SG_KIND_AGENT_VEHICLE));
+    const double *rider_row = (RIDERS || CTAB) ? tab + (size_t)(rider ? fld<int64_t>(st, ST_CTL) : 0) * tab_lane_stride : nullptr;
     int last_k = -1;                                                 // last step of this launch the scenario executed
     constexpr int TL = SG_TAB_LANES(G, WV);
     int cl[TL];                       // wave-uniform: the controlled lanes of this wavefront
@@ -2942,7 +2966,8 @@ __device__ __forceinline__ void rollout_body(
         if (upd && rss_cd == RSS_CD_ISECT) // unsafe_distance, callback.py:196-213: the entry exists from now on, its class is pending
             rss_st = (rss_st & 0xff00) | 3 | RSS_ST_PENDING | (ab ? RSS_ST_AB : 0);
     };
-    if (RSSV && do_reset != 0) rss_call(rs, t, vel[0], vel[1]); // State.reset ends with update_callbacks(), state.py:138-140
+    // State.reset ends with update_callbacks(), state.py:138-140 (the table variant is never the reset launch)
+    if (RSSV && !CTAB && do_reset != 0) rss_call(rs, t, vel[0], vel[1]);
 
     Segment S;
     if (!CROWD) { // (a crowd has no replay lanes: its only trajectory lookup is the rare spawn, done on the spot)
@@ -3149,7 +3174,12 @@ __device__ __forceinline__ void rollout_body(
                     const double tx = np_[0], ty = np_[1];
 #pragma unroll
                     for (int c = 0; c < 6; ++c) np_[c] = pose[c];
-                    if (kind == SG_KIND_AGENT_PID || kind == SG_KIND_AGENT_VEHICLE) {
+                    if (CTAB && (kind == SG_KIND_AGENT_PID || kind == SG_KIND_AGENT_VEHICLE)) {
+                        // the pre-pass row of this step; z / pitch / roll stay (controller.py:126-131)
+                        const double4 a = *reinterpret_cast<const double4 *>(rider_row + (size_t)k * CT_W);
+                        sg_loads_done();
+                        np_[0] = a.x; np_[1] = a.y; np_[3] = a.z;
+                    } else if (!CTAB && (kind == SG_KIND_AGENT_PID || kind == SG_KIND_AGENT_VEHICLE)) {
                         const double bl = lds.boxwl[1][sl];
                         double sin_h, cos_h; // of the current heading
                         sg_sincos(pose[3], sin_h, cos_h, K);
@@ -3490,7 +3520,7 @@ __device__ __forceinline__ void rollout_body(
                     m_avg = lr2[CT_MAVG]; m_max = lr2[CT_MMAX]; m_t = lr2[CT_MT];
                 }
             }
-        } else if (RIDERS && rider) {
+        } else if ((RIDERS || CTAB) && rider) {
             if (last_k >= 0 && (kind == SG_KIND_AGENT_PID || kind == SG_KIND_AGENT_VEHICLE)) { // controller state after the last executed step
                 const double *lr = rider_row + (size_t)last_k * CT_W;
                 const double *lr1 = lr + (size_t)p.n_ctl_pad * tab_lane_stride; // plane 1
@@ -3561,6 +3591,14 @@ __global__ __launch_bounds__(64 * WV, SG_WAVES_PER_SIMD) void rollout_kernel_rss
     Params p, double timestep, int n_steps, int do_reset, int force, const double *actions, const double *tab)
 {
     rollout_body<G, WV, false, false, false, false, true>(p, timestep, n_steps, do_reset, force, actions, tab);
+}
+
+// ... with the PID / vehicle agents on the controller pre-pass's table (CTAB): one wavefront per tile
+template <int G>
+__global__ __launch_bounds__(64, SG_WAVES_PER_SIMD) void rollout_kernel_rss_tab(
+    Params p, double timestep, int n_steps, int do_reset, int force, const double *actions, const double *tab)
+{
+    rollout_body<G, 1, false, false, false, false, true, false, false, false, false, true>(p, timestep, n_steps, do_reset, force, actions, tab);
 }
 
 // ... with the ego_off_road terminal condition / with pedestrian agents (RSSDistances treats every entity alike)

@@ -380,6 +380,8 @@ static void launch_variant(sg_handle *h, dim3 grid, int n_steps, int do_reset, i
     else if (h->has_ped)
         sg::rollout_kernel<(WV > 1 || G >= 16) ? G : 16, WV, true, false><<<grid, block, 0, h->stream>>>(
             h->p, h->cfg.timestep, n_steps, do_reset, force, d_actions, nullptr);
+    else if (h->rss_fused && use_tab && WV == 1) // (launch_rollout: the controlled lanes' poses come from the pre-pass table)
+        sg::rollout_kernel_rss_tab<G><<<grid, block, 0, h->stream>>>(h->p, h->cfg.timestep, n_steps, 0, force, nullptr, d_tab);
     else if (h->rss_fused)
         sg::rollout_kernel_rss<G, WV><<<grid, block, 0, h->stream>>>(h->p, h->cfg.timestep, n_steps, do_reset, force, d_actions, nullptr);
     else if (h->cfg.terminal_mask & SG_TERM_EGO_OFF_ROAD)
@@ -464,7 +466,11 @@ static int launch_rollout(sg_handle *h, int n_steps, int do_reset, int force, co
     // (a crowd with riders: lanes of other kinds ride the crowd kernel on a pre-pass table; short calls -- the per-tick loop of
     // an RL driver -- keep the general pedestrian variant, like the table path keeps the in-kernel controllers)
     const bool riders = h->crowd_riders && !h->has_road && !h->rss_fused && h->n_ctl > 0 && n_steps >= tab_min;
-    const bool use_tab = riders || (h->WV <= 4 && !h->has_ped && !h->rss_fused && !(h->cfg.terminal_mask & SG_TERM_EGO_OFF_ROAD) && h->n_ext == 0 && n_steps >= tab_min && h->max_ctl_per_block <= SG_TAB_LANES(h->G, h->WV));
+    // (the RSS callback inside the kernel: its controlled lanes ride the table too -- rollout_kernel_rss_tab -- which takes the
+    // controller code out of the one variant that has no issue slot to spare; launches stay within the line-test queue)
+    const bool rss_tab = h->rss_fused && h->WV == 1 && !h->has_ped && !(h->cfg.terminal_mask & SG_TERM_EGO_OFF_ROAD) && h->n_ext == 0 &&
+                         h->n_ctl > 0 && n_steps >= tab_min && env_int("SG_RSS_TAB", 1) != 0;
+    const bool use_tab = riders || rss_tab || (h->WV <= 4 && !h->has_ped && !h->rss_fused && !(h->cfg.terminal_mask & SG_TERM_EGO_OFF_ROAD) && h->n_ext == 0 && n_steps >= tab_min && h->max_ctl_per_block <= SG_TAB_LANES(h->G, h->WV));
     // short calls (the per-tick loop of an RL driver) are not timed: four event records cost more than their kernel
     h->timing_now = use_tab || n_steps >= 16;
     if (h->timing_now) HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
@@ -490,8 +496,11 @@ static int launch_rollout(sg_handle *h, int n_steps, int do_reset, int force, co
             // chunk length: SG_CHUNK_STEPS, capped so that one table buffer stays under 1 GiB
             int ch = (int)std::min<size_t>((size_t)chunk_steps, std::max<size_t>(1, ((size_t)1 << 27) / row));
             ch = std::min(ch, n_steps);
-            if (ch > h->p.tab_steps) { // grow: tab_steps + 1 rows per lane is part of the table addressing
-                const size_t need = (size_t)(ch + 1) * row * sizeof(double);
+            if (rss_tab) ch = std::min(ch, std::max(1, h->rssq_steps)); // one launch fills at most the line-test queue
+            if (ch > h->p.tab_steps || (size_t)(h->p.tab_steps + 1) * row * sizeof(double) > h->tab_bytes) {
+                // grow: tab_steps + 1 rows per lane is part of the table addressing
+                const int ts = std::max(ch, h->p.tab_steps);
+                const size_t need = (size_t)(ts + 1) * row * sizeof(double);
                 if (need > h->tab_bytes) { // (the buffers outlive sg_upload: the next batch of the same shape reuses them)
                     HIP_TRY(h, hipStreamSynchronize(h->stream));
                     HIP_TRY(h, hipStreamSynchronize(h->ctl_stream));
@@ -503,7 +512,7 @@ static int launch_rollout(sg_handle *h, int n_steps, int do_reset, int force, co
                     for (int b = 0; b < 2; ++b) HIP_TRY(h, hipMalloc((void **)&h->d_tab[b], need));
                     h->tab_bytes = need;
                 }
-                h->p.tab_steps = ch;
+                h->p.tab_steps = ts;
             }
             hipStream_t cs = no_overlap ? h->stream : h->ctl_stream;
             hipEvent_t e;
@@ -514,6 +523,7 @@ static int launch_rollout(sg_handle *h, int n_steps, int do_reset, int force, co
             }
             std::vector<hipEvent_t> main_done;
             const dim3 cgrid((unsigned)(np / 64)), cblock(64);
+            const bool rss_fast = env_int("SG_RSS_CTL_FAST", 1) != 0;
             // chunk lengths double from two slices up to `ch`: the rollout kernel cannot start before the table of
             // its chunk exists, and the pre-pass of chunk c+1 (about 0.4x the rollout kernel's time per step) then
             // always finishes under the rollout kernel of chunk c
@@ -527,9 +537,12 @@ static int launch_rollout(sg_handle *h, int n_steps, int do_reset, int force, co
                     if (riders)
                         sg::control_kernel_riders<<<cgrid, cblock, 0, cs>>>(h->p, h->cfg.timestep, ns, c == 0 && s0 == 0, k0 + s0,
                                                                             d_actions, tab, s0, 0);
+                    else if (rss_tab && rss_fast) // (the ego's metrics are the rollout kernel's, from its own velocities)
+                        sg::control_kernel_fast<<<cgrid, cblock, 0, cs>>>(h->p, h->cfg.timestep, ns, c == 0 && s0 == 0, k0 + s0,
+                                                                          d_actions, tab, s0, 0);
                     else
                         sg::control_kernel<<<cgrid, cblock, 0, cs>>>(h->p, h->cfg.timestep, ns, c == 0 && s0 == 0, k0 + s0,
-                                                                     d_actions, tab, s0, 1);
+                                                                     d_actions, tab, s0, rss_tab ? 0 : 1);
                 }
                 HIP_TRY(h, hipGetLastError());
                 if (!no_overlap) {
@@ -1669,8 +1682,14 @@ static int ensure_rssq(sg_handle *h)
 {
     if (!h->d_rssq) {
         const size_t nw = h->NE / 64, per_step = nw * 64 * sg::RSSQ_REC * sizeof(double);
-        const size_t budget = (size_t)env_int("SG_RSSQ_MB", 4096) << 20;
-        int steps = (int)std::min<size_t>(256, std::max<size_t>(2, budget / per_step) - 1);
+        // (SG_RSSQ_MB; default: an eighth of the free device memory, at least 4 GiB -- every launch boundary costs the tail of a
+        // launch, and 288 GB hold the queues of a whole 1000-step rollout of the largest batches)
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
+        const int mb = env_int("SG_RSSQ_MB", 0);
+        const size_t budget = mb > 0 ? (size_t)mb << 20 : std::max<size_t>((size_t)4096 << 20, free_b / 8);
+        const int cap = std::max(1, env_int("SG_RSSQ_STEPS", 1024));
+        int steps = (int)std::min<size_t>((size_t)cap, std::max<size_t>(2, budget / per_step) - 1);
         // the queue only sets how many steps one launch covers: when the device is short of memory, shorter launches
         //  instead of a failed sg_upload / sg_reset
         for (;; steps = std::max(1, steps / 2)) {

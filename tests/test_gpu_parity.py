@@ -1955,6 +1955,42 @@ def test_rss_line_test_queues_across_launches(sga, monkeypatch, E, ego):
     assert (out[0][0][2] >= 4).any() and (out[0][0][2] == 1).any() and (out[0][0][2] == 2).any()  # unsafe, lateral, longitudinal
 
 
+@pytest.mark.parametrize("E,n_pid", [(5, 1), (64, 7), (20, 20), (200, 9)])
+def test_rss_rollout_with_table_lanes_equals_in_kernel_controllers(sga, monkeypatch, E, n_pid):
+    """rollout_kernel_rss_tab (controlled lanes read the poses control_kernel wrote; the default for a long rollout) against
+    rollout_kernel_rss (the PID controllers inside the rollout kernel; SG_RSS_TAB=0): entity states, controller states, the
+    ego's metric recurrences, step counts, events and every RSS record are the same bits, with one and with many PID lanes per
+    scenario, some of them not the ego."""
+    import scenario_gym_amd._lib as L
+    from scenario_gym_amd import synthetic
+
+    R, steps = 70, 90
+    packed = synthetic.make_batch(R, E, n_steps=steps, ego_kind=L.KIND_AGENT_PID, extent=14.0 if E < 100 else 40.0, vanish_frac=0.2)
+    packed.length = packed.length * np.linspace(0.4, 1.0, R)
+    kind = packed.kind.reshape(R, E)
+    for r in range(R):
+        lanes = [e for e in range(E) if kind[r, e] == L.KIND_REPLAY][:n_pid - 1]
+        kind[r, lanes] = L.KIND_AGENT_PID
+    out = []
+    for mode in ("1", "0"):
+        monkeypatch.setenv("SG_RSS_TAB", mode)
+        eng = sga.RolloutEngine(R, E)
+        eng.set_rss(True)
+        eng.upload(packed)
+        eng.rollout(steps)
+        m, ev = eng.metrics()
+        out.append((eng.rss(), eng.state(), m, ev, eng.collision_points()))
+        eng.close()
+    a, b = out
+    for x, y in zip(a[0], b[0]):
+        assert np.array_equal(x, y, equal_nan=True)
+    for k in a[1]:
+        assert np.array_equal(a[1][k], b[1][k], equal_nan=True), k
+    assert a[2].tobytes() == b[2].tobytes() and a[3].tobytes() == b[3].tobytes()
+    assert np.array_equal(a[4], b[4], equal_nan=True)
+    assert (a[2]["ego_distance_travelled"] > 0).all()
+
+
 # --------------------------------------------------------------------------- crowds with riders
 _ALL_RIDERS = [("pid", 0, "car"), ("vehicle", 0, "car"), ("replay", 0, "car-leaves"), ("replay", 2, "static"),
                ("agent_replay", 0, "late"), ("replay", 1, "ped"), ("replay", 1, "ped")]
