@@ -534,7 +534,8 @@ def main(argv=None, make_engine=None):
                                     rows["n_collisions"].astype(np.float64), rows["n_steps"].astype(np.float64)],
                                    axis=1), dist)
             n_launch, launch_ms = eng.last_launch_stats()
-            return int(rows["n_steps"].sum()) * E, (eng.last_kernel_ms(), n_launch, launch_ms)
+            gross = eng.last_launch_gross_ms() if hasattr(eng, "last_launch_gross_ms") else launch_ms
+            return int(rows["n_steps"].sum()) * E, (eng.last_kernel_ms(), n_launch, launch_ms, gross)
 
         elapsed, ent_steps, stats = timed_passes(one_pass, args.steps, args.warmup, dist, sync)
         ver = None
@@ -566,10 +567,15 @@ def main(argv=None, make_engine=None):
         R = m["R"]
         # dominant kernel = the rollout kernel.  A long rollout is cut into chunks of steps (one launch each, so that the
         # controller pre-pass of the next chunk overlaps it): per-launch units and duration are averages over the
-        # launches of the timed passes, each launch timed with its own HIP event pair on the handle's stream.
+        # launches of the timed passes, each launch timed with its own HIP event pair on its stream.  Large batches with
+        # controlled agents run as two halves on two streams (launch_rollout): two launches of the same kernel are then in
+        # flight, and the time a launch is charged is its share of the time at least one of them was running -- the union
+        # of the launches' intervals / launches (`kernel_ms`); `kernel_ms_gross` is the plain average duration of a launch,
+        # the figure a kernel trace shows, `launch_overlap` their ratio (1.0: one launch at a time).
         n_launches = sum(k[1] for k in m["stats"])
         per_launch = m["ent_steps"] / n_launches
         avg_ms = sum(k[2] for k in m["stats"]) / n_launches
+        gross_ms = sum(k[3] for k in m["stats"]) / n_launches
         rollout_ms = sum(k[0] for k in m["stats"]) / len(m["stats"])  # everything one sg_rollout enqueues
         b_alg = wl["b_alg"]
         achieved = per_launch * b_alg / (avg_ms * 1e-3) / 1e9
@@ -648,7 +654,8 @@ def main(argv=None, make_engine=None):
                 "secondary": secondary,
                 "kernel": (f"sg::rollout_kernel_slice{'_tab' if ego_kind == L.KIND_AGENT_PID else ''}<{min(64, max(4, 1 << (E - 1).bit_length()))}>" if wl.get("sliced") else
                            kernel_name(E, crowd, ego_kind == L.KIND_AGENT_PID, bool(wl.get("rss")), bool(wl.get("mix")))),
-                "kernel_ms": avg_ms, "launches_per_rollout": launches_per_rollout, "rollout_device_ms": rollout_ms,
+                "kernel_ms": avg_ms, "kernel_ms_gross": gross_ms, "launch_overlap": gross_ms / avg_ms if avg_ms else None,
+                "launches_per_rollout": launches_per_rollout, "rollout_device_ms": rollout_ms,
                 "bytes_per_entity_step": b_alg, "entity_steps_per_launch": per_launch,
                 "src_sha16": L.source_sha16(),
             },

@@ -348,7 +348,8 @@ int sg_rss_update(sg_handle *h, int32_t reset);
  * after the reset and after every step, inside the rollout kernel (any number of steps per launch; also with pedestrian
  * agents and with SG_TERM_EGO_OFF_ROAD) -- as ScenarioGym(state_callbacks=[RSSDistances()]) does.  The line tests of the
  * callback are queued on the device and finished by a second kernel after each launch (queues: env SG_RSSQ_MB, default
- * 4096 MiB per handle; longer calls are cut into several launches).  A scenario that has not stepped since its latest
+ * an eighth of the free device memory and at least 4096 MiB per handle, at most SG_RSSQ_STEPS = 1024 steps per launch; longer
+ * calls are cut into several launches; a device short of memory gets shorter launches, not an error).  A scenario that has not stepped since its latest
  * update (it is done) is left alone.  The ego has to be entity 0 (else: one sg_rss_update per step, which says so). */
 int sg_set_rss(sg_handle *h, int32_t enabled);
 /* flags [R]: bit 0 = RSS_safe_longitudinal, bit 1 = RSS_safe_lateral (no entity's history holds the corresponding
@@ -383,9 +384,12 @@ int sg_copy_to_host(sg_handle *h, const void *device_ptr, void *host_ptr, uint64
 int sg_last_kernel_ms(sg_handle *h, float *ms);
 
 /* the rollout-kernel launches of that call (long rollouts are cut into chunks of steps so that the controller
- * pre-pass of chunk c+1 overlaps the rollout kernel of chunk c): how many, and the sum of their durations, each
- * measured with its own HIP event pair on the handle's stream */
+ * pre-pass of chunk c+1 overlaps the rollout kernel of chunk c; large batches with controlled agents run as two halves
+ * on two streams, whose launches overlap): how many, and the time during which at least one of them was running -- the
+ * union of their intervals, each measured with its own HIP event pair on the launch's stream */
 int sg_last_launch_stats(sg_handle *h, int32_t *n_launches, float *kernel_ms_total);
+/* ... and the plain sum of their durations (what a kernel trace adds up; equal to the union when nothing overlaps) */
+int sg_last_launch_gross_ms(sg_handle *h, float *kernel_ms_gross);
 
 /* ScenarioGym.rollout (scenario_gym.py:256-267) of a batch whose entities are all replay entities / replay agents is a
  * pure function of the clock except for three ordered sums (State.distances, EgoAvgSpeed, the event list); PID / vehicle

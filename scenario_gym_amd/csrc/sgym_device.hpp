@@ -2522,8 +2522,10 @@ template <int G, int WV, bool PED, bool TAB, bool HAST, bool ROAD = false, bool 
           bool PLANAR = false, bool RIDERS = false, bool CTAB = false>
 __device__ __forceinline__ void rollout_body(
     const Params &p, double timestep, int n_steps, int do_reset, int force, const double *actions /*[n][R][2]*/,
-    const double *tab /*controller table planes*/, const SliceArgs &sa = SliceArgs{})
+    const double *tab /*controller table planes*/, const SliceArgs &sa = SliceArgs{},
+    const unsigned bx_arg = ~0u /* the 64-slot block (WV == 1) / scenario of this workgroup when it is not bx: TabGroups */)
 {
+    const unsigned bx = bx_arg == ~0u ? blockIdx.x : bx_arg;
     static_assert(!SLICE || (TAB && WV == 1 && !PED && !ROAD && !RSSV), "slices: the table variant, one wavefront per tile");
     static_assert(!(PED && TAB), "pedestrian scenarios run their controllers in the rollout kernel");
     static_assert(!CROWD || (PED && G == 64 && !ROAD && !RSSV), "the crowd variant is a pedestrian variant with 64-lane tiles");
@@ -2543,13 +2545,13 @@ __device__ __forceinline__ void rollout_body(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t voff = lane * 8u;
     // one wavefront = one 64-slot block of the state arrays: wave-uniform block pointers
-    const size_t blk = (size_t)blockIdx.x * WV + wave;
+    const size_t blk = (size_t)bx * WV + wave;
     const double *st_blk = p.stat + blk * (ST_COUNT * 64);
     const LanePtr st(st_blk, voff);
     const LanePtr dy(p.dyn + blk * ((size_t)(SG_F_COLL + WV) * 64), voff);
     // scenario / slot of this lane
-    const int gl = blockIdx.x * NS + tid;
-    const int r_raw = WV == 1 ? gl / G : blockIdx.x;
+    const int gl = bx * NS + tid;
+    const int r_raw = WV == 1 ? gl / G : bx;
     const int slot = WV == 1 ? (gl & (G - 1)) : tid;
     const int tile0 = WV == 1 ? (lane & ~(G - 1)) : 0; // first LDS slot of this lane's tile
     const int sl = tid;                                 // this lane's LDS slot
@@ -2890,7 +2892,7 @@ __device__ __forceinline__ void rollout_body(
     double rss_bw = 0.0, rss_bl = 0.0, rss_ew = 0.0, rss_el = 0.0;
     int rss_gn = 0;          // groups queued by this wavefront (uniform)
     unsigned rss_k = 0;      // ordinal of this lane's latest update within the launch
-    const size_t rss_wave = (size_t)blockIdx.x * WV + wave;
+    const size_t rss_wave = (size_t)bx * WV + wave;
     SG_GLOBAL v2d *const rss_rec = RSSV ? (SG_GLOBAL v2d *)(p.rssq + rss_wave * (size_t)p.rssq_cap * RSSQ_REC) : nullptr;
     if (RSSV) {
         if (!rs && in_range && slot < p.E) rss_st = p.rss_state[rss_idx];
@@ -2991,7 +2993,7 @@ __device__ __forceinline__ void rollout_body(
     PhaseTimers ptm;
 #ifdef SG_PHASE_TIMERS
     ptm.start();
-    if (lane == 0 && blockIdx.x < 1024) p.phase_cycles[16 + blockIdx.x * 4 + wave] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); // HW_REG_HW_ID
+    if (lane == 0 && bx < 1024) p.phase_cycles[16 + bx * 4 + wave] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); // HW_REG_HW_ID
 #endif
     sg_loads_done(); // everything loaded so far is in its registers before the first store is issued
     sg_lgkm_done();
@@ -3423,7 +3425,7 @@ __device__ __forceinline__ void rollout_body(
                     }
                     // catalog type of the other entity (slot j of this scenario)
                     const int oj = (WV == 1 ? tile0 : 0) + j; // slot inside the workgroup's blocks
-                    const double *oblk = p.stat + ((size_t)blockIdx.x * WV + (oj >> 6)) * (ST_COUNT * 64);
+                    const double *oblk = p.stat + ((size_t)bx * WV + (oj >> 6)) * (ST_COUNT * 64);
                     int64_t ometa = reinterpret_cast<const int64_t *>(oblk)[ST_META * 64 + (oj & 63)];
                     for (int q = 0; q < mult; ++q) {
                         if (n_ev < p.ev_cap) {
@@ -3615,21 +3617,60 @@ __global__ __launch_bounds__(64 * WV, SG_WAVES_PER_SIMD_PED) void rollout_kernel
     rollout_body<G, WV, true, false, false, false, true>(p, timestep, n_steps, do_reset, force, actions, tab);
 }
 
+// Block groups of a table-variant launch (launch_rollout): the 64-slot blocks of the batch are cut into up to 64 groups of
+// `gsz` consecutive blocks; a launch runs the groups of `active` only -- as many as fill the wavefront slots of the device
+// exactly once -- and every group reads the controller-table buffer (and runs the number of steps) of the chunk of the time
+// axis IT has reached: buffer index = 2 bits per group in `bufof`.  A batch that is not a whole number of "rounds" of the
+// device (4096 wavefronts on 3 x 1024 slots) then still runs as full rounds: the groups take turns sitting a launch out.
+// One group, active = 1: an ordinary launch.
+struct TabGroups {
+    unsigned long long active, bufof[2];
+    int gsz, n[4];
+    const double *buf[4];
+    // the launch's grid holds the active blocks only (a wavefront that starts just to find its group idle costs ~0.1 us of
+    // the dispatcher's time, 0.3 ms for a thousand): grid block i is block start0 + i for i < len0, else start1 + (i - len0)
+    unsigned start0, len0, start1, len1;
+    __device__ __forceinline__ unsigned map(unsigned i) const { return i < len0 ? start0 + i : start1 + (i - len0); }
+    __device__ __forceinline__ bool pick(unsigned blk, int &n_steps, const double *&tab) const
+    {
+        const unsigned g = blk / (unsigned)gsz;
+        if (!((active >> g) & 1)) return false;
+        const unsigned b = (unsigned)(bufof[g >> 5] >> (2 * (g & 31))) & 3u;
+        n_steps = b == 0 ? n[0] : (b == 1 ? n[1] : (b == 2 ? n[2] : n[3]));
+        tab = b == 0 ? buf[0] : (b == 1 ? buf[1] : (b == 2 ? buf[2] : buf[3]));
+        return true;
+    }
+};
+
 // The table variant with one wavefront per tile (C2 / C3 shapes) under a 192-VGPR cap: two of its wavefronts and one of
 // control_kernel (<= 128) fill the 512 VGPRs of a SIMD exactly, so the pre-pass of the next chunk is co-resident with
 // the rollout kernel instead of waiting for one of its wavefronts to retire.
 template <int G>
 __global__ __launch_bounds__(64, 2) __attribute__((amdgpu_num_vgpr(96))) void rollout_kernel_tab(
-    Params p, double timestep, int n_steps, int do_reset, int force, const double *actions, const double *tab)
+    Params p, double timestep, int force, TabGroups tg)
 {
-    rollout_body<G, 1, false, true, true>(p, timestep, n_steps, do_reset, force, actions, tab);
+    int n_steps;
+    const double *tab;
+    const unsigned blk = tg.map(blockIdx.x);
+    if (!tg.pick(blk, n_steps, tab)) return;
+    rollout_body<G, 1, false, true, true>(p, timestep, n_steps, 0, force, nullptr, tab, SliceArgs{}, blk);
 }
 // ... for batches whose knots all have z = pitch = roll = +0.0 (PLANAR)
+// Three wavefronts per SIMD (168 VGPRs): the kernel issues ~0.73 of the peak with two, ~0.85 with three.  The pre-pass does
+// not fit beside three of them (launch_rollout gives it slots of its own: block groups).
+#ifndef SG_PLANAR_WAVES // (experiment builds: -DSG_PLANAR_WAVES=2 -DSG_PLANAR_VGPR=96)
+#define SG_PLANAR_WAVES 3
+#define SG_PLANAR_VGPR 84
+#endif
 template <int G>
-__global__ __launch_bounds__(64, 2) __attribute__((amdgpu_num_vgpr(96))) void rollout_kernel_tab_planar(
-    Params p, double timestep, int n_steps, int do_reset, int force, const double *actions, const double *tab)
+__global__ __launch_bounds__(64, SG_PLANAR_WAVES) __attribute__((amdgpu_num_vgpr(SG_PLANAR_VGPR))) void rollout_kernel_tab_planar(
+    Params p, double timestep, int force, TabGroups tg)
 {
-    rollout_body<G, 1, false, true, true, false, false, false, false, true>(p, timestep, n_steps, do_reset, force, actions, tab);
+    int n_steps;
+    const double *tab;
+    const unsigned blk = tg.map(blockIdx.x);
+    if (!tg.pick(blk, n_steps, tab)) return;
+    rollout_body<G, 1, false, true, true, false, false, false, false, true>(p, timestep, n_steps, 0, force, nullptr, tab, SliceArgs{}, blk);
 }
 
 // One slice of a time-sliced replay (grid.y = slices; SliceArgs), or its last step with the full state stores
@@ -4398,11 +4439,15 @@ __device__ inline int sg_classify_collision(const double *eb, double ex, double 
 // Right after a table-variant launch, while its controller table is still there: the events it recorded for Vehicle hazards
 // (type packed with k, the step inside the launch) take the controlled ego's pose at that step from the table row and become
 // ordinary pending events.  A few loads and stores per event; the classification itself waits for sg_read_metrics.
-__global__ __launch_bounds__(64) void event_ego_pose_kernel(Params p, const double *tab)
+// (`tg`: the block groups of that launch -- the scenario's group says which buffer its rows are in)
+__global__ __launch_bounds__(64) void event_ego_pose_kernel(Params p, TabGroups tg)
 {
     const int r = blockIdx.x;
     const int n = min(p.sdyn[r].n_events, p.ev_cap);
     if (n == 0) return;
+    int n_launch;
+    const double *tab;
+    if (!tg.pick((unsigned)(((size_t)r * p.EP) >> 6), n_launch, tab)) return; // (its group sat the launch out: nothing packed)
     const uint32_t eidx = (uint32_t)r * p.EP + p.sstat[r].ego;
     const LanePtr est(p.stat + (size_t)(eidx >> 6) * (ST_COUNT * 64), (eidx & 63) * 8u);
     const int64_t ectl = fld<int64_t>(est, ST_CTL);

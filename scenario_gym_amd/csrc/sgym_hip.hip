@@ -83,7 +83,10 @@ struct sg_handle {
     double *d_ext = nullptr;  // [NE][6]
     int max_ctl_per_block = 0; // controlled lanes in the fullest 64-slot block
     hipStream_t ctl_stream = nullptr;
-    double *d_tab[2] = {nullptr, nullptr};
+    hipStream_t stream2 = nullptr; // second rollout pipeline (launch_rollout, SG_TAB_SPLIT), created on first use
+    double *d_tab[4] = {nullptr, nullptr, nullptr, nullptr}; // controller-table buffers (launch_rollout: two, four with block groups)
+    int n_tab = 0;
+    int n_simd = 1024;                                       // SIMDs of the device (4 per compute unit)
     size_t tab_bytes = 0;     // bytes of each table buffer
     std::vector<hipEvent_t> ev_pool;
     int tab_min = 16, chunk_steps = 1024, overlap = 1; // sg_set_tuning
@@ -290,6 +293,11 @@ extern "C" int sg_create(const sg_config *cfg, sg_handle **out)
         delete h;
         return fail(nullptr, SG_ERR_HIP, "sg_create: stream/event creation failed");
     }
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device) == hipSuccess && cus > 0) h->n_simd = 4 * cus;
+        else (void)hipGetLastError();
+    }
     *out = h;
     return SG_OK;
 }
@@ -342,12 +350,13 @@ extern "C" int sg_destroy(sg_handle *h)
     if (h->d_actions) (void)hipFree(h->d_actions);
     if (h->d_gon) (void)hipFree(h->d_gon);
     if (h->d_normals) (void)hipFree(h->d_normals);
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < 4; ++b)
         if (h->d_tab[b]) (void)hipFree(h->d_tab[b]);
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->up_ev) (void)hipEventDestroy(e);
     if (h->up_stat) (void)hipHostFree(h->up_stat);
     if (h->ctl_stream) (void)hipStreamDestroy(h->ctl_stream);
+    if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -360,9 +369,48 @@ extern "C" int sg_destroy(sg_handle *h)
 static const double kDefaultCtrl[SG_NCTRL] = {0.7, 5.0, NAN, 0.0, 0.03054, 1.5709, 0.3753, 1.8970, 0.0204,
                                               0.0, 5.0, 0.0, 1.0, 0, 0, 0};
 
+// one group holding every block: an ordinary launch of a table variant
+static sg::TabGroups one_group(const sg_handle *h, const double *tab, int n_steps)
+{
+    sg::TabGroups tg{};
+    tg.active = 1;
+    tg.gsz = (int)std::max<size_t>(1, h->NE / 64);
+    tg.n[0] = n_steps;
+    tg.buf[0] = tab;
+    tg.start0 = 0; tg.len0 = (unsigned)tg.gsz; tg.start1 = 0; tg.len1 = 0;
+    return tg;
+}
+
+// the blocks of the active groups as (at most) two ranges of the launch's grid; more runs than that: the whole grid, idle
+// groups return at once
+static void set_ranges(sg::TabGroups &tg, int P, size_t nblk)
+{
+    unsigned st[3] = {0, 0, 0}, ln[3] = {0, 0, 0};
+    int runs = 0;
+    for (int g = 0; g < P; ++g) {
+        if (!((tg.active >> g) & 1)) continue;
+        const bool cont = g > 0 && ((tg.active >> (g - 1)) & 1);
+        const unsigned b0 = (unsigned)g * (unsigned)tg.gsz, b1 = (unsigned)std::min<size_t>(nblk, (size_t)(g + 1) * (size_t)tg.gsz);
+        if (!cont) {
+            if (++runs > 2) break;
+            st[runs - 1] = b0;
+            ln[runs - 1] = 0;
+        }
+        ln[runs - 1] += b1 > b0 ? b1 - b0 : 0;
+    }
+    if (runs > 2 || runs == 0) { tg.start0 = 0; tg.len0 = (unsigned)nblk; tg.start1 = 0; tg.len1 = 0; return; }
+    tg.start0 = st[0]; tg.len0 = ln[0]; tg.start1 = st[1]; tg.len1 = ln[1];
+}
+
+// grid of a launch of the one-wavefront-per-tile table kernels: the blocks of the active groups
+static dim3 tab_grid(const sg_handle *h, const sg::TabGroups &tg)
+{
+    return dim3((unsigned)std::min<size_t>(h->NE / 64, (size_t)tg.len0 + tg.len1));
+}
+
 template <int G, int WV>
 static void launch_variant(sg_handle *h, dim3 grid, int n_steps, int do_reset, int force, const double *d_actions,
-                           const double *d_tab, bool use_tab)
+                           const double *d_tab, bool use_tab, const sg::TabGroups &tg)
 {
     dim3 block(64 * WV);
 #ifdef SG_ONLY_CROWD // experiment builds (tools/ab_build.sh): only the crowd variant is compiled
@@ -387,9 +435,9 @@ static void launch_variant(sg_handle *h, dim3 grid, int n_steps, int do_reset, i
     else if (h->cfg.terminal_mask & SG_TERM_EGO_OFF_ROAD)
         sg::rollout_kernel_road<G, WV><<<grid, block, 0, h->stream>>>(h->p, h->cfg.timestep, n_steps, do_reset, force, d_actions, nullptr);
     else if (use_tab && WV == 1 && h->n_ctl > 0 && h->planar)
-        sg::rollout_kernel_tab_planar<G><<<grid, block, 0, h->stream>>>(h->p, h->cfg.timestep, n_steps, 0, force, nullptr, d_tab);
+        sg::rollout_kernel_tab_planar<G><<<tab_grid(h, tg), block, 0, h->stream>>>(h->p, h->cfg.timestep, force, tg);
     else if (use_tab && WV == 1 && h->n_ctl > 0)
-        sg::rollout_kernel_tab<G><<<grid, block, 0, h->stream>>>(h->p, h->cfg.timestep, n_steps, 0, force, nullptr, d_tab);
+        sg::rollout_kernel_tab<G><<<tab_grid(h, tg), block, 0, h->stream>>>(h->p, h->cfg.timestep, force, tg);
     else if (use_tab)
         sg::rollout_kernel<G, WV, false, true><<<grid, block, 0, h->stream>>>(h->p, h->cfg.timestep, n_steps, 0, force,
                                                                                nullptr, d_tab);
@@ -410,9 +458,11 @@ static int get_event(sg_handle *h, size_t idx, hipEvent_t *out)
 }
 
 // one rollout_kernel launch on the handle's stream, bracketed by its own pair of timing events
+// (groups: the block groups of a grouped table-variant launch, launch_rollout; else every block runs n_steps on d_tab)
 static int launch_main(sg_handle *h, int n_steps, int do_reset, int force, const double *d_actions, const double *d_tab,
-                       bool use_tab, size_t *ev_next)
+                       bool use_tab, size_t *ev_next, const sg::TabGroups *groups = nullptr)
 {
+    const sg::TabGroups tg = groups ? *groups : one_group(h, d_tab, n_steps);
     dim3 grid(h->WV == 1 ? (unsigned)(h->NE / 64) : (unsigned)h->R);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     int rc;
@@ -422,20 +472,20 @@ static int launch_main(sg_handle *h, int n_steps, int do_reset, int force, const
     }
     if (h->WV == 8) // (launch_rollout never takes the table path at this width)
         sg::rollout_kernel<64, 8, false, false><<<grid, dim3(512), 0, h->stream>>>(h->p, h->cfg.timestep, n_steps, do_reset, force, d_actions, nullptr);
-    else if (h->WV == 4) launch_variant<64, 4>(h, grid, n_steps, do_reset, force, d_actions, d_tab, use_tab);
-    else if (h->WV == 2) launch_variant<64, 2>(h, grid, n_steps, do_reset, force, d_actions, d_tab, use_tab);
+    else if (h->WV == 4) launch_variant<64, 4>(h, grid, n_steps, do_reset, force, d_actions, d_tab, use_tab, tg);
+    else if (h->WV == 2) launch_variant<64, 2>(h, grid, n_steps, do_reset, force, d_actions, d_tab, use_tab, tg);
     else switch (h->G) {
-    case 4: launch_variant<4, 1>(h, grid, n_steps, do_reset, force, d_actions, d_tab, use_tab); break;
-    case 8: launch_variant<8, 1>(h, grid, n_steps, do_reset, force, d_actions, d_tab, use_tab); break;
-    case 16: launch_variant<16, 1>(h, grid, n_steps, do_reset, force, d_actions, d_tab, use_tab); break;
-    case 32: launch_variant<32, 1>(h, grid, n_steps, do_reset, force, d_actions, d_tab, use_tab); break;
-    default: launch_variant<64, 1>(h, grid, n_steps, do_reset, force, d_actions, d_tab, use_tab); break;
+    case 4: launch_variant<4, 1>(h, grid, n_steps, do_reset, force, d_actions, d_tab, use_tab, tg); break;
+    case 8: launch_variant<8, 1>(h, grid, n_steps, do_reset, force, d_actions, d_tab, use_tab, tg); break;
+    case 16: launch_variant<16, 1>(h, grid, n_steps, do_reset, force, d_actions, d_tab, use_tab, tg); break;
+    case 32: launch_variant<32, 1>(h, grid, n_steps, do_reset, force, d_actions, d_tab, use_tab, tg); break;
+    default: launch_variant<64, 1>(h, grid, n_steps, do_reset, force, d_actions, d_tab, use_tab, tg); break;
     }
     HIP_TRY(h, hipGetLastError());
     if (use_tab && d_tab && h->n_ctl > 0 && h->p.ev_cap > 0 && n_steps > 0) {
         // a controlled ego's pose at an event of this chunk is a row of the chunk's controller table: copied into the event
         // now -- before the event below, which the pre-pass of a later chunk waits for before it reuses the buffer
-        sg::event_ego_pose_kernel<<<dim3((unsigned)h->R), dim3(64), 0, h->stream>>>(h->p, d_tab);
+        sg::event_ego_pose_kernel<<<dim3((unsigned)h->R), dim3(64), 0, h->stream>>>(h->p, tg);
         HIP_TRY(h, hipGetLastError());
     }
     if (h->rss_fused) { // (launch_variant ran a rollout_kernel_rss* variant)
@@ -488,6 +538,7 @@ static int launch_rollout(sg_handle *h, int n_steps, int do_reset, int force, co
                 HIP_TRY(h, hipMalloc((void **)&h->d_tab[0], 64 * sizeof(double)));
                 HIP_TRY(h, hipMalloc((void **)&h->d_tab[1], 64 * sizeof(double)));
                 h->tab_bytes = 64 * sizeof(double);
+                h->n_tab = 2;
                 HIP_TRY(h, hipMemsetAsync(h->d_tab[0], 0, 64 * sizeof(double), h->stream));
             }
             rc = launch_main(h, n_steps, 0, force, nullptr, h->d_tab[0], true, &ev_next);
@@ -497,62 +548,119 @@ static int launch_rollout(sg_handle *h, int n_steps, int do_reset, int force, co
             int ch = (int)std::min<size_t>((size_t)chunk_steps, std::max<size_t>(1, ((size_t)1 << 27) / row));
             ch = std::min(ch, n_steps);
             if (rss_tab) ch = std::min(ch, std::max(1, h->rssq_steps)); // one launch fills at most the line-test queue
-            if (ch > h->p.tab_steps || (size_t)(h->p.tab_steps + 1) * row * sizeof(double) > h->tab_bytes) {
+            // Two pipelines (sgym_device.hpp, TabGroups).  A launch of the one-wavefront-per-tile table kernels is as slow as its
+            // slowest wavefront, and a batch is rarely a whole number of rounds of the device's wavefront slots (4096
+            // wavefronts on 3 x 1024): with one launch at a time the slots idle at every launch boundary.  So the two halves of
+            // the blocks run as launches of their own on two streams, each half chunk after chunk: whenever one half's launch
+            // drains, wavefronts of the other half's take the slots.  Both consume the same pre-pass tables (four buffers: the
+            // halves may be a chunk or two apart, the pre-pass ahead of both).  Results do not depend on it (scenarios never
+            // interact); SG_TAB_SPLIT=1: one pipeline.
+            const size_t nblk = h->NE / 64;
+            int H = 1;
+            if (h->WV == 1 && !h->rss_fused && !riders && !no_overlap && env_int("SG_TAB_SPLIT", 2) >= 2 &&
+                nblk >= (size_t)std::max(2, env_int("SG_TAB_SPLIT_MIN", 512))) {
+                H = 2;
+                if (!h->stream2) HIP_TRY(h, hipStreamCreate(&h->stream2));
+            }
+            const int gsz = (int)std::max<size_t>(1, (nblk + H - 1) / H);
+            const int NB = H > 1 ? 4 : 2; // table buffers
+            // the pre-pass in launches of ctl_slice steps (its load then moves between SIMDs) -- but the planar kernel's three
+            // wavefronts (168 VGPRs each) leave it no room on a SIMD: with both pipelines keeping every slot taken, each of
+            // its launches waits for a wavefront to retire, so there it is one launch per chunk
+            const int ctl_slice = (H > 1 && h->planar && SG_PLANAR_WAVES > 2 && !env_int("SG_CTL_SLICE", 0)) ? ch : h->ctl_slice;
+            if (ch > h->p.tab_steps || (size_t)(h->p.tab_steps + 1) * row * sizeof(double) > h->tab_bytes || NB > h->n_tab) {
                 // grow: tab_steps + 1 rows per lane is part of the table addressing
                 const int ts = std::max(ch, h->p.tab_steps);
                 const size_t need = (size_t)(ts + 1) * row * sizeof(double);
-                if (need > h->tab_bytes) { // (the buffers outlive sg_upload: the next batch of the same shape reuses them)
+                if (need > h->tab_bytes || NB > h->n_tab) { // (the buffers outlive sg_upload: the next batch of the same shape reuses them)
                     HIP_TRY(h, hipStreamSynchronize(h->stream));
                     HIP_TRY(h, hipStreamSynchronize(h->ctl_stream));
-                    for (int b = 0; b < 2; ++b) {
+                    if (h->stream2) HIP_TRY(h, hipStreamSynchronize(h->stream2));
+                    for (int b = 0; b < 4; ++b) {
                         if (h->d_tab[b]) HIP_TRY(h, hipFree(h->d_tab[b]));
                         h->d_tab[b] = nullptr;
                     }
+                    const size_t bytes = std::max(need, h->tab_bytes);
                     h->tab_bytes = 0;
-                    for (int b = 0; b < 2; ++b) HIP_TRY(h, hipMalloc((void **)&h->d_tab[b], need));
-                    h->tab_bytes = need;
+                    h->n_tab = 0;
+                    for (int b = 0; b < NB; ++b) HIP_TRY(h, hipMalloc((void **)&h->d_tab[b], bytes));
+                    h->tab_bytes = bytes;
+                    h->n_tab = NB;
                 }
                 h->p.tab_steps = ts;
             }
             hipStream_t cs = no_overlap ? h->stream : h->ctl_stream;
             hipEvent_t e;
-            if (!no_overlap) { // the controller stream starts after everything queued so far (reset, uploads)
+            if (!no_overlap) { // the other streams start after everything queued so far (reset, uploads)
                 if ((rc = get_event(h, ev_next++, &e))) return rc;
                 HIP_TRY(h, hipEventRecord(e, h->stream));
                 HIP_TRY(h, hipStreamWaitEvent(cs, e, 0));
+                if (H > 1) HIP_TRY(h, hipStreamWaitEvent(h->stream2, e, 0));
             }
-            std::vector<hipEvent_t> main_done;
             const dim3 cgrid((unsigned)(np / 64)), cblock(64);
             const bool rss_fast = env_int("SG_RSS_CTL_FAST", 1) != 0;
-            // chunk lengths double from two slices up to `ch`: the rollout kernel cannot start before the table of
-            // its chunk exists, and the pre-pass of chunk c+1 (about 0.4x the rollout kernel's time per step) then
-            // always finishes under the rollout kernel of chunk c
-            int c = 0;
-            for (int k0 = 0, n = 0; k0 < n_steps; k0 += n, ++c) {
+            // chunks of the time axis: lengths double from two slices up to `ch` -- the rollout kernel cannot start before
+            // the table of its chunk exists, and the pre-pass of the chunks after it (about 0.4x the rollout kernel's time
+            // per step) then always finishes under the rollout kernel
+            std::vector<int> ck0, cn;
+            for (int k0 = 0, n = 0, c = 0; k0 < n_steps; k0 += n, ++c) {
                 n = std::min(std::min(ch, c < 20 ? (2 * h->ctl_slice) << c : ch), n_steps - k0);
-                double *tab = h->d_tab[c & 1];
-                if (!no_overlap && c >= 2) HIP_TRY(h, hipStreamWaitEvent(cs, main_done[c - 2], 0)); // table buffer free
-                for (int s0 = 0; s0 < n; s0 += h->ctl_slice) { // short launches: the pre-pass load moves between SIMDs
-                    const int ns = std::min(h->ctl_slice, n - s0);
-                    if (riders)
-                        sg::control_kernel_riders<<<cgrid, cblock, 0, cs>>>(h->p, h->cfg.timestep, ns, c == 0 && s0 == 0, k0 + s0,
-                                                                            d_actions, tab, s0, 0);
-                    else if (rss_tab && rss_fast) // (the ego's metrics are the rollout kernel's, from its own velocities)
-                        sg::control_kernel_fast<<<cgrid, cblock, 0, cs>>>(h->p, h->cfg.timestep, ns, c == 0 && s0 == 0, k0 + s0,
-                                                                          d_actions, tab, s0, 0);
-                    else
-                        sg::control_kernel<<<cgrid, cblock, 0, cs>>>(h->p, h->cfg.timestep, ns, c == 0 && s0 == 0, k0 + s0,
-                                                                     d_actions, tab, s0, rss_tab ? 0 : 1);
-                }
-                HIP_TRY(h, hipGetLastError());
-                if (!no_overlap) {
-                    if ((rc = get_event(h, ev_next++, &e))) return rc;
-                    HIP_TRY(h, hipEventRecord(e, cs));
-                    HIP_TRY(h, hipStreamWaitEvent(h->stream, e, 0));
-                }
-                if ((rc = launch_main(h, n, 0, force, nullptr, tab, true, &ev_next))) return rc;
-                main_done.push_back(h->ev_pool[ev_next - 1]);
+                ck0.push_back(k0);
+                cn.push_back(n);
             }
+            const int C = (int)cn.size();
+            std::vector<hipEvent_t> ctl_done((size_t)C, nullptr), chunk_done[2];
+            chunk_done[0].assign((size_t)C, nullptr);
+            chunk_done[1].assign((size_t)C, nullptr);
+            int ctl_issued = 0;
+            auto issue_ctl = [&](int upto) -> int { // the pre-pass of the chunks up to `upto`, each into buffer (chunk mod NB)
+                for (; ctl_issued <= upto && ctl_issued < C; ++ctl_issued) {
+                    const int c = ctl_issued, k0 = ck0[(size_t)c], n = cn[(size_t)c];
+                    double *tab = h->d_tab[c % NB];
+                    if (!no_overlap && c >= NB) // the buffer is free once every pipeline is through chunk c - NB
+                        for (int j = 0; j < H; ++j) HIP_TRY(h, hipStreamWaitEvent(cs, chunk_done[j][(size_t)(c - NB)], 0));
+                    for (int s0 = 0; s0 < n; s0 += ctl_slice) {
+                        const int ns = std::min(ctl_slice, n - s0);
+                        if (riders)
+                            sg::control_kernel_riders<<<cgrid, cblock, 0, cs>>>(h->p, h->cfg.timestep, ns, c == 0 && s0 == 0, k0 + s0,
+                                                                                d_actions, tab, s0, 0);
+                        else if (rss_tab && rss_fast) // (the ego's metrics are the rollout kernel's, from its own velocities)
+                            sg::control_kernel_fast<<<cgrid, cblock, 0, cs>>>(h->p, h->cfg.timestep, ns, c == 0 && s0 == 0, k0 + s0,
+                                                                              d_actions, tab, s0, 0);
+                        else
+                            sg::control_kernel<<<cgrid, cblock, 0, cs>>>(h->p, h->cfg.timestep, ns, c == 0 && s0 == 0, k0 + s0,
+                                                                         d_actions, tab, s0, rss_tab ? 0 : 1);
+                    }
+                    HIP_TRY(h, hipGetLastError());
+                    if (!no_overlap) {
+                        const int rc2 = get_event(h, ev_next++, &ctl_done[(size_t)c]);
+                        if (rc2) return rc2;
+                        HIP_TRY(h, hipEventRecord(ctl_done[(size_t)c], cs));
+                    }
+                }
+                return SG_OK;
+            };
+            for (int c = 0; c < C; ++c) {
+                // (chunk c + NB - 1 goes into the buffer of chunk c - 1, whose launches were queued by the previous iteration)
+                if ((rc = issue_ctl(std::min(C - 1, c + NB - 1)))) return rc;
+                for (int j = 0; j < H; ++j) {
+                    sg::TabGroups tg{};
+                    const int b = c % NB;
+                    tg.gsz = gsz;
+                    tg.active = 1ull << j;
+                    tg.bufof[0] = (unsigned long long)b << (2 * j);
+                    tg.n[b] = cn[(size_t)c];
+                    tg.buf[b] = h->d_tab[b];
+                    set_ranges(tg, H, nblk);
+                    if (j == 1) std::swap(h->stream, h->stream2); // (launch_main works on h->stream)
+                    const hipError_t we = no_overlap ? hipSuccess : hipStreamWaitEvent(h->stream, ctl_done[(size_t)c], 0);
+                    rc = we == hipSuccess ? launch_main(h, cn[(size_t)c], 0, force, nullptr, h->d_tab[b], true, &ev_next, &tg) : SG_ERR_HIP;
+                    if (j == 1) std::swap(h->stream, h->stream2);
+                    if (rc) return we == hipSuccess ? rc : fail(h, SG_ERR_HIP, "sg_rollout: hipStreamWaitEvent failed");
+                    chunk_done[j][(size_t)c] = h->ev_pool[ev_next - 1];
+                }
+            }
+            if (H > 1) HIP_TRY(h, hipStreamWaitEvent(h->stream, chunk_done[1][(size_t)(C - 1)], 0)); // join
         }
     }
     if (rc) return rc;
@@ -739,7 +847,7 @@ static int launch_sliced(sg_handle *h, int n_steps)
         HIP_TRY(h, hipStreamWaitEvent(h->ctl_stream, e_nf, 0));
         sg::replay_scenario_fixup_kernel<<<dim3((unsigned)((R + 63) / 64)), dim3(64), 0, h->ctl_stream>>>(ps, sa, h->d_n_final, h->d_slice_done);
         if (ctl && h->p.ev_cap > 0) // the controlled egos' (and hazards') poses at the events: rows of the table
-            sg::event_ego_pose_kernel<<<dim3((unsigned)R), dim3(64), 0, h->ctl_stream>>>(ps, tab);
+            sg::event_ego_pose_kernel<<<dim3((unsigned)R), dim3(64), 0, h->ctl_stream>>>(ps, one_group(h, tab, n_steps));
     }
     sa.mode = 1;
     sa.n_final = h->d_n_final;
@@ -1586,20 +1694,56 @@ extern "C" int sg_last_kernel_ms(sg_handle *h, float *ms)
     return SG_OK;
 }
 
+// (start, end) of the hot-path launches of the last timed call, ms after the call's first event
+static int launch_intervals(sg_handle *h, std::vector<std::pair<float, float>> &iv)
+{
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, hipEventSynchronize(h->ev1));
+    iv.clear();
+    for (int i : h->launch_ev) {
+        float a = 0.0f, d = 0.0f;
+        HIP_TRY(h, hipEventElapsedTime(&a, h->ev0, h->ev_pool[i]));
+        HIP_TRY(h, hipEventElapsedTime(&d, h->ev_pool[i], h->ev_pool[i + 1]));
+        iv.emplace_back(a, a + d);
+    }
+    return SG_OK;
+}
+
 extern "C" int sg_last_launch_stats(sg_handle *h, int32_t *n_launches, float *kernel_ms_total)
 {
     if (!h || !n_launches || !kernel_ms_total) return SG_ERR_INVALID;
     if (!h->timed) return fail(h, SG_ERR_STATE, "sg_last_launch_stats: the last call was not timed (nothing launched yet, or fewer than 16 steps)");
-    HIP_TRY(h, hipSetDevice(h->cfg.device));
-    HIP_TRY(h, hipEventSynchronize(h->ev1));
-    float total = 0.0f;
-    for (int i : h->launch_ev) {
-        float ms = 0.0f;
-        HIP_TRY(h, hipEventElapsedTime(&ms, h->ev_pool[i], h->ev_pool[i + 1]));
-        total += ms;
+    std::vector<std::pair<float, float>> iv;
+    int rc = launch_intervals(h, iv);
+    if (rc) return rc;
+    // the union of the launches' intervals: launches of the two pipelines overlap (launch_rollout), time counts once
+    std::sort(iv.begin(), iv.end());
+    float total = 0.0f, lo = 0.0f, hi = -1.0f;
+    for (const auto &x : iv) {
+        if (hi < lo || x.first > hi) {
+            if (hi >= lo) total += hi - lo;
+            lo = x.first;
+            hi = x.second;
+        } else {
+            hi = std::max(hi, x.second);
+        }
     }
+    if (hi >= lo) total += hi - lo;
     *n_launches = h->n_launches;
     *kernel_ms_total = total;
+    return SG_OK;
+}
+
+extern "C" int sg_last_launch_gross_ms(sg_handle *h, float *kernel_ms_gross)
+{
+    if (!h || !kernel_ms_gross) return SG_ERR_INVALID;
+    if (!h->timed) return fail(h, SG_ERR_STATE, "sg_last_launch_gross_ms: the last call was not timed (nothing launched yet, or fewer than 16 steps)");
+    std::vector<std::pair<float, float>> iv;
+    int rc = launch_intervals(h, iv);
+    if (rc) return rc;
+    float total = 0.0f;
+    for (const auto &x : iv) total += x.second - x.first;
+    *kernel_ms_gross = total;
     return SG_OK;
 }
 

@@ -341,10 +341,16 @@ class RolloutEngine:
         self._check(self.lib.sg_set_slicing(self.h, 2 if on == "always" else int(bool(on))), "sg_set_slicing")
 
     def last_launch_stats(self):
-        """(number of rollout-kernel launches of the last call, sum of their durations in ms)."""
+        """(number of rollout-kernel launches of the last call, the time in ms during which at least one of them ran)."""
         n, ms = C.c_int32(), C.c_float()
         self._check(self.lib.sg_last_launch_stats(self.h, C.byref(n), C.byref(ms)), "sg_last_launch_stats")
         return n.value, ms.value
+
+    def last_launch_gross_ms(self):
+        """Sum of the durations of those launches (launches of the two pipelines overlap: more than the time above)."""
+        ms = C.c_float()
+        self._check(self.lib.sg_last_launch_gross_ms(self.h, C.byref(ms)), "sg_last_launch_gross_ms")
+        return ms.value
 
     def debug_trig32(self, heading):
         """The broad phase's fp32 (sin, cos) of fp64 headings (test hook)."""
