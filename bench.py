@@ -20,6 +20,10 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# The rollout runs on up to four HIP streams at once (three pipelines + the controller pre-pass); HIP multiplexes a
+# process's streams over GPU_MAX_HW_QUEUES hardware queues (default 4), and RCCL / torch bring streams of their own.  Read
+# when the HIP runtime loads, i.e. before torch is imported.  (The library probes what it got: sg_create, probe_pipelines.)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # BASELINE.json configs: scenarios, entities; algorithmic bytes per entity-step (pose 48 + velocity 48 +

@@ -83,7 +83,8 @@ struct sg_handle {
     double *d_ext = nullptr;  // [NE][6]
     int max_ctl_per_block = 0; // controlled lanes in the fullest 64-slot block
     hipStream_t ctl_stream = nullptr;
-    hipStream_t stream2 = nullptr; // second rollout pipeline (launch_rollout, SG_TAB_SPLIT), created on first use
+    hipStream_t xstream[2] = {nullptr, nullptr}; // further rollout pipelines (launch_rollout)
+    int n_pipes = 1;                             // rollout pipelines that really run side by side (probe_pipelines)
     double *d_tab[4] = {nullptr, nullptr, nullptr, nullptr}; // controller-table buffers (launch_rollout: two, four with block groups)
     int n_tab = 0;
     int n_simd = 1024;                                       // SIMDs of the device (4 per compute unit)
@@ -243,6 +244,52 @@ extern "C" int sg_version(void) { return SG_ABI_VERSION; }
 
 extern "C" const char *sg_last_error(const sg_handle *h) { return h ? h->err.c_str() : g_create_err.c_str(); }
 
+// How many rollout pipelines (streams) of this handle really run side by side?  HIP multiplexes its streams over a few
+// hardware queues (GPU_MAX_HW_QUEUES, 4 by default, per process and device); two streams that share one run their kernels
+// one after the other, and two pipelines that do are slower than one.  A 0.2 ms spin kernel on every stream at once, its
+// start and end read back: pipeline j counts if its kernel overlapped those of the main stream, the controller stream and
+// the pipelines before it.
+namespace sg {
+__global__ void spin_kernel(long long ticks)
+{
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) {}
+}
+}
+static int probe_pipelines(sg_handle *h, int want)
+{
+    h->n_pipes = 1;
+    if (want < 2) return SG_OK;
+    hipStream_t st[4] = {h->stream, h->ctl_stream, h->xstream[0], h->xstream[1]};
+    const int n = std::min(4, 1 + want);
+    hipEvent_t a[4] = {}, b[4] = {};
+    for (int i = 0; i < n; ++i) {
+        HIP_TRY(h, hipEventCreate(&a[i]));
+        HIP_TRY(h, hipEventCreate(&b[i]));
+    }
+    for (int i = 0; i < n; ++i) {
+        HIP_TRY(h, hipEventRecord(a[i], st[i]));
+        sg::spin_kernel<<<dim3(1), dim3(64), 0, st[i]>>>(20000); // 100 MHz ticks
+        HIP_TRY(h, hipEventRecord(b[i], st[i]));
+    }
+    float t0[4] = {0, 0, 0, 0}, t1[4] = {0, 0, 0, 0};
+    for (int i = 0; i < n; ++i) HIP_TRY(h, hipStreamSynchronize(st[i]));
+    for (int i = 0; i < n; ++i) {
+        float d = 0.0f;
+        if (i > 0) HIP_TRY(h, hipEventElapsedTime(&t0[i], a[0], a[i]));
+        HIP_TRY(h, hipEventElapsedTime(&d, a[i], b[i]));
+        t1[i] = t0[i] + d;
+    }
+    auto together = [&](int i, int j) { return std::min(t1[i], t1[j]) - std::max(t0[i], t0[j]) > 0.05f; };
+    bool ok = together(0, 1);
+    for (int j = 2; j < n && ok; ++j) { // pipeline j - 1 on xstream[j - 2]
+        for (int i = 0; i < j && ok; ++i) ok = together(i, j);
+        if (ok) h->n_pipes = j;
+    }
+    for (int i = 0; i < n; ++i) { (void)hipEventDestroy(a[i]); (void)hipEventDestroy(b[i]); }
+    return SG_OK;
+}
+
 extern "C" int sg_create(const sg_config *cfg, sg_handle **out)
 {
     if (!cfg || !out) return fail(nullptr, SG_ERR_INVALID, "sg_create: null argument");
@@ -297,6 +344,16 @@ extern "C" int sg_create(const sg_config *cfg, sg_handle **out)
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device) == hipSuccess && cus > 0) h->n_simd = 4 * cus;
         else (void)hipGetLastError();
+    }
+    {   // the rollout pipelines of the table path (launch_rollout): up to SG_TAB_SPLIT (default 3), as many as run side by side
+        const int want = std::min(3, std::max(1, env_int("SG_TAB_SPLIT", 3)));
+        bool ok = true;
+        for (int j = 1; j < want && ok; ++j) ok = hipStreamCreate(&h->xstream[j - 1]) == hipSuccess;
+        int rc = ok ? probe_pipelines(h, want) : SG_ERR_HIP;
+        if (rc) {
+            sg_destroy(h);
+            return fail(nullptr, SG_ERR_HIP, "sg_create: stream creation / pipeline probe failed");
+        }
     }
     *out = h;
     return SG_OK;
@@ -356,7 +413,8 @@ extern "C" int sg_destroy(sg_handle *h)
     for (hipEvent_t e : h->up_ev) (void)hipEventDestroy(e);
     if (h->up_stat) (void)hipHostFree(h->up_stat);
     if (h->ctl_stream) (void)hipStreamDestroy(h->ctl_stream);
-    if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
+    for (hipStream_t &x : h->xstream)
+        if (x) { (void)hipStreamSynchronize(x); (void)hipStreamDestroy(x); }
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -557,10 +615,9 @@ static int launch_rollout(sg_handle *h, int n_steps, int do_reset, int force, co
             // interact); SG_TAB_SPLIT=1: one pipeline.
             const size_t nblk = h->NE / 64;
             int H = 1;
-            if (h->WV == 1 && !h->rss_fused && !riders && !no_overlap && env_int("SG_TAB_SPLIT", 2) >= 2 &&
-                nblk >= (size_t)std::max(2, env_int("SG_TAB_SPLIT_MIN", 512))) {
-                H = 2;
-                if (!h->stream2) HIP_TRY(h, hipStreamCreate(&h->stream2));
+            if (h->WV == 1 && !h->rss_fused && !riders && !no_overlap && h->n_pipes > 1 &&
+                nblk >= (size_t)std::max(4, env_int("SG_TAB_SPLIT_MIN", 512))) {
+                H = h->n_pipes;
             }
             const int gsz = (int)std::max<size_t>(1, (nblk + H - 1) / H);
             const int NB = H > 1 ? 4 : 2; // table buffers
@@ -575,7 +632,8 @@ static int launch_rollout(sg_handle *h, int n_steps, int do_reset, int force, co
                 if (need > h->tab_bytes || NB > h->n_tab) { // (the buffers outlive sg_upload: the next batch of the same shape reuses them)
                     HIP_TRY(h, hipStreamSynchronize(h->stream));
                     HIP_TRY(h, hipStreamSynchronize(h->ctl_stream));
-                    if (h->stream2) HIP_TRY(h, hipStreamSynchronize(h->stream2));
+                    for (hipStream_t x : h->xstream)
+                        if (x) HIP_TRY(h, hipStreamSynchronize(x));
                     for (int b = 0; b < 4; ++b) {
                         if (h->d_tab[b]) HIP_TRY(h, hipFree(h->d_tab[b]));
                         h->d_tab[b] = nullptr;
@@ -595,7 +653,7 @@ static int launch_rollout(sg_handle *h, int n_steps, int do_reset, int force, co
                 if ((rc = get_event(h, ev_next++, &e))) return rc;
                 HIP_TRY(h, hipEventRecord(e, h->stream));
                 HIP_TRY(h, hipStreamWaitEvent(cs, e, 0));
-                if (H > 1) HIP_TRY(h, hipStreamWaitEvent(h->stream2, e, 0));
+                for (int j = 1; j < H; ++j) HIP_TRY(h, hipStreamWaitEvent(h->xstream[j - 1], e, 0));
             }
             const dim3 cgrid((unsigned)(np / 64)), cblock(64);
             const bool rss_fast = env_int("SG_RSS_CTL_FAST", 1) != 0;
@@ -609,9 +667,8 @@ static int launch_rollout(sg_handle *h, int n_steps, int do_reset, int force, co
                 cn.push_back(n);
             }
             const int C = (int)cn.size();
-            std::vector<hipEvent_t> ctl_done((size_t)C, nullptr), chunk_done[2];
-            chunk_done[0].assign((size_t)C, nullptr);
-            chunk_done[1].assign((size_t)C, nullptr);
+            std::vector<hipEvent_t> ctl_done((size_t)C, nullptr), chunk_done[3];
+            for (auto &v : chunk_done) v.assign((size_t)C, nullptr);
             int ctl_issued = 0;
             auto issue_ctl = [&](int upto) -> int { // the pre-pass of the chunks up to `upto`, each into buffer (chunk mod NB)
                 for (; ctl_issued <= upto && ctl_issued < C; ++ctl_issued) {
@@ -652,15 +709,15 @@ static int launch_rollout(sg_handle *h, int n_steps, int do_reset, int force, co
                     tg.n[b] = cn[(size_t)c];
                     tg.buf[b] = h->d_tab[b];
                     set_ranges(tg, H, nblk);
-                    if (j == 1) std::swap(h->stream, h->stream2); // (launch_main works on h->stream)
+                    if (j > 0) std::swap(h->stream, h->xstream[j - 1]); // (launch_main works on h->stream)
                     const hipError_t we = no_overlap ? hipSuccess : hipStreamWaitEvent(h->stream, ctl_done[(size_t)c], 0);
                     rc = we == hipSuccess ? launch_main(h, cn[(size_t)c], 0, force, nullptr, h->d_tab[b], true, &ev_next, &tg) : SG_ERR_HIP;
-                    if (j == 1) std::swap(h->stream, h->stream2);
+                    if (j > 0) std::swap(h->stream, h->xstream[j - 1]);
                     if (rc) return we == hipSuccess ? rc : fail(h, SG_ERR_HIP, "sg_rollout: hipStreamWaitEvent failed");
                     chunk_done[j][(size_t)c] = h->ev_pool[ev_next - 1];
                 }
             }
-            if (H > 1) HIP_TRY(h, hipStreamWaitEvent(h->stream, chunk_done[1][(size_t)(C - 1)], 0)); // join
+            for (int j = 1; j < H; ++j) HIP_TRY(h, hipStreamWaitEvent(h->stream, chunk_done[j][(size_t)(C - 1)], 0)); // join
         }
     }
     if (rc) return rc;
