@@ -3555,6 +3555,31 @@ __device__ __forceinline__ void rollout_body(
     }
 }
 
+// Block groups of a table-variant launch (launch_rollout): the 64-slot blocks of the batch are cut into up to 64 groups of
+// `gsz` consecutive blocks; a launch runs the groups of `active` only -- as many as fill the wavefront slots of the device
+// exactly once -- and every group reads the controller-table buffer (and runs the number of steps) of the chunk of the time
+// axis IT has reached: buffer index = 2 bits per group in `bufof`.  A batch that is not a whole number of "rounds" of the
+// device (4096 wavefronts on 3 x 1024 slots) then still runs as full rounds: the groups take turns sitting a launch out.
+// One group, active = 1: an ordinary launch.
+struct TabGroups {
+    unsigned long long active, bufof[2];
+    int gsz, n[4];
+    const double *buf[4];
+    // the launch's grid holds the active blocks only (a wavefront that starts just to find its group idle costs ~0.1 us of
+    // the dispatcher's time, 0.3 ms for a thousand): grid block i is block start0 + i for i < len0, else start1 + (i - len0)
+    unsigned start0, len0, start1, len1;
+    __device__ __forceinline__ unsigned map(unsigned i) const { return i < len0 ? start0 + i : start1 + (i - len0); }
+    __device__ __forceinline__ bool pick(unsigned blk, int &n_steps, const double *&tab) const
+    {
+        const unsigned g = blk / (unsigned)gsz;
+        if (!((active >> g) & 1)) return false;
+        const unsigned b = (unsigned)(bufof[g >> 5] >> (2 * (g & 31))) & 3u;
+        n_steps = b == 0 ? n[0] : (b == 1 ? n[1] : (b == 2 ? n[2] : n[3]));
+        tab = b == 0 ? buf[0] : (b == 1 ? buf[1] : (b == 2 ? buf[2] : buf[3]));
+        return true;
+    }
+};
+
 template <int G, int WV, bool PED, bool TAB>
 __global__ __launch_bounds__(64 * WV, PED ? SG_WAVES_PER_SIMD_PED : (TAB ? SG_WAVES_PER_SIMD_TAB : SG_WAVES_PER_SIMD)) void rollout_kernel(
     Params p, double timestep, int n_steps, int do_reset, int force, const double *actions, const double *tab)
@@ -3598,9 +3623,14 @@ __global__ __launch_bounds__(64 * WV, SG_WAVES_PER_SIMD) void rollout_kernel_rss
 // ... with the PID / vehicle agents on the controller pre-pass's table (CTAB): one wavefront per tile
 template <int G>
 __global__ __launch_bounds__(64, SG_WAVES_PER_SIMD) void rollout_kernel_rss_tab(
-    Params p, double timestep, int n_steps, int do_reset, int force, const double *actions, const double *tab)
+    Params p, double timestep, int force, TabGroups tg)
 {
-    rollout_body<G, 1, false, false, false, false, true, false, false, false, false, true>(p, timestep, n_steps, do_reset, force, actions, tab);
+    int n_steps;
+    const double *tab;
+    const unsigned blk = tg.map(blockIdx.x);
+    if (!tg.pick(blk, n_steps, tab)) return;
+    rollout_body<G, 1, false, false, false, false, true, false, false, false, false, true>(p, timestep, n_steps, 0, force, nullptr, tab,
+                                                                                             SliceArgs{}, blk);
 }
 
 // ... with the ego_off_road terminal condition / with pedestrian agents (RSSDistances treats every entity alike)
@@ -3616,31 +3646,6 @@ __global__ __launch_bounds__(64 * WV, SG_WAVES_PER_SIMD_PED) void rollout_kernel
 {
     rollout_body<G, WV, true, false, false, false, true>(p, timestep, n_steps, do_reset, force, actions, tab);
 }
-
-// Block groups of a table-variant launch (launch_rollout): the 64-slot blocks of the batch are cut into up to 64 groups of
-// `gsz` consecutive blocks; a launch runs the groups of `active` only -- as many as fill the wavefront slots of the device
-// exactly once -- and every group reads the controller-table buffer (and runs the number of steps) of the chunk of the time
-// axis IT has reached: buffer index = 2 bits per group in `bufof`.  A batch that is not a whole number of "rounds" of the
-// device (4096 wavefronts on 3 x 1024 slots) then still runs as full rounds: the groups take turns sitting a launch out.
-// One group, active = 1: an ordinary launch.
-struct TabGroups {
-    unsigned long long active, bufof[2];
-    int gsz, n[4];
-    const double *buf[4];
-    // the launch's grid holds the active blocks only (a wavefront that starts just to find its group idle costs ~0.1 us of
-    // the dispatcher's time, 0.3 ms for a thousand): grid block i is block start0 + i for i < len0, else start1 + (i - len0)
-    unsigned start0, len0, start1, len1;
-    __device__ __forceinline__ unsigned map(unsigned i) const { return i < len0 ? start0 + i : start1 + (i - len0); }
-    __device__ __forceinline__ bool pick(unsigned blk, int &n_steps, const double *&tab) const
-    {
-        const unsigned g = blk / (unsigned)gsz;
-        if (!((active >> g) & 1)) return false;
-        const unsigned b = (unsigned)(bufof[g >> 5] >> (2 * (g & 31))) & 3u;
-        n_steps = b == 0 ? n[0] : (b == 1 ? n[1] : (b == 2 ? n[2] : n[3]));
-        tab = b == 0 ? buf[0] : (b == 1 ? buf[1] : (b == 2 ? buf[2] : buf[3]));
-        return true;
-    }
-};
 
 // The table variant with one wavefront per tile (C2 / C3 shapes) under a 192-VGPR cap: two of its wavefronts and one of
 // control_kernel (<= 128) fill the 512 VGPRs of a SIMD exactly, so the pre-pass of the next chunk is co-resident with
@@ -4580,12 +4585,13 @@ __global__ __launch_bounds__(256) void rss_kernel(Params p, int reset, int32_t *
 
 // The queued line tests of one rollout_kernel_rss launch (see RssQueue): block w = the queue of rollout wavefront w, whose
 // lane l carries entity index w * 64 + l.
-__global__ __launch_bounds__(64) void rss_lines_kernel(Params p)
+// (tg: the blocks of that launch -- one pipeline's part of the batch, launch_rollout; else all of them)
+__global__ __launch_bounds__(64) void rss_lines_kernel(Params p, TabGroups tg)
 {
     __shared__ RssQueue q;
     const RssQueueLds ql = (RssQueueLds)&q;
     const int lane = threadIdx.x;
-    const size_t w = blockIdx.x;
+    const size_t w = tg.map(blockIdx.x);
     const int n = p.rssq_n[w];
     const uint32_t idx = (uint32_t)(w * 64 + lane);
     int32_t st = p.rss_state[idx];

@@ -487,7 +487,7 @@ static void launch_variant(sg_handle *h, dim3 grid, int n_steps, int do_reset, i
         sg::rollout_kernel<(WV > 1 || G >= 16) ? G : 16, WV, true, false><<<grid, block, 0, h->stream>>>(
             h->p, h->cfg.timestep, n_steps, do_reset, force, d_actions, nullptr);
     else if (h->rss_fused && use_tab && WV == 1) // (launch_rollout: the controlled lanes' poses come from the pre-pass table)
-        sg::rollout_kernel_rss_tab<G><<<grid, block, 0, h->stream>>>(h->p, h->cfg.timestep, n_steps, 0, force, nullptr, d_tab);
+        sg::rollout_kernel_rss_tab<G><<<tab_grid(h, tg), block, 0, h->stream>>>(h->p, h->cfg.timestep, force, tg);
     else if (h->rss_fused)
         sg::rollout_kernel_rss<G, WV><<<grid, block, 0, h->stream>>>(h->p, h->cfg.timestep, n_steps, do_reset, force, d_actions, nullptr);
     else if (h->cfg.terminal_mask & SG_TERM_EGO_OFF_ROAD)
@@ -547,7 +547,7 @@ static int launch_main(sg_handle *h, int n_steps, int do_reset, int force, const
         HIP_TRY(h, hipGetLastError());
     }
     if (h->rss_fused) { // (launch_variant ran a rollout_kernel_rss* variant)
-        sg::rss_lines_kernel<<<dim3((unsigned)(h->NE / 64)), dim3(64), 0, h->stream>>>(h->p);
+        sg::rss_lines_kernel<<<tab_grid(h, tg), dim3(64), 0, h->stream>>>(h->p, tg);
         HIP_TRY(h, hipGetLastError());
     }
     if (!h->timing_now) return SG_OK;
@@ -615,7 +615,7 @@ static int launch_rollout(sg_handle *h, int n_steps, int do_reset, int force, co
             // interact); SG_TAB_SPLIT=1: one pipeline.
             const size_t nblk = h->NE / 64;
             int H = 1;
-            if (h->WV == 1 && !h->rss_fused && !riders && !no_overlap && h->n_pipes > 1 &&
+            if (h->WV == 1 && (!h->rss_fused || rss_tab) && !riders && !no_overlap && h->n_pipes > 1 &&
                 nblk >= (size_t)std::max(4, env_int("SG_TAB_SPLIT_MIN", 512))) {
                 H = h->n_pipes;
             }
@@ -624,7 +624,7 @@ static int launch_rollout(sg_handle *h, int n_steps, int do_reset, int force, co
             // the pre-pass in launches of ctl_slice steps (its load then moves between SIMDs) -- but the planar kernel's three
             // wavefronts (168 VGPRs each) leave it no room on a SIMD: with both pipelines keeping every slot taken, each of
             // its launches waits for a wavefront to retire, so there it is one launch per chunk
-            const int ctl_slice = (H > 1 && h->planar && SG_PLANAR_WAVES > 2 && !env_int("SG_CTL_SLICE", 0)) ? ch : h->ctl_slice;
+            const int ctl_slice = (H > 1 && ((h->planar && SG_PLANAR_WAVES > 2) || rss_tab) && !env_int("SG_CTL_SLICE", 0)) ? ch : h->ctl_slice;
             if (ch > h->p.tab_steps || (size_t)(h->p.tab_steps + 1) * row * sizeof(double) > h->tab_bytes || NB > h->n_tab) {
                 // grow: tab_steps + 1 rows per lane is part of the table addressing
                 const int ts = std::max(ch, h->p.tab_steps);

@@ -777,6 +777,57 @@ def test_controller_prepass_equals_inline_controllers(sga, ego_kind, terminal):
         assert bits_equal(t, t0) and bits_equal(poses, poses0)
 
 
+@pytest.mark.parametrize("E,ego_kind,zpr", [(64, "pid", False), (24, "vehicle", False), (12, "pid", False), (64, "pid", True), (30, "pid", True)])
+def test_rollout_pipelines_equal_one_pipeline(sga, monkeypatch, E, ego_kind, zpr):
+    """The table path runs large batches as two or three pipelines -- parts of the blocks as launches of their own on their
+    own streams, sharing the pre-pass tables through four buffers (launch_rollout) -- when the batch has at least
+    SG_TAB_SPLIT_MIN blocks; lowered here so that small batches take it too: one, two and three pipelines leave the same bits
+    (every recorded pose, final state, controller state, metrics, events), with many chunk boundaries (the buffers are
+    recycled several times), for the planar and the general table kernel, 64-lane and narrow tiles, rollouts and forced
+    steps with external actions, and a rollout continued in pieces."""
+    import scenario_gym_amd._lib as L
+    from scenario_gym_amd import synthetic
+
+    R, steps = 203, 150
+    kind = dict(pid=L.KIND_AGENT_PID, vehicle=L.KIND_AGENT_VEHICLE)[ego_kind]
+    packed = synthetic.make_batch(R, E, n_steps=steps, ego_kind=kind, static_frac=0.15, vanish_frac=0.2, extent=25.0 if E > 8 else 8.0)
+    if zpr:  # knots with z / pitch / roll: the general table kernel (rollout_kernel_tab<G>)
+        rng = np.random.default_rng(5)
+        packed.knots[:, 3] = rng.normal(0.0, 1.0, len(packed.knots))
+        packed.knots[:, 5] = rng.normal(0.0, 0.1, len(packed.knots))
+    acts = synthetic.make_actions(steps, R) if ego_kind == "vehicle" else None
+    monkeypatch.setenv("SG_TAB_SPLIT_MIN", "4")
+    runs, pipes, launches = [], [], []
+    for split in ("1", "2", "3"):
+        monkeypatch.setenv("SG_TAB_SPLIT", split)
+        runs.append(_engine_run(sga, packed, 1 / 30, steps, terminal=["max_length", "ego_collision"], actions=acts, ev_cap=128,
+                                tuning=dict(tab_min_steps=1, chunk_steps=16)))
+        # ... and continued in pieces
+        eng = sga.RolloutEngine(R, E, terminal_conditions=["max_length"], event_capacity=64)
+        eng.set_tuning(tab_min_steps=1, chunk_steps=16)
+        eng.upload(packed)
+        eng.rollout(40)
+        eng.rollout_async(70, do_reset=False)
+        eng.step(30)
+        pipes.append((eng.state(), eng.metrics()))
+        launches.append(eng.last_launch_stats()[0])
+        eng.close()
+    assert launches[2] > launches[0] and launches[1] > launches[0], launches  # the pipelines did run as launches of their own
+    st0, rows0, ev0, t0, poses0 = runs[0]
+    if acts is None:
+        assert (rows0["n_steps"] < steps).any() and (rows0["n_steps"] == steps).any()
+    for st, rows, ev, t, poses in runs[1:]:
+        for k in ("poses", "vels", "dists", "ctrl_state", "t", "prev_t"):
+            assert bits_equal(st[k], st0[k]), k
+        assert np.array_equal(st["coll"], st0["coll"]) and np.array_equal(st["present"], st0["present"])
+        assert rows.tobytes() == rows0.tobytes() and ev.tobytes() == ev0.tobytes()
+        assert bits_equal(t, t0) and bits_equal(poses, poses0)
+    for st, (rows, ev) in pipes[1:]:
+        for k in ("poses", "vels", "dists", "ctrl_state", "t", "prev_t"):
+            assert bits_equal(st[k], pipes[0][0][k]), k
+        assert rows.tobytes() == pipes[0][1][0].tobytes() and ev.tobytes() == pipes[0][1][1].tobytes()
+
+
 def test_prepass_resumes_from_the_state_blocks(sga):
     """A rollout that ends early followed by forced steps (gym.step on a done scenario), and a rollout continued in
     pieces: the controller pre-pass restarts from the device state at every call."""
