@@ -399,6 +399,12 @@ def test_register_budgets_of_the_two_kernel_path():
     for n, r in tabs.items():
         assert r["vgpr"] + r["agpr"] <= 192, (n, r)
     assert tabs["void sg::rollout_kernel_tab<64>"]["scratch"] == 0
+    # the planar variant (the headline's kernel): three wavefronts per SIMD = 168 VGPRs each
+    planar = {n: r for n, r in t.items() if "rollout_kernel_tab_planar<" in n}
+    assert len(planar) == 5
+    for n, r in planar.items():
+        assert r["vgpr"] + r["agpr"] <= 168, (n, r)
+    assert planar["void sg::rollout_kernel_tab_planar<64>"]["scratch"] <= 32
     ctl = t["sg::control_kernel"]
     assert ctl["vgpr"] + ctl["agpr"] <= 128 and ctl["scratch"] == 0
     crowd = t["void sg::rollout_kernel_crowd<4>"]
