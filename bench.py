@@ -120,7 +120,9 @@ def kernel_name(E, crowd, controlled, rss=False, mix=False):
     """Entry point the library launches for this shape (sgym_hip.hip launch_variant): tile lanes G, wavefronts per tile;
     `controlled`: the batch has PID / vehicle agents (their pre-pass table is replayed by rollout_kernel_tab)."""
     G, WV = min(64, max(4, 1 << (E - 1).bit_length())), (1 if E <= 64 else 2 if E <= 128 else 4)
-    if rss:
+    if rss:  # (controlled lanes on the pre-pass table: the variant without in-kernel controllers)
+        if WV == 1 and controlled and os.environ.get("SG_RSS_TAB", "1") != "0":
+            return f"sg::rollout_kernel_rss_tab<{G}>"
         return f"sg::rollout_kernel_rss<{G}, {WV}>"
     if crowd:
         if G == 64:  # (a crowd with riders -- lanes of other kinds on a pre-pass table -- has its own entry point)

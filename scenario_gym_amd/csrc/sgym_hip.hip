@@ -615,9 +615,12 @@ static int launch_rollout(sg_handle *h, int n_steps, int do_reset, int force, co
             // interact); SG_TAB_SPLIT=1: one pipeline.
             const size_t nblk = h->NE / 64;
             int H = 1;
-            if (h->WV == 1 && (!h->rss_fused || rss_tab) && !riders && !no_overlap && h->n_pipes > 1 &&
-                nblk >= (size_t)std::max(4, env_int("SG_TAB_SPLIT_MIN", 512))) {
-                H = h->n_pipes;
+            const size_t per_pipe = (size_t)std::max(1, env_int("SG_TAB_SPLIT_MIN", h->n_simd)); // blocks a pipeline should at least have
+            if (h->WV == 1 && (!h->rss_fused || rss_tab) && !riders && !no_overlap && h->n_pipes > 1 && nblk >= 2 * per_pipe) {
+                // (a batch that does not fill the slots is latency-bound either way, and more launches only cost: measured
+                // 512 blocks 16.2 / 16.7 / 15.8 G with 1 / 2 / 3 pipelines, 1024: 31.6 / 31.4 / 29.2, 2048: 54.4 / 60.8 / 56.9,
+                // 4096: 67 / 90 / 95, 8192: 87.5 / 99.8 / 100.7)
+                H = (int)std::min<size_t>((size_t)h->n_pipes, nblk / per_pipe);
             }
             const int gsz = (int)std::max<size_t>(1, (nblk + H - 1) / H);
             const int NB = H > 1 ? 4 : 2; // table buffers
