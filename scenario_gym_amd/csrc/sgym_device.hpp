@@ -3647,11 +3647,17 @@ __global__ __launch_bounds__(64 * WV, SG_WAVES_PER_SIMD_PED) void rollout_kernel
     rollout_body<G, WV, true, false, false, false, true>(p, timestep, n_steps, do_reset, force, actions, tab);
 }
 
-// The table variant with one wavefront per tile (C2 / C3 shapes) under a 192-VGPR cap: two of its wavefronts and one of
-// control_kernel (<= 128) fill the 512 VGPRs of a SIMD exactly, so the pre-pass of the next chunk is co-resident with
-// the rollout kernel instead of waiting for one of its wavefronts to retire.
+// The table variant with one wavefront per tile (C2 / C3 shapes) under a 168-VGPR cap: three wavefronts per SIMD.  A
+// wavefront of this kernel is latency-bound (1024 steps take 1.7 ms with one wavefront per SIMD, 2.3 ms with three), so the
+// third one is nearly free: 73.8 -> 91.7 G entity-steps/s on the C3 shape with z / pitch / roll knots, for 64 B of scratch.
+// (Rounds 1-2 held it at 192 so that two of its wavefronts and one of control_kernel (<= 128) filled a SIMD's 512 VGPRs;
+// the pre-pass now takes a wavefront slot of its own, one launch per chunk: launch_rollout.)
+#ifndef SG_TAB_WAVES // (experiment builds: -DSG_TAB_WAVES=2 -DSG_TAB_VGPR=96)
+#define SG_TAB_WAVES 3
+#define SG_TAB_VGPR 84
+#endif
 template <int G>
-__global__ __launch_bounds__(64, 2) __attribute__((amdgpu_num_vgpr(96))) void rollout_kernel_tab(
+__global__ __launch_bounds__(64, SG_TAB_WAVES) __attribute__((amdgpu_num_vgpr(SG_TAB_VGPR))) void rollout_kernel_tab(
     Params p, double timestep, int force, TabGroups tg)
 {
     int n_steps;

@@ -627,7 +627,7 @@ static int launch_rollout(sg_handle *h, int n_steps, int do_reset, int force, co
             // the pre-pass in launches of ctl_slice steps (its load then moves between SIMDs) -- but the planar kernel's three
             // wavefronts (168 VGPRs each) leave it no room on a SIMD: with both pipelines keeping every slot taken, each of
             // its launches waits for a wavefront to retire, so there it is one launch per chunk
-            const int ctl_slice = (H > 1 && ((h->planar && SG_PLANAR_WAVES > 2) || rss_tab) && !env_int("SG_CTL_SLICE", 0)) ? ch : h->ctl_slice;
+            const int ctl_slice = (H > 1 && ((h->planar ? SG_PLANAR_WAVES > 2 : SG_TAB_WAVES > 2) || rss_tab) && !env_int("SG_CTL_SLICE", 0)) ? ch : h->ctl_slice;
             if (ch > h->p.tab_steps || (size_t)(h->p.tab_steps + 1) * row * sizeof(double) > h->tab_bytes || NB > h->n_tab) {
                 // grow: tab_steps + 1 rows per lane is part of the table addressing
                 const int ts = std::max(ch, h->p.tab_steps);
