@@ -660,6 +660,7 @@ static int launch_rollout(sg_handle *h, int n_steps, int do_reset, int force, co
             }
             const dim3 cgrid((unsigned)(np / 64)), cblock(64);
             const bool rss_fast = env_int("SG_RSS_CTL_FAST", 1) != 0;
+            const bool tab_fast = H > 1 && !riders && !rss_tab && env_int("SG_TAB_CTL_FAST", 1) != 0;
             // chunks of the time axis: lengths double from two slices up to `ch` -- the rollout kernel cannot start before
             // the table of its chunk exists, and the pre-pass of the chunks after it (about 0.4x the rollout kernel's time
             // per step) then always finishes under the rollout kernel
@@ -687,6 +688,9 @@ static int launch_rollout(sg_handle *h, int n_steps, int do_reset, int force, co
                         else if (rss_tab && rss_fast) // (the ego's metrics are the rollout kernel's, from its own velocities)
                             sg::control_kernel_fast<<<cgrid, cblock, 0, cs>>>(h->p, h->cfg.timestep, ns, c == 0 && s0 == 0, k0 + s0,
                                                                               d_actions, tab, s0, 0);
+                        else if (tab_fast) // (pipelines: the pre-pass chain is the critical path -- its straight-line form)
+                            sg::control_kernel_fast<<<cgrid, cblock, 0, cs>>>(h->p, h->cfg.timestep, ns, c == 0 && s0 == 0, k0 + s0,
+                                                                              d_actions, tab, s0, 1);
                         else
                             sg::control_kernel<<<cgrid, cblock, 0, cs>>>(h->p, h->cfg.timestep, ns, c == 0 && s0 == 0, k0 + s0,
                                                                          d_actions, tab, s0, rss_tab ? 0 : 1);
