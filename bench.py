@@ -660,6 +660,11 @@ def main(argv=None, make_engine=None):
                 "secondary": secondary,
                 "kernel": (f"sg::rollout_kernel_slice{'_tab' if ego_kind == L.KIND_AGENT_PID else ''}<{min(64, max(4, 1 << (E - 1).bit_length()))}>" if wl.get("sliced") else
                            kernel_name(E, crowd, ego_kind == L.KIND_AGENT_PID, bool(wl.get("rss")), bool(wl.get("mix")))),
+                "note": ("frac > 1: the algorithmic bytes of SURVEY 8d (the step-materialised state, rewritten in place every step) "
+                         "never reach HBM -- they live in L2 / MALL (traffic_ratio) -- so the HBM figure is not the binding roof; "
+                         "`secondary` (vector-instruction issue) is.  kernel_ms = union of the launches' intervals / launches "
+                         "(launches of the rollout pipelines overlap); kernel_ms_gross = plain average launch duration, the figure "
+                         "rocprofv3 --kernel-trace --stats shows") if achieved / HBM_PEAK_GBS > 1.0 or gross_ms > 1.01 * avg_ms else None,
                 "kernel_ms": avg_ms, "kernel_ms_gross": gross_ms, "launch_overlap": gross_ms / avg_ms if avg_ms else None,
                 "launches_per_rollout": launches_per_rollout, "rollout_device_ms": rollout_ms,
                 "bytes_per_entity_step": b_alg, "entity_steps_per_launch": per_launch,
