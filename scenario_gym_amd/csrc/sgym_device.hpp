@@ -27,7 +27,7 @@
 #endif
 // controlled lanes per wavefront the table variant of the rollout kernel serves: one per scenario of the wavefront, at most 4
 #ifndef SG_CTL_WAVES
-#define SG_CTL_WAVES 4 // control_kernel: <= 128 VGPRs; two wavefronts of rollout_kernel_tab (<= 192 each) + one of these fill a SIMD's 512
+#define SG_CTL_WAVES 4 // control_kernel: <= 128 VGPRs (one of them beside two wavefronts of a table kernel, 168 each)
 #endif
 #ifndef SG_WAVES_PER_SIMD_PED
 #define SG_WAVES_PER_SIMD_PED 2 // pedestrian variant
@@ -1895,8 +1895,8 @@ __device__ __forceinline__ void tile_collisions(bool present, const double *pose
     }
 #endif
     } else {
-    // (vehicle scenes only come here with coordinates beyond 4000 cells; this form of the loop keeps rollout_kernel_tab
-    // inside the 192 registers its co-residency with control_kernel depends on)
+    // (vehicle scenes only come here with coordinates beyond 4000 cells; this form of the loop keeps the table kernels
+    // inside their register budget)
 #pragma unroll 4
     for (int jb = TS - 4; jb >= 0; jb -= 4) {
         v4f xs2 = xs1, ys2 = ys1; // two groups of four slots stay in flight
@@ -2476,9 +2476,8 @@ __device__ __forceinline__ Table lane_table(const Params &p, int kind, const Sce
 //
 // TAB: the PID / vehicle agents were integrated by control_kernel; their lanes read (x, y, h) per step from
 // its table `tab` instead of running the controller with 1 of 64 lanes active.  TAB launches never reset.
-// Register budgets: 2 wavefronts of the table variant (<= 192 VGPRs each) + 1 of control_kernel (<= 128) fill the 512
-// VGPRs of a SIMD exactly, so the pre-pass of the next chunk is co-resident instead of waiting for a rollout wavefront
-// to retire.
+// Register budget of the one-wavefront-per-tile entry points (rollout_kernel_tab / _tab_planar): 168 VGPRs, three
+// wavefronts per SIMD; the pre-pass takes a wavefront slot of its own (sgym_hip.hip, launch_rollout).
 // HAST (TAB only): the batch has controlled lanes, i.e. there is a table to replay; without it the table code is
 // compiled out (batches of replay entities only: the C2 shape).
 // ROAD: the ego_off_road terminal condition is compiled in (its own entry point, rollout_kernel_road: the other
@@ -3453,7 +3452,7 @@ __device__ __forceinline__ void rollout_body(
                                 }
                             }
                             if (!TAB) { // in-kernel controllers: the ego pose of the event goes along.  (Not in the table
-                                        // variant, which sits 1 VGPR under its 192 budget: its events are classified right
+                                        // variant, which has no register to spare: its events are classified right
                                         // after the launch, with the ego pose taken from the table row `reserved`.)
                                 double *ep = p.ev_pose + ((size_t)r * p.ev_cap + n_ev) * 3;
                                 ep[0] = pose[0]; ep[1] = pose[1]; ep[2] = pose[3];
@@ -3555,12 +3554,11 @@ __device__ __forceinline__ void rollout_body(
     }
 }
 
-// Block groups of a table-variant launch (launch_rollout): the 64-slot blocks of the batch are cut into up to 64 groups of
-// `gsz` consecutive blocks; a launch runs the groups of `active` only -- as many as fill the wavefront slots of the device
-// exactly once -- and every group reads the controller-table buffer (and runs the number of steps) of the chunk of the time
-// axis IT has reached: buffer index = 2 bits per group in `bufof`.  A batch that is not a whole number of "rounds" of the
-// device (4096 wavefronts on 3 x 1024 slots) then still runs as full rounds: the groups take turns sitting a launch out.
-// One group, active = 1: an ordinary launch.
+// The blocks a launch of a table variant works on (launch_rollout): the 64-slot blocks of the batch are cut into groups of
+// `gsz` consecutive blocks -- the host uses one group per rollout PIPELINE, two or three of them, each launched chunk after
+// chunk on its own stream -- and a launch runs the groups of `active` only; every group reads the controller-table buffer
+// (and runs the number of steps) of the chunk of the time axis IT has reached: buffer index = 2 bits per group in `bufof`.
+// One group, active = 1: an ordinary launch over all blocks.
 struct TabGroups {
     unsigned long long active, bufof[2];
     int gsz, n[4];
@@ -3879,8 +3877,8 @@ struct CtlLds { double ctrl[9][64]; double seg[5][64]; };
 // some lane spawns, crosses a knot, saturates its steering beyond the tangent polynomial's range or leaves RecipDiv's range
 // runs the general code below it.  Same operations on the same operands in the same order: same bits
 // (test_controller_prepass_equals_inline_controllers, SG_CTL_FAST=0 forces the general code).
-// FAST: compiled in for control_kernel_fast only (the time-sliced path, where the pre-pass is alone on the chip and has no
-// register budget to keep); control_kernel -- co-resident with the rollout kernel under 128 VGPRs -- stays as it was.
+// FAST: compiled in for control_kernel_fast only (151 VGPRs: the time-sliced path, the RSS table variant and the pipelined
+// table path, where the pre-pass chain is the critical path); control_kernel (<= 128 VGPRs) stays as it was.
 // RIDERS (control_kernel_riders, for rollout_kernel_crowd_riders): the lanes are ALL non-pedestrian entities of a crowd batch
 // -- replay entities (the scenario's union grid, presence rule of batch.py:45-52) and replay agents (own knots, clamped;
 // agent.py:125-128) beside the PID / vehicle agents -- and every row also gets plane 2 = z, pitch, roll, presence.

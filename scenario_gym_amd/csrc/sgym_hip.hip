@@ -562,7 +562,8 @@ static int launch_main(sg_handle *h, int n_steps, int do_reset, int force, const
 
 // ScenarioGym.rollout / n x step for the whole batch.  Scenarios without pedestrians and with at least
 // SG_TAB_MIN_STEPS steps to do take the two-kernel path: control_kernel integrates the PID / vehicle agents
-// for a chunk of steps on its own stream while rollout_kernel<TAB> consumes the previous chunk's table.
+// for a chunk of steps on its own stream while rollout_kernel<TAB> consumes the previous chunks' tables -- large batches as
+// two or three pipelines on streams of their own (below).
 static int launch_rollout(sg_handle *h, int n_steps, int do_reset, int force, const double *d_actions)
 {
     const int tab_min = h->tab_min, chunk_steps = std::max(1, h->chunk_steps), no_overlap = !h->overlap;

@@ -4,7 +4,7 @@
     python tools/kernel_resources.py [path/to/lib.so]       prints one line per kernel
     from tools.kernel_resources import table                 -> {demangled name: dict(vgpr, agpr, sgpr, lds, scratch)}
 
-(rollout_kernel_tab has to stay within 192 VGPRs and control_kernel within 128 for the two to be co-resident on a SIMD:
+(the table kernels of the rollout have to stay within 168 VGPRs -- three wavefronts per SIMD -- and control_kernel within 128:
 tests/test_host_api.py checks it on every build.)
 """
 import os
