@@ -96,6 +96,47 @@ class Trajectory:
         self._data = np.array(cols).T.copy()
         self._data.flags.writeable = False
 
+    @classmethod
+    def many(cls, datas):
+        """[Trajectory(d) for d in datas], with the usual case -- (n, 7) float64 vertices as the importers build them, t
+        strictly increasing, t / x / y / heading finite -- normalised for all trajectories of the same length at once (one
+        scenario file: tens of trajectories, a few numpy calls instead of ~15 per trajectory).  Same operations in the same
+        order per trajectory (np.diff, %, the select and cumsum run along the vertex axis): same bits as the constructor;
+        anything else (unsorted times, missing headings, other shapes) goes through the constructor."""
+        out = [None] * len(datas)
+        groups = {}
+        for i, d in enumerate(datas):
+            if isinstance(d, np.ndarray) and d.ndim == 2 and d.shape[1] == 7 and d.dtype == np.float64 and d.shape[0] > 1:
+                groups.setdefault(d.shape[0], []).append(i)
+            else:
+                out[i] = cls(d)
+        for n, idx in groups.items():
+            if len(idx) < 4:
+                for i in idx:
+                    out[i] = cls(datas[i])
+                continue
+            A = np.stack([datas[i] for i in idx])                          # [E, n, 7]
+            t = A[:, :, 0]
+            fin = np.isfinite(A).all(axis=1)                               # [E, 7]
+            ok = (t[:, 1:] > t[:, :-1]).all(axis=1) & fin[:, 0] & fin[:, 1] & fin[:, 2] & fin[:, 4]
+            B = A.copy()
+            for c in (3, 5, 6):
+                B[~fin[:, c], :, c] = 0.0
+            h = B[:, :, 4]
+            with np.errstate(invalid="ignore"):                            # (rows that are not ok are not used)
+                deltas = np.diff(h, axis=1) % (2 * np.pi)
+                deltas = np.where(deltas > np.pi, deltas - 2 * np.pi, deltas)
+                B[:, :, 4] = np.concatenate([h[:, :1], deltas], axis=1).cumsum(axis=1)
+            for k, i in enumerate(idx):
+                if ok[k]:
+                    tr = cls.__new__(cls)
+                    tr._data = B[k].copy()
+                    tr._data.flags.writeable = False
+                    out[i] = tr
+                else:
+                    out[i] = cls(datas[i])
+        return out
+
     # ------------------------------------------------------------------ container API
     @property
     def data(self):

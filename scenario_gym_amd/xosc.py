@@ -382,8 +382,9 @@ def import_scenario(osc_file: str, relabel: bool = True) -> Scenario:
     for ref, verts in scan["trajectories"]:
         if ref in entities and len(verts):
             last[ref] = (verts, True)
-    for ref, (data, fill) in last.items():
-        entities[ref].trajectory = Trajectory(_fill_elevation(data, road_network) if fill else data)
+    refs = list(last)
+    for ref, tr in zip(refs, Trajectory.many([_fill_elevation(last[r][0], road_network) if last[r][1] else last[r][0] for r in refs])):
+        entities[ref].trajectory = tr
     properties, actions = {}, []
     if b"<UserDefinedAction" in text or b"<Properties" in text[: text.find(b"<Entities")]:
         # (rare) header properties / user-defined actions: not part of the native scan

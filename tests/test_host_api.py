@@ -20,6 +20,40 @@ def test_trajectory_normalisation_matches_reference():
         assert not tr.data.flags.writeable
 
 
+def test_trajectory_many_equals_the_constructor():
+    """Trajectory.many (all trajectories of a scenario file normalised together, xosc.import_scenario) returns what the
+    constructor returns for each of them, bit for bit: equal and different lengths, single knots, unsorted and repeated times,
+    missing z / pitch / roll (whole columns or one value), missing or infinite headings (the finite-difference fill), wrapped
+    headings; and it raises what the constructor raises."""
+    from scenario_gym_amd.trajectory import Trajectory
+
+    rng = np.random.default_rng(3)
+    datas = []
+    for _ in range(400):
+        n = int(rng.choice([1, 2, 5, 40, 40, 40, 111, 111]))
+        t = np.sort(rng.uniform(0, 10, n)) if rng.random() < 0.9 else rng.uniform(0, 10, n)
+        d = np.column_stack([t, rng.normal(0, 50, n), rng.normal(0, 50, n), rng.normal(0, 1, n), rng.uniform(-10, 10, n),
+                             rng.normal(0, 0.1, n), rng.normal(0, 0.1, n)])
+        r = rng.random()
+        if r < 0.15:
+            d[:, 3] = np.nan
+        elif r < 0.25:
+            d[rng.integers(0, n), 5] = np.nan
+        elif r < 0.35:
+            d[:, 4] = np.nan
+        elif r < 0.4:
+            d[rng.integers(0, n), 4] = np.inf
+        if rng.random() < 0.05 and n > 2:
+            d[1, 0] = d[0, 0]
+        datas.append(d)
+    datas.append([[0.0, 1.0, 2.0, 0.0, 0.0, 0.0, 0.0]])  # (not an array: the constructor's own path)
+    for d, x in zip(datas, Trajectory.many(datas)):
+        y = Trajectory(d)
+        assert x.data.shape == y.data.shape and x.data.tobytes() == y.data.tobytes() and not x.data.flags.writeable
+    with pytest.raises(ValueError, match="Invalid values found for x"):
+        Trajectory.many([np.array([[0, np.nan, 0, 0, 0, 0, 0], [1, 1, 1, 0, 0, 0, 0.0]])] * 5)
+
+
 def test_trajectory_queries_match_reference():
     from scenario_gym_amd import Trajectory
 
