@@ -828,6 +828,34 @@ def test_rollout_pipelines_equal_one_pipeline(sga, monkeypatch, E, ego_kind, zpr
         assert rows.tobytes() == pipes[0][1][0].tobytes() and ev.tobytes() == pipes[0][1][1].tobytes()
 
 
+def test_launch_stats_count_overlapping_launches_once(sga, monkeypatch):
+    """sg_last_launch_stats reports the time during which at least one rollout launch ran (the union of the launches'
+    intervals), sg_last_launch_gross_ms the plain sum of their durations: equal with one pipeline, and with pipelines the sum
+    exceeds the union (their launches overlap) while the union stays within the device time of the whole call."""
+    import scenario_gym_amd._lib as L
+    from scenario_gym_amd import synthetic
+
+    R, E, steps = 1024, 64, 400
+    packed = synthetic.make_batch(R, E, n_steps=steps, ego_kind=L.KIND_AGENT_PID)
+    monkeypatch.setenv("SG_TAB_SPLIT_MIN", "64")
+    out = {}
+    for split in ("1", "3"):
+        monkeypatch.setenv("SG_TAB_SPLIT", split)
+        eng = sga.RolloutEngine(R, E)
+        eng.set_slicing(False)
+        eng.upload(packed)
+        eng.rollout(steps)
+        eng.rollout(steps)
+        n, net = eng.last_launch_stats()
+        out[split] = (n, net, eng.last_launch_gross_ms(), eng.last_kernel_ms())
+        eng.close()
+    n1, net1, gross1, call1 = out["1"]
+    n3, net3, gross3, call3 = out["3"]
+    assert n3 > n1 >= 1
+    assert abs(gross1 - net1) <= 1e-3 * gross1 and net1 <= call1 * 1.001
+    assert gross3 > 1.3 * net3 and net3 <= call3 * 1.001
+
+
 def test_prepass_resumes_from_the_state_blocks(sga):
     """A rollout that ends early followed by forced steps (gym.step on a done scenario), and a rollout continued in
     pieces: the controller pre-pass restarts from the device state at every call."""
