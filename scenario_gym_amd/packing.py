@@ -46,7 +46,10 @@ def pack_arrays(scenarios: Sequence[dict], kinds: Optional[Sequence[np.ndarray]]
             ctrl[r * E:r * E + Er] = ctrls[r]
         knot_off[r * E:r * E + Er + 1] = rows + off
         knot_off[r * E + Er + 1:(r + 1) * E + 1] = rows + off[-1]
-        chunks.append(np.asarray(s["knots"], np.float64)[: off[-1]])
+        if isinstance(s["knots"], list):  # per-entity arrays (pack_scenarios): they join the batch's one concatenation
+            chunks.extend(s["knots"])
+        else:
+            chunks.append(np.asarray(s["knots"], np.float64)[: off[-1]])
         rows += int(off[-1])
         ego[r], t0[r], length[r] = s["ego"], s["t0"], s["length"]
     knots = np.concatenate(chunks, axis=0) if chunks else np.zeros((0, 7))
@@ -115,7 +118,7 @@ def pack_scenarios(scenarios, create_agent=None):
         arrays.append(dict(
             route_off=np.concatenate([[0], np.cumsum([len(x) for x in routes])]).astype(np.int64),
             routes=np.concatenate(routes, axis=0) if any(len(x) for x in routes) else None,
-            knot_off=off, knots=np.concatenate([e.trajectory.data for e in ents], axis=0),
+            knot_off=off, knots=[e.trajectory.data for e in ents],
             bbox=np.array([[e.bounding_box.width, e.bounding_box.length, e.bounding_box.center_x,
                             e.bounding_box.center_y] for e in ents], np.float64),
             etype=np.array([catalog_type_code(e) for e in ents], np.int32), ego=ego,
