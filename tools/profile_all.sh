@@ -1,6 +1,9 @@
 #!/bin/bash
 # Usage (GPU box): bash tools/profile_all.sh <tag>   -- tools/profile_round.sh for every bench workload (c3 = <tag>_*, the others
-# <tag>_<workload>_*), + the upload and RSS timings.  ~15 minutes.  Copy gpurun_out/<tag>_* and gpurun_out/latest_* into profiles/.
+# <tag>_<workload>_*), + the upload and RSS timings, the launch timeline, the one-pipeline and general-table-kernel lines; then
+# the counter passes go where bench.py looks for them (profiles/latest_* in the box's copy of the tree) and the bench lines are
+# run again, so that they carry `traffic` and `secondary` of THESE sources.  ~17 minutes.  Copy gpurun_out/<tag>_* and
+# gpurun_out/latest_* into profiles/ (not the *_trace / *_pmc_* directories).
 tag=${1:-rXX}
 bash tools/profile_round.sh ${tag} --steps 5 --warmup 1
 bash tools/profile_round.sh ${tag}_c5 --workload c5 --steps 2 --warmup 1
@@ -15,4 +18,15 @@ for R in 512 1024 2048; do python3 bench.py --scenarios $R --steps 10 --warmup 2
 python3 tools/upload_time.py > gpurun_out/${tag}_upload_time.txt 2>&1
 python3 tools/rss_time.py > gpurun_out/${tag}_rss_time.txt 2>&1
 python3 bench.py --workload c5 --ped-noise device --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/${tag}_c5_noise_bench.json 2>/dev/null
+bash tools/timeline.sh > gpurun_out/${tag}_timeline.txt 2>&1
+cp gpurun_out/latest_* profiles/
+python3 bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
+python3 bench.py --workload c5 --steps 2 --warmup 1 > gpurun_out/${tag}_c5_bench.json 2>/dev/null
+python3 bench.py --workload c2 --steps 5 --warmup 1 > gpurun_out/${tag}_c2_bench.json 2>/dev/null
+python3 bench.py --workload c2s --steps 5 --warmup 1 > gpurun_out/${tag}_c2s_bench.json 2>/dev/null
+python3 bench.py --workload c3rss --steps 3 --warmup 1 > gpurun_out/${tag}_c3rss_bench.json 2>/dev/null
+python3 bench.py --workload c3s --steps 5 --warmup 1 > gpurun_out/${tag}_c3s_bench.json 2>/dev/null
+python3 bench.py --workload c5mix --steps 1 --warmup 1 > gpurun_out/${tag}_c5mix_bench.json 2>/dev/null
+SG_PLANAR=0 python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/${tag}_nonplanar_bench.json 2>/dev/null
+SG_TAB_SPLIT=1 python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/${tag}_one_pipeline_bench.json 2>/dev/null
 tail -3 gpurun_out/${tag}_upload_time.txt gpurun_out/${tag}_rss_time.txt
