@@ -256,10 +256,24 @@ __global__ void spin_kernel(long long ticks)
     while (wall_clock64() - t0 < ticks) {}
 }
 }
+static int probe_once(sg_handle *h, int want, int *found);
 static int probe_pipelines(sg_handle *h, int want)
 {
     h->n_pipes = 1;
     if (want < 2) return SG_OK;
+    // up to three attempts, the best one counts: the first launch on a stream may still be setting the stream up (queues are
+    // created on first use), and a process that starts beside seven others is not in a hurry
+    for (int attempt = 0; attempt < 3 && h->n_pipes < want; ++attempt) {
+        int found = 1;
+        int rc = probe_once(h, want, &found);
+        if (rc) return rc;
+        h->n_pipes = std::max(h->n_pipes, found);
+    }
+    return SG_OK;
+}
+static int probe_once(sg_handle *h, int want, int *found)
+{
+    *found = 1;
     hipStream_t st[4] = {h->stream, h->ctl_stream, h->xstream[0], h->xstream[1]};
     const int n = std::min(4, 1 + want);
     hipEvent_t a[4] = {}, b[4] = {};
@@ -284,7 +298,7 @@ static int probe_pipelines(sg_handle *h, int want)
     bool ok = together(0, 1);
     for (int j = 2; j < n && ok; ++j) { // pipeline j - 1 on xstream[j - 2]
         for (int i = 0; i < j && ok; ++i) ok = together(i, j);
-        if (ok) h->n_pipes = j;
+        if (ok) *found = j;
     }
     for (int i = 0; i < n; ++i) { (void)hipEventDestroy(a[i]); (void)hipEventDestroy(b[i]); }
     return SG_OK;
@@ -607,13 +621,13 @@ static int launch_rollout(sg_handle *h, int n_steps, int do_reset, int force, co
             int ch = (int)std::min<size_t>((size_t)chunk_steps, std::max<size_t>(1, ((size_t)1 << 27) / row));
             ch = std::min(ch, n_steps);
             if (rss_tab) ch = std::min(ch, std::max(1, h->rssq_steps)); // one launch fills at most the line-test queue
-            // Two pipelines (sgym_device.hpp, TabGroups).  A launch of the one-wavefront-per-tile table kernels is as slow as its
+            // Pipelines (sgym_device.hpp, TabGroups).  A launch of the one-wavefront-per-tile table kernels is as slow as its
             // slowest wavefront, and a batch is rarely a whole number of rounds of the device's wavefront slots (4096
-            // wavefronts on 3 x 1024): with one launch at a time the slots idle at every launch boundary.  So the two halves of
-            // the blocks run as launches of their own on two streams, each half chunk after chunk: whenever one half's launch
-            // drains, wavefronts of the other half's take the slots.  Both consume the same pre-pass tables (four buffers: the
-            // halves may be a chunk or two apart, the pre-pass ahead of both).  Results do not depend on it (scenarios never
-            // interact); SG_TAB_SPLIT=1: one pipeline.
+            // wavefronts on 3 x 1024): with one launch at a time the slots idle at every launch boundary.  So the blocks are
+            // cut into H = 2 or 3 contiguous parts that run as launches of their own on their own streams, each part chunk
+            // after chunk: whenever one part's launch drains, wavefronts of the others take the slots.  All consume the same
+            // pre-pass tables (four buffers: the parts may be a chunk or two apart, the pre-pass ahead of them).  Results do
+            // not depend on it (scenarios never interact); SG_TAB_SPLIT=1: one pipeline.
             const size_t nblk = h->NE / 64;
             int H = 1;
             const size_t per_pipe = (size_t)std::max(1, env_int("SG_TAB_SPLIT_MIN", h->n_simd)); // blocks a pipeline should at least have
@@ -626,7 +640,7 @@ static int launch_rollout(sg_handle *h, int n_steps, int do_reset, int force, co
             const int gsz = (int)std::max<size_t>(1, (nblk + H - 1) / H);
             const int NB = H > 1 ? 4 : 2; // table buffers
             // the pre-pass in launches of ctl_slice steps (its load then moves between SIMDs) -- but the planar kernel's three
-            // wavefronts (168 VGPRs each) leave it no room on a SIMD: with both pipelines keeping every slot taken, each of
+            // wavefronts (168 VGPRs each) leave it no room on a SIMD: with the pipelines keeping every slot taken, each of
             // its launches waits for a wavefront to retire, so there it is one launch per chunk
             const int ctl_slice = (H > 1 && ((h->planar ? SG_PLANAR_WAVES > 2 : SG_TAB_WAVES > 2) || rss_tab) && !env_int("SG_CTL_SLICE", 0)) ? ch : h->ctl_slice;
             if (ch > h->p.tab_steps || (size_t)(h->p.tab_steps + 1) * row * sizeof(double) > h->tab_bytes || NB > h->n_tab) {
