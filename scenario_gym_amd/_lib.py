@@ -89,7 +89,9 @@ def source_sha16() -> str:
     import hashlib
 
     h = hashlib.sha256()
-    for rel in ("csrc/sgym_device.hpp", "csrc/sgym_hip.hip", "../include/sgym.h"):
+    csrc = os.path.join(HERE, "csrc")
+    units = sorted(f for f in os.listdir(csrc) if f.endswith((".hpp", ".hip")))  # one object per kernel family (csrc/Makefile)
+    for rel in [os.path.join("csrc", f) for f in units] + ["../include/sgym.h"]:
         with open(os.path.join(HERE, rel), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]

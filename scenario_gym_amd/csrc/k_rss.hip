@@ -1,0 +1,14 @@
+// k_rss.hip -- the RSSDistances callback inside the rollout kernel, controllers in the kernel: rollout_kernel_rss<G, WV>,
+// and with the ego_off_road terminal condition rollout_kernel_rss_road<G, WV>.
+#include "sgym_launch.hpp"
+
+namespace sgl {
+void rollout_rss(int G, int WV, bool road, dim3 grid, hipStream_t s, const RolloutArgs &a)
+{
+#define CALL(G_, WV_)                                                                                                                \
+    if (road) sg::rollout_kernel_rss_road<G_, WV_><<<grid, dim3(64 * WV_), 0, s>>>(SGL_ARGS(a));                                     \
+    else sg::rollout_kernel_rss<G_, WV_><<<grid, dim3(64 * WV_), 0, s>>>(SGL_ARGS(a))
+    SGL_DISPATCH(G, WV, CALL);
+#undef CALL
+}
+} // namespace sgl

@@ -207,7 +207,7 @@ __device__ __noinline__ double2 sg_sincos_slow(double x)
 // The 16 fp64 coefficients live in constant memory and are fetched with scalar loads at the point of
 // use (the table pointer is made opaque once per time step), so they occupy SGPRs for a few dozen
 // instructions instead of 32 VGPRs for the whole kernel.
-__constant__ double SG_TRIG[32] = {
+static __constant__ double SG_TRIG[32] = {
     6.36619772367581382433e-01,  // 0 2/pi
     1.57079632673412561417e+00,  // 1 pi/2 head (33 bits)
     6.07710050630396597660e-11,  // 2 pi/2 next 33 bits
@@ -2090,7 +2090,7 @@ __device__ __forceinline__ void tile_collisions(bool present, const double *pose
 // BatchReplayEntity.add_entities stage 1 (entity/batch.py:83-109): resample every batch-replay
 // trajectory onto its scenario's union grid.  One thread per (grid row, entity slot).
 // ------------------------------------------------------------------------------------------------
-__global__ void build_grid_kernel(Params p, const int32_t *row_scen /*[totalN]*/, int64_t row0, int64_t row_end)
+static __global__ void build_grid_kernel(Params p, const int32_t *row_scen /*[totalN]*/, int64_t row0, int64_t row_end)
 {
     int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int64_t row = row0 + gid / p.EP; // grid rows [row0, row_end): sg_upload launches one range per chunk of the knot copy
@@ -2378,7 +2378,7 @@ struct RssQueue {
 };
 typedef __attribute__((address_space(3))) RssQueue *RssQueueLds;
 #ifdef SG_RSS_STATS
-__device__ unsigned long long sg_rss_stats[8]; // experiment builds: flushes, groups, items, passes, updates (per wavefront)
+static __device__ unsigned long long sg_rss_stats[8]; // experiment builds: flushes, groups, items, passes, updates (per wavefront)
 #define RSS_STAT(i, v) do { if ((threadIdx.x & 63) == 0) atomicAdd(&sg_rss_stats[i], (unsigned long long)(v)); } while (0)
 #else
 #define RSS_STAT(i, v) ((void)0)
@@ -3697,7 +3697,7 @@ __global__ __launch_bounds__(64, SG_WAVES_PER_SIMD_TAB) void rollout_kernel_slic
 
 // The clocks of a sliced replay: tt[c][j] = State.t after j steps = t0_c + dt + dt + ... (scenario_gym.py:229), the
 // additions of the step loop itself; scenarios with the same start time share a clock (launch_sliced).  One lane per clock.
-__global__ __launch_bounds__(64) void clock_kernel(const double *t0 /*[n_clocks]*/, int n_clocks, double timestep, int n_total, double *tt)
+static __global__ __launch_bounds__(64) void clock_kernel(const double *t0 /*[n_clocks]*/, int n_clocks, double timestep, int n_total, double *tt)
 {
     const int c = blockIdx.x * 64 + threadIdx.x;
     if (c >= n_clocks) return;
@@ -3716,7 +3716,7 @@ __global__ __launch_bounds__(64) void clock_kernel(const double *t0 /*[n_clocks]
 }
 
 // n_final[r] = the step at which scenario r became done (the first over its slices), else all n_total steps
-__global__ __launch_bounds__(64) void slice_final_kernel(Params p, SliceArgs sa, int *n_final, int *done_out)
+static __global__ __launch_bounds__(64) void slice_final_kernel(Params p, SliceArgs sa, int *n_final, int *done_out)
 {
     const int r = blockIdx.x * 64 + threadIdx.x;
     if (r >= p.R) return;
@@ -3777,7 +3777,7 @@ __global__ __launch_bounds__(64) void replay_fixup_kernel(Params p, SliceArgs sa
 }
 
 // (a controlled ego is no different here: the slices leave its speeds like a replay ego's, the pre-pass skips the metrics)
-__global__ __launch_bounds__(64) void replay_scenario_fixup_kernel(Params p, SliceArgs sa, const int *n_final, const int *done_in)
+static __global__ __launch_bounds__(64) void replay_scenario_fixup_kernel(Params p, SliceArgs sa, const int *n_final, const int *done_in)
 {
     const int lane = threadIdx.x;
     const int r = (int)blockIdx.x * 64 + lane;
@@ -4139,17 +4139,17 @@ __device__ __forceinline__ void control_body(const Params &p, double timestep, i
     cst[(CS_METRIC + 0) * NP] = m_avg; cst[(CS_METRIC + 1) * NP] = m_max; cst[(CS_METRIC + 2) * NP] = m_t;
 }
 
-__global__ __launch_bounds__(64, SG_CTL_WAVES) void control_kernel(Params p, double timestep, int n_steps, int first, int k0,
+static __global__ __launch_bounds__(64, SG_CTL_WAVES) void control_kernel(Params p, double timestep, int n_steps, int first, int k0,
                                                      const double *actions /*[n][R][2]*/, double *tab, int row0, int metrics)
 {
     control_body<false>(p, timestep, n_steps, first, k0, actions, tab, row0, metrics);
 }
-__global__ __launch_bounds__(64, 2) void control_kernel_riders(Params p, double timestep, int n_steps, int first, int k0,
+static __global__ __launch_bounds__(64, 2) void control_kernel_riders(Params p, double timestep, int n_steps, int first, int k0,
                                                                const double *actions /*[n][R][2]*/, double *tab, int row0, int metrics)
 {
     control_body<false, true>(p, timestep, n_steps, first, k0, actions, tab, row0, 0);
 }
-__global__ __launch_bounds__(64, 1) void control_kernel_fast(Params p, double timestep, int n_steps, int first, int k0,
+static __global__ __launch_bounds__(64, 1) void control_kernel_fast(Params p, double timestep, int n_steps, int first, int k0,
                                                              const double *actions /*[n][R][2]*/, double *tab, int row0, int metrics)
 {
     control_body<true>(p, timestep, n_steps, first, k0, actions, tab, row0, metrics);
@@ -4181,7 +4181,7 @@ __device__ __forceinline__ void own_position_clamped(const double *kn, int n, do
 // knots are chains of dependent loads: 10 samples one after the other per entity thread took 250 us for 4096 x 64).
 // Pass 1: the ego's corners at every sample time into LDS; pass 2: every other pair against them.
 #define SG_FUT_MAX_SAMPLES 64
-__global__ __launch_bounds__(256) void future_kernel(Params p, double horizon, int n_samples, unsigned char *out /*[R]*/)
+static __global__ __launch_bounds__(256) void future_kernel(Params p, double horizon, int n_samples, unsigned char *out /*[R]*/)
 {
     __shared__ double ego_c[SG_FUT_MAX_SAMPLES][8];
     const int r = blockIdx.x, tid = threadIdx.x;
@@ -4241,7 +4241,7 @@ __device__ __forceinline__ double sg_linspace_at(double start, double stop, int 
     return (double)j * step + start;
 }
 
-__global__ __launch_bounds__(256) void raster_kernel(Params p, double width, double height, int nw, int nh,
+static __global__ __launch_bounds__(256) void raster_kernel(Params p, double width, double height, int nw, int nh,
                                                      unsigned char *out /*[R][nh][nw] at stride bytes per scenario*/,
                                                      int64_t stride)
 {
@@ -4313,7 +4313,7 @@ __global__ __launch_bounds__(256) void raster_kernel(Params p, double width, dou
 
 // The road-surface layers of RasterizedMapSensor (sensor/map.py:194-271) on the same grid: one thread per grid point
 // looks its cell up once for all requested layers; out[r][k] for the layers[k] != 0 (the entity layer is raster_kernel's).
-__global__ __launch_bounds__(256) void raster_surface_kernel(Params p, RoadIndex R, double width, double height, int nw, int nh,
+static __global__ __launch_bounds__(256) void raster_surface_kernel(Params p, RoadIndex R, double width, double height, int nw, int nh,
                                                              int n_layers, const int32_t *layers,
                                                              unsigned char *out /*[R][n_layers][nh][nw]*/)
 {
@@ -4449,7 +4449,7 @@ __device__ inline int sg_classify_collision(const double *eb, double ex, double 
 // (type packed with k, the step inside the launch) take the controlled ego's pose at that step from the table row and become
 // ordinary pending events.  A few loads and stores per event; the classification itself waits for sg_read_metrics.
 // (`tg`: the block groups of that launch -- the scenario's group says which buffer its rows are in)
-__global__ __launch_bounds__(64) void event_ego_pose_kernel(Params p, TabGroups tg)
+static __global__ __launch_bounds__(64) void event_ego_pose_kernel(Params p, TabGroups tg)
 {
     const int r = blockIdx.x;
     const int n = min(p.sdyn[r].n_events, p.ev_cap);
@@ -4490,7 +4490,7 @@ __global__ __launch_bounds__(64) void event_ego_pose_kernel(Params p, TabGroups 
 
 // one thread per (scenario, event slot): pending events (-1) get their type, or -2 when the hazard's pose cannot be
 // re-evaluated.  Ego pose: its trajectory (replay agents), else the pose stored with the event.
-__global__ __launch_bounds__(64) void classify_events_kernel(Params p, double c_tol)
+static __global__ __launch_bounds__(64) void classify_events_kernel(Params p, double c_tol)
 {
     const int r = blockIdx.x;
     const ScenStatic &ss = p.sstat[r];
@@ -4550,7 +4550,7 @@ __global__ __launch_bounds__(64) void classify_events_kernel(Params p, double c_
 // 5 unsafe_longitudinal, 6 found, -1 not updated; safe [NE][2] = lateral, longitudinal
 // seen [R]: State.n_steps at the scenario's latest update -- a scenario that did not step since (it is done) is left alone,
 // as the reference stops calling the callback once its rollout loop has ended
-__global__ __launch_bounds__(256) void rss_kernel(Params p, int reset, int32_t *rss_state, int32_t *code, double *safe, int32_t *seen)
+static __global__ __launch_bounds__(256) void rss_kernel(Params p, int reset, int32_t *rss_state, int32_t *code, double *safe, int32_t *seen)
 {
     __shared__ double ego[8]; // x, y, heading, vx, vy, width, length, present
     const int r = blockIdx.x, e = threadIdx.x;
@@ -4590,7 +4590,7 @@ __global__ __launch_bounds__(256) void rss_kernel(Params p, int reset, int32_t *
 // The queued line tests of one rollout_kernel_rss launch (see RssQueue): block w = the queue of rollout wavefront w, whose
 // lane l carries entity index w * 64 + l.
 // (tg: the blocks of that launch -- one pipeline's part of the batch, launch_rollout; else all of them)
-__global__ __launch_bounds__(64) void rss_lines_kernel(Params p, TabGroups tg)
+static __global__ __launch_bounds__(64) void rss_lines_kernel(Params p, TabGroups tg)
 {
     __shared__ RssQueue q;
     const RssQueueLds ql = (RssQueueLds)&q;
@@ -4641,7 +4641,7 @@ __global__ __launch_bounds__(64) void rss_lines_kernel(Params p, TabGroups tg)
 // The observation of one RL tick in ONE launch (sg_tick): every requested map layer -- the entity layer of raster_kernel and
 // the surface layers of raster_surface_kernel, same arithmetic, the grid point computed once -- and the terminal flags of
 // terminal_flags_kernel.  One workgroup per scenario.  has_road: road networks are set (else the surface layers are empty).
-__global__ __launch_bounds__(256) void observe_kernel(Params p, RoadIndex R, int has_road, double width, double height, int nw,
+static __global__ __launch_bounds__(256) void observe_kernel(Params p, RoadIndex R, int has_road, double width, double height, int nw,
                                                       int nh, int n_layers, const int32_t *layers,
                                                       unsigned char *out /*[R][n_layers][nh][nw]*/, uint32_t *flags /*[R]*/)
 {
@@ -4735,7 +4735,7 @@ __global__ __launch_bounds__(256) void observe_kernel(Params p, RoadIndex R, int
 // TERMINAL_CONDITIONS (state/state.py:397-408), all four evaluated on the CURRENT state of every scenario, whatever the
 // handle's terminal mask says: out[r] = SG_TERM_* bits.  The reward of the reference's RL agent asks exactly this of a
 // done state (integrations/openaigym.py:300-310).  One wavefront per scenario.
-__global__ __launch_bounds__(64) void terminal_flags_kernel(Params p, double timestep, uint32_t *out)
+static __global__ __launch_bounds__(64) void terminal_flags_kernel(Params p, double timestep, uint32_t *out)
 {
     const int r = blockIdx.x, lane = threadIdx.x;
     const sg_scenario_state &sd = p.sdyn[r];
@@ -4772,7 +4772,7 @@ __global__ __launch_bounds__(64) void terminal_flags_kernel(Params p, double tim
 }
 
 // sg_debug_trig32: the broad phase's hardware sin/cos, exposed so that the parity tests can bound its error
-__global__ void trig32_kernel(const double *h, float *s, float *c, int64_t n)
+static __global__ void trig32_kernel(const double *h, float *s, float *c, int64_t n)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) sg_sincos_f32(h[i], s[i], c[i]);

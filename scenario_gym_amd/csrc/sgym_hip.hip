@@ -17,7 +17,7 @@
 #include <thread>
 #include <vector>
 
-#include "sgym_device.hpp"
+#include "sgym_launch.hpp"
 
 using sg::Params;
 
@@ -480,42 +480,42 @@ static dim3 tab_grid(const sg_handle *h, const sg::TabGroups &tg)
     return dim3((unsigned)std::min<size_t>(h->NE / 64, (size_t)tg.len0 + tg.len1));
 }
 
-template <int G, int WV>
+// the rollout kernel family of this handle's batch (launchers: sgym_launch.hpp, one object per family)
 static void launch_variant(sg_handle *h, dim3 grid, int n_steps, int do_reset, int force, const double *d_actions,
                            const double *d_tab, bool use_tab, const sg::TabGroups &tg)
 {
-    dim3 block(64 * WV);
+    const int G = h->G, WV = h->WV;
+    const hipStream_t s = h->stream;
+    const sgl::RolloutArgs a{&h->p, h->cfg.timestep, n_steps, do_reset, force, d_actions, nullptr};
+    const sgl::RolloutArgs at{&h->p, h->cfg.timestep, n_steps, 0, force, nullptr, d_tab}; // table variants never reset
 #ifdef SG_ONLY_CROWD // experiment builds (tools/ab_build.sh): only the crowd variant is compiled
-    sg::rollout_kernel_crowd<WV><<<grid, block, 0, h->stream>>>(h->p, h->cfg.timestep, n_steps, do_reset, force, d_actions, nullptr);
+    sgl::rollout_crowd(WV, false, grid, s, a);
     return;
 #endif
-    if (h->has_ped && h->all_ped && G == 64 && !h->has_road && h->crowd_kernel && !h->rss_fused)
-        sg::rollout_kernel_crowd<WV><<<grid, block, 0, h->stream>>>(h->p, h->cfg.timestep, n_steps, do_reset, force, d_actions, nullptr);
+    if (WV == 8) // 257..512 entities: vehicles and replay only (launch_rollout never takes the table path at this width)
+        sgl::rollout_plain(64, 8, false, grid, s, a);
+    else if (h->has_ped && h->all_ped && G == 64 && !h->has_road && h->crowd_kernel && !h->rss_fused)
+        sgl::rollout_crowd(WV, false, grid, s, a);
     else if (use_tab && h->has_ped && G == 64) // (launch_rollout: a crowd with riders, their table is d_tab)
-        sg::rollout_kernel_crowd_riders<WV><<<grid, block, 0, h->stream>>>(h->p, h->cfg.timestep, n_steps, 0, force, nullptr, d_tab);
+        sgl::rollout_crowd(WV, true, grid, s, at);
     else if (h->has_ped && h->rss_fused)
-        sg::rollout_kernel_rss_ped<(WV > 1 || G >= 16) ? G : 16, WV><<<grid, block, 0, h->stream>>>(h->p, h->cfg.timestep, n_steps, do_reset, force, d_actions, nullptr);
+        sgl::rollout_ped(G, WV, true, grid, s, a);
     else if (h->rss_fused && (h->cfg.terminal_mask & SG_TERM_EGO_OFF_ROAD))
-        sg::rollout_kernel_rss_road<G, WV><<<grid, block, 0, h->stream>>>(h->p, h->cfg.timestep, n_steps, do_reset, force, d_actions, nullptr);
+        sgl::rollout_rss(G, WV, true, grid, s, a);
     else if (h->has_ped)
-        sg::rollout_kernel<(WV > 1 || G >= 16) ? G : 16, WV, true, false><<<grid, block, 0, h->stream>>>(
-            h->p, h->cfg.timestep, n_steps, do_reset, force, d_actions, nullptr);
+        sgl::rollout_ped(G, WV, false, grid, s, a);
     else if (h->rss_fused && use_tab && WV == 1) // (launch_rollout: the controlled lanes' poses come from the pre-pass table)
-        sg::rollout_kernel_rss_tab<G><<<tab_grid(h, tg), block, 0, h->stream>>>(h->p, h->cfg.timestep, force, tg);
+        sgl::rollout_rss_tab(G, tab_grid(h, tg), s, h->p, h->cfg.timestep, force, tg);
     else if (h->rss_fused)
-        sg::rollout_kernel_rss<G, WV><<<grid, block, 0, h->stream>>>(h->p, h->cfg.timestep, n_steps, do_reset, force, d_actions, nullptr);
+        sgl::rollout_rss(G, WV, false, grid, s, a);
     else if (h->cfg.terminal_mask & SG_TERM_EGO_OFF_ROAD)
-        sg::rollout_kernel_road<G, WV><<<grid, block, 0, h->stream>>>(h->p, h->cfg.timestep, n_steps, do_reset, force, d_actions, nullptr);
-    else if (use_tab && WV == 1 && h->n_ctl > 0 && h->planar)
-        sg::rollout_kernel_tab_planar<G><<<tab_grid(h, tg), block, 0, h->stream>>>(h->p, h->cfg.timestep, force, tg);
+        sgl::rollout_road(G, WV, grid, s, a);
     else if (use_tab && WV == 1 && h->n_ctl > 0)
-        sg::rollout_kernel_tab<G><<<tab_grid(h, tg), block, 0, h->stream>>>(h->p, h->cfg.timestep, force, tg);
+        sgl::rollout_tab(G, h->planar, tab_grid(h, tg), s, h->p, h->cfg.timestep, force, tg);
     else if (use_tab)
-        sg::rollout_kernel<G, WV, false, true><<<grid, block, 0, h->stream>>>(h->p, h->cfg.timestep, n_steps, 0, force,
-                                                                               nullptr, d_tab);
+        sgl::rollout_plain(G, WV, true, grid, s, at);
     else
-        sg::rollout_kernel<G, WV, false, false><<<grid, block, 0, h->stream>>>(h->p, h->cfg.timestep, n_steps, do_reset,
-                                                                                force, d_actions, nullptr);
+        sgl::rollout_plain(G, WV, false, grid, s, a);
 }
 
 static int get_event(sg_handle *h, size_t idx, hipEvent_t *out)
@@ -542,17 +542,7 @@ static int launch_main(sg_handle *h, int n_steps, int do_reset, int force, const
         if ((rc = get_event(h, *ev_next, &e0)) || (rc = get_event(h, *ev_next + 1, &e1))) return rc;
         HIP_TRY(h, hipEventRecord(e0, h->stream));
     }
-    if (h->WV == 8) // (launch_rollout never takes the table path at this width)
-        sg::rollout_kernel<64, 8, false, false><<<grid, dim3(512), 0, h->stream>>>(h->p, h->cfg.timestep, n_steps, do_reset, force, d_actions, nullptr);
-    else if (h->WV == 4) launch_variant<64, 4>(h, grid, n_steps, do_reset, force, d_actions, d_tab, use_tab, tg);
-    else if (h->WV == 2) launch_variant<64, 2>(h, grid, n_steps, do_reset, force, d_actions, d_tab, use_tab, tg);
-    else switch (h->G) {
-    case 4: launch_variant<4, 1>(h, grid, n_steps, do_reset, force, d_actions, d_tab, use_tab, tg); break;
-    case 8: launch_variant<8, 1>(h, grid, n_steps, do_reset, force, d_actions, d_tab, use_tab, tg); break;
-    case 16: launch_variant<16, 1>(h, grid, n_steps, do_reset, force, d_actions, d_tab, use_tab, tg); break;
-    case 32: launch_variant<32, 1>(h, grid, n_steps, do_reset, force, d_actions, d_tab, use_tab, tg); break;
-    default: launch_variant<64, 1>(h, grid, n_steps, do_reset, force, d_actions, d_tab, use_tab, tg); break;
-    }
+    launch_variant(h, grid, n_steps, do_reset, force, d_actions, d_tab, use_tab, tg);
     HIP_TRY(h, hipGetLastError());
     if (use_tab && d_tab && h->n_ctl > 0 && h->p.ev_cap > 0 && n_steps > 0) {
         // a controlled ego's pose at an event of this chunk is a row of the chunk's controller table: copied into the event
@@ -561,7 +551,7 @@ static int launch_main(sg_handle *h, int n_steps, int do_reset, int force, const
         HIP_TRY(h, hipGetLastError());
     }
     if (h->rss_fused) { // (launch_variant ran a rollout_kernel_rss* variant)
-        sg::rss_lines_kernel<<<tab_grid(h, tg), dim3(64), 0, h->stream>>>(h->p, tg);
+        sgl::rss_lines(tab_grid(h, tg), h->stream, h->p, tg);
         HIP_TRY(h, hipGetLastError());
     }
     if (!h->timing_now) return SG_OK;
@@ -673,7 +663,7 @@ static int launch_rollout(sg_handle *h, int n_steps, int do_reset, int force, co
                 HIP_TRY(h, hipStreamWaitEvent(cs, e, 0));
                 for (int j = 1; j < H; ++j) HIP_TRY(h, hipStreamWaitEvent(h->xstream[j - 1], e, 0));
             }
-            const dim3 cgrid((unsigned)(np / 64)), cblock(64);
+            const dim3 cgrid((unsigned)(np / 64));
             const bool rss_fast = env_int("SG_RSS_CTL_FAST", 1) != 0;
             const bool tab_fast = H > 1 && !riders && !rss_tab && env_int("SG_TAB_CTL_FAST", 1) != 0;
             // chunks of the time axis: lengths double from two slices up to `ch` -- the rollout kernel cannot start before
@@ -698,17 +688,14 @@ static int launch_rollout(sg_handle *h, int n_steps, int do_reset, int force, co
                     for (int s0 = 0; s0 < n; s0 += ctl_slice) {
                         const int ns = std::min(ctl_slice, n - s0);
                         if (riders)
-                            sg::control_kernel_riders<<<cgrid, cblock, 0, cs>>>(h->p, h->cfg.timestep, ns, c == 0 && s0 == 0, k0 + s0,
-                                                                                d_actions, tab, s0, 0);
+                            sgl::control(sgl::CTL_RIDERS, cgrid, cs, h->p, h->cfg.timestep, ns, c == 0 && s0 == 0, k0 + s0, d_actions, tab, s0, 0);
                         else if (rss_tab && rss_fast) // (the ego's metrics are the rollout kernel's, from its own velocities)
-                            sg::control_kernel_fast<<<cgrid, cblock, 0, cs>>>(h->p, h->cfg.timestep, ns, c == 0 && s0 == 0, k0 + s0,
-                                                                              d_actions, tab, s0, 0);
+                            sgl::control(sgl::CTL_FAST, cgrid, cs, h->p, h->cfg.timestep, ns, c == 0 && s0 == 0, k0 + s0, d_actions, tab, s0, 0);
                         else if (tab_fast) // (pipelines: the pre-pass chain is the critical path -- its straight-line form)
-                            sg::control_kernel_fast<<<cgrid, cblock, 0, cs>>>(h->p, h->cfg.timestep, ns, c == 0 && s0 == 0, k0 + s0,
-                                                                              d_actions, tab, s0, 1);
+                            sgl::control(sgl::CTL_FAST, cgrid, cs, h->p, h->cfg.timestep, ns, c == 0 && s0 == 0, k0 + s0, d_actions, tab, s0, 1);
                         else
-                            sg::control_kernel<<<cgrid, cblock, 0, cs>>>(h->p, h->cfg.timestep, ns, c == 0 && s0 == 0, k0 + s0,
-                                                                         d_actions, tab, s0, rss_tab ? 0 : 1);
+                            sgl::control(sgl::CTL_GENERAL, cgrid, cs, h->p, h->cfg.timestep, ns, c == 0 && s0 == 0, k0 + s0, d_actions, tab, s0,
+                                         rss_tab ? 0 : 1);
                     }
                     HIP_TRY(h, hipGetLastError());
                     if (!no_overlap) {
@@ -754,21 +741,9 @@ static int launch_rollout(sg_handle *h, int n_steps, int do_reset, int force, co
 // the whole call, running ahead of the slices group by group.  Worth it when the batch alone cannot fill the chip (BASELINE
 // config 2: 64 wavefronts; config 4's shards: 512); the results are bit-identical to launch_rollout's, the intermediate
 // states are not written anywhere.
-template <int G>
 static void launch_slice_kernels(sg_handle *h, const Params &ps, const sg::SliceArgs &sa, dim3 grid, const double *tab)
 {
-    if (tab) sg::rollout_kernel_slice_tab<G><<<grid, dim3(64), 0, h->stream>>>(ps, h->cfg.timestep, sa, tab);
-    else sg::rollout_kernel_slice<G><<<grid, dim3(64), 0, h->stream>>>(ps, h->cfg.timestep, sa);
-}
-static void launch_slice_kernels(sg_handle *h, const Params &ps, const sg::SliceArgs &sa, dim3 grid, const double *tab)
-{
-    switch (h->G) {
-    case 4: launch_slice_kernels<4>(h, ps, sa, grid, tab); break;
-    case 8: launch_slice_kernels<8>(h, ps, sa, grid, tab); break;
-    case 16: launch_slice_kernels<16>(h, ps, sa, grid, tab); break;
-    case 32: launch_slice_kernels<32>(h, ps, sa, grid, tab); break;
-    default: launch_slice_kernels<64>(h, ps, sa, grid, tab); break;
-    }
+    sgl::rollout_slice(h->G, grid, h->stream, ps, h->cfg.timestep, sa, tab);
 }
 static void launch_fixup_kernel(sg_handle *h, const Params &ps, const sg::SliceArgs &sa)
 {
@@ -895,10 +870,9 @@ static int launch_sliced(sg_handle *h, int n_steps)
         const int ns = std::min(pl.SG, S - s0);
         if (ctl) { // rows (s0 * len, (s0 + ns) * len] of the table, then the event the group waits for
             const int k0 = s0 * len, k1 = std::min(n_steps, (s0 + ns) * len);
-            const dim3 cgrid((unsigned)(ps.n_ctl_pad / 64)), cblock(64);
+            const dim3 cgrid((unsigned)(ps.n_ctl_pad / 64));
             for (int k = k0; k < k1; k += ctl_len)
-                sg::control_kernel_fast<<<cgrid, cblock, 0, h->ctl_stream>>>(ps, h->cfg.timestep, std::min(ctl_len, k1 - k), k == 0, k, nullptr,
-                                                                        h->d_slice_tab, k, 0);
+                sgl::control(sgl::CTL_FAST, cgrid, h->ctl_stream, ps, h->cfg.timestep, std::min(ctl_len, k1 - k), k == 0, k, nullptr, h->d_slice_tab, k, 0);
             HIP_TRY(h, hipGetLastError());
             hipEvent_t e_c = nullptr;
             if ((rc = get_event(h, ev_next++, &e_c))) return rc;

@@ -20,11 +20,20 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 def table(lib=None):
     lib = lib or os.path.join(ROOT, "scenario_gym_amd", "lib", "libsgym_hip.so")
     with tempfile.TemporaryDirectory() as d:
-        fat, co = os.path.join(d, "fat.bin"), os.path.join(d, "dev.co")
+        fat = os.path.join(d, "fat.bin")
         subprocess.check_call([f"{LLVM}/llvm-objcopy", "--dump-section", f".hip_fatbin={fat}", lib, os.path.join(d, "x.so")])
-        subprocess.check_call([f"{LLVM}/clang-offload-bundler", "--unbundle", "--type=o", f"--input={fat}",
-                               "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"])
-        notes = subprocess.run([f"{LLVM}/llvm-readelf", "--notes", co], capture_output=True, text=True, check=True).stdout
+        # one offload bundle per object the library was linked from (csrc/Makefile: one object per kernel family)
+        blob = open(fat, "rb").read()
+        magic = b"__CLANG_OFFLOAD_BUNDLE__"
+        starts = [m.start() for m in re.finditer(re.escape(magic), blob)]
+        notes = ""
+        for i, a in enumerate(starts):
+            part, co = os.path.join(d, f"fat{i}.bin"), os.path.join(d, f"dev{i}.co")
+            with open(part, "wb") as f:
+                f.write(blob[a:starts[i + 1] if i + 1 < len(starts) else len(blob)])
+            subprocess.check_call([f"{LLVM}/clang-offload-bundler", "--unbundle", "--type=o", f"--input={part}",
+                                   "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"])
+            notes += subprocess.run([f"{LLVM}/llvm-readelf", "--notes", co], capture_output=True, text=True, check=True).stdout
     rows = {}
     for k in notes.split("  - .agpr_count")[1:]:
         g = lambda key: int(re.search(r"\.%s:\s+(\d+)" % key, k).group(1))
