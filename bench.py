@@ -26,6 +26,11 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# fp64 vector ALU: 256 CUs x 4 SIMDs x 16 lanes x 2 (fma) x 2.4 GHz (AMD's datasheet figure for MI355X; the
+# live figure of tools/valu_peak.hip is reported beside it)
+FP64_VALU_PEAK_TFLOPS = 78.6
+# whose counted algorithmic flops (profiles/flops_<key>.json, tools/count_flops.py) a workload is priced with
+FLOPS_OF = {"c3": "c3", "c3s": "c3", "c2": "c2", "c2s": "c2", "c5": "c5", "c5mix": "c5", "c3rss": "c3"}
 # BASELINE.json configs: scenarios, entities; algorithmic bytes per entity-step (pose 48 + velocity 48 +
 # distance 8 + collision row 8 x words + knots 2 [+ force 16]); bytes the kernel actually stores per steady entity-step
 # (unchanged z / pitch / roll rows are not stored again: x, y, h of pose and velocity, distance,
@@ -101,18 +106,28 @@ def cpu_baseline(workload, seconds_budget=20.0):
                   f"{cores} threads (= the CPUs the cgroup quota grants of {os.cpu_count()} logical), C oracle "
                   f"(oracle/sgym_oracle.c), {dt:.1f}s",
     }
-    ref = os.path.join(ROOT, "profiles", "reference_cpu.json")
-    if os.path.exists(ref):  # the real reference cannot travel to the GPU box: its number from the build container
-        with open(ref) as f:
+    # the real reference cannot travel to the GPU box: its numbers from the build container (tools/time_reference.py)
+    refs = {}
+    for key, name in (("reference", "reference_cpu_c3.json"), ("reference_default_agents", "reference_cpu.json")):
+        path = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(path):
+            continue
+        with open(path) as f:
             r = json.load(f)
-        out["reference"] = {
+        refs[key] = {
             "value": r["entity_steps_per_s_box"], "per_core": r["entity_steps_per_s_per_core"], "cores": r["processes"],
-            "unit": "entity-steps/s",
-            "note": f"driskai/scenario_gym v0.3.1 itself, E = {r['entities']}, T = {r['sim_steps']} steps (its per-step cost grows with the "
-                    "step index -- sensor/common.py:46-50 rebuilds the recorded poses every step -- so a 10,000-step rollout is "
-                    "slower per step than this), default agents + 3 ego metrics, NO collision detection: conditions that flatter "
-                    "it; timed in the build container (tools/time_reference.py, profiles/reference_cpu.json)",
+            "unit": "entity-steps/s", "config": r.get("config", "other"), "ego": r.get("ego", "replay"),
+            "entities": r["entities"], "sim_steps": r["sim_steps"], "scenarios_per_process": r["scenarios_per_process"],
+            "collision_metric": bool(r.get("collision_metric", False)),
+            "note": f"driskai/scenario_gym v0.3.1 itself, imported with stand-ins for the absent lxml / shapely; "
+                    f"{r['processes']} single-threaded processes x {r['scenarios_per_process']} scenarios x {r['entities']} entities x "
+                    f"{r['sim_steps']} steps, ego = {r.get('ego', 'replay')}, 3 ego metrics, no CollisionMetric (GEOS is absent; the "
+                    f"stand-in's exact-rational SAT says nothing about it); timed in the 8-core build container "
+                    f"(tools/time_reference.py, profiles/{name})",
         }
+    if workload.get("crowd") or rss:  # (the reference was timed on the c3 / default-agent vehicle batches only)
+        refs = {k + "_c3_batch": v for k, v in refs.items()}
+    out.update(refs)
     return out
 
 
@@ -148,6 +163,22 @@ def committed_profile(workload, kind, R, E, T=None):
         return None
     if rec.get("src_sha16") != L.source_sha16():
         return None
+    return rec
+
+
+def counted_flops(workload, E, T):
+    """profiles/flops_<key>.json (tools/count_flops.py: the counter build of the CPU oracle over scenarios of this very
+    batch, full horizon), or None when it was counted on another shape."""
+    key = FLOPS_OF.get(workload)
+    path = os.path.join(ROOT, "profiles", f"flops_{key}.json") if key else None
+    if not path or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        rec = json.load(f)
+    if (rec.get("entities"), rec.get("sim_steps")) != (E, T):
+        return None
+    rec["file"] = f"profiles/flops_{key}.json"
+    rec["exact"] = key == workload or (workload, key) in (("c3s", "c3"), ("c2s", "c2"))
     return rec
 
 
@@ -528,6 +559,7 @@ def main(argv=None, make_engine=None):
         return v
 
     def measure(R, sliced=None):
+        pipes = []
         first = rank * R  # rank r owns scenarios [r R, (r + 1) R) of the seeded family (chunk-aligned: R % 64 == 0 or 1 rank)
         eng = make_engine(R, first) if sliced is None else make_engine(R, first, sliced)
 
@@ -541,6 +573,7 @@ def main(argv=None, make_engine=None):
                                    axis=1), dist)
             n_launch, launch_ms = eng.last_launch_stats()
             gross = eng.last_launch_gross_ms() if hasattr(eng, "last_launch_gross_ms") else launch_ms
+            pipes.append(eng.pipeline_info() if hasattr(eng, "pipeline_info") else None)
             return int(rows["n_steps"].sum()) * E, (eng.last_kernel_ms(), n_launch, launch_ms, gross)
 
         elapsed, ent_steps, stats = timed_passes(one_pass, args.steps, args.warmup, dist, sync)
@@ -552,7 +585,12 @@ def main(argv=None, make_engine=None):
         if ver is not None and dist is not None:  # every rank checks scenarios of its own shard
             ver["equal"] = D.sum_over_ranks(0.0 if ver["equal"] else 1.0, dist) == 0.0
             ver["scenarios"] = int(D.sum_over_ranks(float(ver["scenarios"]), dist))
-        return dict(elapsed=worst, total=total, per_rank=per_rank, ent_steps=ent_steps, stats=stats, R=R, verified=ver)
+        # every rank's launch schedule to rank 0: [pipelines found by the probe, pipelines the timed passes ran (min), blocks, SIMDs]
+        pi = pipes[-1] if pipes and pipes[-1] else None
+        sched = D.gather_rows(np.array([[pi["found"], min(q["used_last_call"] for q in pipes), pi["blocks"], pi["simds"],
+                                         pi["wanted"], pi["hw_queues"], float(pi["pinned"])]] if pi else [[0.0] * 7], np.float64), dist)
+        return dict(elapsed=worst, total=total, per_rank=per_rank, ent_steps=ent_steps, stats=stats, R=R, verified=ver,
+                    sched=None if sched is None else sched.tolist())
 
     main_run = measure(shapes[args.scaling])
     other_run = None
@@ -613,6 +651,70 @@ def main(argv=None, make_engine=None):
             secondary = {"bound": "valu_issue", "unit": "wavefront-instructions/s", "peak": peak["instr_per_s"],
                          "achieved": None, "frac": None, "peak_fp64_tflops": peak["fp64_tflops"],
                          "note": "no committed SQ profile of these kernel sources on this shape (profiles/latest_*_pmc_sq.json)"}
+        kname = (f"sg::rollout_kernel_slice{'_tab' if ego_kind == L.KIND_AGENT_PID else ''}<{min(64, max(4, 1 << (E - 1).bit_length()))}>" if wl.get("sliced") else
+                 kernel_name(E, crowd, ego_kind == L.KIND_AGENT_PID, bool(wl.get("rss")), bool(wl.get("mix"))))
+        # The contract's HBM model (the step-materialised state as compulsory writes) does not bind this design: the
+        # rows are rewritten in place every step and live in L2, so it can pass 1.  Kept as a secondary figure.
+        hbm_contract = {
+            "bound": "hbm", "unit": "GB/s", "achieved": achieved, "peak": HBM_PEAK_GBS, "frac": achieved / HBM_PEAK_GBS,
+            "bytes_per_entity_step": b_alg, "stored_bytes_per_entity_step": wl["stored"], "traffic": traffic,
+            "traffic_ratio": (traffic / (per_launch * b_alg)) if traffic else None,
+            "note": "SURVEY 8d's algorithmic bytes x entity-steps per launch / kernel_ms over the 8 TB/s HBM peak.  NOT the binding "
+                    "roof: the state rows are overwritten in place every step and stay in L2 / MALL (traffic = measured HBM bytes "
+                    "per launch, calibrated counters), so this can exceed 1",
+        }
+        fl = counted_flops(args.workload, E, T)
+        if fl:
+            F = fl["flops_per_entity_step_total"]
+            F0 = fl["flops_per_entity_step_without_pair_search"]
+            tf = per_launch * F / (avg_ms * 1e-3) / 1e12
+            tf0 = per_launch * F0 / (avg_ms * 1e-3) / 1e12
+            roofline = {
+                # primary roof: the fp64 vector ALU, numerator = ALGORITHMIC flops counted by the oracle's counter build on
+                # scenarios of this very batch (not executed instructions: `valu_issue` below is the utilisation figure)
+                "bound": "valu_fp64", "unit": "TFLOP/s", "achieved": tf, "peak": FP64_VALU_PEAK_TFLOPS,
+                "frac": tf / FP64_VALU_PEAK_TFLOPS,
+                "flops_per_entity_step": F, "flops_by_category": fl["flops_per_entity_step"], "flops_file": fl["file"],
+                "flops_exact_for_this_workload": fl["exact"],
+                "achieved_without_pair_search": tf0, "frac_without_pair_search": tf0 / FP64_VALU_PEAK_TFLOPS,
+                "peak_measured": peak["fp64_tflops"] if peak else None,
+                "frac_of_measured_peak": (tf / peak["fp64_tflops"]) if peak and peak.get("fp64_tflops") else None,
+                "traffic": traffic,
+                "binding": "ordered_sum_latency" if wl.get("sliced") else "valu_issue",
+                "note": "achieved = counted algorithmic fp64 flops per entity-step (profiles/flops_*.json: add/sub/mul/div/sqrt/"
+                        "compare = 1, fma = 2, minimal formulation; pair_search = SURVEY 8d's 6 flops per unordered pair of present "
+                        "entities, which the stripe-mask broad phase does NOT execute -- frac_without_pair_search leaves it out) x "
+                        "entity-steps per launch / kernel_ms; peak = 256 CUs x 4 SIMDs x 16 lanes x 2 x 2.4 GHz; peak_measured = "
+                        "tools/valu_peak.hip run in this process; traffic = HBM bytes per launch (calibrated PMC counters)"
+                        + ("" if fl["exact"] else "; the flops are those of the nearest counted workload (the RSS callback / the car "
+                                                  "among the pedestrians are not in the count): a lower bound"),
+            }
+        else:  # no count for this shape: the contract's HBM figure stands in
+            roofline = dict(hbm_contract)
+            roofline["binding"] = "ordered_sum_latency" if wl.get("sliced") else "valu_issue"
+        sched = m.get("sched")
+        pipelines = None
+        if sched and any(r_[2] for r_ in sched):
+            found, used = [int(r_[0]) for r_ in sched], [int(r_[1]) for r_ in sched]
+            pipelines = {"wanted": int(sched[0][4]), "found_per_rank": found, "used_per_rank": used, "hw_queues": int(sched[0][5]),
+                         "pinned": bool(sched[0][6]), "blocks_per_rank": int(sched[0][2]), "simds": int(sched[0][3])}
+            # a batch of >= 3 x SIMDs blocks on the table path wants three pipelines; fewer = a slower schedule
+            want_now = min(pipelines["wanted"], pipelines["blocks_per_rank"] // max(1, pipelines["simds"]))
+            if kname.startswith("sg::rollout_kernel_tab") and want_now >= 2 and min(used) < want_now:
+                pipelines["degraded"] = True
+                print(f"bench: DEGRADED launch schedule: {min(used)} of {want_now} rollout pipelines ran side by side "
+                      f"(GPU_MAX_HW_QUEUES={pipelines['hw_queues']}; the probe at sg_create found {found}); results are the same, "
+                      f"throughput is not (one pipeline ~0.7x of three)", file=sys.stderr)
+        roofline.update({
+            "kernel": kname, "kernel_ms": avg_ms, "kernel_ms_gross": gross_ms,
+            "launch_overlap": gross_ms / avg_ms if avg_ms else None,
+            "kernel_ms_note": "kernel_ms = union of the launches' HIP-event intervals / launches (launches of the rollout pipelines "
+                              "overlap); kernel_ms_gross = plain average launch duration, the figure rocprofv3 --kernel-trace --stats shows",
+            "launches_per_rollout": launches_per_rollout, "rollout_device_ms": rollout_ms,
+            "entity_steps_per_launch": per_launch, "pipelines": pipelines,
+            "valu_issue": secondary, "hbm_contract": hbm_contract if fl else None,
+            "src_sha16": L.source_sha16(),
+        })
         line = {
             "metric": "entity-steps/sec (batched rollout)",
             "value": m["total"] / m["elapsed"],
@@ -649,27 +751,7 @@ def main(argv=None, make_engine=None):
                 "scenarios_per_gpu": R, "entities": E, "sim_steps": T, "timestep": dt,
                 "sharding": f"replicas x{world}, no data-path collective",
             },
-            "roofline": {
-                # `frac` is the contract's figure (algorithmic bytes over the HBM peak).  What binds is vector-ALU
-                # instruction issue: the rewritten state lives in L2 (traffic_ratio), see `secondary`.
-                "bound": "ordered_sum_latency" if wl.get("sliced") else "valu_issue", "contract_bound": "hbm",
-                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
-                "traffic_ratio": (traffic / (per_launch * b_alg)) if traffic else None,
-                "stored_bytes_per_entity_step": wl["stored"],
-                "secondary": secondary,
-                "kernel": (f"sg::rollout_kernel_slice{'_tab' if ego_kind == L.KIND_AGENT_PID else ''}<{min(64, max(4, 1 << (E - 1).bit_length()))}>" if wl.get("sliced") else
-                           kernel_name(E, crowd, ego_kind == L.KIND_AGENT_PID, bool(wl.get("rss")), bool(wl.get("mix")))),
-                "note": ("frac > 1: the algorithmic bytes of SURVEY 8d (the step-materialised state, rewritten in place every step) "
-                         "never reach HBM -- they live in L2 / MALL (traffic_ratio) -- so the HBM figure is not the binding roof; "
-                         "`secondary` (vector-instruction issue) is.  kernel_ms = union of the launches' intervals / launches "
-                         "(launches of the rollout pipelines overlap); kernel_ms_gross = plain average launch duration, the figure "
-                         "rocprofv3 --kernel-trace --stats shows") if achieved / HBM_PEAK_GBS > 1.0 or gross_ms > 1.01 * avg_ms else None,
-                "kernel_ms": avg_ms, "kernel_ms_gross": gross_ms, "launch_overlap": gross_ms / avg_ms if avg_ms else None,
-                "launches_per_rollout": launches_per_rollout, "rollout_device_ms": rollout_ms,
-                "bytes_per_entity_step": b_alg, "entity_steps_per_launch": per_launch,
-                "src_sha16": L.source_sha16(),
-            },
+            "roofline": roofline,
         }
         line["verified"] = m["verified"]
         if other_run:
@@ -682,7 +764,9 @@ def main(argv=None, make_engine=None):
                                      "scenarios_per_gpu": o["R"], "per_rank_value": o["per_rank"], "verified": o["verified"],
                                      "accounting": "workload c3s: time-sliced rollout, final state + metrics + events bit-identical "
                                                    "to the step-by-step path, the intermediate states are not written to memory"}
-        if live and world == 1 and not args.no_cpu_baseline:
+        if pipelines and pipelines.get("degraded"):
+            line["degraded"] = "fewer rollout pipelines than the batch wants ran side by side (roofline.pipelines)"
+        if live and not args.no_cpu_baseline:  # (rank 0 only, after the timed region; the other ranks wait at the teardown)
             line["cpu_baseline"] = cpu_baseline(dict(E=E, T=T, dt=dt, ego_kind=ego_kind, crowd=crowd, rss=bool(wl.get("rss"))))
         print(json.dumps(line))
     if dist is not None and (live or args.engine_factory):

@@ -391,6 +391,16 @@ int sg_last_launch_stats(sg_handle *h, int32_t *n_launches, float *kernel_ms_tot
 /* ... and the plain sum of their durations (what a kernel trace adds up; equal to the union when nothing overlaps) */
 int sg_last_launch_gross_ms(sg_handle *h, float *kernel_ms_gross);
 
+/* The launch schedule of the table path (no reference counterpart: scenario_gym/scenario_gym.py:256-267 is one Python loop).
+ * Large batches with controlled agents run as up to three pipelines on streams of their own; how many really run side by
+ * side depends on the hardware queues the process got (GPU_MAX_HW_QUEUES, read when the HIP runtime loads), which sg_create
+ * probes -- or takes from the environment variable SG_PIPELINES (1..3: no probe).  Results never depend on it, throughput
+ * does (one pipeline ~0.7x of three on 4096 x 64).  info[8]: [0] pipelines asked for, [1] pipelines the probe found (or the
+ * pinned count), [2] pipelines the last sg_rollout / sg_step call ran (0: it did not take the table path), [3]
+ * GPU_MAX_HW_QUEUES as this process sees it (4 = HIP's default when unset), [4] 1 when the count was pinned, [5] 64-slot
+ * blocks of the batch, [6] SIMDs of the device, [7] reserved. */
+int sg_pipeline_info(sg_handle *h, int32_t *info);
+
 /* ScenarioGym.rollout (scenario_gym.py:256-267) of a batch whose entities are all replay entities / replay agents is a
  * pure function of the clock except for three ordered sums (State.distances, EgoAvgSpeed, the event list); PID / vehicle
  * agents (controller.py:100-258) never look at another entity, so their poses are a function of the step alone once the

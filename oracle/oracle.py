@@ -11,7 +11,8 @@ import subprocess
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "_build", "libsgym_oracle.so")
+# (SGYM_ORACLE_LIB: tools/count_flops.py loads the counter build, _build/libsgym_oracle_count.so)
+LIB_PATH = os.environ.get("SGYM_ORACLE_LIB") or os.path.join(HERE, "_build", "libsgym_oracle.so")
 
 KIND_NONE, KIND_REPLAY, KIND_AGENT_REPLAY, KIND_AGENT_PID, KIND_AGENT_VEHICLE, KIND_AGENT_PEDESTRIAN = range(6)
 TERM_MAX_LENGTH, TERM_COLLISION, TERM_EGO_COLLISION = 1, 2, 4

@@ -15,6 +15,45 @@
 #define MAXE 1024
 
 /* ------------------------------------------------------------------------------------------
+ * Counter build (-DSGO_COUNT_FLOPS -> _build/libsgym_oracle_count.so; tools/count_flops.py): the ALGORITHMIC fp64
+ * operations of the path, per category, for bench.py's vector-ALU roofline (SURVEY 8d "Algorithmic flops").
+ * Convention: add / sub / mul / div / sqrt / rint / compare-select (min, max, an ordered compare that decides) = 1, fma = 2;
+ * index arithmetic, searches and copies = 0.  Each site adds the count of the MINIMAL formulation of what it computes --
+ * slopes of a knot segment, and terms that depend on one entity only, are prepared once (per segment / per entity-step),
+ * not per use -- times nothing: the number of calls is what the run measures.  The all-pairs searches (collision broad
+ * phase, pedestrian neighbour search) are charged SURVEY 8d's 6 flops (dx, dy, two products, sum, compare) per UNORDERED
+ * pair of present entities, and are reported apart so that a reader can leave them out.
+ * ---------------------------------------------------------------------------------------- */
+#ifdef SGO_COUNT_FLOPS
+enum { FL_LERP, FL_STATS, FL_SINCOS, FL_CORNERS, FL_BROAD, FL_SAT, FL_CTRL, FL_METRIC, FL_PED_GOAL, FL_PED_ENTITY,
+       FL_PED_PAIR, FL_PED_MOVE, FL_ENTITY_STEPS, FL_NCAT };
+static unsigned long long sgo_flops[FL_NCAT];
+#define FLOPS(c, n) (sgo_flops[c] += (unsigned long long)(n))
+/* out[FL_NCAT]; the last entry counts entity-steps (entities x executed steps); reset != 0 clears the counters */
+int sgo_flops_read(unsigned long long *out, int reset)
+{
+    for (int i = 0; i < FL_NCAT; ++i) { out[i] = sgo_flops[i]; if (reset) sgo_flops[i] = 0; }
+    return FL_NCAT;
+}
+#else
+#define FLOPS(c, n) ((void)0)
+#endif
+/* per-call constants (derivations beside each site) */
+#define FLN_LERP 13    /* dq = t - x_lo; 6 x (slope * dq + y_lo) */
+#define FLN_STATS 19   /* 6 sub, 6 div, norm3 = mul + 2 fma + sqrt, distance += */
+#define FLN_SINCOS 49  /* sgo_sincos: Cody-Waite reduction 12, sin kernel 18, cos kernel 19 */
+#define FLN_CORNERS 40 /* 4 half-extent offsets x 2, 8 coordinates x (2 mul + 2 add) */
+#define FLN_PAIR_SEARCH 6
+#define FLN_PID 29     /* errors 8, gain 4, derivative / integral terms 6, steer 3, |e_lon| test 1, accel 5, gains 2 */
+#define FLN_VEHICLE 48 /* clips 4, dx dy 2, tan polynomial 30, dh 2, pose += 6, speed 2 + 2 clamps */
+#define FLN_METRIC 12  /* norm3 6, w 1, running mean 4, max 1 */
+#define FLN_PED_FORCE_GOAL 16 /* g 2, |g| 4, test 1, 1/tau 1, 2 x (div, mul, sub, mul) */
+#define FLN_PED_ENTITY 8      /* per pedestrian that is somebody's neighbour: |v| + 1e-10 (5), unit velocity 2, step 1 */
+#define FLN_PED_PAIR 91       /* r 2, |r| 4, q 4, |q| 5, sum 1, b 5, k1 3, db 8, -b/sigma 1, exp 25, k2 1, rep 2, att 2,
+                                 two sight weights 2 x 10, 2 x (w * f) 4, force += 4 */
+#define FLN_PED_MOVE 44       /* |F| 4 + 1, speed cap 2, atan2 30, clip 2, sd 1, pose += 4 */
+
+/* ------------------------------------------------------------------------------------------
  * log for the Box-Muller transform of noise_mode 2: the classic Sun fdlibm __ieee754_log restated
  * (argument reduction to [sqrt(2)/2, sqrt(2)], degree-14 minimax in s = f / (2 + f)); domain: finite
  * normal x > 0.  Shared by restatement with the device (sg_log): plain add / mul / div only.
@@ -92,6 +131,7 @@ static const double C1 = 4.16666666666666019037e-02, C2 = -1.3888888888874109574
 
 void sgo_sincos(double x, double *s, double *c)
 {
+    FLOPS(FL_SINCOS, FLN_SINCOS);
     if (!(fabs(x) < 1.0e5)) { /* huge / inf / nan headings: defer to libm */
         *s = sin(x);
         *c = cos(x);
@@ -291,6 +331,7 @@ int sgo_position_at_t(const double *knots, int n, double t, int ext_bck, int ext
         double slope = (b[1 + c] - a[1 + c]) / (b[0] - a[0]);
         out[c] = slope * (t - a[0]) + a[1 + c];
     }
+    FLOPS(FL_LERP, FLN_LERP);
     return 1;
 }
 
@@ -390,6 +431,7 @@ static void batch_eval(const batch_t *B, double t, double *out /*[n_ent][6]*/)
     else if (t > B->ts[B->n_grid - 1])
         memcpy(out, B->X + (size_t)(B->n_grid - 1) * m, m * sizeof(double));
     else call_linear(B->ts, B->X, B->n_grid, m, m, t, out);
+    FLOPS(FL_LERP, (unsigned long long)FLN_LERP * (unsigned)B->n_ent); /* (clamped rows: charged alike, the GPU lane interpolates a constant piece) */
 }
 
 void sgo_batch_eval(const int64_t *knot_off, const double *knots, int n_ent, int persist,
@@ -421,6 +463,7 @@ void sgo_corners(const double *pose, const double *bbox, double *out)
     double W = bbox[0], L = bbox[1], cx = bbox[2], cy = bbox[3];
     double s, c;
     sgo_sincos(pose[3], &s, &c);
+    FLOPS(FL_CORNERS, FLN_CORNERS);
     double px[4] = {cx - 0.5 * L, cx + 0.5 * L, cx + 0.5 * L, cx - 0.5 * L};
     double py[4] = {cy + 0.5 * W, cy + 0.5 * W, cy - 0.5 * W, cy - 0.5 * W};
     for (int i = 0; i < 4; ++i) {
@@ -435,19 +478,26 @@ void sgo_corners(const double *pose, const double *bbox, double *out)
  * Orientation-agnostic (sign of the quad's own doubled area picks the outer side). */
 static double cross2(double ex, double ey, double dx, double dy) { return ex * dy - ey * dx; }
 
+#ifdef SGO_COUNT_FLOPS
+static int sgo_sat_count = 1; /* detect_collisions evaluates both (i, j) and (j, i): the predicate is symmetric, one is charged */
+#endif
 int sgo_quads_intersect(const double *A, const double *B)
 {
+    /* counter build: as executed, with the early exits -- 7 per pass (orientation), 2 per edge, 6 per vertex tested */
     for (int pass = 0; pass < 2; ++pass) {
         const double *P = pass ? B : A, *Q = pass ? A : B;
         /* orientation from the diagonal cross product (doubled area) */
         double o = cross2(P[4] - P[0], P[5] - P[1], P[6] - P[2], P[7] - P[3]);
+        FLOPS(FL_SAT, sgo_sat_count ? 7 : 0);
         for (int i = 0; i < 4; ++i) {
             int j = (i + 1) & 3;
             double ax = P[2 * i], ay = P[2 * i + 1];
             double ex = P[2 * j] - ax, ey = P[2 * j + 1] - ay;
             int all_out = 1;
+            FLOPS(FL_SAT, sgo_sat_count ? 2 : 0);
             for (int k = 0; k < 4 && all_out; ++k) {
                 double cr = cross2(ex, ey, Q[2 * k] - ax, Q[2 * k + 1] - ay);
+                FLOPS(FL_SAT, sgo_sat_count ? 6 : 0);
                 /* outside = opposite side to the interior; interior has sign(o) */
                 if (o > 0 ? !(cr < 0) : !(cr > 0)) all_out = 0;
             }
@@ -693,6 +743,13 @@ static void detect_collisions(int E, int W, const uint8_t *present, const double
             if (c[2 * k + 1] > b[3]) b[3] = c[2 * k + 1];
         }
     }
+#ifdef SGO_COUNT_FLOPS
+    {
+        unsigned long long np = 0;
+        for (int i = 0; i < E; ++i) np += present[i] != 0;
+        FLOPS(FL_BROAD, FLN_PAIR_SEARCH * (np * (np - (np > 0)) / 2)); /* all unordered pairs of present entities */
+    }
+#endif
     for (int i = 0; i < E; ++i) {
         if (!present[i]) continue;
         last[i] = i;
@@ -706,7 +763,14 @@ static void detect_collisions(int E, int W, const uint8_t *present, const double
             const double *a = aabb + (size_t)i * 4, *b = aabb + (size_t)j * 4;
             if (a[2] < b[0] || b[2] < a[0] || a[3] < b[1] || b[3] < a[1]) continue; /* STRtree envelope */
             if (corners_equal(cor + (size_t)i * 8, cor + (size_t)j * 8)) continue;  /* g != g_prime */
+#ifdef SGO_COUNT_FLOPS
+            sgo_sat_count = j > i;
+            const int hit_ = sgo_quads_intersect(cor + (size_t)i * 8, cor + (size_t)j * 8);
+            sgo_sat_count = 1;
+            if (!hit_) continue;
+#else
             if (!sgo_quads_intersect(cor + (size_t)i * 8, cor + (size_t)j * 8)) continue;
+#endif
             int o = last[j];
             rows[(size_t)i * W + (o >> 6)] |= (uint64_t)1 << (o & 63);
             if (mult) mult[(size_t)i * E + o]++;
@@ -725,6 +789,7 @@ static void vehicle_step(ctrl_state *cs, const double *ctrl, double l, double dt
                          double steer, double *pose)
 {
     double max_accel = ctrl[SGO_C_MAX_ACCEL], max_steer = ctrl[SGO_C_MAX_STEER];
+    FLOPS(FL_CTRL, FLN_VEHICLE);
     accel = fmin(fmax(accel, -max_accel), max_accel); /* np.clip */
     steer = fmin(fmax(steer, -max_steer), max_steer);
     double h = pose[3], s, c;
@@ -747,6 +812,7 @@ static void pid_step(ctrl_state *cs, const double *ctrl, double l, double state_
 {
     double h = pose[3], s, c;
     sgo_sincos(h, &s, &c);
+    FLOPS(FL_CTRL, FLN_PID);
     double e0 = target[0] - pose[0], e1 = target[1] - pose[1];
     double e_lon = c * e0 + s * e1;
     double e_lat = -s * e0 + c * e1;
@@ -931,6 +997,7 @@ static void ped_step(const sgo_scenario *sc, const sgo_config *cfg, int i, const
     double speed = 0.0, heading = 0.0;
     /* goal update, pedestrian/agent.py:59-62 */
     if (ps->goal_idx <= nwp - 1) {
+        FLOPS(FL_PED_GOAL, 27 * (nwp - 1) + 6 * (nwp - 1) + nwp); /* project: 27 per segment; arc lengths 6 per segment, 1 compare per waypoint */
         double s = route_project(wp, nwp, pose[0], pose[1]);
         double arc = 0.0;
         int last = 0;
@@ -953,11 +1020,15 @@ static void ped_step(const sgo_scenario *sc, const sgo_config *cfg, int i, const
         double fx = inv_tau * (vdes * (gx / gn) - vel[0]);
         double fy = inv_tau * (vdes * (gy / gn) - vel[1]);
         double hs, hc;
+        FLOPS(FL_PED_GOAL, FLN_PED_FORCE_GOAL);
+        FLOPS(FL_SINCOS, -FLN_SINCOS); /* (the head rotation is a constant of the pedestrian: its sin / cos is prepared once, not per step) */
         sgo_sincos(ct[SGO_C_PED_HEAD_ROT], &hs, &hc); /* rotate_coords: math.cos/math.sin(theta) */
         for (int j = 0; j < E; ++j) { /* PedestrianSensor.get_nearby_pedestrians, sensor.py:55-64 */
             if (j == i || !present[j] || sc->etype[j] != 1) continue;
+            FLOPS(FL_BROAD, j > i ? 1 : 0); /* the neighbour search shares the squared distance of the collision search: one more compare per unordered pair */
             const double *op = poses + (size_t)j * 6, *ov = vels + (size_t)j * 6;
             if (!sgo_in_radius(pose[0], pose[1], ct[SGO_C_PED_RADIUS], op[0], op[1])) continue;
+            FLOPS(FL_PED_PAIR, FLN_PED_PAIR);
             /* view direction of the NEIGHBOUR's rotated velocity, social_force.py:59-62; X.dot(R.T) */
             double vx = fma(ov[0], hc, ov[1] * (-hs)), vy = fma(ov[0], hs, ov[1] * hc);
             double vn = norm2(vx, vy) + 0.0000000001;
@@ -1020,6 +1091,7 @@ static void ped_step(const sgo_scenario *sc, const sgo_config *cfg, int i, const
             speed_rand = sf[SGO_SF_BIAS_LON] + cfg->std_lon * z[0];
             heading_rand = sf[SGO_SF_BIAS_LAT] + cfg->std_lat * z[1];
         }
+        FLOPS(FL_PED_MOVE, FLN_PED_MOVE);
         speed = fmin(norm2(fx, fy) + speed_rand, vdes * sf[SGO_SF_MAX_SPEED_FACTOR]);
         heading = sgo_atan2(fy, fx) + heading_rand;
         ps->fx = fx;
@@ -1476,10 +1548,13 @@ int sgo_rollout(const sgo_scenario *sc, const sgo_config *cfg, int max_steps, in
             }
             dists[i] += norm3(d[0], d[1], d[2]);
             velvalid[i] = 1;
+            FLOPS(FL_STATS, FLN_STATS);
+            if (sc->kind[i] == SGO_KIND_AGENT_PEDESTRIAN) FLOPS(FL_PED_ENTITY, FLN_PED_ENTITY);
         }
         memcpy(poses, newp, (size_t)E * 48);
         memcpy(present, newpres, E);
         ++n_steps;
+        FLOPS(FL_ENTITY_STEPS, E);
         /* collisions are evaluated lazily in the reference; results are per-step pure */
         detect_collisions(E, W, present, poses, sc->bbox, rows, mult, scratch);
         /* check_terminal, state.py:268-270, 397-408 */
@@ -1502,6 +1577,7 @@ int sgo_rollout(const sgo_scenario *sc, const sgo_config *cfg, int max_steps, in
             m_t = t;
             vmax = fmax(speed, vmax); /* np.maximum */
             ego_dist = dists[ego];
+            FLOPS(FL_METRIC, FLN_METRIC);
             /* CollisionMetric._step, metrics/collision.py:70-75 */
             for (int j = 0; j < E; ++j) {
                 int hit = (rows[(size_t)ego * W + (j >> 6)] >> (j & 63)) & 1;

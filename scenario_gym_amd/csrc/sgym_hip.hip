@@ -85,6 +85,9 @@ struct sg_handle {
     hipStream_t ctl_stream = nullptr;
     hipStream_t xstream[2] = {nullptr, nullptr}; // further rollout pipelines (launch_rollout)
     int n_pipes = 1;                             // rollout pipelines that really run side by side (probe_pipelines)
+    int pipes_wanted = 1;                        // ... of how many asked for (SG_TAB_SPLIT, default 3)
+    int pipes_pinned = 0;                        // env SG_PIPELINES: the count was set by hand, not probed
+    int last_pipes = 0;                          // pipelines the last table-path call ran (0: it did not take the table path)
     double *d_tab[4] = {nullptr, nullptr, nullptr, nullptr}; // controller-table buffers (launch_rollout: two, four with block groups)
     int n_tab = 0;
     int n_simd = 1024;                                       // SIMDs of the device (4 per compute unit)
@@ -260,7 +263,13 @@ static int probe_once(sg_handle *h, int want, int *found);
 static int probe_pipelines(sg_handle *h, int want)
 {
     h->n_pipes = 1;
+    h->pipes_wanted = want;
     if (want < 2) return SG_OK;
+    if (const int pin = env_int("SG_PIPELINES", 0)) { // the count by hand (1..want): no probe, no dependence on timing noise
+        h->n_pipes = std::min(want, std::max(1, pin));
+        h->pipes_pinned = 1;
+        return SG_OK;
+    }
     // up to three attempts, the best one counts: the first launch on a stream may still be setting the stream up (queues are
     // created on first use), and a process that starts beside seven others is not in a hurry
     for (int attempt = 0; attempt < 3 && h->n_pipes < want; ++attempt) {
@@ -276,7 +285,11 @@ static int probe_once(sg_handle *h, int want, int *found)
     *found = 1;
     hipStream_t st[4] = {h->stream, h->ctl_stream, h->xstream[0], h->xstream[1]};
     const int n = std::min(4, 1 + want);
-    hipEvent_t a[4] = {}, b[4] = {};
+    struct Events { // destroyed on every path out of this function (a failing HIP_TRY returns from the middle)
+        hipEvent_t a[4] = {}, b[4] = {};
+        ~Events() { for (int i = 0; i < 4; ++i) { if (a[i]) (void)hipEventDestroy(a[i]); if (b[i]) (void)hipEventDestroy(b[i]); } }
+    } evs;
+    hipEvent_t *a = evs.a, *b = evs.b;
     for (int i = 0; i < n; ++i) {
         HIP_TRY(h, hipEventCreate(&a[i]));
         HIP_TRY(h, hipEventCreate(&b[i]));
@@ -300,7 +313,6 @@ static int probe_once(sg_handle *h, int want, int *found)
         for (int i = 0; i < j && ok; ++i) ok = together(i, j);
         if (ok) *found = j;
     }
-    for (int i = 0; i < n; ++i) { (void)hipEventDestroy(a[i]); (void)hipEventDestroy(b[i]); }
     return SG_OK;
 }
 
@@ -568,8 +580,27 @@ static int launch_main(sg_handle *h, int n_steps, int do_reset, int force, const
 // SG_TAB_MIN_STEPS steps to do take the two-kernel path: control_kernel integrates the PID / vehicle agents
 // for a chunk of steps on its own stream while rollout_kernel<TAB> consumes the previous chunks' tables -- large batches as
 // two or three pipelines on streams of their own (below).
+static int launch_rollout_impl(sg_handle *h, int n_steps, int do_reset, int force, const double *d_actions);
+// Work of a failed call may still be running on the controller stream and the pipeline streams (the fan-out of the table
+// path joins them into h->stream only at its end): wait for it, so that a later sg_synchronize / sg_upload / table regrow,
+// which look at h->stream alone, never free a buffer a kernel is reading.
+static void drain_streams(sg_handle *h)
+{
+    if (h->ctl_stream) (void)hipStreamSynchronize(h->ctl_stream);
+    for (hipStream_t x : h->xstream)
+        if (x) (void)hipStreamSynchronize(x);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    (void)hipGetLastError();
+}
 static int launch_rollout(sg_handle *h, int n_steps, int do_reset, int force, const double *d_actions)
 {
+    const int rc = launch_rollout_impl(h, n_steps, do_reset, force, d_actions);
+    if (rc) drain_streams(h);
+    return rc;
+}
+static int launch_rollout_impl(sg_handle *h, int n_steps, int do_reset, int force, const double *d_actions)
+{
+    h->last_pipes = 0;
     const int tab_min = h->tab_min, chunk_steps = std::max(1, h->chunk_steps), no_overlap = !h->overlap;
     h->n_launches = 0;
     h->launch_ev.clear();
@@ -627,6 +658,7 @@ static int launch_rollout(sg_handle *h, int n_steps, int do_reset, int force, co
                 // 4096: 67 / 90 / 95, 8192: 87.5 / 99.8 / 100.7)
                 H = (int)std::min<size_t>((size_t)h->n_pipes, nblk / per_pipe);
             }
+            h->last_pipes = H;
             const int gsz = (int)std::max<size_t>(1, (nblk + H - 1) / H);
             const int NB = H > 1 ? 4 : 2; // table buffers
             // the pre-pass in launches of ctl_slice steps (its load then moves between SIMDs) -- but the planar kernel's three
@@ -1784,6 +1816,21 @@ extern "C" int sg_last_launch_stats(sg_handle *h, int32_t *n_launches, float *ke
     if (hi >= lo) total += hi - lo;
     *n_launches = h->n_launches;
     *kernel_ms_total = total;
+    return SG_OK;
+}
+
+extern "C" int sg_pipeline_info(sg_handle *h, int32_t *info)
+{
+    if (!h || !info) return SG_ERR_INVALID;
+    const char *q = getenv("GPU_MAX_HW_QUEUES");
+    info[0] = h->pipes_wanted;
+    info[1] = h->n_pipes;
+    info[2] = h->last_pipes;
+    info[3] = (q && *q) ? atoi(q) : 4; // HIP's default
+    info[4] = h->pipes_pinned;
+    info[5] = (int32_t)std::min<size_t>(0x7fffffff, h->NE / 64);
+    info[6] = h->n_simd;
+    info[7] = 0;
     return SG_OK;
 }
 

@@ -352,6 +352,13 @@ class RolloutEngine:
         self._check(self.lib.sg_last_launch_gross_ms(self.h, C.byref(ms)), "sg_last_launch_gross_ms")
         return ms.value
 
+    def pipeline_info(self):
+        """The launch schedule of the table path (sg_pipeline_info): pipelines asked for / found by the probe at sg_create (or
+        pinned with SG_PIPELINES) / run by the last call, GPU_MAX_HW_QUEUES as the process sees it."""
+        v = (C.c_int32 * 8)()
+        self._check(self.lib.sg_pipeline_info(self.h, v), "sg_pipeline_info")
+        return dict(wanted=v[0], found=v[1], used_last_call=v[2], hw_queues=v[3], pinned=bool(v[4]), blocks=v[5], simds=v[6])
+
     def debug_trig32(self, heading):
         """The broad phase's fp32 (sin, cos) of fp64 headings (test hook)."""
         h = np.ascontiguousarray(heading, np.float64).ravel()

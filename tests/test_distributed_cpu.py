@@ -116,7 +116,9 @@ def test_bench_dispatch_and_collection_strong_scaling(tmp_path):
     assert len(line["per_rank_value"]) == 2 and len(line["weak"]["per_rank_value"]) == 2
     ent_steps = 2 * 64 * 6 * 40 * 2  # ranks x scenarios x entities x T x timed passes
     assert abs(line["value"] * line["ms_per_step"] * 1e-3 * 2 - ent_steps) < 1e-6 * ent_steps
-    assert line["roofline"]["bound"] == "valu_issue" and line["roofline"]["traffic"] is None
+    # (no counted flops for this toy shape: the contract's HBM figure stands in; the stand-in engine has no pipelines)
+    assert line["roofline"]["bound"] == "hbm" and line["roofline"]["binding"] == "valu_issue" and line["roofline"]["traffic"] is None
+    assert line["roofline"]["pipelines"] is None and "degraded" not in line
     assert line["roofline"]["entity_steps_per_launch"] == 64 * 6 * 40 / 2
 
 

@@ -19,11 +19,12 @@ for f in sorted(glob.glob(os.path.join(root, f"{tag}*_bench.json"))):
         continue
     l = json.loads(lines[-1])
     r = l.get("roofline") or {}
-    s = r.get("secondary") or {}
+    s = r.get("valu_issue") or r.get("secondary") or {}
+    hc = r.get("hbm_contract") or r
     val = f"{l['value'] / 1e9:.3f} G" if l["value"] > 1e6 else f"{l['value']:.1f}"
     print(f"{os.path.basename(f)[len(tag) + 1:]:28s} {val:>10s} {l['ms_per_step']:9.2f} ms  verified={(l.get('verified') or {}).get('equal')}  "
           f"{(r.get('kernel') or '')[4:]}  kernel_ms={r.get('kernel_ms') and round(r['kernel_ms'], 3)} gross={r.get('kernel_ms_gross') and round(r['kernel_ms_gross'], 3)} "
-          f"launches={r.get('launches_per_rollout')} frac={r.get('frac') and round(r['frac'], 3)} traffic_ratio={r.get('traffic_ratio') and round(r['traffic_ratio'], 3)} "
+          f"launches={r.get('launches_per_rollout')} frac={r.get('frac') and round(r['frac'], 3)} traffic_ratio={hc.get('traffic_ratio') and round(hc['traffic_ratio'], 3)} bound={r.get('bound')} pipes={(r.get('pipelines') or {}).get('used_per_rank')} "
           f"valu_frac={s.get('frac') and round(s['frac'], 2)} sha={r.get('src_sha16')}")
     if "stage_seconds" in l:
         print("   ", l["stage_seconds"], "x_realtime", round(l.get("x_realtime", 0)), "cpu", (l.get("cpu_baseline") or {}).get("value"))
