@@ -401,6 +401,14 @@ int sg_last_launch_gross_ms(sg_handle *h, float *kernel_ms_gross);
  * blocks of the batch, [6] SIMDs of the device, [7] reserved. */
 int sg_pipeline_info(sg_handle *h, int32_t *info);
 
+/* Long rollouts of all-pedestrian scenarios of 129..256 entities run in chunks of steps; in every chunk a scenario whose
+ * pedestrians have mostly ARRIVED (speed 0, heading 0, force 0 from then on: pedestrian/agent.py:64-68) is stepped by a
+ * kernel that spends lanes only on the entities that still change (scenario_gym_amd/csrc/sgym_walk.hpp).  Results never
+ * depend on it (SG_CROWD_WALK=0 switches it off).  out[8], summed since the last reset of the counters: [0..2] scenario-chunks
+ * run by the full kernel / by the walker kernel with one / with two wavefronts, [4] walker workgroups that stopped early and
+ * were finished by the full kernel, [7] chunks of the last call.  Test and diagnostics hook. */
+int sg_crowd_walk_stats(sg_handle *h, int32_t *out, int32_t reset);
+
 /* ScenarioGym.rollout (scenario_gym.py:256-267) of a batch whose entities are all replay entities / replay agents is a
  * pure function of the clock except for three ordered sums (State.distances, EgoAvgSpeed, the event list); PID / vehicle
  * agents (controller.py:100-258) never look at another entity, so their poses are a function of the step alone once the

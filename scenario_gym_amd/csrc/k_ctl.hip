@@ -1,4 +1,5 @@
 // k_ctl.hip -- the controller pre-pass: control_kernel, control_kernel_riders, control_kernel_fast.
+#define SG_UNIT_CTL
 #include "sgym_launch.hpp"
 
 namespace sgl {

@@ -1,5 +1,6 @@
 // k_rss_tab.hip -- rollout_kernel_rss_tab<G>: the RSS callback with the controlled lanes on the pre-pass table, and
 // rss_lines_kernel, which finishes the queued line tests of every RSS variant after a launch.
+#define SG_UNIT_RSS_LINES
 #include "sgym_launch.hpp"
 
 namespace sgl {

@@ -2090,6 +2090,7 @@ __device__ __forceinline__ void tile_collisions(bool present, const double *pose
 // BatchReplayEntity.add_entities stage 1 (entity/batch.py:83-109): resample every batch-replay
 // trajectory onto its scenario's union grid.  One thread per (grid row, entity slot).
 // ------------------------------------------------------------------------------------------------
+#ifdef SG_UNIT_MAIN // (emitted by the one object that launches it: csrc/Makefile, sgym_launch.hpp)
 static __global__ void build_grid_kernel(Params p, const int32_t *row_scen /*[totalN]*/, int64_t row0, int64_t row_end)
 {
     int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2136,6 +2137,7 @@ static __global__ void build_grid_kernel(Params p, const int32_t *row_scen /*[to
     }
     for (int c = 0; c < 6; ++c) p.grid_y[((size_t)row * 6 + c) * p.EP + e] = out[c];
 }
+#endif // SG_UNIT_MAIN
 
 // ------------------------------------------------------------------------------------------------
 // RSSDistances.__call__ (metrics/rss/callback.py:58-128) on the current state of every scenario, + the flags RSS reads
@@ -2511,6 +2513,14 @@ struct SliceArgs {
                          // slices group by group, each group as soon as the controller pre-pass has reached its last step
 };
 
+// Chunked crowd rollouts (launch_crowd_chunks in sgym_hip.hip, sgym_walk.hpp): which scenarios a launch of the crowd kernel
+// works on and where they stop.  cls == nullptr: every scenario, n_steps steps.
+struct WalkSel {
+    const int8_t *cls;     // [R] class of the scenario in this chunk (0 = this kernel, 1 / 2 = walk_kernel<1 / 2>)
+    const int32_t *target; // [R] steps-since-reset at which the chunk ends
+    int want;              // the class this launch serves; -1: every scenario that has not reached its target (and may run)
+};
+
 // CROWD (PED only): every entity of the batch is a pedestrian agent (or padding), default head rotation, no road network:
 // no knot segment, no vehicle / replay code, crowd_pairs for the neighbour sums (rollout_kernel_crowd, BASELINE config 5).
 // SLICE (TAB, one wavefront per tile): one slice of a time-sliced replay, see SliceArgs.  With HAST the controlled lanes
@@ -2522,7 +2532,8 @@ template <int G, int WV, bool PED, bool TAB, bool HAST, bool ROAD = false, bool 
 __device__ __forceinline__ void rollout_body(
     const Params &p, double timestep, int n_steps, int do_reset, int force, const double *actions /*[n][R][2]*/,
     const double *tab /*controller table planes*/, const SliceArgs &sa = SliceArgs{},
-    const unsigned bx_arg = ~0u /* the 64-slot block (WV == 1) / scenario of this workgroup when it is not bx: TabGroups */)
+    const unsigned bx_arg = ~0u /* the 64-slot block (WV == 1) / scenario of this workgroup when it is not bx: TabGroups */,
+    const WalkSel &sel = WalkSel{nullptr, nullptr, 0})
 {
     const unsigned bx = bx_arg == ~0u ? blockIdx.x : bx_arg;
     static_assert(!SLICE || (TAB && WV == 1 && !PED && !ROAD && !RSSV), "slices: the table variant, one wavefront per tile");
@@ -2558,6 +2569,13 @@ __device__ __forceinline__ void rollout_body(
     const uint32_t r = in_range ? r_raw : p.R - 1;
     const ScenStatic &ss = p.sstat[r];
     sg_scenario_state &sd = p.sdyn[r];
+    int step_target = 0x7fffffff;
+    if (CROWD && !RIDERS && WV > 1 && sel.cls) { // (one scenario per workgroup: uniform)
+        const int tg = sel.target[r];
+        const bool mine = sel.want >= 0 ? sel.cls[r] == sel.want : (sd.n_steps < tg && (force || !sd.done));
+        if (!mine) return;
+        step_target = tg;
+    }
     const int64_t meta = fld<int64_t>(st, ST_META);
     const int kind = (in_range && slot < p.E) ? (int)(meta & 0xff) : SG_KIND_NONE;
     const bool is_ped_type = ((meta >> 8) & 0xff) == 1;
@@ -3013,7 +3031,8 @@ __device__ __forceinline__ void rollout_body(
         // SLICE: round 0 is the warm-up step (state a - 1 -> a, nothing recorded); a lane that starts from the reset state
         // itself (a == 0) sits it out
         const bool warm = SLICE && k == 0;
-        const bool run_lane = in_range && (force || !done) && !(SLICE && k == 0 && slice_a == 0);
+        const bool run_lane = in_range && (force || !done) && !(SLICE && k == 0 && slice_a == 0) &&
+                              (!(CROWD && !RIDERS && WV > 1) || steps < step_target);
         PH(5);
         // (a workgroup of several wavefronts carries ONE scenario: `run` is already uniform, nothing to vote)
         const bool any_run_ = WV == 1 ? sg_any(run_lane || (SLICE && k == 0 && in_range && !done)) : run_lane;
@@ -3589,9 +3608,9 @@ __global__ __launch_bounds__(64 * WV, PED ? SG_WAVES_PER_SIMD_PED : (TAB ? SG_WA
 // All-pedestrian batches without road networks (BASELINE config 5): see rollout_body, CROWD
 template <int WV>
 __global__ __launch_bounds__(64 * WV, SG_WAVES_PER_SIMD_PED) void rollout_kernel_crowd(
-    Params p, double timestep, int n_steps, int do_reset, int force, const double *actions, const double *tab)
+    Params p, double timestep, int n_steps, int do_reset, int force, const double *actions, const double *tab, WalkSel sel)
 {
-    rollout_body<64, WV, true, false, false, false, false, true>(p, timestep, n_steps, do_reset, force, actions, tab);
+    rollout_body<64, WV, true, false, false, false, false, true>(p, timestep, n_steps, do_reset, force, actions, tab, SliceArgs{}, ~0u, sel);
 }
 
 // ... with riders: lanes of other kinds whose poses come from the pre-pass table (see rollout_body, RIDERS)
@@ -3697,6 +3716,7 @@ __global__ __launch_bounds__(64, SG_WAVES_PER_SIMD_TAB) void rollout_kernel_slic
 
 // The clocks of a sliced replay: tt[c][j] = State.t after j steps = t0_c + dt + dt + ... (scenario_gym.py:229), the
 // additions of the step loop itself; scenarios with the same start time share a clock (launch_sliced).  One lane per clock.
+#ifdef SG_UNIT_MAIN // (emitted by the one object that launches it: csrc/Makefile, sgym_launch.hpp)
 static __global__ __launch_bounds__(64) void clock_kernel(const double *t0 /*[n_clocks]*/, int n_clocks, double timestep, int n_total, double *tt)
 {
     const int c = blockIdx.x * 64 + threadIdx.x;
@@ -3714,8 +3734,10 @@ static __global__ __launch_bounds__(64) void clock_kernel(const double *t0 /*[n_
     }
     for (; j <= n_total; ++j) { t = t + timestep; row[j] = t; }
 }
+#endif // SG_UNIT_MAIN
 
 // n_final[r] = the step at which scenario r became done (the first over its slices), else all n_total steps
+#ifdef SG_UNIT_MAIN // (emitted by the one object that launches it: csrc/Makefile, sgym_launch.hpp)
 static __global__ __launch_bounds__(64) void slice_final_kernel(Params p, SliceArgs sa, int *n_final, int *done_out)
 {
     const int r = blockIdx.x * 64 + threadIdx.x;
@@ -3725,6 +3747,7 @@ static __global__ __launch_bounds__(64) void slice_final_kernel(Params p, SliceA
     done_out[r] = nf != 0x7f7f7f7f;
     n_final[r] = min(nf, sa.n_total);
 }
+#endif // SG_UNIT_MAIN
 
 // The ordered pass of a sliced replay, after the last step has been materialised.  replay_fixup_kernel: per entity
 // State.distances = the |delta pose| terms added up in step order (state.py:237-239), 32 rows of the block in flight.
@@ -3777,6 +3800,7 @@ __global__ __launch_bounds__(64) void replay_fixup_kernel(Params p, SliceArgs sa
 }
 
 // (a controlled ego is no different here: the slices leave its speeds like a replay ego's, the pre-pass skips the metrics)
+#ifdef SG_UNIT_MAIN // (emitted by the one object that launches it: csrc/Makefile, sgym_launch.hpp)
 static __global__ __launch_bounds__(64) void replay_scenario_fixup_kernel(Params p, SliceArgs sa, const int *n_final, const int *done_in)
 {
     const int lane = threadIdx.x;
@@ -3848,6 +3872,7 @@ static __global__ __launch_bounds__(64) void replay_scenario_fixup_kernel(Params
     sd.done = done_in[r];
     sd.n_steps = nf;
 }
+#endif // SG_UNIT_MAIN
 
 // ------------------------------------------------------------------------------------------------
 // Controller pre-pass.  A PIDAgent / external-action VehicleController lane never looks at another
@@ -4139,21 +4164,27 @@ __device__ __forceinline__ void control_body(const Params &p, double timestep, i
     cst[(CS_METRIC + 0) * NP] = m_avg; cst[(CS_METRIC + 1) * NP] = m_max; cst[(CS_METRIC + 2) * NP] = m_t;
 }
 
+#ifdef SG_UNIT_CTL // (emitted by the one object that launches it: csrc/Makefile, sgym_launch.hpp)
 static __global__ __launch_bounds__(64, SG_CTL_WAVES) void control_kernel(Params p, double timestep, int n_steps, int first, int k0,
                                                      const double *actions /*[n][R][2]*/, double *tab, int row0, int metrics)
 {
     control_body<false>(p, timestep, n_steps, first, k0, actions, tab, row0, metrics);
 }
+#endif // SG_UNIT_CTL
+#ifdef SG_UNIT_CTL // (emitted by the one object that launches it: csrc/Makefile, sgym_launch.hpp)
 static __global__ __launch_bounds__(64, 2) void control_kernel_riders(Params p, double timestep, int n_steps, int first, int k0,
                                                                const double *actions /*[n][R][2]*/, double *tab, int row0, int metrics)
 {
     control_body<false, true>(p, timestep, n_steps, first, k0, actions, tab, row0, 0);
 }
+#endif // SG_UNIT_CTL
+#ifdef SG_UNIT_CTL // (emitted by the one object that launches it: csrc/Makefile, sgym_launch.hpp)
 static __global__ __launch_bounds__(64, 1) void control_kernel_fast(Params p, double timestep, int n_steps, int first, int k0,
                                                              const double *actions /*[n][R][2]*/, double *tab, int row0, int metrics)
 {
     control_body<true>(p, timestep, n_steps, first, k0, actions, tab, row0, metrics);
 }
+#endif // SG_UNIT_CTL
 
 // ------------------------------------------------------------------------------------------------
 // FutureCollisionDetector._step (sensor/common.py:87-106), SURVEY 8f N2: does the ego's box, moved along its
@@ -4181,6 +4212,7 @@ __device__ __forceinline__ void own_position_clamped(const double *kn, int n, do
 // knots are chains of dependent loads: 10 samples one after the other per entity thread took 250 us for 4096 x 64).
 // Pass 1: the ego's corners at every sample time into LDS; pass 2: every other pair against them.
 #define SG_FUT_MAX_SAMPLES 64
+#ifdef SG_UNIT_MAIN // (emitted by the one object that launches it: csrc/Makefile, sgym_launch.hpp)
 static __global__ __launch_bounds__(256) void future_kernel(Params p, double horizon, int n_samples, unsigned char *out /*[R]*/)
 {
     __shared__ double ego_c[SG_FUT_MAX_SAMPLES][8];
@@ -4226,6 +4258,7 @@ static __global__ __launch_bounds__(256) void future_kernel(Params p, double hor
     const int any = __syncthreads_or(hit);
     if (tid == 0) out[r] = (unsigned char)(any != 0);
 }
+#endif // SG_UNIT_MAIN
 
 // ------------------------------------------------------------------------------------------------
 // RasterizedMapSensor, "entity" layer (sensor/map.py:120-192), SURVEY 8f N2: for the ego of every scenario an
@@ -4241,6 +4274,7 @@ __device__ __forceinline__ double sg_linspace_at(double start, double stop, int 
     return (double)j * step + start;
 }
 
+#ifdef SG_UNIT_MAIN // (emitted by the one object that launches it: csrc/Makefile, sgym_launch.hpp)
 static __global__ __launch_bounds__(256) void raster_kernel(Params p, double width, double height, int nw, int nh,
                                                      unsigned char *out /*[R][nh][nw] at stride bytes per scenario*/,
                                                      int64_t stride)
@@ -4310,9 +4344,11 @@ static __global__ __launch_bounds__(256) void raster_kernel(Params p, double wid
         o[q] = ego_present ? (unsigned char)hit : 0; // the reference sensor needs state.poses[entity]
     }
 }
+#endif // SG_UNIT_MAIN
 
 // The road-surface layers of RasterizedMapSensor (sensor/map.py:194-271) on the same grid: one thread per grid point
 // looks its cell up once for all requested layers; out[r][k] for the layers[k] != 0 (the entity layer is raster_kernel's).
+#ifdef SG_UNIT_MAIN // (emitted by the one object that launches it: csrc/Makefile, sgym_launch.hpp)
 static __global__ __launch_bounds__(256) void raster_surface_kernel(Params p, RoadIndex R, double width, double height, int nw, int nh,
                                                              int n_layers, const int32_t *layers,
                                                              unsigned char *out /*[R][n_layers][nh][nw]*/)
@@ -4345,6 +4381,7 @@ static __global__ __launch_bounds__(256) void raster_surface_kernel(Params p, Ro
             if (layers[k]) o[(size_t)k * nw * nh + q] = (in & (uint32_t)layers[k]) != 0;
     }
 }
+#endif // SG_UNIT_MAIN
 
 // ------------------------------------------------------------------------------------------------
 // CollisionMetric.record_collision / get_collision_point / angle_between (metrics/collision.py:13-22, 81-203) for the
@@ -4449,6 +4486,7 @@ __device__ inline int sg_classify_collision(const double *eb, double ex, double 
 // (type packed with k, the step inside the launch) take the controlled ego's pose at that step from the table row and become
 // ordinary pending events.  A few loads and stores per event; the classification itself waits for sg_read_metrics.
 // (`tg`: the block groups of that launch -- the scenario's group says which buffer its rows are in)
+#ifdef SG_UNIT_MAIN // (emitted by the one object that launches it: csrc/Makefile, sgym_launch.hpp)
 static __global__ __launch_bounds__(64) void event_ego_pose_kernel(Params p, TabGroups tg)
 {
     const int r = blockIdx.x;
@@ -4487,9 +4525,11 @@ static __global__ __launch_bounds__(64) void event_ego_pose_kernel(Params p, Tab
         ev.type = base == 15 ? -1 : base;
     }
 }
+#endif // SG_UNIT_MAIN
 
 // one thread per (scenario, event slot): pending events (-1) get their type, or -2 when the hazard's pose cannot be
 // re-evaluated.  Ego pose: its trajectory (replay agents), else the pose stored with the event.
+#ifdef SG_UNIT_MAIN // (emitted by the one object that launches it: csrc/Makefile, sgym_launch.hpp)
 static __global__ __launch_bounds__(64) void classify_events_kernel(Params p, double c_tol)
 {
     const int r = blockIdx.x;
@@ -4545,11 +4585,13 @@ static __global__ __launch_bounds__(64) void classify_events_kernel(Params p, do
         pt[0] = cpx; pt[1] = cpy; pt[2] = cang;
     }
 }
+#endif // SG_UNIT_MAIN
 
 // rss_state [NE] = found | last << 8; code [NE]: 0 safe, 1 lateral, 2 longitudinal, 3 both, 4 unsafe_lateral,
 // 5 unsafe_longitudinal, 6 found, -1 not updated; safe [NE][2] = lateral, longitudinal
 // seen [R]: State.n_steps at the scenario's latest update -- a scenario that did not step since (it is done) is left alone,
 // as the reference stops calling the callback once its rollout loop has ended
+#ifdef SG_UNIT_MAIN // (emitted by the one object that launches it: csrc/Makefile, sgym_launch.hpp)
 static __global__ __launch_bounds__(256) void rss_kernel(Params p, int reset, int32_t *rss_state, int32_t *code, double *safe, int32_t *seen)
 {
     __shared__ double ego[8]; // x, y, heading, vx, vy, width, length, present
@@ -4586,10 +4628,12 @@ static __global__ __launch_bounds__(256) void rss_kernel(Params p, int reset, in
     safe[(size_t)idx * 2] = s_lat;
     safe[(size_t)idx * 2 + 1] = s_long;
 }
+#endif // SG_UNIT_MAIN
 
 // The queued line tests of one rollout_kernel_rss launch (see RssQueue): block w = the queue of rollout wavefront w, whose
 // lane l carries entity index w * 64 + l.
 // (tg: the blocks of that launch -- one pipeline's part of the batch, launch_rollout; else all of them)
+#ifdef SG_UNIT_RSS_LINES // (emitted by the one object that launches it: csrc/Makefile, sgym_launch.hpp)
 static __global__ __launch_bounds__(64) void rss_lines_kernel(Params p, TabGroups tg)
 {
     __shared__ RssQueue q;
@@ -4637,10 +4681,12 @@ static __global__ __launch_bounds__(64) void rss_lines_kernel(Params p, TabGroup
     if (st != st0) p.rss_state[idx] = st;
     if (cd != cd0) p.rss_code[idx] = cd;
 }
+#endif // SG_UNIT_RSS_LINES
 
 // The observation of one RL tick in ONE launch (sg_tick): every requested map layer -- the entity layer of raster_kernel and
 // the surface layers of raster_surface_kernel, same arithmetic, the grid point computed once -- and the terminal flags of
 // terminal_flags_kernel.  One workgroup per scenario.  has_road: road networks are set (else the surface layers are empty).
+#ifdef SG_UNIT_MAIN // (emitted by the one object that launches it: csrc/Makefile, sgym_launch.hpp)
 static __global__ __launch_bounds__(256) void observe_kernel(Params p, RoadIndex R, int has_road, double width, double height, int nw,
                                                       int nh, int n_layers, const int32_t *layers,
                                                       unsigned char *out /*[R][n_layers][nh][nw]*/, uint32_t *flags /*[R]*/)
@@ -4731,10 +4777,12 @@ static __global__ __launch_bounds__(256) void observe_kernel(Params p, RoadIndex
             o[(size_t)k * nw * nh + q] = layers[k] == 0 ? (unsigned char)(ego_pres && hit) : (unsigned char)((in & (uint32_t)layers[k]) != 0);
     }
 }
+#endif // SG_UNIT_MAIN
 
 // TERMINAL_CONDITIONS (state/state.py:397-408), all four evaluated on the CURRENT state of every scenario, whatever the
 // handle's terminal mask says: out[r] = SG_TERM_* bits.  The reward of the reference's RL agent asks exactly this of a
 // done state (integrations/openaigym.py:300-310).  One wavefront per scenario.
+#ifdef SG_UNIT_MAIN // (emitted by the one object that launches it: csrc/Makefile, sgym_launch.hpp)
 static __global__ __launch_bounds__(64) void terminal_flags_kernel(Params p, double timestep, uint32_t *out)
 {
     const int r = blockIdx.x, lane = threadIdx.x;
@@ -4770,12 +4818,15 @@ static __global__ __launch_bounds__(64) void terminal_flags_kernel(Params p, dou
         out[r] = bits;
     }
 }
+#endif // SG_UNIT_MAIN
 
 // sg_debug_trig32: the broad phase's hardware sin/cos, exposed so that the parity tests can bound its error
+#ifdef SG_UNIT_MAIN // (emitted by the one object that launches it: csrc/Makefile, sgym_launch.hpp)
 static __global__ void trig32_kernel(const double *h, float *s, float *c, int64_t n)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) sg_sincos_f32(h[i], s[i], c[i]);
 }
+#endif // SG_UNIT_MAIN
 
 } // namespace sg

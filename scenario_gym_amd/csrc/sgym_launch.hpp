@@ -7,6 +7,7 @@
 // scenario (the plain variant also 8).
 #pragma once
 #include "sgym_device.hpp"
+#include "sgym_walk.hpp"
 
 namespace sgl {
 
@@ -17,6 +18,7 @@ struct RolloutArgs {
     int n_steps, do_reset, force;
     const double *actions; // [n][R][2] or nullptr
     const double *tab;     // controller table planes or nullptr
+    sg::WalkSel sel{nullptr, nullptr, 0}; // rollout_kernel_crowd only: the scenarios of a chunked rollout this launch serves
 };
 
 // k_plain.hip: rollout_kernel<G, WV, false, tab>  (WV == 8: rollout_kernel<64, 8, false, false>)
@@ -25,6 +27,10 @@ void rollout_plain(int G, int WV, bool tab, dim3 grid, hipStream_t s, const Roll
 void rollout_ped(int G, int WV, bool rss, dim3 grid, hipStream_t s, const RolloutArgs &a);
 // k_crowd.hip: rollout_kernel_crowd<WV> / rollout_kernel_crowd_riders<WV>
 void rollout_crowd(int WV, bool riders, dim3 grid, hipStream_t s, const RolloutArgs &a);
+// k_walk.hip (sgym_walk.hpp): the chunk classifier and the walker variant of the crowd rollout (WVL = 1, 2 wavefronts of
+// active lanes per scenario)
+void walk_classify(dim3 grid, hipStream_t s, const sg::Params &p, const sg::WalkArgs &wa, int chunk_len, int enable_mask);
+void walk_rollout(int WVL, dim3 grid, hipStream_t s, const sg::Params &p, double timestep, int n_steps, int force, const sg::WalkArgs &wa);
 // k_rss.hip: rollout_kernel_rss<G, WV> / rollout_kernel_rss_road<G, WV> (road)
 void rollout_rss(int G, int WV, bool road, dim3 grid, hipStream_t s, const RolloutArgs &a);
 // k_rss_tab.hip: rollout_kernel_rss_tab<G> + rss_lines_kernel

@@ -56,14 +56,17 @@ def export_network(rn):
         for g in gs:
             geoms.setdefault(g.id, [g, 0])[1] |= bit
     rings, ring_off, layers = [], [0], []
-    for g, bits in geoms.values():
+    # sorted by geometry id: the reference walks some of its collections in an order that changes from one interpreter run
+    # to the next, and a fixture must come out the same every time it is regenerated
+    ids = sorted(geoms)
+    for g, bits in (geoms[k] for k in ids):
         rs = [np.array(g.boundary.exterior.coords)[:-1]] + [np.array(i.coords) for i in g.boundary.interiors]
         rings += rs
         ring_off.append(len(rings))
         layers.append(bits)
     vert_off = np.concatenate([[0], np.cumsum([len(r) for r in rings])]).astype(np.int64)
     return dict(ring_off=np.array(ring_off, np.int64), vert_off=vert_off, verts=np.concatenate(rings, axis=0),
-                layers=np.array(layers, np.uint32), ids=np.array(list(geoms)))
+                layers=np.array(layers, np.uint32), ids=np.array(ids))
 
 
 def export_scenario(out, key, s):

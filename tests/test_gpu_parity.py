@@ -1240,6 +1240,69 @@ def test_crowd_kernel_equals_general_pedestrian_kernel(sga, monkeypatch, E, side
     assert np.array_equal(sa["coll"], sb["coll"])
 
 
+@pytest.mark.parametrize("E,side,steps,chunk,noise,late,term", [
+    (256, 14.0, 1200, 50, "off", False, ["max_length"]),
+    (256, 14.0, 900, 37, "device", True, ["max_length"]),
+    (200, 10.0, 800, 64, "stream", False, ["max_length"]),
+    (256, 20.0, 700, 1, "off", True, ["max_length"]),            # a chunk per step: every transition between the kernels
+    (256, 14.0, 600, 100, "off", False, ["max_length", "ego_collision"]),
+    (130, 9.0, 900, 33, "device", False, ["max_length"]),
+])
+def test_crowd_walker_variant_is_invisible(sga, oracle, monkeypatch, E, side, steps, chunk, noise, late, term):
+    """Long rollouts of all-pedestrian scenes run in chunks; scenarios whose pedestrians have mostly arrived are stepped by
+    walk_kernel<1 / 2> (sgym_walk.hpp: lanes for the entities that still change, the arrived ones are LDS rows, their
+    collision rows rewritten from the active side), the others by rollout_kernel_crowd.  SG_CROWD_WALK=0 runs the crowd kernel
+    alone in one launch: same state, metric rows and events, bit for bit -- and both equal the oracle's.  Dense squares (the
+    pedestrians collide and get stuck), odd chunk lengths, late spawns, the three noise modes, a terminal condition that
+    looks at collision rows; the walker kernels must really have run."""
+    import scenario_gym_amd._lib as L
+    from oracle import check
+    from scenario_gym_amd import synthetic
+
+    R, dt = 6, 1 / 30
+    packed = synthetic.make_crowd(R, E, n_steps=steps, side=side)
+    rng = np.random.default_rng(E * 1000 + steps)
+    if late:  # every seventh pedestrian joins the scene later (the spawn rule, scenario_gym.py:240-244)
+        kn = packed.knots.reshape(R * E, 2, 7)
+        kn[::7, 0, 0] = rng.uniform(0.1, 0.6, len(kn[::7])) * steps * dt
+    kw, noise_of = {}, None
+    if noise == "device":
+        kw = dict(social_force=dict(std_lon=0.1, std_lat=0.05, noise="device", noise_seed=11))
+        noise_of = lambda r: dict(mode="device", std_lon=0.1, std_lat=0.05, seed=11, scenario_index=r)  # noqa: E731
+    elif noise == "stream":
+        normals = np.random.RandomState(5).standard_normal((R, 2 * E * (steps + 1)))
+        kw = dict(social_force=dict(std_lon=0.05, std_lat=0.1, noise="stream", normals=normals))
+        noise_of = lambda r: dict(mode="stream", std_lon=0.05, std_lat=0.1, normals=normals[r])  # noqa: E731
+    monkeypatch.setenv("SG_CROWD_CHUNK", str(chunk))
+    monkeypatch.setenv("SG_CROWD_WALK_MIN", "1")
+    out, stats = [], None
+    for walk in ("0", "3"):
+        monkeypatch.setenv("SG_CROWD_WALK", walk)
+        eng = sga.RolloutEngine(R, E, timestep=dt, terminal_conditions=term, event_capacity=256, **kw)
+        eng.upload(packed)
+        eng.rollout(steps)
+        out.append((eng.state(), eng.metrics()))
+        if walk == "3":
+            stats = eng.crowd_walk_stats()
+            tm = 0
+            for name in term:
+                tm |= {"max_length": oracle.TERM_MAX_LENGTH, "ego_collision": oracle.TERM_EGO_COLLISION}[name]
+            ver = check.verify_engine(eng, packed, dt, steps, K=3, event_cap=256, ped=True, noise_of=noise_of, terminal_mask=tm)
+            assert ver["equal"], ver["mismatches"]
+        eng.close()
+    (sa, (ra, ea)), (sb, (rb, eb)) = out
+    for k in ("poses", "vels", "dists", "force", "ctrl_state", "present"):
+        if k in sa:
+            assert bits_equal(sa[k], sb[k]), k
+    assert np.array_equal(sa["coll"], sb["coll"])
+    assert np.array_equal(ea, eb)
+    for k in ra.dtype.names if hasattr(ra, "dtype") and ra.dtype.names else ra.keys():
+        assert bits_equal(np.asarray(ra[k], np.float64), np.asarray(rb[k], np.float64)), k
+    assert stats["chunks_last_call"] == -(-steps // chunk)
+    if "ego_collision" not in term:  # (with it most scenarios end early, possibly before anybody arrives)
+        assert stats["walk1"] + stats["walk2"] > 0, stats
+
+
 def test_negative_zero_pose_delta_keeps_its_sign(sga):
     """velocity = delta / dt (state.py:226-233) for a delta of -0.0 is -0.0: the shared-reciprocal shortcut of the velocity
     division only takes +0 numerators (its fused correction step would turn -0 into +0)."""
