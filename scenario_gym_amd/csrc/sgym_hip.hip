@@ -592,7 +592,7 @@ static int launch_main(sg_handle *h, int n_steps, int do_reset, int force, const
 // 2>, sgym_walk.hpp: one lane per ACTIVE entity, the arrived pedestrians are LDS rows), else rollout_kernel_crowd -- and runs
 // the three kernels side by side; a walker workgroup that meets a case it does not handle stops before that step, and a
 // last launch of rollout_kernel_crowd finishes the chunk for it.  Bit-identical to one launch of rollout_kernel_crowd
-// (SG_CROWD_WALK=0).  SG_CROWD_CHUNK: steps per chunk (default 200); SG_CROWD_WALK: bit 0 walk_kernel<1>, bit 1 <2>.
+// (SG_CROWD_WALK=0, the default).  SG_CROWD_CHUNK: steps per chunk (default 200); SG_CROWD_WALK: bit 0 walk_kernel<1>, bit 1 <2>.
 static int launch_crowd_chunks(sg_handle *h, int n_steps, int do_reset, int force, int enable_mask, size_t *ev_next)
 {
     const int R = h->R;
@@ -606,7 +606,8 @@ static int launch_crowd_chunks(sg_handle *h, int n_steps, int do_reset, int forc
         if ((rc = dev_alloc(h, A, &h->walk.cls, (size_t)R)) || (rc = dev_alloc(h, A, &h->walk.target, (size_t)R)) ||
             (rc = dev_alloc(h, A, &h->walk.n_active, (size_t)R)) || (rc = dev_alloc(h, A, &h->walk.ent, (size_t)R * 128)) ||
             (rc = dev_alloc(h, A, &h->walk.smask, (size_t)R * 4)) ||
-            (rc = dev_alloc(h, A, &h->walk.base, (size_t)R * sg::WALK_SLOTS * 4, false)) || (rc = dev_alloc(h, A, &h->walk.stats, 8)))
+            (rc = dev_alloc(h, A, &h->walk.base, (size_t)R * sg::WALK_SLOTS * 4, false)) || (rc = dev_alloc(h, A, &h->walk.stats, 8)) ||
+            (rc = dev_alloc(h, A, &h->walk.stats64, 16)))
             return rc;
         h->walk_R = R;
     }
@@ -703,8 +704,10 @@ static int launch_rollout_impl(sg_handle *h, int n_steps, int do_reset, int forc
             rc = launch_main(h, std::min(h->rssq_steps, n_steps - k0), k0 == 0 ? do_reset : 0, force,
                              d_actions ? d_actions + (size_t)k0 * h->R * 2 : nullptr, nullptr, false, &ev_next);
     } else if (!use_tab && h->has_ped && h->all_ped && h->G == 64 && h->WV == 4 && !h->has_road && h->crowd_kernel && !h->rss_fused &&
-               h->p.rec_cap == 0 && !d_actions && n_steps >= env_int("SG_CROWD_WALK_MIN", 64) && env_int("SG_CROWD_WALK", 3) != 0) {
-        rc = launch_crowd_chunks(h, n_steps, do_reset, force, env_int("SG_CROWD_WALK", 3) & 3, &ev_next);
+               h->p.rec_cap == 0 && !d_actions && n_steps >= env_int("SG_CROWD_WALK_MIN", 64) && (env_int("SG_CROWD_WALK", 0) & 3) != 0) {
+        // (OFF by default: on 1024 scenarios the walker kernels are one wavefront per SIMD and, measured, no faster than
+        // rollout_kernel_crowd -- HISTORY.md, round 4; SG_CROWD_WALK=3 switches the dispatch on, the parity tests do)
+        rc = launch_crowd_chunks(h, n_steps, do_reset, force, env_int("SG_CROWD_WALK", 0) & 3, &ev_next);
     } else if (!use_tab) {
         rc = launch_main(h, n_steps, do_reset, force, d_actions, nullptr, false, &ev_next);
     } else {
@@ -1910,6 +1913,17 @@ extern "C" int sg_crowd_walk_stats(sg_handle *h, int32_t *out, int32_t reset)
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     HIP_TRY(h, hipMemcpy(out, h->walk.stats, 8 * sizeof(int32_t), hipMemcpyDeviceToHost));
     out[7] = h->last_walk_chunks;
+#ifdef SG_WALK_TIMERS
+    {
+        unsigned long long c[16], tot = 0;
+        (void)hipMemcpy(c, h->walk.stats64, sizeof c, hipMemcpyDeviceToHost);
+        for (int i = 0; i < 16; ++i) tot += c[i];
+        fprintf(stderr, "walker phase cycles:");
+        for (int i = 0; i < 16; ++i) if (c[i]) fprintf(stderr, " [%d] %.1f%%", i, 100.0 * c[i] / tot);
+        fprintf(stderr, "  raw [1] %.4e [7] %.4e [14] %.4e", (double)c[1], (double)c[7], (double)c[14]);
+        fprintf(stderr, "  total %.3e\n", (double)tot);
+    }
+#endif
     if (reset) HIP_TRY(h, hipMemset(h->walk.stats, 0, 8 * sizeof(int32_t)));
     return SG_OK;
 }

@@ -35,10 +35,11 @@ struct WalkArgs {
     int8_t *cls;            // [R] class of the scenario in this chunk
     int32_t *target;        // [R] steps-since-reset at which the chunk ends
     int32_t *n_active;      // [R]
-    uint8_t *ent;           // [R][128] entity of active lane l (ascending), 255 = padding
+    uint8_t *ent;           // [R][128] entity of active lane l (ascending), the first n_active entries
     uint64_t *smask;        // [R][4] entities at their fixed point ("statics")
     uint64_t *base;         // [R][256][4] collision row of a static restricted to statics (constant while they are static)
     int32_t *stats;         // [8] counters: scenarios per class, bails (diagnostics)
+    unsigned long long *stats64; // [16] experiment builds: phase cycles
 };
 
 // Is entity e of block `blk` (64-slot state block) at the fixed point?  All from memory: the state the previous launch left.
@@ -86,7 +87,7 @@ static __global__ __launch_bounds__(256) void walk_classify_kernel(Params p, Wal
     active = active || (kind != SG_KIND_NONE && (e == 0 || e == ss.ego)); // terminal conditions look at entity 0, metrics at the ego
     const bool stat = stat_ && !active;
     // what the walker variant does not do: other kinds, a pedestrian with a head rotation or a radius outside crowd_pair's
-    // guards, statics far from the origin (stripe range: checked per step for the active ones)
+    // guards
     bool odd = kind != SG_KIND_NONE && kind != SG_KIND_AGENT_PEDESTRIAN;
     odd = odd || (kind != SG_KIND_NONE && ((meta >> 8) & 0xff) != 1);
     if (kind == SG_KIND_AGENT_PEDESTRIAN) {
@@ -134,7 +135,6 @@ static __global__ __launch_bounds__(256) void walk_classify_kernel(Params p, Wal
     if (usable && n_act <= 64 && (enable_mask & 1)) cls = 1;
     else if (usable && n_act <= 128 && (enable_mask & 2)) cls = 2;
     if (active && before < 128) wa.ent[(size_t)r * 128 + before] = (uint8_t)e;
-    if (e >= n_act && e < 128) wa.ent[(size_t)r * 128 + e] = 255;
     // base rows: the hits among statics (they stay as they are while both stay static)
     if (cls != 0) {
         uint64_t *b = wa.base + ((size_t)r * WALK_SLOTS + e) * 4;
@@ -156,13 +156,12 @@ static __global__ __launch_bounds__(256) void walk_classify_kernel(Params p, Wal
 template <int WVL>
 struct WalkLds {
     static constexpr int NL = 64 * WVL;
-    static constexpr int PAIR_CAP = 128;
-    float cx[WALK_SLOTS], cy[WALK_SLOTS]; // box centres (NaN: absent)
+    static constexpr int PAIR_CAP = 320; // pairs a wavefront can hand over to its idle lanes (4 B + 16 B each)
+    float cx[WALK_SLOTS], cy[WALK_SLOTS]; // box centres (NaN: absent), SoA: the all-pairs walk reads four consecutive slots at once
     float2 sc[WALK_SLOTS];                // sin, cos of the heading
     float2 half[WALK_SLOTS];              // half length, half width
     double px[WALK_SLOTS], py[WALK_SLOTS], hd[WALK_SLOTS]; // reference point (px NaN: absent), heading
     double ox[WALK_SLOTS], oy[WALK_SLOTS], sx[WALK_SLOTS], sy[WALK_SLOTS], ss[WALK_SLOTS]; // crowd_pair's per-neighbour terms
-    unsigned long long xtab[64][WALK_NW], ytab[64][WALK_NW];
     unsigned long long wbits[WALK_SLOTS][WVL], wprev[WALK_SLOTS][WVL]; // statics: active lanes that hit them (this / previous step)
     unsigned char lane_of[WALK_SLOTS];    // 255: the entity has no lane
     unsigned char ent_of[NL];
@@ -170,8 +169,18 @@ struct WalkLds {
     double r2hi[NL], r2lo[NL], rad[NL];   // radius rule of the lane's pedestrian
     int vote[4][WVL];
     int misc[8];
+    double gon[128];                      // cos, sin of 2 pi i / 64 (p.gon): the 64-gon of the radius rule, read in the pair loop
     alignas(16) char pair_scratch[WVL][PAIR_CAP * 20]; // (the results of handed-over pairs are double2: 16-byte LDS accesses)
 };
+
+// experiment builds (-DSG_WALK_TIMERS): cycles per phase of the walker step, summed over wavefronts into wa.stats64[16]
+#ifdef SG_WALK_TIMERS
+struct WalkTimers { unsigned long long acc[16], last; };
+#define WT(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); wt.acc[i] += now_ - wt.last; wt.last = now_; } while (0)
+#else
+struct WalkTimers {};
+#define WT(i) ((void)0)
+#endif
 
 template <int WVL>
 __device__ __forceinline__ void walk_sync()
@@ -198,11 +207,15 @@ __device__ __forceinline__ int walk_vote(WalkLds<WVL> &L, int site, bool b0, boo
 // candidate row (256 entity bits) walked as a queue of its non-empty 32-bit words.  Same pair arithmetic, same order of the
 // sums.  `ql` = this lane's column of the per-lane tables; a pair outside crowd_pair's guards raises `bail` (the caller stops
 // before the step is committed) instead of being recomputed here.
-template <int WVL>
+// ILP: (pedestrian, neighbour) pairs a lane evaluates per round of the loop (one LDS round trip for the operands of all of
+// them).  (The pair arithmetic itself gains nothing from more chains side by side: tools/dbg/pair_bench.hip measures ~700
+// cycles per pair for one chain of a wavefront that is alone on its SIMD -- 160 instructions at the fp64 issue rate -- and the
+// same with 2, 4 or 8 interleaved chains, crowd_pair_n.)
+template <int WVL, int ILP>
 __device__ __forceinline__ void walk_pairs(const Params &p, WalkLds<WVL> &L, const CrowdConsts &C, int e, int ql,
-                                           const uint64_t (&nbr)[WALK_NW], bool go, double &fx, double &fy, bool &bail)
+                                           const uint64_t (&nbr)[WALK_NW], bool go, double &fx, double &fy, bool &bail, WalkTimers &wt)
 {
-    constexpr int CAP = WalkLds<WVL>::PAIR_CAP, ND = 2 * WALK_NW, ILP = 2;
+    constexpr int CAP = WalkLds<WVL>::PAIR_CAP, ND = 2 * WALK_NW;
     const int lane = threadIdx.x & 63, wave = WVL == 1 ? 0 : (int)(threadIdx.x >> 6);
     uint32_t *list = reinterpret_cast<uint32_t *>(L.pair_scratch[wave]);
     double2 *res = reinterpret_cast<double2 *>(list + CAP);
@@ -223,6 +236,9 @@ __device__ __forceinline__ void walk_pairs(const Params &p, WalkLds<WVL> &L, con
     for (int o = 1; o < 64; o <<= 1) total += __shfl_xor(total, o, 64);
     if (total == 0) return; // wave-uniform
     const int T = (total + 63) >> 6;
+#ifdef SG_WALK_TIMERS
+    wt.acc[1] += (unsigned long long)total; // (a count: candidate pairs of the wavefront)
+#endif
     const int excess = max(n - T, 0), spare = max(T - n, 0);
     int scan = excess | (spare << 16);
 #pragma unroll
@@ -237,6 +253,7 @@ __device__ __forceinline__ void walk_pairs(const Params &p, WalkLds<WVL> &L, con
     const int h_end = min((scan >> 16), listed_all);
     const int keep = n - out;
     tile_sync<1>();
+    WT(12);
     if (sg_any(out > 0)) { // hand over the LAST `out` neighbours, written in entity order
         int qe = nw - 1;
         uint32_t curh = L.nq[max(qe, 0)][ql];
@@ -254,10 +271,14 @@ __device__ __forceinline__ void walk_pairs(const Params &p, WalkLds<WVL> &L, con
         }
     }
     tile_sync<1>();
+    WT(13);
     const int wave_ql = ql - lane; // column of lane 0 of this wavefront
     int k = 0, qi = 0;
     uint32_t cur = L.nq[0][ql];
     while (sg_any((k < keep) | (h < h_end))) {
+#ifdef SG_WALK_TIMERS
+        wt.acc[7] += ILP; // (a count, not cycles: pair evaluations per lane)
+#endif
         bool own[ILP], help[ILP], act[ILP], bad[ILP], ring[ILP];
         int jj[ILP], oq[ILP], oe[ILP], hi_[ILP];
         uint32_t ent[ILP];
@@ -298,7 +319,7 @@ __device__ __forceinline__ void walk_pairs(const Params &p, WalkLds<WVL> &L, con
         if (sg_any(any_ring)) { // rare: between the inscribed circle and the vertices of the 64-gon Point.buffer(r)
 #pragma unroll
             for (int u = 0; u < ILP; ++u)
-                if (ring[u]) act[u] = sg_in_radius(L.px[oe[u]], L.py[oe[u]], L.rad[oq[u]], L.px[jj[u]], L.py[jj[u]], p.gon);
+                if (ring[u]) act[u] = sg_in_radius(L.px[oe[u]], L.py[oe[u]], L.rad[oq[u]], L.px[jj[u]], L.py[jj[u]], L.gon);
         }
 #pragma unroll
         for (int u = 0; u < ILP; ++u) any_bad |= bad[u] & act[u];
@@ -317,6 +338,7 @@ __device__ __forceinline__ void walk_pairs(const Params &p, WalkLds<WVL> &L, con
         }
     }
     tile_sync<1>();
+    WT(14);
     for (int q = 0; sg_any(q < out); ++q) {
         if (q < out) {
             const uint32_t en = list[e0 + q];
@@ -328,6 +350,7 @@ __device__ __forceinline__ void walk_pairs(const Params &p, WalkLds<WVL> &L, con
         }
     }
     tile_sync<1>();
+    WT(15);
 }
 
 // What a lane needs to know about itself for the collision pass (constant over the launch)
@@ -335,7 +358,7 @@ struct WalkLane {
     int e;                  // entity slot, -1: idle lane
     bool is_ped_type;
     double bcx, bcy, bw, bl;
-    float rad_thr, trig_eps, nbr_thr, cell_inv, hl, hw;
+    float rad_thr, trig_eps, nbr_thr, hl, hw;
 };
 
 // State.collisions() of the active lanes against every entity + the neighbour candidates of the coming step, for the state
@@ -344,8 +367,8 @@ struct WalkLane {
 template <int WVL>
 __device__ __forceinline__ void walk_collisions(const Params &p, WalkLds<WVL> &L, const WalkLane &W, int r, bool npres,
                                                 double x, double y, double h, double vx, double vy, double dtn,
-                                                int &oix, int &oiy, bool &in_tab, bool scatter, uint64_t (&rows)[WALK_NW],
-                                                uint64_t (&nbr)[WALK_NW], bool &bail, int &n_static_hits)
+                                                bool scatter, uint64_t (&rows)[WALK_NW],
+                                                uint64_t (&nbr)[WALK_NW], bool &bail, int &n_static_hits, WalkTimers &wt)
 {
     const int tid = threadIdx.x, lane = tid & 63;
     const int e = W.e;
@@ -363,9 +386,6 @@ __device__ __forceinline__ void walk_collisions(const Params &p, WalkLds<WVL> &L
     const float thr = reach * reach;
     const float nreach = W.nbr_thr + 1.9073486e-6f * mag;
     const float nthr = nreach * nreach;
-    const float ax = fx * W.cell_inv, ay = fy * W.cell_inv;
-    const int ix = pres ? (int)__builtin_floorf(ax) : 0, iy = pres ? (int)__builtin_floorf(ay) : 0;
-    const bool far_out = pres && !(__builtin_fabsf(ax) < 4000.0f && __builtin_fabsf(ay) < 4000.0f);
     // the neighbour's terms of the repulsion, once per neighbour (tile_collisions)
     const double vmag = sg_norm2(vx, vy) + 0.0000000001;
     const double uox = vx / vmag, uoy = vy / vmag, stp = vmag * dtn;
@@ -382,16 +402,6 @@ __device__ __forceinline__ void walk_collisions(const Params &p, WalkLds<WVL> &L
         L.hd[e] = h;
         L.ox[e] = uox; L.oy[e] = uoy;
         L.sx[e] = sxx; L.sy[e] = syy; L.ss[e] = stp * stp;
-        // stripe membership: moved between cells, appeared, vanished
-        const uint64_t bit = 1ull << (e & 63);
-        const int wd = e >> 6;
-        if (in_tab && (!pres || ix != oix)) atomicAnd(&L.xtab[oix & 63][wd], ~bit);
-        if (in_tab && (!pres || iy != oiy)) atomicAnd(&L.ytab[oiy & 63][wd], ~bit);
-        if (pres && (!in_tab || ix != oix)) atomicOr(&L.xtab[ix & 63][wd], bit);
-        if (pres && (!in_tab || iy != oiy)) atomicOr(&L.ytab[iy & 63][wd], bit);
-        in_tab = pres;
-        oix = ix;
-        oiy = iy;
     }
     // the statics' step * step: |v| + 1e-10 with v = 0, times THIS step's dt (social_force.py:148-155)
     {
@@ -404,31 +414,67 @@ __device__ __forceinline__ void walk_collisions(const Params &p, WalkLds<WVL> &L
     }
 #pragma unroll
     for (int w = 0; w < WALK_NW; ++w) { rows[w] = 0; nbr[w] = 0; }
-    if (walk_vote<WVL>(L, 0, far_out | insane)) { bail = true; return; } // (uniform)
+    WT(8);
+    if (walk_vote<WVL>(L, 0, insane)) { bail = true; return; } // (uniform; the vote also publishes the LDS rows above)
     if (WVL == 1) walk_sync<WVL>();
+    // ---- broad phase: every lane against all 256 slots, wave-uniform LDS broadcast reads of four slots at a time, packed
+    // fp32 (tile_collisions, all_pairs): a fixed ~1.4 k instructions without a single dependent LDS round trip -- the walker
+    // wavefront is alone on its SIMD, the per-candidate loops of the stripe-mask variant ran at the LDS latency.  No
+    // coordinate range to respect either.  Absent slots hold NaN centres: whatever their sign bit says, the filter and the
+    // pair loop drop them (NaN-safe compares), as in the wide tiles of tile_collisions. ----
     uint64_t close[WALK_NW];
     bool any_cand = false;
+    {
+        const v2f fx2 = {fx, fx}, fy2 = {fy, fy}, thr2 = {thr, thr}, nthr2 = {nthr, nthr};
+        constexpr int TS = WALK_SLOTS, NW32 = TS / 32, PER = 8;
+        uint32_t out_w[NW32], nout_w[NW32]; // bit j = 1: slot j is OUTSIDE this lane's reach
+        v4f xs = *reinterpret_cast<const v4f *>(&L.cx[TS - 4]);
+        v4f ys = *reinterpret_cast<const v4f *>(&L.cy[TS - 4]);
+        v4f xs1 = *reinterpret_cast<const v4f *>(&L.cx[TS - 8]);
+        v4f ys1 = *reinterpret_cast<const v4f *>(&L.cy[TS - 8]);
 #pragma unroll
-    for (int w = 0; w < WALK_NW; ++w) {
-        uint64_t mx = L.xtab[(ix - 1) & 63][w] | L.xtab[ix & 63][w] | L.xtab[(ix + 1) & 63][w];
-        uint64_t my = L.ytab[(iy - 1) & 63][w] | L.ytab[iy & 63][w] | L.ytab[(iy + 1) & 63][w];
-        uint64_t m = mx & my;
-        if ((es >> 6) == w) m &= ~(1ull << (es & 63));
-        uint64_t cand = pres ? m : 0;
-        close[w] = 0;
-        while (sg_any(cand != 0)) {
-            if (cand) {
-                const int jl = __builtin_ctzll(cand);
-                cand &= cand - 1;
-                const int j = w * 64 + jl;
-                const float dx = L.cx[j] - fx, dy = L.cy[j] - fy;
-                const float d2 = __builtin_fmaf(dy, dy, dx * dx);
-                if (d2 <= thr) close[w] |= 1ull << jl;
-                if (d2 <= nthr) nbr[w] |= 1ull << jl;
+        for (int w2 = NW32 - 1; w2 >= 0; --w2) {
+            uint32_t w = 0u, v = 0u;
+#pragma unroll 1 // (a real loop: unrolled, the 128 LDS reads of the walk are hoisted to its top and take hundreds of registers)
+            for (int q = PER - 1; q >= 0; --q) {
+                const int jb = w2 * 32 + q * 4;
+                v4f xs2 = xs1, ys2 = ys1; // two groups of four slots stay in flight
+                if (jb >= 8) {
+                    xs2 = *reinterpret_cast<const v4f *>(&L.cx[jb - 8]);
+                    ys2 = *reinterpret_cast<const v4f *>(&L.cy[jb - 8]);
+                }
+                v2f dxa = v2f{xs.x, xs.y} - fx2, dya = v2f{ys.x, ys.y} - fy2;
+                v2f dxb = v2f{xs.z, xs.w} - fx2, dyb = v2f{ys.z, ys.w} - fy2;
+                v2f d2a = __builtin_elementwise_fma(dya, dya, dxa * dxa);
+                v2f d2b = __builtin_elementwise_fma(dyb, dyb, dxb * dxb);
+                v2f ma = thr2 - d2a, mb = thr2 - d2b;
+                w = __builtin_amdgcn_alignbit(w, __float_as_uint(mb.y), 31); // w = (w << 1) | sign
+                w = __builtin_amdgcn_alignbit(w, __float_as_uint(mb.x), 31);
+                w = __builtin_amdgcn_alignbit(w, __float_as_uint(ma.y), 31);
+                w = __builtin_amdgcn_alignbit(w, __float_as_uint(ma.x), 31);
+                v2f na = nthr2 - d2a, nb = nthr2 - d2b;
+                v = __builtin_amdgcn_alignbit(v, __float_as_uint(nb.y), 31);
+                v = __builtin_amdgcn_alignbit(v, __float_as_uint(nb.x), 31);
+                v = __builtin_amdgcn_alignbit(v, __float_as_uint(na.y), 31);
+                v = __builtin_amdgcn_alignbit(v, __float_as_uint(na.x), 31);
+                xs = xs1; ys = ys1;
+                xs1 = xs2; ys1 = ys2;
             }
+            out_w[w2] = w;
+            nout_w[w2] = v;
+            __builtin_amdgcn_sched_barrier(0); // (else every LDS read of the walk is hoisted to its top: hundreds of registers)
         }
-        any_cand = any_cand || close[w] != 0;
+#pragma unroll
+        for (int w = 0; w < WALK_NW; ++w) {
+            uint64_t inside = ~(((uint64_t)out_w[2 * w + 1] << 32) | out_w[2 * w]);
+            uint64_t nin = ~(((uint64_t)nout_w[2 * w + 1] << 32) | nout_w[2 * w]);
+            if ((es >> 6) == w) { inside &= ~(1ull << (es & 63)); nin &= ~(1ull << (es & 63)); } // not with itself
+            close[w] = pres ? inside : 0;
+            nbr[w] = (pres && W.nbr_thr > 0.0f) ? nin : 0;
+            any_cand = any_cand || close[w] != 0;
+        }
     }
+    WT(9);
     // ---- fp32 SAT filter (tile_collisions) ----
     uint64_t fuzzy[WALK_NW];
 #pragma unroll
@@ -464,6 +510,7 @@ __device__ __forceinline__ void walk_collisions(const Params &p, WalkLds<WVL> &L
             any_fuzzy = any_fuzzy || fuzzy[w] != 0;
         }
     }
+    WT(10);
     // ---- exact fp64 SAT on the pairs inside the margin; the partner's corners from its LDS pose + its static rows ----
     bool eq = false;
     if (sg_any(any_fuzzy)) {
@@ -493,6 +540,7 @@ __device__ __forceinline__ void walk_collisions(const Params &p, WalkLds<WVL> &L
             }
         }
     }
+    WT(11);
     if (sg_any(eq)) bail = true; // (made uniform by the caller's vote)
     // ---- the same hits from the statics' side ----
     n_static_hits = 0;
@@ -526,8 +574,8 @@ __device__ __forceinline__ void walk_body(const Params &p, double timestep, int 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int step_target = wa.target[r];
     const int n_act = wa.n_active[r];
-    const int e_raw = tid < 128 ? (int)wa.ent[(size_t)r * 128 + tid] : 255;
-    const bool act = tid < n_act && e_raw != 255;
+    const int e_raw = tid < 128 ? (int)wa.ent[(size_t)r * 128 + tid] : 0;
+    const bool act = tid < n_act; // (every value 0..255 of the list is an entity: the count says where it ends)
     const int e = act ? e_raw : -1, es = act ? e_raw : 0;
     const ScenStatic &ss = p.sstat[r];
     sg_scenario_state &sd = p.sdyn[r];
@@ -604,10 +652,6 @@ __device__ __forceinline__ void walk_body(const Params &p, double timestep, int 
             L.wprev[s][w] = other ? ~0ull : 0ull;
         }
     }
-    for (int k = tid; k < 64 * WALK_NW; k += NL) {
-        reinterpret_cast<unsigned long long *>(L.xtab)[k] = 0ull;
-        reinterpret_cast<unsigned long long *>(L.ytab)[k] = 0ull;
-    }
     // workgroup maxima (every lane needs them for its reach)
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -635,24 +679,7 @@ __device__ __forceinline__ void walk_body(const Params &p, double timestep, int 
         W.hl = (float)(0.5 * W.bl);
         W.hw = (float)(0.5 * W.bw);
     }
-    // broad-phase cell: >= every reach of the scenario.  rollout_kernel_crowd takes the maximum over its lanes' reaches; any
-    // cell at least that large gives the same (conservative) candidate sets' supersets, hence the same results
-    {
-        float tmax = __builtin_fmaxf(W.rad_thr, W.nbr_thr);
-        // statics may have a larger radius than any active lane: bound with the scenario's largest radius on both sides
-        tmax = __builtin_fmaxf(tmax, 2.0f * rmax + 2e-3f + 4.0f * SG_TRIG32_ERR * omax);
-        float rmaxr = act ? tmax : 0.0f;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) rmaxr = __builtin_fmaxf(rmaxr, __shfl_xor(rmaxr, o, 64));
-        if (WVL > 1) {
-            float *red = reinterpret_cast<float *>(L.pair_scratch[0]);
-            if (lane == 0) red[wave] = rmaxr;
-            __syncthreads();
-            for (int w = 0; w < WVL; ++w) rmaxr = __builtin_fmaxf(rmaxr, red[w]);
-            __syncthreads();
-        }
-        W.cell_inv = 1.0f / (1.05f * rmaxr + 0.05f);
-    }
+    for (int k = tid; k < 128; k += NL) L.gon[k] = p.gon[k];
     walk_sync<WVL>();
     if (act) {
         L.lane_of[e] = (unsigned char)tid;
@@ -666,18 +693,7 @@ __device__ __forceinline__ void walk_body(const Params &p, double timestep, int 
         L.r2hi[tid] = 0.0; L.r2lo[tid] = 0.0; L.rad[tid] = 0.0;
     }
     walk_sync<WVL>();
-    // statics into the stripe tables (their cells never change); far-away statics were refused by the classifier
     bool bail = false;
-    for (int k = 0; k < WALK_SLOTS / NL; ++k) {
-        const int s = tid + k * NL;
-        if ((smask[s >> 6] >> (s & 63)) & 1) {
-            const float ax = L.cx[s] * W.cell_inv, ay = L.cy[s] * W.cell_inv;
-            if (!(__builtin_fabsf(ax) < 4000.0f && __builtin_fabsf(ay) < 4000.0f)) bail = true;
-            const int ix = (int)__builtin_floorf(ax), iy = (int)__builtin_floorf(ay);
-            atomicOr(&L.xtab[ix & 63][s >> 6], 1ull << (s & 63));
-            atomicOr(&L.ytab[iy & 63][s >> 6], 1ull << (s & 63));
-        }
-    }
     // ---- the lane's state from memory (rollout_body, continuing launch) ----
     CrowdConsts CC{};
     {
@@ -714,15 +730,22 @@ __device__ __forceinline__ void walk_body(const Params &p, double timestep, int 
     }();
     sg_loads_done();
     // ---- opening pass: LDS entries, stripe membership and neighbour candidates of the state in memory ----
-    int oix = 0, oiy = 0, n_hits = 0;
-    bool in_tab = false;
+    WalkTimers wt;
+#ifdef SG_WALK_TIMERS
+    for (int i = 0; i < 16; ++i) wt.acc[i] = 0;
+    wt.last = __builtin_amdgcn_s_memtime();
+#endif
+    int n_hits = 0;
     {
         uint64_t tmp[WALK_NW];
-        walk_collisions<WVL>(p, L, W, r, present, pose[0], pose[1], pose[3], velx, vely, (t + timestep) - t, oix, oiy, in_tab, false,
-                             tmp, nbr, bail, n_hits);
+        walk_collisions<WVL>(p, L, W, r, present, pose[0], pose[1], pose[3], velx, vely, (t + timestep) - t, false,
+                             tmp, nbr, bail, n_hits, wt);
         bail = walk_vote<WVL>(L, 1, bail) != 0;
     }
     const double *Kp = SG_TRIG;
+#ifdef SG_WALK_TIMERS
+    wt.last = __builtin_amdgcn_s_memtime();
+#endif
     bool first_store = true; // this launch has not stored its velocity z / pitch / roll rows yet
     for (int k = 0; k < n_steps && !bail; ++k) {
         if (!((force || !done) && steps < step_target)) break; // (uniform: one scenario per workgroup)
@@ -748,7 +771,9 @@ __device__ __forceinline__ void walk_body(const Params &p, double timestep, int 
             }
         }
         bool pbail = false;
-        walk_pairs<WVL>(p, L, CC, es, tid, nbr, go, fx, fy, pbail);
+        WT(0);
+        walk_pairs<WVL, 2>(p, L, CC, es, tid, nbr, go, fx, fy, pbail, wt);
+        WT(1);
         // ---- random fluctuations (rollout_body) ----
         double speed_rand = p.sf.bias_lon, heading_rand = p.sf.bias_lat;
         if (p.noise_mode == 1) {
@@ -810,12 +835,14 @@ __device__ __forceinline__ void walk_body(const Params &p, double timestep, int 
         }
 #pragma unroll
         for (int c = 0; c < 6; ++c) vel[c] = d[c] / dt;
+        WT(2);
         // ---- State.collisions of the new state; nothing of this step has been stored yet ----
         uint64_t nrow[WALK_NW], nnbr[WALK_NW];
         bool cbail = pbail;
-        walk_collisions<WVL>(p, L, W, r, npres, np_[0], np_[1], np_[3], vel[0], vel[1], (next_t + timestep) - next_t, oix, oiy, in_tab,
-                             true, nrow, nnbr, cbail, n_hits);
+        walk_collisions<WVL>(p, L, W, r, npres, np_[0], np_[1], np_[3], vel[0], vel[1], (next_t + timestep) - next_t,
+                             true, nrow, nnbr, cbail, n_hits, wt);
         if (walk_vote<WVL>(L, 1, cbail)) { bail = true; break; }
+        WT(3);
         // ---- commit ----
         const bool was_present = present;
         (void)was_present;
@@ -847,6 +874,7 @@ __device__ __forceinline__ void walk_body(const Params &p, double timestep, int 
             for (int w = 0; w < WALK_NW; ++w) stf(dy, SG_F_COLL + w, row[w]);
         }
         first_store = false;
+        WT(4);
         // ---- the rows of the statics the active lanes touch (or touched in the previous step) ----
         walk_sync<WVL>();
         for (int q = 0; q < WALK_SLOTS / NL; ++q) {
@@ -876,6 +904,7 @@ __device__ __forceinline__ void walk_body(const Params &p, double timestep, int 
                 for (int v = 0; v < 4; ++v) reinterpret_cast<uint64_t *>(drow)[(SG_F_COLL + v) * 64] = rw[v];
             }
         }
+        WT(5);
         // ---- ego metrics, scenario_gym.py:251-252 ----
         if (is_ego && present) {
             const double speed = sg_norm3(vel[0], vel[1], vel[2]);
@@ -921,7 +950,11 @@ __device__ __forceinline__ void walk_body(const Params &p, double timestep, int 
                 last_row[w] = row[w];
             }
         }
+        WT(6);
     }
+#ifdef SG_WALK_TIMERS
+    if (lane == 0 && wa.stats64) for (int i = 0; i < 16; ++i) if (wt.acc[i]) atomicAdd(wa.stats64 + i, wt.acc[i]);
+#endif
     (void)first_store;
     // ---- write back what lives in registers ----
     if (act) {

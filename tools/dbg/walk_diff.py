@@ -39,3 +39,14 @@ if differs(sa, sb):
     r, e = idx[0][0], idx[0][1] if len(idx[0]) > 1 else 0
     print("scenario", r, "entity", e, "full:", sa["poses"][r, e], sa["vels"][r, e], sa["ctrl_state"][r, e], hex(int(sa["coll"][r, e, 0])))
     print("                     walk:", sb["poses"][r, e], sb["vels"][r, e], sb["ctrl_state"][r, e], hex(int(sb["coll"][r, e, 0])))
+    # who are the neighbours of the differing entities in the state before the step?
+    s0, *_ = run(hi - 1, "0")
+    bad = sorted({(i[0], i[1]) for i in np.argwhere(~((sa["force"] == sb["force"]) | ((sa["force"] != sa["force"]) & (sb["force"] != sb["force"]))))})
+    P = s0["poses"]; V = s0["vels"]; C = s0["ctrl_state"]
+    for (r, e) in bad[:12]:
+        d = np.hypot(P[r, :, 0] - P[r, e, 0], P[r, :, 1] - P[r, e, 1])
+        nb = [j for j in np.argsort(d) if j != e and d[j] <= 3.0]
+        stat = [(int(j), bool((V[r, j] == 0).all() and C[r, j, 1] > 1 and P[r, j, 3] == 0 and C[r, j, 0] == 0)) for j in nb]
+        print("r", r, "e", e, "goal", C[r, e, 1], "n_nb", len(nb), "force full", sa["force"][r, e], "walk", sb["force"][r, e], "nbrs (j, static):", stat)
+    act = [(r, int((~((V[r] == 0).all(1) & (C[r, :, 1] > 1) & (P[r, :, 3] == 0) & (C[r, :, 0] == 0))).sum())) for r in range(R)]
+    print("active per scenario", act)
