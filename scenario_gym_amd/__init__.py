@@ -31,6 +31,7 @@ from .gym import BatchedScenarioGym, ScenarioGym  # noqa: F401
 from .metrics import (  # noqa: F401
     RSS, CollisionMetric, CollisionPointMetric, EgoAvgSpeed, EgoDistanceTravelled, EgoMaxSpeed, Metric, RSSDistances, StateCallback,
 )
+from .actions import FixedTAction, ScenarioAction, UpdateStateVariableAction, UserDefinedAction  # noqa: F401
 from .scenario import Scenario  # noqa: F401
 from .state import State  # noqa: F401
 from .trajectory import Trajectory  # noqa: F401

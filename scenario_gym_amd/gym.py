@@ -67,7 +67,31 @@ class BatchedScenarioGym:
     def _per_step_host_path(self) -> bool:
         custom_metric = any(not isinstance(m, _DeviceMetric) for ms in self.metrics for m in ms)
         return bool(custom_metric or self._host_callbacks or self._host_terminals() or self._host_agents
-                    or self._policy_agents)
+                    or self._policy_agents or self._custom_actions())
+
+    def _custom_actions(self) -> bool:
+        """Some scenario carries an action whose trigger / effect is the caller's own code (not one of the time-triggered
+        classes of actions.py): State.update_actions then runs after every tick, like any other Python extension."""
+        from .actions import time_triggered
+
+        return any(time_triggered(a) is None for st in getattr(self, "states", ()) for a in st.scenario.actions)
+
+    def _replay_actions(self, before):
+        """State.update_actions for the steps a multi-step device call just ran: the clock of scenario i after each of them is
+        t + dt + dt + ... (scenario_gym.py:229, the additions of the step loop), so the time-triggered actions fire at the
+        same State.t -- bit for bit -- as when the scenario is stepped one tick at a time."""
+        if not any(st.unapplied_actions for st in self.states):
+            return
+        now = self._fetch_state()
+        for i, st in enumerate(self.states):
+            if not st.unapplied_actions:
+                continue
+            t, k = float(before["t"][i]), int(now["n_steps"][i]) - int(before["n_steps"][i])
+            clock = []
+            for _ in range(max(k, 0)):
+                t = t + self._timestep
+                clock.append(t)
+            st._replay_actions(clock)
 
     def _push_host_agents(self, actions):
         """scenario_gym.py:233-239 for the agents that run in Python.  Pose agents: agent.step(state) of every present
@@ -297,6 +321,10 @@ class BatchedScenarioGym:
         return self._rec
 
     def _reset_host_side(self):
+        for st in self.states:  # State.reset: _reset_data, ..., update_actions() at t0 (state.py:106-143)
+            st._reset_actions()
+            if st.unapplied_actions:
+                st.update_actions()
         for i, _, agent in self._host_agents:  # Agent.reset -> sensor / controller reset (scenario_gym.py:217-225)
             agent.reset(self.states[i])
         for i, agent in self._policy_agents:
@@ -319,6 +347,8 @@ class BatchedScenarioGym:
     def _after_host_step(self):
         done_host = np.zeros(len(self.states), bool)
         for i, (st, ms) in enumerate(zip(self.states, self.metrics)):
+            if st.unapplied_actions:  # State.step: update_poses, update_actions, update_callbacks, check_terminal (state.py:165-171)
+                st.update_actions()
             for cb in self._host_callbacks:
                 cb(st)
             done_host[i] = any(c(st) for c in self._host_terminals())
@@ -330,13 +360,19 @@ class BatchedScenarioGym:
     def step(self, actions=None, n: int = 1):
         """n x ScenarioGym.step() for every scenario; actions [n, R, 2] for ExternalVehicleAgent egos."""
         if n == 1 or not self._per_step_host_path():
-            self._prev_state = self._fetch_state() if self._per_step_host_path() or n == 1 else None
+            has_actions = any(st.unapplied_actions for st in self.states)
+            self._prev_state = self._fetch_state() if self._per_step_host_path() or n == 1 or has_actions else None
+            before = self._prev_state
             if n == 1:
                 actions = self._push_host_agents(actions)
             self.engine.step(n, actions)
             self._invalidate()
             if self._per_step_host_path():
                 self._after_host_step()
+            elif has_actions:
+                self._replay_actions(before)
+            if n > 1 and not self._per_step_host_path():
+                self._prev_state = None
             return
         actions = None if actions is None else np.asarray(actions, np.float64).reshape(n, len(self.states), 2)
         for k in range(n):
@@ -348,6 +384,21 @@ class BatchedScenarioGym:
         if not self._per_step_host_path():
             self.engine.rollout(max_steps)
             self._invalidate()
+            if any(st.scenario.actions for st in self.states):  # the reset's update_actions(), then one per executed step
+                now = self._fetch_state()
+                for st in self.states:
+                    st._reset_actions()
+                # (the clock at the reset: what the device holds minus the executed steps is not exact -- take it from t0)
+                t0 = getattr(self._packed, "t0", None)
+                for i, st in enumerate(self.states):
+                    if not st.unapplied_actions:
+                        continue
+                    t = float(t0[i]) if t0 is not None else max(0.0, st.scenario.ego.trajectory.min_t)
+                    clock = [t]
+                    for _ in range(int(now["n_steps"][i])):
+                        t = t + self._timestep
+                        clock.append(t)
+                    st._replay_actions(clock)
         else:
             self.reset_scenarios()
             done = np.zeros(len(self.states), bool)

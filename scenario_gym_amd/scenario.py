@@ -8,25 +8,8 @@ from .entity import Entity, Pedestrian, Vehicle
 from .trajectory import Trajectory
 
 
-class ScenarioActionRecord:
-    """A scenario action as the files carry it (scenario/actions.py:12-110: t, action_class, entity_ref, action_variables).
-    Applying actions to a running state is not part of the device path; the record survives load / save unchanged.
-    kind: the reference class it stands for ("UserDefinedAction" from OpenSCENARIO, "UpdateStateVariableAction" from JSON)."""
-
-    def __init__(self, t: float, action_class: str, entity_ref: str, action_variables: Dict[str, Any],
-                 kind: str = "UpdateStateVariableAction"):
-        self.t, self.action_class, self.entity_ref, self.action_variables, self.kind = t, action_class, entity_ref, action_variables, kind
-
-    def to_dict(self) -> Dict[str, Any]:
-        return {"action_class": self.action_class, "entity_ref": self.entity_ref, "action_variables": self.action_variables,
-                "t": self.t}
-
-    @classmethod
-    def from_dict(cls, data: Dict[str, Any]):
-        return cls(data["t"], data["action_class"], data["entity_ref"], data["action_variables"])
-
-    def copy(self):
-        return ScenarioActionRecord(self.t, self.action_class, self.entity_ref, dict(self.action_variables), self.kind)
+from .actions import (FixedTAction, ScenarioAction, ScenarioActionRecord, UpdateStateVariableAction,  # noqa: E402,F401
+                      UserDefinedAction)
 
 
 class Scenario:
@@ -69,11 +52,18 @@ class Scenario:
         """scenario.py:88-91."""
         return max(e.trajectory.max_t for e in self._entities)
 
+    def add_action(self, action, inplace: bool = False):
+        """scenario.py:160-164."""
+        scenario = self if inplace else self.copy()
+        scenario.actions.append(action)
+        return scenario
+
     def translate(self, x):
         """scenario.py:157-177: every entity's trajectory translated by `x` ([t, x, y, z, h, p, r] offsets)."""
         new = self.copy()
         for e in new._entities:
             e.trajectory = e.trajectory.translate(x)
+        new.actions = [a.translate(x) for a in new.actions]  # FixedTAction.translate: t += x[0] (actions.py:102-106)
         new.name = self.name
         return new
 
@@ -105,7 +95,8 @@ class Scenario:
                     rn = None
             else:
                 rn = RoadNetwork.create_from_dict(rn)
-        actions = [ScenarioActionRecord.from_dict(a) for a in data.get("actions", ())]
+        # (scenario.py:214-221: "action_class" names one of a_classes, UpdateStateVariableAction by default)
+        actions = [UpdateStateVariableAction.from_dict(a) for a in data.get("actions", ())]
         return cls(entities, name=data.get("name"), road_network=rn, actions=actions, properties=data.get("properties", {}))
 
     def to_dict(self, road_network_path: Optional[str] = "../Road_Networks") -> Dict[str, Any]:
@@ -149,4 +140,4 @@ class Scenario:
     def copy(self):
         return self.__class__([e.copy() for e in self._entities],
                               name=f"Copy of {self.name}" if self.name is not None else None,
-                              road_network=self.road_network, actions=list(self.actions), properties=self.properties)
+                              road_network=self.road_network, actions=[a.copy() for a in self.actions], properties=self.properties)

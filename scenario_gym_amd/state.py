@@ -18,6 +18,50 @@ class State:
         self.last_keystroke = None
         self.state_callbacks = []
         self._prev_poses_arr = None
+        self._t_replay = None  # the clock value update_actions sees while a device rollout's actions are replayed
+        self._reset_actions()
+
+    # ------------------------------------------------------------------ scenario actions (state/state.py:150-160, 241-266)
+    def _reset_actions(self) -> None:
+        """State._reset_data: every action of the scenario is unapplied again, no entity has a state."""
+        self.unapplied_actions = list(self._scenario.actions)
+        self.action_apply_times = {a: float("nan") for a in self._scenario.actions}
+        self.entity_state = dict.fromkeys(self._scenario.entities)
+
+    def update_actions(self) -> None:
+        """state.py:241-251: apply the actions whose trigger holds now, in the scenario's order; keep the others."""
+        unapplied = []
+        for act in self.unapplied_actions:
+            if act.trigger_condition(self):
+                self.apply_action(act)
+                self.action_apply_times[act] = self.t
+            else:
+                unapplied.append(act)
+        self.unapplied_actions = unapplied
+
+    def apply_action(self, action) -> None:
+        """state.py:253-262."""
+        import warnings
+
+        entity = self._scenario.entity_by_name(action.entity_ref)
+        if entity is None:
+            warnings.warn(f"No entity with name {action.entity_ref} was found for action {action.__class__.__name__}.")
+        else:
+            action.apply(self, entity)
+
+    def _replay_actions(self, clock) -> None:
+        """update_actions() once per value of `clock` (State.t after each step of a device call that ran several steps at
+        once): what stepping one by one would have done, for actions whose trigger reads nothing but State.t."""
+        if not self.unapplied_actions:
+            return
+        try:
+            for t in clock:
+                self._t_replay = float(t)
+                self.update_actions()
+                if not self.unapplied_actions:
+                    break
+        finally:
+            self._t_replay = None
 
     # ------------------------------------------------------------------ plumbing
     def _s(self):
@@ -46,6 +90,8 @@ class State:
     # ------------------------------------------------------------------ reference read API
     @property
     def t(self) -> float:
+        if self._t_replay is not None:
+            return self._t_replay
         return float(self._s()["t"][self._i])
 
     @property
@@ -113,7 +159,7 @@ class State:
     def get_entity_data(self, entity: Entity):
         """state.py:292-304."""
         return (self.t, self.next_t, self.poses.get(entity), self.velocities.get(entity),
-                self.distances.get(entity), self.recorded_poses(entity=entity), None)
+                self.distances.get(entity), self.recorded_poses(entity=entity), self.entity_state.get(entity, None))
 
     def get_entity_box_points(self, e: Entity) -> np.ndarray:
         return e.get_bounding_box_points(self.poses[e])

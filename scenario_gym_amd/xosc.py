@@ -23,7 +23,8 @@ import numpy as np
 
 from .road_network import RoadNetwork
 from .entity import Axle, BoundingBox, Catalog, CatalogEntry, Entity, MiscObject, Pedestrian, Vehicle
-from .scenario import Scenario, ScenarioActionRecord
+from .actions import UserDefinedAction
+from .scenario import Scenario
 from .trajectory import Trajectory
 
 _ENTITY_CLASSES = {"Vehicle": Vehicle, "Pedestrian": Pedestrian, "MiscObject": MiscObject}
@@ -143,7 +144,7 @@ def _header_and_actions(root, entities):
                 continue
             t = float(cond.attrib.get("value"))
             for child in list(ua):
-                actions.append(ScenarioActionRecord(t, child.tag, entity.ref, dict(child.attrib), "UserDefinedAction"))
+                actions.append(UserDefinedAction(t, child.tag, entity.ref, dict(child.attrib)))
     return properties, actions
 
 
@@ -282,6 +283,31 @@ def load_native():
     return _xlib
 
 
+_XML_ENTITIES = {"amp": "&", "lt": "<", "gt": ">", "quot": '"', "apos": "'"}
+
+
+def _xml_unescape(v: str) -> str:
+    """The references an XML parser resolves in an attribute value: the five predefined entities and numeric character
+    references.  Anything else ("&nbsp;", a bare "&copy") is an undefined entity to a parser -- the reference's lxml raises --
+    so it raises here too and the caller falls back to the ElementTree import (which raises the parser's own error)."""
+    import re as _re2
+
+    def one(m):
+        name = m.group(1)
+        if name.startswith("#x") or name.startswith("#X"):
+            return chr(int(name[2:], 16))
+        if name.startswith("#"):
+            return chr(int(name[1:]))
+        if name in _XML_ENTITIES:
+            return _XML_ENTITIES[name]
+        raise ValueError(f"undefined XML entity &{name};")
+
+    out = _re2.sub(r"&(#[0-9]+|#[xX][0-9a-fA-F]+|[A-Za-z_][A-Za-z0-9._-]*);", one, v)
+    if "&" in _re2.sub(r"&(?=amp;)", "", v.replace("&amp;", "")) and _re2.search(r"&(?!(#[0-9]+|#[xX][0-9a-fA-F]+|[A-Za-z_][A-Za-z0-9._-]*);)", v):
+        raise ValueError("a bare '&' in an attribute value")
+    return out
+
+
 def scan_xosc(text: bytes):
     """sgx_parse on the bytes of one file: dict(dirs, road_file, objects, teleports, trajectories) with decoded strings and
     the trajectory vertices as [n, 7] arrays."""
@@ -312,7 +338,7 @@ def scan_xosc(text: bytes):
         if x.len < 0:
             return None
         v = text[x.off:x.off + x.len].decode(enc)
-        return _html.unescape(v) if "&" in v else v
+        return _xml_unescape(v) if "&" in v else v
 
     return dict(
         dirs=[st(dirs[i]) for i in range(cnt.n_dirs)], road_file=st(cnt.road_file),

@@ -1787,6 +1787,63 @@ def test_device_group_equals_single_handle(sga, oracle):
     eng.close()
 
 
+def test_device_group_four_handles_at_the_timed_width(sga, oracle):
+    """sg_group with FOUR handles on device 0, 1024 scenarios x 64 entities each, against ONE handle with all 4096 (the
+    config-4 partitioning, on the one GPU there is): metric rows and events equal row for row, and both runs' first / last
+    scenarios equal the oracle.  The handles of a group launch before any of them is waited for: four engines' streams,
+    pipeline probes and controller pre-passes side by side on one device."""
+    import ctypes as C
+    import time
+
+    import scenario_gym_amd._lib as L
+    from oracle import check
+    from scenario_gym_amd import synthetic
+
+    R, E, steps = 4096, 64, 1000
+    packed = synthetic.make_batch(R, E, n_steps=steps, ego_kind=L.KIND_AGENT_PID)
+    eng = sga.RolloutEngine(R, E, event_capacity=32)
+    eng.upload(packed)
+    eng.rollout(steps)
+    eng.synchronize()
+    t0 = time.perf_counter()
+    eng.rollout(steps)
+    eng.synchronize()
+    t_one = time.perf_counter() - t0
+    rows1, ev1 = eng.metrics()
+    ver = check.verify_engine(eng, packed, 1 / 30, steps, K=4, event_cap=32, threads=8)
+    assert ver["equal"], ver["mismatches"]
+    lib = eng.lib
+    n_dev = 4
+    cfg = L.SgConfig(0, R, E, 0, L.TERM_MAX_LENGTH, 0, 32, 0, 1 / 30)
+    devs = np.zeros(n_dev, np.int32)
+    g = C.c_void_p()
+    assert lib.sg_group_create(C.byref(cfg), n_dev, devs.ctypes.data, C.byref(g)) == 0
+    arrs = dict(kind=np.ascontiguousarray(packed.kind, np.int32), etype=np.ascontiguousarray(packed.etype, np.int32),
+                bbox=np.ascontiguousarray(packed.bbox), knot_off=np.ascontiguousarray(packed.knot_off, np.int64),
+                knots=np.ascontiguousarray(packed.knots), ctrl=np.ascontiguousarray(packed.ctrl),
+                ego=np.ascontiguousarray(packed.ego, np.int32), t0=np.ascontiguousarray(packed.t0),
+                length=np.ascontiguousarray(packed.length), route_off=None, routes=None)
+    sc = L.SgScenarios(*[None if arrs[k] is None else arrs[k].ctypes.data for k, _ in L.SgScenarios._fields_])
+    assert lib.sg_group_upload(g, C.byref(sc)) == 0, lib.sg_group_last_error(g)
+    assert lib.sg_group_rollout(g, steps) == 0, lib.sg_group_last_error(g)
+    t0 = time.perf_counter()
+    assert lib.sg_group_rollout(g, steps) == 0, lib.sg_group_last_error(g)
+    t_group = time.perf_counter() - t0
+    rows = np.zeros(R, rows1.dtype)
+    ev = np.zeros(1 << 17, ev1.dtype)
+    n_ev = C.c_int32()
+    assert lib.sg_group_read_metrics(g, rows.ctypes.data, ev.ctypes.data, len(ev), C.byref(n_ev)) == 0
+    assert n_ev.value == len(ev1)
+    for k in rows1.dtype.names:
+        assert bits_equal(rows[k], rows1[k]), k
+    for k in ("t", "scenario", "other", "type"):
+        assert np.array_equal(ev[: n_ev.value][k], ev1[k]), k
+    assert lib.sg_group_destroy(g) == 0
+    eng.close()
+    print(f"one handle 4096 x 64 x {steps}: {t_one * 1e3:.1f} ms; four handles of 1024: {t_group * 1e3:.1f} ms")
+    assert t_group < 3.0 * t_one  # (not a performance claim: four shards of 1024 blocks are latency-bound, DESIGN 4)
+
+
 def test_rss_distances_match_reference_and_oracle(sga, oracle):
     """sg_rss_update after every tick: the 46 scenarios of rss.npz as one ragged batch -- every record RSSDistances appended
     (per step, per entity), its safe distances and the two RSS metric flags equal the reference's; a dense synthetic batch
@@ -2483,21 +2540,24 @@ def test_timed_shape_c3_full_horizon_32_scenarios(sga, oracle):
     assert (rows["n_steps"] >= T - 1).all() and rows["done"].all()
 
 
-def test_timed_shape_c5_crowd_2000_steps_8_scenarios(sga, oracle):
-    """BASELINE config 5 at its timed width -- 1024 scenarios x 256 pedestrians, the crowd kernel -- for 2,000 steps (through
-    the densest phase and well into the dispersal), 8 scenarios spread over the batch against the oracle: poses, velocities,
-    distances, collision rows (4 words per entity), social forces, ego metrics, events."""
+def test_timed_shape_c5_crowd_full_horizon_8_scenarios(sga, oracle):
+    """BASELINE config 5 at its timed width AND length -- 1024 scenarios x 256 pedestrians x 10,000 steps, the crowd kernel,
+    exactly what `bench.py --workload c5` times -- 8 scenarios spread over the batch against the oracle over the full horizon
+    (through the densest phase, the dispersal and the thousands of steps in which most pedestrians have arrived and a few
+    are stuck): poses, velocities, distances, collision rows (4 words per entity), social forces, ego metrics, events."""
     from oracle import check
     from scenario_gym_amd import synthetic
 
-    R, E, T = 1024, 256, 2000
+    R, E, T = 1024, 256, 10000
     packed = synthetic.make_crowd(R, E, n_steps=T)
     eng = sga.RolloutEngine(R, E, terminal_conditions=["max_length"], event_capacity=64)
     eng.upload(packed)
     eng.rollout(T)
     ver = check.verify_engine(eng, packed, 1 / 30, T, K=8, event_cap=64, ped=True, threads=16)
+    rows, _ = eng.metrics()
     eng.close()
     assert ver["scenarios"] == 8 and ver["equal"], ver["mismatches"]
+    assert (rows["n_steps"] >= T - 1).all() and rows["done"].all()
 
 
 def test_crowd_with_a_car_matches_oracle(sga, oracle):
