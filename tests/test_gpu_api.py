@@ -375,16 +375,24 @@ def test_entities_in_area_and_radius():
     gym.close()
 
 
-@pytest.mark.parametrize("name", ["a5e43fe4", "3fee6507", "41dac6fa", "5c5188e0", "a98d5c7d"])
-def test_state_info_radius_counts_as_the_reference_asserts(name):
-    """tests/test_state.py:75-97, statement by statement, on every exported scenario: timestep 0.1, 50 steps, then
-    get_entities_in_radius around entities[0] with min(distance) - 0.1 finds exactly 1 entity and with max(distance) + 1
-    all of them (distances are the 3-d norms of the reference's assertion; the device evaluates the 64-gon Point.buffer(r))."""
-    import scenario_gym_amd as sga
+def test_state_info_radius_counts_as_the_reference_asserts():
+    """tests/test_state.py:75-97, statement by statement, on the scenario the reference's fixture names (3e39a079...): timestep
+    0.1, 50 steps, then get_entities_in_radius around entities[0] with min(distance) - 0.1 finds exactly 1 entity and with
+    max(distance) + 1 all of them (distances are the 3-d norms of the reference's assertion; the test evaluates the 64-gon
+    Point.buffer(r) of state.py:356-372)."""
+    import json
 
-    g = load_golden("scenarios")
+    import scenario_gym_amd as sga
+    from scenario_gym_amd.scenario import Scenario
+
+    gj = load_golden("json")
+    n = "3e39a079-5653-440c-bcbe-24dc9f6bf0e6"
+    d = json.loads(str(gj[f"{n}/to_dict"]))
+    for e in d["entities"]:
+        e["trajectory"] = gj[f"{n}/traj_{e['trajectory']}"].tolist()
+    d["road_network"] = None
     gym = sga.ScenarioGym(timestep=0.1)
-    gym.set_scenario(_scenario(g, f"{name}/scenario"))
+    gym.set_scenario(Scenario.from_dict(d))
     for _ in range(50):
         gym.step()
     st = gym.state
