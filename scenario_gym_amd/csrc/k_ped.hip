@@ -5,6 +5,10 @@
 namespace sgl {
 void rollout_ped(int G, int WV, bool rss, dim3 grid, hipStream_t s, const RolloutArgs &a)
 {
+    if (WV == 8) { // 257..512 entities: the general pedestrian variant on eight wavefronts (no RSS callback at that width)
+        sg::rollout_kernel<64, 8, true, false><<<grid, dim3(512), 0, s>>>(SGL_ARGS(a));
+        return;
+    }
     if (WV == 1 && G < 16) G = 16;
 #define CALL(G_, WV_)                                                                                                                \
     if (rss) sg::rollout_kernel_rss_ped<(G_ < 16 ? 16 : G_), WV_><<<grid, dim3(64 * WV_), 0, s>>>(SGL_ARGS(a));                      \

@@ -5,6 +5,10 @@
 namespace sgl {
 void rollout_rss(int G, int WV, bool road, dim3 grid, hipStream_t s, const RolloutArgs &a)
 {
+    if (WV == 8) { // 257..512 entities (no road variant at that width)
+        sg::rollout_kernel_rss<64, 8><<<grid, dim3(512), 0, s>>>(SGL_ARGS(a));
+        return;
+    }
 #define CALL(G_, WV_)                                                                                                                \
     if (road) sg::rollout_kernel_rss_road<G_, WV_><<<grid, dim3(64 * WV_), 0, s>>>(SGL_ARGS(a));                                     \
     else sg::rollout_kernel_rss<G_, WV_><<<grid, dim3(64 * WV_), 0, s>>>(SGL_ARGS(a))

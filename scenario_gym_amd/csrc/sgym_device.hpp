@@ -1264,7 +1264,7 @@ __device__ __forceinline__ void ped_pairs_balanced(const Params &p, LDS &L, int 
 #pragma unroll
             for (int w = 0; w < WV; ++w)
                 if ((j >> 6) == w) m[w] &= ~(1ull << (j & 63));
-            list[e0 + out - 1 - q] = (uint32_t)(j + tile0) | ((uint32_t)lane << 8);
+            list[e0 + out - 1 - q] = (uint32_t)(j + tile0) | ((uint32_t)lane << 10) /* slot in bits 0..9 (tiles of up to 512 slots), owner lane above */;
         }
     }
     tile_sync<1>();
@@ -1281,7 +1281,7 @@ __device__ __forceinline__ void ped_pairs_balanced(const Params &p, LDS &L, int 
             if ((j >> 6) == w) m[w] &= m[w] - 1; // j = -1 matches no word
         const int hi = min(h, CAP - 1);
         const uint32_t ent = list[hi];
-        const int isl = wave_sl + (int)((ent >> 8) & 63);
+        const int isl = wave_sl + (int)((ent >> 10) & 63);
         const int jj = own ? j + tile0 : (int)(ent & (LDS::SLOTS - 1));
         const double qx = own ? ipx : L.px[isl], qy = own ? ipy : L.py[isl];
         const double qr = own ? irad : L.ctrl[SG_C_PED_RADIUS - SG_C_PED_SPEED_DESIRED][isl];
@@ -4391,12 +4391,12 @@ __device__ __forceinline__ double sg_linspace_at(double start, double stop, int 
 }
 
 #ifdef SG_UNIT_MAIN // (emitted by the one object that launches it: csrc/Makefile, sgym_launch.hpp)
-static __global__ __launch_bounds__(256) void raster_kernel(Params p, double width, double height, int nw, int nh,
+static __global__ __launch_bounds__(512) void raster_kernel(Params p, double width, double height, int nw, int nh,
                                                      unsigned char *out /*[R][nh][nw] at stride bytes per scenario*/,
                                                      int64_t stride)
 {
-    __shared__ double cor[8][256];
-    __shared__ unsigned char pres[256];
+    __shared__ double cor[8][512]; // (one thread per entity slot: 256 threads, 512 for scenarios of 257..512 entities)
+    __shared__ unsigned char pres[512];
     __shared__ double ego_pose[4]; // x, y, sin(theta), cos(theta)
     __shared__ int near_n;
     const int r = blockIdx.x, e = threadIdx.x;
@@ -4441,7 +4441,7 @@ static __global__ __launch_bounds__(256) void raster_kernel(Params p, double wid
     const bool ego_present = pres[ss.ego] != 0;
     const int nn = near_n;
     unsigned char *o = out + (size_t)r * stride;
-    for (int q = e; q < nw * nh; q += 256) {
+    for (int q = e; q < nw * nh; q += (int)blockDim.x) {
         const int i = q / nw, j = q - i * nw;
         const double x0 = sg_linspace_at(-width / 2, width / 2, nw, j), x1 = sg_linspace_at(-height / 2, height / 2, nh, i);
         const double px = __builtin_fma(x1, -s, x0 * c) + ex, py = __builtin_fma(x1, c, x0 * s) + ey;
@@ -4708,7 +4708,7 @@ static __global__ __launch_bounds__(64) void classify_events_kernel(Params p, do
 // seen [R]: State.n_steps at the scenario's latest update -- a scenario that did not step since (it is done) is left alone,
 // as the reference stops calling the callback once its rollout loop has ended
 #ifdef SG_UNIT_MAIN // (emitted by the one object that launches it: csrc/Makefile, sgym_launch.hpp)
-static __global__ __launch_bounds__(256) void rss_kernel(Params p, int reset, int32_t *rss_state, int32_t *code, double *safe, int32_t *seen)
+static __global__ __launch_bounds__(512) void rss_kernel(Params p, int reset, int32_t *rss_state, int32_t *code, double *safe, int32_t *seen)
 {
     __shared__ double ego[8]; // x, y, heading, vx, vy, width, length, present
     const int r = blockIdx.x, e = threadIdx.x;
@@ -4803,11 +4803,11 @@ static __global__ __launch_bounds__(64) void rss_lines_kernel(Params p, TabGroup
 // the surface layers of raster_surface_kernel, same arithmetic, the grid point computed once -- and the terminal flags of
 // terminal_flags_kernel.  One workgroup per scenario.  has_road: road networks are set (else the surface layers are empty).
 #ifdef SG_UNIT_MAIN // (emitted by the one object that launches it: csrc/Makefile, sgym_launch.hpp)
-static __global__ __launch_bounds__(256) void observe_kernel(Params p, RoadIndex R, int has_road, double width, double height, int nw,
+static __global__ __launch_bounds__(512) void observe_kernel(Params p, RoadIndex R, int has_road, double width, double height, int nw,
                                                       int nh, int n_layers, const int32_t *layers,
                                                       unsigned char *out /*[R][n_layers][nh][nw]*/, uint32_t *flags /*[R]*/)
 {
-    __shared__ double cor[8][256];
+    __shared__ double cor[8][512]; // (one thread per entity slot: 256 threads, 512 for scenarios of 257..512 entities)
     __shared__ double ego_pose[4]; // x, y, sin(theta), cos(theta)
     __shared__ int near_n, ego_present, any_coll;
     const int r = blockIdx.x, e = threadIdx.x;
@@ -4872,7 +4872,7 @@ static __global__ __launch_bounds__(256) void observe_kernel(Params p, RoadIndex
     const int nn = near_n;
     const bool ego_pres = ego_present != 0;
     unsigned char *o = out + (size_t)r * n_layers * nw * nh;
-    for (int q = e; q < nw * nh; q += 256) {
+    for (int q = e; q < nw * nh; q += (int)blockDim.x) {
         const int i = q / nw, j = q - i * nw;
         const double x0 = sg_linspace_at(-width / 2, width / 2, nw, j), x1 = sg_linspace_at(-height / 2, height / 2, nh, i);
         const double px = __builtin_fma(x1, -s, x0 * c) + ex, py = __builtin_fma(x1, c, x0 * s) + ey;

@@ -94,6 +94,10 @@ struct sg_handle {
     sg::WalkArgs walk{};
     int walk_R = 0;
     int last_walk_chunks = 0;                    // chunks of the last call that went through the walker dispatch
+    // page-locked staging of sg_read_metrics (the per-scenario state and the event table travel every time metrics are read:
+    // 0.5 + up to 6 MB for 4096 scenarios; pageable copies ran at a third of the PCIe rate)
+    void *pin_sd = nullptr, *pin_ev = nullptr;
+    size_t pin_sd_cap = 0, pin_ev_cap = 0;
     double *d_tab[4] = {nullptr, nullptr, nullptr, nullptr}; // controller-table buffers (launch_rollout: two, four with block groups)
     int n_tab = 0;
     int n_simd = 1024;                                       // SIMDs of the device (4 per compute unit)
@@ -331,8 +335,6 @@ extern "C" int sg_create(const sg_config *cfg, sg_handle **out)
     if (cfg->n_entities > 512)
         return fail(nullptr, SG_ERR_INVALID, "sg_create: n_entities=%d > 512 is not supported by ABI version %d",
                     cfg->n_entities, SG_ABI_VERSION);
-    if (cfg->n_entities > 256 && (cfg->terminal_mask & SG_TERM_EGO_OFF_ROAD))
-        return fail(nullptr, SG_ERR_INVALID, "sg_create: the ego_off_road terminal condition is available up to 256 entities per scenario");
     if (!(cfg->timestep > 0.0)) return fail(nullptr, SG_ERR_INVALID, "sg_create: timestep must be > 0");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -426,6 +428,8 @@ extern "C" int sg_destroy(sg_handle *h)
     free_pool(h->road_allocs);
     free_pool(h->slice_allocs);
     free_pool(h->walk_allocs);
+    if (h->pin_sd) (void)hipHostFree(h->pin_sd);
+    if (h->pin_ev) (void)hipHostFree(h->pin_ev);
     if (h->obs_buf) (void)hipFree(h->obs_buf);
     if (h->d_reset_mask) (void)hipFree(h->d_reset_mask);
     if (h->d_term_flags) (void)hipFree(h->d_term_flags);
@@ -511,7 +515,16 @@ static void launch_variant(sg_handle *h, dim3 grid, int n_steps, int do_reset, i
     sgl::rollout_crowd(WV, false, grid, s, a);
     return;
 #endif
-    if (WV == 8) // 257..512 entities: vehicles and replay only (launch_rollout never takes the table path at this width)
+    if (WV == 8 && !h->has_ped && (h->cfg.terminal_mask & SG_TERM_EGO_OFF_ROAD)) { // 257..512 entities, ego_off_road
+        // (RSSDistances + ego_off_road in one wide rollout: no fused variant at that width, sg_set_rss refuses it)
+        sgl::rollout_road(64, 8, grid, s, a);
+        return;
+    }
+    if (WV == 8 && h->rss_fused && !h->has_ped) // 257..512 entities: the RSS callback inside the kernel, eight wavefronts
+        sgl::rollout_rss(64, 8, false, grid, s, a);
+    else if (WV == 8 && h->has_ped) // 257..512 entities with pedestrian agents: the general pedestrian variant on eight wavefronts
+        sgl::rollout_ped(64, 8, false, grid, s, a);
+    else if (WV == 8) // ... vehicles and replay only (launch_rollout never takes the table path at this width)
         sgl::rollout_plain(64, 8, false, grid, s, a);
     else if (h->has_ped && h->all_ped && G == 64 && !h->has_road && h->crowd_kernel && !h->rss_fused)
         sgl::rollout_crowd(WV, false, grid, s, a);
@@ -1114,14 +1127,15 @@ extern "C" int sg_upload(sg_handle *h, const sg_scenarios *sc)
     }
     if (h->has_ped && h->WV == 1 && h->G < 16) { h->G = 16; h->EP = 16; h->NE = (((size_t)h->R * h->EP + 63) / 64) * 64; }
     h->crowd_riders = false;
-    if (h->has_ped && !h->all_ped && h->G == 64 && h->crowd_kernel && env_int("SG_CROWD_RIDERS", 1) != 0) {
+    if (h->has_ped && !h->all_ped && h->G == 64 && h->WV <= 4 && h->crowd_kernel && env_int("SG_CROWD_RIDERS", 1) != 0) {
         bool ok = true; // pedestrian agents of catalog type Pedestrian, and nothing the pre-pass cannot ride for
         for (size_t i = 0; i < (size_t)h->R * h->E && ok; ++i)
             ok = sc->kind[i] == SG_KIND_AGENT_PEDESTRIAN ? sc->etype[i] == 1 : sc->kind[i] != SG_KIND_AGENT_EXTERNAL;
         h->crowd_riders = ok;
     }
     if (h->has_ped && (!sc->route_off || !sc->routes)) return fail(h, SG_ERR_INVALID, "sg_upload: pedestrian agents need route_off/routes");
-    if (h->has_ped && h->WV > 4) return fail(h, SG_ERR_INVALID, "sg_upload: pedestrian agents are available up to 256 entities per scenario");
+    // (257..512 entities: pedestrian agents run the general pedestrian variant, rollout_kernel<64, 8, true, false>; the crowd
+    // kernels, the riders' pre-pass and road networks with pedestrians stop at 256)
     if (h->has_ped && (h->cfg.terminal_mask & SG_TERM_EGO_OFF_ROAD))
         return fail(h, SG_ERR_INVALID, "sg_upload: the ego_off_road terminal condition is not available for batches with pedestrian agents");
     const int R = h->R, E = h->E, EP = h->EP;
@@ -1589,7 +1603,6 @@ extern "C" int sg_tick(sg_handle *h, const double *actions, int32_t actions_devi
     if (!layers || n_layers < 1 || n_layers > 8 || nw < 1 || nh < 1 || !(width >= 0.0) || !(height >= 0.0))
         return fail(h, SG_ERR_INVALID, "sg_tick: bad observation geometry (1..8 layers)");
     if (h->n_ext > 0) return fail(h, SG_ERR_STATE, "sg_tick: batches with caller-run agents are driven through sg_set_external_poses + sg_step");
-    if (h->WV > 4) return fail(h, SG_ERR_INVALID, "%s: available up to 256 entities per scenario", "sg_tick");
     bool any_surface = false;
     for (int k = 0; k < n_layers; ++k) {
         const uint32_t L = (uint32_t)layers[k];
@@ -1637,7 +1650,7 @@ extern "C" int sg_tick(sg_handle *h, const double *actions, int32_t actions_devi
         h->rss_fused = false;
         hipError_t e = hipSuccess;
         if (!rc) { // the whole observation (map layers + terminal flags) in one launch
-            sg::observe_kernel<<<dim3((unsigned)h->R), dim3(256), 0, h->stream>>>(h->p, h->road, h->has_road ? 1 : 0, width, height, nw,
+            sg::observe_kernel<<<dim3((unsigned)h->R), dim3(h->EP > 256 ? 512 : 256), 0, h->stream>>>(h->p, h->road, h->has_road ? 1 : 0, width, height, nw,
                                                                                 nh, n_layers, dl, d, h->d_term_flags);
             e = hipGetLastError();
         }
@@ -1758,11 +1771,22 @@ extern "C" int sg_read_metrics(sg_handle *h, sg_metrics *out, sg_event *events, 
         sg::classify_events_kernel<<<dim3((unsigned)h->R), dim3(64), 0, h->stream>>>(h->p, h->c_tol);
         HIP_TRY(h, hipGetLastError());
     }
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
     const int R = h->R;
     const Params &p = h->p;
-    std::vector<sg_scenario_state> sd(R);
-    HIP_TRY(h, hipMemcpy(sd.data(), p.sdyn, (size_t)R * sizeof(sg_scenario_state), hipMemcpyDeviceToHost));
+    auto pinned = [&](void **buf, size_t *cap, size_t bytes) -> int { // grown on demand, kept on the handle
+        if (*cap >= bytes) return SG_OK;
+        if (*buf) HIP_TRY(h, hipHostFree(*buf));
+        *buf = nullptr;
+        *cap = 0;
+        HIP_TRY(h, hipHostMalloc(buf, bytes, hipHostMallocDefault));
+        *cap = bytes;
+        return SG_OK;
+    };
+    int rc0 = pinned(&h->pin_sd, &h->pin_sd_cap, (size_t)R * sizeof(sg_scenario_state));
+    if (rc0) return rc0;
+    sg_scenario_state *sd = static_cast<sg_scenario_state *>(h->pin_sd);
+    HIP_TRY(h, hipMemcpyAsync(sd, p.sdyn, (size_t)R * sizeof(sg_scenario_state), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
     int64_t total = 0;
     bool overflow = false;
     for (int r = 0; r < R; ++r) {
@@ -1781,9 +1805,11 @@ extern "C" int sg_read_metrics(sg_handle *h, sg_metrics *out, sg_event *events, 
     if (events && cap > 0 && p.ev_cap > 0 && total > 0) {
         int width = 0; // only the columns in use travel over PCIe
         for (int r = 0; r < R; ++r) width = std::max(width, std::min(sd[r].n_events, p.ev_cap));
-        std::vector<sg_event> all((size_t)R * width);
-        HIP_TRY(h, hipMemcpy2D(all.data(), (size_t)width * sizeof(sg_event), p.events, (size_t)p.ev_cap * sizeof(sg_event),
-                               (size_t)width * sizeof(sg_event), (size_t)R, hipMemcpyDeviceToHost));
+        if ((rc0 = pinned(&h->pin_ev, &h->pin_ev_cap, (size_t)R * width * sizeof(sg_event)))) return rc0;
+        sg_event *all = static_cast<sg_event *>(h->pin_ev);
+        HIP_TRY(h, hipMemcpy2DAsync(all, (size_t)width * sizeof(sg_event), p.events, (size_t)p.ev_cap * sizeof(sg_event),
+                                    (size_t)width * sizeof(sg_event), (size_t)R, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
         int64_t k = 0;
         for (int r = 0; r < R; ++r)
             for (int i = 0; i < std::min(sd[r].n_events, p.ev_cap); ++i) {
@@ -2064,14 +2090,14 @@ extern "C" int sg_rss_update(sg_handle *h, int32_t reset)
 {
     if (!h) return SG_ERR_INVALID;
     if (!h->uploaded) return fail(h, SG_ERR_STATE, "sg_rss_update: no scenarios uploaded");
-    if (h->WV > 4) return fail(h, SG_ERR_INVALID, "%s: available up to 256 entities per scenario", "sg_rss_update");
+
     if (!h->ego_first) return fail(h, SG_ERR_STATE, "sg_rss_update: RSSDistances keeps its records for entities[1:], the ego has to be entity 0 of every scenario");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     bool fresh = false;
     int rc0 = ensure_rss(h, &fresh);
     if (rc0) return rc0;
     if (fresh) reset = 1;
-    sg::rss_kernel<<<dim3((unsigned)h->R), dim3(256), 0, h->stream>>>(h->p, reset ? 1 : 0, h->d_rss_state, h->d_rss_code, h->d_rss_safe, h->d_rss_seen);
+    sg::rss_kernel<<<dim3((unsigned)h->R), dim3(h->EP > 256 ? 512 : 256), 0, h->stream>>>(h->p, reset ? 1 : 0, h->d_rss_state, h->d_rss_code, h->d_rss_safe, h->d_rss_seen);
     HIP_TRY(h, hipGetLastError());
     return SG_OK;
 }
@@ -2079,7 +2105,8 @@ extern "C" int sg_rss_update(sg_handle *h, int32_t reset)
 extern "C" int sg_set_rss(sg_handle *h, int32_t enabled)
 {
     if (!h) return SG_ERR_INVALID;
-    if (enabled && h->WV > 4) return fail(h, SG_ERR_INVALID, "sg_set_rss: available up to 256 entities per scenario");
+    if (enabled && h->WV > 4 && (h->has_ped || (h->cfg.terminal_mask & SG_TERM_EGO_OFF_ROAD)))
+        return fail(h, SG_ERR_INVALID, "sg_set_rss: with pedestrian agents or the ego_off_road terminal condition the callback is available up to 256 entities per scenario");
     h->rss_enabled = enabled != 0;
     return SG_OK;
 }
@@ -2121,7 +2148,6 @@ extern "C" int sg_future_collision(sg_handle *h, double horizon, int32_t n_sampl
 {
     if (!h || !out || n_samples < 1 || !(horizon >= 0.0)) return h ? fail(h, SG_ERR_INVALID, "sg_future_collision: bad argument") : SG_ERR_INVALID;
     if (!h->uploaded) return fail(h, SG_ERR_STATE, "sg_future_collision: no scenarios uploaded");
-    if (h->WV > 4) return fail(h, SG_ERR_INVALID, "%s: available up to 256 entities per scenario", "sg_future_collision");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     unsigned char *d = nullptr;
     int rc = obs_scratch(h, (size_t)h->R, &d);
@@ -2366,7 +2392,6 @@ static int raster_map_launch(sg_handle *h, const char *who, double width, double
     if (!layers || n_layers < 1 || nw < 1 || nh < 1 || !(width >= 0.0) || !(height >= 0.0))
         return fail(h, SG_ERR_INVALID, "%s: bad argument", who);
     if (!h->uploaded) return fail(h, SG_ERR_STATE, "%s: no scenarios uploaded", who);
-    if (h->WV > 4) return fail(h, SG_ERR_INVALID, "%s: available up to 256 entities per scenario", who);
     bool any_surface = false;
     for (int k = 0; k < n_layers; ++k) {
         const uint32_t L = (uint32_t)layers[k];
@@ -2383,7 +2408,7 @@ static int raster_map_launch(sg_handle *h, const char *who, double width, double
     if (any_surface && !h->has_road) HIP_TRY(h, hipMemsetAsync(d, 0, bytes, h->stream)); // no networks: empty surfaces
     for (int k = 0; k < n_layers; ++k)
         if (layers[k] == 0) {
-            sg::raster_kernel<<<dim3((unsigned)h->R), dim3(256), 0, h->stream>>>(h->p, width, height, nw, nh, d + (size_t)k * plane,
+            sg::raster_kernel<<<dim3((unsigned)h->R), dim3(h->EP > 256 ? 512 : 256), 0, h->stream>>>(h->p, width, height, nw, nh, d + (size_t)k * plane,
                                                                                (int64_t)(n_layers * plane));
             HIP_TRY(h, hipGetLastError());
         }
@@ -2426,13 +2451,12 @@ extern "C" int sg_raster_entities(sg_handle *h, double width, double height, int
     if (!h || !out || nw < 1 || nh < 1 || !(width >= 0.0) || !(height >= 0.0))
         return h ? fail(h, SG_ERR_INVALID, "sg_raster_entities: bad argument") : SG_ERR_INVALID;
     if (!h->uploaded) return fail(h, SG_ERR_STATE, "sg_raster_entities: no scenarios uploaded");
-    if (h->WV > 4) return fail(h, SG_ERR_INVALID, "%s: available up to 256 entities per scenario", "sg_raster_entities");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     const size_t bytes = (size_t)h->R * nw * nh;
     unsigned char *d = nullptr;
     int rc = obs_scratch(h, bytes, &d);
     if (rc) return rc;
-    sg::raster_kernel<<<dim3((unsigned)h->R), dim3(256), 0, h->stream>>>(h->p, width, height, nw, nh, d, (int64_t)nw * nh);
+    sg::raster_kernel<<<dim3((unsigned)h->R), dim3(h->EP > 256 ? 512 : 256), 0, h->stream>>>(h->p, width, height, nw, nh, d, (int64_t)nw * nh);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(out, d, bytes, hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);

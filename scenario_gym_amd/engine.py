@@ -409,7 +409,9 @@ class RolloutEngine:
         """(per-scenario metric rows, CollisionMetric events) as structured arrays (sg_metrics / sg_event layout)."""
         cap = self.R * max(self.cfg.event_capacity, 1) if event_cap is None else int(event_cap)
         rows = np.empty(self.R, self.METRIC_DTYPE)   # uninitialised host buffers: the library fills what it reports
-        ev = np.empty(cap, self.EVENT_DTYPE)
+        if getattr(self, "_ev_buf", None) is None or len(self._ev_buf) < cap:
+            self._ev_buf = np.empty(cap, self.EVENT_DTYPE)   # kept between calls (6 MB for 4096 x 64: not touched unless filled)
+        ev = self._ev_buf
         n_ev = C.c_int32()
         self._check(self.lib.sg_read_metrics(self.h, rows.ctypes.data_as(C.POINTER(L.SgMetrics)),
                                              ev.ctypes.data_as(C.POINTER(L.SgEvent)), cap, C.byref(n_ev)), "sg_read_metrics")

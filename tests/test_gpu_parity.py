@@ -418,6 +418,62 @@ def test_wide_scenarios_match_oracle(sga, oracle, R, E, steps, ego_kind):
     assert n_ev > 0
 
 
+@pytest.mark.parametrize("R,E,steps,side,noise", [(3, 300, 90, 22.0, "off"), (2, 512, 70, 30.0, "device"), (3, 400, 60, 60.0, "off")])
+def test_wide_crowds_match_oracle(sga, oracle, R, E, steps, side, noise):
+    """Pedestrian agents in scenarios of 257..512 entities: the general pedestrian variant on eight wavefronts of one
+    workgroup (rollout_kernel<64, 8, true, false>; the crowd kernels stop at 256).  Poses of every step, forces, distances,
+    collision rows (8 words per entity), ego metrics and events equal the oracle's, with the counter-based noise too; a
+    vehicle and a replay entity among the pedestrians (every kind in one wide scenario)."""
+    import scenario_gym_amd._lib as L
+    from scenario_gym_amd import synthetic
+    from scenario_gym_amd.packing import unpack_scenario
+
+    packed = synthetic.make_crowd(R, E, n_steps=steps, side=side)
+    # entity 1 of every scenario becomes a replay entity (a recorded pedestrian), entity 2 a PID car crossing the square
+    kn = packed.knots.reshape(R * E, 2, 7)
+    for r in range(R):
+        i1, i2 = r * E + 1, r * E + 2
+        packed.kind[i1] = L.KIND_REPLAY
+        kn[i1, 1, 1:3] = kn[i1, 0, 1:3] + np.array([3.0, -2.0])
+        packed.kind[i2] = L.KIND_AGENT_PID
+        packed.etype[i2] = 0
+        packed.bbox[i2] = synthetic.CAR1_BBOX
+        packed.ctrl[i2] = synthetic.DEFAULT_CTRL
+        kn[i2, 0, 1:3] = (-side / 2 - 4.0, 0.5 * r)
+        kn[i2, 1, 1:3] = (side / 2 + 4.0, 0.5 * r)
+        kn[i2, :, 4] = 0.0
+    keep = np.ones(R * E, bool)
+    keep[[r * E + k for r in range(R) for k in (1, 2)]] = False
+    packed.routes = packed.routes.reshape(R * E, 2, 2)[keep].reshape(-1, 2)
+    packed.route_off = np.concatenate([[0], np.cumsum(np.where(keep, 2, 0))]).astype(np.int64)
+    packed = packed.validate()
+    kw, noise_o = {}, [None] * R
+    if noise == "device":
+        kw = dict(social_force=dict(std_lon=0.1, std_lat=0.05, noise="device", noise_seed=3))
+        noise_o = [dict(mode="device", std_lon=0.1, std_lat=0.05, seed=3, scenario_index=r) for r in range(R)]
+    eng = sga.RolloutEngine(R, E, record_capacity=steps + 1, event_capacity=512, **kw)
+    eng.upload(packed)
+    eng.rollout(steps)
+    st = eng.state()
+    rows, events = eng.metrics()
+    t, poses = eng.record(steps + 1)
+    eng.close()
+    for r in range(R):
+        s = unpack_scenario(packed, r)
+        o = oracle.rollout(s["knot_off"], s["knots"], s["bbox"], s["etype"], s["kind"], s["ego"], s["t0"], s["length"], 1 / 30,
+                           ctrl=s["ctrl"], route_off=s["route_off"], routes=s["routes"], max_steps=steps, event_cap=512, noise=noise_o[r])
+        n = o["n_steps"]
+        assert rows["n_steps"][r] == n, r
+        assert bits_equal(poses[: n + 1, r], o["poses"]), (r, "poses")
+        ped = s["kind"] == L.KIND_AGENT_PEDESTRIAN
+        assert bits_equal(st["force"][r][ped], o["extra"][-1, ped, 2:]) and bits_equal(st["dists"][r], o["dists"][-1]), r
+        assert np.array_equal(_dense_words(st["coll"][r], E), oracle.coll_to_dense(o["coll"], E)[-1]), r
+        for k in ("ego_avg_speed", "ego_max_speed", "ego_distance_travelled"):
+            assert rows[k][r] == o["metric_" + k], (r, k)
+        ev = events[events["scenario"] == r]
+        assert np.array_equal(ev["t"], o["ev_t"][: len(ev)]) and np.array_equal(ev["other"], o["ev_other"][: len(ev)]), r
+
+
 def test_wide_scenario_collision_terminal(sga, oracle):
     """terminal_conditions=["collision"] across wavefronts (workgroup-wide OR)."""
     import scenario_gym_amd._lib as L
@@ -982,6 +1038,33 @@ def test_future_collision_batch_matches_oracle(sga, oracle):
     assert seen == {True, False}
 
 
+def test_sensors_on_wide_scenarios_match_oracle(sga, oracle):
+    """FutureCollisionDetector and the entity layer of RasterizedMapSensor on scenarios of 300 and 512 entities (one thread
+    per entity slot: 512 threads per scenario): every flag / every cell equals the oracle's, after a reset and after 60 steps."""
+    from scenario_gym_amd import synthetic
+    from scenario_gym_amd.packing import unpack_scenario
+
+    for R, E, extent in ((6, 300, 45.0), (4, 512, 60.0)):
+        packed = synthetic.make_batch(R, E, n_steps=200, static_frac=0.15, vanish_frac=0.2, extent=extent)
+        eng = sga.RolloutEngine(R, E)
+        eng.upload(packed)
+        cells = 0
+        for n_adv in (0, 60):
+            if n_adv:
+                eng.step(n_adv)
+            st = eng.state()
+            fut = eng.future_collision(2.0, 10)
+            ras = eng.raster_entities(30.0, 24.0, 25, 19)
+            for r in range(R):
+                s = unpack_scenario(packed, r)
+                assert fut[r] == oracle.future_collision(s["knot_off"], s["knots"], s["bbox"], s["kind"], s["ego"], st["t"][r], 2.0, 10), (E, r)
+                want = oracle.raster_entities(st["poses"][r, :len(s["bbox"])], s["bbox"], s["ego"], 30.0, 24.0, 25, 19)
+                assert np.array_equal(ras[r], want), (E, n_adv, r)
+                cells += int(want.sum())
+        eng.close()
+        assert cells > 100
+
+
 def test_raster_entities_batch_matches_oracle(sga, oracle):
     """sg_raster_entities on a synthetic batch (256 x 40, dense scenes, vanishing entities) at two state times and two
     grids (one not square): every cell of every scenario equals the oracle's."""
@@ -1498,11 +1581,11 @@ def test_ego_off_road_terminal_matches_reference_and_oracle(sga, oracle):
     assert early >= 2 and st["n_steps"][-1] == 1 and st["done"][-1]
 
 
-@pytest.mark.parametrize("R,E", [(96, 8), (40, 3), (12, 100), (6, 200)])
+@pytest.mark.parametrize("R,E", [(96, 8), (40, 3), (12, 100), (6, 200), (6, 300), (4, 512)])
 def test_ego_off_road_with_controlled_egos_on_synthetic_roads(sga, oracle, R, E):
     """PID egos (entity 0) wandering over random polygon "roads": every scenario stops at the oracle's step -- cells
     wholly inside or outside answer from the grid, boundary cells through the exact test.  Tile widths 4, 8 and the
-    two- and four-wavefront scenarios."""
+    two-, four- and eight-wavefront scenarios."""
     import scenario_gym_amd._lib as L
     from scenario_gym_amd import synthetic
     from scenario_gym_amd.packing import unpack_scenario
@@ -1952,7 +2035,8 @@ def test_rss_inside_rollout_equals_tick_by_tick(sga):
     c.close()
 
 
-@pytest.mark.parametrize("R,E,ego", [(30, 3, "pid"), (12, 40, "replay"), (6, 100, "pid"), (4, 200, "replay"), (20, 64, "vehicle")])
+@pytest.mark.parametrize("R,E,ego", [(30, 3, "pid"), (12, 40, "replay"), (6, 100, "pid"), (4, 200, "replay"), (20, 64, "vehicle"),
+                                     (3, 300, "pid"), (2, 512, "replay")])
 def test_rss_fused_rollout_matches_oracle(sga, oracle, R, E, ego):
     """rollout_kernel_rss over the tile widths (4 ... 64 lanes) and the two- / four-wavefront scenarios, replay, PID and
     external-action egos: records of the latest update, safe distances and metric flags equal the oracle's callback run
@@ -1963,7 +2047,7 @@ def test_rss_fused_rollout_matches_oracle(sga, oracle, R, E, ego):
 
     steps = 70
     kind = dict(replay=L.KIND_AGENT_REPLAY, pid=L.KIND_AGENT_PID, vehicle=L.KIND_AGENT_VEHICLE)[ego]
-    packed = synthetic.make_batch(R, E, n_steps=steps, ego_kind=kind, extent=20.0 if E < 100 else 45.0, vanish_frac=0.3)
+    packed = synthetic.make_batch(R, E, n_steps=steps, ego_kind=kind, extent=20.0 if E < 100 else (45.0 if E <= 256 else 80.0), vanish_frac=0.3)
     packed.length = packed.length * np.linspace(0.5, 1.0, R)
     acts = synthetic.make_actions(steps, R) if ego == "vehicle" else None
     eng = sga.RolloutEngine(R, E)
