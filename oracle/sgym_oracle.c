@@ -12,7 +12,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-#define MAXE 1024
+#define MAXE 16384
 
 /* ------------------------------------------------------------------------------------------
  * Counter build (-DSGO_COUNT_FLOPS -> _build/libsgym_oracle_count.so; tools/count_flops.py): the ALGORITHMIC fp64

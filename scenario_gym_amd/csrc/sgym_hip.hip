@@ -94,6 +94,9 @@ struct sg_handle {
     sg::WalkArgs walk{};
     int walk_R = 0;
     int last_walk_chunks = 0;                    // chunks of the last call that went through the walker dispatch
+    bool wide = false;                           // more than 512 entities per scenario: the multi-kernel step (sgym_wide.hpp)
+    std::vector<void *> wide_allocs;
+    sg::WideArgs wide_args{};
     // page-locked staging of sg_read_metrics (the per-scenario state and the event table travel every time metrics are read:
     // 0.5 + up to 6 MB for 4096 scenarios; pageable copies ran at a third of the PCIe rate)
     void *pin_sd = nullptr, *pin_ev = nullptr;
@@ -332,9 +335,10 @@ extern "C" int sg_create(const sg_config *cfg, sg_handle **out)
     *out = nullptr;
     if (cfg->n_scenarios <= 0 || cfg->n_entities <= 0)
         return fail(nullptr, SG_ERR_INVALID, "sg_create: n_scenarios and n_entities must be positive");
-    if (cfg->n_entities > 512)
-        return fail(nullptr, SG_ERR_INVALID, "sg_create: n_entities=%d > 512 is not supported by ABI version %d",
-                    cfg->n_entities, SG_ABI_VERSION);
+    if (cfg->n_entities > 16384)
+        return fail(nullptr, SG_ERR_INVALID, "sg_create: n_entities=%d > 16384 (the event record keeps the other entity in 32 bits, "
+                    "the state blocks SG_F_COLL + n_entities / 64 rows: nothing stops at 512 any more, this is a sanity bound)",
+                    cfg->n_entities);
     if (!(cfg->timestep > 0.0)) return fail(nullptr, SG_ERR_INVALID, "sg_create: timestep must be > 0");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -356,7 +360,9 @@ extern "C" int sg_create(const sg_config *cfg, sg_handle **out)
     h->G = G;
     // wavefronts per scenario.  8 (257..512 entities): replay entities, replay agents and in-kernel PID / vehicle controllers
     // through rollout_kernel<64, 8, false, false>; no pedestrian agents, RSS callback or observation kernels at that width
-    h->WV = h->E <= 64 ? 1 : (h->E <= 128 ? 2 : (h->E <= 256 ? 4 : 8));
+    // more than 512: no fused kernel -- the step runs as four kernels over as many workgroups as the scenario needs (sgym_wide.hpp)
+    h->WV = h->E <= 64 ? 1 : (h->E <= 128 ? 2 : (h->E <= 256 ? 4 : (h->E <= 512 ? 8 : (h->E + 63) / 64)));
+    h->wide = h->WV > 8;
     h->EP = G * h->WV;
     // SocialForceParameters defaults, pedestrian/social_force.py:16-30 (noise off)
     h->sf = sg_social_force{1.5, 1.0, 1.0, 0.0, 0.5, 1.0, std::cos(200.0 / 2 * M_PI / 180), 1.3, 0.0, 0.0, 2.0, 0.1};
@@ -428,6 +434,7 @@ extern "C" int sg_destroy(sg_handle *h)
     free_pool(h->road_allocs);
     free_pool(h->slice_allocs);
     free_pool(h->walk_allocs);
+    free_pool(h->wide_allocs);
     if (h->pin_sd) (void)hipHostFree(h->pin_sd);
     if (h->pin_ev) (void)hipHostFree(h->pin_ev);
     if (h->obs_buf) (void)hipFree(h->obs_buf);
@@ -600,6 +607,47 @@ static int launch_main(sg_handle *h, int n_steps, int do_reset, int force, const
 // SG_TAB_MIN_STEPS steps to do take the two-kernel path: control_kernel integrates the PID / vehicle agents
 // for a chunk of steps on its own stream while rollout_kernel<TAB> consumes the previous chunks' tables -- large batches as
 // two or three pipelines on streams of their own (below).
+// Scenarios of more than 512 entities (sgym_wide.hpp): State.reset / n x ScenarioGym.step as four kernels per step.  Every
+// scenario that may run steps in lockstep (a done scenario sits the step out unless `force`); rollout() stops launching when
+// a readback every 64 steps says everybody is done.
+static int launch_wide(sg_handle *h, int n_steps, int do_reset, int force, const double *d_actions)
+{
+    const int R = h->R, EP = h->EP;
+    int rc = SG_OK;
+    if (!h->wide_args.scr) {
+        auto &A = h->wide_allocs;
+        if ((rc = dev_alloc(h, A, &h->wide_args.scr, h->NE * sg::WS_W)) || (rc = dev_alloc(h, A, &h->wide_args.cor, h->NE * 8)) ||
+            (rc = dev_alloc(h, A, &h->wide_args.circ, h->NE * 4)) || (rc = dev_alloc(h, A, &h->wide_args.last_row, (size_t)R * h->WV)))
+            return rc;
+    }
+    const dim3 ge((unsigned)((EP + 255) / 256), (unsigned)R), gs((unsigned)R);
+    auto one = [&](int mode, const double *acts) {
+        sg::WideArgs wa = h->wide_args;
+        wa.mode = mode;
+        wa.force = force;
+        wa.actions = acts;
+        sgl::wide_step(ge, gs, h->stream, h->p, h->cfg.timestep, wa);
+    };
+    if (do_reset) {
+        one(do_reset == 2 ? 2 : 1, nullptr);
+        HIP_TRY(h, hipGetLastError());
+    }
+    for (int k = 0; k < n_steps; ++k) {
+        one(0, d_actions ? d_actions + (size_t)k * R * 2 : nullptr);
+        if (!force && (k & 63) == 63 && k + 1 < n_steps) { // is anybody still running?
+            HIP_TRY(h, hipGetLastError());
+            std::vector<sg_scenario_state> sd((size_t)R);
+            HIP_TRY(h, hipMemcpyAsync(sd.data(), h->p.sdyn, (size_t)R * sizeof(sg_scenario_state), hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
+            bool all = true;
+            for (int r = 0; r < R && all; ++r) all = sd[(size_t)r].done != 0;
+            if (all) break;
+        }
+    }
+    HIP_TRY(h, hipGetLastError());
+    return SG_OK;
+}
+
 // A long rollout of an all-pedestrian batch of 129..256 entities (BASELINE config 5) in chunks of steps: every chunk sorts
 // its scenarios into classes (walk_classify_kernel) -- few enough entities still working: the walker variant (walk_kernel<1 /
 // 2>, sgym_walk.hpp: one lane per ACTIVE entity, the arrived pedestrians are LDS rows), else rollout_kernel_crowd -- and runs
@@ -694,6 +742,17 @@ static int launch_rollout(sg_handle *h, int n_steps, int do_reset, int force, co
 static int launch_rollout_impl(sg_handle *h, int n_steps, int do_reset, int force, const double *d_actions)
 {
     h->last_pipes = 0;
+    if (h->wide) {
+        h->n_launches = 0;
+        h->launch_ev.clear();
+        h->timing_now = n_steps >= 16;
+        if (h->timing_now) HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
+        const int rcw = launch_wide(h, n_steps, do_reset, force, d_actions);
+        if (rcw) return rcw;
+        if (h->timing_now) HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
+        h->timed = h->timing_now;
+        return SG_OK;
+    }
     const int tab_min = h->tab_min, chunk_steps = std::max(1, h->chunk_steps), no_overlap = !h->overlap;
     h->n_launches = 0;
     h->launch_ev.clear();
@@ -1134,6 +1193,15 @@ extern "C" int sg_upload(sg_handle *h, const sg_scenarios *sc)
         h->crowd_riders = ok;
     }
     if (h->has_ped && (!sc->route_off || !sc->routes)) return fail(h, SG_ERR_INVALID, "sg_upload: pedestrian agents need route_off/routes");
+    if (h->wide) { // more than 512 entities per scenario: the multi-kernel step (sgym_wide.hpp) and what it does not do
+        for (size_t i = 0; i < (size_t)h->R * h->E; ++i)
+            if (sc->kind[i] == SG_KIND_AGENT_EXTERNAL)
+                return fail(h, SG_ERR_INVALID, "sg_upload: caller-run agents (SG_KIND_AGENT_EXTERNAL) are available up to 512 entities per scenario");
+        if (h->cfg.terminal_mask & SG_TERM_EGO_OFF_ROAD)
+            return fail(h, SG_ERR_INVALID, "sg_upload: the ego_off_road terminal condition is available up to 512 entities per scenario");
+        if (h->has_ped && h->noise_mode == SG_NOISE_STREAM)
+            return fail(h, SG_ERR_INVALID, "sg_upload: the pedestrian noise stream is available up to 512 entities per scenario (the counter-based generator works)");
+    }
     // (257..512 entities: pedestrian agents run the general pedestrian variant, rollout_kernel<64, 8, true, false>; the crowd
     // kernels, the riders' pre-pass and road networks with pedestrians stop at 256)
     if (h->has_ped && (h->cfg.terminal_mask & SG_TERM_EGO_OFF_ROAD))
@@ -1598,6 +1666,7 @@ static int obs_scratch(sg_handle *h, size_t bytes, unsigned char **out)
 extern "C" int sg_tick(sg_handle *h, const double *actions, int32_t actions_device, double width, double height, int32_t nw,
                        int32_t nh, int32_t n_layers, const int32_t *layers, const uint8_t **d_obs, const uint32_t **d_flags)
 {
+    if (h && h->wide) return fail(h, SG_ERR_INVALID, "%s: available up to 512 entities per scenario", "sg_tick");
     if (!h) return SG_ERR_INVALID;
     if (!h->uploaded) return fail(h, SG_ERR_STATE, "sg_tick: no scenarios uploaded");
     if (!layers || n_layers < 1 || n_layers > 8 || nw < 1 || nh < 1 || !(width >= 0.0) || !(height >= 0.0))
@@ -2088,6 +2157,7 @@ static int ensure_rssq(sg_handle *h)
 
 extern "C" int sg_rss_update(sg_handle *h, int32_t reset)
 {
+    if (h && h->wide) return fail(h, SG_ERR_INVALID, "%s: available up to 512 entities per scenario", "sg_rss_update");
     if (!h) return SG_ERR_INVALID;
     if (!h->uploaded) return fail(h, SG_ERR_STATE, "sg_rss_update: no scenarios uploaded");
 
@@ -2104,6 +2174,7 @@ extern "C" int sg_rss_update(sg_handle *h, int32_t reset)
 
 extern "C" int sg_set_rss(sg_handle *h, int32_t enabled)
 {
+    if (h && h->wide) return fail(h, SG_ERR_INVALID, "%s: available up to 512 entities per scenario", "sg_set_rss");
     if (!h) return SG_ERR_INVALID;
     if (enabled && h->WV > 4 && (h->has_ped || (h->cfg.terminal_mask & SG_TERM_EGO_OFF_ROAD)))
         return fail(h, SG_ERR_INVALID, "sg_set_rss: with pedestrian agents or the ego_off_road terminal condition the callback is available up to 256 entities per scenario");
@@ -2321,6 +2392,7 @@ int build_road_network(const sg_road_networks *in, int n, RoadBuild &B)
 
 extern "C" int sg_set_road_networks(sg_handle *h, const sg_road_networks *in)
 {
+    if (h && h->wide) return fail(h, SG_ERR_INVALID, "%s: available up to 512 entities per scenario", "sg_set_road_networks");
     if (!h || !in) return h ? fail(h, SG_ERR_INVALID, "sg_set_road_networks: null argument") : SG_ERR_INVALID;
     if (!h->uploaded) return fail(h, SG_ERR_STATE, "sg_set_road_networks: no scenarios uploaded");
     if (in->n_networks < 0 || !in->net_of_scenario || (in->n_networks > 0 && (!in->poly_off || !in->ring_off || !in->vert_off || !in->layers)))
@@ -2389,6 +2461,7 @@ extern "C" int sg_set_road_networks(sg_handle *h, const sg_road_networks *in)
 static int raster_map_launch(sg_handle *h, const char *who, double width, double height, int32_t nw, int32_t nh, int32_t n_layers,
                              const int32_t *layers, unsigned char **d_out, size_t *bytes_out)
 {
+    if (h && h->wide) return fail(h, SG_ERR_INVALID, "%s: available up to 512 entities per scenario", "sg_raster_map");
     if (!layers || n_layers < 1 || nw < 1 || nh < 1 || !(width >= 0.0) || !(height >= 0.0))
         return fail(h, SG_ERR_INVALID, "%s: bad argument", who);
     if (!h->uploaded) return fail(h, SG_ERR_STATE, "%s: no scenarios uploaded", who);
@@ -2448,6 +2521,7 @@ extern "C" int sg_raster_map_device(sg_handle *h, double width, double height, i
 
 extern "C" int sg_raster_entities(sg_handle *h, double width, double height, int32_t nw, int32_t nh, uint8_t *out)
 {
+    if (h && h->wide) return fail(h, SG_ERR_INVALID, "%s: available up to 512 entities per scenario", "sg_raster_entities");
     if (!h || !out || nw < 1 || nh < 1 || !(width >= 0.0) || !(height >= 0.0))
         return h ? fail(h, SG_ERR_INVALID, "sg_raster_entities: bad argument") : SG_ERR_INVALID;
     if (!h->uploaded) return fail(h, SG_ERR_STATE, "sg_raster_entities: no scenarios uploaded");

@@ -8,6 +8,7 @@
 #pragma once
 #include "sgym_device.hpp"
 #include "sgym_walk.hpp"
+#include "sgym_wide.hpp"
 
 namespace sgl {
 
@@ -31,6 +32,8 @@ void rollout_crowd(int WV, bool riders, dim3 grid, hipStream_t s, const RolloutA
 // active lanes per scenario)
 void walk_classify(dim3 grid, hipStream_t s, const sg::Params &p, const sg::WalkArgs &wa, int chunk_len, int enable_mask);
 void walk_rollout(int WVL, dim3 grid, hipStream_t s, const sg::Params &p, double timestep, int n_steps, int force, const sg::WalkArgs &wa);
+// k_wide.hip (sgym_wide.hpp): one step (mode 0) or State.reset (mode 1 / 2) of scenarios of more than 512 entities, four kernels
+void wide_step(dim3 grid_entities, dim3 grid_scenarios, hipStream_t s, const sg::Params &p, double timestep, const sg::WideArgs &wa);
 // k_rss.hip: rollout_kernel_rss<G, WV> / rollout_kernel_rss_road<G, WV> (road)
 void rollout_rss(int G, int WV, bool road, dim3 grid, hipStream_t s, const RolloutArgs &a);
 // k_rss_tab.hip: rollout_kernel_rss_tab<G> + rss_lines_kernel

@@ -1,0 +1,459 @@
+// sgym_wide.hpp -- scenarios of MORE THAN 512 entities: the step as four kernels over any number of workgroups.
+//
+// The reference has no entity limit (State.collisions is a Python loop over an STRtree, state/utils.py:10-49); the fused
+// rollout kernels (sgym_device.hpp) keep one scenario inside one workgroup and stop at 512 entities.  Beyond that a scenario
+// spans several workgroups, which can only meet at kernel boundaries, so ScenarioGym.step (scenario_gym.py:227-254) becomes
+//   wide_move_kernel     one thread per entity: the new pose -- BatchReplayEntity / replay agent interpolation, PID and vehicle
+//                        controllers, the social force over ALL pedestrians of the scenario (staged through LDS 256 at a
+//                        time, neighbours in entity order) -- into a scratch row; nothing of the state is touched yet
+//   wide_commit_kernel   State.update_poses / update_statistics for the entity, its row stores, its fp64 box corners and
+//                        bounding circle for the collision pass
+//   wide_collide_kernel  State.collisions: every present entity against every other one of its scenario (circles staged
+//                        through LDS, exact fp64 separating-axis test on the pairs whose circles overlap; equal geometries
+//                        never list each other and map to the last owner, utils.py:59, state/utils.py:32-40)
+//   wide_finish_kernel   one workgroup per scenario: the clock, terminal conditions, ego metrics, CollisionMetric events
+// in that order, once per step.  Same arithmetic as the fused kernels and the oracle (plain IEEE operations: ExactArith), so
+// the same bits; ~4 launches per step instead of thousands of steps per launch -- the price of not having a ceiling.
+// Not at this width: caller-run agents (SG_KIND_AGENT_EXTERNAL), road networks, the RSS callback, the observation kernels,
+// the noise stream mode (the counter-based generator works).
+#pragma once
+#include "sgym_device.hpp"
+
+namespace sg {
+
+struct WideArgs {
+    double *scr;          // [NE][16] per entity: new pose 6, new presence, velocity 6 (reset), spare
+    double *cor;          // [NE][8] fp64 corners of the committed pose
+    double *circ;         // [NE][4] bounding circle of the box: cx, cy, radius (NaN cx: absent)
+    uint64_t *last_row;   // [R][WV] CollisionMetric.last_timestep
+    const double *actions; // [R][2] of THIS step or nullptr
+    int mode;             // 0 step, 1 reset (State.reset for every scenario), 2 reset of the scenarios in p.reset_mask
+    int force;
+};
+enum { WS_NP = 0, WS_NPRES = 6, WS_VEL = 7, WS_FPX = 13, WS_FPY = 14, WS_W = 16 };
+
+struct WideEnt {
+    int r, e;
+    uint32_t g;
+    LanePtr st, dy;
+    __device__ __forceinline__ WideEnt(const Params &p, int r_, int e_)
+        : r(r_), e(e_), g((uint32_t)r_ * p.EP + e_),
+          st(p.stat + (size_t)(((uint32_t)r_ * p.EP + e_) >> 6) * (ST_COUNT * 64), ((((uint32_t)r_ * p.EP + e_)) & 63) * 8u),
+          dy(p.dyn + (size_t)(((uint32_t)r_ * p.EP + e_) >> 6) * ((size_t)p.FROWS * 64), ((((uint32_t)r_ * p.EP + e_)) & 63) * 8u) {}
+};
+
+__device__ __forceinline__ bool wide_runs(const Params &p, const WideArgs &wa, int r)
+{
+    if (wa.mode == 1) return true;
+    if (wa.mode == 2) return p.reset_mask[r] != 0;
+    return wa.force || !p.sdyn[r].done;
+}
+
+#ifdef SG_UNIT_WIDE
+// ---- new poses: scenario_gym.py:233-245 (step) / State.reset, state.py:106-143 (reset) --------------------------------------
+static __global__ __launch_bounds__(256) void wide_move_kernel(Params p, double timestep, WideArgs wa)
+{
+    __shared__ double s_px[256], s_py[256], s_vx[256], s_vy[256];
+    __shared__ unsigned char s_ok[256];
+    const int r = blockIdx.y, tid = threadIdx.x, e = blockIdx.x * 256 + tid;
+    if (!wide_runs(p, wa, r)) return;
+    const bool in = e < p.E;
+    const WideEnt w(p, r, in ? e : 0);
+    const ScenStatic &ss = p.sstat[r];
+    const sg_scenario_state &sd = p.sdyn[r];
+    const int64_t meta = fld<int64_t>(w.st, ST_META);
+    const int kind = in ? (int)(meta & 0xff) : SG_KIND_NONE;
+    const int nk = (int)(meta >> 32);
+    const bool is_static = nk == 1;
+    const double min_t = fld(w.st, ST_MIN_T), max_t = fld(w.st, ST_MAX_T);
+    const double *kn = p.knots + fld<int64_t>(w.st, ST_KNOT_OFF) * 7;
+    double *scr = wa.scr + (size_t)w.g * WS_W;
+    double np_[6] = {0, 0, 0, 0, 0, 0};
+    bool npres = false;
+    if (wa.mode != 0) { // ---- State.reset(t0) ----
+        const double t = ss.t0;
+        double vel[6] = {0, 0, 0, 0, 0, 0};
+        if (kind != SG_KIND_NONE) {
+            const bool inside = (t >= min_t) && (t <= max_t);
+            if (is_static || inside) { own_position_extrap(kn, nk, t, np_); npres = true; }
+            else if (p.persist) {
+                const double *rowp = t < min_t ? kn : kn + (size_t)(nk - 1) * 7;
+                for (int c = 0; c < 6; ++c) np_[c] = rowp[1 + c];
+                npres = true;
+            }
+            if (npres && inside) { // Trajectory.velocity_at_t, trajectory.py:243-273
+                const double eps = 1e-4;
+                double a[6], b[6];
+                own_position_extrap(kn, nk, t + eps / 2, a);
+                own_position_extrap(kn, nk, t - eps / 2, b);
+                for (int c = 0; c < 6; ++c) vel[c] = (a[c] - b[c]) / eps;
+            }
+        }
+        if (in) {
+            for (int c = 0; c < 6; ++c) { scr[WS_NP + c] = np_[c]; scr[WS_VEL + c] = vel[c]; }
+            scr[WS_NPRES] = npres ? 1.0 : 0.0;
+            scr[WS_FPX] = scr[WS_FPY] = 0.0;
+        }
+        return;
+    }
+    // ---- one step ----
+    const double t = sd.t, prev_t = sd.prev_t;
+    const double next_t = t + timestep, state_dt = t - prev_t, dt = next_t - t;
+    const bool present = in && kind != SG_KIND_NONE && fld<uint64_t>(w.dy, SG_F_PRESENT) != 0;
+    double pose[6];
+    for (int c = 0; c < 6; ++c) pose[c] = fld(w.dy, SG_F_POSE + c);
+    const double velx = fld(w.dy, SG_F_VEL + 0), vely = fld(w.dy, SG_F_VEL + 1);
+    CtrlState cs{fld(w.dy, SG_F_CTRL + 0), fld(w.dy, SG_F_CTRL + 1), fld(w.dy, SG_F_CTRL + 2), fld(w.dy, SG_F_CTRL + 3)};
+    int goal_idx = (int)cs.e_lon_prev; // (pedestrians keep goal_idx in the second controller row)
+    double fpx = 0.0, fpy = 0.0;
+    ConstTbl K = (ConstTbl)SG_TRIG;
+    // the trajectory position at next_t: union grid for batch-replay entities, own knots for agents (constant outside)
+    auto traj_at = [&](double tq, double (&out)[6]) {
+        Table T = lane_table(p, kind, ss, e, w.st);
+        Segment S;
+        S.cur = seg_locate(T, tq);
+        seg_load(T, S);
+        const double dq = tq - S.x_lo;
+        for (int c = 0; c < 6; ++c) out[c] = S.sl[c] * dq + S.ylo[c];
+    };
+    // ---- the social force needs every pedestrian of the scenario: all threads stage, pedestrian threads accumulate ----
+    const bool is_ped = kind == SG_KIND_AGENT_PEDESTRIAN;
+    const double *wp = nullptr;
+    int nwp = 0;
+    bool go = false;
+    double fx = 0.0, fy = 0.0, vdes = 0.0, hs = 0.0, hc = 1.0, radius = 0.0;
+    if (is_ped && present) {
+        const int64_t rt = fld<int64_t>(w.st, ST_ROUTE);
+        wp = p.routes + (rt & 0xffffffffffffll) * 2;
+        nwp = (int)(rt >> 48);
+        if (goal_idx <= nwp - 1) goal_idx = ped_goal_update(wp, nwp, pose[0], pose[1]);
+        if (goal_idx <= nwp - 1) {
+            go = true;
+            double gx = wp[2 * goal_idx] - pose[0], gy = wp[2 * goal_idx + 1] - pose[1]; // _force_to_goal, social_force.py:119-138
+            double gn = sg_norm2(gx, gy);
+            if (gn == 0) gn += 0.000000001;
+            vdes = fld(w.st, ST_CTRL + SG_C_PED_SPEED_DESIRED);
+            const double inv_tau = 1 / p.sf.relaxation_time;
+            fx = inv_tau * (vdes * (gx / gn) - velx);
+            fy = inv_tau * (vdes * (gy / gn) - vely);
+            sg_sincos(fld(w.st, ST_CTRL + SG_C_PED_HEAD_ROT), hs, hc, K);
+            radius = fld(w.st, ST_CTRL + SG_C_PED_RADIUS);
+        }
+    }
+    const double k2_scale = p.sf.ped_repulse_V / p.sf.ped_repulse_sigma;
+    // (the loop bounds are uniform over the grid row of the scenario: every thread of every block walks all chunks)
+    for (int c0 = 0; c0 < p.EP; c0 += 256) {
+        const int j = c0 + tid;
+        __syncthreads();
+        {
+            bool ok = false;
+            double jx = 0, jy = 0, jvx = 0, jvy = 0;
+            if (j < p.E) {
+                const WideEnt o(p, r, j);
+                const int64_t m2 = fld<int64_t>(o.st, ST_META);
+                ok = (int)(m2 & 0xff) != SG_KIND_NONE && ((m2 >> 8) & 0xff) == 1 && fld<uint64_t>(o.dy, SG_F_PRESENT) != 0;
+                jx = fld(o.dy, SG_F_POSE + 0); jy = fld(o.dy, SG_F_POSE + 1);
+                jvx = fld(o.dy, SG_F_VEL + 0); jvy = fld(o.dy, SG_F_VEL + 1);
+            }
+            s_px[tid] = jx; s_py[tid] = jy; s_vx[tid] = jvx; s_vy[tid] = jvy; s_ok[tid] = ok;
+        }
+        __syncthreads();
+        if (go) {
+            const int n = min(256, p.E - c0);
+            for (int q = 0; q < n; ++q) { // PedestrianSensor.get_nearby_pedestrians in entity order, sensor.py:55-64
+                if (c0 + q == e || !s_ok[q]) continue;
+                const double ox = s_px[q], oy = s_py[q];
+                if (!sg_in_radius(pose[0], pose[1], radius, ox, oy, p.gon)) continue;
+                const double ovx = s_vx[q], ovy = s_vy[q];
+                const double vmag = sg_norm2(ovx, ovy) + 0.0000000001;
+                const double odx = ovx / vmag, ody = ovy / vmag, step = vmag * (next_t - t);
+                ExactArith EA;
+                double c1x, c1y, c2x, c2y;
+                ped_pair<false, false>(EA, p.sf, k2_scale, pose[0], pose[1], hs, hc, ox, oy, ovx, ovy, odx, ody, step, c1x, c1y, c2x, c2y);
+                ped_accumulate(p.sf, c1x, c1y, c2x, c2y, fx, fy);
+            }
+        }
+    }
+    // ---- the pose ----
+    if (kind == SG_KIND_REPLAY) { // BatchReplayEntity.step, batch.py:34-53
+        npres = p.persist || is_static || (next_t >= min_t && next_t <= max_t);
+        traj_at(next_t, np_);
+    } else if (kind >= SG_KIND_AGENT_REPLAY && in) {
+        if (present) {
+            npres = true;
+            if (kind == SG_KIND_AGENT_REPLAY) {
+                traj_at(next_t, np_);
+            } else if (kind == SG_KIND_AGENT_PID || kind == SG_KIND_AGENT_VEHICLE) {
+                double tgt[6];
+                traj_at(next_t, tgt);
+                for (int c = 0; c < 6; ++c) np_[c] = pose[c];
+                const double bl = fld(w.st, ST_BL);
+                double sin_h, cos_h;
+                sg_sincos(pose[3], sin_h, cos_h, K);
+                const LanePtr st_c = w.st;
+                auto cp = [&](int q) -> double { return fld(st_c, ST_CTRL + q); };
+                if (kind == SG_KIND_AGENT_PID) pid_step(cs, cp, bl, state_dt, dt, tgt[0], tgt[1], sin_h, cos_h, np_, K);
+                else {
+                    double aa = 0.0, as = 0.0;
+                    if (wa.actions) { aa = wa.actions[(size_t)r * 2]; as = wa.actions[(size_t)r * 2 + 1]; }
+                    vehicle_step(cs, cp, bl, dt, aa, as, sin_h, cos_h, np_, K);
+                }
+            } else if (is_ped) {
+                double speed_rand = p.sf.bias_lon, heading_rand = p.sf.bias_lat;
+                if (p.noise_mode == 2) {
+                    double z0, z1;
+                    sg_noise_pair(p.noise_seed, (uint32_t)r, (uint32_t)e, (uint32_t)sd.n_steps, z0, z1, K);
+                    speed_rand = p.sf.bias_lon + p.noise_std_lon * z0;
+                    heading_rand = p.sf.bias_lat + p.noise_std_lat * z1;
+                }
+                ped_move(p, go, fx, fy, vdes, fld(w.st, ST_CTRL + SG_C_PED_MAX_SPEED), pose, state_dt, cs.speed, fpx, fpy, np_, K,
+                         speed_rand, heading_rand);
+                cs.e_lon_prev = (double)goal_idx;
+            }
+        } else if (min_t >= t) { // scenario_gym.py:240-244: spawn at the trajectory position of next_t
+            npres = true;
+            traj_at(next_t, np_);
+        }
+    }
+    if (in) {
+        for (int c = 0; c < 6; ++c) scr[WS_NP + c] = np_[c];
+        scr[WS_NPRES] = npres ? 1.0 : 0.0;
+        scr[WS_FPX] = fpx; scr[WS_FPY] = fpy;
+        // controller state of this step (committed by wide_commit_kernel together with the pose)
+        scr[WS_VEL + 0] = cs.speed; scr[WS_VEL + 1] = cs.e_lon_prev; scr[WS_VEL + 2] = cs.e_lat_prev; scr[WS_VEL + 3] = cs.e_lon_int;
+    }
+}
+
+// ---- State.update_poses / update_statistics (state.py:203-239), the row stores, corners + circle for the collision pass -------
+static __global__ __launch_bounds__(256) void wide_commit_kernel(Params p, double timestep, WideArgs wa)
+{
+    const int r = blockIdx.y, e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= p.EP) return;
+    const WideEnt w(p, r, e);
+    double *circ = wa.circ + (size_t)w.g * 4, *cor = wa.cor + (size_t)w.g * 8;
+    const bool runs = wide_runs(p, wa, r);
+    const int64_t meta = fld<int64_t>(w.st, ST_META);
+    const int kind = e < p.E ? (int)(meta & 0xff) : SG_KIND_NONE;
+    const sg_scenario_state &sd = p.sdyn[r];
+    const ScenStatic &ss = p.sstat[r];
+    double pose[6];
+    bool present;
+    if (runs && kind != SG_KIND_NONE) {
+        const double *scr = wa.scr + (size_t)w.g * WS_W;
+        const bool npres = scr[WS_NPRES] != 0.0;
+        double np_[6], vel[6];
+        for (int c = 0; c < 6; ++c) np_[c] = scr[WS_NP + c];
+        if (wa.mode != 0) { // reset: velocities from the trajectory, distances 0, controllers at rest
+            for (int c = 0; c < 6; ++c) { vel[c] = scr[WS_VEL + c]; pose[c] = np_[c]; }
+            present = npres;
+            for (int c = 0; c < 6; ++c) { stf(w.dy, SG_F_POSE + c, pose[c]); stf(w.dy, SG_F_VEL + c, vel[c]); }
+            stf(w.dy, SG_F_DIST, 0.0);
+            stf(w.dy, SG_F_PRESENT, (uint64_t)present);
+            stf(w.dy, SG_F_FORCE + 0, 0.0); stf(w.dy, SG_F_FORCE + 1, 0.0);
+            double speed = present ? sg_norm2(vel[0], vel[1]) : 0.0; // controller.py:100-103
+            if (kind == SG_KIND_AGENT_PEDESTRIAN) speed = 0.0;         // pedestrian/controller.py:21-23
+            stf(w.dy, SG_F_CTRL + 0, speed); stf(w.dy, SG_F_CTRL + 1, 0.0); stf(w.dy, SG_F_CTRL + 2, 0.0); stf(w.dy, SG_F_CTRL + 3, 0.0);
+            if (p.rec_cap > 0)
+                for (int c = 0; c < 6; ++c)
+                    p.rec_pose[(size_t)c * p.R * p.EP + (size_t)r * p.EP + e] = present ? pose[c] : __builtin_nan("");
+        } else {
+            const double t = sd.t, next_t = t + timestep, dt = next_t - t;
+            const bool was = fld<uint64_t>(w.dy, SG_F_PRESENT) != 0;
+            double prev[6];
+            if (npres && !was) // newcomer: previous pose from the extrapolated trajectory, state.py:219-222
+                own_position_extrap(p.knots + fld<int64_t>(w.st, ST_KNOT_OFF) * 7, (int)(meta >> 32), t, prev);
+            else
+                for (int c = 0; c < 6; ++c) prev[c] = fld(w.dy, SG_F_POSE + c);
+            double d[6];
+            for (int c = 0; c < 6; ++c) { d[c] = np_[c] - prev[c]; vel[c] = d[c] / dt; }
+            present = npres;
+            for (int c = 0; c < 6; ++c) pose[c] = npres ? np_[c] : fld(w.dy, SG_F_POSE + c);
+            if (npres) {
+                for (int c = 0; c < 6; ++c) { stf(w.dy, SG_F_POSE + c, pose[c]); stf(w.dy, SG_F_VEL + c, vel[c]); }
+                stf(w.dy, SG_F_DIST, fld(w.dy, SG_F_DIST) + sg_norm3(d[0], d[1], d[2]));
+            }
+            stf(w.dy, SG_F_PRESENT, (uint64_t)present);
+            if (kind >= SG_KIND_AGENT_REPLAY && was) { // an agent that stepped: its controller state
+                if (kind != SG_KIND_AGENT_REPLAY) {
+                    stf(w.dy, SG_F_CTRL + 0, scr[WS_VEL + 0]); stf(w.dy, SG_F_CTRL + 1, scr[WS_VEL + 1]);
+                    stf(w.dy, SG_F_CTRL + 2, scr[WS_VEL + 2]); stf(w.dy, SG_F_CTRL + 3, scr[WS_VEL + 3]);
+                }
+                if (kind == SG_KIND_AGENT_PEDESTRIAN) { stf(w.dy, SG_F_FORCE + 0, scr[WS_FPX]); stf(w.dy, SG_F_FORCE + 1, scr[WS_FPY]); }
+            }
+            const int steps = sd.n_steps + 1;
+            if (p.rec_cap > 0 && steps < p.rec_cap)
+                for (int c = 0; c < 6; ++c)
+                    p.rec_pose[((size_t)steps * 6 + c) * p.R * p.EP + (size_t)r * p.EP + e] = present ? pose[c] : __builtin_nan("");
+        }
+        (void)ss;
+    } else {
+        present = kind != SG_KIND_NONE && fld<uint64_t>(w.dy, SG_F_PRESENT) != 0;
+        for (int c = 0; c < 6; ++c) pose[c] = fld(w.dy, SG_F_POSE + c);
+    }
+    // the box for the collision pass (every scenario, also the ones that did not step: their rows are recomputed alike)
+    if (present) {
+        double s, c;
+        sg_sincos(pose[3], s, c);
+        const double bw = fld(w.st, ST_BW), bl = fld(w.st, ST_BL), bcx = fld(w.st, ST_BCX), bcy = fld(w.st, ST_BCY);
+        double C[8];
+        sg_corners(pose[0], pose[1], s, c, bw, bl, bcx, bcy, C);
+        for (int k = 0; k < 8; ++k) cor[k] = C[k];
+        const double cx = 0.25 * (C[0] + C[2] + C[4] + C[6]), cy = 0.25 * (C[1] + C[3] + C[5] + C[7]);
+        double rad = 0.0;
+        for (int k = 0; k < 4; ++k) rad = __builtin_fmax(rad, sg_norm2(C[2 * k] - cx, C[2 * k + 1] - cy));
+        circ[0] = cx; circ[1] = cy; circ[2] = rad * (1.0 + 1e-12) + 1e-9 * (1.0 + __builtin_fabs(cx) + __builtin_fabs(cy));
+    } else {
+        circ[0] = __builtin_nan(""); circ[1] = 0.0; circ[2] = 0.0;
+    }
+}
+
+__device__ __forceinline__ bool wide_same(const double *a, const double *b)
+{
+    bool same = true;
+    for (int k = 0; k < 8; ++k) same = same && (a[k] == b[k]);
+    return same;
+}
+
+// ---- State.collisions(): every present entity against every other one of its scenario ---------------------------------------
+static __global__ __launch_bounds__(256) void wide_collide_kernel(Params p, WideArgs wa)
+{
+    __shared__ double s_c[256][3];
+    const int r = blockIdx.y, tid = threadIdx.x, e = blockIdx.x * 256 + tid;
+    const int W = p.FROWS - SG_F_COLL;
+    const bool in = e < p.E;
+    const WideEnt w(p, r, in ? e : 0);
+    const double *circ = wa.circ + (size_t)w.g * 4, *A = wa.cor + (size_t)w.g * 8;
+    const double cx = in ? circ[0] : __builtin_nan(""), cy = circ[1], rad = circ[2];
+    const bool present = cx == cx;
+    if (in)
+        for (int q = 0; q < W; ++q) stf(w.dy, SG_F_COLL + q, (uint64_t)0);
+    for (int c0 = 0; c0 < p.EP; c0 += 256) {
+        __syncthreads();
+        {
+            const int j = c0 + tid;
+            const double *cj = wa.circ + ((size_t)r * p.EP + min(j, p.EP - 1)) * 4;
+            s_c[tid][0] = j < p.E ? cj[0] : __builtin_nan(""); s_c[tid][1] = cj[1]; s_c[tid][2] = cj[2];
+        }
+        __syncthreads();
+        if (!present) continue;
+        const int n = min(256, p.E - c0);
+        for (int q = 0; q < n; ++q) {
+            const int j = c0 + q;
+            const double dx = s_c[q][0] - cx, dy = s_c[q][1] - cy, rr = s_c[q][2] + rad;
+            if (j == e || !(dx * dx + dy * dy <= rr * rr)) continue; // (an absent slot: NaN, the compare fails)
+            const double *B = wa.cor + ((size_t)r * p.EP + j) * 8;
+            if (wide_same(A, B)) continue;                 // g != g_prime: never listed (utils.py:59)
+            if (!sg_quads_intersect(A, B)) continue;
+            int o = j;                                     // geometry -> LAST entity owning it (state/utils.py:32-40)
+            for (int k = j + 1; k < p.E; ++k) {
+                const double *ck = wa.circ + ((size_t)r * p.EP + k) * 4;
+                if (ck[0] == s_c[q][0] && ck[1] == s_c[q][1] && wide_same(B, wa.cor + ((size_t)r * p.EP + k) * 8)) o = k;
+            }
+            const uint64_t old = fld<uint64_t>(w.dy, SG_F_COLL + (o >> 6));
+            stf(w.dy, SG_F_COLL + (o >> 6), old | (1ull << (o & 63)));
+        }
+    }
+}
+
+// ---- per scenario: clock, check_terminal (state.py:268-270, 397-408), ego metrics, CollisionMetric._step ------------------------
+static __global__ __launch_bounds__(256) void wide_finish_kernel(Params p, double timestep, WideArgs wa)
+{
+    __shared__ int s_any, s_ego0;
+    const int r = blockIdx.x, tid = threadIdx.x;
+    if (!wide_runs(p, wa, r)) return;
+    const int W = p.FROWS - SG_F_COLL;
+    const ScenStatic &ss = p.sstat[r];
+    sg_scenario_state &sd = p.sdyn[r];
+    if (tid == 0) { s_any = 0; s_ego0 = 0; }
+    __syncthreads();
+    bool any = false;
+    for (int e = tid; e < p.E; e += 256) {
+        const WideEnt w(p, r, e);
+        bool mine = false;
+        for (int q = 0; q < W; ++q) mine = mine || fld<uint64_t>(w.dy, SG_F_COLL + q) != 0;
+        any = any || mine;
+        if (e == 0 && mine && fld<uint64_t>(w.dy, SG_F_PRESENT) != 0) s_ego0 = 1;
+    }
+    if (any) s_any = 1;
+    __syncthreads();
+    if (tid != 0) return;
+    const WideEnt eg(p, r, ss.ego);
+    const bool ego_present = fld<uint64_t>(eg.dy, SG_F_PRESENT) != 0;
+    uint64_t *last = wa.last_row + (size_t)r * W;
+    if (wa.mode != 0) { // the reset's metric resets: metrics/trajectory.py:13-17,36-39; metrics/collision.py:64-68
+        const double v0 = fld(eg.dy, SG_F_VEL + 0), v1 = fld(eg.dy, SG_F_VEL + 1), v2 = fld(eg.dy, SG_F_VEL + 2);
+        sd.t = ss.t0;
+        sd.prev_t = ss.t0 - 0.1; // state.py:135
+        sd.ego_avg_speed = sd.ego_max_speed = ego_present ? sg_norm3(v0, v1, v2) : __builtin_nan("");
+        sd.avg_t = 0.0;
+        sd.ego_distance_travelled = __builtin_nan("");
+        sd.done = 0; sd.n_steps = 0; sd.n_events = 0; sd.noise_pos = 0;
+        sd.rec_rows = p.rec_cap > 0 ? 1 : 0;
+        if (p.rec_cap > 0) p.rec_t[r] = ss.t0;
+        for (int q = 0; q < W; ++q) last[q] = 0;
+        for (int q = 0; q < 4; ++q) { sd.last_row[q] = 0; sd.last_row_hi[q] = 0; }
+        return;
+    }
+    const double t_old = sd.t, t = t_old + timestep, dt = t - t_old;
+    sd.prev_t = t_old;
+    sd.t = t;
+    const int steps = ++sd.n_steps;
+    if (p.rec_cap > 0 && steps < p.rec_cap) { p.rec_t[(size_t)steps * p.R + r] = t; sd.rec_rows = steps + 1; }
+    if (ego_present) { // scenario_gym.py:251-252
+        const double speed = sg_norm3(fld(eg.dy, SG_F_VEL + 0), fld(eg.dy, SG_F_VEL + 1), fld(eg.dy, SG_F_VEL + 2));
+        const double wgt = sd.avg_t / t; // EgoAvgSpeed._step, metrics/trajectory.py:19-24
+        sd.ego_avg_speed += (1.0 - wgt) * (speed - sd.ego_avg_speed);
+        sd.avg_t = t;
+        sd.ego_max_speed = __builtin_fmax(speed, sd.ego_max_speed);
+        sd.ego_distance_travelled = fld(eg.dy, SG_F_DIST);
+    }
+    int ndone = 0;
+    if ((p.term_mask & SG_TERM_MAX_LENGTH) && (t + dt > ss.length)) ndone = 1;
+    if ((p.term_mask & SG_TERM_COLLISION) && s_any) ndone = 1;
+    if ((p.term_mask & SG_TERM_EGO_COLLISION) && s_ego0) ndone = 1;
+    sd.done = ndone;
+    if (ego_present) { // CollisionMetric._step, metrics/collision.py:70-75
+        int n_ev = sd.n_events;
+        const double *A = wa.cor + ((size_t)r * p.EP + ss.ego) * 8;
+        for (int q = 0; q < W; ++q) {
+            const uint64_t rowq = fld<uint64_t>(eg.dy, SG_F_COLL + q);
+            uint64_t fresh = rowq & ~last[q];
+            while (fresh) {
+                const int j = q * 64 + __builtin_ctzll(fresh);
+                fresh &= fresh - 1;
+                // how often j is listed for the ego: once per entity that hits the ego and shares j's geometry (j is its last owner)
+                const double *Bj = wa.cor + ((size_t)r * p.EP + j) * 8;
+                int mult = 0;
+                for (int k = 0; k <= j; ++k) {
+                    const double *ck = wa.circ + ((size_t)r * p.EP + k) * 4;
+                    if (!(ck[0] == ck[0]) || k == ss.ego) continue;
+                    const double *Bk = wa.cor + ((size_t)r * p.EP + k) * 8;
+                    if ((k == j || wide_same(Bj, Bk)) && !wide_same(A, Bk) && sg_quads_intersect(A, Bk)) ++mult;
+                }
+                const WideEnt o(p, r, j);
+                const int64_t ometa = fld<int64_t>(o.st, ST_META);
+                const int okind = (int)(ometa & 0xff);
+                for (int m = 0; m < mult; ++m) {
+                    if (n_ev < p.ev_cap) {
+                        sg_event *dst = &p.events[(size_t)r * p.ev_cap + n_ev];
+                        dst->t = t; dst->scenario = r; dst->other = j; dst->reserved = 0;
+                        dst->type = ((ometa >> 8) & 0xff) == 0 ? -1 : 5;
+                        double *hp = p.ev_hpose + ((size_t)r * p.ev_cap + n_ev) * 3;
+                        hp[0] = hp[1] = hp[2] = __builtin_nan("");
+                        if (okind == SG_KIND_AGENT_PID || okind == SG_KIND_AGENT_VEHICLE) { // a controlled hazard leaves its pose beside the event
+                            hp[0] = fld(o.dy, SG_F_POSE + 0); hp[1] = fld(o.dy, SG_F_POSE + 1); hp[2] = fld(o.dy, SG_F_POSE + 3);
+                        }
+                        double *ep = p.ev_pose + ((size_t)r * p.ev_cap + n_ev) * 3;
+                        ep[0] = fld(eg.dy, SG_F_POSE + 0); ep[1] = fld(eg.dy, SG_F_POSE + 1); ep[2] = fld(eg.dy, SG_F_POSE + 3);
+                    }
+                    ++n_ev;
+                }
+            }
+            last[q] = rowq;
+        }
+        sd.n_events = n_ev;
+    }
+}
+#endif // SG_UNIT_WIDE
+
+} // namespace sg

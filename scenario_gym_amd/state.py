@@ -138,8 +138,12 @@ class State:
         s = self._s()
         ents = self._scenario.entities
         rows, pres = s["coll"][self._i], s["present"][self._i]
-        return {e: [ents[j] for j in range(len(ents)) if (int(rows[k]) >> j) & 1]
-                for k, e in enumerate(ents) if pres[k]}
+        rows = rows.reshape(len(rows), -1)  # [E, words]: one 64-bit word per 64 entity slots (scenarios of any width)
+
+        def listed(k):
+            return [ents[j] for j in range(len(ents)) if (int(rows[k, j >> 6]) >> (j & 63)) & 1]
+
+        return {e: listed(k) for k, e in enumerate(ents) if pres[k]}
 
     def recorded_poses(self, entity: Optional[Entity] = None):
         """state.py:272-290: (n, 7) rows [t, x, y, z, h, p, r] of the steps the entity was present."""

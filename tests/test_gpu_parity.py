@@ -474,6 +474,89 @@ def test_wide_crowds_match_oracle(sga, oracle, R, E, steps, side, noise):
         assert np.array_equal(ev["t"], o["ev_t"][: len(ev)]) and np.array_equal(ev["other"], o["ev_other"][: len(ev)]), r
 
 
+@pytest.mark.parametrize("R,E,steps,ego_kind", [(3, 700, 60, "pid"), (2, 1024, 50, "replay"), (2, 1024, 40, "vehicle"), (1, 1500, 30, "pid")])
+def test_scenarios_beyond_512_entities_match_oracle(sga, oracle, R, E, steps, ego_kind):
+    """No entity ceiling (sgym_wide.hpp): scenarios of 700, 1024, 1500 entities step as four kernels over as many workgroups
+    as they need.  Same checks as the fused widths: poses of every step, velocities, distances, collision rows (E / 64 words
+    per entity), ego metrics, events -- replay, PID and external-action egos, static and vanishing entities."""
+    import scenario_gym_amd._lib as L
+    from scenario_gym_amd import synthetic
+
+    kind = dict(replay=L.KIND_AGENT_REPLAY, pid=L.KIND_AGENT_PID, vehicle=L.KIND_AGENT_VEHICLE)[ego_kind]
+    packed = synthetic.make_batch(R, E, n_steps=steps, ego_kind=kind, static_frac=0.15, vanish_frac=0.2, extent=110.0)
+    acts = synthetic.make_actions(steps, R, seed=E) if ego_kind == "vehicle" else None
+    st, rows, events, t, poses = _engine_run(sga, packed, 1 / 30, steps, ev_cap=256, actions=acts)
+    n_ev = 0
+    for r in range(R):
+        kw = dict(actions=acts[:, r], force_steps=True) if acts is not None else {}
+        o = _oracle_one(oracle, packed, r, 1 / 30, steps, **kw)
+        n = o["n_steps"]
+        assert rows["n_steps"][r] == n and rows["final_t"][r] == o["final_t"], r
+        assert bits_equal(poses[: n + 1, r], o["poses"]), r
+        assert bits_equal(st["vels"][r], o["vels"][-1]) and bits_equal(st["dists"][r], o["dists"][-1]), r
+        assert np.array_equal(_dense_words(st["coll"][r], E), oracle.coll_to_dense(o["coll"], E)[-1]), r
+        for k in ("ego_avg_speed", "ego_max_speed", "ego_distance_travelled"):
+            assert rows[k][r] == o["metric_" + k], (r, k)
+        ev = events[events["scenario"] == r]
+        assert np.array_equal(ev["t"], o["ev_t"]) and np.array_equal(ev["other"], o["ev_other"]), r
+        n_ev += len(ev)
+    assert n_ev > 0
+
+
+@pytest.mark.parametrize("E,side,noise", [(1024, 45.0, "off"), (600, 30.0, "device")])
+def test_crowds_beyond_512_entities_match_oracle(sga, oracle, E, side, noise):
+    """... and with every KIND in one scenario of 1024 entities: pedestrian agents (the social force over all pedestrians of
+    the scenario, neighbours in entity order), a replay entity, a PID car; forces, collision rows, events equal the oracle's."""
+    import scenario_gym_amd._lib as L
+    from scenario_gym_amd import synthetic
+    from scenario_gym_amd.packing import unpack_scenario
+
+    R, steps = 2, 45
+    packed = synthetic.make_crowd(R, E, n_steps=steps, side=side)
+    kn = packed.knots.reshape(R * E, 2, 7)
+    for r in range(R):
+        i1, i2 = r * E + 1, r * E + 2
+        packed.kind[i1] = L.KIND_REPLAY
+        kn[i1, 1, 1:3] = kn[i1, 0, 1:3] + np.array([3.0, -2.0])
+        packed.kind[i2] = L.KIND_AGENT_PID
+        packed.etype[i2] = 0
+        packed.bbox[i2] = synthetic.CAR1_BBOX
+        packed.ctrl[i2] = synthetic.DEFAULT_CTRL
+        kn[i2, 0, 1:3] = (-side / 2 - 4.0, 0.5 * r)
+        kn[i2, 1, 1:3] = (side / 2 + 4.0, 0.5 * r)
+        kn[i2, :, 4] = 0.0
+    keep = np.ones(R * E, bool)
+    keep[[r * E + k for r in range(R) for k in (1, 2)]] = False
+    packed.routes = packed.routes.reshape(R * E, 2, 2)[keep].reshape(-1, 2)
+    packed.route_off = np.concatenate([[0], np.cumsum(np.where(keep, 2, 0))]).astype(np.int64)
+    packed = packed.validate()
+    kw, noise_o = {}, [None] * R
+    if noise == "device":
+        kw = dict(social_force=dict(std_lon=0.1, std_lat=0.05, noise="device", noise_seed=3))
+        noise_o = [dict(mode="device", std_lon=0.1, std_lat=0.05, seed=3, scenario_index=r) for r in range(R)]
+    eng = sga.RolloutEngine(R, E, record_capacity=steps + 1, event_capacity=512, **kw)
+    eng.upload(packed)
+    eng.rollout(steps)
+    st = eng.state()
+    rows, events = eng.metrics()
+    t, poses = eng.record(steps + 1)
+    eng.close()
+    for r in range(R):
+        s = unpack_scenario(packed, r)
+        o = oracle.rollout(s["knot_off"], s["knots"], s["bbox"], s["etype"], s["kind"], s["ego"], s["t0"], s["length"], 1 / 30,
+                           ctrl=s["ctrl"], route_off=s["route_off"], routes=s["routes"], max_steps=steps, event_cap=512, noise=noise_o[r])
+        n = o["n_steps"]
+        assert rows["n_steps"][r] == n, r
+        assert bits_equal(poses[: n + 1, r], o["poses"]), (r, "poses")
+        ped = s["kind"] == L.KIND_AGENT_PEDESTRIAN
+        assert bits_equal(st["force"][r][ped], o["extra"][-1, ped, 2:]) and bits_equal(st["dists"][r], o["dists"][-1]), r
+        assert np.array_equal(_dense_words(st["coll"][r], E), oracle.coll_to_dense(o["coll"], E)[-1]), r
+        for k in ("ego_avg_speed", "ego_max_speed", "ego_distance_travelled"):
+            assert rows[k][r] == o["metric_" + k], (r, k)
+        ev = events[events["scenario"] == r]
+        assert np.array_equal(ev["t"], o["ev_t"][: len(ev)]) and np.array_equal(ev["other"], o["ev_other"][: len(ev)]), r
+
+
 def test_wide_scenario_collision_terminal(sga, oracle):
     """terminal_conditions=["collision"] across wavefronts (workgroup-wide OR)."""
     import scenario_gym_amd._lib as L
