@@ -148,11 +148,64 @@ extern "C" int sgx_parse(const char *text, int64_t len, sgx_counts *counts, sgx_
     attrs.reserve(16);
 
     const char *p = text, *end = text + len;
+    // The rest of a canonical vertex after its opening tag: <Position><WorldPosition x y [z h p r]/></Position></Vertex>
+    // (white space anywhere between the tags).  On a match the row is appended and *pp moves behind </Vertex>.
+    auto vertex_tail = [&](const char **pp, double time) -> bool {
+        const char *q = *pp;
+        auto ws = [&]() { while (q < end && is_ws(*q)) ++q; };
+        auto lit = [&](const char *s_, int n_) { if (end - q >= n_ && memcmp(q, s_, n_) == 0) { q += n_; return true; } return false; };
+        ws();
+        if (!lit("<Position>", 10)) return false;
+        ws();
+        if (!(lit("<WorldPosition", 14) && q < end && is_ws(*q))) return false;
+        double row[7] = {time, std::nan(""), std::nan(""), std::nan(""), std::nan(""), std::nan(""), std::nan("")};
+        unsigned seen = 0;
+        bool bad_here = false;
+        for (;;) {
+            ws();
+            if (q >= end) return false;
+            if (*q == '/') break;
+            int col = -1;
+            switch (*q) { case 'x': col = 1; break; case 'y': col = 2; break; case 'z': col = 3; break;
+                          case 'h': col = 4; break; case 'p': col = 5; break; case 'r': col = 6; break; default: break; }
+            if (col < 0 || end - q < 4 || q[1] != '=' || (q[2] != '"' && q[2] != '\'') || (seen >> col) & 1) return false;
+            const char quote = q[2];
+            const char *v0 = q + 3;
+            const char *v1 = (const char *)memchr(v0, quote, end - v0);
+            if (!v1) return false;
+            row[col] = to_double(Attr{q, 1, v0, (int)(v1 - v0)}, &bad_here);
+            seen |= 1u << col;
+            q = v1 + 1;
+        }
+        if (bad_here || !lit("/>", 2)) return false;
+        ws();
+        if (!lit("</Position>", 11)) return false;
+        ws();
+        if (!lit("</Vertex>", 9) || (seen & 6u) != 6u) return false;
+        if (C.n_vertices < cap_vertices) memcpy(vertices + C.n_vertices * 7, row, sizeof row);
+        ++C.n_vertices;
+        *pp = q;
+        return true;
+    };
+    // every push / pop of the element stack bumps stack_ver; a Vertex met while stack_ver == vtx_ver is a sibling of the
+    // vertex that was last validated against the stack (same parents): it needs no second look at the stack
+    unsigned stack_ver = 1, vtx_ver = 0;
     while (p < end) {
         const char *lt = (const char *)memchr(p, '<', end - p);
         if (!lt) break;
         p = lt + 1;
         if (p >= end) break;
+        if (in_first_fta && vtx_ver == stack_ver && end - p > 14 && memcmp(p, "Vertex time=\"", 13) == 0) {
+            // (the common vertex, start to end, without the generic tokenizer)
+            const char *v0 = p + 13;
+            const char *v1 = (const char *)memchr(v0, '"', end - v0);
+            if (v1 && v1 + 1 < end && v1[1] == '>') {
+                bool bad_here = false;
+                const double tm = to_double(Attr{p, 4, v0, (int)(v1 - v0)}, &bad_here);
+                const char *q = v1 + 2;
+                if (!bad_here && vertex_tail(&q, tm)) { p = q; continue; }
+            }
+        }
         if (*p == '?') { // declaration / processing instruction
             const char *q = p;
             while (q + 1 < end && !(q[0] == '?' && q[1] == '>')) ++q;
@@ -175,6 +228,7 @@ extern "C" int sgx_parse(const char *text, int64_t len, sgx_counts *counts, sgx_
             if (!q || S.stack.empty()) return SGX_ERR_SYNTAX;
             const Tag t = S.stack.back();
             S.stack.pop_back();
+            ++stack_ver;
             if (t == T_SCENARIO_OBJECT) cur_obj = -1;
             else if (t == T_PRIVATE) private_ref = none;
             else if (t == T_FOLLOW_TRAJECTORY_ACTION && in_first_fta && (int)S.stack.size() == fta_depth) {
@@ -324,6 +378,16 @@ extern "C" int sgx_parse(const char *text, int64_t len, sgx_counts *counts, sgx_
                 const Attr *tm = attr("time");
                 if (!tm) return SGX_ERR_SYNTAX; // (a Vertex without time: the document readers raise as well)
                 vertex_time = to_double(*tm, &bad_number);
+                // Nearly every byte of a scenario file is vertices, and nearly every vertex is written the same way: read that
+                // shape in one go (vertex_tail); anything else is left to the generic path, byte for byte as before
+                if (!self_close) {
+                    const char *q = p;
+                    if (vertex_tail(&q, vertex_time)) {
+                        p = q;
+                        vtx_ver = stack_ver; // its siblings skip the stack check
+                        continue;            // (the Vertex element is closed: nothing was pushed on the stack)
+                    }
+                }
             }
             break;
         }
@@ -353,7 +417,7 @@ extern "C" int sgx_parse(const char *text, int64_t len, sgx_counts *counts, sgx_
         default:
             break;
         }
-        if (!self_close) S.stack.push_back(t);
+        if (!self_close) { S.stack.push_back(t); ++stack_ver; }
         else if (t == T_FOLLOW_TRAJECTORY_ACTION) in_first_fta = false;
     }
     *counts = C;

@@ -1,6 +1,8 @@
 """Pack scenarios into the sg_scenarios layout (host side, numpy only)."""
 from typing import List, Optional, Sequence
 
+import os
+
 import numpy as np
 
 from . import _lib as L
@@ -133,12 +135,98 @@ def pack_scenarios(scenarios, create_agent=None):
     return packed, agents
 
 
+def _file_arrays(path: str, relabel: bool):
+    """One OpenSCENARIO file as the arrays pack_arrays takes -- what import_scenario + pack_scenarios produce for it with the
+    reference's default agents (the ego replays its trajectory as an agent, everybody else through the batch path), without a
+    Scenario / Entity / Trajectory / Agent object in between: the native scan, the catalog boxes, the last trajectory
+    assignment per entity (read.py:133-217), Trajectory.__init__'s normalisation (trajectory.py:34-96), relabel
+    (read.py:244-273).  Returns None for anything off that path (a road network whose elevation would be needed, inline
+    entity definitions, files the strict scan refuses, an entity without a trajectory): the caller takes the object route."""
+    from . import xosc as X
+    from .entity import catalog_type_code
+    from .trajectory import Trajectory
+
+    with open(path, "rb") as f:
+        text = f.read()
+    try:
+        scan = X.scan_xosc(text)
+    except (ValueError, UnicodeDecodeError):
+        return None
+    if any(o["catalog"] is None for o in scan["objects"]):
+        return None
+    cwd = os.path.dirname(path)
+    catalogs = {}
+    for d in scan["dirs"]:
+        d = d if os.path.isabs(d) else os.path.join(cwd, d)
+        for fn in X.catalog_files(d):
+            name, entries = X.read_catalog(fn)
+            catalogs[name] = entries
+    protos = {}
+    for o in scan["objects"]:
+        try:
+            protos[o["name"]] = catalogs[o["catalog"]][o["entry"]]
+        except KeyError:
+            return None  # (import_scenario warns and drops the entity)
+    last = {}
+    for ref, knot in scan["teleports"]:
+        if ref in protos:
+            last[ref] = (knot[None, :], False)
+    for ref, verts in scan["trajectories"]:
+        if ref in protos and len(verts):
+            last[ref] = (verts, True)
+    if len(last) != len(protos):
+        return None
+    if scan["road_file"] and any(is_traj and np.isnan(v[:, 3]).any() for v, is_traj in last.values()):
+        return None  # read.py:212-215 would fill z from the road network's elevation
+    names = list(protos)
+    knots = Trajectory.many_arrays([last[n][0] for n in names])
+    ents = [protos[n] for n in names]
+    if relabel:
+        counts = {"vehicle": 0, "pedestrian": 0, "other": 0}
+        refs = ["ego"]
+        for e in ents[1:]:
+            key = "vehicle" if isinstance(e, X.Vehicle) else "pedestrian" if isinstance(e, X.Pedestrian) else "other"
+            refs.append(f"{key}_{counts[key]}")
+            counts[key] += 1
+    else:
+        refs = names
+    ego = refs.index("ego") if "ego" in refs else 0  # Scenario.ego: the entity called "ego", else the first one
+    off = np.zeros(len(names) + 1, np.int64)
+    np.cumsum([len(k) for k in knots], out=off[1:])
+    t_first, t_last = float(knots[ego][0, 0]), float(max(k[-1, 0] for k in knots))
+    if isinstance(knots, np.ndarray):  # one block for the file: a single chunk for the batch's concatenation
+        knots = knots.reshape(-1, 7)
+    kind = np.full(len(names), L.KIND_REPLAY, np.int32)
+    if refs[ego] == "ego":
+        kind[ego] = L.KIND_AGENT_REPLAY  # _create_agent: only the entity with ref "ego" gets an agent
+    return dict(knot_off=off, knots=knots, ego=ego, t0=max(0.0, t_first), length=t_last,
+                bbox=np.array([[e.bounding_box.width, e.bounding_box.length, e.bounding_box.center_x, e.bounding_box.center_y]
+                               for e in ents], np.float64),
+                etype=np.array([catalog_type_code(e) for e in ents], np.int32)), kind, refs
+
+
 def load_and_pack(paths: Sequence[str], n_entities: Optional[int] = None, relabel: bool = True) -> PackedScenarios:
-    """Import the files (xosc.load_scenario_file) and pack them with the reference's default agents: what a worker process
-    of a many-file sweep returns -- a few large arrays instead of thousands of Python objects."""
+    """Import the files and pack them with the reference's default agents: what a worker process of a many-file sweep
+    returns -- a few large arrays instead of thousands of Python objects.  OpenSCENARIO files on the usual path never become
+    objects at all (_file_arrays); the others go through xosc.load_scenario_file + pack_scenarios.  Same arrays either way
+    (tests/test_ingest_json.py::test_bulk_ingest_equals_object_path)."""
     from .xosc import load_scenario_file
 
-    packed, _ = pack_scenarios([load_scenario_file(p, relabel=relabel) for p in paths])
+    arrays, kinds, refs = [], [], []
+    for p in paths:
+        got = _file_arrays(p, relabel) if (os.path.splitext(p)[1].lower() != ".json" and os.environ.get("SG_INGEST_OBJECTS") != "1") else None
+        if got is None:
+            one, _ = pack_scenarios([load_scenario_file(p, relabel=relabel)])
+            E1 = one.n_entities
+            n = int((one.kind != L.KIND_NONE).sum())
+            got = (dict(knot_off=one.knot_off[: n + 1], knots=one.knots, ego=int(one.ego[0]), t0=float(one.t0[0]),
+                        length=float(one.length[0]), bbox=one.bbox[:n], etype=one.etype[:n]), one.kind[:n], one.refs[0])
+            assert n == E1
+        arrays.append(got[0])
+        kinds.append(got[1])
+        refs.append(got[2])
+    packed = pack_arrays(arrays, kinds=kinds)
+    packed.refs = refs
     if n_entities is not None and n_entities != packed.n_entities:
         packed = widen_packed(packed, n_entities)
     return packed

@@ -137,6 +137,40 @@ class Trajectory:
                     out[i] = cls(datas[i])
         return out
 
+    @classmethod
+    def many_arrays(cls, datas):
+        """The normalised knot arrays of Trajectory.many(datas) without the Trajectory objects around them (the bulk ingest
+        packs arrays: packing.load_and_pack): same operations, same bits."""
+        out = [None] * len(datas)
+        groups = {}
+        for i, d in enumerate(datas):
+            if isinstance(d, np.ndarray) and d.ndim == 2 and d.shape[1] == 7 and d.dtype == np.float64 and d.shape[0] > 1:
+                groups.setdefault(d.shape[0], []).append(i)
+            else:
+                out[i] = cls(d)._data
+        for n, idx in groups.items():
+            if len(idx) < 4:
+                for i in idx:
+                    out[i] = cls(datas[i])._data
+                continue
+            A = np.stack([datas[i] for i in idx])
+            t = A[:, :, 0]
+            fin = np.isfinite(A).all(axis=1)
+            ok = (t[:, 1:] > t[:, :-1]).all(axis=1) & fin[:, 0] & fin[:, 1] & fin[:, 2] & fin[:, 4]
+            B = A.copy()
+            for c in (3, 5, 6):
+                B[~fin[:, c], :, c] = 0.0
+            h = B[:, :, 4]
+            with np.errstate(invalid="ignore"):
+                deltas = np.diff(h, axis=1) % (2 * np.pi)
+                deltas = np.where(deltas > np.pi, deltas - 2 * np.pi, deltas)
+                B[:, :, 4] = np.concatenate([h[:, :1], deltas], axis=1).cumsum(axis=1)
+            for k, i in enumerate(idx):
+                out[i] = B[k] if ok[k] else cls(datas[i])._data
+            if len(groups) == 1 and len(idx) == len(datas) and ok.all():
+                return B  # every trajectory of the file has the same length: one [E, n, 7] block, rows already in entity order
+        return out
+
     # ------------------------------------------------------------------ container API
     @property
     def data(self):

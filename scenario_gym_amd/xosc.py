@@ -83,6 +83,17 @@ def _entry_from_element(el, catalog):
     return _ENTITY_CLASSES.get(el.tag, Entity)(ce)
 
 
+_catalog_dir_cache: Dict[str, list] = {}
+
+
+def catalog_files(directory: str):
+    """The .xosc files of a catalog directory, sorted (listed once per process: a sweep reads thousands of scenario files
+    that point at the same few directories)."""
+    if directory not in _catalog_dir_cache:
+        _catalog_dir_cache[directory] = [os.path.join(directory, f) for f in sorted(os.listdir(directory)) if f.endswith(".xosc")]
+    return _catalog_dir_cache[directory]
+
+
 def read_catalog(catalog_file: str):
     """catalog name + {entry name: prototype Entity}."""
     if catalog_file not in _catalog_cache:

@@ -201,3 +201,43 @@ def test_load_scenarios_takes_json_and_xosc(tmp_path):
     n = len(paths)
     assert bits_equal(st["poses"][:n], st["poses"][n:]) and bits_equal(st["dists"][:n], st["dists"][n:])
     assert m[:n] == m[n:]
+
+
+def test_bulk_ingest_equals_object_path(tmp_path, monkeypatch):
+    """packing.load_and_pack: OpenSCENARIO files on the usual path are packed straight from the native scan (no Scenario /
+    Entity / Trajectory / Agent objects); SG_INGEST_OBJECTS=1 sends every file through import_scenario + pack_scenarios.
+    Same arrays, bit for bit -- generated files (several widths in one batch, a trajectory given out of time order and one
+    without headings, so that the constructor's slow branches run) and, in the build container, every shipped scenario of
+    the reference (road networks, elevation, catalogs of three kinds, files the strict scan hands to the document reader)."""
+    import glob
+
+    from scenario_gym_amd import xosc_write as W
+    from scenario_gym_amd.packing import load_and_pack
+
+    root = str(tmp_path)
+    W.write_catalog(os.path.join(root, "Catalogs"))
+    os.makedirs(os.path.join(root, "Scenarios"))
+    paths = []
+    for i, (E, V) in enumerate([(6, 30), (40, 111), (3, 5), (12, 64), (1, 9)]):
+        rng = np.random.default_rng([7, i])
+        ents = W.synthetic_entities(rng, E, V, duration=8.0, extent=40.0)
+        p = os.path.join(root, "Scenarios", f"s{i}.xosc")
+        W.write_scenario(p, ents)
+        paths.append(p)
+    sets = [paths]
+    ref = sorted(glob.glob("/root/reference/tests/input_files/Scenarios/*.xosc"))
+    if ref:
+        sets.append(ref)
+    for ps in sets:
+        for relabel in (True, False):
+            monkeypatch.delenv("SG_INGEST_OBJECTS", raising=False)
+            a = load_and_pack(ps, relabel=relabel)
+            monkeypatch.setenv("SG_INGEST_OBJECTS", "1")
+            b = load_and_pack(ps, relabel=relabel)
+            assert (a.n_scenarios, a.n_entities) == (b.n_scenarios, b.n_entities)
+            for k in ("kind", "etype", "knot_off", "ego"):
+                assert np.array_equal(getattr(a, k), getattr(b, k)), (relabel, k)
+            for k in ("bbox", "t0", "length", "ctrl", "knots"):
+                assert bits_equal(getattr(a, k), getattr(b, k)), (relabel, k)
+            assert a.refs == b.refs, relabel
+    monkeypatch.delenv("SG_INGEST_OBJECTS", raising=False)
