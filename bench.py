@@ -285,10 +285,10 @@ def _e2e_load(path):
 
 def _e2e_load_pack(arg):
     """One worker task: import a handful of files and pack them (default agents) -- a few arrays travel back, not objects."""
-    from scenario_gym_amd.packing import load_and_pack
+    from scenario_gym_amd.packing import load_and_pack, packed_to_shm
 
     paths, E = arg
-    return load_and_pack(paths, E, relabel=True)
+    return packed_to_shm(load_and_pack(paths, E, relabel=True))  # (the knots through shared memory, not through pickle)
 
 
 def run_e2e(args):
@@ -336,12 +336,18 @@ def run_e2e(args):
         def tasks(ch):
             return [(ch[i:i + SUB], E) for i in range(0, len(ch), SUB)]
 
-        def device_part(gym, parts):
-            from scenario_gym_amd.packing import merge_packed
+        def merged(fut):
+            """(a helper thread) wait for the import of a chunk, then merge the workers' arrays: one copy out of their
+            shared-memory segments; numpy's copies release the GIL, so this runs under the main thread's upload of the chunk before"""
+            from scenario_gym_amd.packing import merge_packed_shm
 
             t = time.perf_counter()
-            packed = merge_packed(parts)
-            stages["merge"] += time.perf_counter() - t
+            parts = list(fut)
+            t1 = time.perf_counter()
+            packed = merge_packed_shm(parts)
+            return packed, t1 - t, time.perf_counter() - t1
+
+        def device_part(gym, packed):
             t = time.perf_counter()
             gym.set_packed(packed)                         # sg_upload (+ the reset launch); the engine is reused
             stages["upload"] += time.perf_counter() - t
@@ -355,26 +361,37 @@ def run_e2e(args):
             return out
 
         with cf.ProcessPoolExecutor(cores, mp_context=ctx) as ex:
-            list(ex.map(_e2e_load_pack, [([p], E) for p in paths[:cores]]))   # (workers started and warm: imports, catalog cache)
+            from scenario_gym_amd.packing import packed_from_shm as _drop
+
+            for q in ex.map(_e2e_load_pack, [([p], E) for p in paths[:cores]]):   # (workers started and warm: imports, catalog cache)
+                _drop(q)
             gym = sga.BatchedScenarioGym(timestep=dt, state_callbacks=[M.RSSDistances()], metrics=factory, event_capacity=16)
             # warm, not timed: library load, the engine of the chunk shape with its allocations (the RSS line-test queue alone
             # is GiBs), first launches
-            device_part(gym, list(ex.map(_e2e_load_pack, tasks(chunks[0]))))
+            device_part(gym, merged(ex.map(_e2e_load_pack, tasks(chunks[0])))[0])
             for k in stages:
                 stages[k] = 0.0
+            stages["main_waits_for_chunk"] = 0.0
             import torch
 
             torch.cuda.synchronize()
             t_all = time.perf_counter()
-            t = time.perf_counter()
-            fut = ex.map(_e2e_load_pack, tasks(chunks[0]))
-            for c in range(len(chunks)):
-                parts = list(fut)                          # waits for the import of chunk c ...
-                stages["ingest"] += time.perf_counter() - t
-                if c + 1 < len(chunks):
-                    fut = ex.map(_e2e_load_pack, tasks(chunks[c + 1]))   # ... the next one runs under this chunk's device work
-                all_metrics.extend(device_part(gym, parts))
-                t = time.perf_counter()
+            with cf.ThreadPoolExecutor(1) as helper:
+                # the import pool works two chunks ahead, the helper thread merges one chunk ahead, the main thread uploads
+                # and runs the device
+                futs = [ex.map(_e2e_load_pack, tasks(chunks[c])) for c in range(min(2, len(chunks)))]
+                nxt = helper.submit(merged, futs[0])
+                for c in range(len(chunks)):
+                    t = time.perf_counter()
+                    packed, t_ing, t_mer = nxt.result()
+                    stages["main_waits_for_chunk"] += time.perf_counter() - t
+                    stages["ingest"] += t_ing
+                    stages["merge"] += t_mer
+                    if c + 2 < len(chunks):
+                        futs.append(ex.map(_e2e_load_pack, tasks(chunks[c + 2])))
+                    if c + 1 < len(chunks):
+                        nxt = helper.submit(merged, futs[c + 1])
+                    all_metrics.extend(device_part(gym, packed))
             wall = time.perf_counter() - t_all
             gym.close()
         assert len(all_metrics) == n_files
@@ -386,10 +403,11 @@ def run_e2e(args):
             "x_realtime": n_files * duration / wall,
             "entity_steps_per_s": n_files * E * steps / wall,
             "stage_seconds": {k: round(v, 4) for k, v in stages.items()},
-            "stage_note": "ingest = time the device loop waited for the import pool (native scan + Trajectory normalisation + packing "
-                          "in the workers; the import of chunk k + 1 overlaps the device work of chunk k); merge = concatenating "
-                          "the workers' arrays; upload = sg_upload + reset; device = sg_rollout incl. the RSS callback; "
-                          "readback = get_metrics (events classified on the device, one Python dict per scenario)",
+            "stage_note": "three stages side by side: the import pool (native scan + normalisation + packing as arrays, two chunks "
+                          "ahead; its knots come back through shared memory), a helper thread (ingest = its wait for the pool, "
+                          "merge = one copy of the workers' rows into the chunk's batch) and the main thread (upload = sg_upload + "
+                          "reset, device = sg_rollout incl. the RSS callback, readback = get_metrics; main_waits_for_chunk = its "
+                          "idle time)",
             "config": {"name": "e2e", "workload": f"{n_files} generated OpenSCENARIO files ({E} entities, {nv} vertices = {duration:g} s at 10 Hz, "
                                                   f"~{n_bytes / n_files / 1e3:.0f} kB each) -> import_scenario (native scan, {cores} processes) -> "
                                                   f"pack -> sg_upload -> rollout at dt = 1/30 ({steps} steps) with RSSDistances + CollisionMetric "
@@ -466,7 +484,7 @@ def main(argv=None, make_engine=None):
                          "for bit; a mismatch makes the exit code non-zero.  Default 16 (c5, c3rss: 4); 0 = off")
     ap.add_argument("--engine-factory", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--files", type=int, default=4096, help="e2e: OpenSCENARIO files to generate and run")
-    ap.add_argument("--chunk", type=int, default=1024, help="e2e: scenarios per device batch")
+    ap.add_argument("--chunk", type=int, default=512, help="e2e: scenarios per device batch")
     ap.add_argument("--ped-noise", default="off", choices=["off", "device"],
                     help="c5: SocialForce noise terms (social_force.py:106-114): off = std 0 (parity runs), device = the "
                          "reference's default std with the counter-based device RNG")

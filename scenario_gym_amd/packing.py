@@ -273,6 +273,80 @@ def merge_packed(parts: Sequence[PackedScenarios]) -> PackedScenarios:
     return out.validate()
 
 
+def packed_to_shm(p: PackedScenarios) -> dict:
+    """A packed batch handed from a worker process to its parent WITHOUT pickling its knots (the bulk of it: tens of MB per
+    task of a many-file sweep, a gigabyte per few thousand files -- the parent's single result thread unpickles them one
+    after the other and becomes the bottleneck of the whole ingest): the knot rows go into a shared-memory segment, the
+    small arrays travel as usual.  The parent calls packed_from_shm, which copies them out and removes the segment."""
+    from multiprocessing import shared_memory
+
+    kn = np.ascontiguousarray(p.knots, np.float64)
+    shm = shared_memory.SharedMemory(create=True, size=max(kn.nbytes, 8))
+    np.ndarray(kn.shape, np.float64, buffer=shm.buf)[...] = kn
+    meta = dict(shm=shm.name, shape=kn.shape, R=p.n_scenarios, E=p.n_entities, kind=p.kind, etype=p.etype, bbox=p.bbox,
+                knot_off=p.knot_off, ego=p.ego, t0=p.t0, length=p.length, ctrl=p.ctrl, refs=getattr(p, "refs", None))
+    shm.close()
+    try:  # the parent unlinks it: keep this process's resource tracker from doing so at exit
+        from multiprocessing import resource_tracker
+
+        resource_tracker.unregister(shm._name, "shared_memory")
+    except Exception:
+        pass
+    return meta
+
+
+def packed_from_shm(meta: dict) -> PackedScenarios:
+    from multiprocessing import shared_memory
+
+    shm = shared_memory.SharedMemory(name=meta["shm"])
+    try:
+        knots = np.ndarray(meta["shape"], np.float64, buffer=shm.buf).copy()
+    finally:
+        shm.close()
+        shm.unlink()
+    out = PackedScenarios(meta["R"], meta["E"], meta["kind"], meta["etype"], meta["bbox"], meta["knot_off"], knots, meta["ego"],
+                          meta["t0"], meta["length"], meta["ctrl"])
+    out.refs = meta["refs"]
+    return out
+
+
+def merge_packed_shm(metas: Sequence[dict], threads: int = 4) -> PackedScenarios:
+    """merge_packed([packed_from_shm(m) for m in metas]) with ONE copy of the knots: every worker's rows go from its
+    shared-memory segment straight into their slice of the merged array."""
+    from multiprocessing import shared_memory
+
+    E = metas[0]["E"]
+    if any(m["E"] != E for m in metas):
+        raise ValueError("merge_packed_shm: same n_entities")
+    rows = np.cumsum([0] + [m["shape"][0] for m in metas])
+    knots = np.empty((int(rows[-1]), 7))
+
+    def one(args):  # (numpy's copy releases the GIL: the segments are copied -- and their pages faulted in -- side by side)
+        m, a, b = args
+        shm = shared_memory.SharedMemory(name=m["shm"])
+        try:
+            knots[a:b] = np.ndarray(m["shape"], np.float64, buffer=shm.buf)
+        finally:
+            shm.close()
+            shm.unlink()
+
+    jobs = list(zip(metas, rows[:-1], rows[1:]))
+    if threads > 1 and len(jobs) > 1:
+        from concurrent.futures import ThreadPoolExecutor
+
+        with ThreadPoolExecutor(threads) as ex:
+            list(ex.map(one, jobs))
+    else:
+        for j in jobs:
+            one(j)
+    ko = np.concatenate([m["knot_off"][:-1] + r for m, r in zip(metas, rows)] + [rows[-1:]])
+    cat = lambda f: np.concatenate([m[f] for m in metas])  # noqa: E731
+    out = PackedScenarios(sum(m["R"] for m in metas), E, cat("kind"), cat("etype"), cat("bbox"), ko.astype(np.int64), knots,
+                          cat("ego"), cat("t0"), cat("length"), None if metas[0]["ctrl"] is None else cat("ctrl"))
+    out.refs = [r for m in metas for r in (m["refs"] or [])]
+    return out.validate()
+
+
 def effective_cpus() -> int:
     """Host CPUs this process may actually use: os.cpu_count() capped by the cgroup CPU quota (a box can show 256 logical
     CPUs under a quota of 16: more busy threads or processes than that are throttled, not run)."""
