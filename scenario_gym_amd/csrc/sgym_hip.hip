@@ -518,10 +518,6 @@ static void launch_variant(sg_handle *h, dim3 grid, int n_steps, int do_reset, i
     const hipStream_t s = h->stream;
     const sgl::RolloutArgs a{&h->p, h->cfg.timestep, n_steps, do_reset, force, d_actions, nullptr};
     const sgl::RolloutArgs at{&h->p, h->cfg.timestep, n_steps, 0, force, nullptr, d_tab}; // table variants never reset
-#ifdef SG_ONLY_CROWD // experiment builds (tools/ab_build.sh): only the crowd variant is compiled
-    sgl::rollout_crowd(WV, false, grid, s, a);
-    return;
-#endif
     if (WV == 8 && !h->has_ped && (h->cfg.terminal_mask & SG_TERM_EGO_OFF_ROAD)) { // 257..512 entities, ego_off_road
         // (RSSDistances + ego_off_road in one wide rollout: no fused variant at that width, sg_set_rss refuses it)
         sgl::rollout_road(64, 8, grid, s, a);

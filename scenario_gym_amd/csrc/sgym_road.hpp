@@ -1,0 +1,209 @@
+// sgym_road.hpp -- Road surfaces: exact point-in-union tests on the cell grid, the boundary terms of the social force.
+// Part of the gfx950 device code of the batched rollout engine; included by sgym_device.hpp (in order: every part builds on
+// the ones before it), never on its own.
+#pragma once
+
+namespace sg {
+
+// ------------------------------------------------------------------------------------------------
+// Road surfaces: point strictly inside the union of the polygons of a layer.
+// shapely contains(Point) (state.py:401-407, sensor/map.py:198-271) = JTS/GEOS RayCrossingCounter: the ray towards +x
+// crosses the polygon's rings an odd number of times; a point ON a ring is not contained.  The orientation sign is
+// exact: fp64 determinant with Shewchuk's stage-A error bound, else the six products of the expanded determinant as
+// two-term expansions, summed exactly (grow-expansion); the sign of the sum is the sign of its largest component.
+// Host and device share these functions (the host uses them to classify the grid cells, sgym_hip.hip).
+// ------------------------------------------------------------------------------------------------
+__host__ __device__ inline void rn_two_sum(double a, double b, double &s, double &e)
+{
+    const double x = a + b, bb = x - a;
+    s = x;
+    e = (a - (x - bb)) + (b - bb);
+}
+
+__host__ __device__ __attribute__((noinline)) inline int rn_orient_exact(double ax, double ay, double bx, double by, double px, double py)
+{
+    // (ax - px)(by - py) - (ay - py)(bx - px) = ax*by - ax*py - px*by - ay*bx + ay*px + py*bx
+    const double fa[6] = {ax, -ax, -px, -ay, ay, py}, fb[6] = {by, py, by, bx, px, bx};
+    double e[12];
+    int n = 0;
+    for (int k = 0; k < 6; ++k) {
+        const double hi = fa[k] * fb[k], lo = __builtin_fma(fa[k], fb[k], -hi);
+        for (int u = 0; u < 2; ++u) {
+            double q = u ? hi : lo;
+            for (int i = 0; i < n; ++i) rn_two_sum(q, e[i], q, e[i]);
+            e[n++] = q;
+        }
+    }
+    for (int i = n - 1; i >= 0; --i)
+        if (e[i] != 0.0) return e[i] > 0 ? 1 : -1;
+    return 0;
+}
+
+__host__ __device__ inline int rn_orient_sign(double ax, double ay, double bx, double by, double px, double py)
+{
+    const double dl = (ax - px) * (by - py), dr = (ay - py) * (bx - px), det = dl - dr;
+    const double bound = 1e-15 * (__builtin_fabs(dl) + __builtin_fabs(dr));
+    if (det > bound) return 1;
+    if (det < -bound) return -1;
+    return rn_orient_exact(ax, ay, bx, by, px, py);
+}
+
+// RayCrossingCounter.countSegment: toggles `cross` on a crossing, returns true if the point is ON the edge
+__host__ __device__ inline bool rn_ray_edge(double x1, double y1, double x2, double y2, double px, double py, bool &cross)
+{
+    if (x1 < px && x2 < px) return false;
+    if (px == x2 && py == y2) return true;
+    if (y1 == py && y2 == py) {
+        const double lo = x1 < x2 ? x1 : x2, hi = x1 < x2 ? x2 : x1;
+        return px >= lo && px <= hi;
+    }
+    if ((y1 > py && y2 <= py) || (y2 > py && y1 <= py)) {
+        int o = rn_orient_sign(x1, y1, x2, y2, px, py);
+        if (o == 0) return true;
+        if (y2 < y1) o = -o;
+        if (o > 0) cross = !cross;
+    }
+    return false;
+}
+
+// 0 outside, 1 strictly inside, 2 on a ring -- the whole polygon (host: cell classification and reference points)
+__host__ __device__ inline int rn_polygon_locate(const double *edges, int64_t e0, int64_t e1, double px, double py)
+{
+    bool cross = false;
+    for (int64_t i = e0; i < e1; ++i) {
+        const double *e = edges + i * 4;
+        if (rn_ray_edge(e[0], e[1], e[2], e[3], px, py, cross)) return 2;
+    }
+    return cross ? 1 : 0;
+}
+
+// cell of a point; false = outside the grid (the grid covers every polygon with a margin, so: outside every surface)
+__host__ __device__ inline bool rn_cell_of(const RoadNet &N, double px, double py, int &ix, int &iy)
+{
+    const double fx = (px - N.x0) * N.inv_cell, fy = (py - N.y0) * N.inv_cell;
+    if (!(fx >= 0.0 && fx < (double)N.nx && fy >= 0.0 && fy < (double)N.ny)) return false;
+    ix = (int)fx;
+    iy = (int)fy;
+    return true;
+}
+
+// candidate reference points of a cell (fractions of the cell side; cell = 1 / inv_cell is a power of two, so the
+// products are exact and host and device agree bit for bit)
+#define RN_NREF 8
+__host__ __device__ inline void rn_ref_point(const RoadNet &N, int ix, int iy, int sel, double &x, double &y)
+{
+    const double FX[RN_NREF] = {0.5, 0.25, 0.75, 0.25, 0.75, 0.375, 0.625, 0.4375};
+    const double FY[RN_NREF] = {0.5, 0.25, 0.25, 0.75, 0.75, 0.5625, 0.3125, 0.6875};
+    const double c = 1.0 / N.inv_cell;
+    x = N.x0 + ((double)ix + FX[sel]) * c;
+    y = N.y0 + ((double)iy + FY[sel]) * c;
+}
+
+// Inside a cell whose reference point R has a known status: P has the same status unless the segment R -> P crosses the
+// polygon's boundary an odd number of times, and only edges that touch the cell can cross a segment inside it.
+// Crossing of edge (a, b): a and b on different sides of the line R-P (half-open: "left of" vs "not left of", so a
+// boundary passing through a vertex counts once) and R, P on different sides of the line a-b.  Returns 0 outside,
+// 1 inside, 2 = P lies on one of the edges.
+__host__ __device__ inline int rn_locate_in_cell(const double *edges, const int32_t *list, int n, double rx, double ry,
+                                                 bool r_inside, double px, double py)
+{
+    bool inside = r_inside;
+    for (int j = 0; j < n; ++j) {
+        const double *e = edges + (int64_t)list[j] * 4;
+        const double ax = e[0], ay = e[1], bx = e[2], by = e[3];
+        const int o2 = rn_orient_sign(ax, ay, bx, by, px, py);
+        if (o2 == 0 && px >= (ax < bx ? ax : bx) && px <= (ax < bx ? bx : ax) && py >= (ay < by ? ay : by) && py <= (ay < by ? by : ay))
+            return 2;
+        const bool sa = rn_orient_sign(rx, ry, px, py, ax, ay) > 0, sb = rn_orient_sign(rx, ry, px, py, bx, by) > 0;
+        if (sa != sb) {
+            const int o1 = rn_orient_sign(ax, ay, bx, by, rx, ry);
+            if ((o1 > 0) != (o2 > 0)) inside = !inside;
+        }
+    }
+    return inside ? 1 : 0;
+}
+
+// the layers of `want` whose union strictly contains the point (one thread)
+__device__ inline uint32_t rn_layers_at(const RoadIndex &R, int net, uint32_t want, double px, double py)
+{
+    if (net < 0) return 0u;
+    const RoadNet N = R.nets[net];
+    int ix, iy;
+    if (!rn_cell_of(N, px, py, ix, iy)) return 0u;
+    const int64_t cell = N.cell_base + (int64_t)iy * N.nx + ix;
+    const uint32_t m = R.cells[cell];
+    uint32_t in = m & 0xffu & want, todo = (m >> 8) & want & ~in;
+    if (todo) {
+        for (uint32_t k = R.cell_off[cell]; k < R.cell_off[cell + 1] && todo; ++k) {
+            const RoadCand cd = R.cand[k];
+            const uint32_t L = R.poly_layers[cd.poly] & todo;
+            if (!L) continue;
+            double rx, ry;
+            rn_ref_point(N, ix, iy, cd.ref_sel, rx, ry);
+            if (rn_locate_in_cell(R.edges, R.cand_edges + cd.edge_off, cd.n_edges, rx, ry, cd.ref_inside != 0, px, py) == 1) {
+                in |= L;
+                todo &= ~L;
+            }
+        }
+    }
+    return in;
+}
+
+// The boundary terms of SocialForce._step (pedestrian/social_force.py:86-104, _force_boundary :190-211) for one
+// pedestrian at (px, py) of scenario r.  nearest_points(surface, point) is GEOS DistanceOp: a point inside (or on) an
+// areal geometry is its own nearest point, so the walkable term -- evaluated only INSIDE the walkable surface -- is the
+// zero vector (+0.0 is still added, as the reference does), and so is the impenetrable term inside a building (-0.0);
+// outside, every ring edge of the buildings in order: Distance::pointToSegment, nearest first on ties,
+// LineSegment::closestPoint.  Same operation sequence as the oracle.
+__device__ inline void ped_boundary_terms(const Params &p, int r, double px, double py, double &fx, double &fy)
+{
+    if (!p.road) return;
+    const RoadIndex RI = *p.road;
+    const int net = RI.net_of_scen[r];
+    if (net < 0) return;
+    const uint32_t flags = RI.net_flags[net];
+    if (!flags) return;
+    const uint32_t in = rn_layers_at(RI, net, SG_LAYER_WALKABLE | SG_LAYER_IMPENETRABLE, px, py);
+    if ((flags & 1u) && (in & SG_LAYER_WALKABLE)) { fx += 0.0; fy += 0.0; }
+    if (!(flags & 2u)) return;
+    if (in & SG_LAYER_IMPENETRABLE) { fx += -0.0; fy += -0.0; return; }
+    double best = __builtin_inf(), cx = px, cy = py;
+    for (int64_t i = RI.imp_off[net]; i < RI.imp_off[net + 1]; ++i) {
+        const double *e = RI.imp_edges + i * 4;
+        const double ax = e[0], ay = e[1], bx = e[2], by = e[3];
+        auto dist = [](double x0, double y0, double x1, double y1) {
+            const double dx = x0 - x1, dy = y0 - y1;
+            return __builtin_sqrt(dx * dx + dy * dy);
+        };
+        double d;
+        if (ax == bx && ay == by) {
+            d = dist(px, py, ax, ay);
+        } else {
+            const double len2 = (bx - ax) * (bx - ax) + (by - ay) * (by - ay);
+            const double rr = ((px - ax) * (bx - ax) + (py - ay) * (by - ay)) / len2;
+            if (rr <= 0.0) d = dist(px, py, ax, ay);
+            else if (rr >= 1.0) d = dist(px, py, bx, by);
+            else d = __builtin_fabs(((ay - py) * (bx - ax) - (ax - px) * (by - ay)) / len2) * __builtin_sqrt(len2);
+        }
+        if (d < best) {
+            best = d;
+            double f;
+            if (px == ax && py == ay) f = 0.0;
+            else if (px == bx && py == by) f = 1.0;
+            else {
+                const double dx = bx - ax, dy = by - ay, len = dx * dx + dy * dy;
+                f = len <= 0.0 ? __builtin_nan("") : ((px - ax) * dx + (py - ay) * dy) / len;
+            }
+            if (f > 0.0 && f < 1.0) { cx = ax + f * (bx - ax); cy = ay + f * (by - ay); }
+            else if (dist(ax, ay, px, py) < dist(bx, by, px, py)) { cx = ax; cy = ay; }
+            else { cx = bx; cy = by; }
+        }
+    }
+    const double rx = px - cx, ry = py - cy, rn = sg_norm2(rx, ry);
+    const double ux = rx / (rn + 0.0000000001), uy = ry / (rn + 0.0000000001);
+    const double k = p.sf.imp_boundary_repulse_U / p.sf.imp_boundary_repulse_R, ex = sg_exp(-rn / p.sf.imp_boundary_repulse_R);
+    fx += 1.0 * (k * ux * ex);
+    fy += 1.0 * (k * uy * ex);
+}
+
+} // namespace sg

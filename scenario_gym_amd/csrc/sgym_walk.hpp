@@ -173,15 +173,6 @@ struct WalkLds {
     alignas(16) char pair_scratch[WVL][PAIR_CAP * 20]; // (the results of handed-over pairs are double2: 16-byte LDS accesses)
 };
 
-// experiment builds (-DSG_WALK_TIMERS): cycles per phase of the walker step, summed over wavefronts into wa.stats64[16]
-#ifdef SG_WALK_TIMERS
-struct WalkTimers { unsigned long long acc[16], last; };
-#define WT(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); wt.acc[i] += now_ - wt.last; wt.last = now_; } while (0)
-#else
-struct WalkTimers {};
-#define WT(i) ((void)0)
-#endif
-
 template <int WVL>
 __device__ __forceinline__ void walk_sync()
 {
