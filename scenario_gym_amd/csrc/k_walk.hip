@@ -3,9 +3,9 @@
 #include "sgym_launch.hpp"
 
 namespace sgl {
-void walk_classify(dim3 grid, hipStream_t s, const sg::Params &p, const sg::WalkArgs &wa, int chunk_len, int enable_mask)
+void walk_classify(dim3 grid, hipStream_t s, const sg::Params &p, const sg::WalkArgs &wa, int chunk_len, int enable_mask, int walk1_max)
 {
-    sg::walk_classify_kernel<<<grid, dim3(256), 0, s>>>(p, wa, chunk_len, enable_mask);
+    sg::walk_classify_kernel<<<grid, dim3(256), 0, s>>>(p, wa, chunk_len, enable_mask, walk1_max);
 }
 void walk_rollout(int WVL, dim3 grid, hipStream_t s, const sg::Params &p, double timestep, int n_steps, int force, const sg::WalkArgs &wa)
 {

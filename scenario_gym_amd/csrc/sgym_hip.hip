@@ -681,7 +681,7 @@ static int launch_crowd_chunks(sg_handle *h, int n_steps, int do_reset, int forc
             if ((rc = get_event(h, *ev_next, &e0)) || (rc = get_event(h, *ev_next + 1, &e1))) return rc;
             HIP_TRY(h, hipEventRecord(e0, h->stream));
         }
-        sgl::walk_classify(grid, h->stream, h->p, h->walk, len, enable_mask);
+        sgl::walk_classify(grid, h->stream, h->p, h->walk, len, enable_mask, std::min(64, std::max(1, env_int("SG_WALK1_MAX", 64))));
         HIP_TRY(h, hipGetLastError());
         if (s1 != h->stream) {
             if ((rc = get_event(h, *ev_next + 2, &ec)) || (rc = get_event(h, *ev_next + 3, &ew1)) || (rc = get_event(h, *ev_next + 4, &ew2))) return rc;

@@ -30,7 +30,7 @@ void rollout_ped(int G, int WV, bool rss, dim3 grid, hipStream_t s, const Rollou
 void rollout_crowd(int WV, bool riders, dim3 grid, hipStream_t s, const RolloutArgs &a);
 // k_walk.hip (sgym_walk.hpp): the chunk classifier and the walker variant of the crowd rollout (WVL = 1, 2 wavefronts of
 // active lanes per scenario)
-void walk_classify(dim3 grid, hipStream_t s, const sg::Params &p, const sg::WalkArgs &wa, int chunk_len, int enable_mask);
+void walk_classify(dim3 grid, hipStream_t s, const sg::Params &p, const sg::WalkArgs &wa, int chunk_len, int enable_mask, int walk1_max);
 void walk_rollout(int WVL, dim3 grid, hipStream_t s, const sg::Params &p, double timestep, int n_steps, int force, const sg::WalkArgs &wa);
 // k_wide.hip (sgym_wide.hpp): one step (mode 0) or State.reset (mode 1 / 2) of scenarios of more than 512 entities, four kernels
 void wide_step(dim3 grid_entities, dim3 grid_scenarios, hipStream_t s, const sg::Params &p, double timestep, const sg::WideArgs &wa);

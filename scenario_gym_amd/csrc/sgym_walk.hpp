@@ -67,7 +67,7 @@ __device__ __forceinline__ bool walk_is_static(const LanePtr &dy, const LanePtr 
 // One workgroup of 256 threads per scenario, thread = entity slot: the class of the scenario for the coming chunk, its
 // active-lane list, the static mask and the statics' base rows.
 #ifdef SG_UNIT_WALK
-static __global__ __launch_bounds__(256) void walk_classify_kernel(Params p, WalkArgs wa, int chunk_len, int enable_mask)
+static __global__ __launch_bounds__(256) void walk_classify_kernel(Params p, WalkArgs wa, int chunk_len, int enable_mask, int walk1_max)
 {
     __shared__ uint64_t s_static[4], s_active[4], s_flags;
     __shared__ float s_cx[WALK_SLOTS], s_cy[WALK_SLOTS];
@@ -132,7 +132,7 @@ static __global__ __launch_bounds__(256) void walk_classify_kernel(Params p, Wal
     before += __builtin_popcountll(ba & ((1ull << lane) - 1));
     const bool usable = s_flags == 0 && crowd_params_ok(p.sf) && !p.ped_serial && p.rec_cap == 0;
     int cls = 0;
-    if (usable && n_act <= 64 && (enable_mask & 1)) cls = 1;
+    if (usable && n_act <= walk1_max && (enable_mask & 1)) cls = 1; // (walk1_max <= 64: busier scenarios get two wavefronts)
     else if (usable && n_act <= 128 && (enable_mask & 2)) cls = 2;
     if (active && before < 128) wa.ent[(size_t)r * 128 + before] = (uint8_t)e;
     // base rows: the hits among statics (they stay as they are while both stay static)
