@@ -313,6 +313,12 @@ static __global__ __launch_bounds__(64, 2) void control_kernel_riders(Params p, 
 static __global__ __launch_bounds__(64, 1) void control_kernel_fast(Params p, double timestep, int n_steps, int first, int k0,
                                                              const double *actions /*[n][R][2]*/, double *tab, int row0, int metrics)
 {
+    // (s_setprio(3) here shortens this kernel's launches by a quarter -- its 64 wavefronts share their SIMDs with the rollout
+    // kernels' -- but the 4096 x 64 table path is bound by the rollout kernels, not by this chain: 2-3 % slower overall.
+    // With the collision pass compiled out the chain IS the bound and the priority is worth 99 -> 126 G: HISTORY.md, round 4)
+#ifdef SG_CTL_SETPRIO
+    __builtin_amdgcn_s_setprio(3);
+#endif
     control_body<true>(p, timestep, n_steps, first, k0, actions, tab, row0, metrics);
 }
 #endif // SG_UNIT_CTL

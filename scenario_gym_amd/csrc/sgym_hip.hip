@@ -374,8 +374,13 @@ extern "C" int sg_create(const sg_config *cfg, sg_handle **out)
     h->ped_serial = env_int("SG_PED_SERIAL", 0) != 0;
     h->crowd_kernel = env_int("SG_CROWD_KERNEL", 1);
     h->slice_mode = env_int("SG_SLICE", 1);
+    // the controller stream carries the serial chain of the table path (control_kernel_fast: 64 wavefronts that every rollout
+    // launch waits for): highest stream priority, so that its launches are dispatched ahead of the rollout kernels'
+    // (measured: no difference at 4096 x 64, where the launches never queue; SG_CTL_PRIO=0 creates it at the lowest)
+    int prio_lo = 0, prio_hi = 0;
     if (hipSetDevice(cfg->device) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess ||
-        hipStreamCreate(&h->ctl_stream) != hipSuccess ||
+        hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess ||
+        hipStreamCreateWithPriority(&h->ctl_stream, hipStreamNonBlocking * 0, env_int("SG_CTL_PRIO", 1) ? prio_hi : prio_lo) != hipSuccess ||
         hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {
         delete h;
         return fail(nullptr, SG_ERR_HIP, "sg_create: stream/event creation failed");
