@@ -379,9 +379,10 @@ class RolloutEngine:
         self._check(self.lib.sg_copy_to_host(self.h, ptr, out.ctypes.data, out.nbytes), "sg_copy_to_host")
         return out
 
-    def state(self):
+    def state(self, raw=False):
         """Host copy of the step-materialised state: dict of [R, E, ...] arrays (NaN = absent).
-        `coll` is [R, E] uint64 for up to 64 entities, else [R, E, row_words]."""
+        `coll` is [R, E] uint64 for up to 64 entities, else [R, E, row_words].
+        raw: the stored pose / velocity rows as they are, also for entities that are not in the scene (debugging, tests)."""
         v, R, E, EP = self._view, self.R, self.E, self._view.entity_stride
         n = R * EP
         blocks = self._d2h(v.blocks, (v.n_blocks, v.block_rows, 64), np.float64)
@@ -394,8 +395,8 @@ class RolloutEngine:
         scen = self._d2h(v.scen, R, SCEN_DTYPE)
         coll = rows(L.F_COLL, v.row_words, np.uint64)
         return dict(
-            poses=np.where(present[..., None], rows(L.F_POSE, 6), np.nan),
-            vels=np.where(present[..., None], rows(L.F_VEL, 6), np.nan),
+            poses=rows(L.F_POSE, 6).copy() if raw else np.where(present[..., None], rows(L.F_POSE, 6), np.nan),
+            vels=rows(L.F_VEL, 6).copy() if raw else np.where(present[..., None], rows(L.F_VEL, 6), np.nan),
             present=present, dists=rows(L.F_DIST)[..., 0], coll=coll[..., 0] if v.row_words == 1 else coll,
             ctrl_state=rows(L.F_CTRL, 4), force=rows(L.F_FORCE, 2), t=scen["t"].copy(), prev_t=scen["prev_t"].copy(),
             done=scen["done"].astype(bool), n_steps=scen["n_steps"].copy(), noise_pos=scen["noise_pos"].copy(),

@@ -967,6 +967,73 @@ def test_rollout_pipelines_equal_one_pipeline(sga, monkeypatch, E, ego_kind, zpr
         assert rows.tobytes() == pipes[0][1][0].tobytes() and ev.tobytes() == pipes[0][1][1].tobytes()
 
 
+@pytest.mark.parametrize("split", ["1", "3"])
+@pytest.mark.parametrize("persist", [False, True])
+def test_planar_table_kernel_with_late_spawns(sga, oracle, monkeypatch, split, persist):
+    """The planar table kernel (rollout_kernel_tab_planar) never stores the z / pitch / roll rows of a pose: it relies on the
+    reset having left +0.0 there for every lane that is absent or spawns later.  A planar batch in which half of the
+    entities appear late or vanish (PID ego), as one pipeline and as three, with and without persist, the rollout continued
+    in pieces on the same handle: after the reset the rows the kernel skips hold +0.0 bit for bit (pose, and velocity --
+    checked on the lanes not yet in the scene), and the final state, metrics and events equal the oracle's."""
+    import scenario_gym_amd._lib as L
+    from oracle import check
+    from scenario_gym_amd import synthetic
+
+    R, E, steps, dt = 72, 64, 300, 1 / 30
+    packed = synthetic.make_batch(R, E, n_steps=steps, ego_kind=L.KIND_AGENT_PID, static_frac=0.1, vanish_frac=0.5, extent=30.0)
+    assert not packed.knots[:, [3, 5, 6]].any()  # planar
+    monkeypatch.setenv("SG_TAB_SPLIT_MIN", "4")
+    monkeypatch.setenv("SG_TAB_SPLIT", split)
+    eng = sga.RolloutEngine(R, E, timestep=dt, persist=persist, terminal_conditions=["max_length"], event_capacity=64)
+    eng.set_tuning(tab_min_steps=1, chunk_steps=16)
+    eng.upload(packed)
+    st = eng.state(raw=True)
+    absent = ~st["present"].astype(bool)
+    assert persist or absent.sum() > R * E // 4  # (persist: replay entities are in the scene from the reset on, state.py:99, entity/batch.py)
+    for k in ("poses", "vels"):
+        assert not np.ascontiguousarray(st[k][..., [2, 4, 5]]).view(np.uint64).any(), k  # +0.0: no sign bit, no NaN
+    eng.rollout(150)
+    assert persist or (eng.state()["present"].astype(bool) & absent).sum() > R  # entities joined the scenes on the way
+    eng.rollout(90)
+    eng.rollout_async(130, do_reset=False)
+    eng.rollout_async(steps, do_reset=False)  # (max_length ends every scenario before the count runs out)
+    eng.synchronize()
+    ver = check.verify_engine(eng, packed, dt, steps, K=R, event_cap=64, persist=persist)
+    assert ver["equal"], ver["mismatches"]
+    st = eng.state(raw=True)
+    assert not np.ascontiguousarray(st["poses"][..., [2, 4, 5]]).view(np.uint64).any()
+    eng.close()
+
+
+@pytest.mark.parametrize("zpr", [False, True])
+def test_table_kernels_on_a_clock_that_stands_still(sga, oracle, zpr):
+    """A timestep below half an ulp of the clock (1e-300 on scenarios that start at t = 1): t + timestep == t, next_t - t == 0
+    in every step, so every velocity is 0 / 0 = NaN (state.py:148-152 divides by the clock difference) -- the planar table
+    kernel must not take its "z / pitch / roll velocity rows hold +0" shortcut there (`flat` requires dt > 0), nor the
+    general one its shared reciprocal.  Both kernels against the oracle."""
+    import scenario_gym_amd._lib as L
+    from oracle import check
+    from scenario_gym_amd import synthetic
+
+    R, E, steps = 16, 64, 12
+    packed = synthetic.make_batch(R, E, n_steps=300, ego_kind=L.KIND_AGENT_PID, static_frac=0.1, vanish_frac=0.3, extent=30.0)
+    if zpr:
+        packed.knots[:, 3] = np.random.default_rng(3).normal(0.0, 1.0, len(packed.knots))
+    packed.knots[:, 0] += 1.0
+    packed.t0 += 1.0
+    packed.length += 1.0
+    dt = 1e-300
+    eng = sga.RolloutEngine(R, E, timestep=dt, terminal_conditions=["max_length"], event_capacity=64)
+    eng.set_tuning(tab_min_steps=1, chunk_steps=4)
+    eng.upload(packed)
+    eng.rollout(steps)
+    ver = check.verify_engine(eng, packed, dt, steps, K=R, event_cap=64)
+    assert ver["equal"], ver["mismatches"]
+    st = eng.state()
+    assert (st["n_steps"] == steps).all() and (st["t"] == 1.0).all() and np.isnan(st["vels"][st["present"].astype(bool)]).all()
+    eng.close()
+
+
 def test_launch_stats_count_overlapping_launches_once(sga, monkeypatch):
     """sg_last_launch_stats reports the time during which at least one rollout launch ran (the union of the launches'
     intervals), sg_last_launch_gross_ms the plain sum of their durations: equal with one pipeline, and with pipelines the sum
