@@ -252,6 +252,18 @@ int sg_set_social_force(sg_handle *h, const sg_social_force *params);
 int sg_set_ped_noise(sg_handle *h, int32_t mode, double std_lon, double std_lat, const double *normals, int64_t per_scenario,
                      uint64_t seed);
 
+/* The behaviour model of the handle's pedestrian agents (PedestrianAgent(..., behaviour=...), pedestrian/agent.py:23):
+ *   SG_PED_SOCIAL_FORCE  SocialForce (pedestrian/social_force.py:33-222), the default;
+ *   SG_PED_RANDOM_WALK   RandomWalk (pedestrian/random_walk.py:22-44): speed = np.random.normal(speed_desired + bias_lon,
+ *                        std_lon), heading = np.random.normal(atan2(goal - position) + bias_lat, std_lat) -- no neighbours,
+ *                        no speed limit other than the controller's max_speed, PedestrianAgent.force stays (0, 0).  bias_* from
+ *                        sg_set_social_force, the variates and std_* from sg_set_ped_noise (two per walking pedestrian
+ *                        and step, speed first, as SocialForce draws them).
+ * Call before sg_upload (SG_ERR_STATE afterwards: the kernels of a batch are chosen there). */
+#define SG_PED_SOCIAL_FORCE 0
+#define SG_PED_RANDOM_WALK 1
+int sg_set_ped_behaviour(sg_handle *h, int32_t behaviour);
+
 /* ScenarioGym.reset_scenario -> State.reset(t0), Controller.reset, Metric.reset (scenario_gym.py:217-225) */
 int sg_reset(sg_handle *h);
 

@@ -124,7 +124,7 @@ def raster_map(poses, bbox, ego, net, layers, width=20.0, height=20.0, nw=20, nh
 class _Config(C.Structure):
     _fields_ = [("dt", C.c_double), ("persist", C.c_int32), ("terminal_mask", C.c_int32), ("sf", C.c_double * NSF),
                 ("noise_mode", C.c_int32), ("scenario_index", C.c_int32), ("std_lon", C.c_double), ("std_lat", C.c_double),
-                ("normals", C.c_void_p), ("n_normals", C.c_int64), ("noise_seed", C.c_uint64)]
+                ("normals", C.c_void_p), ("n_normals", C.c_int64), ("noise_seed", C.c_uint64), ("behaviour", C.c_int32)]
 
 
 class _Event(C.Structure):
@@ -186,8 +186,10 @@ def default_kinds(n, ego=0):
 
 def rollout(knot_off, knots, bbox, etype, kind, ego, t0, length, dt, persist=False,
             terminal_mask=TERM_MAX_LENGTH, ctrl=None, actions=None, max_steps=None,
-            force_steps=False, record=True, event_cap=256, route_off=None, routes=None, sf=None, road=None, noise=None):
+            force_steps=False, record=True, event_cap=256, route_off=None, routes=None, sf=None, road=None, noise=None,
+            behaviour="social_force"):
     """One scenario through the oracle.  Returns a dict shaped like make_golden.record_rollout.
+    behaviour: "social_force" or "random_walk" -- the model of the pedestrian agents (PedestrianAgent(..., behaviour=...)).
     noise: None, or dict(mode="stream", std_lon, std_lat, normals=[...]) / dict(mode="device", std_lon, std_lat, seed,
     scenario_index): the random fluctuations of SocialForce._step (see sgo_config)."""
     L = lib()
@@ -213,6 +215,7 @@ def rollout(knot_off, knots, bbox, etype, kind, ego, t0, length, dt, persist=Fal
         sc.road = road.ref()
     sf = social_force_params() if sf is None else np.ascontiguousarray(sf, np.float64)
     cfg = _Config(float(dt), int(bool(persist)), int(terminal_mask), (C.c_double * NSF)(*sf))
+    cfg.behaviour = {"social_force": 0, "random_walk": 1}[behaviour]
     normals = None
     if noise is not None:
         cfg.std_lon, cfg.std_lat = float(noise["std_lon"]), float(noise["std_lat"])

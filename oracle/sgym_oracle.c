@@ -1010,7 +1010,29 @@ static void ped_step(const sgo_scenario *sc, const sgo_config *cfg, int i, const
         }
         ps->goal_idx = last + 1;
     }
-    if (ps->goal_idx <= nwp - 1) {
+    if (ps->goal_idx <= nwp - 1 && cfg->behaviour == 1) {
+        /* RandomWalk._step, pedestrian/random_walk.py:32-44: np.random.normal(loc, scale) = loc + scale * z (std 0: == loc);
+         * agent.force is not touched (it stays the zeros of PedestrianAgent.__init__, agent.py:41) */
+        const double gx = wp[2 * ps->goal_idx] - pose[0], gy = wp[2 * ps->goal_idx + 1] - pose[1];
+        const double loc_s = ct[SGO_C_PED_SPEED_DESIRED] + sf[SGO_SF_BIAS_LON];
+        const double loc_h = sgo_atan2(gy, gx) + sf[SGO_SF_BIAS_LAT];
+        speed = loc_s;
+        heading = loc_h;
+        if (cfg->noise_mode == 1) {
+            const int64_t k = *noise_pos;
+            const double z0 = k + 1 < cfg->n_normals ? cfg->normals[k] : 0.0, z1 = k + 1 < cfg->n_normals ? cfg->normals[k + 1] : 0.0;
+            *noise_pos = k + 2;
+            speed = loc_s + cfg->std_lon * z0;
+            heading = loc_h + cfg->std_lat * z1;
+        } else if (cfg->noise_mode == 2) {
+            double z[2];
+            sgo_noise_pair(cfg->noise_seed, (uint32_t)cfg->scenario_index, (uint32_t)i, (uint32_t)step_index, z);
+            speed = loc_s + cfg->std_lon * z[0];
+            heading = loc_h + cfg->std_lat * z[1];
+        }
+        FLOPS(FL_PED_MOVE, FLN_PED_MOVE - 5);
+        ps->fx = ps->fy = 0.0;
+    } else if (ps->goal_idx <= nwp - 1) {
         /* _force_to_goal, social_force.py:119-138 */
         double gx = wp[2 * ps->goal_idx] - pose[0], gy = wp[2 * ps->goal_idx + 1] - pose[1];
         double gn = norm2(gx, gy);

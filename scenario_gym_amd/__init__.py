@@ -18,7 +18,10 @@ from .agent import (  # noqa: F401
     Sensor,
     VehicleController,
     PedestrianAgent,
+    PedestrianBehaviour,
     PIDAgent,
+    RandomWalk,
+    RandomWalkParameters,
     ReplayTrajectoryAgent,
     SocialForce,
     SocialForceParameters,

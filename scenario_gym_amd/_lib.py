@@ -17,6 +17,7 @@ ABI_VERSION = 2
 TERM_MAX_LENGTH, TERM_COLLISION, TERM_EGO_COLLISION, TERM_EGO_OFF_ROAD = 1, 2, 4, 8
 NCTRL = 16
 NOISE_OFF, NOISE_STREAM, NOISE_DEVICE = 0, 1, 2  # sg_set_ped_noise
+PED_SOCIAL_FORCE, PED_RANDOM_WALK = 0, 1         # sg_set_ped_behaviour
 (C_MAX_STEER, C_MAX_ACCEL, C_MAX_SPEED, C_ALLOW_REVERSE, C_STEER_KP, C_STEER_KD, C_ACCEL_KP,
  C_ACCEL_KD, C_ACCEL_KI, C_PED_SPEED_DESIRED, C_PED_MAX_SPEED, C_PED_HEAD_ROT, C_PED_RADIUS) = range(13)
 
@@ -25,7 +26,7 @@ F_POSE, F_VEL, F_DIST, F_PRESENT, F_CTRL, F_FORCE, F_COLL = 0, 6, 12, 13, 14, 18
 
 # every symbol include/sgym.h declares
 SYMBOLS = (
-    "sg_version", "sg_last_error", "sg_create", "sg_destroy", "sg_upload", "sg_set_social_force", "sg_set_ped_noise", "sg_reset",
+    "sg_version", "sg_last_error", "sg_create", "sg_destroy", "sg_upload", "sg_set_social_force", "sg_set_ped_behaviour", "sg_set_ped_noise", "sg_reset",
     "sg_set_timestep", "sg_step", "sg_rollout", "sg_rollout_async", "sg_synchronize", "sg_stream",
     "sg_state_view_get", "sg_read_metrics", "sg_read_record", "sg_copy_to_host", "sg_last_kernel_ms",
     "sg_last_launch_stats", "sg_last_launch_gross_ms", "sg_pipeline_info", "sg_crowd_walk_stats", "sg_debug_trig32", "sg_set_tuning", "sg_set_slicing", "sg_set_external_poses", "sg_future_collision", "sg_raster_entities",
@@ -137,6 +138,7 @@ def load():
     lib.sg_destroy.argtypes = [H]
     lib.sg_upload.argtypes = [H, C.POINTER(SgScenarios)]
     lib.sg_set_social_force.argtypes = [H, C.POINTER(SgSocialForce)]
+    lib.sg_set_ped_behaviour.argtypes = [H, C.c_int32]
     lib.sg_set_ped_noise.argtypes = [H, C.c_int32, C.c_double, C.c_double, C.c_void_p, C.c_int64, C.c_uint64]
     lib.sg_reset.argtypes = [H]
     lib.sg_set_timestep.argtypes = [H, C.c_double]

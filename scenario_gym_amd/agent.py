@@ -339,25 +339,61 @@ class SocialForceParameters(BehaviourParameters):
     noise_seed = 0
 
 
-class SocialForce:
-    """pedestrian/social_force.py:33-42: the behaviour object only carries its parameters here."""
+def _noise_params(p) -> dict:
+    noisy = p.std_lon != 0 or p.std_lat != 0
+    noise = getattr(p, "noise", "device")
+    if noisy and noise not in ("device", "numpy"):
+        raise ValueError(f"{type(p).__name__}.noise = {noise!r}: 'device' or 'numpy'")
+    return dict(bias_lon=p.bias_lon, bias_lat=p.bias_lat, std_lon=p.std_lon, std_lat=p.std_lat,
+                noise=("off" if not noisy else ("stream" if noise == "numpy" else "device")), noise_seed=getattr(p, "noise_seed", 0))
 
-    def __init__(self, params: SocialForceParameters):
+
+class PedestrianBehaviour:
+    """pedestrian/behaviour.py:18-53: the behaviour object only carries its parameters here -- the models run on the device."""
+
+    def __init__(self, params: BehaviourParameters):
         self.params = params
         self.max_speed_factor = params.max_speed_factor
 
     def device_params(self) -> dict:
+        raise NotImplementedError("only SocialForce and RandomWalk are lowered to the device")
+
+
+class SocialForce(PedestrianBehaviour):
+    """pedestrian/social_force.py:33-42."""
+
+    def device_params(self) -> dict:
         p = self.params
-        noisy = p.std_lon != 0 or p.std_lat != 0
-        if noisy and p.noise not in ("device", "numpy"):
-            raise ValueError(f"SocialForceParameters.noise = {p.noise!r}: 'device' or 'numpy'")
         return dict(relaxation_time=p.relaxation_time, ped_repulse_V=p.ped_repulse_V,
                     ped_repulse_sigma=p.ped_repulse_sigma, ped_attract_C=p.ped_attract_C,
                     sight_weight=p.sight_weight, sight_weight_use=p.sight_weight_use, sight_angle=p.sight_angle,
-                    max_speed_factor=p.max_speed_factor, bias_lon=p.bias_lon, bias_lat=p.bias_lat,
+                    max_speed_factor=p.max_speed_factor,
                     imp_boundary_repulse_U=p.imp_boundary_repulse_U, imp_boundary_repulse_R=p.imp_boundary_repulse_R,
-                    std_lon=p.std_lon, std_lat=p.std_lat,
-                    noise=("off" if not noisy else ("stream" if p.noise == "numpy" else "device")), noise_seed=p.noise_seed)
+                    behaviour="social_force", **_noise_params(p))
+
+
+class RandomWalkParameters(BehaviourParameters):
+    """pedestrian/random_walk.py:13-19 (+ `noise` / `noise_seed`: where the Gaussian variates come from, as in
+    SocialForceParameters)."""
+
+    bias_lon = 0.0
+    bias_lat = 0.0
+    std_lon = 0.000002
+    std_lat = 0.0000001
+    noise = "device"
+    noise_seed = 0
+
+
+class RandomWalk(PedestrianBehaviour):
+    """pedestrian/random_walk.py:22-44: speed ~ N(speed_desired + bias_lon, std_lon), heading ~ N(angle to the goal point +
+    bias_lat, std_lat); no neighbours, no max_speed_factor (the controller's max_speed alone clips)."""
+
+    def __init__(self, params: RandomWalkParameters):
+        super().__init__(params)
+        self.bias_lon, self.bias_lat, self.std_lon, self.std_lat = params.bias_lon, params.bias_lat, params.std_lon, params.std_lat
+
+    def device_params(self) -> dict:
+        return dict(max_speed_factor=self.params.max_speed_factor, behaviour="random_walk", **_noise_params(self.params))
 
 
 class PedestrianSensor(Sensor):
@@ -380,14 +416,14 @@ class PedestrianController(Controller):
 
 
 class PedestrianAgent(Agent):
-    """pedestrian/agent.py:15-69: follows `route` with the social force model."""
+    """pedestrian/agent.py:15-69: follows `route` with a behaviour model (SocialForce or RandomWalk)."""
 
-    def __init__(self, entity, route, speed_desired: float, behaviour: SocialForce, max_speed: float = 5.0,
+    def __init__(self, entity, route, speed_desired: float, behaviour: PedestrianBehaviour, max_speed: float = 5.0,
                  head_rot_angle: float = 0.0, distance_threshold: float = 1.0):
         super().__init__(entity, PedestrianController(entity, max_speed=max_speed),
                          PedestrianSensor(entity, head_rot_angle=head_rot_angle, distance_threshold=distance_threshold))
-        if not isinstance(behaviour, SocialForce):
-            raise NotImplementedError("only the SocialForce behaviour is lowered to the device")
+        if not isinstance(behaviour, (SocialForce, RandomWalk)):
+            raise NotImplementedError("only the SocialForce and RandomWalk behaviours are lowered to the device")
         self.speed_desired = speed_desired
         self.behaviour = behaviour
         self.route = np.asarray(route, np.float64).reshape(-1, 2)
@@ -403,6 +439,14 @@ class PedestrianAgent(Agent):
             return np.array([0.0, 0.0])
         gym, i, slot = self._bound
         return gym._fetch_state()["force"][i, slot].copy()
+
+    @property
+    def speed(self) -> float:
+        """PedestrianController.speed (pedestrian/controller.py:39): the clipped speed of the latest step, from the device state."""
+        if self._bound is None:
+            return 0.0
+        gym, i, slot = self._bound
+        return float(gym._fetch_state()["ctrl_state"][i, slot, 0])
 
     @property
     def goal_idx(self) -> int:

@@ -89,6 +89,7 @@ struct Params {
     const double *noise_normals; // [R][noise_len]
     long long noise_len;
     unsigned long long noise_seed;
+    int ped_behaviour;       // sg_set_ped_behaviour: 0 SocialForce, 1 RandomWalk (never with the crowd variants)
 #ifdef SG_PHASE_TIMERS
     unsigned long long *phase_cycles; // [16] experiment builds: s_memtime cycles per phase of the step, summed over wavefronts
 #endif

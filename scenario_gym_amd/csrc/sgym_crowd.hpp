@@ -625,10 +625,15 @@ __device__ __forceinline__ void ped_force(const Params &p, LDS &L, int r, int sl
             const double inv_tau = 1 / sf.relaxation_time;
             fx = inv_tau * (vdes * (gx / gn) - velx);
             fy = inv_tau * (vdes * (gy / gn) - vely);
+            if (!CROWD && p.ped_behaviour == SG_PED_RANDOM_WALK) { // RandomWalk._step: the vector to the goal point is all it
+                fx = gx;                                           // looks at (random_walk.py:40-41; ped_move takes its angle)
+                fy = gy;
+            }
             if (!CROWD) sg_sincos(L.ctrl[SG_C_PED_HEAD_ROT - SG_C_PED_SPEED_DESIRED][sl], hs, hc, K);
             radius = L.ctrl[SG_C_PED_RADIUS - SG_C_PED_SPEED_DESIRED][sl];
         }
     }
+    if (!CROWD && p.ped_behaviour == SG_PED_RANDOM_WALK) return; // (launch-uniform: no neighbours, no boundary terms)
     const double k2_scale = sf.ped_repulse_V / sf.ped_repulse_sigma;
     if (CROWD) {
         if (crowd_fast) { // wave-uniform: the guards of crowd_pair hold
@@ -649,22 +654,40 @@ __device__ __forceinline__ void ped_force(const Params &p, LDS &L, int r, int sl
     if (!CROWD && go) ped_boundary_terms(p, r, pose[0], pose[1], fx, fy); // after the neighbours, social_force.py:83-104
 }
 
+// The random fluctuations of one pedestrian's step: scale * z of np.random.normal(loc, scale) = loc + scale * z for the
+// speed (s) and the heading (h); on == false: no generator in use (std 0), the locations alone.
+struct PedNoise {
+    double s, h;
+    bool on;
+};
+
 // PedestrianAgent.step, part 2 (one lane): speed and heading from the force (:110-114, or zero at the goal,
 // agent.py:65-68) + PedestrianController._step (pedestrian/controller.py:25-46).
-// speed_rand / heading_rand: the random fluctuations np.random.normal(bias, std) of :106-108 (== the bias when std is 0).
+// SocialForce: speed_rand = np.random.normal(bias_lon, std_lon) joins |F|, heading_rand = np.random.normal(bias_lat, std_lat)
+// the force's angle (social_force.py:106-113).  RandomWalk (RW: compiled in for the variants that can run it; fx, fy = the
+// vector to the goal point): the locations carry the signal, speed = np.random.normal(speed_desired + bias_lon, std_lon),
+// heading = np.random.normal(angle + bias_lat, std_lat), no max_speed_factor, agent.force untouched (random_walk.py:37-43).
+template <bool RW = true>
 __device__ __forceinline__ void ped_move(const Params &p, bool go, double fx, double fy, double vdes, double maxs,
                                          const double *pose, double state_dt, double &cspeed, double &fxo, double &fyo,
-                                         double *np_, ConstTbl K, double speed_rand, double heading_rand)
+                                         double *np_, ConstTbl K, PedNoise nz)
 {
     const sg_social_force &sf = p.sf;
     double speed = 0.0, heading = 0.0;
-    if (go) {
+    fxo = fyo = 0.0;
+    if (RW && p.ped_behaviour == SG_PED_RANDOM_WALK) {
+        if (go) {
+            const double loc_s = vdes + sf.bias_lon, loc_h = sg_atan2(fy, fx) + sf.bias_lat;
+            speed = nz.on ? loc_s + nz.s : loc_s;
+            heading = nz.on ? loc_h + nz.h : loc_h;
+        }
+    } else if (go) {
+        const double speed_rand = nz.on ? sf.bias_lon + nz.s : sf.bias_lon;
+        const double heading_rand = nz.on ? sf.bias_lat + nz.h : sf.bias_lat;
         speed = __builtin_fmin(sg_norm2(fx, fy) + speed_rand, vdes * sf.max_speed_factor);
         heading = sg_atan2(fy, fx) + heading_rand;
         fxo = fx;
         fyo = fy;
-    } else {
-        fxo = fyo = 0.0;
     }
     cspeed = __builtin_fmin(__builtin_fmax(speed, -maxs), maxs);
     double hs2, hc2;

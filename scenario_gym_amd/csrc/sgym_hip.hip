@@ -54,6 +54,7 @@ struct sg_handle {
                                // rollout_kernel_crowd_riders + control_kernel_riders (env SG_CROWD_RIDERS=0: the general variant)
     int crowd_kernel = 1;     // env SG_CROWD_KERNEL=0: all-pedestrian batches take the general pedestrian variant too
     sg_social_force sf{};
+    int ped_behaviour = 0;        // sg_set_ped_behaviour
     int noise_mode = 0;           // sg_set_ped_noise
     double noise_std[2] = {0.0, 0.0};
     double *d_normals = nullptr;  // [R][noise_len]
@@ -137,6 +138,9 @@ struct sg_handle {
     std::vector<int> launch_ev;   // their (start, stop) event indices into ev_pool
     std::string err;
 };
+
+// the crowd variants (rollout_kernel_crowd / _riders, the walker kernels) hold the social force model alone
+static bool crowd_allowed(const sg_handle *h) { return h->crowd_kernel && h->ped_behaviour == SG_PED_SOCIAL_FORCE; }
 
 static int env_int(const char *name, int dflt)
 {
@@ -534,7 +538,7 @@ static void launch_variant(sg_handle *h, dim3 grid, int n_steps, int do_reset, i
         sgl::rollout_ped(64, 8, false, grid, s, a);
     else if (WV == 8) // ... vehicles and replay only (launch_rollout never takes the table path at this width)
         sgl::rollout_plain(64, 8, false, grid, s, a);
-    else if (h->has_ped && h->all_ped && G == 64 && !h->has_road && h->crowd_kernel && !h->rss_fused)
+    else if (h->has_ped && h->all_ped && G == 64 && !h->has_road && crowd_allowed(h) && !h->rss_fused)
         sgl::rollout_crowd(WV, false, grid, s, a);
     else if (use_tab && h->has_ped && G == 64) // (launch_rollout: a crowd with riders, their table is d_tab)
         sgl::rollout_crowd(WV, true, grid, s, at);
@@ -776,7 +780,7 @@ static int launch_rollout_impl(sg_handle *h, int n_steps, int do_reset, int forc
         for (int k0 = 0; k0 < n_steps && !rc; k0 += h->rssq_steps)
             rc = launch_main(h, std::min(h->rssq_steps, n_steps - k0), k0 == 0 ? do_reset : 0, force,
                              d_actions ? d_actions + (size_t)k0 * h->R * 2 : nullptr, nullptr, false, &ev_next);
-    } else if (!use_tab && h->has_ped && h->all_ped && h->G == 64 && h->WV == 4 && !h->has_road && h->crowd_kernel && !h->rss_fused &&
+    } else if (!use_tab && h->has_ped && h->all_ped && h->G == 64 && h->WV == 4 && !h->has_road && crowd_allowed(h) && !h->rss_fused &&
                h->p.rec_cap == 0 && !d_actions && n_steps >= env_int("SG_CROWD_WALK_MIN", 64) && (env_int("SG_CROWD_WALK", 0) & 3) != 0) {
         // (OFF by default: on 1024 scenarios the walker kernels are one wavefront per SIMD and, measured, no faster than
         // rollout_kernel_crowd -- HISTORY.md, round 4; SG_CROWD_WALK=3 switches the dispatch on, the parity tests do)
@@ -1117,6 +1121,19 @@ extern "C" int sg_set_social_force(sg_handle *h, const sg_social_force *params)
     return SG_OK;
 }
 
+extern "C" int sg_set_ped_behaviour(sg_handle *h, int32_t behaviour)
+{
+    if (!h) return SG_ERR_INVALID;
+    if (behaviour != SG_PED_SOCIAL_FORCE && behaviour != SG_PED_RANDOM_WALK)
+        return fail(h, SG_ERR_INVALID, "sg_set_ped_behaviour: unknown behaviour %d", behaviour);
+    if (h->uploaded && behaviour != h->ped_behaviour)
+        return fail(h, SG_ERR_STATE, "sg_set_ped_behaviour: call before sg_upload (the batch's kernels are chosen there)");
+    h->ped_behaviour = behaviour;
+    h->p.ped_behaviour = behaviour;
+    ++h->generation;
+    return SG_OK;
+}
+
 static void apply_noise(sg_handle *h)
 {
     h->p.noise_mode = h->noise_mode;
@@ -1187,7 +1204,7 @@ extern "C" int sg_upload(sg_handle *h, const sg_scenarios *sc)
     }
     if (h->has_ped && h->WV == 1 && h->G < 16) { h->G = 16; h->EP = 16; h->NE = (((size_t)h->R * h->EP + 63) / 64) * 64; }
     h->crowd_riders = false;
-    if (h->has_ped && !h->all_ped && h->G == 64 && h->WV <= 4 && h->crowd_kernel && env_int("SG_CROWD_RIDERS", 1) != 0) {
+    if (h->has_ped && !h->all_ped && h->G == 64 && h->WV <= 4 && crowd_allowed(h) && env_int("SG_CROWD_RIDERS", 1) != 0) {
         bool ok = true; // pedestrian agents of catalog type Pedestrian, and nothing the pre-pass cannot ride for
         for (size_t i = 0; i < (size_t)h->R * h->E && ok; ++i)
             ok = sc->kind[i] == SG_KIND_AGENT_PEDESTRIAN ? sc->etype[i] == 1 : sc->kind[i] != SG_KIND_AGENT_EXTERNAL;
@@ -1439,6 +1456,7 @@ extern "C" int sg_upload(sg_handle *h, const sg_scenarios *sc)
     p.R = R; p.E = E; p.EP = EP;
     p.WV = h->WV; p.FROWS = SG_F_COLL + h->WV;
     p.sf = h->sf;
+    p.ped_behaviour = h->ped_behaviour;
     apply_noise(h);
     p.ped_serial = h->ped_serial;
     p.ctl_general = env_int("SG_CTL_FAST", 1) == 0;

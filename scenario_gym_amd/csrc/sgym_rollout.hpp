@@ -638,7 +638,7 @@ __device__ __forceinline__ void rollout_body(
         // random fluctuations of the speed and the heading (social_force.py:106-108): np.random.normal(loc, scale) is
         // loc + scale * z; z from the scenario's stream of variates -- two per walking pedestrian, in agent order, as the
         // reference draws them from numpy's global generator -- or from the counter-based generator
-        double speed_rand = p.sf.bias_lon, heading_rand = p.sf.bias_lat;
+        PedNoise nz{0.0, 0.0, false};
         if (PED && p.noise_mode == 1) { // (launch-uniform branch)
             const uint64_t walk = __ballot(ped_go);
             int before, count;
@@ -664,16 +664,14 @@ __device__ __forceinline__ void rollout_body(
             if (ped_go) {
                 const bool inside = at + 1 < p.noise_len;
                 const double *z = p.noise_normals + (size_t)r * (size_t)p.noise_len + (inside ? at : 0);
-                speed_rand = p.sf.bias_lon + p.noise_std_lon * (inside ? z[0] : 0.0);
-                heading_rand = p.sf.bias_lat + p.noise_std_lat * (inside ? z[1] : 0.0);
+                nz = PedNoise{p.noise_std_lon * (inside ? z[0] : 0.0), p.noise_std_lat * (inside ? z[1] : 0.0), true};
                 sg_loads_done();
             }
             if (run) noise_pos += 2 * count;
         } else if (PED && p.noise_mode == 2) {
             double z0, z1;
             sg_noise_pair(p.noise_seed, r, (uint32_t)slot, (uint32_t)steps, z0, z1, K);
-            speed_rand = p.sf.bias_lon + p.noise_std_lon * z0;
-            heading_rand = p.sf.bias_lat + p.noise_std_lat * z1;
+            nz = PedNoise{p.noise_std_lon * z0, p.noise_std_lat * z1, true};
         }
         if (TAB) {
             // Straight-line lane masks (the kernel is bound by instruction issue, branches included):
@@ -712,8 +710,8 @@ __device__ __forceinline__ void rollout_body(
                 if (present) {
                     npres = true;
                     if (run)
-                        ped_move(p, ped_go, ped_fx, ped_fy, ped_vdes, lds.ctrl[PED ? SG_C_PED_MAX_SPEED - SG_C_PED_SPEED_DESIRED : 0][sl],
-                                 pose, state_dt, cs.speed, fpx, fpy, np_, K, speed_rand, heading_rand);
+                        ped_move<!CROWD>(p, ped_go, ped_fx, ped_fy, ped_vdes, lds.ctrl[PED ? SG_C_PED_MAX_SPEED - SG_C_PED_SPEED_DESIRED : 0][sl],
+                                 pose, state_dt, cs.speed, fpx, fpy, np_, K, nz);
                 } else if (min_t >= t) { // scenario_gym.py:240-244: spawn at the trajectory position of next_t (clamped)
                     npres = true;
                     LanePtr st_o = st;
@@ -771,9 +769,9 @@ __device__ __forceinline__ void rollout_body(
                         else
                             vehicle_step(cs, cp, bl, dt, act_a, act_s, sin_h, cos_h, np_, K);
                     } else if (PED)
-                        ped_move(p, ped_go, ped_fx, ped_fy, ped_vdes,
+                        ped_move<!CROWD>(p, ped_go, ped_fx, ped_fy, ped_vdes,
                                  lds.ctrl[PED ? SG_C_PED_MAX_SPEED - SG_C_PED_SPEED_DESIRED : 0][sl], pose, state_dt,
-                                 cs.speed, fpx, fpy, np_, K, speed_rand, heading_rand);
+                                 cs.speed, fpx, fpy, np_, K, nz);
                 }
             } else if (min_t >= t) { // scenario_gym.py:240-244: spawn at trajectory start
                 npres = true;

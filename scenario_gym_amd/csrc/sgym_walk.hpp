@@ -766,7 +766,7 @@ __device__ __forceinline__ void walk_body(const Params &p, double timestep, int 
         walk_pairs<WVL, 2>(p, L, CC, es, tid, nbr, go, fx, fy, pbail, wt);
         WT(1);
         // ---- random fluctuations (rollout_body) ----
-        double speed_rand = p.sf.bias_lon, heading_rand = p.sf.bias_lat;
+        PedNoise nz{0.0, 0.0, false};
         if (p.noise_mode == 1) {
             const uint64_t walk = __ballot(go);
             int before = __builtin_popcountll(walk & ((1ull << lane) - 1)), count = __builtin_popcountll(walk);
@@ -785,15 +785,13 @@ __device__ __forceinline__ void walk_body(const Params &p, double timestep, int 
             if (go) {
                 const bool inside = at + 1 < p.noise_len;
                 const double *z = p.noise_normals + (size_t)r * (size_t)p.noise_len + (inside ? at : 0);
-                speed_rand = p.sf.bias_lon + p.noise_std_lon * (inside ? z[0] : 0.0);
-                heading_rand = p.sf.bias_lat + p.noise_std_lat * (inside ? z[1] : 0.0);
+                nz = PedNoise{p.noise_std_lon * (inside ? z[0] : 0.0), p.noise_std_lat * (inside ? z[1] : 0.0), true};
             }
             noise_pos += 2 * count;
         } else if (p.noise_mode == 2) {
             double z0, z1;
             sg_noise_pair(p.noise_seed, (uint32_t)r, (uint32_t)es, (uint32_t)steps, z0, z1, K);
-            speed_rand = p.sf.bias_lon + p.noise_std_lon * z0;
-            heading_rand = p.sf.bias_lat + p.noise_std_lat * z1;
+            nz = PedNoise{p.noise_std_lon * z0, p.noise_std_lat * z1, true};
         }
         // ---- new poses: scenario_gym.py:233-245 ----
         bool npres = false;
@@ -801,7 +799,7 @@ __device__ __forceinline__ void walk_body(const Params &p, double timestep, int 
         if (is_ped) {
             if (present) {
                 npres = true;
-                ped_move(p, go, fx, fy, vdes, maxs_c, pose, state_dt, ncspeed, fpx, fpy, np_, K, speed_rand, heading_rand);
+                ped_move<false>(p, go, fx, fy, vdes, maxs_c, pose, state_dt, ncspeed, fpx, fpy, np_, K, nz);
             } else if (min_t >= t) { // spawn at the trajectory position of next_t
                 npres = true;
                 Table T = lane_table(p, SG_KIND_AGENT_PEDESTRIAN, ss, es, st);

@@ -138,11 +138,13 @@ static __global__ __launch_bounds__(256) void wide_move_kernel(Params p, double 
             fy = inv_tau * (vdes * (gy / gn) - vely);
             sg_sincos(fld(w.st, ST_CTRL + SG_C_PED_HEAD_ROT), hs, hc, K);
             radius = fld(w.st, ST_CTRL + SG_C_PED_RADIUS);
+            if (p.ped_behaviour == SG_PED_RANDOM_WALK) { fx = gx; fy = gy; } // RandomWalk._step: the vector to the goal point
         }
     }
+    const bool pairs = p.ped_behaviour != SG_PED_RANDOM_WALK; // (grid-uniform)
     const double k2_scale = p.sf.ped_repulse_V / p.sf.ped_repulse_sigma;
     // (the loop bounds are uniform over the grid row of the scenario: every thread of every block walks all chunks)
-    for (int c0 = 0; c0 < p.EP; c0 += 256) {
+    for (int c0 = 0; c0 < p.EP && pairs; c0 += 256) {
         const int j = c0 + tid;
         __syncthreads();
         {
@@ -199,15 +201,13 @@ static __global__ __launch_bounds__(256) void wide_move_kernel(Params p, double 
                     vehicle_step(cs, cp, bl, dt, aa, as, sin_h, cos_h, np_, K);
                 }
             } else if (is_ped) {
-                double speed_rand = p.sf.bias_lon, heading_rand = p.sf.bias_lat;
+                PedNoise nz{0.0, 0.0, false};
                 if (p.noise_mode == 2) {
                     double z0, z1;
                     sg_noise_pair(p.noise_seed, (uint32_t)r, (uint32_t)e, (uint32_t)sd.n_steps, z0, z1, K);
-                    speed_rand = p.sf.bias_lon + p.noise_std_lon * z0;
-                    heading_rand = p.sf.bias_lat + p.noise_std_lat * z1;
+                    nz = PedNoise{p.noise_std_lon * z0, p.noise_std_lat * z1, true};
                 }
-                ped_move(p, go, fx, fy, vdes, fld(w.st, ST_CTRL + SG_C_PED_MAX_SPEED), pose, state_dt, cs.speed, fpx, fpy, np_, K,
-                         speed_rand, heading_rand);
+                ped_move(p, go, fx, fy, vdes, fld(w.st, ST_CTRL + SG_C_PED_MAX_SPEED), pose, state_dt, cs.speed, fpx, fpy, np_, K, nz);
                 cs.e_lon_prev = (double)goal_idx;
             }
         } else if (min_t >= t) { // scenario_gym.py:240-244: spawn at the trajectory position of next_t

@@ -110,18 +110,25 @@ class RolloutEngine:
     def set_social_force(self, relaxation_time=1.5, ped_repulse_V=1.0, ped_repulse_sigma=1.0, ped_attract_C=0.0,
                          sight_weight=0.5, sight_weight_use=True, sight_angle=200, max_speed_factor=1.3,
                          bias_lon=0.0, bias_lat=0.0, imp_boundary_repulse_U=2.0, imp_boundary_repulse_R=0.1,
-                         std_lon=0.0, std_lat=0.0, noise=None, noise_seed=0, normals=None):
+                         std_lon=0.0, std_lat=0.0, noise=None, noise_seed=0, normals=None, behaviour="social_force"):
         """SocialForceParameters of every pedestrian agent on this handle (pedestrian/social_force.py:16-30);
-        call before upload().  std_lon / std_lat with noise="device" (counter-based generator on the GPU, the default when
+        call before upload().  behaviour="random_walk": the pedestrians follow RandomWalk (pedestrian/random_walk.py:22-44)
+        instead, which reads bias_lon / bias_lat / std_lon / std_lat only.  std_lon / std_lat with noise="device" (counter-based generator on the GPU, the default when
         a std is non-zero) or noise="stream" + normals[R, n] (the variates numpy's legacy generator would hand out:
         np.random.RandomState(k).standard_normal(n) per scenario) are the random fluctuations of :106-108."""
         sf = L.SgSocialForce(relaxation_time, ped_repulse_V, ped_repulse_sigma, ped_attract_C, sight_weight,
                              float(bool(sight_weight_use)), float(np.cos(sight_angle / 2 * np.pi / 180)),
                              max_speed_factor, bias_lon, bias_lat, imp_boundary_repulse_U, imp_boundary_repulse_R)
         self._check(self.lib.sg_set_social_force(self.h, C.byref(sf)), "sg_set_social_force")
+        self.set_ped_behaviour(behaviour)
         if noise is None:
             noise = "device" if (std_lon != 0 or std_lat != 0) else "off"
         self.set_ped_noise(noise, std_lon, std_lat, normals=normals, seed=noise_seed)
+
+    def set_ped_behaviour(self, behaviour="social_force"):
+        """sg_set_ped_behaviour: "social_force" or "random_walk" for every pedestrian agent of the handle; before upload()."""
+        code = {"social_force": L.PED_SOCIAL_FORCE, "random_walk": L.PED_RANDOM_WALK}[behaviour]
+        self._check(self.lib.sg_set_ped_behaviour(self.h, code), "sg_set_ped_behaviour")
 
     def set_ped_noise(self, mode="off", std_lon=0.0, std_lat=0.0, normals=None, seed=0):
         """sg_set_ped_noise: "off", "stream" (normals[R, n] standard normal variates per scenario) or "device"."""

@@ -211,10 +211,12 @@ class BatchedScenarioGym:
             if c not in TERMINAL_BITS:
                 raise ValueError(f"terminal condition {c!r} is not supported")
         sf = None
-        for sc_agents in agents:  # one SocialForce parameter set per batch (the first pedestrian agent's)
+        for sc_agents in agents:  # one behaviour model and parameter set per batch (the first pedestrian agent's)
             for a in sc_agents.values():
                 if hasattr(a, "behaviour"):
                     sf = sf or a.behaviour.device_params()
+                    if a.behaviour.device_params()["behaviour"] != sf["behaviour"]:
+                        raise NotImplementedError("SocialForce and RandomWalk pedestrians in one batch: one behaviour model per gym")
         if sf is not None and sf.get("noise") == "stream":
             # parity with the reference's global generator: scenario i draws what numpy hands out after seed(noise_seed + i)
             seeds = sf.pop("noise_seed")

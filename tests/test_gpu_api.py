@@ -317,6 +317,55 @@ def test_social_force_with_the_reference_default_noise():
             assert 0 < np.abs(early - ref[30]).max() < 1e-3 and np.isfinite(end).all()
 
 
+def test_random_walk_agents_through_the_gym():
+    """tests/pedestrian/test_random_walk.py: PedestrianAgent(entity, route, speed_desired, behaviour=RandomWalk(params)) steps
+    and moves (last speed > 0); with noise="numpy" the gym walks the reference's own rollout after np.random.seed(k) (golden
+    random_walk/loop0: nine pedestrians and a car), goal indices included; SocialForce and RandomWalk agents in one gym are
+    refused."""
+    import scenario_gym_amd as sga
+
+    g = load_golden("random_walk")
+    sc = _scenario(g, "loop0/scenario")
+    routes, vdes = g["loop0/routes"], g["loop0/vdes"]
+    std_lon, std_lat, bias_lon, bias_lat, max_speed, seed = g["loop0/params"]
+    idx = {e.ref: i for i, e in enumerate(sc.entities)}
+    ref = g["loop0/dt30/poses"]
+
+    def create_agent(s, e):
+        if e.ref == "ego":
+            return sga.agent._create_agent(s, e)
+        i = idx[e.ref]
+        params = sga.RandomWalkParameters(std_lon=std_lon, std_lat=std_lat, noise="numpy", noise_seed=int(seed))
+        return sga.PedestrianAgent(e, routes[i], vdes[i], sga.RandomWalk(params), max_speed=max_speed)
+
+    gym = sga.ScenarioGym(timestep=1 / 30, metrics=[sga.CollisionMetric()])
+    gym.set_scenario(sc, create_agent=create_agent)
+    gym.step()
+    walker = next(a for a in gym.state.agents.values() if isinstance(a, sga.PedestrianAgent))
+    assert walker.speed > 0  # (the reference's test: agent.last_action.speed > 0)
+    for _ in range(29):
+        gym.step()
+    early = np.array([gym.state.poses[e] for e in sc.entities])
+    gym.rollout()
+    end = np.array([gym.state.poses[e] for e in sc.entities])
+    goal = [a.goal_idx for e, a in gym.state.agents.items() if isinstance(a, sga.PedestrianAgent)]
+    want = [int(k) for k in g["loop0/dt30/extra"][-1][:, 1] if not np.isnan(k)]
+    gym.close()
+    assert np.nanmax(np.abs(early - ref[30])) < 1e-9 and np.nanmax(np.abs(end - ref[-1])) < 1e-8 and goal == want
+
+    def mixed(s, e):
+        if e.ref == "ego":
+            return sga.agent._create_agent(s, e)
+        i = idx[e.ref]
+        b = sga.RandomWalk(sga.RandomWalkParameters()) if i % 2 else sga.SocialForce(sga.SocialForceParameters())
+        return sga.PedestrianAgent(e, routes[i], vdes[i], b)
+
+    gym = sga.ScenarioGym(timestep=1 / 30)
+    with pytest.raises(NotImplementedError, match="one behaviour model per gym"):
+        gym.set_scenario(sc, create_agent=mixed)
+    gym.close()
+
+
 def test_to_scenario_round_trip():
     """tests/test_state.py:210-260: roll out, write the recording back as a scenario (State.to_scenario), roll the
     recording out again: same entities, the ego follows the recorded poses."""

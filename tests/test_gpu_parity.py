@@ -571,14 +571,15 @@ def test_wide_scenario_collision_terminal(sga, oracle):
 
 
 # --------------------------------------------------------------------------- pedestrians / social force
-def _ped_packed(g, si):
+def _ped_packed(g, si, max_speed=None):
     from scenario_gym_amd.engine import DEFAULT_CTRL
     from scenario_gym_amd.packing import default_kinds, pack_arrays
     import scenario_gym_amd._lib as L
 
     sc = scenario_arrays(g, f"loop{si}/scenario")
     E = len(sc["etype"])
-    Rt, vdes, thr = g[f"loop{si}/routes"], g[f"loop{si}/vdes"], float(g[f"loop{si}/distance_threshold"])
+    Rt, vdes = g[f"loop{si}/routes"], g[f"loop{si}/vdes"]
+    thr = float(g[f"loop{si}/distance_threshold"]) if f"loop{si}/distance_threshold" in g else 1.0  # (agent.py:26: the default)
     kind = default_kinds(E, sc["ego"])
     ctrl = np.tile(DEFAULT_CTRL, (E, 1))
     roff, rows = [0], []
@@ -587,6 +588,8 @@ def _ped_packed(g, si):
         if isped:
             kind[i] = L.KIND_AGENT_PEDESTRIAN
             ctrl[i, L.C_PED_SPEED_DESIRED], ctrl[i, L.C_PED_RADIUS] = vdes[i], thr
+            if max_speed is not None:
+                ctrl[i, L.C_PED_MAX_SPEED] = max_speed
             rows.append(Rt[i])
         roff.append(roff[-1] + (len(Rt[i]) if isped else 0))
     sc = dict(sc, route_off=np.array(roff, np.int64), routes=np.concatenate(rows))
@@ -662,6 +665,78 @@ def test_pedestrian_noise_closed_loops_match_reference(sga, oracle, si):
     with pytest.raises(RuntimeError, match="noise variates"):
         eng.metrics()
     eng.close()
+
+
+@pytest.mark.parametrize("si", [0, 1, 2, 3])
+def test_random_walk_closed_loops_match_reference(sga, oracle, si):
+    """RandomWalk (pedestrian/random_walk.py:22-44) on the device, stream mode: closed loops of the reference's
+    PedestrianAgent(..., behaviour=RandomWalk(params)) after np.random.seed(k) -- with a bias and a clipping max_speed (loop
+    1), the reference's default parameters (loop 2), std 0 (loop 3).  Poses <= 1e-8 of the reference, goal indices and
+    controller speeds, the (zero) force, events; bit-identical to the oracle; the same number of variates."""
+    g = load_golden("random_walk")
+    std_lon, std_lat, bias_lon, bias_lat, max_speed, seed = g[f"loop{si}/params"]
+    packed, E = _ped_packed(g, si, max_speed=max_speed)
+    used = int(g[f"loop{si}/variates_used"])
+    normals = np.random.RandomState(int(seed)).standard_normal(used + 64)
+    p = f"loop{si}/dt30"
+    n = int(g[p + "/n_steps"])
+    eng = sga.RolloutEngine(1, E, timestep=1 / 30, record_capacity=n + 3, event_capacity=256,
+                            social_force=dict(behaviour="random_walk", bias_lon=bias_lon, bias_lat=bias_lat, std_lon=std_lon,
+                                              std_lat=std_lat, noise="stream", normals=normals[None, :]))
+    eng.upload(packed)
+    with pytest.raises(RuntimeError, match="before sg_upload"):
+        eng.set_ped_behaviour("social_force")
+    eng.rollout(n + 2)
+    st = eng.state()
+    rows, events = eng.metrics()
+    t, poses = eng.record(n + 3)
+    eng.close()
+    assert rows["n_steps"][0] == n and st["noise_pos"][0] == used
+    ref = g[p + "/poses"]
+    assert np.array_equal(np.isnan(poses[: n + 1, 0]), np.isnan(ref)) and np.nanmax(np.abs(poses[: n + 1, 0] - ref)) < 1e-8
+    ex = g[p + "/extra"][-1]
+    ped = ~np.isnan(ex[:, 0])
+    assert np.array_equal(st["ctrl_state"][0, ped, 1], ex[ped, 1]) and np.abs(st["ctrl_state"][0, ped, 0] - ex[ped, 0]).max() < 1e-8
+    assert not st["force"][0, ped].any()
+    assert np.array_equal(events["t"], g[p + "/ev_t"]) and np.array_equal(events["other"], g[p + "/ev_other"])
+    sf = oracle.social_force_params(bias_lon=bias_lon, bias_lat=bias_lat)
+    o = _oracle_one(oracle, packed, 0, 1 / 30, n + 2, sf=sf, behaviour="random_walk",
+                    noise=dict(mode="stream", std_lon=std_lon, std_lat=std_lat, normals=normals))
+    assert bits_equal(poses[: n + 1, 0], o["poses"]) and bits_equal(st["vels"][0], o["vels"][-1])
+    assert bits_equal(st["ctrl_state"][0, ped, 0], o["extra"][-1, ped, 0])
+
+
+@pytest.mark.parametrize("R,E,steps,side,noise", [(8, 256, 60, 30.0, "device"), (16, 40, 90, 10.0, "off"), (3, 300, 50, 30.0, "device"),
+                                                  (2, 700, 40, 40.0, "device")])
+def test_random_walk_crowds_match_oracle(sga, oracle, R, E, steps, side, noise):
+    """RandomWalk over the crowd batches of config 5's family -- 40 ... 700 pedestrians per scenario: the general pedestrian
+    variant on one to eight wavefronts and the multi-kernel step beyond 512 entities (the crowd kernels hold the social force
+    model only) -- with the counter-based generator and without noise: every recorded pose, the final state, the events
+    equal the oracle's; the walk differs from the social force model's."""
+    from scenario_gym_amd import synthetic
+
+    packed = synthetic.make_crowd(R, E, n_steps=steps, side=side)
+    kw = dict(behaviour="random_walk", bias_lon=0.05, bias_lat=-0.02)
+    noise_of = None
+    if noise == "device":
+        kw.update(std_lon=0.2, std_lat=0.3, noise="device", noise_seed=77)
+        noise_of = lambda r: dict(mode="device", std_lon=0.2, std_lat=0.3, seed=77, scenario_index=r)  # noqa: E731
+    eng = sga.RolloutEngine(R, E, record_capacity=steps + 1, event_capacity=512, social_force=kw)
+    eng.upload(packed)
+    eng.rollout(steps)
+    st = eng.state()
+    t, poses = eng.record(steps + 1)
+    from oracle import check
+
+    sf = oracle.social_force_params(bias_lon=0.05, bias_lat=-0.02)
+    ver = check.verify_engine(eng, packed, 1 / 30, steps, K=R, event_cap=512, ped=True, sf=sf, noise_of=noise_of, behaviour="random_walk")
+    assert ver["equal"], ver["mismatches"]
+    eng.close()
+    o = _oracle_one(oracle, packed, 0, 1 / 30, steps, sf=sf, behaviour="random_walk", noise=None if noise_of is None else noise_of(0))
+    assert bits_equal(poses[: o["n_steps"] + 1, 0], o["poses"])
+    assert not st["force"].any()
+    o0 = _oracle_one(oracle, packed, 0, 1 / 30, steps, sf=sf, noise=None if noise_of is None else noise_of(0))
+    assert np.nanmax(np.abs(o0["poses"][-1] - o["poses"][-1])) > 1e-3
 
 
 @pytest.mark.parametrize("R,E,steps,side", [(6, 256, 70, 30.0), (16, 40, 100, 10.0), (5, 100, 60, 14.0)])

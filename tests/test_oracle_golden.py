@@ -228,11 +228,12 @@ def test_pair_intersections_exact(oracle):
 
 
 # ---------------------------------------------------------------- F1-F4 pedestrians / social force
-def ped_inputs(g, si, oracle):
+def ped_inputs(g, si, oracle, max_speed=None):
     """Arrays for the closed-loop pedestrian goldens: kinds, controller rows, routes."""
     sc = scenario_arrays(g, f"loop{si}/scenario")
     E = len(sc["etype"])
-    R, vdes, thr = g[f"loop{si}/routes"], g[f"loop{si}/vdes"], float(g[f"loop{si}/distance_threshold"])
+    R, vdes = g[f"loop{si}/routes"], g[f"loop{si}/vdes"]
+    thr = float(g[f"loop{si}/distance_threshold"]) if f"loop{si}/distance_threshold" in g else 1.0  # (agent.py:26: the default)
     kind = oracle.default_kinds(E, sc["ego"])
     ctrl = np.tile(oracle.DEFAULT_CTRL, (E, 1))
     roff, rows = [0], []
@@ -240,6 +241,8 @@ def ped_inputs(g, si, oracle):
         if not np.isnan(vdes[i]):
             kind[i] = oracle.KIND_AGENT_PEDESTRIAN
             ctrl[i, 9], ctrl[i, 12] = vdes[i], thr
+            if max_speed is not None:
+                ctrl[i, 10] = max_speed
             rows.append(R[i])
         roff.append(roff[-1] + (len(R[i]) if not np.isnan(vdes[i]) else 0))
     return sc, kind, ctrl, np.array(roff, np.int64), np.concatenate(rows)
@@ -549,6 +552,44 @@ def test_pedestrian_noise_closed_loops(oracle, si):
     # without the noise the trajectories differ (the test would pass trivially otherwise)
     o0 = oracle.rollout(**sc, kind=kind, dt=1 / 30, ctrl=ctrl, route_off=roff, routes=routes)
     assert np.nanmax(np.abs(o0["poses"][: o["n_steps"] + 1] - o["poses"])) > (1e-3 if si < 2 else 1e-9)
+
+
+@pytest.mark.parametrize("si", [0, 1, 2, 3])
+def test_random_walk_closed_loops(oracle, si):
+    """RandomWalk (pedestrian/random_walk.py:22-44) closed loops of the reference after np.random.seed(k): speed =
+    np.random.normal(speed_desired + bias_lon, std_lon), heading = np.random.normal(angle to the goal point + bias_lat,
+    std_lat) -- with a bias and a max_speed that clips (loop 1), the reference's default parameters (loop 2) and std 0
+    (loop 3: the variates are still drawn).  The oracle consumes the same legacy stream and lands on the reference's
+    trajectories, speeds, goal indices and (zero) forces, with exactly as many variates as numpy handed out."""
+    g = load_golden("random_walk")
+    std_lon, std_lat, bias_lon, bias_lat, max_speed, seed = g[f"loop{si}/params"]
+    sc, kind, ctrl, roff, routes = ped_inputs(g, si, oracle, max_speed=max_speed)
+    E = len(kind)
+    used = int(g[f"loop{si}/variates_used"])
+    normals = np.random.RandomState(int(seed)).standard_normal(used + 64)
+    sf = oracle.social_force_params(bias_lon=bias_lon, bias_lat=bias_lat)
+    p = f"loop{si}/dt30"
+    o = oracle.rollout(**sc, kind=kind, dt=1 / 30, ctrl=ctrl, route_off=roff, routes=routes, sf=sf, behaviour="random_walk",
+                       noise=dict(mode="stream", std_lon=std_lon, std_lat=std_lat, normals=normals))
+    assert o["n_steps"] == int(g[p + "/n_steps"]) and bits_equal(o["t"], g[p + "/t"])
+    assert o["noise_used"] == used
+    for k in ("poses", "vels", "dists"):
+        assert np.array_equal(np.isnan(o[k]), np.isnan(g[p + "/" + k]))
+        assert np.nanmax(np.abs(o[k] - g[p + "/" + k])) < PED_TOL, (p, k)
+    ex = g[p + "/extra"]
+    ped = ~np.isnan(ex[0, :, 0])
+    assert np.array_equal(o["extra"][:, ped, 1], ex[:, ped, 1])              # goal_idx exact
+    assert np.abs(o["extra"][:, ped] - ex[:, ped]).max() < PED_TOL           # controller speed; force
+    assert not ex[:, ped, 2:].any() and not o["extra"][:, ped, 2:].any()     # RandomWalk never touches agent.force
+    assert np.array_equal(oracle.coll_to_dense(o["coll"], E), g[p + "/coll"])
+    assert np.array_equal(o["ev_t"], g[p + "/ev_t"]) and np.array_equal(o["ev_other"], g[p + "/ev_other"])
+    if si == 1:
+        assert (np.abs(ex[1:, ped, 0]) == max_speed).any()                   # the controller's clip did act
+    # the social force model on the same inputs walks elsewhere (the test would pass trivially otherwise)
+    o0 = oracle.rollout(**sc, kind=kind, dt=1 / 30, ctrl=ctrl, route_off=roff, routes=routes, sf=sf,
+                        noise=dict(mode="stream", std_lon=std_lon, std_lat=std_lat, normals=normals))
+    n = min(o0["n_steps"], o["n_steps"]) + 1
+    assert np.nanmax(np.abs(o0["poses"][:n] - o["poses"][:n])) > 1e-3
 
 
 def test_counter_based_noise_generator(oracle):
