@@ -1,7 +1,7 @@
 #!/bin/bash
 # SQ_INSTS_VALU / SALU per wave-step of the c3 headline kernel for the library given in SGYM_LIB (ablation builds)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" && mkdir -p gpurun_out
-for lib in "" scenario_gym_amd/lib/ab/nocoll.so; do
+for lib in ${LIBS:-"" scenario_gym_amd/lib/ab/nocoll.so}; do
   tag=$(basename "${lib:-base}" .so)
   SGYM_LIB=$lib timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_INSTS_BRANCH SQ_INSTS_VMEM_WR --output-format csv -d gpurun_out/pmc_$tag -o p -- python3 bench.py --no-cpu-baseline --verify 0 --steps 1 --warmup 0 > gpurun_out/pmc_$tag.log 2>&1
   python3 - "$tag" <<'PY'
