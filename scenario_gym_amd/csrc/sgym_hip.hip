@@ -124,6 +124,8 @@ struct sg_handle {
     double *d_rssq = nullptr;                              // line-test queues of rollout_kernel_rss: [NE / 64][(rssq_steps + 1) * 64][12]
     int32_t *d_rssq_n = nullptr;                           // [NE / 64]
     int rssq_steps = 0;                                    // steps per launch the queues are sized for
+    size_t rss_NE = 0, rssq_NE = 0;                        // padded entity counts the records / the queues were allocated for
+    bool rss_stale = true;                                 // the records belong to a batch that is gone (sg_upload): cleared on next use
     double c_tol = 0.4;                                // CollisionMetric(c_tol): angular half-width of a box corner, metrics/collision.py:57
     unsigned char *d_reset_mask = nullptr;             // [R] sg_reset_scenarios
     uint32_t *d_term_flags = nullptr;                  // [R] sg_terminal_flags
@@ -138,6 +140,9 @@ struct sg_handle {
     std::vector<int> launch_ev;   // their (start, stop) event indices into ev_pool
     std::string err;
 };
+
+// the RSSDistances records hold results of the current batch (sg_upload leaves the buffers, not their contents)
+static bool rss_live(const sg_handle *h) { return h->d_rss_state && !h->rss_stale; }
 
 // the crowd variants (rollout_kernel_crowd / _riders, the walker kernels) hold the social force model alone
 static bool crowd_allowed(const sg_handle *h) { return h->crowd_kernel && h->ped_behaviour == SG_PED_SOCIAL_FORCE; }
@@ -1183,8 +1188,12 @@ extern "C" int sg_upload(sg_handle *h, const sg_scenarios *sc)
     h->static_allocs.rewind(); // (buffers of the previous batch are reused where they are large enough)
     h->state_allocs.rewind();
     free_pool(h->road_allocs); // the networks belong to a batch (net_of_scenario)
-    if (h->d_rss_state) { (void)hipFree(h->d_rss_state); (void)hipFree(h->d_rss_code); (void)hipFree(h->d_rss_safe); (void)hipFree(h->d_rss_seen); h->d_rss_state = nullptr; h->d_rss_code = nullptr; h->d_rss_safe = nullptr; h->d_rss_seen = nullptr; }
-    if (h->d_rssq) { (void)hipFree(h->d_rssq); (void)hipFree(h->d_rssq_n); h->d_rssq = nullptr; h->d_rssq_n = nullptr; h->p.rssq = nullptr; h->p.rssq_n = nullptr; }
+    // the RSS records and the line-test queue (GiBs) belong to the handle's shape, not to the batch: they stay allocated and
+    // start anew (ensure_rss / ensure_rssq on first use; a hipFree + hipMalloc of the queue per upload stalled every tenth
+    // or so sg_upload of a sweep for a second)
+    h->rss_stale = true;
+    h->p.rss_state = nullptr; h->p.rss_code = nullptr; h->p.rss_seen = nullptr; h->p.rss_safe = nullptr;
+    h->p.rssq = nullptr; h->p.rssq_n = nullptr;
     h->has_road = false;
     h->road = sg::RoadIndex{};
     h->uploaded = false; // (the controller table buffers stay: launch_rollout regrows them when the new batch needs more)
@@ -1575,7 +1584,7 @@ extern "C" int sg_reset_scenarios(sg_handle *h, const uint8_t *mask)
     HIP_TRY(h, hipMemcpyAsync(h->d_reset_mask, mask, (size_t)h->R, hipMemcpyHostToDevice, h->stream));
     h->p.reset_mask = h->d_reset_mask;
     int rc;
-    if (h->rss_enabled && h->ego_first && h->d_rss_state) { // the flagged scenarios' RSS histories start anew as well
+    if (h->rss_enabled && h->ego_first && rss_live(h)) { // the flagged scenarios' RSS histories start anew as well
         bool fresh = false;
         if ((rc = ensure_rss(h, &fresh)) || (rc = ensure_rssq(h))) return rc;
         h->rss_fused = true;
@@ -1645,7 +1654,7 @@ extern "C" int sg_step(sg_handle *h, int32_t n_steps, const double *actions, int
         d_act = h->d_actions;
     }
     int rc = SG_OK;
-    if (h->rss_enabled && h->ego_first && h->d_rss_state) {
+    if (h->rss_enabled && h->ego_first && rss_live(h)) {
         bool fresh = false;
         if (!(rc = ensure_rss(h, &fresh))) rc = ensure_rssq(h);
         h->rss_fused = true;
@@ -1715,7 +1724,7 @@ extern "C" int sg_tick(sg_handle *h, const double *actions, int32_t actions_devi
     int32_t *dl = reinterpret_cast<int32_t *>(d + lay_off);
     // sg_set_rss: the callback runs after the step, inside the captured launch (like sg_step; without records of a reset --
     // the callback was switched on after sg_upload -- through sg_rss_update after the graph)
-    const bool rss_tick = h->rss_enabled && h->ego_first && h->d_rss_state;
+    const bool rss_tick = h->rss_enabled && h->ego_first && rss_live(h);
     if (rss_tick) { // (allocations stay outside the capture)
         bool fresh = false;
         if ((rc = ensure_rss(h, &fresh)) || (rc = ensure_rssq(h))) return rc;
@@ -2128,26 +2137,38 @@ extern "C" int sg_set_tuning(sg_handle *h, int32_t tab_min_steps, int32_t chunk_
 static int ensure_rss(sg_handle *h, bool *fresh)
 {
     *fresh = false;
+    if (h->d_rss_state && h->rss_NE != h->NE) { // (another padded entity count: sg_upload of a pedestrian batch narrower than 16)
+        (void)hipFree(h->d_rss_state); (void)hipFree(h->d_rss_code); (void)hipFree(h->d_rss_safe); (void)hipFree(h->d_rss_seen);
+        h->d_rss_state = nullptr; h->d_rss_code = nullptr; h->d_rss_safe = nullptr; h->d_rss_seen = nullptr;
+    }
     if (!h->d_rss_state) {
         HIP_TRY(h, hipMalloc((void **)&h->d_rss_state, h->NE * sizeof(int32_t)));
         HIP_TRY(h, hipMalloc((void **)&h->d_rss_code, h->NE * sizeof(int32_t)));
         HIP_TRY(h, hipMalloc((void **)&h->d_rss_safe, h->NE * 2 * sizeof(double)));
         HIP_TRY(h, hipMalloc((void **)&h->d_rss_seen, (size_t)h->R * sizeof(int32_t)));
+        h->rss_NE = h->NE;
+        h->rss_stale = true;
+    }
+    if (h->rss_stale) { // first use after sg_create / sg_upload: the records of a new batch
         HIP_TRY(h, hipMemsetAsync(h->d_rss_state, 0, h->NE * sizeof(int32_t), h->stream));
         HIP_TRY(h, hipMemsetAsync(h->d_rss_code, 0xff, h->NE * sizeof(int32_t), h->stream));
         HIP_TRY(h, hipMemsetAsync(h->d_rss_safe, 0xff, h->NE * 2 * sizeof(double), h->stream));
         HIP_TRY(h, hipMemsetAsync(h->d_rss_seen, 0xff, (size_t)h->R * sizeof(int32_t), h->stream));
+        h->rss_stale = false;
         *fresh = true;
     }
     h->p.rss_state = h->d_rss_state; h->p.rss_code = h->d_rss_code; h->p.rss_safe = h->d_rss_safe; h->p.rss_seen = h->d_rss_seen;
     return SG_OK;
 }
 
-// The line-test queues of rollout_kernel_rss (sgym_device.hpp, RssQueue): (steps + 1) x 64 groups of 96 B per wavefront, the
-// steps per launch chosen so that the queues of the batch stay under SG_RSSQ_BYTES (default 4 GiB).
 static int ensure_rssq(sg_handle *h)
 {
+    if (h->d_rssq && h->rssq_NE != h->NE) {
+        (void)hipFree(h->d_rssq); (void)hipFree(h->d_rssq_n);
+        h->d_rssq = nullptr; h->d_rssq_n = nullptr;
+    }
     if (!h->d_rssq) {
+        h->rssq_NE = h->NE;
         const size_t nw = h->NE / 64, per_step = nw * 64 * sg::RSSQ_REC * sizeof(double);
         // (SG_RSSQ_MB; default: an eighth of the free device memory, at least 4 GiB -- every launch boundary costs the tail of a
         // launch, and 288 GB hold the queues of a whole 1000-step rollout of the largest batches)
@@ -2204,7 +2225,7 @@ extern "C" int sg_set_rss(sg_handle *h, int32_t enabled)
 extern "C" int sg_rss_read(sg_handle *h, uint8_t *flags, int32_t *codes, double *safe)
 {
     if (!h) return SG_ERR_INVALID;
-    if (!h->uploaded || !h->d_rss_state) return fail(h, SG_ERR_STATE, "sg_rss_read: sg_rss_update has not run on this batch");
+    if (!h->uploaded || !rss_live(h)) return fail(h, SG_ERR_STATE, "sg_rss_read: sg_rss_update has not run on this batch");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     const int R = h->R, E = h->E, EP = h->EP;

@@ -1109,6 +1109,51 @@ def test_table_kernels_on_a_clock_that_stands_still(sga, oracle, zpr):
     eng.close()
 
 
+@pytest.mark.parametrize("ego", ["replay", "pid"])
+def test_rss_records_start_anew_on_every_upload(sga, oracle, ego):
+    """A sweep reuses one handle for batch after batch (BatchedScenarioGym.set_packed): the RSS records and the line-test queue
+    stay allocated across sg_upload -- freeing and re-allocating the queue (GiBs) stalled every tenth or so upload for a
+    second -- but their CONTENTS belong to a batch: after the next upload sg_rss_read refuses until the callback has run, and
+    the second batch's flags, codes and safe distances equal those of a fresh handle and the oracle's."""
+    import scenario_gym_amd._lib as L
+    from scenario_gym_amd import synthetic
+    from scenario_gym_amd.packing import unpack_scenario
+
+    R, E, steps = 24, 40, 60
+    kind = dict(replay=L.KIND_AGENT_REPLAY, pid=L.KIND_AGENT_PID)[ego]
+    a = synthetic.make_batch(R, E, n_steps=steps, ego_kind=kind, extent=20.0, vanish_frac=0.3)
+    b = synthetic.make_batch(R, E, n_steps=steps, ego_kind=kind, extent=16.0, vanish_frac=0.2, seed=99)
+    eng = sga.RolloutEngine(R, E)
+    eng.set_rss(True)
+    eng.upload(a)
+    eng.rollout(steps)
+    first = eng.rss()
+    eng.set_rss(False)
+    eng.upload(b)
+    with pytest.raises(RuntimeError, match="has not run on this batch"):
+        eng.rss()
+    eng.set_rss(True)
+    eng.upload(b)
+    eng.rollout(steps)
+    again = eng.rss()
+    eng.close()
+    fresh = sga.RolloutEngine(R, E)
+    fresh.set_rss(True)
+    fresh.upload(b)
+    fresh.rollout(steps)
+    want = fresh.rss()
+    fresh.close()
+    for x, y in zip(again, want):
+        assert np.array_equal(x, y, equal_nan=True)
+    assert not all(np.array_equal(x, y, equal_nan=True) for x, y in zip(first, want))
+    for r in range(0, R, 5):
+        s = unpack_scenario(b, r)
+        o = oracle.rollout(s["knot_off"], s["knots"], s["bbox"], s["etype"], s["kind"], s["ego"], s["t0"], s["length"], 1 / 30,
+                           ctrl=s["ctrl"], max_steps=steps)
+        w = oracle.rss_rollout(o, s["bbox"], s["ego"])
+        assert np.array_equal(again[2][r], w["code"][-1]) and np.array_equal(again[3][r], w["safe"][-1], equal_nan=True), r
+
+
 def test_launch_stats_count_overlapping_launches_once(sga, monkeypatch):
     """sg_last_launch_stats reports the time during which at least one rollout launch ran (the union of the launches'
     intervals), sg_last_launch_gross_ms the plain sum of their durations: equal with one pipeline, and with pipelines the sum
