@@ -103,8 +103,12 @@ enum {
 typedef struct {
     int32_t device;          /* HIP device ordinal */
     int32_t n_scenarios;     /* R */
-    int32_t n_entities;      /* E, entity slots per scenario (<= 512 in this ABI version; 257..512: replay entities, replay agents and
-                                PID / vehicle agents only -- no pedestrian agents, RSS callback, ego_off_road or observation calls) */
+    int32_t n_entities;      /* E, entity slots per scenario (the reference has no ceiling, state/utils.py:10-49; here <= 16384).
+                                Up to 512: one workgroup per scenario, every kind, callback and observation call.  Beyond: the
+                                step runs as four kernels over as many workgroups as the scenario needs (every entity kind incl.
+                                pedestrian agents with the counter-based noise) -- without caller-run agents, the RSS callback,
+                                road networks, observation calls, sg_tick and the noise stream (those calls fail with
+                                SG_ERR_INVALID on such a handle) */
     int32_t persist;         /* ScenarioGym(persist=...) */
     uint32_t terminal_mask;  /* SG_TERM_* */
     int32_t record_capacity; /* rows of State._recorded_poses kept on device (0 = off), state.py:227-228 */
@@ -178,7 +182,8 @@ typedef struct {
     int32_t n_events;              /* len(CollisionMetric.collisions) */
     int32_t rec_rows;              /* rows written to the pose record */
     int64_t noise_pos;             /* variates of the scenario's noise stream consumed so far (sg_set_ped_noise, SG_NOISE_STREAM) */
-    uint64_t last_row_hi[4];       /* words 4..7 of last_row (scenarios of 257..512 entities) */
+    uint64_t last_row_hi[4];       /* words 4..7 of last_row (scenarios of 257..512 entities; beyond 512 the rows live in
+                                      sg_handle scratch, sgym_wide.hpp) */
 } sg_scenario_state;               /* 136 bytes */
 
 typedef struct {
@@ -413,10 +418,10 @@ int sg_last_launch_gross_ms(sg_handle *h, float *kernel_ms_gross);
  * blocks of the batch, [6] SIMDs of the device, [7] reserved. */
 int sg_pipeline_info(sg_handle *h, int32_t *info);
 
-/* Long rollouts of all-pedestrian scenarios of 129..256 entities run in chunks of steps; in every chunk a scenario whose
- * pedestrians have mostly ARRIVED (speed 0, heading 0, force 0 from then on: pedestrian/agent.py:64-68) is stepped by a
- * kernel that spends lanes only on the entities that still change (scenario_gym_amd/csrc/sgym_walk.hpp).  Results never
- * depend on it (SG_CROWD_WALK=0 switches it off).  out[8], summed since the last reset of the counters: [0..2] scenario-chunks
+/* With SG_CROWD_WALK=3 in the environment (OFF by default: measured no faster, HISTORY.md round 4) long rollouts of
+ * all-pedestrian scenarios of 129..256 entities run in chunks of steps; in every chunk a scenario whose pedestrians have
+ * mostly ARRIVED (speed 0, heading 0, force 0 from then on: pedestrian/agent.py:64-68) is stepped by a kernel that spends
+ * lanes only on the entities that still change (scenario_gym_amd/csrc/sgym_walk.hpp).  Results never depend on it.  out[8], summed since the last reset of the counters: [0..2] scenario-chunks
  * run by the full kernel / by the walker kernel with one / with two wavefronts, [4] walker workgroups that stopped early and
  * were finished by the full kernel, [7] chunks of the last call.  Test and diagnostics hook. */
 int sg_crowd_walk_stats(sg_handle *h, int32_t *out, int32_t reset);
