@@ -345,11 +345,20 @@ def scan_xosc(text: bytes):
     m = _re.match(rb"\s*<\?xml[^>]*encoding\s*=\s*[\"']([A-Za-z0-9._-]+)[\"']", text[:200])
     enc = m.group(1).decode("ascii") if m else "utf-8"
 
-    def st(x):
-        if x.len < 0:
-            return None
-        v = text[x.off:x.off + x.len].decode(enc)
-        return _xml_unescape(v) if "&" in v else v
+    if text.isascii():  # (the usual file: one decode, then plain slices -- byte offsets are character offsets)
+        whole = text.decode("ascii")
+
+        def st(x):
+            if x.len < 0:
+                return None
+            v = whole[x.off:x.off + x.len]
+            return _xml_unescape(v) if "&" in v else v
+    else:
+        def st(x):
+            if x.len < 0:
+                return None
+            v = text[x.off:x.off + x.len].decode(enc)
+            return _xml_unescape(v) if "&" in v else v
 
     return dict(
         dirs=[st(dirs[i]) for i in range(cnt.n_dirs)], road_file=st(cnt.road_file),
@@ -357,7 +366,8 @@ def scan_xosc(text: bytes):
                       inline_name=st(o.inline_name), inline_category=st(o.inline_category), bbox=tuple(o.bbox),
                       has_bbox=o.has_inline_bbox == 3) for o in (objs[i] for i in range(cnt.n_objects))],
         teleports=[(st(t.entity), np.array(t.knot)) for t in (tele[i] for i in range(cnt.n_teleports))],
-        trajectories=[(st(t.entity), verts[t.v0:t.v1].copy()) for t in (traj[i] for i in range(cnt.n_trajectories))],
+        # (views into this call's own vertex buffer: Trajectory / many_arrays normalise into arrays of their own)
+        trajectories=[(st(t.entity), verts[t.v0:t.v1]) for t in (traj[i] for i in range(cnt.n_trajectories))],
     )
 
 
