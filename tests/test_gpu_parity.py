@@ -905,12 +905,12 @@ def test_abi_rejects_bad_input(sga):
     from scenario_gym_amd.packing import pack_arrays
 
     with pytest.raises(RuntimeError, match="n_entities"):
-        sga.RolloutEngine(4, 513)
-    with pytest.raises(RuntimeError, match="256 entities"):   # what tiles of 8 wavefronts do not offer
-        sga.RolloutEngine(4, 300, terminal_conditions=["max_length", "ego_off_road"])
-    wide = sga.RolloutEngine(2, 300)
-    with pytest.raises(RuntimeError, match="256 entities"):
+        sga.RolloutEngine(4, 16385)
+    wide = sga.RolloutEngine(2, 600)    # beyond 512 entities: the multi-kernel step, and what it does not offer says so
+    with pytest.raises(RuntimeError, match="up to 512 entities"):
         wide.set_rss(True)
+    with pytest.raises(RuntimeError, match="up to 512 entities"):
+        wide.rss_update(reset=True)
     wide.close()
     with pytest.raises(RuntimeError, match="timestep"):
         sga.RolloutEngine(4, 4, timestep=0.0)
