@@ -367,11 +367,15 @@ extern "C" int sg_create(const sg_config *cfg, sg_handle **out)
     int G = 4;
     while (G < h->E && G < 64) G <<= 1;
     h->G = G;
-    // wavefronts per scenario.  8 (257..512 entities): replay entities, replay agents and in-kernel PID / vehicle controllers
-    // through rollout_kernel<64, 8, false, false>; no pedestrian agents, RSS callback or observation kernels at that width
-    // more than 512: no fused kernel -- the step runs as four kernels over as many workgroups as the scenario needs (sgym_wide.hpp)
+    // wavefronts per scenario.  8 (257..512 entities): the eight-wavefront instances of the general variants (plain, pedestrian,
+    // RSS, road); the table path, the crowd kernels and the riders' pre-pass stop at 256.
+    // More than 512: no fused kernel -- the step runs as four kernels over as many workgroups as the scenario needs (sgym_wide.hpp)
     h->WV = h->E <= 64 ? 1 : (h->E <= 128 ? 2 : (h->E <= 256 ? 4 : (h->E <= 512 ? 8 : (h->E + 63) / 64)));
     h->wide = h->WV > 8;
+    if (h->wide && h->R > 65535) { // (the scenario is the y coordinate of the wide kernels' grids)
+        delete h;
+        return fail(nullptr, SG_ERR_INVALID, "sg_create: more than 65535 scenarios of more than 512 entities in one handle (n_scenarios=%d)", cfg->n_scenarios);
+    }
     h->EP = G * h->WV;
     // SocialForceParameters defaults, pedestrian/social_force.py:16-30 (noise off)
     h->sf = sg_social_force{1.5, 1.0, 1.0, 0.0, 0.5, 1.0, std::cos(200.0 / 2 * M_PI / 180), 1.3, 0.0, 0.0, 2.0, 0.1};

@@ -2594,6 +2594,7 @@ def _add_riders(packed, rng, side, T, spec):
 def _random_crowds(n, seed=77):
     rng = np.random.default_rng(seed)
     rrng = np.random.default_rng([seed, 9])  # (its own stream: earlier configurations keep their draws)
+    brng = np.random.default_rng([seed, 10])
     out = []
     for k in range(n):
         E = int([20, 64, 100, 256, 40, 130][k % 6])
@@ -2601,18 +2602,20 @@ def _random_crowds(n, seed=77):
                         side=float(rng.choice([6.0, 12.0, 25.0])), roads=bool(rng.integers(0, 2)), seed=int(rng.integers(1, 1 << 30)),
                         dt=float(rng.choice([1 / 30, 0.1])), noise=str(rng.choice(["off", "off", "device", "stream"])),
                         radii=bool(rng.integers(0, 2)), late=bool(rng.integers(0, 3) == 0),
-                        riders=int(rrng.integers(0, 8)) if rrng.integers(0, 2) else 0))  # how many of _ALL_RIDERS ride along
+                        riders=int(rrng.integers(0, 8)) if rrng.integers(0, 2) else 0,  # how many of _ALL_RIDERS ride along
+                        walk=bool(brng.integers(0, 5) == 0)))                            # RandomWalk instead of SocialForce
     return out
 
 
 @pytest.mark.parametrize("cfg", _random_crowds(int(os.environ.get("SG_FUZZ_CROWDS", "8")), int(os.environ.get("SG_FUZZ_SEED", "77"))),
-                         ids=lambda c: f"E{c['E']}-s{c['side']:.0f}-{'roads' if c['roads'] else 'free'}-{c['noise']}")
+                         ids=lambda c: f"E{c['E']}-s{c['side']:.0f}-{'roads' if c['roads'] else 'free'}-{c['noise']}{'-walk' if c['walk'] else ''}")
 def test_randomized_crowds_match_oracle(sga, oracle, cfg):
     """Random social-force crowds (tile widths up to four wavefronts, sparse to packed), half of them on a road network with
     random convex buildings and pavements among the pedestrians: poses of every step, forces, collision rows and events
     bit-identical to the oracle (crowd kernel and the general pedestrian variant, balanced pair loops, boundary terms,
     density-adaptive broad phase); a quarter each with the counter-based noise generator and with a stream of variates,
-    half with per-pedestrian sensor radii, a third with pedestrians that join the scene late (the spawn rule)."""
+    half with per-pedestrian sensor radii, a third with pedestrians that join the scene late (the spawn rule), a fifth with
+    RandomWalk as the behaviour model (on road networks too: it ignores them, as the reference's does)."""
     import scenario_gym_amd._lib as L
     from scenario_gym_amd import synthetic
     from scenario_gym_amd.packing import unpack_scenario
@@ -2649,6 +2652,10 @@ def test_randomized_crowds_match_oracle(sga, oracle, cfg):
             nets.append(dict(ring_off=np.arange(len(rings) + 1), vert_off=np.concatenate([[0], np.cumsum([len(r) for r in rings])]),
                              verts=np.concatenate(rings), layers=np.array(layers)))
         net_of = rng.integers(-1, 2, R).astype(np.int32)
+    behaviour, sf = "social_force", None
+    if cfg["walk"]:  # a fifth of the configurations: every pedestrian follows RandomWalk (pedestrian/random_walk.py), with a bias
+        behaviour, sf = "random_walk", oracle.social_force_params(bias_lon=0.1, bias_lat=-0.03)
+        noise_kw = dict(noise_kw, behaviour="random_walk", bias_lon=0.1, bias_lat=-0.03)
     eng = sga.RolloutEngine(R, E, timestep=dt, record_capacity=steps + 1, event_capacity=512, social_force=noise_kw or None)
     eng.upload(packed)
     if nets:
@@ -2663,7 +2670,8 @@ def test_randomized_crowds_match_oracle(sga, oracle, cfg):
         road = nets[net_of[r]] if (nets and net_of[r] >= 0) else None
         o = oracle.rollout(s["knot_off"], s["knots"], s["bbox"], s["etype"], s["kind"], s["ego"], s["t0"], s["length"], dt,
                            ctrl=s["ctrl"], route_off=s["route_off"], routes=s["routes"], max_steps=steps, event_cap=512, road=road,
-                           noise=noise_o[r], actions=np.zeros((steps, 2)) if (s["kind"] == L.KIND_AGENT_VEHICLE).any() else None)
+                           noise=noise_o[r], actions=np.zeros((steps, 2)) if (s["kind"] == L.KIND_AGENT_VEHICLE).any() else None,
+                           sf=sf, behaviour=behaviour)
         n = o["n_steps"]
         assert rows["n_steps"][r] == n, r
         assert bits_equal(poses[: n + 1, r], o["poses"]), (r, "poses")
