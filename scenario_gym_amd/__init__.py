@@ -7,6 +7,7 @@ _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 from .agent import (  # noqa: F401
     Action,
     Agent,
+    CombinedSensor,
     Controller,
     EgoLocalizationSensor,
     ExternalVehicleAgent,
@@ -29,6 +30,9 @@ from .agent import (  # noqa: F401
     VehicleAction,
 )
 from .engine import PackedScenarios, RolloutEngine  # noqa: F401
+from .observation import (  # noqa: F401
+    CollisionObservation, FutureCollisionObservation, MapObservation, Observation, SingleEntityObservation, combine_observations,
+)
 from .entity import BoundingBox, CatalogEntry, Entity, MiscObject, Pedestrian, Vehicle  # noqa: F401
 from .gym import BatchedScenarioGym, ScenarioGym  # noqa: F401
 from .metrics import (  # noqa: F401

@@ -14,6 +14,8 @@ import numpy as np
 
 from . import _lib as L
 from .entity import Entity
+from .observation import (CollisionObservation, FutureCollisionObservation, MapObservation, SingleEntityObservation,
+                          combine_observations)
 from .scenario import Scenario
 
 
@@ -64,11 +66,30 @@ class Sensor:
         return None
 
 
+class CombinedSensor(Sensor):
+    """sensor/common.py:18-36: several sensors of one entity as one; the observation class is made at reset from the
+    classes of the sensors' first observations (combine_observations)."""
+
+    def __init__(self, entity: Entity, *sensors: Sensor):
+        assert all(s.entity == entity for s in sensors)
+        super().__init__(entity)
+        self.sensors = sensors
+        self.obs_class = None
+
+    def _reset(self, state):
+        first = [s.reset(state) for s in self.sensors]
+        self.obs_class = combine_observations(*(type(o) for o in first))
+        return self.obs_class.from_obs(*first)
+
+    def _step(self, state):
+        return self.obs_class.from_obs(*(s.step(state) for s in self.sensors))
+
+
 class EgoLocalizationSensor(Sensor):
     """sensor/common.py:39-50: the observation is State.get_entity_data(entity)."""
 
     def _step(self, state):
-        return state.get_entity_data(self.entity)
+        return SingleEntityObservation(self.entity, *state.get_entity_data(self.entity))
 
 
 class FutureCollisionDetector(Sensor):
@@ -84,7 +105,7 @@ class FutureCollisionDetector(Sensor):
     def _step(self, state):
         if state.scenario.ego is not self.entity:
             raise NotImplementedError("the device look-ahead is evaluated for the ego of each scenario")
-        return tuple(state.get_entity_data(self.entity)) + (state.future_collision(self.horizon),)
+        return FutureCollisionObservation(self.entity, *state.get_entity_data(self.entity), state.future_collision(self.horizon))
 
 
 class RasterizedMapSensor(Sensor):
@@ -117,14 +138,14 @@ class RasterizedMapSensor(Sensor):
         if state.scenario.ego is not self.entity:
             raise NotImplementedError("the device raster is evaluated for the ego of each scenario")
         m = state.raster_map(self.layers, self.width, self.height, self.nw, self.nh)
-        return tuple(state.get_entity_data(self.entity)) + (m if self.channels_first else m.transpose(1, 2, 0),)
+        return MapObservation(self.entity, *state.get_entity_data(self.entity), m if self.channels_first else m.transpose(1, 2, 0))
 
 
 class GlobalCollisionDetector(Sensor):
     """sensor/common.py:115-129: the localisation observation plus State.collisions() (the device's adjacency rows)."""
 
     def _step(self, state):
-        return tuple(state.get_entity_data(self.entity)) + (state.collisions(),)
+        return CollisionObservation(self.entity, *state.get_entity_data(self.entity), state.collisions())
 
 
 class Controller:
