@@ -40,7 +40,7 @@ from .metrics import (  # noqa: F401
 )
 from .actions import FixedTAction, ScenarioAction, UpdateStateVariableAction, UserDefinedAction  # noqa: F401
 from .scenario import Scenario  # noqa: F401
-from .state import State  # noqa: F401
+from .state import TERMINAL_CONDITIONS, State  # noqa: F401
 from .trajectory import Trajectory  # noqa: F401
 from .road_network import RoadNetwork  # noqa: F401
 from .route import RouteFinder  # noqa: F401

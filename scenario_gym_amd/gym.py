@@ -300,6 +300,14 @@ class BatchedScenarioGym:
             self._cache = self.engine.state()
         return self._cache
 
+    def _terminal_flags(self):
+        """SG_TERM_* bits of every scenario's current state (all four conditions), cached per state."""
+        key = ("term",)
+        if self._fut is None or key not in self._fut:
+            self._fut = dict(self._fut or {})
+            self._fut[key] = self.engine.terminal_flags()
+        return self._fut[key]
+
     def _future(self, horizon: float, n_samples: int):
         key = (horizon, n_samples)
         if self._fut is None or key not in self._fut:

@@ -110,6 +110,16 @@ class State:
     def is_done(self) -> bool:
         return bool(self._s()["done"][self._i])
 
+    def terminal_condition(self, name: str) -> bool:
+        """TERMINAL_CONDITIONS[name](state) of the reference (state.py:397-408) on the current state, whatever the gym's own
+        terminal_conditions are: all four are evaluated on the device for every scenario (sg_terminal_flags; ego_off_road
+        against the scenario's road network -- none: off the road)."""
+        from .engine import TERMINAL_BITS
+
+        if name == "ego_off_road":
+            self._gym._set_road_networks()
+        return bool(self._gym._terminal_flags()[self._i] & TERMINAL_BITS[name])
+
     @property
     def poses(self) -> Dict[Entity, np.ndarray]:
         return self._dict(self._s()["poses"])
@@ -232,3 +242,9 @@ class State:
             if (cr < 0).all():  # clockwise ring: strictly inside
                 out.append(e)
         return out
+
+
+# state.py:397-408: name -> predicate over a State, as the reference's callers index it (TERMINAL_CONDITIONS["collision"](state));
+# ScenarioGym(terminal_conditions=[...]) takes the names (evaluated inside the rollout kernels) or any callable (host, per step).
+TERMINAL_CONDITIONS = {name: (lambda s, _n=name: s.terminal_condition(_n))
+                       for name in ("max_length", "collision", "ego_collision", "ego_off_road")}

@@ -366,6 +366,31 @@ def test_random_walk_agents_through_the_gym():
     gym.close()
 
 
+def test_terminal_conditions_mapping():
+    """state.py:397-408: TERMINAL_CONDITIONS[name](state) -- the four predicates a caller (e.g. the RL reward of
+    integrations/openaigym.py:300-310) evaluates on a state, whatever conditions the gym itself stops on: on one of the
+    reference's scenarios, step by step, they equal the reference's own expressions over the State (max_length at the end;
+    the Scenario object carries no road network here: the ego counts as off the road)."""
+    import scenario_gym_amd as sga
+
+    g = load_golden("scenarios")
+    sc = _scenario(g, "a5e43fe4/scenario")
+    gym = sga.ScenarioGym(timestep=0.1, terminal_conditions=["max_length"])
+    gym.set_scenario(sc)
+    assert set(sga.TERMINAL_CONDITIONS) == {"max_length", "collision", "ego_collision", "ego_off_road"}
+    seen_done = False
+    while not gym.state.is_done:
+        s = gym.state
+        assert sga.TERMINAL_CONDITIONS["max_length"](s) == (s.t + s.dt > s.scenario.length)
+        assert sga.TERMINAL_CONDITIONS["collision"](s) == any(len(v) > 0 for v in s.collisions().values())
+        assert sga.TERMINAL_CONDITIONS["ego_collision"](s) == (len(s.collisions()[s.scenario.entities[0]]) > 0)
+        gym.step()
+        seen_done = True
+    assert seen_done and sga.TERMINAL_CONDITIONS["max_length"](gym.state)
+    assert sga.TERMINAL_CONDITIONS["ego_off_road"](gym.state)  # (no road network attached to this Scenario object: off the road)
+    gym.close()
+
+
 def test_combined_sensor():
     """tests/test_sensor.py:13-36: CombinedSensor over the localisation, future-collision and collision sensors of the ego
     (the keyboard sensor needs the viewer: out of scope) -- no observation class before the reset, one afterwards, and an
