@@ -1414,6 +1414,7 @@ def test_lattice_scenes_touching_boxes_every_step(sga, oracle):
 def _random_configs(n, seed=2024):
     rng = np.random.default_rng(seed)
     zrng = np.random.default_rng([seed, 3])  # (its own stream: the configurations of earlier rounds keep their draws)
+    wrng = np.random.default_rng([seed, 4])
     widths = [1, 3, 4, 5, 8, 9, 16, 17, 31, 33, 63, 64, 65, 100, 128, 129, 200, 256, 257, 400, 512]
     out = []
     for k in range(n):
@@ -1427,6 +1428,9 @@ def _random_configs(n, seed=2024):
             extent=float(rng.choice([8.0, 25.0, 60.0])), knots=int(rng.choice([6, 9, 40])), seed=int(rng.integers(1, 1 << 30)),
             chunk=int(rng.choice([5, 16, 1024])),
             zpr=bool(zrng.integers(0, 2))))  # knots with z / pitch / roll: the general table kernel instead of the planar one
+        if wrng.integers(0, 12) == 0:        # one in twelve: more than 512 entities (the multi-kernel step, sgym_wide.hpp)
+            out[-1].update(E=int(wrng.choice([513, 600, 777, 1100])), R=int(wrng.integers(1, 4)), steps=min(out[-1]["steps"], 45),
+                           extent=float(wrng.choice([25.0, 60.0, 120.0])))
     return out
 
 
@@ -2604,6 +2608,10 @@ def _random_crowds(n, seed=77):
                         radii=bool(rng.integers(0, 2)), late=bool(rng.integers(0, 3) == 0),
                         riders=int(rrng.integers(0, 8)) if rrng.integers(0, 2) else 0,  # how many of _ALL_RIDERS ride along
                         walk=bool(brng.integers(0, 5) == 0)))                            # RandomWalk instead of SocialForce
+        if brng.integers(0, 15) == 0:  # one in fifteen: a crowd of more than 512 (the multi-kernel step: no road networks, no
+            c = out[-1]                # noise stream there; riders of every kind stay)
+            c.update(E=int(brng.choice([520, 640])), R=int(brng.integers(1, 3)), steps=min(c["steps"], 40), roads=False,
+                     side=float(brng.choice([25.0, 40.0])), noise="device" if c["noise"] == "stream" else c["noise"])
     return out
 
 
@@ -2696,8 +2704,8 @@ def test_randomized_rss_matches_oracle(sga, oracle, cfg):
 
     kind = dict(replay=L.KIND_AGENT_REPLAY, pid=L.KIND_AGENT_PID, vehicle=L.KIND_AGENT_VEHICLE)[cfg["ego"]]
     R, E, steps, dt = cfg["R"], cfg["E"], cfg["steps"], cfg["dt"]
-    if E > 256:  # (the callback is offered up to 256 entities per scenario: sg_set_rss refuses wider handles)
-        E = 256
+    if E > 512:  # (the callback is offered up to 512 entities per scenario: sg_set_rss refuses the multi-kernel handles)
+        E = 512
     packed = synthetic.make_batch(R, E, n_steps=steps, timestep=dt, n_knots=cfg["knots"], ego_kind=kind,
                                   static_frac=cfg["static"], vanish_frac=cfg["vanish"], extent=cfg["extent"], seed=cfg["seed"])
     force = cfg["ego"] == "vehicle"
