@@ -631,7 +631,8 @@ static int launch_wide(sg_handle *h, int n_steps, int do_reset, int force, const
     if (!h->wide_args.scr) {
         auto &A = h->wide_allocs;
         if ((rc = dev_alloc(h, A, &h->wide_args.scr, h->NE * sg::WS_W)) || (rc = dev_alloc(h, A, &h->wide_args.cor, h->NE * 8)) ||
-            (rc = dev_alloc(h, A, &h->wide_args.circ, h->NE * 4)) || (rc = dev_alloc(h, A, &h->wide_args.last_row, (size_t)R * h->WV)))
+            (rc = dev_alloc(h, A, &h->wide_args.circ, h->NE * 4)) || (rc = dev_alloc(h, A, &h->wide_args.last_row, (size_t)R * h->WV)) ||
+            (rc = dev_alloc(h, A, &h->wide_args.last_same, h->NE)) || (rc = dev_alloc(h, A, &h->wide_args.dup, (size_t)R)))
             return rc;
     }
     const dim3 ge((unsigned)((EP + 255) / 256), (unsigned)R), gs((unsigned)R);

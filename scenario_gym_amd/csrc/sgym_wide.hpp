@@ -1,4 +1,4 @@
-// sgym_wide.hpp -- scenarios of MORE THAN 512 entities: the step as four kernels over any number of workgroups.
+// sgym_wide.hpp -- scenarios of MORE THAN 512 entities: the step as five kernels over any number of workgroups.
 //
 // The reference has no entity limit (State.collisions is a Python loop over an STRtree, state/utils.py:10-49); the fused
 // rollout kernels (sgym_device.hpp) keep one scenario inside one workgroup and stop at 512 entities.  Beyond that a scenario
@@ -10,10 +10,12 @@
 //                        bounding circle for the collision pass
 //   wide_collide_kernel  State.collisions: every present entity against every other one of its scenario (circles staged
 //                        through LDS, exact fp64 separating-axis test on the pairs whose circles overlap; equal geometries
-//                        never list each other and map to the last owner, utils.py:59, state/utils.py:32-40)
+//                        never list each other, utils.py:59)
+//   wide_owner_kernel    ... and stand for their last owner in everybody else's row (state/utils.py:32-40): rare, a no-op
+//                        for scenarios without twins
 //   wide_finish_kernel   one workgroup per scenario: the clock, terminal conditions, ego metrics, CollisionMetric events
 // in that order, once per step.  Same arithmetic as the fused kernels and the oracle (plain IEEE operations: ExactArith), so
-// the same bits; ~4 launches per step instead of thousands of steps per launch -- the price of not having a ceiling.
+// the same bits; 5 launches per step instead of thousands of steps per launch -- the price of not having a ceiling.
 // Not at this width: caller-run agents (SG_KIND_AGENT_EXTERNAL), road networks, the RSS callback, the observation kernels,
 // the noise stream mode (the counter-based generator works).
 #pragma once
@@ -26,6 +28,8 @@ struct WideArgs {
     double *cor;          // [NE][8] fp64 corners of the committed pose
     double *circ;         // [NE][4] bounding circle of the box: cx, cy, radius (NaN cx: absent)
     uint64_t *last_row;   // [R][WV] CollisionMetric.last_timestep
+    int32_t *last_same;   // [NE] the LAST entity of the scenario whose box is bit-identical to this one's (itself: nobody's is)
+    uint32_t *dup;        // [R] != 0: some entity of the scenario has a twin this step (wide_owner_kernel has work)
     const double *actions; // [R][2] of THIS step or nullptr
     int mode;             // 0 step, 1 reset (State.reset for every scenario), 2 reset of the scenarios in p.reset_mask
     int force;
@@ -229,6 +233,7 @@ static __global__ __launch_bounds__(256) void wide_commit_kernel(Params p, doubl
 {
     const int r = blockIdx.y, e = blockIdx.x * 256 + threadIdx.x;
     if (e >= p.EP) return;
+    if (e == 0) wa.dup[r] = 0; // (wide_collide_kernel, the next launch, raises it again when it meets twins)
     const WideEnt w(p, r, e);
     double *circ = wa.circ + (size_t)w.g * 4, *cor = wa.cor + (size_t)w.g * 8;
     const bool runs = wide_runs(p, wa, r);
@@ -315,9 +320,13 @@ __device__ __forceinline__ bool wide_same(const double *a, const double *b)
 }
 
 // ---- State.collisions(): every present entity against every other one of its scenario ---------------------------------------
+// The row holds the entities whose boxes MEET this one's (bit j = entity j).  Bit-identical boxes never list each other
+// (utils.py:59) and, seen from a third entity, stand for the last of their owners (the reference keys a dict by geometry,
+// state/utils.py:32-40): the twins are noted here (last_same, dup) and wide_owner_kernel moves the bits -- a scan for the
+// last owner inside this loop cost a thousand dependent global loads per hit (1 ms per step on 1,024 entities).
 static __global__ __launch_bounds__(256) void wide_collide_kernel(Params p, WideArgs wa)
 {
-    __shared__ double s_c[256][3];
+    __shared__ double s_c[256][4];
     const int r = blockIdx.y, tid = threadIdx.x, e = blockIdx.x * 256 + tid;
     const int W = p.FROWS - SG_F_COLL;
     const bool in = e < p.E;
@@ -327,6 +336,7 @@ static __global__ __launch_bounds__(256) void wide_collide_kernel(Params p, Wide
     const bool present = cx == cx;
     if (in)
         for (int q = 0; q < W; ++q) stf(w.dy, SG_F_COLL + q, (uint64_t)0);
+    int last = e;
     for (int c0 = 0; c0 < p.EP; c0 += 256) {
         __syncthreads();
         {
@@ -337,21 +347,47 @@ static __global__ __launch_bounds__(256) void wide_collide_kernel(Params p, Wide
         __syncthreads();
         if (!present) continue;
         const int n = min(256, p.E - c0);
+        uint64_t word = 0; // the row word of the 64 slots being walked (4 words per tile of 256)
         for (int q = 0; q < n; ++q) {
             const int j = c0 + q;
             const double dx = s_c[q][0] - cx, dy = s_c[q][1] - cy, rr = s_c[q][2] + rad;
-            if (j == e || !(dx * dx + dy * dy <= rr * rr)) continue; // (an absent slot: NaN, the compare fails)
-            const double *B = wa.cor + ((size_t)r * p.EP + j) * 8;
-            if (wide_same(A, B)) continue;                 // g != g_prime: never listed (utils.py:59)
-            if (!sg_quads_intersect(A, B)) continue;
-            int o = j;                                     // geometry -> LAST entity owning it (state/utils.py:32-40)
-            for (int k = j + 1; k < p.E; ++k) {
-                const double *ck = wa.circ + ((size_t)r * p.EP + k) * 4;
-                if (ck[0] == s_c[q][0] && ck[1] == s_c[q][1] && wide_same(B, wa.cor + ((size_t)r * p.EP + k) * 8)) o = k;
+            if (j != e && dx * dx + dy * dy <= rr * rr) { // (an absent slot: NaN, the compare fails)
+                const double *B = wa.cor + ((size_t)r * p.EP + j) * 8;
+                if (wide_same(A, B)) last = max(last, j);  // g == g_prime: never listed (utils.py:59)
+                else if (sg_quads_intersect(A, B)) word |= 1ull << (q & 63);
             }
-            const uint64_t old = fld<uint64_t>(w.dy, SG_F_COLL + (o >> 6));
-            stf(w.dy, SG_F_COLL + (o >> 6), old | (1ull << (o & 63)));
+            if ((q & 63) == 63 || q == n - 1) {
+                if (word) stf(w.dy, SG_F_COLL + ((c0 + q) >> 6), word);
+                word = 0;
+            }
         }
+    }
+    if (in) {
+        wa.last_same[w.g] = last;
+        if (last != e) atomicOr(&wa.dup[r], 1u);
+    }
+}
+
+// ... and the twins' bits move to the last owner of the geometry (rare: only scenarios that have twins this step do anything)
+static __global__ __launch_bounds__(256) void wide_owner_kernel(Params p, WideArgs wa)
+{
+    const int r = blockIdx.y, e = blockIdx.x * 256 + threadIdx.x;
+    if (!wa.dup[r] || e >= p.E) return;
+    const int W = p.FROWS - SG_F_COLL;
+    const WideEnt w(p, r, e);
+    const int32_t *ls = wa.last_same + (size_t)r * p.EP;
+    // in place, words in increasing order: a bit only moves FORWARD (to the last owner, whose own entry is itself), and an entity
+    // never lists its own twins, so a moved bit is never moved again and never lands on a twin of e
+    for (int q = 0; q < W; ++q) {
+        uint64_t m = fld<uint64_t>(w.dy, SG_F_COLL + q);
+        for (uint64_t t = m; t; t &= t - 1) {
+            const int j = q * 64 + __builtin_ctzll(t), o = ls[j];
+            if (o == j) continue;
+            m &= ~(1ull << (j & 63));
+            if ((o >> 6) == q) m |= 1ull << (o & 63);
+            else stf(w.dy, SG_F_COLL + (o >> 6), fld<uint64_t>(w.dy, SG_F_COLL + (o >> 6)) | (1ull << (o & 63)));
+        }
+        stf(w.dy, SG_F_COLL + q, m);
     }
 }
 

@@ -287,6 +287,59 @@ def test_identical_boxes_alias_rule(sga, oracle):
     assert np.array_equal(st["coll"][0], o["coll"][-1, :, 0])
 
 
+@pytest.mark.parametrize("E", [300, 700])
+def test_identical_boxes_in_wide_scenarios(sga, oracle, E):
+    """The alias rule (state/utils.py:32-40, utils.py:59) in scenarios of several row words and beyond 512 entities, where the
+    collision rows are built by wide_collide_kernel and the twins' bits are moved by wide_owner_kernel: groups of two to four
+    entities with bit-identical trajectories and boxes -- far apart in the entity order, across word and workgroup
+    boundaries -- never list each other, everybody else lists the LAST of a group; rows of every step's final state,
+    events of the ego (which drives through a group) and their order equal the oracle's."""
+    import scenario_gym_amd._lib as L
+    from scenario_gym_amd import synthetic
+    from scenario_gym_amd.packing import unpack_scenario
+
+    R, steps = 3, 50
+    packed = synthetic.make_batch(R, E, n_steps=steps, ego_kind=L.KIND_AGENT_REPLAY, static_frac=0.2, vanish_frac=0.1, extent=45.0, n_knots=8)
+    rng = np.random.default_rng(E)
+    off = packed.knot_off
+    rows = [packed.knots[off[i]:off[i + 1]].copy() for i in range(R * E)]
+    n_groups = 0
+    for r in range(R):
+        for _ in range(12):  # copy entity a's knots and box onto 1..3 others of the same scenario
+            a = int(rng.integers(1, E))
+            for b in rng.choice(np.arange(1, E), int(rng.integers(1, 4)), replace=False):
+                rows[r * E + int(b)] = rows[r * E + a].copy()
+                packed.bbox[r * E + int(b)] = packed.bbox[r * E + a]
+            n_groups += 1
+        # ... and one group sits on the ego's path: the ego meets twins
+        ego = rows[r * E]
+        mid = ego[len(ego) // 2].copy()
+        for b in (E // 3, E - 2):
+            rows[r * E + b] = mid[None, :].copy()
+            packed.bbox[r * E + b] = packed.bbox[r * E + E // 3]
+    packed.knots = np.concatenate(rows)
+    packed.knot_off = np.concatenate([[0], np.cumsum([len(x) for x in rows])]).astype(np.int64)
+    packed = packed.validate()
+    eng = sga.RolloutEngine(R, E, event_capacity=256)
+    eng.upload(packed)
+    eng.rollout(steps)
+    st = eng.state()
+    mrows, events = eng.metrics()
+    eng.close()
+    met = 0
+    for r in range(R):
+        s = unpack_scenario(packed, r)
+        o = oracle.rollout(s["knot_off"], s["knots"], s["bbox"], s["etype"], s["kind"], s["ego"], s["t0"], s["length"], 1 / 30,
+                           ctrl=s["ctrl"], max_steps=steps, event_cap=256)
+        assert mrows["n_steps"][r] == o["n_steps"]
+        assert np.array_equal(_dense_words(st["coll"][r], E), oracle.coll_to_dense(o["coll"], E)[-1]), r
+        ev = events[events["scenario"] == r]
+        assert mrows["n_collisions"][r] == o["n_events"] and np.array_equal(ev["t"], o["ev_t"]) and np.array_equal(ev["other"], o["ev_other"]), r
+        met += int((ev["other"] == E - 2).sum())
+        assert not (ev["other"] == E // 3).any()  # the earlier twin is never the one that is listed
+    assert met >= R and n_groups == 12 * R
+
+
 def test_full_size_invariants(sga, oracle):
     """BASELINE config 3 width (4096 x 64, PID ego) for 300 steps: size-independent properties +
     oracle spot checks on scattered scenarios."""
