@@ -326,7 +326,7 @@ __device__ __forceinline__ bool wide_same(const double *a, const double *b)
 // last owner inside this loop cost a thousand dependent global loads per hit (1 ms per step on 1,024 entities).
 static __global__ __launch_bounds__(256) void wide_collide_kernel(Params p, WideArgs wa)
 {
-    __shared__ double s_c[256][4];
+    __shared__ double s_x[256], s_y[256], s_r[256];
     const int r = blockIdx.y, tid = threadIdx.x, e = blockIdx.x * 256 + tid;
     const int W = p.FROWS - SG_F_COLL;
     const bool in = e < p.E;
@@ -337,30 +337,48 @@ static __global__ __launch_bounds__(256) void wide_collide_kernel(Params p, Wide
     if (in)
         for (int q = 0; q < W; ++q) stf(w.dy, SG_F_COLL + q, (uint64_t)0);
     int last = e;
+    // The circle scan and the exact tests are two loops: a candidate is rare per lane but not per wavefront -- tested where it
+    // is found, every one of them would send all 64 lanes through the corner loads and the separating-axis test (64 x 0.5
+    // candidates per 1,024 slots).  The lane notes its candidates of the tile (8 slots; a ninth is tested on the spot) and
+    // walks its own short list afterwards.  The scan reads four slots' circles at a time (wave-uniform LDS broadcasts, all
+    // issued before the first compare: one wait per four slots instead of one per slot).
+    __shared__ unsigned short s_cand[8][256];
+    auto exact = [&](int q, int c0, uint64_t (&words)[4]) {
+        const int j = c0 + q;
+        const double *B = wa.cor + ((size_t)r * p.EP + j) * 8;
+        if (wide_same(A, B)) last = max(last, j);  // g == g_prime: never listed (utils.py:59)
+        else if (sg_quads_intersect(A, B)) words[q >> 6] |= 1ull << (q & 63);
+    };
     for (int c0 = 0; c0 < p.EP; c0 += 256) {
         __syncthreads();
         {
             const int j = c0 + tid;
             const double *cj = wa.circ + ((size_t)r * p.EP + min(j, p.EP - 1)) * 4;
-            s_c[tid][0] = j < p.E ? cj[0] : __builtin_nan(""); s_c[tid][1] = cj[1]; s_c[tid][2] = cj[2];
+            s_x[tid] = j < p.E ? cj[0] : __builtin_nan(""); s_y[tid] = cj[1]; s_r[tid] = cj[2]; // (NaN: absent, or beyond E)
         }
         __syncthreads();
         if (!present) continue;
-        const int n = min(256, p.E - c0);
-        uint64_t word = 0; // the row word of the 64 slots being walked (4 words per tile of 256)
-        for (int q = 0; q < n; ++q) {
-            const int j = c0 + q;
-            const double dx = s_c[q][0] - cx, dy = s_c[q][1] - cy, rr = s_c[q][2] + rad;
-            if (j != e && dx * dx + dy * dy <= rr * rr) { // (an absent slot: NaN, the compare fails)
-                const double *B = wa.cor + ((size_t)r * p.EP + j) * 8;
-                if (wide_same(A, B)) last = max(last, j);  // g == g_prime: never listed (utils.py:59)
-                else if (sg_quads_intersect(A, B)) word |= 1ull << (q & 63);
-            }
-            if ((q & 63) == 63 || q == n - 1) {
-                if (word) stf(w.dy, SG_F_COLL + ((c0 + q) >> 6), word);
-                word = 0;
+        uint64_t words[4] = {0, 0, 0, 0}; // the row words of this tile's 256 slots
+        int nc = 0;
+        const int self = e - c0;          // this lane's own slot, if it is inside the tile
+#pragma unroll 1
+        for (int q0 = 0; q0 < 256; q0 += 4) {
+            double X[4], Y[4], RR[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { X[u] = s_x[q0 + u]; Y[u] = s_y[q0 + u]; RR[u] = s_r[q0 + u]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const double dx = X[u] - cx, dy = Y[u] - cy, rr = RR[u] + rad;
+                if (q0 + u != self && dx * dx + dy * dy <= rr * rr) { // (an absent slot: NaN, the compare fails)
+                    if (nc < 8) s_cand[nc++][tid] = (unsigned short)(q0 + u);
+                    else exact(q0 + u, c0, words);
+                }
             }
         }
+        for (int k = 0; k < nc; ++k) exact((int)s_cand[k][tid], c0, words);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (words[k]) stf(w.dy, SG_F_COLL + (c0 >> 6) + k, words[k]);
     }
     if (in) {
         wa.last_same[w.g] = last;
