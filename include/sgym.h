@@ -105,7 +105,7 @@ typedef struct {
     int32_t n_scenarios;     /* R */
     int32_t n_entities;      /* E, entity slots per scenario (the reference has no ceiling, state/utils.py:10-49; here <= 16384).
                                 Up to 512: one workgroup per scenario, every kind, callback and observation call.  Beyond: the
-                                step runs as five kernels over as many workgroups as the scenario needs (every entity kind incl.
+                                step runs as four kernels over as many workgroups as the scenario needs (every entity kind incl.
                                 pedestrian agents with the counter-based noise) -- without caller-run agents, the RSS callback,
                                 road networks, observation calls, sg_tick and the noise stream (those calls fail with
                                 SG_ERR_INVALID on such a handle) */

@@ -1,4 +1,4 @@
-// k_wide.hip -- scenarios of more than 512 entities: the step as five kernels over any number of workgroups (sgym_wide.hpp).
+// k_wide.hip -- scenarios of more than 512 entities: the step as four kernels over any number of workgroups (sgym_wide.hpp).
 #define SG_UNIT_WIDE
 #include "sgym_launch.hpp"
 
@@ -8,7 +8,6 @@ void wide_step(dim3 ge, dim3 gs, hipStream_t s, const sg::Params &p, double time
     sg::wide_move_kernel<<<ge, dim3(256), 0, s>>>(p, timestep, wa);
     sg::wide_commit_kernel<<<ge, dim3(256), 0, s>>>(p, timestep, wa);
     sg::wide_collide_kernel<<<ge, dim3(256), 0, s>>>(p, wa);
-    sg::wide_owner_kernel<<<ge, dim3(256), 0, s>>>(p, wa);
     sg::wide_finish_kernel<<<gs, dim3(256), 0, s>>>(p, timestep, wa);
 }
 } // namespace sgl

@@ -1,4 +1,4 @@
-// sgym_wide.hpp -- scenarios of MORE THAN 512 entities: the step as five kernels over any number of workgroups.
+// sgym_wide.hpp -- scenarios of MORE THAN 512 entities: the step as four kernels over any number of workgroups.
 //
 // The reference has no entity limit (State.collisions is a Python loop over an STRtree, state/utils.py:10-49); the fused
 // rollout kernels (sgym_device.hpp) keep one scenario inside one workgroup and stop at 512 entities.  Beyond that a scenario
@@ -11,11 +11,11 @@
 //   wide_collide_kernel  State.collisions: every present entity against every other one of its scenario (circles staged
 //                        through LDS, exact fp64 separating-axis test on the pairs whose circles overlap; equal geometries
 //                        never list each other, utils.py:59)
-//   wide_owner_kernel    ... and stand for their last owner in everybody else's row (state/utils.py:32-40): rare, a no-op
-//                        for scenarios without twins
+//                        ... and stand for their last owner in everybody else's row (state/utils.py:32-40): noted here, moved
+//                        by the first part of wide_finish_kernel (rare)
 //   wide_finish_kernel   one workgroup per scenario: the clock, terminal conditions, ego metrics, CollisionMetric events
 // in that order, once per step.  Same arithmetic as the fused kernels and the oracle (plain IEEE operations: ExactArith), so
-// the same bits; 5 launches per step instead of thousands of steps per launch -- the price of not having a ceiling.
+// the same bits; 4 launches per step instead of thousands of steps per launch -- the price of not having a ceiling.
 // Not at this width: caller-run agents (SG_KIND_AGENT_EXTERNAL), road networks, the RSS callback, the observation kernels,
 // the noise stream mode (the counter-based generator works).
 #pragma once
@@ -29,7 +29,8 @@ struct WideArgs {
     double *circ;         // [NE][4] bounding circle of the box: cx, cy, radius (NaN cx: absent)
     uint64_t *last_row;   // [R][WV] CollisionMetric.last_timestep
     int32_t *last_same;   // [NE] the LAST entity of the scenario whose box is bit-identical to this one's (itself: nobody's is)
-    uint32_t *dup;        // [R] != 0: some entity of the scenario has a twin this step (wide_owner_kernel has work)
+    uint32_t *dup;        // [R] bit 0: some entity of the scenario has a twin this step (wide_owner_row has work); bit 1: some
+                          // entity's collision row is not empty; bit 2: entity 0's is not (the terminal conditions of wide_finish_kernel)
     const double *actions; // [R][2] of THIS step or nullptr
     int mode;             // 0 step, 1 reset (State.reset for every scenario), 2 reset of the scenarios in p.reset_mask
     int force;
@@ -322,11 +323,13 @@ __device__ __forceinline__ bool wide_same(const double *a, const double *b)
 // ---- State.collisions(): every present entity against every other one of its scenario ---------------------------------------
 // The row holds the entities whose boxes MEET this one's (bit j = entity j).  Bit-identical boxes never list each other
 // (utils.py:59) and, seen from a third entity, stand for the last of their owners (the reference keys a dict by geometry,
-// state/utils.py:32-40): the twins are noted here (last_same, dup) and wide_owner_kernel moves the bits -- a scan for the
+// state/utils.py:32-40): the twins are noted here (last_same, dup) and wide_finish_kernel moves the bits -- a scan for the
 // last owner inside this loop cost a thousand dependent global loads per hit (1 ms per step on 1,024 entities).
 static __global__ __launch_bounds__(256) void wide_collide_kernel(Params p, WideArgs wa)
 {
-    __shared__ double s_x[256], s_y[256], s_r[256];
+    __shared__ alignas(16) float s_fx[256], s_fy[256]; // fp32 centres of the tile's slots
+    __shared__ unsigned int s_rmax;                     // bits of the tile's largest fp32 radius (radii are >= 0: ordered as uints)
+    __shared__ uint64_t s_pres[4];                      // presence bits of the tile's slots
     const int r = blockIdx.y, tid = threadIdx.x, e = blockIdx.x * 256 + tid;
     const int W = p.FROWS - SG_F_COLL;
     const bool in = e < p.E;
@@ -337,60 +340,88 @@ static __global__ __launch_bounds__(256) void wide_collide_kernel(Params p, Wide
     if (in)
         for (int q = 0; q < W; ++q) stf(w.dy, SG_F_COLL + q, (uint64_t)0);
     int last = e;
-    // The circle scan and the exact tests are two loops: a candidate is rare per lane but not per wavefront -- tested where it
-    // is found, every one of them would send all 64 lanes through the corner loads and the separating-axis test (64 x 0.5
-    // candidates per 1,024 slots).  The lane notes its candidates of the tile (8 slots; a ninth is tested on the spot) and
-    // walks its own short list afterwards.  The scan reads four slots' circles at a time (wave-uniform LDS broadcasts, all
-    // issued before the first compare: one wait per four slots instead of one per slot).
-    __shared__ unsigned short s_cand[8][256];
-    auto exact = [&](int q, int c0, uint64_t (&words)[4]) {
-        const int j = c0 + q;
-        const double *B = wa.cor + ((size_t)r * p.EP + j) * 8;
-        if (wide_same(A, B)) last = max(last, j);  // g == g_prime: never listed (utils.py:59)
-        else if (sg_quads_intersect(A, B)) words[q >> 6] |= 1ull << (q & 63);
-    };
+    bool hit = false; // this entity's row is not empty
+    // Broad phase as the fused kernels walk their tiles (sgym_collide.hpp, all-pairs form): bounding circles in packed fp32, four
+    // slots per LDS read, no branch in the scan -- thr - d2 leaves "outside" in the SIGN bit, which v_alignbit shifts into the
+    // lane's mask.  Strictly conservative: the reach is this entity's radius + the LARGEST radius of the tile, both rounded
+    // up, + 2^-18 x the coordinates for the fp32 conversion of the centres; the fp64 separating-axis test below decides.
+    // A candidate is rare per lane but not per wavefront: the lane walks its own mask AFTER the scan.
+    const float fx = (float)cx, fy = (float)cy;
+    const float mag = __builtin_fabsf(fx) + __builtin_fabsf(fy);
+    const float radf = (float)rad * 1.000001f;
+    const v2f fx2 = {fx, fx}, fy2 = {fy, fy};
     for (int c0 = 0; c0 < p.EP; c0 += 256) {
+        __syncthreads();
+        if (tid == 0) s_rmax = 0u;
         __syncthreads();
         {
             const int j = c0 + tid;
             const double *cj = wa.circ + ((size_t)r * p.EP + min(j, p.EP - 1)) * 4;
-            s_x[tid] = j < p.E ? cj[0] : __builtin_nan(""); s_y[tid] = cj[1]; s_r[tid] = cj[2]; // (NaN: absent, or beyond E)
+            const double xj = j < p.E ? cj[0] : __builtin_nan("");
+            const bool pj = xj == xj;
+            s_fx[tid] = pj ? (float)xj : 0.0f;
+            s_fy[tid] = pj ? (float)cj[1] : 0.0f;
+            if (pj) atomicMax(&s_rmax, __float_as_uint((float)cj[2] * 1.000001f));
+            const uint64_t b = __ballot(pj);
+            if ((tid & 63) == 0) s_pres[tid >> 6] = b;
         }
         __syncthreads();
         if (!present) continue;
-        uint64_t words[4] = {0, 0, 0, 0}; // the row words of this tile's 256 slots
-        int nc = 0;
-        const int self = e - c0;          // this lane's own slot, if it is inside the tile
+        const float reach = (radf + __uint_as_float(s_rmax)) * 1.000001f + 3.8146973e-6f * mag + 1e-5f;
+        const float thr = reach * reach * 1.000001f;
+        const v2f thr2 = {thr, thr};
+        const int self = e - c0; // this lane's own slot, if it is inside the tile
 #pragma unroll 1
-        for (int q0 = 0; q0 < 256; q0 += 4) {
-            double X[4], Y[4], RR[4];
+        for (int k = 0; k < 4; ++k) { // 64 slots = one row word at a time
+            uint32_t half[2];         // bit j = 1: slot j is OUTSIDE this lane's reach
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { X[u] = s_x[q0 + u]; Y[u] = s_y[q0 + u]; RR[u] = s_r[q0 + u]; }
+            for (int h2 = 1; h2 >= 0; --h2) {
+                uint32_t m = 0u;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const double dx = X[u] - cx, dy = Y[u] - cy, rr = RR[u] + rad;
-                if (q0 + u != self && dx * dx + dy * dy <= rr * rr) { // (an absent slot: NaN, the compare fails)
-                    if (nc < 8) s_cand[nc++][tid] = (unsigned short)(q0 + u);
-                    else exact(q0 + u, c0, words);
+                for (int q = 7; q >= 0; --q) {
+                    const int jb = k * 64 + h2 * 32 + q * 4;
+                    const v4f xs = *reinterpret_cast<const v4f *>(&s_fx[jb]);
+                    const v4f ys = *reinterpret_cast<const v4f *>(&s_fy[jb]);
+                    const v2f dxa = v2f{xs.x, xs.y} - fx2, dya = v2f{ys.x, ys.y} - fy2;
+                    const v2f dxb = v2f{xs.z, xs.w} - fx2, dyb = v2f{ys.z, ys.w} - fy2;
+                    const v2f ma = thr2 - __builtin_elementwise_fma(dya, dya, dxa * dxa);
+                    const v2f mb = thr2 - __builtin_elementwise_fma(dyb, dyb, dxb * dxb);
+                    m = __builtin_amdgcn_alignbit(m, __float_as_uint(mb.y), 31); // m = (m << 1) | sign
+                    m = __builtin_amdgcn_alignbit(m, __float_as_uint(mb.x), 31);
+                    m = __builtin_amdgcn_alignbit(m, __float_as_uint(ma.y), 31);
+                    m = __builtin_amdgcn_alignbit(m, __float_as_uint(ma.x), 31);
                 }
+                half[h2] = m;
+            }
+            uint64_t cand = ~(((uint64_t)half[1] << 32) | half[0]) & s_pres[k];
+            if ((self >> 6) == k) cand &= ~(1ull << (self & 63));
+            uint64_t word = 0;
+            for (; cand; cand &= cand - 1) {
+                const int q = __builtin_ctzll(cand), j = c0 + k * 64 + q;
+                const double *cj = wa.circ + ((size_t)r * p.EP + j) * 4;
+                const double dx = cj[0] - cx, dy = cj[1] - cy, rr = cj[2] + rad;
+                if (!(dx * dx + dy * dy <= rr * rr)) continue; // the pair's own circles, fp64 (what the scan was conservative for)
+                const double *B = wa.cor + ((size_t)r * p.EP + j) * 8;
+                if (wide_same(A, B)) last = max(last, j);      // g == g_prime: never listed (utils.py:59)
+                else if (sg_quads_intersect(A, B)) word |= 1ull << q;
+            }
+            if (word) {
+                stf(w.dy, SG_F_COLL + (c0 >> 6) + k, word);
+                hit = true;
             }
         }
-        for (int k = 0; k < nc; ++k) exact((int)s_cand[k][tid], c0, words);
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (words[k]) stf(w.dy, SG_F_COLL + (c0 >> 6) + k, words[k]);
     }
     if (in) {
         wa.last_same[w.g] = last;
-        if (last != e) atomicOr(&wa.dup[r], 1u);
+        const unsigned flags = (last != e ? 1u : 0u) | (hit ? (e == 0 ? 6u : 2u) : 0u);
+        if (flags) atomicOr(&wa.dup[r], flags);
     }
 }
 
-// ... and the twins' bits move to the last owner of the geometry (rare: only scenarios that have twins this step do anything)
-static __global__ __launch_bounds__(256) void wide_owner_kernel(Params p, WideArgs wa)
+// ... and the twins' bits move to the last owner of the geometry (rare: only scenarios that have twins this step do anything;
+// the first part of wide_finish_kernel)
+__device__ __forceinline__ void wide_owner_row(const Params &p, const WideArgs &wa, int r, int e)
 {
-    const int r = blockIdx.y, e = blockIdx.x * 256 + threadIdx.x;
-    if (!wa.dup[r] || e >= p.E) return;
     const int W = p.FROWS - SG_F_COLL;
     const WideEnt w(p, r, e);
     const int32_t *ls = wa.last_same + (size_t)r * p.EP;
@@ -412,25 +443,19 @@ static __global__ __launch_bounds__(256) void wide_owner_kernel(Params p, WideAr
 // ---- per scenario: clock, check_terminal (state.py:268-270, 397-408), ego metrics, CollisionMetric._step ------------------------
 static __global__ __launch_bounds__(256) void wide_finish_kernel(Params p, double timestep, WideArgs wa)
 {
-    __shared__ int s_any, s_ego0;
     const int r = blockIdx.x, tid = threadIdx.x;
-    if (!wide_runs(p, wa, r)) return;
+    if (wa.dup[r] & 1u) { // twins in this scenario: every row maps them to their last owner first (state/utils.py:32-40)
+        for (int e = tid; e < p.E; e += (int)blockDim.x) wide_owner_row(p, wa, r, e);
+        __threadfence();
+        __syncthreads();
+    }
+    if (tid != 0 || !wide_runs(p, wa, r)) return; // (one thread per scenario: the per-entity work is the kernels' before this one)
     const int W = p.FROWS - SG_F_COLL;
     const ScenStatic &ss = p.sstat[r];
     sg_scenario_state &sd = p.sdyn[r];
-    if (tid == 0) { s_any = 0; s_ego0 = 0; }
-    __syncthreads();
-    bool any = false;
-    for (int e = tid; e < p.E; e += 256) {
-        const WideEnt w(p, r, e);
-        bool mine = false;
-        for (int q = 0; q < W; ++q) mine = mine || fld<uint64_t>(w.dy, SG_F_COLL + q) != 0;
-        any = any || mine;
-        if (e == 0 && mine && fld<uint64_t>(w.dy, SG_F_PRESENT) != 0) s_ego0 = 1;
-    }
-    if (any) s_any = 1;
-    __syncthreads();
-    if (tid != 0) return;
+    // "some entity collides" / "entity 0 collides" (state.py:397-400): noted by wide_collide_kernel while it filled the rows (an
+    // absent entity's row is empty; moving a twin's bit leaves a row non-empty)
+    const int s_any = (wa.dup[r] & 2u) != 0, s_ego0 = (wa.dup[r] & 4u) != 0;
     const WideEnt eg(p, r, ss.ego);
     const bool ego_present = fld<uint64_t>(eg.dy, SG_F_PRESENT) != 0;
     uint64_t *last = wa.last_row + (size_t)r * W;
