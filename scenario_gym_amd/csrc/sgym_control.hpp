@@ -315,7 +315,7 @@ static __global__ __launch_bounds__(64, 1) void control_kernel_fast(Params p, do
 {
     // (s_setprio(3) here shortens this kernel's launches by a quarter -- its 64 wavefronts share their SIMDs with the rollout
     // kernels' -- but the 4096 x 64 table path is bound by the rollout kernels, not by this chain: 2-3 % slower overall.
-    // With the collision pass compiled out the chain IS the bound and the priority is worth 99 -> 126 G: HISTORY.md, round 4)
+    // With the collision pass compiled out the chain IS the bound and the priority is worth 98-107 -> 114-126 G: HISTORY.md, round 4)
 #ifdef SG_CTL_SETPRIO
     __builtin_amdgcn_s_setprio(3);
 #endif

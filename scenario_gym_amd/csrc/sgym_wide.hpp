@@ -60,6 +60,8 @@ static __global__ __launch_bounds__(256) void wide_move_kernel(Params p, double 
 {
     __shared__ double s_px[256], s_py[256], s_vx[256], s_vy[256];
     __shared__ unsigned char s_ok[256];
+    constexpr int WIDE_NB = 24;
+    __shared__ unsigned char s_nb[WIDE_NB][256]; // per thread: the tile slots inside its sensor circle, in order
     const int r = blockIdx.y, tid = threadIdx.x, e = blockIdx.x * 256 + tid;
     if (!wide_runs(p, wa, r)) return;
     const bool in = e < p.E;
@@ -166,19 +168,36 @@ static __global__ __launch_bounds__(256) void wide_move_kernel(Params p, double 
         }
         __syncthreads();
         if (go) {
+            // PedestrianSensor.get_nearby_pedestrians in entity order (sensor.py:55-64).  A neighbour is rare per slot but not per
+            // wavefront: evaluated where it is found, every lane's neighbour would send all 64 lanes through the pair force.
+            // The scan only notes the slots inside the circle about the 64-gon (a cheap superset of sg_in_radius); the lane
+            // then walks its own list IN ORDER (the force is a sum: the order of the terms is the reference's).  A full list
+            // is worked off before the scan goes on, which keeps that order.
             const int n = min(256, p.E - c0);
-            for (int q = 0; q < n; ++q) { // PedestrianSensor.get_nearby_pedestrians in entity order, sensor.py:55-64
-                if (c0 + q == e || !s_ok[q]) continue;
-                const double ox = s_px[q], oy = s_py[q];
-                if (!sg_in_radius(pose[0], pose[1], radius, ox, oy, p.gon)) continue;
-                const double ovx = s_vx[q], ovy = s_vy[q];
-                const double vmag = sg_norm2(ovx, ovy) + 0.0000000001;
-                const double odx = ovx / vmag, ody = ovy / vmag, step = vmag * (next_t - t);
-                ExactArith EA;
-                double c1x, c1y, c2x, c2y;
-                ped_pair<false, false>(EA, p.sf, k2_scale, pose[0], pose[1], hs, hc, ox, oy, ovx, ovy, odx, ody, step, c1x, c1y, c2x, c2y);
-                ped_accumulate(p.sf, c1x, c1y, c2x, c2y, fx, fy);
+            const double r2 = radius * radius * (1.0 + 1e-9);
+            int nc = 0;
+            auto work_off = [&]() {
+                for (int k = 0; k < nc; ++k) {
+                    const int q = s_nb[k][tid];
+                    const double ox = s_px[q], oy = s_py[q];
+                    if (!sg_in_radius(pose[0], pose[1], radius, ox, oy, p.gon)) continue;
+                    const double ovx = s_vx[q], ovy = s_vy[q];
+                    const double vmag = sg_norm2(ovx, ovy) + 0.0000000001;
+                    const double odx = ovx / vmag, ody = ovy / vmag, step = vmag * (next_t - t);
+                    ExactArith EA;
+                    double c1x, c1y, c2x, c2y;
+                    ped_pair<false, false>(EA, p.sf, k2_scale, pose[0], pose[1], hs, hc, ox, oy, ovx, ovy, odx, ody, step, c1x, c1y, c2x, c2y);
+                    ped_accumulate(p.sf, c1x, c1y, c2x, c2y, fx, fy);
+                }
+                nc = 0;
+            };
+            for (int q = 0; q < n; ++q) {
+                const double dx = s_px[q] - pose[0], dy = s_py[q] - pose[1];
+                if (c0 + q == e || !s_ok[q] || !(dx * dx + dy * dy <= r2)) continue; // (sg_in_radius: false beyond r2 as well)
+                if (nc == WIDE_NB) work_off();
+                s_nb[nc++][tid] = (unsigned char)q;
             }
+            work_off();
         }
     }
     // ---- the pose ----
