@@ -1,5 +1,5 @@
-// k_ped.hip -- the general pedestrian variants: rollout_kernel<G, WV, true, false> and rollout_kernel_rss_ped<G, WV>
-// (tiles narrower than 16 lanes run as 16-lane tiles).
+// k_ped.hip -- the general pedestrian variants rollout_kernel<G, WV, true, false> (tiles narrower than 16 lanes run as
+// 16-lane tiles); the variants with the RSS callback are an object of their own (k_ped_rss.hip: they compile as long again).
 #include "sgym_launch.hpp"
 
 namespace sgl {
@@ -10,9 +10,11 @@ void rollout_ped(int G, int WV, bool rss, dim3 grid, hipStream_t s, const Rollou
         return;
     }
     if (WV == 1 && G < 16) G = 16;
-#define CALL(G_, WV_)                                                                                                                \
-    if (rss) sg::rollout_kernel_rss_ped<(G_ < 16 ? 16 : G_), WV_><<<grid, dim3(64 * WV_), 0, s>>>(SGL_ARGS(a));                      \
-    else sg::rollout_kernel<(G_ < 16 ? 16 : G_), WV_, true, false><<<grid, dim3(64 * WV_), 0, s>>>(SGL_ARGS(a))
+    if (rss) {
+        rollout_ped_rss(G, WV, grid, s, a);
+        return;
+    }
+#define CALL(G_, WV_) sg::rollout_kernel<(G_ < 16 ? 16 : G_), WV_, true, false><<<grid, dim3(64 * WV_), 0, s>>>(SGL_ARGS(a))
     SGL_DISPATCH(G, WV, CALL);
 #undef CALL
 }

@@ -1,5 +1,5 @@
-// k_rss.hip -- the RSSDistances callback inside the rollout kernel, controllers in the kernel: rollout_kernel_rss<G, WV>,
-// and with the ego_off_road terminal condition rollout_kernel_rss_road<G, WV>.
+// k_rss.hip -- the RSSDistances callback inside the rollout kernel, controllers in the kernel: rollout_kernel_rss<G, WV>; with
+// the ego_off_road terminal condition rollout_kernel_rss_road<G, WV> (an object of its own: k_rss_road.hip).
 #include "sgym_launch.hpp"
 
 namespace sgl {
@@ -9,9 +9,11 @@ void rollout_rss(int G, int WV, bool road, dim3 grid, hipStream_t s, const Rollo
         sg::rollout_kernel_rss<64, 8><<<grid, dim3(512), 0, s>>>(SGL_ARGS(a));
         return;
     }
-#define CALL(G_, WV_)                                                                                                                \
-    if (road) sg::rollout_kernel_rss_road<G_, WV_><<<grid, dim3(64 * WV_), 0, s>>>(SGL_ARGS(a));                                     \
-    else sg::rollout_kernel_rss<G_, WV_><<<grid, dim3(64 * WV_), 0, s>>>(SGL_ARGS(a))
+    if (road) {
+        rollout_rss_road(G, WV, grid, s, a);
+        return;
+    }
+#define CALL(G_, WV_) sg::rollout_kernel_rss<G_, WV_><<<grid, dim3(64 * WV_), 0, s>>>(SGL_ARGS(a))
     SGL_DISPATCH(G, WV, CALL);
 #undef CALL
 }

@@ -26,6 +26,7 @@ struct RolloutArgs {
 void rollout_plain(int G, int WV, bool tab, dim3 grid, hipStream_t s, const RolloutArgs &a);
 // k_ped.hip: rollout_kernel<max(G, 16), WV, true, false> / rollout_kernel_rss_ped (rss)
 void rollout_ped(int G, int WV, bool rss, dim3 grid, hipStream_t s, const RolloutArgs &a);
+void rollout_ped_rss(int G, int WV, dim3 grid, hipStream_t s, const RolloutArgs &a); // (k_ped_rss.hip, through rollout_ped)
 // k_crowd.hip: rollout_kernel_crowd<WV> / rollout_kernel_crowd_riders<WV>
 void rollout_crowd(int WV, bool riders, dim3 grid, hipStream_t s, const RolloutArgs &a);
 // k_walk.hip (sgym_walk.hpp): the chunk classifier and the walker variant of the crowd rollout (WVL = 1, 2 wavefronts of
@@ -36,6 +37,7 @@ void walk_rollout(int WVL, dim3 grid, hipStream_t s, const sg::Params &p, double
 void wide_step(dim3 grid_entities, dim3 grid_scenarios, hipStream_t s, const sg::Params &p, double timestep, const sg::WideArgs &wa);
 // k_rss.hip: rollout_kernel_rss<G, WV> / rollout_kernel_rss_road<G, WV> (road)
 void rollout_rss(int G, int WV, bool road, dim3 grid, hipStream_t s, const RolloutArgs &a);
+void rollout_rss_road(int G, int WV, dim3 grid, hipStream_t s, const RolloutArgs &a); // (k_rss_road.hip, through rollout_rss)
 // k_rss_tab.hip: rollout_kernel_rss_tab<G> + rss_lines_kernel
 void rollout_rss_tab(int G, dim3 grid, hipStream_t s, const sg::Params &p, double timestep, int force, const sg::TabGroups &tg);
 void rss_lines(dim3 grid, hipStream_t s, const sg::Params &p, const sg::TabGroups &tg);
