@@ -153,6 +153,16 @@ int main(void)
         CHECK(sg_host_free(pk));
     }
 
+    /* the launch schedule the handle got (sg_pipeline_info), and the behaviour model switch: refused after sg_upload unless it
+     * is the one in force */
+    {
+        int32_t info[8];
+        CHECK(sg_pipeline_info(h, info));
+        bad |= info[0] < 1 || info[0] > 3 || info[1] < 1 || info[1] > info[0] || info[6] <= 0;
+        CHECK(sg_set_ped_behaviour(h, SG_PED_SOCIAL_FORCE));
+        bad |= sg_set_ped_behaviour(h, SG_PED_RANDOM_WALK) != SG_ERR_STATE || sg_set_ped_behaviour(h, 7) != SG_ERR_INVALID;
+    }
+
     /* error behaviour: a bad argument returns a negative status and a message, nothing aborts */
     int rc = sg_step(h, -1, NULL, 0);
     bad |= rc != SG_ERR_INVALID || strlen(sg_last_error(h)) == 0;
