@@ -1950,15 +1950,16 @@ def test_ego_off_road_with_controlled_egos_on_synthetic_roads(sga, oracle, R, E)
     assert stopped > R // 10
 
 
-@pytest.mark.parametrize("R,E,crowd", [(40, 12, False), (9, 150, False), (24, 30, True)])
+@pytest.mark.parametrize("R,E,crowd", [(40, 12, False), (9, 150, False), (24, 30, True), (6, 300, False), (5, 600, False), (4, 560, True)])
 def test_masked_reset_equals_fresh_reset(sga, R, E, crowd):
     """sg_reset_scenarios: after some steps, the flagged scenarios are exactly in the state a full reset gives them and the
-    others exactly where they were; stepping on from there equals stepping two engines that were treated wholesale."""
+    others exactly where they were; stepping on from there equals stepping two engines that were treated wholesale.  (Also on
+    eight-wavefront tiles and on the multi-kernel step of scenarios beyond 512 entities, vehicles and crowds.)"""
     import scenario_gym_amd._lib as L
     from scenario_gym_amd import synthetic
 
-    packed = synthetic.make_crowd(R, E, n_steps=120, side=10.0) if crowd else \
-        synthetic.make_batch(R, E, n_steps=120, ego_kind=L.KIND_AGENT_PID, extent=20.0)
+    packed = synthetic.make_crowd(R, E, n_steps=120, side=10.0 if E < 256 else 34.0) if crowd else \
+        synthetic.make_batch(R, E, n_steps=120, ego_kind=L.KIND_AGENT_PID, extent=20.0 if E < 256 else 90.0)
     a, b, c = (sga.RolloutEngine(R, E, record_capacity=8) for _ in range(3))
     for e in (a, b, c):
         e.upload(packed)
