@@ -154,7 +154,10 @@ __device__ __forceinline__ void tile_collisions(bool present, const double *pose
             cand[w] = close[w];
             any_cand = any_cand || cand[w] != 0;
         }
-        if (PED) dense = iters > (2 * TS) / 5; // ~ where 25 instructions per candidate overtake the walk (voted by the next call)
+        // (the walk costs ~5 instructions per slot and no barrier; a candidate ~25 and the stripe masks two workgroup barriers.
+        // Measured on 1024 x 256 (tools/dbg/dense_sweep.sh): switching at TS/10 ... TS/40 candidates and back below TS/24 ...
+        // TS/256 neighbours all give 4.35 G, the earlier 2 TS/5 and TS/12 3.98 G, always walking 4.25 G)
+        if (PED) dense = iters > TS / 16; // (voted by the next call)
         PH(9);
     } else {
     // ---- fallback for coordinates beyond 4000 cells: all pairs of the tile ----
@@ -259,11 +262,11 @@ __device__ __forceinline__ void tile_collisions(bool present, const double *pose
         }
         any_cand = any_cand || cand[w] != 0;
     }
-    if (PED) { // back to the stripe masks once nobody has more than TS/12 neighbour candidates (hysteresis)
+    if (PED) { // back to the stripe masks once nobody has more than TS/64 neighbour candidates (hysteresis)
         int cnt = 0;
 #pragma unroll
         for (int w = 0; w < WV; ++w) cnt += __builtin_popcountll(nbr_out[w]);
-        dense = cnt > TS / 12; // (a wish: voted by the next call)
+        dense = cnt > TS / 64; // (a wish: voted by the next call)
         PH(10);
     }
     }
