@@ -328,7 +328,7 @@ def run_e2e(args):
         chunks = [paths[i:i + chunk] for i in range(0, n_files, chunk)]
         stages = dict(ingest=0.0, merge=0.0, upload=0.0, device=0.0, readback=0.0)
         all_metrics = []
-        SUB = 32  # files per worker task
+        SUB = int(os.environ.get("SG_E2E_SUB", "32"))  # files per worker task
 
         def factory():
             return [M.EgoAvgSpeed(), M.EgoMaxSpeed(), M.EgoDistanceTravelled(), M.CollisionMetric(), M.RSS()]
