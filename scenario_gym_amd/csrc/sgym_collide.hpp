@@ -110,7 +110,9 @@ __device__ __forceinline__ void tile_collisions(bool present, const double *pose
     }
     PH(12);
     if (CROWD) *crowd_ok = !odd;
-    const bool all_pairs = odd || (PED && dense);
+    // (vehicle tiles of up to 16 lanes always walk: four groups of four slots, no atomics, no mask reads, no candidate loop --
+    // 256 x 16 replay 3.10 -> 3.31 G, 16384 x 16 70.6 -> 73.1 G; from 32 lanes on the stripe masks win, HISTORY.md round 4)
+    const bool all_pairs = odd || (PED && dense) || (!PED && TS <= 16);
     if (!all_pairs) { // block_any / the barrier below also publish the LDS writes above
         // ---- stripe masks: O(tile) instead of O(tile^2) ----
         if (WV == 1) tile_sync<WV>();

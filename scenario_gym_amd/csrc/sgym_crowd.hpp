@@ -435,7 +435,8 @@ __device__ __forceinline__ void crowd_pair_n(const CrowdConsts &C, const double 
 }
 
 #ifndef SG_CROWD_ILP
-#define SG_CROWD_ILP 2 // (pedestrian, neighbour) pairs a lane evaluates side by side: independent fp64 dependency chains
+#define SG_CROWD_ILP 1 // (pedestrian, neighbour) pairs a lane evaluates side by side.  fp64 issue, not latency, bounds the chain
+                       // (tools/dbg/pair_bench.hip): 1 -> 4.38, 2 -> 4.35, 3 -> 4.17 G on 1024 x 256, three alternating repetitions
 #endif
 
 // The neighbour sums of one wavefront of an all-pedestrian scene: ped_pairs_balanced's scheme (every lane works through
