@@ -20,10 +20,8 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# The rollout runs on up to four HIP streams at once (three pipelines + the controller pre-pass); HIP multiplexes a
-# process's streams over GPU_MAX_HW_QUEUES hardware queues (default 4), and RCCL / torch bring streams of their own.  Read
-# when the HIP runtime loads, i.e. before torch is imported.  (The library probes what it got: sg_create, probe_pipelines.)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# (The table path is ONE persistent launch on ONE stream since round 5 -- csrc/sgym_queue.hpp: the line no longer depends on
+# how many hardware queues HIP gives the process, and nothing here sets GPU_MAX_HW_QUEUES any more.)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # fp64 vector ALU: 256 CUs x 4 SIMDs x 16 lanes x 2 (fma) x 2.4 GHz (AMD's datasheet figure for MI355X; the
@@ -145,7 +143,8 @@ def kernel_name(E, crowd, controlled, rss=False, mix=False):
                 (f"sg::rollout_kernel<64, {WV}, true, false>" if mix else f"sg::rollout_kernel_crowd<{WV}>")
         return f"sg::rollout_kernel<{max(G, 16)}, {WV}, true, false>"
     if WV == 1 and controlled:  # (the synthetic batches are planar: z = pitch = roll = +0.0 in every knot)
-        return f"sg::rollout_kernel_tab_planar<{G}>" if os.environ.get("SG_PLANAR", "1") != "0" else f"sg::rollout_kernel_tab<{G}>"
+        q = "q" if os.environ.get("SG_QUEUE", "1") != "0" else ""  # rollout_kernel_tabq*: the persistent launch (sgym_queue.hpp)
+        return f"sg::rollout_kernel_tab{q}_planar<{G}>" if os.environ.get("SG_PLANAR", "1") != "0" else f"sg::rollout_kernel_tab{q}<{G}>"
     return f"sg::rollout_kernel<{G}, {WV}, false, true>"
 
 
@@ -494,6 +493,9 @@ def main(argv=None, make_engine=None):
                          "through the CPU oracle for the full horizon and compare the final state / metric rows / events bit "
                          "for bit; a mismatch makes the exit code non-zero.  Default 16 (c5, c3rss: 4); 0 = off")
     ap.add_argument("--engine-factory", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--require-queue", action="store_true",
+                    help="exit non-zero (code 4) unless every rank ran the table path as the one persistent launch "
+                         "(roofline.schedule; without the flag a rank that fell back to chunk launches only marks the line \"degraded\")")
     ap.add_argument("--files", type=int, default=4096, help="e2e: OpenSCENARIO files to generate and run")
     ap.add_argument("--chunk", type=int, default=512, help="e2e: scenarios per device batch")
     ap.add_argument("--ped-noise", default="off", choices=["off", "device"],
@@ -602,7 +604,7 @@ def main(argv=None, make_engine=None):
                                    axis=1), dist)
             n_launch, launch_ms = eng.last_launch_stats()
             gross = eng.last_launch_gross_ms() if hasattr(eng, "last_launch_gross_ms") else launch_ms
-            pipes.append(eng.pipeline_info() if hasattr(eng, "pipeline_info") else None)
+            pipes.append(eng.schedule_info() if hasattr(eng, "schedule_info") else None)
             return int(rows["n_steps"].sum()) * E, (eng.last_kernel_ms(), n_launch, launch_ms, gross)
 
         elapsed, ent_steps, stats = timed_passes(one_pass, args.steps, args.warmup, dist, sync)
@@ -614,10 +616,11 @@ def main(argv=None, make_engine=None):
         if ver is not None and dist is not None:  # every rank checks scenarios of its own shard
             ver["equal"] = D.sum_over_ranks(0.0 if ver["equal"] else 1.0, dist) == 0.0
             ver["scenarios"] = int(D.sum_over_ranks(float(ver["scenarios"]), dist))
-        # every rank's launch schedule to rank 0: [pipelines found by the probe, pipelines the timed passes ran (min), blocks, SIMDs]
+        # every rank's launch schedule to rank 0: [schedule of the timed passes (min over them), chunks, ring, grid, pre-pass
+        # wavefronts, blocks, SIMDs, launches per call]
         pi = pipes[-1] if pipes and pipes[-1] else None
-        sched = D.gather_rows(np.array([[pi["found"], min(q["used_last_call"] for q in pipes), pi["blocks"], pi["simds"],
-                                         pi["wanted"], pi["hw_queues"], float(pi["pinned"])]] if pi else [[0.0] * 7], np.float64), dist)
+        sched = D.gather_rows(np.array([[min(q["schedule"] for q in pipes), pi["chunks"], pi["ring"], pi["grid"], pi["ctl_waves"],
+                                         pi["blocks"], pi["simds"], pi["launches"]]] if pi else [[0.0] * 8], np.float64), dist)
         return dict(elapsed=worst, total=total, per_rank=per_rank, ent_steps=ent_steps, stats=stats, R=R, verified=ver,
                     sched=None if sched is None else sched.tolist())
 
@@ -700,21 +703,25 @@ def main(argv=None, make_engine=None):
             tf0 = per_launch * F0 / (avg_ms * 1e-3) / 1e12
             roofline = {
                 # primary roof: the fp64 vector ALU, numerator = ALGORITHMIC flops counted by the oracle's counter build on
-                # scenarios of this very batch (not executed instructions: `valu_issue` below is the utilisation figure)
-                "bound": "valu_fp64", "unit": "TFLOP/s", "achieved": tf, "peak": FP64_VALU_PEAK_TFLOPS,
-                "frac": tf / FP64_VALU_PEAK_TFLOPS,
-                "flops_per_entity_step": F, "flops_by_category": fl["flops_per_entity_step"], "flops_file": fl["file"],
+                # scenarios of this very batch (not executed instructions: `valu_issue` below is the utilisation figure).
+                # `achieved` / `frac` leave the pair search out: SURVEY 8d charges 6 flops per unordered pair of
+                # present entities for it, the stripe-mask broad phase executes none of them (and where a broad phase runs
+                # it is fp32) -- the figure with that charge is kept beside it, labelled
+                "bound": "valu_fp64", "unit": "TFLOP/s", "achieved": tf0, "peak": FP64_VALU_PEAK_TFLOPS,
+                "frac": tf0 / FP64_VALU_PEAK_TFLOPS,
+                "flops_per_entity_step": F0, "flops_by_category": fl["flops_per_entity_step"], "flops_file": fl["file"],
                 "flops_exact_for_this_workload": fl["exact"],
-                "achieved_without_pair_search": tf0, "frac_without_pair_search": tf0 / FP64_VALU_PEAK_TFLOPS,
+                "flops_per_entity_step_with_pair_search": F,
+                "achieved_with_pair_search": tf, "frac_with_pair_search": tf / FP64_VALU_PEAK_TFLOPS,
                 "peak_measured": peak["fp64_tflops"] if peak else None,
-                "frac_of_measured_peak": (tf / peak["fp64_tflops"]) if peak and peak.get("fp64_tflops") else None,
+                "frac_of_measured_peak": (tf0 / peak["fp64_tflops"]) if peak and peak.get("fp64_tflops") else None,
                 "traffic": traffic,
                 "binding": "ordered_sum_latency" if wl.get("sliced") else "valu_issue",
                 "note": "achieved = counted algorithmic fp64 flops per entity-step (profiles/flops_*.json: add/sub/mul/div/sqrt/"
-                        "compare = 1, fma = 2, minimal formulation; pair_search = SURVEY 8d's 6 flops per unordered pair of present "
-                        "entities, which the stripe-mask broad phase does NOT execute -- frac_without_pair_search leaves it out) x "
-                        "entity-steps per launch / kernel_ms; peak = 256 CUs x 4 SIMDs x 16 lanes x 2 x 2.4 GHz; peak_measured = "
-                        "tools/valu_peak.hip run in this process; traffic = HBM bytes per launch (calibrated PMC counters)"
+                        "compare = 1, fma = 2, minimal formulation) WITHOUT the pair search x entity-steps per launch / kernel_ms; "
+                        "*_with_pair_search adds SURVEY 8d's 6 flops per unordered pair of present entities, which the "
+                        "stripe-mask broad phase does NOT execute; peak = 256 CUs x 4 SIMDs x 16 lanes x 2 x 2.4 GHz; "
+                        "peak_measured = tools/valu_peak.hip run in this process; traffic = HBM bytes per launch (calibrated PMC counters)"
                         + ("" if fl["exact"] else "; the flops are those of the nearest counted workload (the RSS callback / the car "
                                                   "among the pedestrians are not in the count): a lower bound"),
             }
@@ -722,25 +729,27 @@ def main(argv=None, make_engine=None):
             roofline = dict(hbm_contract)
             roofline["binding"] = "ordered_sum_latency" if wl.get("sliced") else "valu_issue"
         sched = m.get("sched")
-        pipelines = None
-        if sched and any(r_[2] for r_ in sched):
-            found, used = [int(r_[0]) for r_ in sched], [int(r_[1]) for r_ in sched]
-            pipelines = {"wanted": int(sched[0][4]), "found_per_rank": found, "used_per_rank": used, "hw_queues": int(sched[0][5]),
-                         "pinned": bool(sched[0][6]), "blocks_per_rank": int(sched[0][2]), "simds": int(sched[0][3])}
-            # a batch of >= 3 x SIMDs blocks on the table path wants three pipelines; fewer = a slower schedule
-            want_now = min(pipelines["wanted"], pipelines["blocks_per_rank"] // max(1, pipelines["simds"]))
-            if kname.startswith("sg::rollout_kernel_tab") and want_now >= 2 and min(used) < want_now:
-                pipelines["degraded"] = True
-                print(f"bench: DEGRADED launch schedule: {min(used)} of {want_now} rollout pipelines ran side by side "
-                      f"(GPU_MAX_HW_QUEUES={pipelines['hw_queues']}; the probe at sg_create found {found}); results are the same, "
-                      f"throughput is not (one pipeline ~0.7x of three)", file=sys.stderr)
+        schedule = None
+        if sched and any(r_[5] for r_ in sched):
+            names = {0: "none", 1: "chunk_launches", 2: "persistent_queue"}
+            schedule = {"per_rank": [names.get(int(r_[0]), "?") for r_ in sched], "chunks": int(sched[0][1]), "table_ring": int(sched[0][2]),
+                        "wavefronts": int(sched[0][3]), "prepass_wavefronts": int(sched[0][4]), "blocks_per_rank": int(sched[0][5]),
+                        "simds": int(sched[0][6]), "launches_per_rollout": int(sched[0][7]),
+                        "note": "persistent_queue = the controller pre-pass and every chunk of the rollout in ONE launch, work items "
+                                "(chunk, block) from a device-side counter (csrc/sgym_queue.hpp); no timing probe, no hardware-queue "
+                                "dependence"}
+            # the table kernels of a batch with controlled lanes are expected to run as the persistent launch
+            if kname.startswith("sg::rollout_kernel_tab") and any(int(r_[0]) != 2 for r_ in sched):
+                schedule["degraded"] = True
+                print(f"bench: DEGRADED launch schedule: {schedule['per_rank']} (SG_QUEUE=0, or the table ring could not be "
+                      f"allocated); results are the same, throughput is not", file=sys.stderr)
         roofline.update({
             "kernel": kname, "kernel_ms": avg_ms, "kernel_ms_gross": gross_ms,
             "launch_overlap": gross_ms / avg_ms if avg_ms else None,
-            "kernel_ms_note": "kernel_ms = union of the launches' HIP-event intervals / launches (launches of the rollout pipelines "
-                              "overlap); kernel_ms_gross = plain average launch duration, the figure rocprofv3 --kernel-trace --stats shows",
+            "kernel_ms_note": "kernel_ms = union of the launches' HIP-event intervals / launches; kernel_ms_gross = plain average launch "
+                              "duration, the figure rocprofv3 --kernel-trace --stats shows (equal: one launch at a time)",
             "launches_per_rollout": launches_per_rollout, "rollout_device_ms": rollout_ms,
-            "entity_steps_per_launch": per_launch, "pipelines": pipelines,
+            "entity_steps_per_launch": per_launch, "schedule": schedule,
             "valu_issue": secondary, "hbm_contract": hbm_contract if fl else None,
             "src_sha16": L.source_sha16(),
         })
@@ -793,8 +802,10 @@ def main(argv=None, make_engine=None):
                                      "scenarios_per_gpu": o["R"], "per_rank_value": o["per_rank"], "verified": o["verified"],
                                      "accounting": "workload c3s: time-sliced rollout, final state + metrics + events bit-identical "
                                                    "to the step-by-step path, the intermediate states are not written to memory"}
-        if pipelines and pipelines.get("degraded"):
-            line["degraded"] = "fewer rollout pipelines than the batch wants ran side by side (roofline.pipelines)"
+        if schedule and schedule.get("degraded"):
+            line["degraded"] = "a rank ran the table path as chunk launches instead of the persistent launch (roofline.schedule)"
+        # which engine produced the line (a stand-in injected by the CPU tests must never pass for the HIP library)
+        line["engine"] = "scenario_gym_amd.RolloutEngine (libsgym_hip.so)" if live else (args.engine_factory or "injected stand-in (tests)")
         if live and not args.no_cpu_baseline:  # (rank 0 only, after the timed region; the other ranks wait at the teardown)
             line["cpu_baseline"] = cpu_baseline(dict(E=E, T=T, dt=dt, ego_kind=ego_kind, crowd=crowd, rss=bool(wl.get("rss"))))
         print(json.dumps(line))
@@ -804,6 +815,9 @@ def main(argv=None, make_engine=None):
     if failed:
         print(f"bench: the device state DIFFERS from the oracle: {failed[0]['verified']['mismatches']}", file=sys.stderr)
         raise SystemExit(3)
+    if args.require_queue and line is not None and (line.get("degraded") or not (line["roofline"].get("schedule") or {}).get("per_rank")):
+        print("bench: --require-queue: not every rank ran the persistent table launch", file=sys.stderr)
+        raise SystemExit(4)
     return line
 
 

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SG_ABI_VERSION 2 /* 2: sg_scenario_state.last_row_hi (scenarios of up to 512 entities) */
+#define SG_ABI_VERSION 3 /* 2: sg_scenario_state.last_row_hi (scenarios of up to 512 entities); 3: sg_schedule_info replaces sg_pipeline_info */
 
 typedef enum {
     SG_OK = 0,
@@ -400,23 +400,27 @@ int sg_copy_to_host(sg_handle *h, const void *device_ptr, void *host_ptr, uint64
  * the kernel of a one-step tick): SG_ERR_STATE after such a call. */
 int sg_last_kernel_ms(sg_handle *h, float *ms);
 
-/* the rollout-kernel launches of that call (long rollouts are cut into chunks of steps so that the controller
- * pre-pass of chunk c+1 overlaps the rollout kernel of chunk c; large batches with controlled agents run as two halves
- * on two streams, whose launches overlap): how many, and the time during which at least one of them was running -- the
- * union of their intervals, each measured with its own HIP event pair on the launch's stream */
+/* the rollout-kernel launches of that call (ONE for the persistent table launch, sg_schedule_info; chunk launches otherwise:
+ * long rollouts are cut into chunks of steps so that the controller pre-pass of chunk c+1 overlaps the rollout kernel of
+ * chunk c): how many, and the time during which at least one of them was running -- the union of their intervals, each
+ * measured with its own HIP event pair on the launch's stream */
 int sg_last_launch_stats(sg_handle *h, int32_t *n_launches, float *kernel_ms_total);
 /* ... and the plain sum of their durations (what a kernel trace adds up; equal to the union when nothing overlaps) */
 int sg_last_launch_gross_ms(sg_handle *h, float *kernel_ms_gross);
 
-/* The launch schedule of the table path (no reference counterpart: scenario_gym/scenario_gym.py:256-267 is one Python loop).
- * Large batches with controlled agents run as up to three pipelines on streams of their own; how many really run side by
- * side depends on the hardware queues the process got (GPU_MAX_HW_QUEUES, read when the HIP runtime loads), which sg_create
- * probes -- or takes from the environment variable SG_PIPELINES (1..3: no probe).  Results never depend on it, throughput
- * does (one pipeline ~0.7x of three on 4096 x 64).  info[8]: [0] pipelines asked for, [1] pipelines the probe found (or the
- * pinned count), [2] pipelines the last sg_rollout / sg_step call ran (0: it did not take the table path), [3]
- * GPU_MAX_HW_QUEUES as this process sees it (4 = HIP's default when unset), [4] 1 when the count was pinned, [5] 64-slot
- * blocks of the batch, [6] SIMDs of the device, [7] reserved. */
-int sg_pipeline_info(sg_handle *h, int32_t *info);
+/* The launch schedule of the table path (no reference counterpart: scenario_gym/scenario_gym.py:256-267 is one Python loop,
+ * and as deterministic as one).  Batches with controlled agents and at least SG_TAB_MIN_STEPS steps to do run as ONE
+ * persistent launch (csrc/sgym_queue.hpp): the controller pre-pass and the rollout of every chunk of the time axis in one grid,
+ * work items (chunk, block) pulled from a device-side counter -- no timing probe, no dependence on how many hardware queues
+ * the process got (rounds 3-4 ran "pipelines" on streams of their own and probed how many overlapped; gone).  Crowds with
+ * riders, the in-kernel RSS callback, tiles of several wavefronts and SG_QUEUE=0 take chunk launches on two streams.
+ * Results never depend on it.  info[8], all about the last sg_rollout / sg_step call: [0] 0 it did not take the table path,
+ * 1 chunk launches, 2 the persistent launch; [1] chunks of the time axis, [2] buffers of the table ring (== [1]: no buffer
+ * was reused), [3] wavefronts of the launch (0 unless [0] == 2); [4] wavefronts of the controller pre-pass (controlled lanes
+ * / 64), [5] 64-slot blocks of the batch, [6] SIMDs of the device, [7] rollout-kernel launches of the call.
+ * A persistent launch whose wavefronts wait longer than SG_QUEUE_TIMEOUT_MS (default 20000) for each other gives up instead
+ * of hanging: the next synchronising call returns SG_ERR_HIP and says so. */
+int sg_schedule_info(sg_handle *h, int32_t *info);
 
 /* With SG_CROWD_WALK=3 in the environment (OFF by default: measured no faster, HISTORY.md round 4) long rollouts of
  * all-pedestrian scenarios of 129..256 entities run in chunks of steps; in every chunk a scenario whose pedestrians have

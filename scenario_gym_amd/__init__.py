@@ -1,9 +1,4 @@
 """scenario_gym_amd: MI355X-native batched rollout engine behind scenario_gym's Python API."""
-import os as _os
-
-# (before the HIP runtime loads, if it has not yet: room for the engine's rollout pipelines beside the streams of torch and
-# RCCL -- see sgym_hip.hip, probe_pipelines; without effect, and without harm, once the runtime is up)
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 from .agent import (  # noqa: F401
     Action,
     Agent,

@@ -39,12 +39,13 @@ struct CtlLds { double ctrl[9][64]; double seg[5][64]; };
 // -- replay entities (the scenario's union grid, presence rule of batch.py:45-52) and replay agents (own knots, clamped;
 // agent.py:125-128) beside the PID / vehicle agents -- and every row also gets plane 2 = z, pitch, roll, presence.
 template <bool FAST, bool RIDERS = false>
-__device__ __forceinline__ void control_body(const Params &p, double timestep, int n_steps, int first, int k0,
-                                             const double *actions /*[n][R][2]*/, double *tab, int row0, int metrics)
+__device__ __forceinline__ void control_body_l(CtlLds &lds /* the wavefront's LDS (rollout_kernel_tabq lays it over its tile) */,
+                                               const unsigned qblock /* the 64 controlled lanes of this wavefront */,
+                                               const Params &p, double timestep, int n_steps, int first, int k0,
+                                               const double *actions /*[n][R][2]*/, double *tab, int row0, int metrics)
 {
-    __shared__ CtlLds lds;
     const int lane = threadIdx.x;
-    const size_t q = (size_t)blockIdx.x * 64 + lane;
+    const size_t q = (size_t)qblock * 64 + lane;
     const int ent_raw = p.ctl_ent[q];
     const bool active = ent_raw >= 0;
     const uint32_t ent = active ? (uint32_t)ent_raw : 0u;
@@ -293,6 +294,15 @@ __device__ __forceinline__ void control_body(const Params &p, double timestep, i
     cst[CS_T * NP] = t;
     cst[CS_PREV_T * NP] = prev_t;
     cst[(CS_METRIC + 0) * NP] = m_avg; cst[(CS_METRIC + 1) * NP] = m_max; cst[(CS_METRIC + 2) * NP] = m_t;
+}
+
+// the ordinary form: one workgroup per 64 controlled lanes, the LDS belongs to this call
+template <bool FAST, bool RIDERS = false>
+__device__ __forceinline__ void control_body(const Params &p, double timestep, int n_steps, int first, int k0,
+                                             const double *actions /*[n][R][2]*/, double *tab, int row0, int metrics)
+{
+    __shared__ CtlLds lds;
+    control_body_l<FAST, RIDERS>(lds, blockIdx.x, p, timestep, n_steps, first, k0, actions, tab, row0, metrics);
 }
 
 #ifdef SG_UNIT_CTL // (emitted by the one object that launches it: csrc/Makefile, sgym_launch.hpp)

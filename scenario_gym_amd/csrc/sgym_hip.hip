@@ -85,11 +85,6 @@ struct sg_handle {
     double *d_ext = nullptr;  // [NE][6]
     int max_ctl_per_block = 0; // controlled lanes in the fullest 64-slot block
     hipStream_t ctl_stream = nullptr;
-    hipStream_t xstream[2] = {nullptr, nullptr}; // further rollout pipelines (launch_rollout)
-    int n_pipes = 1;                             // rollout pipelines that really run side by side (probe_pipelines)
-    int pipes_wanted = 1;                        // ... of how many asked for (SG_TAB_SPLIT, default 3)
-    int pipes_pinned = 0;                        // env SG_PIPELINES: the count was set by hand, not probed
-    int last_pipes = 0;                          // pipelines the last table-path call ran (0: it did not take the table path)
     // chunked crowd rollouts (launch_crowd_chunks, sgym_walk.hpp): per-scenario scratch, allocated on first use
     std::vector<void *> walk_allocs;
     sg::WalkArgs walk{};
@@ -102,6 +97,16 @@ struct sg_handle {
     // 0.5 + up to 6 MB for 4096 scenarios; pageable copies ran at a third of the PCIe rate)
     void *pin_sd = nullptr, *pin_ev = nullptr;
     size_t pin_sd_cap = 0, pin_ev_cap = 0;
+    // the table path as one persistent launch (sgym_queue.hpp, launch_queue)
+    unsigned *d_qwords = nullptr;   // queue state + progress words: [Q_STATE_WORDS + n_ctl_waves + nblk + Q_MAX_CHUNKS]
+    size_t qwords_cap = 0;
+    double *d_qtab = nullptr;       // the table ring
+    size_t qtab_bytes = 0;
+    unsigned *q_host = nullptr;     // page-locked copy of the queue state words of the last queue launch (give-up code, items done)
+    bool q_pending = false;         // ... which has not been looked at yet (check_queue)
+    int queue_mode = 1;             // env SG_QUEUE=0: the chunk launches of rounds 1-4 instead
+    int last_schedule = 0;          // 0: not the table path, 1: chunk launches, 2: the persistent queue launch
+    int last_chunks = 0, last_ring = 0, last_grid = 0;
     double *d_tab[4] = {nullptr, nullptr, nullptr, nullptr}; // controller-table buffers (launch_rollout: two, four with block groups)
     int n_tab = 0;
     int n_simd = 1024;                                       // SIMDs of the device (4 per compute unit)
@@ -269,75 +274,6 @@ extern "C" int sg_version(void) { return SG_ABI_VERSION; }
 
 extern "C" const char *sg_last_error(const sg_handle *h) { return h ? h->err.c_str() : g_create_err.c_str(); }
 
-// How many rollout pipelines (streams) of this handle really run side by side?  HIP multiplexes its streams over a few
-// hardware queues (GPU_MAX_HW_QUEUES, 4 by default, per process and device); two streams that share one run their kernels
-// one after the other, and two pipelines that do are slower than one.  A 0.2 ms spin kernel on every stream at once, its
-// start and end read back: pipeline j counts if its kernel overlapped those of the main stream, the controller stream and
-// the pipelines before it.
-namespace sg {
-__global__ void spin_kernel(long long ticks)
-{
-    const long long t0 = wall_clock64();
-    while (wall_clock64() - t0 < ticks) {}
-}
-}
-static int probe_once(sg_handle *h, int want, int *found);
-static int probe_pipelines(sg_handle *h, int want)
-{
-    h->n_pipes = 1;
-    h->pipes_wanted = want;
-    if (want < 2) return SG_OK;
-    if (const int pin = env_int("SG_PIPELINES", 0)) { // the count by hand (1..want): no probe, no dependence on timing noise
-        h->n_pipes = std::min(want, std::max(1, pin));
-        h->pipes_pinned = 1;
-        return SG_OK;
-    }
-    // up to three attempts, the best one counts: the first launch on a stream may still be setting the stream up (queues are
-    // created on first use), and a process that starts beside seven others is not in a hurry
-    for (int attempt = 0; attempt < 3 && h->n_pipes < want; ++attempt) {
-        int found = 1;
-        int rc = probe_once(h, want, &found);
-        if (rc) return rc;
-        h->n_pipes = std::max(h->n_pipes, found);
-    }
-    return SG_OK;
-}
-static int probe_once(sg_handle *h, int want, int *found)
-{
-    *found = 1;
-    hipStream_t st[4] = {h->stream, h->ctl_stream, h->xstream[0], h->xstream[1]};
-    const int n = std::min(4, 1 + want);
-    struct Events { // destroyed on every path out of this function (a failing HIP_TRY returns from the middle)
-        hipEvent_t a[4] = {}, b[4] = {};
-        ~Events() { for (int i = 0; i < 4; ++i) { if (a[i]) (void)hipEventDestroy(a[i]); if (b[i]) (void)hipEventDestroy(b[i]); } }
-    } evs;
-    hipEvent_t *a = evs.a, *b = evs.b;
-    for (int i = 0; i < n; ++i) {
-        HIP_TRY(h, hipEventCreate(&a[i]));
-        HIP_TRY(h, hipEventCreate(&b[i]));
-    }
-    for (int i = 0; i < n; ++i) {
-        HIP_TRY(h, hipEventRecord(a[i], st[i]));
-        sg::spin_kernel<<<dim3(1), dim3(64), 0, st[i]>>>(20000); // 100 MHz ticks
-        HIP_TRY(h, hipEventRecord(b[i], st[i]));
-    }
-    float t0[4] = {0, 0, 0, 0}, t1[4] = {0, 0, 0, 0};
-    for (int i = 0; i < n; ++i) HIP_TRY(h, hipStreamSynchronize(st[i]));
-    for (int i = 0; i < n; ++i) {
-        float d = 0.0f;
-        if (i > 0) HIP_TRY(h, hipEventElapsedTime(&t0[i], a[0], a[i]));
-        HIP_TRY(h, hipEventElapsedTime(&d, a[i], b[i]));
-        t1[i] = t0[i] + d;
-    }
-    auto together = [&](int i, int j) { return std::min(t1[i], t1[j]) - std::max(t0[i], t0[j]) > 0.05f; };
-    bool ok = together(0, 1);
-    for (int j = 2; j < n && ok; ++j) { // pipeline j - 1 on xstream[j - 2]
-        for (int i = 0; i < j && ok; ++i) ok = together(i, j);
-        if (ok) *found = j;
-    }
-    return SG_OK;
-}
-
 extern "C" int sg_create(const sg_config *cfg, sg_handle **out)
 {
     if (!cfg || !out) return fail(nullptr, SG_ERR_INVALID, "sg_create: null argument");
@@ -387,6 +323,7 @@ extern "C" int sg_create(const sg_config *cfg, sg_handle **out)
     h->ped_serial = env_int("SG_PED_SERIAL", 0) != 0;
     h->crowd_kernel = env_int("SG_CROWD_KERNEL", 1);
     h->slice_mode = env_int("SG_SLICE", 1);
+    h->queue_mode = env_int("SG_QUEUE", 1);
     // the controller stream carries the serial chain of the table path (control_kernel_fast: 64 wavefronts that every rollout
     // launch waits for): highest stream priority, so that its launches are dispatched ahead of the rollout kernels'
     // (measured: no difference at 4096 x 64, where the launches never queue; SG_CTL_PRIO=0 creates it at the lowest)
@@ -402,16 +339,6 @@ extern "C" int sg_create(const sg_config *cfg, sg_handle **out)
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device) == hipSuccess && cus > 0) h->n_simd = 4 * cus;
         else (void)hipGetLastError();
-    }
-    {   // the rollout pipelines of the table path (launch_rollout): up to SG_TAB_SPLIT (default 3), as many as run side by side
-        const int want = std::min(3, std::max(1, env_int("SG_TAB_SPLIT", 3)));
-        bool ok = true;
-        for (int j = 1; j < want && ok; ++j) ok = hipStreamCreate(&h->xstream[j - 1]) == hipSuccess;
-        int rc = ok ? probe_pipelines(h, want) : SG_ERR_HIP;
-        if (rc) {
-            sg_destroy(h);
-            return fail(nullptr, SG_ERR_HIP, "sg_create: stream creation / pipeline probe failed");
-        }
     }
     *out = h;
     return SG_OK;
@@ -471,12 +398,13 @@ extern "C" int sg_destroy(sg_handle *h)
     if (h->d_normals) (void)hipFree(h->d_normals);
     for (int b = 0; b < 4; ++b)
         if (h->d_tab[b]) (void)hipFree(h->d_tab[b]);
+    if (h->d_qwords) (void)hipFree(h->d_qwords);
+    if (h->d_qtab) (void)hipFree(h->d_qtab);
+    if (h->q_host) (void)hipHostFree(h->q_host);
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->up_ev) (void)hipEventDestroy(e);
     if (h->up_stat) (void)hipHostFree(h->up_stat);
     if (h->ctl_stream) (void)hipStreamDestroy(h->ctl_stream);
-    for (hipStream_t &x : h->xstream)
-        if (x) { (void)hipStreamSynchronize(x); (void)hipStreamDestroy(x); }
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -499,27 +427,6 @@ static sg::TabGroups one_group(const sg_handle *h, const double *tab, int n_step
     tg.buf[0] = tab;
     tg.start0 = 0; tg.len0 = (unsigned)tg.gsz; tg.start1 = 0; tg.len1 = 0;
     return tg;
-}
-
-// the blocks of the active groups as (at most) two ranges of the launch's grid; more runs than that: the whole grid, idle
-// groups return at once
-static void set_ranges(sg::TabGroups &tg, int P, size_t nblk)
-{
-    unsigned st[3] = {0, 0, 0}, ln[3] = {0, 0, 0};
-    int runs = 0;
-    for (int g = 0; g < P; ++g) {
-        if (!((tg.active >> g) & 1)) continue;
-        const bool cont = g > 0 && ((tg.active >> (g - 1)) & 1);
-        const unsigned b0 = (unsigned)g * (unsigned)tg.gsz, b1 = (unsigned)std::min<size_t>(nblk, (size_t)(g + 1) * (size_t)tg.gsz);
-        if (!cont) {
-            if (++runs > 2) break;
-            st[runs - 1] = b0;
-            ln[runs - 1] = 0;
-        }
-        ln[runs - 1] += b1 > b0 ? b1 - b0 : 0;
-    }
-    if (runs > 2 || runs == 0) { tg.start0 = 0; tg.len0 = (unsigned)nblk; tg.start1 = 0; tg.len1 = 0; return; }
-    tg.start0 = st[0]; tg.len0 = ln[0]; tg.start1 = st[1]; tg.len1 = ln[1];
 }
 
 // grid of a launch of the one-wavefront-per-tile table kernels: the blocks of the active groups
@@ -690,7 +597,7 @@ static int launch_crowd_chunks(sg_handle *h, int n_steps, int do_reset, int forc
     if (do_reset && (rc = launch_main(h, 0, do_reset, 0, nullptr, nullptr, false, ev_next, nullptr))) return rc;
     const int chunk = std::max(1, env_int("SG_CROWD_CHUNK", 200));
     const dim3 grid((unsigned)R);
-    hipStream_t s1 = h->ctl_stream, s2 = h->xstream[0] ? h->xstream[0] : h->ctl_stream;
+    hipStream_t s1 = h->ctl_stream, s2 = h->ctl_stream;
     if (!h->overlap) s1 = s2 = h->stream;
     h->last_walk_chunks = 0;
     for (int k0 = 0; k0 < n_steps; k0 += chunk) {
@@ -736,6 +643,176 @@ static int launch_crowd_chunks(sg_handle *h, int n_steps, int do_reset, int forc
     return SG_OK;
 }
 
+// The table path as ONE launch (sgym_queue.hpp): the controller pre-pass and the rollout of every chunk of the time axis in one
+// grid of persistent wavefronts, work items (chunk, block) from a device-side counter.  `chunk` = the longest chunk.
+// Returns SG_OK, an error, or SG_QUEUE_FALLBACK: the table ring could not be allocated -- the caller takes the chunk launches.
+#define SG_QUEUE_FALLBACK 1
+static int launch_queue(sg_handle *h, int n_steps, int force, const double *d_actions, int chunk, size_t *ev_next)
+{
+    const size_t nblk = h->NE / 64, np = (size_t)h->p.n_ctl_pad, n_ctl_waves = np / 64;
+    // chunks of the time axis: short at first (the first rollout items cannot start before the pre-pass has written their chunk),
+    // growing by ~1.4x up to `chunk` -- the pre-pass is only 1.3 ... 1.9x faster per step than a rollout wavefront beside it, so
+    // chunk c + 1 has to be written in about the time chunk c takes to roll out: with lengths that doubled, a quarter of the
+    // wavefronts waited through the first 4 ms (tools/dbg/queue_timeline.py) -- and halving again at the end (the last items of
+    // the queue leave slots idle for as long as the longest of them runs).  SG_QUEUE_GROW: the growth in percent.
+    std::vector<int> len;
+    const int first = std::max(1, std::min(chunk, env_int("SG_QUEUE_FIRST", 96)));
+    const int grow = std::max(101, env_int("SG_QUEUE_GROW", 140));
+    for (int k0 = 0, n = 0; k0 < n_steps; k0 += n) {
+        const long long want = len.empty() ? first : std::max<long long>((long long)len.back() + 1, (long long)len.back() * grow / 100);
+        n = (int)std::min<long long>(std::min<long long>(chunk, want), n_steps - k0);
+        if (want >= chunk / 2 + chunk / 4 && want < chunk) n = std::min(chunk, n_steps - k0); // (no odd chunk just below the cap)
+        len.push_back(n);
+    }
+    while (len.size() > 1 && len.back() >= 2 * first && len.back() > 128) { // ..., L -> ..., L - L / 2, L / 2, repeated on the tail
+        const int L = len.back(), half = L / 2;
+        len.back() = L - half;
+        len.push_back(half);
+    }
+    const int C = (int)len.size();
+    if (C > sg::Q_MAX_CHUNKS) return SG_QUEUE_FALLBACK;
+    // the table ring: as many chunk buffers as the call has chunks when they fit a quarter of the free memory (no buffer is
+    // ever reused: the pre-pass never waits), else a ring of at least three
+    const size_t row = (size_t)sg::CT_PLANES * sg::CT_W * np;
+    const int ts = std::max(chunk, h->p.tab_steps);
+    const size_t buf_bytes = (size_t)(ts + 1) * row * sizeof(double);
+    int n_buf = C;
+    {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = (size_t)8 << 30; }
+        const size_t budget = std::min<size_t>((free_b + h->qtab_bytes) / 4, (size_t)std::max(1, env_int("SG_QUEUE_TAB_MB", 32768)) << 20);
+        n_buf = (int)std::min<size_t>((size_t)C, std::max<size_t>(3, budget / buf_bytes));
+        if (const int forced = env_int("SG_QUEUE_RING", 0)) n_buf = std::min(C, std::max(2, forced)); // (tests: a ring that is reused)
+    }
+    const size_t need = (size_t)n_buf * buf_bytes;
+    if (need > h->qtab_bytes) {
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        if (h->d_qtab) HIP_TRY(h, hipFree(h->d_qtab));
+        h->d_qtab = nullptr;
+        h->qtab_bytes = 0;
+        if (hipMalloc((void **)&h->d_qtab, need) != hipSuccess) {
+            (void)hipGetLastError();
+            h->d_qtab = nullptr;
+            return SG_QUEUE_FALLBACK;
+        }
+        h->qtab_bytes = need;
+    }
+    h->p.tab_steps = ts;
+    const bool q_trace = env_int("SG_QUEUE_DEBUG", 0) != 0;
+    const size_t words = (size_t)sg::Q_STATE_WORDS + n_ctl_waves + nblk + (size_t)sg::Q_MAX_CHUNKS + 1 + (size_t)sg::Q_SEATS + (q_trace ? nblk : 0);
+    if (words > h->qwords_cap) {
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        if (h->d_qwords) HIP_TRY(h, hipFree(h->d_qwords));
+        h->d_qwords = nullptr;
+        h->qwords_cap = 0;
+        HIP_TRY(h, hipMalloc((void **)&h->d_qwords, words * sizeof(unsigned)));
+        h->qwords_cap = words;
+    }
+    if (!h->q_host) HIP_TRY(h, hipHostMalloc((void **)&h->q_host, sg::Q_STATE_WORDS * sizeof(unsigned), hipHostMallocDefault));
+    HIP_TRY(h, hipMemsetAsync(h->d_qwords, 0, words * sizeof(unsigned), h->stream)); // every polled word, before every launch
+    sg::TabQueue tq{};
+    tq.state = h->d_qwords;
+    tq.ctl_prog = tq.state + sg::Q_STATE_WORDS;
+    tq.blk_prog = tq.ctl_prog + n_ctl_waves;
+    tq.chunk_cnt = tq.blk_prog + nblk;
+    tq.seats = tq.chunk_cnt + sg::Q_MAX_CHUNKS + 1;
+    tq.trace = q_trace ? tq.seats + sg::Q_SEATS : nullptr;
+    tq.defer_ticks = (long long)std::max(1, env_int("SG_QUEUE_DEFER_US", 30)) * 100ll; // 100 MHz
+    tq.tab = h->d_qtab;
+    tq.buf_doubles = buf_bytes / sizeof(double);
+    tq.actions = d_actions;
+    tq.timeout_ticks = (long long)std::max(1, env_int("SG_QUEUE_TIMEOUT_MS", 20000)) * 100000ll; // 100 MHz
+    tq.handoff = env_int("SG_QUEUE_HANDOFF", 1);
+    const char *times_path = getenv("SG_QUEUE_TIMES"); // experiment: per-item time stamps, dumped as u64 after the launch
+    static unsigned long long *d_times = nullptr;
+    static size_t times_cap = 0;
+    const size_t n_times = (size_t)C * nblk * 4 + n_ctl_waves * (size_t)C;
+    if (times_path && *times_path) {
+        if (n_times > times_cap) {
+            if (d_times) HIP_TRY(h, hipFree(d_times));
+            HIP_TRY(h, hipMalloc((void **)&d_times, n_times * 8));
+            times_cap = n_times;
+        }
+        HIP_TRY(h, hipMemsetAsync(d_times, 0, n_times * 8, h->stream));
+        tq.times = d_times;
+    }
+    tq.n_chunks = C;
+    tq.n_buf = n_buf;
+    tq.nblk = (int)nblk;
+    tq.n_ctl_waves = (int)n_ctl_waves;
+    tq.k0[0] = 0;
+    for (int c = 0; c < C; ++c) tq.k0[c + 1] = tq.k0[c] + len[(size_t)c];
+    // as many wavefronts as the device holds at once (three per SIMD), no more than there is work for
+    const size_t slots = (size_t)h->n_simd * (size_t)(h->planar ? SG_PLANAR_WAVES : SG_TAB_WAVES);
+    const unsigned grid = (unsigned)std::min(slots, n_ctl_waves + nblk);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc;
+    if ((rc = get_event(h, *ev_next, &e0)) || (rc = get_event(h, *ev_next + 1, &e1))) return rc;
+    static hipStream_t ws = nullptr; // SG_QUEUE_DEBUG: the watcher's stream and page-locked words, made before the launch
+    static unsigned *w = nullptr;
+    if (q_trace && !ws) {
+        HIP_TRY(h, hipStreamCreateWithFlags(&ws, hipStreamNonBlocking));
+        HIP_TRY(h, hipHostMalloc((void **)&w, (sg::Q_STATE_WORDS + 16) * sizeof(unsigned), hipHostMallocDefault));
+        HIP_TRY(h, hipMemcpyAsync(w, h->d_qwords, 64, hipMemcpyDeviceToHost, ws));
+        HIP_TRY(h, hipStreamSynchronize(ws));
+    }
+    HIP_TRY(h, hipEventRecord(e0, h->stream));
+    sgl::rollout_tabq(h->G, h->planar, dim3(grid), h->stream, h->p, h->cfg.timestep, force, tq);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipEventRecord(e1, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->q_host, h->d_qwords, sg::Q_STATE_WORDS * sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
+    h->q_pending = true;
+    if (tq.times) {
+        std::vector<unsigned long long> ht(n_times + 4);
+        HIP_TRY(h, hipMemcpyAsync(ht.data() + 4, d_times, n_times * 8, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        ht[0] = (unsigned long long)C; ht[1] = nblk; ht[2] = n_ctl_waves; ht[3] = grid;
+        if (FILE *f = fopen(times_path, "wb")) {
+            fwrite(ht.data(), 8, ht.size(), f);
+            fwrite(tq.k0, sizeof(int), (size_t)C + 1, f);
+            fclose(f);
+        }
+    }
+    if (const int dbg = env_int("SG_QUEUE_DEBUG", 0)) { // watch the queue words from the host while the launch runs (dbg x 100 ms)
+        fprintf(stderr, "queue: grid %u, %d chunks, ring %d, %zu blocks, %zu pre-pass wavefronts, first chunk %d steps\n", grid, C, n_buf, nblk, n_ctl_waves, len[0]);
+        const int us = std::max(50, env_int("SG_QUEUE_DEBUG_US", 100000));
+        const auto t_start = std::chrono::steady_clock::now();
+        for (int i = 0; i < dbg; ++i) {
+            std::this_thread::sleep_for(std::chrono::microseconds(us));
+            if (hipMemcpyAsync(w, h->d_qwords, (sg::Q_STATE_WORDS + 4) * sizeof(unsigned), hipMemcpyDeviceToHost, ws) != hipSuccess || hipStreamSynchronize(ws) != hipSuccess) break;
+            fprintf(stderr, "queue +%.2f ms: tickets %u head %u err %u items done %u | ctl_prog %u %u %u %u",
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(), w[0], w[1], w[2], w[3], w[8], w[9], w[10], w[11]);
+            unsigned *tr = w + sg::Q_STATE_WORDS + 8;
+            if (hipMemcpyAsync(tr, tq.trace, 8 * sizeof(unsigned), hipMemcpyDeviceToHost, ws) == hipSuccess && hipStreamSynchronize(ws) == hipSuccess)
+                fprintf(stderr, " | trace (chunk << 8 | stage) of blocks 0..7: %x %x %x %x %x %x %x %x", tr[0], tr[1], tr[2], tr[3], tr[4], tr[5], tr[6], tr[7]);
+            fprintf(stderr, "\n");
+            if (hipStreamQuery(h->stream) == hipSuccess) break;
+        }
+    }
+    h->launch_ev.push_back((int)*ev_next);
+    ++h->n_launches;
+    *ev_next += 2;
+    h->last_schedule = 2;
+    h->last_chunks = C;
+    h->last_ring = n_buf;
+    h->last_grid = (int)grid;
+    return SG_OK;
+}
+
+// after a synchronisation of h->stream: did the last queue launch run to its end?
+static int check_queue(sg_handle *h)
+{
+    if (!h->q_pending) return SG_OK;
+    h->q_pending = false;
+    const unsigned code = h->q_host[sg::Q_ERR];
+    if (code == 0) return SG_OK;
+    static const char *what[] = {"", "a rollout wavefront waited for the controller pre-pass", "a rollout wavefront waited for the previous chunk of its block",
+                                 "the controller pre-pass waited for a buffer of the table ring"};
+    return fail(h, SG_ERR_HIP, "sg_rollout: the persistent table launch gave up (%s longer than SG_QUEUE_TIMEOUT_MS; %u work items had finished): "
+                               "the state of the batch is undefined -- sg_reset / sg_upload before the next call", what[code < 4 ? code : 0],
+                h->q_host[sg::Q_ITEMS_DONE]);
+}
+
 static int launch_rollout_impl(sg_handle *h, int n_steps, int do_reset, int force, const double *d_actions);
 // Work of a failed call may still be running on the controller stream and the pipeline streams (the fan-out of the table
 // path joins them into h->stream only at its end): wait for it, so that a later sg_synchronize / sg_upload / table regrow,
@@ -743,8 +820,6 @@ static int launch_rollout_impl(sg_handle *h, int n_steps, int do_reset, int forc
 static void drain_streams(sg_handle *h)
 {
     if (h->ctl_stream) (void)hipStreamSynchronize(h->ctl_stream);
-    for (hipStream_t x : h->xstream)
-        if (x) (void)hipStreamSynchronize(x);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     (void)hipGetLastError();
 }
@@ -756,7 +831,7 @@ static int launch_rollout(sg_handle *h, int n_steps, int do_reset, int force, co
 }
 static int launch_rollout_impl(sg_handle *h, int n_steps, int do_reset, int force, const double *d_actions)
 {
-    h->last_pipes = 0;
+    h->last_schedule = 0;
     if (h->wide) {
         h->n_launches = 0;
         h->launch_ev.clear();
@@ -814,29 +889,24 @@ static int launch_rollout_impl(sg_handle *h, int n_steps, int do_reset, int forc
             int ch = (int)std::min<size_t>((size_t)chunk_steps, std::max<size_t>(1, ((size_t)1 << 27) / row));
             ch = std::min(ch, n_steps);
             if (rss_tab) ch = std::min(ch, std::max(1, h->rssq_steps)); // one launch fills at most the line-test queue
-            // Pipelines (sgym_device.hpp, TabGroups).  A launch of the one-wavefront-per-tile table kernels is as slow as its
-            // slowest wavefront, and a batch is rarely a whole number of rounds of the device's wavefront slots (4096
-            // wavefronts on 3 x 1024): with one launch at a time the slots idle at every launch boundary.  So the blocks are
-            // cut into H = 2 or 3 contiguous parts that run as launches of their own on their own streams, each part chunk
-            // after chunk: whenever one part's launch drains, wavefronts of the others take the slots.  All consume the same
-            // pre-pass tables (four buffers: the parts may be a chunk or two apart, the pre-pass ahead of them).  Results do
-            // not depend on it (scenarios never interact); SG_TAB_SPLIT=1: one pipeline.
-            const size_t nblk = h->NE / 64;
-            int H = 1;
-            const size_t per_pipe = (size_t)std::max(1, env_int("SG_TAB_SPLIT_MIN", h->n_simd)); // blocks a pipeline should at least have
-            if (h->WV == 1 && (!h->rss_fused || rss_tab) && !riders && !no_overlap && h->n_pipes > 1 && nblk >= 2 * per_pipe) {
-                // (a batch that does not fill the slots is latency-bound either way, and more launches only cost: measured
-                // 512 blocks 16.2 / 16.7 / 15.8 G with 1 / 2 / 3 pipelines, 1024: 31.6 / 31.4 / 29.2, 2048: 54.4 / 60.8 / 56.9,
-                // 4096: 67 / 90 / 95, 8192: 87.5 / 99.8 / 100.7)
-                H = (int)std::min<size_t>((size_t)h->n_pipes, nblk / per_pipe);
+            // one persistent launch (sgym_queue.hpp) where the batch is one wavefront per block and nothing rides along; the
+            // pre-pass role must leave most of the wavefront slots to the rollout
+            if (h->queue_mode && h->WV == 1 && !riders && !rss_tab && !no_overlap &&
+                (size_t)h->p.n_ctl_pad / 64 <= (size_t)h->n_simd / 2) {
+                rc = launch_queue(h, n_steps, force, d_actions, ch, &ev_next);
+                if (rc != SG_QUEUE_FALLBACK) {
+                    if (rc) return rc;
+                    if (h->timing_now) HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
+                    h->timed = h->timing_now;
+                    return SG_OK;
+                }
+                rc = SG_OK;
             }
-            h->last_pipes = H;
-            const int gsz = (int)std::max<size_t>(1, (nblk + H - 1) / H);
-            const int NB = H > 1 ? 4 : 2; // table buffers
-            // the pre-pass in launches of ctl_slice steps (its load then moves between SIMDs) -- but the planar kernel's three
-            // wavefronts (168 VGPRs each) leave it no room on a SIMD: with the pipelines keeping every slot taken, each of
-            // its launches waits for a wavefront to retire, so there it is one launch per chunk
-            const int ctl_slice = (H > 1 && ((h->planar ? SG_PLANAR_WAVES > 2 : SG_TAB_WAVES > 2) || rss_tab) && !env_int("SG_CTL_SLICE", 0)) ? ch : h->ctl_slice;
+            h->last_schedule = 1;
+            // The chunk launches of rounds 1-4 (crowds with riders, the RSS table variant, tiles of several wavefronts, SG_QUEUE=0):
+            // the pre-pass (its own stream) writes chunk c + 1 into the second table buffer while the rollout kernel reads chunk c
+            const int NB = 2; // table buffers
+            const int ctl_slice = h->ctl_slice; // the pre-pass in launches of ctl_slice steps (its load then moves between SIMDs)
             if (ch > h->p.tab_steps || (size_t)(h->p.tab_steps + 1) * row * sizeof(double) > h->tab_bytes || NB > h->n_tab) {
                 // grow: tab_steps + 1 rows per lane is part of the table addressing
                 const int ts = std::max(ch, h->p.tab_steps);
@@ -844,8 +914,6 @@ static int launch_rollout_impl(sg_handle *h, int n_steps, int do_reset, int forc
                 if (need > h->tab_bytes || NB > h->n_tab) { // (the buffers outlive sg_upload: the next batch of the same shape reuses them)
                     HIP_TRY(h, hipStreamSynchronize(h->stream));
                     HIP_TRY(h, hipStreamSynchronize(h->ctl_stream));
-                    for (hipStream_t x : h->xstream)
-                        if (x) HIP_TRY(h, hipStreamSynchronize(x));
                     for (int b = 0; b < 4; ++b) {
                         if (h->d_tab[b]) HIP_TRY(h, hipFree(h->d_tab[b]));
                         h->d_tab[b] = nullptr;
@@ -865,11 +933,9 @@ static int launch_rollout_impl(sg_handle *h, int n_steps, int do_reset, int forc
                 if ((rc = get_event(h, ev_next++, &e))) return rc;
                 HIP_TRY(h, hipEventRecord(e, h->stream));
                 HIP_TRY(h, hipStreamWaitEvent(cs, e, 0));
-                for (int j = 1; j < H; ++j) HIP_TRY(h, hipStreamWaitEvent(h->xstream[j - 1], e, 0));
             }
             const dim3 cgrid((unsigned)(np / 64));
             const bool rss_fast = env_int("SG_RSS_CTL_FAST", 1) != 0;
-            const bool tab_fast = H > 1 && !riders && !rss_tab && env_int("SG_TAB_CTL_FAST", 1) != 0;
             // chunks of the time axis: lengths double from two slices up to `ch` -- the rollout kernel cannot start before
             // the table of its chunk exists, and the pre-pass of the chunks after it (about 0.4x the rollout kernel's time
             // per step) then always finishes under the rollout kernel
@@ -880,23 +946,20 @@ static int launch_rollout_impl(sg_handle *h, int n_steps, int do_reset, int forc
                 cn.push_back(n);
             }
             const int C = (int)cn.size();
-            std::vector<hipEvent_t> ctl_done((size_t)C, nullptr), chunk_done[3];
-            for (auto &v : chunk_done) v.assign((size_t)C, nullptr);
+            std::vector<hipEvent_t> ctl_done((size_t)C, nullptr), chunk_done((size_t)C, nullptr);
             int ctl_issued = 0;
             auto issue_ctl = [&](int upto) -> int { // the pre-pass of the chunks up to `upto`, each into buffer (chunk mod NB)
                 for (; ctl_issued <= upto && ctl_issued < C; ++ctl_issued) {
                     const int c = ctl_issued, k0 = ck0[(size_t)c], n = cn[(size_t)c];
                     double *tab = h->d_tab[c % NB];
-                    if (!no_overlap && c >= NB) // the buffer is free once every pipeline is through chunk c - NB
-                        for (int j = 0; j < H; ++j) HIP_TRY(h, hipStreamWaitEvent(cs, chunk_done[j][(size_t)(c - NB)], 0));
+                    if (!no_overlap && c >= NB) // the buffer is free once the rollout is through chunk c - NB
+                        HIP_TRY(h, hipStreamWaitEvent(cs, chunk_done[(size_t)(c - NB)], 0));
                     for (int s0 = 0; s0 < n; s0 += ctl_slice) {
                         const int ns = std::min(ctl_slice, n - s0);
                         if (riders)
                             sgl::control(sgl::CTL_RIDERS, cgrid, cs, h->p, h->cfg.timestep, ns, c == 0 && s0 == 0, k0 + s0, d_actions, tab, s0, 0);
                         else if (rss_tab && rss_fast) // (the ego's metrics are the rollout kernel's, from its own velocities)
                             sgl::control(sgl::CTL_FAST, cgrid, cs, h->p, h->cfg.timestep, ns, c == 0 && s0 == 0, k0 + s0, d_actions, tab, s0, 0);
-                        else if (tab_fast) // (pipelines: the pre-pass chain is the critical path -- its straight-line form)
-                            sgl::control(sgl::CTL_FAST, cgrid, cs, h->p, h->cfg.timestep, ns, c == 0 && s0 == 0, k0 + s0, d_actions, tab, s0, 1);
                         else
                             sgl::control(sgl::CTL_GENERAL, cgrid, cs, h->p, h->cfg.timestep, ns, c == 0 && s0 == 0, k0 + s0, d_actions, tab, s0,
                                          rss_tab ? 0 : 1);
@@ -913,24 +976,12 @@ static int launch_rollout_impl(sg_handle *h, int n_steps, int do_reset, int forc
             for (int c = 0; c < C; ++c) {
                 // (chunk c + NB - 1 goes into the buffer of chunk c - 1, whose launches were queued by the previous iteration)
                 if ((rc = issue_ctl(std::min(C - 1, c + NB - 1)))) return rc;
-                for (int j = 0; j < H; ++j) {
-                    sg::TabGroups tg{};
-                    const int b = c % NB;
-                    tg.gsz = gsz;
-                    tg.active = 1ull << j;
-                    tg.bufof[0] = (unsigned long long)b << (2 * j);
-                    tg.n[b] = cn[(size_t)c];
-                    tg.buf[b] = h->d_tab[b];
-                    set_ranges(tg, H, nblk);
-                    if (j > 0) std::swap(h->stream, h->xstream[j - 1]); // (launch_main works on h->stream)
-                    const hipError_t we = no_overlap ? hipSuccess : hipStreamWaitEvent(h->stream, ctl_done[(size_t)c], 0);
-                    rc = we == hipSuccess ? launch_main(h, cn[(size_t)c], 0, force, nullptr, h->d_tab[b], true, &ev_next, &tg) : SG_ERR_HIP;
-                    if (j > 0) std::swap(h->stream, h->xstream[j - 1]);
-                    if (rc) return we == hipSuccess ? rc : fail(h, SG_ERR_HIP, "sg_rollout: hipStreamWaitEvent failed");
-                    chunk_done[j][(size_t)c] = h->ev_pool[ev_next - 1];
-                }
+                const int b = c % NB;
+                const sg::TabGroups tg = one_group(h, h->d_tab[b], cn[(size_t)c]);
+                if (!no_overlap) HIP_TRY(h, hipStreamWaitEvent(h->stream, ctl_done[(size_t)c], 0));
+                if ((rc = launch_main(h, cn[(size_t)c], 0, force, nullptr, h->d_tab[b], true, &ev_next, &tg))) return rc;
+                chunk_done[(size_t)c] = h->ev_pool[ev_next - 1];
             }
-            for (int j = 1; j < H; ++j) HIP_TRY(h, hipStreamWaitEvent(h->stream, chunk_done[j][(size_t)(C - 1)], 0)); // join
         }
     }
     if (rc) return rc;
@@ -1673,7 +1724,7 @@ extern "C" int sg_step(sg_handle *h, int32_t n_steps, const double *actions, int
     }
     if (rc) return rc;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    return SG_OK;
+    return check_queue(h);
 }
 
 // device scratch shared by the observation entry points: a tick of an RL loop calls them once per step, a hipMalloc /
@@ -1838,7 +1889,7 @@ extern "C" int sg_rollout(sg_handle *h, int32_t max_steps)
     int rc = sg_rollout_async(h, max_steps, 1);
     if (rc) return rc;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    return SG_OK;
+    return check_queue(h);
 }
 
 extern "C" int sg_synchronize(sg_handle *h)
@@ -1846,7 +1897,7 @@ extern "C" int sg_synchronize(sg_handle *h)
     if (!h) return SG_ERR_INVALID;
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    return SG_OK;
+    return check_queue(h);
 }
 
 extern "C" void *sg_stream(sg_handle *h) { return h ? (void *)h->stream : nullptr; }
@@ -1889,6 +1940,7 @@ extern "C" int sg_read_metrics(sg_handle *h, sg_metrics *out, sg_event *events, 
     sg_scenario_state *sd = static_cast<sg_scenario_state *>(h->pin_sd);
     HIP_TRY(h, hipMemcpyAsync(sd, p.sdyn, (size_t)R * sizeof(sg_scenario_state), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if ((rc0 = check_queue(h))) return rc0;
     int64_t total = 0;
     bool overflow = false;
     for (int r = 0; r < R; ++r) {
@@ -1979,7 +2031,7 @@ extern "C" int sg_copy_to_host(sg_handle *h, const void *device_ptr, void *host_
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     HIP_TRY(h, hipMemcpy(host_ptr, device_ptr, bytes, hipMemcpyDeviceToHost));
-    return SG_OK;
+    return check_queue(h);
 }
 
 extern "C" int sg_last_kernel_ms(sg_handle *h, float *ms)
@@ -2056,18 +2108,17 @@ extern "C" int sg_crowd_walk_stats(sg_handle *h, int32_t *out, int32_t reset)
     return SG_OK;
 }
 
-extern "C" int sg_pipeline_info(sg_handle *h, int32_t *info)
+extern "C" int sg_schedule_info(sg_handle *h, int32_t *info)
 {
     if (!h || !info) return SG_ERR_INVALID;
-    const char *q = getenv("GPU_MAX_HW_QUEUES");
-    info[0] = h->pipes_wanted;
-    info[1] = h->n_pipes;
-    info[2] = h->last_pipes;
-    info[3] = (q && *q) ? atoi(q) : 4; // HIP's default
-    info[4] = h->pipes_pinned;
+    info[0] = h->last_schedule;
+    info[1] = h->last_schedule == 2 ? h->last_chunks : 0;
+    info[2] = h->last_schedule == 2 ? h->last_ring : 0;
+    info[3] = h->last_schedule == 2 ? h->last_grid : 0;
+    info[4] = h->p.n_ctl_pad / 64;
     info[5] = (int32_t)std::min<size_t>(0x7fffffff, h->NE / 64);
     info[6] = h->n_simd;
-    info[7] = 0;
+    info[7] = h->n_launches;
     return SG_OK;
 }
 

@@ -9,6 +9,7 @@
 #include "sgym_device.hpp"
 #include "sgym_walk.hpp"
 #include "sgym_wide.hpp"
+#include "sgym_queue.hpp"
 
 namespace sgl {
 
@@ -45,6 +46,8 @@ void rss_lines(dim3 grid, hipStream_t s, const sg::Params &p, const sg::TabGroup
 void rollout_road(int G, int WV, dim3 grid, hipStream_t s, const RolloutArgs &a);
 // k_tab.hip: rollout_kernel_tab<G> / rollout_kernel_tab_planar<G>
 void rollout_tab(int G, bool planar, dim3 grid, hipStream_t s, const sg::Params &p, double timestep, int force, const sg::TabGroups &tg);
+// k_tabq.hip (sgym_queue.hpp): rollout_kernel_tabq<G> / rollout_kernel_tabq_planar<G> -- the table path as one persistent launch
+void rollout_tabq(int G, bool planar, dim3 grid, hipStream_t s, const sg::Params &p, double timestep, int force, const sg::TabQueue &tq);
 // k_slice.hip: rollout_kernel_slice<G> / rollout_kernel_slice_tab<G> (tab != nullptr)
 void rollout_slice(int G, dim3 grid, hipStream_t s, const sg::Params &p, double timestep, const sg::SliceArgs &sa, const double *tab);
 // k_ctl.hip: the controller pre-pass.  which: 0 control_kernel, 1 control_kernel_riders, 2 control_kernel_fast

@@ -89,7 +89,8 @@ struct WalkSel {
 // like everything else it needs in the clock.
 template <int G, int WV, bool PED, bool TAB, bool HAST, bool ROAD = false, bool RSSV = false, bool CROWD = false, bool SLICE = false,
           bool PLANAR = false, bool RIDERS = false, bool CTAB = false>
-__device__ __forceinline__ void rollout_body(
+__device__ __forceinline__ void rollout_body_l(
+    TileLds<64 * WV, PED, CROWD> &lds /* the workgroup's LDS tile: the entry point owns it (rollout_kernel_tabq shares it between roles) */,
     const Params &p, double timestep, int n_steps, int do_reset, int force, const double *actions /*[n][R][2]*/,
     const double *tab /*controller table planes*/, const SliceArgs &sa = SliceArgs{},
     const unsigned bx_arg = ~0u /* the 64-slot block (WV == 1) / scenario of this workgroup when it is not bx: TabGroups */,
@@ -111,7 +112,6 @@ __device__ __forceinline__ void rollout_body(
     // lane in 64) is not compiled into this kernel at all.
     static_assert(!CTAB || (!TAB && !PED && !CROWD), "CTAB: table rows into an in-kernel-controller variant");
     constexpr int NS = 64 * WV;
-    __shared__ TileLds<NS, PED, CROWD> lds;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t voff = lane * 8u;
     // one wavefront = one 64-slot block of the state arrays: wave-uniform block pointers
@@ -1112,6 +1112,18 @@ __device__ __forceinline__ void rollout_body(
             sd.n_events = n_ev;
         }
     }
+}
+
+// the ordinary form: the LDS tile belongs to this call
+template <int G, int WV, bool PED, bool TAB, bool HAST, bool ROAD = false, bool RSSV = false, bool CROWD = false, bool SLICE = false,
+          bool PLANAR = false, bool RIDERS = false, bool CTAB = false>
+__device__ __forceinline__ void rollout_body(
+    const Params &p, double timestep, int n_steps, int do_reset, int force, const double *actions, const double *tab,
+    const SliceArgs &sa = SliceArgs{}, const unsigned bx_arg = ~0u, const WalkSel &sel = WalkSel{nullptr, nullptr, 0})
+{
+    __shared__ TileLds<64 * WV, PED, CROWD> lds;
+    rollout_body_l<G, WV, PED, TAB, HAST, ROAD, RSSV, CROWD, SLICE, PLANAR, RIDERS, CTAB>(lds, p, timestep, n_steps, do_reset, force, actions, tab,
+                                                                                       sa, bx_arg, sel);
 }
 
 // The blocks a launch of a table variant works on (launch_rollout): the 64-slot blocks of the batch are cut into groups of

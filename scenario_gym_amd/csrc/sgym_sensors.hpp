@@ -305,6 +305,42 @@ __device__ inline int sg_classify_collision(const double *eb, double ex, double 
 // (type packed with k, the step inside the launch) take the controlled ego's pose at that step from the table row and become
 // ordinary pending events.  A few loads and stores per event; the classification itself waits for sg_read_metrics.
 // (`tg`: the block groups of that launch -- the scenario's group says which buffer its rows are in)
+// event i of scenario r, if a table-variant launch packed it (type >= 16): the controlled ego's (and a controlled hazard's)
+// pose at that step from the table rows of `tab`, the event becomes an ordinary pending one
+__device__ __forceinline__ void event_take_table_pose(const Params &p, int r, int i, const double *tab, bool from_tab, int64_t ectl)
+{
+    sg_event &ev = p.events[(size_t)r * p.ev_cap + i];
+    if (ev.type < 16) return; // not packed: recorded by another launch
+    const int k_launch = (ev.type >> 4) - 1, base = ev.type & 15;
+    if (from_tab) {
+        const double *row = tab + ((size_t)ectl * (size_t)(p.tab_steps + 1) + (size_t)k_launch) * CT_W;
+        double *ep = p.ev_pose + ((size_t)r * p.ev_cap + i) * 3;
+        ep[0] = row[CT_X]; ep[1] = row[CT_Y]; ep[2] = row[CT_H];
+    }
+    {   // a hazard that is a controlled agent: its pose at that step is a row of the table as well
+        const uint32_t hidx = (uint32_t)r * p.EP + ev.other;
+        const LanePtr hst(p.stat + (size_t)(hidx >> 6) * (ST_COUNT * 64), (hidx & 63) * 8u);
+        const int64_t hctl = fld<int64_t>(hst, ST_CTL);
+        const int hkind = (int)(fld<int64_t>(hst, ST_META) & 0xff);
+        double *hp = p.ev_hpose + ((size_t)r * p.ev_cap + i) * 3;
+        if (hctl >= 0 && (hkind == SG_KIND_AGENT_PID || hkind == SG_KIND_AGENT_VEHICLE)) {
+            const double *row = tab + ((size_t)hctl * (size_t)(p.tab_steps + 1) + (size_t)k_launch) * CT_W;
+            hp[0] = row[CT_X]; hp[1] = row[CT_Y]; hp[2] = row[CT_H];
+        } else {
+            hp[0] = hp[1] = hp[2] = __builtin_nan("");
+        }
+    }
+    ev.type = base == 15 ? -1 : base;
+}
+// is scenario r's ego a lane of the controller table, and which column
+__device__ __forceinline__ bool ego_table_column(const Params &p, int r, int64_t &ectl)
+{
+    const uint32_t eidx = (uint32_t)r * p.EP + p.sstat[r].ego;
+    const LanePtr est(p.stat + (size_t)(eidx >> 6) * (ST_COUNT * 64), (eidx & 63) * 8u);
+    ectl = fld<int64_t>(est, ST_CTL);
+    const int ekind = (int)(fld<int64_t>(est, ST_META) & 0xff);
+    return ectl >= 0 && (ekind == SG_KIND_AGENT_PID || ekind == SG_KIND_AGENT_VEHICLE);
+}
 #ifdef SG_UNIT_MAIN // (emitted by the one object that launches it: csrc/Makefile, sgym_launch.hpp)
 static __global__ __launch_bounds__(64) void event_ego_pose_kernel(Params p, TabGroups tg)
 {
@@ -314,35 +350,9 @@ static __global__ __launch_bounds__(64) void event_ego_pose_kernel(Params p, Tab
     int n_launch;
     const double *tab;
     if (!tg.pick((unsigned)(((size_t)r * p.EP) >> 6), n_launch, tab)) return; // (its group sat the launch out: nothing packed)
-    const uint32_t eidx = (uint32_t)r * p.EP + p.sstat[r].ego;
-    const LanePtr est(p.stat + (size_t)(eidx >> 6) * (ST_COUNT * 64), (eidx & 63) * 8u);
-    const int64_t ectl = fld<int64_t>(est, ST_CTL);
-    const int ekind = (int)(fld<int64_t>(est, ST_META) & 0xff);
-    const bool from_tab = ectl >= 0 && (ekind == SG_KIND_AGENT_PID || ekind == SG_KIND_AGENT_VEHICLE);
-    for (int i = threadIdx.x; i < n; i += 64) {
-        sg_event &ev = p.events[(size_t)r * p.ev_cap + i];
-        if (ev.type < 16) continue; // not packed: recorded by another launch
-        const int k_launch = (ev.type >> 4) - 1, base = ev.type & 15;
-        if (from_tab) {
-            const double *row = tab + ((size_t)ectl * (size_t)(p.tab_steps + 1) + (size_t)k_launch) * CT_W;
-            double *ep = p.ev_pose + ((size_t)r * p.ev_cap + i) * 3;
-            ep[0] = row[CT_X]; ep[1] = row[CT_Y]; ep[2] = row[CT_H];
-        }
-        {   // a hazard that is a controlled agent: its pose at that step is a row of the table as well
-            const uint32_t hidx = (uint32_t)r * p.EP + ev.other;
-            const LanePtr hst(p.stat + (size_t)(hidx >> 6) * (ST_COUNT * 64), (hidx & 63) * 8u);
-            const int64_t hctl = fld<int64_t>(hst, ST_CTL);
-            const int hkind = (int)(fld<int64_t>(hst, ST_META) & 0xff);
-            double *hp = p.ev_hpose + ((size_t)r * p.ev_cap + i) * 3;
-            if (hctl >= 0 && (hkind == SG_KIND_AGENT_PID || hkind == SG_KIND_AGENT_VEHICLE)) {
-                const double *row = tab + ((size_t)hctl * (size_t)(p.tab_steps + 1) + (size_t)k_launch) * CT_W;
-                hp[0] = row[CT_X]; hp[1] = row[CT_Y]; hp[2] = row[CT_H];
-            } else {
-                hp[0] = hp[1] = hp[2] = __builtin_nan("");
-            }
-        }
-        ev.type = base == 15 ? -1 : base;
-    }
+    int64_t ectl;
+    const bool from_tab = ego_table_column(p, r, ectl);
+    for (int i = threadIdx.x; i < n; i += 64) event_take_table_pose(p, r, i, tab, from_tab, ectl);
 }
 #endif // SG_UNIT_MAIN
 

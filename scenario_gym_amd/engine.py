@@ -359,12 +359,13 @@ class RolloutEngine:
         self._check(self.lib.sg_last_launch_gross_ms(self.h, C.byref(ms)), "sg_last_launch_gross_ms")
         return ms.value
 
-    def pipeline_info(self):
-        """The launch schedule of the table path (sg_pipeline_info): pipelines asked for / found by the probe at sg_create (or
-        pinned with SG_PIPELINES) / run by the last call, GPU_MAX_HW_QUEUES as the process sees it."""
+    def schedule_info(self):
+        """The launch schedule of the last rollout / step call (sg_schedule_info): schedule 0 = not the table path, 1 = chunk
+        launches, 2 = one persistent launch (csrc/sgym_queue.hpp); its chunks, table-ring buffers and wavefronts; the
+        pre-pass wavefronts, blocks and SIMDs; the rollout-kernel launches of the call."""
         v = (C.c_int32 * 8)()
-        self._check(self.lib.sg_pipeline_info(self.h, v), "sg_pipeline_info")
-        return dict(wanted=v[0], found=v[1], used_last_call=v[2], hw_queues=v[3], pinned=bool(v[4]), blocks=v[5], simds=v[6])
+        self._check(self.lib.sg_schedule_info(self.h, v), "sg_schedule_info")
+        return dict(schedule=v[0], chunks=v[1], ring=v[2], grid=v[3], ctl_waves=v[4], blocks=v[5], simds=v[6], launches=v[7])
 
     def crowd_walk_stats(self, reset=False):
         """Chunked crowd rollouts (sg_crowd_walk_stats): scenario-chunks per kernel class, early stops, chunks of the last call."""

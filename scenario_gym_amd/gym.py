@@ -271,6 +271,10 @@ class BatchedScenarioGym:
             net_of.append(index[id(rn)])
         self.engine.set_road_networks(nets, net_of)
         self._roads_set = True
+        # flags cached before the upload were computed without a road index (ego_off_road set for everybody): the answer must
+        # not depend on which terminal condition was asked first
+        if self._fut is not None:
+            self._fut.pop(("term",), None)
 
     def _raster_map(self, layers, width, height, nw, nh):
         """[R][n_layers][nh][nw] of RasterizedMapSensor layers (names of sensor/map.py:44-53), cached per state."""

@@ -153,12 +153,13 @@ int main(void)
         CHECK(sg_host_free(pk));
     }
 
-    /* the launch schedule the handle got (sg_pipeline_info), and the behaviour model switch: refused after sg_upload unless it
-     * is the one in force */
+    /* the launch schedule of the last call (sg_schedule_info: 0 not the table path, 1 chunk launches, 2 the persistent
+     * launch), and the behaviour model switch: refused after sg_upload unless it is the one in force */
     {
         int32_t info[8];
-        CHECK(sg_pipeline_info(h, info));
-        bad |= info[0] < 1 || info[0] > 3 || info[1] < 1 || info[1] > info[0] || info[6] <= 0;
+        CHECK(sg_schedule_info(h, info));
+        bad |= info[0] < 0 || info[0] > 2 || (info[0] == 2 && (info[1] < 1 || info[2] < 1 || info[2] > info[1] || info[3] < 1)) ||
+               info[5] <= 0 || info[6] <= 0;
         CHECK(sg_set_ped_behaviour(h, SG_PED_SOCIAL_FORCE));
         bad |= sg_set_ped_behaviour(h, SG_PED_RANDOM_WALK) != SG_ERR_STATE || sg_set_ped_behaviour(h, 7) != SG_ERR_INVALID;
     }

@@ -570,7 +570,7 @@ def main():
     if ONLY:  # regenerate a single group without touching the others
         groups = {"pedestrian": g_pedestrian(np.random.default_rng(20240808))} if "pedestrian" in ONLY else {}
         for name, d in groups.items():
-            path = os.path.join(HERE, name + ".npz")
+            path = os.path.join(os.environ.get("SG_GOLDEN_OUT", HERE), name + ".npz")
             np.savez_compressed(path, **d)
             print(f"{name}: {len(d)} arrays, {os.path.getsize(path) / 1e6:.2f} MB")
         return
@@ -584,7 +584,7 @@ def main():
     )
     groups["pedestrian"] = g_pedestrian(np.random.default_rng(20240808))
     for name, d in groups.items():
-        path = os.path.join(HERE, name + ".npz")
+        path = os.path.join(os.environ.get("SG_GOLDEN_OUT", HERE), name + ".npz")
         np.savez_compressed(path, **d)
         print(f"{name}: {len(d)} arrays, {os.path.getsize(path) / 1e6:.2f} MB")
 

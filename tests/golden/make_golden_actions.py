@@ -83,7 +83,7 @@ def main():
         out[f"{tag}/to_dict_actions"] = np.array(json.dumps([a.to_dict() for a in s.actions]))
         print(tag, len(acts), "actions,", int(np.isfinite(out[f"{tag}/apply_times"]).sum()), "applied,", len(times) - 1, "steps",
               out[f"{tag}/entity_state"])
-    np.savez_compressed(os.path.join(HERE, "actions.npz"), **out)
+    np.savez_compressed(os.path.join(os.environ.get("SG_GOLDEN_OUT", HERE), "actions.npz"), **out)
 
 
 if __name__ == "__main__":

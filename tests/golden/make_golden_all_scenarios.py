@@ -86,7 +86,7 @@ def main():
             out[f"{n}/metric_{key}"] = np.float64(m[key])
         print(n, E, k, m)
     out["names"] = np.array(names)
-    np.savez_compressed(os.path.join(HERE, "all_scenarios.npz"), **out)
+    np.savez_compressed(os.path.join(os.environ.get("SG_GOLDEN_OUT", HERE), "all_scenarios.npz"), **out)
 
 
 if __name__ == "__main__":

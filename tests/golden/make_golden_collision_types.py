@@ -89,7 +89,7 @@ def main():
     out["types"] = np.array(TYPES)
     allt = np.concatenate([out[f"{n}/ev_type"] for n in names])
     print("events", total, {TYPES[k]: int((allt == k).sum()) for k in range(6)})
-    np.savez_compressed(os.path.join(HERE, "collision_types.npz"), **out)
+    np.savez_compressed(os.path.join(os.environ.get("SG_GOLDEN_OUT", HERE), "collision_types.npz"), **out)
 
 
 if __name__ == "__main__":

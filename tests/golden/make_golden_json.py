@@ -93,7 +93,7 @@ def make_json():
                     out[f"{n}/embedded/{k}"] = np.array(digest_list(v))
                     out[f"{n}/embedded_n/{k}"] = np.array(len(v))
     out["names"] = np.array(names)
-    np.savez_compressed(os.path.join(HERE, "json.npz"), **out)
+    np.savez_compressed(os.path.join(os.environ.get("SG_GOLDEN_OUT", HERE), "json.npz"), **out)
     print("json.npz:", len(out), "arrays,", names)
 
 
@@ -162,7 +162,7 @@ def make_elevation():
         out["n_entities"] = np.array(len(s.entities))
         for i, e in enumerate(gym.state.scenario.entities):
             out[f"recorded_{i}"] = np.asarray(rec[e])
-    np.savez_compressed(os.path.join(HERE, "elevation.npz"), **out)
+    np.savez_compressed(os.path.join(os.environ.get("SG_GOLDEN_OUT", HERE), "elevation.npz"), **out)
     print("elevation.npz:", len(out), "arrays; z range", out["query_z"].min(), out["query_z"].max())
 
 

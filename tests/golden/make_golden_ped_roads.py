@@ -107,7 +107,7 @@ def main():
             rec = MG.record_rollout(gym, extra=extra)
             out.update(MG.flat(f"loop{si}/{dt_name}", rec))
             print(si, dt_name, len(rec["t"]), "max |force|", float(np.nanmax(np.abs(np.array(rec["extra"])[:, :, 2:]))))
-    np.savez_compressed(os.path.join(HERE, "ped_roads.npz"), **out)
+    np.savez_compressed(os.path.join(os.environ.get("SG_GOLDEN_OUT", HERE), "ped_roads.npz"), **out)
 
 
 if __name__ == "__main__":

@@ -70,7 +70,7 @@ def main():
         used = int(np.argmax(stream == nxt))
         assert stream[used] == nxt
         out[f"loop{si}/variates_used"] = np.int64(used)
-    path = os.path.join(HERE, "random_walk.npz")
+    path = os.path.join(os.environ.get("SG_GOLDEN_OUT", HERE), "random_walk.npz")
     np.savez_compressed(path, **out)
     print(f"random_walk: {len(out)} arrays, {os.path.getsize(path) / 1e6:.2f} MB; variates used:",
           [int(out[f'loop{i}/variates_used']) for i in range(len(cases))])

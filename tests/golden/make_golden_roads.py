@@ -167,7 +167,7 @@ def main():
             out[f"{key}/t"] = np.array(ts)
             out[f"{key}/final_ego"] = np.array(gym.state.poses[s.ego])
             print(key, len(ts) - 1, ts[-1], "length", s.length)
-    np.savez_compressed(os.path.join(HERE, "roads.npz"), **out)
+    np.savez_compressed(os.path.join(os.environ.get("SG_GOLDEN_OUT", HERE), "roads.npz"), **out)
 
 
 if __name__ == "__main__":

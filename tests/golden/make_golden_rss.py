@@ -120,7 +120,7 @@ def main():
         names.append(n)
         print(n, len(t), "long", slong, "lat", slat, np.bincount(codes[codes >= 0], minlength=7))
     out["names"] = np.array(names)
-    np.savez_compressed(os.path.join(HERE, "rss.npz"), **out)
+    np.savez_compressed(os.path.join(os.environ.get("SG_GOLDEN_OUT", HERE), "rss.npz"), **out)
 
 
 if __name__ == "__main__":

@@ -64,7 +64,7 @@ def main():
             out[f"{n}/{dtn}/t"] = np.array(ts)
             out[f"{n}/{dtn}/future"] = np.array(flags, np.uint8)  # [steps + 1][horizon]
             print(n, dtn, len(ts), np.array(flags).sum(0))
-    np.savez_compressed(os.path.join(HERE, "sensors.npz"), **out)
+    np.savez_compressed(os.path.join(os.environ.get("SG_GOLDEN_OUT", HERE), "sensors.npz"), **out)
 
 
 if __name__ == "__main__":

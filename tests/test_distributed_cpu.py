@@ -116,9 +116,10 @@ def test_bench_dispatch_and_collection_strong_scaling(tmp_path):
     assert len(line["per_rank_value"]) == 2 and len(line["weak"]["per_rank_value"]) == 2
     ent_steps = 2 * 64 * 6 * 40 * 2  # ranks x scenarios x entities x T x timed passes
     assert abs(line["value"] * line["ms_per_step"] * 1e-3 * 2 - ent_steps) < 1e-6 * ent_steps
-    # (no counted flops for this toy shape: the contract's HBM figure stands in; the stand-in engine has no pipelines)
+    # (no counted flops for this toy shape: the contract's HBM figure stands in; the stand-in engine has no schedule to report,
+    # and the line says which engine produced it)
     assert line["roofline"]["bound"] == "hbm" and line["roofline"]["binding"] == "valu_issue" and line["roofline"]["traffic"] is None
-    assert line["roofline"]["pipelines"] is None and "degraded" not in line
+    assert line["roofline"]["schedule"] is None and "degraded" not in line and line["engine"] == "injected stand-in (tests)"
     assert line["roofline"]["entity_steps_per_launch"] == 64 * 6 * 40 / 2
 
 
@@ -142,5 +143,6 @@ def test_bench_py_starts_its_own_ranks(tmp_path):
     assert line["ranks"] == 2 and line["n_gpus"] == 2 and line["backend"] == "gloo" and line["scaling"] == "weak"
     assert line["config"]["scenarios_per_gpu"] == 128 and line["strong"]["scenarios_per_gpu"] == 64
     assert len(line["per_rank_value"]) == 2 and len(line["strong"]["per_rank_value"]) == 2
+    assert line["engine"] == "tests.standin_engine:make"
     ent_steps = 2 * 128 * 6 * 40 * 2
     assert abs(line["value"] * line["ms_per_step"] * 1e-3 * 2 - ent_steps) < 1e-6 * ent_steps

@@ -1044,14 +1044,17 @@ def test_controller_prepass_equals_inline_controllers(sga, ego_kind, terminal):
         assert bits_equal(t, t0) and bits_equal(poses, poses0)
 
 
+SCHED_CHUNKS, SCHED_QUEUE = 1, 2  # sg_schedule_info()[0]: chunk launches / one persistent launch (sgym_queue.hpp)
+
+
 @pytest.mark.parametrize("E,ego_kind,zpr", [(64, "pid", False), (24, "vehicle", False), (12, "pid", False), (64, "pid", True), (30, "pid", True)])
-def test_rollout_pipelines_equal_one_pipeline(sga, monkeypatch, E, ego_kind, zpr):
-    """The table path runs large batches as two or three pipelines -- parts of the blocks as launches of their own on their
-    own streams, sharing the pre-pass tables through four buffers (launch_rollout) -- when the batch has at least
-    SG_TAB_SPLIT_MIN blocks; lowered here so that small batches take it too: one, two and three pipelines leave the same bits
-    (every recorded pose, final state, controller state, metrics, events), with many chunk boundaries (the buffers are
-    recycled several times), for the planar and the general table kernel, 64-lane and narrow tiles, rollouts and forced
-    steps with external actions, and a rollout continued in pieces."""
+def test_queue_launch_equals_chunk_launches(sga, monkeypatch, E, ego_kind, zpr):
+    """The table path runs as ONE persistent launch (rollout_kernel_tabq: pre-pass and rollout roles in one grid, work items
+    (chunk, block) from a device-side counter, the table ring as large as the call) -- and, with SG_QUEUE=0, as the chunk
+    launches of rounds 1-4 on two streams.  Same bits either way (every recorded pose, final state, controller state,
+    metrics, events), with many chunk boundaries, with a table ring of two buffers that the pre-pass has to wait for, for the
+    planar and the general table kernel, 64-lane and narrow tiles, rollouts and forced steps with external actions, and a
+    rollout continued in pieces.  Which schedule ran is what the handle says it ran: nothing here depends on timing."""
     import scenario_gym_amd._lib as L
     from scenario_gym_amd import synthetic
 
@@ -1063,10 +1066,10 @@ def test_rollout_pipelines_equal_one_pipeline(sga, monkeypatch, E, ego_kind, zpr
         packed.knots[:, 3] = rng.normal(0.0, 1.0, len(packed.knots))
         packed.knots[:, 5] = rng.normal(0.0, 0.1, len(packed.knots))
     acts = synthetic.make_actions(steps, R) if ego_kind == "vehicle" else None
-    monkeypatch.setenv("SG_TAB_SPLIT_MIN", "4")
-    runs, pipes, launches = [], [], []
-    for split in ("1", "2", "3"):
-        monkeypatch.setenv("SG_TAB_SPLIT", split)
+    runs, pieces, sched = [], [], []
+    for queue, ring in (("0", "0"), ("1", "0"), ("1", "2")):
+        monkeypatch.setenv("SG_QUEUE", queue)
+        monkeypatch.setenv("SG_QUEUE_RING", ring)
         runs.append(_engine_run(sga, packed, 1 / 30, steps, terminal=["max_length", "ego_collision"], actions=acts, ev_cap=128,
                                 tuning=dict(tab_min_steps=1, chunk_steps=16)))
         # ... and continued in pieces
@@ -1076,10 +1079,11 @@ def test_rollout_pipelines_equal_one_pipeline(sga, monkeypatch, E, ego_kind, zpr
         eng.rollout(40)
         eng.rollout_async(70, do_reset=False)
         eng.step(30)
-        pipes.append((eng.state(), eng.metrics()))
-        launches.append(eng.last_launch_stats()[0])
+        pieces.append((eng.state(), eng.metrics()))
+        sched.append(eng.schedule_info())
         eng.close()
-    assert launches[2] > launches[0] and launches[1] > launches[0], launches  # the pipelines did run as launches of their own
+    assert [s["schedule"] for s in sched] == [SCHED_CHUNKS, SCHED_QUEUE, SCHED_QUEUE], sched
+    assert sched[1]["ring"] == sched[1]["chunks"] >= 2 and sched[2]["ring"] == 2 and sched[2]["launches"] == 1, sched
     st0, rows0, ev0, t0, poses0 = runs[0]
     if acts is None:
         assert (rows0["n_steps"] < steps).any() and (rows0["n_steps"] == steps).any()
@@ -1089,18 +1093,40 @@ def test_rollout_pipelines_equal_one_pipeline(sga, monkeypatch, E, ego_kind, zpr
         assert np.array_equal(st["coll"], st0["coll"]) and np.array_equal(st["present"], st0["present"])
         assert rows.tobytes() == rows0.tobytes() and ev.tobytes() == ev0.tobytes()
         assert bits_equal(t, t0) and bits_equal(poses, poses0)
-    for st, (rows, ev) in pipes[1:]:
+    for st, (rows, ev) in pieces[1:]:
         for k in ("poses", "vels", "dists", "ctrl_state", "t", "prev_t"):
-            assert bits_equal(st[k], pipes[0][0][k]), k
-        assert rows.tobytes() == pipes[0][1][0].tobytes() and ev.tobytes() == pipes[0][1][1].tobytes()
+            assert bits_equal(st[k], pieces[0][0][k]), k
+        assert rows.tobytes() == pieces[0][1][0].tobytes() and ev.tobytes() == pieces[0][1][1].tobytes()
 
 
-@pytest.mark.parametrize("split", ["1", "3"])
+def test_queue_launch_with_many_blocks_per_slot(sga, oracle, monkeypatch):
+    """More blocks than the device has wavefront slots (3 x 1024 SIMDs), a ring of three buffers, chunks of 32 steps: every slot
+    serves several blocks, the blocks of a chunk finish out of order, the pre-pass waits for the ring -- the state after the
+    rollout equals the oracle's on scenarios spread over the batch."""
+    import scenario_gym_amd._lib as L
+    from oracle import check
+    from scenario_gym_amd import synthetic
+
+    R, E, steps, dt = 3600, 64, 200, 1 / 30
+    packed = synthetic.make_batch(R, E, n_steps=steps, ego_kind=L.KIND_AGENT_PID, static_frac=0.1, vanish_frac=0.3, extent=30.0)
+    monkeypatch.setenv("SG_QUEUE_RING", "3")
+    eng = sga.RolloutEngine(R, E, timestep=dt, terminal_conditions=["max_length"], event_capacity=64)
+    eng.set_tuning(tab_min_steps=1, chunk_steps=32)
+    eng.upload(packed)
+    eng.rollout(steps)
+    info = eng.schedule_info()
+    assert info["schedule"] == SCHED_QUEUE and info["ring"] == 3 and info["chunks"] >= 6 and info["launches"] == 1, info
+    ver = check.verify_engine(eng, packed, dt, steps, K=24, event_cap=64)
+    assert ver["equal"], ver["mismatches"]
+    eng.close()
+
+
+@pytest.mark.parametrize("queue", ["0", "1"])
 @pytest.mark.parametrize("persist", [False, True])
-def test_planar_table_kernel_with_late_spawns(sga, oracle, monkeypatch, split, persist):
+def test_planar_table_kernel_with_late_spawns(sga, oracle, monkeypatch, queue, persist):
     """The planar table kernel (rollout_kernel_tab_planar) never stores the z / pitch / roll rows of a pose: it relies on the
     reset having left +0.0 there for every lane that is absent or spawns later.  A planar batch in which half of the
-    entities appear late or vanish (PID ego), as one pipeline and as three, with and without persist, the rollout continued
+    entities appear late or vanish (PID ego), as chunk launches and as the persistent launch, with and without persist, the rollout continued
     in pieces on the same handle: after the reset the rows the kernel skips hold +0.0 bit for bit (pose, and velocity --
     checked on the lanes not yet in the scene), and the final state, metrics and events equal the oracle's."""
     import scenario_gym_amd._lib as L
@@ -1110,8 +1136,7 @@ def test_planar_table_kernel_with_late_spawns(sga, oracle, monkeypatch, split, p
     R, E, steps, dt = 72, 64, 300, 1 / 30
     packed = synthetic.make_batch(R, E, n_steps=steps, ego_kind=L.KIND_AGENT_PID, static_frac=0.1, vanish_frac=0.5, extent=30.0)
     assert not packed.knots[:, [3, 5, 6]].any()  # planar
-    monkeypatch.setenv("SG_TAB_SPLIT_MIN", "4")
-    monkeypatch.setenv("SG_TAB_SPLIT", split)
+    monkeypatch.setenv("SG_QUEUE", queue)
     eng = sga.RolloutEngine(R, E, timestep=dt, persist=persist, terminal_conditions=["max_length"], event_capacity=64)
     eng.set_tuning(tab_min_steps=1, chunk_steps=16)
     eng.upload(packed)
@@ -1207,32 +1232,33 @@ def test_rss_records_start_anew_on_every_upload(sga, oracle, ego):
         assert np.array_equal(again[2][r], w["code"][-1]) and np.array_equal(again[3][r], w["safe"][-1], equal_nan=True), r
 
 
-def test_launch_stats_count_overlapping_launches_once(sga, monkeypatch):
-    """sg_last_launch_stats reports the time during which at least one rollout launch ran (the union of the launches'
-    intervals), sg_last_launch_gross_ms the plain sum of their durations: equal with one pipeline, and with pipelines the sum
-    exceeds the union (their launches overlap) while the union stays within the device time of the whole call."""
+def test_launch_stats_of_both_schedules(sga, monkeypatch):
+    """sg_last_launch_stats reports the rollout-kernel launches of the last call and the time during which at least one of
+    them ran (the union of their intervals), sg_last_launch_gross_ms the plain sum of their durations.  The persistent table
+    launch is ONE launch; the chunk launches (SG_QUEUE=0) are several on one stream: union and sum agree in both, and both stay
+    within the device time of the whole call.  (Counts only: nothing here compares speeds.)"""
     import scenario_gym_amd._lib as L
     from scenario_gym_amd import synthetic
 
     R, E, steps = 1024, 64, 400
     packed = synthetic.make_batch(R, E, n_steps=steps, ego_kind=L.KIND_AGENT_PID)
-    monkeypatch.setenv("SG_TAB_SPLIT_MIN", "64")
     out = {}
-    for split in ("1", "3"):
-        monkeypatch.setenv("SG_TAB_SPLIT", split)
+    for queue in ("0", "1"):
+        monkeypatch.setenv("SG_QUEUE", queue)
         eng = sga.RolloutEngine(R, E)
         eng.set_slicing(False)
         eng.upload(packed)
         eng.rollout(steps)
         eng.rollout(steps)
         n, net = eng.last_launch_stats()
-        out[split] = (n, net, eng.last_launch_gross_ms(), eng.last_kernel_ms())
+        out[queue] = (n, net, eng.last_launch_gross_ms(), eng.last_kernel_ms(), eng.schedule_info())
         eng.close()
-    n1, net1, gross1, call1 = out["1"]
-    n3, net3, gross3, call3 = out["3"]
-    assert n3 > n1 >= 1
-    assert abs(gross1 - net1) <= 1e-3 * gross1 and net1 <= call1 * 1.001
-    assert gross3 > 1.3 * net3 and net3 <= call3 * 1.001
+    n0, net0, gross0, call0, info0 = out["0"]
+    n1, net1, gross1, call1, info1 = out["1"]
+    assert info0["schedule"] == SCHED_CHUNKS and info1["schedule"] == SCHED_QUEUE
+    assert n0 > 1 and n1 == 1 and info1["launches"] == 1 and info1["grid"] == info1["blocks"] + info1["ctl_waves"]
+    for net, gross, call in ((net0, gross0, call0), (net1, gross1, call1)):
+        assert abs(gross - net) <= 1e-3 * gross and 0.0 < net <= call * 1.001
 
 
 def test_prepass_resumes_from_the_state_blocks(sga):
@@ -1312,9 +1338,9 @@ def test_full_horizon_matches_oracle(sga, oracle):
     eng.rollout(steps)
     st = eng.state()
     rows, events = eng.metrics()
-    n_launches, _ = eng.last_launch_stats()
+    n_launches, _ = eng.last_launch_stats()  # (a batch of 1024 blocks is time-sliced by default: several slice groups)
     # t accumulates in fp64: max_length (t + dt > length) fires one step before or at the nominal horizon
-    assert n_launches >= 10 and (rows["n_steps"] >= steps - 1).all() and rows["done"].all()
+    assert n_launches >= 1 and (rows["n_steps"] >= steps - 1).all() and rows["done"].all()
     eng.rollout(steps)
     st2 = eng.state()
     rows2, _ = eng.metrics()
@@ -2139,7 +2165,8 @@ def test_collisions_with_controlled_hazards_are_classified(sga, oracle, path):
             eng.step(1)
     else:
         eng.rollout(steps)
-        assert (eng.last_launch_stats()[0] > 1) == (path == "table")   # chunks of the controller table, or one launch
+        # the table path (here: the persistent launch) or the controllers inside the rollout kernel
+        assert eng.schedule_info()["schedule"] == (SCHED_QUEUE if path == "table" else 0)
     rows, events = eng.metrics()
     points = eng.collision_points()
     eng.close()

