@@ -796,6 +796,17 @@ def main(argv=None, make_engine=None):
             name, o = other_run
             line[name] = {"value": o["total"] / o["elapsed"], "ms_per_step": o["elapsed"] / args.steps * 1e3,
                           "scenarios_per_gpu": o["R"], "per_rank_value": o["per_rank"], "verified": o["verified"]}
+        elif world == 1:
+            # one rank: the weak and the strong shape are the same batch -- the block repeats `value` (no second run), so that
+            # the N = 1 point of a scaling run carries the same keys as its N > 1 points
+            other = "strong" if args.scaling == "weak" else "weak"
+            line[other] = {"value": line["value"], "ms_per_step": line["ms_per_step"], "scenarios_per_gpu": R,
+                           "per_rank_value": m["per_rank"], "verified": m["verified"],
+                           "note": "one rank: the same batch as `value`, not measured twice"}
+            if args.workload == "c3" and live:
+                line["strong_sliced"] = {"value": None, "scenarios_per_gpu": R,
+                                         "note": "one rank: the shard is the whole batch, which fills the chip -- the time-sliced "
+                                                 "path engages only on shards of <= 1024 blocks (N >= 4 at 4096 scenarios)"}
         if sliced_run:
             o = sliced_run
             line["strong_sliced"] = {"value": o["total"] / o["elapsed"], "ms_per_step": o["elapsed"] / args.steps * 1e3,

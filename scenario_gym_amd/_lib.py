@@ -188,7 +188,7 @@ def load():
     lib.sg_raster_map_device.argtypes = [H, C.c_double, C.c_double, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]
     lib.sg_debug_trig32.argtypes = [H, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
     for name in SYMBOLS:
-        if name not in ("sg_last_error", "sg_stream", "sg_version"):
+        if name not in ("sg_last_error", "sg_stream", "sg_version", "sg_group_handle", "sg_group_last_error"):  # (pointers / strings)
             getattr(lib, name).restype = C.c_int
     if lib.sg_version() != ABI_VERSION:
         raise RuntimeError(f"libsgym_hip.so ABI {lib.sg_version()} != binding {ABI_VERSION}")

@@ -607,7 +607,9 @@ static int launch_crowd_chunks(sg_handle *h, int n_steps, int do_reset, int forc
             if ((rc = get_event(h, *ev_next, &e0)) || (rc = get_event(h, *ev_next + 1, &e1))) return rc;
             HIP_TRY(h, hipEventRecord(e0, h->stream));
         }
-        sgl::walk_classify(grid, h->stream, h->p, h->walk, len, enable_mask, std::min(64, std::max(1, env_int("SG_WALK1_MAX", 64))));
+        // (class 1 -- at most 64 active entities -- runs walk_kernel<1> [bit 0] or the four-wavefront walk4_kernel [bit 2])
+        sgl::walk_classify(grid, h->stream, h->p, h->walk, len, (enable_mask & 2) | ((enable_mask & 5) ? 1 : 0),
+                           std::min(64, std::max(1, env_int("SG_WALK1_MAX", 64))));
         HIP_TRY(h, hipGetLastError());
         if (s1 != h->stream) {
             if ((rc = get_event(h, *ev_next + 2, &ec)) || (rc = get_event(h, *ev_next + 3, &ew1)) || (rc = get_event(h, *ev_next + 4, &ew2))) return rc;
@@ -618,7 +620,8 @@ static int launch_crowd_chunks(sg_handle *h, int n_steps, int do_reset, int forc
         sgl::RolloutArgs a{&h->p, h->cfg.timestep, len, 0, force, nullptr, nullptr};
         a.sel = sg::WalkSel{h->walk.cls, h->walk.target, 0};
         sgl::rollout_crowd(h->WV, false, grid, h->stream, a);                                   // class 0: every entity a lane
-        if (enable_mask & 1) sgl::walk_rollout(1, grid, s1, h->p, h->cfg.timestep, len, force, h->walk); // class 1: <= 64 active
+        if (enable_mask & 4) sgl::walk_rollout(4, grid, s1, h->p, h->cfg.timestep, len, force, h->walk);      // class 1: <= 64 active, four wavefronts
+        else if (enable_mask & 1) sgl::walk_rollout(1, grid, s1, h->p, h->cfg.timestep, len, force, h->walk); // class 1: <= 64 active
         if (enable_mask & 2) sgl::walk_rollout(2, grid, s2, h->p, h->cfg.timestep, len, force, h->walk); // class 2: <= 128 active
         HIP_TRY(h, hipGetLastError());
         if (s1 != h->stream) {
@@ -866,10 +869,10 @@ static int launch_rollout_impl(sg_handle *h, int n_steps, int do_reset, int forc
             rc = launch_main(h, std::min(h->rssq_steps, n_steps - k0), k0 == 0 ? do_reset : 0, force,
                              d_actions ? d_actions + (size_t)k0 * h->R * 2 : nullptr, nullptr, false, &ev_next);
     } else if (!use_tab && h->has_ped && h->all_ped && h->G == 64 && h->WV == 4 && !h->has_road && crowd_allowed(h) && !h->rss_fused &&
-               h->p.rec_cap == 0 && !d_actions && n_steps >= env_int("SG_CROWD_WALK_MIN", 64) && (env_int("SG_CROWD_WALK", 0) & 3) != 0) {
+               h->p.rec_cap == 0 && !d_actions && n_steps >= env_int("SG_CROWD_WALK_MIN", 64) && (env_int("SG_CROWD_WALK", 0) & 7) != 0) {
         // (OFF by default: on 1024 scenarios the walker kernels are one wavefront per SIMD and, measured, no faster than
         // rollout_kernel_crowd -- HISTORY.md, round 4; SG_CROWD_WALK=3 switches the dispatch on, the parity tests do)
-        rc = launch_crowd_chunks(h, n_steps, do_reset, force, env_int("SG_CROWD_WALK", 0) & 3, &ev_next);
+        rc = launch_crowd_chunks(h, n_steps, do_reset, force, env_int("SG_CROWD_WALK", 0) & 7, &ev_next);
     } else if (!use_tab) {
         rc = launch_main(h, n_steps, do_reset, force, d_actions, nullptr, false, &ev_next);
     } else {
@@ -2102,6 +2105,9 @@ extern "C" int sg_crowd_walk_stats(sg_handle *h, int32_t *out, int32_t reset)
         for (int i = 0; i < 16; ++i) if (c[i]) fprintf(stderr, " [%d] %.1f%%", i, 100.0 * c[i] / tot);
         fprintf(stderr, "  raw [1] %.4e [7] %.4e [14] %.4e", (double)c[1], (double)c[7], (double)c[14]);
         fprintf(stderr, "  total %.3e\n", (double)tot);
+        fprintf(stderr, "walk4 raw cycles, wavefront 0: A %.3e wait %.3e B %.3e B2w %.3e C %.3e D %.3e E %.3e | wavefront 1: A %.3e wait %.3e B %.3e B2w %.3e C %.3e D %.3e E %.3e | scenario-steps %.3e\n",
+                (double)c[0], (double)c[1], (double)c[2], (double)c[3], (double)c[4], (double)c[5], (double)c[6], (double)c[8], (double)c[9], (double)c[10],
+                (double)c[11], (double)c[12], (double)c[13], (double)c[14], (double)c[7]);
     }
 #endif
     if (reset) HIP_TRY(h, hipMemset(h->walk.stats, 0, 8 * sizeof(int32_t)));

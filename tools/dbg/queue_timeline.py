@@ -10,6 +10,8 @@ R, E, steps = int(os.environ.get("QT_R", 4096)), 64, 10000
 packed = synthetic.make_batch(R, E, n_steps=steps, ego_kind=L.KIND_AGENT_PID)
 eng = sga.RolloutEngine(R, E, terminal_conditions=["max_length"], event_capacity=64)
 eng.set_slicing(False)
+if os.environ.get("QT_CHUNK"):
+    eng.set_tuning(chunk_steps=int(os.environ["QT_CHUNK"]))
 eng.upload(packed)
 eng.rollout(steps)
 eng.rollout(steps)

@@ -11,7 +11,7 @@ agg = collections.defaultdict(float)
 for f in glob.glob(f"gpurun_out/{tag}_a/**/*counter_collection.csv", recursive=True)[:1] + glob.glob(f"gpurun_out/{tag}_b/**/*counter_collection.csv", recursive=True)[:1]:
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"]
-        k = "walk1" if "walk_kernel<1>" in n else "walk2" if "walk_kernel<2>" in n else "full" if "rollout_kernel_crowd" in n else None
+        k = "walk1" if ("walk_kernel<1>" in n or "walk4_kernel" in n) else "walk2" if "walk_kernel<2>" in n else "full" if "rollout_kernel_crowd" in n else None
         if k: agg[(k, r["Counter_Name"])] += float(r["Counter_Value"])
 ws = {"walk1": st["walk1"] * st["chunk"] * 1, "walk2": st["walk2"] * st["chunk"] * 2, "full": st["full"] * st["chunk"] * 4}
 out = {k: {c[1]: round(v / max(ws[k], 1), 1) for c, v in agg.items() if c[0] == k} for k in ws}
