@@ -238,6 +238,27 @@ int sg_host_free(void *p);
 /* SocialForce(params) shared by every pedestrian agent of the handle; call before sg_upload (defaults otherwise) */
 int sg_set_social_force(sg_handle *h, const sg_social_force *params);
 
+/* Per-agent behaviour models.  The reference gives every PedestrianAgent its own behaviour object with its own parameters
+ * (pedestrian/agent.py:18-41 `behaviour`, social_force.py:33-42, random_walk.py:22-31): a scenario may mix SocialForce
+ * pedestrians of different parameter sets with RandomWalk pedestrians.  `models[n_models]` are the distinct (behaviour,
+ * parameters, noise std) combinations of the batch, `model_of[n_scenarios * n_entities]` the model of every entity slot (read
+ * for SG_KIND_AGENT_PEDESTRIAN slots only; others: any value in range, or -1).  Call before sg_upload (the batch's kernels
+ * are chosen there).  One model: the same as sg_set_social_force + sg_set_ped_behaviour + the std of sg_set_ped_noise.
+ * Several: every pedestrian steps under its own model (the force on a pedestrian is computed with ITS parameters from its
+ * neighbours' states, social_force.py:44-114); the all-pedestrian crowd kernels, which hold one parameter set, stand back
+ * for the general pedestrian variant.  The noise MODE (off / stream / device, sg_set_ped_noise) stays one per handle: the
+ * reference draws every agent's two variates from the one global generator, in agent order, whatever its model.
+ * SG_ERR_INVALID: more than SG_MAX_PED_MODELS models, an index out of range, scenarios of more than 512 entities with more
+ * than one model. */
+#define SG_MAX_PED_MODELS 16
+typedef struct {
+    int32_t behaviour;       /* SG_PED_SOCIAL_FORCE / SG_PED_RANDOM_WALK */
+    int32_t reserved;
+    sg_social_force params;
+    double std_lon, std_lat; /* social_force.py:106-108 / random_walk.py:37-43 (used when the handle's noise mode is not off) */
+} sg_ped_model;
+int sg_set_ped_models(sg_handle *h, int32_t n_models, const sg_ped_model *models, const int32_t *model_of);
+
 /* The random fluctuations of SocialForce._step (pedestrian/social_force.py:106-114): every pedestrian that is still
  * walking adds np.random.normal(bias_lon, std_lon) to its speed and np.random.normal(bias_lat, std_lat) to its heading, in
  * agent (entity) order, from numpy's global legacy generator: loc + scale * z.

@@ -25,7 +25,7 @@ def spread(R, K):
 
 
 def oracle_final(packed, r, dt, T, persist=False, terminal_mask=O.TERM_MAX_LENGTH, event_cap=64, sf=None, noise=None,
-                 record="last", behaviour="social_force"):
+                 record="last", behaviour="social_force", models=None, model_of=None):
     from scenario_gym_amd.packing import unpack_scenario
 
     s = unpack_scenario(packed, r)
@@ -34,7 +34,7 @@ def oracle_final(packed, r, dt, T, persist=False, terminal_mask=O.TERM_MAX_LENGT
     return O.rollout(s["knot_off"], s["knots"], s["bbox"], s["etype"], s["kind"], s["ego"], s["t0"], s["length"], dt,
                      persist=persist, terminal_mask=terminal_mask, ctrl=s["ctrl"], actions=actions, max_steps=T, record=record,
                      event_cap=event_cap, route_off=s.get("route_off"), routes=s.get("routes"), sf=sf, noise=noise,
-                     behaviour=behaviour)
+                     behaviour=behaviour, models=models, model_of=model_of)
 
 
 def compare_final(st, rows, events, r, o, E, event_cap=64, ped=False, kind=None):

@@ -121,10 +121,23 @@ def raster_map(poses, bbox, ego, net, layers, width=20.0, height=20.0, nw=20, nh
     return out.astype(bool)
 
 
+PM_W = 16  # doubles of a behaviour-model row (sgo_config.models): behaviour, sf[NSF], std_lon, std_lat, pad
+
+
+def ped_model_row(behaviour="social_force", sf=None, std_lon=0.0, std_lat=0.0):
+    """One row of `models` for rollout(models=..., model_of=...)."""
+    row = np.zeros(PM_W)
+    row[0] = {"social_force": 0, "random_walk": 1}[behaviour]
+    row[1:1 + NSF] = social_force_params() if sf is None else sf
+    row[13], row[14] = std_lon, std_lat
+    return row
+
+
 class _Config(C.Structure):
     _fields_ = [("dt", C.c_double), ("persist", C.c_int32), ("terminal_mask", C.c_int32), ("sf", C.c_double * NSF),
                 ("noise_mode", C.c_int32), ("scenario_index", C.c_int32), ("std_lon", C.c_double), ("std_lat", C.c_double),
-                ("normals", C.c_void_p), ("n_normals", C.c_int64), ("noise_seed", C.c_uint64), ("behaviour", C.c_int32)]
+                ("normals", C.c_void_p), ("n_normals", C.c_int64), ("noise_seed", C.c_uint64), ("behaviour", C.c_int32),
+                ("n_models", C.c_int32), ("models", C.c_void_p), ("model_of", C.c_void_p)]
 
 
 class _Event(C.Structure):
@@ -187,9 +200,11 @@ def default_kinds(n, ego=0):
 def rollout(knot_off, knots, bbox, etype, kind, ego, t0, length, dt, persist=False,
             terminal_mask=TERM_MAX_LENGTH, ctrl=None, actions=None, max_steps=None,
             force_steps=False, record=True, event_cap=256, route_off=None, routes=None, sf=None, road=None, noise=None,
-            behaviour="social_force"):
+            behaviour="social_force", models=None, model_of=None):
     """One scenario through the oracle.  Returns a dict shaped like make_golden.record_rollout.
     behaviour: "social_force" or "random_walk" -- the model of the pedestrian agents (PedestrianAgent(..., behaviour=...)).
+    models / model_of: per-agent behaviour models -- models[n][PM_W] rows (behaviour 0 / 1, the NSF parameters, std_lon,
+    std_lat: ped_model_row) and the row of every entity.
     noise: None, or dict(mode="stream", std_lon, std_lat, normals=[...]) / dict(mode="device", std_lon, std_lat, seed,
     scenario_index): the random fluctuations of SocialForce._step (see sgo_config)."""
     L = lib()
@@ -216,6 +231,11 @@ def rollout(knot_off, knots, bbox, etype, kind, ego, t0, length, dt, persist=Fal
     sf = social_force_params() if sf is None else np.ascontiguousarray(sf, np.float64)
     cfg = _Config(float(dt), int(bool(persist)), int(terminal_mask), (C.c_double * NSF)(*sf))
     cfg.behaviour = {"social_force": 0, "random_walk": 1}[behaviour]
+    if models is not None:
+        models = np.ascontiguousarray(models, np.float64).reshape(-1, PM_W)
+        model_of = np.ascontiguousarray(model_of, np.int32)
+        assert len(model_of) == E and model_of.max() < len(models)
+        cfg.n_models, cfg.models, cfg.model_of = len(models), _p(models), _p(model_of)
     normals = None
     if noise is not None:
         cfg.std_lon, cfg.std_lat = float(noise["std_lon"]), float(noise["std_lat"])

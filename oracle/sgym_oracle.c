@@ -991,6 +991,15 @@ static void ped_step(const sgo_scenario *sc, const sgo_config *cfg, int i, const
 {
     const int E = sc->n_entities;
     const double *sf = cfg->sf, *ct = sc->ctrl + (size_t)i * SGO_NCTRL;
+    int behaviour = cfg->behaviour;
+    double std_lon = cfg->std_lon, std_lat = cfg->std_lat;
+    if (cfg->model_of && cfg->models && cfg->n_models > 0) { /* this agent's own behaviour object, pedestrian/agent.py:39 */
+        const double *row = cfg->models + (size_t)cfg->model_of[i] * SGO_PM_W;
+        behaviour = (int)row[SGO_PM_BEHAVIOUR];
+        sf = row + SGO_PM_SF;
+        std_lon = row[SGO_PM_STD_LON];
+        std_lat = row[SGO_PM_STD_LAT];
+    }
     const double *pose = poses + (size_t)i * 6, *vel = vels + (size_t)i * 6;
     const double *wp = sc->routes + sc->route_off[i] * 2;
     const int nwp = (int)(sc->route_off[i + 1] - sc->route_off[i]);
@@ -1010,7 +1019,7 @@ static void ped_step(const sgo_scenario *sc, const sgo_config *cfg, int i, const
         }
         ps->goal_idx = last + 1;
     }
-    if (ps->goal_idx <= nwp - 1 && cfg->behaviour == 1) {
+    if (ps->goal_idx <= nwp - 1 && behaviour == 1) {
         /* RandomWalk._step, pedestrian/random_walk.py:32-44: np.random.normal(loc, scale) = loc + scale * z (std 0: == loc);
          * agent.force is not touched (it stays the zeros of PedestrianAgent.__init__, agent.py:41) */
         const double gx = wp[2 * ps->goal_idx] - pose[0], gy = wp[2 * ps->goal_idx + 1] - pose[1];
@@ -1022,13 +1031,13 @@ static void ped_step(const sgo_scenario *sc, const sgo_config *cfg, int i, const
             const int64_t k = *noise_pos;
             const double z0 = k + 1 < cfg->n_normals ? cfg->normals[k] : 0.0, z1 = k + 1 < cfg->n_normals ? cfg->normals[k + 1] : 0.0;
             *noise_pos = k + 2;
-            speed = loc_s + cfg->std_lon * z0;
-            heading = loc_h + cfg->std_lat * z1;
+            speed = loc_s + std_lon * z0;
+            heading = loc_h + std_lat * z1;
         } else if (cfg->noise_mode == 2) {
             double z[2];
             sgo_noise_pair(cfg->noise_seed, (uint32_t)cfg->scenario_index, (uint32_t)i, (uint32_t)step_index, z);
-            speed = loc_s + cfg->std_lon * z[0];
-            heading = loc_h + cfg->std_lat * z[1];
+            speed = loc_s + std_lon * z[0];
+            heading = loc_h + std_lat * z[1];
         }
         FLOPS(FL_PED_MOVE, FLN_PED_MOVE - 5);
         ps->fx = ps->fy = 0.0;
@@ -1105,13 +1114,13 @@ static void ped_step(const sgo_scenario *sc, const sgo_config *cfg, int i, const
             const int64_t k = *noise_pos;
             const double z0 = k + 1 < cfg->n_normals ? cfg->normals[k] : 0.0, z1 = k + 1 < cfg->n_normals ? cfg->normals[k + 1] : 0.0;
             *noise_pos = k + 2;
-            speed_rand = sf[SGO_SF_BIAS_LON] + cfg->std_lon * z0;
-            heading_rand = sf[SGO_SF_BIAS_LAT] + cfg->std_lat * z1;
+            speed_rand = sf[SGO_SF_BIAS_LON] + std_lon * z0;
+            heading_rand = sf[SGO_SF_BIAS_LAT] + std_lat * z1;
         } else if (cfg->noise_mode == 2) {
             double z[2];
             sgo_noise_pair(cfg->noise_seed, (uint32_t)cfg->scenario_index, (uint32_t)i, (uint32_t)step_index, z);
-            speed_rand = sf[SGO_SF_BIAS_LON] + cfg->std_lon * z[0];
-            heading_rand = sf[SGO_SF_BIAS_LAT] + cfg->std_lat * z[1];
+            speed_rand = sf[SGO_SF_BIAS_LON] + std_lon * z[0];
+            heading_rand = sf[SGO_SF_BIAS_LAT] + std_lat * z[1];
         }
         FLOPS(FL_PED_MOVE, FLN_PED_MOVE);
         speed = fmin(norm2(fx, fy) + speed_rand, vdes * sf[SGO_SF_MAX_SPEED_FACTOR]);

@@ -26,7 +26,7 @@ F_POSE, F_VEL, F_DIST, F_PRESENT, F_CTRL, F_FORCE, F_COLL = 0, 6, 12, 13, 14, 18
 
 # every symbol include/sgym.h declares
 SYMBOLS = (
-    "sg_version", "sg_last_error", "sg_create", "sg_destroy", "sg_upload", "sg_set_social_force", "sg_set_ped_behaviour", "sg_set_ped_noise", "sg_reset",
+    "sg_version", "sg_last_error", "sg_create", "sg_destroy", "sg_upload", "sg_set_social_force", "sg_set_ped_models", "sg_set_ped_behaviour", "sg_set_ped_noise", "sg_reset",
     "sg_set_timestep", "sg_step", "sg_rollout", "sg_rollout_async", "sg_synchronize", "sg_stream",
     "sg_state_view_get", "sg_read_metrics", "sg_read_record", "sg_copy_to_host", "sg_last_kernel_ms",
     "sg_last_launch_stats", "sg_last_launch_gross_ms", "sg_schedule_info", "sg_crowd_walk_stats", "sg_debug_trig32", "sg_set_tuning", "sg_set_slicing", "sg_set_external_poses", "sg_future_collision", "sg_raster_entities",
@@ -58,6 +58,10 @@ class SgSocialForce(C.Structure):
     _fields_ = [(n, C.c_double) for n in
                 ("relaxation_time", "ped_repulse_V", "ped_repulse_sigma", "ped_attract_C", "sight_weight",
                  "sight_weight_use", "cos_sight", "max_speed_factor", "bias_lon", "bias_lat", "imp_boundary_repulse_U", "imp_boundary_repulse_R")]
+
+
+class SgPedModel(C.Structure):  # include/sgym.h sg_ped_model
+    _fields_ = [("behaviour", C.c_int32), ("reserved", C.c_int32), ("params", SgSocialForce), ("std_lon", C.c_double), ("std_lat", C.c_double)]
 
 
 class SgStateView(C.Structure):
@@ -138,6 +142,7 @@ def load():
     lib.sg_destroy.argtypes = [H]
     lib.sg_upload.argtypes = [H, C.POINTER(SgScenarios)]
     lib.sg_set_social_force.argtypes = [H, C.POINTER(SgSocialForce)]
+    lib.sg_set_ped_models.argtypes = [H, C.c_int32, C.POINTER(SgPedModel), C.c_void_p]
     lib.sg_set_ped_behaviour.argtypes = [H, C.c_int32]
     lib.sg_set_ped_noise.argtypes = [H, C.c_int32, C.c_double, C.c_double, C.c_void_p, C.c_int64, C.c_uint64]
     lib.sg_reset.argtypes = [H]

@@ -90,10 +90,17 @@ struct Params {
     long long noise_len;
     unsigned long long noise_seed;
     int ped_behaviour;       // sg_set_ped_behaviour: 0 SocialForce, 1 RandomWalk (never with the crowd variants)
+    // per-agent behaviour models (sg_set_ped_models; n_ped_models <= 1: `sf` / `ped_behaviour` / `noise_std_*` above are the model)
+    int n_ped_models;
+    const double *ped_models; // [n_ped_models][PM_W]: behaviour, the 12 doubles of sg_social_force, std_lon, std_lat
+    const int32_t *model_of;  // [NE] model of every padded entity slot (0 where there is none)
 #ifdef SG_PHASE_TIMERS
     unsigned long long *phase_cycles; // [16] experiment builds: s_memtime cycles per phase of the step, summed over wavefronts
 #endif
 };
+
+enum { PM_BEHAVIOUR = 0, PM_SF = 1, PM_STD_LON = 13, PM_STD_LAT = 14, PM_W = 16 }; // doubles of one row of Params::ped_models
+static_assert(sizeof(sg_social_force) == 12 * sizeof(double), "sg_social_force is twelve doubles");
 
 // controller table written by control_kernel, read by rollout_kernel<.., TAB = true>.  Two planes of
 // [n_ctl_pad][tab_steps + 1][4] doubles (the steps of one lane are contiguous: 32 B per step, so the scalar loads of

@@ -668,24 +668,33 @@ struct PedNoise {
 // the force's angle (social_force.py:106-113).  RandomWalk (RW: compiled in for the variants that can run it; fx, fy = the
 // vector to the goal point): the locations carry the signal, speed = np.random.normal(speed_desired + bias_lon, std_lon),
 // heading = np.random.normal(angle + bias_lat, std_lat), no max_speed_factor, agent.force untouched (random_walk.py:37-43).
+// the part of a behaviour model ped_move reads: per LANE where a batch mixes models (sg_set_ped_models)
+struct PedMoveModel {
+    int behaviour;
+    double bias_lon, bias_lat, max_speed_factor;
+};
+__device__ __forceinline__ PedMoveModel ped_move_model(const Params &p)
+{
+    return PedMoveModel{p.ped_behaviour, p.sf.bias_lon, p.sf.bias_lat, p.sf.max_speed_factor};
+}
+
 template <bool RW = true>
-__device__ __forceinline__ void ped_move(const Params &p, bool go, double fx, double fy, double vdes, double maxs,
+__device__ __forceinline__ void ped_move(const PedMoveModel &pm, bool go, double fx, double fy, double vdes, double maxs,
                                          const double *pose, double state_dt, double &cspeed, double &fxo, double &fyo,
                                          double *np_, ConstTbl K, PedNoise nz)
 {
-    const sg_social_force &sf = p.sf;
     double speed = 0.0, heading = 0.0;
     fxo = fyo = 0.0;
-    if (RW && p.ped_behaviour == SG_PED_RANDOM_WALK) {
+    if (RW && pm.behaviour == SG_PED_RANDOM_WALK) {
         if (go) {
-            const double loc_s = vdes + sf.bias_lon, loc_h = sg_atan2(fy, fx) + sf.bias_lat;
+            const double loc_s = vdes + pm.bias_lon, loc_h = sg_atan2(fy, fx) + pm.bias_lat;
             speed = nz.on ? loc_s + nz.s : loc_s;
             heading = nz.on ? loc_h + nz.h : loc_h;
         }
     } else if (go) {
-        const double speed_rand = nz.on ? sf.bias_lon + nz.s : sf.bias_lon;
-        const double heading_rand = nz.on ? sf.bias_lat + nz.h : sf.bias_lat;
-        speed = __builtin_fmin(sg_norm2(fx, fy) + speed_rand, vdes * sf.max_speed_factor);
+        const double speed_rand = nz.on ? pm.bias_lon + nz.s : pm.bias_lon;
+        const double heading_rand = nz.on ? pm.bias_lat + nz.h : pm.bias_lat;
+        speed = __builtin_fmin(sg_norm2(fx, fy) + speed_rand, vdes * pm.max_speed_factor);
         heading = sg_atan2(fy, fx) + heading_rand;
         fxo = fx;
         fyo = fy;
@@ -699,6 +708,14 @@ __device__ __forceinline__ void ped_move(const Params &p, bool go, double fx, do
     np_[0] += sd * hc2;
     np_[1] += sd * hs2;
     np_[3] = heading;
+}
+
+template <bool RW = true>
+__device__ __forceinline__ void ped_move(const Params &p, bool go, double fx, double fy, double vdes, double maxs,
+                                         const double *pose, double state_dt, double &cspeed, double &fxo, double &fyo,
+                                         double *np_, ConstTbl K, PedNoise nz)
+{
+    ped_move<RW>(ped_move_model(p), go, fx, fy, vdes, maxs, pose, state_dt, cspeed, fxo, fyo, np_, K, nz);
 }
 
 } // namespace sg

@@ -55,6 +55,9 @@ struct sg_handle {
     int crowd_kernel = 1;     // env SG_CROWD_KERNEL=0: all-pedestrian batches take the general pedestrian variant too
     sg_social_force sf{};
     int ped_behaviour = 0;        // sg_set_ped_behaviour
+    int n_ped_models = 0;         // sg_set_ped_models: > 1 = the batch mixes behaviour models / parameter sets
+    double *d_ped_models = nullptr;  // [n_ped_models][PM_W]
+    int32_t *d_model_of = nullptr;   // [NE]
     int noise_mode = 0;           // sg_set_ped_noise
     double noise_std[2] = {0.0, 0.0};
     double *d_normals = nullptr;  // [R][noise_len]
@@ -150,7 +153,7 @@ struct sg_handle {
 static bool rss_live(const sg_handle *h) { return h->d_rss_state && !h->rss_stale; }
 
 // the crowd variants (rollout_kernel_crowd / _riders, the walker kernels) hold the social force model alone
-static bool crowd_allowed(const sg_handle *h) { return h->crowd_kernel && h->ped_behaviour == SG_PED_SOCIAL_FORCE; }
+static bool crowd_allowed(const sg_handle *h) { return h->crowd_kernel && h->ped_behaviour == SG_PED_SOCIAL_FORCE && h->n_ped_models <= 1; }
 
 static int env_int(const char *name, int dflt)
 {
@@ -398,6 +401,8 @@ extern "C" int sg_destroy(sg_handle *h)
     if (h->d_normals) (void)hipFree(h->d_normals);
     for (int b = 0; b < 4; ++b)
         if (h->d_tab[b]) (void)hipFree(h->d_tab[b]);
+    if (h->d_ped_models) (void)hipFree(h->d_ped_models);
+    if (h->d_model_of) (void)hipFree(h->d_model_of);
     if (h->d_qwords) (void)hipFree(h->d_qwords);
     if (h->d_qtab) (void)hipFree(h->d_qtab);
     if (h->q_host) (void)hipHostFree(h->q_host);
@@ -650,6 +655,7 @@ static int launch_crowd_chunks(sg_handle *h, int n_steps, int do_reset, int forc
 // grid of persistent wavefronts, work items (chunk, block) from a device-side counter.  `chunk` = the longest chunk.
 // Returns SG_OK, an error, or SG_QUEUE_FALLBACK: the table ring could not be allocated -- the caller takes the chunk launches.
 #define SG_QUEUE_FALLBACK 1
+static size_t slots_of(const sg_handle *h) { return (size_t)h->n_simd * (size_t)(h->planar ? SG_PLANAR_WAVES : SG_TAB_WAVES); }
 static int launch_queue(sg_handle *h, int n_steps, int force, const double *d_actions, int chunk, size_t *ev_next)
 {
     const size_t nblk = h->NE / 64, np = (size_t)h->p.n_ctl_pad, n_ctl_waves = np / 64;
@@ -746,7 +752,7 @@ static int launch_queue(sg_handle *h, int n_steps, int force, const double *d_ac
     tq.k0[0] = 0;
     for (int c = 0; c < C; ++c) tq.k0[c + 1] = tq.k0[c] + len[(size_t)c];
     // as many wavefronts as the device holds at once (three per SIMD), no more than there is work for
-    const size_t slots = (size_t)h->n_simd * (size_t)(h->planar ? SG_PLANAR_WAVES : SG_TAB_WAVES);
+    const size_t slots = slots_of(h);
     const unsigned grid = (unsigned)std::min(slots, n_ctl_waves + nblk);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     int rc;
@@ -1198,6 +1204,62 @@ extern "C" int sg_set_ped_behaviour(sg_handle *h, int32_t behaviour)
     return SG_OK;
 }
 
+static void apply_noise(sg_handle *h);
+// PedestrianAgent(..., behaviour=...) per agent (pedestrian/agent.py:18-41): the distinct models of the batch + the model of
+// every entity slot.  One model: the handle-wide setters.
+extern "C" int sg_set_ped_models(sg_handle *h, int32_t n_models, const sg_ped_model *models, const int32_t *model_of)
+{
+    if (!h) return SG_ERR_INVALID;
+    if (n_models < 1 || n_models > SG_MAX_PED_MODELS || !models)
+        return fail(h, SG_ERR_INVALID, "sg_set_ped_models: n_models=%d (1 .. %d) or null models", n_models, SG_MAX_PED_MODELS);
+    if (h->uploaded) return fail(h, SG_ERR_STATE, "sg_set_ped_models: call before sg_upload (the batch's kernels are chosen there)");
+    for (int m = 0; m < n_models; ++m) {
+        if (models[m].behaviour != SG_PED_SOCIAL_FORCE && models[m].behaviour != SG_PED_RANDOM_WALK)
+            return fail(h, SG_ERR_INVALID, "sg_set_ped_models: model %d: unknown behaviour %d", m, models[m].behaviour);
+        if (!(models[m].std_lon >= 0.0) || !(models[m].std_lat >= 0.0))
+            return fail(h, SG_ERR_INVALID, "sg_set_ped_models: model %d: std must be >= 0", m);
+    }
+    if (n_models > 1 && !model_of) return fail(h, SG_ERR_INVALID, "sg_set_ped_models: several models need model_of[n_scenarios * n_entities]");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    // model 0 is also what the handle-wide fields say (the single-model kernels, the oracle of a one-model batch)
+    h->sf = models[0].params;
+    h->p.sf = h->sf;
+    h->ped_behaviour = models[0].behaviour;
+    h->p.ped_behaviour = h->ped_behaviour;
+    if (h->noise_mode != SG_NOISE_OFF) { h->noise_std[0] = models[0].std_lon; h->noise_std[1] = models[0].std_lat; }
+    h->n_ped_models = n_models;
+    if (n_models > 1) {
+        if (h->wide) return fail(h, SG_ERR_INVALID, "sg_set_ped_models: several models on scenarios of more than 512 entities");
+        std::vector<double> rows((size_t)n_models * sg::PM_W, 0.0);
+        for (int m = 0; m < n_models; ++m) {
+            double *r = rows.data() + (size_t)m * sg::PM_W;
+            r[sg::PM_BEHAVIOUR] = (double)models[m].behaviour;
+            memcpy(r + sg::PM_SF, &models[m].params, sizeof(sg_social_force));
+            r[sg::PM_STD_LON] = models[m].std_lon; // (read only when the handle's noise mode is not off)
+            r[sg::PM_STD_LAT] = models[m].std_lat;
+        }
+        std::vector<int32_t> mo(h->NE, 0);
+        for (int r = 0; r < h->R; ++r)
+            for (int e = 0; e < h->E; ++e) {
+                const int32_t v = model_of[(size_t)r * h->E + e];
+                if (v >= n_models) return fail(h, SG_ERR_INVALID, "sg_set_ped_models: model_of[%d][%d] = %d >= n_models = %d", r, e, v, n_models);
+                mo[(size_t)r * h->EP + e] = v < 0 ? 0 : v;
+            }
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        if (h->d_ped_models) HIP_TRY(h, hipFree(h->d_ped_models));
+        if (h->d_model_of) HIP_TRY(h, hipFree(h->d_model_of));
+        h->d_ped_models = nullptr;
+        h->d_model_of = nullptr;
+        HIP_TRY(h, hipMalloc((void **)&h->d_ped_models, rows.size() * sizeof(double)));
+        HIP_TRY(h, hipMalloc((void **)&h->d_model_of, mo.size() * sizeof(int32_t)));
+        HIP_TRY(h, hipMemcpy(h->d_ped_models, rows.data(), rows.size() * sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMemcpy(h->d_model_of, mo.data(), mo.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
+    apply_noise(h);
+    ++h->generation;
+    return SG_OK;
+}
+
 static void apply_noise(sg_handle *h)
 {
     h->p.noise_mode = h->noise_mode;
@@ -1279,6 +1341,9 @@ extern "C" int sg_upload(sg_handle *h, const sg_scenarios *sc)
         h->crowd_riders = ok;
     }
     if (h->has_ped && (!sc->route_off || !sc->routes)) return fail(h, SG_ERR_INVALID, "sg_upload: pedestrian agents need route_off/routes");
+    if (h->wide && h->n_ped_models > 1)
+        return fail(h, SG_ERR_INVALID, "sg_upload: several pedestrian behaviour models (sg_set_ped_models) on scenarios of more than 512 entities: "
+                                       "the multi-kernel step holds one model");
     if (h->wide) { // more than 512 entities per scenario: the multi-kernel step (sgym_wide.hpp) and what it does not do
         for (size_t i = 0; i < (size_t)h->R * h->E; ++i)
             if (sc->kind[i] == SG_KIND_AGENT_EXTERNAL)
@@ -1525,6 +1590,9 @@ extern "C" int sg_upload(sg_handle *h, const sg_scenarios *sc)
     p.WV = h->WV; p.FROWS = SG_F_COLL + h->WV;
     p.sf = h->sf;
     p.ped_behaviour = h->ped_behaviour;
+    p.n_ped_models = h->n_ped_models;
+    p.ped_models = h->d_ped_models;
+    p.model_of = h->d_model_of;
     apply_noise(h);
     p.ped_serial = h->ped_serial;
     p.ctl_general = env_int("SG_CTL_FAST", 1) == 0;

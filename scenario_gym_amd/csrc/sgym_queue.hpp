@@ -173,7 +173,11 @@ __device__ __forceinline__ void tabq_body(const Params &p, double timestep, int 
             if (tq.times && lane == 0) tq.times[(size_t)tq.n_chunks * tq.nblk * 4 + (size_t)ticket * tq.n_chunks + c] = wall_clock64();
             if (lane == 0) __hip_atomic_store(tq.ctl_prog + ticket, (unsigned)(c + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        return;
+        // the chain is written: this wavefront rolls out like the others from here on (its slot would idle for the second half
+        // of the call otherwise).  (Measured and dropped, round 5: rollout wavefronts that leave their SIMD to the pre-pass
+        // wavefront on it for the first ~3000 steps -- the pre-pass got no faster, c3 88 -> 82 G.)
+        __builtin_amdgcn_s_setprio(0);
+        if (q_peek(tq.state + Q_ERR) != 0) return;
     }
 
     // ---- rollout role: work items (chunk, block) ----

@@ -632,7 +632,33 @@ __device__ __forceinline__ void rollout_body_l(
         double fpx = 0.0, fpy = 0.0; // PedestrianAgent.force
         bool ped_go = false;
         double ped_fx = 0.0, ped_fy = 0.0, ped_vdes = 0.0;
-        if (PED) // the social force of every stepping pedestrian of the wavefront (wave-collective)
+        PedMoveModel pmm = ped_move_model(p); // what ped_move reads of the behaviour model: this lane's, where the batch mixes models
+        double nstd_lon = p.noise_std_lon, nstd_lat = p.noise_std_lat;
+        if (PED && !CROWD && p.n_ped_models > 1) {
+            // Per-agent behaviour models (sg_set_ped_models; pedestrian/agent.py:18-41): the force on a pedestrian is computed with
+            // ITS model's parameters from its neighbours' states, so the tile's pedestrians step model by model -- one pass of
+            // the (wave-collective) force code per model that has a stepping pedestrian in the tile, everybody else sitting
+            // the pass out.  A tile whose pedestrians share one model pays one pass, as before.
+            const bool stepping = is_agent && kind == SG_KIND_AGENT_PEDESTRIAN && present && run;
+            const int my_model = in_range ? p.model_of[(size_t)r * p.EP + slot] : 0;
+            const double *mm = p.ped_models + (size_t)my_model * PM_W;
+            pmm = PedMoveModel{(int)mm[PM_BEHAVIOUR], mm[PM_SF + 8], mm[PM_SF + 9], mm[PM_SF + 7]}; // bias_lon, bias_lat, max_speed_factor
+            nstd_lon = mm[PM_STD_LON];
+            nstd_lat = mm[PM_STD_LAT];
+            sg_loads_done();
+            for (int m = 0; m < p.n_ped_models; ++m) {
+                const bool mine = stepping && my_model == m;
+                if (!block_any<WV>(mine)) continue; // (workgroup-uniform)
+                Params q = p;
+                const double *row = p.ped_models + (size_t)m * PM_W;
+                q.ped_behaviour = (int)row[PM_BEHAVIOUR];
+                q.sf = *reinterpret_cast<const sg_social_force *>(row + PM_SF);
+                bool go_m = false;
+                double fx_m = 0.0, fy_m = 0.0, vdes_m = 0.0;
+                ped_force<WV, false>(q, lds, (int)r, sl, tile0, nbr, mine, pose, velx, vely, wp, nwp, goal_idx, go_m, fx_m, fy_m, vdes_m, K);
+                if (mine) { ped_go = go_m; ped_fx = fx_m; ped_fy = fy_m; ped_vdes = vdes_m; }
+            }
+        } else if (PED) // the social force of every stepping pedestrian of the wavefront (wave-collective)
             ped_force<WV, CROWD>(p, lds, (int)r, sl, tile0, nbr, is_agent && kind == SG_KIND_AGENT_PEDESTRIAN && present && run, pose,
                                  velx, vely, wp, nwp, goal_idx, ped_go, ped_fx, ped_fy, ped_vdes, K, crowd_static_ok && crowd_ok, CC, &ptm);
         // random fluctuations of the speed and the heading (social_force.py:106-108): np.random.normal(loc, scale) is
@@ -664,14 +690,14 @@ __device__ __forceinline__ void rollout_body_l(
             if (ped_go) {
                 const bool inside = at + 1 < p.noise_len;
                 const double *z = p.noise_normals + (size_t)r * (size_t)p.noise_len + (inside ? at : 0);
-                nz = PedNoise{p.noise_std_lon * (inside ? z[0] : 0.0), p.noise_std_lat * (inside ? z[1] : 0.0), true};
+                nz = PedNoise{nstd_lon * (inside ? z[0] : 0.0), nstd_lat * (inside ? z[1] : 0.0), true};
                 sg_loads_done();
             }
             if (run) noise_pos += 2 * count;
         } else if (PED && p.noise_mode == 2) {
             double z0, z1;
             sg_noise_pair(p.noise_seed, r, (uint32_t)slot, (uint32_t)steps, z0, z1, K);
-            nz = PedNoise{p.noise_std_lon * z0, p.noise_std_lat * z1, true};
+            nz = PedNoise{nstd_lon * z0, nstd_lat * z1, true};
         }
         if (TAB) {
             // Straight-line lane masks (the kernel is bound by instruction issue, branches included):
@@ -710,7 +736,7 @@ __device__ __forceinline__ void rollout_body_l(
                 if (present) {
                     npres = true;
                     if (run)
-                        ped_move<!CROWD>(p, ped_go, ped_fx, ped_fy, ped_vdes, lds.ctrl[PED ? SG_C_PED_MAX_SPEED - SG_C_PED_SPEED_DESIRED : 0][sl],
+                        ped_move<!CROWD>(pmm, ped_go, ped_fx, ped_fy, ped_vdes, lds.ctrl[PED ? SG_C_PED_MAX_SPEED - SG_C_PED_SPEED_DESIRED : 0][sl],
                                  pose, state_dt, cs.speed, fpx, fpy, np_, K, nz);
                 } else if (min_t >= t) { // scenario_gym.py:240-244: spawn at the trajectory position of next_t (clamped)
                     npres = true;
@@ -769,7 +795,7 @@ __device__ __forceinline__ void rollout_body_l(
                         else
                             vehicle_step(cs, cp, bl, dt, act_a, act_s, sin_h, cos_h, np_, K);
                     } else if (PED)
-                        ped_move<!CROWD>(p, ped_go, ped_fx, ped_fy, ped_vdes,
+                        ped_move<!CROWD>(pmm, ped_go, ped_fx, ped_fy, ped_vdes,
                                  lds.ctrl[PED ? SG_C_PED_MAX_SPEED - SG_C_PED_SPEED_DESIRED : 0][sl], pose, state_dt,
                                  cs.speed, fpx, fpy, np_, K, nz);
                 }

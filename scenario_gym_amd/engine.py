@@ -104,7 +104,10 @@ class RolloutEngine:
             raise RuntimeError(f"sg_create failed ({rc}): {msg}")
         self._view = None
         self._keep = None
-        if social_force is not None:
+        if social_force is not None and "models" in social_force:  # per-agent models (BatchedScenarioGym)
+            self.set_ped_models(social_force["models"], social_force.get("model_of"), noise=social_force.get("noise"),
+                                noise_seed=social_force.get("noise_seed", 0), normals=social_force.get("normals"))
+        elif social_force is not None:
             self.set_social_force(**social_force)
 
     def set_social_force(self, relaxation_time=1.5, ped_repulse_V=1.0, ped_repulse_sigma=1.0, ped_attract_C=0.0,
@@ -124,6 +127,44 @@ class RolloutEngine:
         if noise is None:
             noise = "device" if (std_lon != 0 or std_lat != 0) else "off"
         self.set_ped_noise(noise, std_lon, std_lat, normals=normals, seed=noise_seed)
+
+    def set_ped_models(self, models, model_of=None, noise=None, noise_seed=0, normals=None):
+        """sg_set_ped_models: per-agent behaviour models (pedestrian/agent.py:18-41: every PedestrianAgent holds its own
+        behaviour object).  models: dicts of set_social_force()'s parameter names (+ behaviour, std_lon, std_lat);
+        model_of[R * E]: the model of every entity slot (ignored where there is no pedestrian agent).  The noise MODE is one
+        per handle (noise = "off" / "device" / "stream" + normals; default: "device" when any std is non-zero); before upload()."""
+        rows = (L.SgPedModel * len(models))()
+        any_std = False
+        for i, m in enumerate(models):
+            m = dict(m)
+            beh = m.pop("behaviour", "social_force")
+            std_lon, std_lat = float(m.pop("std_lon", 0.0)), float(m.pop("std_lat", 0.0))
+            for k in ("noise", "noise_seed", "normals"):
+                m.pop(k, None)
+            d = dict(relaxation_time=1.5, ped_repulse_V=1.0, ped_repulse_sigma=1.0, ped_attract_C=0.0, sight_weight=0.5,
+                     sight_weight_use=True, sight_angle=200, max_speed_factor=1.3, bias_lon=0.0, bias_lat=0.0,
+                     imp_boundary_repulse_U=2.0, imp_boundary_repulse_R=0.1)
+            unknown = set(m) - set(d)
+            if unknown:
+                raise TypeError(f"set_ped_models: unknown parameters {sorted(unknown)}")
+            d.update(m)
+            rows[i].behaviour = {"social_force": L.PED_SOCIAL_FORCE, "random_walk": L.PED_RANDOM_WALK}[beh]
+            rows[i].params = L.SgSocialForce(d["relaxation_time"], d["ped_repulse_V"], d["ped_repulse_sigma"], d["ped_attract_C"],
+                                             d["sight_weight"], float(bool(d["sight_weight_use"])),
+                                             float(np.cos(d["sight_angle"] / 2 * np.pi / 180)), d["max_speed_factor"], d["bias_lon"],
+                                             d["bias_lat"], d["imp_boundary_repulse_U"], d["imp_boundary_repulse_R"])
+            rows[i].std_lon, rows[i].std_lat = std_lon, std_lat
+            any_std = any_std or std_lon != 0 or std_lat != 0
+        if noise is None:
+            noise = "device" if any_std else "off"
+        # the mode first (its std arguments are those of a one-model handle; the models carry their own)
+        self.set_ped_noise(noise, rows[0].std_lon, rows[0].std_lat, normals=normals, seed=noise_seed)
+        mo = None
+        if model_of is not None:
+            mo = np.ascontiguousarray(model_of, np.int32).ravel()
+            if mo.size != self.R * self.E:
+                raise ValueError(f"model_of must have n_scenarios * n_entities = {self.R * self.E} entries")
+        self._check(self.lib.sg_set_ped_models(self.h, len(models), rows, None if mo is None else mo.ctypes.data), "sg_set_ped_models")
 
     def set_ped_behaviour(self, behaviour="social_force"):
         """sg_set_ped_behaviour: "social_force" or "random_walk" for every pedestrian agent of the handle; before upload()."""

@@ -210,13 +210,32 @@ class BatchedScenarioGym:
         for c in dev_terms:
             if c not in TERMINAL_BITS:
                 raise ValueError(f"terminal condition {c!r} is not supported")
+        # behaviour models: every PedestrianAgent holds its own behaviour object (pedestrian/agent.py:18-41).  The distinct
+        # (behaviour, parameters, std) combinations of the batch become the device's models (sg_set_ped_models), every
+        # pedestrian slot carries the index of its own; one combination: the handle-wide parameter set, as before
         sf = None
-        for sc_agents in agents:  # one behaviour model and parameter set per batch (the first pedestrian agent's)
-            for a in sc_agents.values():
+        models, keys, model_of = [], {}, np.zeros(packed.n_scenarios * packed.n_entities, np.int32)
+        for i, (sc, sc_agents) in enumerate(zip(self.scenarios, agents)):
+            for e, a in sc_agents.items():
                 if hasattr(a, "behaviour"):
-                    sf = sf or a.behaviour.device_params()
-                    if a.behaviour.device_params()["behaviour"] != sf["behaviour"]:
-                        raise NotImplementedError("SocialForce and RandomWalk pedestrians in one batch: one behaviour model per gym")
+                    dp = a.behaviour.device_params()
+                    if sf is None:
+                        sf = dict(dp)
+                    elif (dp["noise"], dp["noise_seed"] if not hasattr(dp["noise_seed"], "__len__") else 0) != \
+                            (sf["noise"], sf["noise_seed"] if not hasattr(sf["noise_seed"], "__len__") else 0) and \
+                            "off" not in (dp["noise"], sf["noise"]):
+                        raise NotImplementedError("pedestrian behaviours with different noise sources (noise / noise_seed) in one gym: the "
+                                                  "reference draws every agent's variates from the one global generator")
+                    if sf["noise"] == "off" and dp["noise"] != "off":  # (a std-0 model beside a noisy one: the noisy one names the source)
+                        sf["noise"], sf["noise_seed"] = dp["noise"], dp["noise_seed"]
+                    key = tuple(sorted((k, v) for k, v in dp.items() if k not in ("noise", "noise_seed")))
+                    if key not in keys:
+                        keys[key] = len(models)
+                        models.append({k: v for k, v in dp.items() if k not in ("noise", "noise_seed")})
+                    model_of[i * packed.n_entities + sc.entities.index(e)] = keys[key]
+        self._n_ped_models = len(models)
+        if len(models) > 1:
+            sf = dict(models=models, model_of=model_of, noise=sf["noise"], noise_seed=sf["noise_seed"])
         if sf is not None and sf.get("noise") == "stream":
             # parity with the reference's global generator: scenario i draws what numpy hands out after seed(noise_seed + i)
             seeds = sf.pop("noise_seed")
@@ -253,6 +272,10 @@ class BatchedScenarioGym:
         self._invalidate()
         self._prev_state = None
         self._reset_host_side()
+
+    def engine_models(self) -> int:
+        """Distinct pedestrian behaviour models (behaviour, parameters, std) of the loaded batch (0: no pedestrian agents)."""
+        return getattr(self, "_n_ped_models", 0)
 
     def _set_road_networks(self):
         """Scenario.road_network of every scenario -> the device (shared networks once); needed by the ego_off_road

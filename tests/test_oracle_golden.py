@@ -592,6 +592,56 @@ def test_random_walk_closed_loops(oracle, si):
     assert np.nanmax(np.abs(o0["poses"][:n] - o["poses"][:n])) > 1e-3
 
 
+def mixed_model_rows(g, si, oracle):
+    """mixed_peds.npz loop si: the oracle's model rows (oracle.ped_model_row) and the model of every entity (0 where none)."""
+    cols = [str(c) for c in g["model_cols"]]
+    rows = []
+    for row in g[f"loop{si}/models"]:
+        m = dict(zip(cols, row))
+        sf = oracle.social_force_params(m["relaxation_time"] or 1.5, m["ped_repulse_V"], m["ped_repulse_sigma"] or 1.0, m["ped_attract_C"],
+                                        m["sight_weight"], bool(m["sight_weight_use"]), m["sight_angle"], m["max_speed_factor"],
+                                        m["bias_lon"], m["bias_lat"])
+        rows.append(oracle.ped_model_row("random_walk" if m["behaviour"] == 1 else "social_force", sf, m["std_lon"], m["std_lat"]))
+    return np.array(rows), np.maximum(g[f"loop{si}/model_of"], 0).astype(np.int32)
+
+
+@pytest.mark.parametrize("si", [0, 1, 2, 3])
+def test_mixed_pedestrian_models_closed_loops(oracle, si):
+    """Every PedestrianAgent of the reference holds its OWN behaviour object (pedestrian/agent.py:18-41): closed loops with
+    SocialForce pedestrians of two or three parameter sets and RandomWalk pedestrians in one scenario, after
+    np.random.seed(k) (mixed_peds.npz, make_golden_mixed_peds.py).  The oracle steps every pedestrian under its own model,
+    draws the two variates per walking pedestrian in agent order from the same legacy stream, and lands on the reference's
+    trajectories, speeds, goal indices and forces with exactly as many variates as numpy handed out."""
+    g = load_golden("mixed_peds")
+    sc, kind, ctrl, roff, routes = ped_inputs(g, si, oracle)
+    E = len(kind)
+    used = int(g[f"loop{si}/variates_used"])
+    normals = np.random.RandomState(int(g[f"loop{si}/np_seed"])).standard_normal(used + 64)
+    models, model_of = mixed_model_rows(g, si, oracle)
+    p = f"loop{si}/dt30"
+    o = oracle.rollout(**sc, kind=kind, dt=1 / 30, ctrl=ctrl, route_off=roff, routes=routes, models=models, model_of=model_of,
+                       noise=dict(mode="stream", std_lon=0.0, std_lat=0.0, normals=normals))
+    assert o["n_steps"] == int(g[p + "/n_steps"]) and bits_equal(o["t"], g[p + "/t"])
+    assert o["noise_used"] == used
+    for k in ("poses", "vels", "dists"):
+        assert np.array_equal(np.isnan(o[k]), np.isnan(g[p + "/" + k]))
+        assert np.nanmax(np.abs(o[k] - g[p + "/" + k])) < PED_TOL, (p, k)
+    ex = g[p + "/extra"]
+    ped = ~np.isnan(ex[0, :, 0])
+    assert np.array_equal(o["extra"][:, ped, 1], ex[:, ped, 1])              # goal_idx exact
+    assert np.abs(o["extra"][:, ped] - ex[:, ped]).max() < PED_TOL           # controller speed; force
+    rw = ped & (models[model_of, 0] == 1)
+    assert not ex[:, rw, 2:].any() and not o["extra"][:, rw, 2:].any()       # RandomWalk never touches agent.force
+    assert np.abs(ex[:, ped & ~rw, 2:]).max() > 0.1                          # ... the SocialForce pedestrians do feel one
+    assert np.array_equal(oracle.coll_to_dense(o["coll"], E), g[p + "/coll"])
+    assert np.array_equal(o["ev_t"], g[p + "/ev_t"]) and np.array_equal(o["ev_other"], g[p + "/ev_other"])
+    # one model for everybody walks elsewhere (the test would pass trivially otherwise)
+    o0 = oracle.rollout(**sc, kind=kind, dt=1 / 30, ctrl=ctrl, route_off=roff, routes=routes, sf=models[0, 1:13],
+                        noise=dict(mode="stream", std_lon=models[0, 13], std_lat=models[0, 14], normals=normals))
+    n = min(o0["n_steps"], o["n_steps"]) + 1
+    assert np.nanmax(np.abs(o0["poses"][:n] - o["poses"][:n])) > 1e-3
+
+
 def test_counter_based_noise_generator(oracle):
     """The timing-run generator (noise mode "device": Philox4x32-10 + Box-Muller with the shared log / sin / cos): standard
     normal moments over 2 x 10^5 variates, no correlation between the two outputs, different streams per scenario, and
@@ -611,7 +661,7 @@ def test_counter_based_noise_generator(oracle):
 # the others -- make_golden (220 s), ped_noise (280 s), roads (140 s), ped_roads / sensors (70-85 s) -- are regenerated by hand
 # with `python tools/regen_golden.py`, whose total ("3241 / 3241") is kept in profiles/
 FAST_GENERATORS = ["make_golden_actions", "make_golden_all_scenarios", "make_golden_collision_types", "make_golden_json",
-                   "make_golden_rss", "make_golden_random_walk"]
+                   "make_golden_rss", "make_golden_random_walk"]  # (+ make_golden_mixed_peds: 65 s, with the by-hand ones)
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/scenario_gym"), reason="build container only: regenerates from the reference")
