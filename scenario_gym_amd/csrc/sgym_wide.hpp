@@ -35,7 +35,7 @@ struct WideArgs {
     int mode;             // 0 step, 1 reset (State.reset for every scenario), 2 reset of the scenarios in p.reset_mask
     int force;
 };
-enum { WS_NP = 0, WS_NPRES = 6, WS_VEL = 7, WS_FPX = 13, WS_FPY = 14, WS_W = 16 };
+enum { WS_NP = 0, WS_NPRES = 6, WS_VEL = 7, WS_FPX = 13, WS_FPY = 14, WS_CUR = 15 /* the entity's knot segment of the previous step */, WS_W = 16 };
 
 struct WideEnt {
     int r, e;
@@ -100,6 +100,7 @@ static __global__ __launch_bounds__(256) void wide_move_kernel(Params p, double 
             for (int c = 0; c < 6; ++c) { scr[WS_NP + c] = np_[c]; scr[WS_VEL + c] = vel[c]; }
             scr[WS_NPRES] = npres ? 1.0 : 0.0;
             scr[WS_FPX] = scr[WS_FPY] = 0.0;
+            scr[WS_CUR] = 0.0; // (no segment yet: the first step searches)
         }
         return;
     }
@@ -115,10 +116,25 @@ static __global__ __launch_bounds__(256) void wide_move_kernel(Params p, double 
     double fpx = 0.0, fpy = 0.0;
     ConstTbl K = (ConstTbl)SG_TRIG;
     // the trajectory position at next_t: union grid for batch-replay entities, own knots for agents (constant outside)
+    // (every step is a launch of its own: the segment the entity was in a step ago is kept in its scratch row -- a step later the
+    // clock is still inside it, or in the next one; the binary search over the scenario's union grid, up to seventeen
+    // dependent loads, was most of this kernel's time on 1,024-entity scenarios)
+    const int cur_prev = in ? (int)scr[WS_CUR] : 0;
+    int cur_now = cur_prev;
     auto traj_at = [&](double tq, double (&out)[6]) {
         Table T = lane_table(p, kind, ss, e, w.st);
         Segment S;
-        S.cur = seg_locate(T, tq);
+        int c = cur_prev;
+        if (c >= 1 && c + 1 <= T.n - 1) { // seg_locate's answer is the first knot at or after tq: c, if the knot before it is earlier
+            const double xa = T.X(c - 1), xb = T.X(c), xc = T.X(c + 1);
+            if (xa < tq && tq <= xb) {}
+            else if (xb < tq && tq <= xc) c = c + 1;
+            else c = seg_locate(T, tq);
+        } else {
+            c = seg_locate(T, tq);
+        }
+        S.cur = c;
+        cur_now = c;
         seg_load(T, S);
         const double dq = tq - S.x_lo;
         for (int c = 0; c < 6; ++c) out[c] = S.sl[c] * dq + S.ylo[c];
@@ -245,6 +261,7 @@ static __global__ __launch_bounds__(256) void wide_move_kernel(Params p, double 
         scr[WS_FPX] = fpx; scr[WS_FPY] = fpy;
         // controller state of this step (committed by wide_commit_kernel together with the pose)
         scr[WS_VEL + 0] = cs.speed; scr[WS_VEL + 1] = cs.e_lon_prev; scr[WS_VEL + 2] = cs.e_lat_prev; scr[WS_VEL + 3] = cs.e_lon_int;
+        scr[WS_CUR] = (double)cur_now;
     }
 }
 
@@ -468,8 +485,28 @@ static __global__ __launch_bounds__(256) void wide_finish_kernel(Params p, doubl
         __threadfence();
         __syncthreads();
     }
-    if (tid != 0 || !wide_runs(p, wa, r)) return; // (one thread per scenario: the per-entity work is the kernels' before this one)
+    if (tid >= 64 || !wide_runs(p, wa, r)) return; // (one wavefront per scenario: the per-entity work is the kernels' before this one)
     const int W = p.FROWS - SG_F_COLL;
+    // The ego's row against CollisionMetric.last_timestep, a word per lane: in almost every step no bit is new, and the row
+    // only has to become the new `last` -- sixteen independent loads and stores instead of a chain of them on one thread
+    // (which was a third of the step on 1,024-entity scenarios).  A step WITH new bits takes the serial walk below.
+    bool lanes_did_rows = false;
+    if (wa.mode == 0) {
+        const WideEnt eg0(p, r, p.sstat[r].ego);
+        const bool egp = fld<uint64_t>(eg0.dy, SG_F_PRESENT) != 0;
+        uint64_t *last0 = wa.last_row + (size_t)r * W;
+        bool fresh_any = false;
+        uint64_t rows_l[4] = {0, 0, 0, 0};
+        for (int q = tid, k = 0; q < W && k < 4; q += 64, ++k) {
+            rows_l[k] = fld<uint64_t>(eg0.dy, SG_F_COLL + q);
+            fresh_any = fresh_any || (rows_l[k] & ~last0[q]) != 0;
+        }
+        if (egp && W <= 256 && !sg_any(fresh_any)) {
+            for (int q = tid, k = 0; q < W && k < 4; q += 64, ++k) last0[q] = rows_l[k];
+            lanes_did_rows = true;
+        }
+    }
+    if (tid != 0) return;
     const ScenStatic &ss = p.sstat[r];
     sg_scenario_state &sd = p.sdyn[r];
     // "some entity collides" / "entity 0 collides" (state.py:397-400): noted by wide_collide_kernel while it filled the rows (an
@@ -510,7 +547,7 @@ static __global__ __launch_bounds__(256) void wide_finish_kernel(Params p, doubl
     if ((p.term_mask & SG_TERM_COLLISION) && s_any) ndone = 1;
     if ((p.term_mask & SG_TERM_EGO_COLLISION) && s_ego0) ndone = 1;
     sd.done = ndone;
-    if (ego_present) { // CollisionMetric._step, metrics/collision.py:70-75
+    if (ego_present && !lanes_did_rows) { // CollisionMetric._step, metrics/collision.py:70-75
         int n_ev = sd.n_events;
         const double *A = wa.cor + ((size_t)r * p.EP + ss.ego) * 8;
         for (int q = 0; q < W; ++q) {
@@ -521,8 +558,8 @@ static __global__ __launch_bounds__(256) void wide_finish_kernel(Params p, doubl
                 fresh &= fresh - 1;
                 // how often j is listed for the ego: once per entity that hits the ego and shares j's geometry (j is its last owner)
                 const double *Bj = wa.cor + ((size_t)r * p.EP + j) * 8;
-                int mult = 0;
-                for (int k = 0; k <= j; ++k) {
+                int mult = (wa.dup[r] & 1u) ? 0 : 1; // (no twins in the scenario this step: j itself is the one entity behind the bit)
+                for (int k = 0; k <= j && (wa.dup[r] & 1u); ++k) {
                     const double *ck = wa.circ + ((size_t)r * p.EP + k) * 4;
                     if (!(ck[0] == ck[0]) || k == ss.ego) continue;
                     const double *Bk = wa.cor + ((size_t)r * p.EP + k) * 8;
