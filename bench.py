@@ -135,7 +135,7 @@ def kernel_name(E, crowd, controlled, rss=False, mix=False):
     G, WV = min(64, max(4, 1 << (E - 1).bit_length())), (1 if E <= 64 else 2 if E <= 128 else 4)
     if rss:  # (controlled lanes on the pre-pass table: the variant without in-kernel controllers)
         if WV == 1 and controlled and os.environ.get("SG_RSS_TAB", "1") != "0":
-            return f"sg::rollout_kernel_rss_tab<{G}>"
+            return f"sg::rollout_kernel_rss_tab{'q' if os.environ.get('SG_QUEUE', '1') != '0' else ''}<{G}>"
         return f"sg::rollout_kernel_rss<{G}, {WV}>"
     if crowd:
         if G == 64:  # (a crowd with riders -- lanes of other kinds on a pre-pass table -- has its own entry point)
@@ -739,7 +739,7 @@ def main(argv=None, make_engine=None):
                                 "(chunk, block) from a device-side counter (csrc/sgym_queue.hpp); no timing probe, no hardware-queue "
                                 "dependence"}
             # the table kernels of a batch with controlled lanes are expected to run as the persistent launch
-            if kname.startswith("sg::rollout_kernel_tab") and any(int(r_[0]) != 2 for r_ in sched):
+            if (kname.startswith("sg::rollout_kernel_tab") or kname.startswith("sg::rollout_kernel_rss_tab")) and any(int(r_[0]) != 2 for r_ in sched):
                 schedule["degraded"] = True
                 print(f"bench: DEGRADED launch schedule: {schedule['per_rank']} (SG_QUEUE=0, or the table ring could not be "
                       f"allocated); results are the same, throughput is not", file=sys.stderr)

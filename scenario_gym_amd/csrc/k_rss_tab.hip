@@ -10,6 +10,12 @@ void rollout_rss_tab(int G, dim3 grid, hipStream_t s, const sg::Params &p, doubl
     SGL_DISPATCH_G(G, CALL);
 #undef CALL
 }
+void rollout_rss_tabq(int G, dim3 grid, hipStream_t s, const sg::Params &p, double timestep, int force, const sg::TabQueue &tq)
+{
+#define CALL(G_) sg::rollout_kernel_rss_tabq<G_><<<grid, dim3(64), 0, s>>>(p, timestep, force, tq)
+    SGL_DISPATCH_G(G, CALL);
+#undef CALL
+}
 void rss_lines(dim3 grid, hipStream_t s, const sg::Params &p, const sg::TabGroups &tg)
 {
     sg::rss_lines_kernel<<<grid, dim3(64), 0, s>>>(p, tg);

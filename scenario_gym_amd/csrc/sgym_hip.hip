@@ -655,8 +655,8 @@ static int launch_crowd_chunks(sg_handle *h, int n_steps, int do_reset, int forc
 // grid of persistent wavefronts, work items (chunk, block) from a device-side counter.  `chunk` = the longest chunk.
 // Returns SG_OK, an error, or SG_QUEUE_FALLBACK: the table ring could not be allocated -- the caller takes the chunk launches.
 #define SG_QUEUE_FALLBACK 1
-static size_t slots_of(const sg_handle *h) { return (size_t)h->n_simd * (size_t)(h->planar ? SG_PLANAR_WAVES : SG_TAB_WAVES); }
-static int launch_queue(sg_handle *h, int n_steps, int force, const double *d_actions, int chunk, size_t *ev_next)
+static size_t slots_of(const sg_handle *h, bool rss) { return (size_t)h->n_simd * (size_t)(rss ? SG_WAVES_PER_SIMD : (h->planar ? SG_PLANAR_WAVES : SG_TAB_WAVES)); }
+static int launch_queue(sg_handle *h, int n_steps, int force, const double *d_actions, int chunk, size_t *ev_next, bool rss = false)
 {
     const size_t nblk = h->NE / 64, np = (size_t)h->p.n_ctl_pad, n_ctl_waves = np / 64;
     // chunks of the time axis: short at first (the first rollout items cannot start before the pre-pass has written their chunk),
@@ -752,7 +752,7 @@ static int launch_queue(sg_handle *h, int n_steps, int force, const double *d_ac
     tq.k0[0] = 0;
     for (int c = 0; c < C; ++c) tq.k0[c + 1] = tq.k0[c] + len[(size_t)c];
     // as many wavefronts as the device holds at once (three per SIMD), no more than there is work for
-    const size_t slots = slots_of(h);
+    const size_t slots = slots_of(h, rss);
     const unsigned grid = (unsigned)std::min(slots, n_ctl_waves + nblk);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     int rc;
@@ -766,7 +766,8 @@ static int launch_queue(sg_handle *h, int n_steps, int force, const double *d_ac
         HIP_TRY(h, hipStreamSynchronize(ws));
     }
     HIP_TRY(h, hipEventRecord(e0, h->stream));
-    sgl::rollout_tabq(h->G, h->planar, dim3(grid), h->stream, h->p, h->cfg.timestep, force, tq);
+    if (rss) sgl::rollout_rss_tabq(h->G, dim3(grid), h->stream, h->p, h->cfg.timestep, force, tq);
+    else sgl::rollout_tabq(h->G, h->planar, dim3(grid), h->stream, h->p, h->cfg.timestep, force, tq);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipEventRecord(e1, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->q_host, h->d_qwords, sg::Q_STATE_WORDS * sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
@@ -900,9 +901,8 @@ static int launch_rollout_impl(sg_handle *h, int n_steps, int do_reset, int forc
             if (rss_tab) ch = std::min(ch, std::max(1, h->rssq_steps)); // one launch fills at most the line-test queue
             // one persistent launch (sgym_queue.hpp) where the batch is one wavefront per block and nothing rides along; the
             // pre-pass role must leave most of the wavefront slots to the rollout
-            if (h->queue_mode && h->WV == 1 && !riders && !rss_tab && !no_overlap &&
-                (size_t)h->p.n_ctl_pad / 64 <= (size_t)h->n_simd / 2) {
-                rc = launch_queue(h, n_steps, force, d_actions, ch, &ev_next);
+            if (h->queue_mode && h->WV == 1 && !riders && !no_overlap && (size_t)h->p.n_ctl_pad / 64 <= (size_t)h->n_simd / 2) {
+                rc = launch_queue(h, n_steps, force, d_actions, ch, &ev_next, rss_tab);
                 if (rc != SG_QUEUE_FALLBACK) {
                     if (rc) return rc;
                     if (h->timing_now) HIP_TRY(h, hipEventRecord(h->ev1, h->stream));

@@ -121,12 +121,16 @@ __device__ __forceinline__ void q_handoff_writethrough(const Params &p, unsigned
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every store has left before the flag does
 }
 
-template <int G, bool PLANAR>
+// RSS: the RSSDistances callback runs inside the step loop (rollout_kernel_rss_tab's body: controlled lanes read the pre-pass
+// table with vector loads, the line tests are queued per wavefront); the queue of a work item is worked off by the same
+// wavefront right after its steps (rss_lines_block), and the entities' RSS state words travel with the block's state.
+template <int G, bool PLANAR, bool RSS = false>
 __device__ __forceinline__ void tabq_body(const Params &p, double timestep, int force, const TabQueue &tq)
 {
     using Tile = TileLds<64, false, false>;
     static_assert(sizeof(Tile) >= sizeof(CtlLds), "the pre-pass role lays its LDS over the tile");
     __shared__ Tile lds;
+    __shared__ typename std::conditional<RSS, RssQueue, char>::type rssq_lds;
     const int lane = threadIdx.x;
     // ---- role election.  The pre-pass chain is fp64 arithmetic back to back: two of its wavefronts on one SIMD run at half speed
     // each, and every block of their lanes waits for them (measured with first-come roles: the slowest pre-pass wavefront took
@@ -167,8 +171,9 @@ __device__ __forceinline__ void tabq_body(const Params &p, double timestep, int 
         CtlLds &cl = *reinterpret_cast<CtlLds *>(&lds);
         for (int c = 0; c < tq.n_chunks; ++c) {
             if (c >= tq.n_buf && !q_wait_ge(tq.chunk_cnt + (c - tq.n_buf), (unsigned)tq.nblk, tq, Q_ERR_RING_WAIT)) break;
+            // (RSS: the ego's metrics are the rollout's own, from its velocities -- the callback variant computes them anyway)
             control_body_l<true>(cl, ticket, p, timestep, tq.k0[c + 1] - tq.k0[c], c == 0, tq.k0[c], tq.actions,
-                                 tq.tab + (size_t)(c % tq.n_buf) * tq.buf_doubles, 0, 1);
+                                 tq.tab + (size_t)(c % tq.n_buf) * tq.buf_doubles, 0, RSS ? 0 : 1);
             q_release();
             if (tq.times && lane == 0) tq.times[(size_t)tq.n_chunks * tq.nblk * 4 + (size_t)ticket * tq.n_chunks + c] = wall_clock64();
             if (lane == 0) __hip_atomic_store(tq.ctl_prog + ticket, (unsigned)(c + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -230,11 +235,19 @@ __device__ __forceinline__ void tabq_body(const Params &p, double timestep, int 
         const bool in_range = r_raw < p.R;
         const int r = in_range ? r_raw : p.R - 1;
         const int ev_before = p.ev_cap > 0 ? min(p.sdyn[r].n_events, p.ev_cap) : 0;
-        rollout_body_l<G, 1, false, true, true, false, false, false, false, PLANAR>(lds, p, timestep, tq.k0[c + 1] - tq.k0[c], 0, force, nullptr,
-                                                                                   tab, SliceArgs{}, b);
+        if (RSS)
+            rollout_body_l<G, 1, false, false, false, false, true, false, false, false, false, true>(lds, p, timestep, tq.k0[c + 1] - tq.k0[c], 0, force,
+                                                                                                    nullptr, tab, SliceArgs{}, b);
+        else
+            rollout_body_l<G, 1, false, true, true, false, false, false, false, PLANAR>(lds, p, timestep, tq.k0[c + 1] - tq.k0[c], 0, force, nullptr,
+                                                                                       tab, SliceArgs{}, b);
         trace(4);
         stamp(2);
-        if (p.ev_cap > 0) { // (uniform) a controlled ego's pose at an event of this chunk is a row of the chunk's table: taken now
+        if (RSS) { // the line tests this item queued, over full wavefronts (rss_lines_kernel's body), then the state words
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            rss_lines_block(p, (RssQueueLds)&rssq_lds, (size_t)b);
+        }
+        if (!RSS && p.ev_cap > 0) { // (uniform) a controlled ego's pose at an event of this chunk is a row of the chunk's table: taken now
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (the ego lane's event stores)
             const int ev_after = in_range ? min(p.sdyn[r].n_events, p.ev_cap) : 0;
             if (ev_after > ev_before) {
@@ -244,6 +257,32 @@ __device__ __forceinline__ void tabq_body(const Params &p, double timestep, int 
             }
         }
         trace(5);
+        if (RSS) {
+            // The entities' RSS words travel with the block: the state word is what the next item starts from; the records of the
+            // latest update (code, safe distances, the step they belong to) are REWRITTEN by every item that touches the
+            // scenario, possibly from another XCD -- left as plain stores, two L2s would hold dirty copies of the same words
+            // and the older one could be written back last.  Write-through, like the state rows.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            typedef SG_GLOBAL int gi32;
+            typedef SG_GLOBAL unsigned long long gu64;
+            const size_t idx = (size_t)b * 64 + lane;
+            gi32 *sw = (gi32 *)(p.rss_state + idx), *cw = (gi32 *)(p.rss_code + idx);
+            gu64 *fw = (gu64 *)(p.rss_safe + idx * 2);
+            const int v0 = __hip_atomic_load(sw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int v1 = __hip_atomic_load(cw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long v2 = __hip_atomic_load(fw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long v3 = __hip_atomic_load(fw + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(sw, v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(cw, v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(fw, v2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(fw + 1, v3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int glr = (int)b * 64 + lane;
+            if ((glr & (G - 1)) == 0 && glr / G < p.R) {
+                gi32 *nw = (gi32 *)(p.rss_seen + glr / G);
+                const int v4 = __hip_atomic_load(nw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(nw, v4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
         if (tq.handoff == 1) q_handoff_writethrough<G>(p, b, lane);
         else if (tq.handoff == 0) q_release();
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (2: measurement only -- nothing makes the stores visible)
@@ -272,6 +311,13 @@ __global__ __launch_bounds__(64, SG_PLANAR_WAVES) __attribute__((amdgpu_num_vgpr
     Params p, double timestep, int force, TabQueue tq)
 {
     tabq_body<G, true>(p, timestep, force, tq);
+}
+
+// ... with the RSSDistances callback in the step loop (rollout_kernel_rss_tab's budget: two wavefronts per SIMD)
+template <int G>
+__global__ __launch_bounds__(64, SG_WAVES_PER_SIMD) void rollout_kernel_rss_tabq(Params p, double timestep, int force, TabQueue tq)
+{
+    tabq_body<G, false, true>(p, timestep, force, tq);
 }
 
 } // namespace sg

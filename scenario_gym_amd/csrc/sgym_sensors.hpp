@@ -466,49 +466,7 @@ static __global__ __launch_bounds__(512) void rss_kernel(Params p, int reset, in
 static __global__ __launch_bounds__(64) void rss_lines_kernel(Params p, TabGroups tg)
 {
     __shared__ RssQueue q;
-    const RssQueueLds ql = (RssQueueLds)&q;
-    const int lane = threadIdx.x;
-    const size_t w = tg.map(blockIdx.x);
-    const int n = p.rssq_n[w];
-    const uint32_t idx = (uint32_t)(w * 64 + lane);
-    int32_t st = p.rss_state[idx];
-    if (n == 0 && !sg_any(st & RSS_ST_PENDING)) return;
-    ql->lastword[lane] = 0;
-    ql->stepcd[lane] = 0;
-    ql->hits[lane] = 0;
-    const double *rec0 = p.rssq + w * (size_t)p.rssq_cap * RSSQ_REC;
-    for (int g0 = 0; g0 < n; g0 += RSSQ_CAP) {
-        const int m = min(RSSQ_CAP, n - g0);
-        if (lane < m) {
-            const double2 *rec = reinterpret_cast<const double2 *>(rec0 + (size_t)(g0 + lane) * RSSQ_REC);
-#pragma unroll
-            for (int k = 0; k < 5; ++k) {
-                const double2 v = rec[k];
-                ql->q[2 * k][lane] = v.x;
-                ql->q[2 * k + 1][lane] = v.y;
-            }
-            const uint64_t mk = (uint64_t)__double_as_longlong(rec[5].x);
-            ql->meta[lane] = (int)(uint32_t)mk;
-            ql->key[lane] = (unsigned)(mk >> 32);
-        }
-        tile_sync<1>();
-        rss_flush_body(ql, m);
-    }
-    tile_sync<1>();
-    const unsigned lw = ql->lastword[lane], sc = ql->stepcd[lane];
-    int cd = p.rss_code[idx];
-    const int32_t st0 = st;
-    const int cd0 = cd;
-    if (lw) st = (st & ~0xff00) | (int)(lw & 3) << 8;
-    if (st & RSS_ST_PENDING) { // the entity entered the buffer during the launch: unsafe_distance, callback.py:196-213
-        const int last = (st >> 8) & 0xff;
-        const int cls = last == 1 ? 5 : (last == 2 ? 4 : ((st & RSS_ST_AB) ? 5 : 4));
-        st = (st & 0xff00) | (cls == 4 ? 1 : 2);
-        if (cd == RSS_CD_ISECT) cd = cls;
-    }
-    if (cd <= -4) cd = (sc >> 3) == (unsigned)(-4 - cd) ? (int)(sc & 7) : 0; // the latest update's line tests were queued
-    if (st != st0) p.rss_state[idx] = st;
-    if (cd != cd0) p.rss_code[idx] = cd;
+    rss_lines_block(p, (RssQueueLds)&q, tg.map(blockIdx.x));
 }
 #endif // SG_UNIT_RSS_LINES
 

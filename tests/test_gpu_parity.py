@@ -2567,8 +2567,9 @@ def test_rss_callback_inside_the_graph_tick(sga):
 
 @pytest.mark.parametrize("E,ego", [(64, "pid"), (9, "replay"), (130, "pid")])
 def test_rss_line_test_queues_across_launches(sga, monkeypatch, E, ego):
-    """The line tests of rollout_kernel_rss are queued per wavefront and evaluated by rss_lines_kernel after each launch; the
-    queues hold a fixed number of steps.  One launch, launches of a few steps each (queues of 1 MiB), and a rollout resumed
+    """The line tests of rollout_kernel_rss are queued per wavefront and evaluated after each launch (rss_lines_kernel) / after
+    each work item of the persistent launch (rss_lines_block); the queues hold a fixed number of steps.  One piece, pieces
+    of a few steps each (queues of 1 MiB), and a rollout resumed
     in pieces by the caller: the same records, states and flags -- the `last` entry and a pending "unsafe" class carry over
     from launch to launch."""
     import scenario_gym_amd._lib as L
@@ -2595,7 +2596,8 @@ def test_rss_line_test_queues_across_launches(sga, monkeypatch, E, ego):
             launches = 0
         else:
             eng.rollout(steps)
-            launches = eng.last_launch_stats()[0]
+            info = eng.schedule_info()  # pieces of the call: chunks of the persistent launch (PID egos), else launches
+            launches = info["chunks"] if info["schedule"] == SCHED_QUEUE else eng.last_launch_stats()[0]
         out.append((eng.rss(), eng.state()["n_steps"].copy(), launches))
         eng.close()
     assert out[1][2] > out[0][2] >= 1  # the small queues did split the call
