@@ -31,7 +31,10 @@ wl = cfg["name"]
 rec = dict(scenarios=cfg["scenarios_per_gpu"], entities=E, sim_steps=T, src_sha16=line["roofline"]["src_sha16"],
            kernel=line["roofline"]["kernel"], waves=waves, per_wave_step=out, control_kernel_per_step=ctl,
            note="rocprofv3 --pmc (SQ counters only) over one rollout of the workload, summed over the rollout-kernel dispatches and "
-                "divided by wavefronts x steps; *_CYCLES / ACTIVE / WAIT in quad-cycles")
+                "divided by wavefronts x steps; *_CYCLES / ACTIVE / WAIT in quad-cycles.  The persistent table launch "
+                "(rollout_kernel_tabq*) carries the controller pre-pass as a role of the same kernel: its instructions (~6.6 VALU per "
+                "wavefront-step of the 4096 x 64 batch) and the cycles its wavefronts and the waiting rollout wavefronts are "
+                "resident are in these figures")
 json.dump(rec, open(f"gpurun_out/{tag}_pmc_sq.json", "w"), indent=1)
 json.dump(rec, open(f"gpurun_out/latest_{wl}_pmc_sq.json", "w"), indent=1)
 print(txt)

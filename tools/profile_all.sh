@@ -1,6 +1,7 @@
 #!/bin/bash
 # Usage (GPU box): bash tools/profile_all.sh <tag>   -- tools/profile_round.sh for every bench workload (c3 = <tag>_*, the others
-# <tag>_<workload>_*), + the upload and RSS timings, the launch timeline, the one-pipeline and general-table-kernel lines; then
+# <tag>_<workload>_*), + the upload and RSS timings, the launch timeline, the chunk-launch (SG_QUEUE=0) and general-table-kernel lines,
+# the per-item timeline of the persistent launch and the wide-scenario timings; then
 # the counter passes go where bench.py looks for them (profiles/latest_* in the box's copy of the tree) and the bench lines are
 # run again, so that they carry `traffic` and `secondary` of THESE sources.  ~17 minutes.  Copy gpurun_out/<tag>_* and
 # gpurun_out/latest_* into profiles/ (not the *_trace / *_pmc_* directories).
@@ -28,5 +29,8 @@ python3 bench.py --workload c3rss --steps 3 --warmup 1 > gpurun_out/${tag}_c3rss
 python3 bench.py --workload c3s --steps 5 --warmup 1 > gpurun_out/${tag}_c3s_bench.json 2>/dev/null
 python3 bench.py --workload c5mix --steps 1 --warmup 1 > gpurun_out/${tag}_c5mix_bench.json 2>/dev/null
 SG_PLANAR=0 python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/${tag}_nonplanar_bench.json 2>/dev/null
-SG_TAB_SPLIT=1 python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/${tag}_one_pipeline_bench.json 2>/dev/null
+SG_QUEUE=0 python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/${tag}_chunk_launches_bench.json 2>/dev/null
+python3 tools/dbg/queue_timeline.py > gpurun_out/${tag}_queue_timeline.txt 2>&1
+python3 tools/dbg/wide_time.py > gpurun_out/${tag}_wide_time.txt 2>&1
+SG_CROWD_WALK=4 python3 bench.py --workload c5 --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/${tag}_c5_walk4_bench.json 2>/dev/null
 tail -3 gpurun_out/${tag}_upload_time.txt gpurun_out/${tag}_rss_time.txt
