@@ -338,12 +338,18 @@ def run_e2e(args):
         def merged(fut):
             """(a helper thread) wait for the import of a chunk, then merge the workers' arrays: one copy out of their
             shared-memory segments; numpy's copies release the GIL, so this runs under the main thread's upload of the chunk before"""
-            from scenario_gym_amd.packing import merge_packed_shm
+            from scenario_gym_amd.packing import merge_packed_shm, release_shm
 
             t = time.perf_counter()
-            parts = list(fut)
+            parts = []
+            try:
+                for q in fut:
+                    parts.append(q)
+            except BaseException:
+                release_shm(parts)  # (a worker failed: the segments received so far would stay in /dev/shm)
+                raise
             t1 = time.perf_counter()
-            packed = merge_packed_shm(parts)
+            packed = merge_packed_shm(parts)  # (removes its segments itself, also when it fails)
             return packed, t1 - t, time.perf_counter() - t1
 
         def device_part(gym, packed):

@@ -322,8 +322,11 @@ int sg_step(sg_handle *h, int32_t n_steps, const double *actions, int32_t action
 int sg_set_external_poses(sg_handle *h, const double *poses);
 
 /* ScenarioGym.rollout(): reset, then step each scenario while it is not done, at most max_steps
- * (scenario_gym.py:256-267).  The time loop runs inside the kernels: one launch of the rollout kernel per chunk of
- * steps (all of them for short runs), preceded by the controller pre-pass when the batch has PID / vehicle agents. */
+ * (scenario_gym.py:256-267).  The time loop runs inside the kernels: one launch for short runs; long runs of batches with
+ * PID / vehicle agents as ONE persistent launch that carries the controller pre-pass (sg_schedule_info), else one launch per
+ * chunk of steps.  Scenarios of more than 512 entities step through four launches per step; the host only enqueues there
+ * too (every 64 steps a kernel reports into page-locked memory how many scenarios still run, and the call stops enqueuing
+ * once an earlier report says none: the steps enqueued meanwhile are no-ops). */
 int sg_rollout(sg_handle *h, int32_t max_steps);
 /* Same without the reset and without waiting: enqueue on the handle's stream (bench timing) */
 int sg_rollout_async(sg_handle *h, int32_t max_steps, int32_t do_reset);

@@ -10,4 +10,5 @@ void wide_step(dim3 ge, dim3 gs, hipStream_t s, const sg::Params &p, double time
     sg::wide_collide_kernel<<<ge, dim3(256), 0, s>>>(p, wa);
     sg::wide_finish_kernel<<<gs, dim3(256), 0, s>>>(p, timestep, wa);
 }
+void wide_running(hipStream_t s, const sg::Params &p, int *host_word) { sg::wide_running_kernel<<<dim3(1), dim3(256), 0, s>>>(p, host_word); }
 } // namespace sgl

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <functional>
 #include <atomic>
 #include <cmath>
 #include <cstdarg>
@@ -96,6 +97,8 @@ struct sg_handle {
     bool wide = false;                           // more than 512 entities per scenario: the multi-kernel step (sgym_wide.hpp)
     std::vector<void *> wide_allocs;
     sg::WideArgs wide_args{};
+    int *wide_running = nullptr;    // page-locked ring of "scenarios still running" answers (launch_wide)
+    unsigned wide_check = 0;        // check points enqueued so far
     // page-locked staging of sg_read_metrics (the per-scenario state and the event table travel every time metrics are read:
     // 0.5 + up to 6 MB for 4096 scenarios; pageable copies ran at a third of the PCIe rate)
     void *pin_sd = nullptr, *pin_ev = nullptr;
@@ -406,6 +409,7 @@ extern "C" int sg_destroy(sg_handle *h)
     if (h->d_qwords) (void)hipFree(h->d_qwords);
     if (h->d_qtab) (void)hipFree(h->d_qtab);
     if (h->q_host) (void)hipHostFree(h->q_host);
+    if (h->wide_running) (void)hipHostFree(h->wide_running);
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->up_ev) (void)hipEventDestroy(e);
     if (h->up_stat) (void)hipHostFree(h->up_stat);
@@ -534,12 +538,14 @@ static int launch_main(sg_handle *h, int n_steps, int do_reset, int force, const
 // for a chunk of steps on its own stream while rollout_kernel<TAB> consumes the previous chunks' tables -- large batches as
 // two or three pipelines on streams of their own (below).
 // Scenarios of more than 512 entities (sgym_wide.hpp): State.reset / n x ScenarioGym.step as four kernels per step.  Every
-// scenario that may run steps in lockstep (a done scenario sits the step out unless `force`); rollout() stops launching when
-// a readback every 64 steps says everybody is done.
+// scenario that may run steps in lockstep (a done scenario sits the step out unless `force`).  The host never waits here: every
+// 64 steps a one-workgroup kernel writes the number of running scenarios into page-locked memory, and rollout() stops
+// enqueuing once an EARLIER check point has answered 0 (what it enqueued in the meantime are no-ops).
 static int launch_wide(sg_handle *h, int n_steps, int do_reset, int force, const double *d_actions)
 {
     const int R = h->R, EP = h->EP;
     int rc = SG_OK;
+    constexpr unsigned RING = 1024;
     if (!h->wide_args.scr) {
         auto &A = h->wide_allocs;
         if ((rc = dev_alloc(h, A, &h->wide_args.scr, h->NE * sg::WS_W)) || (rc = dev_alloc(h, A, &h->wide_args.cor, h->NE * 8)) ||
@@ -547,6 +553,7 @@ static int launch_wide(sg_handle *h, int n_steps, int do_reset, int force, const
             (rc = dev_alloc(h, A, &h->wide_args.last_same, h->NE)) || (rc = dev_alloc(h, A, &h->wide_args.dup, (size_t)R)))
             return rc;
     }
+    if (!h->wide_running) HIP_TRY(h, hipHostMalloc((void **)&h->wide_running, RING * sizeof(int), hipHostMallocDefault));
     const dim3 ge((unsigned)((EP + 255) / 256), (unsigned)R), gs((unsigned)R);
     auto one = [&](int mode, const double *acts) {
         sg::WideArgs wa = h->wide_args;
@@ -559,16 +566,20 @@ static int launch_wide(sg_handle *h, int n_steps, int do_reset, int force, const
         one(do_reset == 2 ? 2 : 1, nullptr);
         HIP_TRY(h, hipGetLastError());
     }
+    const unsigned first_check = h->wide_check;
     for (int k = 0; k < n_steps; ++k) {
         one(0, d_actions ? d_actions + (size_t)k * R * 2 : nullptr);
         if (!force && (k & 63) == 63 && k + 1 < n_steps) { // is anybody still running?
             HIP_TRY(h, hipGetLastError());
-            std::vector<sg_scenario_state> sd((size_t)R);
-            HIP_TRY(h, hipMemcpyAsync(sd.data(), h->p.sdyn, (size_t)R * sizeof(sg_scenario_state), hipMemcpyDeviceToHost, h->stream));
-            HIP_TRY(h, hipStreamSynchronize(h->stream));
-            bool all = true;
-            for (int r = 0; r < R && all; ++r) all = sd[(size_t)r].done != 0;
-            if (all) break;
+            bool nobody = false;
+            for (unsigned c = first_check; c != h->wide_check && !nobody; ++c)
+                nobody = __atomic_load_n(&h->wide_running[c % RING], __ATOMIC_ACQUIRE) == 0;
+            if (nobody) break;
+            if (h->wide_check - first_check < RING) { // (a call of more than 65,536 steps stops asking)
+                int *word = &h->wide_running[h->wide_check++ % RING];
+                __atomic_store_n(word, -1, __ATOMIC_RELEASE);
+                sgl::wide_running(h->stream, h->p, word);
+            }
         }
     }
     HIP_TRY(h, hipGetLastError());
@@ -660,23 +671,44 @@ static int launch_queue(sg_handle *h, int n_steps, int force, const double *d_ac
 {
     const size_t nblk = h->NE / 64, np = (size_t)h->p.n_ctl_pad, n_ctl_waves = np / 64;
     // chunks of the time axis: short at first (the first rollout items cannot start before the pre-pass has written their chunk),
-    // growing by ~1.4x up to `chunk` -- the pre-pass is only 1.3 ... 1.9x faster per step than a rollout wavefront beside it, so
-    // chunk c + 1 has to be written in about the time chunk c takes to roll out: with lengths that doubled, a quarter of the
-    // wavefronts waited through the first 4 ms (tools/dbg/queue_timeline.py) -- and halving again at the end (the last items of
-    // the queue leave slots idle for as long as the longest of them runs).  SG_QUEUE_GROW: the growth in percent.
+    // growing by ~1.4x -- the pre-pass is only 1.3 ... 1.9x faster per step than a rollout wavefront beside it, so chunk c + 1
+    // has to be written in about the time chunk c takes to roll out: with lengths that doubled, a quarter of the wavefronts
+    // waited through the first 4 ms (tools/dbg/queue_timeline.py) -- up to a plateau of SG_QUEUE_CAP = 512 steps (blocks are
+    // at most one chunk apart, and the call ends when the LAST block does: 1024-step chunks measured 4 % slower, 256-step
+    // ones 2 %, profiles/r05_ab_chunk_cap.txt), and shrinking again the same way at the end (SG_QUEUE_DECAY, percent) so that
+    // the last items are short.  SG_QUEUE_GROW: the growth in percent.
     std::vector<int> len;
+    chunk = std::min(chunk, std::max(1, env_int("SG_QUEUE_CAP", 512))); // (never above what the caller allows: the RSS line-test queue holds `chunk` steps)
     const int first = std::max(1, std::min(chunk, env_int("SG_QUEUE_FIRST", 96)));
     const int grow = std::max(101, env_int("SG_QUEUE_GROW", 140));
-    for (int k0 = 0, n = 0; k0 < n_steps; k0 += n) {
-        const long long want = len.empty() ? first : std::max<long long>((long long)len.back() + 1, (long long)len.back() * grow / 100);
-        n = (int)std::min<long long>(std::min<long long>(chunk, want), n_steps - k0);
-        if (want >= chunk / 2 + chunk / 4 && want < chunk) n = std::min(chunk, n_steps - k0); // (no odd chunk just below the cap)
-        len.push_back(n);
-    }
-    while (len.size() > 1 && len.back() >= 2 * first && len.back() > 128) { // ..., L -> ..., L - L / 2, L / 2, repeated on the tail
-        const int L = len.back(), half = L / 2;
-        len.back() = L - half;
-        len.push_back(half);
+    const int decay = env_int("SG_QUEUE_DECAY", 140); // 0: only the last chunk is halved (below)
+    std::vector<int> up, down; // first, first * g, ... (< chunk); the mirror image at the end of the call
+    for (long long n = first; n < chunk && n < chunk * 3ll / 4; n = std::max(n + 1, n * grow / 100)) up.push_back((int)n);
+    if (decay > 100)
+        for (long long n = first; n < chunk && n < chunk * 3ll / 4; n = std::max(n + 1, n * decay / 100)) down.insert(down.begin(), (int)n);
+    long long ramp = 0;
+    for (int n : up) ramp += n;
+    for (int n : down) ramp += n;
+    if (ramp + chunk <= n_steps) {
+        // ramp up, a plateau of whole chunks, ramp down; what is left over (< chunk) goes where the ramp down reaches its length
+        const long long mid = n_steps - ramp;
+        const int whole = (int)(mid / chunk), rest = (int)(mid % chunk);
+        len = up;
+        len.insert(len.end(), (size_t)whole, chunk);
+        if (rest > 0) down.insert(std::lower_bound(down.begin(), down.end(), rest, std::greater<int>()), rest);
+        len.insert(len.end(), down.begin(), down.end());
+    } else {
+        for (int k0 = 0, n = 0; k0 < n_steps; k0 += n) {
+            const long long want = len.empty() ? first : std::max<long long>((long long)len.back() + 1, (long long)len.back() * grow / 100);
+            n = (int)std::min<long long>(std::min<long long>(chunk, want), n_steps - k0);
+            if (want >= chunk / 2 + chunk / 4 && want < chunk) n = std::min(chunk, n_steps - k0); // (no odd chunk just below the cap)
+            len.push_back(n);
+        }
+        while (len.size() > 1 && len.back() >= 2 * first && len.back() > 128) { // ..., L -> ..., L - L / 2, L / 2, repeated on the tail
+            const int L = len.back(), half = L / 2;
+            len.back() = L - half;
+            len.push_back(half);
+        }
     }
     const int C = (int)len.size();
     if (C > sg::Q_MAX_CHUNKS) return SG_QUEUE_FALLBACK;
@@ -732,6 +764,7 @@ static int launch_queue(sg_handle *h, int n_steps, int force, const double *d_ac
     tq.actions = d_actions;
     tq.timeout_ticks = (long long)std::max(1, env_int("SG_QUEUE_TIMEOUT_MS", 20000)) * 100000ll; // 100 MHz
     tq.handoff = env_int("SG_QUEUE_HANDOFF", 1);
+    tq.lag_prio = env_int("SG_QUEUE_LAGPRIO", 2);
     const char *times_path = getenv("SG_QUEUE_TIMES"); // experiment: per-item time stamps, dumped as u64 after the launch
     static unsigned long long *d_times = nullptr;
     static size_t times_cap = 0;
@@ -1345,9 +1378,6 @@ extern "C" int sg_upload(sg_handle *h, const sg_scenarios *sc)
         return fail(h, SG_ERR_INVALID, "sg_upload: several pedestrian behaviour models (sg_set_ped_models) on scenarios of more than 512 entities: "
                                        "the multi-kernel step holds one model");
     if (h->wide) { // more than 512 entities per scenario: the multi-kernel step (sgym_wide.hpp) and what it does not do
-        for (size_t i = 0; i < (size_t)h->R * h->E; ++i)
-            if (sc->kind[i] == SG_KIND_AGENT_EXTERNAL)
-                return fail(h, SG_ERR_INVALID, "sg_upload: caller-run agents (SG_KIND_AGENT_EXTERNAL) are available up to 512 entities per scenario");
         if (h->cfg.terminal_mask & SG_TERM_EGO_OFF_ROAD)
             return fail(h, SG_ERR_INVALID, "sg_upload: the ego_off_road terminal condition is available up to 512 entities per scenario");
         if (h->has_ped && h->noise_mode == SG_NOISE_STREAM)

@@ -43,6 +43,8 @@ struct TabQueue {
                                // wavefront w after chunk c at [n_items * 4 + w * n_chunks + c] (nullptr: not recorded)
     long long timeout_ticks; // of the 100 MHz wall clock
     int n_chunks, n_buf, nblk, n_ctl_waves;
+    int lag_prio;         // items of blocks that are behind run at a raised priority: 0 no, 1 s_setprio 1, 2 s_setprio 2 (c3: 88.5 ->
+                          // 92.5 / 93.0 G, means of six interleaved runs each, profiles/r05_ab_lagprio.txt)
     int handoff;          // how a rollout item hands its block on: 0 = release fence (buffer_wbl2: the whole L2 of the XCD is written
                           // back), 1 = the block's state rows and scenario records re-stored write-through (sc1), no fence
     int k0[Q_MAX_CHUNKS + 1]; // chunk c covers steps k0[c] .. k0[c + 1] - 1 of the call
@@ -212,7 +214,16 @@ __device__ __forceinline__ void tabq_body(const Params &p, double timestep, int 
             if (tq.times && lane == 0) tq.times[(size_t)item * 4 + k] = wall_clock64();
         };
         stamp(0);
+        // A block whose previous chunk is not finished when its next one is pulled is behind the others: the call ends with
+        // the slowest chain of items (tools/dbg/queue_timeline.py: the slowest block's items add up to 24.9 of the call's 27.1 ms),
+        // so its item runs first in line at its SIMD's issue port (tq.lag_prio).
+        const bool behind = c != 0 && q_peek(tq.blk_prog + b) < c;
         bool ok = c == 0 || q_wait_ge(tq.blk_prog + b, c, tq, Q_ERR_BLOCK_WAIT);
+        if (tq.lag_prio) {
+            if (!behind) __builtin_amdgcn_s_setprio(0);
+            else if (tq.lag_prio == 1) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(2);
+        }
         {   // the pre-pass wavefronts that integrate this block's controlled lanes
             const LanePtr st(p.stat + (size_t)b * (ST_COUNT * 64), (uint32_t)lane * 8u);
             const int64_t cq = fld<int64_t>(st, ST_CTL);

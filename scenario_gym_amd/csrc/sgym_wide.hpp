@@ -16,7 +16,7 @@
 //   wide_finish_kernel   one workgroup per scenario: the clock, terminal conditions, ego metrics, CollisionMetric events
 // in that order, once per step.  Same arithmetic as the fused kernels and the oracle (plain IEEE operations: ExactArith), so
 // the same bits; 4 launches per step instead of thousands of steps per launch -- the price of not having a ceiling.
-// Not at this width: caller-run agents (SG_KIND_AGENT_EXTERNAL), road networks, the RSS callback, the observation kernels,
+// Not at this width: road networks, the RSS callback, the observation kernels,
 // the noise stream mode (the counter-based generator works).
 #pragma once
 #include "sgym_device.hpp"
@@ -221,7 +221,17 @@ static __global__ __launch_bounds__(256) void wide_move_kernel(Params p, double 
         npres = p.persist || is_static || (next_t >= min_t && next_t <= max_t);
         traj_at(next_t, np_);
     } else if (kind >= SG_KIND_AGENT_REPLAY && in) {
-        if (present) {
+        if (present && kind == SG_KIND_AGENT_EXTERNAL) {
+            // the caller ran agent.step(state) (agent.py:52-57): its pose, or None = NaN (scenario_gym.py:233-239)
+            const double *ep = p.ext_pose + (size_t)w.g * 6;
+            if (ep[0] == ep[0]) {
+                npres = true;
+                for (int c = 0; c < 6; ++c) np_[c] = ep[c];
+            } else if (p.persist) {
+                npres = true;
+                for (int c = 0; c < 6; ++c) np_[c] = pose[c];
+            }
+        } else if (present) {
             npres = true;
             if (kind == SG_KIND_AGENT_REPLAY) {
                 traj_at(next_t, np_);
@@ -590,5 +600,20 @@ static __global__ __launch_bounds__(256) void wide_finish_kernel(Params p, doubl
     }
 }
 #endif // SG_UNIT_WIDE
+
+// How many scenarios are still running, written to page-locked host memory: launch_wide looks at the answers of EARLIER
+// check points without waiting for them and stops enqueuing steps once one says nobody is (the steps already enqueued are
+// no-ops for a done scenario), so a rollout of wide scenarios stays asynchronous for the host.
+static __global__ __launch_bounds__(256) void wide_running_kernel(Params p, int *out)
+{
+    __shared__ int s_n;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    int n = 0;
+    for (int r = threadIdx.x; r < p.R; r += 256) n += p.sdyn[r].done == 0;
+    if (n) atomicAdd(&s_n, n);
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(out, s_n, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 } // namespace sg

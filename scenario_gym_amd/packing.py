@@ -281,7 +281,21 @@ def packed_to_shm(p: PackedScenarios) -> dict:
     from multiprocessing import shared_memory
 
     kn = np.ascontiguousarray(p.knots, np.float64)
-    shm = shared_memory.SharedMemory(create=True, size=max(kn.nbytes, 8))
+    small = dict(shape=kn.shape, R=p.n_scenarios, E=p.n_entities, kind=p.kind, etype=p.etype, bbox=p.bbox,
+                 knot_off=p.knot_off, ego=p.ego, t0=p.t0, length=p.length, ctrl=p.ctrl, refs=getattr(p, "refs", None))
+    # A /dev/shm that cannot hold the rows (containers default to 64 MB) would kill this process with SIGBUS at the first
+    # page it cannot back, not raise: ask first, and send the rows through the ordinary pickle of the result otherwise.
+    try:
+        st = os.statvfs("/dev/shm")
+        room = st.f_bavail * st.f_frsize >= 2 * kn.nbytes + (16 << 20)
+    except OSError:
+        room = False
+    if not room:
+        return dict(small, shm=None, knots=kn)
+    try:
+        shm = shared_memory.SharedMemory(create=True, size=max(kn.nbytes, 8))
+    except OSError:
+        return dict(small, shm=None, knots=kn)
     np.ndarray(kn.shape, np.float64, buffer=shm.buf)[...] = kn
     meta = dict(shm=shm.name, shape=kn.shape, R=p.n_scenarios, E=p.n_entities, kind=p.kind, etype=p.etype, bbox=p.bbox,
                 knot_off=p.knot_off, ego=p.ego, t0=p.t0, length=p.length, ctrl=p.ctrl, refs=getattr(p, "refs", None))
@@ -298,16 +312,42 @@ def packed_to_shm(p: PackedScenarios) -> dict:
 def packed_from_shm(meta: dict) -> PackedScenarios:
     from multiprocessing import shared_memory
 
-    shm = shared_memory.SharedMemory(name=meta["shm"])
-    try:
-        knots = np.ndarray(meta["shape"], np.float64, buffer=shm.buf).copy()
-    finally:
-        shm.close()
-        shm.unlink()
+    if meta["shm"] is None:
+        knots = meta["knots"]
+    else:
+        shm = shared_memory.SharedMemory(name=meta["shm"])
+        try:
+            knots = np.ndarray(meta["shape"], np.float64, buffer=shm.buf).copy()
+        finally:
+            shm.close()
+            shm.unlink()
     out = PackedScenarios(meta["R"], meta["E"], meta["kind"], meta["etype"], meta["bbox"], meta["knot_off"], knots, meta["ego"],
                           meta["t0"], meta["length"], meta["ctrl"])
     out.refs = meta["refs"]
     return out
+
+
+def release_shm(metas) -> int:
+    """Remove the segments of results that were received and will not be merged (the parent failed in between: a merge
+    error, KeyboardInterrupt, a broken pool).  Segments that are gone already are skipped; returns how many it removed."""
+    from multiprocessing import shared_memory
+
+    n = 0
+    for m in metas:
+        name = m.get("shm") if isinstance(m, dict) else None
+        if not name:
+            continue
+        try:
+            shm = shared_memory.SharedMemory(name=name)
+        except (FileNotFoundError, OSError):
+            continue
+        shm.close()
+        try:
+            shm.unlink()
+            n += 1
+        except FileNotFoundError:
+            pass
+    return n
 
 
 def merge_packed_shm(metas: Sequence[dict], threads: int = 4) -> PackedScenarios:
@@ -323,6 +363,9 @@ def merge_packed_shm(metas: Sequence[dict], threads: int = 4) -> PackedScenarios
 
     def one(args):  # (numpy's copy releases the GIL: the segments are copied -- and their pages faulted in -- side by side)
         m, a, b = args
+        if m["shm"] is None:
+            knots[a:b] = m["knots"]
+            return
         shm = shared_memory.SharedMemory(name=m["shm"])
         try:
             knots[a:b] = np.ndarray(m["shape"], np.float64, buffer=shm.buf)
@@ -331,14 +374,18 @@ def merge_packed_shm(metas: Sequence[dict], threads: int = 4) -> PackedScenarios
             shm.unlink()
 
     jobs = list(zip(metas, rows[:-1], rows[1:]))
-    if threads > 1 and len(jobs) > 1:
-        from concurrent.futures import ThreadPoolExecutor
+    try:
+        if threads > 1 and len(jobs) > 1:
+            from concurrent.futures import ThreadPoolExecutor
 
-        with ThreadPoolExecutor(threads) as ex:
-            list(ex.map(one, jobs))
-    else:
-        for j in jobs:
-            one(j)
+            with ThreadPoolExecutor(threads) as ex:
+                list(ex.map(one, jobs))
+        else:
+            for j in jobs:
+                one(j)
+    except BaseException:
+        release_shm(metas)  # whatever was not copied yet
+        raise
     ko = np.concatenate([m["knot_off"][:-1] + r for m, r in zip(metas, rows)] + [rows[-1:]])
     cat = lambda f: np.concatenate([m[f] for m in metas])  # noqa: E731
     out = PackedScenarios(sum(m["R"] for m in metas), E, cat("kind"), cat("etype"), cat("bbox"), ko.astype(np.int64), knots,

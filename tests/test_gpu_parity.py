@@ -556,6 +556,54 @@ def test_scenarios_beyond_512_entities_match_oracle(sga, oracle, R, E, steps, eg
     assert n_ev > 0
 
 
+@pytest.mark.parametrize("persist", [False, True])
+def test_caller_run_agents_beyond_512_entities(sga, persist):
+    """Custom agents on scenarios of more than 512 entities (sg_set_external_poses + sg_step, one tick at a time): egos whose
+    poses the CALLER supplies -- here the poses a ReplayTrajectoryAgent returns, so the whole state equals the same batch with
+    device-side replay agents bit for bit --, then `None` (NaN) from some step on: the entity vanishes, or keeps its pose
+    under persist (scenario_gym.py:233-239), exactly as at the fused widths."""
+    import scenario_gym_amd._lib as L
+    from scenario_gym_amd import synthetic
+
+    R, E, steps, quit_at = 2, 700, 24, 15
+    packed = synthetic.make_batch(R, E, n_steps=steps, ego_kind=L.KIND_AGENT_REPLAY, static_frac=0.15, vanish_frac=0.2, extent=110.0)
+    ref = sga.RolloutEngine(R, E, event_capacity=256, persist=persist)
+    ref.upload(packed)
+    packed.kind[0::E] = L.KIND_AGENT_EXTERNAL
+    eng = sga.RolloutEngine(R, E, event_capacity=256, persist=persist)
+    eng.upload(packed)
+    ext = np.full((R, E, 6), np.nan)
+    last = None
+    for k in range(steps):
+        ref.step(1)
+        want = ref.state()
+        if k < quit_at:
+            ext[:, 0] = want["poses"][:, 0]  # what the replay agent returned for this tick
+            last = ext[:, 0].copy()
+        else:
+            ext[:, 0] = np.nan               # the agent returns None
+        eng.set_external_poses(ext)
+        eng.step(1)
+        got = eng.state()
+        if k < quit_at:
+            for f in ("poses", "vels", "dists"):
+                assert bits_equal(got[f], want[f]), (k, f)
+            assert np.array_equal(got["present"], want["present"]) and np.array_equal(got["coll"], want["coll"]), k
+        else:
+            others = np.ones(E, bool)
+            others[0] = False
+            assert bits_equal(got["poses"][:, others], want["poses"][:, others]), k
+            if persist:
+                assert got["present"][:, 0].all() and bits_equal(got["poses"][:, 0], last), k
+                if k > quit_at:
+                    assert (got["vels"][:, 0] == 0).all(), k
+            else:
+                assert not got["present"][:, 0].any(), k
+    assert np.array_equal(eng.metrics()[0]["n_steps"], ref.metrics()[0]["n_steps"])
+    eng.close()
+    ref.close()
+
+
 @pytest.mark.parametrize("E,side,noise", [(1024, 45.0, "off"), (600, 30.0, "device")])
 def test_crowds_beyond_512_entities_match_oracle(sga, oracle, E, side, noise):
     """... and with every KIND in one scenario of 1024 entities: pedestrian agents (the social force over all pedestrians of

@@ -148,6 +148,51 @@ def test_pack_scenarios_matches_reference_export():
     assert sh.n_scenarios == 2 and sh.knot_off[0] == 0 and sh.t0[0] == raws[1]["t0"]
 
 
+def test_packed_batches_through_shared_memory(monkeypatch):
+    """Worker -> parent hand-off of packed batches (packing.packed_to_shm / merge_packed_shm / release_shm): same arrays as
+    merge_packed, no segment left behind -- neither after a merge nor when the parent gives up in between --, and the
+    pickle path when /dev/shm has no room."""
+    import os
+
+    import scenario_gym_amd.packing as P
+
+    g = load_golden("scenarios")
+    scs = [scenario_from_arrays(scenario_arrays(g, f"{n}/scenario"), g[f"{n}/scenario/refs"]) for n in g["names"]]
+    E = max(len(s.entities) for s in scs)
+    parts = [P.widen_packed(P.pack_scenarios(q)[0], E) for q in (scs[:2], scs[2:])]
+    want = P.merge_packed(parts)
+
+    def segments(metas):
+        return [m["shm"] for m in metas if m["shm"] and os.path.exists("/dev/shm/" + m["shm"])]
+
+    metas = [P.packed_to_shm(q) for q in parts]
+    assert len(segments(metas)) == 2
+    got = P.merge_packed_shm(metas, threads=2)
+    assert segments(metas) == []
+    for f in ("kind", "etype", "bbox", "knot_off", "knots", "ego", "t0", "length"):
+        assert np.array_equal(getattr(got, f), getattr(want, f)), f
+    one = P.packed_from_shm(P.packed_to_shm(parts[0]))
+    assert np.array_equal(one.knots, parts[0].knots)
+
+    metas = [P.packed_to_shm(q) for q in parts]      # the parent fails before the merge: it releases what it received
+    assert P.release_shm(metas) == 2 and segments(metas) == [] and P.release_shm(metas) == 0
+    metas = [P.packed_to_shm(q) for q in parts]      # the merge itself fails: nothing stays behind
+    metas[1] = dict(metas[1], E=E + 1)
+    with pytest.raises(ValueError):
+        P.merge_packed_shm(metas)
+    P.release_shm(metas)
+    assert segments(metas) == []
+
+    class Full:
+        f_bavail, f_frsize = 0, 4096
+
+    monkeypatch.setattr(P.os, "statvfs", lambda path: Full)
+    metas = [P.packed_to_shm(q) for q in parts]
+    assert all(m["shm"] is None for m in metas)
+    got = P.merge_packed_shm(metas, threads=1)
+    assert np.array_equal(got.knots, want.knots) and np.array_equal(got.knot_off, want.knot_off)
+
+
 def test_agent_descriptors_lower_to_device_kinds():
     import scenario_gym_amd as sga
     import scenario_gym_amd._lib as L

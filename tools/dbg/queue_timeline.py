@@ -48,3 +48,13 @@ for lo in np.arange(0, end, 1000.0):
     inb = ((t[..., 1] < lo + 1000) & (t[..., 2] > lo + 1000)).sum()
     inw = ((t[..., 0] < lo + 1000) & (t[..., 1] > lo + 1000)).sum()
     print(f"t = {lo / 1e3 + 1:5.1f} ms: {inb} items in their body, {inw} waiting (of {slots} rollout wavefronts)")
+# the chain of every block: its items one after the other -- is the call bound by the slots (work / slots) or by its slowest blocks?
+per_block_body = body.sum(axis=0) / 1e3
+finish = t[-1, :, 3] / 1e3
+gap = (t[1:, :, 1] - t[:-1, :, 3]).sum(axis=0) / 1e3  # between the end of an item and the start of the block's next one
+q = lambda a, f: float(np.percentile(a, f))
+print(f"per block, ms: body of all its items p50 {q(per_block_body, 50):.2f} p90 {q(per_block_body, 90):.2f} p99 {q(per_block_body, 99):.2f} max {per_block_body.max():.2f} | "
+      f"between its items p50 {q(gap, 50):.2f} p99 {q(gap, 99):.2f} | finished at p50 {q(finish, 50):.2f} p90 {q(finish, 90):.2f} max {finish.max():.2f}")
+slow = np.argsort(per_block_body)[-5:]
+print("the five slowest blocks (body ms, gaps ms, finished at):", [(int(b), round(float(per_block_body[b]), 2), round(float(gap[b]), 2), round(float(finish[b]), 2)) for b in slow])
+print(f"work / slots: {body.sum() / slots / 1e3:.2f} ms")
