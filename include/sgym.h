@@ -105,10 +105,11 @@ typedef struct {
     int32_t n_scenarios;     /* R */
     int32_t n_entities;      /* E, entity slots per scenario (the reference has no ceiling, state/utils.py:10-49; here <= 16384).
                                 Up to 512: one workgroup per scenario, every kind, callback and observation call.  Beyond: the
-                                step runs as four kernels over as many workgroups as the scenario needs (every entity kind incl.
-                                pedestrian agents with the counter-based noise) -- without caller-run agents, the RSS callback,
-                                road networks, observation calls, sg_tick and the noise stream (those calls fail with
-                                SG_ERR_INVALID on such a handle) */
+                                step runs as four kernels over as many workgroups as the scenario needs -- every entity kind
+                                (caller-run agents; pedestrian agents with the counter-based noise), the RSS callback (a launch
+                                of its own per step), road networks with ego_off_road and the map's surface layers, the
+                                observation calls and sg_tick.  Not served there (SG_ERR_INVALID): road networks under
+                                pedestrian agents, the noise stream, several pedestrian models */
     int32_t persist;         /* ScenarioGym(persist=...) */
     uint32_t terminal_mask;  /* SG_TERM_* */
     int32_t record_capacity; /* rows of State._recorded_poses kept on device (0 = off), state.py:227-228 */

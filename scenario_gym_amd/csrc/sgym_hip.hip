@@ -541,19 +541,26 @@ static int launch_main(sg_handle *h, int n_steps, int do_reset, int force, const
 // scenario that may run steps in lockstep (a done scenario sits the step out unless `force`).  The host never waits here: every
 // 64 steps a one-workgroup kernel writes the number of running scenarios into page-locked memory, and rollout() stops
 // enqueuing once an EARLIER check point has answered 0 (what it enqueued in the meantime are no-ops).
+constexpr unsigned WIDE_RING = 1024;
+static int ensure_wide(sg_handle *h) // (the scratch of the multi-kernel step; sg_tick calls it before it starts capturing)
+{
+    int rc = SG_OK;
+    if (!h->wide_args.scr) {
+        auto &A = h->wide_allocs;
+        if ((rc = dev_alloc(h, A, &h->wide_args.scr, h->NE * sg::WS_W)) || (rc = dev_alloc(h, A, &h->wide_args.cor, h->NE * 8)) ||
+            (rc = dev_alloc(h, A, &h->wide_args.circ, h->NE * 4)) || (rc = dev_alloc(h, A, &h->wide_args.last_row, (size_t)h->R * h->WV)) ||
+            (rc = dev_alloc(h, A, &h->wide_args.last_same, h->NE)) || (rc = dev_alloc(h, A, &h->wide_args.dup, (size_t)h->R)))
+            return rc;
+    }
+    if (!h->wide_running) HIP_TRY(h, hipHostMalloc((void **)&h->wide_running, WIDE_RING * sizeof(int), hipHostMallocDefault));
+    return SG_OK;
+}
+
 static int launch_wide(sg_handle *h, int n_steps, int do_reset, int force, const double *d_actions)
 {
     const int R = h->R, EP = h->EP;
     int rc = SG_OK;
-    constexpr unsigned RING = 1024;
-    if (!h->wide_args.scr) {
-        auto &A = h->wide_allocs;
-        if ((rc = dev_alloc(h, A, &h->wide_args.scr, h->NE * sg::WS_W)) || (rc = dev_alloc(h, A, &h->wide_args.cor, h->NE * 8)) ||
-            (rc = dev_alloc(h, A, &h->wide_args.circ, h->NE * 4)) || (rc = dev_alloc(h, A, &h->wide_args.last_row, (size_t)R * h->WV)) ||
-            (rc = dev_alloc(h, A, &h->wide_args.last_same, h->NE)) || (rc = dev_alloc(h, A, &h->wide_args.dup, (size_t)R)))
-            return rc;
-    }
-    if (!h->wide_running) HIP_TRY(h, hipHostMalloc((void **)&h->wide_running, RING * sizeof(int), hipHostMallocDefault));
+    if ((rc = ensure_wide(h))) return rc;
     const dim3 ge((unsigned)((EP + 255) / 256), (unsigned)R), gs((unsigned)R);
     auto one = [&](int mode, const double *acts) {
         sg::WideArgs wa = h->wide_args;
@@ -562,21 +569,28 @@ static int launch_wide(sg_handle *h, int n_steps, int do_reset, int force, const
         wa.actions = acts;
         sgl::wide_step(ge, gs, h->stream, h->p, h->cfg.timestep, wa);
     };
+    // sg_set_rss at this width: RSSDistances.__call__ as a launch of its own after the reset and after every step
+    auto rss = [&](int reset) {
+        if (h->rss_fused)
+            sg::rss_kernel<<<dim3((unsigned)R), dim3(512), 0, h->stream>>>(h->p, reset, h->d_rss_state, h->d_rss_code, h->d_rss_safe, h->d_rss_seen);
+    };
     if (do_reset) {
         one(do_reset == 2 ? 2 : 1, nullptr);
+        rss(do_reset == 2 ? 2 : 1);
         HIP_TRY(h, hipGetLastError());
     }
     const unsigned first_check = h->wide_check;
     for (int k = 0; k < n_steps; ++k) {
         one(0, d_actions ? d_actions + (size_t)k * R * 2 : nullptr);
+        rss(0);
         if (!force && (k & 63) == 63 && k + 1 < n_steps) { // is anybody still running?
             HIP_TRY(h, hipGetLastError());
             bool nobody = false;
             for (unsigned c = first_check; c != h->wide_check && !nobody; ++c)
-                nobody = __atomic_load_n(&h->wide_running[c % RING], __ATOMIC_ACQUIRE) == 0;
+                nobody = __atomic_load_n(&h->wide_running[c % WIDE_RING], __ATOMIC_ACQUIRE) == 0;
             if (nobody) break;
-            if (h->wide_check - first_check < RING) { // (a call of more than 65,536 steps stops asking)
-                int *word = &h->wide_running[h->wide_check++ % RING];
+            if (h->wide_check - first_check < WIDE_RING) { // (a call of more than 65,536 steps stops asking)
+                int *word = &h->wide_running[h->wide_check++ % WIDE_RING];
                 __atomic_store_n(word, -1, __ATOMIC_RELEASE);
                 sgl::wide_running(h->stream, h->p, word);
             }
@@ -1378,8 +1392,6 @@ extern "C" int sg_upload(sg_handle *h, const sg_scenarios *sc)
         return fail(h, SG_ERR_INVALID, "sg_upload: several pedestrian behaviour models (sg_set_ped_models) on scenarios of more than 512 entities: "
                                        "the multi-kernel step holds one model");
     if (h->wide) { // more than 512 entities per scenario: the multi-kernel step (sgym_wide.hpp) and what it does not do
-        if (h->cfg.terminal_mask & SG_TERM_EGO_OFF_ROAD)
-            return fail(h, SG_ERR_INVALID, "sg_upload: the ego_off_road terminal condition is available up to 512 entities per scenario");
         if (h->has_ped && h->noise_mode == SG_NOISE_STREAM)
             return fail(h, SG_ERR_INVALID, "sg_upload: the pedestrian noise stream is available up to 512 entities per scenario (the counter-based generator works)");
     }
@@ -1851,7 +1863,6 @@ static int obs_scratch(sg_handle *h, size_t bytes, unsigned char **out)
 extern "C" int sg_tick(sg_handle *h, const double *actions, int32_t actions_device, double width, double height, int32_t nw,
                        int32_t nh, int32_t n_layers, const int32_t *layers, const uint8_t **d_obs, const uint32_t **d_flags)
 {
-    if (h && h->wide) return fail(h, SG_ERR_INVALID, "%s: available up to 512 entities per scenario", "sg_tick");
     if (!h) return SG_ERR_INVALID;
     if (!h->uploaded) return fail(h, SG_ERR_STATE, "sg_tick: no scenarios uploaded");
     if (!layers || n_layers < 1 || n_layers > 8 || nw < 1 || nh < 1 || !(width >= 0.0) || !(height >= 0.0))
@@ -1881,6 +1892,7 @@ extern "C" int sg_tick(sg_handle *h, const double *actions, int32_t actions_devi
     int32_t *dl = reinterpret_cast<int32_t *>(d + lay_off);
     // sg_set_rss: the callback runs after the step, inside the captured launch (like sg_step; without records of a reset --
     // the callback was switched on after sg_upload -- through sg_rss_update after the graph)
+    if (h->wide && (rc = ensure_wide(h))) return rc;
     const bool rss_tick = h->rss_enabled && h->ego_first && rss_live(h);
     if (rss_tick) { // (allocations stay outside the capture)
         bool fresh = false;
@@ -1900,10 +1912,27 @@ extern "C" int sg_tick(sg_handle *h, const double *actions, int32_t actions_devi
         h->n_launches = 0;
         h->launch_ev.clear();
         h->rss_fused = rss_tick;
-        rc = launch_main(h, 1, 0, 1, h->d_actions, nullptr, false, &ev_next);
+        rc = h->wide ? launch_wide(h, 1, 0, 1, h->d_actions) : launch_main(h, 1, 0, 1, h->d_actions, nullptr, false, &ev_next);
         h->rss_fused = false;
         hipError_t e = hipSuccess;
-        if (!rc) { // the whole observation (map layers + terminal flags) in one launch
+        if (!rc && h->wide) {
+            // scenarios of more than 512 entities: the entity layers tile by tile (raster_kernel), empty surfaces (no road
+            // networks at this width), the terminal conditions by the kernel of sg_terminal_flags
+            if (any_surface && !h->has_road) e = hipMemsetAsync(d, 0, bytes, h->stream);
+            for (int k = 0; k < n_layers && e == hipSuccess; ++k)
+                if (layers[k] == 0) {
+                    sg::raster_kernel<<<dim3((unsigned)h->R), dim3(512), 0, h->stream>>>(h->p, width, height, nw, nh, d + (size_t)k * plane, (int64_t)(n_layers * plane));
+                    e = hipGetLastError();
+                }
+            if (any_surface && h->has_road && e == hipSuccess) {
+                sg::raster_surface_kernel<<<dim3((unsigned)h->R), dim3(256), 0, h->stream>>>(h->p, h->road, width, height, nw, nh, n_layers, dl, d);
+                e = hipGetLastError();
+            }
+            if (e == hipSuccess) {
+                sg::terminal_flags_kernel<<<dim3((unsigned)h->R), dim3(64), 0, h->stream>>>(h->p, h->cfg.timestep, h->d_term_flags);
+                e = hipGetLastError();
+            }
+        } else if (!rc) { // the whole observation (map layers + terminal flags) in one launch
             sg::observe_kernel<<<dim3((unsigned)h->R), dim3(h->EP > 256 ? 512 : 256), 0, h->stream>>>(h->p, h->road, h->has_road ? 1 : 0, width, height, nw,
                                                                                 nh, n_layers, dl, d, h->d_term_flags);
             e = hipGetLastError();
@@ -2323,6 +2352,7 @@ static int ensure_rss(sg_handle *h, bool *fresh)
 
 static int ensure_rssq(sg_handle *h)
 {
+    if (h->wide) return SG_OK; // (scenarios of more than 512 entities run the callback as a launch of its own: no line-test queue)
     if (h->d_rssq && h->rssq_NE != h->NE) {
         (void)hipFree(h->d_rssq); (void)hipFree(h->d_rssq_n);
         h->d_rssq = nullptr; h->d_rssq_n = nullptr;
@@ -2357,7 +2387,6 @@ static int ensure_rssq(sg_handle *h)
 
 extern "C" int sg_rss_update(sg_handle *h, int32_t reset)
 {
-    if (h && h->wide) return fail(h, SG_ERR_INVALID, "%s: available up to 512 entities per scenario", "sg_rss_update");
     if (!h) return SG_ERR_INVALID;
     if (!h->uploaded) return fail(h, SG_ERR_STATE, "sg_rss_update: no scenarios uploaded");
 
@@ -2374,9 +2403,8 @@ extern "C" int sg_rss_update(sg_handle *h, int32_t reset)
 
 extern "C" int sg_set_rss(sg_handle *h, int32_t enabled)
 {
-    if (h && h->wide) return fail(h, SG_ERR_INVALID, "%s: available up to 512 entities per scenario", "sg_set_rss");
     if (!h) return SG_ERR_INVALID;
-    if (enabled && h->WV > 4 && (h->has_ped || (h->cfg.terminal_mask & SG_TERM_EGO_OFF_ROAD)))
+    if (enabled && !h->wide && h->WV > 4 && (h->has_ped || (h->cfg.terminal_mask & SG_TERM_EGO_OFF_ROAD)))
         return fail(h, SG_ERR_INVALID, "sg_set_rss: with pedestrian agents or the ego_off_road terminal condition the callback is available up to 256 entities per scenario");
     h->rss_enabled = enabled != 0;
     return SG_OK;
@@ -2592,7 +2620,8 @@ int build_road_network(const sg_road_networks *in, int n, RoadBuild &B)
 
 extern "C" int sg_set_road_networks(sg_handle *h, const sg_road_networks *in)
 {
-    if (h && h->wide) return fail(h, SG_ERR_INVALID, "%s: available up to 512 entities per scenario", "sg_set_road_networks");
+    if (h && h->wide && h->has_ped)
+        return fail(h, SG_ERR_INVALID, "sg_set_road_networks: scenarios of more than 512 entities with pedestrian agents (their boundary forces) are not served");
     if (!h || !in) return h ? fail(h, SG_ERR_INVALID, "sg_set_road_networks: null argument") : SG_ERR_INVALID;
     if (!h->uploaded) return fail(h, SG_ERR_STATE, "sg_set_road_networks: no scenarios uploaded");
     if (in->n_networks < 0 || !in->net_of_scenario || (in->n_networks > 0 && (!in->poly_off || !in->ring_off || !in->vert_off || !in->layers)))
@@ -2661,7 +2690,6 @@ extern "C" int sg_set_road_networks(sg_handle *h, const sg_road_networks *in)
 static int raster_map_launch(sg_handle *h, const char *who, double width, double height, int32_t nw, int32_t nh, int32_t n_layers,
                              const int32_t *layers, unsigned char **d_out, size_t *bytes_out)
 {
-    if (h && h->wide) return fail(h, SG_ERR_INVALID, "%s: available up to 512 entities per scenario", "sg_raster_map");
     if (!layers || n_layers < 1 || nw < 1 || nh < 1 || !(width >= 0.0) || !(height >= 0.0))
         return fail(h, SG_ERR_INVALID, "%s: bad argument", who);
     if (!h->uploaded) return fail(h, SG_ERR_STATE, "%s: no scenarios uploaded", who);
@@ -2721,7 +2749,6 @@ extern "C" int sg_raster_map_device(sg_handle *h, double width, double height, i
 
 extern "C" int sg_raster_entities(sg_handle *h, double width, double height, int32_t nw, int32_t nh, uint8_t *out)
 {
-    if (h && h->wide) return fail(h, SG_ERR_INVALID, "%s: available up to 512 entities per scenario", "sg_raster_entities");
     if (!h || !out || nw < 1 || nh < 1 || !(width >= 0.0) || !(height >= 0.0))
         return h ? fail(h, SG_ERR_INVALID, "sg_raster_entities: bad argument") : SG_ERR_INVALID;
     if (!h->uploaded) return fail(h, SG_ERR_STATE, "sg_raster_entities: no scenarios uploaded");

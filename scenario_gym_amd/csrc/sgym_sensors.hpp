@@ -98,69 +98,78 @@ static __global__ __launch_bounds__(512) void raster_kernel(Params p, double wid
                                                      unsigned char *out /*[R][nh][nw] at stride bytes per scenario*/,
                                                      int64_t stride)
 {
-    __shared__ double cor[8][512]; // (one thread per entity slot: 256 threads, 512 for scenarios of 257..512 entities)
-    __shared__ unsigned char pres[512];
+    __shared__ double cor[8][512]; // (one thread per entity slot of a tile: 256 threads, 512 for scenarios of more than 256)
     __shared__ double ego_pose[4]; // x, y, sin(theta), cos(theta)
+    __shared__ int ego_pres;
     __shared__ int near_n;
-    const int r = blockIdx.x, e = threadIdx.x;
+    const int r = blockIdx.x, tid = threadIdx.x, nthr = (int)blockDim.x;
     const ScenStatic &ss = p.sstat[r];
-    const uint32_t idx = (uint32_t)r * p.EP + (e < p.EP ? e : 0);
-    const LanePtr st(p.stat + (size_t)(idx >> 6) * (ST_COUNT * 64), (idx & 63) * 8u);
-    const LanePtr dy(p.dyn + (size_t)(idx >> 6) * ((size_t)p.FROWS * 64), (idx & 63) * 8u);
-    const bool present = e < p.E && fld<uint64_t>(dy, SG_F_PRESENT) != 0;
-    pres[e] = present;
-    if (e == 0) near_n = 0;
-    double C[8];
-    if (present) {
-        const double x = fld(dy, SG_F_POSE + 0), y = fld(dy, SG_F_POSE + 1), h = fld(dy, SG_F_POSE + 3);
-        double s, c;
-        sg_sincos(h, s, c);
-        sg_corners(x, y, s, c, fld(st, ST_BW), fld(st, ST_BL), fld(st, ST_BCX), fld(st, ST_BCY), C);
-    }
-    if (e == ss.ego) {
+    if (tid == 0) {
+        const uint32_t idx = (uint32_t)r * p.EP + (uint32_t)ss.ego;
+        const LanePtr dy(p.dyn + (size_t)(idx >> 6) * ((size_t)p.FROWS * 64), (idx & 63) * 8u);
         double s, c;
         sg_sincos(fld(dy, SG_F_POSE + 3) + 3.14159265358979311600e+00 / 2, s, c); // pose[3] + math.pi / 2
         ego_pose[0] = fld(dy, SG_F_POSE + 0); ego_pose[1] = fld(dy, SG_F_POSE + 1);
         ego_pose[2] = s; ego_pose[3] = c;
+        ego_pres = fld<uint64_t>(dy, SG_F_PRESENT) != 0;
     }
     __syncthreads();
     const double ex = ego_pose[0], ey = ego_pose[1], s = ego_pose[2], c = ego_pose[3];
-    if (present) {
-        // only boxes that can reach the grid are tested per cell: every grid point lies within `reach` of the ego (the
-        // grid's half diagonal, generously rounded up), every point of a box within the largest corner distance of its
-        // first corner
-        const double reach = 0.5 * (__builtin_fabs(width) + __builtin_fabs(height)) * 1.0000001 + 1e-6;
-        double far = 0.0;
-#pragma unroll
-        for (int k = 1; k < 4; ++k) far = __builtin_fmax(far, __builtin_fabs(C[2 * k] - C[0]) + __builtin_fabs(C[2 * k + 1] - C[1]));
-        const double dx = C[0] - ex, dyy = C[1] - ey, lim = reach + far * 1.0000001 + 1e-6 * (1.0 + __builtin_fabs(ex) + __builtin_fabs(ey));
-        if (!(dx * dx + dyy * dyy > lim * lim)) { // NaN-safe: keeps the box
-            const int q = atomicAdd(&near_n, 1);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) cor[k][q] = C[k];
-        }
-    }
-    __syncthreads();
-    const bool ego_present = pres[ss.ego] != 0;
-    const int nn = near_n;
+    const bool ego_present = ego_pres != 0;
     unsigned char *o = out + (size_t)r * stride;
-    for (int q = e; q < nw * nh; q += (int)blockDim.x) {
-        const int i = q / nw, j = q - i * nw;
-        const double x0 = sg_linspace_at(-width / 2, width / 2, nw, j), x1 = sg_linspace_at(-height / 2, height / 2, nh, i);
-        const double px = __builtin_fma(x1, -s, x0 * c) + ex, py = __builtin_fma(x1, c, x0 * s) + ey;
-        bool hit = false;
-        for (int k = 0; k < nn && !hit; ++k) {
-            const double ax = cor[0][k], ay = cor[1][k], bx = cor[2][k], by = cor[3][k];
-            const double cx = cor[4][k], cy = cor[5][k], dx = cor[6][k], dyy = cor[7][k];
-            const double orient = (cx - ax) * (dyy - by) - (cy - ay) * (dx - bx);
-            const double c0 = (bx - ax) * (py - ay) - (by - ay) * (px - ax);
-            const double c1 = (cx - bx) * (py - by) - (cy - by) * (px - bx);
-            const double c2 = (dx - cx) * (py - cy) - (dyy - cy) * (px - cx);
-            const double c3 = (ax - dx) * (py - dyy) - (ay - dyy) * (px - dx);
-            hit = orient > 0 ? (c0 > 0 && c1 > 0 && c2 > 0 && c3 > 0)
-                             : (orient < 0 && c0 < 0 && c1 < 0 && c2 < 0 && c3 < 0);
+    // scenarios of more entities than the workgroup has threads go tile by tile; a grid point that an earlier tile's box
+    // covers stays covered (its byte is this thread's own: written and read back by the same thread)
+    for (int e0 = 0; e0 < p.E || e0 == 0; e0 += nthr) {
+        const int e = e0 + tid;
+        if (tid == 0) near_n = 0;
+        __syncthreads();
+        const uint32_t idx = (uint32_t)r * p.EP + (e < p.EP ? e : 0);
+        const LanePtr st(p.stat + (size_t)(idx >> 6) * (ST_COUNT * 64), (idx & 63) * 8u);
+        const LanePtr dy(p.dyn + (size_t)(idx >> 6) * ((size_t)p.FROWS * 64), (idx & 63) * 8u);
+        const bool present = e < p.E && fld<uint64_t>(dy, SG_F_PRESENT) != 0;
+        if (present) {
+            double C[8];
+            const double x = fld(dy, SG_F_POSE + 0), y = fld(dy, SG_F_POSE + 1), h = fld(dy, SG_F_POSE + 3);
+            double sh, ch;
+            sg_sincos(h, sh, ch);
+            sg_corners(x, y, sh, ch, fld(st, ST_BW), fld(st, ST_BL), fld(st, ST_BCX), fld(st, ST_BCY), C);
+            // only boxes that can reach the grid are tested per cell: every grid point lies within `reach` of the ego (the
+            // grid's half diagonal, generously rounded up), every point of a box within the largest corner distance of its
+            // first corner
+            const double reach = 0.5 * (__builtin_fabs(width) + __builtin_fabs(height)) * 1.0000001 + 1e-6;
+            double far = 0.0;
+#pragma unroll
+            for (int k = 1; k < 4; ++k) far = __builtin_fmax(far, __builtin_fabs(C[2 * k] - C[0]) + __builtin_fabs(C[2 * k + 1] - C[1]));
+            const double dx = C[0] - ex, dyy = C[1] - ey, lim = reach + far * 1.0000001 + 1e-6 * (1.0 + __builtin_fabs(ex) + __builtin_fabs(ey));
+            if (!(dx * dx + dyy * dyy > lim * lim)) { // NaN-safe: keeps the box
+                const int q = atomicAdd(&near_n, 1);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) cor[k][q] = C[k];
+            }
         }
-        o[q] = ego_present ? (unsigned char)hit : 0; // the reference sensor needs state.poses[entity]
+        __syncthreads();
+        const int nn = near_n;
+        for (int q = tid; q < nw * nh; q += nthr) {
+            bool hit = e0 > 0 && o[q] != 0;
+            if (!hit && ego_present) {
+                const int i = q / nw, j = q - i * nw;
+                const double x0 = sg_linspace_at(-width / 2, width / 2, nw, j), x1 = sg_linspace_at(-height / 2, height / 2, nh, i);
+                const double px = __builtin_fma(x1, -s, x0 * c) + ex, py = __builtin_fma(x1, c, x0 * s) + ey;
+                for (int k = 0; k < nn && !hit; ++k) {
+                    const double ax = cor[0][k], ay = cor[1][k], bx = cor[2][k], by = cor[3][k];
+                    const double cx = cor[4][k], cy = cor[5][k], dx = cor[6][k], dyy = cor[7][k];
+                    const double orient = (cx - ax) * (dyy - by) - (cy - ay) * (dx - bx);
+                    const double c0 = (bx - ax) * (py - ay) - (by - ay) * (px - ax);
+                    const double c1 = (cx - bx) * (py - by) - (cy - by) * (px - bx);
+                    const double c2 = (dx - cx) * (py - cy) - (dyy - cy) * (px - cx);
+                    const double c3 = (ax - dx) * (py - dyy) - (ay - dyy) * (px - dx);
+                    hit = orient > 0 ? (c0 > 0 && c1 > 0 && c2 > 0 && c3 > 0)
+                                     : (orient < 0 && c0 < 0 && c1 < 0 && c2 < 0 && c3 < 0);
+                }
+            }
+            o[q] = ego_present ? (unsigned char)hit : 0; // the reference sensor needs state.poses[entity]
+        }
+        __syncthreads();
     }
 }
 #endif // SG_UNIT_MAIN
@@ -423,39 +432,44 @@ static __global__ __launch_bounds__(64) void classify_events_kernel(Params p, do
 #ifdef SG_UNIT_MAIN // (emitted by the one object that launches it: csrc/Makefile, sgym_launch.hpp)
 static __global__ __launch_bounds__(512) void rss_kernel(Params p, int reset, int32_t *rss_state, int32_t *code, double *safe, int32_t *seen)
 {
+    // reset: 0 an update, 1 the histories of every scenario start anew, 2 those of the scenarios flagged in p.reset_mask do
     __shared__ double ego[8]; // x, y, heading, vx, vy, width, length, present
-    const int r = blockIdx.x, e = threadIdx.x;
+    __shared__ int s_stale;
+    const int r = blockIdx.x, tid = threadIdx.x;
     const ScenStatic &ss = p.sstat[r];
-    const uint32_t idx = (uint32_t)r * p.EP + (e < p.EP ? e : 0);
-    const LanePtr st(p.stat + (size_t)(idx >> 6) * (ST_COUNT * 64), (idx & 63) * 8u);
-    const LanePtr dy(p.dyn + (size_t)(idx >> 6) * ((size_t)p.FROWS * 64), (idx & 63) * 8u);
-    const bool in = e < p.E;
-    const bool present = in && fld<uint64_t>(dy, SG_F_PRESENT) != 0;
-    double hp[4] = {0, 0, 0, 0}, hv[2] = {0, 0};
-    if (in) {
-        hp[0] = fld(dy, SG_F_POSE + 0); hp[1] = fld(dy, SG_F_POSE + 1); hp[3] = fld(dy, SG_F_POSE + 3);
-        hv[0] = fld(dy, SG_F_VEL + 0); hv[1] = fld(dy, SG_F_VEL + 1);
-    }
-    if (e == ss.ego) {
-        ego[0] = hp[0]; ego[1] = hp[1]; ego[2] = hp[3]; ego[3] = hv[0]; ego[4] = hv[1];
-        ego[5] = fld(st, ST_BW); ego[6] = fld(st, ST_BL); ego[7] = present ? 1.0 : 0.0;
-    }
     const int steps_now = p.sdyn[r].n_steps;
-    const bool stale = !reset && seen[r] == steps_now;
+    const bool anew = reset == 1 || (reset == 2 && p.reset_mask[r] != 0);
+    if (tid == 0) {
+        const uint32_t idx = (uint32_t)r * p.EP + (uint32_t)ss.ego;
+        const LanePtr st(p.stat + (size_t)(idx >> 6) * (ST_COUNT * 64), (idx & 63) * 8u);
+        const LanePtr dy(p.dyn + (size_t)(idx >> 6) * ((size_t)p.FROWS * 64), (idx & 63) * 8u);
+        ego[0] = fld(dy, SG_F_POSE + 0); ego[1] = fld(dy, SG_F_POSE + 1); ego[2] = fld(dy, SG_F_POSE + 3);
+        ego[3] = fld(dy, SG_F_VEL + 0); ego[4] = fld(dy, SG_F_VEL + 1);
+        ego[5] = fld(st, ST_BW); ego[6] = fld(st, ST_BL); ego[7] = fld<uint64_t>(dy, SG_F_PRESENT) != 0 ? 1.0 : 0.0;
+        s_stale = !anew && seen[r] == steps_now;
+        seen[r] = steps_now;
+    }
     __syncthreads();
-    if (e == 0) seen[r] = steps_now;
-    if (!in || stale) return;
-    int32_t state = reset ? 0 : rss_state[idx];
-    int cd = -1;
-    double s_lat = __builtin_nan(""), s_long = __builtin_nan("");
-    const bool skip = p.sdyn[r].t == 0.0 || ego[7] == 0.0 || e == ss.ego || !present; // callback.py:76-78
-    if (!skip)
-        rss_entity(ego[0], ego[1], ego[2], ego[3], ego[4], ego[5], ego[6], hp[0], hp[1], hp[3], hv[0], hv[1], fld(st, ST_BW),
-                   fld(st, ST_BL), fld(st, ST_BCX), fld(st, ST_BCY), state, cd, s_lat, s_long);
-    rss_state[idx] = state;
-    code[idx] = cd;
-    safe[(size_t)idx * 2] = s_lat;
-    safe[(size_t)idx * 2 + 1] = s_long;
+    if (s_stale) return;
+    for (int e = tid; e < p.E; e += (int)blockDim.x) { // (scenarios of more than 512 entities: tile by tile)
+        const uint32_t idx = (uint32_t)r * p.EP + (uint32_t)e;
+        const LanePtr st(p.stat + (size_t)(idx >> 6) * (ST_COUNT * 64), (idx & 63) * 8u);
+        const LanePtr dy(p.dyn + (size_t)(idx >> 6) * ((size_t)p.FROWS * 64), (idx & 63) * 8u);
+        const bool present = fld<uint64_t>(dy, SG_F_PRESENT) != 0;
+        const double hp0 = fld(dy, SG_F_POSE + 0), hp1 = fld(dy, SG_F_POSE + 1), hp3 = fld(dy, SG_F_POSE + 3);
+        const double hv0 = fld(dy, SG_F_VEL + 0), hv1 = fld(dy, SG_F_VEL + 1);
+        int32_t state = anew ? 0 : rss_state[idx];
+        int cd = -1;
+        double s_lat = __builtin_nan(""), s_long = __builtin_nan("");
+        const bool skip = p.sdyn[r].t == 0.0 || ego[7] == 0.0 || e == ss.ego || !present; // callback.py:76-78
+        if (!skip)
+            rss_entity(ego[0], ego[1], ego[2], ego[3], ego[4], ego[5], ego[6], hp0, hp1, hp3, hv0, hv1, fld(st, ST_BW),
+                       fld(st, ST_BL), fld(st, ST_BCX), fld(st, ST_BCY), state, cd, s_lat, s_long);
+        rss_state[idx] = state;
+        code[idx] = cd;
+        safe[(size_t)idx * 2] = s_lat;
+        safe[(size_t)idx * 2 + 1] = s_long;
+    }
 }
 #endif // SG_UNIT_MAIN
 

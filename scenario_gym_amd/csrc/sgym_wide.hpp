@@ -16,7 +16,7 @@
 //   wide_finish_kernel   one workgroup per scenario: the clock, terminal conditions, ego metrics, CollisionMetric events
 // in that order, once per step.  Same arithmetic as the fused kernels and the oracle (plain IEEE operations: ExactArith), so
 // the same bits; 4 launches per step instead of thousands of steps per launch -- the price of not having a ceiling.
-// Not at this width: road networks, the RSS callback, the observation kernels,
+// Not at this width: road networks under pedestrian agents (their boundary forces), the RSS callback,
 // the noise stream mode (the counter-based generator works).
 #pragma once
 #include "sgym_device.hpp"
@@ -556,6 +556,17 @@ static __global__ __launch_bounds__(256) void wide_finish_kernel(Params p, doubl
     if ((p.term_mask & SG_TERM_MAX_LENGTH) && (t + dt > ss.length)) ndone = 1;
     if ((p.term_mask & SG_TERM_COLLISION) && s_any) ndone = 1;
     if ((p.term_mask & SG_TERM_EGO_COLLISION) && s_ego0) ndone = 1;
+    if (p.term_mask & SG_TERM_EGO_OFF_ROAD) {
+        // TERMINAL_CONDITIONS["ego_off_road"], state.py:401-407: entities[0] (slot 0, not Scenario.ego) absent, or its reference
+        // point not strictly inside the driveable surface
+        const WideEnt e0(p, r, 0);
+        bool off = true;
+        if (fld<uint64_t>(e0.dy, SG_F_PRESENT) != 0 && p.road) {
+            const RoadIndex RI = *p.road;
+            off = !(rn_layers_at(RI, RI.net_of_scen[r], SG_LAYER_DRIVEABLE, fld(e0.dy, SG_F_POSE + 0), fld(e0.dy, SG_F_POSE + 1)) & SG_LAYER_DRIVEABLE);
+        }
+        if (off) ndone = 1;
+    }
     sd.done = ndone;
     if (ego_present && !lanes_did_rows) { // CollisionMetric._step, metrics/collision.py:70-75
         int n_ev = sd.n_events;

@@ -1126,6 +1126,46 @@ def test_vector_env_episodes_match_oracle(oracle):
     assert episodes >= R  # every environment finished at least one episode on average
 
 
+def test_graph_tick_on_scenarios_beyond_512_entities():
+    """sg_tick on scenarios of 700 entities (the step is four kernels there, the observation the tiled entity raster + the
+    terminal-condition kernel, all in one captured graph), with a road network under two of the three scenarios: same state,
+    flags and maps as the three separate calls, through a restart of the scenarios that are done."""
+    import scenario_gym_amd as sga
+    import scenario_gym_amd._lib as L
+    from scenario_gym_amd import synthetic
+
+    R, E = 3, 700
+    packed = synthetic.make_batch(R, E, n_steps=60, ego_kind=L.KIND_AGENT_VEHICLE, extent=70.0, vanish_frac=0.2)
+    packed.length = packed.length * np.array([0.3, 1.0, 1.0])
+    acts = synthetic.make_actions(40, R)
+    sq = np.array([[-9.0, -9.0], [12.0, -9.0], [12.0, 10.0], [-9.0, 10.0]])
+    net = dict(ring_off=[0, 1], vert_off=[0, 4], verts=sq, layers=[1 | 2])
+    a, b = (sga.RolloutEngine(R, E, terminal_conditions=["max_length", "ego_collision"]) for _ in range(2))
+    for e in (a, b):
+        e.upload(packed)
+        e.set_road_networks([net], np.array([0, -1, 0], np.int32))
+    geo = dict(layers=[0, 1], width=30.0, height=24.0, nw=20, nh=16)
+    seen = 0
+    for k in range(40):
+        if k == 25:
+            m = a.state()["done"]
+            assert m.any()
+            a.reset_scenarios(m)
+            b.reset_scenarios(m)
+        a.step(1, acts[k:k + 1])
+        want_fl, want_map = a.terminal_flags(), a.raster_map(geo["layers"], geo["width"], geo["height"], geo["nw"], geo["nh"])
+        obs, fl = b.tick(acts[k], **geo)
+        assert np.array_equal(fl, want_fl) and np.array_equal(obs, want_map), k
+        seen += int(obs[:, 0].sum())
+    sa, sb = a.state(), b.state()
+    for key in ("poses", "vels", "dists", "ctrl_state", "t", "n_steps", "done"):
+        assert bits_equal(sa[key], sb[key]), key
+    assert seen > 100 and not obs[1, 1].any()  # (scenario 1 has no road network: an empty surface)
+    assert (fl[1] & 8) != 0  # ... and its entity 0 is off the road (flags are evaluated whatever the handle's terminal mask says)
+    a.close()
+    b.close()
+
+
 def test_graph_tick_equals_separate_calls():
     """sg_tick (step + terminal flags + map observation replayed as one captured hipGraph) against the three separate calls,
     tick by tick: same state, same flags, same maps -- through restarts of single scenarios, a change of the time step, a

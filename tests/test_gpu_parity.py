@@ -1437,11 +1437,12 @@ def test_future_collision_batch_matches_oracle(sga, oracle):
 
 def test_sensors_on_wide_scenarios_match_oracle(sga, oracle):
     """FutureCollisionDetector and the entity layer of RasterizedMapSensor on scenarios of 300 and 512 entities (one thread
-    per entity slot: 512 threads per scenario): every flag / every cell equals the oracle's, after a reset and after 60 steps."""
+    per entity slot: 512 threads per scenario) and of 1,100 (tile by tile): every flag / every cell equals the oracle's, after
+    a reset and after 60 steps."""
     from scenario_gym_amd import synthetic
     from scenario_gym_amd.packing import unpack_scenario
 
-    for R, E, extent in ((6, 300, 45.0), (4, 512, 60.0)):
+    for R, E, extent in ((6, 300, 45.0), (4, 512, 60.0), (2, 1100, 85.0)):
         packed = synthetic.make_batch(R, E, n_steps=200, static_frac=0.15, vanish_frac=0.2, extent=extent)
         eng = sga.RolloutEngine(R, E)
         eng.upload(packed)
@@ -1462,31 +1463,34 @@ def test_sensors_on_wide_scenarios_match_oracle(sga, oracle):
         assert cells > 100
 
 
-def test_raster_entities_batch_matches_oracle(sga, oracle):
-    """sg_raster_entities on a synthetic batch (256 x 40, dense scenes, vanishing entities) at two state times and two
-    grids (one not square): every cell of every scenario equals the oracle's."""
+@pytest.mark.parametrize("R,E,extent,n_adv2", [(256, 40, 20.0, 85), (5, 300, 45.0, 40), (3, 1300, 90.0, 12)])
+def test_raster_entities_batch_matches_oracle(sga, oracle, R, E, extent, n_adv2):
+    """sg_raster_entities on a synthetic batch (256 x 40, dense scenes, vanishing entities; scenarios of 300 and of 1,300
+    entities: the kernel goes over the entities tile by tile) at two state times and two grids (one not square): every cell
+    of every scenario equals the oracle's; sg_raster_map's entity layer is the same grid."""
     from scenario_gym_amd import synthetic
     from scenario_gym_amd.packing import unpack_scenario
 
-    R, E = 256, 40
-    packed = synthetic.make_batch(R, E, n_steps=300, static_frac=0.15, vanish_frac=0.2, extent=20.0)
+    packed = synthetic.make_batch(R, E, n_steps=300, static_frac=0.15, vanish_frac=0.2, extent=extent)
     eng = sga.RolloutEngine(R, E)
     eng.upload(packed)
     total = 0
-    for n_adv in (0, 85):
+    for n_adv in (0, n_adv2):
         if n_adv:
             eng.step(n_adv)
         st = eng.state()
         for (w, h, nw, nh) in ((20.0, 20.0, 20, 20), (40.0, 16.0, 33, 12)):
             got = eng.raster_entities(w, h, nw, nh)
             assert got.shape == (R, nh, nw)
-            for r in range(0, R, 2):
+            for r in range(0, R, 2 if R > 8 else 1):
                 s = unpack_scenario(packed, r)
                 want = oracle.raster_entities(st["poses"][r, :len(s["bbox"])], s["bbox"], s["ego"], w, h, nw, nh)
                 assert np.array_equal(got[r], want), (n_adv, w, r, int((got[r] != want).sum()))
                 total += int(want.sum())
+            if E > 64:
+                assert np.array_equal(eng.raster_map([0], w, h, nw, nh)[:, 0], got.astype(bool))
     eng.close()
-    assert total > 2000
+    assert total > (2000 if R > 8 else 200)
 
 
 def test_lattice_scenes_touching_boxes_every_step(sga, oracle):
@@ -1983,17 +1987,17 @@ def test_ego_off_road_terminal_matches_reference_and_oracle(sga, oracle):
     assert early >= 2 and st["n_steps"][-1] == 1 and st["done"][-1]
 
 
-@pytest.mark.parametrize("R,E", [(96, 8), (40, 3), (12, 100), (6, 200), (6, 300), (4, 512)])
+@pytest.mark.parametrize("R,E", [(96, 8), (40, 3), (12, 100), (6, 200), (6, 300), (4, 512), (5, 700)])
 def test_ego_off_road_with_controlled_egos_on_synthetic_roads(sga, oracle, R, E):
     """PID egos (entity 0) wandering over random polygon "roads": every scenario stops at the oracle's step -- cells
-    wholly inside or outside answer from the grid, boundary cells through the exact test.  Tile widths 4, 8 and the
-    two-, four- and eight-wavefront scenarios."""
+    wholly inside or outside answer from the grid, boundary cells through the exact test.  Tile widths 4, 8, the
+    two-, four- and eight-wavefront scenarios and the multi-kernel step of scenarios beyond 512 entities."""
     import scenario_gym_amd._lib as L
     from scenario_gym_amd import synthetic
     from scenario_gym_amd.packing import unpack_scenario
 
     rng = np.random.default_rng(23)
-    steps = 400
+    steps = 400 if E <= 512 else 150
     packed = synthetic.make_batch(R, E, n_steps=steps, ego_kind=L.KIND_AGENT_PID, extent=30.0)
     nets = []
     for n in range(6):
@@ -2451,11 +2455,12 @@ def test_rss_inside_rollout_equals_tick_by_tick(sga):
 
 
 @pytest.mark.parametrize("R,E,ego", [(30, 3, "pid"), (12, 40, "replay"), (6, 100, "pid"), (4, 200, "replay"), (20, 64, "vehicle"),
-                                     (3, 300, "pid"), (2, 512, "replay")])
+                                     (3, 300, "pid"), (2, 512, "replay"), (2, 700, "pid"), (2, 600, "vehicle")])
 def test_rss_fused_rollout_matches_oracle(sga, oracle, R, E, ego):
     """rollout_kernel_rss over the tile widths (4 ... 64 lanes) and the two- / four-wavefront scenarios, replay, PID and
     external-action egos: records of the latest update, safe distances and metric flags equal the oracle's callback run
-    over the oracle's rollout; a second rollout() (reset included) gives the same again."""
+    over the oracle's rollout; a second rollout() (reset included) gives the same again.  Scenarios of more than 512
+    entities run the callback as a launch of its own after every step of the multi-kernel step: the same records."""
     import scenario_gym_amd._lib as L
     from scenario_gym_amd import synthetic
     from scenario_gym_amd.packing import unpack_scenario
@@ -2555,14 +2560,14 @@ def test_rss_inside_pedestrian_and_off_road_rollouts(sga, scene, E):
     b.close()
 
 
-def test_masked_reset_restarts_the_rss_histories(sga):
+@pytest.mark.parametrize("R,E,extent", [(16, 12, 10.0), (6, 640, 75.0)])
+def test_masked_reset_restarts_the_rss_histories(sga, R, E, extent):
     """sg_reset_scenarios with the RSS callback on: the flagged scenarios' histories (the "unsafe" entries behind the metric
-    flags, `last`) start anew with the reset-time update, the others carry on."""
+    flags, `last`) start anew with the reset-time update, the others carry on (also on scenarios of more than 512 entities)."""
     import scenario_gym_amd._lib as L
     from scenario_gym_amd import synthetic
 
-    R, E = 16, 12
-    packed = synthetic.make_batch(R, E, n_steps=60, ego_kind=L.KIND_AGENT_PID, extent=10.0)
+    packed = synthetic.make_batch(R, E, n_steps=60, ego_kind=L.KIND_AGENT_PID, extent=extent)
     mask = (np.arange(R) % 3 == 0).astype(np.uint8)
     runs = {}
     for name, plan in (("restarted", (30, "reset", 20)), ("fresh20", (20,)), ("straight50", (50,))):
@@ -2583,14 +2588,16 @@ def test_masked_reset_restarts_the_rss_histories(sga):
         assert np.array_equal(runs["restarted"][k][~m], runs["straight50"][k][~m], equal_nan=True), k
 
 
-def test_rss_callback_inside_the_graph_tick(sga):
-    """sg_tick (one captured launch per RL tick) with sg_set_rss: the captured step is the RSS variant + rss_lines_kernel --
-    the records after every tick equal those of sg_step; switching the callback on or off re-captures the graph."""
+@pytest.mark.parametrize("R,E,extent", [(24, 20, 14.0), (3, 560, 70.0)])
+def test_rss_callback_inside_the_graph_tick(sga, R, E, extent):
+    """sg_tick (one captured launch per RL tick) with sg_set_rss: the captured step is the RSS variant + rss_lines_kernel (the
+    multi-kernel step + rss_kernel on scenarios of more than 512 entities) -- the records after every tick equal those of
+    sg_step; switching the callback on or off re-captures the graph."""
     import scenario_gym_amd._lib as L
     from scenario_gym_amd import synthetic
 
-    R, E, steps = 24, 20, 40
-    packed = synthetic.make_batch(R, E, n_steps=steps, ego_kind=L.KIND_AGENT_VEHICLE, extent=14.0)
+    steps = 40
+    packed = synthetic.make_batch(R, E, n_steps=steps, ego_kind=L.KIND_AGENT_VEHICLE, extent=extent)
     acts = synthetic.make_actions(steps, R)
     a = sga.RolloutEngine(R, E)
     b = sga.RolloutEngine(R, E)
