@@ -567,7 +567,8 @@ static int launch_wide(sg_handle *h, int n_steps, int do_reset, int force, const
         wa.mode = mode;
         wa.force = force;
         wa.actions = acts;
-        sgl::wide_step(ge, gs, h->stream, h->p, h->cfg.timestep, wa);
+        wa.no_peds = h->has_ped ? 0 : 1;
+        sgl::wide_step(ge, gs, h->stream, h->p, h->cfg.timestep, wa, !h->has_ped);
     };
     // sg_set_rss at this width: RSSDistances.__call__ as a launch of its own after the reset and after every step
     auto rss = [&](int reset) {
