@@ -828,9 +828,11 @@ def main(argv=None, make_engine=None):
         print(json.dumps(line))
     if dist is not None and (live or args.engine_factory):
         dist.destroy_process_group()
-    failed = [r for r in (main_run, other_run[1] if other_run else None, sliced_run) if r and r["verified"] and not r["verified"]["equal"]]
+    failed = [(n, r) for n, r in (("value", main_run), ("strong / weak", other_run[1] if other_run else None), ("strong_sliced", sliced_run))
+              if r and r["verified"] and not r["verified"]["equal"]]
     if failed:
-        print(f"bench: the device state DIFFERS from the oracle: {failed[0]['verified']['mismatches']}", file=sys.stderr)
+        print(f"bench: the device state DIFFERS from the oracle in the `{failed[0][0]}` run of rank {rank}: {failed[0][1]['verified']['mismatches']}",
+              file=sys.stderr)
         raise SystemExit(3)
     if args.require_queue and line is not None and (line.get("degraded") or not (line["roofline"].get("schedule") or {}).get("per_rank")):
         print("bench: --require-queue: not every rank ran the persistent table launch", file=sys.stderr)

@@ -206,6 +206,23 @@ static int fail(sg_handle *h, int code, const char *fmt, ...)
                         __FILE__, __LINE__);                                                      \
     } while (0)
 
+// SG_POISON=1 (tests): every device array that is handed out WITHOUT being zeroed is filled with 0xA5 bytes instead of being
+// left as the allocator found it -- a read of something no kernel wrote shows in a fresh process as it would after a
+// thousand other handles (tests/test_gpu_parity.py::test_poisoned_allocations_change_nothing).  Synchronous, so that a fill can never land after a copy another stream makes into the same array.
+static int poison_byte() // 0: off; else the byte (SG_POISON=165: 0xA5, 255: NaNs / -1, 127: huge ints, NaN-free doubles)
+{
+    static const int v = env_int("SG_POISON", 0) & 0xff;
+    return v;
+}
+static bool poison_allocs() { return poison_byte() != 0; }
+static void poison(hipStream_t s, void *ptr, size_t bytes) // (a fresh allocation no kernel has written yet)
+{
+    if (poison_allocs() && ptr) {
+        (void)hipMemsetAsync(ptr, poison_byte(), bytes, s);
+        (void)hipStreamSynchronize(s);
+    }
+}
+
 template <typename T>
 static int dev_alloc(sg_handle *h, std::vector<void *> &pool, T **out, size_t n, bool zero = true)
 {
@@ -214,6 +231,10 @@ static int dev_alloc(sg_handle *h, std::vector<void *> &pool, T **out, size_t n,
     HIP_TRY(h, hipMalloc(&ptr, bytes));
     pool.push_back(ptr);
     if (zero) HIP_TRY(h, hipMemsetAsync(ptr, 0, bytes, h->stream));
+    else if (poison_allocs()) { // (synchronous: the array may be filled on another stream next, e.g. the knot copy of sg_upload)
+        HIP_TRY(h, hipMemsetAsync(ptr, poison_byte(), bytes, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+    }
     *out = (T *)ptr;
     return SG_OK;
 }
@@ -246,6 +267,10 @@ static int dev_alloc(sg_handle *h, ReusePool &pool, T **out, size_t n, bool zero
         pool.cap[i] = bytes;
     }
     if (zero) HIP_TRY(h, hipMemsetAsync(pool.ptr[i], 0, bytes, h->stream));
+    else if (poison_allocs()) {
+        HIP_TRY(h, hipMemsetAsync(pool.ptr[i], poison_byte(), bytes, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+    }
     *out = (T *)pool.ptr[i];
     return SG_OK;
 }
@@ -752,6 +777,7 @@ static int launch_queue(sg_handle *h, int n_steps, int force, const double *d_ac
             return SG_QUEUE_FALLBACK;
         }
         h->qtab_bytes = need;
+        poison(h->stream, h->d_qtab, need);
     }
     h->p.tab_steps = ts;
     const bool q_trace = env_int("SG_QUEUE_DEBUG", 0) != 0;
@@ -978,7 +1004,10 @@ static int launch_rollout_impl(sg_handle *h, int n_steps, int do_reset, int forc
                     const size_t bytes = std::max(need, h->tab_bytes);
                     h->tab_bytes = 0;
                     h->n_tab = 0;
-                    for (int b = 0; b < NB; ++b) HIP_TRY(h, hipMalloc((void **)&h->d_tab[b], bytes));
+                    for (int b = 0; b < NB; ++b) {
+                        HIP_TRY(h, hipMalloc((void **)&h->d_tab[b], bytes));
+                        poison(h->stream, h->d_tab[b], bytes);
+                    }
                     h->tab_bytes = bytes;
                     h->n_tab = NB;
                 }
@@ -1268,6 +1297,13 @@ extern "C" int sg_set_ped_models(sg_handle *h, int32_t n_models, const sg_ped_mo
             return fail(h, SG_ERR_INVALID, "sg_set_ped_models: model %d: std must be >= 0", m);
     }
     if (n_models > 1 && !model_of) return fail(h, SG_ERR_INVALID, "sg_set_ped_models: several models need model_of[n_scenarios * n_entities]");
+    // (every refusal before anything of the handle changes: a refused call leaves the models it had)
+    if (n_models > 1 && h->wide) return fail(h, SG_ERR_INVALID, "sg_set_ped_models: several models on scenarios of more than 512 entities");
+    if (n_models > 1)
+        for (int r = 0; r < h->R; ++r)
+            for (int e = 0; e < h->E; ++e)
+                if (model_of[(size_t)r * h->E + e] >= n_models)
+                    return fail(h, SG_ERR_INVALID, "sg_set_ped_models: model_of[%d][%d] = %d >= n_models = %d", r, e, model_of[(size_t)r * h->E + e], n_models);
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     // model 0 is also what the handle-wide fields say (the single-model kernels, the oracle of a one-model batch)
     h->sf = models[0].params;
@@ -1277,7 +1313,6 @@ extern "C" int sg_set_ped_models(sg_handle *h, int32_t n_models, const sg_ped_mo
     if (h->noise_mode != SG_NOISE_OFF) { h->noise_std[0] = models[0].std_lon; h->noise_std[1] = models[0].std_lat; }
     h->n_ped_models = n_models;
     if (n_models > 1) {
-        if (h->wide) return fail(h, SG_ERR_INVALID, "sg_set_ped_models: several models on scenarios of more than 512 entities");
         std::vector<double> rows((size_t)n_models * sg::PM_W, 0.0);
         for (int m = 0; m < n_models; ++m) {
             double *r = rows.data() + (size_t)m * sg::PM_W;
@@ -1290,7 +1325,6 @@ extern "C" int sg_set_ped_models(sg_handle *h, int32_t n_models, const sg_ped_mo
         for (int r = 0; r < h->R; ++r)
             for (int e = 0; e < h->E; ++e) {
                 const int32_t v = model_of[(size_t)r * h->E + e];
-                if (v >= n_models) return fail(h, SG_ERR_INVALID, "sg_set_ped_models: model_of[%d][%d] = %d >= n_models = %d", r, e, v, n_models);
                 mo[(size_t)r * h->EP + e] = v < 0 ? 0 : v;
             }
         HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -1851,6 +1885,7 @@ static int obs_scratch(sg_handle *h, size_t bytes, unsigned char **out)
         h->obs_buf = nullptr;
         h->obs_cap = 0;
         HIP_TRY(h, hipMalloc(&h->obs_buf, bytes));
+        poison(h->stream, h->obs_buf, bytes);
         h->obs_cap = bytes;
         ++h->generation;
     }
