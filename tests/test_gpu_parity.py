@@ -6,6 +6,7 @@ controller-integrated poses: <= 1e-5 abs (observed ~1e-10 vs the reference, 0 vs
 collision adjacency and events: exact.
 """
 import os
+import sys
 
 import numpy as np
 import pytest
