@@ -51,3 +51,32 @@ def oracle():
 
     O.build()
     return O
+
+
+@pytest.fixture(autouse=True)
+def _scrambled_device_memory(request):
+    """SG_SCRAMBLE=<GiB>: before every GPU test, that much free device memory is filled with a pattern and released, so that
+    what the library allocates next is NOT what a previous run of the same suite left at the same addresses (the first suite run
+    on a fresh box sees other people's bytes there; every later run sees its own, valid-looking ones -- a read of memory nobody
+    wrote only shows in the first).  Patterns rotate: NaNs, random bytes, huge integers."""
+    gib = float(os.environ.get("SG_SCRAMBLE", "0") or 0)
+    if gib > 0 and request.node.get_closest_marker("gpu") is not None:
+        import torch
+
+        n = int(gib * (1 << 30))
+        k = getattr(_scrambled_device_memory, "k", 0)
+        _scrambled_device_memory.k = k + 1
+        parts = []
+        for i in range(8):  # (several pieces: the allocator hands the library blocks out of any of them)
+            t = torch.empty(n // 8, dtype=torch.uint8, device="cuda:0")
+            if k % 3 == 0:
+                t.fill_(0xFF)
+            elif k % 3 == 1:
+                t.random_(0, 256)
+            else:
+                t.fill_(0x7F)
+            parts.append(t)
+        torch.cuda.synchronize()
+        del parts, t
+        torch.cuda.empty_cache()
+    yield

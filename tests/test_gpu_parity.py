@@ -1002,6 +1002,35 @@ def test_far_from_origin_uses_the_all_pairs_fallback(sga, oracle):
     assert (st["coll"] != 0).any()
 
 
+def test_sliced_path_orders_its_two_streams(sga, monkeypatch):
+    """The time-sliced path finishes on two streams: the launch that materialises the last executed step (it starts from the
+    scenario records of the reset) and the per-scenario ordered pass (it overwrites those records with the final ones).
+    SG_SLICE_DELAY_US holds the first one back by a millisecond: the second must still wait for it.  (It did not until round
+    5 -- a scenario already marked done sat the last launch out and kept its reset poses, on one suite run in four of a
+    cold box.)"""
+    import scenario_gym_amd._lib as L
+    from scenario_gym_amd import synthetic
+
+    out = []
+    for delay in ("0", "1000"):
+        monkeypatch.setenv("SG_SLICE_DELAY_US", delay)
+        for ego, E, term in ((L.KIND_AGENT_REPLAY, 31, ["max_length", "ego_collision"]), (L.KIND_AGENT_VEHICLE, 16, ["max_length", "collision"])):
+            packed = synthetic.make_batch(12, E, n_steps=90, ego_kind=ego, static_frac=0.15, vanish_frac=0.25, extent=14.0)
+            res = []
+            for slicing in (False, "always"):
+                eng = sga.RolloutEngine(12, E, terminal_conditions=term, event_capacity=8)
+                eng.set_slicing(slicing)
+                eng.upload(packed)
+                res.append(_final_results(eng, 90))
+                eng.close()
+            (sa, ra, ea), (sb, rb, eb) = res
+            for k in ("poses", "vels", "dists", "t", "prev_t", "ctrl_state"):
+                assert bits_equal(sa[k], sb[k]), (delay, E, k)
+            assert np.array_equal(sa["coll"], sb["coll"]) and np.array_equal(ra, rb) and np.array_equal(ea, eb), (delay, E)
+            out.append(int(ra["n_steps"].min()))
+    assert min(out) < 90  # (some scenario ended early: its last step is not the call's last)
+
+
 @pytest.mark.parametrize("byte", [255, 127])
 def test_poisoned_allocations_change_nothing(byte):
     """SG_POISON fills every device array the library hands out WITHOUT zeroing it (NaNs / -1 with 255, huge integers with
