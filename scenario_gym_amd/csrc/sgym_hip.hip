@@ -804,7 +804,7 @@ static int launch_queue(sg_handle *h, int n_steps, int force, const double *d_ac
     tq.buf_doubles = buf_bytes / sizeof(double);
     tq.actions = d_actions;
     tq.timeout_ticks = (long long)std::max(1, env_int("SG_QUEUE_TIMEOUT_MS", 20000)) * 100000ll; // 100 MHz
-    tq.handoff = env_int("SG_QUEUE_HANDOFF", 1);
+    tq.handoff = env_int("SG_QUEUE_HANDOFF", 1) != 0; // 0: a release fence per item instead (correct as well, 60 G on c3)
     tq.lag_prio = env_int("SG_QUEUE_LAGPRIO", 2);
     const char *times_path = getenv("SG_QUEUE_TIMES"); // experiment: per-item time stamps, dumped as u64 after the launch
     static unsigned long long *d_times = nullptr;

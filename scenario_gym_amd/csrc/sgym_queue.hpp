@@ -295,8 +295,7 @@ __device__ __forceinline__ void tabq_body(const Params &p, double timestep, int 
             }
         }
         if (tq.handoff == 1) q_handoff_writethrough<G>(p, b, lane);
-        else if (tq.handoff == 0) q_release();
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (2: measurement only -- nothing makes the stores visible)
+        else q_release();
         trace(6);
         stamp(3);
         done_b = b;
