@@ -107,9 +107,9 @@ typedef struct {
                                 Up to 512: one workgroup per scenario, every kind, callback and observation call.  Beyond: the
                                 step runs as four kernels over as many workgroups as the scenario needs -- every entity kind
                                 (caller-run agents; pedestrian agents with the counter-based noise), the RSS callback (a launch
-                                of its own per step), road networks with ego_off_road and the map's surface layers, the
-                                observation calls and sg_tick.  Not served there (SG_ERR_INVALID): road networks under
-                                pedestrian agents, the noise stream, several pedestrian models */
+                                of its own per step), road networks with ego_off_road, the pedestrians' boundary forces and the
+                                map's surface layers, the observation calls and sg_tick.  Not served there (SG_ERR_INVALID):
+                                the noise stream (the counter-based generator is), several pedestrian models */
     int32_t persist;         /* ScenarioGym(persist=...) */
     uint32_t terminal_mask;  /* SG_TERM_* */
     int32_t record_capacity; /* rows of State._recorded_poses kept on device (0 = off), state.py:227-228 */

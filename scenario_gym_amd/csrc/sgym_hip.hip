@@ -2669,8 +2669,6 @@ int build_road_network(const sg_road_networks *in, int n, RoadBuild &B)
 
 extern "C" int sg_set_road_networks(sg_handle *h, const sg_road_networks *in)
 {
-    if (h && h->wide && h->has_ped)
-        return fail(h, SG_ERR_INVALID, "sg_set_road_networks: scenarios of more than 512 entities with pedestrian agents (their boundary forces) are not served");
     if (!h || !in) return h ? fail(h, SG_ERR_INVALID, "sg_set_road_networks: null argument") : SG_ERR_INVALID;
     if (!h->uploaded) return fail(h, SG_ERR_STATE, "sg_set_road_networks: no scenarios uploaded");
     if (in->n_networks < 0 || !in->net_of_scenario || (in->n_networks > 0 && (!in->poly_off || !in->ring_off || !in->vert_off || !in->layers)))

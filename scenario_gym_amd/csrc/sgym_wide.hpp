@@ -16,7 +16,7 @@
 //   wide_finish_kernel   one workgroup per scenario: the clock, terminal conditions, ego metrics, CollisionMetric events
 // in that order, once per step.  Same arithmetic as the fused kernels and the oracle (plain IEEE operations: ExactArith), so
 // the same bits; 4 launches per step instead of thousands of steps per launch -- the price of not having a ceiling.
-// Not at this width: road networks under pedestrian agents (their boundary forces), the RSS callback,
+// Not at this width: the noise stream mode (the counter-based generator works), several pedestrian models;
 // the noise stream mode (the counter-based generator works).
 #pragma once
 #include "sgym_device.hpp"
@@ -217,6 +217,8 @@ __device__ __forceinline__ void wide_move_body(const Params &p, double timestep,
             work_off();
         }
     }
+    // the boundary terms of SocialForce._step, after the neighbours (social_force.py:83-104); RandomWalk has none
+    if (go && pairs) ped_boundary_terms(p, r, pose[0], pose[1], fx, fy);
     // ---- the pose ----
     if (kind == SG_KIND_REPLAY) { // BatchReplayEntity.step, batch.py:34-53
         npres = p.persist || is_static || (next_t >= min_t && next_t <= max_t);

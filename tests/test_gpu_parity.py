@@ -1054,7 +1054,7 @@ def test_abi_rejects_bad_input(sga):
 
     with pytest.raises(RuntimeError, match="n_entities"):
         sga.RolloutEngine(4, 16385)
-    # beyond 512 entities: the multi-kernel step, and the three things it does not offer say so
+    # beyond 512 entities: the multi-kernel step, and the two things it does not offer say so
     from scenario_gym_amd import synthetic
 
     crowd = synthetic.make_crowd(1, 600, n_steps=5, side=30.0)
@@ -1066,10 +1066,6 @@ def test_abi_rejects_bad_input(sga):
     wide = sga.RolloutEngine(1, 600)
     with pytest.raises(RuntimeError, match="more than 512 entities"):
         wide.set_ped_models([dict(behaviour="social_force"), dict(behaviour="random_walk")], np.zeros(600, np.int32))
-    wide.upload(crowd)
-    tri0 = dict(ring_off=[0, 1], vert_off=[0, 3], verts=[[0, 0], [1, 0], [0, 1]], layers=[1])
-    with pytest.raises(RuntimeError, match="pedestrian agents"):
-        wide.set_road_networks([tri0], [0])
     wide.close()
     with pytest.raises(RuntimeError, match="timestep"):
         sga.RolloutEngine(4, 4, timestep=0.0)
@@ -2816,14 +2812,19 @@ def _random_crowds(n, seed=77):
                         radii=bool(rng.integers(0, 2)), late=bool(rng.integers(0, 3) == 0),
                         riders=int(rrng.integers(0, 8)) if rrng.integers(0, 2) else 0,  # how many of _ALL_RIDERS ride along
                         walk=bool(brng.integers(0, 5) == 0)))                            # RandomWalk instead of SocialForce
-        if brng.integers(0, 15) == 0:  # one in fifteen: a crowd of more than 512 (the multi-kernel step: no road networks, no
-            c = out[-1]                # noise stream there; riders of every kind stay)
-            c.update(E=int(brng.choice([520, 640])), R=int(brng.integers(1, 3)), steps=min(c["steps"], 40), roads=False,
+        if brng.integers(0, 15) == 0:  # one in fifteen: a crowd of more than 512 (the multi-kernel step: no noise stream there;
+            c = out[-1]                # road networks and riders of every kind stay)
+            c.update(E=int(brng.choice([520, 640])), R=int(brng.integers(1, 3)), steps=min(c["steps"], 40),
                      side=float(brng.choice([25.0, 40.0])), noise="device" if c["noise"] == "stream" else c["noise"])
     return out
 
 
-@pytest.mark.parametrize("cfg", _random_crowds(int(os.environ.get("SG_FUZZ_CROWDS", "8")), int(os.environ.get("SG_FUZZ_SEED", "77"))),
+# (two fixed ones beside the random draw: crowds of more than 512 pedestrians ON road networks -- the boundary terms at that width)
+_WIDE_ROAD_CROWDS = [dict(E=600, R=2, steps=30, side=25.0, roads=True, seed=424243, dt=1 / 30, noise="off", radii=True, late=False, riders=0, walk=False),
+                     dict(E=530, R=3, steps=25, side=40.0, roads=True, seed=424244, dt=0.1, noise="device", radii=False, late=True, riders=3, walk=False)]
+
+
+@pytest.mark.parametrize("cfg", _random_crowds(int(os.environ.get("SG_FUZZ_CROWDS", "8")), int(os.environ.get("SG_FUZZ_SEED", "77"))) + _WIDE_ROAD_CROWDS,
                          ids=lambda c: f"E{c['E']}-s{c['side']:.0f}-{'roads' if c['roads'] else 'free'}-{c['noise']}{'-walk' if c['walk'] else ''}")
 def test_randomized_crowds_match_oracle(sga, oracle, cfg):
     """Random social-force crowds (tile widths up to four wavefronts, sparse to packed), half of them on a road network with
