@@ -108,8 +108,8 @@ typedef struct {
                                 step runs as four kernels over as many workgroups as the scenario needs -- every entity kind
                                 (caller-run agents; pedestrian agents with the counter-based noise), the RSS callback (a launch
                                 of its own per step), road networks with ego_off_road, the pedestrians' boundary forces and the
-                                map's surface layers, the observation calls and sg_tick.  Not served there (SG_ERR_INVALID):
-                                the noise stream (the counter-based generator is), several pedestrian models */
+                                map's surface layers, both noise modes, several pedestrian models, the observation calls and
+                                sg_tick: nothing is refused at that width */
     int32_t persist;         /* ScenarioGym(persist=...) */
     uint32_t terminal_mask;  /* SG_TERM_* */
     int32_t record_capacity; /* rows of State._recorded_poses kept on device (0 = off), state.py:227-228 */
@@ -249,8 +249,8 @@ int sg_set_social_force(sg_handle *h, const sg_social_force *params);
  * neighbours' states, social_force.py:44-114); the all-pedestrian crowd kernels, which hold one parameter set, stand back
  * for the general pedestrian variant.  The noise MODE (off / stream / device, sg_set_ped_noise) stays one per handle: the
  * reference draws every agent's two variates from the one global generator, in agent order, whatever its model.
- * SG_ERR_INVALID: more than SG_MAX_PED_MODELS models, an index out of range, scenarios of more than 512 entities with more
- * than one model. */
+ * SG_ERR_INVALID: more than SG_MAX_PED_MODELS models, an index out of range (a refused call leaves the handle's models as
+ * they were). */
 #define SG_MAX_PED_MODELS 16
 typedef struct {
     int32_t behaviour;       /* SG_PED_SOCIAL_FORCE / SG_PED_RANDOM_WALK */

@@ -574,7 +574,8 @@ static int ensure_wide(sg_handle *h) // (the scratch of the multi-kernel step; s
         auto &A = h->wide_allocs;
         if ((rc = dev_alloc(h, A, &h->wide_args.scr, h->NE * sg::WS_W)) || (rc = dev_alloc(h, A, &h->wide_args.cor, h->NE * 8)) ||
             (rc = dev_alloc(h, A, &h->wide_args.circ, h->NE * 4)) || (rc = dev_alloc(h, A, &h->wide_args.last_row, (size_t)h->R * h->WV)) ||
-            (rc = dev_alloc(h, A, &h->wide_args.last_same, h->NE)) || (rc = dev_alloc(h, A, &h->wide_args.dup, (size_t)h->R)))
+            (rc = dev_alloc(h, A, &h->wide_args.last_same, h->NE)) || (rc = dev_alloc(h, A, &h->wide_args.dup, (size_t)h->R)) ||
+            (rc = dev_alloc(h, A, &h->wide_args.walkers, (size_t)h->R)))
             return rc;
     }
     if (!h->wide_running) HIP_TRY(h, hipHostMalloc((void **)&h->wide_running, WIDE_RING * sizeof(int), hipHostMallocDefault));
@@ -1311,7 +1312,6 @@ extern "C" int sg_set_ped_models(sg_handle *h, int32_t n_models, const sg_ped_mo
     }
     if (n_models > 1 && !model_of) return fail(h, SG_ERR_INVALID, "sg_set_ped_models: several models need model_of[n_scenarios * n_entities]");
     // (every refusal before anything of the handle changes: a refused call leaves the models it had)
-    if (n_models > 1 && h->wide) return fail(h, SG_ERR_INVALID, "sg_set_ped_models: several models on scenarios of more than 512 entities");
     if (n_models > 1)
         for (int r = 0; r < h->R; ++r)
             for (int e = 0; e < h->E; ++e)
@@ -1436,13 +1436,6 @@ extern "C" int sg_upload(sg_handle *h, const sg_scenarios *sc)
         h->crowd_riders = ok;
     }
     if (h->has_ped && (!sc->route_off || !sc->routes)) return fail(h, SG_ERR_INVALID, "sg_upload: pedestrian agents need route_off/routes");
-    if (h->wide && h->n_ped_models > 1)
-        return fail(h, SG_ERR_INVALID, "sg_upload: several pedestrian behaviour models (sg_set_ped_models) on scenarios of more than 512 entities: "
-                                       "the multi-kernel step holds one model");
-    if (h->wide) { // more than 512 entities per scenario: the multi-kernel step (sgym_wide.hpp) and what it does not do
-        if (h->has_ped && h->noise_mode == SG_NOISE_STREAM)
-            return fail(h, SG_ERR_INVALID, "sg_upload: the pedestrian noise stream is available up to 512 entities per scenario (the counter-based generator works)");
-    }
     // (257..512 entities: pedestrian agents run the general pedestrian variant, rollout_kernel<64, 8, true, false>; the crowd
     // kernels, the riders' pre-pass and road networks with pedestrians stop at 256)
     if (h->has_ped && (h->cfg.terminal_mask & SG_TERM_EGO_OFF_ROAD))

@@ -16,7 +16,7 @@
 //   wide_finish_kernel   one workgroup per scenario: the clock, terminal conditions, ego metrics, CollisionMetric events
 // in that order, once per step.  Same arithmetic as the fused kernels and the oracle (plain IEEE operations: ExactArith), so
 // the same bits; 4 launches per step instead of thousands of steps per launch -- the price of not having a ceiling.
-// Not at this width: the noise stream mode (the counter-based generator works), several pedestrian models;
+// (Nothing is refused at this width any more: round 5.)
 // the noise stream mode (the counter-based generator works).
 #pragma once
 #include "sgym_device.hpp"
@@ -29,6 +29,7 @@ struct WideArgs {
     double *circ;         // [NE][4] bounding circle of the box: cx, cy, radius (NaN cx: absent)
     uint64_t *last_row;   // [R][WV] CollisionMetric.last_timestep
     int32_t *last_same;   // [NE] the LAST entity of the scenario whose box is bit-identical to this one's (itself: nobody's is)
+    int32_t *walkers;     // [R] pedestrians that walk in this step (noise stream mode: the scenario's stream advances by two per walker)
     uint32_t *dup;        // [R] bit 0: some entity of the scenario has a twin this step (wide_owner_row has work); bit 1: some
                           // entity's collision row is not empty; bit 2: entity 0's is not (the terminal conditions of wide_finish_kernel)
     const double *actions; // [R][2] of THIS step or nullptr
@@ -142,6 +143,18 @@ __device__ __forceinline__ void wide_move_body(const Params &p, double timestep,
     };
     // ---- the social force needs every pedestrian of the scenario: all threads stage, pedestrian threads accumulate ----
     const bool is_ped = kind == SG_KIND_AGENT_PEDESTRIAN;
+    // this pedestrian's behaviour model: the handle's, or its own row where the batch mixes models (sg_set_ped_models;
+    // pedestrian/agent.py:18-41) -- the force on a pedestrian is computed with ITS parameters from its neighbours' states
+    sg_social_force sf = p.sf;
+    int beh = p.ped_behaviour;
+    double nstd_lon = p.noise_std_lon, nstd_lat = p.noise_std_lat;
+    if (p.n_ped_models > 1 && is_ped) {
+        const double *mm = p.ped_models + (size_t)p.model_of[w.g] * PM_W;
+        beh = (int)mm[PM_BEHAVIOUR];
+        sf = *reinterpret_cast<const sg_social_force *>(mm + PM_SF);
+        nstd_lon = mm[PM_STD_LON];
+        nstd_lat = mm[PM_STD_LAT];
+    }
     const double *wp = nullptr;
     int nwp = 0;
     bool go = false;
@@ -157,16 +170,53 @@ __device__ __forceinline__ void wide_move_body(const Params &p, double timestep,
             double gn = sg_norm2(gx, gy);
             if (gn == 0) gn += 0.000000001;
             vdes = fld(w.st, ST_CTRL + SG_C_PED_SPEED_DESIRED);
-            const double inv_tau = 1 / p.sf.relaxation_time;
+            const double inv_tau = 1 / sf.relaxation_time;
             fx = inv_tau * (vdes * (gx / gn) - velx);
             fy = inv_tau * (vdes * (gy / gn) - vely);
             sg_sincos(fld(w.st, ST_CTRL + SG_C_PED_HEAD_ROT), hs, hc, K);
             radius = fld(w.st, ST_CTRL + SG_C_PED_RADIUS);
-            if (p.ped_behaviour == SG_PED_RANDOM_WALK) { fx = gx; fy = gy; } // RandomWalk._step: the vector to the goal point
+            if (beh == SG_PED_RANDOM_WALK) { fx = gx; fy = gy; } // RandomWalk._step: the vector to the goal point
         }
     }
-    const bool pairs = p.ped_behaviour != SG_PED_RANDOM_WALK && !wa.no_peds; // (grid-uniform)
-    const double k2_scale = p.sf.ped_repulse_V / p.sf.ped_repulse_sigma;
+    // The noise stream (sg_set_ped_noise, SG_NOISE_STREAM): two variates per WALKING pedestrian in entity order, as the reference
+    // draws them from numpy's global generator (social_force.py:106-108) -- this entity's place in that order is the number of
+    // walkers before it in the whole scenario, over all workgroups: every workgroup looks at every tile (parity runs, not
+    // timing runs).  A pedestrian walks iff it is present and has a goal left after this step's goal update.
+    int walkers_before = 0, walkers = 0;
+    if (p.noise_mode == 1 && !wa.no_peds) { // (grid-uniform)
+        __shared__ uint64_t s_walk[4];
+        for (int c0 = 0; c0 < p.EP; c0 += 256) {
+            const int j = c0 + tid;
+            bool gj = false;
+            if (j < p.E) {
+                const WideEnt o(p, r, j);
+                if ((int)(fld<int64_t>(o.st, ST_META) & 0xff) == SG_KIND_AGENT_PEDESTRIAN && fld<uint64_t>(o.dy, SG_F_PRESENT) != 0) {
+                    const int64_t rt = fld<int64_t>(o.st, ST_ROUTE);
+                    const double *wj = p.routes + (rt & 0xffffffffffffll) * 2;
+                    const int nj = (int)(rt >> 48);
+                    int gi = (int)fld(o.dy, SG_F_CTRL + 1);
+                    if (gi <= nj - 1) gi = ped_goal_update(wj, nj, fld(o.dy, SG_F_POSE + 0), fld(o.dy, SG_F_POSE + 1));
+                    gj = gi <= nj - 1;
+                }
+            }
+            __syncthreads();
+            const uint64_t b = __ballot(gj);
+            if ((tid & 63) == 0) s_walk[tid >> 6] = b;
+            __syncthreads();
+            for (int k = 0; k < 4; ++k) {
+                const int base = c0 + k * 64;
+                const uint64_t m = s_walk[k];
+                walkers += __builtin_popcountll(m);
+                if (base + 64 <= e) walkers_before += __builtin_popcountll(m);
+                else if (base <= e) walkers_before += __builtin_popcountll(m & ((1ull << (e - base)) - 1));
+            }
+        }
+        if (e == 0) wa.walkers[r] = walkers;
+    }
+    // (grid-uniform: the tiles are staged when some pedestrian of the batch may follow SocialForce; a RandomWalk lane sits the pairs out)
+    const bool pairs = (p.n_ped_models > 1 || p.ped_behaviour != SG_PED_RANDOM_WALK) && !wa.no_peds;
+    const bool lane_pairs = beh != SG_PED_RANDOM_WALK;
+    const double k2_scale = sf.ped_repulse_V / sf.ped_repulse_sigma;
     // (the loop bounds are uniform over the grid row of the scenario: every thread of every block walks all chunks)
     for (int c0 = 0; c0 < p.EP && pairs; c0 += 256) {
         const int j = c0 + tid;
@@ -184,7 +234,7 @@ __device__ __forceinline__ void wide_move_body(const Params &p, double timestep,
             s_px[tid] = jx; s_py[tid] = jy; s_vx[tid] = jvx; s_vy[tid] = jvy; s_ok[tid] = ok;
         }
         __syncthreads();
-        if (go) {
+        if (go && lane_pairs) {
             // PedestrianSensor.get_nearby_pedestrians in entity order (sensor.py:55-64).  A neighbour is rare per slot but not per
             // wavefront: evaluated where it is found, every lane's neighbour would send all 64 lanes through the pair force.
             // The scan only notes the slots inside the circle about the 64-gon (a cheap superset of sg_in_radius); the lane
@@ -203,8 +253,8 @@ __device__ __forceinline__ void wide_move_body(const Params &p, double timestep,
                     const double odx = ovx / vmag, ody = ovy / vmag, step = vmag * (next_t - t);
                     ExactArith EA;
                     double c1x, c1y, c2x, c2y;
-                    ped_pair<false, false>(EA, p.sf, k2_scale, pose[0], pose[1], hs, hc, ox, oy, ovx, ovy, odx, ody, step, c1x, c1y, c2x, c2y);
-                    ped_accumulate(p.sf, c1x, c1y, c2x, c2y, fx, fy);
+                    ped_pair<false, false>(EA, sf, k2_scale, pose[0], pose[1], hs, hc, ox, oy, ovx, ovy, odx, ody, step, c1x, c1y, c2x, c2y);
+                    ped_accumulate(sf, c1x, c1y, c2x, c2y, fx, fy);
                 }
                 nc = 0;
             };
@@ -218,7 +268,11 @@ __device__ __forceinline__ void wide_move_body(const Params &p, double timestep,
         }
     }
     // the boundary terms of SocialForce._step, after the neighbours (social_force.py:83-104); RandomWalk has none
-    if (go && pairs) ped_boundary_terms(p, r, pose[0], pose[1], fx, fy);
+    if (go && pairs && lane_pairs) {
+        Params q = p; // (the boundary terms read the impenetrable-surface parameters of the lane's model)
+        q.sf = sf;
+        ped_boundary_terms(q, r, pose[0], pose[1], fx, fy);
+    }
     // ---- the pose ----
     if (kind == SG_KIND_REPLAY) { // BatchReplayEntity.step, batch.py:34-53
         npres = p.persist || is_static || (next_t >= min_t && next_t <= max_t);
@@ -258,9 +312,15 @@ __device__ __forceinline__ void wide_move_body(const Params &p, double timestep,
                 if (p.noise_mode == 2) {
                     double z0, z1;
                     sg_noise_pair(p.noise_seed, (uint32_t)r, (uint32_t)e, (uint32_t)sd.n_steps, z0, z1, K);
-                    nz = PedNoise{p.noise_std_lon * z0, p.noise_std_lat * z1, true};
+                    nz = PedNoise{nstd_lon * z0, nstd_lat * z1, true};
+                } else if (p.noise_mode == 1 && go) {
+                    const long long at = sd.noise_pos + 2ll * walkers_before;
+                    const bool inside = at + 1 < p.noise_len;
+                    const double *z = p.noise_normals + (size_t)r * (size_t)p.noise_len + (inside ? at : 0);
+                    nz = PedNoise{nstd_lon * (inside ? z[0] : 0.0), nstd_lat * (inside ? z[1] : 0.0), true};
                 }
-                ped_move(p, go, fx, fy, vdes, fld(w.st, ST_CTRL + SG_C_PED_MAX_SPEED), pose, state_dt, cs.speed, fpx, fpy, np_, K, nz);
+                ped_move(PedMoveModel{beh, sf.bias_lon, sf.bias_lat, sf.max_speed_factor}, go, fx, fy, vdes,
+                         fld(w.st, ST_CTRL + SG_C_PED_MAX_SPEED), pose, state_dt, cs.speed, fpx, fpy, np_, K, nz);
                 cs.e_lon_prev = (double)goal_idx;
             }
         } else if (min_t >= t) { // scenario_gym.py:240-244: spawn at the trajectory position of next_t
@@ -560,6 +620,7 @@ static __global__ __launch_bounds__(256) void wide_finish_kernel(Params p, doubl
     sd.prev_t = t_old;
     sd.t = t;
     const int steps = ++sd.n_steps;
+    if (p.noise_mode == 1 && !wa.no_peds) sd.noise_pos += 2ll * wa.walkers[r]; // (counted by wide_move_kernel of this step)
     if (p.rec_cap > 0 && steps < p.rec_cap) { p.rec_t[(size_t)steps * p.R + r] = t; sd.rec_rows = steps + 1; }
     if (ego_present) { // scenario_gym.py:251-252
         const double speed = sg_norm3(fld(eg.dy, SG_F_VEL + 0), fld(eg.dy, SG_F_VEL + 1), fld(eg.dy, SG_F_VEL + 2));

@@ -418,7 +418,7 @@ def test_every_pedestrian_agent_with_its_own_behaviour(si):
 
 def test_ped_models_on_the_device_equal_the_oracle(oracle):
     """sg_set_ped_models through the engine on a batch: 40 scenarios x 48 pedestrians (general pedestrian variant, one
-    wavefront per tile) and 6 x 200 (four wavefronts per scenario) with three models dealt out at random -- two SocialForce
+    wavefront per tile), 6 x 200 (four wavefronts per scenario) and 2 x 600 (the multi-kernel step) with three models dealt out at random -- two SocialForce
     parameter sets and a RandomWalk -- with the counter-based noise: final state, forces, metrics and events equal the oracle's
     per-agent models bit for bit; and the same batch under ONE model differs (the models do act)."""
     import scenario_gym_amd as sga
@@ -434,7 +434,7 @@ def test_ped_models_on_the_device_equal_the_oracle(oracle):
         d = {k: v for k, v in m.items() if k not in ("behaviour", "std_lon", "std_lat")}
         rows.append(oracle.ped_model_row(m.get("behaviour", "social_force"), oracle.social_force_params(**d), m["std_lon"], m["std_lat"]))
     rows = np.array(rows)
-    for R, E, side, steps in ((40, 48, 14.0, 300), (6, 200, 30.0, 250)):
+    for R, E, side, steps in ((40, 48, 14.0, 300), (6, 200, 30.0, 250), (2, 600, 45.0, 60)):  # (600: the multi-kernel step)
         dt = 1 / 30
         packed = synthetic.make_crowd(R, E, n_steps=steps, side=side)
         model_of = np.random.default_rng(R).integers(0, 3, R * E).astype(np.int32)

@@ -1054,19 +1054,10 @@ def test_abi_rejects_bad_input(sga):
 
     with pytest.raises(RuntimeError, match="n_entities"):
         sga.RolloutEngine(4, 16385)
-    # beyond 512 entities: the multi-kernel step, and the two things it does not offer say so
-    from scenario_gym_amd import synthetic
-
-    crowd = synthetic.make_crowd(1, 600, n_steps=5, side=30.0)
-    wide = sga.RolloutEngine(1, 600)
-    wide.set_ped_noise("stream", 0.1, 0.1, normals=np.zeros((1, 64)))
-    with pytest.raises(RuntimeError, match="noise stream is available up to 512"):
-        wide.upload(crowd)
-    wide.close()
-    wide = sga.RolloutEngine(1, 600)
-    with pytest.raises(RuntimeError, match="more than 512 entities"):
-        wide.set_ped_models([dict(behaviour="social_force"), dict(behaviour="random_walk")], np.zeros(600, np.int32))
-    wide.close()
+    eng = sga.RolloutEngine(1, 8)
+    with pytest.raises(RuntimeError, match="model_of"):   # (a refused call leaves the handle as it was)
+        eng.set_ped_models([dict(behaviour="social_force"), dict(behaviour="random_walk")], np.full(8, 2, np.int32))
+    eng.close()
     with pytest.raises(RuntimeError, match="timestep"):
         sga.RolloutEngine(4, 4, timestep=0.0)
     with pytest.raises(ValueError):
@@ -2812,16 +2803,18 @@ def _random_crowds(n, seed=77):
                         radii=bool(rng.integers(0, 2)), late=bool(rng.integers(0, 3) == 0),
                         riders=int(rrng.integers(0, 8)) if rrng.integers(0, 2) else 0,  # how many of _ALL_RIDERS ride along
                         walk=bool(brng.integers(0, 5) == 0)))                            # RandomWalk instead of SocialForce
-        if brng.integers(0, 15) == 0:  # one in fifteen: a crowd of more than 512 (the multi-kernel step: no noise stream there;
-            c = out[-1]                # road networks and riders of every kind stay)
+        if brng.integers(0, 15) == 0:  # one in fifteen: a crowd of more than 512 (the multi-kernel step; road networks, both noise
+            c = out[-1]                # modes and riders of every kind stay)
             c.update(E=int(brng.choice([520, 640])), R=int(brng.integers(1, 3)), steps=min(c["steps"], 40),
-                     side=float(brng.choice([25.0, 40.0])), noise="device" if c["noise"] == "stream" else c["noise"])
+                     side=float(brng.choice([25.0, 40.0])))
     return out
 
 
 # (two fixed ones beside the random draw: crowds of more than 512 pedestrians ON road networks -- the boundary terms at that width)
 _WIDE_ROAD_CROWDS = [dict(E=600, R=2, steps=30, side=25.0, roads=True, seed=424243, dt=1 / 30, noise="off", radii=True, late=False, riders=0, walk=False),
-                     dict(E=530, R=3, steps=25, side=40.0, roads=True, seed=424244, dt=0.1, noise="device", radii=False, late=True, riders=3, walk=False)]
+                     dict(E=530, R=3, steps=25, side=40.0, roads=True, seed=424244, dt=0.1, noise="device", radii=False, late=True, riders=3, walk=False),
+                     dict(E=700, R=2, steps=28, side=25.0, roads=False, seed=424245, dt=1 / 30, noise="stream", radii=True, late=True, riders=2, walk=False),
+                     dict(E=520, R=2, steps=20, side=40.0, roads=True, seed=424246, dt=0.1, noise="stream", radii=False, late=False, riders=0, walk=True)]
 
 
 @pytest.mark.parametrize("cfg", _random_crowds(int(os.environ.get("SG_FUZZ_CROWDS", "8")), int(os.environ.get("SG_FUZZ_SEED", "77"))) + _WIDE_ROAD_CROWDS,
