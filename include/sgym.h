@@ -51,7 +51,8 @@ typedef enum {
 #define SG_TERM_MAX_LENGTH 1u
 #define SG_TERM_COLLISION 2u
 #define SG_TERM_EGO_COLLISION 4u
-#define SG_TERM_EGO_OFF_ROAD 8u /* entities[0] absent or not strictly inside RoadNetwork.driveable_surface (sg_set_road_networks) */
+#define SG_TERM_EGO_OFF_ROAD 8u /* entities[0] absent or not strictly inside RoadNetwork.driveable_surface (sg_set_road_networks);
+                                   with pedestrian agents in the batch: a launch of its own behind every step */
 
 /* The unions of RoadGeometry boundaries the reference takes: RoadNetwork.driveable_surface / walkable_surface /
  * impenetrable_surface (road_network/road_network.py:306-328, flags in road_network/objects.py) and the per-layer
@@ -392,7 +393,9 @@ int sg_rss_update(sg_handle *h, int32_t reset);
  * callback are queued on the device and finished by a second kernel after each launch (queues: env SG_RSSQ_MB, default
  * an eighth of the free device memory and at least 4096 MiB per handle, at most SG_RSSQ_STEPS = 1024 steps per launch; longer
  * calls are cut into several launches; a device short of memory gets shorter launches, not an error).  A scenario that has not stepped since its latest
- * update (it is done) is left alone.  The ego has to be entity 0 (else: one sg_rss_update per step, which says so). */
+ * update (it is done) is left alone.  The ego has to be entity 0 (else: one sg_rss_update per step, which says so).
+ * Combinations no fused kernel variant carries -- scenarios of more than 512 entities; 257..512 entities with pedestrian
+ * agents or SG_TERM_EGO_OFF_ROAD -- run the callback as a launch of its own behind every step: same records. */
 int sg_set_rss(sg_handle *h, int32_t enabled);
 /* flags [R]: bit 0 = RSS_safe_longitudinal, bit 1 = RSS_safe_lateral (no entity's history holds the corresponding
  * "unsafe_*" record); codes [R*E] of the latest update: 0 safe, 1 lateral, 2 longitudinal, 3 both, 4 unsafe_lateral,

@@ -914,6 +914,14 @@ static int launch_rollout(sg_handle *h, int n_steps, int do_reset, int force, co
     if (rc) drain_streams(h);
     return rc;
 }
+// what no fused rollout variant carries (launch_rollout_impl runs these step by step, sg_tick appends the same launches)
+static bool unfused_off_road(const sg_handle *h) { return !h->wide && h->has_ped && (h->cfg.terminal_mask & SG_TERM_EGO_OFF_ROAD); }
+static bool unfused_rss(const sg_handle *h)
+{
+    return !h->wide && h->rss_fused && h->WV == 8 && (h->has_ped || (h->cfg.terminal_mask & SG_TERM_EGO_OFF_ROAD));
+}
+static bool needs_unfused_extras(const sg_handle *h) { return unfused_off_road(h) || unfused_rss(h); }
+
 static int launch_rollout_impl(sg_handle *h, int n_steps, int do_reset, int force, const double *d_actions)
 {
     h->last_schedule = 0;
@@ -926,6 +934,39 @@ static int launch_rollout_impl(sg_handle *h, int n_steps, int do_reset, int forc
         if (rcw) return rcw;
         if (h->timing_now) HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
         h->timed = h->timing_now;
+        return SG_OK;
+    }
+    if (needs_unfused_extras(h)) {
+        // Combinations no fused variant carries go step by step with the missing part as a launch of its own behind every step:
+        // pedestrian agents AND the ego_off_road terminal condition (ego_off_road_kernel: check_terminal is the last thing a step
+        // does to `done`, so a condition added afterwards is the same as one in the list); the RSS callback on scenarios of
+        // 257..512 entities with pedestrian agents or ego_off_road (rss_kernel, as beyond 512).  A scenario that is done sits
+        // the later launches out.  Rare enough combinations not to deserve kernel variants of their own.
+        const bool off_road = unfused_off_road(h), rss = unfused_rss(h);
+        const bool rss_was = h->rss_fused;
+        if (rss) h->rss_fused = false;
+        h->n_launches = 0;
+        h->launch_ev.clear();
+        h->timing_now = false;
+        h->timed = false;
+        size_t evn = 0;
+        int rc1 = SG_OK;
+        auto rss_launch = [&](int reset) {
+            sg::rss_kernel<<<dim3((unsigned)h->R), dim3(512), 0, h->stream>>>(h->p, reset, h->d_rss_state, h->d_rss_code, h->d_rss_safe, h->d_rss_seen);
+        };
+        if (do_reset) {
+            rc1 = launch_main(h, 0, do_reset, 0, nullptr, nullptr, false, &evn);
+            if (!rc1 && rss) rss_launch(do_reset == 2 ? 2 : 1);
+        }
+        for (int k = 0; k < n_steps && !rc1; ++k) {
+            rc1 = launch_main(h, 1, 0, force, d_actions ? d_actions + (size_t)k * h->R * 2 : nullptr, nullptr, false, &evn);
+            if (rc1) break;
+            if (off_road) sg::ego_off_road_kernel<<<dim3((unsigned)((h->R + 63) / 64)), dim3(64), 0, h->stream>>>(h->p);
+            if (rss) rss_launch(0);
+        }
+        h->rss_fused = rss_was;
+        if (rc1) return rc1;
+        HIP_TRY(h, hipGetLastError());
         return SG_OK;
     }
     const int tab_min = h->tab_min, chunk_steps = std::max(1, h->chunk_steps), no_overlap = !h->overlap;
@@ -1438,8 +1479,6 @@ extern "C" int sg_upload(sg_handle *h, const sg_scenarios *sc)
     if (h->has_ped && (!sc->route_off || !sc->routes)) return fail(h, SG_ERR_INVALID, "sg_upload: pedestrian agents need route_off/routes");
     // (257..512 entities: pedestrian agents run the general pedestrian variant, rollout_kernel<64, 8, true, false>; the crowd
     // kernels, the riders' pre-pass and road networks with pedestrians stop at 256)
-    if (h->has_ped && (h->cfg.terminal_mask & SG_TERM_EGO_OFF_ROAD))
-        return fail(h, SG_ERR_INVALID, "sg_upload: the ego_off_road terminal condition is not available for batches with pedestrian agents");
     const int R = h->R, E = h->E, EP = h->EP;
     const size_t NE = h->NE;
     const bool trace = env_int("SG_TRACE_UPLOAD", 0) != 0; // stage timings on stderr
@@ -1955,6 +1994,10 @@ extern "C" int sg_tick(sg_handle *h, const double *actions, int32_t actions_devi
         h->launch_ev.clear();
         h->rss_fused = rss_tick;
         rc = h->wide ? launch_wide(h, 1, 0, 1, h->d_actions) : launch_main(h, 1, 0, 1, h->d_actions, nullptr, false, &ev_next);
+        if (!rc && unfused_off_road(h)) // (launch_rollout_impl: the same launches behind the step)
+            sg::ego_off_road_kernel<<<dim3((unsigned)((h->R + 63) / 64)), dim3(64), 0, h->stream>>>(h->p);
+        if (!rc && unfused_rss(h))
+            sg::rss_kernel<<<dim3((unsigned)h->R), dim3(512), 0, h->stream>>>(h->p, 0, h->d_rss_state, h->d_rss_code, h->d_rss_safe, h->d_rss_seen);
         h->rss_fused = false;
         hipError_t e = hipSuccess;
         if (!rc && h->wide) {
@@ -2446,8 +2489,6 @@ extern "C" int sg_rss_update(sg_handle *h, int32_t reset)
 extern "C" int sg_set_rss(sg_handle *h, int32_t enabled)
 {
     if (!h) return SG_ERR_INVALID;
-    if (enabled && !h->wide && h->WV > 4 && (h->has_ped || (h->cfg.terminal_mask & SG_TERM_EGO_OFF_ROAD)))
-        return fail(h, SG_ERR_INVALID, "sg_set_rss: with pedestrian agents or the ego_off_road terminal condition the callback is available up to 256 entities per scenario");
     h->rss_enabled = enabled != 0;
     return SG_OK;
 }

@@ -621,6 +621,25 @@ static __global__ __launch_bounds__(64) void terminal_flags_kernel(Params p, dou
 }
 #endif // SG_UNIT_MAIN
 
+// TERMINAL_CONDITIONS["ego_off_road"] (state.py:401-407) for batches with pedestrian agents, whose rollout variants do not carry
+// it: evaluated by a launch of its own after every step (check_terminal is the last thing a step does to `done`, so adding a
+// condition afterwards is the same as having it in the list).  One thread per scenario; entities[0] is slot 0.
+#ifdef SG_UNIT_MAIN
+static __global__ __launch_bounds__(64) void ego_off_road_kernel(Params p)
+{
+    const int r = (int)blockIdx.x * 64 + (int)threadIdx.x;
+    if (r >= p.R) return;
+    const uint32_t idx = (uint32_t)r * p.EP;
+    const LanePtr dy(p.dyn + (size_t)(idx >> 6) * ((size_t)p.FROWS * 64), (idx & 63) * 8u);
+    bool off = true;
+    if (fld<uint64_t>(dy, SG_F_PRESENT) != 0 && p.road) {
+        const RoadIndex RI = *p.road;
+        off = !(rn_layers_at(RI, RI.net_of_scen[r], SG_LAYER_DRIVEABLE, fld(dy, SG_F_POSE + 0), fld(dy, SG_F_POSE + 1)) & SG_LAYER_DRIVEABLE);
+    }
+    if (off) p.sdyn[r].done = 1;
+}
+#endif // SG_UNIT_MAIN
+
 // sg_debug_trig32: the broad phase's hardware sin/cos, exposed so that the parity tests can bound its error
 #ifdef SG_UNIT_MAIN // (emitted by the one object that launches it: csrc/Makefile, sgym_launch.hpp)
 static __global__ void trig32_kernel(const double *h, float *s, float *c, int64_t n)
