@@ -720,7 +720,9 @@ static int launch_queue(sg_handle *h, int n_steps, int force, const double *d_ac
     // the last items are short.  SG_QUEUE_GROW: the growth in percent.
     std::vector<int> len;
     chunk = std::min(chunk, std::max(1, env_int("SG_QUEUE_CAP", 512))); // (never above what the caller allows: the RSS line-test queue holds `chunk` steps)
-    const int first = std::max(1, std::min(chunk, env_int("SG_QUEUE_FIRST", 96)));
+    // (first chunk 96 / 128 / 160 / 192 / 256 steps: 94.3 / 95.9 / 97.4 / 97.2 / 95.4 G, means of four interleaved runs on one box,
+    // profiles/r05_ab_first_chunk.txt -- the length also sets the last chunk's, the ramps mirror each other)
+    const int first = std::max(1, std::min(chunk, env_int("SG_QUEUE_FIRST", 160)));
     const int grow = std::max(101, env_int("SG_QUEUE_GROW", 140));
     const int decay = env_int("SG_QUEUE_DECAY", 140); // 0: only the last chunk is halved (below)
     std::vector<int> up, down; // first, first * g, ... (< chunk); the mirror image at the end of the call
