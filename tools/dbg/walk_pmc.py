@@ -1,6 +1,5 @@
 import os, sys, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import scenario_gym_amd as sga
 from scenario_gym_amd import synthetic
 R, E, T = int(os.environ.get("R", "1024")), 256, int(os.environ.get("T", "10000"))
