@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SG_ABI_VERSION 3 /* 2: sg_scenario_state.last_row_hi (scenarios of up to 512 entities); 3: sg_schedule_info replaces sg_pipeline_info */
+#define SG_ABI_VERSION 4 /* 2: sg_scenario_state.last_row_hi (scenarios of up to 512 entities); 3: sg_schedule_info replaces sg_pipeline_info; 4: sg_crowd_walk_stats removed */
 
 typedef enum {
     SG_OK = 0,
@@ -449,14 +449,6 @@ int sg_last_launch_gross_ms(sg_handle *h, float *kernel_ms_gross);
  * A persistent launch whose wavefronts wait longer than SG_QUEUE_TIMEOUT_MS (default 20000) for each other gives up instead
  * of hanging: the next synchronising call returns SG_ERR_HIP and says so. */
 int sg_schedule_info(sg_handle *h, int32_t *info);
-
-/* With SG_CROWD_WALK=3 in the environment (OFF by default: measured no faster, HISTORY.md round 4) long rollouts of
- * all-pedestrian scenarios of 129..256 entities run in chunks of steps; in every chunk a scenario whose pedestrians have
- * mostly ARRIVED (speed 0, heading 0, force 0 from then on: pedestrian/agent.py:64-68) is stepped by a kernel that spends
- * lanes only on the entities that still change (scenario_gym_amd/csrc/sgym_walk.hpp).  Results never depend on it.  out[8], summed since the last reset of the counters: [0..2] scenario-chunks
- * run by the full kernel / by the walker kernel with one / with two wavefronts, [4] walker workgroups that stopped early and
- * were finished by the full kernel, [7] chunks of the last call.  Test and diagnostics hook. */
-int sg_crowd_walk_stats(sg_handle *h, int32_t *out, int32_t reset);
 
 /* ScenarioGym.rollout (scenario_gym.py:256-267) of a batch whose entities are all replay entities / replay agents is a
  * pure function of the clock except for three ordered sums (State.distances, EgoAvgSpeed, the event list); PID / vehicle

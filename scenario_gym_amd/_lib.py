@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SGYM_LIB") or os.path.join(HERE, "lib", "libsgym_hip.so")  # SGYM_LIB: A/B builds
 
 SG_OK = 0
-ABI_VERSION = 3
+ABI_VERSION = 4
 (KIND_NONE, KIND_REPLAY, KIND_AGENT_REPLAY, KIND_AGENT_PID, KIND_AGENT_VEHICLE, KIND_AGENT_PEDESTRIAN,
  KIND_AGENT_EXTERNAL) = range(7)
 TERM_MAX_LENGTH, TERM_COLLISION, TERM_EGO_COLLISION, TERM_EGO_OFF_ROAD = 1, 2, 4, 8
@@ -29,7 +29,7 @@ SYMBOLS = (
     "sg_version", "sg_last_error", "sg_create", "sg_destroy", "sg_upload", "sg_set_social_force", "sg_set_ped_models", "sg_set_ped_behaviour", "sg_set_ped_noise", "sg_reset",
     "sg_set_timestep", "sg_step", "sg_rollout", "sg_rollout_async", "sg_synchronize", "sg_stream",
     "sg_state_view_get", "sg_read_metrics", "sg_read_record", "sg_copy_to_host", "sg_last_kernel_ms",
-    "sg_last_launch_stats", "sg_last_launch_gross_ms", "sg_schedule_info", "sg_crowd_walk_stats", "sg_debug_trig32", "sg_set_tuning", "sg_set_slicing", "sg_set_external_poses", "sg_future_collision", "sg_raster_entities",
+    "sg_last_launch_stats", "sg_last_launch_gross_ms", "sg_schedule_info", "sg_debug_trig32", "sg_set_tuning", "sg_set_slicing", "sg_set_external_poses", "sg_future_collision", "sg_raster_entities",
     "sg_set_road_networks", "sg_raster_map", "sg_raster_map_device", "sg_reset_scenarios", "sg_terminal_flags", "sg_tick", "sg_set_collision_tolerance", "sg_read_collision_points", "sg_rss_update", "sg_rss_read", "sg_set_rss",
     "sg_group_create", "sg_group_destroy", "sg_group_size", "sg_group_handle", "sg_group_upload", "sg_group_rollout",
     "sg_group_read_metrics", "sg_group_last_error", "sg_host_alloc", "sg_host_free",
@@ -161,7 +161,6 @@ def load():
     lib.sg_last_launch_stats.argtypes = [H, C.POINTER(C.c_int32), C.POINTER(C.c_float)]
     lib.sg_last_launch_gross_ms.argtypes = [H, C.POINTER(C.c_float)]
     lib.sg_schedule_info.argtypes = [H, C.POINTER(C.c_int32)]
-    lib.sg_crowd_walk_stats.argtypes = [H, C.POINTER(C.c_int32), C.c_int32]
     lib.sg_set_tuning.argtypes = [H, C.c_int32, C.c_int32, C.c_int32]
     lib.sg_set_slicing.argtypes = [H, C.c_int32]
     lib.sg_host_alloc.argtypes = [C.c_int32, C.c_uint64, C.POINTER(C.c_void_p)]

@@ -7,7 +7,7 @@ void rollout_crowd(int WV, bool riders, dim3 grid, hipStream_t s, const RolloutA
 {
 #define CALL(WV_)                                                                                                                    \
     if (riders) sg::rollout_kernel_crowd_riders<WV_><<<grid, dim3(64 * WV_), 0, s>>>(SGL_ARGS(a));                                   \
-    else sg::rollout_kernel_crowd<WV_><<<grid, dim3(64 * WV_), 0, s>>>(SGL_ARGS(a), a.sel)
+    else sg::rollout_kernel_crowd<WV_><<<grid, dim3(64 * WV_), 0, s>>>(SGL_ARGS(a))
     if (WV == 4) { CALL(4); }
     else if (WV == 2) { CALL(2); }
     else { CALL(1); }

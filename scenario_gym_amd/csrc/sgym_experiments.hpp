@@ -1,4 +1,4 @@
-// sgym_experiments.hpp -- instrumentation of experiment builds (tools/ab_build.sh <name> -DSG_PHASE_TIMERS / -DSG_WALK_TIMERS /
+// sgym_experiments.hpp -- instrumentation of experiment builds (tools/ab_build.sh <name> -DSG_PHASE_TIMERS /
 // -DSG_RSS_STATS): cycle counters per phase of a step, statistics of the RSS line-test queue.  None of it changes a result;
 // in the product build every macro below is empty and every struct has no members.  (The timing ABLATIONS -- builds that
 // leave a phase out and produce wrong results on purpose -- are not in the sources at all: tools/experiments/ablations.patch.)
@@ -26,15 +26,6 @@ static __device__ unsigned long long sg_rss_stats[8]; // experiment builds: flus
 #define RSS_STAT(i, v) do { if ((threadIdx.x & 63) == 0) atomicAdd(&sg_rss_stats[i], (unsigned long long)(v)); } while (0)
 #else
 #define RSS_STAT(i, v) ((void)0)
-#endif
-
-// experiment builds (-DSG_WALK_TIMERS): cycles per phase of the walker step, summed over wavefronts into wa.stats64[16]
-#ifdef SG_WALK_TIMERS
-struct WalkTimers { unsigned long long acc[16], last; };
-#define WT(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); wt.acc[i] += now_ - wt.last; wt.last = now_; } while (0)
-#else
-struct WalkTimers {};
-#define WT(i) ((void)0)
 #endif
 
 } // namespace sg

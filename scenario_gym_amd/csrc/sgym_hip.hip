@@ -89,11 +89,6 @@ struct sg_handle {
     double *d_ext = nullptr;  // [NE][6]
     int max_ctl_per_block = 0; // controlled lanes in the fullest 64-slot block
     hipStream_t ctl_stream = nullptr;
-    // chunked crowd rollouts (launch_crowd_chunks, sgym_walk.hpp): per-scenario scratch, allocated on first use
-    std::vector<void *> walk_allocs;
-    sg::WalkArgs walk{};
-    int walk_R = 0;
-    int last_walk_chunks = 0;                    // chunks of the last call that went through the walker dispatch
     bool wide = false;                           // more than 512 entities per scenario: the multi-kernel step (sgym_wide.hpp)
     std::vector<void *> wide_allocs;
     sg::WideArgs wide_args{};
@@ -409,7 +404,6 @@ extern "C" int sg_destroy(sg_handle *h)
     free_pool(h->state_allocs);
     free_pool(h->road_allocs);
     free_pool(h->slice_allocs);
-    free_pool(h->walk_allocs);
     free_pool(h->wide_allocs);
     if (h->pin_sd) (void)hipHostFree(h->pin_sd);
     if (h->pin_ev) (void)hipHostFree(h->pin_ev);
@@ -624,82 +618,6 @@ static int launch_wide(sg_handle *h, int n_steps, int do_reset, int force, const
         }
     }
     HIP_TRY(h, hipGetLastError());
-    return SG_OK;
-}
-
-// A long rollout of an all-pedestrian batch of 129..256 entities (BASELINE config 5) in chunks of steps: every chunk sorts
-// its scenarios into classes (walk_classify_kernel) -- few enough entities still working: the walker variant (walk_kernel<1 /
-// 2>, sgym_walk.hpp: one lane per ACTIVE entity, the arrived pedestrians are LDS rows), else rollout_kernel_crowd -- and runs
-// the three kernels side by side; a walker workgroup that meets a case it does not handle stops before that step, and a
-// last launch of rollout_kernel_crowd finishes the chunk for it.  Bit-identical to one launch of rollout_kernel_crowd
-// (SG_CROWD_WALK=0, the default).  SG_CROWD_CHUNK: steps per chunk (default 200); SG_CROWD_WALK: bit 0 walk_kernel<1>, bit 1 <2>.
-static int launch_crowd_chunks(sg_handle *h, int n_steps, int do_reset, int force, int enable_mask, size_t *ev_next)
-{
-    const int R = h->R;
-    int rc = SG_OK;
-    if (h->walk_R != R) {
-        HIP_TRY(h, hipStreamSynchronize(h->stream));
-        free_pool(h->walk_allocs);
-        h->walk = sg::WalkArgs{};
-        h->walk_R = 0;
-        auto &A = h->walk_allocs;
-        if ((rc = dev_alloc(h, A, &h->walk.cls, (size_t)R)) || (rc = dev_alloc(h, A, &h->walk.target, (size_t)R)) ||
-            (rc = dev_alloc(h, A, &h->walk.n_active, (size_t)R)) || (rc = dev_alloc(h, A, &h->walk.ent, (size_t)R * 128)) ||
-            (rc = dev_alloc(h, A, &h->walk.smask, (size_t)R * 4)) ||
-            (rc = dev_alloc(h, A, &h->walk.base, (size_t)R * sg::WALK_SLOTS * 4, false)) || (rc = dev_alloc(h, A, &h->walk.stats, 8)) ||
-            (rc = dev_alloc(h, A, &h->walk.stats64, 16)))
-            return rc;
-        h->walk_R = R;
-    }
-    if (do_reset && (rc = launch_main(h, 0, do_reset, 0, nullptr, nullptr, false, ev_next, nullptr))) return rc;
-    const int chunk = std::max(1, env_int("SG_CROWD_CHUNK", 200));
-    const dim3 grid((unsigned)R);
-    hipStream_t s1 = h->ctl_stream, s2 = h->ctl_stream;
-    if (!h->overlap) s1 = s2 = h->stream;
-    h->last_walk_chunks = 0;
-    for (int k0 = 0; k0 < n_steps; k0 += chunk) {
-        const int len = std::min(chunk, n_steps - k0);
-        hipEvent_t e0 = nullptr, e1 = nullptr, ec = nullptr, ew1 = nullptr, ew2 = nullptr;
-        if (h->timing_now) {
-            if ((rc = get_event(h, *ev_next, &e0)) || (rc = get_event(h, *ev_next + 1, &e1))) return rc;
-            HIP_TRY(h, hipEventRecord(e0, h->stream));
-        }
-        // (class 1 -- at most 64 active entities -- runs walk_kernel<1> [bit 0] or the four-wavefront walk4_kernel [bit 2])
-        sgl::walk_classify(grid, h->stream, h->p, h->walk, len, (enable_mask & 2) | ((enable_mask & 5) ? 1 : 0),
-                           std::min(64, std::max(1, env_int("SG_WALK1_MAX", 64))));
-        HIP_TRY(h, hipGetLastError());
-        if (s1 != h->stream) {
-            if ((rc = get_event(h, *ev_next + 2, &ec)) || (rc = get_event(h, *ev_next + 3, &ew1)) || (rc = get_event(h, *ev_next + 4, &ew2))) return rc;
-            HIP_TRY(h, hipEventRecord(ec, h->stream));
-            HIP_TRY(h, hipStreamWaitEvent(s1, ec, 0));
-            if (s2 != s1) HIP_TRY(h, hipStreamWaitEvent(s2, ec, 0));
-        }
-        sgl::RolloutArgs a{&h->p, h->cfg.timestep, len, 0, force, nullptr, nullptr};
-        a.sel = sg::WalkSel{h->walk.cls, h->walk.target, 0};
-        sgl::rollout_crowd(h->WV, false, grid, h->stream, a);                                   // class 0: every entity a lane
-        if (enable_mask & 4) sgl::walk_rollout(4, grid, s1, h->p, h->cfg.timestep, len, force, h->walk);      // class 1: <= 64 active, four wavefronts
-        else if (enable_mask & 1) sgl::walk_rollout(1, grid, s1, h->p, h->cfg.timestep, len, force, h->walk); // class 1: <= 64 active
-        if (enable_mask & 2) sgl::walk_rollout(2, grid, s2, h->p, h->cfg.timestep, len, force, h->walk); // class 2: <= 128 active
-        HIP_TRY(h, hipGetLastError());
-        if (s1 != h->stream) {
-            HIP_TRY(h, hipEventRecord(ew1, s1));
-            HIP_TRY(h, hipStreamWaitEvent(h->stream, ew1, 0));
-            if (s2 != s1) {
-                HIP_TRY(h, hipEventRecord(ew2, s2));
-                HIP_TRY(h, hipStreamWaitEvent(h->stream, ew2, 0));
-            }
-        }
-        a.sel.want = -1; // whoever stopped short of the chunk's end (a walker workgroup that bailed): the full kernel finishes it
-        sgl::rollout_crowd(h->WV, false, grid, h->stream, a);
-        HIP_TRY(h, hipGetLastError());
-        if (h->timing_now) {
-            HIP_TRY(h, hipEventRecord(e1, h->stream));
-            h->launch_ev.push_back((int)*ev_next);
-            ++h->n_launches;
-        }
-        *ev_next += 5;
-        ++h->last_walk_chunks;
-    }
     return SG_OK;
 }
 
@@ -993,11 +911,6 @@ static int launch_rollout_impl(sg_handle *h, int n_steps, int do_reset, int forc
         for (int k0 = 0; k0 < n_steps && !rc; k0 += h->rssq_steps)
             rc = launch_main(h, std::min(h->rssq_steps, n_steps - k0), k0 == 0 ? do_reset : 0, force,
                              d_actions ? d_actions + (size_t)k0 * h->R * 2 : nullptr, nullptr, false, &ev_next);
-    } else if (!use_tab && h->has_ped && h->all_ped && h->G == 64 && h->WV == 4 && !h->has_road && crowd_allowed(h) && !h->rss_fused &&
-               h->p.rec_cap == 0 && !d_actions && n_steps >= env_int("SG_CROWD_WALK_MIN", 64) && (env_int("SG_CROWD_WALK", 0) & 7) != 0) {
-        // (OFF by default: on 1024 scenarios the walker kernels are one wavefront per SIMD and, measured, no faster than
-        // rollout_kernel_crowd -- HISTORY.md, round 4; SG_CROWD_WALK=3 switches the dispatch on, the parity tests do)
-        rc = launch_crowd_chunks(h, n_steps, do_reset, force, env_int("SG_CROWD_WALK", 0) & 7, &ev_next);
     } else if (!use_tab) {
         rc = launch_main(h, n_steps, do_reset, force, d_actions, nullptr, false, &ev_next);
     } else {
@@ -2298,33 +2211,6 @@ extern "C" int sg_last_launch_stats(sg_handle *h, int32_t *n_launches, float *ke
     if (hi >= lo) total += hi - lo;
     *n_launches = h->n_launches;
     *kernel_ms_total = total;
-    return SG_OK;
-}
-
-extern "C" int sg_crowd_walk_stats(sg_handle *h, int32_t *out, int32_t reset)
-{
-    if (!h || !out) return SG_ERR_INVALID;
-    for (int i = 0; i < 8; ++i) out[i] = 0;
-    if (!h->walk.stats) return SG_OK;
-    HIP_TRY(h, hipSetDevice(h->cfg.device));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    HIP_TRY(h, hipMemcpy(out, h->walk.stats, 8 * sizeof(int32_t), hipMemcpyDeviceToHost));
-    out[7] = h->last_walk_chunks;
-#ifdef SG_WALK_TIMERS
-    {
-        unsigned long long c[16], tot = 0;
-        (void)hipMemcpy(c, h->walk.stats64, sizeof c, hipMemcpyDeviceToHost);
-        for (int i = 0; i < 16; ++i) tot += c[i];
-        fprintf(stderr, "walker phase cycles:");
-        for (int i = 0; i < 16; ++i) if (c[i]) fprintf(stderr, " [%d] %.1f%%", i, 100.0 * c[i] / tot);
-        fprintf(stderr, "  raw [1] %.4e [7] %.4e [14] %.4e", (double)c[1], (double)c[7], (double)c[14]);
-        fprintf(stderr, "  total %.3e\n", (double)tot);
-        fprintf(stderr, "walk4 raw cycles, wavefront 0: A %.3e wait %.3e B %.3e B2w %.3e C %.3e D %.3e E %.3e | wavefront 1: A %.3e wait %.3e B %.3e B2w %.3e C %.3e D %.3e E %.3e | scenario-steps %.3e\n",
-                (double)c[0], (double)c[1], (double)c[2], (double)c[3], (double)c[4], (double)c[5], (double)c[6], (double)c[8], (double)c[9], (double)c[10],
-                (double)c[11], (double)c[12], (double)c[13], (double)c[14], (double)c[7]);
-    }
-#endif
-    if (reset) HIP_TRY(h, hipMemset(h->walk.stats, 0, 8 * sizeof(int32_t)));
     return SG_OK;
 }
 

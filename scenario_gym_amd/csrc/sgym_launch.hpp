@@ -7,7 +7,6 @@
 // scenario (the plain variant also 8).
 #pragma once
 #include "sgym_device.hpp"
-#include "sgym_walk.hpp"
 #include "sgym_wide.hpp"
 #include "sgym_queue.hpp"
 
@@ -20,7 +19,6 @@ struct RolloutArgs {
     int n_steps, do_reset, force;
     const double *actions; // [n][R][2] or nullptr
     const double *tab;     // controller table planes or nullptr
-    sg::WalkSel sel{nullptr, nullptr, 0}; // rollout_kernel_crowd only: the scenarios of a chunked rollout this launch serves
 };
 
 // k_plain.hip: rollout_kernel<G, WV, false, tab>  (WV == 8: rollout_kernel<64, 8, false, false>)
@@ -30,10 +28,6 @@ void rollout_ped(int G, int WV, bool rss, dim3 grid, hipStream_t s, const Rollou
 void rollout_ped_rss(int G, int WV, dim3 grid, hipStream_t s, const RolloutArgs &a); // (k_ped_rss.hip, through rollout_ped)
 // k_crowd.hip: rollout_kernel_crowd<WV> / rollout_kernel_crowd_riders<WV>
 void rollout_crowd(int WV, bool riders, dim3 grid, hipStream_t s, const RolloutArgs &a);
-// k_walk.hip (sgym_walk.hpp): the chunk classifier and the walker variant of the crowd rollout (WVL = 1, 2 wavefronts of
-// active lanes per scenario)
-void walk_classify(dim3 grid, hipStream_t s, const sg::Params &p, const sg::WalkArgs &wa, int chunk_len, int enable_mask, int walk1_max);
-void walk_rollout(int WVL, dim3 grid, hipStream_t s, const sg::Params &p, double timestep, int n_steps, int force, const sg::WalkArgs &wa);
 // k_wide.hip (sgym_wide.hpp): one step (mode 0) or State.reset (mode 1 / 2) of scenarios of more than 512 entities, four kernels
 void wide_step(dim3 grid_entities, dim3 grid_scenarios, hipStream_t s, const sg::Params &p, double timestep, const sg::WideArgs &wa,
                bool no_peds /* move + commit as one launch */);

@@ -73,14 +73,6 @@ struct SliceArgs {
                          // slices group by group, each group as soon as the controller pre-pass has reached its last step
 };
 
-// Chunked crowd rollouts (launch_crowd_chunks in sgym_hip.hip, sgym_walk.hpp): which scenarios a launch of the crowd kernel
-// works on and where they stop.  cls == nullptr: every scenario, n_steps steps.
-struct WalkSel {
-    const int8_t *cls;     // [R] class of the scenario in this chunk (0 = this kernel, 1 / 2 = walk_kernel<1 / 2>)
-    const int32_t *target; // [R] steps-since-reset at which the chunk ends
-    int want;              // the class this launch serves; -1: every scenario that has not reached its target (and may run)
-};
-
 // CROWD (PED only): every entity of the batch is a pedestrian agent (or padding), default head rotation, no road network:
 // no knot segment, no vehicle / replay code, crowd_pairs for the neighbour sums (rollout_kernel_crowd, BASELINE config 5).
 // SLICE (TAB, one wavefront per tile): one slice of a time-sliced replay, see SliceArgs.  With HAST the controlled lanes
@@ -93,8 +85,7 @@ __device__ __forceinline__ void rollout_body_l(
     TileLds<64 * WV, PED, CROWD> &lds /* the workgroup's LDS tile: the entry point owns it (rollout_kernel_tabq shares it between roles) */,
     const Params &p, double timestep, int n_steps, int do_reset, int force, const double *actions /*[n][R][2]*/,
     const double *tab /*controller table planes*/, const SliceArgs &sa = SliceArgs{},
-    const unsigned bx_arg = ~0u /* the 64-slot block (WV == 1) / scenario of this workgroup when it is not bx: TabGroups */,
-    const WalkSel &sel = WalkSel{nullptr, nullptr, 0})
+    const unsigned bx_arg = ~0u /* the 64-slot block (WV == 1) / scenario of this workgroup when it is not bx: TabGroups */)
 {
     const unsigned bx = bx_arg == ~0u ? blockIdx.x : bx_arg;
     static_assert(!SLICE || (TAB && WV == 1 && !PED && !ROAD && !RSSV), "slices: the table variant, one wavefront per tile");
@@ -129,13 +120,6 @@ __device__ __forceinline__ void rollout_body_l(
     const uint32_t r = in_range ? r_raw : p.R - 1;
     const ScenStatic &ss = p.sstat[r];
     sg_scenario_state &sd = p.sdyn[r];
-    int step_target = 0x7fffffff;
-    if (CROWD && !RIDERS && WV > 1 && sel.cls) { // (one scenario per workgroup: uniform)
-        const int tg = sel.target[r];
-        const bool mine = sel.want >= 0 ? sel.cls[r] == sel.want : (sd.n_steps < tg && (force || !sd.done));
-        if (!mine) return;
-        step_target = tg;
-    }
     const int64_t meta = fld<int64_t>(st, ST_META);
     const int kind = (in_range && slot < p.E) ? (int)(meta & 0xff) : SG_KIND_NONE;
     const bool is_ped_type = ((meta >> 8) & 0xff) == 1;
@@ -588,8 +572,7 @@ __device__ __forceinline__ void rollout_body_l(
         // SLICE: round 0 is the warm-up step (state a - 1 -> a, nothing recorded); a lane that starts from the reset state
         // itself (a == 0) sits it out
         const bool warm = SLICE && k == 0;
-        const bool run_lane = in_range && (force || !done) && !(SLICE && k == 0 && slice_a == 0) &&
-                              (!(CROWD && !RIDERS && WV > 1) || steps < step_target);
+        const bool run_lane = in_range && (force || !done) && !(SLICE && k == 0 && slice_a == 0);
         PH(5);
         // (a workgroup of several wavefronts carries ONE scenario: `run` is already uniform, nothing to vote)
         const bool any_run_ = WV == 1 ? sg_any(run_lane || (SLICE && k == 0 && in_range && !done)) : run_lane;
@@ -1145,11 +1128,11 @@ template <int G, int WV, bool PED, bool TAB, bool HAST, bool ROAD = false, bool 
           bool PLANAR = false, bool RIDERS = false, bool CTAB = false>
 __device__ __forceinline__ void rollout_body(
     const Params &p, double timestep, int n_steps, int do_reset, int force, const double *actions, const double *tab,
-    const SliceArgs &sa = SliceArgs{}, const unsigned bx_arg = ~0u, const WalkSel &sel = WalkSel{nullptr, nullptr, 0})
+    const SliceArgs &sa = SliceArgs{}, const unsigned bx_arg = ~0u)
 {
     __shared__ TileLds<64 * WV, PED, CROWD> lds;
     rollout_body_l<G, WV, PED, TAB, HAST, ROAD, RSSV, CROWD, SLICE, PLANAR, RIDERS, CTAB>(lds, p, timestep, n_steps, do_reset, force, actions, tab,
-                                                                                       sa, bx_arg, sel);
+                                                                                       sa, bx_arg);
 }
 
 // The blocks a launch of a table variant works on (launch_rollout): the 64-slot blocks of the batch are cut into groups of
@@ -1187,9 +1170,9 @@ __global__ __launch_bounds__(64 * WV, PED ? SG_WAVES_PER_SIMD_PED : (TAB ? SG_WA
 // All-pedestrian batches without road networks (BASELINE config 5): see rollout_body, CROWD
 template <int WV>
 __global__ __launch_bounds__(64 * WV, SG_WAVES_PER_SIMD_PED) void rollout_kernel_crowd(
-    Params p, double timestep, int n_steps, int do_reset, int force, const double *actions, const double *tab, WalkSel sel)
+    Params p, double timestep, int n_steps, int do_reset, int force, const double *actions, const double *tab)
 {
-    rollout_body<64, WV, true, false, false, false, false, true>(p, timestep, n_steps, do_reset, force, actions, tab, SliceArgs{}, ~0u, sel);
+    rollout_body<64, WV, true, false, false, false, false, true>(p, timestep, n_steps, do_reset, force, actions, tab);
 }
 
 // ... with riders: lanes of other kinds whose poses come from the pre-pass table (see rollout_body, RIDERS)

@@ -408,12 +408,6 @@ class RolloutEngine:
         self._check(self.lib.sg_schedule_info(self.h, v), "sg_schedule_info")
         return dict(schedule=v[0], chunks=v[1], ring=v[2], grid=v[3], ctl_waves=v[4], blocks=v[5], simds=v[6], launches=v[7])
 
-    def crowd_walk_stats(self, reset=False):
-        """Chunked crowd rollouts (sg_crowd_walk_stats): scenario-chunks per kernel class, early stops, chunks of the last call."""
-        v = (C.c_int32 * 8)()
-        self._check(self.lib.sg_crowd_walk_stats(self.h, v, int(bool(reset))), "sg_crowd_walk_stats")
-        return dict(full=v[0], walk1=v[1], walk2=v[2], bails=v[4], chunks_last_call=v[7])
-
     def debug_trig32(self, heading):
         """The broad phase's fp32 (sin, cos) of fp64 headings (test hook)."""
         h = np.ascontiguousarray(heading, np.float64).ravel()

@@ -32,5 +32,4 @@ SG_PLANAR=0 python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out
 SG_QUEUE=0 python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/${tag}_chunk_launches_bench.json 2>/dev/null
 python3 tools/dbg/queue_timeline.py > gpurun_out/${tag}_queue_timeline.txt 2>&1
 python3 tools/dbg/wide_time.py > gpurun_out/${tag}_wide_time.txt 2>&1
-SG_CROWD_WALK=4 python3 bench.py --workload c5 --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/${tag}_c5_walk4_bench.json 2>/dev/null
 tail -3 gpurun_out/${tag}_upload_time.txt gpurun_out/${tag}_rss_time.txt
