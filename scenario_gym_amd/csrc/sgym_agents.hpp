@@ -250,36 +250,35 @@ __device__ __forceinline__ void sg_noise_pair(unsigned long long seed, uint32_t 
     z1 = r * sn;
 }
 
-__device__ __forceinline__ double sg_atan_pos(double ax)
+__device__ __forceinline__ double sg_atan_pos(double ax, ConstTbl K)
 {
-    const double A0 = 3.33333333333329318027e-01, A1 = -1.99999999998764832476e-01,
-                 A2 = 1.42857142725034663711e-01, A3 = -1.11111104054623557880e-01,
-                 A4 = 9.09088713343650656196e-02, A5 = -7.69187620504482999495e-02,
-                 A6 = 6.66107313738753120669e-02, A7 = -5.83357013379057348645e-02,
-                 A8 = 4.97687799461593236017e-02, A9 = -3.65315727442169155270e-02,
-                 A10 = 1.62858201153657823623e-02;
-    if (ax >= 7.378697629483821e19) return 1.57079632679489655800e+00 + 6.12323399573676603587e-17;
-    int id;
-    double x, hi, lo;
-    if (ax < 0.4375) { id = -1; x = ax; hi = 0.0; lo = 0.0; }
-    else if (ax < 0.6875) { id = 0; x = (2.0 * ax - 1.0) / (2.0 + ax); hi = 4.63647609000806093515e-01; lo = 2.26987774529616870924e-17; }
-    else if (ax < 1.1875) { id = 1; x = (ax - 1.0) / (ax + 1.0); hi = 7.85398163397448278999e-01; lo = 3.06161699786838301793e-17; }
-    else if (ax < 2.4375) { id = 2; x = (ax - 1.5) / (1.0 + 1.5 * ax); hi = 9.82793723247329054082e-01; lo = 1.39033110312309984516e-17; }
-    else { id = 3; x = -1.0 / ax; hi = 1.57079632679489655800e+00; lo = 6.12323399573676603587e-17; }
+    // (the eleven coefficients come from the constant table through scalar loads: as literals they were 22 VGPRs that the
+    // pedestrian kernels, whose registers are full, spilled and reloaded on every step)
+    ConstTbl A = K + 32;
+    const double A0 = A[0], A1 = A[1], A2 = A[2], A3 = A[3], A4 = A[4], A5 = A[5], A6 = A[6], A7 = A[7], A8 = A[8], A9 = A[9], A10 = A[10];
+    // fdlibm's five argument ranges as selects around ONE division (ax / 1.0 == ax in the first range): the lanes of a crowd
+    // sit in all of them, and as branches the wavefront ran the four divisions one after the other
+    const bool r0 = ax < 0.4375, r1 = ax < 0.6875, r2 = ax < 1.1875, r3 = ax < 2.4375;
+    const double num = r0 ? ax : (r1 ? 2.0 * ax - 1.0 : (r2 ? ax - 1.0 : (r3 ? ax - 1.5 : -1.0)));
+    const double den = r0 ? 1.0 : (r1 ? 2.0 + ax : (r2 ? ax + 1.0 : (r3 ? 1.0 + 1.5 * ax : ax)));
+    const double hi = r0 ? 0.0 : (r1 ? 4.63647609000806093515e-01 : (r2 ? 7.85398163397448278999e-01 : (r3 ? 9.82793723247329054082e-01 : 1.57079632679489655800e+00)));
+    const double lo = r0 ? 0.0 : (r1 ? 2.26987774529616870924e-17 : (r2 ? 3.06161699786838301793e-17 : (r3 ? 1.39033110312309984516e-17 : 6.12323399573676603587e-17)));
+    const double x = num / den;
     double z = x * x, w = z * z;
     double s1 = z * (A0 + w * (A2 + w * (A4 + w * (A6 + w * (A8 + w * A10)))));
     double s2 = w * (A1 + w * (A3 + w * (A5 + w * (A7 + w * A9))));
-    if (id < 0) return x - x * (s1 + s2);
-    return hi - ((x * (s1 + s2) - lo) - x);
+    const double xs = x * (s1 + s2);
+    const double res = r0 ? x - xs : hi - ((xs - lo) - x);
+    return ax >= 7.378697629483821e19 ? 1.57079632679489655800e+00 + 6.12323399573676603587e-17 : res;
 }
 
-__device__ __forceinline__ double sg_atan2(double y, double x)
+__device__ __forceinline__ double sg_atan2(double y, double x, ConstTbl K = (ConstTbl)SG_TRIG)
 {
     const double PI = 3.1415926535897931160E+00, PI_LO = 1.2246467991473531772E-16;
     if (x != x || y != y) return x + y;
     if (y == 0.0) return (x < 0.0 || (x == 0.0 && __builtin_signbit(x))) ? __builtin_copysign(PI, y) : y;
     if (x == 0.0) return __builtin_copysign(0.5 * PI, y);
-    double z = sg_atan_pos(__builtin_fabs(y / x));
+    double z = sg_atan_pos(__builtin_fabs(y / x), K);
     if (x > 0.0) return y > 0.0 ? z : -z;
     z = PI - (z - PI_LO);
     return y > 0.0 ? z : -z;

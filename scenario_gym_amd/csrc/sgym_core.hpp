@@ -166,7 +166,7 @@ __device__ __noinline__ double2 sg_sincos_slow(double x)
 // The 16 fp64 coefficients live in constant memory and are fetched with scalar loads at the point of
 // use (the table pointer is made opaque once per time step), so they occupy SGPRs for a few dozen
 // instructions instead of 32 VGPRs for the whole kernel.
-static __constant__ double SG_TRIG[32] = {
+static __constant__ double SG_TRIG[48] = {
     6.36619772367581382433e-01,  // 0 2/pi
     1.57079632673412561417e+00,  // 1 pi/2 head (33 bits)
     6.07710050630396597660e-11,  // 2 pi/2 next 33 bits
@@ -181,6 +181,10 @@ static __constant__ double SG_TRIG[32] = {
     1.45620945432529025516e-03, 5.88041240820264096874e-04, 2.46463134818469906812e-04,
     7.81794442939557092300e-05, 7.14072491382608190305e-05, -1.85586374855275456654e-05,
     2.59073051863633712884e-05, 0.0, 0.0, 0.0,
+    // 32-42: atan polynomial A0..A10 (sg_atan_pos)
+    3.33333333333329318027e-01, -1.99999999998764832476e-01, 1.42857142725034663711e-01, -1.11111104054623557880e-01,
+    9.09088713343650656196e-02, -7.69187620504482999495e-02, 6.66107313738753120669e-02, -5.83357013379057348645e-02,
+    4.97687799461593236017e-02, -3.65315727442169155270e-02, 1.62858201153657823623e-02, 0.0, 0.0, 0.0, 0.0, 0.0,
 };
 
 typedef const __attribute__((address_space(4))) double *ConstTbl; // constant address space: scalar loads
@@ -522,6 +526,11 @@ struct TileLds {
     double sx[CROWD ? NS : 1], sy[CROWD ? NS : 1], ss[CROWD ? NS : 1];
     double r2hi[CROWD ? NS : 1], r2lo[CROWD ? NS : 1];
     uint32_t nq[CROWD ? 8 : 1][CROWD ? NS : 1];
+    // (crowd variants: one scenario per workgroup) the ego lane's accumulators -- EgoAvgSpeed, EgoMaxSpeed, EgoAvgSpeed.t; CollisionMetric.last_timestep; the
+    // event count -- wait here between their two uses per step instead of in 15 registers of every lane
+    double ego_m[CROWD ? 3 : 1];
+    unsigned long long ego_last[CROWD ? (NS + 63) / 64 : 1];
+    int ego_nev[2];
 
     static constexpr int SLOTS = NS;
     static constexpr int SCRATCH_BYTES = NS * 40 + 64 * (NS > 64 ? NS : 2); // cx ... cor

@@ -20,6 +20,20 @@ __device__ __forceinline__ void tile_sync()
     }
 }
 
+// Inclusive prefix sum over the 64 lanes of a wavefront with six DPP adds (row_shr 1, 2, 4, 8 inside each row of 16 lanes, then
+// row_bcast 15 / 31 across the rows): no LDS round trips and no per-distance lane indices to keep in registers, which is what
+// a __shfl_up loop costs.  The wavefront's total is lane 63's value.
+__device__ __forceinline__ int wave_scan_incl(int x)
+{
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false); // row_shr:1 (lanes without a source add 0)
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false); // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false); // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false); // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false); // row_bcast:15 into rows 1 and 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false); // row_bcast:31 into rows 2 and 3
+    return x;
+}
+
 template <int WV>
 __device__ __forceinline__ bool block_any(bool x)
 {
@@ -469,19 +483,12 @@ __device__ __forceinline__ void crowd_pairs(const Params &p, LDS &L, const Crowd
         }
         n += __builtin_popcount(d);
     }
-    int total = n;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) total += __shfl_xor(total, o, 64);
+    const int total = __builtin_amdgcn_readlane(wave_scan_incl(n), 63);
     if (total == 0) return; // wave-uniform
     const int T = (total + 63) >> 6;
     const int excess = max(n - T, 0), spare = max(T - n, 0);
-    int scan = excess | (spare << 16); // both prefix sums at once (each < 2^15)
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        int u = __shfl_up(scan, o, 64);
-        if (lane >= o) scan += u;
-    }
-    const int listed_all = min(__shfl(scan, 63, 64) & 0xffff, CAP);
+    const int scan = wave_scan_incl(excess | (spare << 16)); // both prefix sums at once (each < 2^15)
+    const int listed_all = min(__builtin_amdgcn_readlane(scan, 63) & 0xffff, CAP);
     const int e0 = (scan & 0xffff) - excess;              // first list position of this lane's hand-over
     const int out = min(max(CAP - e0, 0), excess);        // pairs handed over (all of the excess unless the list is full)
     int h = min((scan >> 16) - spare, listed_all);        // listed pairs this lane evaluates: [h, h_end)
@@ -687,7 +694,7 @@ __device__ __forceinline__ void ped_move(const PedMoveModel &pm, bool go, double
     fxo = fyo = 0.0;
     if (RW && pm.behaviour == SG_PED_RANDOM_WALK) {
         if (go) {
-            const double loc_s = vdes + pm.bias_lon, loc_h = sg_atan2(fy, fx) + pm.bias_lat;
+            const double loc_s = vdes + pm.bias_lon, loc_h = sg_atan2(fy, fx, K) + pm.bias_lat;
             speed = nz.on ? loc_s + nz.s : loc_s;
             heading = nz.on ? loc_h + nz.h : loc_h;
         }
@@ -695,7 +702,7 @@ __device__ __forceinline__ void ped_move(const PedMoveModel &pm, bool go, double
         const double speed_rand = nz.on ? pm.bias_lon + nz.s : pm.bias_lon;
         const double heading_rand = nz.on ? pm.bias_lat + nz.h : pm.bias_lat;
         speed = __builtin_fmin(sg_norm2(fx, fy) + speed_rand, vdes * pm.max_speed_factor);
-        heading = sg_atan2(fy, fx) + heading_rand;
+        heading = sg_atan2(fy, fx, K) + heading_rand;
         fxo = fx;
         fyo = fy;
     }

@@ -363,6 +363,24 @@ __device__ __forceinline__ void rollout_body_l(
 #pragma unroll
         for (int w = 0; w < WV; ++w) row[w] = fld<uint64_t>(dy, SG_F_COLL + w);
     }
+    // (crowd variants -- one scenario, one ego per workgroup: the ego's accumulators live in LDS between their uses, see TileLds)
+    auto ego_park = [&]() {
+        if (CROWD && is_ego) {
+            lds.ego_m[0] = m_avg; lds.ego_m[1] = m_max; lds.ego_m[2] = m_t;
+#pragma unroll
+            for (int w = 0; w < WV; ++w) lds.ego_last[w] = last_row[w];
+            lds.ego_nev[0] = n_ev;
+        }
+    };
+    auto ego_fetch = [&]() {
+        if (CROWD && is_ego) {
+            m_avg = lds.ego_m[0]; m_max = lds.ego_m[1]; m_t = lds.ego_m[2];
+#pragma unroll
+            for (int w = 0; w < WV; ++w) last_row[w] = lds.ego_last[w];
+            n_ev = lds.ego_nev[0];
+        }
+    };
+    ego_park();
     // SLICE: the lane has to be in state `a` (after a steps) before its real steps.  a <= 1: the reset state just loaded
     // (a == 1: + the warm-up step); a >= 2: state a - 1 rebuilt from the clock -- time, and the presence of an agent lane
     // (it has its pose from the reset on, or spawns at step 1: scenario_gym.py:240-244); everything else about that state
@@ -903,11 +921,13 @@ __device__ __forceinline__ void rollout_body_l(
             }
             // ---- ego metrics, scenario_gym.py:251-252 ----
             if (!SLICE && is_ego && present && !tab_lane) { // a controlled ego's metrics come with its table (control_kernel)
+                if (CROWD) { m_avg = lds.ego_m[0]; m_max = lds.ego_m[1]; m_t = lds.ego_m[2]; }
                 double speed = sg_norm3(vel[0], vel[1], vel[2]);
                 double w = m_t / t; // EgoAvgSpeed._step, metrics/trajectory.py:19-24
                 m_avg += (1.0 - w) * (speed - m_avg);
                 m_t = t;
                 m_max = __builtin_fmax(speed, m_max); // EgoMaxSpeed, :41-44
+                if (CROWD) { lds.ego_m[0] = m_avg; lds.ego_m[1] = m_max; lds.ego_m[2] = m_t; }
             }
         }
         PH(1);
@@ -969,6 +989,11 @@ __device__ __forceinline__ void rollout_body_l(
         uint64_t ev_fresh0 = 0;   // (ego lane) the hazards of this step's new events, first row word
         int ev_base = -1;         // (ego lane) index of the first of them in the event list; -1: none / not representable
         if (run && is_ego && present) {
+            if (CROWD) {
+                n_ev = lds.ego_nev[0];
+#pragma unroll
+                for (int w = 0; w < WV; ++w) last_row[w] = lds.ego_last[w];
+            }
             if (!TAB) ev_base = n_ev;
 #pragma unroll
             for (int w = 0; w < WV; ++w) {
@@ -1031,7 +1056,9 @@ __device__ __forceinline__ void rollout_body_l(
                     }
                 }
                 last_row[w] = row[w];
+                if (CROWD) lds.ego_last[w] = row[w];
             }
+            if (CROWD) lds.ego_nev[0] = n_ev;
         }
         if (!TAB && WV == 1 && p.ev_cap > 0) {
             // A hazard that is itself a controlled agent (PID / vehicle controller) has no trajectory its pose at the event
@@ -1075,6 +1102,7 @@ __device__ __forceinline__ void rollout_body_l(
         }
         return;
     }
+    ego_fetch();
     if (RSSV && lane == 0) p.rssq_n[rss_wave] = min(rss_gn, p.rssq_cap);
     // ---- write back what lives in registers during the loop ----
     if (in_range) {
