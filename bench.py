@@ -475,7 +475,7 @@ def e2e_cpu_baseline(paths, dt, steps, cores):
                       f"its RSS callback driven step by step from Python + metrics, {dtm:.1f}s"}
 
 
-def main(argv=None, make_engine=None):
+def main(argv=None, make_engine=None, emit=True):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -489,10 +489,13 @@ def main(argv=None, make_engine=None):
                          "every step materialised), c5 = 1024x256 social-force crowd; c2s = the c2 batch through the "
                          "time-sliced replay path (final state + metrics + events only: a separate mode, never the headline); c3rss = the c3 "
                          "batch with the RSSDistances callback after every step")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="what `value` is: weak (default) = --scenarios per GPU; strong = --scenarios in total, split evenly "
-                         "over the ranks (BASELINE.json configs[3] read literally: 4096 replicas over 8 GPUs = 512 per GPU)."
-                         "  With N > 1 the other one is timed too and reported under its own key")
+    ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
+                    help="what `value` is: strong (the default with more than one rank) = --scenarios in TOTAL, split evenly over "
+                         "the ranks -- BASELINE.json's metric and configs[3] as written: 4096 scenarios x 64 entities at 1 / 2 / 4 / 8 "
+                         "GPUs = 512 per GPU at 8; weak = --scenarios per GPU.  With one rank the two are the same batch (reported "
+                         "as \"weak\": per-GPU work is what it is).  With N > 1 the other one is timed too and reported under its own key")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="c3 on one GPU: do not time the other single-GPU BASELINE configs (c2, c5) after the headline's timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify", type=int, default=None,
                     help="after the timed passes (outside the timed region) re-run this many scenarios spread over the batch "
@@ -535,6 +538,8 @@ def main(argv=None, make_engine=None):
         args.ego = "replay"
     crowd = args.workload in ("c5", "c5mix")
     rank, world, local_rank, dist = D.init()
+    if args.scaling is None:
+        args.scaling = "strong" if world > 1 else "weak"
     if args.gpus != world and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
     dt = 1.0 / 30.0
@@ -825,7 +830,24 @@ def main(argv=None, make_engine=None):
         line["engine"] = "scenario_gym_amd.RolloutEngine (libsgym_hip.so)" if live else (args.engine_factory or "injected stand-in (tests)")
         if live and not args.no_cpu_baseline:  # (rank 0 only, after the timed region; the other ranks wait at the teardown)
             line["cpu_baseline"] = cpu_baseline(dict(E=E, T=T, dt=dt, ego_kind=ego_kind, crowd=crowd, rss=bool(wl.get("rss"))))
-        print(json.dumps(line))
+        if (live and world == 1 and args.workload == "c3" and not args.no_configs and emit
+                and (R, E, T) == (WORKLOADS["c3"]["R"], WORKLOADS["c3"]["E"], 10000) and args.ego == "pid"):
+            # the driver times ONE line: the other single-GPU BASELINE configs ride in it, each measured
+            # the same way after the headline's timed region -- 3 timed passes, oracle-verified, its own roofline
+            line["configs"] = {}
+            for name in ("c2", "c5"):
+                sub = main(["--workload", name, "--steps", "3", "--warmup", "1", "--no-cpu-baseline"], emit=False)
+                rf = sub["roofline"]
+                line["configs"][name] = {
+                    "value": sub["value"], "unit": sub["unit"], "ms_per_step": sub["ms_per_step"], "steps": sub["steps"],
+                    "warmup": sub["warmup"], "workload": sub["config"]["workload"], "scenarios": sub["config"]["scenarios_per_gpu"],
+                    "entities": sub["config"]["entities"], "sim_steps": sub["config"]["sim_steps"],
+                    "roofline": {k: rf.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "kernel", "kernel_ms", "binding",
+                                                        "flops_per_entity_step", "frac_with_pair_search")},
+                    "verified": sub["verified"] and {k: sub["verified"][k] for k in ("equal", "scenarios", "steps")},
+                }
+        if emit:
+            print(json.dumps(line))
     if dist is not None and (live or args.engine_factory):
         dist.destroy_process_group()
     failed = [(n, r) for n, r in (("value", main_run), ("strong / weak", other_run[1] if other_run else None), ("strong_sliced", sliced_run))

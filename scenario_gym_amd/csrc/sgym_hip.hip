@@ -103,8 +103,14 @@ struct sg_handle {
     size_t qwords_cap = 0;
     double *d_qtab = nullptr;       // the table ring
     size_t qtab_bytes = 0;
-    unsigned *q_host = nullptr;     // page-locked copy of the queue state words of the last queue launch (give-up code, items done)
-    bool q_pending = false;         // ... which has not been looked at yet (check_queue)
+    // page-locked copies of the queue state words (give-up code, items done) of the persistent launches that have not been looked
+    // at yet (check_queue): a ring with one slot per launch, so that a second launch before the check cannot overwrite the
+    // first one's code.  A give-up is STICKY: every later call that runs or reads the batch fails with its message until
+    // sg_reset / sg_upload start the batch anew (the state is undefined in between).
+    unsigned *q_host = nullptr;
+    int q_head = 0, q_count = 0;    // next slot to use; launches not yet looked at
+    bool q_failed = false;
+    char q_msg[320] = {0};
     int queue_mode = 1;             // env SG_QUEUE=0: the chunk launches of rounds 1-4 instead
     int last_schedule = 0;          // 0: not the table path, 1: chunk launches, 2: the persistent queue launch
     int last_chunks = 0, last_ring = 0, last_grid = 0;
@@ -472,7 +478,8 @@ static void launch_variant(sg_handle *h, dim3 grid, int n_steps, int do_reset, i
     const sgl::RolloutArgs a{&h->p, h->cfg.timestep, n_steps, do_reset, force, d_actions, nullptr};
     const sgl::RolloutArgs at{&h->p, h->cfg.timestep, n_steps, 0, force, nullptr, d_tab}; // table variants never reset
     if (WV == 8 && !h->has_ped && (h->cfg.terminal_mask & SG_TERM_EGO_OFF_ROAD)) { // 257..512 entities, ego_off_road
-        // (RSSDistances + ego_off_road in one wide rollout: no fused variant at that width, sg_set_rss refuses it)
+        // (RSSDistances + ego_off_road in one wide rollout: no fused variant at that width -- launch_rollout_impl and sg_tick clear
+        // rss_fused for it and run the callback as a launch of its own behind every step: unfused_rss)
         sgl::rollout_road(64, 8, grid, s, a);
         return;
     }
@@ -621,6 +628,30 @@ static int launch_wide(sg_handle *h, int n_steps, int do_reset, int force, const
     return SG_OK;
 }
 
+enum { Q_HOST_RING = 16 };
+// after a synchronisation of h->stream: did every persistent launch since the last look run to its end?  (Sticky: see q_failed.)
+static int check_queue(sg_handle *h)
+{
+    for (; h->q_count > 0; --h->q_count) {
+        const unsigned *w = h->q_host + (size_t)((h->q_head - h->q_count + Q_HOST_RING) % Q_HOST_RING) * sg::Q_STATE_WORDS;
+        const unsigned code = w[sg::Q_ERR];
+        if (code == 0 || h->q_failed) continue; // (the first give-up is the one reported)
+        static const char *what[] = {"", "a rollout wavefront waited for the controller pre-pass", "a rollout wavefront waited for the previous chunk of its block",
+                                     "the controller pre-pass waited for a buffer of the table ring"};
+        h->q_failed = true;
+        snprintf(h->q_msg, sizeof h->q_msg, "sg_rollout: the persistent table launch gave up (%s longer than SG_QUEUE_TIMEOUT_MS; %u work items had finished): "
+                                            "the state of the batch is undefined -- sg_reset / sg_upload before the next call", what[code < 4 ? code : 0],
+                 w[sg::Q_ITEMS_DONE]);
+    }
+    return h->q_failed ? fail(h, SG_ERR_HIP, "%s", h->q_msg) : SG_OK;
+}
+// sg_reset / sg_upload start the batch anew: whatever a launch before them gave up on is history
+static void forget_queue_failure(sg_handle *h)
+{
+    h->q_count = 0;
+    h->q_failed = false;
+}
+
 // The table path as ONE launch (sgym_queue.hpp): the controller pre-pass and the rollout of every chunk of the time axis in one
 // grid of persistent wavefronts, work items (chunk, block) from a device-side counter.  `chunk` = the longest chunk.
 // Returns SG_OK, an error, or SG_QUEUE_FALLBACK: the table ring could not be allocated -- the caller takes the chunk launches.
@@ -711,7 +742,12 @@ static int launch_queue(sg_handle *h, int n_steps, int force, const double *d_ac
         HIP_TRY(h, hipMalloc((void **)&h->d_qwords, words * sizeof(unsigned)));
         h->qwords_cap = words;
     }
-    if (!h->q_host) HIP_TRY(h, hipHostMalloc((void **)&h->q_host, sg::Q_STATE_WORDS * sizeof(unsigned), hipHostMallocDefault));
+    if (!h->q_host) HIP_TRY(h, hipHostMalloc((void **)&h->q_host, (size_t)Q_HOST_RING * sg::Q_STATE_WORDS * sizeof(unsigned), hipHostMallocDefault));
+    if (h->q_count == Q_HOST_RING) { // every slot holds a launch nobody has looked at: look now
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        const int rcq = check_queue(h);
+        if (rcq) return rcq;
+    }
     HIP_TRY(h, hipMemsetAsync(h->d_qwords, 0, words * sizeof(unsigned), h->stream)); // every polled word, before every launch
     sg::TabQueue tq{};
     tq.state = h->d_qwords;
@@ -725,6 +761,7 @@ static int launch_queue(sg_handle *h, int n_steps, int force, const double *d_ac
     tq.buf_doubles = buf_bytes / sizeof(double);
     tq.actions = d_actions;
     tq.timeout_ticks = (long long)std::max(1, env_int("SG_QUEUE_TIMEOUT_MS", 20000)) * 100000ll; // 100 MHz
+    if (const int us = env_int("SG_QUEUE_TIMEOUT_US", 0)) tq.timeout_ticks = (long long)std::max(1, us) * 100ll; // (tests: a give-up on demand)
     tq.handoff = env_int("SG_QUEUE_HANDOFF", 1) != 0; // 0: a release fence per item instead (correct as well, 60 G on c3)
     tq.lag_prio = env_int("SG_QUEUE_LAGPRIO", 2);
     const char *times_path = getenv("SG_QUEUE_TIMES"); // experiment: per-item time stamps, dumped as u64 after the launch
@@ -765,8 +802,9 @@ static int launch_queue(sg_handle *h, int n_steps, int force, const double *d_ac
     else sgl::rollout_tabq(h->G, h->planar, dim3(grid), h->stream, h->p, h->cfg.timestep, force, tq);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipEventRecord(e1, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(h->q_host, h->d_qwords, sg::Q_STATE_WORDS * sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
-    h->q_pending = true;
+    HIP_TRY(h, hipMemcpyAsync(h->q_host + (size_t)h->q_head * sg::Q_STATE_WORDS, h->d_qwords, sg::Q_STATE_WORDS * sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
+    h->q_head = (h->q_head + 1) % Q_HOST_RING;
+    ++h->q_count;
     if (tq.times) {
         std::vector<unsigned long long> ht(n_times + 4);
         HIP_TRY(h, hipMemcpyAsync(ht.data() + 4, d_times, n_times * 8, hipMemcpyDeviceToHost, h->stream));
@@ -804,19 +842,6 @@ static int launch_queue(sg_handle *h, int n_steps, int force, const double *d_ac
     return SG_OK;
 }
 
-// after a synchronisation of h->stream: did the last queue launch run to its end?
-static int check_queue(sg_handle *h)
-{
-    if (!h->q_pending) return SG_OK;
-    h->q_pending = false;
-    const unsigned code = h->q_host[sg::Q_ERR];
-    if (code == 0) return SG_OK;
-    static const char *what[] = {"", "a rollout wavefront waited for the controller pre-pass", "a rollout wavefront waited for the previous chunk of its block",
-                                 "the controller pre-pass waited for a buffer of the table ring"};
-    return fail(h, SG_ERR_HIP, "sg_rollout: the persistent table launch gave up (%s longer than SG_QUEUE_TIMEOUT_MS; %u work items had finished): "
-                               "the state of the batch is undefined -- sg_reset / sg_upload before the next call", what[code < 4 ? code : 0],
-                h->q_host[sg::Q_ITEMS_DONE]);
-}
 
 static int launch_rollout_impl(sg_handle *h, int n_steps, int do_reset, int force, const double *d_actions);
 // Work of a failed call may still be running on the controller stream and the pipeline streams (the fan-out of the table
@@ -844,6 +869,8 @@ static bool needs_unfused_extras(const sg_handle *h) { return unfused_off_road(h
 
 static int launch_rollout_impl(sg_handle *h, int n_steps, int do_reset, int force, const double *d_actions)
 {
+    if (h->q_failed && do_reset != 1) return fail(h, SG_ERR_HIP, "%s", h->q_msg); // (a give-up is sticky until the batch starts anew)
+    if (do_reset == 1) forget_queue_failure(h); // (State.reset of the whole batch)
     h->last_schedule = 0;
     if (h->wide) {
         h->n_launches = 0;
@@ -1356,6 +1383,7 @@ extern "C" int sg_upload(sg_handle *h, const sg_scenarios *sc)
     const auto t_entry = std::chrono::steady_clock::now();
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    forget_queue_failure(h);
     HIP_TRY(h, hipStreamSynchronize(h->ctl_stream));
     h->static_allocs.rewind(); // (buffers of the previous batch are reused where they are large enough)
     h->state_allocs.rewind();
@@ -1773,6 +1801,7 @@ extern "C" int sg_terminal_flags(sg_handle *h, uint32_t *out, const uint32_t **d
     if (out) {
         HIP_TRY(h, hipMemcpyAsync(out, h->d_term_flags, (size_t)h->R * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
+        if (const int rcq = check_queue(h)) return rcq; // (a persistent launch that gave up: sticky)
     }
     if (d_out) *d_out = h->d_term_flags;
     return SG_OK;
@@ -1899,6 +1928,7 @@ extern "C" int sg_tick(sg_handle *h, const double *actions, int32_t actions_devi
                       std::equal(layers, layers + n_layers, h->tick_layers);
     if (!same) {
         HIP_TRY(h, hipStreamSynchronize(h->stream));
+        if (const int rcq = check_queue(h)) return rcq; // (a persistent launch that gave up: sticky)
         if (h->tick_exec) { HIP_TRY(h, hipGraphExecDestroy(h->tick_exec)); h->tick_exec = nullptr; }
         HIP_TRY(h, hipMemcpy(dl, layers, (size_t)n_layers * sizeof(int32_t), hipMemcpyHostToDevice));
         hipGraph_t graph = nullptr;
@@ -1907,7 +1937,7 @@ extern "C" int sg_tick(sg_handle *h, const double *actions, int32_t actions_devi
         h->timing_now = false;
         h->n_launches = 0;
         h->launch_ev.clear();
-        h->rss_fused = rss_tick;
+        h->rss_fused = rss_tick && !unfused_rss(h); // (as launch_rollout_impl: the callback as a launch of its own where no fused variant exists)
         rc = h->wide ? launch_wide(h, 1, 0, 1, h->d_actions) : launch_main(h, 1, 0, 1, h->d_actions, nullptr, false, &ev_next);
         if (!rc && unfused_off_road(h)) // (launch_rollout_impl: the same launches behind the step)
             sg::ego_off_road_kernel<<<dim3((unsigned)((h->R + 63) / 64)), dim3(64), 0, h->stream>>>(h->p);
@@ -2119,6 +2149,7 @@ extern "C" int sg_read_collision_points(sg_handle *h, double *out, int32_t cap, 
         HIP_TRY(h, hipGetLastError());
     }
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (const int rcq = check_queue(h)) return rcq; // (a persistent launch that gave up: sticky)
     std::vector<sg_scenario_state> sd(R);
     HIP_TRY(h, hipMemcpy(sd.data(), p.sdyn, (size_t)R * sizeof(sg_scenario_state), hipMemcpyDeviceToHost));
     std::vector<double> all((size_t)R * std::max(p.ev_cap, 1) * 3);
@@ -2141,6 +2172,7 @@ extern "C" int sg_read_record(sg_handle *h, int32_t n_rows, double *t_out, doubl
     if (n_rows > p.rec_cap) return fail(h, SG_ERR_CAPACITY, "sg_read_record: n_rows=%d > record_capacity=%d", n_rows, p.rec_cap);
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (const int rcq = check_queue(h)) return rcq; // (a persistent launch that gave up: sticky)
     const int R = h->R, E = h->E, EP = h->EP;
     if (t_out && n_rows) HIP_TRY(h, hipMemcpy(t_out, p.rec_t, (size_t)n_rows * R * 8, hipMemcpyDeviceToHost));
     if (pose_out && n_rows) {
@@ -2387,6 +2419,7 @@ extern "C" int sg_rss_read(sg_handle *h, uint8_t *flags, int32_t *codes, double 
     if (!h->uploaded || !rss_live(h)) return fail(h, SG_ERR_STATE, "sg_rss_read: sg_rss_update has not run on this batch");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (const int rcq = check_queue(h)) return rcq; // (a persistent launch that gave up: sticky)
     const int R = h->R, E = h->E, EP = h->EP;
     std::vector<int32_t> st(h->NE), cd(h->NE);
     std::vector<double> sf(h->NE * 2);
@@ -2701,6 +2734,7 @@ extern "C" int sg_raster_map(sg_handle *h, double width, double height, int32_t 
     if (rc) return rc;
     HIP_TRY(h, hipMemcpyAsync(out, d, bytes, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (const int rcq = check_queue(h)) return rcq; // (a persistent launch that gave up: sticky)
     return SG_OK;
 }
 

@@ -244,6 +244,13 @@ def _orient(ring):
 
 def convex_intersects_exact(A, B):
     """Closed-set intersection of two convex rings, exact rational SAT."""
+    # (speed only: rings whose bounding boxes are a clear distance apart cannot touch -- the exact test would say the same)
+    ax0, ax1 = min(p[0] for p in A), max(p[0] for p in A)
+    ay0, ay1 = min(p[1] for p in A), max(p[1] for p in A)
+    bx0, bx1 = min(p[0] for p in B), max(p[0] for p in B)
+    by0, by1 = min(p[1] for p in B), max(p[1] for p in B)
+    if ax0 - bx1 > 1e-6 or bx0 - ax1 > 1e-6 or ay0 - by1 > 1e-6 or by0 - ay1 > 1e-6:
+        return False
     for P, Q in ((A, B), (B, A)):
         o = _orient(P)
         if o == 0:

@@ -125,8 +125,9 @@ def test_bench_dispatch_and_collection_strong_scaling(tmp_path):
 
 def test_bench_py_starts_its_own_ranks(tmp_path):
     """`python bench.py --gpus 2` the way the driver invokes it (no launcher, WORLD_SIZE unset): bench.py starts the two
-    ranks itself (torch.distributed.run as a child, gloo here), relays rank 0's line: ranks 2, n_gpus 2, the weak value and
-    the strong (batch split over the ranks) block."""
+    ranks itself (torch.distributed.run as a child, gloo here), relays rank 0's line: ranks 2, n_gpus 2.  With more than one
+    rank `value` is BASELINE.json's metric as written -- the batch SPLIT over the ranks (scaling "strong", configs[3]) -- and the
+    weak shape (the whole batch per rank) rides beside it."""
     import json
     import subprocess
     import sys
@@ -140,9 +141,9 @@ def test_bench_py_starts_its_own_ranks(tmp_path):
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout
     line = json.loads(lines[0])
-    assert line["ranks"] == 2 and line["n_gpus"] == 2 and line["backend"] == "gloo" and line["scaling"] == "weak"
-    assert line["config"]["scenarios_per_gpu"] == 128 and line["strong"]["scenarios_per_gpu"] == 64
-    assert len(line["per_rank_value"]) == 2 and len(line["strong"]["per_rank_value"]) == 2
+    assert line["ranks"] == 2 and line["n_gpus"] == 2 and line["backend"] == "gloo" and line["scaling"] == "strong"
+    assert line["config"]["scenarios_per_gpu"] == 128 // 2 and line["weak"]["scenarios_per_gpu"] == 128
+    assert len(line["per_rank_value"]) == 2 and len(line["weak"]["per_rank_value"]) == 2
     assert line["engine"] == "tests.standin_engine:make"
-    ent_steps = 2 * 128 * 6 * 40 * 2
+    ent_steps = 2 * 64 * 6 * 40 * 2
     assert abs(line["value"] * line["ms_per_step"] * 1e-3 * 2 - ent_steps) < 1e-6 * ent_steps

@@ -1332,7 +1332,8 @@ def test_rss_metric_through_the_gym():
 def test_bench_two_live_ranks_on_one_gpu(tmp_path):
     """`python bench.py --gpus 2` with the REAL engine: bench.py starts its two ranks itself; both share GPU 0 here
     (SGYM_DIST_ONE_DEVICE; gloo carries the dispatch / collection bytes because RCCL refuses two ranks on one device).  Rank 0's
-    line has both ranks, the weak / strong / strong_sliced blocks, and every block's scenarios verified against the oracle."""
+    line has both ranks; `value` is the batch SPLIT over the ranks (scaling "strong": BASELINE.json's metric as written), the weak
+    and the strong_sliced blocks ride beside it, and every block's scenarios are verified against the oracle."""
     import json
     import subprocess
     import sys
@@ -1344,10 +1345,10 @@ def test_bench_two_live_ranks_on_one_gpu(tmp_path):
                          cwd=str(tmp_path))
     assert out.returncode == 0, out.stderr[-3000:]
     line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
-    assert line["ranks"] == 2 and line["n_gpus"] == 2 and line["backend"] == "gloo" and line["scaling"] == "weak"
-    assert line["config"]["scenarios_per_gpu"] == 1024 and line["strong"]["scenarios_per_gpu"] == 512
-    assert line["strong_sliced"]["scenarios_per_gpu"] == 512
-    for blk in (line, line["strong"], line["strong_sliced"]):
+    assert line["ranks"] == 2 and line["n_gpus"] == 2 and line["backend"] == "gloo" and line["scaling"] == "strong"
+    assert line["config"]["scenarios_per_gpu"] == 1024 // 2 and line["weak"]["scenarios_per_gpu"] == 1024
+    assert line["strong_sliced"]["scenarios_per_gpu"] == 512 and "configs" not in line
+    for blk in (line, line["weak"], line["strong_sliced"]):
         assert blk["verified"]["equal"] and blk["verified"]["scenarios"] >= 4 and len(blk["per_rank_value"]) == 2
     assert line["value"] > 0 and line["strong_sliced"]["value"] > 0
 
@@ -1367,7 +1368,7 @@ def test_rccl_initialised_first_then_the_persistent_launch(tmp_path):
 
     def run(extra):
         out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--verify", "4",
-                              "--no-cpu-baseline", "--require-queue"], capture_output=True, text=True, timeout=900, env=dict(base, **extra),
+                              "--no-cpu-baseline", "--require-queue", "--no-configs"], capture_output=True, text=True, timeout=900, env=dict(base, **extra),
                              cwd=str(tmp_path))
         assert out.returncode == 0, out.stderr[-3000:]
         return json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
@@ -1381,6 +1382,32 @@ def test_rccl_initialised_first_then_the_persistent_launch(tmp_path):
         assert "degraded" not in ln and ln["verified"]["equal"] and ln["engine"].startswith("scenario_gym_amd.RolloutEngine")
         assert ln["roofline"]["bound"] == "valu_fp64" and 0.0 < ln["roofline"]["frac"] <= 1.0
     print(f"persistent launch: {plain['value'] / 1e9:.1f} G alone, {rccl['value'] / 1e9:.1f} G with RCCL initialised first")
+
+
+def test_bench_line_carries_every_single_gpu_config(tmp_path):
+    """The driver times ONE `python bench.py` line: besides the c3 headline it carries the other single-GPU BASELINE configs -- c2
+    (256 x 16 replay, the state of every step materialised) and c5 (1024 x 256 crowd) -- each with its own timed passes, roofline
+    fraction and oracle verification; the headline's own keys are what they were."""
+    import json
+    import subprocess
+    import sys
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--verify", "2", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=900, env=env, cwd=str(tmp_path))
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["scaling"] == "weak" and line["n_gpus"] == 1 and line["config"]["scenarios_per_gpu"] == 4096 and line["verified"]["equal"]
+    cf = line["configs"]
+    assert set(cf) == {"c2", "c5"}
+    assert (cf["c2"]["scenarios"], cf["c2"]["entities"], cf["c2"]["sim_steps"]) == (256, 16, 10000)
+    assert (cf["c5"]["scenarios"], cf["c5"]["entities"], cf["c5"]["sim_steps"]) == (1024, 256, 10000)
+    for c in cf.values():
+        assert c["value"] > 0 and c["steps"] == 3 and c["verified"]["equal"] and c["verified"]["steps"] == 10000
+        assert 0.0 < c["roofline"]["frac"] <= 1.0 and c["roofline"]["kernel_ms"] > 0 and c["roofline"]["kernel"].startswith("sg::rollout_kernel")
+    print(f"c3 {line['value'] / 1e9:.1f} G, c2 {cf['c2']['value'] / 1e9:.2f} G, c5 {cf['c5']['value'] / 1e9:.2f} G")
 
 
 def test_chunk_launch_fallback_is_flagged(tmp_path):

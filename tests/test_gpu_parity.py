@@ -1192,6 +1192,80 @@ def test_queue_launch_equals_chunk_launches(sga, monkeypatch, E, ego_kind, zpr):
         assert rows.tobytes() == pieces[0][1][0].tobytes() and ev.tobytes() == pieces[0][1][1].tobytes()
 
 
+@pytest.mark.parametrize("rss", [False, True])
+def test_queue_handoff_variants_agree(sga, monkeypatch, rss):
+    """A block's consecutive chunks run on different XCDs, whose L2s are not coherent.  The default hand-over re-stores the
+    block's state rows, its scenarios' records and (RSS) the RSS words with write-through stores (SG_QUEUE_HANDOFF=1); the
+    other one is a release fence per item (SG_QUEUE_HANDOFF=0).  Same batch through both, with the table ring as large as the
+    call and with two buffers, and through the chunk launches: every state row, controller state, metric row, event and
+    (RSS) every RSS record are the same bits -- whatever an item writes that a later item of its block reads travels."""
+    import scenario_gym_amd._lib as L
+    from scenario_gym_amd import synthetic
+
+    R, E, steps = 700, 64, 260
+    packed = synthetic.make_batch(R, E, n_steps=steps, ego_kind=L.KIND_AGENT_PID, static_frac=0.1, vanish_frac=0.3, extent=22.0)
+    out, sched = [], []
+    for queue, handoff, ring in (("0", "1", "0"), ("1", "1", "0"), ("1", "0", "0"), ("1", "1", "2"), ("1", "0", "2")):
+        monkeypatch.setenv("SG_QUEUE", queue)
+        monkeypatch.setenv("SG_QUEUE_HANDOFF", handoff)
+        monkeypatch.setenv("SG_QUEUE_RING", ring)
+        eng = sga.RolloutEngine(R, E, terminal_conditions=["max_length"], event_capacity=96)
+        eng.set_tuning(tab_min_steps=1, chunk_steps=16)
+        if rss:
+            eng.set_rss(True)
+        eng.upload(packed)
+        eng.rollout(steps)
+        m, ev = eng.metrics()
+        out.append((eng.state(), m, ev, eng.rss() if rss else None))
+        sched.append(eng.schedule_info()["schedule"])
+        eng.close()
+    assert sched == [SCHED_CHUNKS] + [SCHED_QUEUE] * 4, sched
+    st0, m0, ev0, rss0 = out[0]
+    assert len(ev0) > 0
+    for st, m, ev, rs in out[1:]:
+        for k in st0:
+            assert np.array_equal(st[k], st0[k], equal_nan=True), k
+        assert m.tobytes() == m0.tobytes() and ev.tobytes() == ev0.tobytes()
+        if rss:
+            for x, y in zip(rs, rss0):
+                assert np.array_equal(x, y, equal_nan=True)
+
+
+def test_queue_give_up_is_loud_and_sticky(sga, monkeypatch):
+    """A persistent launch whose wavefronts wait longer than the limit for each other gives up instead of hanging (here on
+    demand: a limit of one microsecond, which the first wait for the controller pre-pass exceeds).  The state of the batch is
+    undefined from then on, and every call that would run or read it says so -- the synchronising call, a read of the metrics, a
+    second rollout queued behind it without a look in between, a continued rollout -- until sg_reset (or a rollout that
+    resets, or sg_upload) starts the batch anew; then the same handle runs the batch to the oracle's bits."""
+    import scenario_gym_amd._lib as L
+    from oracle import check
+    from scenario_gym_amd import synthetic
+
+    R, E, steps, dt = 1024, 64, 400, 1 / 30
+    packed = synthetic.make_batch(R, E, n_steps=steps, ego_kind=L.KIND_AGENT_PID, extent=30.0)
+    eng = sga.RolloutEngine(R, E, timestep=dt, terminal_conditions=["max_length"], event_capacity=64)
+    eng.upload(packed)
+    monkeypatch.setenv("SG_QUEUE_TIMEOUT_US", "1")
+    eng.rollout_async(steps, do_reset=True)
+    eng.rollout_async(steps, do_reset=False)  # (queued behind it: its own slot for the give-up code)
+    with pytest.raises(RuntimeError, match="gave up"):
+        eng.synchronize()
+    assert eng.schedule_info()["schedule"] == SCHED_QUEUE
+    with pytest.raises(RuntimeError, match="gave up"):
+        eng.metrics()
+    with pytest.raises(RuntimeError, match="gave up"):
+        eng.rollout_async(10, do_reset=False)
+    with pytest.raises(RuntimeError, match="gave up"):
+        eng.terminal_flags()
+    monkeypatch.delenv("SG_QUEUE_TIMEOUT_US")
+    eng.reset()
+    eng.rollout_async(steps, do_reset=False)
+    eng.synchronize()
+    ver = check.verify_engine(eng, packed, dt, steps, K=8, event_cap=64)
+    assert ver["equal"], ver["mismatches"]
+    eng.close()
+
+
 def test_queue_launch_with_many_blocks_per_slot(sga, oracle, monkeypatch):
     """More blocks than the device has wavefront slots (3 x 1024 SIMDs), a ring of three buffers, chunks of 32 steps: every slot
     serves several blocks, the blocks of a chunk finish out of order, the pre-pass waits for the ring -- the state after the
