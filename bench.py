@@ -28,7 +28,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # live figure of tools/valu_peak.hip is reported beside it)
 FP64_VALU_PEAK_TFLOPS = 78.6
 # whose counted algorithmic flops (profiles/flops_<key>.json, tools/count_flops.py) a workload is priced with
-FLOPS_OF = {"c3": "c3", "c3s": "c3", "c2": "c2", "c2s": "c2", "c5": "c5", "c5mix": "c5", "c3rss": "c3"}
+FLOPS_OF = {"c3": "c3", "c3s": "c3", "c2": "c2", "c2s": "c2", "c5": "c5", "c5mix": "c5", "c5roads": "c5", "c3rss": "c3"}
 # BASELINE.json configs: scenarios, entities; algorithmic bytes per entity-step (pose 48 + velocity 48 +
 # distance 8 + collision row 8 x words + knots 2 [+ force 16]); bytes the kernel actually stores per steady entity-step
 # (unchanged z / pitch / roll rows are not stored again: x, y, h of pose and velocity, distance,
@@ -47,6 +47,10 @@ WORKLOADS = {
     # the c5 crowd with ONE PID car per scenario among the 255 pedestrians: the crowd kernel with riders (the car's poses come
     # from the controller pre-pass); SG_CROWD_RIDERS=0 runs the general pedestrian variant instead -- the cliff, measured
     "c5mix": dict(R=1024, E=256, b_alg=154.0, stored=112.0, config=4, mix=True),
+    # the c5 crowd as the reference actually runs crowds (pedestrian/sensor.py:50-51 refuses to run without a road network,
+    # examples/crowds.py:149-205): on a pavement with four buildings, routes along the streets, the boundary forces of
+    # social_force.py:86-104 as a phase of the crowd kernel
+    "c5roads": dict(R=1024, E=256, b_alg=154.0, stored=112.0, config=4, roads=True),
     # the c3 batch with the RSSDistances state callback (metrics/rss/callback.py:58-128) after the reset and after every step,
     # inside the rollout kernel: + one record per entity-step (code 4 B, safe lateral / longitudinal distance 16 B)
     "c3rss": dict(R=4096, E=64, b_alg=134.0, stored=72.0, config=2, rss=True),
@@ -74,9 +78,13 @@ def cpu_baseline(workload, seconds_budget=20.0):
     cores = effective_cpus()
     E, T = workload["E"], workload["T"]
     rss = bool(workload.get("rss"))
+    net = None
     if workload.get("crowd"):
         t_sample, n_scen = min(T, 1000), min(max(cores, 1) * 16, 1024)
-        packed = synthetic.make_crowd(n_scen, E, n_steps=t_sample)
+        if workload.get("roads"):
+            packed, net, _ = synthetic.make_crowd_roads(n_scen, E, n_steps=t_sample)
+        else:
+            packed = synthetic.make_crowd(n_scen, E, n_steps=t_sample)
     elif rss:  # (the oracle's callback runs over the recorded poses of its rollout)
         t_sample, n_scen = min(T, 500), min(max(cores, 1) * 16, 1024)
         packed = synthetic.make_batch(n_scen, E, n_steps=t_sample, ego_kind=workload["ego_kind"])
@@ -88,7 +96,7 @@ def cpu_baseline(workload, seconds_budget=20.0):
     def one(s):
         o = O.rollout(s["knot_off"], s["knots"], s["bbox"], s["etype"], s["kind"], s["ego"], s["t0"],
                       s["length"], workload["dt"], ctrl=s["ctrl"], max_steps=t_sample, record=rss,
-                      route_off=s.get("route_off"), routes=s.get("routes"))
+                      route_off=s.get("route_off"), routes=s.get("routes"), road=net)
         if rss:
             O.rss_rollout(o, s["bbox"], s["ego"])
         return o["n_steps"]
@@ -484,7 +492,7 @@ def main(argv=None, make_engine=None, emit=True):
     ap.add_argument("--entities", type=int, default=None)
     ap.add_argument("--sim-steps", type=int, default=10000)
     ap.add_argument("--ego", default="pid", choices=["pid", "replay"])
-    ap.add_argument("--workload", default="c3", choices=["c3", "c2", "c2s", "c5", "c5mix", "c3rss", "c3s", "e2e"],
+    ap.add_argument("--workload", default="c3", choices=["c3", "c2", "c2s", "c5", "c5mix", "c5roads", "c3rss", "c3s", "e2e"],
                     help="BASELINE.json configs: c3 = 4096x64 PID ego (default, the headline), c2 = 256x16 replay (state of "
                          "every step materialised), c5 = 1024x256 social-force crowd; c2s = the c2 batch through the "
                          "time-sliced replay path (final state + metrics + events only: a separate mode, never the headline); c3rss = the c3 "
@@ -536,7 +544,7 @@ def main(argv=None, make_engine=None, emit=True):
     args.entities = args.entities or wl["E"]
     if args.workload in ("c2", "c2s"):
         args.ego = "replay"
-    crowd = args.workload in ("c5", "c5mix")
+    crowd = args.workload in ("c5", "c5mix", "c5roads")
     rank, world, local_rank, dist = D.init()
     if args.scaling is None:
         args.scaling = "strong" if world > 1 else "weak"
@@ -561,7 +569,11 @@ def main(argv=None, make_engine=None, emit=True):
             torch.cuda.synchronize()
 
         def make_engine(R, first, sliced=None):
-            if crowd and wl.get("mix"):
+            road = None
+            if crowd and wl.get("roads"):
+                packed, net, net_of = synthetic.make_crowd_roads(R, E, n_steps=T, timestep=dt, seed=seed, first_scenario=first)
+                road = (net, net_of)
+            elif crowd and wl.get("mix"):
                 packed = synthetic.make_crowd_with_car(R, E, n_steps=T, timestep=dt, seed=seed, first_scenario=first)
             elif crowd:
                 packed = synthetic.make_crowd(R, E, n_steps=T, timestep=dt, seed=seed, first_scenario=first)
@@ -577,7 +589,10 @@ def main(argv=None, make_engine=None, emit=True):
             if wl.get("rss"):
                 eng.set_rss(True)
             eng.upload(packed)
+            if road:
+                eng.set_road_networks([road[0]], road[1])
             eng._bench_packed = packed  # (kept for the oracle check after the timed passes)
+            eng._bench_road = road
             return eng
     else:  # tests drive the dispatch / timing / collection code with a stand-in engine on CPU
         def sync():
@@ -594,7 +609,8 @@ def main(argv=None, make_engine=None, emit=True):
             noise_of = lambda r: dict(mode="device", std_lon=0.1, std_lat=0.1, seed=0, scenario_index=r)  # noqa: E731
         t0 = time.perf_counter()
         v = check.verify_engine(eng, eng._bench_packed, dt, T, K=K, event_cap=64, ped=crowd, rss=bool(wl.get("rss")),
-                                noise_of=noise_of, threads=effective_cpus())
+                                noise_of=noise_of, threads=effective_cpus(),
+                                road_of=(lambda r: eng._bench_road[0]) if getattr(eng, "_bench_road", None) else None)
         v["seconds"] = round(time.perf_counter() - t0, 2)
         v["what"] = ("after the timed passes, outside the timed region: the device state left by the last timed rollout vs "
                      "oracle/sgym_oracle.c run over the full horizon, bit for bit")
@@ -785,6 +801,10 @@ def main(argv=None, make_engine=None, emit=True):
                 "workload": (f"{R} scenarios x ({E - 1} pedestrians + 1 PID car) x {T} steps per GPU, PedestrianAgent + SocialForce / "
                              f"PIDAgent, all-pairs OBB collisions, CollisionMetric, terminal max_length (BASELINE.json configs[4] "
                              f"with a vehicle in the crowd)") if (crowd and wl.get("mix")) else
+                            (f"{R} scenarios x {E} pedestrians x {T} steps per GPU on a road network (a pavement, four buildings; routes along "
+                             f"the streets), PedestrianAgent + SocialForce with its boundary forces (radius 3 m, noise {args.ped_noise}) + "
+                             "PedestrianController, all-pairs OBB collisions, CollisionMetric, terminal max_length (BASELINE.json "
+                             "configs[4] as examples/crowds.py runs crowds)") if (crowd and wl.get("roads")) else
                             (f"{R} scenarios x {E} pedestrians x {T} steps per GPU, PedestrianAgent + SocialForce "
                              f"(radius 3 m, noise {args.ped_noise}) + PedestrianController, all-pairs OBB collisions, "
                              "CollisionMetric, terminal max_length (BASELINE.json configs[4])") if crowd else
@@ -829,7 +849,7 @@ def main(argv=None, make_engine=None, emit=True):
         # which engine produced the line (a stand-in injected by the CPU tests must never pass for the HIP library)
         line["engine"] = "scenario_gym_amd.RolloutEngine (libsgym_hip.so)" if live else (args.engine_factory or "injected stand-in (tests)")
         if live and not args.no_cpu_baseline:  # (rank 0 only, after the timed region; the other ranks wait at the teardown)
-            line["cpu_baseline"] = cpu_baseline(dict(E=E, T=T, dt=dt, ego_kind=ego_kind, crowd=crowd, rss=bool(wl.get("rss"))))
+            line["cpu_baseline"] = cpu_baseline(dict(E=E, T=T, dt=dt, ego_kind=ego_kind, crowd=crowd, rss=bool(wl.get("rss")), roads=bool(wl.get("roads"))))
         if (live and world == 1 and args.workload == "c3" and not args.no_configs and emit
                 and (R, E, T) == (WORKLOADS["c3"]["R"], WORKLOADS["c3"]["E"], 10000) and args.ego == "pid"):
             # the driver times ONE line: the other single-GPU BASELINE configs ride in it, each measured

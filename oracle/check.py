@@ -25,7 +25,7 @@ def spread(R, K):
 
 
 def oracle_final(packed, r, dt, T, persist=False, terminal_mask=O.TERM_MAX_LENGTH, event_cap=64, sf=None, noise=None,
-                 record="last", behaviour="social_force", models=None, model_of=None):
+                 record="last", behaviour="social_force", models=None, model_of=None, road=None):
     from scenario_gym_amd.packing import unpack_scenario
 
     s = unpack_scenario(packed, r)
@@ -34,7 +34,7 @@ def oracle_final(packed, r, dt, T, persist=False, terminal_mask=O.TERM_MAX_LENGT
     return O.rollout(s["knot_off"], s["knots"], s["bbox"], s["etype"], s["kind"], s["ego"], s["t0"], s["length"], dt,
                      persist=persist, terminal_mask=terminal_mask, ctrl=s["ctrl"], actions=actions, max_steps=T, record=record,
                      event_cap=event_cap, route_off=s.get("route_off"), routes=s.get("routes"), sf=sf, noise=noise,
-                     behaviour=behaviour, models=models, model_of=model_of)
+                     behaviour=behaviour, models=models, model_of=model_of, road=road)
 
 
 def compare_final(st, rows, events, r, o, E, event_cap=64, ped=False, kind=None):
@@ -74,9 +74,10 @@ def compare_final(st, rows, events, r, o, E, event_cap=64, ped=False, kind=None)
 
 
 def verify_engine(eng, packed, dt, T, K=16, event_cap=64, ped=False, rss=False, sf=None, noise_of=None, threads=8,
-                  persist=False, terminal_mask=O.TERM_MAX_LENGTH, behaviour="social_force"):
+                  persist=False, terminal_mask=O.TERM_MAX_LENGTH, behaviour="social_force", road_of=None):
     """The engine's CURRENT state (after a rollout of at most T steps from reset) against the oracle on K scenarios spread
-    over the batch, full horizon.  noise_of(r) -> the oracle's noise dict of scenario r.  rss: also the RSSDistances records
+    over the batch, full horizon.  noise_of(r) -> the oracle's noise dict of scenario r; road_of(r) -> the polygon arrays of its
+    road network (None: none).  rss: also the RSSDistances records
     (codes, safe distances, the two metric flags)."""
     O.build()
     O.lib()
@@ -88,7 +89,8 @@ def verify_engine(eng, packed, dt, T, K=16, event_cap=64, ped=False, rss=False, 
 
     def one(r):
         o = oracle_final(packed, r, dt, T, persist=persist, terminal_mask=terminal_mask, event_cap=max(event_cap, 1), sf=sf,
-                         noise=None if noise_of is None else noise_of(r), record=True if rss else "last", behaviour=behaviour)
+                         noise=None if noise_of is None else noise_of(r), record=True if rss else "last", behaviour=behaviour,
+                         road=None if road_of is None else road_of(r))
         bad = compare_final(st, rows, events, r, o, E, event_cap=event_cap, ped=ped, kind=packed.kind[r * E:(r + 1) * E])
         if rss:
             from scenario_gym_amd.packing import unpack_scenario

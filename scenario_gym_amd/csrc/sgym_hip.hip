@@ -164,6 +164,9 @@ static int env_int(const char *name, int dflt)
     const char *v = getenv(name);
     return (v && *v) ? atoi(v) : dflt;
 }
+// ... and a road network only as the source of the boundary forces (social_force.py:86-104: a phase behind the neighbour sums,
+// gated on the launch having polygons at all); ego_off_road needs the cell lookup of rollout_kernel_road / the general variants
+static bool crowd_road_ok(const sg_handle *h) { return !h->has_road || (!(h->cfg.terminal_mask & SG_TERM_EGO_OFF_ROAD) && env_int("SG_CROWD_ROADS", 1) != 0); }
 
 // Host threads for sg_upload's pass over the scenarios: the logical CPUs, capped at 64 and by the cgroup CPU quota (a box can
 // show 256 CPUs under a quota of 16: more busy threads than that are throttled, not run -- ADVICE r2); SG_UPLOAD_THREADS overrides.
@@ -489,7 +492,7 @@ static void launch_variant(sg_handle *h, dim3 grid, int n_steps, int do_reset, i
         sgl::rollout_ped(64, 8, false, grid, s, a);
     else if (WV == 8) // ... vehicles and replay only (launch_rollout never takes the table path at this width)
         sgl::rollout_plain(64, 8, false, grid, s, a);
-    else if (h->has_ped && h->all_ped && G == 64 && !h->has_road && crowd_allowed(h) && !h->rss_fused)
+    else if (h->has_ped && h->all_ped && G == 64 && crowd_road_ok(h) && crowd_allowed(h) && !h->rss_fused)
         sgl::rollout_crowd(WV, false, grid, s, a);
     else if (use_tab && h->has_ped && G == 64) // (launch_rollout: a crowd with riders, their table is d_tab)
         sgl::rollout_crowd(WV, true, grid, s, at);
@@ -924,7 +927,7 @@ static int launch_rollout_impl(sg_handle *h, int n_steps, int do_reset, int forc
     // in the rollout kernel, where they fill the wavefront anyway
     // (a crowd with riders: lanes of other kinds ride the crowd kernel on a pre-pass table; short calls -- the per-tick loop of
     // an RL driver -- keep the general pedestrian variant, like the table path keeps the in-kernel controllers)
-    const bool riders = h->crowd_riders && !h->has_road && !h->rss_fused && h->n_ctl > 0 && n_steps >= tab_min;
+    const bool riders = h->crowd_riders && crowd_road_ok(h) && !h->rss_fused && h->n_ctl > 0 && n_steps >= tab_min;
     // (the RSS callback inside the kernel: its controlled lanes ride the table too -- rollout_kernel_rss_tab -- which takes the
     // controller code out of the one variant that has no issue slot to spare; launches stay within the line-test queue)
     const bool rss_tab = h->rss_fused && h->WV == 1 && !h->has_ped && !(h->cfg.terminal_mask & SG_TERM_EGO_OFF_ROAD) && h->n_ext == 0 &&

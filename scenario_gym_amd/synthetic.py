@@ -137,6 +137,87 @@ def make_crowd(n_scenarios, n_entities=256, n_steps=10000, timestep=1.0 / 30.0, 
     ).validate()
 
 
+def building_blocks(side=40.0, blocks=2, building=8.0, margin=3.0):
+    """A road network in the spirit of examples/crowds.py:149-205 for the crowd workloads: one pavement that covers the whole
+    square (walkable) and blocks x blocks square buildings (impenetrable: the nearest-point boundary force of
+    social_force.py:190-211) with streets between and around them.  polygon_arrays() layout: ring_off, vert_off, verts, layers."""
+    from .road_network import LAYER_IMPENETRABLE, LAYER_PAVEMENT, LAYER_WALKABLE
+
+    h = side / 2 + margin
+    rings = [np.array([[-h, -h], [-h, h], [h, h], [h, -h]], np.float64)]
+    layers = [LAYER_WALKABLE | LAYER_PAVEMENT]
+    pitch = side / blocks
+    for i in range(blocks):
+        for j in range(blocks):
+            cx, cy = -side / 2 + (i + 0.5) * pitch, -side / 2 + (j + 0.5) * pitch
+            b = building / 2
+            rings.append(np.array([[cx - b, cy - b], [cx - b, cy + b], [cx + b, cy + b], [cx + b, cy - b]], np.float64))
+            layers.append(LAYER_IMPENETRABLE | LAYER_WALKABLE)
+    return dict(ring_off=np.arange(len(rings) + 1, dtype=np.int64), vert_off=np.arange(len(rings) + 1, dtype=np.int64) * 4,
+                verts=np.concatenate(rings), layers=np.array(layers, np.uint32))
+
+
+def make_crowd_roads(n_scenarios, n_entities=256, n_steps=10000, timestep=1.0 / 30.0, side=40.0, radius=3.0, blocks=2,
+                     building=8.0, seed=SEED, first_scenario=0):
+    """The config-5 crowd on building_blocks(): every pedestrian starts on a street (never inside a building) and walks a
+    route along the streets -- up to four waypoints: along its own street to a crossing, along the crossing street, into the
+    goal's street -- as the pavement-graph routes of examples/crowds.py do.  Returns (packed, network, net_of_scenario)."""
+    R, E = int(n_scenarios), int(n_entities)
+    length = n_steps * timestep
+    assert first_scenario % CHUNK == 0
+    pitch = side / blocks
+    lines = -side / 2 + pitch * np.arange(blocks + 1)      # street centre lines, both directions
+    half = (pitch - building) / 2 - 0.6                     # lateral room on a street (a margin to the walls)
+    NW = 4
+    kn, routes, ctrl = [], [], []
+    for c0 in range(0, R, CHUNK):
+        n = min(CHUNK, R - c0)
+        rng = np.random.default_rng([seed, 7, (first_scenario + c0) // CHUNK])
+
+        def street_points(shape):
+            """random points on the streets: (xy, is the street parallel to x, index of its line)"""
+            horiz = rng.random(shape) < 0.5
+            k = rng.integers(0, blocks + 1, shape)
+            along = rng.uniform(-side / 2, side / 2, shape)
+            across = lines[k] + rng.uniform(-half, half, shape)
+            xy = np.where(horiz[..., None], np.stack([along, across], -1), np.stack([across, along], -1))
+            return xy, horiz, k
+
+        start, sh, sk = street_points((CHUNK, E))
+        goal, gh, gk = street_points((CHUNK, E))
+        via = lines[rng.integers(0, blocks + 1, (CHUNK, E))]  # a crossing street, for start and goal on parallel streets
+        wp = np.empty((CHUNK, E, NW, 2))
+        wp[:, :, 0] = start
+        wp[:, :, 3] = goal
+        # perpendicular streets: one corner (the crossing of the two lines), repeated; parallel ones: over the `via` street
+        sx, sy, gx, gy = start[..., 0], start[..., 1], goal[..., 0], goal[..., 1]
+        perp = sh != gh
+        c1 = np.where(sh[..., None], np.stack([np.where(perp, lines[gk], via), sy], -1), np.stack([sx, np.where(perp, lines[gk], via)], -1))
+        c2 = np.where(gh[..., None], np.stack([np.where(perp, lines[sk], via), gy], -1), np.stack([gx, np.where(perp, lines[sk], via)], -1))
+        wp[:, :, 1] = c1
+        wp[:, :, 2] = np.where(perp[..., None], c1, c2)
+        wp[:, :, 1:3] += rng.uniform(-0.5, 0.5, (CHUNK, E, 2, 2))  # (nobody aims at the exact same corner point)
+        h0 = rng.uniform(-np.pi, np.pi, (CHUNK, E))
+        vdes = rng.uniform(0.5, 1.5, (CHUNK, E)) * 1.3
+        k = np.zeros((CHUNK, E, 2, 7))
+        k[:, :, 1, 0] = length
+        k[:, :, :, 1:3] = start[:, :, None, :]
+        k[:, :, :, 4] = h0[:, :, None]
+        kn.append(k[:n].reshape(-1, 7))
+        routes.append(wp[:n].reshape(-1, 2))
+        row = np.tile(DEFAULT_CTRL, (n * E, 1))
+        row[:, L.C_PED_SPEED_DESIRED] = vdes[:n].ravel()
+        row[:, L.C_PED_RADIUS] = radius
+        ctrl.append(row)
+    packed = PackedScenarios(
+        R, E, np.full(R * E, L.KIND_AGENT_PEDESTRIAN, np.int32), np.ones(R * E, np.int32),
+        np.tile(np.array(PEDESTRIAN1_BBOX), (R * E, 1)), np.arange(R * E + 1, dtype=np.int64) * 2,
+        np.concatenate(kn), np.zeros(R, np.int32), np.zeros(R), np.full(R, length), np.concatenate(ctrl),
+        route_off=np.arange(R * E + 1, dtype=np.int64) * NW, routes=np.concatenate(routes),
+    ).validate()
+    return packed, building_blocks(side, blocks, building), np.zeros(R, np.int32)
+
+
 def make_crowd_with_car(n_scenarios, n_entities=256, n_steps=10000, timestep=1.0 / 30.0, side=40.0, radius=3.0,
                         seed=SEED, first_scenario=0, car_kind=L.KIND_AGENT_PID) -> PackedScenarios:
     """make_crowd with entity 0 of every scenario replaced by a car (car1, a PIDAgent by default) that crosses the square

@@ -2291,6 +2291,51 @@ def test_pedestrians_beside_a_building_match_reference(sga, oracle, si):
         assert np.nanmax(np.abs(o_road["poses"] - o_free["poses"])) > 0.1
 
 
+@pytest.mark.parametrize("E,blocks,riders", [(100, 2, False), (256, 2, False), (200, 3, False), (180, 2, True)])
+def test_crowd_kernels_take_road_networks(sga, oracle, monkeypatch, E, blocks, riders):
+    """The reference's pedestrians need a road network to run at all (pedestrian/sensor.py:50-51) and feel its buildings
+    (social_force.py:86-104, 190-211).  Batches that have one no longer leave the crowd kernels: the boundary terms are a
+    phase behind the neighbour sums (rollout_kernel_crowd on 2 and 4 wavefronts, rollout_kernel_crowd_riders with a PID car).
+    Same bits as the general pedestrian kernel (SG_CROWD_ROADS=0) and as the oracle, scenarios with and without a network in
+    one batch; the network is felt (the rollout differs from the one without it)."""
+    import scenario_gym_amd._lib as L
+    from oracle import check
+    from scenario_gym_amd import synthetic
+
+    R, steps, dt = 6, 700, 1 / 30
+    packed, net, net_of = synthetic.make_crowd_roads(R, E, n_steps=steps, side=30.0, blocks=blocks, building=30.0 / blocks - 5.0)
+    net_of[2] = -1  # one scenario without a network
+    if riders:  # a PID car on the centre street
+        packed = _add_riders(packed_two_waypoints(packed), np.random.default_rng(4), 30.0, steps * dt, [("pid", 0, "car")])
+    out = []
+    for roads in ("1", "0", "off"):
+        monkeypatch.setenv("SG_CROWD_ROADS", "0" if roads == "0" else "1")
+        eng = sga.RolloutEngine(R, E, timestep=dt, terminal_conditions=["max_length"], event_capacity=256)
+        eng.upload(packed)
+        if roads != "off":
+            eng.set_road_networks([net], net_of)
+        eng.rollout(steps)
+        out.append((eng.state(), eng.metrics()))
+        if roads == "1":
+            ver = check.verify_engine(eng, packed, dt, steps, K=R, event_cap=256, ped=True, road_of=lambda r: net if net_of[r] == 0 else None)
+            assert ver["equal"], ver["mismatches"]
+        eng.close()
+    (sa, (ra, ea)), (sb, (rb, eb)), (sc, _) = out
+    for k in ("poses", "vels", "dists", "force", "ctrl_state", "present"):
+        assert bits_equal(sa[k], sb[k]), k
+    assert np.array_equal(sa["coll"], sb["coll"]) and ra.tobytes() == rb.tobytes() and ea.tobytes() == eb.tobytes()
+    assert bits_equal(sa["poses"][2], sc["poses"][2]) and np.abs(sa["poses"][0] - sc["poses"][0]).max() > 0.05
+
+
+def packed_two_waypoints(packed):
+    """_add_riders edits batches whose pedestrians have two waypoints each: keep the first and the last of every route."""
+    R, E = packed.n_scenarios, packed.n_entities
+    nw = int(packed.route_off[1] - packed.route_off[0])
+    packed.routes = packed.routes.reshape(R * E, nw, 2)[:, [0, nw - 1]].reshape(-1, 2)
+    packed.route_off = np.arange(R * E + 1, dtype=np.int64) * 2
+    return packed.validate()
+
+
 def test_collision_types_match_reference_code_and_oracle(sga, oracle):
     """CollisionMetric's classification (t_bone / head_on / rear_end / side_swipe / non_vehicle) for the 47 scenes of
     collision_types.npz as one ragged batch: times, hazards and types equal the output of the reference's own
