@@ -9,7 +9,12 @@
     bench.py's headline rolls out: the ego's pose and controller state after EVERY one of the 10,000 steps, the final
     state of all 64 entities, the metrics.  (No CollisionMetric: State.collisions() would run the exact-rational stand-in
     for GEOS 10,000 x 64 times.)  The scenario itself is not stored -- the consumer rebuilds it with the same generator call
-    and checks the recorded checksum of its knots.
+    and checks the recorded checksums: of the generator's knots, and of Trajectory.data as the reference's constructor left
+    them (trajectory.py:34-96 re-sums the headings, _resolve_heading :465-469: an ulp here and there), which is what rolls out.
+    `self_divergence`: the SAME reference run once more with the ego's first x one ulp larger -- how far the reference moves
+    away from itself, step by step: the PID loop on these trajectories amplifies a rounding error by ten every ~100 steps, so
+    beyond ~1,500 steps "the reference's trajectory" is a property of its libm, and the 1e-5 contract is checked on the steps
+    before the reference's own one-ulp twin has left that band.
 (b) `crowd/<k>`: 32 pedestrians on a 12 m square, two-waypoint routes, sensor radius 3 m, SocialForce defaults, empty road
     network, 3,300 steps of dt = 1/30 with CollisionMetric: (0) std 0; (1) the reference's noise with np.random.seed(5)
     (std_lon 0.05, std_lat 0.02).  Every pedestrian's pose every 25 steps and after the last step, four pedestrians after
@@ -52,35 +57,45 @@ def knots_digest(s):
                                         + np.ascontiguousarray(s["bbox"]).tobytes()).digest(), np.uint8).copy()
 
 
+def c3_run(s, k, nudge):
+    """One rollout of scenario `s`; nudge: the ego's first x moved by that many ulps."""
+    ents = []
+    for e in range(C3_E):
+        ce = CatalogEntry("synthetic", "car1", "car", "Vehicle", BoundingBox(*[float(x) for x in s["bbox"][e]]), {}, [])
+        kn = s["knots"][s["knot_off"][e]:s["knot_off"][e + 1]].copy()
+        if e == 0 and nudge:
+            kn[0, 1] = np.nextafter(kn[0, 1], np.inf)
+        ents.append(Entity(ce, ref="ego" if e == 0 else f"vehicle_{e - 1}", trajectory=Trajectory(kn)))
+    sc = Scenario(ents, name=f"synthetic_{k}")
+    gym = ScenarioGym(timestep=DT, metrics=[EgoAvgSpeed(), EgoMaxSpeed(), EgoDistanceTravelled()])
+    gym.set_scenario(sc, create_agent=lambda sc_, e: PIDAgent(e) if e.ref == "ego" else _create_agent(sc_, e))
+    st = gym.state
+    ctl = st.agents[sc.ego].controller
+    gym.reset_scenario()
+    trace, ts = [], []
+
+    def snap():
+        ts.append(st.t)
+        trace.append(list(st.poses[sc.ego]) + [ctl.speed, ctl.e_lon_prev, ctl.e_lat_prev, ctl.e_lon_int])
+
+    snap()
+    n = 0
+    while not st.is_done and n < C3_STEPS + 5:
+        gym.step()
+        snap()
+        n += 1
+    return gym, ents, n, ts, trace
+
+
 def g_c3():
     out = {}
     packed = synthetic.make_batch(synthetic.CHUNK, C3_E, n_steps=C3_STEPS, timestep=DT, first_scenario=0)
     for k in (0, 1):
         s = unpack_scenario(packed, k)
-        ents = []
-        for e in range(C3_E):
-            ce = CatalogEntry("synthetic", "car1", "car", "Vehicle", BoundingBox(*[float(x) for x in s["bbox"][e]]), {}, [])
-            ents.append(Entity(ce, ref="ego" if e == 0 else f"vehicle_{e - 1}",
-                               trajectory=Trajectory(s["knots"][s["knot_off"][e]:s["knot_off"][e + 1]])))
-        sc = Scenario(ents, name=f"synthetic_{k}")
-        gym = ScenarioGym(timestep=DT, metrics=[EgoAvgSpeed(), EgoMaxSpeed(), EgoDistanceTravelled()])
-        gym.set_scenario(sc, create_agent=lambda sc_, e: PIDAgent(e) if e.ref == "ego" else _create_agent(sc_, e))
+        gym, ents, n, ts, trace = c3_run(s, k, 0)
         st = gym.state
-        ego = sc.ego
-        ctl = st.agents[ego].controller
-        gym.reset_scenario()
-        trace, ts = [], []
-
-        def snap():
-            ts.append(st.t)
-            trace.append(list(st.poses[ego]) + [ctl.speed, ctl.e_lon_prev, ctl.e_lat_prev, ctl.e_lon_int])
-
-        snap()
-        n = 0
-        while not st.is_done and n < C3_STEPS + 5:
-            gym.step()
-            snap()
-            n += 1
+        twin = np.array(c3_run(s, k, 1)[4])
+        norm = hashlib.sha256(np.ascontiguousarray(np.concatenate([e.trajectory.data for e in ents])).tobytes()).digest()
         P = np.full((C3_E, 6), np.nan)
         V = np.full((C3_E, 6), np.nan)
         for i, e in enumerate(ents):
@@ -90,7 +105,9 @@ def g_c3():
                 V[i] = st.velocities[e]
         m = gym.get_metrics()
         out.update(G.flat(f"c3/{k}", dict(
-            knots_sha256=knots_digest(s), n_steps=np.int64(n), is_done=np.bool_(st.is_done), t=np.array(ts), ego=np.array(trace),
+            knots_sha256=knots_digest(s), trajectory_data_sha256=np.frombuffer(norm, np.uint8).copy(),
+            self_divergence=np.abs(twin[:, :6] - np.array(trace)[:, :6]).max(axis=1),
+            n_steps=np.int64(n), is_done=np.bool_(st.is_done), t=np.array(ts), ego=np.array(trace),
             final_poses=P, final_vels=V, final_dists=np.array([st.distances[e] for e in ents], np.float64),
             metric_ego_avg_speed=np.float64(m["ego_avg_speed"]), metric_ego_max_speed=np.float64(m["ego_max_speed"]),
             metric_ego_distance_travelled=np.float64(m["ego_distance_travelled"]))))
@@ -176,6 +193,9 @@ def g_crowd():
 def main():
     only = set(sys.argv[1:])
     out = {}
+    if only:  # (development: one part anew, the other as committed)
+        old = np.load(os.path.join(HERE, "long.npz"))
+        out = {k_: old[k_] for k_ in old.files if k_.split("/")[0] not in only}
     if not only or "c3" in only:
         out.update(g_c3())
     if not only or "crowd" in only:

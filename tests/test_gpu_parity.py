@@ -769,6 +769,68 @@ def test_pedestrian_noise_closed_loops_match_reference(sga, oracle, si):
     eng.close()
 
 
+def test_headline_horizon_pid_ego_on_the_device(sga, oracle):
+    """BASELINE config 3 at its own length against the REAL reference (tests/golden/long.npz: two scenarios of the bench's
+    family, PIDAgent ego, 10,000 steps): the device's clock and every replay lane bit for bit over the whole horizon; the PID
+    ego inside the 1e-5 contract on every step for as long as the reference agrees with its own one-ulp twin (1,290 / 720
+    steps: this closed loop multiplies a rounding error by ten every ~100 steps, test_oracle_golden.check_long_c3), diverging
+    no faster than that twin afterwards; and the same bits as the oracle over all 10,000."""
+    from test_oracle_golden import check_long_c3, long_c3_batch
+
+    packed, g = long_c3_batch()
+    st, rows, events, t, poses = _engine_run(sga, packed, 1 / 30, 10002, ev_cap=64)
+    for k in (0, 1):
+        n = int(rows["n_steps"][k])
+        err, prefix, over = check_long_c3(g, k, n, t[: n + 1, k], poses[: n + 1, k, 0], None, st["poses"][k], st["vels"][k], st["dists"][k])
+        o = _oracle_one(oracle, packed, k, 1 / 30, 10002)
+        assert bits_equal(poses[: n + 1, k], o["poses"]) and bits_equal(st["ctrl_state"][k, 0], o["extra"][-1, 0])
+        print(f"device vs reference c3/{k}: max |ego pose error| on the first {prefix} steps = {err:.3e}, exceeds 1e-5 at step {over}")
+
+
+@pytest.mark.parametrize("k", [0, 1])
+def test_long_crowd_on_the_device_matches_reference(sga, oracle, k):
+    """32 pedestrians, 3,300 steps, recorded from the REAL reference (long.npz; k = 1 with the reference's noise from numpy's
+    global stream): every recorded pose within the contract, goal indices, final adjacency and the ego's events exact, the
+    same number of variates consumed -- and the same bits as the oracle."""
+    import scenario_gym_amd._lib as L
+    from scenario_gym_amd.engine import DEFAULT_CTRL
+    from scenario_gym_amd.packing import pack_arrays
+    from test_oracle_golden import check_long_crowd
+
+    g = load_golden("long")
+    sc = scenario_arrays(g, f"crowd/{k}/scenario")
+    E = len(sc["etype"])
+    ctrl = np.tile(DEFAULT_CTRL, (E, 1))
+    ctrl[:, L.C_PED_SPEED_DESIRED], ctrl[:, L.C_PED_RADIUS] = g[f"crowd/{k}/vdes"], float(g[f"crowd/{k}/distance_threshold"])
+    nw = g[f"crowd/{k}/routes"].shape[1]
+    sc = dict(sc, route_off=np.arange(E + 1, dtype=np.int64) * nw, routes=g[f"crowd/{k}/routes"].reshape(-1, 2))
+    packed = pack_arrays([sc], kinds=[np.full(E, L.KIND_AGENT_PEDESTRIAN, np.int32)], ctrls=[ctrl])
+    std_lon, std_lat, seed = g[f"crowd/{k}/noise"]
+    kw, noise = {}, None
+    if std_lon or std_lat:
+        used = int(g[f"crowd/{k}/variates_used"])
+        normals = np.random.RandomState(int(seed)).standard_normal(used + 64)
+        kw = dict(social_force=dict(std_lon=std_lon, std_lat=std_lat, noise="stream", normals=normals[None, :]))
+        noise = dict(mode="stream", std_lon=std_lon, std_lat=std_lat, normals=normals)
+    n_cap = 3304
+    eng = sga.RolloutEngine(1, E, timestep=1 / 30, record_capacity=n_cap, event_capacity=512, **kw)
+    eng.upload(packed)
+    eng.rollout(n_cap - 1)
+    st = eng.state()
+    rows, events = eng.metrics()
+    t, poses = eng.record(n_cap)
+    eng.close()
+    n = int(rows["n_steps"][0])
+    if noise:
+        assert st["noise_pos"][0] == used
+    extra = np.concatenate([st["ctrl_state"][0][:, :2], st["force"][0]], axis=1)
+    err = check_long_crowd(g, k, n, t[: n + 1, 0], poses[: n + 1, 0], st["vels"][0], st["dists"][0], extra, _dense_words(st["coll"][0], E),
+                           events["t"], events["other"])
+    o = _oracle_one(oracle, packed, 0, 1 / 30, n_cap - 1, noise=noise, event_cap=512)
+    assert bits_equal(poses[: n + 1, 0], o["poses"]) and bits_equal(st["force"][0], o["extra"][-1, :, 2:])
+    print(f"device vs reference, crowd/{k} over 3,300 steps: max |pose error| = {err:.3e}")
+
+
 @pytest.mark.parametrize("si", [0, 1, 2, 3])
 def test_random_walk_closed_loops_match_reference(sga, oracle, si):
     """RandomWalk (pedestrian/random_walk.py:22-44) on the device, stream mode: closed loops of the reference's

@@ -28,6 +28,7 @@ GENERATORS = {
     "make_golden_all_scenarios": ["all_scenarios"],
     "make_golden_collision_types": ["collision_types"],
     "make_golden_json": ["json", "elevation"],
+    "make_golden_long": ["long"],
     "make_golden_mixed_peds": ["mixed_peds"],
     "make_golden_ped_noise": ["ped_noise"],
     "make_golden_ped_roads": ["ped_roads"],
