@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SG_ABI_VERSION 4 /* 2: sg_scenario_state.last_row_hi (scenarios of up to 512 entities); 3: sg_schedule_info replaces sg_pipeline_info; 4: sg_crowd_walk_stats removed */
+#define SG_ABI_VERSION 5 /* 2: sg_scenario_state.last_row_hi (scenarios of up to 512 entities); 3: sg_schedule_info replaces sg_pipeline_info; 4: sg_crowd_walk_stats removed; 5: sg_last_kernel */
 
 typedef enum {
     SG_OK = 0,
@@ -449,6 +449,12 @@ int sg_last_launch_gross_ms(sg_handle *h, float *kernel_ms_gross);
  * A persistent launch whose wavefronts wait longer than SG_QUEUE_TIMEOUT_MS (default 20000) for each other gives up instead
  * of hanging: the next synchronising call returns SG_ERR_HIP and says so. */
 int sg_schedule_info(sg_handle *h, int32_t *info);
+
+/* No reference counterpart (diagnostics): the entry point the handle launched last for a step loop -- "sg::rollout_kernel_crowd<4>",
+ * "sg::rollout_kernel_tabq_planar<64>", ... -- as a kernel trace of the call names it (without the return type and the argument
+ * list).  The string lives in the handle and changes with the next sg_step / sg_rollout / sg_tick.  bench.py reports it as
+ * roofline.kernel. */
+const char *sg_last_kernel(sg_handle *h);
 
 /* ScenarioGym.rollout (scenario_gym.py:256-267) of a batch whose entities are all replay entities / replay agents is a
  * pure function of the clock except for three ordered sums (State.distances, EgoAvgSpeed, the event list); PID / vehicle

@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SGYM_LIB") or os.path.join(HERE, "lib", "libsgym_hip.so")  # SGYM_LIB: A/B builds
 
 SG_OK = 0
-ABI_VERSION = 4
+ABI_VERSION = 5
 (KIND_NONE, KIND_REPLAY, KIND_AGENT_REPLAY, KIND_AGENT_PID, KIND_AGENT_VEHICLE, KIND_AGENT_PEDESTRIAN,
  KIND_AGENT_EXTERNAL) = range(7)
 TERM_MAX_LENGTH, TERM_COLLISION, TERM_EGO_COLLISION, TERM_EGO_OFF_ROAD = 1, 2, 4, 8
@@ -29,7 +29,7 @@ SYMBOLS = (
     "sg_version", "sg_last_error", "sg_create", "sg_destroy", "sg_upload", "sg_set_social_force", "sg_set_ped_models", "sg_set_ped_behaviour", "sg_set_ped_noise", "sg_reset",
     "sg_set_timestep", "sg_step", "sg_rollout", "sg_rollout_async", "sg_synchronize", "sg_stream",
     "sg_state_view_get", "sg_read_metrics", "sg_read_record", "sg_copy_to_host", "sg_last_kernel_ms",
-    "sg_last_launch_stats", "sg_last_launch_gross_ms", "sg_schedule_info", "sg_debug_trig32", "sg_set_tuning", "sg_set_slicing", "sg_set_external_poses", "sg_future_collision", "sg_raster_entities",
+    "sg_last_launch_stats", "sg_last_launch_gross_ms", "sg_schedule_info", "sg_last_kernel", "sg_debug_trig32", "sg_set_tuning", "sg_set_slicing", "sg_set_external_poses", "sg_future_collision", "sg_raster_entities",
     "sg_set_road_networks", "sg_raster_map", "sg_raster_map_device", "sg_reset_scenarios", "sg_terminal_flags", "sg_tick", "sg_set_collision_tolerance", "sg_read_collision_points", "sg_rss_update", "sg_rss_read", "sg_set_rss",
     "sg_group_create", "sg_group_destroy", "sg_group_size", "sg_group_handle", "sg_group_upload", "sg_group_rollout",
     "sg_group_read_metrics", "sg_group_last_error", "sg_host_alloc", "sg_host_free",
@@ -136,6 +136,8 @@ def load():
     lib = C.CDLL(LIB_PATH)
     H = C.c_void_p
     lib.sg_version.restype = C.c_int
+    lib.sg_last_kernel.restype = C.c_char_p
+    lib.sg_last_kernel.argtypes = [H]
     lib.sg_last_error.restype = C.c_char_p
     lib.sg_last_error.argtypes = [H]
     lib.sg_create.argtypes = [C.POINTER(SgConfig), C.POINTER(H)]
@@ -192,7 +194,7 @@ def load():
     lib.sg_raster_map_device.argtypes = [H, C.c_double, C.c_double, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]
     lib.sg_debug_trig32.argtypes = [H, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
     for name in SYMBOLS:
-        if name not in ("sg_last_error", "sg_stream", "sg_version", "sg_group_handle", "sg_group_last_error"):  # (pointers / strings)
+        if name not in ("sg_last_error", "sg_last_kernel", "sg_stream", "sg_version", "sg_group_handle", "sg_group_last_error"):  # (pointers / strings)
             getattr(lib, name).restype = C.c_int
     if lib.sg_version() != ABI_VERSION:
         raise RuntimeError(f"libsgym_hip.so ABI {lib.sg_version()} != binding {ABI_VERSION}")

@@ -107,6 +107,7 @@ struct sg_handle {
     // at yet (check_queue): a ring with one slot per launch, so that a second launch before the check cannot overwrite the
     // first one's code.  A give-up is STICKY: every later call that runs or reads the batch fails with its message until
     // sg_reset / sg_upload start the batch anew (the state is undefined in between).
+    char last_kernel[96] = {0};     // sg_last_kernel
     unsigned *q_host = nullptr;
     int q_head = 0, q_count = 0;    // next slot to use; launches not yet looked at
     bool q_failed = false;
@@ -473,6 +474,8 @@ static dim3 tab_grid(const sg_handle *h, const sg::TabGroups &tg)
 }
 
 // the rollout kernel family of this handle's batch (launchers: sgym_launch.hpp, one object per family)
+// the entry point the handle launched last for a step loop (sg_last_kernel): what a kernel trace of the call shows
+static void note_kernel(sg_handle *h, const char *fmt, int a = 0, int b = 0) { snprintf(h->last_kernel, sizeof h->last_kernel, fmt, a, b); }
 static void launch_variant(sg_handle *h, dim3 grid, int n_steps, int do_reset, int force, const double *d_actions,
                            const double *d_tab, bool use_tab, const sg::TabGroups &tg)
 {
@@ -483,37 +486,38 @@ static void launch_variant(sg_handle *h, dim3 grid, int n_steps, int do_reset, i
     if (WV == 8 && !h->has_ped && (h->cfg.terminal_mask & SG_TERM_EGO_OFF_ROAD)) { // 257..512 entities, ego_off_road
         // (RSSDistances + ego_off_road in one wide rollout: no fused variant at that width -- launch_rollout_impl and sg_tick clear
         // rss_fused for it and run the callback as a launch of its own behind every step: unfused_rss)
+        note_kernel(h, "sg::rollout_kernel_road<64, 8>");
         sgl::rollout_road(64, 8, grid, s, a);
         return;
     }
     if (WV == 8 && h->rss_fused && !h->has_ped) // 257..512 entities: the RSS callback inside the kernel, eight wavefronts
-        sgl::rollout_rss(64, 8, false, grid, s, a);
+        note_kernel(h, "sg::rollout_kernel_rss<64, 8>"), sgl::rollout_rss(64, 8, false, grid, s, a);
     else if (WV == 8 && h->has_ped) // 257..512 entities with pedestrian agents: the general pedestrian variant on eight wavefronts
-        sgl::rollout_ped(64, 8, false, grid, s, a);
+        note_kernel(h, "sg::rollout_kernel<64, 8, true, false>"), sgl::rollout_ped(64, 8, false, grid, s, a);
     else if (WV == 8) // ... vehicles and replay only (launch_rollout never takes the table path at this width)
-        sgl::rollout_plain(64, 8, false, grid, s, a);
+        note_kernel(h, "sg::rollout_kernel<64, 8, false, false>"), sgl::rollout_plain(64, 8, false, grid, s, a);
     else if (h->has_ped && h->all_ped && G == 64 && crowd_road_ok(h) && crowd_allowed(h) && !h->rss_fused)
-        sgl::rollout_crowd(WV, false, grid, s, a);
+        note_kernel(h, "sg::rollout_kernel_crowd<%d>", WV), sgl::rollout_crowd(WV, false, grid, s, a);
     else if (use_tab && h->has_ped && G == 64) // (launch_rollout: a crowd with riders, their table is d_tab)
-        sgl::rollout_crowd(WV, true, grid, s, at);
+        note_kernel(h, "sg::rollout_kernel_crowd_riders<%d>", WV), sgl::rollout_crowd(WV, true, grid, s, at);
     else if (h->has_ped && h->rss_fused)
-        sgl::rollout_ped(G, WV, true, grid, s, a);
+        note_kernel(h, "sg::rollout_kernel_rss_ped<%d, %d>", std::max(G, 16), WV), sgl::rollout_ped(G, WV, true, grid, s, a);
     else if (h->rss_fused && (h->cfg.terminal_mask & SG_TERM_EGO_OFF_ROAD))
-        sgl::rollout_rss(G, WV, true, grid, s, a);
+        note_kernel(h, "sg::rollout_kernel_rss_road<%d, %d>", G, WV), sgl::rollout_rss(G, WV, true, grid, s, a);
     else if (h->has_ped)
-        sgl::rollout_ped(G, WV, false, grid, s, a);
+        note_kernel(h, "sg::rollout_kernel<%d, %d, true, false>", std::max(G, 16), WV), sgl::rollout_ped(G, WV, false, grid, s, a);
     else if (h->rss_fused && use_tab && WV == 1) // (launch_rollout: the controlled lanes' poses come from the pre-pass table)
-        sgl::rollout_rss_tab(G, tab_grid(h, tg), s, h->p, h->cfg.timestep, force, tg);
+        note_kernel(h, "sg::rollout_kernel_rss_tab<%d>", G), sgl::rollout_rss_tab(G, tab_grid(h, tg), s, h->p, h->cfg.timestep, force, tg);
     else if (h->rss_fused)
-        sgl::rollout_rss(G, WV, false, grid, s, a);
+        note_kernel(h, "sg::rollout_kernel_rss<%d, %d>", G, WV), sgl::rollout_rss(G, WV, false, grid, s, a);
     else if (h->cfg.terminal_mask & SG_TERM_EGO_OFF_ROAD)
-        sgl::rollout_road(G, WV, grid, s, a);
+        note_kernel(h, "sg::rollout_kernel_road<%d, %d>", G, WV), sgl::rollout_road(G, WV, grid, s, a);
     else if (use_tab && WV == 1 && h->n_ctl > 0)
-        sgl::rollout_tab(G, h->planar, tab_grid(h, tg), s, h->p, h->cfg.timestep, force, tg);
+        note_kernel(h, h->planar ? "sg::rollout_kernel_tab_planar<%d>" : "sg::rollout_kernel_tab<%d>", G), sgl::rollout_tab(G, h->planar, tab_grid(h, tg), s, h->p, h->cfg.timestep, force, tg);
     else if (use_tab)
-        sgl::rollout_plain(G, WV, true, grid, s, at);
+        note_kernel(h, "sg::rollout_kernel<%d, %d, false, true>", G, WV), sgl::rollout_plain(G, WV, true, grid, s, at);
     else
-        sgl::rollout_plain(G, WV, false, grid, s, a);
+        note_kernel(h, "sg::rollout_kernel<%d, %d, false, false>", G, WV), sgl::rollout_plain(G, WV, false, grid, s, a);
 }
 
 static int get_event(sg_handle *h, size_t idx, hipEvent_t *out)
@@ -598,6 +602,7 @@ static int launch_wide(sg_handle *h, int n_steps, int do_reset, int force, const
         wa.force = force;
         wa.actions = acts;
         wa.no_peds = h->has_ped ? 0 : 1;
+        note_kernel(h, "sg::wide_move_kernel + wide_commit_kernel + wide_collide_kernel + wide_finish_kernel");
         sgl::wide_step(ge, gs, h->stream, h->p, h->cfg.timestep, wa, !h->has_ped);
     };
     // sg_set_rss at this width: RSSDistances.__call__ as a launch of its own after the reset and after every step
@@ -801,6 +806,7 @@ static int launch_queue(sg_handle *h, int n_steps, int force, const double *d_ac
         HIP_TRY(h, hipStreamSynchronize(ws));
     }
     HIP_TRY(h, hipEventRecord(e0, h->stream));
+    note_kernel(h, rss ? "sg::rollout_kernel_rss_tabq<%d>" : (h->planar ? "sg::rollout_kernel_tabq_planar<%d>" : "sg::rollout_kernel_tabq<%d>"), h->G);
     if (rss) sgl::rollout_rss_tabq(h->G, dim3(grid), h->stream, h->p, h->cfg.timestep, force, tq);
     else sgl::rollout_tabq(h->G, h->planar, dim3(grid), h->stream, h->p, h->cfg.timestep, force, tq);
     HIP_TRY(h, hipGetLastError());
@@ -1071,6 +1077,7 @@ static int launch_rollout_impl(sg_handle *h, int n_steps, int do_reset, int forc
 // states are not written anywhere.
 static void launch_slice_kernels(sg_handle *h, const Params &ps, const sg::SliceArgs &sa, dim3 grid, const double *tab)
 {
+    note_kernel(h, tab ? "sg::rollout_kernel_slice_tab<%d>" : "sg::rollout_kernel_slice<%d>", h->G);
     sgl::rollout_slice(h->G, grid, h->stream, ps, h->cfg.timestep, sa, tab);
 }
 static void launch_fixup_kernel(sg_handle *h, const Params &ps, const sg::SliceArgs &sa)
@@ -2248,6 +2255,8 @@ extern "C" int sg_last_launch_stats(sg_handle *h, int32_t *n_launches, float *ke
     *kernel_ms_total = total;
     return SG_OK;
 }
+
+extern "C" const char *sg_last_kernel(sg_handle *h) { return h ? h->last_kernel : ""; }
 
 extern "C" int sg_schedule_info(sg_handle *h, int32_t *info)
 {

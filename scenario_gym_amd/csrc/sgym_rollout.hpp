@@ -903,7 +903,9 @@ __device__ __forceinline__ void rollout_body_l(
                 }
             }
             stf(dy, SG_F_DIST, dist);
-            stf(dy, SG_F_PRESENT, (uint64_t)present);
+            // (the presence row changes when an entity enters or leaves the scene: a wavefront in which nobody did holds
+            // the row it would store -- memory stays the exact step-materialised state, one store instruction less)
+            if (SLICE || sg_any(present != was_present)) stf(dy, SG_F_PRESENT, (uint64_t)present);
             }
             if (PED && kind == SG_KIND_AGENT_PEDESTRIAN) {
                 stf(dy, SG_F_FORCE + 0, fpx);
@@ -938,8 +940,10 @@ __device__ __forceinline__ void rollout_body_l(
         if (run) {
 #pragma unroll
             for (int w = 0; w < WV; ++w) {
+                // (likewise the collision row: stored when it differs from the stored one in some lane of the wavefront)
+                const bool row_moved = SLICE || sg_any(nrow[w] != row[w]);
                 row[w] = nrow[w];
-                if (!SLICE || (sa.mode == 1 && !warm)) stf(dy, SG_F_COLL + w, row[w]);
+                if ((!SLICE || (sa.mode == 1 && !warm)) && row_moved) stf(dy, SG_F_COLL + w, row[w]);
             }
         }
 

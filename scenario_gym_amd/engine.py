@@ -408,6 +408,10 @@ class RolloutEngine:
         self._check(self.lib.sg_schedule_info(self.h, v), "sg_schedule_info")
         return dict(schedule=v[0], chunks=v[1], ring=v[2], grid=v[3], ctl_waves=v[4], blocks=v[5], simds=v[6], launches=v[7])
 
+    def last_kernel(self):
+        """The rollout entry point the handle launched last (sg_last_kernel), e.g. "sg::rollout_kernel_crowd<4>"."""
+        return (self.lib.sg_last_kernel(self.h) or b"").decode()
+
     def debug_trig32(self, heading):
         """The broad phase's fp32 (sin, cos) of fp64 headings (test hook)."""
         h = np.ascontiguousarray(heading, np.float64).ravel()

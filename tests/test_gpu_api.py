@@ -1384,6 +1384,38 @@ def test_rccl_initialised_first_then_the_persistent_launch(tmp_path):
     print(f"persistent launch: {plain['value'] / 1e9:.1f} G alone, {rccl['value'] / 1e9:.1f} G with RCCL initialised first")
 
 
+def test_library_names_the_kernel_it_launched(monkeypatch):
+    """roofline.kernel in bench.py's line is what the library says it launched (sg_last_kernel), not what the shape implies:
+    the persistent table launch and its chunk-launch fallback, the crowd kernel and the general pedestrian kernel it falls
+    back to, the time-sliced replay."""
+    import scenario_gym_amd as sga
+    import scenario_gym_amd._lib as L
+    from scenario_gym_amd import synthetic
+
+    def name(packed, steps, **env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        eng = sga.RolloutEngine(packed.n_scenarios, packed.n_entities)
+        eng.upload(packed)
+        eng.rollout(steps)
+        n = eng.last_kernel()
+        eng.close()
+        for k in env:
+            monkeypatch.delenv(k)
+        return n
+
+    pid = synthetic.make_batch(128, 64, n_steps=300, ego_kind=L.KIND_AGENT_PID)
+    assert name(pid, 300) == "sg::rollout_kernel_tabq_planar<64>"
+    assert name(pid, 300, SG_QUEUE="0") == "sg::rollout_kernel_tab_planar<64>"
+    assert name(pid, 300, SG_PLANAR="0") == "sg::rollout_kernel_tabq<64>"
+    assert name(pid, 4) == "sg::rollout_kernel<64, 1, false, false>"  # (a short call keeps its controllers in the kernel)
+    crowd = synthetic.make_crowd(8, 200, n_steps=100)
+    assert name(crowd, 100) == "sg::rollout_kernel_crowd<4>"
+    assert name(crowd, 100, SG_CROWD_KERNEL="0") == "sg::rollout_kernel<64, 4, true, false>"
+    replay = synthetic.make_batch(64, 16, n_steps=400, ego_kind=L.KIND_AGENT_REPLAY)
+    assert name(replay, 400) in ("sg::rollout_kernel_slice<16>", "sg::rollout_kernel<16, 1, false, true>")
+
+
 def test_bench_line_carries_every_single_gpu_config(tmp_path):
     """The driver times ONE `python bench.py` line: besides the c3 headline it carries the other single-GPU BASELINE configs -- c2
     (256 x 16 replay, the state of every step materialised) and c5 (1024 x 256 crowd) -- each with its own timed passes, roofline
