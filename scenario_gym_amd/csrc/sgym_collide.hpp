@@ -301,6 +301,7 @@ __device__ __forceinline__ void tile_collisions(bool present, const double *pose
 #pragma unroll
     for (int w = 0; w < WV; ++w) fuzzy[w] = 0;
     bool any_fuzzy = false;
+    const float eps_own = __builtin_fmaf(1.9073486e-6f, mag, 1e-3f + trig_eps); // this lane's share of the margin (the candidate adds its own)
     if (sg_any(any_cand)) {
 #pragma unroll
         for (int w = 0; w < WV; ++w) {
@@ -309,17 +310,20 @@ __device__ __forceinline__ void tile_collisions(bool present, const double *pose
                     const int jl = __builtin_ctzll(cand[w]);
                     cand[w] &= cand[w] - 1;
                     const int j = tile0 + w * 64 + jl;
-                    float2 oc = make_float2(L.cx[j], L.cy[j]), os = L.sc[j], oh = L.half[j];
+                    const float2 oc = L.cen[j], os = L.sc[j], oh = L.half[j];
                     float dx = oc.x - fx, dy = oc.y - fy;
-                    float cd = __builtin_fabsf(fc * os.y + fs * os.x);  // |cos(delta heading)|
-                    float sd = __builtin_fabsf(fs * os.y - fc * os.x);  // |sin(delta heading)|
-                    float g0 = __builtin_fabsf(dx * fc + dy * fs) - (hl + oh.x * cd + oh.y * sd);
-                    float g1 = __builtin_fabsf(dy * fc - dx * fs) - (hw + oh.x * sd + oh.y * cd);
-                    float g2 = __builtin_fabsf(dx * os.y + dy * os.x) - (oh.x + hl * cd + hw * sd);
-                    float g3 = __builtin_fabsf(dy * os.y - dx * os.x) - (oh.y + hl * sd + hw * cd);
+                    // (explicit fused multiply-adds: the filter only has to be conservative inside `eps`, which dwarfs an fp32
+                    // rounding either way -- 38 instead of 54 instructions per candidate; whatever it leaves undecided the fp64
+                    // test decides, so no output depends on this arithmetic)
+                    float cd = __builtin_fabsf(__builtin_fmaf(fc, os.y, fs * os.x));   // |cos(delta heading)|
+                    float sd = __builtin_fabsf(__builtin_fmaf(fs, os.y, -(fc * os.x))); // |sin(delta heading)|
+                    float g0 = __builtin_fabsf(__builtin_fmaf(dx, fc, dy * fs)) - __builtin_fmaf(oh.y, sd, __builtin_fmaf(oh.x, cd, hl));
+                    float g1 = __builtin_fabsf(__builtin_fmaf(dy, fc, -(dx * fs))) - __builtin_fmaf(oh.y, cd, __builtin_fmaf(oh.x, sd, hw));
+                    float g2 = __builtin_fabsf(__builtin_fmaf(dx, os.y, dy * os.x)) - __builtin_fmaf(hw, sd, __builtin_fmaf(hl, cd, oh.x));
+                    float g3 = __builtin_fabsf(__builtin_fmaf(dy, os.y, -(dx * os.x))) - __builtin_fmaf(hw, cd, __builtin_fmaf(hl, sd, oh.y));
                     float gap = __builtin_fmaxf(__builtin_fmaxf(g0, g1), __builtin_fmaxf(g2, g3));
                     // fp32 rounding of the centres + trig_eps: the hardware sin/cos error on every product
-                    float eps = 1e-3f + 1.9073486e-6f * (mag + __builtin_fabsf(oc.x) + __builtin_fabsf(oc.y)) + trig_eps;
+                    float eps = __builtin_fmaf(1.9073486e-6f, __builtin_fabsf(oc.x) + __builtin_fabsf(oc.y), eps_own);
                     // an absent slot has NaN centres: gap is NaN, neither branch below fires
                     bool unsure = (gap <= eps) && (gap >= -eps);
                     unsure = unsure || (dx == 0.0f && dy == 0.0f); // possibly bit-identical boxes

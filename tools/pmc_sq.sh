@@ -4,8 +4,8 @@
 # the crowd's instruction mix changes over the rollout, bench.py multiplies these by the wave-steps / s of the same rollout).
 tag=${1:-x}; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" && mkdir -p gpurun_out
-timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_SMEM --output-format csv -d gpurun_out/${tag}_pmc_sq -o p -- python3 bench.py --no-cpu-baseline "$@" --steps 1 --warmup 0 > gpurun_out/${tag}_pmc_sq.log 2>&1
-timeout 300 rocprofv3 --pmc SQ_INSTS_BRANCH SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_SCA SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_BUSY_CYCLES --output-format csv -d gpurun_out/${tag}_pmc_sq_b -o p -- python3 bench.py --no-cpu-baseline "$@" --steps 1 --warmup 0 > gpurun_out/${tag}_pmc_sq_b.log 2>&1
+timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_SMEM --output-format csv -d gpurun_out/${tag}_pmc_sq -o p -- python3 bench.py --no-cpu-baseline --no-configs "$@" --steps 1 --warmup 0 > gpurun_out/${tag}_pmc_sq.log 2>&1
+timeout 300 rocprofv3 --pmc SQ_INSTS_BRANCH SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_SCA SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_BUSY_CYCLES --output-format csv -d gpurun_out/${tag}_pmc_sq_b -o p -- python3 bench.py --no-cpu-baseline --no-configs "$@" --steps 1 --warmup 0 > gpurun_out/${tag}_pmc_sq_b.log 2>&1
 python3 - "$tag" <<'PY'
 import csv, glob, json, sys, collections
 tag = sys.argv[1]

@@ -13,6 +13,8 @@ bash tools/profile_round.sh ${tag}_c2s --workload c2s --steps 5 --warmup 1
 bash tools/profile_round.sh ${tag}_c3rss --workload c3rss --steps 3 --warmup 1
 bash tools/profile_round.sh ${tag}_c3s --workload c3s --steps 5 --warmup 1
 bash tools/profile_round.sh ${tag}_c5mix --workload c5mix --steps 1 --warmup 1
+bash tools/profile_round.sh ${tag}_c5roads --workload c5roads --steps 1 --warmup 1
+SG_CROWD_ROADS=0 python3 bench.py --workload c5roads --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/${tag}_c5roads_general_bench.json 2>/dev/null
 SG_CROWD_RIDERS=0 python3 bench.py --workload c5mix --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/${tag}_c5mix_general_bench.json 2>/dev/null
 python3 bench.py --workload e2e > gpurun_out/${tag}_e2e_bench.json 2> gpurun_out/${tag}_e2e.err
 for R in 512 1024 2048; do python3 bench.py --scenarios $R --steps 10 --warmup 2 --no-cpu-baseline > gpurun_out/${tag}_shard_${R}_bench.json 2>/dev/null; python3 bench.py --workload c3s --scenarios $R --steps 10 --warmup 2 --no-cpu-baseline > gpurun_out/${tag}_c3s_${R}_bench.json 2>/dev/null; done
@@ -28,6 +30,7 @@ python3 bench.py --workload c2s --steps 5 --warmup 1 > gpurun_out/${tag}_c2s_ben
 python3 bench.py --workload c3rss --steps 3 --warmup 1 > gpurun_out/${tag}_c3rss_bench.json 2>/dev/null
 python3 bench.py --workload c3s --steps 5 --warmup 1 > gpurun_out/${tag}_c3s_bench.json 2>/dev/null
 python3 bench.py --workload c5mix --steps 1 --warmup 1 > gpurun_out/${tag}_c5mix_bench.json 2>/dev/null
+python3 bench.py --workload c5roads --steps 1 --warmup 1 > gpurun_out/${tag}_c5roads_bench.json 2>/dev/null
 SG_PLANAR=0 python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/${tag}_nonplanar_bench.json 2>/dev/null
 SG_QUEUE=0 python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/${tag}_chunk_launches_bench.json 2>/dev/null
 python3 tools/dbg/queue_timeline.py > gpurun_out/${tag}_queue_timeline.txt 2>&1

@@ -11,10 +11,10 @@ tag=${1:-r01}; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" && mkdir -p gpurun_out
 python3 bench.py "$@" > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
 cut -c1-300 gpurun_out/${tag}_bench.json
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_trace -o t -- python3 bench.py --no-cpu-baseline "$@" > gpurun_out/${tag}_bench_under_trace.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_trace -o t -- python3 bench.py --no-cpu-baseline --no-configs "$@" > gpurun_out/${tag}_bench_under_trace.log 2>&1
 f=$(find gpurun_out/${tag}_trace -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/${tag}_kernel_stats.csv
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --pmc $c --output-format csv -d gpurun_out/${tag}_pmc_$c -o p -- python3 bench.py --no-cpu-baseline "$@" --steps 1 --warmup 0 > gpurun_out/${tag}_pmc_$c.log 2>&1
+  timeout 600 rocprofv3 --pmc $c --output-format csv -d gpurun_out/${tag}_pmc_$c -o p -- python3 bench.py --no-cpu-baseline --no-configs "$@" --steps 1 --warmup 0 > gpurun_out/${tag}_pmc_$c.log 2>&1
 done
 python3 - "$tag" <<'PY'
 import csv, glob, json, sys
