@@ -54,6 +54,7 @@ struct sg_handle {
     bool crowd_riders = false; // a crowd (64-lane tiles) whose other lanes are replay entities / replay agents / PID / vehicle agents:
                                // rollout_kernel_crowd_riders + control_kernel_riders (env SG_CROWD_RIDERS=0: the general variant)
     int crowd_kernel = 1;     // env SG_CROWD_KERNEL=0: all-pedestrian batches take the general pedestrian variant too
+    bool crowd_models = true, models_all_sf = true; // env SG_CROWD_MODELS; every model of sg_set_ped_models is a SocialForce
     sg_social_force sf{};
     int ped_behaviour = 0;        // sg_set_ped_behaviour
     int n_ped_models = 0;         // sg_set_ped_models: > 1 = the batch mixes behaviour models / parameter sets
@@ -158,7 +159,11 @@ struct sg_handle {
 static bool rss_live(const sg_handle *h) { return h->d_rss_state && !h->rss_stale; }
 
 // the crowd variants (rollout_kernel_crowd / _riders, the walker kernels) hold the social force model alone
-static bool crowd_allowed(const sg_handle *h) { return h->crowd_kernel && h->ped_behaviour == SG_PED_SOCIAL_FORCE && h->n_ped_models <= 1; }
+// (several models: a pass of the force code per model, as the general variant does it -- up to four, SocialForce all of them)
+static bool crowd_allowed(const sg_handle *h)
+{
+    return h->crowd_kernel && h->ped_behaviour == SG_PED_SOCIAL_FORCE && (h->n_ped_models <= 1 || (h->n_ped_models <= 4 && h->models_all_sf && h->crowd_models));
+}
 
 static int env_int(const char *name, int dflt)
 {
@@ -358,6 +363,7 @@ extern "C" int sg_create(const sg_config *cfg, sg_handle **out)
     h->ctl_slice = std::max(1, env_int("SG_CTL_SLICE", h->ctl_slice));
     h->ped_serial = env_int("SG_PED_SERIAL", 0) != 0;
     h->crowd_kernel = env_int("SG_CROWD_KERNEL", 1);
+    h->crowd_models = env_int("SG_CROWD_MODELS", 1) != 0; // (0: batches with several pedestrian models keep to the general variant; the tests compare)
     h->slice_mode = env_int("SG_SLICE", 1);
     h->queue_mode = env_int("SG_QUEUE", 1);
     // the controller stream carries the serial chain of the table path (control_kernel_fast: 64 wavefronts that every rollout
@@ -497,7 +503,8 @@ static void launch_variant(sg_handle *h, dim3 grid, int n_steps, int do_reset, i
     else if (WV == 8) // ... vehicles and replay only (launch_rollout never takes the table path at this width)
         note_kernel(h, "sg::rollout_kernel<64, 8, false, false>"), sgl::rollout_plain(64, 8, false, grid, s, a);
     else if (h->has_ped && h->all_ped && G == 64 && crowd_road_ok(h) && crowd_allowed(h) && !h->rss_fused)
-        note_kernel(h, "sg::rollout_kernel_crowd<%d>", WV), sgl::rollout_crowd(WV, false, grid, s, a);
+        note_kernel(h, h->n_ped_models > 1 ? "sg::rollout_kernel_crowd_models<%d>" : "sg::rollout_kernel_crowd<%d>", WV),
+            sgl::rollout_crowd(WV, false, grid, s, a, h->n_ped_models > 1);
     else if (use_tab && h->has_ped && G == 64) // (launch_rollout: a crowd with riders, their table is d_tab)
         note_kernel(h, "sg::rollout_kernel_crowd_riders<%d>", WV), sgl::rollout_crowd(WV, true, grid, s, at);
     else if (h->has_ped && h->rss_fused)
@@ -1318,6 +1325,8 @@ extern "C" int sg_set_ped_models(sg_handle *h, int32_t n_models, const sg_ped_mo
     h->p.ped_behaviour = h->ped_behaviour;
     if (h->noise_mode != SG_NOISE_OFF) { h->noise_std[0] = models[0].std_lon; h->noise_std[1] = models[0].std_lat; }
     h->n_ped_models = n_models;
+    h->models_all_sf = true;
+    for (int m = 0; m < n_models; ++m) h->models_all_sf = h->models_all_sf && models[m].behaviour == SG_PED_SOCIAL_FORCE;
     if (n_models > 1) {
         std::vector<double> rows((size_t)n_models * sg::PM_W, 0.0);
         for (int m = 0; m < n_models; ++m) {
@@ -1423,7 +1432,8 @@ extern "C" int sg_upload(sg_handle *h, const sg_scenarios *sc)
     }
     if (h->has_ped && h->WV == 1 && h->G < 16) { h->G = 16; h->EP = 16; h->NE = (((size_t)h->R * h->EP + 63) / 64) * 64; }
     h->crowd_riders = false;
-    if (h->has_ped && !h->all_ped && h->G == 64 && h->WV <= 4 && crowd_allowed(h) && env_int("SG_CROWD_RIDERS", 1) != 0) {
+    if (h->has_ped && !h->all_ped && h->G == 64 && h->WV <= 4 && crowd_allowed(h) && h->n_ped_models <= 1 /* (the riders variant knows one model) */ &&
+        env_int("SG_CROWD_RIDERS", 1) != 0) {
         bool ok = true; // pedestrian agents of catalog type Pedestrian, and nothing the pre-pass cannot ride for
         for (size_t i = 0; i < (size_t)h->R * h->E && ok; ++i)
             ok = sc->kind[i] == SG_KIND_AGENT_PEDESTRIAN ? sc->etype[i] == 1 : sc->kind[i] != SG_KIND_AGENT_EXTERNAL;

@@ -26,8 +26,8 @@ void rollout_plain(int G, int WV, bool tab, dim3 grid, hipStream_t s, const Roll
 // k_ped.hip: rollout_kernel<max(G, 16), WV, true, false> / rollout_kernel_rss_ped (rss)
 void rollout_ped(int G, int WV, bool rss, dim3 grid, hipStream_t s, const RolloutArgs &a);
 void rollout_ped_rss(int G, int WV, dim3 grid, hipStream_t s, const RolloutArgs &a); // (k_ped_rss.hip, through rollout_ped)
-// k_crowd.hip: rollout_kernel_crowd<WV> / rollout_kernel_crowd_riders<WV>
-void rollout_crowd(int WV, bool riders, dim3 grid, hipStream_t s, const RolloutArgs &a);
+// k_crowd.hip: rollout_kernel_crowd<WV> / rollout_kernel_crowd_models<WV> / rollout_kernel_crowd_riders<WV>
+void rollout_crowd(int WV, bool riders, dim3 grid, hipStream_t s, const RolloutArgs &a, bool models = false);
 // k_wide.hip (sgym_wide.hpp): one step (mode 0) or State.reset (mode 1 / 2) of scenarios of more than 512 entities, four kernels
 void wide_step(dim3 grid_entities, dim3 grid_scenarios, hipStream_t s, const sg::Params &p, double timestep, const sg::WideArgs &wa,
                bool no_peds /* move + commit as one launch */);

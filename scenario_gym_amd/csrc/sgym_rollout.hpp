@@ -80,7 +80,7 @@ struct SliceArgs {
 // control_kernel launches that run ahead of the slices -- so a slice that starts at step a finds its lanes' poses there
 // like everything else it needs in the clock.
 template <int G, int WV, bool PED, bool TAB, bool HAST, bool ROAD = false, bool RSSV = false, bool CROWD = false, bool SLICE = false,
-          bool PLANAR = false, bool RIDERS = false, bool CTAB = false>
+          bool PLANAR = false, bool RIDERS = false, bool CTAB = false, bool MODELS = !CROWD>
 __device__ __forceinline__ void rollout_body_l(
     TileLds<64 * WV, PED, CROWD> &lds /* the workgroup's LDS tile: the entry point owns it (rollout_kernel_tabq shares it between roles) */,
     const Params &p, double timestep, int n_steps, int do_reset, int force, const double *actions /*[n][R][2]*/,
@@ -188,12 +188,12 @@ __device__ __forceinline__ void rollout_body_l(
     }
     // CROWD: may this wavefront use crowd_pairs at all?  Default head rotation in every lane, a radius and parameters inside
     // the guards of crowd_pair (wave-uniform, fixed for the launch); the per-step guards are voted in tile_collisions.
-    bool crowd_static_ok = false;
+    bool crowd_static_ok = false, crowd_geom_ok = false; // (geometry: the lanes' own rows; static: + the parameters of model 0)
     CrowdConsts CC{};
     if (CROWD) {
         const double rr = fld(st, ST_CTRL + SG_C_PED_RADIUS), hr = fld(st, ST_CTRL + SG_C_PED_HEAD_ROT);
-        crowd_static_ok = sg_all(kind != SG_KIND_AGENT_PEDESTRIAN || (hr == 0.0 && rr > 0.0 && rr < 0x1p20)) &&
-                          crowd_params_ok(p.sf) && !p.ped_serial;
+        crowd_geom_ok = sg_all(kind != SG_KIND_AGENT_PEDESTRIAN || (hr == 0.0 && rr > 0.0 && rr < 0x1p20)) && !p.ped_serial;
+        crowd_static_ok = crowd_geom_ok && crowd_params_ok(p.sf);
         const RecipDiv rs(p.sf.ped_repulse_sigma);
         CC.k2_scale = p.sf.ped_repulse_V / p.sf.ped_repulse_sigma;
         CC.sig_b = rs.b;
@@ -635,7 +635,9 @@ __device__ __forceinline__ void rollout_body_l(
         double ped_fx = 0.0, ped_fy = 0.0, ped_vdes = 0.0;
         PedMoveModel pmm = ped_move_model(p); // what ped_move reads of the behaviour model: this lane's, where the batch mixes models
         double nstd_lon = p.noise_std_lon, nstd_lat = p.noise_std_lat;
-        if (PED && !CROWD && p.n_ped_models > 1) {
+        // (MODELS: compiled in for every general pedestrian variant, and for the crowd variant as an entry point of its own --
+        // rollout_kernel_crowd_models: the one-model crowd kernel has no register to spare for a second copy of the force code)
+        if (PED && MODELS && p.n_ped_models > 1) {
             // Per-agent behaviour models (sg_set_ped_models; pedestrian/agent.py:18-41): the force on a pedestrian is computed with
             // ITS model's parameters from its neighbours' states, so the tile's pedestrians step model by model -- one pass of
             // the (wave-collective) force code per model that has a stepping pedestrian in the tile, everybody else sitting
@@ -649,14 +651,27 @@ __device__ __forceinline__ void rollout_body_l(
             sg_loads_done();
             for (int m = 0; m < p.n_ped_models; ++m) {
                 const bool mine = stepping && my_model == m;
-                if (!block_any<WV>(mine)) continue; // (workgroup-uniform)
+                // (the crowd variants' force code is collective over the WAVEFRONT only: no workgroup vote)
+                if (CROWD ? !sg_any(mine) : !block_any<WV>(mine)) continue; // (wavefront- / workgroup-uniform)
                 Params q = p;
                 const double *row = p.ped_models + (size_t)m * PM_W;
                 q.ped_behaviour = (int)row[PM_BEHAVIOUR];
                 q.sf = *reinterpret_cast<const sg_social_force *>(row + PM_SF);
                 bool go_m = false;
                 double fx_m = 0.0, fy_m = 0.0, vdes_m = 0.0;
-                ped_force<WV, false>(q, lds, (int)r, sl, tile0, nbr, mine, pose, velx, vely, wp, nwp, goal_idx, go_m, fx_m, fy_m, vdes_m, K);
+                if (CROWD) { // this model's constants of crowd_pair; its parameters inside the guards, or the general pair code
+                    CrowdConsts CM;
+                    const RecipDiv rsm(q.sf.ped_repulse_sigma);
+                    CM.k2_scale = q.sf.ped_repulse_V / q.sf.ped_repulse_sigma;
+                    CM.sig_b = rsm.b;
+                    CM.sig_r = rsm.r;
+                    CM.cos_sight = q.sf.cos_sight;
+                    CM.sight_weight = q.sf.sight_weight;
+                    CM.k3 = 2 * q.sf.ped_attract_C;
+                    ped_force<WV, CROWD>(q, lds, (int)r, sl, tile0, nbr, mine, pose, velx, vely, wp, nwp, goal_idx, go_m, fx_m, fy_m, vdes_m, K,
+                                         crowd_geom_ok && crowd_params_ok(q.sf) && crowd_ok, CM, &ptm);
+                } else
+                    ped_force<WV, false>(q, lds, (int)r, sl, tile0, nbr, mine, pose, velx, vely, wp, nwp, goal_idx, go_m, fx_m, fy_m, vdes_m, K);
                 if (mine) { ped_go = go_m; ped_fx = fx_m; ped_fy = fy_m; ped_vdes = vdes_m; }
             }
         } else if (PED) // the social force of every stepping pedestrian of the wavefront (wave-collective)
@@ -1157,13 +1172,13 @@ __device__ __forceinline__ void rollout_body_l(
 
 // the ordinary form: the LDS tile belongs to this call
 template <int G, int WV, bool PED, bool TAB, bool HAST, bool ROAD = false, bool RSSV = false, bool CROWD = false, bool SLICE = false,
-          bool PLANAR = false, bool RIDERS = false, bool CTAB = false>
+          bool PLANAR = false, bool RIDERS = false, bool CTAB = false, bool MODELS = !CROWD>
 __device__ __forceinline__ void rollout_body(
     const Params &p, double timestep, int n_steps, int do_reset, int force, const double *actions, const double *tab,
     const SliceArgs &sa = SliceArgs{}, const unsigned bx_arg = ~0u)
 {
     __shared__ TileLds<64 * WV, PED, CROWD> lds;
-    rollout_body_l<G, WV, PED, TAB, HAST, ROAD, RSSV, CROWD, SLICE, PLANAR, RIDERS, CTAB>(lds, p, timestep, n_steps, do_reset, force, actions, tab,
+    rollout_body_l<G, WV, PED, TAB, HAST, ROAD, RSSV, CROWD, SLICE, PLANAR, RIDERS, CTAB, MODELS>(lds, p, timestep, n_steps, do_reset, force, actions, tab,
                                                                                        sa, bx_arg);
 }
 
@@ -1205,6 +1220,14 @@ __global__ __launch_bounds__(64 * WV, SG_WAVES_PER_SIMD_PED) void rollout_kernel
     Params p, double timestep, int n_steps, int do_reset, int force, const double *actions, const double *tab)
 {
     rollout_body<64, WV, true, false, false, false, false, true>(p, timestep, n_steps, do_reset, force, actions, tab);
+}
+
+// ... whose pedestrians follow up to four social-force models (sg_set_ped_models): a pass of the force code per model
+template <int WV>
+__global__ __launch_bounds__(64 * WV, SG_WAVES_PER_SIMD_PED) void rollout_kernel_crowd_models(
+    Params p, double timestep, int n_steps, int do_reset, int force, const double *actions, const double *tab)
+{
+    rollout_body<64, WV, true, false, false, false, false, true, false, false, false, false, true>(p, timestep, n_steps, do_reset, force, actions, tab);
 }
 
 // ... with riders: lanes of other kinds whose poses come from the pre-pass table (see rollout_body, RIDERS)

@@ -458,6 +458,60 @@ def test_ped_models_on_the_device_equal_the_oracle(oracle):
         assert np.nanmax(np.abs(finals[0] - finals[1])) > 1e-2
 
 
+def test_crowd_kernel_with_several_pedestrian_models(oracle, monkeypatch):
+    """All-pedestrian batches whose pedestrians follow several SocialForce parameter sets (PedestrianAgent(entity, route, speed,
+    behaviour): pedestrian/agent.py:18-41) stay on the crowd kernel: a pass of the force code per model with that model's
+    constants (rollout_kernel_crowd_models<2 | 4>).  Same bits as the general pedestrian variant (SG_CROWD_MODELS=0) and as the
+    oracle's per-agent models, with the counter-based noise; a model with an attraction term falls back to the general pair code
+    inside the crowd kernel; a RandomWalk among the models sends the batch to the general variant."""
+    import scenario_gym_amd as sga
+    from oracle import check
+    from scenario_gym_amd import synthetic
+
+    models = [dict(std_lon=0.05, std_lat=0.02),
+              dict(relaxation_time=0.8, ped_repulse_V=2.5, ped_repulse_sigma=0.6, sight_weight=0.3, sight_angle=160,
+                   max_speed_factor=1.1, bias_lon=0.05, bias_lat=-0.02, std_lon=0.02, std_lat=0.1),
+              dict(ped_repulse_V=1.4, ped_attract_C=0.002, std_lon=0.0, std_lat=0.0),  # (attraction: outside crowd_pair's shortcuts)
+              dict(relaxation_time=0.3, ped_repulse_sigma=0.35, sight_weight_use=False, std_lon=0.01, std_lat=0.01)]
+    rows = []
+    for m in models:
+        d = {k: v for k, v in m.items() if k not in ("behaviour", "std_lon", "std_lat")}
+        rows.append(oracle.ped_model_row("social_force", oracle.social_force_params(**d), m["std_lon"], m["std_lat"]))
+    rows = np.array(rows)
+    dt = 1 / 30
+    for R, E, side, steps in ((8, 120, 22.0, 260), (6, 230, 32.0, 240)):
+        packed = synthetic.make_crowd(R, E, n_steps=steps, side=side)
+        model_of = np.random.default_rng(E).integers(0, len(models), R * E).astype(np.int32)
+        out = []
+        for crowd in ("1", "0"):
+            monkeypatch.setenv("SG_CROWD_MODELS", crowd)
+            eng = sga.RolloutEngine(R, E, timestep=dt, terminal_conditions=["max_length"], event_capacity=128)
+            eng.set_ped_models(models, model_of, noise="device", noise_seed=3)
+            eng.upload(packed)
+            eng.rollout(steps)
+            st = eng.state()
+            rws, evs = eng.metrics()
+            out.append((st, rws, evs, eng.last_kernel()))
+            if crowd == "1":
+                for r in range(R):
+                    o = check.oracle_final(packed, r, dt, steps, event_cap=128, noise=dict(mode="device", std_lon=0.0, std_lat=0.0, seed=3, scenario_index=r),
+                                           models=rows, model_of=model_of[r * E:(r + 1) * E])
+                    bad = check.compare_final(st, rws, evs, r, o, E, event_cap=128, ped=True, kind=packed.kind[r * E:(r + 1) * E])
+                    assert not bad, (E, r, bad)
+            eng.close()
+        (sa, ra, ea, ka), (sb, rb, eb, kb) = out
+        assert ka == f"sg::rollout_kernel_crowd_models<{2 if E <= 128 else 4}>" and kb == f"sg::rollout_kernel<64, {2 if E <= 128 else 4}, true, false>", (ka, kb)
+        for k in ("poses", "vels", "dists", "force", "ctrl_state"):
+            assert bits_equal(sa[k], sb[k]), k
+        assert np.array_equal(sa["coll"], sb["coll"]) and ra.tobytes() == rb.tobytes() and ea.tobytes() == eb.tobytes()
+    eng = sga.RolloutEngine(4, 100, timestep=dt)
+    eng.set_ped_models(models[:1] + [dict(behaviour="random_walk", std_lon=0.1, std_lat=0.1)], np.zeros(400, np.int32), noise="device")
+    eng.upload(synthetic.make_crowd(4, 100, n_steps=30, side=20.0))
+    eng.rollout(30)
+    assert eng.last_kernel() == "sg::rollout_kernel<64, 2, true, false>"
+    eng.close()
+
+
 def test_scenario_of_700_entities_through_the_gym(oracle):
     """A Scenario object of 700 entities through the reference's one-scenario API (no entity ceiling: state/utils.py:10-49
     has none): set_scenario -> rollout; State.poses / collisions() (rows of eleven words) / the metrics equal the oracle's."""
