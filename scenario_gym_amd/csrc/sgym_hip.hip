@@ -722,7 +722,10 @@ static int launch_queue(sg_handle *h, int n_steps, int force, const double *d_ac
     // the table ring: as many chunk buffers as the call has chunks when they fit a quarter of the free memory (no buffer is
     // ever reused: the pre-pass never waits), else a ring of at least three
     const size_t row = (size_t)sg::CT_PLANES * sg::CT_W * np;
-    const int ts = std::max(chunk, h->p.tab_steps);
+    // (rows per lane = the longest chunk of THIS launch + 1, whatever table an earlier chunk-launch call of the handle needed:
+    // the stride is a launch parameter -- ADVICE r5: a handle that once ran thousands of steps per chunk kept ring buffers of
+    // that size for ever)
+    const int ts = chunk;
     const size_t buf_bytes = (size_t)(ts + 1) * row * sizeof(double);
     int n_buf = C;
     {
