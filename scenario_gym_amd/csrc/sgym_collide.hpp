@@ -118,16 +118,22 @@ __device__ __forceinline__ void tile_collisions(bool present, const double *pose
         if (WV == 1) tile_sync<WV>();
         const int wsl = (WV == 1) ? 0 : (slot >> 6);              // word of this slot inside the tile's row
         const uint64_t mybit = 1ull << ((WV == 1) ? (sl & 63) : (slot & 63));
-        if (present) {
-            atomicOr(&L.xtab[ix & 63][wsl], mybit);
-            atomicOr(&L.ytab[iy & 63][wsl], mybit);
+        if (present) { // (a tile of one wavefront: wavefront scope -- no wait behind the two ds_or)
+            if (WV == 1) {
+                __hip_atomic_fetch_or(&L.xtab[ix & 63][wsl], mybit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                __hip_atomic_fetch_or(&L.ytab[iy & 63][wsl], mybit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            } else {
+                atomicOr(&L.xtab[ix & 63][wsl], mybit);
+                atomicOr(&L.ytab[iy & 63][wsl], mybit);
+            }
         }
         PH(2); tile_sync<WV>(); PH(13);
 #pragma unroll
         for (int w = 0; w < WV; ++w) {
-            uint64_t mx = L.xtab[(ix - 1) & 63][w] | L.xtab[ix & 63][w] | L.xtab[(ix + 1) & 63][w];
-            uint64_t my = L.ytab[(iy - 1) & 63][w] | L.ytab[iy & 63][w] | L.ytab[(iy + 1) & 63][w];
-            uint64_t m = mx & my;
+            // (all six words in flight before the first is used: one wait instead of two)
+            const uint64_t x0 = L.xtab[(ix - 1) & 63][w], x1 = L.xtab[ix & 63][w], x2 = L.xtab[(ix + 1) & 63][w];
+            const uint64_t y0 = L.ytab[(iy - 1) & 63][w], y1 = L.ytab[iy & 63][w], y2 = L.ytab[(iy + 1) & 63][w];
+            uint64_t m = (x0 | x1 | x2) & (y0 | y1 | y2);
             if (WV == 1) { // several tiles share the wave: keep this tile's slots, tile-local bit positions
                 m >>= tile0;
                 if (G < 64) m &= (1ull << (G & 63)) - 1;

@@ -12,9 +12,11 @@ template <int WV>
 __device__ __forceinline__ void tile_sync()
 {
     if (WV == 1) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        // (compiler barriers only: a wavefront-scope fence made LLVM wait for lgkmcnt(0) here -- a full LDS round trip the
+        // hardware does not need, its LDS instructions execute in issue order)
+        asm volatile("" ::: "memory");
         __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        asm volatile("" ::: "memory");
     } else {
         __syncthreads();
     }
