@@ -7,7 +7,7 @@ namespace sg {
 
 // Barrier between the lanes of one tile's workgroup.  A single wavefront (WV == 1) needs no s_barrier and no
 // s_waitcnt: the LDS executes the instructions of one wavefront in issue order, so a ds_read issued after another
-// lane's ds_write / ds_or already sees it; a wavefront-scope fence keeps the compiler from reordering them.
+// lane's ds_write / ds_or already sees it; compiler barriers keep the compiler from reordering them.
 template <int WV>
 __device__ __forceinline__ void tile_sync()
 {
