@@ -16,6 +16,16 @@ void rollout_rss_tabq(int G, dim3 grid, hipStream_t s, const sg::Params &p, doub
     SGL_DISPATCH_G(G, CALL);
 #undef CALL
 }
+int rss_tabq_waves_per_cu(int G) // (as tabq_waves_per_cu)
+{
+    int n = 0;
+    hipError_t e = hipSuccess;
+#define CALL(G_) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, sg::rollout_kernel_rss_tabq<G_>, 64, 0)
+    SGL_DISPATCH_G(G, CALL);
+#undef CALL
+    if (e != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
 void rss_lines(dim3 grid, hipStream_t s, const sg::Params &p, const sg::TabGroups &tg)
 {
     sg::rss_lines_kernel<<<grid, dim3(64), 0, s>>>(p, tg);

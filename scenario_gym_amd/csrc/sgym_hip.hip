@@ -109,6 +109,7 @@ struct sg_handle {
     // first one's code.  A give-up is STICKY: every later call that runs or reads the batch fails with its message until
     // sg_reset / sg_upload start the batch anew (the state is undefined in between).
     char last_kernel[96] = {0};     // sg_last_kernel
+    int q_waves_per_cu[3] = {-1, -1, -1}; // occupancy of rollout_kernel_tabq / _planar / _rss_tabq (slots_of), queried once
     unsigned *q_host = nullptr;
     int q_head = 0, q_count = 0;    // next slot to use; launches not yet looked at
     bool q_failed = false;
@@ -654,6 +655,7 @@ static int check_queue(sg_handle *h)
         static const char *what[] = {"", "a rollout wavefront waited for the controller pre-pass", "a rollout wavefront waited for the previous chunk of its block",
                                      "the controller pre-pass waited for a buffer of the table ring"};
         h->q_failed = true;
+        h->queue_mode = 0; // (whatever kept its wavefronts from meeting will do so again: the handle's later calls take the chunk launches)
         snprintf(h->q_msg, sizeof h->q_msg, "sg_rollout: the persistent table launch gave up (%s longer than SG_QUEUE_TIMEOUT_MS; %u work items had finished): "
                                             "the state of the batch is undefined -- sg_reset / sg_upload before the next call", what[code < 4 ? code : 0],
                  w[sg::Q_ITEMS_DONE]);
@@ -671,7 +673,16 @@ static void forget_queue_failure(sg_handle *h)
 // grid of persistent wavefronts, work items (chunk, block) from a device-side counter.  `chunk` = the longest chunk.
 // Returns SG_OK, an error, or SG_QUEUE_FALLBACK: the table ring could not be allocated -- the caller takes the chunk launches.
 #define SG_QUEUE_FALLBACK 1
-static size_t slots_of(const sg_handle *h, bool rss) { return (size_t)h->n_simd * (size_t)(rss ? SG_WAVES_PER_SIMD : (h->planar ? SG_PLANAR_WAVES : SG_TAB_WAVES)); }
+// Wavefront slots of the persistent kernel on this device: what the build's launch bounds say (wavefronts per SIMD x SIMDs), cut
+// down to what the runtime's occupancy query grants when that is less (a CU mask, a partitioned device, a build whose
+// registers or LDS grew) -- every wavefront of the grid has to be resident at once, the pre-pass roles never yield.
+static size_t slots_of(sg_handle *h, bool rss)
+{
+    const size_t by_bounds = (size_t)h->n_simd * (size_t)(rss ? SG_WAVES_PER_SIMD : (h->planar ? SG_PLANAR_WAVES : SG_TAB_WAVES));
+    int &cached = h->q_waves_per_cu[rss ? 2 : (h->planar ? 1 : 0)];
+    if (cached < 0) cached = rss ? sgl::rss_tabq_waves_per_cu(h->G) : sgl::tabq_waves_per_cu(h->G, h->planar);
+    return cached > 0 ? std::min(by_bounds, (size_t)cached * (size_t)(h->n_simd / 4)) : by_bounds;
+}
 static int launch_queue(sg_handle *h, int n_steps, int force, const double *d_actions, int chunk, size_t *ev_next, bool rss = false)
 {
     const size_t nblk = h->NE / 64, np = (size_t)h->p.n_ctl_pad, n_ctl_waves = np / 64;
@@ -978,7 +989,8 @@ static int launch_rollout_impl(sg_handle *h, int n_steps, int do_reset, int forc
             if (rss_tab) ch = std::min(ch, std::max(1, h->rssq_steps)); // one launch fills at most the line-test queue
             // one persistent launch (sgym_queue.hpp) where the batch is one wavefront per block and nothing rides along; the
             // pre-pass role must leave most of the wavefront slots to the rollout
-            if (h->queue_mode && h->WV == 1 && !riders && !no_overlap && (size_t)h->p.n_ctl_pad / 64 <= (size_t)h->n_simd / 2) {
+            if (h->queue_mode && h->WV == 1 && !riders && !no_overlap && (size_t)h->p.n_ctl_pad / 64 <= std::min((size_t)h->n_simd, slots_of(h, rss_tab)) / 2 /* a SIMD of
+                its own for every pre-pass role, and at least as many rollout wavefronts resident beside them */) {
                 rc = launch_queue(h, n_steps, force, d_actions, ch, &ev_next, rss_tab);
                 if (rc != SG_QUEUE_FALLBACK) {
                     if (rc) return rc;

@@ -44,6 +44,8 @@ void rollout_road(int G, int WV, dim3 grid, hipStream_t s, const RolloutArgs &a)
 void rollout_tab(int G, bool planar, dim3 grid, hipStream_t s, const sg::Params &p, double timestep, int force, const sg::TabGroups &tg);
 // k_tabq.hip (sgym_queue.hpp): rollout_kernel_tabq<G> / rollout_kernel_tabq_planar<G> -- the table path as one persistent launch
 void rollout_tabq(int G, bool planar, dim3 grid, hipStream_t s, const sg::Params &p, double timestep, int force, const sg::TabQueue &tq);
+int tabq_waves_per_cu(int G, bool planar); // resident wavefronts of that kernel per compute unit (occupancy query; 0: unknown)
+int rss_tabq_waves_per_cu(int G);          // (k_rss_tab.hip)
 // k_rss_tab.hip: rollout_kernel_rss_tabq<G> -- the same launch with the RSS callback in the step loop
 void rollout_rss_tabq(int G, dim3 grid, hipStream_t s, const sg::Params &p, double timestep, int force, const sg::TabQueue &tq);
 // k_slice.hip: rollout_kernel_slice<G> / rollout_kernel_slice_tab<G> (tab != nullptr)

@@ -1298,7 +1298,7 @@ def test_queue_give_up_is_loud_and_sticky(sga, monkeypatch):
     demand: a limit of one microsecond, which the first wait for the controller pre-pass exceeds).  The state of the batch is
     undefined from then on, and every call that would run or read it says so -- the synchronising call, a read of the metrics, a
     second rollout queued behind it without a look in between, a continued rollout -- until sg_reset (or a rollout that
-    resets, or sg_upload) starts the batch anew; then the same handle runs the batch to the oracle's bits."""
+    resets, or sg_upload) starts the batch anew; then the same handle runs the batch to the oracle's bits, as chunk launches."""
     import scenario_gym_amd._lib as L
     from oracle import check
     from scenario_gym_amd import synthetic
@@ -1325,6 +1325,8 @@ def test_queue_give_up_is_loud_and_sticky(sga, monkeypatch):
     eng.synchronize()
     ver = check.verify_engine(eng, packed, dt, steps, K=8, event_cap=64)
     assert ver["equal"], ver["mismatches"]
+    # whatever kept the wavefronts from meeting would do so again: after a give-up the handle takes the chunk launches
+    assert eng.schedule_info()["schedule"] == SCHED_CHUNKS
     eng.close()
 
 
