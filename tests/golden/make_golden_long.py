@@ -15,6 +15,9 @@
     away from itself, step by step: the PID loop on these trajectories amplifies a rounding error by ten every ~100 steps, so
     beyond ~1,500 steps "the reference's trajectory" is a property of its libm, and the 1e-5 contract is checked on the steps
     before the reference's own one-ulp twin has left that band.
+(a') `c3t/<k>`: the same two scenarios with the PID gains of the reference's own controller test (tests/test_controller.py:7-25:
+    accel_Kp 2.0, max_accel 5.0, max_steer pi/90), with which the loop TRACKS: the one-ulp twin stays within 1e-12 for all 10,000
+    steps, so here the 1e-5 contract is checkable over the whole horizon.
 (b) `crowd/<k>`: 32 pedestrians on a 12 m square, two-waypoint routes, sensor radius 3 m, SocialForce defaults, empty road
     network, 3,300 steps of dt = 1/30 with CollisionMetric: (0) std 0; (1) the reference's noise with np.random.seed(5)
     (std_lon 0.05, std_lat 0.02).  Every pedestrian's pose every 25 steps and after the last step, four pedestrians after
@@ -57,8 +60,11 @@ def knots_digest(s):
                                         + np.ascontiguousarray(s["bbox"]).tobytes()).digest(), np.uint8).copy()
 
 
-def c3_run(s, k, nudge):
-    """One rollout of scenario `s`; nudge: the ego's first x moved by that many ulps."""
+TRACKING = dict(accel_Kp=2.0, max_accel=5.0, max_steer=np.pi / 90)  # the gains of the reference's own controller test (tests/test_controller.py:7-25)
+
+
+def c3_run(s, k, nudge, gains=None):
+    """One rollout of scenario `s`; nudge: the ego's first x moved by that many ulps; gains: PIDAgent keyword arguments."""
     ents = []
     for e in range(C3_E):
         ce = CatalogEntry("synthetic", "car1", "car", "Vehicle", BoundingBox(*[float(x) for x in s["bbox"][e]]), {}, [])
@@ -68,7 +74,7 @@ def c3_run(s, k, nudge):
         ents.append(Entity(ce, ref="ego" if e == 0 else f"vehicle_{e - 1}", trajectory=Trajectory(kn)))
     sc = Scenario(ents, name=f"synthetic_{k}")
     gym = ScenarioGym(timestep=DT, metrics=[EgoAvgSpeed(), EgoMaxSpeed(), EgoDistanceTravelled()])
-    gym.set_scenario(sc, create_agent=lambda sc_, e: PIDAgent(e) if e.ref == "ego" else _create_agent(sc_, e))
+    gym.set_scenario(sc, create_agent=lambda sc_, e: PIDAgent(e, **(gains or {})) if e.ref == "ego" else _create_agent(sc_, e))
     st = gym.state
     ctl = st.agents[sc.ego].controller
     gym.reset_scenario()
@@ -87,14 +93,14 @@ def c3_run(s, k, nudge):
     return gym, ents, n, ts, trace
 
 
-def g_c3():
+def g_c3(tag="c3", gains=None):
     out = {}
     packed = synthetic.make_batch(synthetic.CHUNK, C3_E, n_steps=C3_STEPS, timestep=DT, first_scenario=0)
     for k in (0, 1):
         s = unpack_scenario(packed, k)
-        gym, ents, n, ts, trace = c3_run(s, k, 0)
+        gym, ents, n, ts, trace = c3_run(s, k, 0, gains)
         st = gym.state
-        twin = np.array(c3_run(s, k, 1)[4])
+        twin = np.array(c3_run(s, k, 1, gains)[4])
         norm = hashlib.sha256(np.ascontiguousarray(np.concatenate([e.trajectory.data for e in ents])).tobytes()).digest()
         P = np.full((C3_E, 6), np.nan)
         V = np.full((C3_E, 6), np.nan)
@@ -104,14 +110,14 @@ def g_c3():
             if e in st.velocities:
                 V[i] = st.velocities[e]
         m = gym.get_metrics()
-        out.update(G.flat(f"c3/{k}", dict(
+        out.update(G.flat(f"{tag}/{k}", dict(
             knots_sha256=knots_digest(s), trajectory_data_sha256=np.frombuffer(norm, np.uint8).copy(),
             self_divergence=np.abs(twin[:, :6] - np.array(trace)[:, :6]).max(axis=1),
             n_steps=np.int64(n), is_done=np.bool_(st.is_done), t=np.array(ts), ego=np.array(trace),
             final_poses=P, final_vels=V, final_dists=np.array([st.distances[e] for e in ents], np.float64),
             metric_ego_avg_speed=np.float64(m["ego_avg_speed"]), metric_ego_max_speed=np.float64(m["ego_max_speed"]),
             metric_ego_distance_travelled=np.float64(m["ego_distance_travelled"]))))
-        print(f"c3/{k}: {n} steps, final ego {trace[-1][:4]}", flush=True)
+        print(f"{tag}/{k}: {n} steps, final ego {trace[-1][:4]}, the one-ulp twin ends {float(np.abs(twin[-1, :6] - np.array(trace)[-1, :6]).max()):.2e} away", flush=True)
     return out
 
 
@@ -198,6 +204,8 @@ def main():
         out = {k_: old[k_] for k_ in old.files if k_.split("/")[0] not in only}
     if not only or "c3" in only:
         out.update(g_c3())
+    if not only or "c3t" in only:
+        out.update(g_c3("c3t", TRACKING))
     if not only or "crowd" in only:
         out.update(g_crowd())
     path = os.path.join(os.environ.get("SG_GOLDEN_OUT", HERE), "long.npz")

@@ -787,6 +787,24 @@ def test_headline_horizon_pid_ego_on_the_device(sga, oracle):
         print(f"device vs reference c3/{k}: max |ego pose error| on the first {prefix} steps = {err:.3e}, exceeds 1e-5 at step {over}")
 
 
+def test_headline_horizon_with_a_tracking_pid_on_the_device(sga, oracle):
+    """The 1e-5 contract over config 3's full horizon where it is well-posed (long.npz c3t: the bench's scenarios, the PID gains of
+    the reference's own controller test, 10,000 steps of the real reference): the device's ego pose after EVERY step, the final
+    state of all entities (replay lanes bit for bit), the controller state and the three ego metrics; same bits as the oracle."""
+    from test_oracle_golden import check_long_c3t, long_c3_batch
+
+    packed, g = long_c3_batch(tracking=True)
+    st, rows, events, t, poses = _engine_run(sga, packed, 1 / 30, 10002, ev_cap=64)
+    for k in (0, 1):
+        n = int(rows["n_steps"][k])
+        err = check_long_c3t(g, k, n, t[: n + 1, k], poses[: n + 1, k, 0], None, st["poses"][k], st["vels"][k], st["dists"][k],
+                             {name: float(rows[name][k]) for name in ("ego_avg_speed", "ego_max_speed", "ego_distance_travelled")})
+        assert np.abs(st["ctrl_state"][k, 0] - g[f"c3t/{k}/ego"][-1, 6:10]).max() < 1e-8 and err < 1e-8
+        o = _oracle_one(oracle, packed, k, 1 / 30, 10002)
+        assert bits_equal(poses[: n + 1, k], o["poses"]) and bits_equal(st["ctrl_state"][k, 0], o["extra"][-1, 0])
+        print(f"device vs reference c3t/{k}: max |ego pose error| over 10,000 steps = {err:.3e}")
+
+
 @pytest.mark.parametrize("k", [0, 1])
 def test_long_crowd_on_the_device_matches_reference(sga, oracle, k):
     """32 pedestrians, 3,300 steps, recorded from the REAL reference (long.npz; k = 1 with the reference's noise from numpy's

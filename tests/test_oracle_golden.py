@@ -646,7 +646,7 @@ def test_mixed_pedestrian_models_closed_loops(oracle, si):
 LONG_TOL = 1e-5  # the contract for controller-integrated poses (north_star); measured maxima are asserted far below it
 
 
-def long_c3_batch():
+def long_c3_batch(tracking=False):
     """Scenarios 0 and 1 of the bench's c3 family (the generator call of tests/golden/make_golden_long.py), PID egos, every
     entity's knots passed through Trajectory.__init__ as the reference does when it builds the scenario (trajectory.py:34-96
     re-sums the headings: scenario_gym_amd.trajectory.Trajectory, row T3) -- checked against the fixture's checksums of both."""
@@ -677,7 +677,48 @@ def long_c3_batch():
         a, b = packed.knot_off[k * E], packed.knot_off[(k + 1) * E]
         d = hashlib.sha256(np.ascontiguousarray(packed.knots[a:b]).tobytes()).digest()
         assert np.array_equal(np.frombuffer(d, np.uint8), g[f"c3/{k}/trajectory_data_sha256"]), k  # == the reference's Trajectory.data
+    if tracking:  # the PID gains of the reference's own controller test (tests/test_controller.py:7-25), as make_golden_long's c3t
+        for k in (0, 1):
+            packed.ctrl[k * E, L.C_ACCEL_KP], packed.ctrl[k * E, L.C_MAX_ACCEL], packed.ctrl[k * E, L.C_MAX_STEER] = 2.0, 5.0, np.pi / 90
     return packed.validate(), g
+
+
+def check_long_c3t(g, k, n_steps, t, ego_poses, ego_extra, final_poses, final_vels, final_dists, metrics):
+    """c3t: the same scenario with a PID loop that tracks (the reference's one-ulp twin stays within 1e-12 over the whole
+    horizon).  Every step of all 10,000 within the contract -- far inside it --, replay lanes and clock bit for bit, the three
+    ego metrics.  Returns the largest ego deviation."""
+    p = f"c3t/{k}"
+    assert n_steps == int(g[p + "/n_steps"]) >= 9999 and bits_equal(t, g[p + "/t"])
+    assert g[p + "/self_divergence"].max() < 1e-11
+    ref = g[p + "/ego"]
+    err = float(np.abs(ego_poses - ref[:, :6]).max())
+    if ego_extra is not None:
+        err = max(err, float(np.abs(ego_extra - ref[:, 6:10]).max()))
+    assert err < LONG_TOL, err
+    fp, fv, fd = g[p + "/final_poses"], g[p + "/final_vels"], g[p + "/final_dists"]
+    assert bits_equal(final_poses[1:], fp[1:]) and bits_equal(final_vels[1:], fv[1:]) and bits_equal(final_dists[1:], fd[1:])
+    assert np.abs(final_poses[0] - fp[0]).max() < LONG_TOL and np.abs(final_vels[0] - fv[0]).max() < LONG_TOL and abs(final_dists[0] - fd[0]) < LONG_TOL
+    for name in ("ego_avg_speed", "ego_max_speed", "ego_distance_travelled"):
+        assert abs(metrics[name] - float(g[f"{p}/metric_{name}"])) < LONG_TOL, name
+    return err
+
+
+@pytest.mark.parametrize("k", [0, 1])
+def test_headline_horizon_with_a_tracking_pid_matches_reference(oracle, k):
+    """The 1e-5 contract for controller-integrated poses over config 3's FULL horizon, where it is well-posed: the bench's
+    scenarios with the PID gains of the reference's own controller test (the loop tracks; the reference's one-ulp twin stays
+    within 1e-12).  10,000 steps of the real reference: the oracle's ego pose and controller state after every step, the final
+    state of all 64 entities and the three ego metrics."""
+    from scenario_gym_amd.packing import unpack_scenario
+
+    packed, g = long_c3_batch(tracking=True)
+    s = unpack_scenario(packed, k)
+    o = oracle.rollout(s["knot_off"], s["knots"], s["bbox"], s["etype"], s["kind"], s["ego"], s["t0"], s["length"], 1.0 / 30.0,
+                       ctrl=s["ctrl"], max_steps=10005)
+    err = check_long_c3t(g, k, o["n_steps"], o["t"], o["poses"][:, 0], o["extra"][:, 0], o["poses"][-1], o["vels"][-1], o["dists"][-1],
+                         {n: o["metric_" + n] for n in ("ego_avg_speed", "ego_max_speed", "ego_distance_travelled")})
+    assert err < 1e-8, err
+    print(f"c3t/{k}: max |ego pose / controller state - reference| over 10,000 steps = {err:.3e}")
 
 
 def check_long_c3(g, k, n_steps, t, ego_poses, ego_extra, final_poses, final_vels, final_dists):
