@@ -159,7 +159,7 @@ struct sg_handle {
 // the RSSDistances records hold results of the current batch (sg_upload leaves the buffers, not their contents)
 static bool rss_live(const sg_handle *h) { return h->d_rss_state && !h->rss_stale; }
 
-// the crowd variants (rollout_kernel_crowd / _riders, the walker kernels) hold the social force model alone
+// the crowd variants (rollout_kernel_crowd / _riders / _models) hold the social force model alone
 // (several models: a pass of the force code per model, as the general variant does it -- up to four, SocialForce all of them)
 static bool crowd_allowed(const sg_handle *h)
 {
@@ -480,9 +480,9 @@ static dim3 tab_grid(const sg_handle *h, const sg::TabGroups &tg)
     return dim3((unsigned)std::min<size_t>(h->NE / 64, (size_t)tg.len0 + tg.len1));
 }
 
-// the rollout kernel family of this handle's batch (launchers: sgym_launch.hpp, one object per family)
 // the entry point the handle launched last for a step loop (sg_last_kernel): what a kernel trace of the call shows
 static void note_kernel(sg_handle *h, const char *fmt, int a = 0, int b = 0) { snprintf(h->last_kernel, sizeof h->last_kernel, fmt, a, b); }
+// the rollout kernel family of this handle's batch (launchers: sgym_launch.hpp, one object per family)
 static void launch_variant(sg_handle *h, dim3 grid, int n_steps, int do_reset, int force, const double *d_actions,
                            const double *d_tab, bool use_tab, const sg::TabGroups &tg)
 {
@@ -2497,7 +2497,7 @@ extern "C" int sg_future_collision(sg_handle *h, double horizon, int32_t n_sampl
     if (e == hipSuccess) e = hipMemcpyAsync(out, d, (size_t)h->R, hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     if (e != hipSuccess) return fail(h, SG_ERR_HIP, "sg_future_collision: %s", hipGetErrorString(e));
-    return SG_OK;
+    return check_queue(h); // (a persistent launch that gave up: sticky)
 }
 
 // ---- road surfaces -------------------------------------------------------------------------------
@@ -2802,7 +2802,7 @@ extern "C" int sg_raster_entities(sg_handle *h, double width, double height, int
     if (e == hipSuccess) e = hipMemcpyAsync(out, d, bytes, hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     if (e != hipSuccess) return fail(h, SG_ERR_HIP, "sg_raster_entities: %s", hipGetErrorString(e));
-    return SG_OK;
+    return check_queue(h); // (a persistent launch that gave up: sticky)
 }
 
 // ---- several devices from one process ---------------------------------------------------------------

@@ -1,5 +1,6 @@
 // microbenchmark: cycles per crowd_pair evaluation of a wavefront that is alone on its SIMD
 #include "../../scenario_gym_amd/csrc/sgym_device.hpp"
+#include "pair_bench_pairs.hpp"
 #include <cstdio>
 #include <vector>
 template <int N, bool INTERLEAVED>
