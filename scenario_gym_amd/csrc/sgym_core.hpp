@@ -43,6 +43,8 @@ struct RoadIndex {
     const uint32_t *net_flags;      // [n_nets] bit 0: the walkable surface has area, bit 1: the impenetrable surface has
     const int64_t *imp_off;         // [n_nets + 1] ranges of imp_edges
     const double *imp_edges;        // [n][4] ring edges of the impenetrable polygons (buildings), for the nearest-point search
+    const double *imp_aux;          // [n][4] per such edge: bx - ax, by - ay, ~1 / |b - a|^2, 0 (the filter of ped_boundary_terms)
+    const double *imp_m;            // [n_nets] the largest |coordinate| of the network's impenetrable edges (its error margin)
     int32_t n_nets;
 };
 
@@ -531,6 +533,11 @@ struct TileLds {
     double ego_m[CROWD ? 3 : 1];
     unsigned long long ego_last[CROWD ? (NS + 63) / 64 : 1];
     int ego_nev[2];
+    // (crowd variants) the ring edges of the scenario's buildings for the boundary terms of the social force, staged once per
+    // launch (rollout_body_l; ped_boundary_terms): [k][6] = ax, ay, bx, by, ~1 / |b - a|^2, the network's largest |coordinate|;
+    // road_info = edges staged (-1: none -- no network, no buildings, more than 64 edges: device memory), the network, its flags
+    double road_tab[CROWD ? 64 * 6 : 1];
+    int road_info[4];
 
     static constexpr int SLOTS = NS;
     static constexpr int SCRATCH_BYTES = NS * 40 + 64 * (NS > 64 ? NS : 2); // cx ... cor

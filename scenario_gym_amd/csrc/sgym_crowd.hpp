@@ -534,7 +534,7 @@ __device__ __forceinline__ void ped_force(const Params &p, LDS &L, int r, int sl
             PH(0);
             crowd_pairs<WV>(p, L, CC, sl, nbr, go, k2_scale, pose[0], pose[1], fx, fy);
             PH(6);
-            if (p.road && go) ped_boundary_terms(p, r, pose[0], pose[1], fx, fy); // (launch-uniform: the batch has road networks) after the neighbours, social_force.py:83-104
+            if (p.road && go) ped_boundary_terms(p, r, pose[0], pose[1], fx, fy, L.road_tab, L.road_info); // (launch-uniform: the batch has road networks) after the neighbours, social_force.py:83-104
             return;
         }
         if (go) sg_sincos(L.ctrl[SG_C_PED_HEAD_ROT - SG_C_PED_SPEED_DESIRED][sl], hs, hc, K);
@@ -546,7 +546,10 @@ __device__ __forceinline__ void ped_force(const Params &p, LDS &L, int r, int sl
         ped_pairs_balanced<WV>(p, L, sl, tile0, nbr, go, k2_scale, pose[0], pose[1], radius, fx, fy);
     else // (CROWD: the guards of crowd_pair do not hold, or SG_PED_SERIAL: the plain serial loop)
         ped_pairs_serial<WV>(p, L, tile0, nbr, go, plain, k2_scale, pose[0], pose[1], radius, hs, hc, fx, fy);
-    if (go) ped_boundary_terms(p, r, pose[0], pose[1], fx, fy); // after the neighbours, social_force.py:83-104 (a no-op without road networks)
+    if (go) { // after the neighbours, social_force.py:83-104 (a no-op without road networks)
+        if (CROWD) ped_boundary_terms(p, r, pose[0], pose[1], fx, fy, L.road_tab, L.road_info);
+        else ped_boundary_terms(p, r, pose[0], pose[1], fx, fy);
+    }
 }
 
 // The random fluctuations of one pedestrian's step: scale * z of np.random.normal(loc, scale) = loc + scale * z for the

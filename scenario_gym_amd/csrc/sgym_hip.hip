@@ -2713,6 +2713,22 @@ extern "C" int sg_set_road_networks(sg_handle *h, const sg_road_networks *in)
     if ((rc = dev_upload(h, A, &R.net_flags, B.net_flags))) return rc;
     if ((rc = dev_upload(h, A, &R.imp_off, B.imp_off))) return rc;
     if ((rc = dev_upload(h, A, &R.imp_edges, B.imp_edges))) return rc;
+    {   // the filter tables of ped_boundary_terms (sgym_road.hpp)
+        const size_t ne = B.imp_edges.size() / 4;
+        std::vector<double> aux(ne * 4, 0.0), big(B.imp_off.size() - 1, 0.0);
+        for (size_t i = 0; i < ne; ++i) {
+            const double *e = &B.imp_edges[i * 4];
+            const double dx = e[2] - e[0], dy = e[3] - e[1];
+            aux[i * 4] = dx;
+            aux[i * 4 + 1] = dy;
+            aux[i * 4 + 2] = 1.0 / (dx * dx + dy * dy); // (a point edge: inf -- the filter's clamp turns the NaN it makes into t = 0)
+        }
+        for (size_t n = 0; n + 1 < B.imp_off.size(); ++n)
+            for (int64_t i = B.imp_off[n] * 4; i < B.imp_off[n + 1] * 4; ++i) big[n] = std::max(big[n], std::fabs(B.imp_edges[(size_t)i]));
+        if (big.empty()) big.push_back(0.0);
+        if ((rc = dev_upload(h, A, &R.imp_aux, aux))) return rc;
+        if ((rc = dev_upload(h, A, &R.imp_m, big))) return rc;
+    }
     R.n_nets = in->n_networks;
     std::vector<sg::RoadIndex> one(1, R);
     const sg::RoadIndex *dR = nullptr;

@@ -149,54 +149,139 @@ __device__ inline uint32_t rn_layers_at(const RoadIndex &R, int net, uint32_t wa
     return in;
 }
 
+// One ring edge (a, b) of GEOS DistanceOp's nearest-point search folded into (best, cx, cy): Distance::pointToSegment, nearest
+// first on ties, LineSegment::closestPoint -- the operation sequence of the oracle (sgo_boundary_terms).
+__device__ __forceinline__ void nearest_edge_exact(double ax, double ay, double bx, double by, double px, double py, double &best,
+                                                   double &cx, double &cy)
+{
+    auto dist = [](double x0, double y0, double x1, double y1) {
+        const double dx = x0 - x1, dy = y0 - y1;
+        return __builtin_sqrt(dx * dx + dy * dy);
+    };
+    double d;
+    if (ax == bx && ay == by) {
+        d = dist(px, py, ax, ay);
+    } else {
+        const double len2 = (bx - ax) * (bx - ax) + (by - ay) * (by - ay);
+        const double rr = ((px - ax) * (bx - ax) + (py - ay) * (by - ay)) / len2;
+        if (rr <= 0.0) d = dist(px, py, ax, ay);
+        else if (rr >= 1.0) d = dist(px, py, bx, by);
+        else d = __builtin_fabs(((ay - py) * (bx - ax) - (ax - px) * (by - ay)) / len2) * __builtin_sqrt(len2);
+    }
+    if (d < best) {
+        best = d;
+        double f;
+        if (px == ax && py == ay) f = 0.0;
+        else if (px == bx && py == by) f = 1.0;
+        else {
+            const double dx = bx - ax, dy = by - ay, len = dx * dx + dy * dy;
+            f = len <= 0.0 ? __builtin_nan("") : ((px - ax) * dx + (py - ay) * dy) / len;
+        }
+        if (f > 0.0 && f < 1.0) { cx = ax + f * (bx - ax); cy = ay + f * (by - ay); }
+        else if (dist(ax, ay, px, py) < dist(bx, by, px, py)) { cx = ax; cy = ay; }
+        else { cx = bx; cy = by; }
+    }
+}
+
 // The boundary terms of SocialForce._step (pedestrian/social_force.py:86-104, _force_boundary :190-211) for one
 // pedestrian at (px, py) of scenario r.  nearest_points(surface, point) is GEOS DistanceOp: a point inside (or on) an
 // areal geometry is its own nearest point, so the walkable term -- evaluated only INSIDE the walkable surface -- is the
 // zero vector (+0.0 is still added, as the reference does), and so is the impenetrable term inside a building (-0.0);
 // outside, every ring edge of the buildings in order: Distance::pointToSegment, nearest first on ties,
 // LineSegment::closestPoint.  Same operation sequence as the oracle.
-__device__ inline void ped_boundary_terms(const Params &p, int r, double px, double py, double &fx, double &fy)
+//
+// The search visits the edges in order and keeps the FIRST one that attains the smallest rounded distance; only that edge
+// decides the result (cx, cy are overwritten, never accumulated).  The reference's sequence costs two IEEE divisions and up
+// to five square roots per edge, in branches a crowd's lanes take all of (~160 instructions per edge and wavefront: on the
+// c5roads batch -- 16 edges -- the search was 43 % of the step).  So a FILTER first (networks of up to 64 such edges): the
+// squared distance to every edge in plain fp64 with the edge's precomputed direction and reciprocal length (11 operations,
+// no division, no root), twice -- the smallest, then who is within `margin` of it.  margin = 1e-11 x a bound on every
+// squared length in play: the filter's own error is < 3e-15 of that bound and the reference's rounding < 2e-15 of it, so an
+// edge outside the margin has a rounded distance strictly above the minimum and cannot be the one kept, whatever the
+// order.  The reference's sequence then runs over the candidates only, in edge order: the point's own edge, both edges of a
+// corner, the walls on either side of a street when they are equally far.  NaN anywhere makes everything a candidate.
+// `tab` / `info` (crowd variants, one scenario per workgroup): the scenario's building edges staged in LDS once per launch
+// (TileLds::road_tab / road_info, filled by rollout_body_l) -- as loads from device memory every edge of the two filter
+// passes waited a full memory latency (the compiler cannot make them scalar loads: the kernel stores to global memory).
+__device__ __forceinline__ double nearest_edge_approx_d2(double ax, double ay, double dx, double dy, double inv, double px, double py)
+{
+    const double dxp = px - ax, dyp = py - ay;
+    const double t = __builtin_fmin(__builtin_fmax(__builtin_fma(dxp, dx, dyp * dy) * inv, 0.0), 1.0);
+    const double qx = __builtin_fma(-t, dx, dxp), qy = __builtin_fma(-t, dy, dyp);
+    return __builtin_fma(qx, qx, qy * qy);
+}
+__device__ inline void ped_boundary_terms(const Params &p, int r, double px, double py, double &fx, double &fy,
+                                          const double *tab = nullptr, const int *info = nullptr)
 {
     if (!p.road) return;
     const RoadIndex RI = *p.road;
-    const int net = RI.net_of_scen[r];
-    if (net < 0) return;
-    const uint32_t flags = RI.net_flags[net];
+    int net, n_tab = -1;
+    uint32_t flags;
+    if (info) { // (the same values in every lane: scalars)
+        n_tab = __builtin_amdgcn_readfirstlane(info[0]);
+        net = __builtin_amdgcn_readfirstlane(info[1]);
+        flags = (uint32_t)__builtin_amdgcn_readfirstlane(info[2]);
+        if (net < 0) return;
+    } else {
+        net = RI.net_of_scen[r];
+        if (net < 0) return;
+        flags = RI.net_flags[net];
+    }
     if (!flags) return;
     const uint32_t in = rn_layers_at(RI, net, SG_LAYER_WALKABLE | SG_LAYER_IMPENETRABLE, px, py);
     if ((flags & 1u) && (in & SG_LAYER_WALKABLE)) { fx += 0.0; fy += 0.0; }
     if (!(flags & 2u)) return;
     if (in & SG_LAYER_IMPENETRABLE) { fx += -0.0; fy += -0.0; return; }
     double best = __builtin_inf(), cx = px, cy = py;
-    for (int64_t i = RI.imp_off[net]; i < RI.imp_off[net + 1]; ++i) {
-        const double *e = RI.imp_edges + i * 4;
-        const double ax = e[0], ay = e[1], bx = e[2], by = e[3];
-        auto dist = [](double x0, double y0, double x1, double y1) {
-            const double dx = x0 - x1, dy = y0 - y1;
-            return __builtin_sqrt(dx * dx + dy * dy);
-        };
-        double d;
-        if (ax == bx && ay == by) {
-            d = dist(px, py, ax, ay);
-        } else {
-            const double len2 = (bx - ax) * (bx - ax) + (by - ay) * (by - ay);
-            const double rr = ((px - ax) * (bx - ax) + (py - ay) * (by - ay)) / len2;
-            if (rr <= 0.0) d = dist(px, py, ax, ay);
-            else if (rr >= 1.0) d = dist(px, py, bx, by);
-            else d = __builtin_fabs(((ay - py) * (bx - ax) - (ax - px) * (by - ay)) / len2) * __builtin_sqrt(len2);
+    const auto margin_of = [&](double m) {
+        const double sxb = __builtin_fabs(px) + m, syb = __builtin_fabs(py) + m;
+        return 1e-11 * (sxb * sxb + syb * syb + 8.0 * (m * m));
+    };
+    if (n_tab >= 0) { // the staged table: [k][6] = ax, ay, bx, by, ~1 / |b - a|^2, the network's largest |coordinate|
+        const double margin = margin_of(tab[5]);
+        double dmin = __builtin_inf();
+#pragma unroll 4
+        for (int k = 0; k < n_tab; ++k) {
+            const double *e = tab + k * 6;
+            dmin = __builtin_fmin(dmin, nearest_edge_approx_d2(e[0], e[1], e[2] - e[0], e[3] - e[1], e[4], px, py));
         }
-        if (d < best) {
-            best = d;
-            double f;
-            if (px == ax && py == ay) f = 0.0;
-            else if (px == bx && py == by) f = 1.0;
-            else {
-                const double dx = bx - ax, dy = by - ay, len = dx * dx + dy * dy;
-                f = len <= 0.0 ? __builtin_nan("") : ((px - ax) * dx + (py - ay) * dy) / len;
+        const double thr = dmin + margin;
+        uint64_t cand = 0;
+#pragma unroll 4
+        for (int k = 0; k < n_tab; ++k) {
+            const double *e = tab + k * 6;
+            if (!(nearest_edge_approx_d2(e[0], e[1], e[2] - e[0], e[3] - e[1], e[4], px, py) > thr)) cand |= 1ull << k;
+        }
+        while (cand) {
+            const double *e = tab + __builtin_ctzll(cand) * 6;
+            cand &= cand - 1;
+            nearest_edge_exact(e[0], e[1], e[2], e[3], px, py, best, cx, cy);
+        }
+    } else {
+        const int64_t e0 = RI.imp_off[net], e1 = RI.imp_off[net + 1];
+        if (e1 - e0 <= 64) {
+            const double margin = margin_of(RI.imp_m[net]);
+            double dmin = __builtin_inf();
+            for (int64_t i = e0; i < e1; ++i) {
+                const double *e = RI.imp_edges + i * 4, *a = RI.imp_aux + i * 4; // a: bx - ax, by - ay, ~1 / |b - a|^2
+                dmin = __builtin_fmin(dmin, nearest_edge_approx_d2(e[0], e[1], a[0], a[1], a[2], px, py));
             }
-            if (f > 0.0 && f < 1.0) { cx = ax + f * (bx - ax); cy = ay + f * (by - ay); }
-            else if (dist(ax, ay, px, py) < dist(bx, by, px, py)) { cx = ax; cy = ay; }
-            else { cx = bx; cy = by; }
+            const double thr = dmin + margin;
+            uint64_t cand = 0;
+            for (int64_t i = e0; i < e1; ++i) {
+                const double *e = RI.imp_edges + i * 4, *a = RI.imp_aux + i * 4;
+                if (!(nearest_edge_approx_d2(e[0], e[1], a[0], a[1], a[2], px, py) > thr)) cand |= 1ull << (int)(i - e0);
+            }
+            while (cand) {
+                const double *e = RI.imp_edges + (e0 + __builtin_ctzll(cand)) * 4;
+                cand &= cand - 1;
+                nearest_edge_exact(e[0], e[1], e[2], e[3], px, py, best, cx, cy);
+            }
+        } else {
+            for (int64_t i = e0; i < e1; ++i) {
+                const double *e = RI.imp_edges + i * 4;
+                nearest_edge_exact(e[0], e[1], e[2], e[3], px, py, best, cx, cy);
+            }
         }
     }
     const double rx = px - cx, ry = py - cy, rn = sg_norm2(rx, ry);

@@ -184,6 +184,29 @@ __device__ __forceinline__ void rollout_body_l(
             const double rr = fld(st, ST_CTRL + SG_C_PED_RADIUS), r2 = rr * rr;
             lds.r2hi[sl] = r2 * (1.0 + 1e-9);
             lds.r2lo[sl] = r2 * 0.9975;
+            // the buildings of this scenario's road network (TileLds::road_tab; the barriers below publish it)
+            int n_staged = -1, net = -1;
+            uint32_t net_flags = 0;
+            if (p.road) {
+                const RoadIndex &RI = *p.road;
+                net = RI.net_of_scen[r];
+                if (net >= 0) {
+                    net_flags = RI.net_flags[net];
+                    const int64_t e0 = RI.imp_off[net], ne = RI.imp_off[net + 1] - e0;
+                    if ((net_flags & 2u) && ne <= 64) {
+                        n_staged = (int)ne;
+                        const double m = RI.imp_m[net];
+                        for (int k = tid; k < n_staged; k += NS) {
+                            const double *e = RI.imp_edges + (e0 + k) * 4;
+                            double *t = lds.road_tab + k * 6;
+                            t[0] = e[0]; t[1] = e[1]; t[2] = e[2]; t[3] = e[3];
+                            t[4] = RI.imp_aux[(e0 + k) * 4 + 2];
+                            t[5] = m;
+                        }
+                    }
+                }
+            }
+            if (tid == 0) { lds.road_info[0] = n_staged; lds.road_info[1] = net; lds.road_info[2] = (int)net_flags; }
         }
     }
     // CROWD: may this wavefront use crowd_pairs at all?  Default head rotation in every lane, a radius and parameters inside

@@ -2373,7 +2373,8 @@ def test_pedestrians_beside_a_building_match_reference(sga, oracle, si):
         assert np.nanmax(np.abs(o_road["poses"] - o_free["poses"])) > 0.1
 
 
-@pytest.mark.parametrize("E,blocks,riders", [(100, 2, False), (256, 2, False), (200, 3, False), (180, 2, True)])
+@pytest.mark.parametrize("E,blocks,riders", [(100, 2, False), (256, 2, False), (200, 3, False), (180, 2, True),
+                                             (60, 4, False), (120, 5, False)])  # (64 building edges: the staged table full; 100: not staged)
 def test_crowd_kernels_take_road_networks(sga, oracle, monkeypatch, E, blocks, riders):
     """The reference's pedestrians need a road network to run at all (pedestrian/sensor.py:50-51) and feel its buildings
     (social_force.py:86-104, 190-211).  Batches that have one no longer leave the crowd kernels: the boundary terms are a
@@ -2407,6 +2408,43 @@ def test_crowd_kernels_take_road_networks(sga, oracle, monkeypatch, E, blocks, r
         assert bits_equal(sa[k], sb[k]), k
     assert np.array_equal(sa["coll"], sb["coll"]) and ra.tobytes() == rb.tobytes() and ea.tobytes() == eb.tobytes()
     assert bits_equal(sa["poses"][2], sc["poses"][2]) and np.abs(sa["poses"][0] - sc["poses"][0]).max() > 0.05
+
+
+@pytest.mark.parametrize("E", [48, 130])
+def test_boundary_force_filter_keeps_the_reference_tie_rules(sga, oracle, monkeypatch, E):
+    """The nearest building edge of the boundary force (social_force.py:190-211, GEOS DistanceOp: the FIRST edge at the smallest
+    rounded distance) is found by a filter on squared distances and the reference's sequence over its candidates
+    (ped_boundary_terms, sgym_road.hpp).  Pedestrians placed where the filter has to keep several: on the centre line of a street
+    (two walls equally far), on the diagonal of a building's corner (its two edges), in the middle of a crossing (four corners,
+    eight edges), on a wall, on a corner, inside a building, far outside -- first step and the following ones equal the oracle
+    bit for bit, through the crowd kernel (table staged in LDS) and the general pedestrian kernel (device memory)."""
+    from oracle import check
+    from scenario_gym_amd import synthetic
+
+    R, steps, dt = 3, 40, 1 / 30
+    packed, net, net_of = synthetic.make_crowd_roads(R, E, n_steps=steps, side=30.0, blocks=2, building=10.0)
+    # buildings: [-12.5, -2.5] and [2.5, 12.5] in x and in y; streets along x = 0, y = 0, x = +-15, y = +-15
+    special = [(0.0, -7.5), (0.0, 6.0), (-7.5, 0.0), (4.0, 0.0), (0.0, 0.0), (-1.0, -1.0), (-2.0, -2.0), (1.5, -1.5), (-2.5, -7.5),
+               (2.5, 2.5), (-2.5, -2.5), (-7.5, -7.5), (-3.0, -7.5), (100.0, 50.0), (0.25, -7.5), (-14.0, -14.0), (-13.0, -13.0),
+               (0.0, 1e-9), (1e-9, -7.5), (-2.5 - 1e-12, -2.5 - 1e-12), (0.5, 14.0), (-14.0, 0.0)]
+    kn = packed.knots.reshape(R * E, 2, 7)
+    rng = np.random.default_rng(8)
+    for r in range(R):
+        order = rng.permutation(E)[: len(special)]
+        for e, (x, y) in zip(order, special):
+            kn[r * E + e, :, 1], kn[r * E + e, :, 2] = x, y
+    packed.validate()
+    for roads in ("1", "0"):
+        monkeypatch.setenv("SG_CROWD_ROADS", roads)
+        eng = sga.RolloutEngine(R, E, timestep=dt, terminal_conditions=["max_length"], event_capacity=256)
+        eng.upload(packed)
+        eng.set_road_networks([net], net_of)
+        for n in (1, steps):
+            eng.rollout(n)
+            ver = check.verify_engine(eng, packed, dt, n, K=R, event_cap=256, ped=True, road_of=lambda r: net)
+            assert ver["equal"], (roads, n, ver["mismatches"])
+        assert ("rollout_kernel_crowd" in eng.last_kernel()) == (roads == "1")
+        eng.close()
 
 
 def packed_two_waypoints(packed):
