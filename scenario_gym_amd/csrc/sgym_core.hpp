@@ -494,7 +494,7 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 
 // Workgroup-shared tile data.  NS = slots of the tile set a workgroup owns: 64 when one wavefront
 // carries 64/G scenarios (WV = 1), 64*WV when WV wavefronts carry one scenario of up to 64*WV entities.
-template <int NS, bool PED, bool CROWD = false>
+template <int NS, bool PED, bool CROWD = false, bool ROADTAB = false>
 struct TileLds {
     // ---- collision scratch: rewritten by every tile_collisions call and dead once it returns (its last reads sit
     // before its last workgroup barrier).  Contiguous, in this order: the pedestrian pair balancer (ped_pairs_balanced)
@@ -533,10 +533,16 @@ struct TileLds {
     double ego_m[CROWD ? 3 : 1];
     unsigned long long ego_last[CROWD ? (NS + 63) / 64 : 1];
     int ego_nev[2];
-    // (crowd variants) the ring edges of the scenario's buildings for the boundary terms of the social force, staged once per
-    // launch (rollout_body_l; ped_boundary_terms): [k][6] = ax, ay, bx, by, ~1 / |b - a|^2, the network's largest |coordinate|;
-    // road_info = edges staged (-1: none -- no network, no buildings, more than 64 edges: device memory), the network, its flags
-    double road_tab[CROWD ? 64 * 6 : 1];
+    // ROADTAB (rollout_kernel_crowd / _models: one scenario per workgroup): the ring edges of the scenario's buildings for the
+    // boundary terms of the social force, staged once per launch (rollout_body_l; ped_boundary_terms): [k][5] = ax, ay, bx, by,
+    // ~1 / |b - a|^2; road_m = the network's largest |coordinate|; road_info = edges staged (-1: none -- no network, no
+    // buildings, more than 64 edges: device memory), the network, its flags.  Not in the riders variant: two of its
+    // workgroups and one of control_kernel_riders (7 KB) share a compute unit's 160 KB, and these 2.5 KB would evict the latter
+    // (measured: c5mix 781 -> 902 ms).
+    static constexpr bool ROAD_TAB = ROADTAB;
+    static constexpr int ROAD_EDGES = 64;
+    double road_tab[ROADTAB ? ROAD_EDGES * 5 : 1];
+    double road_m;
     int road_info[4];
 
     static constexpr int SLOTS = NS;

@@ -529,25 +529,22 @@ __device__ __forceinline__ void ped_force(const Params &p, LDS &L, int r, int sl
     }
     if (!CROWD && p.ped_behaviour == SG_PED_RANDOM_WALK) return; // (launch-uniform: no neighbours, no boundary terms)
     const double k2_scale = sf.ped_repulse_V / sf.ped_repulse_sigma;
-    if (CROWD) {
-        if (crowd_fast) { // wave-uniform: the guards of crowd_pair hold
-            PH(0);
-            crowd_pairs<WV>(p, L, CC, sl, nbr, go, k2_scale, pose[0], pose[1], fx, fy);
-            PH(6);
-            if (p.road && go) ped_boundary_terms(p, r, pose[0], pose[1], fx, fy, L.road_tab, L.road_info); // (launch-uniform: the batch has road networks) after the neighbours, social_force.py:83-104
-            return;
-        }
-        if (go) sg_sincos(L.ctrl[SG_C_PED_HEAD_ROT - SG_C_PED_SPEED_DESIRED][sl], hs, hc, K);
+    if (CROWD && crowd_fast) { // wave-uniform: the guards of crowd_pair hold
+        PH(0);
+        crowd_pairs<WV>(p, L, CC, sl, nbr, go, k2_scale, pose[0], pose[1], fx, fy);
+        PH(6);
+    } else {
+        if (CROWD && go) sg_sincos(L.ctrl[SG_C_PED_HEAD_ROT - SG_C_PED_SPEED_DESIRED][sl], hs, hc, K);
+        // the shortcuts of ped_pair need the sight-weight branch (c2 = w2 * att) and hold for the whole wavefront
+        const bool plain = sg_all(hs == 0.0 && hc == 1.0) && sf.ped_attract_C == 0.0 && sf.sight_weight > 0.0 &&
+                           sf.sight_weight_use != 0.0;
+        if (!CROWD && plain && !p.ped_serial)
+            ped_pairs_balanced<WV>(p, L, sl, tile0, nbr, go, k2_scale, pose[0], pose[1], radius, fx, fy);
+        else // (CROWD: the guards of crowd_pair do not hold, or SG_PED_SERIAL: the plain serial loop)
+            ped_pairs_serial<WV>(p, L, tile0, nbr, go, plain, k2_scale, pose[0], pose[1], radius, hs, hc, fx, fy);
     }
-    // the shortcuts of ped_pair need the sight-weight branch (c2 = w2 * att) and hold for the whole wavefront
-    const bool plain = sg_all(hs == 0.0 && hc == 1.0) && sf.ped_attract_C == 0.0 && sf.sight_weight > 0.0 &&
-                       sf.sight_weight_use != 0.0;
-    if (!CROWD && plain && !p.ped_serial)
-        ped_pairs_balanced<WV>(p, L, sl, tile0, nbr, go, k2_scale, pose[0], pose[1], radius, fx, fy);
-    else // (CROWD: the guards of crowd_pair do not hold, or SG_PED_SERIAL: the plain serial loop)
-        ped_pairs_serial<WV>(p, L, tile0, nbr, go, plain, k2_scale, pose[0], pose[1], radius, hs, hc, fx, fy);
-    if (go) { // after the neighbours, social_force.py:83-104 (a no-op without road networks)
-        if (CROWD) ped_boundary_terms(p, r, pose[0], pose[1], fx, fy, L.road_tab, L.road_info);
+    if (p.road && go) { // (launch-uniform: the batch has road networks) after the neighbours, social_force.py:83-104
+        if (LDS::ROAD_TAB) ped_boundary_terms<true>(p, r, pose[0], pose[1], fx, fy, L.road_tab, L.road_info, &L.road_m);
         else ped_boundary_terms(p, r, pose[0], pose[1], fx, fy);
     }
 }

@@ -196,13 +196,14 @@ __device__ __forceinline__ void nearest_edge_exact(double ax, double ay, double 
 // c5roads batch -- 16 edges -- the search was 43 % of the step).  So a FILTER first (networks of up to 64 such edges): the
 // squared distance to every edge in plain fp64 with the edge's precomputed direction and reciprocal length (11 operations,
 // no division, no root), twice -- the smallest, then who is within `margin` of it.  margin = 1e-11 x a bound on every
-// squared length in play: the filter's own error is < 3e-15 of that bound and the reference's rounding < 2e-15 of it, so an
+// squared length in play: the filter's own error is < 4e-15 of that bound and the reference's rounding < 2e-15 of it, so an
 // edge outside the margin has a rounded distance strictly above the minimum and cannot be the one kept, whatever the
 // order.  The reference's sequence then runs over the candidates only, in edge order: the point's own edge, both edges of a
 // corner, the walls on either side of a street when they are equally far.  NaN anywhere makes everything a candidate.
-// `tab` / `info` (crowd variants, one scenario per workgroup): the scenario's building edges staged in LDS once per launch
-// (TileLds::road_tab / road_info, filled by rollout_body_l) -- as loads from device memory every edge of the two filter
-// passes waited a full memory latency (the compiler cannot make them scalar loads: the kernel stores to global memory).
+// `tab` / `info` / `tab_m` (rollout_kernel_crowd / _models, one scenario per workgroup): the scenario's building edges staged in
+// LDS once per launch (TileLds::road_tab / road_info / road_m, filled by rollout_body_l) -- as loads from device memory every
+// edge of the two filter passes waited a full memory latency (the compiler cannot make them scalar loads: the kernel stores
+// to global memory): c5roads 4.72 -> 5.0 G.
 __device__ __forceinline__ double nearest_edge_approx_d2(double ax, double ay, double dx, double dy, double inv, double px, double py)
 {
     const double dxp = px - ax, dyp = py - ay;
@@ -210,8 +211,11 @@ __device__ __forceinline__ double nearest_edge_approx_d2(double ax, double ay, d
     const double qx = __builtin_fma(-t, dx, dxp), qy = __builtin_fma(-t, dy, dyp);
     return __builtin_fma(qx, qx, qy * qy);
 }
+// STAGED: a caller that stages (its scenarios without a staged table -- more than 64 edges -- walk every edge: one copy less
+// of the filter in kernels whose registers are full).
+template <bool STAGED = false>
 __device__ inline void ped_boundary_terms(const Params &p, int r, double px, double py, double &fx, double &fy,
-                                          const double *tab = nullptr, const int *info = nullptr)
+                                          const double *tab = nullptr, const int *info = nullptr, const double *tab_m = nullptr)
 {
     if (!p.road) return;
     const RoadIndex RI = *p.road;
@@ -237,29 +241,29 @@ __device__ inline void ped_boundary_terms(const Params &p, int r, double px, dou
         const double sxb = __builtin_fabs(px) + m, syb = __builtin_fabs(py) + m;
         return 1e-11 * (sxb * sxb + syb * syb + 8.0 * (m * m));
     };
-    if (n_tab >= 0) { // the staged table: [k][6] = ax, ay, bx, by, ~1 / |b - a|^2, the network's largest |coordinate|
-        const double margin = margin_of(tab[5]);
+    if (n_tab >= 0) { // the staged table: [k][5] = ax, ay, bx, by, ~1 / |b - a|^2
+        const double margin = margin_of(*tab_m);
         double dmin = __builtin_inf();
 #pragma unroll 4
         for (int k = 0; k < n_tab; ++k) {
-            const double *e = tab + k * 6;
+            const double *e = tab + k * 5;
             dmin = __builtin_fmin(dmin, nearest_edge_approx_d2(e[0], e[1], e[2] - e[0], e[3] - e[1], e[4], px, py));
         }
         const double thr = dmin + margin;
         uint64_t cand = 0;
 #pragma unroll 4
         for (int k = 0; k < n_tab; ++k) {
-            const double *e = tab + k * 6;
+            const double *e = tab + k * 5;
             if (!(nearest_edge_approx_d2(e[0], e[1], e[2] - e[0], e[3] - e[1], e[4], px, py) > thr)) cand |= 1ull << k;
         }
         while (cand) {
-            const double *e = tab + __builtin_ctzll(cand) * 6;
+            const double *e = tab + __builtin_ctzll(cand) * 5;
             cand &= cand - 1;
             nearest_edge_exact(e[0], e[1], e[2], e[3], px, py, best, cx, cy);
         }
     } else {
         const int64_t e0 = RI.imp_off[net], e1 = RI.imp_off[net + 1];
-        if (e1 - e0 <= 64) {
+        if (!STAGED && e1 - e0 <= 64) {
             const double margin = margin_of(RI.imp_m[net]);
             double dmin = __builtin_inf();
             for (int64_t i = e0; i < e1; ++i) {

@@ -82,7 +82,7 @@ struct SliceArgs {
 template <int G, int WV, bool PED, bool TAB, bool HAST, bool ROAD = false, bool RSSV = false, bool CROWD = false, bool SLICE = false,
           bool PLANAR = false, bool RIDERS = false, bool CTAB = false, bool MODELS = !CROWD>
 __device__ __forceinline__ void rollout_body_l(
-    TileLds<64 * WV, PED, CROWD> &lds /* the workgroup's LDS tile: the entry point owns it (rollout_kernel_tabq shares it between roles) */,
+    TileLds<64 * WV, PED, CROWD, CROWD && !RIDERS> &lds /* the workgroup's LDS tile: the entry point owns it (rollout_kernel_tabq shares it between roles) */,
     const Params &p, double timestep, int n_steps, int do_reset, int force, const double *actions /*[n][R][2]*/,
     const double *tab /*controller table planes*/, const SliceArgs &sa = SliceArgs{},
     const unsigned bx_arg = ~0u /* the 64-slot block (WV == 1) / scenario of this workgroup when it is not bx: TabGroups */)
@@ -184,7 +184,8 @@ __device__ __forceinline__ void rollout_body_l(
             const double rr = fld(st, ST_CTRL + SG_C_PED_RADIUS), r2 = rr * rr;
             lds.r2hi[sl] = r2 * (1.0 + 1e-9);
             lds.r2lo[sl] = r2 * 0.9975;
-            // the buildings of this scenario's road network (TileLds::road_tab; the barriers below publish it)
+        }
+        if (CROWD && !RIDERS) { // the buildings of this scenario's road network (TileLds::road_tab; the barriers below publish it)
             int n_staged = -1, net = -1;
             uint32_t net_flags = 0;
             if (p.road) {
@@ -193,16 +194,15 @@ __device__ __forceinline__ void rollout_body_l(
                 if (net >= 0) {
                     net_flags = RI.net_flags[net];
                     const int64_t e0 = RI.imp_off[net], ne = RI.imp_off[net + 1] - e0;
-                    if ((net_flags & 2u) && ne <= 64) {
+                    if ((net_flags & 2u) && ne <= lds.ROAD_EDGES) {
                         n_staged = (int)ne;
-                        const double m = RI.imp_m[net];
                         for (int k = tid; k < n_staged; k += NS) {
                             const double *e = RI.imp_edges + (e0 + k) * 4;
-                            double *t = lds.road_tab + k * 6;
+                            double *t = lds.road_tab + k * 5;
                             t[0] = e[0]; t[1] = e[1]; t[2] = e[2]; t[3] = e[3];
                             t[4] = RI.imp_aux[(e0 + k) * 4 + 2];
-                            t[5] = m;
                         }
+                        if (tid == 0) lds.road_m = RI.imp_m[net];
                     }
                 }
             }
@@ -1200,7 +1200,7 @@ __device__ __forceinline__ void rollout_body(
     const Params &p, double timestep, int n_steps, int do_reset, int force, const double *actions, const double *tab,
     const SliceArgs &sa = SliceArgs{}, const unsigned bx_arg = ~0u)
 {
-    __shared__ TileLds<64 * WV, PED, CROWD> lds;
+    __shared__ TileLds<64 * WV, PED, CROWD, CROWD && !RIDERS> lds;
     rollout_body_l<G, WV, PED, TAB, HAST, ROAD, RSSV, CROWD, SLICE, PLANAR, RIDERS, CTAB, MODELS>(lds, p, timestep, n_steps, do_reset, force, actions, tab,
                                                                                        sa, bx_arg);
 }
