@@ -334,4 +334,70 @@ __device__ __forceinline__ int ped_goal_update(const double *wp, int nwp, double
     return last + 1;
 }
 
+// ped_goal_update for a route of TWO waypoints (a start and a goal: BASELINE config 5) -- the same operations on the one
+// segment, its four coordinates loaded once: the general form reads them in its first loop, again in its second, and the
+// caller once more for the goal (three memory latencies in a row in every step of every walking pedestrian).  (gx, gy) = the
+// second waypoint, the goal whenever the returned index is 1.
+__device__ __forceinline__ int ped_goal_update2(const double *wp, double px, double py, double &gx, double &gy)
+{
+    const double ax = wp[0], ay = wp[1];
+    gx = wp[2];
+    gy = wp[3];
+    const double dx = gx - ax, dy = gy - ay;
+    const double L2 = dx * dx + dy * dy;
+    const double u = L2 == 0.0 ? 0.0 : __builtin_fmin(1.0, __builtin_fmax(0.0, ((px - ax) * dx + (py - ay) * dy) / L2));
+    const double qx = ax + u * dx, qy = ay + u * dy;
+    const double ex = px - qx, ey = py - qy;
+    const double dist = __builtin_sqrt(ex * ex + ey * ey);
+    const double L = __builtin_sqrt(L2);
+    const double best_s = dist < __builtin_inf() ? 0.0 + u * L : 0.0;
+    // (second loop of the general form: arc_0 = 0 keeps last = 0 whatever best_s is; arc_1 = 0 + L)
+    return (0.0 + L <= best_s) ? 2 : 1;
+}
+
+// ... and for routes of up to MAXW waypoints (the street routes of the crowds on road networks have four): every waypoint
+// loaded once, all loads in flight together, both loops of the general form from registers (the second loop's segment lengths
+// are the first loop's: the same expression on the same operands).  (gx, gy) = the goal's coordinates when the returned
+// index is a waypoint.
+template <int MAXW>
+__device__ __forceinline__ int ped_goal_update_reg(const double *wp, int nwp, double px, double py, double &gx, double &gy)
+{
+    double wx[MAXW], wy[MAXW], Ls[MAXW];
+#pragma unroll
+    for (int k = 0; k < MAXW; ++k) {
+        wx[k] = wy[k] = Ls[k] = 0.0;
+        if (k < nwp) { wx[k] = wp[2 * k]; wy[k] = wp[2 * k + 1]; }
+    }
+    double best = __builtin_inf(), best_s = 0.0, acc = 0.0;
+#pragma unroll
+    for (int i = 0; i + 1 < MAXW; ++i) {
+        if (i + 1 < nwp) {
+            const double ax = wx[i], ay = wy[i], dx = wx[i + 1] - ax, dy = wy[i + 1] - ay;
+            const double L2 = dx * dx + dy * dy;
+            const double u = L2 == 0.0 ? 0.0 : __builtin_fmin(1.0, __builtin_fmax(0.0, ((px - ax) * dx + (py - ay) * dy) / L2));
+            const double qx = ax + u * dx, qy = ay + u * dy;
+            const double ex = px - qx, ey = py - qy;
+            const double dist = __builtin_sqrt(ex * ex + ey * ey);
+            const double L = __builtin_sqrt(L2);
+            if (dist < best) { best = dist; best_s = acc + u * L; }
+            acc += L;
+            Ls[i + 1] = L;
+        }
+    }
+    double arc = 0.0;
+    int last = 0;
+#pragma unroll
+    for (int k = 0; k < MAXW; ++k) {
+        if (k < nwp) {
+            if (k > 0) arc += Ls[k];
+            if (arc <= best_s) last = k;
+        }
+    }
+    gx = gy = 0.0;
+#pragma unroll
+    for (int k = 1; k < MAXW; ++k)
+        if (last + 1 == k) { gx = wx[k]; gy = wy[k]; }
+    return last + 1;
+}
+
 } // namespace sg

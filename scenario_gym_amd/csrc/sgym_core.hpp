@@ -539,10 +539,16 @@ struct TileLds {
     // buildings, more than 64 edges: device memory), the network, its flags.  Not in the riders variant: two of its
     // workgroups and one of control_kernel_riders (7 KB) share a compute unit's 160 KB, and these 2.5 KB would evict the latter
     // (measured: c5mix 781 -> 902 ms).
+    // (crowd variants of one and four wavefronts; the two-wavefront tile has no kilobyte to spare: four workgroups per unit) the
+    // vertex table of Point.buffer(r) for the radius rule's thin ring (sg_in_radius): from device memory its four vertices
+    // were four memory latencies in a row, met by about one pair-loop round in seven
+    static constexpr bool GON = CROWD && NS != 128;
+    double gon[GON ? 128 : 1];
     static constexpr bool ROAD_TAB = ROADTAB;
     static constexpr int ROAD_EDGES = 64;
     double road_tab[ROADTAB ? ROAD_EDGES * 5 : 1];
     double road_m;
+    RoadNet road_net;   // the network's grid header (rn_probe)
     int road_info[4];
 
     static constexpr int SLOTS = NS;

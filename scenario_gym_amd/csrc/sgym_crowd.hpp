@@ -71,7 +71,7 @@ __device__ __forceinline__ bool ped_pair_eval(const Params &p, const LDS &L, boo
 {
     const sg_social_force &sf = p.sf;
     const double ox = L.px[j], oy = L.py[j];
-    const bool act = valid & (L.isped[j] != 0) & sg_in_radius(ipx, ipy, irad, ox, oy, p.gon);
+    const bool act = valid & (L.isped[j] != 0) & sg_in_radius(ipx, ipy, irad, ox, oy, LDS::GON ? L.gon : p.gon);
     const double ovx = L.vx[j], ovy = L.vy[j];
     const double odx = L.ox[j], ody = L.oy[j], step = L.stp[j];
     FastArith FA;
@@ -447,7 +447,7 @@ __device__ __forceinline__ void crowd_pairs(const Params &p, LDS &L, const Crowd
             for (int u = 0; u < SG_CROWD_ILP; ++u)
                 if (ring[u])
                     act[u] = sg_in_radius(L.px[osl[u]], L.py[osl[u]], L.ctrl[SG_C_PED_RADIUS - SG_C_PED_SPEED_DESIRED][osl[u]],
-                                          L.px[jj[u]], L.py[jj[u]], p.gon);
+                                          L.px[jj[u]], L.py[jj[u]], LDS::GON ? L.gon : p.gon);
         }
 #pragma unroll
         for (int u = 0; u < SG_CROWD_ILP; ++u) any_bad |= bad[u] & act[u];
@@ -509,10 +509,16 @@ __device__ __forceinline__ void ped_force(const Params &p, LDS &L, int r, int sl
     vdes = 0.0;
     double hs = 0.0, hc = 1.0, radius = 0.0;
     if (stepping) {
-        if (goal_idx <= nwp - 1) goal_idx = ped_goal_update(wp, nwp, pose[0], pose[1]);
+        double w1x = 0.0, w1y = 0.0;
+        // (the crowd variants: the route's waypoints loaded once per step -- one memory latency instead of three)
+        const bool two = CROWD && nwp == 2 && goal_idx <= 1, few = CROWD && nwp > 2 && nwp <= 4 && goal_idx <= nwp - 1;
+        if (two) goal_idx = ped_goal_update2(wp, pose[0], pose[1], w1x, w1y);
+        else if (few) goal_idx = ped_goal_update_reg<4>(wp, nwp, pose[0], pose[1], w1x, w1y);
+        else if (goal_idx <= nwp - 1) goal_idx = ped_goal_update(wp, nwp, pose[0], pose[1]);
         if (goal_idx <= nwp - 1) {
             go = true;
-            double gx = wp[2 * goal_idx] - pose[0], gy = wp[2 * goal_idx + 1] - pose[1]; // _force_to_goal, :119-138
+            const bool have = two | few;
+            double gx = (have ? w1x : wp[2 * goal_idx]) - pose[0], gy = (have ? w1y : wp[2 * goal_idx + 1]) - pose[1]; // _force_to_goal, :119-138
             double gn = sg_norm2(gx, gy);
             if (gn == 0) gn += 0.000000001;
             vdes = L.ctrl[SG_C_PED_SPEED_DESIRED - SG_C_PED_SPEED_DESIRED][sl];
@@ -544,7 +550,7 @@ __device__ __forceinline__ void ped_force(const Params &p, LDS &L, int r, int sl
             ped_pairs_serial<WV>(p, L, tile0, nbr, go, plain, k2_scale, pose[0], pose[1], radius, hs, hc, fx, fy);
     }
     if (p.road && go) { // (launch-uniform: the batch has road networks) after the neighbours, social_force.py:83-104
-        if (LDS::ROAD_TAB) ped_boundary_terms<true>(p, r, pose[0], pose[1], fx, fy, L.road_tab, L.road_info, &L.road_m);
+        if (LDS::ROAD_TAB) ped_boundary_terms<true>(p, r, pose[0], pose[1], fx, fy, L.road_tab, L.road_info, &L.road_m, &L.road_net);
         else ped_boundary_terms(p, r, pose[0], pose[1], fx, fy);
     }
 }

@@ -123,18 +123,28 @@ __host__ __device__ inline int rn_locate_in_cell(const double *edges, const int3
     return inside ? 1 : 0;
 }
 
-// the layers of `want` whose union strictly contains the point (one thread)
-__device__ inline uint32_t rn_layers_at(const RoadIndex &R, int net, uint32_t want, double px, double py)
+// the layers of `want` whose union strictly contains the point (one thread), in two halves: the loads that depend on the
+// point's cell alone (rn_probe: the cell word and the range of its candidates, three gathers in flight together), and
+// what follows from them (rn_resolve).  A caller with work of its own puts it in between (ped_boundary_terms).
+struct RoadProbe { bool ok; int ix, iy; uint32_t m, k0, k1; };
+__device__ __forceinline__ RoadProbe rn_probe(const RoadIndex &R, const RoadNet &N, double px, double py)
 {
-    if (net < 0) return 0u;
-    const RoadNet N = R.nets[net];
-    int ix, iy;
-    if (!rn_cell_of(N, px, py, ix, iy)) return 0u;
-    const int64_t cell = N.cell_base + (int64_t)iy * N.nx + ix;
-    const uint32_t m = R.cells[cell];
-    uint32_t in = m & 0xffu & want, todo = (m >> 8) & want & ~in;
+    RoadProbe q{false, 0, 0, 0u, 0u, 0u};
+    if (!rn_cell_of(N, px, py, q.ix, q.iy)) return q;
+    const int64_t cell = N.cell_base + (int64_t)q.iy * N.nx + q.ix;
+    q.ok = true;
+    q.m = R.cells[cell];
+    q.k0 = R.cell_off[cell];
+    q.k1 = R.cell_off[cell + 1];
+    return q;
+}
+__device__ inline uint32_t rn_resolve(const RoadIndex &R, const RoadNet &N, const RoadProbe &q, uint32_t want, double px, double py)
+{
+    if (!q.ok) return 0u;
+    const int ix = q.ix, iy = q.iy;
+    uint32_t in = q.m & 0xffu & want, todo = (q.m >> 8) & want & ~in;
     if (todo) {
-        for (uint32_t k = R.cell_off[cell]; k < R.cell_off[cell + 1] && todo; ++k) {
+        for (uint32_t k = q.k0; k < q.k1 && todo; ++k) {
             const RoadCand cd = R.cand[k];
             const uint32_t L = R.poly_layers[cd.poly] & todo;
             if (!L) continue;
@@ -147,6 +157,18 @@ __device__ inline uint32_t rn_layers_at(const RoadIndex &R, int net, uint32_t wa
         }
     }
     return in;
+}
+__device__ inline uint32_t rn_layers_at(const RoadIndex &R, int net, uint32_t want, double px, double py)
+{
+    if (net < 0) return 0u;
+    const RoadNet N = R.nets[net];
+    int ix, iy;
+    if (!rn_cell_of(N, px, py, ix, iy)) return 0u;
+    const int64_t cell = N.cell_base + (int64_t)iy * N.nx + ix;
+    const uint32_t m = R.cells[cell];
+    RoadProbe q{true, ix, iy, m, 0u, 0u};
+    if ((m >> 8) & want & ~(m & 0xffu & want)) { q.k0 = R.cell_off[cell]; q.k1 = R.cell_off[cell + 1]; }
+    return rn_resolve(R, N, q, want, px, py);
 }
 
 // One ring edge (a, b) of GEOS DistanceOp's nearest-point search folded into (best, cx, cy): Distance::pointToSegment, nearest
@@ -200,8 +222,8 @@ __device__ __forceinline__ void nearest_edge_exact(double ax, double ay, double 
 // edge outside the margin has a rounded distance strictly above the minimum and cannot be the one kept, whatever the
 // order.  The reference's sequence then runs over the candidates only, in edge order: the point's own edge, both edges of a
 // corner, the walls on either side of a street when they are equally far.  NaN anywhere makes everything a candidate.
-// `tab` / `info` / `tab_m` (rollout_kernel_crowd / _models, one scenario per workgroup): the scenario's building edges staged in
-// LDS once per launch (TileLds::road_tab / road_info / road_m, filled by rollout_body_l) -- as loads from device memory every
+// `tab` / `info` / `tab_m` / `tab_net` (rollout_kernel_crowd / _models, one scenario per workgroup): the scenario's building edges
+// and its network's grid header staged in LDS once per launch (TileLds::road_tab / road_info / road_m / road_net, filled by rollout_body_l) -- as loads from device memory every
 // edge of the two filter passes waited a full memory latency (the compiler cannot make them scalar loads: the kernel stores
 // to global memory): c5roads 4.72 -> 5.0 G.
 __device__ __forceinline__ double nearest_edge_approx_d2(double ax, double ay, double dx, double dy, double inv, double px, double py)
@@ -215,7 +237,8 @@ __device__ __forceinline__ double nearest_edge_approx_d2(double ax, double ay, d
 // of the filter in kernels whose registers are full).
 template <bool STAGED = false>
 __device__ inline void ped_boundary_terms(const Params &p, int r, double px, double py, double &fx, double &fy,
-                                          const double *tab = nullptr, const int *info = nullptr, const double *tab_m = nullptr)
+                                          const double *tab = nullptr, const int *info = nullptr, const double *tab_m = nullptr,
+                                          const RoadNet *tab_net = nullptr)
 {
     if (!p.road) return;
     const RoadIndex RI = *p.road;
@@ -232,16 +255,16 @@ __device__ inline void ped_boundary_terms(const Params &p, int r, double px, dou
         flags = RI.net_flags[net];
     }
     if (!flags) return;
-    const uint32_t in = rn_layers_at(RI, net, SG_LAYER_WALKABLE | SG_LAYER_IMPENETRABLE, px, py);
-    if ((flags & 1u) && (in & SG_LAYER_WALKABLE)) { fx += 0.0; fy += 0.0; }
-    if (!(flags & 2u)) return;
-    if (in & SG_LAYER_IMPENETRABLE) { fx += -0.0; fy += -0.0; return; }
-    double best = __builtin_inf(), cx = px, cy = py;
     const auto margin_of = [&](double m) {
         const double sxb = __builtin_fabs(px) + m, syb = __builtin_fabs(py) + m;
         return 1e-11 * (sxb * sxb + syb * syb + 8.0 * (m * m));
     };
+    uint32_t in;
+    uint64_t cand = 0;
     if (n_tab >= 0) { // the staged table: [k][5] = ax, ay, bx, by, ~1 / |b - a|^2
+        // (the cell lookup's loads first, the filter passes while they are in flight, what follows from them after)
+        const RoadNet N = *tab_net;
+        const RoadProbe q = rn_probe(RI, N, px, py);
         const double margin = margin_of(*tab_m);
         double dmin = __builtin_inf();
 #pragma unroll 4
@@ -250,12 +273,20 @@ __device__ inline void ped_boundary_terms(const Params &p, int r, double px, dou
             dmin = __builtin_fmin(dmin, nearest_edge_approx_d2(e[0], e[1], e[2] - e[0], e[3] - e[1], e[4], px, py));
         }
         const double thr = dmin + margin;
-        uint64_t cand = 0;
 #pragma unroll 4
         for (int k = 0; k < n_tab; ++k) {
             const double *e = tab + k * 5;
             if (!(nearest_edge_approx_d2(e[0], e[1], e[2] - e[0], e[3] - e[1], e[4], px, py) > thr)) cand |= 1ull << k;
         }
+        in = rn_resolve(RI, N, q, SG_LAYER_WALKABLE | SG_LAYER_IMPENETRABLE, px, py);
+    } else {
+        in = rn_layers_at(RI, net, SG_LAYER_WALKABLE | SG_LAYER_IMPENETRABLE, px, py);
+    }
+    if ((flags & 1u) && (in & SG_LAYER_WALKABLE)) { fx += 0.0; fy += 0.0; }
+    if (!(flags & 2u)) return;
+    if (in & SG_LAYER_IMPENETRABLE) { fx += -0.0; fy += -0.0; return; }
+    double best = __builtin_inf(), cx = px, cy = py;
+    if (n_tab >= 0) {
         while (cand) {
             const double *e = tab + __builtin_ctzll(cand) * 5;
             cand &= cand - 1;
@@ -271,7 +302,6 @@ __device__ inline void ped_boundary_terms(const Params &p, int r, double px, dou
                 dmin = __builtin_fmin(dmin, nearest_edge_approx_d2(e[0], e[1], a[0], a[1], a[2], px, py));
             }
             const double thr = dmin + margin;
-            uint64_t cand = 0;
             for (int64_t i = e0; i < e1; ++i) {
                 const double *e = RI.imp_edges + i * 4, *a = RI.imp_aux + i * 4;
                 if (!(nearest_edge_approx_d2(e[0], e[1], a[0], a[1], a[2], px, py) > thr)) cand |= 1ull << (int)(i - e0);

@@ -185,6 +185,8 @@ __device__ __forceinline__ void rollout_body_l(
             lds.r2hi[sl] = r2 * (1.0 + 1e-9);
             lds.r2lo[sl] = r2 * 0.9975;
         }
+        if (CROWD && lds.GON)
+            for (int k = tid; k < 128; k += NS) lds.gon[k] = p.gon[k];
         if (CROWD && !RIDERS) { // the buildings of this scenario's road network (TileLds::road_tab; the barriers below publish it)
             int n_staged = -1, net = -1;
             uint32_t net_flags = 0;
@@ -202,7 +204,7 @@ __device__ __forceinline__ void rollout_body_l(
                             t[0] = e[0]; t[1] = e[1]; t[2] = e[2]; t[3] = e[3];
                             t[4] = RI.imp_aux[(e0 + k) * 4 + 2];
                         }
-                        if (tid == 0) lds.road_m = RI.imp_m[net];
+                        if (tid == 0) { lds.road_m = RI.imp_m[net]; lds.road_net = RI.nets[net]; }
                     }
                 }
             }

@@ -2447,6 +2447,43 @@ def test_boundary_force_filter_keeps_the_reference_tie_rules(sga, oracle, monkey
         eng.close()
 
 
+@pytest.mark.parametrize("E", [40, 100, 256])
+def test_crowd_routes_of_any_length_match_oracle(sga, oracle, E):
+    """PedestrianAgent's goal update (LineString(route).project, pedestrian/agent.py:59-62) in the crowd kernels keeps the
+    route's waypoints in registers when there are at most four (ped_goal_update2 / ped_goal_update_reg, sgym_agents.hpp) and
+    walks device memory otherwise: routes of 2 ... 7 waypoints side by side in one batch, with a repeated waypoint (a
+    segment of length zero) and a route whose pedestrian starts beyond its last waypoint, equal the oracle bit for bit."""
+    from oracle import check
+    from scenario_gym_amd import synthetic
+
+    R, steps, dt = 3, 500, 1 / 30
+    base = synthetic.make_crowd(R, E, n_steps=steps, timestep=dt, seed=12, side=24.0)
+    rng = np.random.default_rng(5)
+    two = base.routes.reshape(R * E, 2, 2)
+    routes, off = [], [0]
+    for i in range(R * E):
+        n = int(rng.integers(2, 8))
+        t = np.sort(rng.uniform(0.0, 1.0, n - 2))
+        mid = two[i, 0] + t[:, None] * (two[i, 1] - two[i, 0]) + rng.normal(0, 1.5, (n - 2, 2))
+        wp = np.concatenate([two[i, :1], mid, two[i, 1:]])
+        if i % 11 == 3 and n > 2:
+            wp[1] = wp[0]          # a segment of length zero
+        if i % 13 == 5:
+            wp = wp[::-1].copy()   # the pedestrian stands at the END of its route
+        routes.append(wp)
+        off.append(off[-1] + n)
+    base.routes = np.concatenate(routes)
+    base.route_off = np.array(off, np.int64)
+    packed = base.validate()
+    eng = sga.RolloutEngine(R, E, timestep=dt, terminal_conditions=["max_length"], event_capacity=256)
+    eng.upload(packed)
+    eng.rollout(steps)
+    assert "rollout_kernel_crowd" in eng.last_kernel()
+    ver = check.verify_engine(eng, packed, dt, steps, K=R, event_cap=256, ped=True)
+    assert ver["equal"], ver["mismatches"]
+    eng.close()
+
+
 def packed_two_waypoints(packed):
     """_add_riders edits batches whose pedestrians have two waypoints each: keep the first and the last of every route."""
     R, E = packed.n_scenarios, packed.n_entities
