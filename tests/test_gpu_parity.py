@@ -3110,6 +3110,7 @@ def _random_crowds(n, seed=77):
     rng = np.random.default_rng(seed)
     rrng = np.random.default_rng([seed, 9])  # (its own stream: earlier configurations keep their draws)
     brng = np.random.default_rng([seed, 10])
+    wrng = np.random.default_rng([seed, 11])
     out = []
     for k in range(n):
         E = int([20, 64, 100, 256, 40, 130][k % 6])
@@ -3119,6 +3120,9 @@ def _random_crowds(n, seed=77):
                         radii=bool(rng.integers(0, 2)), late=bool(rng.integers(0, 3) == 0),
                         riders=int(rrng.integers(0, 8)) if rrng.integers(0, 2) else 0,  # how many of _ALL_RIDERS ride along
                         walk=bool(brng.integers(0, 5) == 0)))                            # RandomWalk instead of SocialForce
+        # a third of the configurations without riders: routes of 2 ... 6 waypoints side by side (the goal update from registers
+        # up to four, from device memory beyond)
+        out[-1]["routes"] = bool(wrng.integers(0, 3) == 0) and out[-1]["riders"] == 0
         if brng.integers(0, 15) == 0:  # one in fifteen: a crowd of more than 512 (the multi-kernel step; road networks, both noise
             c = out[-1]                # modes and riders of every kind stay)
             c.update(E=int(brng.choice([520, 640])), R=int(brng.integers(1, 3)), steps=min(c["steps"], 40),
@@ -3154,6 +3158,18 @@ def test_randomized_crowds_match_oracle(sga, oracle, cfg):
     if cfg["late"]:  # every fifth pedestrian's trajectory starts later: it is not in the scene at the reset and spawns
         kn = packed.knots.reshape(R * E, 2, 7)
         kn[::5, 0, 0] = rng.uniform(0.2, 1.0, len(kn[::5])) * steps * dt * 0.5
+    if cfg.get("routes"):
+        wr = np.random.default_rng([cfg["seed"], 17])
+        two = packed.routes.reshape(R * E, 2, 2)
+        routes, off = [], [0]
+        for i in range(R * E):
+            n = int(wr.integers(2, 7))
+            frac = np.sort(wr.uniform(0.0, 1.0, n - 2))
+            mid = two[i, 0] + frac[:, None] * (two[i, 1] - two[i, 0]) + wr.normal(0, 0.08 * cfg["side"], (n - 2, 2))
+            routes.append(np.concatenate([two[i, :1], mid, two[i, 1:]]))
+            off.append(off[-1] + n)
+        packed.routes, packed.route_off = np.concatenate(routes), np.array(off, np.int64)
+        packed.validate()
     if cfg["riders"]:  # cars / obstacles / recorded pedestrians among the walkers (64-lane tiles without roads: the riders' path)
         _add_riders(packed, np.random.default_rng([cfg["seed"], 13]), cfg["side"], steps * dt, _ALL_RIDERS[: cfg["riders"]])
     noise_kw, noise_o = {}, [None] * R
