@@ -481,8 +481,19 @@ def test_register_budgets_of_the_two_kernel_path():
         assert tabs[f"void sg::{fam}64>"]["scratch"] <= spill
     ctl = t["sg::control_kernel"]
     assert ctl["vgpr"] + ctl["agpr"] <= 128 and ctl["scratch"] == 0
-    crowd = t["void sg::rollout_kernel_crowd<4>"]
-    assert crowd["lds"] <= 80 * 1024  # two workgroups per CU (160 KB of LDS)
+    # the crowd tiles against a compute unit's 160 KB of LDS ("LDS residency"): a byte too many costs a resident
+    # workgroup, and nothing but the clock shows it (round 6: the riders tile + 3 KB = c5mix 15 % slower)
+    CU = 160 * 1024
+    lds = lambda n: t[n]["lds"]  # noqa: E731
+    for v in ("crowd", "crowd_models"):
+        assert 2 * lds(f"void sg::rollout_kernel_{v}<4>") <= CU
+        assert 4 * lds(f"void sg::rollout_kernel_{v}<2>") <= CU
+        assert 8 * lds(f"void sg::rollout_kernel_{v}<1>") <= CU
+    # ... and the riders variant WITH its controller pre-pass beside it
+    ctl_r = lds("sg::control_kernel_riders")
+    assert 2 * lds("void sg::rollout_kernel_crowd_riders<4>") + ctl_r <= CU
+    assert 4 * lds("void sg::rollout_kernel_crowd_riders<2>") + ctl_r <= CU
+    assert 8 * lds("void sg::rollout_kernel_crowd_riders<1>") + ctl_r <= CU
 
 
 def test_walk_graph_bfs_equals_list_of_paths_search():
